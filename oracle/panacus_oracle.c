@@ -1,0 +1,1245 @@
+/*
+ * panacus_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See panacus_oracle.h for scope, parity status and the golden vectors that pin it.
+ * Plain C11, serial, written to mirror the reference's loop order literally; speed is a
+ * non-goal.  Citations are file:line in the reference tree (marschall-lab/panacus v0.4.1).
+ */
+#define _GNU_SOURCE
+#include "panacus_oracle.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static char g_err[512];
+static void set_err(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *orc_graph_last_error(void) { return g_err; }
+void orc_free(void *p) { free(p); }
+
+static void *xmalloc(size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p) {
+        fprintf(stderr, "oracle: out of memory (%zu bytes)\n", n);
+        abort();
+    }
+    return p;
+}
+static void *xcalloc(size_t n, size_t s) {
+    void *p = calloc(n ? n : 1, s ? s : 1);
+    if (!p) {
+        fprintf(stderr, "oracle: out of memory\n");
+        abort();
+    }
+    return p;
+}
+static void *xrealloc(void *q, size_t n) {
+    void *p = realloc(q, n ? n : 1);
+    if (!p) {
+        fprintf(stderr, "oracle: out of memory\n");
+        abort();
+    }
+    return p;
+}
+static char *xstrndup(const char *s, size_t n) {
+    char *p = xmalloc(n + 1);
+    memcpy(p, s, n);
+    p[n] = 0;
+    return p;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* byte-string -> u64 map (stands in for HashMap<Vec<u8>, ItemId>, graph.rs:167)         */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    char **keys;
+    size_t *klen;
+    uint64_t *vals;
+    size_t cap, n;
+} smap;
+
+static uint64_t fnv1a(const char *s, size_t n) {
+    uint64_t h = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; i++) {
+        h ^= (unsigned char)s[i];
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+static void smap_init(smap *m, size_t cap) {
+    m->cap = 16;
+    while (m->cap < cap * 2) m->cap <<= 1;
+    m->keys = xcalloc(m->cap, sizeof *m->keys);
+    m->klen = xcalloc(m->cap, sizeof *m->klen);
+    m->vals = xcalloc(m->cap, sizeof *m->vals);
+    m->n = 0;
+}
+static void smap_free(smap *m) {
+    for (size_t i = 0; i < m->cap; i++) free(m->keys[i]);
+    free(m->keys);
+    free(m->klen);
+    free(m->vals);
+    memset(m, 0, sizeof *m);
+}
+static int smap_put(smap *m, const char *k, size_t n, uint64_t v); /* fwd */
+static void smap_grow(smap *m) {
+    smap o = *m;
+    smap_init(m, o.cap);
+    for (size_t i = 0; i < o.cap; i++)
+        if (o.keys[i]) {
+            size_t j = fnv1a(o.keys[i], o.klen[i]) & (m->cap - 1);
+            while (m->keys[j]) j = (j + 1) & (m->cap - 1);
+            m->keys[j] = o.keys[i];
+            m->klen[j] = o.klen[i];
+            m->vals[j] = o.vals[i];
+            m->n++;
+        }
+    free(o.keys);
+    free(o.klen);
+    free(o.vals);
+}
+/* returns 1 if inserted, 0 if key existed (value left unchanged) */
+static int smap_put(smap *m, const char *k, size_t n, uint64_t v) {
+    if ((m->n + 1) * 2 > m->cap) smap_grow(m);
+    size_t j = fnv1a(k, n) & (m->cap - 1);
+    while (m->keys[j]) {
+        if (m->klen[j] == n && memcmp(m->keys[j], k, n) == 0) return 0;
+        j = (j + 1) & (m->cap - 1);
+    }
+    m->keys[j] = xstrndup(k, n);
+    m->klen[j] = n;
+    m->vals[j] = v;
+    m->n++;
+    return 1;
+}
+static int smap_get(const smap *m, const char *k, size_t n, uint64_t *v) {
+    size_t j = fnv1a(k, n) & (m->cap - 1);
+    while (m->keys[j]) {
+        if (m->klen[j] == n && memcmp(m->keys[j], k, n) == 0) {
+            *v = m->vals[j];
+            return 1;
+        }
+        j = (j + 1) & (m->cap - 1);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* canonical edge -> id map (HashMap<Edge, ItemId>, graph.rs:276-306)                    */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t u, v;
+    uint8_t o1, o2; /* 0 = Forward, 1 = Backward (graph.rs:20-24) */
+} edge_t;
+
+typedef struct {
+    edge_t *keys;
+    uint64_t *vals; /* 0 = empty */
+    size_t cap, n;
+} emap;
+
+static uint64_t edge_hash(edge_t e) {
+    uint64_t h = e.u * 0x9E3779B97F4A7C15ULL;
+    h ^= (e.v + 0x7F4A7C15ULL) * 0xC2B2AE3D27D4EB4FULL;
+    h ^= ((uint64_t)e.o1 << 1 | e.o2) * 0x165667B19E3779F9ULL;
+    h ^= h >> 29;
+    return h;
+}
+static int edge_eq(edge_t a, edge_t b) {
+    return a.u == b.u && a.v == b.v && a.o1 == b.o1 && a.o2 == b.o2;
+}
+static void emap_init(emap *m, size_t cap) {
+    m->cap = 16;
+    while (m->cap < cap * 2) m->cap <<= 1;
+    m->keys = xcalloc(m->cap, sizeof *m->keys);
+    m->vals = xcalloc(m->cap, sizeof *m->vals);
+    m->n = 0;
+}
+static void emap_grow(emap *m) {
+    emap o = *m;
+    emap_init(m, o.cap);
+    for (size_t i = 0; i < o.cap; i++)
+        if (o.vals[i]) {
+            size_t j = edge_hash(o.keys[i]) & (m->cap - 1);
+            while (m->vals[j]) j = (j + 1) & (m->cap - 1);
+            m->keys[j] = o.keys[i];
+            m->vals[j] = o.vals[i];
+            m->n++;
+        }
+    free(o.keys);
+    free(o.vals);
+}
+static int emap_put(emap *m, edge_t e, uint64_t v) {
+    if ((m->n + 1) * 2 > m->cap) emap_grow(m);
+    size_t j = edge_hash(e) & (m->cap - 1);
+    while (m->vals[j]) {
+        if (edge_eq(m->keys[j], e)) return 0;
+        j = (j + 1) & (m->cap - 1);
+    }
+    m->keys[j] = e;
+    m->vals[j] = v;
+    m->n++;
+    return 1;
+}
+static uint64_t emap_get(const emap *m, edge_t e) {
+    size_t j = edge_hash(e) & (m->cap - 1);
+    while (m->vals[j]) {
+        if (edge_eq(m->keys[j], e)) return m->vals[j];
+        j = (j + 1) & (m->cap - 1);
+    }
+    return 0;
+}
+
+/* Edge::canonical, graph.rs:142-148 */
+static edge_t edge_canonical(uint64_t u, uint8_t o1, uint64_t v, uint8_t o2) {
+    edge_t e;
+    if (u > v || (u == v && o1 == 1)) {
+        e.u = v;
+        e.o1 = (uint8_t)!o2;
+        e.v = u;
+        e.o2 = (uint8_t)!o1;
+    } else {
+        e.u = u;
+        e.o1 = o1;
+        e.v = v;
+        e.o2 = o2;
+    }
+    return e;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* PathSegment (graph.rs:472-627)                                                        */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    char *sample;
+    char *haplotype; /* NULL = None */
+    char *seqid;     /* NULL = None */
+    int has_start, has_end;
+    uint64_t start, end;
+} pathseg;
+
+static void pathseg_free(pathseg *p) {
+    free(p->sample);
+    free(p->haplotype);
+    free(p->seqid);
+    memset(p, 0, sizeof *p);
+}
+
+static int all_digits(const char *s, size_t n) {
+    if (n == 0) return 0;
+    for (size_t i = 0; i < n; i++)
+        if (s[i] < '0' || s[i] > '9') return 0;
+    return 1;
+}
+static int parse_usize(const char *s, size_t n, uint64_t *out) {
+    /* usize::from_str(..).ok(): None on overflow */
+    uint64_t v = 0;
+    if (n == 0) return 0;
+    for (size_t i = 0; i < n; i++) {
+        if (s[i] < '0' || s[i] > '9') return 0;
+        uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (UINT64_MAX - d) / 10) return 0;
+        v = v * 10 + d;
+    }
+    *out = v;
+    return 1;
+}
+
+/* PATHID_COORDS = ^(.+):([0-9]+)-([0-9]+)$ (graph.rs:18).  On match returns 1 and the
+ * length of group 1 plus the two numbers (has_* = 0 when usize parsing overflowed). */
+static int match_coords(const char *s, size_t n, size_t *g1len, int *hs, uint64_t *st, int *he,
+                        uint64_t *en) {
+    /* group 3: maximal digit suffix must reach back to the last '-' */
+    size_t i = n;
+    while (i > 0 && s[i - 1] >= '0' && s[i - 1] <= '9') i--;
+    if (i == n || i == 0 || s[i - 1] != '-') return 0;
+    size_t dash = i - 1;
+    size_t j = dash;
+    while (j > 0 && s[j - 1] >= '0' && s[j - 1] <= '9') j--;
+    if (j == dash || j == 0 || s[j - 1] != ':') return 0;
+    size_t colon = j - 1;
+    if (colon == 0) return 0; /* (.+) needs at least one char */
+    (void)all_digits;
+    *g1len = colon;
+    *hs = parse_usize(s + j, dash - j, st);
+    *he = parse_usize(s + dash + 1, n - dash - 1, en);
+    return 1;
+}
+
+/* PathSegment::from_str, graph.rs:495-549.  PATHID_PANSN = ^([^#]+)(#[^#]+)?(#[^#].*)?$ */
+static pathseg pathseg_from_str(const char *s, size_t n) {
+    pathseg r;
+    memset(&r, 0, sizeof r);
+    r.sample = xstrndup(s, n);
+
+    size_t a = 0;
+    while (a < n && s[a] != '#') a++;
+    if (a == 0) return r; /* group 1 needs >= 1 non-'#' char: no match */
+    /* candidate groups */
+    const char *g2 = NULL, *g3 = NULL;
+    size_t g2n = 0, g3n = 0;
+    int matched = 0;
+    if (a == n) {
+        matched = 1; /* only group 1 */
+    } else {
+        /* try group 2 = '#' + maximal non-'#' run (non-empty) */
+        size_t b = a + 1;
+        while (b < n && s[b] != '#') b++;
+        if (b > a + 1) {
+            if (b == n) {
+                g2 = s + a;
+                g2n = b - a;
+                matched = 1;
+            } else if (b + 1 < n && s[b + 1] != '#') {
+                g2 = s + a;
+                g2n = b - a;
+                g3 = s + b;
+                g3n = n - b;
+                matched = 1;
+            }
+        }
+        if (!matched) {
+            /* backtrack: group 2 absent, group 3 = '#' [^#] .* from a */
+            if (a + 1 < n && s[a + 1] != '#') {
+                g3 = s + a;
+                g3n = n - a;
+                matched = 1;
+            }
+        }
+    }
+    if (!matched) return r;
+
+    int nseg = 2 + (g2 != NULL) + (g3 != NULL);
+    size_t g1len;
+    int hs, he;
+    uint64_t st, en;
+    if (nseg == 4) {
+        free(r.sample);
+        r.sample = xstrndup(s, a);
+        r.haplotype = xstrndup(g2 + 1, g2n - 1);
+        if (match_coords(g3 + 1, g3n - 1, &g1len, &hs, &st, &he, &en)) {
+            r.seqid = xstrndup(g3 + 1, g1len);
+            r.has_start = hs;
+            r.start = st;
+            r.has_end = he;
+            r.end = en;
+        } else {
+            r.seqid = xstrndup(g3 + 1, g3n - 1);
+        }
+    } else if (nseg == 3) {
+        const char *seg = g2 ? g2 : g3;
+        size_t segn = g2 ? g2n : g3n;
+        free(r.sample);
+        r.sample = xstrndup(s, a);
+        if (match_coords(seg + 1, segn - 1, &g1len, &hs, &st, &he, &en)) {
+            r.haplotype = xstrndup(seg + 1, g1len);
+            r.has_start = hs;
+            r.start = st;
+            r.has_end = he;
+            r.end = en;
+        } else {
+            r.haplotype = xstrndup(seg + 1, segn - 1);
+        }
+    } else { /* nseg == 2: segments[1] is group 1 == whole string (no '#') */
+        if (match_coords(s, a, &g1len, &hs, &st, &he, &en)) {
+            free(r.sample);
+            r.sample = xstrndup(s, g1len);
+            r.has_start = hs;
+            r.start = st;
+            r.has_end = he;
+            r.end = en;
+        }
+    }
+    return r;
+}
+
+/* PathSegment::id(), graph.rs:558-579 */
+static char *pathseg_id(const pathseg *p) {
+    char *out;
+    if (p->haplotype) {
+        if (p->seqid) {
+            if (asprintf(&out, "%s#%s#%s", p->sample, p->haplotype, p->seqid) < 0) abort();
+        } else {
+            if (asprintf(&out, "%s#%s", p->sample, p->haplotype) < 0) abort();
+        }
+    } else if (p->seqid) {
+        if (asprintf(&out, "%s#*#%s", p->sample, p->seqid) < 0) abort();
+    } else {
+        out = xstrndup(p->sample, strlen(p->sample));
+    }
+    return out;
+}
+/* identity of clear_coords() (graph.rs:581-589): (sample, Option<hap>, Option<seqid>) */
+static char *pathseg_clearkey(const pathseg *p) {
+    char *out;
+    if (asprintf(&out, "%s\x01%c%s\x01%c%s", p->sample, p->haplotype ? '1' : '0',
+                 p->haplotype ? p->haplotype : "", p->seqid ? '1' : '0',
+                 p->seqid ? p->seqid : "") < 0)
+        abort();
+    return out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* GraphStorage                                                                           */
+/* ------------------------------------------------------------------------------------ */
+struct orc_graph {
+    char *gfa_file;
+    smap node2id;
+    uint32_t *node_lens;
+    uint64_t n_nodes;
+    int has_edges;
+    emap edge2id;
+    uint64_t n_edges;
+    pathseg *paths;
+    char **path_disp;
+    uint64_t n_paths;
+    /* grouping state */
+    char **path_group; /* group name per path */
+    char **group_names;
+    uint64_t n_groups;
+};
+
+uint64_t orc_graph_n_nodes(const orc_graph *g) { return g->n_nodes; }
+uint64_t orc_graph_n_edges(const orc_graph *g) { return g->n_edges; }
+uint64_t orc_graph_n_paths(const orc_graph *g) { return g->n_paths; }
+const uint32_t *orc_graph_node_lens(const orc_graph *g) { return g->node_lens; }
+const char *orc_graph_path_display(const orc_graph *g, uint64_t i) { return g->path_disp[i]; }
+const char *orc_graph_group_name(const orc_graph *g, uint64_t gid) {
+    return gid < g->n_groups ? g->group_names[gid] : NULL;
+}
+
+static size_t field_end(const char *s, size_t from, size_t n) {
+    while (from < n && s[from] != '\t') from++;
+    return from;
+}
+
+/* parse_walk_segment / parse_walk_identifier (graph.rs:381-412; util.rs:366-395) */
+static int parse_walk_ident(const char *line, size_t n, pathseg *out, size_t *walk_off) {
+    size_t col[7];
+    size_t pos = 0;
+    for (int k = 0; k < 6; k++) {
+        size_t e = field_end(line, pos, n);
+        if (e >= n) return 0;
+        col[k] = pos;
+        pos = e + 1;
+    }
+    col[6] = pos;
+    memset(out, 0, sizeof *out);
+    out->sample = xstrndup(line + col[1], col[2] - col[1] - 1);
+    out->haplotype = xstrndup(line + col[2], col[3] - col[2] - 1);
+    out->seqid = xstrndup(line + col[3], col[4] - col[3] - 1);
+    size_t l4 = col[5] - col[4] - 1, l5 = col[6] - col[5] - 1;
+    if (!(l4 == 1 && line[col[4]] == '*')) {
+        if (!parse_usize(line + col[4], l4, &out->start)) return 0;
+        out->has_start = 1;
+    }
+    if (!(l5 == 1 && line[col[5]] == '*')) {
+        if (!parse_usize(line + col[5], l5, &out->end)) return 0;
+        out->has_end = 1;
+    }
+    *walk_off = pos;
+    return 1;
+}
+
+static void graph_add_path(orc_graph *g, pathseg p, size_t *cap) {
+    if (g->n_paths == *cap) {
+        *cap = *cap ? *cap * 2 : 64;
+        g->paths = xrealloc(g->paths, *cap * sizeof *g->paths);
+    }
+    g->paths[g->n_paths++] = p;
+}
+
+/* GraphStorage::from_gfa (graph.rs:195-220): parse_nodes_gfa (308-375) then, for
+ * Edge/All, parse_edge_gfa (276-306) in a second pass over the file. */
+orc_graph *orc_graph_from_gfa(const char *gfa_file, int index_edges) {
+    FILE *f = fopen(gfa_file, "rb");
+    if (!f) {
+        set_err("cannot open %s", gfa_file);
+        return NULL;
+    }
+    orc_graph *g = xcalloc(1, sizeof *g);
+    g->gfa_file = xstrndup(gfa_file, strlen(gfa_file));
+    smap_init(&g->node2id, 1024);
+    size_t lens_cap = 1024, path_cap = 0;
+    g->node_lens = xmalloc(lens_cap * sizeof *g->node_lens);
+    g->node_lens[0] = 0;
+    uint64_t node_id = 1;
+
+    char *line = NULL;
+    size_t lcap = 0;
+    ssize_t n;
+    while ((n = getline(&line, &lcap, f)) > 0) {
+        if (line[0] == 'S') {
+            size_t e = field_end(line, 2, (size_t)n);
+            if (!smap_put(&g->node2id, line + 2, e - 2, node_id)) {
+                set_err("Segment with ID %.*s occurs multiple times in GFA", (int)(e - 2), line + 2);
+                free(line);
+                fclose(f);
+                orc_graph_free(g);
+                return NULL;
+            }
+            size_t s0 = e + 1, s1 = s0;
+            while (s1 < (size_t)n && line[s1] != '\t' && line[s1] != '\n' && line[s1] != '\r') s1++;
+            if (node_id >= lens_cap) {
+                lens_cap *= 2;
+                g->node_lens = xrealloc(g->node_lens, lens_cap * sizeof *g->node_lens);
+            }
+            g->node_lens[node_id] = (uint32_t)(s1 - s0);
+            node_id++;
+        } else if (line[0] == 'P') {
+            size_t s0 = field_end(line, 0, (size_t)n) + 1;
+            size_t s1 = field_end(line, s0, (size_t)n);
+            graph_add_path(g, pathseg_from_str(line + s0, s1 - s0), &path_cap);
+        } else if (line[0] == 'W') {
+            pathseg p;
+            size_t off;
+            if (!parse_walk_ident(line, (size_t)n, &p, &off)) {
+                set_err("malformed W line");
+                free(line);
+                fclose(f);
+                orc_graph_free(g);
+                return NULL;
+            }
+            graph_add_path(g, p, &path_cap);
+        }
+    }
+    g->n_nodes = node_id - 1;
+    g->path_disp = xcalloc(g->n_paths, sizeof *g->path_disp);
+    for (uint64_t i = 0; i < g->n_paths; i++) {
+        char *id = pathseg_id(&g->paths[i]);
+        if (g->paths[i].has_start && g->paths[i].has_end) {
+            if (asprintf(&g->path_disp[i], "%s:%llu-%llu", id, (unsigned long long)g->paths[i].start,
+                         (unsigned long long)g->paths[i].end) < 0)
+                abort();
+            free(id);
+        } else {
+            g->path_disp[i] = id;
+        }
+    }
+
+    if (index_edges) {
+        g->has_edges = 1;
+        emap_init(&g->edge2id, 1024);
+        uint64_t edge_id = 1;
+        rewind(f);
+        while ((n = getline(&line, &lcap, f)) > 0) {
+            if (line[0] != 'L') continue;
+            /* Edge::from_link, graph.rs:100-136 */
+            size_t a0 = 2, a1 = field_end(line, a0, (size_t)n);
+            uint64_t u, v;
+            if (!smap_get(&g->node2id, line + a0, a1 - a0, &u)) {
+                set_err("unknown node %.*s", (int)(a1 - a0), line + a0);
+                goto fail;
+            }
+            uint8_t o1 = line[a1 + 1] == '+' ? 0 : 1;
+            size_t b0 = a1 + 3, b1 = field_end(line, b0, (size_t)n);
+            if (!smap_get(&g->node2id, line + b0, b1 - b0, &v)) {
+                set_err("unknown node %.*s", (int)(b1 - b0), line + b0);
+                goto fail;
+            }
+            uint8_t o2 = line[b1 + 1] == '+' ? 0 : 1;
+            edge_t e = edge_canonical(u, o1, v, o2);
+            if (emap_put(&g->edge2id, e, edge_id)) edge_id++; /* duplicates warn + skip */
+        }
+        g->n_edges = edge_id - 1;
+    }
+    free(line);
+    fclose(f);
+    return g;
+fail:
+    free(line);
+    fclose(f);
+    orc_graph_free(g);
+    return NULL;
+}
+
+static void graph_clear_groups(orc_graph *g) {
+    if (g->path_group) {
+        for (uint64_t i = 0; i < g->n_paths; i++) free(g->path_group[i]);
+        free(g->path_group);
+        g->path_group = NULL;
+    }
+    if (g->group_names) {
+        for (uint64_t i = 0; i < g->n_groups; i++) free(g->group_names[i]);
+        free(g->group_names);
+        g->group_names = NULL;
+    }
+    g->n_groups = 0;
+}
+
+void orc_graph_free(orc_graph *g) {
+    if (!g) return;
+    graph_clear_groups(g);
+    free(g->gfa_file);
+    if (g->node2id.keys) smap_free(&g->node2id);
+    free(g->node_lens);
+    if (g->has_edges) {
+        free(g->edge2id.keys);
+        free(g->edge2id.vals);
+    }
+    for (uint64_t i = 0; i < g->n_paths; i++) {
+        pathseg_free(&g->paths[i]);
+        if (g->path_disp) free(g->path_disp[i]);
+    }
+    free(g->paths);
+    free(g->path_disp);
+    free(g);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* GraphMask::load_groups (abacus.rs:242-308) + get_path_order (310-347) + group ids     */
+/* (555-559).  Subset/exclude lists are not restated (no golden outputs in the reference) */
+/* ------------------------------------------------------------------------------------ */
+int64_t orc_graph_path_order(orc_graph *g, int group_mode, const char *group_file,
+                             const char *order_file, uint64_t *path_idx, uint64_t *group_id,
+                             uint64_t *n_out) {
+    graph_clear_groups(g);
+    uint64_t P = g->n_paths;
+    g->path_group = xcalloc(P, sizeof *g->path_group);
+
+    /* clear_coords key -> first path index with that key */
+    smap key2path;
+    smap_init(&key2path, P + 1);
+    char **keys = xcalloc(P, sizeof *keys);
+    for (uint64_t i = 0; i < P; i++) {
+        keys[i] = pathseg_clearkey(&g->paths[i]);
+        smap_put(&key2path, keys[i], strlen(keys[i]), i);
+    }
+
+    int64_t ret = -1;
+    smap file_groups; /* clearkey -> index into fg_names */
+    char **fg_names = NULL;
+    size_t fg_n = 0, fg_cap = 0;
+    int have_fg = 0;
+
+    if (group_mode == ORC_GROUP_HAPLOTYPE) {
+        for (uint64_t i = 0; i < P; i++)
+            if (asprintf(&g->path_group[i], "%s#%s", g->paths[i].sample,
+                         g->paths[i].haplotype ? g->paths[i].haplotype : "") < 0)
+                abort();
+    } else if (group_mode == ORC_GROUP_SAMPLE) {
+        for (uint64_t i = 0; i < P; i++)
+            g->path_group[i] = xstrndup(g->paths[i].sample, strlen(g->paths[i].sample));
+    } else if (group_mode == ORC_GROUP_FILE) {
+        FILE *f = fopen(group_file, "rb");
+        if (!f) {
+            set_err("cannot open group file %s", group_file);
+            goto done;
+        }
+        smap_init(&file_groups, 64);
+        have_fg = 1;
+        char *line = NULL;
+        size_t lcap = 0;
+        ssize_t n;
+        int lineno = 1;
+        while ((n = getline(&line, &lcap, f)) > 0) {
+            /* parse_groups, io.rs:121-151: strip ONE trailing \n or \r */
+            if (n > 0 && (line[n - 1] == '\n' || line[n - 1] == '\r')) n--;
+            size_t tabs = 0, t0 = 0;
+            for (ssize_t k = 0; k < n; k++)
+                if (line[k] == '\t') {
+                    if (!tabs) t0 = (size_t)k;
+                    tabs++;
+                }
+            if (tabs != 1) {
+                set_err("error in line %d: table must have exactly two columns", lineno);
+                free(line);
+                fclose(f);
+                goto done;
+            }
+            pathseg ps = pathseg_from_str(line, t0);
+            char *k = pathseg_clearkey(&ps);
+            uint64_t idx;
+            const char *grp = line + t0 + 1;
+            size_t grpn = (size_t)n - t0 - 1;
+            if (smap_get(&file_groups, k, strlen(k), &idx)) {
+                if (strlen(fg_names[idx]) != grpn || memcmp(fg_names[idx], grp, grpn) != 0) {
+                    set_err("path cannot be assigned to more than one group (line %d)", lineno);
+                    free(k);
+                    pathseg_free(&ps);
+                    free(line);
+                    fclose(f);
+                    goto done;
+                }
+            } else {
+                if (fg_n == fg_cap) {
+                    fg_cap = fg_cap ? fg_cap * 2 : 64;
+                    fg_names = xrealloc(fg_names, fg_cap * sizeof *fg_names);
+                }
+                fg_names[fg_n] = xstrndup(grp, grpn);
+                smap_put(&file_groups, k, strlen(k), fg_n);
+                fg_n++;
+            }
+            free(k);
+            pathseg_free(&ps);
+            lineno++;
+        }
+        free(line);
+        fclose(f);
+        for (uint64_t i = 0; i < P; i++) {
+            uint64_t idx;
+            if (smap_get(&file_groups, keys[i], strlen(keys[i]), &idx))
+                g->path_group[i] = xstrndup(fg_names[idx], strlen(fg_names[idx]));
+            else
+                g->path_group[i] = pathseg_id(&g->paths[i]); /* abacus.rs:290-294 */
+        }
+    } else {
+        for (uint64_t i = 0; i < P; i++) g->path_group[i] = pathseg_id(&g->paths[i]);
+    }
+    /* `groups` is a HashMap keyed by clear_coords(): paths sharing a key share the entry.
+     * With -S/-H/default the value is a pure function of the key, so nothing to reconcile. */
+
+    /* get_path_order: bucket path indices by group name (file order inside a bucket) */
+    {
+        smap grp2bucket;
+        smap_init(&grp2bucket, P + 1);
+        uint64_t nb = 0;
+        uint64_t *bucket_of = xcalloc(P, sizeof *bucket_of);
+        for (uint64_t i = 0; i < P; i++) {
+            uint64_t b;
+            const char *gn = g->path_group[i];
+            if (!smap_get(&grp2bucket, gn, strlen(gn), &b)) {
+                b = nb++;
+                smap_put(&grp2bucket, gn, strlen(gn), b);
+            }
+            bucket_of[i] = b;
+        }
+        uint8_t *bucket_done = xcalloc(nb ? nb : 1, 1);
+
+        /* the order source: a list of group names to visit */
+        uint64_t *visit = NULL; /* bucket ids in visiting order */
+        uint64_t nvisit = 0, vcap = 0;
+#define PUSH_VISIT(b)                                          \
+    do {                                                       \
+        if (nvisit == vcap) {                                  \
+            vcap = vcap ? vcap * 2 : 64;                       \
+            visit = xrealloc(visit, vcap * sizeof *visit);     \
+        }                                                      \
+        visit[nvisit++] = (b);                                 \
+    } while (0)
+        if (order_file) {
+            FILE *f = fopen(order_file, "rb");
+            if (!f) {
+                set_err("cannot open order file %s", order_file);
+                free(bucket_of);
+                free(bucket_done);
+                smap_free(&grp2bucket);
+                goto done;
+            }
+            char *line = NULL;
+            size_t lcap = 0;
+            ssize_t n;
+            while ((n = getline(&line, &lcap, f)) > 0) {
+                /* BufRead::lines strips \n and \r\n (io.rs:42) */
+                if (n > 0 && line[n - 1] == '\n') n--;
+                if (n > 0 && line[n - 1] == '\r') n--;
+                size_t e = field_end(line, 0, (size_t)n);
+                if ((e >= 8 && memcmp(line, "browser ", 8) == 0) ||
+                    (e >= 6 && memcmp(line, "track ", 6) == 0) || (e >= 1 && line[0] == '#'))
+                    continue;
+                pathseg ps = pathseg_from_str(line, e);
+                char *k = pathseg_clearkey(&ps);
+                uint64_t pi, b;
+                /* complement_with_group_assignments, abacus.rs:152-206 */
+                if (smap_get(&key2path, k, strlen(k), &pi)) {
+                    PUSH_VISIT(bucket_of[pi]);
+                } else {
+                    char *id = pathseg_id(&ps);
+                    if (smap_get(&grp2bucket, id, strlen(id), &b)) PUSH_VISIT(b);
+                    /* else: unknown path/group -> logged and skipped */
+                    free(id);
+                }
+                free(k);
+                pathseg_free(&ps);
+            }
+            free(line);
+            fclose(f);
+        } else {
+            for (uint64_t i = 0; i < P; i++) PUSH_VISIT(bucket_of[i]);
+        }
+#undef PUSH_VISIT
+
+        uint64_t out = 0, ngroups = 0;
+        size_t gcap = 0;
+        for (uint64_t vi = 0; vi < nvisit; vi++) {
+            uint64_t b = visit[vi];
+            if (bucket_done[b]) continue; /* group_to_paths.remove(..).unwrap_or_default() */
+            bucket_done[b] = 1;
+            for (uint64_t i = 0; i < P; i++) {
+                if (bucket_of[i] != b) continue;
+                const char *gn = g->path_group[i];
+                /* abacus.rs:555-559: new group id whenever the emitted name changes */
+                if (ngroups == 0 || strcmp(g->group_names[ngroups - 1], gn) != 0) {
+                    if (ngroups == gcap) {
+                        gcap = gcap ? gcap * 2 : 64;
+                        g->group_names = xrealloc(g->group_names, gcap * sizeof *g->group_names);
+                    }
+                    g->group_names[ngroups++] = xstrndup(gn, strlen(gn));
+                }
+                path_idx[out] = i;
+                group_id[out] = ngroups - 1;
+                out++;
+            }
+        }
+        g->n_groups = ngroups;
+        *n_out = out;
+        ret = (int64_t)ngroups;
+        free(visit);
+        free(bucket_of);
+        free(bucket_done);
+        smap_free(&grp2bucket);
+    }
+done:
+    if (have_fg) {
+        smap_free(&file_groups);
+        for (size_t i = 0; i < fg_n; i++) free(fg_names[i]);
+        free(fg_names);
+    }
+    for (uint64_t i = 0; i < P; i++) free(keys[i]);
+    free(keys);
+    smap_free(&key2path);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ItemTable: parse_gfa_paths_walks_multiple without subset/exclude (util.rs:22-206);     */
+/* node steps via get_path_segment_ids / get_walk_segment_ids (util.rs:1048-1142), edge   */
+/* steps via update_tables_edgecount (util.rs:723-795) with include=[(0,MAX)], exclude=[] */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t *v;
+    size_t n, cap;
+} u64vec;
+static void u64vec_push(u64vec *a, uint64_t x) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 1024;
+        a->v = xrealloc(a->v, a->cap * sizeof *a->v);
+    }
+    a->v[a->n++] = x;
+}
+
+int64_t orc_graph_item_table(const orc_graph *g, int count_type, uint64_t **items_out,
+                             uint64_t *prefsum) {
+    if (count_type == ORC_EDGE && !g->has_edges) {
+        set_err("graph was loaded without edge index");
+        return -1;
+    }
+    FILE *f = fopen(g->gfa_file, "rb");
+    if (!f) {
+        set_err("cannot open %s", g->gfa_file);
+        return -1;
+    }
+    u64vec items = {0};
+    u64vec sids = {0};
+    u64vec oris = {0};
+    uint64_t num_path = 0;
+    prefsum[0] = 0;
+    char *line = NULL;
+    size_t lcap = 0;
+    ssize_t n;
+    while ((n = getline(&line, &lcap, f)) > 0) {
+        if (line[0] != 'P' && line[0] != 'W') continue;
+        sids.n = 0;
+        oris.n = 0;
+        size_t pos, end;
+        if (line[0] == 'P') {
+            size_t s0 = field_end(line, 0, (size_t)n) + 1;
+            pos = field_end(line, s0, (size_t)n) + 1;
+            end = pos;
+            while (end < (size_t)n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
+            /* steps "name+,name-": get_segment_id util.rs:1017-1031 */
+            while (pos < end) {
+                size_t e = pos;
+                while (e < end && line[e] != ',') e++;
+                if (e > pos) {
+                    char o = line[e - 1];
+                    uint64_t id;
+                    if ((o != '+' && o != '-') || !smap_get(&g->node2id, line + pos, e - 1 - pos, &id)) {
+                        set_err("unknown node %.*s", (int)(e - pos), line + pos);
+                        goto fail;
+                    }
+                    u64vec_push(&sids, id);
+                    u64vec_push(&oris, o == '+' ? 0 : 1);
+                }
+                pos = e + 1;
+            }
+        } else {
+            pathseg ps;
+            if (!parse_walk_ident(line, (size_t)n, &ps, &pos)) {
+                set_err("malformed W line");
+                goto fail;
+            }
+            pathseg_free(&ps);
+            end = pos;
+            while (end < (size_t)n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
+            /* walk ">name<name": get_walk_segment_id util.rs:1033-1046 */
+            while (pos < end) {
+                size_t e = pos + 1;
+                while (e < end && line[e] != '>' && line[e] != '<') e++;
+                char o = line[pos];
+                uint64_t id;
+                if ((o != '>' && o != '<') || !smap_get(&g->node2id, line + pos + 1, e - pos - 1, &id)) {
+                    set_err("unknown node %.*s", (int)(e - pos), line + pos);
+                    goto fail;
+                }
+                u64vec_push(&sids, id);
+                u64vec_push(&oris, o == '>' ? 0 : 1);
+                pos = e;
+            }
+        }
+        uint64_t added = 0;
+        if (count_type == ORC_EDGE) {
+            /* util.rs:723-795 with include=[(0,usize::MAX)], exclude=[], offset = path start */
+            if (sids.n > 0) {
+                uint64_t p = g->paths[num_path].has_start && g->paths[num_path].has_end
+                                 ? g->paths[num_path].start
+                                 : 0;
+                p += g->node_lens[sids.v[0]];
+                for (size_t k = 0; k + 1 < sids.n; k++) {
+                    uint64_t l = g->node_lens[sids.v[k + 1]];
+                    edge_t e = edge_canonical(sids.v[k], (uint8_t)oris.v[k], sids.v[k + 1],
+                                              (uint8_t)oris.v[k + 1]);
+                    uint64_t eid = emap_get(&g->edge2id, e);
+                    if (!eid) {
+                        set_err("unknown edge %c%llu%c%llu", e.o1 ? '<' : '>', (unsigned long long)e.u,
+                                e.o2 ? '<' : '>', (unsigned long long)e.v);
+                        goto fail;
+                    }
+                    if (0 < p + l) { /* include_coords[0].0 < p + l */
+                        u64vec_push(&items, eid);
+                        added++;
+                    }
+                    p += l;
+                }
+            }
+        } else {
+            for (size_t k = 0; k < sids.n; k++) u64vec_push(&items, sids.v[k]);
+            added = sids.n;
+        }
+        prefsum[num_path + 1] = prefsum[num_path] + added;
+        num_path++;
+    }
+    free(line);
+    free(sids.v);
+    free(oris.v);
+    fclose(f);
+    *items_out = items.v ? items.v : xmalloc(8);
+    return (int64_t)items.n;
+fail:
+    free(line);
+    free(sids.v);
+    free(oris.v);
+    free(items.v);
+    fclose(f);
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* AbacusByTotal::item_table_to_abacus + coverage (abacus.rs:539-586, 719-744)           */
+/* ------------------------------------------------------------------------------------ */
+void orc_coverage(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                  const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                  const uint8_t *exclude, uint32_t *countable) {
+    uint64_t *last = xmalloc((n_items + 1) * sizeof *last);
+    for (uint64_t i = 0; i <= n_items; i++) {
+        countable[i] = 0;
+        last[i] = UINT64_MAX;
+    }
+    countable[0] = UINT32_MAX;
+    for (uint64_t k = 0; k < n_ordered; k++) {
+        uint64_t start = prefsum[path_idx[k]], end = prefsum[path_idx[k] + 1];
+        uint64_t grp = group_id[k];
+        for (uint64_t j = start; j < end; j++) {
+            uint64_t sid = items[j];
+            if (last[sid] != grp && (!exclude || !exclude[sid])) {
+                countable[sid] += 1;
+                last[sid] = grp;
+            }
+        }
+    }
+    free(last);
+}
+
+/* construct_hist / construct_hist_bps (abacus.rs:746-787) */
+void orc_hist(const uint32_t *countable, uint64_t n_items, uint64_t n_groups,
+              const uint32_t *weights, uint64_t *hist) {
+    for (uint64_t i = 0; i <= n_groups; i++) hist[i] = 0;
+    for (uint64_t i = 0; i <= n_items; i++) {
+        uint64_t cov = countable[i];
+        if (cov >= n_groups + 1) continue; /* index 0 holds u32::MAX and is skipped here */
+        hist[cov] += weights ? weights[i] : 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* closed-form growth (graph_broker/hist.rs:21-187)                                      */
+/* ------------------------------------------------------------------------------------ */
+/* Threshold::to_absolute / to_relative, util.rs:350-363 */
+static uint64_t thr_to_absolute(int kind, double val, uint64_t n) {
+    if (kind == ORC_THR_ABSOLUTE) return (uint64_t)val;
+    return (uint64_t)ceil((double)n * val);
+}
+static double thr_to_relative(int kind, double val, uint64_t n) {
+    if (kind == ORC_THR_RELATIVE) return val;
+    return (double)(uint64_t)val / (double)n;
+}
+
+/* hist.rs:21-36 */
+double orc_choose(uint64_t n, uint64_t k) {
+    double res = 0.0;
+    if (k > n) return 0.0;
+    if (k > n - k) k = n - k;
+    double nf = (double)n;
+    for (uint64_t i = 0; i < k; i++) {
+        res += log2(nf - (double)i);
+        res -= log2((double)i + 1.0);
+    }
+    return res;
+}
+
+/* hist.rs:89-114 */
+void orc_growth_union(const uint64_t *cov, uint64_t n, int ck, double cv, double *out) {
+    uint64_t c = thr_to_absolute(ck, cv, n);
+    if (c < 1) c = 1;
+    double n_fall_m = 0.0;
+    uint64_t tot_i = 0;
+    for (uint64_t i = c; i <= n; i++) tot_i += cov[i];
+    double tot = (double)tot_i;
+    double *perc_mult = xcalloc(n + 1, sizeof *perc_mult);
+    for (uint64_t m = 1; m < n + 1; m++) {
+        double y = 0.0;
+        n_fall_m += log2((double)n - (double)m + 1.0);
+        for (uint64_t i = c; i < n - m + 1; i++) {
+            perc_mult[i] += log2((double)n - (double)m - (double)i + 1.0);
+            y += exp2(log2((double)cov[i]) + perc_mult[i] - n_fall_m);
+        }
+        out[m - 1] = tot - y;
+    }
+    free(perc_mult);
+}
+
+/* hist.rs:116-138 */
+void orc_growth_core(const uint64_t *cov, uint64_t n, int ck, double cv, double *out) {
+    uint64_t c = thr_to_absolute(ck, cv, n + 1);
+    if (c < 1) c = 1;
+    double n_fall_m = 0.0;
+    double *perc_mult = xcalloc(n + 1, sizeof *perc_mult);
+    for (uint64_t m = 1; m < n + 1; m++) {
+        double y = 0.0;
+        n_fall_m += log2((double)n - (double)m + 1.0);
+        for (uint64_t i = (m > c ? m : c); i < n + 1; i++) {
+            perc_mult[i] += log2((double)i - (double)m + 1.0);
+            y += exp2(log2((double)cov[i]) + perc_mult[i] - n_fall_m);
+        }
+        out[m - 1] = y;
+    }
+    free(perc_mult);
+}
+
+/* hist.rs:140-187 */
+void orc_growth_quorum(const uint64_t *cov, uint64_t n, int ck, double cv, int qk, double qv,
+                          double *out) {
+    uint64_t c = thr_to_absolute(ck, cv, n);
+    if (c < 1) c = 1;
+    double quorum = thr_to_relative(qk, qv, n);
+    double n_fall_m = 0.0, m_fact = 0.0;
+    double *perc_mult = xcalloc(n + 1, sizeof *perc_mult);
+    double *q = xcalloc((n + 1) * (n + 1), sizeof *q);
+    for (uint64_t m = 1; m < n + 1; m++) {
+        m_fact += log2((double)m);
+        uint64_t m_quorum = (uint64_t)ceil((double)m * quorum);
+        double yl = 0.0;
+        n_fall_m += log2((double)n - (double)m + 1.0);
+        for (uint64_t i = (m > c ? m : c); i < n + 1; i++) {
+            perc_mult[i] += log2((double)i - (double)m + 1.0);
+            yl += exp2(log2((double)cov[i]) + perc_mult[i] - n_fall_m);
+        }
+        double yr = 0.0;
+        for (uint64_t i = m_quorum; i < n; i++) {
+            double sum_q = 0.0;
+            int add = 0;
+            for (uint64_t j = (m_quorum > c ? m_quorum : c); j < m; j++) {
+                if (n + j + 1 > i + m && j <= i) {
+                    double *qij = &q[i * (n + 1) + j];
+                    if (*qij == 0.0) *qij = orc_choose(i, j);
+                    *qij += log2((double)n - (double)i - (double)m + 1.0 + (double)j);
+                    *qij -= log2((double)m - (double)j);
+                    sum_q += exp2(*qij + m_fact - n_fall_m);
+                    add = 1;
+                }
+            }
+            if (add) yr += exp2(log2((double)cov[i]) + log2(sum_q));
+        }
+        out[m - 1] = yl + yr;
+    }
+    free(perc_mult);
+    free(q);
+}
+
+/* Hist::calc_growth dispatch, hist.rs:51-66 */
+int64_t orc_growth(const uint64_t *hist, uint64_t hist_len, int cov_kind, double cov_val,
+                   int quo_kind, double quo_val, double *out) {
+    if (hist_len == 0) return 0;
+    uint64_t n = hist_len - 1;
+    if (n == 0) return 0;
+    uint64_t quorum = thr_to_absolute(quo_kind, quo_val, n);
+    if (quorum < 1) quorum = 1;
+    if (quorum == 1)
+        orc_growth_union(hist, n, cov_kind, cov_val, out);
+    else if (quorum >= n)
+        orc_growth_core(hist, n, cov_kind, cov_val, out);
+    else
+        orc_growth_quorum(hist, n, cov_kind, cov_val, quo_kind, quo_val, out);
+    return (int64_t)n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* AbacusByGroup: compute_row_storage_space (abacus.rs:859-899) +                        */
+/* compute_column_values (901-986, report_values=false) restated with the same           */
+/* "last slot is the write cursor" trick so that any quirk of it is reproduced.           */
+/* ------------------------------------------------------------------------------------ */
+int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                     const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                     const uint8_t *exclude, uint64_t *r, uint64_t **c_out) {
+    uint64_t *last = xmalloc((n_items + 1) * sizeof *last);
+    for (uint64_t i = 0; i <= n_items; i++) last[i] = UINT64_MAX;
+    for (uint64_t i = 0; i < n_items + 2; i++) r[i] = 0;
+    for (uint64_t k = 0; k < n_ordered; k++) {
+        uint64_t start = prefsum[path_idx[k]], end = prefsum[path_idx[k] + 1];
+        for (uint64_t j = start; j < end; j++) {
+            uint64_t sid = items[j];
+            if (last[sid] != group_id[k] && (!exclude || !exclude[sid])) {
+                r[sid] += 1;
+                last[sid] = group_id[k];
+            }
+        }
+    }
+    free(last);
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < n_items + 2; i++) {
+        uint64_t tmp = r[i];
+        r[i] = acc;
+        acc += tmp;
+    }
+    uint64_t nnz = r[n_items + 1];
+    uint64_t *c = xmalloc((nnz ? nnz : 1) * sizeof *c);
+    for (uint64_t i = 0; i < nnz; i++) c[i] = UINT64_MAX;
+    for (uint64_t k = 0; k < n_ordered; k++) {
+        uint64_t start = prefsum[path_idx[k]], end = prefsum[path_idx[k] + 1];
+        uint64_t grp = group_id[k];
+        for (uint64_t j = start; j < end; j++) {
+            uint64_t sid = items[j];
+            uint64_t cv_start = r[sid], cv_end = r[sid + 1];
+            if (cv_end == cv_start) continue;
+            uint64_t p = c[cv_end - 1];
+            if (c[cv_end - 1] == UINT64_MAX) {
+                c[cv_start] = grp;
+                if (cv_start < cv_end - 1) c[cv_end - 1] = 0;
+            } else if (cv_start + p < cv_end - 1) {
+                if (c[cv_start + p] < grp) {
+                    c[cv_end - 1] += 1;
+                    p += 1;
+                    c[cv_start + p] = grp;
+                }
+            }
+        }
+    }
+    *c_out = c;
+    return (int64_t)nnz;
+}
+
+/* AbacusByGroup::calc_growth, abacus.rs:989-1032 */
+void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
+                        uint64_t n_groups, int cov_kind, double cov_val, int quo_kind,
+                        double quo_val, const uint32_t *weights, double *out) {
+    for (uint64_t j = 0; j < n_groups; j++) out[j] = 0.0;
+    uint64_t cthr = thr_to_absolute(cov_kind, cov_val, n_groups);
+    if (cthr < 1) cthr = 1;
+    double q = thr_to_relative(quo_kind, quo_val, n_groups);
+    if (!(q > 0.0)) q = 0.0; /* f64::max(0.0, q) */
+    for (uint64_t i = 1; i <= n_items; i++) {
+        uint64_t start = r[i], end = r[i + 1];
+        if (end - start >= cthr) {
+            uint64_t k = start;
+            for (uint64_t j = c[start]; j < n_groups; j++) {
+                if (k < end - 1 && c[k + 1] <= j) k += 1;
+                if (k - start + 1 >= (uint64_t)ceil(((double)c[k] + 1.0) * q))
+                    out[j] += weights ? (double)weights[i] : 1.0;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* pansyn-v1: counter-based synthetic pangenome generator (integer-only)      */
+/* ------------------------------------------------------------------------------------ */
+uint64_t pansyn_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static uint64_t pansyn_key(uint64_t seed, uint64_t stream) {
+    return pansyn_splitmix64(seed ^ (0xA0761D6478BD642FULL * (stream + 1)));
+}
+#define PANSYN_ONE53 (1ULL << 53)
+
+uint32_t pansyn_node_len(uint64_t seed, uint64_t i) {
+    uint64_t t = pansyn_splitmix64(pansyn_key(seed, 1) + i) >> 11;
+    if (t < PANSYN_ONE53 / 100 * 55) return 1;
+    uint64_t e = pansyn_splitmix64(pansyn_key(seed, 2) + i);
+    uint64_t k = e ? (uint64_t)__builtin_clzll(e) : 63;
+    if (k > 63) k = 63;
+    uint64_t f16 = e & 0xFFFF;
+    uint64_t len = 1 + ((180 * ((k << 16) + f16)) >> 16);
+    return (uint32_t)(len > 50000 ? 50000 : len);
+}
+
+void pansyn_node_lens(uint64_t seed, uint64_t n_nodes, uint32_t *out /* n_nodes+1 */) {
+    out[0] = 0;
+    for (uint64_t i = 1; i <= n_nodes; i++) out[i] = pansyn_node_len(seed, i);
+}
+
+uint64_t pansyn_node_thr(uint64_t seed, uint64_t i, uint64_t n_paths) {
+    uint64_t t = pansyn_splitmix64(pansyn_key(seed, 3) + i) >> 11;
+    if (t < PANSYN_ONE53 / 100 * 20) return PANSYN_ONE53;           /* core: in every path */
+    if (t < PANSYN_ONE53 / 100 * 65) return PANSYN_ONE53 / n_paths; /* near-singleton */
+    return pansyn_splitmix64(pansyn_key(seed, 4) + i) >> 11;        /* shell: uniform freq */
+}
+
+int64_t pansyn_generate(uint64_t seed, uint64_t n_nodes, uint64_t n_paths, uint64_t **items_out,
+                        uint64_t *prefsum) {
+    u64vec items = {0};
+    uint64_t *thr = xmalloc((n_nodes + 1) * sizeof *thr);
+    for (uint64_t i = 1; i <= n_nodes; i++) thr[i] = pansyn_node_thr(seed, i, n_paths);
+    uint64_t k5 = pansyn_key(seed, 5);
+    prefsum[0] = 0;
+    for (uint64_t p = 0; p < n_paths; p++) {
+        uint64_t kp = pansyn_splitmix64(k5 + p);
+        size_t begin = items.n;
+        for (uint64_t i = 1; i <= n_nodes; i++) {
+            uint64_t h = pansyn_splitmix64(kp + i);
+            if ((h >> 11) < thr[i]) {
+                u64vec_push(&items, i);
+                if ((h & 63) == 0) u64vec_push(&items, i);
+            }
+        }
+        if (p % 16 == 15) { /* descending path: reverse */
+            for (size_t a = begin, b = items.n; a + 1 < b; a++, b--) {
+                uint64_t t = items.v[a];
+                items.v[a] = items.v[b - 1];
+                items.v[b - 1] = t;
+            }
+        }
+        prefsum[p + 1] = items.n;
+    }
+    free(thr);
+    *items_out = items.v ? items.v : xmalloc(8);
+    return (int64_t)items.n;
+}
