@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- histgrowth throughput of the MI355X hot path (BASELINE.json metric).
+
+One "step" = one full histgrowth pass over one synthetic pangenome resident in HBM:
+  tile index (K0) -> tile coverage (K1) -> histogram (K2) on the GPU, the (G+1)-bin
+  histogram back to the host, then the exact closed-form growth curves (f64, host threads)
+  for the configured (coverage, quorum) pairs -- i.e. `panacus histgrowth -c node -l 1,2,1
+  -q 0,0,0.5` after the GFA has been turned into the CSR.  The tile index is rebuilt in every
+  step (PNX_CFG_CACHE_INDEX = 0), so nothing is cached across the timed passes.
+
+Workload at N = 1: BASELINE.json configs[2] ("histgrowth ... on 10M-node / 256-path
+synthetic"), generator pansyn-v1 seed 42.  With --gpus N each rank owns one node-range
+shard of the same shape (weak scaling: the global graph has N x 10M nodes, seeds 42+rank),
+the per-rank histograms are summed with an RCCL all-reduce on the device counters, and
+rank 0 evaluates the closed forms.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def algorithmic_bytes_hist(S, P, N, G, weighted=False):
+    """B_hist = 4*S + 8*(P+1) + 4*N [+ 4*N if bp] + 8*(G+1)."""
+    return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
+
+
+def cpu_baseline(sample_nodes, n_paths, pairs, seed=42):
+    """The oracle (a plain-C port of the reference's serial loops) on a bounded sample of the
+    same workload, timed on this host: coverage + hist + closed-form growth."""
+    import oracle as orc
+    items, pre, _ = orc.pansyn(seed, sample_nodes, n_paths)
+    pi = np.arange(n_paths, dtype=np.uint64)
+    t0 = time.perf_counter()
+    cov = orc.coverage(items, pre, pi, pi, sample_nodes)
+    h = orc.hist(cov, n_paths)
+    for c, q in pairs:
+        orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample_nodes * n_paths / dt / 1e6,
+        "unit": "M node*paths/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"pansyn-v1 seed {seed}, {sample_nodes} nodes x {n_paths} paths "
+                  f"({len(items)} steps), serial coverage+hist+growth, {dt:.2f} s",
+    }, h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--paths", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--tile-blocks", type=int, default=1)
+    ap.add_argument("--cpu-sample-nodes", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--growth-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: panacus_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+
+    N, P = args.nodes, args.paths
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]  # -l 1,2,1 -q 0,0,0.5
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+
+    ctx = capi.Context(local_rank)
+    ctx.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
+    ctx.config(capi.CFG_CACHE_INDEX, 0)
+    ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
+    info = ctx.info()
+    S = int(info.n_steps)
+
+    hist_host = np.zeros(P + 1, dtype=np.uint64)
+    hist_dev = None
+
+    def step(collect_growth=True):
+        nonlocal hist_dev
+        ctx.hist_async()
+        if world > 1:
+            d_hist, _ = ctx.hist_device()  # settles the pass, leaves the counters in HBM
+            if hist_dev is None:
+                hist_dev = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
+            dist.all_reduce(hist_dev)  # RCCL, int64 sum == uint64 sum for counts < 2^63
+            torch.cuda.current_stream().synchronize()
+        _, h = ctx.hist_fetch(want_countable=False)
+        if rank == 0 and collect_growth:
+            return h, [hostlib.calc_growth(h, c, q, args.growth_threads) for c, q in thr]
+        return h, None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h, growths = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # host-side share of a step (closed-form growth), measured separately on rank 0
+    growth_ms = None
+    if rank == 0:
+        g0 = time.perf_counter()
+        for _ in range(3):
+            for c, q in thr:
+                hostlib.calc_growth(h, c, q, args.growth_threads)
+        growth_ms = (time.perf_counter() - g0) / 3 * 1e3
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * N * P / (dt / args.steps) / 1e6
+        cover_ms, cover_n = prof["cover"]
+        index_ms, index_n = prof["index"]
+        hist_ms, hist_n = prof["hist"]
+        cover_avg_ms = cover_ms / max(cover_n, 1)
+        B = algorithmic_bytes_hist(S, P, N, P)
+        achieved = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
+        device_ms = (cover_ms + index_ms + hist_ms) / max(cover_n, 1)
+        out = {
+            "metric": "histgrowth_throughput",
+            "value": value,
+            "unit": "M node*paths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 synthetic, "
+                            f"{N} nodes x {P} paths per GPU (BASELINE.json configs[2])",
+                "nodes_per_gpu": N, "paths": P, "groups": P, "steps_in_csr": S, "seed": args.seed,
+                "threshold_pairs": pairs, "tile_items": int(info.tile_items),
+                "parallelism": "node-range shards, RCCL all-reduce of hist counters" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_tile_cover",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": B,
+                "avg_launch_ms": cover_avg_ms,
+                "launches": cover_n,
+            },
+            "breakdown_ms": {
+                "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
+                "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
+                "host_closed_form_growth": growth_ms,
+            },
+            "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,
+            "checks": {"hist_sum": int(h.sum()), "expected_hist_sum": world * N,
+                       "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, _ = cpu_baseline(min(args.cpu_sample_nodes, N), P, pairs, args.seed)
+                out["cpu_baseline"] = cb
+            except Exception as e:  # the oracle is optional test infrastructure
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

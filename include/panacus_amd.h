@@ -1,0 +1,166 @@
+/*
+ * panacus_amd.h -- C ABI of the MI355X coverage-histogram / pangenome-growth engine.
+ *
+ * This is the drop-in boundary for the hot path of marschall-lab/panacus v0.4.1
+ * (hist / growth / histgrowth / ordered-histgrowth).  The reference has no FFI seam of
+ * its own; the seam sits where its internal constructors turn an ItemTable (CSR of path
+ * steps) into results.  Every entry point names the reference routine(s) it replaces
+ * (file:line relative to the reference root).  A Rust host binds these with a plain
+ * `extern "C"` block; this repository's own host is C++/Python.
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative PNX_E* code; nothing unwinds across
+ *     the ABI; pnx_last_error() holds a human-readable message for the failing call;
+ *   - plain pointers + sizes; host buffers are caller-owned and copied by the library;
+ *   - one pnx_ctx per process per GPU (one process per GPU; multi-GPU = several
+ *     processes, each with its own node-range shard or permutation shard, combined by the
+ *     caller with an RCCL all-reduce on the device counters, see pnx_hist_device());
+ *   - a pnx_ctx is not thread-safe; calls are serialised by the caller;
+ *   - results are exact integers, independent of launch geometry and device count;
+ *   - there is NO CPU fallback: every call fails with PNX_ENODEV without a HIP device.
+ *
+ * Item ids are 1..n_items (0 is the reference's reserved "zero element",
+ * abacus.rs:549-551); ItemIdSize narrows from u64 to u32 at this boundary (n_items and
+ * n_paths < 2^32-1); step offsets stay u64.
+ */
+#ifndef PANACUS_AMD_H
+#define PANACUS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNX_OK 0
+#define PNX_EINVAL (-1)   /* bad argument / call order */
+#define PNX_ENODEV (-2)   /* no usable HIP device */
+#define PNX_EHIP (-3)     /* HIP runtime error (message has the hipError string) */
+#define PNX_ENOMEM (-4)   /* device or host allocation failed */
+#define PNX_ELIMIT (-5)   /* input exceeds an implementation limit (stated in the message) */
+
+typedef struct pnx_ctx pnx_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+/* device = HIP device ordinal visible to this process (LOCAL_RANK for torchrun launches). */
+int pnx_init(pnx_ctx **out, int device);
+void pnx_free(pnx_ctx *ctx);
+/* message of the last failing call on ctx (ctx == NULL: last pnx_init failure) */
+const char *pnx_last_error(const pnx_ctx *ctx);
+const char *pnx_version(void);
+
+/* ---- graph upload: the ItemTable (src/util.rs:81-93) ------------------------------------
+ * Replaces the hand-off of `item_table` into AbacusByTotal::item_table_to_abacus
+ * (src/graph_broker/abacus.rs:539-547) and AbacusByGroup::from_gfa (abacus.rs:803-804).
+ *   items     S step ids (1..n_items), duplicates within a path kept, FILE order of paths
+ *   path_off  n_paths+1 offsets into items (the reference's id_prefsum)
+ *   weights   n_items+1 values (weights[0] ignored) = GraphStorage::node_lens
+ *             (graph.rs:323-351) for CountType::Bp, NULL for node/edge counts
+ *   exclude   n_items+1 flags = ActiveTable::items (src/util.rs:118-124), NULL if unused
+ */
+int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                uint32_t n_items, const uint32_t *weights, const uint8_t *exclude);
+
+/* Synthetic graph generated directly in HBM by the pansyn-v1 generator: the
+ * bench/test input of BASELINE.json configs 2-4.  Equivalent to pnx_set_csr on the arrays
+ * the CPU generator produces for (seed, n_nodes, n_paths). with_weights != 0 also derives
+ * node lengths (CountType::Bp). */
+int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
+                       int with_weights);
+
+/* Read the resident graph back (tests / caching): any pointer may be NULL.
+ * n_steps receives S; items needs S entries, path_off n_paths+1, weights n_items+1. */
+int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path_off,
+                uint32_t *weights);
+
+/* ---- visiting order: result of GraphMask::get_path_order (abacus.rs:310-347) plus the
+ * group-id assignment of item_table_to_abacus (abacus.rs:555-559).  group_id must be
+ * non-decreasing (groups are contiguous) and dense in 0..n_groups-1. */
+int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_id,
+                  uint32_t n_ordered, uint32_t n_groups);
+
+/* ---- coverage + histogram ---------------------------------------------------------------
+ * Replaces AbacusByTotal::item_table_to_abacus -> coverage (abacus.rs:539-586, 719-744)
+ * and construct_hist / construct_hist_bps (abacus.rs:746-787; weighted iff weights were
+ * uploaded; the sparse uncovered_bps fix-up of :779-785 stays with the caller).
+ *   countable  n_items+1 values, countable[0] = UINT32_MAX like the reference; may be NULL
+ *   hist       n_groups+1 values
+ */
+int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
+
+/* Split form for pipelining and multi-GPU: enqueue on the context's stream, leave results
+ * in HBM, expose the device counters so the caller can all-reduce them (RCCL, uint64 sum)
+ * before fetching.  d_hist has n_groups+1 u64, d_countable n_items+1 u32. */
+int pnx_hist_async(pnx_ctx *ctx);
+int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable);
+int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
+int pnx_sync(pnx_ctx *ctx);
+/* raw hipStream_t of the context (for RCCL / event interop in the host layer) */
+void *pnx_stream(pnx_ctx *ctx);
+
+/* ---- ordered / permuted growth ------------------------------------------------------------
+ * Replaces AbacusByGroup::compute_row_storage_space + compute_column_values
+ * (abacus.rs:859-986; the (r,c) matrix becomes a bit-packed group x item presence matrix
+ * in HBM) and AbacusByGroup::calc_growth (abacus.rs:989-1032) for R group orders at once.
+ *   perms       R*n_groups entries, perms[r*G + rank] = group id visited at that rank;
+ *               NULL = identity (R must be 1): exactly the reference's ordered-histgrowth
+ *   cov_thr     T entries: c = max(1, t_coverage.to_absolute(G))        (abacus.rs:997)
+ *   quorum_tab  T*n_groups entries: ceil((rank + 1.0) * q) in f64       (abacus.rs:1009)
+ *   out         R*T*n_groups u64: res[j] of calc_growth (integer-valued in the reference)
+ * Weighted (bp) iff weights were uploaded; the caller applies uncovered_bps by passing
+ * weights = node_lens - uncovered.
+ */
+int pnx_ordered_growth(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms,
+                       const uint32_t *cov_thr, const uint32_t *quorum_tab, uint32_t n_thr,
+                       uint64_t *out);
+int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms,
+                             const uint32_t *cov_thr, const uint32_t *quorum_tab, uint32_t n_thr);
+int pnx_ordered_growth_device(pnx_ctx *ctx, uint64_t **d_out); /* R*T*G u64 */
+int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
+
+/* ---- measurement ---------------------------------------------------------------------------
+ * HIP-event timing of the kernels, recorded on the context's own stream.  Slots: */
+enum {
+    PNX_K_INDEX = 0,   /* tile boundary index (binary searches)            */
+    PNX_K_SCATTER = 1, /* presence scatter of non-monotone paths           */
+    PNX_K_COVER = 2,   /* tile coverage kernel -- the dominant hist kernel */
+    PNX_K_HIST = 3,    /* histogram of the coverage vector                 */
+    PNX_K_MASK = 4,    /* threshold masks / weight planes for growth       */
+    PNX_K_GROWTH = 5,  /* ordered / permuted growth kernel                 */
+    PNX_K_COUNT = 6
+};
+int pnx_profile_enable(pnx_ctx *ctx, int on);
+/* accumulated milliseconds and launch counts per slot since the last reset */
+int pnx_profile_read(pnx_ctx *ctx, double ms[PNX_K_COUNT], uint64_t launches[PNX_K_COUNT]);
+int pnx_profile_reset(pnx_ctx *ctx);
+
+/* ---- tunables -------------------------------------------------------------------------- */
+enum {
+    PNX_CFG_CACHE_INDEX = 1,   /* 1 (default): keep the tile index across pnx_hist calls on the
+                                  same graph; 0: rebuild it in every call (benchmark honesty:
+                                  the index is then part of every timed pass) */
+    PNX_CFG_TILE_BLOCKS = 2,   /* 1 or 2 blocks of 2048 items per coverage tile (default 1) */
+    PNX_CFG_KEEP_PRESENCE = 3  /* 1: pnx_hist also leaves the presence bit matrix in HBM
+                                  (default 0; pnx_ordered_growth turns it on by itself) */
+};
+int pnx_config(pnx_ctx *ctx, int key, int64_t value);
+
+/* workload facts of the resident graph/order (for algorithmic-byte accounting) */
+typedef struct {
+    uint64_t n_steps;        /* S */
+    uint32_t n_items;        /* N */
+    uint32_t n_paths;        /* P */
+    uint32_t n_ordered;      /* paths in the visiting order */
+    uint32_t n_groups;       /* G */
+    uint32_t n_tiles;        /* item tiles of the coverage kernel */
+    uint32_t tile_items;     /* items per tile */
+    uint32_t n_general_paths;/* paths that took the scatter route in the last pnx_hist */
+    uint32_t weighted;       /* 1 if weights are resident */
+} pnx_info_t;
+int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANACUS_AMD_H */

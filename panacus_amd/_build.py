@@ -1,0 +1,107 @@
+"""Builds the native parts of panacus_amd in-tree with hipcc / g++ (no JIT cache).
+
+  libpanacus_hip.so   HIP kernels + the C ABI of include/panacus_amd.h   (gfx950)
+  libpanacus_host.so  C++ host layer (GFA front end, closed-form growth, TSV writers)
+  panacus-amd         CLI (hist | growth | histgrowth | ordered-histgrowth)
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only build
+container; the .so files travel to the GPU box with the source tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOSTSRC = os.path.join(HERE, "host")
+LIB_HIP = os.path.join(HERE, "libpanacus_hip.so")
+LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
+CLI = os.path.join(HERE, "panacus-amd")
+
+HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_growth.hip", "pansyn.hip"]
+HOST_SOURCES = ["growth_closed_form.cpp", "host_api.cpp"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: panacus_amd needs the ROCm toolchain (no CPU fallback exists)")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(ROOT, "include", "panacus_amd.h")]
+    objs = []
+    procs = []
+    for src in HIP_SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
+                   "-Wno-unused-result"]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("build failed: " + " ".join(cmd))
+        if verbose and out.strip():
+            print(out)
+    if force or procs or _newer(LIB_HIP, objs):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs)
+    return LIB_HIP
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(HOSTSRC, s) for s in HOST_SOURCES]
+    hdrs = [os.path.join(HOSTSRC, h) for h in os.listdir(HOSTSRC) if h.endswith(".hpp")] if os.path.isdir(HOSTSRC) else []
+    hdrs.append(os.path.join(ROOT, "include", "panacus_amd.h"))
+    if not all(os.path.exists(s) for s in srcs):
+        return ""
+    if force or _newer(LIB_HOST, srcs + hdrs):
+        # -ffp-contract=off: the closed-form growth must keep the reference's f64 operation order
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-fast-math",
+               "-Wall", "-o", LIB_HOST] + srcs + ["-lz", "-lm"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    main = os.path.join(HOSTSRC, "cli_main.cpp")
+    if os.path.exists(main) and (force or _newer(CLI, [main, LIB_HOST, LIB_HIP] + hdrs)):
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", CLI, main, "-L" + HERE, "-lpanacus_host", "-lpanacus_hip",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    return LIB_HOST
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    build_hip(force, verbose)
+    build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built:", LIB_HIP, os.path.exists(LIB_HIP), LIB_HOST, os.path.exists(LIB_HOST))

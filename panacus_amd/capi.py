@@ -1,0 +1,245 @@
+"""ctypes binding of libpanacus_hip.so -- the C ABI declared in include/panacus_amd.h.
+
+This is the same seam a Rust host would bind with ``extern "C"``.  There
+is no CPU fallback: loading fails loudly if the HIP library has not been built, and every
+call fails with PNX_ENODEV when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
+
+PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
+K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_COUNT = range(7)
+KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth"]
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE = 1, 2, 3
+
+# every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn",
+    "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch",
+    "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
+    "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
+    "pnx_profile_reset", "pnx_config", "pnx_info",
+]
+
+
+class PnxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"panacus_amd error {code}: {msg}")
+        self.code = code
+
+
+class PnxInfo(C.Structure):
+    _fields_ = [("n_steps", C.c_uint64), ("n_items", C.c_uint32), ("n_paths", C.c_uint32),
+                ("n_ordered", C.c_uint32), ("n_groups", C.c_uint32), ("n_tiles", C.c_uint32),
+                ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libpanacus_hip.so (built in-tree by panacus_amd._build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m panacus_amd._build` "
+            "(hipcc, gfx950). panacus_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32p, u64p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+    L.pnx_init.argtypes = [C.POINTER(vp), C.c_int]
+    L.pnx_free.argtypes = [vp]
+    L.pnx_free.restype = None
+    L.pnx_last_error.argtypes = [vp]
+    L.pnx_last_error.restype = C.c_char_p
+    L.pnx_version.restype = C.c_char_p
+    L.pnx_set_csr.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p]
+    L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.pnx_get_csr.argtypes = [vp, u64p, u32p, u64p, u32p]
+    L.pnx_set_order.argtypes = [vp, u32p, u32p, C.c_uint32, C.c_uint32]
+    L.pnx_hist.argtypes = [vp, u32p, u64p]
+    L.pnx_hist_async.argtypes = [vp]
+    L.pnx_hist_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.pnx_hist_fetch.argtypes = [vp, u32p, u64p]
+    L.pnx_sync.argtypes = [vp]
+    L.pnx_stream.argtypes = [vp]
+    L.pnx_stream.restype = vp
+    L.pnx_ordered_growth.argtypes = [vp, u32p, C.c_uint32, u32p, u32p, C.c_uint32, u64p]
+    L.pnx_ordered_growth_async.argtypes = [vp, u32p, C.c_uint32, u32p, u32p, C.c_uint32]
+    L.pnx_ordered_growth_device.argtypes = [vp, C.POINTER(vp)]
+    L.pnx_ordered_growth_fetch.argtypes = [vp, u64p]
+    L.pnx_profile_enable.argtypes = [vp, C.c_int]
+    L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
+    L.pnx_profile_reset.argtypes = [vp]
+    L.pnx_config.argtypes = [vp, C.c_int, C.c_int64]
+    L.pnx_info.argtypes = [vp, C.POINTER(PnxInfo)]
+    _lib = L
+    return L
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class Context:
+    """One engine context = one GPU (one process per GPU)."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        rc = self._L.pnx_init(C.byref(h), device)
+        if rc != PNX_OK:
+            raise PnxError(rc, self._L.pnx_last_error(None).decode())
+        self._h = h
+        self.n_groups = 0
+        self.n_items = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pnx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != PNX_OK:
+            raise PnxError(rc, self._L.pnx_last_error(self._h).decode())
+
+    # ---- graph ----
+    def set_csr(self, items, path_off, n_items, weights=None, exclude=None):
+        items = np.ascontiguousarray(items, dtype=np.uint32)
+        path_off = np.ascontiguousarray(path_off, dtype=np.uint64)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+        if w is not None and len(w) != n_items + 1:
+            raise ValueError("weights must have n_items+1 entries")
+        if ex is not None and len(ex) != n_items + 1:
+            raise ValueError("exclude must have n_items+1 entries")
+        self._ck(self._L.pnx_set_csr(self._h, _ptr(items, C.c_uint32), _ptr(path_off, C.c_uint64),
+                                     len(path_off) - 1, n_items, _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
+        self.n_items = n_items
+
+    def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
+        self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
+        self.n_items = n_nodes
+
+    def get_csr(self, want_weights=False):
+        n = C.c_uint64(0)
+        self._ck(self._L.pnx_get_csr(self._h, C.byref(n), None, None, None))
+        info = self.info()
+        items = np.zeros(max(n.value, 1), dtype=np.uint32)
+        off = np.zeros(info.n_paths + 1, dtype=np.uint64)
+        w = np.zeros(info.n_items + 1, dtype=np.uint32) if want_weights else None
+        self._ck(self._L.pnx_get_csr(self._h, C.byref(n), _ptr(items, C.c_uint32), _ptr(off, C.c_uint64),
+                                     _ptr(w, C.c_uint32)))
+        return items[: n.value], off, w
+
+    def set_order(self, path_idx, group_id, n_groups=None):
+        pi = np.ascontiguousarray(path_idx, dtype=np.uint32)
+        gi = np.ascontiguousarray(group_id, dtype=np.uint32)
+        if n_groups is None:
+            n_groups = int(gi[-1]) + 1 if len(gi) else 0
+        self._ck(self._L.pnx_set_order(self._h, _ptr(pi, C.c_uint32), _ptr(gi, C.c_uint32), len(pi), n_groups))
+        self.n_groups = n_groups
+
+    # ---- hist ----
+    def hist(self, want_countable=True):
+        cnt = np.zeros(self.n_items + 1, dtype=np.uint32) if want_countable else None
+        h = np.zeros(self.n_groups + 1, dtype=np.uint64)
+        self._ck(self._L.pnx_hist(self._h, _ptr(cnt, C.c_uint32), _ptr(h, C.c_uint64)))
+        return cnt, h
+
+    def hist_async(self):
+        self._ck(self._L.pnx_hist_async(self._h))
+
+    def hist_fetch(self, want_countable=False):
+        cnt = np.zeros(self.n_items + 1, dtype=np.uint32) if want_countable else None
+        h = np.zeros(self.n_groups + 1, dtype=np.uint64)
+        self._ck(self._L.pnx_hist_fetch(self._h, _ptr(cnt, C.c_uint32), _ptr(h, C.c_uint64)))
+        return cnt, h
+
+    def hist_device(self):
+        dh, dc = C.c_void_p(), C.c_void_p()
+        self._ck(self._L.pnx_hist_device(self._h, C.byref(dh), C.byref(dc)))
+        return dh.value, dc.value
+
+    def sync(self):
+        self._ck(self._L.pnx_sync(self._h))
+
+    def stream(self) -> int:
+        return self._L.pnx_stream(self._h)
+
+    # ---- growth ----
+    def ordered_growth(self, cov_thr, quorum_tab, perms=None):
+        """cov_thr: T u32; quorum_tab: T x G u32; perms: R x G u32 or None. -> (R, T, G) u64"""
+        G = self.n_groups
+        ct = np.ascontiguousarray(cov_thr, dtype=np.uint32)
+        qt = np.ascontiguousarray(quorum_tab, dtype=np.uint32).reshape(len(ct), G)
+        if perms is None:
+            R, pp = 1, None
+        else:
+            pp = np.ascontiguousarray(perms, dtype=np.uint32).reshape(-1, G)
+            R = pp.shape[0]
+        out = np.zeros((R, len(ct), G), dtype=np.uint64)
+        self._ck(self._L.pnx_ordered_growth(self._h, _ptr(pp, C.c_uint32), R, _ptr(ct, C.c_uint32),
+                                            _ptr(qt, C.c_uint32), len(ct), _ptr(out, C.c_uint64)))
+        return out
+
+    def ordered_growth_async(self, cov_thr, quorum_tab, perms=None):
+        G = self.n_groups
+        ct = np.ascontiguousarray(cov_thr, dtype=np.uint32)
+        qt = np.ascontiguousarray(quorum_tab, dtype=np.uint32).reshape(len(ct), G)
+        pp = None if perms is None else np.ascontiguousarray(perms, dtype=np.uint32).reshape(-1, G)
+        R = 1 if pp is None else pp.shape[0]
+        self._ck(self._L.pnx_ordered_growth_async(self._h, _ptr(pp, C.c_uint32), R, _ptr(ct, C.c_uint32),
+                                                  _ptr(qt, C.c_uint32), len(ct)))
+        return (R, len(ct), G)
+
+    def ordered_growth_fetch(self, shape):
+        out = np.zeros(shape, dtype=np.uint64)
+        self._ck(self._L.pnx_ordered_growth_fetch(self._h, _ptr(out, C.c_uint64)))
+        return out
+
+    def ordered_growth_device(self) -> int:
+        d = C.c_void_p()
+        self._ck(self._L.pnx_ordered_growth_device(self._h, C.byref(d)))
+        return d.value
+
+    # ---- measurement / tunables ----
+    def profile_enable(self, on=True):
+        self._ck(self._L.pnx_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms = (C.c_double * K_COUNT)()
+        n = (C.c_uint64 * K_COUNT)()
+        self._ck(self._L.pnx_profile_read(self._h, ms, n))
+        return {KERNEL_SLOT_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(K_COUNT)}
+
+    def profile_reset(self):
+        self._ck(self._L.pnx_profile_reset(self._h))
+
+    def config(self, key, value):
+        self._ck(self._L.pnx_config(self._h, key, int(value)))
+
+    def info(self) -> PnxInfo:
+        out = PnxInfo()
+        self._ck(self._L.pnx_info(self._h, C.byref(out)))
+        return out

@@ -1,0 +1,435 @@
+// kernels_cover.hip -- coverage counting + histogram on gfx950 (MI355X).
+//
+// Replaces, on the device, the reference's serial loops
+//   AbacusByTotal::coverage            src/graph_broker/abacus.rs:719-744
+//   AbacusByTotal::construct_hist      src/graph_broker/abacus.rs:746-762
+//   AbacusByTotal::construct_hist_bps  src/graph_broker/abacus.rs:764-787
+// and produces the bit-packed presence matrix that stands in for AbacusByGroup's (r, c)
+// (abacus.rs:859-986).
+//
+// Design (HBM-bound integer set work; no MFMA):
+//   * the item id space is cut into tiles of WT*2048 ids; ONE WAVE owns one tile for the
+//     whole kernel, so no global atomics and no inter-workgroup traffic exist on the fast
+//     path, and a workgroup (4 waves) never needs __syncthreads();
+//   * K0 finds, for every (path, tile boundary), where the path's steps cross the boundary
+//     (binary search; exact for tile-monotone paths, verified by K1);
+//   * K1 streams each (path, tile) segment of the CSR exactly once with 16 B/lane coalesced
+//     loads, ORs presence bits into a per-wave 256 B LDS bitmap (ds_or_b32; dedupes repeated
+//     visits inside a group for free), and at every group change folds the bitmap into
+//     bit-sliced vertical counters held in registers (carry-save ripple adder: NPL planes);
+//   * at the end the counters are unpacked to the u32 coverage vector with coalesced
+//     stores; K2 turns it into the (optionally bp-weighted) histogram in LDS;
+//   * paths that are not tile-monotone (edge ids, cyclic walks) are detected, not assumed
+//     away: they take the scatter route (global atomicOr into the presence matrix, merged by
+//     K1 at flush time) and the pass is re-run when a violation is first seen.
+#include "pnx_context.hpp"
+
+namespace pnx {
+
+// ------------------------------------------------------------------------------------------
+// upload validation: every step id must be in 1..n_items
+// ------------------------------------------------------------------------------------------
+__global__ void k_validate_items(const uint32_t *__restrict__ items, uint64_t n_steps,
+                                 uint32_t n_items, uint32_t *bad) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t b = 0;
+    for (; i < n_steps; i += stride) {
+        uint32_t id = items[i];
+        b |= (id == 0u) | (id > n_items);
+    }
+    if (b) atomicOr(bad, 1u);
+}
+
+int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
+    if (ctx->n_steps == 0) return PNX_OK;
+    uint64_t want = (ctx->n_steps + 255) / 256;
+    int grid = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_validate_items, dim3(grid), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)ctx->d_items.p, ctx->n_steps, ctx->n_items, d_bad);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K0: tile boundary index.  B[p][t] = path_off[p] + (#steps of p "before" tile t), where
+// "before" means id < t*tile_items for an ascending path and id >= t*tile_items for a
+// descending one (direction = first step vs last step).  For a tile-monotone path the steps
+// of tile t are exactly [min(B[t],B[t+1]), max(B[t],B[t+1])).
+// ------------------------------------------------------------------------------------------
+__global__ void k_tile_index(const uint32_t *__restrict__ items,
+                             const uint64_t *__restrict__ path_off, uint32_t n_paths,
+                             uint32_t n_tiles, uint32_t tile_items, uint64_t *__restrict__ B) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t per = (uint64_t)n_tiles + 1;
+    if (gid >= per * n_paths) return;
+    uint32_t p = (uint32_t)(gid / per);
+    uint32_t t = (uint32_t)(gid % per);
+    uint64_t s = path_off[p], e = path_off[p + 1];
+    uint64_t len = e - s;
+    if (len == 0) {
+        B[gid] = s;
+        return;
+    }
+    const uint32_t *a = items + s;
+    bool asc = a[0] <= a[len - 1];
+    uint64_t key = (uint64_t)t * tile_items;
+    uint64_t lo = 0, hi = len;
+    if (asc) {
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)a[mid] < key) lo = mid + 1; else hi = mid;
+        }
+    } else {
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)a[mid] >= key) lo = mid + 1; else hi = mid;
+        }
+    }
+    B[gid] = s + lo;
+}
+
+// boundaries of a tile-monotone path are monotone; anything else goes the scatter route
+__global__ void k_tile_index_check(const uint32_t *__restrict__ items,
+                                   const uint64_t *__restrict__ path_off,
+                                   const uint64_t *__restrict__ B, uint32_t n_paths,
+                                   uint32_t n_tiles, uint8_t *path_class) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)n_tiles * n_paths) return;
+    uint32_t p = (uint32_t)(gid / n_tiles);
+    uint32_t t = (uint32_t)(gid % n_tiles);
+    uint64_t s = path_off[p], e = path_off[p + 1];
+    if (e == s) return;
+    bool asc = items[s] <= items[e - 1];
+    uint64_t a = B[(uint64_t)p * (n_tiles + 1) + t], b = B[(uint64_t)p * (n_tiles + 1) + t + 1];
+    if (asc ? (a > b) : (a < b)) path_class[p] = 1;
+}
+
+int launch_tile_index(pnx_ctx *ctx) {
+    const uint32_t tile_items = ctx->tile_blocks * BLOCK_ITEMS;
+    uint64_t nb = (uint64_t)ctx->n_paths * (ctx->n_tiles + 1);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tile_idx, nb * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_path_class, ctx->n_paths ? ctx->n_paths : 1))) return rc;
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_path_class.p, 0, ctx->n_paths ? ctx->n_paths : 1, ctx->stream));
+    if (nb == 0) return PNX_OK;
+    prof_begin(ctx, PNX_K_INDEX);
+    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
+                       ctx->n_paths, ctx->n_tiles, tile_items, (uint64_t *)ctx->d_tile_idx.p);
+    uint64_t nc = (uint64_t)ctx->n_paths * ctx->n_tiles;
+    hipLaunchKernelGGL(k_tile_index_check, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0,
+                       ctx->stream, (const uint32_t *)ctx->d_items.p,
+                       (const uint64_t *)ctx->d_path_off.p, (const uint64_t *)ctx->d_tile_idx.p,
+                       ctx->n_paths, ctx->n_tiles, (uint8_t *)ctx->d_path_class.p);
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// general (non tile-monotone) paths: bookkeeping + scatter route
+// ------------------------------------------------------------------------------------------
+__global__ void k_count_general(const uint8_t *__restrict__ path_class,
+                                const uint32_t *__restrict__ ord_path,
+                                const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
+                                uint8_t *grp_general, uint32_t *flags) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_ordered) return;
+    if (path_class[ord_path[k]]) {
+        grp_general[ord_group[k]] = 1;
+        atomicAdd(&flags[1], 1u);
+    }
+}
+
+__global__ void k_zero_if_general(uint4 *__restrict__ M, uint64_t n_vec4,
+                                  const uint32_t *__restrict__ flags) {
+    if (flags[1] == 0) return;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_vec4; i += stride) M[i] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ void k_scatter_general(const uint32_t *__restrict__ items,
+                                  const uint64_t *__restrict__ path_off,
+                                  const uint32_t *__restrict__ ord_path,
+                                  const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
+                                  const uint8_t *__restrict__ path_class, uint32_t *M,
+                                  uint64_t row_words, const uint32_t *__restrict__ flags) {
+    if (flags[1] == 0) return;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint32_t k = 0; k < n_ordered; ++k) {
+        uint32_t p = ord_path[k];
+        if (!path_class[p]) continue;
+        uint32_t *row = M + (uint64_t)ord_group[k] * row_words;
+        uint64_t e = path_off[p + 1];
+        for (uint64_t j = path_off[p] + tid; j < e; j += stride) {
+            uint32_t id = items[j];
+            atomicOr(&row[(uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u)], 1u << ((id >> 6) & 31u));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: tile coverage kernel (the dominant kernel of hist / histgrowth)
+// ------------------------------------------------------------------------------------------
+constexpr int COVER_WAVES = 4;   // waves (= tiles) per workgroup
+constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane
+
+template <int NPL, int WT, bool WRITE_M>
+__global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
+    const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
+    const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
+    uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
+    const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags) {
+    constexpr uint32_t TILE = WT * BLOCK_ITEMS;
+    __shared__ uint32_t bm_all[COVER_WAVES][WT * BLOCK_WORDS];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * COVER_WAVES + wave;
+    if (tile >= n_tiles) return;  // whole wave leaves; no workgroup barrier is ever used
+    uint32_t *bm = bm_all[wave];
+    const uint32_t tile_lo = tile * TILE;
+
+#pragma unroll
+    for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
+
+    // exclusion words in presence layout (ActiveTable, src/util.rs:118-124)
+    uint32_t excl[WT];
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+        excl[w] = 0;
+        if (exclude) {
+            for (uint32_t b = 0; b < 32; ++b) {
+                uint64_t node = (uint64_t)tile_lo + (uint32_t)w * BLOCK_ITEMS + b * 64u + lane;
+                if (node <= n_items && exclude[node]) excl[w] |= 1u << b;
+            }
+        }
+    }
+
+    uint32_t cnt[NPL][WT];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k)
+#pragma unroll
+        for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
+
+    // fold the LDS bitmap of the finished group into the bit-sliced counters
+    auto flush = [&](uint32_t g) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool merge = grp_general != nullptr && grp_general[g] != 0;
+#pragma unroll
+        for (int w = 0; w < WT; ++w) {
+            uint32_t x = bm[w * BLOCK_WORDS + lane];
+            bm[w * BLOCK_WORDS + lane] = 0;
+            const uint32_t blk = tile * WT + w;
+            if (blk < n_blocks) {
+                uint32_t *mw = M + (uint64_t)g * row_words + (uint64_t)blk * BLOCK_WORDS + lane;
+                if (merge) x |= *mw;
+                x &= ~excl[w];
+                if (WRITE_M) *mw = x;
+            }
+            uint32_t carry = x;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                uint32_t t = cnt[k][w] & carry;
+                cnt[k][w] ^= carry;
+                carry = t;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    const uint64_t brow = (uint64_t)n_tiles + 1;
+    uint32_t cur_g = n_ordered ? ord_group[0] : 0;
+    for (uint32_t k = 0; k < n_ordered; ++k) {
+        const uint32_t p = ord_path[k];
+        const uint32_t g = ord_group[k];
+        if (g != cur_g) {
+            flush(cur_g);
+            cur_g = g;
+        }
+        if (path_class[p]) continue;  // scatter route
+        const uint64_t ba = B[(uint64_t)p * brow + tile], bb = B[(uint64_t)p * brow + tile + 1];
+        const uint64_t lo = ba < bb ? ba : bb, hi = ba < bb ? bb : ba;
+        uint32_t viol = 0;
+        for (uint64_t base = lo & ~3ull; base < hi; base += 256ull * COVER_UNROLL) {
+            uint4 v[COVER_UNROLL];
+#pragma unroll
+            for (int u = 0; u < COVER_UNROLL; ++u) {
+                const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (j < hi) v[u] = *reinterpret_cast<const uint4 *>(items + j);
+            }
+#pragma unroll
+            for (int u = 0; u < COVER_UNROLL; ++u) {
+                const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
+                const uint32_t ids[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint64_t idx = j + e;
+                    if (idx >= lo && idx < hi) {
+                        const uint32_t n = ids[e] - tile_lo;
+                        if (n < TILE)
+                            atomicOr(&bm[(n & 63u) + ((n >> 11) << 6)], 1u << ((n >> 6) & 31u));
+                        else
+                            viol = 1;
+                    }
+                }
+            }
+        }
+        if (__any(viol)) {
+            // the path is not tile-monotone after all: send it down the scatter route and
+            // invalidate this pass (the host re-runs it)
+            if (lane == 0) {
+                path_class[p] = 1;
+                atomicAdd(&flags[0], 1u);
+            }
+        }
+    }
+    if (n_ordered) flush(cur_g);
+
+    // unpack the bit-sliced counters: one coalesced 256 B store per bit position
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+        const uint32_t blk = tile * WT + w;
+        if (blk >= n_blocks) break;
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) v |= ((cnt[k][w] >> b) & 1u) << k;
+            const uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
+            // countable[0] is the reference's reserved element (abacus.rs:549-551)
+            if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: histogram of the coverage vector (construct_hist / construct_hist_bps)
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t HIST_LDS_BINS = 4096;
+
+template <bool WEIGHTED, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_hist(const uint32_t *__restrict__ countable,
+                                              const uint32_t *__restrict__ weights,
+                                              uint32_t n_items, uint32_t n_groups,
+                                              unsigned long long *hist) {
+    __shared__ unsigned long long sh[USE_LDS ? HIST_LDS_BINS : 1];
+    if (USE_LDS) {
+        for (uint32_t i = threadIdx.x; i <= n_groups; i += blockDim.x) sh[i] = 0;
+        __syncthreads();
+    }
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // item 0 is skipped
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i <= n_items; i += stride) {
+        const uint32_t c = countable[i];
+        if (c <= n_groups) {  // abacus.rs:752 / :771: coverage beyond #groups is ignored
+            const unsigned long long w = WEIGHTED ? weights[i] : 1ull;
+            if (USE_LDS) atomicAdd(&sh[c], w); else atomicAdd(&hist[c], w);
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b <= n_groups; b += blockDim.x)
+            if (sh[b]) atomicAdd(&hist[b], sh[b]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one full pass for the current order: general bookkeeping -> scatter -> K1 -> K2
+// ------------------------------------------------------------------------------------------
+template <int NPL, int WT>
+static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
+    const unsigned grid = (ctx->n_tiles + COVER_WAVES - 1) / COVER_WAVES;
+    const uint64_t row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
+    auto args = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(COVER_WAVES * 64), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_tile_idx.p,
+                           (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
+                           ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
+                           use_m ? (const uint8_t *)ctx->d_grp_general.p : (const uint8_t *)nullptr,
+                           ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
+                           ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
+                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_flags.p);
+    };
+    if (write_m) args(k_tile_cover<NPL, WT, true>); else args(k_tile_cover<NPL, WT, false>);
+}
+
+template <int WT>
+static int launch_cover_wt(pnx_ctx *ctx, bool write_m, bool use_m) {
+    // planes needed to count up to n_groups inclusive
+    uint32_t bits = 1;
+    while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;
+    if (bits <= 8) launch_cover_t<8, WT>(ctx, write_m, use_m);
+    else if (bits <= 12) launch_cover_t<12, WT>(ctx, write_m, use_m);
+    else if (bits <= 16) launch_cover_t<16, WT>(ctx, write_m, use_m);
+    else if (bits <= 24) launch_cover_t<24, WT>(ctx, write_m, use_m);
+    else return ctx->fail(PNX_ELIMIT, "more than 2^24-1 groups are not supported (got %u)", ctx->n_groups);
+    return PNX_OK;
+}
+
+int launch_cover_pass(pnx_ctx *ctx) {
+    int rc;
+    const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
+    const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
+    if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_grp_general, ctx->n_groups ? ctx->n_groups : 1))) return rc;
+    if ((rc = ensure(ctx, ctx->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t)))) return rc;
+    if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
+
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_grp_general.p, 0, ctx->n_groups ? ctx->n_groups : 1, ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_hist.p, 0, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), ctx->stream));
+
+    if (ctx->n_ordered) {
+        prof_begin(ctx, PNX_K_SCATTER);
+        hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint8_t *)ctx->d_path_class.p, (const uint32_t *)ctx->d_ord_path.p,
+                           (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
+                           (uint8_t *)ctx->d_grp_general.p, (uint32_t *)ctx->d_flags.p);
+        if (use_m && m_words) {
+            hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->stream,
+                               (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->d_flags.p);
+            hipLaunchKernelGGL(k_scatter_general, dim3(2048), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
+                               (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
+                               ctx->n_ordered, (const uint8_t *)ctx->d_path_class.p, (uint32_t *)ctx->d_M.p,
+                               (uint64_t)ctx->n_blocks * BLOCK_WORDS, (const uint32_t *)ctx->d_flags.p);
+        }
+        prof_end(ctx);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+
+    prof_begin(ctx, PNX_K_COVER);
+    if (ctx->tile_blocks == 2) rc = launch_cover_wt<2>(ctx, ctx->want_M, use_m);
+    else rc = launch_cover_wt<1>(ctx, ctx->want_M, use_m);
+    prof_end(ctx);
+    if (rc) return rc;
+    PNX_HIP(ctx, hipGetLastError());
+
+    prof_begin(ctx, PNX_K_HIST);
+    {
+        uint64_t want = ((uint64_t)ctx->n_items + 255) / 256;
+        unsigned grid = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+        const bool lds = ctx->n_groups + 1 <= HIST_LDS_BINS;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_countable.p, (const uint32_t *)ctx->d_weights.p,
+                               ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->d_hist.p);
+        };
+        if (ctx->weighted) { if (lds) go(k_hist<true, true>); else go(k_hist<true, false>); }
+        else { if (lds) go(k_hist<false, true>); else go(k_hist<false, false>); }
+    }
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    ctx->M_valid = false;  // settled by the verification in pnx_api
+    return PNX_OK;
+}
+
+}  // namespace pnx

@@ -1,0 +1,433 @@
+// kernels_growth.hip -- ordered / permuted pangenome growth on the presence bit matrix.
+//
+// Replaces AbacusByGroup::calc_growth (src/graph_broker/abacus.rs:989-1032) for R group
+// orders at once.  Per item i with ascending group ranks g_0 < g_1 < ... (under the order
+// being evaluated) and total degree deg_i the reference adds w_i to res[j] for every
+// j in [g_m, g_{m+1}) iff deg_i >= c and (m+1) >= ceil((g_m + 1) * q)   (abacus.rs:1001-1010),
+// i.e. with x_j(i) = presence of i in the group of rank j:
+//      cnt_j = cnt_{j-1} + x_j ;  ok_j = x_j ? (cnt_j >= Tq[j]) : ok_{j-1} ;
+//      res[j] = sum_i w_i * [deg_i >= c] * ok_j(i).
+// The quirk that the quorum bound uses the rank of the LAST containing group (not j) is
+// exactly the "ok persists until the next set bit" rule above.
+//
+// Device formulation (integer set work, bit-parallel; no MFMA):
+//   * one lane owns one u32 word = 32 items of a 2048-item block; a wave walks the ranks
+//     of one order sequentially, reading one coalesced 256 B row slice per rank;
+//   * q == 0 pairs:  ok_j = "seen so far", so only NEW bits (x & ~seen) change res; they
+//     are sparse (32 per lane per order in total) and are pushed as deltas with LDS atomics;
+//   * q > 0 pairs:   cnt is kept bit-sliced (NPL planes, ripple-carry increment by the
+//     bitmask x), compared against the wave-uniform Tq[j] plane by plane, and the dense
+//     popcount is reduced over the wave with a 6-instruction DPP row/bcast reduction;
+//   * per-workgroup LDS accumulators (u64 per rank) are flushed once with global atomics;
+//     deltas of the q == 0 path are prefix-summed by a finishing kernel;
+//   * bp counts use bit planes of the weights: sum_i w_i b_i = sum_p 2^p popc(b & W_p).
+// Orders are independent, so R orders shard over workgroups (and over GPUs: permutation
+// sharding, DESIGN.md "Multi-GPU").
+#include "pnx_context.hpp"
+
+namespace pnx {
+
+constexpr int GROW_WAVES = 4;
+constexpr int GROW_PREFETCH = 16;  // row slices in flight per wave
+constexpr int GROW_Q0_MAX = 4;     // q == 0 threshold pairs handled by one launch
+constexpr int WPLANES_MAX = 32;
+
+// full-wave sum, result valid in lane 63 (gfx9 DPP: row_shr within rows of 16, then row_bcast)
+__device__ static inline uint32_t wave_sum_to_lane63(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xe, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xc, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);  // row_bcast:31
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// threshold masks and weight planes in presence layout
+// ------------------------------------------------------------------------------------------
+// cmask[ci][blk][lane] bit b = countable[node] >= cvals[ci]
+__global__ void k_cov_masks(const uint32_t *__restrict__ countable, uint32_t n_items, uint32_t n_blocks,
+                            const uint32_t *__restrict__ cvals, uint32_t n_c, uint32_t *__restrict__ cmask) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    for (uint32_t ci = 0; ci < n_c; ++ci) {
+        const uint32_t c = cvals[ci];
+        uint32_t m = 0;
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
+            if (node >= 1 && node <= n_items && countable[node] >= c) m |= 1u << b;
+        }
+        cmask[((uint64_t)ci * n_blocks + blk) * BLOCK_WORDS + lane] = m;
+    }
+}
+
+__global__ void k_max_u32(const uint32_t *__restrict__ a, uint64_t first, uint64_t n, uint32_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + first;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t m = 0;
+    for (; i < n; i += stride) m = a[i] > m ? a[i] : m;
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_down(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// wplanes[p][blk][lane] bit b = bit p of weights[node]
+__global__ void k_weight_planes(const uint32_t *__restrict__ weights, uint32_t n_items, uint32_t n_blocks,
+                                uint32_t n_planes, uint32_t *__restrict__ wplanes) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    uint32_t w[32];
+#pragma unroll
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
+        w[b] = (node >= 1 && node <= n_items) ? weights[node] : 0u;
+    }
+    for (uint32_t p = 0; p < n_planes; ++p) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 32; ++b) m |= ((w[b] >> p) & 1u) << b;
+        wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane] = m;
+    }
+}
+
+// weighted popcount through bit planes held in LDS (per wave: [plane][lane])
+__device__ static inline unsigned long long weighted_popc(uint32_t bits, const uint32_t *wp_lds, uint32_t n_planes,
+                                                          uint32_t lane) {
+    unsigned long long s = 0;
+    for (uint32_t p = 0; p < n_planes; ++p)
+        s += (unsigned long long)__popc(bits & wp_lds[p * 64 + lane]) << p;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// q == 0 pairs: res[j] = sum_i w_i [deg_i >= c] [first rank of i <= j]; deltas at first ranks
+// ------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_q0(
+    const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
+    const uint32_t *__restrict__ perms, uint32_t n_chunks, uint32_t blocks_per_chunk,
+    const uint32_t *__restrict__ cmask, const int32_t *__restrict__ mask_idx /* per q0 pair, -1 = none */,
+    const uint32_t *__restrict__ pair_slot /* output slot t of each q0 pair */, uint32_t n_q0, uint32_t T,
+    const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
+    extern __shared__ unsigned long long smem[];
+    unsigned long long *acc = smem;  // [n_q0][G]
+    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc + (size_t)n_q0 * G);  // [waves][planes][64]
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+    const uint32_t *perm = perms + (uint64_t)r * G;
+    uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
+
+    for (uint32_t i = threadIdx.x; i < n_q0 * G; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+
+    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
+    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
+        uint32_t mask[GROW_Q0_MAX];
+#pragma unroll
+        for (int t = 0; t < GROW_Q0_MAX; ++t) {
+            mask[t] = 0xFFFFFFFFu;
+            if ((uint32_t)t < n_q0 && mask_idx[t] >= 0)
+                mask[t] = cmask[((uint64_t)mask_idx[t] * n_blocks + blk) * BLOCK_WORDS + lane];
+        }
+        if (WEIGHTED) {
+            for (uint32_t p = 0; p < n_planes; ++p)
+                wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const uint32_t *col = M + (uint64_t)blk * BLOCK_WORDS + lane;
+        uint32_t seen = 0;
+        for (uint32_t jb = 0; jb < G; jb += GROW_PREFETCH) {
+            uint32_t x[GROW_PREFETCH];
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                x[u] = 0;
+                if (jb + u < G) x[u] = col[(uint64_t)perm[jb + u] * row_words];
+            }
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                const uint32_t nw = x[u] & ~seen;
+                seen |= x[u];
+                if (nw) {
+#pragma unroll
+                    for (int t = 0; t < GROW_Q0_MAX; ++t) {
+                        if ((uint32_t)t < n_q0) {
+                            const uint32_t bits = nw & mask[t];
+                            if (bits) {
+                                unsigned long long c = WEIGHTED ? weighted_popc(bits, wp, n_planes, lane)
+                                                                : (unsigned long long)__popc(bits);
+                                atomicAdd(&acc[(size_t)t * G + jb + u], c);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // deltas -> global (prefix-summed over ranks by k_growth_prefix)
+    for (uint32_t i = threadIdx.x; i < n_q0 * G; i += blockDim.x) {
+        const unsigned long long v = acc[i];
+        if (v) {
+            const uint32_t t = pair_slot[i / G], j = i % G;
+            atomicAdd(&out[((uint64_t)r * T + t) * G + j], v);
+        }
+    }
+}
+
+// out rows flagged as "delta" become running sums over the ranks
+__global__ void k_growth_prefix(unsigned long long *out, uint32_t G, uint32_t T, const uint32_t *__restrict__ is_delta) {
+    const uint32_t row = blockIdx.x;  // r * T + t
+    if (!is_delta[row % T]) return;
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        unsigned long long *o = out + (uint64_t)row * G;
+        for (uint32_t j = 0; j < G; ++j) {
+            run += o[j];
+            o[j] = run;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// q > 0 pair (one per launch): bit-sliced running counts, dense popcount per rank
+// ------------------------------------------------------------------------------------------
+template <int NPL, bool WEIGHTED>
+__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
+    const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
+    const uint32_t *__restrict__ perms, uint32_t n_chunks, uint32_t blocks_per_chunk,
+    const uint32_t *__restrict__ cmask_t /* mask of this pair or nullptr */, const uint32_t *__restrict__ qtab_t,
+    uint32_t t_slot, uint32_t T, const uint32_t *__restrict__ wplanes, uint32_t n_planes,
+    unsigned long long *out) {
+    extern __shared__ unsigned long long smem[];
+    unsigned long long *acc = smem;  // [G]
+    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc + G);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
+    const uint32_t *perm = perms + (uint64_t)r * G;
+    uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
+
+    for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+
+    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
+    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
+        const uint32_t mask = cmask_t ? cmask_t[(uint64_t)blk * BLOCK_WORDS + lane] : 0xFFFFFFFFu;
+        if (WEIGHTED) {
+            for (uint32_t p = 0; p < n_planes; ++p)
+                wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const uint32_t *col = M + (uint64_t)blk * BLOCK_WORDS + lane;
+        uint32_t cnt[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) cnt[k] = 0;
+        uint32_t ok = 0;
+        for (uint32_t jb = 0; jb < G; jb += GROW_PREFETCH) {
+            uint32_t x[GROW_PREFETCH];
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                x[u] = 0;
+                if (jb + u < G) x[u] = col[(uint64_t)perm[jb + u] * row_words];
+            }
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                if (jb + u < G) {  // wave-uniform
+                    const uint32_t thr = qtab_t[jb + u];  // wave-uniform (scalar)
+                    // cnt += x  (ripple-carry over the planes)
+                    uint32_t carry = x[u];
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) {
+                        const uint32_t tmp = cnt[k] & carry;
+                        cnt[k] ^= carry;
+                        carry = tmp;
+                    }
+                    // ge = (cnt >= thr), most significant plane first; thr is uniform
+                    uint32_t gt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = NPL - 1; k >= 0; --k) {
+                        const uint32_t tb = 0u - ((thr >> k) & 1u);  // all-ones if bit k of thr is set
+                        gt |= eq & cnt[k] & ~tb;
+                        eq &= ~(cnt[k] ^ tb);
+                    }
+                    const uint32_t ge = gt | eq;
+                    ok = (ok & ~x[u]) | (ge & x[u]);
+                    const uint32_t bits = ok & mask;
+                    if (WEIGHTED) {
+                        unsigned long long s = weighted_popc(bits, wp, n_planes, lane);
+                        uint32_t lo = wave_sum_to_lane63((uint32_t)(s & 0xFFFFFFu));         // 24 + 6 bits
+                        uint32_t mi = wave_sum_to_lane63((uint32_t)((s >> 24) & 0xFFFFFFu));
+                        if (lane == 63) atomicAdd(&acc[jb + u], (unsigned long long)lo + ((unsigned long long)mi << 24));
+                    } else {
+                        const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(bits));
+                        if (lane == 63 && tot) atomicAdd(&acc[jb + u], (unsigned long long)tot);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < G; j += blockDim.x) {
+        const unsigned long long v = acc[j];
+        if (v) atomicAdd(&out[((uint64_t)r * T + t_slot) * G + j], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+int launch_growth(pnx_ctx *ctx, bool identity_perm) {
+    const uint32_t G = ctx->n_groups, R = ctx->g_R, T = ctx->g_T, NB = ctx->n_blocks;
+    int rc;
+    const size_t out_n = (size_t)R * T * G;
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_growth_out.p, 0, (out_n ? out_n : 1) * sizeof(uint64_t), ctx->stream));
+    if (G == 0 || NB == 0) return PNX_OK;
+
+    // host copies of the thresholds: cov_thr[T] then is_q0[T]
+    const std::vector<uint32_t> &meta = ctx->h_thr_meta;
+    if (meta.size() != 2 * (size_t)T) return ctx->fail(PNX_EINVAL, "internal: threshold table missing");
+    if (identity_perm) {
+        std::vector<uint32_t> id(G);
+        for (uint32_t j = 0; j < G; ++j) id[j] = j;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_perms.p, id.data(), (size_t)G * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+
+    // distinct coverage thresholds >= 2 need a mask; c <= 1 is implied by presence
+    std::vector<uint32_t> cvals;
+    std::vector<int32_t> mask_of(T, -1);
+    for (uint32_t t = 0; t < T; ++t) {
+        if (meta[t] <= 1) continue;
+        size_t k = 0;
+        while (k < cvals.size() && cvals[k] != meta[t]) ++k;
+        if (k == cvals.size()) cvals.push_back(meta[t]);
+        mask_of[t] = (int32_t)k;
+    }
+    prof_begin(ctx, PNX_K_MASK);
+    // layout of d_cmask: [n_c masks][NB][64] u32, then scratch words for cvals / pair tables
+    const size_t mask_words = cvals.size() * (size_t)NB * BLOCK_WORDS;
+    // aux: [0..31] cvals, [32] max weight, [64..64+T) delta flags, then 8 words per q0 launch
+    if (cvals.size() > 32) return ctx->fail(PNX_ELIMIT, "at most 32 distinct coverage thresholds >= 2 per call");
+    const size_t aux_words = 64 + (size_t)T + 8 * (((size_t)T + GROW_Q0_MAX - 1) / GROW_Q0_MAX);
+    if ((rc = ensure(ctx, ctx->d_cmask, (mask_words + aux_words) * sizeof(uint32_t)))) return rc;
+    uint32_t *d_aux = (uint32_t *)ctx->d_cmask.p + mask_words;
+    if (!cvals.empty()) {
+        PNX_HIP(ctx, hipMemcpyAsync(d_aux, cvals.data(), cvals.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_cov_masks, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_countable.p, ctx->n_items, NB, (const uint32_t *)d_aux,
+                           (uint32_t)cvals.size(), (uint32_t *)ctx->d_cmask.p);
+    }
+    if (ctx->weighted && !ctx->wplanes_valid) {
+        uint32_t *d_max = d_aux + 32;
+        PNX_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_max_u32, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_weights.p,
+                           (uint64_t)1, (uint64_t)ctx->n_items + 1, d_max);
+        uint32_t mx = 0;
+        PNX_HIP(ctx, hipMemcpyAsync(&mx, d_max, sizeof mx, hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t planes = 0;
+        while (planes < 32 && (mx >> planes) != 0) ++planes;
+        if (planes == 0) planes = 1;
+        ctx->n_wplanes = planes;
+        if ((rc = ensure(ctx, ctx->d_wplanes, (size_t)planes * NB * BLOCK_WORDS * sizeof(uint32_t)))) return rc;
+        hipLaunchKernelGGL(k_weight_planes, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_weights.p, ctx->n_items, NB, planes, (uint32_t *)ctx->d_wplanes.p);
+        ctx->wplanes_valid = true;
+    }
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+
+    // geometry: ~4096 workgroups in total, each walking a chunk of blocks for one order
+    uint32_t n_chunks = 4096 / R;
+    if (n_chunks < 1) n_chunks = 1;
+    uint32_t max_chunks = (NB + GROW_WAVES - 1) / GROW_WAVES;
+    if (n_chunks > max_chunks) n_chunks = max_chunks;
+    const uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
+    n_chunks = (NB + bpc - 1) / bpc;
+    const uint64_t row_words = (uint64_t)NB * BLOCK_WORDS;
+    const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;
+    const uint32_t *d_wpl = ctx->weighted ? (const uint32_t *)ctx->d_wplanes.p : nullptr;
+    const uint32_t n_planes = ctx->weighted ? ctx->n_wplanes : 0;
+
+    // delta flags per threshold slot, for the finishing prefix kernel
+    std::vector<uint32_t> is_delta(T, 0);
+    prof_begin(ctx, PNX_K_GROWTH);
+    {   // q == 0 pairs, GROW_Q0_MAX per launch
+        std::vector<uint32_t> q0;
+        for (uint32_t t = 0; t < T; ++t)
+            if (meta[T + t]) q0.push_back(t);
+        for (size_t base = 0; base < q0.size(); base += GROW_Q0_MAX) {
+            const uint32_t n = (uint32_t)std::min<size_t>(GROW_Q0_MAX, q0.size() - base);
+            if ((size_t)n * G * 8 + wp_bytes > 64 * 1024)
+                return ctx->fail(PNX_ELIMIT, "ordered growth supports at most %u groups per launch (got %u)",
+                                 (unsigned)((64 * 1024 - wp_bytes) / (8 * n)), G);
+            int32_t h_midx[GROW_Q0_MAX];
+            uint32_t h_slot[GROW_Q0_MAX];
+            for (uint32_t k = 0; k < GROW_Q0_MAX; ++k) {
+                h_midx[k] = k < n ? mask_of[q0[base + k]] : -1;
+                h_slot[k] = k < n ? q0[base + k] : 0;
+                if (k < n) is_delta[q0[base + k]] = 1;
+            }
+            // small per-launch tables live behind the masks: [midx x4][slot x4] per launch
+            uint32_t *d_tab = d_aux + 64 + T + 8 * (uint32_t)(base / GROW_Q0_MAX);
+            PNX_HIP(ctx, hipMemcpyAsync(d_tab, h_midx, sizeof h_midx, hipMemcpyHostToDevice, ctx->stream));
+            PNX_HIP(ctx, hipMemcpyAsync(d_tab + 4, h_slot, sizeof h_slot, hipMemcpyHostToDevice, ctx->stream));
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_* are stack arrays
+            const size_t shmem = (size_t)n * G * 8 + wp_bytes;
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
+                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p,
+                                   n_chunks, bpc, (const uint32_t *)ctx->d_cmask.p, (const int32_t *)d_tab,
+                                   (const uint32_t *)(d_tab + 4), n, T, d_wpl, n_planes,
+                                   (unsigned long long *)ctx->d_growth_out.p);
+            };
+            if (ctx->weighted) go(k_growth_q0<true>); else go(k_growth_q0<false>);
+        }
+    }
+    {   // q > 0 pairs, one launch each
+        uint32_t bits = 1;
+        while (bits < 32 && (G >> bits) != 0) ++bits;
+        for (uint32_t t = 0; t < T; ++t) {
+            if (meta[T + t]) continue;
+            if ((size_t)G * 8 + wp_bytes > 64 * 1024)
+                return ctx->fail(PNX_ELIMIT, "ordered growth supports at most %u groups (got %u)",
+                                 (unsigned)((64 * 1024 - wp_bytes) / 8), G);
+            const uint32_t *d_mask_t = mask_of[t] >= 0 ? (const uint32_t *)ctx->d_cmask.p + (size_t)mask_of[t] * NB * BLOCK_WORDS : nullptr;
+            const uint32_t *d_q = (const uint32_t *)ctx->d_qtab.p + (size_t)t * G;
+            const size_t shmem = (size_t)G * 8 + wp_bytes;
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
+                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p,
+                                   n_chunks, bpc, d_mask_t, d_q, t, T, d_wpl, n_planes,
+                                   (unsigned long long *)ctx->d_growth_out.p);
+            };
+            if (ctx->weighted) {
+                if (bits <= 8) go(k_growth_quorum<8, true>);
+                else if (bits <= 12) go(k_growth_quorum<12, true>);
+                else go(k_growth_quorum<16, true>);
+            } else {
+                if (bits <= 8) go(k_growth_quorum<8, false>);
+                else if (bits <= 12) go(k_growth_quorum<12, false>);
+                else go(k_growth_quorum<16, false>);
+            }
+        }
+    }
+    {   // deltas -> running sums
+        uint32_t *d_isd = d_aux + 64;
+        PNX_HIP(ctx, hipMemcpyAsync(d_isd, is_delta.data(), (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(k_growth_prefix, dim3(R * T), dim3(64), 0, ctx->stream,
+                           (unsigned long long *)ctx->d_growth_out.p, G, T, (const uint32_t *)d_isd);
+    }
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+}  // namespace pnx

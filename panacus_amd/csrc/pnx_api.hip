@@ -1,0 +1,479 @@
+// pnx_api.hip -- extern "C" entry points of libpanacus_hip.so (see include/panacus_amd.h).
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "pnx_context.hpp"
+
+static std::string g_init_err;
+
+namespace pnx {
+
+int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (b.cap >= bytes) return PNX_OK;
+    if (b.p) {
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes + 256);  // +256: vector loads may over-read a tail
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return ctx->fail(PNX_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    b.cap = bytes;
+    return PNX_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static hipEvent_t prof_event(pnx_ctx *ctx) {
+    if (!ctx->prof.pool.empty()) {
+        hipEvent_t e = ctx->prof.pool.back();
+        ctx->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(pnx_ctx *ctx, int slot) {
+    if (!ctx->prof.on) return;
+    Profile::Pending pd{prof_event(ctx), prof_event(ctx), slot};
+    (void)hipEventRecord(pd.a, ctx->stream);
+    ctx->prof.pending.push_back(pd);
+}
+
+void prof_end(pnx_ctx *ctx) {
+    if (!ctx->prof.on || ctx->prof.pending.empty()) return;
+    (void)hipEventRecord(ctx->prof.pending.back().b, ctx->stream);
+}
+
+int prof_resolve(pnx_ctx *ctx) {
+    for (auto &pd : ctx->prof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pd.b) == hipSuccess && hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
+            ctx->prof.ms[pd.slot] += ms;
+            ctx->prof.launches[pd.slot] += 1;
+        }
+        ctx->prof.pool.push_back(pd.a);
+        ctx->prof.pool.push_back(pd.b);
+    }
+    ctx->prof.pending.clear();
+    return PNX_OK;
+}
+
+static void invalidate_results(pnx_ctx *ctx) {
+    ctx->hist_pending = false;
+    ctx->hist_valid = false;
+    ctx->M_valid = false;
+    ctx->growth_pending = false;
+}
+
+static void set_geometry(pnx_ctx *ctx) {
+    ctx->n_blocks = (uint32_t)(((uint64_t)ctx->n_items + 1 + BLOCK_ITEMS - 1) / BLOCK_ITEMS);
+    ctx->n_tiles = (ctx->n_blocks + ctx->tile_blocks - 1) / ctx->tile_blocks;
+    ctx->index_valid = false;
+    ctx->wplanes_valid = false;
+    ctx->last_general_paths = 0;
+}
+
+// run passes until one verifies (no tile-monotonicity violation, no unserved general path)
+static int settle_hist(pnx_ctx *ctx) {
+    if (!ctx->hist_pending) return PNX_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        uint32_t flags[8];
+        PNX_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        prof_resolve(ctx);
+        const bool used_m = ctx->want_M || ctx->last_general_paths > 0;
+        const bool bad = flags[0] != 0 || (flags[1] != 0 && !used_m);
+        if (!bad) {
+            ctx->last_general_paths = flags[1];
+            ctx->hist_pending = false;
+            ctx->hist_valid = true;
+            ctx->M_valid = ctx->want_M;
+            return PNX_OK;
+        }
+        ctx->last_general_paths = flags[1] + flags[0];  // > 0: next pass allocates and merges M
+        int rc = launch_cover_pass(ctx);
+        if (rc) return rc;
+    }
+    return ctx->fail(PNX_EHIP, "coverage pass did not converge (internal error)");
+}
+
+}  // namespace pnx
+
+using namespace pnx;
+
+extern "C" {
+
+const char *pnx_version(void) { return "panacus_amd 0.1.0 (gfx950)"; }
+
+const char *pnx_last_error(const pnx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+int pnx_init(pnx_ctx **out, int device) {
+    if (!out) return PNX_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_init_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                     " -- panacus_amd has no CPU fallback";
+        return PNX_ENODEV;
+    }
+    if (device < 0 || device >= n) {
+        g_init_err = "device ordinal out of range";
+        return PNX_EINVAL;
+    }
+    pnx_ctx *ctx = new (std::nothrow) pnx_ctx();
+    if (!ctx) return PNX_ENOMEM;
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_init_err = std::string("device initialisation failed: ") + hipGetErrorString(e);
+        delete ctx;
+        return PNX_EHIP;
+    }
+    *out = ctx;
+    return PNX_OK;
+}
+
+void pnx_free(pnx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
+    for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
+    for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_path_class, &ctx->d_grp_general, &ctx->d_flags,
+                      &ctx->d_countable, &ctx->d_hist, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
+                      &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta})
+        release(*b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                uint32_t n_items, const uint32_t *weights, const uint8_t *exclude) {
+    if (!ctx) return PNX_EINVAL;
+    if (!path_off) return ctx->fail(PNX_EINVAL, "path_off is NULL");
+    if (n_items >= 0xFFFFFFFEu || n_paths >= 0xFFFFFFFEu)
+        return ctx->fail(PNX_ELIMIT, "n_items and n_paths must be < 2^32-2");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    if (path_off[0] != 0) return ctx->fail(PNX_EINVAL, "path_off[0] must be 0");
+    for (uint32_t p = 0; p < n_paths; ++p)
+        if (path_off[p + 1] < path_off[p]) return ctx->fail(PNX_EINVAL, "path_off is not non-decreasing at path %u", p);
+    const uint64_t S = path_off[n_paths];
+    if (S && !items) return ctx->fail(PNX_EINVAL, "items is NULL");
+    invalidate_results(ctx);
+    ctx->have_csr = false;
+    ctx->have_order = false;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t)))) return rc;
+    if (S) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_items.p, items, S * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, path_off, ((size_t)n_paths + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_path_off.assign(path_off, path_off + n_paths + 1);
+    ctx->weighted = weights != nullptr;
+    if (weights) {
+        if ((rc = ensure(ctx, ctx->d_weights, ((size_t)n_items + 1) * sizeof(uint32_t)))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_weights.p, weights, ((size_t)n_items + 1) * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->have_exclude = exclude != nullptr;
+    if (exclude) {
+        if ((rc = ensure(ctx, ctx->d_exclude, (size_t)n_items + 1))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, exclude, (size_t)n_items + 1, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->n_items = n_items;
+    ctx->n_paths = n_paths;
+    ctx->n_steps = S;
+    set_geometry(ctx);
+
+    // every step id must be a valid item (the reference panics on unknown nodes, util.rs:1021)
+    if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+    if ((rc = launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
+    uint32_t bad = 0;
+    PNX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_flags.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+    ctx->have_csr = true;
+    return PNX_OK;
+}
+
+int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
+    if (!ctx) return PNX_EINVAL;
+    if (n_nodes == 0 || n_paths == 0) return ctx->fail(PNX_EINVAL, "n_nodes and n_paths must be > 0");
+    if (n_nodes >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes must be < 2^32-2");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    invalidate_results(ctx);
+    ctx->have_csr = false;
+    ctx->have_order = false;
+    int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights);
+    if (rc) return rc;
+    ctx->have_exclude = false;
+    set_geometry(ctx);
+    ctx->have_csr = true;
+    return PNX_OK;
+}
+
+int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path_off, uint32_t *weights) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "no graph is resident");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_steps) *n_steps = ctx->n_steps;
+    if (items && ctx->n_steps)
+        PNX_HIP(ctx, hipMemcpyAsync(items, ctx->d_items.p, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (path_off) std::copy(ctx->h_path_off.begin(), ctx->h_path_off.end(), path_off);
+    if (weights) {
+        if (!ctx->weighted) return ctx->fail(PNX_EINVAL, "no weights are resident");
+        PNX_HIP(ctx, hipMemcpyAsync(weights, ctx->d_weights.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PNX_OK;
+}
+
+int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_id, uint32_t n_ordered,
+                  uint32_t n_groups) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_set_order before pnx_set_csr");
+    if (n_ordered && (!path_idx || !group_id)) return ctx->fail(PNX_EINVAL, "NULL order arrays");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    uint32_t expect = 0;
+    for (uint32_t k = 0; k < n_ordered; ++k) {
+        if (path_idx[k] >= ctx->n_paths) return ctx->fail(PNX_EINVAL, "path_idx[%u] = %u out of range", k, path_idx[k]);
+        if (k == 0 ? group_id[0] != 0 : (group_id[k] != group_id[k - 1] && group_id[k] != group_id[k - 1] + 1))
+            return ctx->fail(PNX_EINVAL, "group_id must start at 0 and be non-decreasing and dense (entry %u)", k);
+        expect = group_id[k] + 1;
+    }
+    if (expect != n_groups) return ctx->fail(PNX_EINVAL, "n_groups = %u but the order holds %u groups", n_groups, expect);
+    invalidate_results(ctx);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_ord_path, (size_t)n_ordered * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ord_group, (size_t)n_ordered * sizeof(uint32_t)))) return rc;
+    if (n_ordered) {
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_path.p, path_idx, (size_t)n_ordered * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_group.p, group_id, (size_t)n_ordered * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned
+    }
+    ctx->n_ordered = n_ordered;
+    ctx->n_groups = n_groups;
+    ctx->have_order = true;
+    return PNX_OK;
+}
+
+int pnx_hist_async(pnx_ctx *ctx) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "pnx_hist needs pnx_set_csr and pnx_set_order first");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (!ctx->index_valid || !ctx->cache_index) {
+        if ((rc = launch_tile_index(ctx))) return rc;
+        ctx->index_valid = true;
+    }
+    ctx->hist_valid = false;
+    if ((rc = launch_cover_pass(ctx))) return rc;
+    ctx->hist_pending = true;
+    return PNX_OK;
+}
+
+int pnx_sync(pnx_ctx *ctx) {
+    if (!ctx) return PNX_EINVAL;
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = settle_hist(ctx);
+    if (rc) return rc;
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    ctx->growth_pending = false;
+    return PNX_OK;
+}
+
+int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    if (!ctx->hist_valid) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
+    if (d_hist) *d_hist = (uint64_t *)ctx->d_hist.p;
+    if (d_countable) *d_countable = (uint32_t *)ctx->d_countable.p;
+    return PNX_OK;
+}
+
+int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    if (!ctx->hist_valid) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
+    if (hist)
+        PNX_HIP(ctx, hipMemcpyAsync(hist, ctx->d_hist.p, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (countable)
+        PNX_HIP(ctx, hipMemcpyAsync(countable, ctx->d_countable.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PNX_OK;
+}
+
+int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
+    int rc = pnx_hist_async(ctx);
+    if (rc) return rc;
+    return pnx_hist_fetch(ctx, countable, hist);
+}
+
+void *pnx_stream(pnx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms, const uint32_t *cov_thr,
+                             const uint32_t *quorum_tab, uint32_t n_thr) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "pnx_ordered_growth needs pnx_set_csr and pnx_set_order first");
+    if (n_perms == 0 || n_thr == 0 || !cov_thr || !quorum_tab) return ctx->fail(PNX_EINVAL, "bad growth arguments");
+    if (!perms && n_perms != 1) return ctx->fail(PNX_EINVAL, "perms == NULL (identity) requires n_perms == 1");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t G = ctx->n_groups;
+    if (perms) {
+        std::vector<uint8_t> seen(G);
+        for (uint32_t r = 0; r < n_perms; ++r) {
+            std::fill(seen.begin(), seen.end(), 0);
+            for (uint32_t j = 0; j < G; ++j) {
+                uint32_t g = perms[(size_t)r * G + j];
+                if (g >= G || seen[g]) return ctx->fail(PNX_EINVAL, "perms[%u] is not a permutation of 0..%u", r, G ? G - 1 : 0);
+                seen[g] = 1;
+            }
+        }
+    }
+    int rc;
+    // the presence matrix must exist for the current order
+    if (!(ctx->hist_valid && ctx->M_valid)) {
+        ctx->want_M = true;
+        if ((rc = pnx_hist_async(ctx))) return rc;
+        if ((rc = settle_hist(ctx))) return rc;
+    }
+    const size_t RG = (size_t)n_perms * G, TG = (size_t)n_thr * G;
+    if ((rc = ensure(ctx, ctx->d_perms, (RG ? RG : 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_cov_thr, n_thr * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_qtab, (TG ? TG : 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_growth_out, (RG ? RG : 1) * n_thr * sizeof(uint64_t)))) return rc;
+    if (perms && RG)
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_perms.p, perms, RG * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_cov_thr.p, cov_thr, n_thr * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (TG) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_qtab.p, quorum_tab, TG * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned
+    ctx->g_R = n_perms;
+    ctx->g_T = n_thr;
+    // thresholds are needed on the host too (mask selection, q == 0 detection)
+    ctx->h_thr_meta.assign(cov_thr, cov_thr + n_thr);
+    for (uint32_t t = 0; t < n_thr; ++t) {
+        bool q0 = true;
+        for (uint32_t j = 0; j < G && q0; ++j) q0 = quorum_tab[(size_t)t * G + j] <= 1;
+        ctx->h_thr_meta.push_back(q0 ? 1u : 0u);
+    }
+    if ((rc = launch_growth(ctx, perms == nullptr))) return rc;
+    ctx->growth_pending = true;
+    return PNX_OK;
+}
+
+int pnx_ordered_growth_device(pnx_ctx *ctx, uint64_t **d_out) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    if (!ctx->g_R) return ctx->fail(PNX_EINVAL, "no growth has been computed");
+    if (d_out) *d_out = (uint64_t *)ctx->d_growth_out.p;
+    return PNX_OK;
+}
+
+int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    if (!ctx->g_R) return ctx->fail(PNX_EINVAL, "no growth has been computed");
+    const size_t n = (size_t)ctx->g_R * ctx->g_T * ctx->n_groups;
+    if (out && n) {
+        PNX_HIP(ctx, hipMemcpyAsync(out, ctx->d_growth_out.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PNX_OK;
+}
+
+int pnx_ordered_growth(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms, const uint32_t *cov_thr,
+                       const uint32_t *quorum_tab, uint32_t n_thr, uint64_t *out) {
+    int rc = pnx_ordered_growth_async(ctx, perms, n_perms, cov_thr, quorum_tab, n_thr);
+    if (rc) return rc;
+    return pnx_ordered_growth_fetch(ctx, out);
+}
+
+int pnx_profile_enable(pnx_ctx *ctx, int on) {
+    if (!ctx) return PNX_EINVAL;
+    ctx->prof.on = on != 0;
+    return PNX_OK;
+}
+
+int pnx_profile_read(pnx_ctx *ctx, double ms[PNX_K_COUNT], uint64_t launches[PNX_K_COUNT]) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < PNX_K_COUNT; ++i) {
+        if (ms) ms[i] = ctx->prof.ms[i];
+        if (launches) launches[i] = ctx->prof.launches[i];
+    }
+    return PNX_OK;
+}
+
+int pnx_profile_reset(pnx_ctx *ctx) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = pnx_sync(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < PNX_K_COUNT; ++i) {
+        ctx->prof.ms[i] = 0;
+        ctx->prof.launches[i] = 0;
+    }
+    return PNX_OK;
+}
+
+int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
+    if (!ctx || !out) return PNX_EINVAL;
+    out->n_steps = ctx->n_steps;
+    out->n_items = ctx->n_items;
+    out->n_paths = ctx->n_paths;
+    out->n_ordered = ctx->n_ordered;
+    out->n_groups = ctx->n_groups;
+    out->n_tiles = ctx->n_tiles;
+    out->tile_items = ctx->tile_blocks * BLOCK_ITEMS;
+    out->n_general_paths = ctx->last_general_paths;
+    out->weighted = ctx->weighted ? 1 : 0;
+    return PNX_OK;
+}
+
+int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
+    if (!ctx) return PNX_EINVAL;
+    switch (key) {
+        case PNX_CFG_CACHE_INDEX:
+            ctx->cache_index = value != 0;
+            return PNX_OK;
+        case PNX_CFG_TILE_BLOCKS:
+            if (value != 1 && value != 2) return ctx->fail(PNX_EINVAL, "tile_blocks must be 1 or 2");
+            ctx->tile_blocks = (uint32_t)value;
+            if (ctx->have_csr) {
+                invalidate_results(ctx);
+                uint32_t keep = ctx->last_general_paths;
+                set_geometry(ctx);
+                ctx->last_general_paths = keep;
+            }
+            return PNX_OK;
+        case PNX_CFG_KEEP_PRESENCE:
+            ctx->want_M = value != 0;
+            if (!ctx->want_M) ctx->M_valid = false;
+            return PNX_OK;
+        default:
+            return ctx->fail(PNX_EINVAL, "unknown config key %d", key);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// pnx_context.hpp -- device context of the MI355X hist/growth engine (internal).
+//
+// One pnx_ctx owns one HIP device, one stream, the resident graph (CSR of path steps in
+// HBM), the visiting order, and the result buffers.  See include/panacus_amd.h for the ABI
+// and DESIGN.md for the data layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/panacus_amd.h"
+
+namespace pnx {
+
+// ---- geometry of the presence bit matrix ------------------------------------------------
+// A "block" is 2048 consecutive item ids held as 64 u32 words, one per lane of a wave:
+// item n  ->  block n / 2048, word (lane) n % 64, bit (n % 2048) / 64.
+// Lane-interleaving makes both the coverage write-out (one coalesced 256 B store per bit)
+// and the per-rank row reads of the growth kernel (256 B per wave) fully coalesced, and
+// makes consecutive (sorted) step ids hit consecutive LDS banks.
+constexpr uint32_t BLOCK_ITEMS = 2048;
+constexpr uint32_t BLOCK_WORDS = 64;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Profile {
+    bool on = false;
+    double ms[PNX_K_COUNT] = {0};
+    uint64_t launches[PNX_K_COUNT] = {0};
+    // pending (start, stop, slot) event triples, resolved at the next sync
+    struct Pending {
+        hipEvent_t a, b;
+        int slot;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace pnx
+
+struct pnx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipDeviceProp_t prop;
+
+    // ---- resident graph (a1: ItemTable) ----
+    uint32_t n_items = 0, n_paths = 0;
+    uint64_t n_steps = 0;
+    bool have_csr = false, weighted = false, have_exclude = false;
+    pnx::DevBuf d_items, d_path_off, d_weights, d_exclude;
+    std::vector<uint64_t> h_path_off;
+
+    // ---- visiting order (a2) ----
+    uint32_t n_ordered = 0, n_groups = 0;
+    bool have_order = false;
+    pnx::DevBuf d_ord_path, d_ord_group;
+
+    // ---- tile index over the CSR (K0) ----
+    uint32_t tile_blocks = 1;  // blocks per coverage tile (WT)
+    uint32_t n_blocks = 0, n_tiles = 0;
+    bool index_valid = false;
+    bool cache_index = true;
+    pnx::DevBuf d_tile_idx;    // n_paths * (n_tiles + 1) u64
+    pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
+    pnx::DevBuf d_grp_general; // n_groups u8
+    pnx::DevBuf d_flags;       // u32[8]: [0] violations in the last cover pass, [1] #general paths
+    uint32_t last_general_paths = 0;
+
+    // ---- results ----
+    pnx::DevBuf d_countable;  // n_items + 1 u32
+    pnx::DevBuf d_hist;       // n_groups + 1 u64
+    pnx::DevBuf d_M;          // n_groups * n_blocks * 64 u32 presence matrix
+    bool hist_pending = false;  // a pass is enqueued and not yet verified
+    bool hist_valid = false;
+    bool M_valid = false;
+    bool want_M = false;
+
+    // ---- growth ----
+    pnx::DevBuf d_perms, d_cov_thr, d_qtab, d_cmask, d_wplanes, d_growth_out, d_thr_meta;
+    uint32_t g_R = 0, g_T = 0;
+    std::vector<uint32_t> h_thr_meta;  // cov_thr[T] then is_q0[T]
+    uint32_t n_wplanes = 0;
+    bool wplanes_valid = false;
+    bool growth_pending = false;
+
+    pnx::Profile prof;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[768];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define PNX_HIP(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? PNX_ENOMEM : PNX_EHIP,           \
+                               "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                               __FILE__, __LINE__);                                         \
+    } while (0)
+
+namespace pnx {
+
+int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes);
+void release(DevBuf &b);
+
+// profiling brackets around a kernel launch on ctx->stream
+void prof_begin(pnx_ctx *ctx, int slot);
+void prof_end(pnx_ctx *ctx);
+int prof_resolve(pnx_ctx *ctx);
+
+// kernels_cover.hip
+int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
+int launch_tile_index(pnx_ctx *ctx);
+int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
+// kernels_growth.hip
+int launch_growth(pnx_ctx *ctx, bool identity_perm);
+// pansyn.hip
+int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
+                           int with_weights);
+
+}  // namespace pnx

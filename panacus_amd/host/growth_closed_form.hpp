@@ -1,0 +1,34 @@
+// growth_closed_form.hpp -- exact expected pangenome growth from a coverage histogram.
+//
+// Host-side mirror of Hist::calc_growth and its three branches
+// (src/graph_broker/hist.rs:51-187 of the reference).  The values are f64 and the
+// reference prints floor() of them, so the arithmetic here keeps the reference's operation
+// order and uses the platform libm (glibc log2/exp2) exactly like Rust's f64::log2/exp2 on
+// linux-gnu: results are bit-identical.  Work that does not affect rounding is shared
+// (log2 of small integers is tabulated; the O(n^3) quorum branch is spread over threads
+// along the independent histogram index i and summed in the reference's order).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace pnh {
+
+enum ThresholdKind { THR_ABSOLUTE = 0, THR_RELATIVE = 1 };
+struct Threshold {
+    int kind;
+    double value;
+    uint64_t to_absolute(uint64_t n) const;  // src/util.rs:350-355
+    double to_relative(uint64_t n) const;    // src/util.rs:357-362
+};
+
+double choose_log2(uint64_t n, uint64_t k);  // hist.rs:21-36
+
+// n = hist.size() - 1 values (the caller prepends the NaN row, hist.rs:83-85)
+std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
+                                unsigned n_threads = 0);
+std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage);
+std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage);
+std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
+                                       unsigned n_threads = 0);
+
+}  // namespace pnh

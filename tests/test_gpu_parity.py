@@ -1,0 +1,343 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Integer work -> bit-exact equality everywhere."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from panacus_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _load_gfa(ctx, gfa, count, group_mode=orc.GROUP_PATHID, exclude=None):
+    g = orc.Graph(gfa, index_edges=(count == orc.EDGE))
+    pi, gi, names = g.path_order(group_mode)
+    items, pre = g.item_table(count)
+    n = g.n_items(count)
+    w = g.node_lens if count == orc.BP else None
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=exclude)
+    ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), len(names))
+    return g, pi, gi, names, items, pre, n, w
+
+
+# ---------------------------------------------------------------------------------------------
+# reference golden vectors through the HIP path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("count,key", [(orc.NODE, "chrM_sample_node"), (orc.EDGE, "chrM_sample_edge"),
+                                       (orc.BP, "chrM_sample_bp")])
+def test_chrM_golden(ctx, golden, golden_dir, count, key):
+    # src/graph_broker/abacus.rs:1487-1630
+    _load_gfa(ctx, os.path.join(golden_dir, "chrM_test.gfa"), count, orc.GROUP_SAMPLE)
+    cnt, h = ctx.hist()
+    assert cnt.tolist() == golden[key]["countable"]
+    assert h.tolist() == golden[key]["hist"]
+
+
+def test_cdbg_golden(ctx, golden, golden_dir):
+    # src/graph_broker/abacus.rs:1424-1435
+    _load_gfa(ctx, os.path.join(golden_dir, "cdbg.gfa"), orc.NODE)
+    cnt, h = ctx.hist()
+    assert cnt.tolist() == golden["cdbg_node"]["countable"]
+
+
+def test_t_groups_golden(ctx, golden, golden_dir):
+    # tests/test_files/t_groups.hist.tsv
+    _load_gfa(ctx, os.path.join(golden_dir, "t_groups.gfa"), orc.NODE)
+    cnt, h = ctx.hist()
+    assert h.tolist() == golden["t_groups_node_hist"]["hist"]
+
+
+def test_ordered_growth_fixture_values(ctx, golden_dir):
+    """Same expectations as tests/test_oracle_golden.py::test_ordered_growth_survey_values."""
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    g, pi, gi, names, items, pre, n, w = _load_gfa(ctx, os.path.join(golden_dir, "t_groups.gfa"), orc.NODE)
+    G = len(names)
+    cov = [coverage_abs(Threshold(ABSOLUTE, 1), G)] * 2
+    qt = np.stack([quorum_table(Threshold(RELATIVE, 0.0), G), quorum_table(Threshold(RELATIVE, 0.5), G)])
+    out = ctx.ordered_growth(cov, qt)
+    assert out[0, 0].tolist() == [2, 5, 8, 9, 10, 10]
+    assert out[0, 1].tolist() == [2, 5, 5, 5, 5, 0]
+    _load_gfa(ctx, os.path.join(golden_dir, "t_groups.gfa"), orc.BP)
+    out = ctx.ordered_growth(cov[:1], qt[:1])
+    assert out[0, 0].tolist() == [9, 14, 38, 39, 50, 50]
+
+    _load_gfa(ctx, os.path.join(golden_dir, "chrM_test.gfa"), orc.NODE, orc.GROUP_SAMPLE)
+    cov = [1, 2, 1]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), 4) for q in (0.0, 0.0, 0.5)])
+    out = ctx.ordered_growth(cov, qt)
+    assert out[0, 0].tolist() == [89, 106, 140, 154]
+    assert out[0, 1].tolist() == [87, 101, 115, 115]
+    assert out[0, 2].tolist() == [89, 106, 106, 120]
+    _load_gfa(ctx, os.path.join(golden_dir, "chrM_test.gfa"), orc.BP, orc.GROUP_SAMPLE)
+    out = ctx.ordered_growth([1], qt[:1])
+    assert out[0, 0].tolist() == [16569, 17147, 17183, 17197]
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic generator: device CSR == CPU CSR
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p", [(1, 1), (777, 5), (2048, 16), (2049, 17), (50_000, 33)])
+def test_pansyn_device_equals_cpu(ctx, n, p):
+    items, pre, lens = orc.pansyn(42, n, p)
+    ctx.set_csr_pansyn(42, n, p, with_weights=True)
+    d_items, d_off, d_w = ctx.get_csr(want_weights=True)
+    assert d_off.tolist() == pre.tolist()
+    assert np.array_equal(d_items, items.astype(np.uint32))
+    assert np.array_equal(d_w[1:], lens[1:])
+
+
+# ---------------------------------------------------------------------------------------------
+# hist parity on synthetic graphs (monotone fast path), several shapes / groupings
+# ---------------------------------------------------------------------------------------------
+def _oracle_hist(items, pre, pi, gi, n, G, w=None, exclude=None):
+    cov = orc.coverage(items, pre, pi, gi, n, exclude)
+    return cov, orc.hist(cov, G, w)
+
+
+@pytest.mark.parametrize("n,p,tile_blocks", [(5_000, 7, 1), (70_000, 32, 1), (70_000, 32, 2), (300_000, 64, 1)])
+def test_hist_pansyn_vs_oracle(ctx, n, p, tile_blocks):
+    from panacus_amd import capi
+    items, pre, lens = orc.pansyn(42, n, p)
+    ctx.config(capi.CFG_TILE_BLOCKS, tile_blocks)
+    try:
+        ctx.set_csr_pansyn(42, n, p, with_weights=False)
+        # group = path
+        pi = np.arange(p, dtype=np.uint64)
+        ctx.set_order(pi, pi, p)
+        cnt, h = ctx.hist()
+        ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+        assert np.array_equal(cnt, ocov)
+        assert np.array_equal(h, oh)
+        assert ctx.info().n_general_paths == 0  # all paths took the tile route
+        # group = sample (pairs of paths), reversed visiting order of the groups
+        G = (p + 1) // 2
+        order = np.arange(p, dtype=np.uint64)[::-1].copy()
+        gid = np.repeat(np.arange(G, dtype=np.uint64), 2)[:p] if p % 2 == 0 else None
+        if gid is not None:
+            ctx.set_order(order, gid, G)
+            cnt, h = ctx.hist()
+            ocov, oh = _oracle_hist(items, pre, order, gid, n, G)
+            assert np.array_equal(cnt, ocov)
+            assert np.array_equal(h, oh)
+    finally:
+        ctx.config(capi.CFG_TILE_BLOCKS, 1)
+
+
+def test_hist_bp_and_exclude(ctx):
+    n, p = 40_000, 12
+    items, pre, lens = orc.pansyn(7, n, p)
+    rng = np.random.default_rng(1)
+    excl = (rng.random(n + 1) < 0.1).astype(np.uint8)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens, exclude=excl)
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p, lens, excl)
+    assert np.array_equal(cnt, ocov)
+    assert np.array_equal(h, oh)
+    assert int(h.sum()) == int(lens[1:].sum())
+
+
+def test_hist_subset_order_and_empty(ctx):
+    n, p = 10_000, 9
+    items, pre, lens = orc.pansyn(3, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    # only some paths are visited (excluded / subset paths are simply absent from the order)
+    pi = np.array([4, 0, 7], dtype=np.uint64)
+    gi = np.array([0, 1, 2], dtype=np.uint64)
+    ctx.set_order(pi, gi, 3)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, gi, n, 3)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    # empty order: every item has coverage 0
+    ctx.set_order(np.zeros(0, np.uint32), np.zeros(0, np.uint32), 0)
+    cnt, h = ctx.hist()
+    assert cnt[0] == 0xFFFFFFFF and not cnt[1:].any()
+    assert h.tolist() == [n]
+
+
+def test_hist_ragged_and_empty_paths(ctx):
+    # empty paths, a single-step path, repeated steps, ids at tile borders
+    n = 5000
+    paths = [[], [1], [2047, 2048, 2049, 2048], [n, n, n], list(range(1, n + 1)), [], [4096, 1, 4095]]
+    items = np.array([x for p in paths for x in p], dtype=np.uint64)
+    pre = np.cumsum([0] + [len(p) for p in paths]).astype(np.uint64)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(len(paths), dtype=np.uint64)
+    ctx.set_order(pi, pi, len(paths))
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, len(paths))
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+
+
+def test_hist_unsorted_paths_take_scatter_route(ctx):
+    n, p = 30_000, 10
+    items, pre, lens = orc.pansyn(11, n, p)
+    rng = np.random.default_rng(5)
+    items = items.copy()
+    for k in (1, 4, 8):  # shuffle three paths completely
+        seg = items[pre[k]:pre[k + 1]]
+        rng.shuffle(seg)
+    # one path that looks monotone at its ends and on most boundaries but has a late outlier
+    seg = items[pre[2]:pre[2 + 1]]
+    seg[len(seg) // 2] = seg[3]
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(p, dtype=np.uint64)
+    gi = (pi // 2).astype(np.uint64)
+    ctx.set_order(pi, gi, 5)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, gi, n, 5)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    assert ctx.info().n_general_paths >= 3
+    # second call (classification cached) gives the same answer
+    cnt2, h2 = ctx.hist()
+    assert np.array_equal(cnt2, ocov) and np.array_equal(h2, oh)
+
+
+def test_hist_many_groups_uses_wide_counters(ctx):
+    # > 255 groups -> 12-plane counters; items present in every group reach count G
+    n, p = 3000, 300
+    items, pre, lens = orc.pansyn(5, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    assert cnt[1:].max() == p
+
+
+def test_rejects_bad_input(ctx):
+    from panacus_amd.capi import PnxError
+    with pytest.raises(PnxError):
+        ctx.set_csr(np.array([1, 2, 9], np.uint32), np.array([0, 3], np.uint64), 5)  # id 9 > n_items
+    with pytest.raises(PnxError):
+        ctx.set_csr(np.array([0], np.uint32), np.array([0, 1], np.uint64), 5)  # id 0 is reserved
+    ctx.set_csr(np.array([1, 2], np.uint32), np.array([0, 2], np.uint64), 5)
+    with pytest.raises(PnxError):
+        ctx.set_order(np.array([0, 0], np.uint32), np.array([0, 2], np.uint32), 3)  # gap in group ids
+    with pytest.raises(PnxError):
+        ctx.set_order(np.array([3], np.uint32), np.array([0], np.uint32), 1)  # path index out of range
+
+
+# ---------------------------------------------------------------------------------------------
+# ordered / permuted growth parity
+# ---------------------------------------------------------------------------------------------
+def _oracle_growth(items, pre, n, G, path_groups, perm, cov_thr, q, w=None):
+    """ordered growth for the group order `perm` (rank -> group id): relabel and rerun the oracle"""
+    rank_of = np.empty(G, dtype=np.uint64)
+    rank_of[perm] = np.arange(G, dtype=np.uint64)
+    # visiting order: groups by rank, paths of a group contiguous
+    pi, gi = [], []
+    for rank, g in enumerate(perm):
+        for p in np.nonzero(path_groups == g)[0]:
+            pi.append(p)
+            gi.append(rank)
+    r, c = orc.by_group(items, pre, np.array(pi, np.uint64), np.array(gi, np.uint64), n)
+    return orc.ordered_growth(r, c, G, (orc.ABSOLUTE, cov_thr), (orc.RELATIVE, q), w)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ordered_growth_vs_oracle(ctx, weighted):
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 20_000, 24
+    items, pre, lens = orc.pansyn(9, n, p)
+    w = lens if weighted else None
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w)
+    path_groups = (np.arange(p) // 2).astype(np.uint64)  # 12 groups of 2 paths
+    G = 12
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, path_groups, G)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5), (3, 0.3), (1, 1.0), (0, 0.1)]
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), G) for c, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for _, q in pairs])
+    perms = random_orders(42, 5, G)
+    out = ctx.ordered_growth(cov, qt, perms)
+    assert out.shape == (5, len(pairs), G)
+    for r in range(5):
+        for t, (c, q) in enumerate(pairs):
+            exp = _oracle_growth(items, pre, n, G, path_groups, perms[r], c, q, w)
+            assert out[r, t].tolist() == [int(x) for x in exp], (r, c, q)
+    # identity order == reference ordered-histgrowth
+    out1 = ctx.ordered_growth(cov, qt)
+    for t, (c, q) in enumerate(pairs):
+        exp = _oracle_growth(items, pre, n, G, path_groups, np.arange(G), c, q, w)
+        assert out1[0, t].tolist() == [int(x) for x in exp]
+
+
+def test_ordered_growth_many_groups(ctx):
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 6000, 300  # > 255 groups: 12-plane quorum counters
+    items, pre, lens = orc.pansyn(13, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    pairs = [(1, 0.0), (1, 0.5)]
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), p) for c, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), p) for _, q in pairs])
+    perms = random_orders(1, 2, p)
+    out = ctx.ordered_growth(cov, qt, perms)
+    for r in range(2):
+        for t, (c, q) in enumerate(pairs):
+            exp = _oracle_growth(items, pre, n, p, pg, perms[r], c, q)
+            assert out[r, t].tolist() == [int(x) for x in exp]
+
+
+def test_growth_after_scatter_route(ctx):
+    """edge-like (unsorted) paths: the presence matrix comes from the scatter route"""
+    from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
+    n, p = 9000, 8
+    items, pre, lens = orc.pansyn(21, n, p)
+    rng = np.random.default_rng(2)
+    items = items.copy()
+    for k in range(p):
+        rng.shuffle(items[pre[k]:pre[k + 1]])
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), p) for q in (0.0, 0.6)])
+    out = ctx.ordered_growth([1, 2], qt)
+    for t, (c, q) in enumerate([(1, 0.0), (2, 0.6)]):
+        exp = _oracle_growth(items, pre, n, p, pg, np.arange(p), c, q)
+        assert out[0, t].tolist() == [int(x) for x in exp]
+
+
+# ---------------------------------------------------------------------------------------------
+# size-independent properties at a larger size (no oracle run)
+# ---------------------------------------------------------------------------------------------
+def test_properties_large(ctx):
+    from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
+    n, p = 2_000_000, 64
+    ctx.set_csr_pansyn(42, n, p, with_weights=False)
+    pi = np.arange(p, dtype=np.uint32)
+    ctx.set_order(pi, pi, p)
+    cnt, h = ctx.hist()
+    assert int(h.sum()) == n                                  # every item lands in exactly one bin
+    assert np.array_equal(np.bincount(cnt[1:], minlength=p + 1).astype(np.uint64), h)
+    info = ctx.info()
+    # sum of coverages == number of distinct (item, path) incidences <= S
+    assert int(cnt[1:].astype(np.uint64).sum()) <= info.n_steps
+    cnt2, h2 = ctx.hist()                                     # idempotent
+    assert np.array_equal(h, h2) and np.array_equal(cnt, cnt2)
+    # order invariance of the histogram
+    ctx.set_order(pi[::-1].copy(), pi, p)
+    _, h3 = ctx.hist(want_countable=False)
+    assert np.array_equal(h, h3)
+    # growth at q=0, c=1: last value == #items covered at least once; curve is monotone
+    ctx.set_order(pi, pi, p)
+    out = ctx.ordered_growth([1], quorum_table(Threshold(RELATIVE, 0.0), p)[None, :])
+    curve = out[0, 0]
+    assert int(curve[-1]) == n - int(h[0])
+    assert np.all(np.diff(curve.astype(np.int64)) >= 0)

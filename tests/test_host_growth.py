@@ -1,0 +1,41 @@
+"""Host closed-form growth (panacus_amd/host/growth_closed_form.cpp) against the reference's
+known answers and, bit for bit, against the oracle restatement."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from panacus_amd import hostlib
+from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+
+
+def test_known_answers_bit_exact(golden):
+    ka = golden["growth_known_answers"]
+    c0 = Threshold(ABSOLUTE, 0)
+    assert hostlib.calc_growth_branch("union", ka["union"]["hist"], c0, Threshold(RELATIVE, 0)).tolist() == ka["union"]["expected"]
+    assert hostlib.calc_growth_branch("core", ka["core"]["hist"], c0, Threshold(RELATIVE, 1)).tolist() == ka["core"]["expected"]
+    assert hostlib.calc_growth_branch("quorum", ka["quorum"]["hist"], c0, Threshold(RELATIVE, 0.9)).tolist() == ka["quorum"]["expected"]
+
+
+def test_chr22_report(golden):
+    rep = golden["chr22_report"]
+    for count in ("bp", "node", "edge"):
+        h = rep["hists"][count]
+        gr = rep["growths"][count]
+        for c, q, curve in zip(gr["coverage"], gr["quorum"], gr["curves"]):
+            got = hostlib.calc_growth(h, Threshold(ABSOLUTE, c), Threshold(RELATIVE, q))
+            assert [int(math.floor(x)) for x in got] == curve
+
+
+@pytest.mark.parametrize("n", [5, 44, 130, 257])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_matches_oracle_bitwise(n, threads):
+    rng = np.random.default_rng(n)
+    h = rng.integers(0, 10**7, size=n + 1).astype(np.uint64)
+    h[rng.integers(0, n + 1, size=3)] = 0  # log2(0) = -inf terms
+    for c in (0, 1, 2, n // 3):
+        for q in (0.0, 0.1, 0.5, 0.9, 1.0, 1.0 / n):
+            a = hostlib.calc_growth(h, Threshold(ABSOLUTE, c), Threshold(RELATIVE, q), threads)
+            b = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+            assert a.tobytes() == b.tobytes(), (n, c, q)
