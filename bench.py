@@ -44,25 +44,31 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
-def cpu_baseline(sample_nodes, n_paths, pairs, seed=42):
+def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_reps=12):
     """The oracle (a plain-C port of the reference's serial loops) on a bounded sample of the
-    same workload, timed on this host: coverage + hist + closed-form growth."""
+    same workload, timed on this host: coverage + hist + closed-form growth, repeated until
+    about `min_seconds` of CPU work has been measured."""
     import oracle as orc
     items, pre, _ = orc.pansyn(seed, sample_nodes, n_paths)
     pi = np.arange(n_paths, dtype=np.uint64)
-    t0 = time.perf_counter()
-    cov = orc.coverage(items, pre, pi, pi, sample_nodes)
-    h = orc.hist(cov, n_paths)
-    for c, q in pairs:
-        orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
-    dt = time.perf_counter() - t0
+    reps, total = 0, 0.0
+    while reps < max_reps and (total < min_seconds or reps == 0):
+        t0 = time.perf_counter()
+        cov = orc.coverage(items, pre, pi, pi, sample_nodes)
+        h = orc.hist(cov, n_paths)
+        for c, q in pairs:
+            orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+        total += time.perf_counter() - t0
+        reps += 1
+    dt = total / reps
     return {
         "value": sample_nodes * n_paths / dt / 1e6,
         "unit": "M node*paths/s",
         "cores": 1,
         "kind": "port",
         "sample": f"pansyn-v1 seed {seed}, {sample_nodes} nodes x {n_paths} paths "
-                  f"({len(items)} steps), serial coverage+hist+growth, {dt:.2f} s",
+                  f"({len(items)} steps); serial coverage+hist+closed-form growth, "
+                  f"{reps} passes, {dt:.3f} s each ({total:.1f} s of CPU work)",
     }, h
 
 
@@ -75,7 +81,7 @@ def main():
     ap.add_argument("--paths", type=int, default=256)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--tile-blocks", type=int, default=1)
-    ap.add_argument("--cpu-sample-nodes", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
     args = ap.parse_args()
@@ -115,9 +121,12 @@ def main():
     hist_host = np.zeros(P + 1, dtype=np.uint64)
     hist_dev = None
 
-    def step(collect_growth=True):
-        nonlocal hist_dev
+    def enqueue():
         ctx.hist_async()
+
+    def settle():
+        """wait for the enqueued pass; multi-GPU: sum the per-shard counters over RCCL"""
+        nonlocal hist_dev
         if world > 1:
             d_hist, _ = ctx.hist_device()  # settles the pass, leaves the counters in HBM
             if hist_dev is None:
@@ -125,9 +134,25 @@ def main():
             dist.all_reduce(hist_dev)  # RCCL, int64 sum == uint64 sum for counts < 2^63
             torch.cuda.current_stream().synchronize()
         _, h = ctx.hist_fetch(want_countable=False)
-        if rank == 0 and collect_growth:
-            return h, [hostlib.calc_growth(h, c, q, args.growth_threads) for c, q in thr]
-        return h, None
+        return h
+
+    def growth(h):
+        if rank != 0:
+            return None
+        return [hostlib.calc_growth(h, c, q, args.growth_threads) for c, q in thr]
+
+    def run(n_steps):
+        """n_steps complete histgrowth passes.  Consecutive passes are independent, so the
+        host-side closed form of pass k overlaps the device work of pass k+1 (two passes in
+        flight); every pass is finished inside the call."""
+        h = growths = None
+        enqueue()
+        for k in range(n_steps):
+            h = settle()
+            if k + 1 < n_steps:
+                enqueue()
+            growths = growth(h)
+        return h, growths
 
     def barrier():
         if world > 1:
@@ -135,14 +160,13 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run(args.warmup)
     barrier()
     ctx.profile_enable(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h, growths = step()
+    h, growths = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -151,6 +175,14 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # latency of one un-pipelined pass (device + fetch + closed form), for the record
+    barrier()
+    l0 = time.perf_counter()
+    for _ in range(3):
+        run(1)
+    barrier()
+    latency_ms = (time.perf_counter() - l0) / 3 * 1e3
 
     # host-side share of a step (closed-form growth), measured separately on rank 0
     growth_ms = None
@@ -207,6 +239,7 @@ def main():
                 "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
                 "host_closed_form_growth": growth_ms,
+                "single_pass_latency": latency_ms,
             },
             "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,
             "checks": {"hist_sum": int(h.sum()), "expected_hist_sum": world * N,

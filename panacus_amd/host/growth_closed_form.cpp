@@ -5,6 +5,8 @@
 #include <cmath>
 #include <thread>
 
+#include "thread_pool.hpp"
+
 namespace pnh {
 
 uint64_t Threshold::to_absolute(uint64_t n) const {
@@ -40,42 +42,74 @@ double choose_log2(uint64_t n, uint64_t k) {
     return res;
 }
 
-std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage) {
+// Both O(n^2) branches share one shape: per histogram index i a running perc_mult[i]
+// (sequential in m), per m a sum over i in ascending order.  Rows i are independent, so
+// they are cut into chunks for the pool; each chunk fills term[m][i], and the sums over i
+// are then taken serially in the reference's order -- bit-identical to the serial loops.
+namespace {
+template <class RowRange, class Incr>
+void two_level(uint64_t n, const std::vector<double> &lh, const std::vector<double> &n_fall, RowRange row_active,
+               Incr incr, unsigned n_threads, std::vector<double> &term) {
+    // term is (n+1) x (n+1), stored [i][m]: a thread owns whole rows, so no cache line is shared
+    auto work = [&](uint64_t i_lo, uint64_t i_hi) {
+        for (uint64_t i = i_lo; i < i_hi; ++i) {
+            double pm = 0.0;
+            for (uint64_t m = 1; m <= n; ++m) {
+                if (!row_active(i, m)) continue;
+                pm += incr(i, m);
+                term[i * (n + 1) + m] = std::exp2(lh[i] + pm - n_fall[m]);
+            }
+        }
+    };
+    const uint64_t rows = n + 1;
+    if (n < 96) {
+        work(0, rows);
+        return;
+    }
+    const size_t chunks = 64;
+    ThreadPool::instance().parallel_for(
+        chunks, [&](size_t k) { work(rows * k / chunks, rows * (k + 1) / chunks); }, n_threads);
+}
+}  // namespace
+
+std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
     const uint64_t n = hist.size() - 1;
     const uint64_t c = std::max<uint64_t>(1, coverage.to_absolute(n));
-    std::vector<double> out(n, 0.0), perc_mult(n + 1, 0.0), lh(n + 1);
+    std::vector<double> out(n, 0.0), lh(n + 1), n_fall(n + 1, 0.0);
     Log2Table lg(n + 1);
     for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
     uint64_t tot_i = 0;
     for (uint64_t i = c; i <= n; ++i) tot_i += hist[i];
     const double tot = (double)tot_i;
-    double n_fall_m = 0.0;
+    for (uint64_t m = 1; m <= n; ++m) n_fall[m] = n_fall[m - 1] + lg(n - m + 1);
+    std::vector<double> term((n + 1) * (n + 1), 0.0);
+    // hist.rs:102-111: for i in c..n-m+1 { perc_mult[i] += log2(n-m-i+1); y += exp2(..) }
+    two_level(
+        n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= c && i + m <= n; },
+        [&](uint64_t i, uint64_t m) { return lg(n - m - i + 1); }, n_threads, term);
     for (uint64_t m = 1; m <= n; ++m) {
         double y = 0.0;
-        n_fall_m += lg(n - m + 1);
-        for (uint64_t i = c; i + m <= n; ++i) {
-            perc_mult[i] += lg(n - m - i + 1);
-            y += std::exp2(lh[i] + perc_mult[i] - n_fall_m);
-        }
+        for (uint64_t i = c; i + m <= n; ++i) y += term[i * (n + 1) + m];
         out[m - 1] = tot - y;
     }
     return out;
 }
 
-std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage) {
+std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
     const uint64_t n = hist.size() - 1;
     const uint64_t c = std::max<uint64_t>(1, coverage.to_absolute(n + 1));
-    std::vector<double> out(n, 0.0), perc_mult(n + 1, 0.0), lh(n + 1);
+    std::vector<double> out(n, 0.0), lh(n + 1), n_fall(n + 1, 0.0);
     Log2Table lg(n + 1);
     for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
-    double n_fall_m = 0.0;
+    for (uint64_t m = 1; m <= n; ++m) n_fall[m] = n_fall[m - 1] + lg(n - m + 1);
+    std::vector<double> term((n + 1) * (n + 1), 0.0);
+    // hist.rs:127-135: for i in max(m,c)..n+1 { perc_mult[i] += log2(i-m+1); y += exp2(..) }
+    two_level(
+        n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= std::max(m, c); },
+        [&](uint64_t i, uint64_t m) { return lg(i - m + 1); }, n_threads, term);
     for (uint64_t m = 1; m <= n; ++m) {
         double y = 0.0;
-        n_fall_m += lg(n - m + 1);
-        for (uint64_t i = std::max(m, c); i <= n; ++i) {
-            perc_mult[i] += lg(i - m + 1);
-            y += std::exp2(lh[i] + perc_mult[i] - n_fall_m);
-        }
+        for (uint64_t i = std::max(m, c); i <= n; ++i) y += term[i * (n + 1) + m];
         out[m - 1] = y;
     }
     return out;
@@ -99,16 +133,16 @@ std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Thresh
         m_quorum[m] = (uint64_t)std::ceil((double)m * quorum);
     }
 
-    // yl[m]: the "100 % quorum" part -- sequential in m through perc_mult, cheap (O(n^2))
+    // yl[m]: the "100 % quorum" part (hist.rs:157-160), same shape as the core branch
     std::vector<double> yl(n + 1, 0.0);
     {
-        std::vector<double> perc_mult(n + 1, 0.0);
+        std::vector<double> t2((n + 1) * (n + 1), 0.0);
+        two_level(
+            n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= std::max(m, c); },
+            [&](uint64_t i, uint64_t m) { return lg(i - m + 1); }, n_threads, t2);
         for (uint64_t m = 1; m <= n; ++m) {
             double y = 0.0;
-            for (uint64_t i = std::max(m, c); i <= n; ++i) {
-                perc_mult[i] += lg(i - m + 1);
-                y += std::exp2(lh[i] + perc_mult[i] - n_fall[m]);
-            }
+            for (uint64_t i = std::max(m, c); i <= n; ++i) y += t2[i * (n + 1) + m];
             yl[m] = y;
         }
     }
@@ -118,6 +152,17 @@ std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Thresh
     // serially in ascending i like the reference.
     std::vector<double> term((n + 1) * (n + 1), 0.0);
     std::vector<uint8_t> has((n + 1) * (n + 1), 0);
+    // choose(i, j) of hist.rs:21-36 with its log2 calls served from the table (same values)
+    auto choose_tab = [&](uint64_t nn, uint64_t k) -> double {
+        if (k > nn) return 0.0;
+        if (k > nn - k) k = nn - k;
+        double res = 0.0;
+        for (uint64_t a = 0; a < k; ++a) {
+            res += lg(nn - a);
+            res -= lg(a + 1);
+        }
+        return res;
+    };
     auto work = [&](uint64_t i_lo, uint64_t i_hi) {
         std::vector<double> q(n + 1);
         for (uint64_t i = i_lo; i < i_hi; ++i) {
@@ -128,7 +173,7 @@ std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Thresh
                 bool add = false;
                 for (uint64_t j = std::max(m_quorum[m], c); j < m; ++j) {
                     if (n + j + 1 > i + m && j <= i) {
-                        if (q[j] == 0.0) q[j] = choose_log2(i, j);
+                        if (q[j] == 0.0) q[j] = choose_tab(i, j);
                         q[j] += lg(n - i - m + 1 + j);
                         q[j] -= lg(m - j);
                         sum_q += std::exp2(q[j] + m_fact[m] - n_fall[m]);
@@ -136,36 +181,24 @@ std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Thresh
                     }
                 }
                 if (add) {
-                    term[m * (n + 1) + i] = std::exp2(lh[i] + std::log2(sum_q));
-                    has[m * (n + 1) + i] = 1;
+                    term[i * (n + 1) + m] = std::exp2(lh[i] + std::log2(sum_q));
+                    has[i * (n + 1) + m] = 1;
                 }
             }
         }
     };
-    unsigned nt = n_threads ? n_threads : std::max(1u, std::thread::hardware_concurrency());
-    if (n < 64) nt = 1;
-    nt = (unsigned)std::min<uint64_t>(nt, n);
-    if (nt <= 1) {
+    if (n < 48) {
         work(0, n);
     } else {
-        std::vector<std::thread> th;
-        // interleaved blocks: the cost of row i is roughly proportional to i
-        const uint64_t blocks = (uint64_t)nt * 4;
-        std::vector<std::pair<uint64_t, uint64_t>> ranges;
-        for (uint64_t b = 0; b < blocks; ++b) {
-            uint64_t lo = n * b / blocks, hi = n * (b + 1) / blocks;
-            if (hi > lo) ranges.emplace_back(lo, hi);
-        }
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t]() {
-                for (size_t k = t; k < ranges.size(); k += nt) work(ranges[k].first, ranges[k].second);
-            });
-        for (auto &x : th) x.join();
+        // rows get more expensive with i (more admissible j), so cut finely and let the pool balance
+        const size_t chunks = std::min<uint64_t>(n, 256);
+        ThreadPool::instance().parallel_for(
+            chunks, [&](size_t k) { work(n * k / chunks, n * (k + 1) / chunks); }, n_threads);
     }
     for (uint64_t m = 1; m <= n; ++m) {
         double yr = 0.0;
         for (uint64_t i = m_quorum[m]; i < n; ++i)
-            if (has[m * (n + 1) + i]) yr += term[m * (n + 1) + i];
+            if (has[i * (n + 1) + m]) yr += term[i * (n + 1) + m];
         out[m - 1] = yl[m] + yr;
     }
     return out;
@@ -176,8 +209,8 @@ std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold cov
     if (hist.size() < 2) return {};
     const uint64_t n = hist.size() - 1;
     const uint64_t q_abs = std::max<uint64_t>(1, quorum.to_absolute(n));
-    if (q_abs == 1) return calc_growth_union(hist, coverage);
-    if (q_abs >= n) return calc_growth_core(hist, coverage);
+    if (q_abs == 1) return calc_growth_union(hist, coverage, n_threads);
+    if (q_abs >= n) return calc_growth_core(hist, coverage, n_threads);
     return calc_growth_quorum(hist, coverage, quorum, n_threads);
 }
 

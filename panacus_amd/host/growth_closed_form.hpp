@@ -26,8 +26,8 @@ double choose_log2(uint64_t n, uint64_t k);  // hist.rs:21-36
 // n = hist.size() - 1 values (the caller prepends the NaN row, hist.rs:83-85)
 std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
                                 unsigned n_threads = 0);
-std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage);
-std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage);
+std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads = 0);
+std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads = 0);
 std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
                                        unsigned n_threads = 0);
 
