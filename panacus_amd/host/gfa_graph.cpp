@@ -1,0 +1,708 @@
+// gfa_graph.cpp -- see gfa_graph.hpp.
+#include "gfa_graph.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+#include "thread_pool.hpp"
+
+namespace pnh {
+
+// ------------------------------------------------------------------------------------------
+// PathSegment
+// ------------------------------------------------------------------------------------------
+namespace {
+
+bool parse_u64(std::string_view s, uint64_t &out) {  // usize::from_str(..).ok()
+    if (s.empty()) return false;
+    uint64_t v = 0;
+    for (char ch : s) {
+        if (ch < '0' || ch > '9') return false;
+        uint64_t d = (uint64_t)(ch - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+
+// PATHID_COORDS = ^(.+):([0-9]+)-([0-9]+)$  (graph.rs:18); returns length of group 1 or npos
+size_t match_coords(std::string_view s, bool &hs, uint64_t &st, bool &he, uint64_t &en) {
+    size_t i = s.size();
+    while (i > 0 && s[i - 1] >= '0' && s[i - 1] <= '9') --i;
+    if (i == s.size() || i == 0 || s[i - 1] != '-') return std::string_view::npos;
+    const size_t dash = i - 1;
+    size_t j = dash;
+    while (j > 0 && s[j - 1] >= '0' && s[j - 1] <= '9') --j;
+    if (j == dash || j == 0 || s[j - 1] != ':') return std::string_view::npos;
+    const size_t colon = j - 1;
+    if (colon == 0) return std::string_view::npos;
+    hs = parse_u64(s.substr(j, dash - j), st);
+    he = parse_u64(s.substr(dash + 1), en);
+    return colon;
+}
+
+}  // namespace
+
+// PATHID_PANSN = ^([^#]+)(#[^#]+)?(#[^#].*)?$ with leftmost-first (Perl-like) semantics
+PathSegment PathSegment::from_str(std::string_view s) {
+    PathSegment r;
+    r.sample = std::string(s);
+    const size_t n = s.size();
+    size_t a = 0;
+    while (a < n && s[a] != '#') ++a;
+    if (a == 0) return r;  // no match: whole string is the sample
+    std::string_view g2, g3;
+    bool matched = false;
+    if (a == n) {
+        matched = true;
+    } else {
+        size_t b = a + 1;
+        while (b < n && s[b] != '#') ++b;
+        if (b > a + 1) {  // group 2 = '#' + maximal run of non-'#'
+            if (b == n) {
+                g2 = s.substr(a, b - a);
+                matched = true;
+            } else if (b + 1 < n && s[b + 1] != '#') {
+                g2 = s.substr(a, b - a);
+                g3 = s.substr(b);
+                matched = true;
+            }
+        }
+        if (!matched && a + 1 < n && s[a + 1] != '#') {  // backtrack: no group 2, group 3 from a
+            g3 = s.substr(a);
+            matched = true;
+        }
+    }
+    if (!matched) return r;
+    const int nseg = 2 + (g2.empty() ? 0 : 1) + (g3.empty() ? 0 : 1);
+    bool hs = false, he = false;
+    uint64_t st = 0, en = 0;
+    if (nseg == 4) {
+        r.sample = std::string(s.substr(0, a));
+        r.has_haplotype = true;
+        r.haplotype = std::string(g2.substr(1));
+        std::string_view rest = g3.substr(1);
+        size_t g1 = match_coords(rest, hs, st, he, en);
+        r.has_seqid = true;
+        if (g1 == std::string_view::npos) {
+            r.seqid = std::string(rest);
+        } else {
+            r.seqid = std::string(rest.substr(0, g1));
+            r.has_start = hs; r.start = st; r.has_end = he; r.end = en;
+        }
+    } else if (nseg == 3) {
+        std::string_view seg = (g2.empty() ? g3 : g2).substr(1);
+        r.sample = std::string(s.substr(0, a));
+        r.has_haplotype = true;
+        size_t g1 = match_coords(seg, hs, st, he, en);
+        if (g1 == std::string_view::npos) {
+            r.haplotype = std::string(seg);
+        } else {
+            r.haplotype = std::string(seg.substr(0, g1));
+            r.has_start = hs; r.start = st; r.has_end = he; r.end = en;
+        }
+    } else {
+        size_t g1 = match_coords(s.substr(0, a), hs, st, he, en);
+        if (g1 != std::string_view::npos) {
+            r.sample = std::string(s.substr(0, g1));
+            r.has_start = hs; r.start = st; r.has_end = he; r.end = en;
+        }
+    }
+    return r;
+}
+
+std::string PathSegment::id() const {
+    if (has_haplotype) return has_seqid ? sample + "#" + haplotype + "#" + seqid : sample + "#" + haplotype;
+    if (has_seqid) return sample + "#*#" + seqid;
+    return sample;
+}
+
+std::string PathSegment::display() const {
+    if (has_start && has_end) return id() + ":" + std::to_string(start) + "-" + std::to_string(end);
+    return id();
+}
+
+std::string PathSegment::clear_key() const {
+    std::string k = sample;
+    k += '\x01';
+    k += has_haplotype ? '1' : '0';
+    k += haplotype;
+    k += '\x01';
+    k += has_seqid ? '1' : '0';
+    k += seqid;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------
+// implementation state: the file image and the id maps
+// ------------------------------------------------------------------------------------------
+namespace {
+
+inline uint64_t hash_bytes(const char *p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdULL);
+    while (n >= 8) {
+        uint64_t w;
+        std::memcpy(&w, p, 8);
+        h = (h ^ w) * 0x9FB21C651E98DF25ull;
+        h ^= h >> 32;
+        p += 8;
+        n -= 8;
+    }
+    uint64_t w = 0;
+    std::memcpy(&w, p, n);
+    h = (h ^ w) * 0x9FB21C651E98DF25ull;
+    return h ^ (h >> 29);
+}
+
+struct NameMap {  // segment name -> node id; keys are views into the file image
+    struct Slot {
+        const char *p;
+        uint32_t len, id;
+    };
+    std::vector<Slot> tab;
+    uint64_t mask = 0;
+    void init(size_t n) {
+        size_t cap = 64;
+        while (cap < n * 2) cap <<= 1;
+        tab.assign(cap, Slot{nullptr, 0, 0});
+        mask = cap - 1;
+    }
+    bool insert(const char *p, uint32_t len, uint32_t id) {
+        uint64_t j = hash_bytes(p, len) & mask;
+        while (tab[j].p) {
+            if (tab[j].len == len && std::memcmp(tab[j].p, p, len) == 0) return false;
+            j = (j + 1) & mask;
+        }
+        tab[j] = Slot{p, len, id};
+        return true;
+    }
+    uint32_t find(const char *p, uint32_t len) const {
+        uint64_t j = hash_bytes(p, len) & mask;
+        while (tab[j].p) {
+            if (tab[j].len == len && std::memcmp(tab[j].p, p, len) == 0) return tab[j].id;
+            j = (j + 1) & mask;
+        }
+        return 0;
+    }
+};
+
+struct EdgeMap {  // canonical (u, o1, v, o2) -> edge id
+    struct Slot {
+        uint64_t uv;
+        uint32_t id;
+        uint8_t oo;
+    };
+    std::vector<Slot> tab;
+    uint64_t mask = 0;
+    size_t n = 0;
+    void init(size_t want) {
+        size_t cap = 64;
+        while (cap < want * 2) cap <<= 1;
+        tab.assign(cap, Slot{0, 0, 0});
+        mask = cap - 1;
+        n = 0;
+    }
+    static uint64_t h(uint64_t uv, uint8_t oo) {
+        uint64_t x = (uv ^ ((uint64_t)oo << 62)) * 0x9FB21C651E98DF25ull;
+        return x ^ (x >> 31);
+    }
+    uint32_t find(uint64_t uv, uint8_t oo) const {
+        uint64_t j = h(uv, oo) & mask;
+        while (tab[j].id) {
+            if (tab[j].uv == uv && tab[j].oo == oo) return tab[j].id;
+            j = (j + 1) & mask;
+        }
+        return 0;
+    }
+    bool insert(uint64_t uv, uint8_t oo, uint32_t id) {
+        uint64_t j = h(uv, oo) & mask;
+        while (tab[j].id) {
+            if (tab[j].uv == uv && tab[j].oo == oo) return false;
+            j = (j + 1) & mask;
+        }
+        tab[j] = Slot{uv, id, oo};
+        ++n;
+        return true;
+    }
+};
+
+// Edge::canonical (graph.rs:142-148); orientation 0 = Forward, 1 = Backward
+inline void canonical(uint32_t u, uint8_t o1, uint32_t v, uint8_t o2, uint64_t &uv, uint8_t &oo) {
+    if (u > v || (u == v && o1 == 1)) {
+        uv = ((uint64_t)v << 32) | u;
+        oo = (uint8_t)(((o2 ^ 1) << 1) | (o1 ^ 1));
+    } else {
+        uv = ((uint64_t)u << 32) | v;
+        oo = (uint8_t)((o1 << 1) | o2);
+    }
+}
+
+std::string slurp(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    unsigned char magic[2] = {0, 0};
+    size_t got = std::fread(magic, 1, 2, f);
+    std::fclose(f);
+    std::string buf;
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // bufreader_from_compressed_gfa, io.rs:23-33
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (!g) throw std::runtime_error("cannot open " + path);
+        gzbuffer(g, 1 << 20);
+        std::vector<char> chunk(1 << 22);
+        int r;
+        while ((r = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) buf.append(chunk.data(), (size_t)r);
+        gzclose(g);
+        if (r < 0) throw std::runtime_error("error while decompressing " + path);
+    } else {
+        std::ifstream in(path, std::ios::binary | std::ios::ate);
+        if (!in) throw std::runtime_error("cannot open " + path);
+        std::streamsize sz = in.tellg();
+        in.seekg(0);
+        buf.resize((size_t)sz);
+        if (sz > 0 && !in.read(&buf[0], sz)) throw std::runtime_error("cannot read " + path);
+    }
+    return buf;
+}
+
+struct Span {
+    size_t b, e;  // [b, e) in the file image
+};
+
+inline size_t field_end(const std::string &s, size_t from, size_t line_end) {
+    const void *p = std::memchr(s.data() + from, '\t', line_end - from);
+    return p ? (size_t)((const char *)p - s.data()) : line_end;
+}
+
+}  // namespace
+
+struct GraphStorage::Impl {
+    std::string image;                // the whole GFA
+    std::vector<Span> p_lines;        // P and W lines in file order
+    std::vector<Span> step_fields;    // per path: the step / walk column
+    std::vector<uint8_t> is_walk;     // per path
+    NameMap names;
+    bool nice = false;                // segment names are the integers 1..N in file order
+    bool has_edges = false;
+    EdgeMap edges;
+
+    uint32_t node_id(const char *p, size_t len) const {
+        if (nice) {
+            uint64_t v = 0;
+            for (size_t i = 0; i < len; ++i) {
+                if (p[i] < '0' || p[i] > '9') return 0;
+                v = v * 10 + (uint64_t)(p[i] - '0');
+                if (v > 0xFFFFFFFFull) return 0;
+            }
+            return (uint32_t)v;
+        }
+        return names.find(p, (uint32_t)len);
+    }
+};
+
+GraphStorage::GraphStorage() : impl_(std::make_shared<Impl>()) {}
+GraphStorage::~GraphStorage() = default;
+
+// GraphStorage::from_gfa (graph.rs:195-220): parse_nodes_gfa (308-375) + parse_edge_gfa (276-306)
+std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file, bool index_edges, bool /*nice*/) {
+    std::unique_ptr<GraphStorage> g(new GraphStorage());
+    Impl &im = *g->impl_;
+    im.image = slurp(gfa_file);
+    const std::string &s = im.image;
+    const size_t N = s.size();
+
+    std::vector<Span> s_lines, l_lines;
+    for (size_t b = 0; b < N;) {
+        const void *nl = std::memchr(s.data() + b, '\n', N - b);
+        size_t e = nl ? (size_t)((const char *)nl - s.data()) : N;
+        if (e > b) {
+            switch (s[b]) {
+                case 'S': s_lines.push_back({b, e}); break;
+                case 'L': if (index_edges) l_lines.push_back({b, e}); break;
+                case 'P': case 'W': im.p_lines.push_back({b, e}); break;
+                default: break;
+            }
+        }
+        b = e + 1;
+    }
+    if (s_lines.size() >= 0xFFFFFFFEull) throw std::runtime_error("more than 2^32-2 segments are not supported");
+
+    // --- S lines: ids are 1-based ranks, node_lens[id] = length of the sequence column ---
+    g->node_lens_.assign(s_lines.size() + 1, 0);
+    std::vector<Span> name_of(s_lines.size());
+    bool nice = true;
+    for (size_t k = 0; k < s_lines.size(); ++k) {
+        const Span ln = s_lines[k];
+        if (ln.e < ln.b + 3) throw std::runtime_error("malformed S line");
+        size_t ne = field_end(s, ln.b + 2, ln.e);
+        name_of[k] = {ln.b + 2, ne};
+        size_t q0 = ne < ln.e ? ne + 1 : ln.e, q1 = q0;
+        while (q1 < ln.e && s[q1] != '\t' && s[q1] != '\r') ++q1;
+        g->node_lens_[k + 1] = (uint32_t)(q1 - q0);
+        if (nice) {  // is the name exactly the decimal k+1 ?
+            uint64_t v = 0;
+            bool ok = ne > ln.b + 2 && s[ln.b + 2] != '0';
+            for (size_t i = ln.b + 2; ok && i < ne; ++i) {
+                ok = s[i] >= '0' && s[i] <= '9' && v < 0xFFFFFFFFull;
+                v = v * 10 + (uint64_t)(s[i] - '0');
+            }
+            nice = ok && v == k + 1;
+        }
+    }
+    im.nice = nice && !s_lines.empty();
+    if (!im.nice) {
+        im.names.init(s_lines.size());
+        for (size_t k = 0; k < s_lines.size(); ++k)
+            if (!im.names.insert(s.data() + name_of[k].b, (uint32_t)(name_of[k].e - name_of[k].b), (uint32_t)(k + 1)))
+                throw std::runtime_error("Segment with ID " + s.substr(name_of[k].b, name_of[k].e - name_of[k].b) +
+                                         " occurs multiple times in GFA");
+    }
+    g->node_count_ = s_lines.size();
+
+    // --- P / W lines: path identity + the span of the step column ---
+    const size_t P = im.p_lines.size();
+    g->paths_.resize(P);
+    im.step_fields.resize(P);
+    im.is_walk.resize(P);
+    for (size_t k = 0; k < P; ++k) {
+        const Span ln = im.p_lines[k];
+        size_t le = ln.e;
+        if (le > ln.b && s[le - 1] == '\r') --le;
+        if (s[ln.b] == 'P') {
+            size_t n0 = field_end(s, ln.b, le) + 1;
+            if (n0 > le) throw std::runtime_error("malformed P line");
+            size_t n1 = field_end(s, n0, le);
+            g->paths_[k] = PathSegment::from_str(std::string_view(s).substr(n0, n1 - n0));
+            size_t f0 = n1 < le ? n1 + 1 : le;
+            im.step_fields[k] = {f0, field_end(s, f0, le)};
+            im.is_walk[k] = 0;
+        } else {  // W sample hap seqid start end walk  (graph.rs:381-412)
+            size_t col[7];
+            size_t pos = ln.b;
+            for (int c = 0; c < 6; ++c) {
+                size_t e = field_end(s, pos, le);
+                if (e >= le) throw std::runtime_error("malformed W line");
+                col[c] = pos;
+                pos = e + 1;
+            }
+            col[6] = pos;
+            PathSegment ps;
+            ps.sample = s.substr(col[1], col[2] - col[1] - 1);
+            ps.has_haplotype = true;
+            ps.haplotype = s.substr(col[2], col[3] - col[2] - 1);
+            ps.has_seqid = true;
+            ps.seqid = s.substr(col[3], col[4] - col[3] - 1);
+            std::string_view a = std::string_view(s).substr(col[4], col[5] - col[4] - 1);
+            std::string_view b = std::string_view(s).substr(col[5], col[6] - col[5] - 1);
+            if (a != "*") {
+                if (!parse_u64(a, ps.start)) throw std::runtime_error("malformed W line (start)");
+                ps.has_start = true;
+            }
+            if (b != "*") {
+                if (!parse_u64(b, ps.end)) throw std::runtime_error("malformed W line (end)");
+                ps.has_end = true;
+            }
+            g->paths_[k] = std::move(ps);
+            im.step_fields[k] = {pos, field_end(s, pos, le)};
+            im.is_walk[k] = 1;
+        }
+    }
+
+    // --- L lines: edge id = rank of the first occurrence of the canonical form ---
+    if (index_edges) {
+        im.has_edges = true;
+        im.edges.init(l_lines.size());
+        uint32_t next = 1;
+        for (const Span ln : l_lines) {
+            size_t a0 = ln.b + 2, a1 = field_end(s, a0, ln.e);
+            if (a1 + 2 >= ln.e) throw std::runtime_error("malformed L line");
+            uint32_t u = im.node_id(s.data() + a0, a1 - a0);
+            uint8_t o1 = s[a1 + 1] == '+' ? 0 : 1;
+            size_t b0 = a1 + 3, b1 = field_end(s, b0, ln.e);
+            if (b1 + 1 >= ln.e) throw std::runtime_error("malformed L line");
+            uint32_t v = im.node_id(s.data() + b0, b1 - b0);
+            uint8_t o2 = s[b1 + 1] == '+' ? 0 : 1;
+            if (!u || u > g->node_count_) throw std::runtime_error("unknown node " + s.substr(a0, a1 - a0));
+            if (!v || v > g->node_count_) throw std::runtime_error("unknown node " + s.substr(b0, b1 - b0));
+            uint64_t uv;
+            uint8_t oo;
+            canonical(u, o1, v, o2, uv, oo);
+            if (im.edges.insert(uv, oo, next)) ++next;  // duplicated edges are skipped (graph.rs:296)
+        }
+        g->edge_count_ = next - 1;
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------
+// ItemTable
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// chunks of a step column that start on a step boundary, ~64 KiB each
+struct Chunk {
+    uint32_t path;
+    size_t b, e;
+    uint64_t n_steps = 0, out = 0;
+};
+
+}  // namespace
+
+ItemTable GraphStorage::item_table(CountType count) const {
+    const Impl &im = *impl_;
+    const std::string &s = im.image;
+    const size_t P = paths_.size();
+    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    constexpr size_t CHUNK = 64 * 1024;
+
+    std::vector<Chunk> chunks;
+    for (size_t k = 0; k < P; ++k) {
+        const Span f = im.step_fields[k];
+        size_t b = f.b;
+        while (b < f.e) {
+            size_t e = std::min(f.e, b + CHUNK);
+            if (e < f.e) {  // move e forward to the start of the next step
+                if (im.is_walk[k]) {
+                    while (e < f.e && s[e] != '>' && s[e] != '<') ++e;
+                } else {
+                    const void *c = std::memchr(s.data() + e, ',', f.e - e);
+                    e = c ? (size_t)((const char *)c - s.data()) + 1 : f.e;
+                }
+            }
+            chunks.push_back(Chunk{(uint32_t)k, b, e});
+            b = e;
+        }
+    }
+    ThreadPool &pool = ThreadPool::instance();
+    // pass 1: steps per chunk
+    pool.parallel_for(chunks.size(), [&](size_t ci) {
+        Chunk &c = chunks[ci];
+        uint64_t n = 0;
+        if (im.is_walk[c.path]) {
+            for (size_t i = c.b; i < c.e; ++i) n += (s[i] == '>') | (s[i] == '<');
+        } else {
+            // steps are separated by ','; empty pieces (",,") carry no step
+            size_t i = c.b;
+            while (i < c.e) {
+                const void *cm = std::memchr(s.data() + i, ',', c.e - i);
+                size_t e = cm ? (size_t)((const char *)cm - s.data()) : c.e;
+                if (e > i) ++n;
+                i = e + 1;
+            }
+        }
+        c.n_steps = n;
+    });
+    std::vector<uint64_t> node_pref(P + 1, 0);
+    {
+        uint64_t run = 0;
+        size_t ci = 0;
+        for (size_t k = 0; k < P; ++k) {
+            node_pref[k] = run;
+            while (ci < chunks.size() && chunks[ci].path == k) {
+                chunks[ci].out = run;
+                run += chunks[ci].n_steps;
+                ++ci;
+            }
+        }
+        node_pref[P] = run;
+    }
+    const uint64_t S = node_pref[P];
+    std::vector<uint32_t> ids(S);
+    std::vector<uint8_t> ori(count == COUNT_EDGE ? S : 0);
+    std::atomic<size_t> bad_at{(size_t)-1};
+    // pass 2: name -> id (get_segment_id / get_walk_segment_id, util.rs:1017-1046)
+    pool.parallel_for(chunks.size(), [&](size_t ci) {
+        const Chunk &c = chunks[ci];
+        uint64_t o = c.out;
+        if (im.is_walk[c.path]) {
+            size_t i = c.b;
+            while (i < c.e) {
+                size_t e = i + 1;
+                while (e < c.e && s[e] != '>' && s[e] != '<') ++e;
+                uint32_t id = (s[i] == '>' || s[i] == '<') ? im.node_id(s.data() + i + 1, e - i - 1) : 0;
+                if (!id || id > node_count_) { bad_at.store(i); return; }
+                ids[o] = id;
+                if (!ori.empty()) ori[o] = s[i] == '>' ? 0 : 1;
+                ++o;
+                i = e;
+            }
+        } else {
+            size_t i = c.b;
+            while (i < c.e) {
+                const void *cm = std::memchr(s.data() + i, ',', c.e - i);
+                size_t e = cm ? (size_t)((const char *)cm - s.data()) : c.e;
+                if (e > i) {
+                    char oc = s[e - 1];
+                    uint32_t id = (oc == '+' || oc == '-') ? im.node_id(s.data() + i, e - 1 - i) : 0;
+                    if (!id || id > node_count_) { bad_at.store(i); return; }
+                    ids[o] = id;
+                    if (!ori.empty()) ori[o] = oc == '+' ? 0 : 1;
+                    ++o;
+                }
+                i = e + 1;
+            }
+        }
+    });
+    if (bad_at.load() != (size_t)-1) {
+        size_t i = bad_at.load(), e = i;
+        while (e < s.size() && s[e] != ',' && s[e] != '\t' && s[e] != '\n' && e - i < 64) ++e;
+        throw std::runtime_error("unknown node " + s.substr(i, e - i));
+    }
+
+    ItemTable t;
+    if (count != COUNT_EDGE) {
+        t.items = std::move(ids);
+        t.id_prefsum = std::move(node_pref);
+        return t;
+    }
+    // edge steps: update_tables_edgecount (util.rs:723-795) with include=[(0,MAX)], exclude=[]
+    t.id_prefsum.assign(P + 1, 0);
+    std::vector<uint64_t> slot(P + 1, 0);  // upper bound: len-1 edges per path
+    for (size_t k = 0; k < P; ++k) {
+        uint64_t len = node_pref[k + 1] - node_pref[k];
+        slot[k + 1] = slot[k] + (len ? len - 1 : 0);
+    }
+    t.items.assign(slot[P], 0);
+    std::vector<uint64_t> kept(P, 0);
+    std::atomic<int64_t> bad_path{-1};
+    pool.parallel_for(P, [&](size_t k) {
+        const uint64_t b = node_pref[k], e = node_pref[k + 1];
+        if (e - b < 2) return;
+        uint64_t pcoord = (paths_[k].has_start && paths_[k].has_end) ? paths_[k].start : 0;
+        pcoord += node_lens_[ids[b]];
+        uint64_t w = slot[k];
+        for (uint64_t j = b; j + 1 < e; ++j) {
+            const uint64_t l = node_lens_[ids[j + 1]];
+            uint64_t uv;
+            uint8_t oo;
+            canonical(ids[j], ori[j], ids[j + 1], ori[j + 1], uv, oo);
+            uint32_t eid = im.edges.find(uv, oo);
+            if (!eid) { bad_path.store((int64_t)k); return; }
+            if (0 < pcoord + l) t.items[w++] = eid;  // include_coords[0].0 < p + l
+            pcoord += l;
+        }
+        kept[k] = w - slot[k];
+    });
+    if (bad_path.load() >= 0)
+        throw std::runtime_error("unknown edge in path " + paths_[(size_t)bad_path.load()].display());
+    // compact (only needed if some edge was skipped, which requires zero-length segments)
+    uint64_t run = 0;
+    bool dense = true;
+    for (size_t k = 0; k < P; ++k) {
+        t.id_prefsum[k] = run;
+        dense = dense && kept[k] == slot[k + 1] - slot[k];
+        run += kept[k];
+    }
+    t.id_prefsum[P] = run;
+    if (!dense) {
+        std::vector<uint32_t> packed(run);
+        for (size_t k = 0; k < P; ++k)
+            std::copy(t.items.begin() + slot[k], t.items.begin() + slot[k] + kept[k], packed.begin() + t.id_prefsum[k]);
+        t.items.swap(packed);
+    }
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// groups + visiting order
+// ------------------------------------------------------------------------------------------
+namespace {
+std::vector<std::string> read_lines(const std::string &file) {
+    std::ifstream in(file, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open " + file);
+    std::vector<std::string> out;
+    std::string l;
+    while (std::getline(in, l)) out.push_back(l);
+    return out;
+}
+}  // namespace
+
+PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file, const std::string &order_file) const {
+    const size_t P = paths_.size();
+    std::vector<std::string> key(P), group(P);
+    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+
+    // GraphMask::load_groups (abacus.rs:242-308)
+    if (mode == GROUP_HAPLOTYPE) {
+        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].sample + "#" + (paths_[i].has_haplotype ? paths_[i].haplotype : "");
+    } else if (mode == GROUP_SAMPLE) {
+        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].sample;
+    } else if (mode == GROUP_FILE) {
+        std::unordered_map<std::string, std::string> assigned;
+        int lineno = 1;
+        for (std::string l : read_lines(group_file)) {  // parse_groups, io.rs:121-151
+            if (!l.empty() && l.back() == '\r') l.pop_back();
+            size_t t0 = l.find('\t');
+            if (t0 == std::string::npos || l.find('\t', t0 + 1) != std::string::npos)
+                throw std::runtime_error("error in line " + std::to_string(lineno) + ": table must have exactly two columns");
+            std::string k = PathSegment::from_str(std::string_view(l).substr(0, t0)).clear_key();
+            std::string grp = l.substr(t0 + 1);
+            auto it = assigned.find(k);
+            if (it != assigned.end() && it->second != grp)
+                throw std::runtime_error("error in line " + std::to_string(lineno) +
+                                         ": path cannot be assigned to more than one group");
+            assigned.emplace(k, grp);
+            ++lineno;
+        }
+        for (size_t i = 0; i < P; ++i) {
+            auto it = assigned.find(key[i]);
+            group[i] = it != assigned.end() ? it->second : paths_[i].id();
+        }
+    } else {
+        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].id();
+    }
+
+    // get_path_order (abacus.rs:310-347): buckets by group, emitted whole at the first visit
+    std::unordered_map<std::string, uint32_t> bucket_of_group, path_of_key;
+    std::vector<std::vector<uint32_t>> buckets;
+    std::vector<uint32_t> bucket(P);
+    for (size_t i = 0; i < P; ++i) {
+        auto it = bucket_of_group.find(group[i]);
+        if (it == bucket_of_group.end()) {
+            it = bucket_of_group.emplace(group[i], (uint32_t)buckets.size()).first;
+            buckets.emplace_back();
+        }
+        bucket[i] = it->second;
+        buckets[it->second].push_back((uint32_t)i);
+        path_of_key.emplace(key[i], (uint32_t)i);
+    }
+    std::vector<uint32_t> visit;
+    if (!order_file.empty()) {
+        for (std::string l : read_lines(order_file)) {  // parse_bed_to_path_segments, 1-column form
+            if (!l.empty() && l.back() == '\r') l.pop_back();
+            std::string name = l.substr(0, l.find('\t'));
+            if (name.rfind("browser ", 0) == 0 || name.rfind("track ", 0) == 0 || (!name.empty() && name[0] == '#')) continue;
+            PathSegment ps = PathSegment::from_str(name);
+            auto pk = path_of_key.find(ps.clear_key());
+            if (pk != path_of_key.end()) {  // complement_with_group_assignments, abacus.rs:152-206
+                visit.push_back(bucket[pk->second]);
+            } else {
+                auto bg = bucket_of_group.find(ps.id());
+                if (bg != bucket_of_group.end()) visit.push_back(bg->second);
+                // unknown path/group: logged and skipped by the reference
+            }
+        }
+    } else {
+        for (size_t i = 0; i < P; ++i) visit.push_back(bucket[i]);
+    }
+    PathOrder out;
+    std::vector<uint8_t> done(buckets.size(), 0);
+    for (uint32_t b : visit) {
+        if (done[b]) continue;
+        done[b] = 1;
+        for (uint32_t i : buckets[b]) {
+            if (out.groups.empty() || out.groups.back() != group[i]) out.groups.push_back(group[i]);  // abacus.rs:555-559
+            out.path_idx.push_back(i);
+            out.group_id.push_back((uint32_t)out.groups.size() - 1);
+        }
+    }
+    return out;
+}
+
+}  // namespace pnh

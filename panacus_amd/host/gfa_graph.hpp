@@ -1,0 +1,79 @@
+// gfa_graph.hpp -- GFA front end of the host layer: everything the reference does between
+// "GFA file on disk" and "ItemTable + visiting order" (the inputs of the device ABI).
+//
+// Mirrors, file:line in the reference tree:
+//   GraphStorage        src/graph_broker/graph.rs:163-375   (node ids, node_lens, edge ids)
+//   Edge::canonical     src/graph_broker/graph.rs:142-148
+//   PathSegment         src/graph_broker/graph.rs:472-627   (PanSN names, ids, coords)
+//   GraphMask           src/graph_broker/abacus.rs:46-347   (groups, visiting order)
+//   ItemTable           src/util.rs:81-93; src/graph_broker/util.rs:22-206,723-795,1048-1184
+// Design differences (not behaviour): the file is read ONCE into memory (plain or gzip) and
+// all passes run over that buffer; names are hashed as string_views into it; path steps
+// are parsed in parallel over the worker pool; ids narrow to u32 (the device ABI's width).
+// Subset / exclude coordinate lists (-s/-e) are not implemented yet.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+namespace pnh {
+
+enum CountType { COUNT_NODE = 0, COUNT_BP = 1, COUNT_EDGE = 2 };
+enum GroupMode { GROUP_PATHID = 0, GROUP_SAMPLE = 1, GROUP_HAPLOTYPE = 2, GROUP_FILE = 3 };
+
+struct PathSegment {
+    std::string sample;
+    bool has_haplotype = false, has_seqid = false, has_start = false, has_end = false;
+    std::string haplotype, seqid;
+    uint64_t start = 0, end = 0;
+
+    static PathSegment from_str(std::string_view s);  // graph.rs:495-549
+    std::string id() const;                           // graph.rs:558-579
+    std::string display() const;                      // graph.rs:616-626
+    std::string clear_key() const;                    // identity of clear_coords(), graph.rs:581-589
+};
+
+struct ItemTable {  // src/util.rs:81-93, u32 items for the device
+    std::vector<uint32_t> items;
+    std::vector<uint64_t> id_prefsum;  // n_paths + 1
+};
+
+struct PathOrder {  // result of GraphMask::get_path_order + group-id assignment
+    std::vector<uint32_t> path_idx, group_id;
+    std::vector<std::string> groups;
+};
+
+class GraphStorage {
+public:
+    // throws std::runtime_error on malformed input (the reference panics)
+    static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false);
+
+    uint64_t node_count() const { return node_count_; }
+    uint64_t edge_count() const { return edge_count_; }
+    uint64_t number_of_items(CountType c) const { return c == COUNT_EDGE ? edge_count_ : node_count_; }
+    const std::vector<uint32_t> &node_lens() const { return node_lens_; }  // [0] = 0
+    const std::vector<PathSegment> &path_segments() const { return paths_; }
+
+    // parse_gfa_paths_walks[_multiple] without subset/exclude
+    ItemTable item_table(CountType count) const;
+
+    // GraphMask::load_groups + get_path_order (+ optional -O order file)
+    PathOrder path_order(GroupMode mode, const std::string &group_file, const std::string &order_file) const;
+
+    struct Impl;
+
+private:
+    GraphStorage();
+    std::shared_ptr<Impl> impl_;
+    uint64_t node_count_ = 0, edge_count_ = 0;
+    std::vector<uint32_t> node_lens_;
+    std::vector<PathSegment> paths_;
+
+public:
+    ~GraphStorage();
+};
+
+}  // namespace pnh

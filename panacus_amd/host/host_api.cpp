@@ -2,14 +2,98 @@
 // closed-form growth, GFA front end, table writers.  Bound from Python with ctypes
 // (panacus_amd/hostlib.py) and linked into the panacus-amd CLI.
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "gfa_graph.hpp"
 #include "growth_closed_form.hpp"
 #include "thread_pool.hpp"
 
+static thread_local std::string g_host_err;
+
 extern "C" {
+
+const char *pnh_last_error(void) { return g_host_err.c_str(); }
+
+// ---- GFA front end (gfa_graph.hpp) ----
+void *pnh_graph_load(const char *gfa_file, int index_edges) {
+    try {
+        return pnh::GraphStorage::from_gfa(gfa_file, index_edges != 0).release();
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return nullptr;
+    }
+}
+void pnh_graph_free(void *g) { delete static_cast<pnh::GraphStorage *>(g); }
+uint64_t pnh_graph_n_nodes(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_count(); }
+uint64_t pnh_graph_n_edges(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->edge_count(); }
+uint64_t pnh_graph_n_paths(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->path_segments().size(); }
+const uint32_t *pnh_graph_node_lens(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_lens().data(); }
+// copies the display name of path i into buf (NUL-terminated, truncated to cap); returns its length
+uint64_t pnh_graph_path_name(const void *g, uint64_t i, char *buf, uint64_t cap) {
+    std::string s = static_cast<const pnh::GraphStorage *>(g)->path_segments().at(i).display();
+    if (cap) {
+        size_t n = std::min<size_t>(s.size(), cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+
+// ItemTable: first call with items == NULL returns the number of steps (prefsum filled), second fills items
+int64_t pnh_graph_item_table(const void *g, int count_type, uint32_t *items, uint64_t *prefsum) {
+    static thread_local pnh::ItemTable cache;
+    static thread_local const void *cache_g = nullptr;
+    static thread_local int cache_c = -1;
+    try {
+        if (cache_g != g || cache_c != count_type) {
+            cache = static_cast<const pnh::GraphStorage *>(g)->item_table((pnh::CountType)count_type);
+            cache_g = g;
+            cache_c = count_type;
+        }
+        if (prefsum) std::copy(cache.id_prefsum.begin(), cache.id_prefsum.end(), prefsum);
+        int64_t n = (int64_t)cache.items.size();
+        if (items) {
+            std::copy(cache.items.begin(), cache.items.end(), items);
+            cache = pnh::ItemTable();
+            cache_g = nullptr;
+        }
+        return n;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
+// visiting order; group names are returned '\n'-joined in names_buf. Returns #groups or -1.
+int64_t pnh_graph_path_order(const void *g, int group_mode, const char *group_file, const char *order_file,
+                             uint32_t *path_idx, uint32_t *group_id, uint64_t *n_out, char *names_buf,
+                             uint64_t names_cap) {
+    try {
+        pnh::PathOrder o = static_cast<const pnh::GraphStorage *>(g)->path_order(
+            (pnh::GroupMode)group_mode, group_file ? group_file : "", order_file ? order_file : "");
+        std::copy(o.path_idx.begin(), o.path_idx.end(), path_idx);
+        std::copy(o.group_id.begin(), o.group_id.end(), group_id);
+        *n_out = o.path_idx.size();
+        std::string joined;
+        for (size_t i = 0; i < o.groups.size(); ++i) {
+            if (i) joined += '\n';
+            joined += o.groups[i];
+        }
+        if (joined.size() + 1 > names_cap) {
+            g_host_err = "group name buffer too small";
+            return -1;
+        }
+        std::memcpy(names_buf, joined.c_str(), joined.size() + 1);
+        return (int64_t)o.groups.size();
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
 
 // Hist::calc_growth (src/graph_broker/hist.rs:51-66). out: hist_len-1 doubles. Returns n.
 int64_t pnh_calc_growth(const uint64_t *hist, uint64_t hist_len, int cov_kind, double cov_val, int quo_kind,

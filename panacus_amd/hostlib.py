@@ -59,3 +59,116 @@ def calc_all_growths(hist, thresholds, n_threads: int = 0):
         g = calc_growth(hist, c, q, n_threads)
         out.append(np.concatenate([[np.nan], g]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# GFA front end (panacus_amd/host/gfa_graph.cpp)
+# ---------------------------------------------------------------------------------------------
+NODE, BP, EDGE = 0, 1, 2
+GROUP_PATHID, GROUP_SAMPLE, GROUP_HAPLOTYPE, GROUP_FILE = 0, 1, 2, 3
+
+
+def _bind_graph(L):
+    if getattr(L, "_graph_bound", False):
+        return
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.pnh_last_error.restype = C.c_char_p
+    L.pnh_graph_load.restype = C.c_void_p
+    L.pnh_graph_load.argtypes = [C.c_char_p, C.c_int]
+    L.pnh_graph_free.argtypes = [C.c_void_p]
+    for n in ("pnh_graph_n_nodes", "pnh_graph_n_edges", "pnh_graph_n_paths"):
+        getattr(L, n).restype = C.c_uint64
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.pnh_graph_node_lens.restype = u32p
+    L.pnh_graph_node_lens.argtypes = [C.c_void_p]
+    L.pnh_graph_path_name.restype = C.c_uint64
+    L.pnh_graph_path_name.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    L.pnh_graph_item_table.restype = C.c_int64
+    L.pnh_graph_item_table.argtypes = [C.c_void_p, C.c_int, u32p, u64p]
+    L.pnh_graph_path_order.restype = C.c_int64
+    L.pnh_graph_path_order.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, u32p, u32p, u64p, C.c_char_p,
+                                       C.c_uint64]
+    L._graph_bound = True
+
+
+class GfaGraph:
+    """GraphStorage + GraphMask of the reference (graph.rs:163-375, abacus.rs:46-347), host side."""
+
+    def __init__(self, gfa_file: str, index_edges: bool = False):
+        self._L = load()
+        _bind_graph(self._L)
+        self._h = self._L.pnh_graph_load(os.fsencode(gfa_file), int(index_edges))
+        if not self._h:
+            raise ValueError(self._L.pnh_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pnh_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_nodes(self):
+        return int(self._L.pnh_graph_n_nodes(self._h))
+
+    @property
+    def n_edges(self):
+        return int(self._L.pnh_graph_n_edges(self._h))
+
+    @property
+    def n_paths(self):
+        return int(self._L.pnh_graph_n_paths(self._h))
+
+    def n_items(self, count_type):
+        return self.n_edges if count_type == EDGE else self.n_nodes
+
+    @property
+    def node_lens(self):
+        p = self._L.pnh_graph_node_lens(self._h)
+        return np.ctypeslib.as_array(p, shape=(self.n_nodes + 1,)).copy()
+
+    def path_names(self):
+        out = []
+        buf = C.create_string_buffer(4096)
+        for i in range(self.n_paths):
+            self._L.pnh_graph_path_name(self._h, i, buf, 4096)
+            out.append(buf.value.decode())
+        return out
+
+    def item_table(self, count_type):
+        pre = np.zeros(self.n_paths + 1, dtype=np.uint64)
+        n = self._L.pnh_graph_item_table(self._h, count_type, None, pre.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if n < 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        items = np.zeros(max(n, 1), dtype=np.uint32)
+        n = self._L.pnh_graph_item_table(self._h, count_type, items.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         pre.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if n < 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        return items[:n], pre
+
+    def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None):
+        P = max(self.n_paths, 1)
+        pi = np.zeros(P, dtype=np.uint32)
+        gi = np.zeros(P, dtype=np.uint32)
+        n_out = C.c_uint64(0)
+        cap = 1 << 20
+        while True:
+            buf = C.create_string_buffer(cap)
+            ng = self._L.pnh_graph_path_order(self._h, group_mode, os.fsencode(group_file) if group_file else None,
+                                              os.fsencode(order_file) if order_file else None,
+                                              pi.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              gi.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_out), buf, cap)
+            if ng < 0 and b"too small" in self._L.pnh_last_error():
+                cap *= 4
+                continue
+            break
+        if ng < 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        names = buf.value.decode().split("\n") if ng else []
+        return pi[: n_out.value].copy(), gi[: n_out.value].copy(), names
