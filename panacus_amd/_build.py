@@ -23,7 +23,7 @@ LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
 HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_growth.hip", "pansyn.hip"]
-HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "host_api.cpp"]
+HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "commands.cpp", "host_api.cpp"]
 
 
 def _hipcc() -> str:
@@ -80,17 +80,17 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     hdrs.append(os.path.join(ROOT, "include", "panacus_amd.h"))
     if not all(os.path.exists(s) for s in srcs):
         return ""
-    if force or _newer(LIB_HOST, srcs + hdrs):
+    if force or _newer(LIB_HOST, srcs + hdrs + [LIB_HIP]):
         # -ffp-contract=off: the closed-form growth must keep the reference's f64 operation order
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-fast-math",
-               "-Wall", "-o", LIB_HOST] + srcs + ["-lz", "-lm"]
+               "-Wall", "-o", LIB_HOST] + srcs + ["-L" + HERE, "-lpanacus_hip", "-Wl,-rpath,$ORIGIN", "-lz", "-lm"]
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
     main = os.path.join(HOSTSRC, "cli_main.cpp")
     if os.path.exists(main) and (force or _newer(CLI, [main, LIB_HOST, LIB_HIP] + hdrs)):
         cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", CLI, main, "-L" + HERE, "-lpanacus_host", "-lpanacus_hip",
-               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"]
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + HERE, "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         _run(cmd)

@@ -1,0 +1,260 @@
+// commands.cpp -- see commands.hpp.  Plays the role of the reference's GraphBroker
+// (src/graph_broker.rs:96-247) for the four hot-path commands: build the graph once, hand the
+// ItemTable and the visiting order to the GPU through the C ABI, format the results.
+#include "commands.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+
+#include "../../include/panacus_amd.h"
+#include "gfa_graph.hpp"
+#include "growth_closed_form.hpp"
+#include "tables.hpp"
+#include "thread_pool.hpp"
+
+namespace pnh {
+namespace {
+
+struct Options {
+    std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file;
+    bool add_hist = false, by_sample = false, by_haplotype = false;
+    int threads = 0, device = 0;
+};
+
+const char *USAGE =
+    "panacus-amd -- MI355X-native hist / growth / histgrowth / ordered-histgrowth\n"
+    "usage: panacus-amd <hist|growth|histgrowth|ordered-histgrowth> [options] <GFA_FILE | HIST.tsv>\n"
+    "  -c, --count <node|bp|edge|all>   graph quantity to be counted [node]\n"
+    "  -l, --coverage <LIST>            coverage thresholds, e.g. 1,2 [1]\n"
+    "  -q, --quorum <LIST>              quorum thresholds in [0,1], e.g. 0,0.5 [0]\n"
+    "  -a, --hist                       also include the histogram (growth, histgrowth)\n"
+    "  -g, --groupby <FILE>             path-to-group mapping (2-column TSV)\n"
+    "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
+    "  -S, --groupby-sample             merge paths of the same sample\n"
+    "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
+    "  -t, --threads <N>                host threads (0 = all) [0]\n"
+    "      --device <N>                 GPU ordinal [0]\n";
+
+struct Device {  // RAII over pnx_ctx
+    pnx_ctx *ctx = nullptr;
+    explicit Device(int ordinal) {
+        int rc = pnx_init(&ctx, ordinal);
+        if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
+    }
+    ~Device() { pnx_free(ctx); }
+    void check(int rc) const {
+        if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
+    }
+};
+
+std::vector<CountType> count_types(const std::string &c, bool allow_all) {
+    std::string l;
+    for (char ch : c) l += (char)std::tolower((unsigned char)ch);
+    if (l == "all") {
+        if (!allow_all) throw std::runtime_error("count type 'all' is not admissible here");
+        return {COUNT_NODE, COUNT_BP, COUNT_EDGE};
+    }
+    CountType t;
+    if (!parse_count_name(l, t)) throw std::runtime_error("invalid value '" + c + "' for '--count <count>'");
+    return {t};
+}
+
+// upload graph + order for one count type
+void upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order) {
+    ItemTable tab = g.item_table(ct);
+    const uint64_t n_items = g.number_of_items(ct);
+    dev.check(pnx_set_csr(dev.ctx, tab.items.data(), tab.id_prefsum.data(), (uint32_t)g.path_segments().size(),
+                          (uint32_t)n_items, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
+    dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
+                            (uint32_t)order.groups.size()));
+}
+
+std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order) {
+    upload(dev, g, ct, order);
+    std::vector<uint64_t> hist(order.groups.size() + 1, 0);
+    dev.check(pnx_hist(dev.ctx, nullptr, hist.data()));
+    return hist;
+}
+
+std::vector<double> to_f64(const std::vector<uint64_t> &v) {
+    std::vector<double> o(v.size());
+    for (size_t i = 0; i < v.size(); ++i) o[i] = (double)v[i];
+    return o;
+}
+
+// Hist::calc_all_growths (hist.rs:68-87): NaN row 0 + one curve per threshold pair
+std::vector<std::vector<double>> all_growths(const std::vector<uint64_t> &hist, const ThresholdContainer &tc, unsigned threads) {
+    std::vector<std::vector<double>> out;
+    for (size_t t = 0; t < tc.coverage.size(); ++t) {
+        std::vector<double> g = calc_growth(hist, tc.coverage[t], tc.quorum[t], threads);
+        g.insert(g.begin(), std::numeric_limits<double>::quiet_NaN());
+        out.push_back(std::move(g));
+    }
+    return out;
+}
+
+void growth_headers(std::vector<std::vector<std::string>> &headers, const char *what, CountType ct, const ThresholdContainer &tc) {
+    for (size_t t = 0; t < tc.coverage.size(); ++t)
+        headers.push_back({what, count_name(ct), threshold_string(tc.coverage[t]), threshold_string(tc.quorum[t])});
+}
+
+GroupMode group_mode(const Options &o) {
+    if (o.by_haplotype) return GROUP_HAPLOTYPE;  // load_groups checks haplotype first (abacus.rs:248)
+    if (o.by_sample) return GROUP_SAMPLE;
+    if (!o.group_file.empty()) return GROUP_FILE;
+    return GROUP_PATHID;
+}
+
+std::string cmd_hist(const Options &o, const std::string &cmdline) {
+    std::vector<CountType> cts = count_types(o.count, true);
+    bool edges = false;
+    for (CountType c : cts) edges = edges || c == COUNT_EDGE;
+    auto g = GraphStorage::from_gfa(o.file, edges);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, "");
+    Device dev(o.device);
+    std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
+    std::vector<std::vector<double>> cols;
+    for (CountType c : cts) {
+        cols.push_back(to_f64(device_hist(dev, *g, c, order)));
+        headers.push_back({"hist", count_name(c), "", ""});
+    }
+    return metadata_comments(cmdline) + write_table(headers, cols);
+}
+
+// histgrowth (and growth on a GFA, which the reference restricts to node counts)
+std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool growth_cmd) {
+    ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
+    std::vector<CountType> cts = growth_cmd ? std::vector<CountType>{COUNT_NODE} : count_types(o.count, true);
+    bool edges = false;
+    for (CountType c : cts) edges = edges || c == COUNT_EDGE;
+    auto g = GraphStorage::from_gfa(o.file, edges);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, "");
+    Device dev(o.device);
+    std::vector<std::vector<uint64_t>> hists;
+    for (CountType c : cts) hists.push_back(device_hist(dev, *g, c, order));
+    std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
+    std::vector<std::vector<double>> cols;
+    if (o.add_hist)
+        for (size_t k = 0; k < cts.size(); ++k) {
+            cols.push_back(to_f64(hists[k]));
+            headers.push_back({"hist", count_name(cts[k]), "", ""});
+        }
+    for (size_t k = 0; k < cts.size(); ++k) {
+        for (auto &col : all_growths(hists[k], tc, (unsigned)o.threads)) cols.push_back(std::move(col));
+        growth_headers(headers, "growth", cts[k], tc);
+    }
+    return "# " + cmdline + "\n" + write_table(headers, cols);
+}
+
+// growth from a hist TSV (src/lib.rs:160-190, analyses/growth.rs:190-262): no GPU involved
+std::string cmd_growth_from_hist(const Options &o, const std::string &cmdline) {
+    if (o.by_sample || o.by_haplotype || !o.group_file.empty())
+        throw std::runtime_error("subset, exclude and groupby can only be used in graph mode (with a .gfa or .gfa.gz file)");
+    ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
+    ParsedHists ph = parse_hists(o.file);
+    std::string res;
+    for (const auto &c : ph.comments) res += c + "\n";
+    res += "# " + cmdline + "\n";
+    std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
+    std::vector<std::vector<double>> cols;
+    if (o.add_hist)
+        for (const auto &h : ph.hists) {
+            cols.push_back(to_f64(h.second));
+            headers.push_back({"hist", count_name(h.first), "", ""});
+        }
+    for (const auto &h : ph.hists) {
+        for (auto &col : all_growths(h.second, tc, (unsigned)o.threads)) cols.push_back(std::move(col));
+        growth_headers(headers, "growth", h.first, tc);
+    }
+    return res + write_table(headers, cols);
+}
+
+std::string cmd_ordered(const Options &o, const std::string &cmdline) {
+    ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
+    CountType ct = count_types(o.count, false)[0];
+    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file);
+    const uint32_t G = (uint32_t)order.groups.size();
+    const uint32_t T = (uint32_t)tc.coverage.size();
+    Device dev(o.device);
+    upload(dev, *g, ct, order);
+    // AbacusByGroup::calc_growth prologue (abacus.rs:997-998, 1009) in f64 on the host
+    std::vector<uint32_t> cov(T), qtab((size_t)T * G);
+    for (uint32_t t = 0; t < T; ++t) {
+        cov[t] = (uint32_t)std::max<uint64_t>(1, tc.coverage[t].to_absolute(G));
+        const double q = G ? std::max(0.0, tc.quorum[t].to_relative(G)) : 0.0;
+        for (uint32_t r = 0; r < G; ++r) qtab[(size_t)t * G + r] = (uint32_t)std::ceil(((double)r + 1.0) * q);
+    }
+    std::vector<uint64_t> res((size_t)T * G, 0);
+    if (G) dev.check(pnx_ordered_growth(dev.ctx, nullptr, 1, cov.data(), qtab.data(), T, res.data()));
+    std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
+    std::vector<std::vector<double>> cols;
+    for (uint32_t t = 0; t < T; ++t) {
+        std::vector<double> col(G + 1);
+        col[0] = std::numeric_limits<double>::quiet_NaN();
+        for (uint32_t j = 0; j < G; ++j) col[j + 1] = (double)res[(size_t)t * G + j];
+        cols.push_back(std::move(col));
+    }
+    growth_headers(headers, "ordered-growth", ct, tc);
+    return metadata_comments(cmdline) + write_ordered_table(headers, cols, order.groups);
+}
+
+bool ends_with(const std::string &s, const std::string &suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+}  // namespace
+
+int run_cli(const std::vector<std::string> &argv, std::string &out, std::string &err) {
+    std::string cmdline;
+    for (size_t i = 0; i < argv.size(); ++i) cmdline += (i ? " " : "") + argv[i];
+    if (argv.size() < 2 || argv[1] == "-h" || argv[1] == "--help") {
+        out = USAGE;
+        return argv.size() < 2 ? 2 : 0;
+    }
+    Options o;
+    o.cmd = argv[1];
+    if (const char *d = std::getenv("PANACUS_AMD_DEVICE")) o.device = std::atoi(d);
+    try {
+        for (size_t i = 2; i < argv.size(); ++i) {
+            const std::string &a = argv[i];
+            auto value = [&](const char *name) -> std::string {
+                if (i + 1 >= argv.size()) throw std::runtime_error(std::string("option ") + name + " needs a value");
+                return argv[++i];
+            };
+            if (a == "-c" || a == "--count") o.count = value("--count");
+            else if (a == "-l" || a == "--coverage") o.coverage = value("--coverage");
+            else if (a == "-q" || a == "--quorum") o.quorum = value("--quorum");
+            else if (a == "-g" || a == "--groupby") o.group_file = value("--groupby");
+            else if (a == "-O" || a == "--order") o.order_file = value("--order");
+            else if (a == "-t" || a == "--threads") o.threads = std::atoi(value("--threads").c_str());
+            else if (a == "--device") o.device = std::atoi(value("--device").c_str());
+            else if (a == "-a" || a == "--hist") o.add_hist = true;
+            else if (a == "-S" || a == "--groupby-sample") o.by_sample = true;
+            else if (a == "-H" || a == "--groupby-haplotype") o.by_haplotype = true;
+            else if (a == "-s" || a == "--subset" || a == "-e" || a == "--exclude")
+                throw std::runtime_error("subset / exclude lists are not supported by panacus-amd yet");
+            else if (!a.empty() && a[0] == '-' && a.size() > 1) throw std::runtime_error("unknown option " + a);
+            else if (o.file.empty()) o.file = a;
+            else throw std::runtime_error("unexpected argument " + a);
+        }
+        if (o.file.empty()) throw std::runtime_error("missing input file");
+        if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
+        std::string table;
+        if (o.cmd == "hist") table = cmd_hist(o, cmdline);
+        else if (o.cmd == "histgrowth") table = cmd_histgrowth(o, cmdline, false);
+        else if (o.cmd == "growth") table = ends_with(o.file, "tsv") ? cmd_growth_from_hist(o, cmdline) : cmd_histgrowth(o, cmdline, true);
+        else if (o.cmd == "ordered-histgrowth") table = cmd_ordered(o, cmdline);
+        else throw std::runtime_error("unknown subcommand '" + o.cmd + "'\n" + USAGE);
+        out = table + "\n";  // writeln!(out, "{table}") in src/lib.rs:322
+        return 0;
+    } catch (const std::exception &e) {
+        err = std::string("error: ") + e.what() + "\n";
+        return 1;
+    }
+}
+
+}  // namespace pnh

@@ -8,7 +8,9 @@
 #include <string>
 #include <vector>
 
+#include "commands.hpp"
 #include "gfa_graph.hpp"
+#include "tables.hpp"
 #include "growth_closed_form.hpp"
 #include "thread_pool.hpp"
 
@@ -137,6 +139,47 @@ int64_t pnh_calc_all_growths(const uint64_t *hist, uint64_t hist_len, const int 
 
 void pnh_set_threads(unsigned n) { pnh::ThreadPool::instance().set_threads(n); }
 unsigned pnh_get_threads(void) { return pnh::ThreadPool::instance().size(); }
+
+// run the CLI in-process: argv joined by '\n'. Output / error text are copied into the buffers
+// (NUL-terminated, truncated); returns the exit code, *out_len / *err_len get the full lengths.
+int pnh_run_cli(const char *argv_joined, char *out_buf, uint64_t out_cap, uint64_t *out_len, char *err_buf,
+                uint64_t err_cap, uint64_t *err_len) {
+    std::vector<std::string> argv;
+    std::string cur;
+    for (const char *p = argv_joined; *p; ++p) {
+        if (*p == '\n') {
+            argv.push_back(cur);
+            cur.clear();
+        } else {
+            cur += *p;
+        }
+    }
+    argv.push_back(cur);
+    std::string out, err;
+    int rc = pnh::run_cli(argv, out, err);
+    auto put = [](const std::string &s, char *buf, uint64_t cap, uint64_t *len) {
+        if (len) *len = s.size();
+        if (buf && cap) {
+            size_t n = std::min<size_t>(s.size(), cap - 1);
+            std::memcpy(buf, s.data(), n);
+            buf[n] = 0;
+        }
+    };
+    put(out, out_buf, out_cap, out_len);
+    put(err, err_buf, err_cap, err_len);
+    return rc;
+}
+
+// Rust `{}` formatting of an f64 (tables.cpp), for tests
+uint64_t pnh_format_f64(double x, char *buf, uint64_t cap) {
+    std::string s = pnh::format_f64(x);
+    if (cap) {
+        size_t n = std::min<size_t>(s.size(), cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
 
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
 

@@ -172,3 +172,33 @@ class GfaGraph:
             raise ValueError(self._L.pnh_last_error().decode())
         names = buf.value.decode().split("\n") if ng else []
         return pi[: n_out.value].copy(), gi[: n_out.value].copy(), names
+
+
+# ---------------------------------------------------------------------------------------------
+# CLI in-process (panacus_amd/host/commands.cpp) and table helpers
+# ---------------------------------------------------------------------------------------------
+def run_cli(args):
+    """Runs `panacus-amd <args...>` inside this process. -> (exit_code, stdout_text, stderr_text)"""
+    L = load()
+    L.pnh_run_cli.restype = C.c_int
+    L.pnh_run_cli.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64,
+                              C.POINTER(C.c_uint64)]
+    joined = "\n".join(["panacus-amd"] + [str(a) for a in args]).encode()
+    cap = 1 << 22
+    while True:
+        out, err = C.create_string_buffer(cap), C.create_string_buffer(1 << 16)
+        ol, el = C.c_uint64(0), C.c_uint64(0)
+        rc = L.pnh_run_cli(joined, out, cap, C.byref(ol), err, 1 << 16, C.byref(el))
+        if ol.value + 1 > cap:
+            cap = ol.value + 16
+            continue
+        return rc, out.value.decode(), err.value.decode()
+
+
+def format_f64(x: float) -> str:
+    L = load()
+    L.pnh_format_f64.restype = C.c_uint64
+    L.pnh_format_f64.argtypes = [C.c_double, C.c_char_p, C.c_uint64]
+    buf = C.create_string_buffer(512)
+    L.pnh_format_f64(float(x), buf, 512)
+    return buf.value.decode()

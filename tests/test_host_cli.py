@@ -1,0 +1,139 @@
+"""CLI surface (panacus_amd/host/commands.cpp, tables.cpp): TSV shapes of SURVEY.md Appendix B,
+threshold parsing, growth from a hist TSV (host only), and the GPU commands (marked gpu)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from panacus_amd import hostlib as hl
+from panacus_amd import thresholds as th
+
+
+def _body(text):
+    """table without the '#' comment lines"""
+    return "\n".join(l for l in text.split("\n") if not l.startswith("#"))
+
+
+def test_format_f64_like_rust():
+    for x, s in [(0.0, "0"), (1.0, "1"), (0.5, "0.5"), (0.1, "0.1"), (1e-5, "0.00001"), (123456789.0, "123456789"),
+                 (1e21, "1000000000000000000000"), (2.5e-7, "0.00000025"), (float("nan"), "NaN"), (-3.0, "-3"),
+                 (0.30000000000000004, "0.30000000000000004"), (16569.0, "16569")]:
+        assert hl.format_f64(x) == s
+        assert th.format_f64(x) == s
+
+
+def test_threshold_container():
+    tc = th.ThresholdContainer.parse_params("0,0.5,1.0", "1")
+    assert [t.value for t in tc.coverage] == [1, 1, 1]
+    assert [t.get_string() for t in tc.quorum] == ["0", "0.5", "1"]
+    with pytest.raises(ValueError):
+        th.ThresholdContainer.parse_params("0,0.5", "1,2,3")
+    with pytest.raises(ValueError):
+        th.ThresholdContainer.parse_params("1.5", "1")
+    with pytest.raises(ValueError):
+        th.ThresholdContainer.parse_params("0", "0.5")
+
+
+def test_growth_from_hist_tsv(golden_dir):
+    # src/lib.rs:160-190: `growth hist.tsv` never touches the graph (or the GPU)
+    rc, out, err = hl.run_cli(["growth", os.path.join(golden_dir, "t_groups.hist.tsv"), "-l", "1,2", "-q", "0,0.5", "-a"])
+    assert rc == 0, err
+    lines = out.split("\n")
+    assert lines[0].startswith("# target/debug/panacus hist")  # comment of the input is kept
+    assert lines[1].startswith("# panacus-amd growth")
+    assert lines[2:6] == ["panacus\thist\tgrowth\tgrowth", "count\tnode\tnode\tnode", "coverage\t\t1\t2", "quorum\t\t0\t0.5"]
+    hist = [5, 0, 10, 0, 0, 0, 0]
+    exp = [orc.growth(hist, (orc.ABSOLUTE, c), (orc.RELATIVE, q)) for c, q in ((1, 0.0), (2, 0.5))]
+    assert lines[6] == "0\t5\tNaN\tNaN"
+    for i in range(1, 7):
+        cells = lines[6 + i].split("\t")
+        assert cells == [str(i), str(hist[i])] + [hl.format_f64(math.floor(e[i - 1])) for e in exp]
+    assert out.endswith("\n\n")  # writeln!(out, "{table}")
+
+
+def test_growth_from_hist_errors(tmp_path, golden_dir):
+    rc, out, err = hl.run_cli(["growth", os.path.join(golden_dir, "t_groups.hist.tsv"), "-S"])
+    assert rc == 1 and "graph mode" in err
+    bad = tmp_path / "x.tsv"
+    bad.write_text("foo\tbar\n1\t2\n")
+    rc, out, err = hl.run_cli(["growth", str(bad)])
+    assert rc == 1
+    rc, out, err = hl.run_cli(["nosuch", "x"])
+    assert rc == 1 and "unknown subcommand" in err
+    rc, out, err = hl.run_cli(["hist", "-s", "x", "y.gfa"])
+    assert rc == 1 and "not supported" in err
+
+
+def test_gpu_commands_fail_loudly_without_gpu(golden_dir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, out, err = hl.run_cli(["hist", os.path.join(golden_dir, "chrM_test.gfa")])
+    assert rc == 1 and "no CPU fallback" in err
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_cli_hist_chrM(golden_dir):
+    # SURVEY.md Appendix B
+    rc, out, err = hl.run_cli(["hist", "-S", os.path.join(golden_dir, "chrM_test.gfa")])
+    assert rc == 0, err
+    assert out.startswith("# panacus-amd hist -S ")
+    assert _body(out) == "panacus\thist\ncount\tnode\n\t\n\t\n0\t0\n1\t39\n2\t29\n3\t41\n4\t45\n\n"
+    rc, out, err = hl.run_cli(["hist", "-S", "-c", "all", os.path.join(golden_dir, "chrM_test.gfa")])
+    assert rc == 0, err
+    rows = _body(out).split("\n")
+    assert rows[0] == "panacus\thist\thist\thist" and rows[1] == "count\tnode\tbp\tedge"
+    assert rows[4:9] == ["0\t0\t0\t0", "1\t39\t616\t80", "2\t29\t31\t59", "3\t41\t601\t66", "4\t45\t15949\t0"]
+
+
+@pytest.mark.gpu
+def test_cli_histgrowth_chrM(golden_dir):
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    rc, out, err = hl.run_cli(["histgrowth", "-a", "-S", "-l", "1", "-q", "0", gfa])
+    assert rc == 0, err
+    assert _body(out) == ("panacus\thist\tgrowth\ncount\tnode\tnode\ncoverage\t\t1\nquorum\t\t0\n"
+                          "0\t0\tNaN\n1\t39\t100\n2\t29\t129\n3\t41\t144\n4\t45\t154\n\n")
+    # BASELINE cfg1: histgrowth chrM -c node -l 1 (group = path id)
+    rc, out, err = hl.run_cli(["histgrowth", "-c", "node", "-l", "1", gfa])
+    assert rc == 0, err
+    assert [r.split("\t")[1] for r in _body(out).split("\n")[5:9]] == ["100", "129", "144", "154"]
+    # integrated_test.R grid: -S|-H x node|edge x -q 0,0.5,1.0 -l 0,1,2 against the oracle
+    for grp, gm in (("-S", orc.GROUP_SAMPLE), ("-H", orc.GROUP_HAPLOTYPE)):
+        for cname, ct in (("node", orc.NODE), ("edge", orc.EDGE), ("bp", orc.BP)):
+            rc, out, err = hl.run_cli(["histgrowth", grp, "-c", cname, "-q", "0,0.5,1.0", "-l", "0,1,2", "-a", gfa])
+            assert rc == 0, err
+            g = orc.Graph(gfa, index_edges=True)
+            pi, gi, names = g.path_order(gm)
+            items, pre = g.item_table(ct)
+            cov = orc.coverage(items, pre, pi, gi, g.n_items(ct))
+            h = orc.hist(cov, len(names), g.node_lens if ct == orc.BP else None)
+            rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+            assert [int(r[1]) for r in rows] == h.tolist()
+            for k, (c, q) in enumerate(((0, 0.0), (1, 0.5), (2, 1.0))):
+                exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+                assert [r[2 + k] for r in rows[1:]] == [hl.format_f64(math.floor(x)) for x in exp]
+
+
+@pytest.mark.gpu
+def test_cli_ordered_histgrowth_chrM(golden_dir, tmp_path):
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    rc, out, err = hl.run_cli(["ordered-histgrowth", "-S", gfa])
+    assert rc == 0, err
+    assert _body(out) == ("panacus\tordered-growth\ncount\tnode\ncoverage\t1\nquorum\t0\n"
+                          "chm13\t89\ngrch38\t106\nHG00438\t140\nHG00621\t154\n\n")
+    order = tmp_path / "order.txt"
+    order.write_text("HG00621\nchm13\nHG00438\ngrch38\n")
+    rc, out, err = hl.run_cli(["ordered-histgrowth", "-S", "-c", "bp", "-l", "1,2", "-q", "0,0.5", "-O", str(order), gfa])
+    assert rc == 0, err
+    g = orc.Graph(gfa)
+    pi, gi, names = g.path_order(orc.GROUP_SAMPLE, None, str(order))
+    items, pre = g.item_table(orc.BP)
+    r, c = orc.by_group(items, pre, pi, gi, g.n_nodes)
+    rows = [x.split("\t") for x in _body(out).split("\n")[4:] if x]
+    assert [x[0] for x in rows] == names == ["HG00621", "chm13", "HG00438", "grch38"]
+    for k, (cv, q) in enumerate(((1, 0.0), (2, 0.5))):
+        exp = orc.ordered_growth(r, c, 4, (orc.ABSOLUTE, cv), (orc.RELATIVE, q), g.node_lens)
+        assert [x[1 + k] for x in rows] == [str(int(v)) for v in exp]
