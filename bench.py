@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--paths", type=int, default=256)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--tile-blocks", type=int, default=1)
+    ap.add_argument("--cover-variant", type=int, default=None)
+    ap.add_argument("--index-coarse", type=int, default=None)
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
@@ -112,6 +114,10 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
     ctx.config(capi.CFG_CACHE_INDEX, 0)
+    if args.index_coarse is not None:
+        ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
+    if args.cover_variant is not None:
+        ctx.config(capi.CFG_COVER_VARIANT, args.cover_variant)
     ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
     order = np.arange(P, dtype=np.uint32)
     ctx.set_order(order, order, P)

@@ -141,8 +141,13 @@ enum {
                                   same graph; 0: rebuild it in every call (benchmark honesty:
                                   the index is then part of every timed pass) */
     PNX_CFG_TILE_BLOCKS = 2,   /* 1 or 2 blocks of 2048 items per coverage tile (default 1) */
-    PNX_CFG_KEEP_PRESENCE = 3  /* 1: pnx_hist also leaves the presence bit matrix in HBM
+    PNX_CFG_KEEP_PRESENCE = 3, /* 1: pnx_hist also leaves the presence bit matrix in HBM
                                   (default 0; pnx_ordered_growth turns it on by itself) */
+    PNX_CFG_INDEX_COARSE = 5,  /* every n-th tile boundary is found by a full binary search, the
+                                  ones in between by interpolation inside that bracket [8];
+                                  1 = plain binary search for all */
+    PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain, 1 software-pipelined (two segments
+                                  in flight per wave), 2 pipelined + non-temporal CSR loads */
 };
 int pnx_config(pnx_ctx *ctx, int key, int64_t value);
 

@@ -52,41 +52,121 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: tile boundary index.  B[p][t] = path_off[p] + (#steps of p "before" tile t), where
+// K0: tile boundary index (two passes, see k_tile_index_coarse / k_tile_index_fine).  B[p][t] = path_off[p] + (#steps of p "before" tile t), where
 // "before" means id < t*tile_items for an ascending path and id >= t*tile_items for a
 // descending one (direction = first step vs last step).  For a tile-monotone path the steps
 // of tile t are exactly [min(B[t],B[t+1]), max(B[t],B[t+1])).
 // ------------------------------------------------------------------------------------------
-__global__ void k_tile_index(const uint32_t *__restrict__ items,
-                             const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                             uint32_t n_tiles, uint32_t tile_items, uint64_t *__restrict__ B) {
+template <bool ASC>
+__device__ static inline bool before_key(uint32_t v, uint64_t key) {
+    return ASC ? ((uint64_t)v < key) : ((uint64_t)v >= key);
+}
+
+// number of leading elements of a[lo..hi) (absolute indices) that are "before" key, + lo
+template <bool ASC>
+__device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a, uint64_t lo, uint64_t hi, uint64_t key) {
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (before_key<ASC>(a[mid], key)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// K0 pass A: exact boundaries for every `coarse`-th tile (and the last one), full binary search
+__global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
+                                    const uint64_t *__restrict__ path_off, uint32_t n_paths,
+                                    uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
+                                    uint64_t *__restrict__ B) {
+    const uint32_t n_coarse = (n_tiles + coarse - 1) / coarse + 1;  // t = 0, c, 2c, ..., n_tiles
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t per = (uint64_t)n_tiles + 1;
-    if (gid >= per * n_paths) return;
-    uint32_t p = (uint32_t)(gid / per);
-    uint32_t t = (uint32_t)(gid % per);
-    uint64_t s = path_off[p], e = path_off[p + 1];
-    uint64_t len = e - s;
-    if (len == 0) {
-        B[gid] = s;
+    if (gid >= (uint64_t)n_coarse * n_paths) return;
+    const uint32_t p = (uint32_t)(gid / n_coarse);
+    uint32_t t = (uint32_t)(gid % n_coarse) * coarse;
+    if (t > n_tiles) t = n_tiles;
+    const uint64_t s = path_off[p], e = path_off[p + 1];
+    uint64_t *out = B + (uint64_t)p * (n_tiles + 1) + t;
+    if (e == s) {
+        *out = s;
         return;
     }
-    const uint32_t *a = items + s;
-    bool asc = a[0] <= a[len - 1];
-    uint64_t key = (uint64_t)t * tile_items;
-    uint64_t lo = 0, hi = len;
-    if (asc) {
-        while (lo < hi) {
-            uint64_t mid = (lo + hi) >> 1;
-            if ((uint64_t)a[mid] < key) lo = mid + 1; else hi = mid;
-        }
-    } else {
-        while (lo < hi) {
-            uint64_t mid = (lo + hi) >> 1;
-            if ((uint64_t)a[mid] >= key) lo = mid + 1; else hi = mid;
-        }
+    const bool asc = items[s] <= items[e - 1];
+    const uint64_t key = (uint64_t)t * tile_items;
+    *out = asc ? bsearch_before<true>(items, s, e, key) : bsearch_before<false>(items, s, e, key);
+}
+
+// K0 pass B: the boundaries in between, by interpolation inside the bracket of the two
+// enclosing coarse boundaries + galloping + a short binary search.  For a tile-monotone
+// path this touches 2-4 cache lines instead of ~10 (the probes of a full binary search are
+// what made the one-pass index HBM-bound).  For any other path the result is still a
+// monotone sequence inside the bracket, so the (path, tile) segments always partition the
+// path; K1's per-step in-tile check then catches every misplaced step.
+__global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
+                                  const uint64_t *__restrict__ path_off, uint32_t n_paths,
+                                  uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
+                                  uint64_t *__restrict__ B, uint8_t *path_class) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per = (uint64_t)n_tiles + 1;
+    if (gid >= per * n_paths) return;
+    const uint32_t p = (uint32_t)(gid / per);
+    const uint32_t t = (uint32_t)(gid % per);
+    if (t % coarse == 0 || t == n_tiles) return;  // done by pass A
+    const uint32_t t0 = t - t % coarse;
+    const uint32_t t1 = t0 + coarse < n_tiles ? t0 + coarse : n_tiles;
+    const uint64_t s = path_off[p], e = path_off[p + 1];
+    uint64_t *row = B + (uint64_t)p * per;
+    if (e == s) {
+        row[t] = s;
+        return;
     }
-    B[gid] = s + lo;
+    const bool asc = items[s] <= items[e - 1];
+    uint64_t lo = row[t0], hi = row[t1];  // ascending: lo <= hi ; descending: lo >= hi
+    if (!asc) {
+        uint64_t tmp = lo;
+        lo = hi;
+        hi = tmp;
+    }
+    if (lo > hi) {  // coarse boundaries out of order: not tile-monotone
+        path_class[p] = 1;
+        row[t] = asc ? lo : hi;
+        return;
+    }
+    const uint64_t key = (uint64_t)t * tile_items;
+    if (lo < hi) {
+        // ascending: boundary of tile t sits (t-t0)/(t1-t0) into the bracket; descending: from the other end
+        const uint64_t num = asc ? (uint64_t)(t - t0) : (uint64_t)(t1 - t);
+        uint64_t pos = lo + (hi - lo) * num / (t1 - t0);
+        if (pos >= hi) pos = hi - 1;
+        uint64_t w = 16;
+        if (asc ? before_key<true>(items[pos], key) : before_key<false>(items[pos], key)) {
+            lo = pos + 1;
+            for (;;) {
+                const uint64_t q = lo + w - 1;
+                if (q >= hi) break;
+                if (asc ? before_key<true>(items[q], key) : before_key<false>(items[q], key)) {
+                    lo = q + 1;
+                    w <<= 1;
+                } else {
+                    hi = q;
+                    break;
+                }
+            }
+        } else {
+            hi = pos;
+            for (;;) {
+                if (hi - lo < w) break;
+                const uint64_t q = hi - w;
+                if (asc ? before_key<true>(items[q], key) : before_key<false>(items[q], key)) {
+                    lo = q + 1;
+                    break;
+                } else {
+                    hi = q;
+                    w <<= 1;
+                }
+            }
+        }
+        lo = asc ? bsearch_before<true>(items, lo, hi, key) : bsearch_before<false>(items, lo, hi, key);
+    }
+    row[t] = lo;
 }
 
 // boundaries of a tile-monotone path are monotone; anything else goes the scatter route
@@ -114,9 +194,19 @@ int launch_tile_index(pnx_ctx *ctx) {
     PNX_HIP(ctx, hipMemsetAsync(ctx->d_path_class.p, 0, ctx->n_paths ? ctx->n_paths : 1, ctx->stream));
     if (nb == 0) return PNX_OK;
     prof_begin(ctx, PNX_K_INDEX);
-    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
-                       ctx->n_paths, ctx->n_tiles, tile_items, (uint64_t *)ctx->d_tile_idx.p);
+    {
+        const uint32_t coarse = ctx->index_coarse ? ctx->index_coarse : 1;
+        const uint32_t n_coarse = (ctx->n_tiles + coarse - 1) / coarse + 1;
+        const uint64_t na = (uint64_t)n_coarse * ctx->n_paths;
+        hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
+                           ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p);
+        if (coarse > 1)
+            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
+                               ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p,
+                               (uint8_t *)ctx->d_path_class.p);
+    }
     uint64_t nc = (uint64_t)ctx->n_paths * ctx->n_tiles;
     hipLaunchKernelGGL(k_tile_index_check, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0,
                        ctx->stream, (const uint32_t *)ctx->d_items.p,
@@ -310,6 +400,178 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
 }
 
 // ------------------------------------------------------------------------------------------
+// K1, software-pipelined form: the 16-byte loads of segment k+1 (and its boundary pair) are
+// issued before the steps of segment k are folded into the LDS bitmap, so every wave keeps
+// two segments in flight and the HBM latency of one segment hides behind the VALU/LDS work
+// of the previous one.  NT selects non-temporal loads for the CSR stream (read exactly once).
+// ------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ static inline uint4 load_steps(const uint32_t *p) {
+    if (NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+template <int NPL, int WT, bool WRITE_M, bool NT>
+__global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover_pipe(
+    const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
+    const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
+    uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
+    const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags) {
+    constexpr uint32_t TILE = WT * BLOCK_ITEMS;
+    constexpr int U = COVER_UNROLL;
+    __shared__ uint32_t bm_all[COVER_WAVES][WT * BLOCK_WORDS];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x * COVER_WAVES + wave;
+    if (tile >= n_tiles) return;
+    uint32_t *bm = bm_all[wave];
+    const uint32_t tile_lo = tile * TILE;
+
+#pragma unroll
+    for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
+
+    uint32_t excl[WT];
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+        excl[w] = 0;
+        if (exclude) {
+            for (uint32_t b = 0; b < 32; ++b) {
+                uint64_t node = (uint64_t)tile_lo + (uint32_t)w * BLOCK_ITEMS + b * 64u + lane;
+                if (node <= n_items && exclude[node]) excl[w] |= 1u << b;
+            }
+        }
+    }
+
+    uint32_t cnt[NPL][WT];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k)
+#pragma unroll
+        for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
+
+    auto flush = [&](uint32_t g) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool merge = grp_general != nullptr && grp_general[g] != 0;
+#pragma unroll
+        for (int w = 0; w < WT; ++w) {
+            uint32_t x = bm[w * BLOCK_WORDS + lane];
+            bm[w * BLOCK_WORDS + lane] = 0;
+            const uint32_t blk = tile * WT + w;
+            if (blk < n_blocks) {
+                uint32_t *mw = M + (uint64_t)g * row_words + (uint64_t)blk * BLOCK_WORDS + lane;
+                if (merge) x |= *mw;
+                x &= ~excl[w];
+                if (WRITE_M) *mw = x;
+            }
+            uint32_t carry = x;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                uint32_t t = cnt[k][w] & carry;
+                cnt[k][w] ^= carry;
+                carry = t;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    auto fold = [&](const uint4 &v, uint64_t j, uint64_t lo, uint64_t hi, uint32_t &viol) {
+        const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint64_t idx = j + e;
+            if (idx >= lo && idx < hi) {
+                const uint32_t n = ids[e] - tile_lo;
+                if (n < TILE)
+                    atomicOr(&bm[(n & 63u) + ((n >> 11) << 6)], 1u << ((n >> 6) & 31u));
+                else
+                    viol = 1;
+            }
+        }
+    };
+
+    const uint64_t brow = (uint64_t)n_tiles + 1;
+    // prefetch state of the NEXT entry
+    uint4 nxt[U];
+    uint64_t n_lo = 0, n_hi = 0;
+    bool n_act = false;
+    auto issue = [&](uint32_t k) {
+        const uint32_t p = ord_path[k];
+        n_act = path_class[p] == 0;
+        const uint64_t ba = B[(uint64_t)p * brow + tile], bb = B[(uint64_t)p * brow + tile + 1];
+        n_lo = ba < bb ? ba : bb;
+        n_hi = ba < bb ? bb : ba;
+        if (!n_act) n_hi = n_lo;
+        const uint64_t base = n_lo & ~3ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
+            nxt[u] = make_uint4(0, 0, 0, 0);
+            if (j < n_hi) nxt[u] = load_steps<NT>(items + j);
+        }
+    };
+
+    uint32_t cur_g = n_ordered ? ord_group[0] : 0;
+    if (n_ordered) issue(0);
+    for (uint32_t k = 0; k < n_ordered; ++k) {
+        uint4 cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        const uint64_t lo = n_lo, hi = n_hi;
+        const uint32_t g = ord_group[k];
+        if (k + 1 < n_ordered) issue(k + 1);
+        if (g != cur_g) {
+            flush(cur_g);
+            cur_g = g;
+        }
+        if (hi > lo) {
+            uint32_t viol = 0;
+            const uint64_t base = lo & ~3ull;
+#pragma unroll
+            for (int u = 0; u < U; ++u) fold(cur[u], base + (uint64_t)u * 256 + lane * 4u, lo, hi, viol);
+            // long segments (> U*256 steps): the tail is streamed directly
+            for (uint64_t b2 = base + 256ull * U; b2 < hi; b2 += 256ull * U) {
+                uint4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint64_t j = b2 + (uint64_t)u * 256 + lane * 4u;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (j < hi) v[u] = load_steps<NT>(items + j);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) fold(v[u], b2 + (uint64_t)u * 256 + lane * 4u, lo, hi, viol);
+            }
+            if (__any(viol)) {
+                if (lane == 0) {
+                    path_class[ord_path[k]] = 1;
+                    atomicAdd(&flags[0], 1u);
+                }
+            }
+        }
+    }
+    if (n_ordered) flush(cur_g);
+
+#pragma unroll
+    for (int w = 0; w < WT; ++w) {
+        const uint32_t blk = tile * WT + w;
+        if (blk >= n_blocks) break;
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) v |= ((cnt[k][w] >> b) & 1u) << k;
+            const uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
+            if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: histogram of the coverage vector (construct_hist / construct_hist_bps)
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t HIST_LDS_BINS = 4096;
@@ -357,7 +619,16 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
                            (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_flags.p);
     };
-    if (write_m) args(k_tile_cover<NPL, WT, true>); else args(k_tile_cover<NPL, WT, false>);
+    switch (ctx->cover_variant) {
+        case 1:
+            if (write_m) args(k_tile_cover_pipe<NPL, WT, true, false>); else args(k_tile_cover_pipe<NPL, WT, false, false>);
+            break;
+        case 2:
+            if (write_m) args(k_tile_cover_pipe<NPL, WT, true, true>); else args(k_tile_cover_pipe<NPL, WT, false, true>);
+            break;
+        default:
+            if (write_m) args(k_tile_cover<NPL, WT, true>); else args(k_tile_cover<NPL, WT, false>);
+    }
 }
 
 template <int WT>

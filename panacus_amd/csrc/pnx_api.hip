@@ -467,6 +467,15 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
                 ctx->last_general_paths = keep;
             }
             return PNX_OK;
+        case PNX_CFG_COVER_VARIANT:
+            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover variant must be 0, 1 or 2");
+            ctx->cover_variant = (int)value;
+            return PNX_OK;
+        case PNX_CFG_INDEX_COARSE:
+            if (value < 1 || value > 4096) return ctx->fail(PNX_EINVAL, "index_coarse must be in 1..4096");
+            ctx->index_coarse = (uint32_t)value;
+            ctx->index_valid = false;
+            return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:
             ctx->want_M = value != 0;
             if (!ctx->want_M) ctx->M_valid = false;

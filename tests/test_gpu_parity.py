@@ -341,3 +341,39 @@ def test_properties_large(ctx):
     curve = out[0, 0]
     assert int(curve[-1]) == n - int(h[0])
     assert np.all(np.diff(curve.astype(np.int64)) >= 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# every kernel variant / index setting gives the same exact answer
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("coarse", [1, 3, 8, 64])
+def test_variants_agree_with_oracle(ctx, variant, coarse):
+    from panacus_amd import capi
+    n, p = 150_000, 20
+    items, pre, lens = orc.pansyn(17, n, p)
+    rng = np.random.default_rng(3)
+    items = items.copy()
+    rng.shuffle(items[pre[6]:pre[7]])           # one general path
+    items[pre[9] + 1000] = items[pre[9] + 5]     # one late outlier in an otherwise sorted path
+    ctx.config(capi.CFG_COVER_VARIANT, variant)
+    ctx.config(capi.CFG_INDEX_COARSE, coarse)
+    try:
+        ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens)
+        pi = np.arange(p, dtype=np.uint64)
+        gi = (pi // 2).astype(np.uint64)
+        ctx.set_order(pi, gi, 10)
+        cnt, h = ctx.hist()
+        ocov, oh = _oracle_hist(items, pre, pi, gi, n, 10, lens)
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+        # long segments (> 1024 steps per tile and path): dense paths with every step doubled
+        dense = np.repeat(np.arange(1, 6001, dtype=np.uint64), 2)
+        items2 = np.concatenate([dense, dense[::-1]])
+        pre2 = np.array([0, len(dense), 2 * len(dense)], dtype=np.uint64)
+        ctx.set_csr(items2.astype(np.uint32), pre2, 6000)
+        ctx.set_order(np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), 2)
+        cnt, h = ctx.hist()
+        assert h.tolist() == [0, 0, 6000] and cnt[1:].tolist() == [2] * 6000
+    finally:
+        ctx.config(capi.CFG_COVER_VARIANT, 0)
+        ctx.config(capi.CFG_INDEX_COARSE, 8)
