@@ -145,7 +145,7 @@ def main():
     def growth(h):
         if rank != 0:
             return None
-        return [hostlib.calc_growth(h, c, q, args.growth_threads) for c, q in thr]
+        return hostlib.calc_growths(h, thr, args.growth_threads)
 
     def run(n_steps):
         """n_steps complete histgrowth passes.  Consecutive passes are independent, so the
@@ -195,8 +195,7 @@ def main():
     if rank == 0:
         g0 = time.perf_counter()
         for _ in range(3):
-            for c, q in thr:
-                hostlib.calc_growth(h, c, q, args.growth_threads)
+            hostlib.calc_growths(h, thr, args.growth_threads)
         growth_ms = (time.perf_counter() - g0) / 3 * 1e3
 
     if rank == 0:

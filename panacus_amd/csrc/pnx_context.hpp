@@ -67,7 +67,7 @@ struct pnx_ctx {
     // ---- tile index over the CSR (K0) ----
     uint32_t tile_blocks = 1;  // blocks per coverage tile (WT)
     uint32_t index_coarse = 8; // every index_coarse-th tile boundary is searched exactly (K0 pass A)
-    int cover_variant = 0;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads
+    int cover_variant = 2;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads
     uint32_t n_blocks = 0, n_tiles = 0;
     bool index_valid = false;
     bool cache_index = true;

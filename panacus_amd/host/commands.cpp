@@ -87,12 +87,8 @@ std::vector<double> to_f64(const std::vector<uint64_t> &v) {
 
 // Hist::calc_all_growths (hist.rs:68-87): NaN row 0 + one curve per threshold pair
 std::vector<std::vector<double>> all_growths(const std::vector<uint64_t> &hist, const ThresholdContainer &tc, unsigned threads) {
-    std::vector<std::vector<double>> out;
-    for (size_t t = 0; t < tc.coverage.size(); ++t) {
-        std::vector<double> g = calc_growth(hist, tc.coverage[t], tc.quorum[t], threads);
-        g.insert(g.begin(), std::numeric_limits<double>::quiet_NaN());
-        out.push_back(std::move(g));
-    }
+    std::vector<std::vector<double>> out = calc_all_growths(hist, tc.coverage, tc.quorum, threads);
+    for (auto &g : out) g.insert(g.begin(), std::numeric_limits<double>::quiet_NaN());
     return out;
 }
 

@@ -1,9 +1,19 @@
 // growth_closed_form.cpp -- see growth_closed_form.hpp.
+//
+// Structure: every (histogram, coverage, quorum) evaluation is a "job" = cheap serial
+// prologue + independent row tasks + cheap serial epilogue.  The rows are the histogram
+// index i: all state the reference carries from one m to the next (perc_mult[i], Q[i][*])
+// lives inside a row, so rows can run on any thread in any order; the sums over i are then
+// taken serially in ascending i, exactly like the reference's loops, which keeps every
+// result bit-identical to the serial Rust code (same libm calls on the same arguments, same
+// addition order).  All jobs of a calc_all_growths call are flattened into ONE parallel
+// region so the pool is entered once per histogram, not once per branch.
 #include "growth_closed_form.hpp"
 
 #include <algorithm>
 #include <cmath>
-#include <thread>
+#include <functional>
+#include <memory>
 
 #include "thread_pool.hpp"
 
@@ -18,18 +28,6 @@ double Threshold::to_relative(uint64_t n) const {
     return (double)(uint64_t)value / (double)n;
 }
 
-namespace {
-// log2 of the integers 0..m as f64: the same libm call on the same argument the reference
-// makes, hoisted out of the loops (log2(0) = -inf, which the formulas rely on).
-struct Log2Table {
-    std::vector<double> v;
-    explicit Log2Table(uint64_t m) : v(m + 1) {
-        for (uint64_t i = 0; i <= m; ++i) v[i] = std::log2((double)i);
-    }
-    double operator()(uint64_t i) const { return v[i]; }
-};
-}  // namespace
-
 double choose_log2(uint64_t n, uint64_t k) {
     if (k > n) return 0.0;
     if (k > n - k) k = n - k;
@@ -42,176 +40,223 @@ double choose_log2(uint64_t n, uint64_t k) {
     return res;
 }
 
-// Both O(n^2) branches share one shape: per histogram index i a running perc_mult[i]
-// (sequential in m), per m a sum over i in ascending order.  Rows i are independent, so
-// they are cut into chunks for the pool; each chunk fills term[m][i], and the sums over i
-// are then taken serially in the reference's order -- bit-identical to the serial loops.
 namespace {
-template <class RowRange, class Incr>
-void two_level(uint64_t n, const std::vector<double> &lh, const std::vector<double> &n_fall, RowRange row_active,
-               Incr incr, unsigned n_threads, std::vector<double> &term) {
-    // term is (n+1) x (n+1), stored [i][m]: a thread owns whole rows, so no cache line is shared
-    auto work = [&](uint64_t i_lo, uint64_t i_hi) {
-        for (uint64_t i = i_lo; i < i_hi; ++i) {
-            double pm = 0.0;
-            for (uint64_t m = 1; m <= n; ++m) {
-                if (!row_active(i, m)) continue;
-                pm += incr(i, m);
-                term[i * (n + 1) + m] = std::exp2(lh[i] + pm - n_fall[m]);
+
+// log2 of the integers 0..m as f64: the same libm call on the same argument the reference
+// makes, hoisted out of the loops (log2(0) = -inf, which the formulas rely on).
+struct Log2Table {
+    std::vector<double> v;
+    explicit Log2Table(uint64_t m) : v(m + 1) {
+        for (uint64_t i = 0; i <= m; ++i) v[i] = std::log2((double)i);
+    }
+    double operator()(uint64_t i) const { return v[i]; }
+};
+
+enum Branch { UNION, CORE, QUORUM };
+
+struct Job {
+    Branch branch;
+    uint64_t n, c;
+    double quorum = 0.0;
+    const std::vector<uint64_t> &hist;
+    std::shared_ptr<Log2Table> lg;
+    std::vector<double> lh, n_fall, m_fact;
+    std::vector<uint64_t> m_quorum;
+    double tot = 0.0;
+    // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
+    // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
+    std::vector<double> term1, term2;
+    std::vector<double> out;
+
+    Job(Branch b, const std::vector<uint64_t> &h, Threshold cov, Threshold quo, std::shared_ptr<Log2Table> tab)
+        : branch(b), n(h.size() - 1), hist(h), lg(std::move(tab)) {
+        // hist.rs:91, :118, :142 -- core converts the coverage threshold against n + 1
+        c = std::max<uint64_t>(1, cov.to_absolute(b == CORE ? n + 1 : n));
+        if (b == QUORUM) quorum = quo.to_relative(n);
+        lh.resize(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
+        n_fall.assign(n + 1, 0.0);
+        m_fact.assign(n + 1, 0.0);
+        m_quorum.assign(n + 1, 0);
+        const Log2Table &L = *lg;
+        for (uint64_t m = 1; m <= n; ++m) {
+            n_fall[m] = n_fall[m - 1] + L(n - m + 1);
+            if (b == QUORUM) {
+                m_fact[m] = m_fact[m - 1] + L(m);
+                m_quorum[m] = (uint64_t)std::ceil((double)m * quorum);
             }
         }
-    };
-    const uint64_t rows = n + 1;
-    if (n < 96) {
-        work(0, rows);
-        return;
-    }
-    const size_t chunks = 64;
-    ThreadPool::instance().parallel_for(
-        chunks, [&](size_t k) { work(rows * k / chunks, rows * (k + 1) / chunks); }, n_threads);
-}
-}  // namespace
-
-std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
-    const uint64_t n = hist.size() - 1;
-    const uint64_t c = std::max<uint64_t>(1, coverage.to_absolute(n));
-    std::vector<double> out(n, 0.0), lh(n + 1), n_fall(n + 1, 0.0);
-    Log2Table lg(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
-    uint64_t tot_i = 0;
-    for (uint64_t i = c; i <= n; ++i) tot_i += hist[i];
-    const double tot = (double)tot_i;
-    for (uint64_t m = 1; m <= n; ++m) n_fall[m] = n_fall[m - 1] + lg(n - m + 1);
-    std::vector<double> term((n + 1) * (n + 1), 0.0);
-    // hist.rs:102-111: for i in c..n-m+1 { perc_mult[i] += log2(n-m-i+1); y += exp2(..) }
-    two_level(
-        n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= c && i + m <= n; },
-        [&](uint64_t i, uint64_t m) { return lg(n - m - i + 1); }, n_threads, term);
-    for (uint64_t m = 1; m <= n; ++m) {
-        double y = 0.0;
-        for (uint64_t i = c; i + m <= n; ++i) y += term[i * (n + 1) + m];
-        out[m - 1] = tot - y;
-    }
-    return out;
-}
-
-std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
-    const uint64_t n = hist.size() - 1;
-    const uint64_t c = std::max<uint64_t>(1, coverage.to_absolute(n + 1));
-    std::vector<double> out(n, 0.0), lh(n + 1), n_fall(n + 1, 0.0);
-    Log2Table lg(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
-    for (uint64_t m = 1; m <= n; ++m) n_fall[m] = n_fall[m - 1] + lg(n - m + 1);
-    std::vector<double> term((n + 1) * (n + 1), 0.0);
-    // hist.rs:127-135: for i in max(m,c)..n+1 { perc_mult[i] += log2(i-m+1); y += exp2(..) }
-    two_level(
-        n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= std::max(m, c); },
-        [&](uint64_t i, uint64_t m) { return lg(i - m + 1); }, n_threads, term);
-    for (uint64_t m = 1; m <= n; ++m) {
-        double y = 0.0;
-        for (uint64_t i = std::max(m, c); i <= n; ++i) y += term[i * (n + 1) + m];
-        out[m - 1] = y;
-    }
-    return out;
-}
-
-std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum_t,
-                                       unsigned n_threads) {
-    const uint64_t n = hist.size() - 1;
-    const uint64_t c = std::max<uint64_t>(1, coverage.to_absolute(n));
-    const double quorum = quorum_t.to_relative(n);
-    std::vector<double> out(n, 0.0), lh(n + 1);
-    Log2Table lg(2 * n + 2);
-    for (uint64_t i = 0; i <= n; ++i) lh[i] = std::log2((double)hist[i]);
-
-    // scalars of the m-recurrence, one value per m (prefix sums in the reference's order)
-    std::vector<double> n_fall(n + 1, 0.0), m_fact(n + 1, 0.0);
-    std::vector<uint64_t> m_quorum(n + 1, 0);
-    for (uint64_t m = 1; m <= n; ++m) {
-        m_fact[m] = m_fact[m - 1] + lg(m);
-        n_fall[m] = n_fall[m - 1] + lg(n - m + 1);
-        m_quorum[m] = (uint64_t)std::ceil((double)m * quorum);
+        if (b == UNION) {
+            uint64_t t = 0;
+            for (uint64_t i = c; i <= n; ++i) t += hist[i];
+            tot = (double)t;
+        }
+        term1.resize((n + 1) * (n + 1));
+        if (b == QUORUM) term2.resize((n + 1) * (n + 1));
+        out.assign(n, 0.0);
     }
 
-    // yl[m]: the "100 % quorum" part (hist.rs:157-160), same shape as the core branch
-    std::vector<double> yl(n + 1, 0.0);
-    {
-        std::vector<double> t2((n + 1) * (n + 1), 0.0);
-        two_level(
-            n, lh, n_fall, [&](uint64_t i, uint64_t m) { return i >= std::max(m, c); },
-            [&](uint64_t i, uint64_t m) { return lg(i - m + 1); }, n_threads, t2);
+    uint64_t n_rows() const { return n + 1; }
+
+    // everything the reference computes for histogram index i, for all m
+    void run_row(uint64_t i, std::vector<double> &q) const {
+        const Log2Table &L = *lg;
+        double *t1 = const_cast<double *>(term1.data()) + i * (n + 1);
+        double pm = 0.0;
+        if (branch == UNION) {
+            // hist.rs:102-111: for i in c..n-m+1 { perc_mult[i] += log2(n-m-i+1); y += exp2(..) }
+            if (i >= c)
+                for (uint64_t m = 1; i + m <= n; ++m) {
+                    pm += L(n - m - i + 1);
+                    t1[m] = std::exp2(lh[i] + pm - n_fall[m]);
+                }
+            return;
+        }
+        // hist.rs:127-135 / :157-160: for i in max(m,c)..n+1 { perc_mult[i] += log2(i-m+1); .. }
+        if (i >= c)
+            for (uint64_t m = 1; m <= std::min(i, n); ++m) {
+                pm += L(i - m + 1);
+                t1[m] = std::exp2(lh[i] + pm - n_fall[m]);
+            }
+        if (branch != QUORUM || i >= n) return;
+        // hist.rs:163-183, row i of Q
+        double *t2 = const_cast<double *>(term2.data()) + i * (n + 1);
+        q.assign(n + 1, 0.0);
+        const double nan = std::nan("");
+        for (uint64_t m = 1; m <= n; ++m) {
+            t2[m] = nan;
+            if (i < m_quorum[m]) continue;  // the reference loops "for i in m_quorum..n"
+            double sum_q = 0.0;
+            bool add = false;
+            for (uint64_t j = std::max(m_quorum[m], c); j < m; ++j) {
+                if (n + j + 1 > i + m && j <= i) {
+                    if (q[j] == 0.0) {  // choose(i, j), hist.rs:21-36, log2 served from the table
+                        uint64_t k = j > i - j ? i - j : j;
+                        double res = 0.0;
+                        for (uint64_t a = 0; a < k; ++a) {
+                            res += L(i - a);
+                            res -= L(a + 1);
+                        }
+                        q[j] = res;
+                    }
+                    q[j] += L(n - i - m + 1 + j);
+                    q[j] -= L(m - j);
+                    sum_q += std::exp2(q[j] + m_fact[m] - n_fall[m]);
+                    add = true;
+                }
+            }
+            if (add) t2[m] = std::exp2(lh[i] + std::log2(sum_q));
+        }
+    }
+
+    // the sums over i, serially and in ascending i like the reference
+    void finish() {
         for (uint64_t m = 1; m <= n; ++m) {
             double y = 0.0;
-            for (uint64_t i = std::max(m, c); i <= n; ++i) y += t2[i * (n + 1) + m];
-            yl[m] = y;
-        }
-    }
-
-    // term[m][i] = exp2(log2 h[i] + log2 sum_q(i, m)) or "absent": rows i are independent
-    // (Q[i][*] only ever touches row i), so they go to threads; the sum over i is then done
-    // serially in ascending i like the reference.
-    std::vector<double> term((n + 1) * (n + 1), 0.0);
-    std::vector<uint8_t> has((n + 1) * (n + 1), 0);
-    // choose(i, j) of hist.rs:21-36 with its log2 calls served from the table (same values)
-    auto choose_tab = [&](uint64_t nn, uint64_t k) -> double {
-        if (k > nn) return 0.0;
-        if (k > nn - k) k = nn - k;
-        double res = 0.0;
-        for (uint64_t a = 0; a < k; ++a) {
-            res += lg(nn - a);
-            res -= lg(a + 1);
-        }
-        return res;
-    };
-    auto work = [&](uint64_t i_lo, uint64_t i_hi) {
-        std::vector<double> q(n + 1);
-        for (uint64_t i = i_lo; i < i_hi; ++i) {
-            std::fill(q.begin(), q.end(), 0.0);
-            for (uint64_t m = 1; m <= n; ++m) {
-                if (i < m_quorum[m]) continue;  // loop is "for i in m_quorum..n"
-                double sum_q = 0.0;
-                bool add = false;
-                for (uint64_t j = std::max(m_quorum[m], c); j < m; ++j) {
-                    if (n + j + 1 > i + m && j <= i) {
-                        if (q[j] == 0.0) q[j] = choose_tab(i, j);
-                        q[j] += lg(n - i - m + 1 + j);
-                        q[j] -= lg(m - j);
-                        sum_q += std::exp2(q[j] + m_fact[m] - n_fall[m]);
-                        add = true;
-                    }
-                }
-                if (add) {
-                    term[i * (n + 1) + m] = std::exp2(lh[i] + std::log2(sum_q));
-                    has[i * (n + 1) + m] = 1;
-                }
+            if (branch == UNION) {
+                for (uint64_t i = c; i + m <= n; ++i) y += term1[i * (n + 1) + m];
+                out[m - 1] = tot - y;
+                continue;
             }
+            for (uint64_t i = std::max(m, c); i <= n; ++i) y += term1[i * (n + 1) + m];
+            if (branch == CORE) {
+                out[m - 1] = y;
+                continue;
+            }
+            double yr = 0.0;
+            for (uint64_t i = m_quorum[m]; i < n; ++i) {
+                const double t = term2[i * (n + 1) + m];
+                if (t == t) yr += t;  // not NaN <=> add == true
+            }
+            out[m - 1] = y + yr;
         }
-    };
-    if (n < 48) {
-        work(0, n);
-    } else {
-        // rows get more expensive with i (more admissible j), so cut finely and let the pool balance
-        const size_t chunks = std::min<uint64_t>(n, 256);
-        ThreadPool::instance().parallel_for(
-            chunks, [&](size_t k) { work(n * k / chunks, n * (k + 1) / chunks); }, n_threads);
     }
-    for (uint64_t m = 1; m <= n; ++m) {
-        double yr = 0.0;
-        for (uint64_t i = m_quorum[m]; i < n; ++i)
-            if (has[i * (n + 1) + m]) yr += term[i * (n + 1) + m];
-        out[m - 1] = yl[m] + yr;
+};
+
+Branch dispatch(uint64_t n, Threshold quorum) {  // Hist::calc_growth, hist.rs:51-66
+    const uint64_t q_abs = std::max<uint64_t>(1, quorum.to_absolute(n));
+    if (q_abs == 1) return UNION;
+    if (q_abs >= n) return CORE;
+    return QUORUM;
+}
+
+std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &jobs, unsigned n_threads) {
+    // flatten (job, row-chunk) into one task list; quorum rows cost ~i^2, so they are cut finer
+    struct Task {
+        Job *job;
+        uint64_t lo, hi;
+    };
+    std::vector<Task> tasks;
+    for (auto &j : jobs) {
+        const uint64_t rows = j->n_rows();
+        const uint64_t chunks = std::min<uint64_t>(rows, j->branch == QUORUM ? 192 : 32);
+        for (uint64_t k = 0; k < chunks; ++k) {
+            uint64_t lo = rows * k / chunks, hi = rows * (k + 1) / chunks;
+            if (hi > lo) tasks.push_back(Task{j.get(), lo, hi});
+        }
+    }
+    // heavy tasks first (quorum rows with large i), so the tail of the region is short
+    std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) {
+        auto w = [](const Task &t) { return t.job->branch == QUORUM ? (double)t.hi * (double)t.hi : 1.0; };
+        return w(a) > w(b);
+    });
+    auto body = [&](size_t k) {
+        thread_local std::vector<double> q;
+        const Task &t = tasks[k];
+        for (uint64_t i = t.lo; i < t.hi; ++i) t.job->run_row(i, q);
+    };
+    uint64_t work = 0;
+    for (auto &j : jobs) work += j->n * j->n * (j->branch == QUORUM ? j->n / 8 + 1 : 1);
+    if (work < 20000 || n_threads == 1) {
+        for (size_t k = 0; k < tasks.size(); ++k) body(k);
+    } else {
+        ThreadPool::instance().parallel_for(tasks.size(), body, n_threads);
+    }
+    std::vector<std::vector<double>> out;
+    for (auto &j : jobs) {
+        j->finish();
+        out.push_back(std::move(j->out));
     }
     return out;
 }
 
+}  // namespace
+
+std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &hist,
+                                                  const std::vector<Threshold> &coverage,
+                                                  const std::vector<Threshold> &quorum, unsigned n_threads) {
+    std::vector<std::vector<double>> res;
+    if (hist.size() < 2) return std::vector<std::vector<double>>(coverage.size());
+    const uint64_t n = hist.size() - 1;
+    auto tab = std::make_shared<Log2Table>(2 * n + 2);
+    std::vector<std::unique_ptr<Job>> jobs;
+    for (size_t t = 0; t < coverage.size(); ++t)
+        jobs.emplace_back(new Job(dispatch(n, quorum[t]), hist, coverage[t], quorum[t], tab));
+    return run_jobs(jobs, n_threads);
+}
+
+static std::vector<double> one(Branch b, const std::vector<uint64_t> &hist, Threshold c, Threshold q, unsigned n_threads) {
+    if (hist.size() < 2) return {};
+    auto tab = std::make_shared<Log2Table>(2 * (hist.size() - 1) + 2);
+    std::vector<std::unique_ptr<Job>> jobs;
+    jobs.emplace_back(new Job(b, hist, c, q, tab));
+    return run_jobs(jobs, n_threads)[0];
+}
+
+std::vector<double> calc_growth_union(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
+    return one(UNION, hist, coverage, Threshold{THR_RELATIVE, 0.0}, n_threads);
+}
+std::vector<double> calc_growth_core(const std::vector<uint64_t> &hist, Threshold coverage, unsigned n_threads) {
+    return one(CORE, hist, coverage, Threshold{THR_RELATIVE, 1.0}, n_threads);
+}
+std::vector<double> calc_growth_quorum(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
+                                       unsigned n_threads) {
+    return one(QUORUM, hist, coverage, quorum, n_threads);
+}
 std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
                                 unsigned n_threads) {
     if (hist.size() < 2) return {};
-    const uint64_t n = hist.size() - 1;
-    const uint64_t q_abs = std::max<uint64_t>(1, quorum.to_absolute(n));
-    if (q_abs == 1) return calc_growth_union(hist, coverage, n_threads);
-    if (q_abs >= n) return calc_growth_core(hist, coverage, n_threads);
-    return calc_growth_quorum(hist, coverage, quorum, n_threads);
+    return one(dispatch(hist.size() - 1, quorum), hist, coverage, quorum, n_threads);
 }
 
 }  // namespace pnh

@@ -23,6 +23,12 @@ struct Threshold {
 
 double choose_log2(uint64_t n, uint64_t k);  // hist.rs:21-36
 
+// Hist::calc_all_growths (hist.rs:68-87) without the NaN row: one curve per (coverage, quorum)
+// pair, all pairs evaluated in one parallel region
+std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &hist,
+                                                  const std::vector<Threshold> &coverage,
+                                                  const std::vector<Threshold> &quorum, unsigned n_threads = 0);
+
 // n = hist.size() - 1 values (the caller prepends the NaN row, hist.rs:83-85)
 std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
                                 unsigned n_threads = 0);

@@ -129,11 +129,13 @@ int64_t pnh_calc_all_growths(const uint64_t *hist, uint64_t hist_len, const int 
     if (!hist || hist_len < 2) return 0;
     std::vector<uint64_t> h(hist, hist + hist_len);
     const uint64_t n = hist_len - 1;
+    std::vector<pnh::Threshold> cov, quo;
     for (uint32_t t = 0; t < n_pairs; ++t) {
-        std::vector<double> g = pnh::calc_growth(h, pnh::Threshold{cov_kind[t], cov_val[t]},
-                                                 pnh::Threshold{quo_kind[t], quo_val[t]}, n_threads);
-        std::memcpy(out + (size_t)t * n, g.data(), g.size() * sizeof(double));
+        cov.push_back(pnh::Threshold{cov_kind[t], cov_val[t]});
+        quo.push_back(pnh::Threshold{quo_kind[t], quo_val[t]});
     }
+    std::vector<std::vector<double>> g = pnh::calc_all_growths(h, cov, quo, n_threads);
+    for (uint32_t t = 0; t < n_pairs; ++t) std::memcpy(out + (size_t)t * n, g[t].data(), g[t].size() * sizeof(double));
     return (int64_t)n;
 }
 

@@ -52,13 +52,30 @@ def calc_growth_branch(branch: str, hist, coverage: Threshold, quorum: Threshold
     return out[:n]
 
 
+def calc_growths(hist, pairs, n_threads: int = 0):
+    """All (coverage, quorum) pairs of one histogram in one parallel region.
+    pairs: list of (Threshold, Threshold). -> list of n-value curves (no NaN row)."""
+    L = load()
+    L.pnh_calc_all_growths.restype = C.c_int64
+    L.pnh_calc_all_growths.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32, C.c_uint, C.POINTER(C.c_double)]
+    h = np.ascontiguousarray(hist, dtype=np.uint64)
+    T = len(pairs)
+    n = max(len(h) - 1, 0)
+    ck = (C.c_int * T)(*[c.kind for c, _ in pairs])
+    cv = (C.c_double * T)(*[float(c.value) for c, _ in pairs])
+    qk = (C.c_int * T)(*[q.kind for _, q in pairs])
+    qv = (C.c_double * T)(*[float(q.value) for _, q in pairs])
+    out = np.zeros((T, max(n, 1)), dtype=np.float64)
+    L.pnh_calc_all_growths(h.ctypes.data_as(C.POINTER(C.c_uint64)), len(h), ck, cv, qk, qv, T, n_threads,
+                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return [out[t, :n].copy() for t in range(T)]
+
+
 def calc_all_growths(hist, thresholds, n_threads: int = 0):
     """Hist::calc_all_growths (hist.rs:68-87): one curve per (coverage, quorum) pair, NaN row 0."""
-    out = []
-    for c, q in zip(thresholds.coverage, thresholds.quorum):
-        g = calc_growth(hist, c, q, n_threads)
-        out.append(np.concatenate([[np.nan], g]))
-    return out
+    curves = calc_growths(hist, list(zip(thresholds.coverage, thresholds.quorum)), n_threads)
+    return [np.concatenate([[np.nan], g]) for g in curves]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -375,5 +375,5 @@ def test_variants_agree_with_oracle(ctx, variant, coarse):
         cnt, h = ctx.hist()
         assert h.tolist() == [0, 0, 6000] and cnt[1:].tolist() == [2] * 6000
     finally:
-        ctx.config(capi.CFG_COVER_VARIANT, 0)
+        ctx.config(capi.CFG_COVER_VARIANT, 2)
         ctx.config(capi.CFG_INDEX_COARSE, 8)

@@ -39,3 +39,13 @@ def test_matches_oracle_bitwise(n, threads):
             a = hostlib.calc_growth(h, Threshold(ABSOLUTE, c), Threshold(RELATIVE, q), threads)
             b = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
             assert a.tobytes() == b.tobytes(), (n, c, q)
+
+
+def test_all_pairs_in_one_region_bitwise():
+    rng = np.random.default_rng(7)
+    for n in (3, 60, 256):
+        h = rng.integers(0, 10**6, size=n + 1).astype(np.uint64)
+        pairs = [(0, 0.0), (1, 0.0), (2, 0.0), (1, 0.5), (1, 1.0), (3, 0.25), (1, 0.1)]
+        got = hostlib.calc_growths(h, [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs])
+        for (c, q), g in zip(pairs, got):
+            assert g.tobytes() == orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes(), (n, c, q)
