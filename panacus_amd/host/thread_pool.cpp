@@ -1,8 +1,15 @@
 #include "thread_pool.hpp"
 
 #include <algorithm>
-#include <cstdint>
+#include <chrono>
 #include <cstdlib>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define PNH_PAUSE() _mm_pause()
+#else
+#define PNH_PAUSE() ((void)0)
+#endif
 
 namespace pnh {
 
@@ -24,14 +31,15 @@ ThreadPool::ThreadPool() {
 ThreadPool::~ThreadPool() { stop(); }
 
 void ThreadPool::start(unsigned n_workers) {
-    quit_ = false;
+    quit_.store(false);
     for (unsigned i = 0; i < n_workers; ++i) workers_.emplace_back([this, i]() { worker_loop(i); });
 }
 
 void ThreadPool::stop() {
+    quit_.store(true);
     {
         std::lock_guard<std::mutex> lk(mu_);
-        quit_ = true;
+        epoch_.fetch_add(1);
     }
     cv_work_.notify_all();
     for (auto &t : workers_) t.join();
@@ -39,53 +47,75 @@ void ThreadPool::stop() {
 }
 
 void ThreadPool::set_threads(unsigned n) {
+    std::lock_guard<std::mutex> call(call_mu_);
     if (n == 0) n = std::max(1u, std::thread::hardware_concurrency());
     stop();
     start(n - 1);
 }
 
-void ThreadPool::worker_loop(unsigned id) {
-    uint64_t seen = 0;
+// Tasks are handed out through one 64-bit ticket = (job id << 32) | next index, advanced by
+// compare-exchange: a worker that is late for job k can never take (or run with a stale
+// function pointer) a task of job k+1, because its job id no longer matches the ticket.
+void ThreadPool::drain(const std::function<void(size_t)> &fn, size_t n_tasks, uint64_t job) {
     for (;;) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_work_.wait(lk, [&]() { return quit_ || (epoch_ != seen && fn_ != nullptr); });
-        if (quit_) return;
-        seen = epoch_;
-        if (id + 1 >= active_limit_) continue;  // this job wants fewer threads
-        while (next_ < n_tasks_) {
-            size_t t = next_++;
-            lk.unlock();
-            (*fn_)(t);
-            lk.lock();
-            if (--pending_ == 0) cv_done_.notify_all();
+        uint64_t t = ticket_.load(std::memory_order_acquire);
+        if ((t >> 32) != (job & 0xFFFFFFFFull)) return;
+        const size_t idx = (size_t)(t & 0xFFFFFFFFull);
+        if (idx >= n_tasks) return;
+        if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+        fn(idx);
+        done_.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void ThreadPool::worker_loop(unsigned id) {
+    uint64_t seen = epoch_.load();
+    for (;;) {
+        // wait for a new epoch: spin for a short while (jobs arrive ~1 ms apart in the
+        // pipelined histgrowth loop), then sleep on the condition variable
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t e;
+        int spins = 0;
+        while ((e = epoch_.load(std::memory_order_acquire)) == seen) {
+            PNH_PAUSE();
+            if ((++spins & 1023) == 0 &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) {
+                std::unique_lock<std::mutex> lk(mu_);
+                sleepers_.fetch_add(1);
+                cv_work_.wait(lk, [&]() { return epoch_.load() != seen; });
+                sleepers_.fetch_sub(1);
+            }
         }
+        seen = e;
+        if (quit_.load()) return;
+        const std::function<void(size_t)> *fn = fn_;
+        const size_t n_tasks = n_tasks_;
+        if (fn && id + 1 < active_limit_) drain(*fn, n_tasks, e);
     }
 }
 
 void ThreadPool::parallel_for(size_t n_tasks, const std::function<void(size_t)> &fn, unsigned max_threads) {
     if (n_tasks == 0) return;
+    std::lock_guard<std::mutex> call(call_mu_);
     unsigned limit = max_threads ? std::min(max_threads, size()) : size();
     if (limit <= 1 || n_tasks == 1 || workers_.empty()) {
         for (size_t t = 0; t < n_tasks; ++t) fn(t);
         return;
     }
-    std::unique_lock<std::mutex> lk(mu_);
+    // publish the job (fn_/n_tasks_ first, then the ticket, then the epoch the workers watch)
     fn_ = &fn;
     n_tasks_ = n_tasks;
-    next_ = 0;
-    pending_ = n_tasks;
     active_limit_ = limit;
-    ++epoch_;
-    cv_work_.notify_all();
-    while (next_ < n_tasks_) {  // the caller works too
-        size_t t = next_++;
-        lk.unlock();
-        fn(t);
-        lk.lock();
-        --pending_;
+    done_.store(0, std::memory_order_relaxed);
+    const uint64_t job = epoch_.load(std::memory_order_relaxed) + 1;
+    ticket_.store((job & 0xFFFFFFFFull) << 32, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        epoch_.store(job, std::memory_order_release);
     }
-    cv_done_.wait(lk, [&]() { return pending_ == 0; });
-    fn_ = nullptr;
+    if (sleepers_.load() > 0) cv_work_.notify_all();
+    drain(fn, n_tasks, job);
+    while (done_.load(std::memory_order_acquire) < n_tasks) PNH_PAUSE();
 }
 
 }  // namespace pnh

@@ -1,10 +1,13 @@
 // thread_pool.hpp -- small persistent worker pool for the host layer (closed-form growth,
 // GFA parsing).  The reference uses one process-wide rayon pool (src/lib.rs:71-83); this is
-// the C++ counterpart: workers are created once and reused, so a 1 ms job does not pay a
-// thread-spawn per call.
+// the C++ counterpart: workers are created once and reused, tasks are handed out through one
+// atomic counter, and idle workers spin briefly before they sleep, so a sub-millisecond job
+// (the closed-form growth of one histogram) does not pay thread-spawn or wake-up latency.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -17,7 +20,7 @@ public:
     static ThreadPool &instance();
     unsigned size() const { return (unsigned)workers_.size() + 1; }
     // runs fn(task) for task in [0, n_tasks) on up to max_threads threads (caller included);
-    // returns when all tasks are done.  Not re-entrant.
+    // returns when all tasks are done.  Not re-entrant; calls are serialised.
     void parallel_for(size_t n_tasks, const std::function<void(size_t)> &fn, unsigned max_threads = 0);
     void set_threads(unsigned n);  // like `panacus -t N` (src/lib.rs:110-127); 0 = all cores
     ~ThreadPool();
@@ -27,14 +30,20 @@ private:
     void start(unsigned n_workers);
     void stop();
     void worker_loop(unsigned id);
+    void drain(const std::function<void(size_t)> &fn, size_t n_tasks, uint64_t job);
+
     std::vector<std::thread> workers_;
+    std::mutex call_mu_;  // serialises parallel_for callers
     std::mutex mu_;
-    std::condition_variable cv_work_, cv_done_;
+    std::condition_variable cv_work_;
+    std::atomic<uint64_t> epoch_{0};
+    std::atomic<uint64_t> ticket_{0};  // (job id << 32) | next task index
+    std::atomic<size_t> done_{0};
+    std::atomic<int> sleepers_{0};
     const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_tasks_ = 0, next_ = 0, pending_ = 0;
+    size_t n_tasks_ = 0;
     unsigned active_limit_ = 0;
-    uint64_t epoch_ = 0;
-    bool quit_ = false;
+    std::atomic<bool> quit_{false};
 };
 
 }  // namespace pnh
