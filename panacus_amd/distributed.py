@@ -1,0 +1,92 @@
+"""Multi-GPU host logic: one process per GPU, node-range shards, RCCL all-reduce of counters.
+
+Every quantity on the hot path is a sum over items (nodes / edges), so the graph shards by
+item-id range with NO data-path collective: each rank runs the unchanged kernels on the CSR
+steps whose id falls into its range, and the only exchange is an all-reduce (sum) of the small
+integer counter arrays -- hist[G+1] (<= a few KB) and, for permuted growth, out[R][T][G].
+Backend "nccl" is RCCL on ROCm (xGMI); the same code runs over "gloo" on CPU for the tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def plan_node_shards(items: np.ndarray, n_items: int, world: int) -> np.ndarray:
+    """Item-id range boundaries, balanced by STEP count (not by item count).
+
+    Returns `cuts` (world+1 ints, cuts[0] = 1, cuts[-1] = n_items+1); rank r owns ids in
+    [cuts[r], cuts[r+1]).  A path step with id i costs one unit for the rank that owns i.
+    """
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    steps_per_item = np.bincount(np.asarray(items, dtype=np.int64), minlength=n_items + 1)
+    cum = np.cumsum(steps_per_item)
+    total = int(cum[-1])
+    cuts = [1]
+    for r in range(1, world):
+        target = total * r // world
+        c = int(np.searchsorted(cum, target, side="left")) + 1
+        cuts.append(min(max(c, cuts[-1]), n_items + 1))
+    cuts.append(n_items + 1)
+    return np.asarray(cuts, dtype=np.int64)
+
+
+def shard_csr(items: np.ndarray, path_off: np.ndarray, lo: int, hi: int):
+    """The CSR restricted to item ids in [lo, hi), re-based to 1..(hi-lo).
+
+    Path order and path count are preserved (a path without steps in the range becomes empty),
+    so the same visiting order (path_idx, group_id) applies to every shard.
+    -> (items_r u32, path_off_r u64, n_items_r)
+    """
+    items = np.asarray(items)
+    path_off = np.asarray(path_off, dtype=np.uint64)
+    keep = (items >= lo) & (items < hi)
+    kept_before = np.concatenate([[0], np.cumsum(keep, dtype=np.uint64)])
+    new_off = kept_before[path_off.astype(np.int64)]
+    new_items = (items[keep] - (lo - 1)).astype(np.uint32)
+    return new_items, new_off.astype(np.uint64), int(hi - lo)
+
+
+def shard_weights(weights: np.ndarray | None, lo: int, hi: int):
+    if weights is None:
+        return None
+    w = np.zeros(hi - lo + 1, dtype=np.uint32)
+    w[1:] = np.asarray(weights)[lo:hi]
+    return w
+
+
+def allreduce_counters(arr: np.ndarray, device=None) -> np.ndarray:
+    """Sum a u64 counter array over all ranks (int64 transport: exact for counts < 2^63)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(arr, dtype=np.uint64)
+    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().view(np.uint64)
+
+
+def gather_countable(local: np.ndarray, cuts: np.ndarray, rank: int, device=None) -> np.ndarray:
+    """Concatenate the per-shard coverage vectors (local[1:] of every rank) into the global
+    countable (index 0 = u32::MAX like the reference)."""
+    import torch
+    import torch.distributed as dist
+    n_items = int(cuts[-1]) - 1
+    out = np.zeros(n_items + 1, dtype=np.int64)
+    out[int(cuts[rank]):int(cuts[rank + 1])] = np.asarray(local[1:], dtype=np.int64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.from_numpy(out)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out = t.cpu().numpy()
+    out = out.astype(np.uint32)
+    out[0] = 0xFFFFFFFF
+    return out
+
+
+def split_orders(n_orders: int, world: int, rank: int) -> range:
+    """Permutation sharding for permuted growth: rank r evaluates orders r, r+world, ..."""
+    return range(rank, n_orders, world)

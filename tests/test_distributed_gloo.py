@@ -1,0 +1,99 @@
+"""The N>1 host path (node-range shards + all-reduce of the counters; permutation shards) on
+CPU with the gloo backend, world_size 2.  Per-shard numbers come from the oracle here (no GPU
+in this suite); what is under test is the shard planner, the re-basing, and the collective
+plumbing of panacus_amd/distributed.py that bench.py / a multi-GPU host use over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import oracle as orc
+from panacus_amd import distributed as pd
+
+N, P, SEED = 30_000, 12, 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        items, pre, lens = orc.pansyn(SEED, N, P)
+        pi = np.arange(P, dtype=np.uint64)
+        gi = (pi // 2).astype(np.uint64)
+        G = P // 2
+        cuts = pd.plan_node_shards(items, N, world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        it_r, off_r, n_r = pd.shard_csr(items, pre, lo, hi)
+        w_r = pd.shard_weights(lens, lo, hi)
+        cov_r = orc.coverage(it_r.astype(np.uint64), off_r, pi, gi, n_r)
+        res = {}
+        for name, w in (("node", None), ("bp", w_r)):
+            h_r = orc.hist(cov_r, G, w)
+            # the zero bin of a shard counts only the shard's own items -> plain sum is exact
+            res[name] = pd.allreduce_counters(h_r)
+        res["countable"] = pd.gather_countable(cov_r, cuts, rank)
+        # permuted growth, node-range sharded: out[R][T][G] summed over ranks
+        r_, c_ = orc.by_group(it_r.astype(np.uint64), off_r, pi, gi, n_r)
+        og = np.stack([orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, qq)).astype(np.uint64)
+                       for c, qq in ((1, 0.0), (2, 0.5))])
+        res["growth"] = pd.allreduce_counters(og.reshape(-1)).reshape(og.shape)
+        res["orders"] = list(pd.split_orders(7, world, rank))
+        res["steps"] = int(len(it_r))
+        if rank == 0:
+            q.put(res)
+        else:
+            q.put({"orders": res["orders"], "steps": res["steps"]})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_node_range_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = next(o for o in outs if "node" in o)
+    items, pre, lens = orc.pansyn(SEED, N, P)
+    pi = np.arange(P, dtype=np.uint64)
+    gi = (pi // 2).astype(np.uint64)
+    G = P // 2
+    cov = orc.coverage(items, pre, pi, gi, N)
+    assert np.array_equal(full["countable"], cov)
+    assert np.array_equal(full["node"], orc.hist(cov, G))
+    assert np.array_equal(full["bp"], orc.hist(cov, G, lens))
+    r_, c_ = orc.by_group(items, pre, pi, gi, N)
+    for k, (c, qq) in enumerate(((1, 0.0), (2, 0.5))):
+        exp = orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, qq))
+        assert full["growth"][k].tolist() == [int(x) for x in exp]
+    # permutation shards cover every order exactly once; step balance within 10 %
+    orders = sorted(x for o in outs for x in o["orders"])
+    assert orders == list(range(7))
+    steps = [o["steps"] for o in outs]
+    assert sum(steps) == len(items) and abs(steps[0] - steps[1]) < 0.1 * len(items)
+
+
+def test_shard_planner_edges():
+    items = np.array([1, 1, 1, 1, 2, 3, 3, 9], dtype=np.uint64)
+    cuts = pd.plan_node_shards(items, 9, 3)
+    assert cuts[0] == 1 and cuts[-1] == 10 and np.all(np.diff(cuts) >= 0)
+    it, off, n = pd.shard_csr(items, np.array([0, 5, 8], np.uint64), 2, 4)
+    assert it.tolist() == [1, 2, 2] and off.tolist() == [0, 1, 3] and n == 2
+    assert pd.plan_node_shards(items, 9, 1).tolist() == [1, 10]
