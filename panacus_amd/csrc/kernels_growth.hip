@@ -282,6 +282,153 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
 }
 
 // ------------------------------------------------------------------------------------------
+// fused kernel: up to GROW_Q0_MAX q == 0 pairs and NQ q > 0 pairs share ONE read of the
+// presence rows.  q > 0 pairs use the slack form s_j = cnt_j - Tq[j] kept bit-sliced in two's
+// complement (NPL1 planes): Tq rises by dT in {0, 1} per rank (q <= 1), so per rank s += x
+// (dT = 0) or s += x - 1 (dT = 1), i.e. one ripple increment under mask x or one ripple
+// decrement under mask ~x, and "cnt >= Tq" is just the complement of the sign plane -- no
+// plane-by-plane comparison.  Workgroups of one block chunk carry consecutive blockIdx for
+// all R orders, so the R walks over the same rows run side by side and are served by
+// L2 / Infinity Cache instead of HBM.
+// ------------------------------------------------------------------------------------------
+struct GrowthTabs {
+    int32_t q0_midx[GROW_Q0_MAX];   // mask index per q == 0 pair, -1 = none
+    uint32_t q0_slot[GROW_Q0_MAX];  // output slot t
+    int32_t qq_midx[2];
+    uint32_t qq_slot[2];
+    uint32_t n_q0;
+};
+
+template <int NPL1, int NQ, bool WEIGHTED>
+__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
+    const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
+    const uint32_t *__restrict__ perms, uint32_t R, uint32_t blocks_per_chunk,
+    const uint32_t *__restrict__ cmask, GrowthTabs tabs, const uint32_t *__restrict__ dtab /* T x G, 0/1 */,
+    uint32_t T, const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
+    extern __shared__ unsigned long long smem[];
+    const uint32_t n_q0 = tabs.n_q0;
+    const uint32_t n_acc = n_q0 + NQ;
+    unsigned long long *acc = smem;  // [n_acc][G]
+    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc + (size_t)n_acc * G);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = blockIdx.x % R, chunk = blockIdx.x / R;
+    const uint32_t *perm = perms + (uint64_t)r * G;
+    uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
+
+    for (uint32_t i = threadIdx.x; i < n_acc * G; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+
+    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
+    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
+        uint32_t mask0[GROW_Q0_MAX];
+#pragma unroll
+        for (int t = 0; t < GROW_Q0_MAX; ++t) {
+            mask0[t] = 0xFFFFFFFFu;
+            if ((uint32_t)t < n_q0 && tabs.q0_midx[t] >= 0)
+                mask0[t] = cmask[((uint64_t)tabs.q0_midx[t] * n_blocks + blk) * BLOCK_WORDS + lane];
+        }
+        uint32_t maskq[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            maskq[qi] = 0xFFFFFFFFu;
+            if (tabs.qq_midx[qi] >= 0)
+                maskq[qi] = cmask[((uint64_t)tabs.qq_midx[qi] * n_blocks + blk) * BLOCK_WORDS + lane];
+        }
+        if (WEIGHTED) {
+            for (uint32_t p = 0; p < n_planes; ++p)
+                wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const uint32_t *col = M + (uint64_t)blk * BLOCK_WORDS + lane;
+        uint32_t seen = 0;
+        uint32_t sl[NQ > 0 ? NQ : 1][NPL1];
+        uint32_t ok[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            ok[qi] = 0;
+#pragma unroll
+            for (int k = 0; k < NPL1; ++k) sl[qi][k] = 0;
+        }
+        for (uint32_t jb = 0; jb < G; jb += GROW_PREFETCH) {
+            uint32_t x[GROW_PREFETCH];
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                x[u] = 0;
+                if (jb + u < G) x[u] = col[(uint64_t)perm[jb + u] * row_words];
+            }
+#pragma unroll
+            for (int u = 0; u < GROW_PREFETCH; ++u) {
+                if (jb + u < G) {  // wave-uniform
+                    const uint32_t xv = x[u];
+                    if (n_q0) {
+                        const uint32_t nw = xv & ~seen;
+                        seen |= xv;
+                        if (nw) {
+    #pragma unroll
+                            for (int t = 0; t < GROW_Q0_MAX; ++t) {
+                                if ((uint32_t)t < n_q0) {
+                                    const uint32_t bits = nw & mask0[t];
+                                    if (bits) {
+                                        unsigned long long c = WEIGHTED ? weighted_popc(bits, wp, n_planes, lane)
+                                                                        : (unsigned long long)__popc(bits);
+                                        atomicAdd(&acc[(size_t)t * G + jb + u], c);
+                                    }
+                                }
+                            }
+                        }
+                    }
+    #pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) {
+                        const uint32_t dT = dtab[(uint64_t)tabs.qq_slot[qi] * G + jb + u];  // wave-uniform
+                        if (dT == 0) {  // s += x
+                            uint32_t carry = xv;
+    #pragma unroll
+                            for (int k = 0; k < NPL1; ++k) {
+                                const uint32_t tmp = sl[qi][k] & carry;
+                                sl[qi][k] ^= carry;
+                                carry = tmp;
+                            }
+                        } else {  // s += x - 1  <=>  s -= 1 where x == 0
+                            uint32_t borrow = ~xv;
+    #pragma unroll
+                            for (int k = 0; k < NPL1; ++k) {
+                                const uint32_t tmp = ~sl[qi][k] & borrow;
+                                sl[qi][k] ^= borrow;
+                                borrow = tmp;
+                            }
+                        }
+                        const uint32_t ge = ~sl[qi][NPL1 - 1];  // s >= 0  <=>  cnt >= Tq
+                        ok[qi] = (ok[qi] & ~xv) | (ge & xv);
+                        const uint32_t bits = ok[qi] & maskq[qi];
+                        unsigned long long *a = &acc[(size_t)(n_q0 + qi) * G + jb + u];
+                        if (WEIGHTED) {
+                            unsigned long long sv = weighted_popc(bits, wp, n_planes, lane);
+                            uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
+                            uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
+                            if (lane == 63) atomicAdd(a, (unsigned long long)lo + ((unsigned long long)mi << 24));
+                        } else {
+                            const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(bits));
+                            if (lane == 63 && tot) atomicAdd(a, (unsigned long long)tot);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_acc * G; i += blockDim.x) {
+        const unsigned long long v = acc[i];
+        if (v) {
+            const uint32_t a = i / G, j = i % G;
+            const uint32_t t = a < n_q0 ? tabs.q0_slot[a] : tabs.qq_slot[a - n_q0];
+            atomicAdd(&out[((uint64_t)r * T + t) * G + j], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     const uint32_t G = ctx->n_groups, R = ctx->g_R, T = ctx->g_T, NB = ctx->n_blocks;
     int rc;
@@ -343,10 +490,10 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
 
-    // geometry: ~4096 workgroups in total, each walking a chunk of blocks for one order
-    uint32_t n_chunks = 4096 / R;
+    // geometry: chunk-major grid (all R orders of a block chunk are neighbours in blockIdx)
+    uint32_t n_chunks = std::max<uint32_t>(4096 / R, (NB + 63) / 64);
     if (n_chunks < 1) n_chunks = 1;
-    uint32_t max_chunks = (NB + GROW_WAVES - 1) / GROW_WAVES;
+    const uint32_t max_chunks = (NB + GROW_WAVES - 1) / GROW_WAVES;
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     const uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
     n_chunks = (NB + bpc - 1) / bpc;
@@ -355,67 +502,105 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     const uint32_t *d_wpl = ctx->weighted ? (const uint32_t *)ctx->d_wplanes.p : nullptr;
     const uint32_t n_planes = ctx->weighted ? ctx->n_wplanes : 0;
 
-    // delta flags per threshold slot, for the finishing prefix kernel
-    std::vector<uint32_t> is_delta(T, 0);
-    prof_begin(ctx, PNX_K_GROWTH);
-    {   // q == 0 pairs, GROW_Q0_MAX per launch
-        std::vector<uint32_t> q0;
-        for (uint32_t t = 0; t < T; ++t)
-            if (meta[T + t]) q0.push_back(t);
-        for (size_t base = 0; base < q0.size(); base += GROW_Q0_MAX) {
-            const uint32_t n = (uint32_t)std::min<size_t>(GROW_Q0_MAX, q0.size() - base);
-            if ((size_t)n * G * 8 + wp_bytes > 64 * 1024)
-                return ctx->fail(PNX_ELIMIT, "ordered growth supports at most %u groups per launch (got %u)",
-                                 (unsigned)((64 * 1024 - wp_bytes) / (8 * n)), G);
-            int32_t h_midx[GROW_Q0_MAX];
-            uint32_t h_slot[GROW_Q0_MAX];
-            for (uint32_t k = 0; k < GROW_Q0_MAX; ++k) {
-                h_midx[k] = k < n ? mask_of[q0[base + k]] : -1;
-                h_slot[k] = k < n ? q0[base + k] : 0;
-                if (k < n) is_delta[q0[base + k]] = 1;
+    // q > 0 pairs whose table rises by 0 or 1 per rank (always true for q in [0,1]) take the
+    // slack form; anything else falls back to the plane-by-plane comparison kernel
+    std::vector<uint32_t> q0, qslack, qgeneral, dtab((size_t)T * G, 0);
+    {
+        std::vector<uint32_t> qt((size_t)T * G);
+        PNX_HIP(ctx, hipMemcpyAsync(qt.data(), ctx->d_qtab.p, qt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t t = 0; t < T; ++t) {
+            if (meta[T + t]) { q0.push_back(t); continue; }
+            bool unit = true;
+            uint32_t prev = 0;
+            for (uint32_t j = 0; j < G && unit; ++j) {
+                const uint32_t v = qt[(size_t)t * G + j];
+                unit = v >= prev && v - prev <= 1;
+                dtab[(size_t)t * G + j] = v - prev;
+                prev = v;
             }
-            // small per-launch tables live behind the masks: [midx x4][slot x4] per launch
-            uint32_t *d_tab = d_aux + 64 + T + 8 * (uint32_t)(base / GROW_Q0_MAX);
-            PNX_HIP(ctx, hipMemcpyAsync(d_tab, h_midx, sizeof h_midx, hipMemcpyHostToDevice, ctx->stream));
-            PNX_HIP(ctx, hipMemcpyAsync(d_tab + 4, h_slot, sizeof h_slot, hipMemcpyHostToDevice, ctx->stream));
-            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_* are stack arrays
-            const size_t shmem = (size_t)n * G * 8 + wp_bytes;
-            auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
-                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p,
-                                   n_chunks, bpc, (const uint32_t *)ctx->d_cmask.p, (const int32_t *)d_tab,
-                                   (const uint32_t *)(d_tab + 4), n, T, d_wpl, n_planes,
-                                   (unsigned long long *)ctx->d_growth_out.p);
-            };
-            if (ctx->weighted) go(k_growth_q0<true>); else go(k_growth_q0<false>);
+            (unit ? qslack : qgeneral).push_back(t);
         }
     }
-    {   // q > 0 pairs, one launch each
-        uint32_t bits = 1;
-        while (bits < 32 && (G >> bits) != 0) ++bits;
-        for (uint32_t t = 0; t < T; ++t) {
-            if (meta[T + t]) continue;
-            if ((size_t)G * 8 + wp_bytes > 64 * 1024)
-                return ctx->fail(PNX_ELIMIT, "ordered growth supports at most %u groups (got %u)",
-                                 (unsigned)((64 * 1024 - wp_bytes) / 8), G);
-            const uint32_t *d_mask_t = mask_of[t] >= 0 ? (const uint32_t *)ctx->d_cmask.p + (size_t)mask_of[t] * NB * BLOCK_WORDS : nullptr;
-            const uint32_t *d_q = (const uint32_t *)ctx->d_qtab.p + (size_t)t * G;
-            const size_t shmem = (size_t)G * 8 + wp_bytes;
+    if ((rc = ensure(ctx, ctx->d_thr_meta, dtab.size() * sizeof(uint32_t) + 16))) return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_thr_meta.p, dtab.data(), dtab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    uint32_t bits = 1;
+    while (bits < 32 && (G >> bits) != 0) ++bits;
+    std::vector<uint32_t> is_delta(T, 0);
+    for (uint32_t t : q0) is_delta[t] = 1;
+    prof_begin(ctx, PNX_K_GROWTH);
+    {   // fused launches: up to GROW_Q0_MAX q == 0 pairs + up to 2 slack pairs each
+        size_t i0 = 0, iq = 0;
+        while (i0 < q0.size() || iq < qslack.size()) {
+            GrowthTabs tabs;
+            tabs.n_q0 = (uint32_t)std::min<size_t>(GROW_Q0_MAX, q0.size() - i0);
+            for (uint32_t k = 0; k < GROW_Q0_MAX; ++k) {
+                tabs.q0_midx[k] = k < tabs.n_q0 ? mask_of[q0[i0 + k]] : -1;
+                tabs.q0_slot[k] = k < tabs.n_q0 ? q0[i0 + k] : 0;
+            }
+            const int nq = (int)std::min<size_t>(2, qslack.size() - iq);
+            for (int k = 0; k < 2; ++k) {
+                tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
+                tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
+            }
+            const size_t shmem = (size_t)(tabs.n_q0 + nq) * G * 8 + wp_bytes;
+            if (shmem > 64 * 1024)
+                return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %u threshold pairs exceed the LDS accumulators",
+                                 G, tabs.n_q0 + nq);
             auto go = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
-                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p,
-                                   n_chunks, bpc, d_mask_t, d_q, t, T, d_wpl, n_planes,
-                                   (unsigned long long *)ctx->d_growth_out.p);
+                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p, R,
+                                   bpc, (const uint32_t *)ctx->d_cmask.p, tabs, (const uint32_t *)ctx->d_thr_meta.p, T,
+                                   d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);
             };
-            if (ctx->weighted) {
-                if (bits <= 8) go(k_growth_quorum<8, true>);
-                else if (bits <= 12) go(k_growth_quorum<12, true>);
-                else go(k_growth_quorum<16, true>);
-            } else {
-                if (bits <= 8) go(k_growth_quorum<8, false>);
-                else if (bits <= 12) go(k_growth_quorum<12, false>);
-                else go(k_growth_quorum<16, false>);
-            }
+#define PNX_GROW_DISPATCH(NPL1)                                                                   \
+    do {                                                                                          \
+        if (ctx->weighted) {                                                                      \
+            if (nq == 0) go(k_growth_fused<NPL1, 0, true>);                                       \
+            else if (nq == 1) go(k_growth_fused<NPL1, 1, true>);                                  \
+            else go(k_growth_fused<NPL1, 2, true>);                                               \
+        } else {                                                                                  \
+            if (nq == 0) go(k_growth_fused<NPL1, 0, false>);                                      \
+            else if (nq == 1) go(k_growth_fused<NPL1, 1, false>);                                 \
+            else go(k_growth_fused<NPL1, 2, false>);                                              \
+        }                                                                                         \
+    } while (0)
+            // planes for s in [-G, G]: bits(G) + 1 (sign)
+            if (bits + 1 <= 7) PNX_GROW_DISPATCH(7);
+            else if (bits + 1 <= 9) PNX_GROW_DISPATCH(9);
+            else if (bits + 1 <= 11) PNX_GROW_DISPATCH(11);
+            else if (bits + 1 <= 13) PNX_GROW_DISPATCH(13);
+            else if (bits + 1 <= 17) PNX_GROW_DISPATCH(17);
+            else return ctx->fail(PNX_ELIMIT, "ordered growth supports at most 65535 groups");
+#undef PNX_GROW_DISPATCH
+            i0 += tabs.n_q0;
+            iq += (size_t)nq;
+        }
+    }
+    for (uint32_t t : qgeneral) {  // arbitrary quorum tables: comparison kernel, one launch each
+        if ((size_t)G * 8 + wp_bytes > 64 * 1024)
+            return ctx->fail(PNX_ELIMIT, "ordered growth supports at most %u groups (got %u)",
+                             (unsigned)((64 * 1024 - wp_bytes) / 8), G);
+        const uint32_t *d_mask_t = mask_of[t] >= 0 ? (const uint32_t *)ctx->d_cmask.p + (size_t)mask_of[t] * NB * BLOCK_WORDS : nullptr;
+        const uint32_t *d_q = (const uint32_t *)ctx->d_qtab.p + (size_t)t * G;
+        const size_t shmem = (size_t)G * 8 + wp_bytes;
+        // this kernel numbers workgroups order-major: r = blockIdx / n_chunks
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
+                               (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p,
+                               n_chunks, bpc, d_mask_t, d_q, t, T, d_wpl, n_planes,
+                               (unsigned long long *)ctx->d_growth_out.p);
+        };
+        if (ctx->weighted) {
+            if (bits <= 8) go(k_growth_quorum<8, true>);
+            else if (bits <= 12) go(k_growth_quorum<12, true>);
+            else go(k_growth_quorum<16, true>);
+        } else {
+            if (bits <= 8) go(k_growth_quorum<8, false>);
+            else if (bits <= 12) go(k_growth_quorum<12, false>);
+            else go(k_growth_quorum<16, false>);
         }
     }
     {   // deltas -> running sums

@@ -377,3 +377,31 @@ def test_variants_agree_with_oracle(ctx, variant, coarse):
     finally:
         ctx.config(capi.CFG_COVER_VARIANT, 2)
         ctx.config(capi.CFG_INDEX_COARSE, 8)
+
+
+def test_growth_arbitrary_quorum_table(ctx):
+    """pnx_ordered_growth takes the quorum bound as a table; tables that do not rise by 0/1 per
+    rank take the comparison kernel.  Reference rule (abacus.rs:1001-1010) evaluated directly."""
+    n, p = 5000, 10
+    items, pre, lens = orc.pansyn(31, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    tabs = np.array([[0, 2, 2, 5, 1, 1, 7, 3, 3, 9], [1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 1, 1, 2, 2, 3, 3, 4, 4, 5]],
+                    dtype=np.uint32)
+    cov = [1, 2, 1]
+    out = ctx.ordered_growth(cov, tabs)
+    r, c = orc.by_group(items, pre, pg, pg, n)
+    for t in range(3):
+        exp = np.zeros(p, dtype=np.int64)
+        for i in range(1, n + 1):
+            grp = c[r[i]:r[i + 1]]
+            if len(grp) < cov[t]:
+                continue
+            k = 0
+            for j in range(int(grp[0]), p):
+                if k < len(grp) - 1 and grp[k + 1] <= j:
+                    k += 1
+                if k + 1 >= tabs[t, int(grp[k])]:
+                    exp[j] += 1
+        assert out[0, t].tolist() == exp.tolist(), t
