@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--orders", type=int, default=128)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--pairs", default="1:0,2:0,1:0.5", help="coverage:quorum pairs")
     args = ap.parse_args()
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -41,7 +42,7 @@ def main():
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
 
     N, P, R = args.nodes, args.paths, args.orders
-    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    pairs = [(int(a.split(':')[0]), float(a.split(':')[1])) for a in args.pairs.split(',')]
     ctx = capi.Context(local_rank)
     ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
     order = np.arange(P, dtype=np.uint32)

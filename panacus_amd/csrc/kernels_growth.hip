@@ -23,6 +23,8 @@
 //   * bp counts use bit planes of the weights: sum_i w_i b_i = sum_p 2^p popc(b & W_p).
 // Orders are independent, so R orders shard over workgroups (and over GPUs: permutation
 // sharding, DESIGN.md "Multi-GPU").
+#include <type_traits>
+
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -102,83 +104,6 @@ __device__ static inline unsigned long long weighted_popc(uint32_t bits, const u
     for (uint32_t p = 0; p < n_planes; ++p)
         s += (unsigned long long)__popc(bits & wp_lds[p * 64 + lane]) << p;
     return s;
-}
-
-// ------------------------------------------------------------------------------------------
-// q == 0 pairs: res[j] = sum_i w_i [deg_i >= c] [first rank of i <= j]; deltas at first ranks
-// ------------------------------------------------------------------------------------------
-template <bool WEIGHTED>
-__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_q0(
-    const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
-    const uint32_t *__restrict__ perms, uint32_t n_chunks, uint32_t blocks_per_chunk,
-    const uint32_t *__restrict__ cmask, const int32_t *__restrict__ mask_idx /* per q0 pair, -1 = none */,
-    const uint32_t *__restrict__ pair_slot /* output slot t of each q0 pair */, uint32_t n_q0, uint32_t T,
-    const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
-    extern __shared__ unsigned long long smem[];
-    unsigned long long *acc = smem;  // [n_q0][G]
-    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc + (size_t)n_q0 * G);  // [waves][planes][64]
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t r = blockIdx.x / n_chunks, chunk = blockIdx.x % n_chunks;
-    const uint32_t *perm = perms + (uint64_t)r * G;
-    uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
-
-    for (uint32_t i = threadIdx.x; i < n_q0 * G; i += blockDim.x) acc[i] = 0;
-    __syncthreads();
-
-    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
-    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
-        uint32_t mask[GROW_Q0_MAX];
-#pragma unroll
-        for (int t = 0; t < GROW_Q0_MAX; ++t) {
-            mask[t] = 0xFFFFFFFFu;
-            if ((uint32_t)t < n_q0 && mask_idx[t] >= 0)
-                mask[t] = cmask[((uint64_t)mask_idx[t] * n_blocks + blk) * BLOCK_WORDS + lane];
-        }
-        if (WEIGHTED) {
-            for (uint32_t p = 0; p < n_planes; ++p)
-                wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        const uint32_t *col = M + (uint64_t)blk * BLOCK_WORDS + lane;
-        uint32_t seen = 0;
-        for (uint32_t jb = 0; jb < G; jb += GROW_PREFETCH) {
-            uint32_t x[GROW_PREFETCH];
-#pragma unroll
-            for (int u = 0; u < GROW_PREFETCH; ++u) {
-                x[u] = 0;
-                if (jb + u < G) x[u] = col[(uint64_t)perm[jb + u] * row_words];
-            }
-#pragma unroll
-            for (int u = 0; u < GROW_PREFETCH; ++u) {
-                const uint32_t nw = x[u] & ~seen;
-                seen |= x[u];
-                if (nw) {
-#pragma unroll
-                    for (int t = 0; t < GROW_Q0_MAX; ++t) {
-                        if ((uint32_t)t < n_q0) {
-                            const uint32_t bits = nw & mask[t];
-                            if (bits) {
-                                unsigned long long c = WEIGHTED ? weighted_popc(bits, wp, n_planes, lane)
-                                                                : (unsigned long long)__popc(bits);
-                                atomicAdd(&acc[(size_t)t * G + jb + u], c);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // deltas -> global (prefix-summed over ranks by k_growth_prefix)
-    for (uint32_t i = threadIdx.x; i < n_q0 * G; i += blockDim.x) {
-        const unsigned long long v = acc[i];
-        if (v) {
-            const uint32_t t = pair_slot[i / G], j = i % G;
-            atomicAdd(&out[((uint64_t)r * T + t) * G + j], v);
-        }
-    }
 }
 
 // out rows flagged as "delta" become running sums over the ranks
@@ -299,29 +224,35 @@ struct GrowthTabs {
     uint32_t n_q0;
 };
 
-template <int NPL1, int NQ, bool WEIGHTED>
-__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
+template <int NPL1, int NQ, bool WEIGHTED, int OW>
+__global__ __launch_bounds__(OW * 64) void k_growth_fused(
     const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
     const uint32_t *__restrict__ perms, uint32_t R, uint32_t blocks_per_chunk,
     const uint32_t *__restrict__ cmask, GrowthTabs tabs, const uint32_t *__restrict__ dtab /* T x G, 0/1 */,
     uint32_t T, const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
+    // one wave = one order; the OW waves of a workgroup walk the SAME blocks, so a block's rows
+    // are pulled from HBM once per workgroup and re-read by the other waves from L2 / MALL
+    typedef typename std::conditional<WEIGHTED, unsigned long long, uint32_t>::type acc_t;
     extern __shared__ unsigned long long smem[];
     const uint32_t n_q0 = tabs.n_q0;
     const uint32_t n_acc = n_q0 + NQ;
-    unsigned long long *acc = smem;  // [n_acc][G]
-    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc + (size_t)n_acc * G);
-
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t r = blockIdx.x % R, chunk = blockIdx.x / R;
-    const uint32_t *perm = perms + (uint64_t)r * G;
+    acc_t *acc_all = reinterpret_cast<acc_t *>(smem);                       // [OW][n_acc][G]
+    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc_all + (size_t)OW * n_acc * G);
+    acc_t *acc = acc_all + (size_t)wave * n_acc * G;
     uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
 
-    for (uint32_t i = threadIdx.x; i < n_acc * G; i += blockDim.x) acc[i] = 0;
-    __syncthreads();
+    const uint32_t n_rgroups = (R + OW - 1) / OW;
+    const uint32_t r = (blockIdx.x % n_rgroups) * OW + wave, chunk = blockIdx.x / n_rgroups;
+    const bool live = r < R;
+    const uint32_t *perm = perms + (uint64_t)(live ? r : 0) * G;
 
-    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
-    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
+    for (uint32_t i = lane; i < n_acc * G; i += 64) acc[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    const uint32_t b_end = live ? min(n_blocks, (chunk + 1) * blocks_per_chunk) : 0;
+    for (uint32_t blk = chunk * blocks_per_chunk; blk < b_end; ++blk) {
         uint32_t mask0[GROW_Q0_MAX];
 #pragma unroll
         for (int t = 0; t < GROW_Q0_MAX; ++t) {
@@ -371,8 +302,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
                                 if ((uint32_t)t < n_q0) {
                                     const uint32_t bits = nw & mask0[t];
                                     if (bits) {
-                                        unsigned long long c = WEIGHTED ? weighted_popc(bits, wp, n_planes, lane)
-                                                                        : (unsigned long long)__popc(bits);
+                                        acc_t c = WEIGHTED ? (acc_t)weighted_popc(bits, wp, n_planes, lane) : (acc_t)__popc(bits);
                                         atomicAdd(&acc[(size_t)t * G + jb + u], c);
                                     }
                                 }
@@ -402,28 +332,30 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
                         const uint32_t ge = ~sl[qi][NPL1 - 1];  // s >= 0  <=>  cnt >= Tq
                         ok[qi] = (ok[qi] & ~xv) | (ge & xv);
                         const uint32_t bits = ok[qi] & maskq[qi];
-                        unsigned long long *a = &acc[(size_t)(n_q0 + qi) * G + jb + u];
+                        acc_t *a = &acc[(size_t)(n_q0 + qi) * G + jb + u];  // this wave's own row: plain add
                         if (WEIGHTED) {
                             unsigned long long sv = weighted_popc(bits, wp, n_planes, lane);
                             uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
                             uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
-                            if (lane == 63) atomicAdd(a, (unsigned long long)lo + ((unsigned long long)mi << 24));
+                            if (lane == 63) *a += (acc_t)((unsigned long long)lo + ((unsigned long long)mi << 24));
                         } else {
                             const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(bits));
-                            if (lane == 63 && tot) atomicAdd(a, (unsigned long long)tot);
+                            if (lane == 63) *a += (acc_t)tot;
                         }
                     }
                 }
             }
         }
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_acc * G; i += blockDim.x) {
-        const unsigned long long v = acc[i];
-        if (v) {
-            const uint32_t a = i / G, j = i % G;
-            const uint32_t t = a < n_q0 ? tabs.q0_slot[a] : tabs.qq_slot[a - n_q0];
-            atomicAdd(&out[((uint64_t)r * T + t) * G + j], v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (live) {
+        for (uint32_t i = lane; i < n_acc * G; i += 64) {
+            const acc_t v = acc[i];
+            if (v) {
+                const uint32_t a = i / G, j = i % G;
+                const uint32_t t = a < n_q0 ? tabs.q0_slot[a] : tabs.qq_slot[a - n_q0];
+                atomicAdd(&out[((uint64_t)r * T + t) * G + j], (unsigned long long)v);
+            }
         }
     }
 }
@@ -545,27 +477,52 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                 tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
-            const size_t shmem = (size_t)(tabs.n_q0 + nq) * G * 8 + wp_bytes;
-            if (shmem > 64 * 1024)
+            // orders per workgroup (= waves): as many as fit the LDS accumulators, at most 16
+            const size_t acc_bytes_per_order = (size_t)(tabs.n_q0 + nq) * G * (ctx->weighted ? 8 : 4);
+            const size_t wp_per_order = ctx->weighted ? (size_t)WPLANES_MAX * 64 * sizeof(uint32_t) : 0;
+            int ow = 1;
+            for (int cand : {16, 4}) {
+                if ((size_t)cand * (acc_bytes_per_order + wp_per_order) <= 96 * 1024 && (uint32_t)cand <= 2 * R) {
+                    ow = cand;
+                    break;
+                }
+            }
+            if ((size_t)ow * (acc_bytes_per_order + wp_per_order) > 150 * 1024)
                 return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %u threshold pairs exceed the LDS accumulators",
                                  G, tabs.n_q0 + nq);
+            const size_t shmem = (size_t)ow * (acc_bytes_per_order + wp_per_order);
+            const uint32_t n_rgroups = (R + ow - 1) / ow;
+            // block chunks: enough workgroups to fill the chip, at least 4 blocks per walk
+            uint32_t fchunks = std::max<uint32_t>(2048 / n_rgroups, (NB + 63) / 64);
+            if (fchunks < 1) fchunks = 1;
+            if (fchunks > (NB + 3) / 4) fchunks = (NB + 3) / 4;
+            const uint32_t fbpc = (NB + fchunks - 1) / fchunks;
+            fchunks = (NB + fbpc - 1) / fbpc;
             auto go = [&](auto kern) {
-                hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
+                if (shmem > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                hipLaunchKernelGGL(kern, dim3(n_rgroups * fchunks), dim3(ow * 64), shmem, ctx->stream,
                                    (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p, R,
-                                   bpc, (const uint32_t *)ctx->d_cmask.p, tabs, (const uint32_t *)ctx->d_thr_meta.p, T,
+                                   fbpc, (const uint32_t *)ctx->d_cmask.p, tabs, (const uint32_t *)ctx->d_thr_meta.p, T,
                                    d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);
             };
-#define PNX_GROW_DISPATCH(NPL1)                                                                   \
+#define PNX_GROW_DISPATCH_OW(NPL1, OWV)                                                           \
     do {                                                                                          \
         if (ctx->weighted) {                                                                      \
-            if (nq == 0) go(k_growth_fused<NPL1, 0, true>);                                       \
-            else if (nq == 1) go(k_growth_fused<NPL1, 1, true>);                                  \
-            else go(k_growth_fused<NPL1, 2, true>);                                               \
+            if (nq == 0) go(k_growth_fused<NPL1, 0, true, OWV>);                                  \
+            else if (nq == 1) go(k_growth_fused<NPL1, 1, true, OWV>);                             \
+            else go(k_growth_fused<NPL1, 2, true, OWV>);                                          \
         } else {                                                                                  \
-            if (nq == 0) go(k_growth_fused<NPL1, 0, false>);                                      \
-            else if (nq == 1) go(k_growth_fused<NPL1, 1, false>);                                 \
-            else go(k_growth_fused<NPL1, 2, false>);                                              \
+            if (nq == 0) go(k_growth_fused<NPL1, 0, false, OWV>);                                 \
+            else if (nq == 1) go(k_growth_fused<NPL1, 1, false, OWV>);                            \
+            else go(k_growth_fused<NPL1, 2, false, OWV>);                                         \
         }                                                                                         \
+    } while (0)
+#define PNX_GROW_DISPATCH(NPL1)                                                                   \
+    do {                                                                                          \
+        if (ow == 16) PNX_GROW_DISPATCH_OW(NPL1, 16);                                             \
+        else if (ow == 4) PNX_GROW_DISPATCH_OW(NPL1, 4);                                          \
+        else PNX_GROW_DISPATCH_OW(NPL1, 1);                                                       \
     } while (0)
             // planes for s in [-G, G]: bits(G) + 1 (sign)
             if (bits + 1 <= 7) PNX_GROW_DISPATCH(7);
@@ -575,6 +532,7 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
             else if (bits + 1 <= 17) PNX_GROW_DISPATCH(17);
             else return ctx->fail(PNX_ELIMIT, "ordered growth supports at most 65535 groups");
 #undef PNX_GROW_DISPATCH
+#undef PNX_GROW_DISPATCH_OW
             i0 += tabs.n_q0;
             iq += (size_t)nq;
         }
