@@ -207,72 +207,69 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
 }
 
 // ------------------------------------------------------------------------------------------
-// fused kernel: up to GROW_Q0_MAX q == 0 pairs and NQ q > 0 pairs share ONE read of the
-// presence rows.  q > 0 pairs use the slack form s_j = cnt_j - Tq[j] kept bit-sliced in two's
-// complement (NPL1 planes): Tq rises by dT in {0, 1} per rank (q <= 1), so per rank s += x
-// (dT = 0) or s += x - 1 (dT = 1), i.e. one ripple increment under mask x or one ripple
-// decrement under mask ~x, and "cnt >= Tq" is just the complement of the sign plane -- no
-// plane-by-plane comparison.  Workgroups of one block chunk carry consecutive blockIdx for
-// all R orders, so the R walks over the same rows run side by side and are served by
-// L2 / Infinity Cache instead of HBM.
+// fused growth kernel: N0 pairs with q == 0 and NQ pairs with q > 0 share ONE read of the
+// presence rows of an order.
+//   * q > 0 pairs use the slack form s_j = cnt_j - Tq[j], bit-sliced in two's complement
+//     (NPL1 planes).  Tq rises by dT in {0,1} per rank (q <= 1), so per rank s += x (dT = 0)
+//     or s += x - 1 (dT = 1): ONE ripple pass under mask m = x ^ dmask with the plane
+//     complemented by dmask (dmask = 0 / ~0 is wave-uniform and comes from a host table), and
+//     "cnt >= Tq" is the complement of the sign plane -- no plane-by-plane comparison.
+//   * everything on the per-rank path is branch-free VALU: the first version of this kernel
+//     was bound by the CU's single scalar unit (27 SALU instructions per rank for uniform
+//     branches, exec-mask juggling and 64-bit address arithmetic); row offsets now come
+//     pre-multiplied from the host as 32-bit byte offsets (saddr + voffset addressing).
+//   * per-rank popcounts (<= 32 per lane) are packed two per register for the 16 ranks of
+//     a batch and reduced over the wave once per batch (8 packed DPP reductions instead of
+//     16), then lanes 0..15 add the 16 totals to the workgroup's LDS accumulators.
+// Workgroups of one block chunk carry consecutive blockIdx for all R orders.
 // ------------------------------------------------------------------------------------------
 struct GrowthTabs {
     int32_t q0_midx[GROW_Q0_MAX];   // mask index per q == 0 pair, -1 = none
     uint32_t q0_slot[GROW_Q0_MAX];  // output slot t
     int32_t qq_midx[2];
     uint32_t qq_slot[2];
-    uint32_t n_q0;
 };
 
-template <int NPL1, int NQ, bool WEIGHTED, int OW>
-__global__ __launch_bounds__(OW * 64) void k_growth_fused(
-    const uint32_t *__restrict__ M, uint64_t row_words, uint32_t n_blocks, uint32_t G,
-    const uint32_t *__restrict__ perms, uint32_t R, uint32_t blocks_per_chunk,
-    const uint32_t *__restrict__ cmask, GrowthTabs tabs, const uint32_t *__restrict__ dtab /* T x G, 0/1 */,
-    uint32_t T, const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
-    // one wave = one order; the OW waves of a workgroup walk the SAME blocks, so a block's rows
-    // are pulled from HBM once per workgroup and re-read by the other waves from L2 / MALL
-    typedef typename std::conditional<WEIGHTED, unsigned long long, uint32_t>::type acc_t;
+template <int NPL1, int N0, int NQ, bool WEIGHTED>
+__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
+    const uint32_t *__restrict__ M, uint32_t n_blocks, uint32_t G,
+    const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
+    uint32_t blocks_per_chunk, const uint32_t *__restrict__ cmask, GrowthTabs tabs,
+    const uint32_t *__restrict__ dmask /* T x G: 0 or ~0 */, uint32_t T,
+    const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
+    constexpr int NA = N0 + NQ;
+    constexpr int B = GROW_PREFETCH;  // ranks per batch
     extern __shared__ unsigned long long smem[];
-    const uint32_t n_q0 = tabs.n_q0;
-    const uint32_t n_acc = n_q0 + NQ;
+    unsigned long long *acc = smem;                                           // [NA][G]
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(acc + (size_t)NA * G);  // [waves][NA][B/2]
+    uint32_t *wp_all = stage_all + GROW_WAVES * NA * (B / 2);                  // [waves][planes][64]
+
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    acc_t *acc_all = reinterpret_cast<acc_t *>(smem);                       // [OW][n_acc][G]
-    uint32_t *wp_all = reinterpret_cast<uint32_t *>(acc_all + (size_t)OW * n_acc * G);
-    acc_t *acc = acc_all + (size_t)wave * n_acc * G;
+    const uint32_t r = blockIdx.x % R, chunk = blockIdx.x / R;
+    const uint32_t *ro = rowoff + (uint64_t)r * G;
+    uint32_t *stage = stage_all + wave * NA * (B / 2);
     uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
+    const char *Mb = reinterpret_cast<const char *>(M);
 
-    const uint32_t n_rgroups = (R + OW - 1) / OW;
-    const uint32_t r = (blockIdx.x % n_rgroups) * OW + wave, chunk = blockIdx.x / n_rgroups;
-    const bool live = r < R;
-    const uint32_t *perm = perms + (uint64_t)(live ? r : 0) * G;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
 
-    for (uint32_t i = lane; i < n_acc * G; i += 64) acc[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    const uint32_t b_end = live ? min(n_blocks, (chunk + 1) * blocks_per_chunk) : 0;
-    for (uint32_t blk = chunk * blocks_per_chunk; blk < b_end; ++blk) {
-        uint32_t mask0[GROW_Q0_MAX];
+    const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
+    for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
+        uint32_t mask[NA > 0 ? NA : 1];
 #pragma unroll
-        for (int t = 0; t < GROW_Q0_MAX; ++t) {
-            mask0[t] = 0xFFFFFFFFu;
-            if ((uint32_t)t < n_q0 && tabs.q0_midx[t] >= 0)
-                mask0[t] = cmask[((uint64_t)tabs.q0_midx[t] * n_blocks + blk) * BLOCK_WORDS + lane];
-        }
-        uint32_t maskq[NQ > 0 ? NQ : 1];
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-            maskq[qi] = 0xFFFFFFFFu;
-            if (tabs.qq_midx[qi] >= 0)
-                maskq[qi] = cmask[((uint64_t)tabs.qq_midx[qi] * n_blocks + blk) * BLOCK_WORDS + lane];
+        for (int a = 0; a < NA; ++a) {
+            const int32_t mi = a < N0 ? tabs.q0_midx[a] : tabs.qq_midx[a - N0];
+            mask[a] = 0xFFFFFFFFu;
+            if (mi >= 0) mask[a] = cmask[((uint64_t)mi * n_blocks + blk) * BLOCK_WORDS + lane];
         }
         if (WEIGHTED) {
             for (uint32_t p = 0; p < n_planes; ++p)
                 wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        const uint32_t *col = M + (uint64_t)blk * BLOCK_WORDS + lane;
+        const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
         uint32_t seen = 0;
         uint32_t sl[NQ > 0 ? NQ : 1][NPL1];
         uint32_t ok[NQ > 0 ? NQ : 1];
@@ -282,80 +279,109 @@ __global__ __launch_bounds__(OW * 64) void k_growth_fused(
 #pragma unroll
             for (int k = 0; k < NPL1; ++k) sl[qi][k] = 0;
         }
-        for (uint32_t jb = 0; jb < G; jb += GROW_PREFETCH) {
-            uint32_t x[GROW_PREFETCH];
+
+        // one rank: returns the NA per-lane contributions
+        auto rank_step = [&](uint32_t xv, uint32_t j, uint32_t (&val)[NA > 0 ? NA : 1]) {
+            if (N0 > 0) {
+                const uint32_t nw = xv & ~seen;
+                seen |= xv;
 #pragma unroll
-            for (int u = 0; u < GROW_PREFETCH; ++u) {
-                x[u] = 0;
-                if (jb + u < G) x[u] = col[(uint64_t)perm[jb + u] * row_words];
+                for (int a = 0; a < N0; ++a) val[a] = nw & mask[a];
             }
 #pragma unroll
-            for (int u = 0; u < GROW_PREFETCH; ++u) {
-                if (jb + u < G) {  // wave-uniform
-                    const uint32_t xv = x[u];
-                    if (n_q0) {
-                        const uint32_t nw = xv & ~seen;
-                        seen |= xv;
-                        if (nw) {
-    #pragma unroll
-                            for (int t = 0; t < GROW_Q0_MAX; ++t) {
-                                if ((uint32_t)t < n_q0) {
-                                    const uint32_t bits = nw & mask0[t];
-                                    if (bits) {
-                                        acc_t c = WEIGHTED ? (acc_t)weighted_popc(bits, wp, n_planes, lane) : (acc_t)__popc(bits);
-                                        atomicAdd(&acc[(size_t)t * G + jb + u], c);
-                                    }
-                                }
-                            }
-                        }
+            for (int qi = 0; qi < NQ; ++qi) {
+                const uint32_t dm = dmask[(uint64_t)tabs.qq_slot[qi] * G + j];  // wave-uniform
+                uint32_t m = xv ^ dm;  // dT = 0: increment where x ; dT = 1: decrement where !x
+#pragma unroll
+                for (int k = 0; k < NPL1; ++k) {
+                    const uint32_t t = (sl[qi][k] ^ dm) & m;
+                    sl[qi][k] ^= m;
+                    m = t;
+                }
+                const uint32_t ge = ~sl[qi][NPL1 - 1];  // s >= 0  <=>  cnt >= Tq
+                ok[qi] = (ok[qi] & ~xv) | (ge & xv);
+                val[N0 + qi] = ok[qi] & mask[N0 + qi];
+            }
+        };
+
+        uint32_t jb = 0;
+        for (; jb + B <= G; jb += B) {  // full batches: no guards on the per-rank path
+            uint32_t x[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) x[u] = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb + u] + voff));
+            if (!WEIGHTED) {
+                uint32_t pk[NA > 0 ? NA : 1][B / 2];
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    uint32_t val[NA > 0 ? NA : 1];
+                    rank_step(x[u], jb + u, val);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const uint32_t c = (uint32_t)__popc(val[a]);
+                        if (u & 1) pk[a][u >> 1] |= c << 16; else pk[a][u >> 1] = c;
                     }
-    #pragma unroll
-                    for (int qi = 0; qi < NQ; ++qi) {
-                        const uint32_t dT = dtab[(uint64_t)tabs.qq_slot[qi] * G + jb + u];  // wave-uniform
-                        if (dT == 0) {  // s += x
-                            uint32_t carry = xv;
-    #pragma unroll
-                            for (int k = 0; k < NPL1; ++k) {
-                                const uint32_t tmp = sl[qi][k] & carry;
-                                sl[qi][k] ^= carry;
-                                carry = tmp;
-                            }
-                        } else {  // s += x - 1  <=>  s -= 1 where x == 0
-                            uint32_t borrow = ~xv;
-    #pragma unroll
-                            for (int k = 0; k < NPL1; ++k) {
-                                const uint32_t tmp = ~sl[qi][k] & borrow;
-                                sl[qi][k] ^= borrow;
-                                borrow = tmp;
-                            }
-                        }
-                        const uint32_t ge = ~sl[qi][NPL1 - 1];  // s >= 0  <=>  cnt >= Tq
-                        ok[qi] = (ok[qi] & ~xv) | (ge & xv);
-                        const uint32_t bits = ok[qi] & maskq[qi];
-                        acc_t *a = &acc[(size_t)(n_q0 + qi) * G + jb + u];  // this wave's own row: plain add
-                        if (WEIGHTED) {
-                            unsigned long long sv = weighted_popc(bits, wp, n_planes, lane);
-                            uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
-                            uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
-                            if (lane == 63) *a += (acc_t)((unsigned long long)lo + ((unsigned long long)mi << 24));
-                        } else {
-                            const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(bits));
-                            if (lane == 63) *a += (acc_t)tot;
-                        }
+                }
+                // 8 packed wave reductions per accumulator, totals land in lane 63
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int k = 0; k < B / 2; ++k) pk[a][k] = wave_sum_to_lane63(pk[a][k]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int k = 0; k < B / 2; ++k) stage[a * (B / 2) + k] = pk[a][k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane < (uint32_t)B) {
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const uint32_t w = stage[a * (B / 2) + (lane >> 1)];
+                        const uint32_t c = (lane & 1) ? (w >> 16) : (w & 0xFFFFu);
+                        if (c) atomicAdd(&acc[(size_t)a * G + jb + lane], (unsigned long long)c);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            } else {
+#pragma unroll
+                for (int u = 0; u < B; ++u) {
+                    uint32_t val[NA > 0 ? NA : 1];
+                    rank_step(x[u], jb + u, val);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        const unsigned long long sv = weighted_popc(val[a], wp, n_planes, lane);
+                        const uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
+                        const uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
+                        if (lane == 63) atomicAdd(&acc[(size_t)a * G + jb + u], (unsigned long long)lo + ((unsigned long long)mi << 24));
                     }
                 }
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (live) {
-        for (uint32_t i = lane; i < n_acc * G; i += 64) {
-            const acc_t v = acc[i];
-            if (v) {
-                const uint32_t a = i / G, j = i % G;
-                const uint32_t t = a < n_q0 ? tabs.q0_slot[a] : tabs.qq_slot[a - n_q0];
-                atomicAdd(&out[((uint64_t)r * T + t) * G + j], (unsigned long long)v);
+        for (; jb < G; ++jb) {  // tail ranks (G not a multiple of the batch)
+            const uint32_t xv = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb] + voff));
+            uint32_t val[NA > 0 ? NA : 1];
+            rank_step(xv, jb, val);
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                if (WEIGHTED) {
+                    const unsigned long long sv = weighted_popc(val[a], wp, n_planes, lane);
+                    const uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
+                    const uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
+                    if (lane == 63) atomicAdd(&acc[(size_t)a * G + jb], (unsigned long long)lo + ((unsigned long long)mi << 24));
+                } else {
+                    const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(val[a]));
+                    if (lane == 63 && tot) atomicAdd(&acc[(size_t)a * G + jb], (unsigned long long)tot);
+                }
             }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) {
+        const unsigned long long v = acc[i];
+        if (v) {
+            const uint32_t a = i / G, j = i % G;
+            const uint32_t t = a < (uint32_t)N0 ? tabs.q0_slot[a] : tabs.qq_slot[a - N0];
+            atomicAdd(&out[((uint64_t)r * T + t) * G + j], v);
         }
     }
 }
@@ -436,7 +462,7 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
 
     // q > 0 pairs whose table rises by 0 or 1 per rank (always true for q in [0,1]) take the
     // slack form; anything else falls back to the plane-by-plane comparison kernel
-    std::vector<uint32_t> q0, qslack, qgeneral, dtab((size_t)T * G, 0);
+    std::vector<uint32_t> q0, qslack, qgeneral, is_delta_general, dtab((size_t)T * G, 0);
     {
         std::vector<uint32_t> qt((size_t)T * G);
         PNX_HIP(ctx, hipMemcpyAsync(qt.data(), ctx->d_qtab.p, qt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -454,9 +480,29 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
             (unit ? qslack : qgeneral).push_back(t);
         }
     }
-    if ((rc = ensure(ctx, ctx->d_thr_meta, dtab.size() * sizeof(uint32_t) + 16))) return rc;
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_thr_meta.p, dtab.data(), dtab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    // device tables: dmask[T][G] (0 / ~0 per rank) then rowoff[R][G] (byte offset of the row of rank j)
+    const uint64_t m_bytes = (uint64_t)G * row_words * 4;
+    const bool use_fused = m_bytes < (1ull << 32);
+    std::vector<uint32_t> tabs_h((size_t)T * G + (size_t)R * G);
+    for (size_t i = 0; i < (size_t)T * G; ++i) tabs_h[i] = dtab[i] ? 0xFFFFFFFFu : 0u;
+    if (use_fused) {
+        std::vector<uint32_t> pm((size_t)R * G);
+        PNX_HIP(ctx, hipMemcpyAsync(pm.data(), ctx->d_perms.p, pm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < pm.size(); ++i) tabs_h[(size_t)T * G + i] = (uint32_t)((uint64_t)pm[i] * row_words * 4);
+    } else {
+        // presence matrix >= 4 GiB: the 32-bit row offsets do not reach; every pair takes the
+        // comparison kernel (64-bit addressing)
+        for (uint32_t t : q0) qgeneral.push_back(t);
+        for (uint32_t t : qslack) qgeneral.push_back(t);
+        q0.clear();
+        qslack.clear();
+    }
+    if ((rc = ensure(ctx, ctx->d_thr_meta, tabs_h.size() * sizeof(uint32_t) + 16))) return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_thr_meta.p, tabs_h.data(), tabs_h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t *d_dmask = (const uint32_t *)ctx->d_thr_meta.p;
+    const uint32_t *d_rowoff = d_dmask + (size_t)T * G;
 
     uint32_t bits = 1;
     while (bits < 32 && (G >> bits) != 0) ++bits;
@@ -467,73 +513,55 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
         size_t i0 = 0, iq = 0;
         while (i0 < q0.size() || iq < qslack.size()) {
             GrowthTabs tabs;
-            tabs.n_q0 = (uint32_t)std::min<size_t>(GROW_Q0_MAX, q0.size() - i0);
-            for (uint32_t k = 0; k < GROW_Q0_MAX; ++k) {
-                tabs.q0_midx[k] = k < tabs.n_q0 ? mask_of[q0[i0 + k]] : -1;
-                tabs.q0_slot[k] = k < tabs.n_q0 ? q0[i0 + k] : 0;
+            const int n0 = (int)std::min<size_t>(GROW_Q0_MAX, q0.size() - i0);
+            for (int k = 0; k < GROW_Q0_MAX; ++k) {
+                tabs.q0_midx[k] = k < n0 ? mask_of[q0[i0 + k]] : -1;
+                tabs.q0_slot[k] = k < n0 ? q0[i0 + k] : 0;
             }
             const int nq = (int)std::min<size_t>(2, qslack.size() - iq);
             for (int k = 0; k < 2; ++k) {
                 tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
-            // orders per workgroup (= waves): as many as fit the LDS accumulators, at most 16
-            const size_t acc_bytes_per_order = (size_t)(tabs.n_q0 + nq) * G * (ctx->weighted ? 8 : 4);
-            const size_t wp_per_order = ctx->weighted ? (size_t)WPLANES_MAX * 64 * sizeof(uint32_t) : 0;
-            int ow = 1;
-            for (int cand : {16, 4}) {
-                if ((size_t)cand * (acc_bytes_per_order + wp_per_order) <= 96 * 1024 && (uint32_t)cand <= 2 * R) {
-                    ow = cand;
-                    break;
-                }
-            }
-            if ((size_t)ow * (acc_bytes_per_order + wp_per_order) > 150 * 1024)
-                return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %u threshold pairs exceed the LDS accumulators",
-                                 G, tabs.n_q0 + nq);
-            const size_t shmem = (size_t)ow * (acc_bytes_per_order + wp_per_order);
-            const uint32_t n_rgroups = (R + ow - 1) / ow;
-            // block chunks: enough workgroups to fill the chip, at least 4 blocks per walk
-            uint32_t fchunks = std::max<uint32_t>(2048 / n_rgroups, (NB + 63) / 64);
-            if (fchunks < 1) fchunks = 1;
-            if (fchunks > (NB + 3) / 4) fchunks = (NB + 3) / 4;
-            const uint32_t fbpc = (NB + fchunks - 1) / fchunks;
-            fchunks = (NB + fbpc - 1) / fbpc;
+            const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wp_bytes;
+            if (shmem > 64 * 1024)
+                return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %d threshold pairs exceed the LDS accumulators",
+                                 G, n0 + nq);
             auto go = [&](auto kern) {
-                if (shmem > 64 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-                hipLaunchKernelGGL(kern, dim3(n_rgroups * fchunks), dim3(ow * 64), shmem, ctx->stream,
-                                   (const uint32_t *)ctx->d_M.p, row_words, NB, G, (const uint32_t *)ctx->d_perms.p, R,
-                                   fbpc, (const uint32_t *)ctx->d_cmask.p, tabs, (const uint32_t *)ctx->d_thr_meta.p, T,
-                                   d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);
+                hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
+                                   (const uint32_t *)ctx->d_M.p, NB, G, d_rowoff, R, bpc, (const uint32_t *)ctx->d_cmask.p,
+                                   tabs, d_dmask, T, d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);
             };
-#define PNX_GROW_DISPATCH_OW(NPL1, OWV)                                                           \
+#define PNX_GROW_NQ(NPL1, N0V, W)                                                                 \
     do {                                                                                          \
-        if (ctx->weighted) {                                                                      \
-            if (nq == 0) go(k_growth_fused<NPL1, 0, true, OWV>);                                  \
-            else if (nq == 1) go(k_growth_fused<NPL1, 1, true, OWV>);                             \
-            else go(k_growth_fused<NPL1, 2, true, OWV>);                                          \
-        } else {                                                                                  \
-            if (nq == 0) go(k_growth_fused<NPL1, 0, false, OWV>);                                 \
-            else if (nq == 1) go(k_growth_fused<NPL1, 1, false, OWV>);                            \
-            else go(k_growth_fused<NPL1, 2, false, OWV>);                                         \
+        if (nq == 0) go(k_growth_fused<NPL1, N0V, 0, W>);                                         \
+        else if (nq == 1) go(k_growth_fused<NPL1, N0V, 1, W>);                                    \
+        else go(k_growth_fused<NPL1, N0V, 2, W>);                                                 \
+    } while (0)
+#define PNX_GROW_N0(NPL1, W)                                                                      \
+    do {                                                                                          \
+        switch (n0) {                                                                             \
+            case 0: PNX_GROW_NQ(NPL1, 0, W); break;                                               \
+            case 1: PNX_GROW_NQ(NPL1, 1, W); break;                                               \
+            case 2: PNX_GROW_NQ(NPL1, 2, W); break;                                               \
+            case 3: PNX_GROW_NQ(NPL1, 3, W); break;                                               \
+            default: PNX_GROW_NQ(NPL1, 4, W); break;                                              \
         }                                                                                         \
     } while (0)
 #define PNX_GROW_DISPATCH(NPL1)                                                                   \
     do {                                                                                          \
-        if (ow == 16) PNX_GROW_DISPATCH_OW(NPL1, 16);                                             \
-        else if (ow == 4) PNX_GROW_DISPATCH_OW(NPL1, 4);                                          \
-        else PNX_GROW_DISPATCH_OW(NPL1, 1);                                                       \
+        if (ctx->weighted) PNX_GROW_N0(NPL1, true); else PNX_GROW_N0(NPL1, false);                \
     } while (0)
             // planes for s in [-G, G]: bits(G) + 1 (sign)
-            if (bits + 1 <= 7) PNX_GROW_DISPATCH(7);
-            else if (bits + 1 <= 9) PNX_GROW_DISPATCH(9);
+            if (bits + 1 <= 9) PNX_GROW_DISPATCH(9);
             else if (bits + 1 <= 11) PNX_GROW_DISPATCH(11);
-            else if (bits + 1 <= 13) PNX_GROW_DISPATCH(13);
+            else if (bits + 1 <= 14) PNX_GROW_DISPATCH(14);
             else if (bits + 1 <= 17) PNX_GROW_DISPATCH(17);
             else return ctx->fail(PNX_ELIMIT, "ordered growth supports at most 65535 groups");
 #undef PNX_GROW_DISPATCH
-#undef PNX_GROW_DISPATCH_OW
-            i0 += tabs.n_q0;
+#undef PNX_GROW_N0
+#undef PNX_GROW_NQ
+            i0 += (size_t)n0;
             iq += (size_t)nq;
         }
     }
