@@ -44,7 +44,7 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
-def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_reps=12):
+def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_reps=40):
     """The oracle (a plain-C port of the reference's serial loops) on a bounded sample of the
     same workload, timed on this host: coverage + hist + closed-form growth, repeated until
     about `min_seconds` of CPU work has been measured."""
@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--tile-blocks", type=int, default=1)
     ap.add_argument("--cover-variant", type=int, default=None)
     ap.add_argument("--index-coarse", type=int, default=None)
+    ap.add_argument("--index-walk", type=int, default=None)
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
@@ -116,6 +117,8 @@ def main():
     ctx.config(capi.CFG_CACHE_INDEX, 0)
     if args.index_coarse is not None:
         ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
+    if args.index_walk is not None:
+        ctx.config(capi.CFG_INDEX_WALK, args.index_walk)
     if args.cover_variant is not None:
         ctx.config(capi.CFG_COVER_VARIANT, args.cover_variant)
     ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)

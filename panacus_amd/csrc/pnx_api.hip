@@ -476,6 +476,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             ctx->index_coarse = (uint32_t)value;
             ctx->index_valid = false;
             return PNX_OK;
+        case PNX_CFG_INDEX_WALK:
+            ctx->index_walk = value != 0;
+            ctx->index_valid = false;
+            return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:
             ctx->want_M = value != 0;
             if (!ctx->want_M) ctx->M_valid = false;

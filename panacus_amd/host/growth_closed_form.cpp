@@ -65,7 +65,7 @@ struct Job {
     double tot = 0.0;
     // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
     // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
-    std::vector<double> term1, term2;
+    std::unique_ptr<double[]> term1, term2;  // left uninitialised: every entry that is read is written by its row
     std::vector<double> out;
 
     Job(Branch b, const std::vector<uint64_t> &h, Threshold cov, Threshold quo, std::shared_ptr<Log2Table> tab)
@@ -91,8 +91,8 @@ struct Job {
             for (uint64_t i = c; i <= n; ++i) t += hist[i];
             tot = (double)t;
         }
-        term1.resize((n + 1) * (n + 1));
-        if (b == QUORUM) term2.resize((n + 1) * (n + 1));
+        term1.reset(new double[(n + 1) * (n + 1)]);
+        if (b == QUORUM) term2.reset(new double[(n + 1) * (n + 1)]);
         out.assign(n, 0.0);
     }
 
@@ -101,7 +101,7 @@ struct Job {
     // everything the reference computes for histogram index i, for all m
     void run_row(uint64_t i, std::vector<double> &q) const {
         const Log2Table &L = *lg;
-        double *t1 = const_cast<double *>(term1.data()) + i * (n + 1);
+        double *t1 = term1.get() + i * (n + 1);
         double pm = 0.0;
         if (branch == UNION) {
             // hist.rs:102-111: for i in c..n-m+1 { perc_mult[i] += log2(n-m-i+1); y += exp2(..) }
@@ -120,7 +120,7 @@ struct Job {
             }
         if (branch != QUORUM || i >= n) return;
         // hist.rs:163-183, row i of Q
-        double *t2 = const_cast<double *>(term2.data()) + i * (n + 1);
+        double *t2 = term2.get() + i * (n + 1);
         q.assign(n + 1, 0.0);
         const double nan = std::nan("");
         for (uint64_t m = 1; m <= n; ++m) {
@@ -149,27 +149,25 @@ struct Job {
         }
     }
 
-    // the sums over i, serially and in ascending i like the reference
-    void finish() {
-        for (uint64_t m = 1; m <= n; ++m) {
-            double y = 0.0;
-            if (branch == UNION) {
-                for (uint64_t i = c; i + m <= n; ++i) y += term1[i * (n + 1) + m];
-                out[m - 1] = tot - y;
-                continue;
-            }
-            for (uint64_t i = std::max(m, c); i <= n; ++i) y += term1[i * (n + 1) + m];
-            if (branch == CORE) {
-                out[m - 1] = y;
-                continue;
-            }
-            double yr = 0.0;
-            for (uint64_t i = m_quorum[m]; i < n; ++i) {
-                const double t = term2[i * (n + 1) + m];
-                if (t == t) yr += t;  // not NaN <=> add == true
-            }
-            out[m - 1] = y + yr;
+    // the sum over i for one m, in ascending i like the reference (different m are independent)
+    void finish_m(uint64_t m) {
+        double y = 0.0;
+        if (branch == UNION) {
+            for (uint64_t i = c; i + m <= n; ++i) y += term1[i * (n + 1) + m];
+            out[m - 1] = tot - y;
+            return;
         }
+        for (uint64_t i = std::max(m, c); i <= n; ++i) y += term1[i * (n + 1) + m];
+        if (branch == CORE) {
+            out[m - 1] = y;
+            return;
+        }
+        double yr = 0.0;
+        for (uint64_t i = m_quorum[m]; i < n; ++i) {
+            const double t = term2[i * (n + 1) + m];
+            if (t == t) yr += t;  // not NaN <=> add == true
+        }
+        out[m - 1] = y + yr;
     }
 };
 
@@ -212,11 +210,24 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
     } else {
         ThreadPool::instance().parallel_for(tasks.size(), body, n_threads);
     }
-    std::vector<std::vector<double>> out;
-    for (auto &j : jobs) {
-        j->finish();
-        out.push_back(std::move(j->out));
+    // epilogue: one task per (job, block of m)
+    struct Fin {
+        Job *job;
+        uint64_t lo, hi;
+    };
+    std::vector<Fin> fins;
+    for (auto &j : jobs)
+        for (uint64_t lo = 1; lo <= j->n; lo += 16) fins.push_back(Fin{j.get(), lo, std::min(j->n, lo + 15)});
+    auto fin_body = [&](size_t k) {
+        for (uint64_t m = fins[k].lo; m <= fins[k].hi; ++m) fins[k].job->finish_m(m);
+    };
+    if (work < 20000 || n_threads == 1) {
+        for (size_t k = 0; k < fins.size(); ++k) fin_body(k);
+    } else {
+        ThreadPool::instance().parallel_for(fins.size(), fin_body, n_threads);
     }
+    std::vector<std::vector<double>> out;
+    for (auto &j : jobs) out.push_back(std::move(j->out));
     return out;
 }
 
