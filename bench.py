@@ -127,21 +127,20 @@ def main():
     info = ctx.info()
     S = int(info.n_steps)
 
-    hist_host = np.zeros(P + 1, dtype=np.uint64)
-    hist_dev = None
+    hist_views = {}
 
     def enqueue():
         ctx.hist_async()
 
     def settle():
-        """wait for the enqueued pass; multi-GPU: sum the per-shard counters over RCCL"""
-        nonlocal hist_dev
+        """wait for the OLDEST enqueued pass; multi-GPU: sum the per-shard counters over RCCL"""
         if world > 1:
-            d_hist, _ = ctx.hist_device()  # settles the pass, leaves the counters in HBM
-            if hist_dev is None:
-                hist_dev = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
-            dist.all_reduce(hist_dev)  # RCCL, int64 sum == uint64 sum for counts < 2^63
-            torch.cuda.current_stream().synchronize()
+            d_hist, _ = ctx.hist_device()  # counters of that pass, still in HBM
+            t = hist_views.get(d_hist)
+            if t is None:
+                t = hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
+            dist.all_reduce(t)  # RCCL, int64 sum == uint64 sum for counts < 2^63
+            return t.cpu().numpy().view(np.uint64)
         _, h = ctx.hist_fetch(want_countable=False)
         return h
 
@@ -151,15 +150,15 @@ def main():
         return hostlib.calc_growths(h, thr, args.growth_threads)
 
     def run(n_steps):
-        """n_steps complete histgrowth passes.  Consecutive passes are independent, so the
-        host-side closed form of pass k overlaps the device work of pass k+1 (two passes in
-        flight); every pass is finished inside the call."""
+        """n_steps complete histgrowth passes.  Consecutive passes are independent, so pass k+1
+        is enqueued on the GPU before the host fetches pass k and evaluates its closed forms
+        (two passes in flight); every pass is finished inside the call."""
         h = growths = None
         enqueue()
         for k in range(n_steps):
-            h = settle()
             if k + 1 < n_steps:
                 enqueue()
+            h = settle()
             growths = growth(h)
         return h, growths
 

@@ -89,9 +89,13 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
  */
 int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
 
-/* Split form for pipelining and multi-GPU: enqueue on the context's stream, leave results
- * in HBM, expose the device counters so the caller can all-reduce them (RCCL, uint64 sum)
- * before fetching.  d_hist has n_groups+1 u64, d_countable n_items+1 u32. */
+/* Split form for pipelining and multi-GPU: pnx_hist_async enqueues one pass on the context's
+ * stream (kernels + an async copy of the counters into pinned host memory).  Up to TWO
+ * passes may be in flight, so pass k+1 can be enqueued before pass k is looked at;
+ * pnx_hist_fetch / pnx_hist_device wait for and return the OLDEST pass in flight (or the last
+ * finished one).  pnx_hist_device exposes that pass's counters in HBM (n_groups+1 u64, owned
+ * by the pass) so the caller can all-reduce them with RCCL; d_countable (n_items+1 u32) is
+ * shared by all passes and only stable once no younger pass is running. */
 int pnx_hist_async(pnx_ctx *ctx);
 int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable);
 int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);

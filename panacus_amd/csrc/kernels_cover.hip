@@ -692,7 +692,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            use_m ? (const uint8_t *)ctx->d_grp_general.p : (const uint8_t *)nullptr,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
-                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_flags.p);
+                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->cur->d_flags.p);
     };
     switch (ctx->cover_variant) {
         case 1:
@@ -723,30 +723,30 @@ int launch_cover_pass(pnx_ctx *ctx) {
     int rc;
     const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
     const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
-    if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->cur->d_flags, 8 * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_grp_general, ctx->n_groups ? ctx->n_groups : 1))) return rc;
     if ((rc = ensure(ctx, ctx->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->d_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->cur->d_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t)))) return rc;
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
 
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->cur->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
     PNX_HIP(ctx, hipMemsetAsync(ctx->d_grp_general.p, 0, ctx->n_groups ? ctx->n_groups : 1, ctx->stream));
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_hist.p, 0, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->cur->d_hist.p, 0, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), ctx->stream));
 
     if (ctx->n_ordered) {
         prof_begin(ctx, PNX_K_SCATTER);
         hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
                            (const uint8_t *)ctx->d_path_class.p, (const uint32_t *)ctx->d_ord_path.p,
                            (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
-                           (uint8_t *)ctx->d_grp_general.p, (uint32_t *)ctx->d_flags.p);
+                           (uint8_t *)ctx->d_grp_general.p, (uint32_t *)ctx->cur->d_flags.p);
         if (use_m && m_words) {
             hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->stream,
-                               (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->d_flags.p);
+                               (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->cur->d_flags.p);
             hipLaunchKernelGGL(k_scatter_general, dim3(2048), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
                                (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                                ctx->n_ordered, (const uint8_t *)ctx->d_path_class.p, (uint32_t *)ctx->d_M.p,
-                               (uint64_t)ctx->n_blocks * BLOCK_WORDS, (const uint32_t *)ctx->d_flags.p);
+                               (uint64_t)ctx->n_blocks * BLOCK_WORDS, (const uint32_t *)ctx->cur->d_flags.p);
         }
         prof_end(ctx);
         PNX_HIP(ctx, hipGetLastError());
@@ -767,7 +767,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_countable.p, (const uint32_t *)ctx->d_weights.p,
-                               ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->d_hist.p);
+                               ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->cur->d_hist.p);
         };
         if (ctx->weighted) { if (lds) go(k_hist<true, true>); else go(k_hist<true, false>); }
         else { if (lds) go(k_hist<false, true>); else go(k_hist<false, false>); }

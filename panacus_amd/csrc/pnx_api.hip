@@ -56,8 +56,13 @@ void prof_end(pnx_ctx *ctx) {
     (void)hipEventRecord(ctx->prof.pending.back().b, ctx->stream);
 }
 
-int prof_resolve(pnx_ctx *ctx) {
+int prof_resolve(pnx_ctx *ctx, bool wait) {
+    std::vector<Profile::Pending> keep;
     for (auto &pd : ctx->prof.pending) {
+        if (!wait && hipEventQuery(pd.b) != hipSuccess) {
+            keep.push_back(pd);
+            continue;
+        }
         float ms = 0.f;
         if (hipEventSynchronize(pd.b) == hipSuccess && hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
             ctx->prof.ms[pd.slot] += ms;
@@ -66,12 +71,16 @@ int prof_resolve(pnx_ctx *ctx) {
         ctx->prof.pool.push_back(pd.a);
         ctx->prof.pool.push_back(pd.b);
     }
-    ctx->prof.pending.clear();
+    ctx->prof.pending.swap(keep);
     return PNX_OK;
 }
 
 static void invalidate_results(pnx_ctx *ctx) {
-    ctx->hist_pending = false;
+    if (ctx->tk_count) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->tk) t.in_flight = false;
+    ctx->tk_count = 0;
+    ctx->tk_oldest = ctx->tk_next;
+    ctx->last_done = nullptr;
     ctx->hist_valid = false;
     ctx->M_valid = false;
     ctx->growth_pending = false;
@@ -85,28 +94,74 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->last_general_paths = 0;
 }
 
-// run passes until one verifies (no tile-monotonicity violation, no unserved general path)
-static int settle_hist(pnx_ctx *ctx) {
-    if (!ctx->hist_pending) return PNX_OK;
+static int stage_results(pnx_ctx *ctx, Ticket *t) {
+    const size_t nh = (size_t)ctx->n_groups + 1;
+    if (t->h_cap < nh) {
+        if (t->h_hist) (void)hipHostFree(t->h_hist);
+        t->h_hist = nullptr;
+        PNX_HIP(ctx, hipHostMalloc((void **)&t->h_hist, nh * sizeof(uint64_t), hipHostMallocDefault));
+        t->h_cap = nh;
+    }
+    if (!t->h_flags) PNX_HIP(ctx, hipHostMalloc((void **)&t->h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!t->done) PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+    PNX_HIP(ctx, hipMemcpyAsync(t->h_hist, t->d_hist.p, nh * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(t->h_flags, t->d_flags.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipEventRecord(t->done, ctx->stream));
+    return PNX_OK;
+}
+
+// enqueue one pass into the next free ticket
+static int enqueue_pass(pnx_ctx *ctx) {
+    if (ctx->tk_count >= 2) return ctx->fail(PNX_EINVAL, "two coverage passes are already in flight; fetch one first");
+    Ticket *t = &ctx->tk[ctx->tk_next];
+    ctx->cur = t;
+    int rc = launch_cover_pass(ctx);
+    if (rc) return rc;
+    if ((rc = stage_results(ctx, t))) return rc;
+    t->in_flight = true;
+    ctx->tk_next ^= 1;
+    ctx->tk_count += 1;
+    return PNX_OK;
+}
+
+// wait for the oldest pass and verify it (no tile-monotonicity violation, no unserved general
+// path); a failed pass is re-run with the paths it flagged sent down the scatter route
+static int settle_oldest(pnx_ctx *ctx) {
+    if (ctx->tk_count == 0) return PNX_OK;
+    Ticket *t = &ctx->tk[ctx->tk_oldest];
     for (int attempt = 0; attempt < 4; ++attempt) {
-        uint32_t flags[8];
-        PNX_HIP(ctx, hipMemcpyAsync(flags, ctx->d_flags.p, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        prof_resolve(ctx);
+        PNX_HIP(ctx, hipEventSynchronize(t->done));
+        prof_resolve(ctx, false);
         const bool used_m = ctx->want_M || ctx->last_general_paths > 0;
-        const bool bad = flags[0] != 0 || (flags[1] != 0 && !used_m);
+        const bool bad = t->h_flags[0] != 0 || (t->h_flags[1] != 0 && !used_m);
         if (!bad) {
-            ctx->last_general_paths = flags[1];
-            ctx->hist_pending = false;
+            ctx->last_general_paths = t->h_flags[1];
+            t->in_flight = false;
+            ctx->tk_oldest ^= 1;
+            ctx->tk_count -= 1;
+            ctx->last_done = t;
             ctx->hist_valid = true;
-            ctx->M_valid = ctx->want_M;
+            ctx->M_valid = ctx->want_M && ctx->tk_count == 0;
             return PNX_OK;
         }
-        ctx->last_general_paths = flags[1] + flags[0];  // > 0: next pass allocates and merges M
+        // a younger pass (if any) ran with the same stale classification; it fails and is
+        // re-run at its own settle
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->last_general_paths = t->h_flags[1] + t->h_flags[0];  // > 0: the re-run allocates and merges M
+        ctx->cur = t;
         int rc = launch_cover_pass(ctx);
         if (rc) return rc;
+        if ((rc = stage_results(ctx, t))) return rc;
     }
     return ctx->fail(PNX_EHIP, "coverage pass did not converge (internal error)");
+}
+
+static int settle_all(pnx_ctx *ctx) {
+    while (ctx->tk_count) {
+        int rc = settle_oldest(ctx);
+        if (rc) return rc;
+    }
+    return PNX_OK;
 }
 
 }  // namespace pnx
@@ -154,9 +209,15 @@ void pnx_free(pnx_ctx *ctx) {
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
                       &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_path_class, &ctx->d_grp_general, &ctx->d_flags,
-                      &ctx->d_countable, &ctx->d_hist, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
+                      &ctx->d_countable, &ctx->tk[0].d_hist, &ctx->tk[0].d_flags, &ctx->tk[1].d_hist,
+                      &ctx->tk[1].d_flags, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta})
         release(*b);
+    for (auto &t : ctx->tk) {
+        if (t.h_hist) (void)hipHostFree(t.h_hist);
+        if (t.h_flags) (void)hipHostFree(t.h_flags);
+        if (t.done) (void)hipEventDestroy(t.done);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -283,15 +344,13 @@ int pnx_hist_async(pnx_ctx *ctx) {
         ctx->index_valid = true;
     }
     ctx->hist_valid = false;
-    if ((rc = launch_cover_pass(ctx))) return rc;
-    ctx->hist_pending = true;
-    return PNX_OK;
+    return enqueue_pass(ctx);
 }
 
 int pnx_sync(pnx_ctx *ctx) {
     if (!ctx) return PNX_EINVAL;
     PNX_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = settle_hist(ctx);
+    int rc = settle_all(ctx);
     if (rc) return rc;
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     prof_resolve(ctx);
@@ -301,30 +360,34 @@ int pnx_sync(pnx_ctx *ctx) {
 
 int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
     if (!ctx) return PNX_EINVAL;
-    int rc = pnx_sync(ctx);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = settle_oldest(ctx);  // the oldest pass in flight (a younger one keeps running)
     if (rc) return rc;
-    if (!ctx->hist_valid) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
-    if (d_hist) *d_hist = (uint64_t *)ctx->d_hist.p;
-    if (d_countable) *d_countable = (uint32_t *)ctx->d_countable.p;
+    if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
+    if (d_hist) *d_hist = (uint64_t *)ctx->last_done->d_hist.p;
+    if (d_countable) *d_countable = (uint32_t *)ctx->d_countable.p;  // shared by all passes
     return PNX_OK;
 }
 
 int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
     if (!ctx) return PNX_EINVAL;
-    int rc = pnx_sync(ctx);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = settle_oldest(ctx);
     if (rc) return rc;
-    if (!ctx->hist_valid) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
-    if (hist)
-        PNX_HIP(ctx, hipMemcpyAsync(hist, ctx->d_hist.p, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (countable)
-        PNX_HIP(ctx, hipMemcpyAsync(countable, ctx->d_countable.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
+    if (hist) std::memcpy(hist, ctx->last_done->h_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t));
+    if (countable) {
+        // the coverage vector is shared by all passes: let a younger pass finish before reading it
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PNX_HIP(ctx, hipMemcpy(countable, ctx->d_countable.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     return PNX_OK;
 }
 
 int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
     int rc = pnx_hist_async(ctx);
     if (rc) return rc;
+    if ((rc = settle_all(ctx))) return rc;  // the result of THIS pass, not of an older one in flight
     return pnx_hist_fetch(ctx, countable, hist);
 }
 
@@ -351,10 +414,11 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
     }
     int rc;
     // the presence matrix must exist for the current order
+    if ((rc = settle_all(ctx))) return rc;
     if (!(ctx->hist_valid && ctx->M_valid)) {
         ctx->want_M = true;
         if ((rc = pnx_hist_async(ctx))) return rc;
-        if ((rc = settle_hist(ctx))) return rc;
+        if ((rc = settle_all(ctx))) return rc;
     }
     const size_t RG = (size_t)n_perms * G, TG = (size_t)n_thr * G;
     if ((rc = ensure(ctx, ctx->d_perms, (RG ? RG : 1) * sizeof(uint32_t)))) return rc;

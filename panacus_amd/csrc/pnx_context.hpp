@@ -31,6 +31,18 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// One enqueued coverage pass.  Two tickets exist so that pass k+1 can be enqueued before the
+// host has looked at pass k: each owns its result counters in HBM, a pinned staging copy and
+// the event that marks "results of this pass are on the host".
+struct Ticket {
+    DevBuf d_hist, d_flags;   // (G+1) u64 ; u32[8]: [0] violations, [1] #general paths in the order
+    uint64_t *h_hist = nullptr;
+    uint32_t *h_flags = nullptr;
+    size_t h_cap = 0;         // entries of h_hist
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
 struct Profile {
     bool on = false;
     double ms[PNX_K_COUNT] = {0};
@@ -75,14 +87,16 @@ struct pnx_ctx {
     pnx::DevBuf d_tile_idx;    // n_paths * (n_tiles + 1) u64
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
     pnx::DevBuf d_grp_general; // n_groups u8
-    pnx::DevBuf d_flags;       // u32[8]: [0] violations in the last cover pass, [1] #general paths
+    pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;
 
     // ---- results ----
     pnx::DevBuf d_countable;  // n_items + 1 u32
-    pnx::DevBuf d_hist;       // n_groups + 1 u64
+    pnx::Ticket tk[2];        // in-flight / finished passes (ring)
+    int tk_next = 0, tk_oldest = 0, tk_count = 0;
+    pnx::Ticket *cur = nullptr;        // the ticket the launch functions write to
+    pnx::Ticket *last_done = nullptr;  // holds the last verified histogram
     pnx::DevBuf d_M;          // n_groups * n_blocks * 64 u32 presence matrix
-    bool hist_pending = false;  // a pass is enqueued and not yet verified
     bool hist_valid = false;
     bool M_valid = false;
     bool want_M = false;
@@ -125,7 +139,7 @@ void release(DevBuf &b);
 // profiling brackets around a kernel launch on ctx->stream
 void prof_begin(pnx_ctx *ctx, int slot);
 void prof_end(pnx_ctx *ctx);
-int prof_resolve(pnx_ctx *ctx);
+int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
 // kernels_cover.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);

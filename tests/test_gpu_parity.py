@@ -407,3 +407,39 @@ def test_growth_arbitrary_quorum_table(ctx):
                 if k + 1 >= tabs[t, int(grp[k])]:
                     exp[j] += 1
         assert out[0, t].tolist() == exp.tolist(), t
+
+
+def test_two_passes_in_flight(ctx):
+    """pnx_hist_async may be called twice before the first result is fetched; results come back
+    oldest first and are identical; a third enqueue is refused; a violation found in an
+    in-flight pass is repaired for both."""
+    from panacus_amd import capi
+    n, p = 60_000, 12
+    items, pre, lens = orc.pansyn(23, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    ctx.set_order(pi, pi, p)
+    ctx.hist_async()
+    ctx.hist_async()
+    with pytest.raises(capi.PnxError):
+        ctx.hist_async()
+    _, h1 = ctx.hist_fetch()
+    cnt, h2 = ctx.hist_fetch(want_countable=True)
+    assert np.array_equal(h1, oh) and np.array_equal(h2, oh) and np.array_equal(cnt, ocov)
+    # unsorted path discovered while two passes are in flight
+    items2 = items.copy()
+    np.random.default_rng(0).shuffle(items2[pre[3]:pre[4]])
+    items2[pre[7] + 500] = items2[pre[7] + 3]
+    ocov2, oh2 = _oracle_hist(items2, pre, pi, pi, n, p)
+    ctx.set_csr(items2.astype(np.uint32), pre, n)
+    ctx.set_order(pi, pi, p)
+    ctx.hist_async()
+    ctx.hist_async()
+    _, h1 = ctx.hist_fetch()
+    cnt, h2 = ctx.hist_fetch(want_countable=True)
+    assert np.array_equal(h1, oh2) and np.array_equal(h2, oh2) and np.array_equal(cnt, ocov2)
+    # blocking call after an async one returns its own (newest) pass
+    ctx.hist_async()
+    cnt, h = ctx.hist()
+    assert np.array_equal(h, oh2) and np.array_equal(cnt, ocov2)
