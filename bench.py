@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--tile-blocks", type=int, default=1)
     ap.add_argument("--cover-variant", type=int, default=None)
     ap.add_argument("--index-coarse", type=int, default=None)
-    ap.add_argument("--index-walk", type=int, default=None)
+    ap.add_argument("--cover-waves", type=int, default=None)
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
@@ -100,10 +100,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: panacus_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # PANACUS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL all-reduce on the device
+    # counters) with a single rank, so it can be exercised on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     from panacus_amd import capi, hostlib
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
@@ -117,8 +122,8 @@ def main():
     ctx.config(capi.CFG_CACHE_INDEX, 0)
     if args.index_coarse is not None:
         ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
-    if args.index_walk is not None:
-        ctx.config(capi.CFG_INDEX_WALK, args.index_walk)
+    if args.cover_waves is not None:
+        ctx.config(capi.CFG_COVER_WAVES, args.cover_waves)
     if args.cover_variant is not None:
         ctx.config(capi.CFG_COVER_VARIANT, args.cover_variant)
     ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
@@ -134,7 +139,7 @@ def main():
 
     def settle():
         """wait for the OLDEST enqueued pass; multi-GPU: sum the per-shard counters over RCCL"""
-        if world > 1:
+        if use_dist:
             d_hist, _ = ctx.hist_device()  # counters of that pass, still in HBM
             t = hist_views.get(d_hist)
             if t is None:
@@ -163,7 +168,7 @@ def main():
         return h, growths
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
@@ -179,7 +184,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile_enable(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -259,7 +264,7 @@ def main():
             except Exception as e:  # the oracle is optional test infrastructure
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 

@@ -150,9 +150,7 @@ enum {
     PNX_CFG_INDEX_COARSE = 5,  /* every n-th tile boundary is found by a full binary search, the
                                   ones in between by interpolation inside that bracket [8];
                                   1 = plain binary search for all */
-    PNX_CFG_INDEX_WALK = 6,    /* 1 (default): the in-between boundaries of a bracket are found one
-                                  after the other, each guess starting from the previous one;
-                                  0: each is interpolated independently from the bracket ends */
+    PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the coverage kernel: 1, 2, 4 [default], 8 */
     PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain, 1 software-pipelined (two segments
                                   in flight per wave), 2 pipelined + non-temporal CSR loads */
 };

@@ -169,75 +169,6 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
     row[t] = lo;
 }
 
-// K0 pass B, walking form: one thread per (path, bracket) finds the bracket's inner boundaries
-// one after the other; each guess starts from the previous boundary plus the average segment
-// length of what is left of the bracket, so it lands within a cache line or two of the answer
-// (the interpolation from the bracket ends in k_tile_index_fine is off by several lines).
-template <bool ASC>
-__device__ static inline void walk_bracket(const uint32_t *__restrict__ items, uint64_t *__restrict__ row,
-                                           uint32_t t0, uint32_t t1, uint32_t tile_items) {
-    // positions are "number of steps before the boundary"; for a descending path they shrink
-    // with t, so walk from the t1 end upwards to keep one code path
-    uint64_t prev = ASC ? row[t0] : row[t1];
-    const uint64_t end = ASC ? row[t1] : row[t0];
-    const uint32_t inner = t1 - t0 - 1;
-    for (uint32_t k = 1; k <= inner; ++k) {
-        const uint32_t t = ASC ? t0 + k : t1 - k;
-        const uint64_t key = (uint64_t)t * tile_items;
-        uint64_t lo = prev, hi = end;
-        if (lo < hi) {
-            uint64_t pos = prev + (end - prev) / (inner - k + 2);
-            if (pos >= hi) pos = hi - 1;
-            uint64_t w = 8;
-            if (before_key<ASC>(items[pos], key)) {
-                lo = pos + 1;
-                for (;;) {
-                    const uint64_t q = lo + w - 1;
-                    if (q >= hi) break;
-                    if (before_key<ASC>(items[q], key)) { lo = q + 1; w <<= 1; } else { hi = q; break; }
-                }
-            } else {
-                hi = pos;
-                for (;;) {
-                    if (hi - lo < w) break;
-                    const uint64_t q = hi - w;
-                    if (before_key<ASC>(items[q], key)) { lo = q + 1; break; } else { hi = q; w <<= 1; }
-                }
-            }
-            lo = bsearch_before<ASC>(items, lo, hi, key);
-        }
-        row[t] = lo;
-        prev = lo;
-    }
-}
-
-__global__ void k_tile_index_walk(const uint32_t *__restrict__ items,
-                                  const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                                  uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
-                                  uint64_t *__restrict__ B, uint8_t *path_class) {
-    const uint32_t n_br = (n_tiles + coarse - 1) / coarse;
-    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_br * n_paths) return;
-    const uint32_t p = (uint32_t)(gid / n_br);
-    const uint32_t t0 = (uint32_t)(gid % n_br) * coarse;
-    const uint32_t t1 = t0 + coarse < n_tiles ? t0 + coarse : n_tiles;
-    if (t1 - t0 < 2) return;
-    const uint64_t s = path_off[p], e = path_off[p + 1];
-    uint64_t *row = B + (uint64_t)p * ((uint64_t)n_tiles + 1);
-    if (e == s) {
-        for (uint32_t t = t0 + 1; t < t1; ++t) row[t] = s;
-        return;
-    }
-    const bool asc = items[s] <= items[e - 1];
-    if (asc ? (row[t0] > row[t1]) : (row[t0] < row[t1])) {  // coarse boundaries out of order
-        path_class[p] = 1;
-        for (uint32_t t = t0 + 1; t < t1; ++t) row[t] = row[t0];
-        return;
-    }
-    if (asc) walk_bracket<true>(items, row, t0, t1, tile_items);
-    else walk_bracket<false>(items, row, t0, t1, tile_items);
-}
-
 // boundaries of a tile-monotone path are monotone; anything else goes the scatter route
 __global__ void k_tile_index_check(const uint32_t *__restrict__ items,
                                    const uint64_t *__restrict__ path_off,
@@ -270,13 +201,7 @@ int launch_tile_index(pnx_ctx *ctx) {
         hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
                            ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p);
-        if (coarse > 1 && ctx->index_walk) {
-            const uint64_t nw = (uint64_t)((ctx->n_tiles + coarse - 1) / coarse) * ctx->n_paths;
-            hipLaunchKernelGGL(k_tile_index_walk, dim3((unsigned)((nw + 63) / 64)), dim3(64), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                               ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p,
-                               (uint8_t *)ctx->d_path_class.p);
-        } else if (coarse > 1)
+        if (coarse > 1)
             hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
                                ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p,
@@ -490,8 +415,8 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
     return *reinterpret_cast<const uint4 *>(p);
 }
 
-template <int NPL, int WT, bool WRITE_M, bool NT>
-__global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover_pipe(
+template <int NPL, int WT, bool WRITE_M, bool NT, int CW>
+__global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
@@ -499,11 +424,11 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover_pipe(
     uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
     constexpr int U = COVER_UNROLL;
-    __shared__ uint32_t bm_all[COVER_WAVES][WT * BLOCK_WORDS];
+    __shared__ uint32_t bm_all[CW][WT * BLOCK_WORDS];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = blockIdx.x * COVER_WAVES + wave;
+    const uint32_t tile = blockIdx.x * CW + wave;
     if (tile >= n_tiles) return;
     uint32_t *bm = bm_all[wave];
     const uint32_t tile_lo = tile * TILE;
@@ -682,10 +607,10 @@ __global__ __launch_bounds__(256) void k_hist(const uint32_t *__restrict__ count
 // ------------------------------------------------------------------------------------------
 template <int NPL, int WT>
 static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
-    const unsigned grid = (ctx->n_tiles + COVER_WAVES - 1) / COVER_WAVES;
     const uint64_t row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
-    auto args = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(COVER_WAVES * 64), 0, ctx->stream,
+    auto launch = [&](auto kern, int cw) {
+        const unsigned grid = (ctx->n_tiles + cw - 1) / cw;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_tile_idx.p,
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
@@ -696,13 +621,19 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     };
     switch (ctx->cover_variant) {
         case 1:
-            if (write_m) args(k_tile_cover_pipe<NPL, WT, true, false>); else args(k_tile_cover_pipe<NPL, WT, false, false>);
+            if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, false, COVER_WAVES>, COVER_WAVES);
+            else launch(k_tile_cover_pipe<NPL, WT, false, false, COVER_WAVES>, COVER_WAVES);
             break;
         case 2:
-            if (write_m) args(k_tile_cover_pipe<NPL, WT, true, true>); else args(k_tile_cover_pipe<NPL, WT, false, true>);
+            switch (ctx->cover_waves) {
+                case 1: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 1>, 1); else launch(k_tile_cover_pipe<NPL, WT, false, true, 1>, 1); break;
+                case 2: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 2>, 2); else launch(k_tile_cover_pipe<NPL, WT, false, true, 2>, 2); break;
+                case 8: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 8>, 8); else launch(k_tile_cover_pipe<NPL, WT, false, true, 8>, 8); break;
+                default: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4>, 4); else launch(k_tile_cover_pipe<NPL, WT, false, true, 4>, 4); break;
+            }
             break;
         default:
-            if (write_m) args(k_tile_cover<NPL, WT, true>); else args(k_tile_cover<NPL, WT, false>);
+            if (write_m) launch(k_tile_cover<NPL, WT, true>, COVER_WAVES); else launch(k_tile_cover<NPL, WT, false>, COVER_WAVES);
     }
 }
 

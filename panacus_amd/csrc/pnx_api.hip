@@ -531,6 +531,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
                 ctx->last_general_paths = keep;
             }
             return PNX_OK;
+        case PNX_CFG_COVER_WAVES:
+            if (value != 1 && value != 2 && value != 4 && value != 8) return ctx->fail(PNX_EINVAL, "cover waves must be 1, 2, 4 or 8");
+            ctx->cover_waves = (int)value;
+            return PNX_OK;
         case PNX_CFG_COVER_VARIANT:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover variant must be 0, 1 or 2");
             ctx->cover_variant = (int)value;
@@ -538,10 +542,6 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
         case PNX_CFG_INDEX_COARSE:
             if (value < 1 || value > 4096) return ctx->fail(PNX_EINVAL, "index_coarse must be in 1..4096");
             ctx->index_coarse = (uint32_t)value;
-            ctx->index_valid = false;
-            return PNX_OK;
-        case PNX_CFG_INDEX_WALK:
-            ctx->index_walk = value != 0;
             ctx->index_valid = false;
             return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:

@@ -78,8 +78,8 @@ struct pnx_ctx {
 
     // ---- tile index over the CSR (K0) ----
     uint32_t tile_blocks = 1;  // blocks per coverage tile (WT)
-    bool index_walk = true;    // K0 pass B: walk each bracket sequentially (else interpolate from its ends)
     uint32_t index_coarse = 8; // every index_coarse-th tile boundary is searched exactly (K0 pass A)
+    int cover_waves = 4;       // waves (= tiles) per workgroup of the pipelined coverage kernel
     int cover_variant = 2;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads
     uint32_t n_blocks = 0, n_tiles = 0;
     bool index_valid = false;
