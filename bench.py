@@ -44,6 +44,25 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
+def pmc_traffic_from_profiles(nodes, paths):
+    """HBM bytes per k_tile_cover launch from the committed rocprofv3 PMC summaries
+    (profiles/, separate --pmc FETCH_SIZE / WRITE_SIZE passes on this same workload).
+    gfx950 reports half of the bytes of wide streaming reads, hence 2 x FETCH_SIZE."""
+    if (nodes, paths) != (10_000_000, 256):
+        return None, None
+    vals = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(ROOT, "profiles", f"r01_hist_cfg3_pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None, None
+        for line in open(path):
+            if "k_tile_cover" in line and f",{name}," in line:
+                vals[name] = float(line.rsplit(",", 2)[1])
+    if len(vals) != 2:
+        return None, None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01_hist_cfg3_pmc_{FETCH,WRITE}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+
+
 def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_reps=40):
     """The oracle (a plain-C port of the reference's serial loops) on a bounded sample of the
     same workload, timed on this host: coverage + hist + closed-form growth, repeated until
@@ -215,6 +234,7 @@ def main():
         B = algorithmic_bytes_hist(S, P, N, P)
         achieved = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
         device_ms = (cover_ms + index_ms + hist_ms) / max(cover_n, 1)
+        traffic, traffic_src = pmc_traffic_from_profiles(N, P)
         out = {
             "metric": "histgrowth_throughput",
             "value": value,
@@ -242,7 +262,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": B,
                 "avg_launch_ms": cover_avg_ms,
                 "launches": cover_n,
