@@ -165,8 +165,11 @@ typedef struct {
     uint32_t n_groups;       /* G */
     uint32_t n_tiles;        /* item tiles of the coverage kernel */
     uint32_t tile_items;     /* items per tile */
-    uint32_t n_general_paths;/* paths that took the scatter route in the last pnx_hist */
+    uint32_t n_general_paths;/* paths that are not tile-monotone (run route + scatter route) */
     uint32_t weighted;       /* 1 if weights are resident */
+    uint32_t n_run_paths;    /* ... of which cut into per-tile runs (no atomics) */
+    uint32_t n_scatter_paths;/* ... of which left to the atomic scatter route */
+    uint64_t n_runs;         /* size of the run index */
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

@@ -38,7 +38,8 @@ class PnxError(RuntimeError):
 class PnxInfo(C.Structure):
     _fields_ = [("n_steps", C.c_uint64), ("n_items", C.c_uint32), ("n_paths", C.c_uint32),
                 ("n_ordered", C.c_uint32), ("n_groups", C.c_uint32), ("n_tiles", C.c_uint32),
-                ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32)]
+                ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32),
+                ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64)]
 
 
 _lib = None

@@ -226,7 +226,10 @@ __global__ void k_count_general(const uint8_t *__restrict__ path_class,
                                 uint8_t *grp_general, uint32_t *flags) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_ordered) return;
-    if (path_class[ord_path[k]]) {
+    const uint8_t cls = path_class[ord_path[k]];
+    if (cls == 1) atomicAdd(&flags[2], 1u);        // not classified yet: this pass cannot be valid
+    else if (cls == 2) atomicAdd(&flags[3], 1u);   // run route
+    else if (cls == 3) {                           // scatter route: K1 merges the row of M
         grp_general[ord_group[k]] = 1;
         atomicAdd(&flags[1], 1u);
     }
@@ -251,7 +254,7 @@ __global__ void k_scatter_general(const uint32_t *__restrict__ items,
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint32_t k = 0; k < n_ordered; ++k) {
         uint32_t p = ord_path[k];
-        if (!path_class[p]) continue;
+        if (path_class[p] != 3) continue;
         uint32_t *row = M + (uint64_t)ord_group[k] * row_words;
         uint64_t e = path_off[p + 1];
         for (uint64_t j = path_off[p] + tid; j < e; j += stride) {
@@ -267,13 +270,57 @@ __global__ void k_scatter_general(const uint32_t *__restrict__ items,
 constexpr int COVER_WAVES = 4;   // waves (= tiles) per workgroup
 constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane
 
+// runs of the run-route paths, sorted by (tile, group); see kernels_runs.hip
+struct RunView {
+    const uint64_t *start;
+    const uint32_t *len;
+    const uint32_t *group;
+    const uint64_t *tile_off;  // n_tiles + 1, nullptr = no run index
+};
+
+// OR the presence bits of up to four steps (positions j..j+3, valid inside [lo, hi)) into the
+// wave's LDS bitmap; a step outside the tile is reported, never mis-counted
+template <uint32_t TILE>
+__device__ static inline void fold_steps(uint32_t *bm, const uint4 &v, uint64_t j, uint64_t lo, uint64_t hi,
+                                         uint32_t tile_lo, uint32_t &viol) {
+    const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint64_t idx = j + e;
+        if (idx >= lo && idx < hi) {
+            const uint32_t n = ids[e] - tile_lo;
+            if (n < TILE)
+                atomicOr(&bm[(n & 63u) + ((n >> 11) << 6)], 1u << ((n >> 6) & 31u));
+            else
+                viol = 1;
+        }
+    }
+}
+
+// stream the runs of group g that fall into this wave's tile (called right before g is folded)
+template <uint32_t TILE>
+__device__ static inline void consume_runs(const RunView &rv, uint64_t &cursor, uint64_t cursor_end, uint32_t g,
+                                           const uint32_t *__restrict__ items, uint32_t *bm, uint32_t lane,
+                                           uint32_t tile_lo, uint32_t *flags) {
+    while (cursor < cursor_end && rv.group[cursor] == g) {
+        const uint64_t lo = rv.start[cursor], hi = lo + rv.len[cursor];
+        uint32_t viol = 0;
+        for (uint64_t base = lo & ~3ull; base < hi; base += 256) {
+            const uint64_t j = base + lane * 4u;
+            if (j < hi) fold_steps<TILE>(bm, *reinterpret_cast<const uint4 *>(items + j), j, lo, hi, tile_lo, viol);
+        }
+        if (__any(viol) && lane == 0) atomicAdd(&flags[4], 1u);  // cannot happen: runs are built per tile
+        ++cursor;
+    }
+}
+
 template <int NPL, int WT, bool WRITE_M>
 __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
     const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
-    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags) {
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
     __shared__ uint32_t bm_all[COVER_WAVES][WT * BLOCK_WORDS];
 
@@ -283,6 +330,8 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
     if (tile >= n_tiles) return;  // whole wave leaves; no workgroup barrier is ever used
     uint32_t *bm = bm_all[wave];
     const uint32_t tile_lo = tile * TILE;
+    uint64_t run_c = rv.tile_off ? rv.tile_off[tile] : 0;
+    const uint64_t run_end = rv.tile_off ? rv.tile_off[tile + 1] : 0;
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
@@ -308,6 +357,7 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
 
     // fold the LDS bitmap of the finished group into the bit-sliced counters
     auto flush = [&](uint32_t g) {
+        if (run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -421,7 +471,7 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
-    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags) {
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
     constexpr int U = COVER_UNROLL;
     __shared__ uint32_t bm_all[CW][WT * BLOCK_WORDS];
@@ -432,6 +482,8 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     if (tile >= n_tiles) return;
     uint32_t *bm = bm_all[wave];
     const uint32_t tile_lo = tile * TILE;
+    uint64_t run_c = rv.tile_off ? rv.tile_off[tile] : 0;
+    const uint64_t run_end = rv.tile_off ? rv.tile_off[tile + 1] : 0;
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
@@ -455,6 +507,7 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
 
     auto flush = [&](uint32_t g) {
+        if (run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -608,6 +661,10 @@ __global__ __launch_bounds__(256) void k_hist(const uint32_t *__restrict__ count
 template <int NPL, int WT>
 static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     const uint64_t row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
+    RunView rv{nullptr, nullptr, nullptr, nullptr};
+    if (ctx->n_runs && ctx->runs_sorted)
+        rv = RunView{(const uint64_t *)ctx->d_srun_start.p, (const uint32_t *)ctx->d_srun_len.p,
+                     (const uint32_t *)ctx->d_srun_group.p, (const uint64_t *)ctx->d_run_tile_off.p};
     auto launch = [&](auto kern, int cw) {
         const unsigned grid = (ctx->n_tiles + cw - 1) / cw;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
@@ -617,7 +674,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            use_m ? (const uint8_t *)ctx->d_grp_general.p : (const uint8_t *)nullptr,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
-                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->cur->d_flags.p);
+                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->cur->d_flags.p, rv);
     };
     switch (ctx->cover_variant) {
         case 1:
@@ -652,6 +709,7 @@ static int launch_cover_wt(pnx_ctx *ctx, bool write_m, bool use_m) {
 
 int launch_cover_pass(pnx_ctx *ctx) {
     int rc;
+    if (ctx->n_runs && !ctx->runs_sorted && (rc = sort_run_index(ctx))) return rc;
     const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
     const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
     if ((rc = ensure(ctx, ctx->cur->d_flags, 8 * sizeof(uint32_t)))) return rc;

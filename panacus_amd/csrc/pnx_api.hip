@@ -86,7 +86,15 @@ static void invalidate_results(pnx_ctx *ctx) {
     ctx->growth_pending = false;
 }
 
+static void drop_run_index(pnx_ctx *ctx) {
+    ctx->n_runs = 0;
+    ctx->n_run_paths = 0;
+    ctx->n_scatter_paths = 0;
+    ctx->runs_sorted = false;
+}
+
 static void set_geometry(pnx_ctx *ctx) {
+    drop_run_index(ctx);
     ctx->n_blocks = (uint32_t)(((uint64_t)ctx->n_items + 1 + BLOCK_ITEMS - 1) / BLOCK_ITEMS);
     ctx->n_tiles = (ctx->n_blocks + ctx->tile_blocks - 1) / ctx->tile_blocks;
     ctx->index_valid = false;
@@ -133,7 +141,11 @@ static int settle_oldest(pnx_ctx *ctx) {
         PNX_HIP(ctx, hipEventSynchronize(t->done));
         prof_resolve(ctx, false);
         const bool used_m = ctx->want_M || ctx->last_general_paths > 0;
-        const bool bad = t->h_flags[0] != 0 || (t->h_flags[1] != 0 && !used_m);
+        // [0] tile-monotonicity violations found by K1, [1] scatter-route paths in the order,
+        // [2] non-monotone paths that are not classified yet, [4] internal run-index check
+        const bool need_build = t->h_flags[0] != 0 || t->h_flags[2] != 0;
+        const bool bad = need_build || (t->h_flags[1] != 0 && !used_m);
+        if (t->h_flags[4] != 0) return ctx->fail(PNX_EHIP, "run index inconsistency (internal error)");
         if (!bad) {
             ctx->last_general_paths = t->h_flags[1];
             t->in_flight = false;
@@ -147,10 +159,16 @@ static int settle_oldest(pnx_ctx *ctx) {
         // a younger pass (if any) ran with the same stale classification; it fails and is
         // re-run at its own settle
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->last_general_paths = t->h_flags[1] + t->h_flags[0];  // > 0: the re-run allocates and merges M
+        int rc;
+        if (need_build) {
+            // cut the non-monotone paths into runs (tile route) or leave them to the scatter route
+            if ((rc = build_run_index(ctx))) return rc;
+            ctx->last_general_paths = ctx->n_scatter_paths;
+        } else {
+            ctx->last_general_paths = t->h_flags[1];  // > 0: the re-run allocates and merges M
+        }
         ctx->cur = t;
-        int rc = launch_cover_pass(ctx);
-        if (rc) return rc;
+        if ((rc = launch_cover_pass(ctx))) return rc;
         if ((rc = stage_results(ctx, t))) return rc;
     }
     return ctx->fail(PNX_EHIP, "coverage pass did not converge (internal error)");
@@ -211,7 +229,9 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_path_class, &ctx->d_grp_general, &ctx->d_flags,
                       &ctx->d_countable, &ctx->tk[0].d_hist, &ctx->tk[0].d_flags, &ctx->tk[1].d_hist,
                       &ctx->tk[1].d_flags, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
-                      &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta})
+                      &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
+                      &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
+                      &ctx->d_srun_group, &ctx->d_run_tile_off})
         release(*b);
     for (auto &t : ctx->tk) {
         if (t.h_hist) (void)hipHostFree(t.h_hist);
@@ -328,6 +348,9 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_group.p, group_id, (size_t)n_ordered * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned
     }
+    ctx->h_ord_path.assign(path_idx, path_idx + n_ordered);
+    ctx->h_ord_group.assign(group_id, group_id + n_ordered);
+    ctx->runs_sorted = false;  // run keys carry the group of the path
     ctx->n_ordered = n_ordered;
     ctx->n_groups = n_groups;
     ctx->have_order = true;
@@ -340,6 +363,7 @@ int pnx_hist_async(pnx_ctx *ctx) {
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if (!ctx->index_valid || !ctx->cache_index) {
+        drop_run_index(ctx);  // path classes are reset with the index
         if ((rc = launch_tile_index(ctx))) return rc;
         ctx->index_valid = true;
     }
@@ -510,7 +534,10 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_groups = ctx->n_groups;
     out->n_tiles = ctx->n_tiles;
     out->tile_items = ctx->tile_blocks * BLOCK_ITEMS;
-    out->n_general_paths = ctx->last_general_paths;
+    out->n_general_paths = ctx->n_run_paths + ctx->n_scatter_paths;
+    out->n_run_paths = ctx->n_run_paths;
+    out->n_scatter_paths = ctx->n_scatter_paths;
+    out->n_runs = ctx->n_runs;
     out->weighted = ctx->weighted ? 1 : 0;
     return PNX_OK;
 }

@@ -75,6 +75,7 @@ struct pnx_ctx {
     uint32_t n_ordered = 0, n_groups = 0;
     bool have_order = false;
     pnx::DevBuf d_ord_path, d_ord_group;
+    std::vector<uint32_t> h_ord_path, h_ord_group;
 
     // ---- tile index over the CSR (K0) ----
     uint32_t tile_blocks = 1;  // blocks per coverage tile (WT)
@@ -88,7 +89,15 @@ struct pnx_ctx {
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
     pnx::DevBuf d_grp_general; // n_groups u8
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
-    uint32_t last_general_paths = 0;
+    uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
+
+    // ---- run index: tile route for non-monotone paths (kernels_runs.hip) ----
+    // path_class: 0 tile-monotone (K0 index), 1 not monotone & unclassified, 2 run route, 3 scatter route
+    pnx::DevBuf d_run_start, d_run_len, d_run_tile, d_run_path;     // runs in path order
+    pnx::DevBuf d_srun_start, d_srun_len, d_srun_group, d_run_tile_off;  // sorted by (tile, group)
+    uint64_t n_runs = 0;
+    uint32_t n_run_paths = 0, n_scatter_paths = 0;
+    bool runs_sorted = false;
 
     // ---- results ----
     pnx::DevBuf d_countable;  // n_items + 1 u32
@@ -145,6 +154,9 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
+// kernels_runs.hip
+int build_run_index(pnx_ctx *ctx);
+int sort_run_index(pnx_ctx *ctx);
 // kernels_growth.hip
 int launch_growth(pnx_ctx *ctx, bool identity_perm);
 // pansyn.hip

@@ -441,3 +441,82 @@ def test_two_passes_in_flight(ctx):
     ctx.hist_async()
     cnt, h = ctx.hist()
     assert np.array_equal(h, oh2) and np.array_equal(cnt, ocov2)
+
+
+# ---------------------------------------------------------------------------------------------
+# run route: nearly monotone paths (local back-steps across tile borders) stay off the atomics
+# ---------------------------------------------------------------------------------------------
+def _jitter(items, pre, paths, rng, width=40, every=300):
+    """reverse short windows of a sorted path: ids step back locally, also across tile borders"""
+    items = items.copy()
+    for k in paths:
+        seg = items[pre[k]:pre[k + 1]]
+        for s in range(0, len(seg) - width, every):
+            seg[s:s + width] = seg[s:s + width][::-1].copy()
+    return items
+
+
+def test_run_route_near_monotone_paths(ctx):
+    from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
+    n, p = 120_000, 16
+    items, pre, lens = orc.pansyn(41, n, p)
+    rng = np.random.default_rng(9)
+    items = _jitter(items, pre, [0, 3, 4, 9, 15], rng)
+    rng.shuffle(items[pre[6]:pre[7]])  # one path with random ids: scatter route
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens)
+    pi = np.arange(p, dtype=np.uint64)
+    gi = (pi // 2).astype(np.uint64)
+    ctx.set_order(pi, gi, 8)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, gi, n, 8, lens)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    info = ctx.info()
+    assert info.n_run_paths == 5 and info.n_scatter_paths == 1 and info.n_runs > 0
+    # a different visiting order / grouping re-sorts the runs
+    order = pi[::-1].copy()
+    g2 = np.arange(p, dtype=np.uint64)
+    ctx.set_order(order, g2, p)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, order, g2, n, p, lens)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    # only some paths visited (runs of unvisited paths are ignored)
+    sub = np.array([3, 9, 1], dtype=np.uint64)
+    ctx.set_order(sub, np.arange(3, dtype=np.uint64), 3)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, sub, np.arange(3, dtype=np.uint64), n, 3, lens)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    # growth on top of the run route (presence rows come out of the same bitmaps)
+    ctx.set_order(pi, gi, 8)
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), 8) for q in (0.0, 0.5)])
+    out = ctx.ordered_growth([1, 2], qt)
+    pg = gi
+    for t, (c, q) in enumerate([(1, 0.0), (2, 0.5)]):
+        exp = _oracle_growth(items, pre, n, 8, pg, np.arange(8), c, q, lens)
+        assert out[0, t].tolist() == [int(x) for x in exp]
+
+
+@pytest.mark.parametrize("tile_blocks", [1, 2])
+def test_run_route_all_paths_and_rebuild(ctx, tile_blocks):
+    from panacus_amd import capi
+    n, p = 50_000, 9
+    items, pre, lens = orc.pansyn(43, n, p)
+    items = _jitter(items, pre, range(p), np.random.default_rng(1), width=25, every=120)
+    ctx.config(capi.CFG_TILE_BLOCKS, tile_blocks)
+    ctx.config(capi.CFG_CACHE_INDEX, 0)  # index (and run index) rebuilt in every call
+    try:
+        ctx.set_csr(items.astype(np.uint32), pre, n)
+        pi = np.arange(p, dtype=np.uint64)
+        ctx.set_order(pi, pi, p)
+        ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+        for _ in range(3):
+            cnt, h = ctx.hist()
+            assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+        assert ctx.info().n_run_paths == p and ctx.info().n_scatter_paths == 0
+        ctx.hist_async()
+        ctx.hist_async()
+        _, h1 = ctx.hist_fetch()
+        _, h2 = ctx.hist_fetch()
+        assert np.array_equal(h1, oh) and np.array_equal(h2, oh)
+    finally:
+        ctx.config(capi.CFG_TILE_BLOCKS, 1)
+        ctx.config(capi.CFG_CACHE_INDEX, 1)
