@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Cost of the three routes on the same graph: tile-monotone paths (K0 index), nearly monotone
+paths (run index, no atomics) and shuffled paths (atomic scatter).  Index cached, as in normal
+use of one graph for several hist calls."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timed(ctx, reps=5):
+    ctx.hist(want_countable=False)  # discovers / builds whatever index the paths need
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, h = ctx.hist(want_countable=False)
+    dt = (time.perf_counter() - t0) / reps
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    return dt * 1e3, {k: v[0] / reps for k, v in prof.items() if v[1]}, h
+
+
+def main():
+    from panacus_amd import capi
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+    p = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    ctx = capi.Context(0)
+    ctx.set_csr_pansyn(42, n, p)
+    order = np.arange(p, dtype=np.uint32)
+    ctx.set_order(order, order, p)
+    out = {"nodes": n, "paths": p}
+    ms, prof, h0 = timed(ctx)
+    out["monotone"] = {"ms": ms, "kernels_ms": prof}
+    items, off, _ = ctx.get_csr()
+    out["steps"] = int(len(items))
+    # nearly monotone: reverse a window of 40 steps every 300 steps in every path
+    jit = items.copy()
+    for k in range(p):
+        seg = jit[off[k]:off[k + 1]]
+        m = (len(seg) // 300) * 300
+        if m:
+            v = seg[:m].reshape(-1, 300)
+            v[:, :40] = v[:, :40][:, ::-1].copy()
+    ctx.set_csr(jit, off, n)
+    ctx.set_order(order, order, p)
+    t0 = time.perf_counter()
+    ctx.hist(want_countable=False)
+    out["run_index_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+    ms, prof, h1 = timed(ctx)
+    info = ctx.info()
+    out["near_monotone"] = {"ms": ms, "kernels_ms": prof, "run_paths": int(info.n_run_paths),
+                            "scatter_paths": int(info.n_scatter_paths), "runs": int(info.n_runs)}
+    assert np.array_equal(h0, h1)
+    sh = items.copy()
+    rng = np.random.default_rng(0)
+    for k in range(p):
+        rng.shuffle(sh[off[k]:off[k + 1]])
+    ctx.set_csr(sh, off, n)
+    ctx.set_order(order, order, p)
+    ms, prof, h2 = timed(ctx)
+    info = ctx.info()
+    out["shuffled"] = {"ms": ms, "kernels_ms": prof, "run_paths": int(info.n_run_paths),
+                       "scatter_paths": int(info.n_scatter_paths)}
+    assert np.array_equal(h0, h2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
