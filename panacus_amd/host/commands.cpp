@@ -12,6 +12,7 @@
 #include "../../include/panacus_amd.h"
 #include "gfa_graph.hpp"
 #include "growth_closed_form.hpp"
+#include "synth_gfa.hpp"
 #include "tables.hpp"
 #include "thread_pool.hpp"
 
@@ -22,6 +23,11 @@ struct Options {
     std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file;
     bool add_hist = false, by_sample = false, by_haplotype = false;
     int threads = 0, device = 0;
+    // synth
+    uint64_t seed = 42;
+    uint32_t nodes = 0, paths = 0;
+    std::string out_file;
+    bool links = false, sequences = false;
 };
 
 const char *USAGE =
@@ -36,7 +42,9 @@ const char *USAGE =
     "  -S, --groupby-sample             merge paths of the same sample\n"
     "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
-    "      --device <N>                 GPU ordinal [0]\n";
+    "      --device <N>                 GPU ordinal [0]\n"
+    "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
+    "                                        write a pansyn-v1 synthetic pangenome as GFA\n";
 
 struct Device {  // RAII over pnx_ctx
     pnx_ctx *ctx = nullptr;
@@ -228,6 +236,12 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "-O" || a == "--order") o.order_file = value("--order");
             else if (a == "-t" || a == "--threads") o.threads = std::atoi(value("--threads").c_str());
             else if (a == "--device") o.device = std::atoi(value("--device").c_str());
+            else if (a == "--nodes") o.nodes = (uint32_t)std::strtoul(value("--nodes").c_str(), nullptr, 10);
+            else if (a == "--paths") o.paths = (uint32_t)std::strtoul(value("--paths").c_str(), nullptr, 10);
+            else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
+            else if (a == "-o" || a == "--output") o.out_file = value("--output");
+            else if (a == "--links") o.links = true;
+            else if (a == "--sequences") o.sequences = true;
             else if (a == "-a" || a == "--hist") o.add_hist = true;
             else if (a == "-S" || a == "--groupby-sample") o.by_sample = true;
             else if (a == "-H" || a == "--groupby-haplotype") o.by_haplotype = true;
@@ -236,6 +250,14 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (!a.empty() && a[0] == '-' && a.size() > 1) throw std::runtime_error("unknown option " + a);
             else if (o.file.empty()) o.file = a;
             else throw std::runtime_error("unexpected argument " + a);
+        }
+        if (o.cmd == "synth") {
+            if (!o.nodes || !o.paths || o.out_file.empty()) throw std::runtime_error("synth needs --nodes, --paths and -o");
+            if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
+            uint64_t steps = write_pansyn_gfa(o.out_file, o.seed, o.nodes, o.paths, o.links, o.sequences);
+            out = "wrote " + o.out_file + ": " + std::to_string(o.nodes) + " nodes, " + std::to_string(o.paths) +
+                  " paths, " + std::to_string(steps) + " steps\n";
+            return 0;
         }
         if (o.file.empty()) throw std::runtime_error("missing input file");
         if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);

@@ -137,3 +137,29 @@ def test_cli_ordered_histgrowth_chrM(golden_dir, tmp_path):
     for k, (cv, q) in enumerate(((1, 0.0), (2, 0.5))):
         exp = orc.ordered_growth(r, c, 4, (orc.ABSOLUTE, cv), (orc.RELATIVE, q), g.node_lens)
         assert [x[1 + k] for x in rows] == [str(int(v)) for v in exp]
+
+
+@pytest.mark.gpu
+def test_cli_cfg2_shape_hist_bp_on_synthetic_gfa(tmp_path):
+    """BASELINE configs[1] at test size: `hist -c bp` on a synthetic GFA file, bit-exact vs the
+    oracle run on the same file; plus node/edge/all and -S grouping."""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "30000", "--paths", "12", "--links", "-o", path])
+    assert rc == 0, err
+    g = orc.Graph(path, index_edges=True)
+    for grp_flag, gm in ((None, orc.GROUP_PATHID), ("-S", orc.GROUP_SAMPLE)):
+        pi, gi, names = g.path_order(gm)
+        exp = {}
+        for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+            items, pre = g.item_table(ct)
+            cov = orc.coverage(items, pre, pi, gi, g.n_items(ct))
+            exp[cname] = orc.hist(cov, len(names), g.node_lens if ct == orc.BP else None)
+        args = ["hist", "-c", "all"] + ([grp_flag] if grp_flag else []) + [path]
+        rc, out, err = hl.run_cli(args)
+        assert rc == 0, err
+        rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+        assert [int(r[1]) for r in rows] == exp["node"].tolist()
+        assert [int(r[2]) for r in rows] == exp["bp"].tolist()
+        assert [int(r[3]) for r in rows] == exp["edge"].tolist()
+    rc, out, err = hl.run_cli(["hist", "-c", "bp", path])
+    assert rc == 0 and _body(out).split("\n")[1] == "count\tbp"

@@ -138,3 +138,21 @@ def test_errors(tmp_path):
         g.item_table(hl.NODE)
     with pytest.raises(ValueError):
         hl.GfaGraph(str(tmp_path / "missing.gfa"))
+
+
+def test_synth_subcommand_roundtrip(tmp_path):
+    """`panacus-amd synth` writes pansyn-v1 as GFA; parsing it gives back the generator's CSR"""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "2500", "--paths", "10", "--seed", "7", "--links", "-o", path])
+    assert rc == 0, err
+    items, pre, lens = orc.pansyn(7, 2500, 10)
+    g = hl.GfaGraph(path, index_edges=True)
+    ia, pa = g.item_table(hl.NODE)
+    assert np.array_equal(ia.astype(np.uint64), items) and np.array_equal(pa, pre)
+    assert np.array_equal(g.node_lens, lens)
+    pi, gi, names = g.path_order(hl.GROUP_SAMPLE)
+    assert names == [f"s{k}" for k in range(5)]
+    b = orc.Graph(path, index_edges=True)
+    ea, _ = g.item_table(hl.EDGE)
+    eb, _ = b.item_table(orc.EDGE)
+    assert np.array_equal(ea.astype(np.uint64), eb)
