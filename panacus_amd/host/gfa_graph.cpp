@@ -1,6 +1,10 @@
 // gfa_graph.cpp -- see gfa_graph.hpp.
 #include "gfa_graph.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -244,38 +248,71 @@ inline void canonical(uint32_t u, uint8_t o1, uint32_t v, uint8_t o2, uint64_t &
     }
 }
 
-std::string slurp(const std::string &path) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
-    unsigned char magic[2] = {0, 0};
-    size_t got = std::fread(magic, 1, 2, f);
-    std::fclose(f);
-    std::string buf;
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // bufreader_from_compressed_gfa, io.rs:23-33
-        gzFile g = gzopen(path.c_str(), "rb");
-        if (!g) throw std::runtime_error("cannot open " + path);
-        gzbuffer(g, 1 << 20);
-        std::vector<char> chunk(1 << 22);
-        int r;
-        while ((r = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) buf.append(chunk.data(), (size_t)r);
-        gzclose(g);
-        if (r < 0) throw std::runtime_error("error while decompressing " + path);
-    } else {
-        std::ifstream in(path, std::ios::binary | std::ios::ate);
-        if (!in) throw std::runtime_error("cannot open " + path);
-        std::streamsize sz = in.tellg();
-        in.seekg(0);
-        buf.resize((size_t)sz);
-        if (sz > 0 && !in.read(&buf[0], sz)) throw std::runtime_error("cannot read " + path);
+// The GFA as one contiguous read-only byte range: plain files are mmap'ed (no copy), gzip
+// files are inflated into an owned buffer (bufreader_from_compressed_gfa, io.rs:23-33).
+struct Image {
+    const char *p = nullptr;
+    size_t n = 0;
+    std::string owned;
+    void *map = nullptr;
+    size_t map_len = 0;
+
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    char operator[](size_t i) const { return p[i]; }
+    std::string substr(size_t a, size_t len) const { return std::string(p + a, std::min(len, n - a)); }
+    std::string_view view(size_t a, size_t len) const { return std::string_view(p + a, len); }
+
+    void open(const std::string &path) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        unsigned char magic[2] = {0, 0};
+        ssize_t got = ::pread(fd, magic, 2, 0);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            ::close(fd);
+            gzFile g = gzopen(path.c_str(), "rb");
+            if (!g) throw std::runtime_error("cannot open " + path);
+            gzbuffer(g, 1 << 20);
+            std::vector<char> chunk(1 << 22);
+            int r;
+            while ((r = gzread(g, chunk.data(), (unsigned)chunk.size())) > 0) owned.append(chunk.data(), (size_t)r);
+            gzclose(g);
+            if (r < 0) throw std::runtime_error("error while decompressing " + path);
+            p = owned.data();
+            n = owned.size();
+            return;
+        }
+        struct stat st;
+        if (fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw std::runtime_error("cannot stat " + path);
+        }
+        n = (size_t)st.st_size;
+        if (n) {
+            map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (map == MAP_FAILED) {
+                map = nullptr;
+                ::close(fd);
+                throw std::runtime_error("cannot map " + path);
+            }
+            map_len = n;
+            p = static_cast<const char *>(map);
+        }
+        ::close(fd);
     }
-    return buf;
-}
+    ~Image() {
+        if (map) munmap(map, map_len);
+    }
+    Image() = default;
+    Image(const Image &) = delete;
+    Image &operator=(const Image &) = delete;
+};
 
 struct Span {
     size_t b, e;  // [b, e) in the file image
 };
 
-inline size_t field_end(const std::string &s, size_t from, size_t line_end) {
+inline size_t field_end(const Image &s, size_t from, size_t line_end) {
     const void *p = std::memchr(s.data() + from, '\t', line_end - from);
     return p ? (size_t)((const char *)p - s.data()) : line_end;
 }
@@ -283,7 +320,7 @@ inline size_t field_end(const std::string &s, size_t from, size_t line_end) {
 }  // namespace
 
 struct GraphStorage::Impl {
-    std::string image;                // the whole GFA
+    Image image;                      // the whole GFA
     std::vector<Span> p_lines;        // P and W lines in file order
     std::vector<Span> step_fields;    // per path: the step / walk column
     std::vector<uint8_t> is_walk;     // per path
@@ -313,48 +350,99 @@ GraphStorage::~GraphStorage() = default;
 std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file, bool index_edges, bool /*nice*/) {
     std::unique_ptr<GraphStorage> g(new GraphStorage());
     Impl &im = *g->impl_;
-    im.image = slurp(gfa_file);
-    const std::string &s = im.image;
+    im.image.open(gfa_file);
+    const Image &s = im.image;
     const size_t N = s.size();
 
+    // line scan in parallel: every worker takes a byte range and starts at the first line that
+    // begins inside it
     std::vector<Span> s_lines, l_lines;
-    for (size_t b = 0; b < N;) {
-        const void *nl = std::memchr(s.data() + b, '\n', N - b);
-        size_t e = nl ? (size_t)((const char *)nl - s.data()) : N;
-        if (e > b) {
-            switch (s[b]) {
-                case 'S': s_lines.push_back({b, e}); break;
-                case 'L': if (index_edges) l_lines.push_back({b, e}); break;
-                case 'P': case 'W': im.p_lines.push_back({b, e}); break;
-                default: break;
+    {
+        const size_t PIECE = 8u << 20;
+        const size_t n_pieces = (N + PIECE - 1) / PIECE;
+        struct Found {
+            std::vector<Span> s, l, p;
+        };
+        std::vector<Found> found(n_pieces);
+        ThreadPool::instance().parallel_for(n_pieces, [&](size_t k) {
+            size_t b = k * PIECE;
+            const size_t stop = std::min(N, b + PIECE);
+            if (b > 0) {  // skip the tail of a line that started in the previous piece
+                if (s[b - 1] != '\n') {
+                    const void *nl = std::memchr(s.data() + b, '\n', N - b);
+                    b = nl ? (size_t)((const char *)nl - s.data()) + 1 : N;
+                }
             }
+            Found &f = found[k];
+            while (b < stop) {
+                const void *nl = std::memchr(s.data() + b, '\n', N - b);
+                const size_t e = nl ? (size_t)((const char *)nl - s.data()) : N;
+                if (e > b) {
+                    switch (s[b]) {
+                        case 'S': f.s.push_back({b, e}); break;
+                        case 'L': if (index_edges) f.l.push_back({b, e}); break;
+                        case 'P': case 'W': f.p.push_back({b, e}); break;
+                        default: break;
+                    }
+                }
+                b = e + 1;
+            }
+        });
+        size_t ns = 0, nl = 0, np = 0;
+        for (auto &f : found) {
+            ns += f.s.size();
+            nl += f.l.size();
+            np += f.p.size();
         }
-        b = e + 1;
+        s_lines.reserve(ns);
+        l_lines.reserve(nl);
+        im.p_lines.reserve(np);
+        for (auto &f : found) {
+            s_lines.insert(s_lines.end(), f.s.begin(), f.s.end());
+            l_lines.insert(l_lines.end(), f.l.begin(), f.l.end());
+            im.p_lines.insert(im.p_lines.end(), f.p.begin(), f.p.end());
+        }
     }
     if (s_lines.size() >= 0xFFFFFFFEull) throw std::runtime_error("more than 2^32-2 segments are not supported");
 
     // --- S lines: ids are 1-based ranks, node_lens[id] = length of the sequence column ---
     g->node_lens_.assign(s_lines.size() + 1, 0);
     std::vector<Span> name_of(s_lines.size());
-    bool nice = true;
-    for (size_t k = 0; k < s_lines.size(); ++k) {
-        const Span ln = s_lines[k];
-        if (ln.e < ln.b + 3) throw std::runtime_error("malformed S line");
-        size_t ne = field_end(s, ln.b + 2, ln.e);
-        name_of[k] = {ln.b + 2, ne};
-        size_t q0 = ne < ln.e ? ne + 1 : ln.e, q1 = q0;
-        while (q1 < ln.e && s[q1] != '\t' && s[q1] != '\r') ++q1;
-        g->node_lens_[k + 1] = (uint32_t)(q1 - q0);
-        if (nice) {  // is the name exactly the decimal k+1 ?
-            uint64_t v = 0;
-            bool ok = ne > ln.b + 2 && s[ln.b + 2] != '0';
-            for (size_t i = ln.b + 2; ok && i < ne; ++i) {
-                ok = s[i] >= '0' && s[i] <= '9' && v < 0xFFFFFFFFull;
-                v = v * 10 + (uint64_t)(s[i] - '0');
+    std::atomic<bool> nice_all{true}, malformed{false};
+    {
+        const size_t BL = 1u << 16;
+        const size_t nb = (s_lines.size() + BL - 1) / BL;
+        ThreadPool::instance().parallel_for(nb, [&](size_t blk) {
+            bool nice = true;
+            const size_t k1 = std::min(s_lines.size(), (blk + 1) * BL);
+            for (size_t k = blk * BL; k < k1; ++k) {
+                const Span ln = s_lines[k];
+                if (ln.e < ln.b + 3) {
+                    malformed.store(true);
+                    return;
+                }
+                size_t ne = field_end(s, ln.b + 2, ln.e);
+                name_of[k] = {ln.b + 2, ne};
+                size_t q0 = ne < ln.e ? ne + 1 : ln.e, q1 = q0;
+                const void *tb = q0 < ln.e ? std::memchr(s.data() + q0, '\t', ln.e - q0) : nullptr;
+                q1 = tb ? (size_t)((const char *)tb - s.data()) : ln.e;
+                if (q1 > q0 && s[q1 - 1] == '\r' && q1 == ln.e) --q1;
+                g->node_lens_[k + 1] = (uint32_t)(q1 - q0);
+                if (nice) {  // is the name exactly the decimal k+1 ?
+                    uint64_t v = 0;
+                    bool ok = ne > ln.b + 2 && s[ln.b + 2] != '0';
+                    for (size_t i = ln.b + 2; ok && i < ne; ++i) {
+                        ok = s[i] >= '0' && s[i] <= '9' && v < 0xFFFFFFFFull;
+                        v = v * 10 + (uint64_t)(s[i] - '0');
+                    }
+                    nice = ok && v == k + 1;
+                }
             }
-            nice = ok && v == k + 1;
-        }
+            if (!nice) nice_all.store(false);
+        });
     }
+    if (malformed.load()) throw std::runtime_error("malformed S line");
+    const bool nice = nice_all.load();
     im.nice = nice && !s_lines.empty();
     if (!im.nice) {
         im.names.init(s_lines.size());
@@ -378,7 +466,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             size_t n0 = field_end(s, ln.b, le) + 1;
             if (n0 > le) throw std::runtime_error("malformed P line");
             size_t n1 = field_end(s, n0, le);
-            g->paths_[k] = PathSegment::from_str(std::string_view(s).substr(n0, n1 - n0));
+            g->paths_[k] = PathSegment::from_str(s.view(n0, n1 - n0));
             size_t f0 = n1 < le ? n1 + 1 : le;
             im.step_fields[k] = {f0, field_end(s, f0, le)};
             im.is_walk[k] = 0;
@@ -398,8 +486,8 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             ps.haplotype = s.substr(col[2], col[3] - col[2] - 1);
             ps.has_seqid = true;
             ps.seqid = s.substr(col[3], col[4] - col[3] - 1);
-            std::string_view a = std::string_view(s).substr(col[4], col[5] - col[4] - 1);
-            std::string_view b = std::string_view(s).substr(col[5], col[6] - col[5] - 1);
+            std::string_view a = s.view(col[4], col[5] - col[4] - 1);
+            std::string_view b = s.view(col[5], col[6] - col[5] - 1);
             if (a != "*") {
                 if (!parse_u64(a, ps.start)) throw std::runtime_error("malformed W line (start)");
                 ps.has_start = true;
@@ -456,7 +544,7 @@ struct Chunk {
 
 ItemTable GraphStorage::item_table(CountType count) const {
     const Impl &im = *impl_;
-    const std::string &s = im.image;
+    const Image &s = im.image;
     const size_t P = paths_.size();
     if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
     constexpr size_t CHUNK = 64 * 1024;
