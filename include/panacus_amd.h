@@ -150,6 +150,8 @@ enum {
     PNX_CFG_INDEX_COARSE = 5,  /* every n-th tile boundary is found by a full binary search, the
                                   ones in between by interpolation inside that bracket [8];
                                   1 = plain binary search for all */
+    PNX_CFG_USE_WEIGHTS = 7,   /* weights were uploaded: 1 = count them (bp), 0 = count items (node) on the
+                                  same resident CSR -- `hist -c all` uploads the graph once */
     PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the coverage kernel: 1, 2, 4 [default], 8 */
     PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain, 1 software-pipelined (two segments
                                   in flight per wave), 2 pipelined + non-temporal CSR loads */

@@ -212,7 +212,7 @@ int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32
     ctx->n_items = n_nodes;
     ctx->n_paths = n_paths;
     ctx->n_steps = S;
-    ctx->weighted = with_weights != 0;
+    ctx->weighted = ctx->have_weights = with_weights != 0;
     return PNX_OK;
 }
 

@@ -264,7 +264,7 @@ int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, u
     PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, path_off, ((size_t)n_paths + 1) * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, ctx->stream));
     ctx->h_path_off.assign(path_off, path_off + n_paths + 1);
-    ctx->weighted = weights != nullptr;
+    ctx->weighted = ctx->have_weights = weights != nullptr;
     if (weights) {
         if ((rc = ensure(ctx, ctx->d_weights, ((size_t)n_items + 1) * sizeof(uint32_t)))) return rc;
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_weights.p, weights, ((size_t)n_items + 1) * sizeof(uint32_t),
@@ -557,6 +557,17 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
                 set_geometry(ctx);
                 ctx->last_general_paths = keep;
             }
+            return PNX_OK;
+        case PNX_CFG_USE_WEIGHTS:
+            if (value && !ctx->have_weights) return ctx->fail(PNX_EINVAL, "no weights are resident");
+            if (ctx->weighted != (value != 0)) {
+                if (ctx->tk_count) (void)hipStreamSynchronize(ctx->stream);
+                for (auto &t : ctx->tk) t.in_flight = false;
+                ctx->tk_count = 0;
+                ctx->tk_oldest = ctx->tk_next;
+                ctx->hist_valid = false;  // the histogram changes meaning; coverage and M do not
+            }
+            ctx->weighted = value != 0;
             return PNX_OK;
         case PNX_CFG_COVER_WAVES:
             if (value != 1 && value != 2 && value != 4 && value != 8) return ctx->fail(PNX_EINVAL, "cover waves must be 1, 2, 4 or 8");

@@ -68,6 +68,7 @@ struct pnx_ctx {
     uint32_t n_items = 0, n_paths = 0;
     uint64_t n_steps = 0;
     bool have_csr = false, weighted = false, have_exclude = false;
+    bool have_weights = false;  // weights are resident (weighted = resident AND enabled)
     pnx::DevBuf d_items, d_path_off, d_weights, d_exclude;
     std::vector<uint64_t> h_path_off;
 

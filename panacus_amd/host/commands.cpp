@@ -87,6 +87,30 @@ std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, Coun
     return hist;
 }
 
+// histograms for several count types; node and bp share one resident CSR (the reference clones
+// the item table for them too, util.rs:201-204)
+std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphStorage &g, const std::vector<CountType> &cts,
+                                                const PathOrder &order) {
+    std::vector<std::vector<uint64_t>> out(cts.size());
+    bool have_node = false, have_bp = false;
+    for (CountType c : cts) {
+        have_node = have_node || c == COUNT_NODE;
+        have_bp = have_bp || c == COUNT_BP;
+    }
+    if (have_node && have_bp) {
+        upload(dev, g, COUNT_BP, order);
+        for (size_t k = 0; k < cts.size(); ++k) {
+            if (cts[k] == COUNT_EDGE) continue;
+            dev.check(pnx_config(dev.ctx, PNX_CFG_USE_WEIGHTS, cts[k] == COUNT_BP ? 1 : 0));
+            out[k].assign(order.groups.size() + 1, 0);
+            dev.check(pnx_hist(dev.ctx, nullptr, out[k].data()));
+        }
+    }
+    for (size_t k = 0; k < cts.size(); ++k)
+        if (out[k].empty()) out[k] = device_hist(dev, g, cts[k], order);
+    return out;
+}
+
 std::vector<double> to_f64(const std::vector<uint64_t> &v) {
     std::vector<double> o(v.size());
     for (size_t i = 0; i < v.size(); ++i) o[i] = (double)v[i];
@@ -121,9 +145,10 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     Device dev(o.device);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
-    for (CountType c : cts) {
-        cols.push_back(to_f64(device_hist(dev, *g, c, order)));
-        headers.push_back({"hist", count_name(c), "", ""});
+    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order);
+    for (size_t k = 0; k < cts.size(); ++k) {
+        cols.push_back(to_f64(hists[k]));
+        headers.push_back({"hist", count_name(cts[k]), "", ""});
     }
     return metadata_comments(cmdline) + write_table(headers, cols);
 }
@@ -137,8 +162,7 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     auto g = GraphStorage::from_gfa(o.file, edges);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "");
     Device dev(o.device);
-    std::vector<std::vector<uint64_t>> hists;
-    for (CountType c : cts) hists.push_back(device_hist(dev, *g, c, order));
+    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
     if (o.add_hist)

@@ -520,3 +520,44 @@ def test_run_route_all_paths_and_rebuild(ctx, tile_blocks):
     finally:
         ctx.config(capi.CFG_TILE_BLOCKS, 1)
         ctx.config(capi.CFG_CACHE_INDEX, 1)
+
+
+def test_many_groups_wide_paths(ctx):
+    """G = 5000 groups: 16-plane coverage counters, histogram bins beyond the LDS limit (global
+    atomics), growth refuses politely when its LDS accumulators cannot hold G."""
+    from panacus_amd import capi
+    n, p = 1500, 5000
+    items, pre, lens = orc.pansyn(77, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens)
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p, lens)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    assert cnt[1:].max() > 4096
+    qt = np.zeros((3, p), dtype=np.uint32)
+    with pytest.raises(capi.PnxError):
+        ctx.ordered_growth([1, 1, 1], qt)  # 3 x 5000 x 8 B > 64 KiB of LDS accumulators
+    out = ctx.ordered_growth([1], qt[:1])  # one pair fits
+    r, c = orc.by_group(items, pre, pi, pi, n)
+    exp = orc.ordered_growth(r, c, p, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.0), lens)
+    assert out[0, 0].tolist() == [int(x) for x in exp]
+
+
+def test_edge_paths_of_sorted_links_take_the_tile_route(ctx, tmp_path):
+    """edge ids follow the L-line order; when links are listed by source node (the usual case)
+    the edge ids along a sorted path are sorted too, so edge counting stays off the atomics"""
+    from panacus_amd import hostlib as hl
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "40000", "--paths", "10", "--links", "-o", path])
+    assert rc == 0, err
+    g = hl.GfaGraph(path, index_edges=True)
+    items, pre = g.item_table(hl.EDGE)
+    pi, gi, names = g.path_order()
+    ctx.set_csr(items, pre, g.n_edges)
+    ctx.set_order(pi, gi, len(names))
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items.astype(np.uint64), pre, pi.astype(np.uint64), gi.astype(np.uint64), g.n_edges, len(names))
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    info = ctx.info()
+    assert info.n_scatter_paths == 0
