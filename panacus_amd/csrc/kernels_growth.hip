@@ -524,10 +524,12 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
             const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wp_bytes;
-            if (shmem > 64 * 1024)
+            if (shmem > 150 * 1024)
                 return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %d threshold pairs exceed the LDS accumulators",
                                  G, n0 + nq);
             auto go = [&](auto kern) {
+                if (shmem > 64 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
                 hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
                                    (const uint32_t *)ctx->d_M.p, NB, G, d_rowoff, R, bpc, (const uint32_t *)ctx->d_cmask.p,
                                    tabs, d_dmask, T, d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);

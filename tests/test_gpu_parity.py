@@ -537,7 +537,7 @@ def test_many_groups_wide_paths(ctx):
     assert cnt[1:].max() > 4096
     qt = np.zeros((3, p), dtype=np.uint32)
     with pytest.raises(capi.PnxError):
-        ctx.ordered_growth([1, 1, 1], qt)  # 3 x 5000 x 8 B > 64 KiB of LDS accumulators
+        ctx.ordered_growth([1, 1, 1], qt)  # 3 x 5000 x 8 B + weight planes > 150 KiB of LDS
     out = ctx.ordered_growth([1], qt[:1])  # one pair fits
     r, c = orc.by_group(items, pre, pi, pi, n)
     exp = orc.ordered_growth(r, c, p, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.0), lens)
