@@ -535,9 +535,9 @@ def test_many_groups_wide_paths(ctx):
     ocov, oh = _oracle_hist(items, pre, pi, pi, n, p, lens)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     assert cnt[1:].max() > 4096
-    qt = np.zeros((3, p), dtype=np.uint32)
+    qt = np.zeros((4, p), dtype=np.uint32)
     with pytest.raises(capi.PnxError):
-        ctx.ordered_growth([1, 1, 1], qt)  # 3 x 5000 x 8 B + weight planes > 150 KiB of LDS
+        ctx.ordered_growth([1, 1, 1, 1], qt)  # 4 x 5000 x 8 B + weight planes > 150 KiB of LDS
     out = ctx.ordered_growth([1], qt[:1])  # one pair fits
     r, c = orc.by_group(items, pre, pi, pi, n)
     exp = orc.ordered_growth(r, c, p, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.0), lens)
