@@ -305,9 +305,17 @@ __device__ static inline void consume_runs(const RunView &rv, uint64_t &cursor, 
     while (cursor < cursor_end && rv.group[cursor] == g) {
         const uint64_t lo = rv.start[cursor], hi = lo + rv.len[cursor];
         uint32_t viol = 0;
-        for (uint64_t base = lo & ~3ull; base < hi; base += 256) {
-            const uint64_t j = base + lane * 4u;
-            if (j < hi) fold_steps<TILE>(bm, *reinterpret_cast<const uint4 *>(items + j), j, lo, hi, tile_lo, viol);
+        for (uint64_t base = lo & ~3ull; base < hi; base += 256ull * COVER_UNROLL) {
+            uint4 v[COVER_UNROLL];
+#pragma unroll
+            for (int u = 0; u < COVER_UNROLL; ++u) {
+                const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (j < hi) v[u] = *reinterpret_cast<const uint4 *>(items + j);
+            }
+#pragma unroll
+            for (int u = 0; u < COVER_UNROLL; ++u)
+                fold_steps<TILE>(bm, v[u], base + (uint64_t)u * 256 + lane * 4u, lo, hi, tile_lo, viol);
         }
         if (__any(viol) && lane == 0) atomicAdd(&flags[4], 1u);  // cannot happen: runs are built per tile
         ++cursor;
