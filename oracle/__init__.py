@@ -62,6 +62,11 @@ def lib() -> C.CDLL:
         L.orc_graph_last_error.restype = C.c_char_p
         L.orc_graph_path_order.restype = C.c_int64
         L.orc_graph_path_order.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, u64p, u64p, u64p]
+        L.orc_graph_path_order_masked.restype = C.c_int64
+        L.orc_graph_path_order_masked.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                                  u64p, u64p, u64p]
+        L.orc_graph_exclude_flags.restype = C.c_int
+        L.orc_graph_exclude_flags.argtypes = [C.c_void_p, C.c_int, C.c_char_p, u8p]
         L.orc_graph_group_name.restype = C.c_char_p
         L.orc_graph_group_name.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_graph_item_table.restype = C.c_int64
@@ -139,21 +144,31 @@ class Graph:
     def n_items(self, count_type: int) -> int:
         return self.n_edges if count_type == EDGE else self.n_nodes
 
-    def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None):
+    def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None, subset_file=None,
+                   exclude_file=None):
         """-> (path_idx[u64], group_id[u64], group_names)"""
         P = self.n_paths
         pi = np.zeros(max(P, 1), dtype=np.uint64)
         gi = np.zeros(max(P, 1), dtype=np.uint64)
         n_out = C.c_uint64(0)
-        ng = lib().orc_graph_path_order(
+        ng = lib().orc_graph_path_order_masked(
             self._h, group_mode,
             os.fsencode(group_file) if group_file else None,
             os.fsencode(order_file) if order_file else None,
+            os.fsencode(subset_file) if subset_file else None,
+            os.fsencode(exclude_file) if exclude_file else None,
             _p(pi, C.c_uint64), _p(gi, C.c_uint64), C.byref(n_out))
         if ng < 0:
             raise ValueError(lib().orc_graph_last_error().decode())
         names = [lib().orc_graph_group_name(self._h, g).decode() for g in range(ng)]
         return pi[: n_out.value].copy(), gi[: n_out.value].copy(), names
+
+    def exclude_flags(self, count_type: int, exclude_file: str) -> np.ndarray:
+        """ActiveTable.items of a whole-path exclude list (call path_order first)."""
+        flags = np.zeros(self.n_items(count_type) + 1, dtype=np.uint8)
+        if lib().orc_graph_exclude_flags(self._h, count_type, os.fsencode(exclude_file), _p(flags, C.c_uint8)) != 0:
+            raise ValueError(lib().orc_graph_last_error().decode())
+        return flags
 
     def item_table(self, count_type: int):
         """-> (items[u64], prefsum[u64, P+1])  (the reference's ItemTable, util.rs:81-93)"""

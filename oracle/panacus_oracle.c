@@ -596,9 +596,102 @@ void orc_graph_free(orc_graph *g) {
 /* GraphMask::load_groups (abacus.rs:242-308) + get_path_order (310-347) + group ids     */
 /* (555-559).  Subset/exclude lists are not restated (no golden outputs in the reference) */
 /* ------------------------------------------------------------------------------------ */
+/* reads a 1-column path/group list (parse_bed_to_path_segments, io.rs:35-119; coordinate
+ * columns are not restated) and marks the paths it names: complement_with_group_assignments
+ * (abacus.rs:152-206) -- a name that is a path selects that path, a name that is a group
+ * selects all paths of the group.  When `exact_coords` is set a path entry only matches a
+ * graph path whose coordinates are equal too (HashSet<&PathSegment> in abacus.rs:329-336).
+ * visit (optional) receives the entries in file order as path indices. */
+static int read_path_list(const orc_graph *g, const char *file, const smap *key2path, char **keys,
+                          int exact_coords, uint8_t *mark, uint64_t **visit, uint64_t *nvisit) {
+    FILE *f = fopen(file, "rb");
+    if (!f) {
+        set_err("cannot open list file %s", file);
+        return -1;
+    }
+    char *line = NULL;
+    size_t lcap = 0, vcap = 0;
+    ssize_t n;
+    uint64_t P = g->n_paths;
+    (void)keys;
+    while ((n = getline(&line, &lcap, f)) > 0) {
+        if (n > 0 && line[n - 1] == '\n') n--;
+        if (n > 0 && line[n - 1] == '\r') n--;
+        size_t e = field_end(line, 0, (size_t)n);
+        if ((e >= 8 && memcmp(line, "browser ", 8) == 0) || (e >= 6 && memcmp(line, "track ", 6) == 0) ||
+            (e >= 1 && line[0] == '#'))
+            continue;
+        if (e < (size_t)n) {
+            set_err("path lists with coordinate columns are not supported");
+            free(line);
+            fclose(f);
+            return -1;
+        }
+        pathseg ps = pathseg_from_str(line, e);
+        char *k = pathseg_clearkey(&ps);
+        uint64_t pi;
+        if (smap_get(key2path, k, strlen(k), &pi)) {
+            /* all graph paths sharing this clear-coords identity */
+            for (uint64_t i = 0; i < P; i++) {
+                char *ki = pathseg_clearkey(&g->paths[i]);
+                int same = strcmp(ki, k) == 0;
+                free(ki);
+                if (!same) continue;
+                if (exact_coords && (g->paths[i].has_start != ps.has_start || g->paths[i].has_end != ps.has_end ||
+                                     (ps.has_start && g->paths[i].start != ps.start) ||
+                                     (ps.has_end && g->paths[i].end != ps.end)))
+                    continue;
+                mark[i] = 1;
+            }
+            if (visit) {
+                if (*nvisit == vcap) {
+                    vcap = vcap ? vcap * 2 : 64;
+                    *visit = xrealloc(*visit, vcap * sizeof **visit);
+                }
+                (*visit)[(*nvisit)++] = pi;
+            }
+        } else {
+            char *id = pathseg_id(&ps);
+            int hit = 0;
+            for (uint64_t i = 0; i < P; i++)
+                if (g->path_group[i] && strcmp(g->path_group[i], id) == 0) {
+                    /* group members come from the keys of `groups`, i.e. WITHOUT coordinates */
+                    if (exact_coords && (g->paths[i].has_start || g->paths[i].has_end)) continue;
+                    mark[i] = 1;
+                    if (visit && !hit) {
+                        if (*nvisit == vcap) {
+                            vcap = vcap ? vcap * 2 : 64;
+                            *visit = xrealloc(*visit, vcap * sizeof **visit);
+                        }
+                        (*visit)[(*nvisit)++] = i;
+                    }
+                    hit = 1;
+                }
+            free(id);
+        }
+        free(k);
+        pathseg_free(&ps);
+    }
+    free(line);
+    fclose(f);
+    return 0;
+}
+
 int64_t orc_graph_path_order(orc_graph *g, int group_mode, const char *group_file,
                              const char *order_file, uint64_t *path_idx, uint64_t *group_id,
                              uint64_t *n_out) {
+    return orc_graph_path_order_masked(g, group_mode, group_file, order_file, NULL, NULL, path_idx, group_id, n_out);
+}
+
+/* With subset / exclude path lists (whole paths only):
+ *   order source (abacus.rs:324-337): -O list, else the subset list, else all paths that are
+ *   not in the exclude list; every entry emits the whole bucket of its group;
+ *   paths outside the subset have an EMPTY item-table entry in the reference
+ *   (util.rs:88-105: skipped during the parse) -- here they are dropped from the order, which
+ *   yields the same countables and the same groups. */
+int64_t orc_graph_path_order_masked(orc_graph *g, int group_mode, const char *group_file,
+                                    const char *order_file, const char *subset_file, const char *exclude_file,
+                                    uint64_t *path_idx, uint64_t *group_id, uint64_t *n_out) {
     graph_clear_groups(g);
     uint64_t P = g->n_paths;
     g->path_group = xcalloc(P, sizeof *g->path_group);
@@ -760,10 +853,48 @@ int64_t orc_graph_path_order(orc_graph *g, int group_mode, const char *group_fil
             }
             free(line);
             fclose(f);
+        } else if (subset_file) {
+            uint64_t *sv = NULL, nsv = 0;
+            uint8_t *tmpmark = xcalloc(P ? P : 1, 1);
+            if (read_path_list(g, subset_file, &key2path, keys, 0, tmpmark, &sv, &nsv) != 0) {
+                free(tmpmark);
+                free(sv);
+                free(bucket_of);
+                free(bucket_done);
+                free(visit);
+                smap_free(&grp2bucket);
+                goto done;
+            }
+            for (uint64_t k = 0; k < nsv; k++) PUSH_VISIT(bucket_of[sv[k]]);
+            free(tmpmark);
+            free(sv);
         } else {
-            for (uint64_t i = 0; i < P; i++) PUSH_VISIT(bucket_of[i]);
+            uint8_t *ex = xcalloc(P ? P : 1, 1);
+            if (exclude_file && read_path_list(g, exclude_file, &key2path, keys, 1, ex, NULL, NULL) != 0) {
+                free(ex);
+                free(bucket_of);
+                free(bucket_done);
+                free(visit);
+                smap_free(&grp2bucket);
+                goto done;
+            }
+            for (uint64_t i = 0; i < P; i++)
+                if (!ex[i]) PUSH_VISIT(bucket_of[i]);
+            free(ex);
         }
 #undef PUSH_VISIT
+        uint8_t *in_subset = NULL;
+        if (subset_file) {
+            in_subset = xcalloc(P ? P : 1, 1);
+            if (read_path_list(g, subset_file, &key2path, keys, 0, in_subset, NULL, NULL) != 0) {
+                free(in_subset);
+                free(bucket_of);
+                free(bucket_done);
+                free(visit);
+                smap_free(&grp2bucket);
+                goto done;
+            }
+        }
 
         uint64_t out = 0, ngroups = 0;
         size_t gcap = 0;
@@ -782,11 +913,13 @@ int64_t orc_graph_path_order(orc_graph *g, int group_mode, const char *group_fil
                     }
                     g->group_names[ngroups++] = xstrndup(gn, strlen(gn));
                 }
+                if (in_subset && !in_subset[i]) continue; /* empty item-table entry in the reference */
                 path_idx[out] = i;
                 group_id[out] = ngroups - 1;
                 out++;
             }
         }
+        free(in_subset);
         g->n_groups = ngroups;
         *n_out = out;
         ret = (int64_t)ngroups;
@@ -1174,6 +1307,44 @@ void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
             }
         }
     }
+}
+
+/* ActiveTable of an exclude list of whole paths (abacus.rs:447-458; util.rs:1171-1181,
+ * 785-787): every item on an excluded path is flagged.  Needs orc_graph_path_order* to have
+ * run (group names).  flags has n_items+1 entries. */
+int orc_graph_exclude_flags(orc_graph *g, int count_type, const char *exclude_file, uint8_t *flags) {
+    uint64_t P = g->n_paths;
+    uint64_t n_items = count_type == ORC_EDGE ? g->n_edges : g->n_nodes;
+    memset(flags, 0, n_items + 1);
+    smap key2path;
+    smap_init(&key2path, P + 1);
+    for (uint64_t i = 0; i < P; i++) {
+        char *k = pathseg_clearkey(&g->paths[i]);
+        smap_put(&key2path, k, strlen(k), i);
+        free(k);
+    }
+    uint8_t *ex = xcalloc(P ? P : 1, 1);
+    int rc = read_path_list(g, exclude_file, &key2path, NULL, 0, ex, NULL, NULL);
+    smap_free(&key2path);
+    if (rc != 0) {
+        free(ex);
+        return -1;
+    }
+    uint64_t *items = NULL;
+    uint64_t *pre = xmalloc((P + 1) * sizeof *pre);
+    int64_t n = orc_graph_item_table(g, count_type, &items, pre);
+    if (n < 0) {
+        free(ex);
+        free(pre);
+        return -1;
+    }
+    for (uint64_t p = 0; p < P; p++)
+        if (ex[p])
+            for (uint64_t j = pre[p]; j < pre[p + 1]; j++) flags[items[j]] = 1;
+    free(items);
+    free(pre);
+    free(ex);
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------ */

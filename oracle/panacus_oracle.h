@@ -59,6 +59,13 @@ int64_t orc_graph_path_order(orc_graph *g, int group_mode, const char *group_fil
                              const char *order_file, uint64_t *path_idx, uint64_t *group_id,
                              uint64_t *n_out);
 const char *orc_graph_group_name(const orc_graph *g, uint64_t gid);
+/* same with whole-path subset (-s) / exclude (-e) lists; either may be NULL.  NOTE: no golden
+ * output for -s/-e exists in the reference repository -- parity unpinned, the restatement is the
+ * definition. */
+int64_t orc_graph_path_order_masked(orc_graph *g, int group_mode, const char *group_file,
+                                    const char *order_file, const char *subset_file, const char *exclude_file,
+                                    uint64_t *path_idx, uint64_t *group_id, uint64_t *n_out);
+int orc_graph_exclude_flags(orc_graph *g, int count_type, const char *exclude_file, uint8_t *flags);
 
 /* ---- ItemTable (src/util.rs:81-93; graph_broker/util.rs:22-206, 723-795) ----
  * Returns number of items; *items is malloc'ed (caller frees with orc_free), prefsum has

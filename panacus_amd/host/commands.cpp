@@ -20,7 +20,7 @@ namespace pnh {
 namespace {
 
 struct Options {
-    std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file;
+    std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file, subset_file, exclude_file;
     bool add_hist = false, by_sample = false, by_haplotype = false;
     int threads = 0, device = 0;
     // synth
@@ -41,6 +41,8 @@ const char *USAGE =
     "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
     "  -S, --groupby-sample             merge paths of the same sample\n"
     "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
+    "  -s, --subset <FILE>              count only the listed paths/groups (1-column list)\n"
+    "  -e, --exclude <FILE>             drop the listed paths/groups and every node/edge/bp they touch\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
     "      --device <N>                 GPU ordinal [0]\n"
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
@@ -71,17 +73,26 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 }
 
 // upload graph + order for one count type
-void upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order) {
+struct Masking {  // -g/-S/-H grouping + -e list, needed to derive the ActiveTable per count type
+    GroupMode mode = GROUP_PATHID;
+    std::string group_file, exclude_file;
+};
+
+void upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk) {
     ItemTable tab = g.item_table(ct);
     const uint64_t n_items = g.number_of_items(ct);
+    std::vector<uint8_t> excl;
+    if (!mk.exclude_file.empty()) excl = g.exclude_flags(ct, tab, mk.mode, mk.group_file, mk.exclude_file);
     dev.check(pnx_set_csr(dev.ctx, tab.items.data(), tab.id_prefsum.data(), (uint32_t)g.path_segments().size(),
-                          (uint32_t)n_items, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
+                          (uint32_t)n_items, ct == COUNT_BP ? g.node_lens().data() : nullptr,
+                          excl.empty() ? nullptr : excl.data()));
     dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
                             (uint32_t)order.groups.size()));
 }
 
-std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order) {
-    upload(dev, g, ct, order);
+std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order,
+                                  const Masking &mk) {
+    upload(dev, g, ct, order, mk);
     std::vector<uint64_t> hist(order.groups.size() + 1, 0);
     dev.check(pnx_hist(dev.ctx, nullptr, hist.data()));
     return hist;
@@ -90,7 +101,7 @@ std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, Coun
 // histograms for several count types; node and bp share one resident CSR (the reference clones
 // the item table for them too, util.rs:201-204)
 std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphStorage &g, const std::vector<CountType> &cts,
-                                                const PathOrder &order) {
+                                                const PathOrder &order, const Masking &mk) {
     std::vector<std::vector<uint64_t>> out(cts.size());
     bool have_node = false, have_bp = false;
     for (CountType c : cts) {
@@ -98,7 +109,7 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
         have_bp = have_bp || c == COUNT_BP;
     }
     if (have_node && have_bp) {
-        upload(dev, g, COUNT_BP, order);
+        upload(dev, g, COUNT_BP, order, mk);
         for (size_t k = 0; k < cts.size(); ++k) {
             if (cts[k] == COUNT_EDGE) continue;
             dev.check(pnx_config(dev.ctx, PNX_CFG_USE_WEIGHTS, cts[k] == COUNT_BP ? 1 : 0));
@@ -107,7 +118,7 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
         }
     }
     for (size_t k = 0; k < cts.size(); ++k)
-        if (out[k].empty()) out[k] = device_hist(dev, g, cts[k], order);
+        if (out[k].empty()) out[k] = device_hist(dev, g, cts[k], order, mk);
     return out;
 }
 
@@ -129,6 +140,15 @@ void growth_headers(std::vector<std::vector<std::string>> &headers, const char *
         headers.push_back({what, count_name(ct), threshold_string(tc.coverage[t]), threshold_string(tc.quorum[t])});
 }
 
+GroupMode group_mode(const Options &o);
+Masking masking(const Options &o) {
+    Masking m;
+    m.mode = group_mode(o);
+    m.group_file = o.group_file;
+    m.exclude_file = o.exclude_file;
+    return m;
+}
+
 GroupMode group_mode(const Options &o) {
     if (o.by_haplotype) return GROUP_HAPLOTYPE;  // load_groups checks haplotype first (abacus.rs:248)
     if (o.by_sample) return GROUP_SAMPLE;
@@ -141,11 +161,11 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
     auto g = GraphStorage::from_gfa(o.file, edges);
-    PathOrder order = g->path_order(group_mode(o), o.group_file, "");
+    PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     Device dev(o.device);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
-    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order);
+    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     for (size_t k = 0; k < cts.size(); ++k) {
         cols.push_back(to_f64(hists[k]));
         headers.push_back({"hist", count_name(cts[k]), "", ""});
@@ -160,9 +180,9 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
     auto g = GraphStorage::from_gfa(o.file, edges);
-    PathOrder order = g->path_order(group_mode(o), o.group_file, "");
+    PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     Device dev(o.device);
-    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order);
+    std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
     if (o.add_hist)
@@ -179,7 +199,7 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
 
 // growth from a hist TSV (src/lib.rs:160-190, analyses/growth.rs:190-262): no GPU involved
 std::string cmd_growth_from_hist(const Options &o, const std::string &cmdline) {
-    if (o.by_sample || o.by_haplotype || !o.group_file.empty())
+    if (o.by_sample || o.by_haplotype || !o.group_file.empty() || !o.subset_file.empty() || !o.exclude_file.empty())
         throw std::runtime_error("subset, exclude and groupby can only be used in graph mode (with a .gfa or .gfa.gz file)");
     ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
     ParsedHists ph = parse_hists(o.file);
@@ -204,11 +224,11 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
     CountType ct = count_types(o.count, false)[0];
     auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
-    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint32_t G = (uint32_t)order.groups.size();
     const uint32_t T = (uint32_t)tc.coverage.size();
     Device dev(o.device);
-    upload(dev, *g, ct, order);
+    upload(dev, *g, ct, order, masking(o));
     // AbacusByGroup::calc_growth prologue (abacus.rs:997-998, 1009) in f64 on the host
     std::vector<uint32_t> cov(T), qtab((size_t)T * G);
     for (uint32_t t = 0; t < T; ++t) {
@@ -269,8 +289,8 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "-a" || a == "--hist") o.add_hist = true;
             else if (a == "-S" || a == "--groupby-sample") o.by_sample = true;
             else if (a == "-H" || a == "--groupby-haplotype") o.by_haplotype = true;
-            else if (a == "-s" || a == "--subset" || a == "-e" || a == "--exclude")
-                throw std::runtime_error("subset / exclude lists are not supported by panacus-amd yet");
+            else if (a == "-s" || a == "--subset") o.subset_file = value("--subset");
+            else if (a == "-e" || a == "--exclude") o.exclude_file = value("--exclude");
             else if (!a.empty() && a[0] == '-' && a.size() > 1) throw std::runtime_error("unknown option " + a);
             else if (o.file.empty()) o.file = a;
             else throw std::runtime_error("unexpected argument " + a);

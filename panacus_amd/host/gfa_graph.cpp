@@ -711,16 +711,17 @@ std::vector<std::string> read_lines(const std::string &file) {
 }
 }  // namespace
 
-PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file, const std::string &order_file) const {
-    const size_t P = paths_.size();
-    std::vector<std::string> key(P), group(P);
-    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+namespace {
 
-    // GraphMask::load_groups (abacus.rs:242-308)
+// groups of all paths: GraphMask::load_groups (abacus.rs:242-308)
+std::vector<std::string> load_groups(const std::vector<PathSegment> &paths, const std::vector<std::string> &key,
+                                     GroupMode mode, const std::string &group_file) {
+    const size_t P = paths.size();
+    std::vector<std::string> group(P);
     if (mode == GROUP_HAPLOTYPE) {
-        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].sample + "#" + (paths_[i].has_haplotype ? paths_[i].haplotype : "");
+        for (size_t i = 0; i < P; ++i) group[i] = paths[i].sample + "#" + (paths[i].has_haplotype ? paths[i].haplotype : "");
     } else if (mode == GROUP_SAMPLE) {
-        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].sample;
+        for (size_t i = 0; i < P; ++i) group[i] = paths[i].sample;
     } else if (mode == GROUP_FILE) {
         std::unordered_map<std::string, std::string> assigned;
         int lineno = 1;
@@ -740,11 +741,81 @@ PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file
         }
         for (size_t i = 0; i < P; ++i) {
             auto it = assigned.find(key[i]);
-            group[i] = it != assigned.end() ? it->second : paths_[i].id();
+            group[i] = it != assigned.end() ? it->second : paths[i].id();
         }
     } else {
-        for (size_t i = 0; i < P; ++i) group[i] = paths_[i].id();
+        for (size_t i = 0; i < P; ++i) group[i] = paths[i].id();
     }
+    return group;
+}
+
+// a 1-column list of paths / groups (parse_bed_to_path_segments, io.rs:35-119, without the
+// coordinate forms) resolved like complement_with_group_assignments (abacus.rs:152-206).
+// mark[i] = path i is named; visit = entries in file order as path indices (first path of a group).
+// exact_coords: a path entry only matches graph paths with equal coordinates, and group members
+// only match paths without coordinates (HashSet<&PathSegment> comparison, abacus.rs:329-336).
+void read_path_list(const std::string &file, const std::vector<PathSegment> &paths, const std::vector<std::string> &key,
+                    const std::vector<std::string> &group, bool exact_coords, std::vector<uint8_t> &mark,
+                    std::vector<uint32_t> *visit) {
+    const size_t P = paths.size();
+    mark.assign(P, 0);
+    std::unordered_map<std::string, std::vector<uint32_t>> by_key, by_group;
+    for (size_t i = 0; i < P; ++i) {
+        by_key[key[i]].push_back((uint32_t)i);
+        by_group[group[i]].push_back((uint32_t)i);
+    }
+    for (std::string l : read_lines(file)) {
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        if (l.rfind("browser ", 0) == 0 || l.rfind("track ", 0) == 0 || (!l.empty() && l[0] == '#')) continue;
+        if (l.find('\t') != std::string::npos)
+            throw std::runtime_error("path lists with coordinate columns (BED) are not supported yet");
+        PathSegment ps = PathSegment::from_str(l);
+        auto pk = by_key.find(ps.clear_key());
+        if (pk != by_key.end()) {
+            for (uint32_t i : pk->second) {
+                if (exact_coords && (paths[i].has_start != ps.has_start || paths[i].has_end != ps.has_end ||
+                                     (ps.has_start && paths[i].start != ps.start) || (ps.has_end && paths[i].end != ps.end)))
+                    continue;
+                mark[i] = 1;
+            }
+            if (visit) visit->push_back(pk->second.front());
+        } else {
+            auto bg = by_group.find(ps.id());
+            if (bg == by_group.end()) continue;  // unknown path/group: logged and skipped by the reference
+            bool first = true;
+            for (uint32_t i : bg->second) {
+                if (exact_coords && (paths[i].has_start || paths[i].has_end)) continue;
+                mark[i] = 1;
+                if (visit && first) visit->push_back(i);
+                first = false;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+std::vector<uint8_t> GraphStorage::exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
+                                                 const std::string &group_file, const std::string &exclude_file) const {
+    const size_t P = paths_.size();
+    std::vector<std::string> key(P);
+    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+    std::vector<std::string> group = load_groups(paths_, key, mode, group_file);
+    std::vector<uint8_t> ex;
+    read_path_list(exclude_file, paths_, key, group, false, ex, nullptr);
+    std::vector<uint8_t> flags(number_of_items(count) + 1, 0);
+    for (size_t p = 0; p < P; ++p)
+        if (ex[p])
+            for (uint64_t j = table.id_prefsum[p]; j < table.id_prefsum[p + 1]; ++j) flags[table.items[j]] = 1;
+    return flags;
+}
+
+PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file, const std::string &order_file,
+                                   const std::string &subset_file, const std::string &exclude_file) const {
+    const size_t P = paths_.size();
+    std::vector<std::string> key(P);
+    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+    std::vector<std::string> group = load_groups(paths_, key, mode, group_file);
 
     // get_path_order (abacus.rs:310-347): buckets by group, emitted whole at the first visit
     std::unordered_map<std::string, uint32_t> bucket_of_group, path_of_key;
@@ -776,9 +847,21 @@ PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file
                 // unknown path/group: logged and skipped by the reference
             }
         }
+    } else if (!subset_file.empty()) {  // the subset list is the order source (abacus.rs:326-327)
+        std::vector<uint8_t> tmp;
+        std::vector<uint32_t> entries;
+        read_path_list(subset_file, paths_, key, group, false, tmp, &entries);
+        for (uint32_t i : entries) visit.push_back(bucket[i]);
     } else {
-        for (size_t i = 0; i < P; ++i) visit.push_back(bucket[i]);
+        std::vector<uint8_t> ex(P, 0);
+        if (!exclude_file.empty()) read_path_list(exclude_file, paths_, key, group, true, ex, nullptr);
+        for (size_t i = 0; i < P; ++i)
+            if (!ex[i]) visit.push_back(bucket[i]);
     }
+    // paths outside the subset have an empty item-table entry in the reference (skipped during the
+    // parse, util.rs:88-105); dropping them from the order gives the same countables and groups
+    std::vector<uint8_t> in_subset;
+    if (!subset_file.empty()) read_path_list(subset_file, paths_, key, group, false, in_subset, nullptr);
     PathOrder out;
     std::vector<uint8_t> done(buckets.size(), 0);
     for (uint32_t b : visit) {
@@ -786,6 +869,7 @@ PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file
         done[b] = 1;
         for (uint32_t i : buckets[b]) {
             if (out.groups.empty() || out.groups.back() != group[i]) out.groups.push_back(group[i]);  // abacus.rs:555-559
+            if (!in_subset.empty() && !in_subset[i]) continue;
             out.path_idx.push_back(i);
             out.group_id.push_back((uint32_t)out.groups.size() - 1);
         }

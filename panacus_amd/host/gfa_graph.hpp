@@ -10,7 +10,8 @@
 // Design differences (not behaviour): the file is read ONCE into memory (plain or gzip) and
 // all passes run over that buffer; names are hashed as string_views into it; path steps
 // are parsed in parallel over the worker pool; ids narrow to u32 (the device ABI's width).
-// Subset / exclude coordinate lists (-s/-e) are not implemented yet.
+// Subset / exclude lists (-s/-e) are supported for whole paths / groups; BED coordinate
+// columns are rejected.
 #pragma once
 #include <cstdint>
 #include <memory>
@@ -60,8 +61,16 @@ public:
     // parse_gfa_paths_walks[_multiple] without subset/exclude
     ItemTable item_table(CountType count) const;
 
-    // GraphMask::load_groups + get_path_order (+ optional -O order file)
-    PathOrder path_order(GroupMode mode, const std::string &group_file, const std::string &order_file) const;
+    // GraphMask::load_groups + get_path_order (+ optional -O order file, -s subset list,
+    // -e exclude list; lists name whole paths or groups, coordinate columns are rejected)
+    PathOrder path_order(GroupMode mode, const std::string &group_file, const std::string &order_file,
+                         const std::string &subset_file = "", const std::string &exclude_file = "") const;
+
+    // ActiveTable.items of a whole-path exclude list for `count` (src/util.rs:118-124;
+    // graph_broker/util.rs:1171-1181, 785-787): n_items + 1 flags, every item that lies on an
+    // excluded path is set.  `order` supplies the group names (a list entry may name a group).
+    std::vector<uint8_t> exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
+                                       const std::string &group_file, const std::string &exclude_file) const;
 
     struct Impl;
 

@@ -70,13 +70,30 @@ int64_t pnh_graph_item_table(const void *g, int count_type, uint32_t *items, uin
     }
 }
 
+// ActiveTable flags (n_items + 1 bytes) of a whole-path exclude list
+int pnh_graph_exclude_flags(const void *g, int count_type, int group_mode, const char *group_file,
+                            const char *exclude_file, uint8_t *flags) {
+    try {
+        const pnh::GraphStorage *gs = static_cast<const pnh::GraphStorage *>(g);
+        pnh::ItemTable t = gs->item_table((pnh::CountType)count_type);
+        std::vector<uint8_t> f = gs->exclude_flags((pnh::CountType)count_type, t, (pnh::GroupMode)group_mode,
+                                                   group_file ? group_file : "", exclude_file);
+        std::copy(f.begin(), f.end(), flags);
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
 // visiting order; group names are returned '\n'-joined in names_buf. Returns #groups or -1.
 int64_t pnh_graph_path_order(const void *g, int group_mode, const char *group_file, const char *order_file,
-                             uint32_t *path_idx, uint32_t *group_id, uint64_t *n_out, char *names_buf,
-                             uint64_t names_cap) {
+                             const char *subset_file, const char *exclude_file, uint32_t *path_idx,
+                             uint32_t *group_id, uint64_t *n_out, char *names_buf, uint64_t names_cap) {
     try {
         pnh::PathOrder o = static_cast<const pnh::GraphStorage *>(g)->path_order(
-            (pnh::GroupMode)group_mode, group_file ? group_file : "", order_file ? order_file : "");
+            (pnh::GroupMode)group_mode, group_file ? group_file : "", order_file ? order_file : "",
+            subset_file ? subset_file : "", exclude_file ? exclude_file : "");
         std::copy(o.path_idx.begin(), o.path_idx.end(), path_idx);
         std::copy(o.group_id.begin(), o.group_id.end(), group_id);
         *n_out = o.path_idx.size();

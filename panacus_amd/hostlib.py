@@ -103,8 +103,10 @@ def _bind_graph(L):
     L.pnh_graph_item_table.restype = C.c_int64
     L.pnh_graph_item_table.argtypes = [C.c_void_p, C.c_int, u32p, u64p]
     L.pnh_graph_path_order.restype = C.c_int64
-    L.pnh_graph_path_order.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, u32p, u32p, u64p, C.c_char_p,
-                                       C.c_uint64]
+    L.pnh_graph_path_order.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, u32p, u32p,
+                                       u64p, C.c_char_p, C.c_uint64]
+    L.pnh_graph_exclude_flags.restype = C.c_int
+    L.pnh_graph_exclude_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
     L._graph_bound = True
 
 
@@ -169,7 +171,17 @@ class GfaGraph:
             raise ValueError(self._L.pnh_last_error().decode())
         return items[:n], pre
 
-    def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None):
+    def exclude_flags(self, count_type, exclude_file, group_mode=GROUP_PATHID, group_file=None):
+        flags = np.zeros(self.n_items(count_type) + 1, dtype=np.uint8)
+        rc = self._L.pnh_graph_exclude_flags(self._h, count_type, group_mode,
+                                             os.fsencode(group_file) if group_file else None,
+                                             os.fsencode(exclude_file), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        return flags
+
+    def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None, subset_file=None,
+                   exclude_file=None):
         P = max(self.n_paths, 1)
         pi = np.zeros(P, dtype=np.uint32)
         gi = np.zeros(P, dtype=np.uint32)
@@ -179,6 +191,8 @@ class GfaGraph:
             buf = C.create_string_buffer(cap)
             ng = self._L.pnh_graph_path_order(self._h, group_mode, os.fsencode(group_file) if group_file else None,
                                               os.fsencode(order_file) if order_file else None,
+                                              os.fsencode(subset_file) if subset_file else None,
+                                              os.fsencode(exclude_file) if exclude_file else None,
                                               pi.ctypes.data_as(C.POINTER(C.c_uint32)),
                                               gi.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(n_out), buf, cap)
             if ng < 0 and b"too small" in self._L.pnh_last_error():

@@ -63,7 +63,7 @@ def test_growth_from_hist_errors(tmp_path, golden_dir):
     rc, out, err = hl.run_cli(["nosuch", "x"])
     assert rc == 1 and "unknown subcommand" in err
     rc, out, err = hl.run_cli(["hist", "-s", "x", "y.gfa"])
-    assert rc == 1 and "not supported" in err
+    assert rc == 1 and "cannot open" in err
 
 
 def test_gpu_commands_fail_loudly_without_gpu(golden_dir):
@@ -163,3 +163,43 @@ def test_cli_cfg2_shape_hist_bp_on_synthetic_gfa(tmp_path):
         assert [int(r[3]) for r in rows] == exp["edge"].tolist()
     rc, out, err = hl.run_cli(["hist", "-c", "bp", path])
     assert rc == 0 and _body(out).split("\n")[1] == "count\tbp"
+
+
+@pytest.mark.gpu
+def test_cli_subset_exclude(tmp_path):
+    """`-s` / `-e` whole-path lists through the CLI vs the oracle; subset == same graph without
+    the other paths; excluded items never count."""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "20000", "--paths", "10", "--links", "-o", path])
+    assert rc == 0, err
+    g = orc.Graph(path, index_edges=True)
+    names = g.path_names()
+    sub = tmp_path / "sub.txt"
+    sub.write_text("\n".join(n.split(":")[0] for n in (names[7], names[0], names[3], names[4])) + "\n")
+    exc = tmp_path / "exc.txt"
+    exc.write_text(names[5].split(":")[0] + "\n")
+    for extra, sf, ef in ((["-s", str(sub)], str(sub), None), (["-e", str(exc)], None, str(exc)),
+                          (["-S", "-s", str(sub), "-e", str(exc)], str(sub), str(exc))):
+        gm = orc.GROUP_SAMPLE if "-S" in extra else orc.GROUP_PATHID
+        pi, gi, gnames = g.path_order(gm, None, None, sf, ef)
+        for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+            items, pre = g.item_table(ct)
+            excl = g.exclude_flags(ct, ef) if ef else None
+            cov = orc.coverage(items, pre, pi, gi, g.n_items(ct), excl)
+            h = orc.hist(cov, len(gnames), g.node_lens if ct == orc.BP else None)
+            rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5"] + extra + [path])
+            assert rc == 0, err
+            rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+            assert [int(r[1]) for r in rows] == h.tolist(), (extra, cname)
+            for k, (c, q) in enumerate(((1, 0.0), (2, 0.5))):
+                exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+                assert [r[2 + k] for r in rows[1:]] == [hl.format_f64(math.floor(x)) for x in exp]
+        # ordered growth with the same masks
+        rc, out, err = hl.run_cli(["ordered-histgrowth", "-c", "bp", "-l", "1", "-q", "0.3"] + extra + [path])
+        assert rc == 0, err
+        items, pre = g.item_table(orc.BP)
+        excl = g.exclude_flags(orc.BP, ef) if ef else None
+        r_, c_ = orc.by_group(items, pre, pi, gi, g.n_nodes, excl)
+        exp = orc.ordered_growth(r_, c_, len(gnames), (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.3), g.node_lens)
+        rows = [x.split("\t") for x in _body(out).split("\n")[4:] if x]
+        assert [x[0] for x in rows] == gnames and [x[1] for x in rows] == [str(int(v)) for v in exp]

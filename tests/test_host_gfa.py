@@ -156,3 +156,42 @@ def test_synth_subcommand_roundtrip(tmp_path):
     ea, _ = g.item_table(hl.EDGE)
     eb, _ = b.item_table(orc.EDGE)
     assert np.array_equal(ea.astype(np.uint64), eb)
+
+
+def test_subset_and_exclude_lists_match_oracle(golden_dir, tmp_path):
+    """-s / -e with whole-path (or group) lists: visiting order, groups and ActiveTable flags.
+    No golden output exists in the reference for -s/-e: the oracle restatement is the definition."""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "4000", "--paths", "12", "--links", "-o", path])
+    assert rc == 0, err
+    a, b = hl.GfaGraph(path, index_edges=True), orc.Graph(path, index_edges=True)
+    names = a.path_names()
+    sub = tmp_path / "sub.txt"
+    sub.write_text("\n".join([names[8].split(":")[0], names[1], "# c", names[4], "nosuch#0#x", names[1]]) + "\n")
+    exc = tmp_path / "exc.txt"
+    exc.write_text(names[2] + "\n" + names[9] + "\n")
+    grp_list = tmp_path / "grp.txt"
+    grp_list.write_text("s3\ns0\n")  # sample names: groups under -S
+    cases = [
+        (hl.GROUP_PATHID, None, str(sub), None), (hl.GROUP_SAMPLE, None, str(sub), None),
+        (hl.GROUP_PATHID, None, None, str(exc)), (hl.GROUP_HAPLOTYPE, None, None, str(exc)),
+        (hl.GROUP_SAMPLE, None, str(grp_list), None), (hl.GROUP_SAMPLE, None, None, str(grp_list)),
+        (hl.GROUP_SAMPLE, None, str(sub), str(exc)),
+    ]
+    for gm, of, sf, ef in cases:
+        pa, ga, na = a.path_order(gm, None, of, sf, ef)
+        pb, gb, nb = b.path_order(gm, None, of, sf, ef)
+        assert na == nb and np.array_equal(pa, pb) and np.array_equal(ga, gb), (gm, sf, ef)
+        if ef:
+            for ct in (hl.NODE, hl.EDGE):
+                fa = a.exclude_flags(ct, ef, gm)
+                fb = b.exclude_flags(ct, ef)
+                assert np.array_equal(fa, fb)
+                assert fa.sum() > 0
+    # subset by explicit paths keeps only those paths, in list order (duplicates ignored)
+    pa, ga, na = a.path_order(hl.GROUP_PATHID, None, None, str(sub), None)
+    assert pa.tolist() == [8, 1, 4]
+    with pytest.raises(ValueError):
+        bed = tmp_path / "bed.txt"
+        bed.write_text(names[0] + "\t0\t100\n")
+        a.path_order(hl.GROUP_PATHID, None, None, str(bed), None)
