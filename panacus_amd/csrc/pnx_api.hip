@@ -367,6 +367,9 @@ int pnx_hist_async(pnx_ctx *ctx) {
         if ((rc = launch_tile_index(ctx))) return rc;
         ctx->index_valid = true;
     }
+    // the presence matrix is only written when asked for (config) or when a growth call needs it
+    ctx->want_M = ctx->keep_M_user || ctx->growth_needs_M;
+    ctx->growth_needs_M = false;
     ctx->hist_valid = false;
     return enqueue_pass(ctx);
 }
@@ -440,7 +443,7 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
     // the presence matrix must exist for the current order
     if ((rc = settle_all(ctx))) return rc;
     if (!(ctx->hist_valid && ctx->M_valid)) {
-        ctx->want_M = true;
+        ctx->growth_needs_M = true;
         if ((rc = pnx_hist_async(ctx))) return rc;
         if ((rc = settle_all(ctx))) return rc;
     }
@@ -583,8 +586,7 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             ctx->index_valid = false;
             return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:
-            ctx->want_M = value != 0;
-            if (!ctx->want_M) ctx->M_valid = false;
+            ctx->keep_M_user = value != 0;
             return PNX_OK;
         default:
             return ctx->fail(PNX_EINVAL, "unknown config key %d", key);

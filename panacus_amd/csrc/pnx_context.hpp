@@ -109,7 +109,9 @@ struct pnx_ctx {
     pnx::DevBuf d_M;          // n_groups * n_blocks * 64 u32 presence matrix
     bool hist_valid = false;
     bool M_valid = false;
-    bool want_M = false;
+    bool want_M = false;        // the pass being enqueued also writes the presence matrix
+    bool keep_M_user = false;   // PNX_CFG_KEEP_PRESENCE
+    bool growth_needs_M = false;
 
     // ---- growth ----
     pnx::DevBuf d_perms, d_cov_thr, d_qtab, d_cmask, d_wplanes, d_growth_out, d_thr_meta;
