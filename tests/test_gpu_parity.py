@@ -561,3 +561,68 @@ def test_edge_paths_of_sorted_links_take_the_tile_route(ctx, tmp_path):
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
     assert info.n_scatter_paths == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle is too slow / too big here)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_cfg3_properties():
+    """configs[2]: 10M nodes x 256 paths.  Every item lands in exactly one bin; the histogram is
+    the bincount of the coverage vector; core nodes reach G; visiting order does not matter."""
+    from panacus_amd import capi
+    n, p = 10_000_000, 256
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(42, n, p)
+        order = np.arange(p, dtype=np.uint32)
+        c.set_order(order, order, p)
+        cnt, h = c.hist()
+        assert int(h.sum()) == n and cnt[0] == 0xFFFFFFFF
+        assert np.array_equal(np.bincount(cnt[1:], minlength=p + 1).astype(np.uint64), h)
+        assert int(cnt[1:].max()) == p and c.info().n_general_paths == 0
+        assert int(cnt[1:].astype(np.uint64).sum()) <= c.info().n_steps
+        # 20 % of the nodes are in every path (pansyn "core"), 45 % in about one path
+        assert abs(int(h[p]) / n - 0.20) < 0.01
+        rng = np.random.default_rng(0)
+        perm = rng.permutation(p).astype(np.uint32)
+        c.set_order(perm, order, p)  # same groups visited in another order
+        _, h2 = c.hist(want_countable=False)
+        assert np.array_equal(h, h2)
+        # -S style grouping (pairs of paths): a checksum that ties the two histograms together
+        c.set_order(order, (order // 2).astype(np.uint32), p // 2)
+        cnt2, h3 = c.hist()
+        assert int(h3.sum()) == n
+        assert np.all(cnt2[1:] <= cnt[1:]) and np.all(2 * cnt2[1:].astype(np.int64) >= cnt[1:])
+
+
+def test_full_size_cfg4_properties():
+    """configs[3]: 10M nodes x 512 paths, permuted ordered growth.  For q = 0 every order ends at
+    the same total, curves are non-decreasing, and the mean first step equals the mean group
+    size; for the quorum pair the last value counts the items present in >= half of the groups."""
+    from panacus_amd import capi
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 10_000_000, 512
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(42, n, p)
+        order = np.arange(p, dtype=np.uint32)
+        c.set_order(order, order, p)
+        cnt, h = c.hist()
+        pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+        cov = [coverage_abs(Threshold(ABSOLUTE, cc), p) for cc, _ in pairs]
+        qt = np.stack([quorum_table(Threshold(RELATIVE, q), p) for _, q in pairs])
+        perms = random_orders(42, 6, p)
+        out = c.ordered_growth(cov, qt, perms)
+        for r in range(6):
+            assert int(out[r, 0, -1]) == n - int(h[0])                    # deg >= 1
+            assert int(out[r, 1, -1]) == n - int(h[0]) - int(h[1])        # deg >= 2
+            assert np.all(np.diff(out[r, 0].astype(np.int64)) >= 0)
+            assert np.all(np.diff(out[r, 1].astype(np.int64)) >= 0)
+            # at the last rank the quorum bound is ceil(G * 0.5) for an item whose last group is
+            # the last rank; items seen in >= half of all groups are always counted there
+            assert int(out[r, 2, -1]) >= int(h[(p + 1) // 2:].sum()) - 1
+        # first rank: res[0] = size of the first group of each order
+        sizes = np.array([int(out[r, 0, 0]) for r in range(6)])
+        assert np.all(sizes > 0.30 * n) and np.all(sizes < 0.45 * n)
+        # identity order == reference ordered-histgrowth semantics, q = 0: distinct items so far
+        ident = c.ordered_growth(cov[:1], qt[:1])
+        assert int(ident[0, 0, -1]) == n - int(h[0])
