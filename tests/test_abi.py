@@ -54,3 +54,41 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b|liboracle|panacus_oracle", txt, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_plain_c_program_links_and_fails_loudly(tmp_path):
+    """A C host (the shape of the Rust FFI) links against libpanacus_hip.so; without a GPU
+    pnx_init returns PNX_ENODEV and a message, it never falls back to a CPU path."""
+    import subprocess
+    import torch
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "panacus_amd.h"
+int main(void) {
+    pnx_ctx *ctx = NULL;
+    int rc = pnx_init(&ctx, 0);
+    printf("%d|%s|%s\n", rc, pnx_version(), rc ? pnx_last_error(NULL) : "ok");
+    if (rc == PNX_OK) {
+        uint32_t items[3] = {1, 2, 2};
+        uint64_t off[2] = {0, 3};
+        uint32_t pi[1] = {0}, gi[1] = {0}, cnt[3];
+        uint64_t hist[2];
+        if (pnx_set_csr(ctx, items, off, 1, 2, NULL, NULL) || pnx_set_order(ctx, pi, gi, 1, 1) ||
+            pnx_hist(ctx, cnt, hist)) { printf("ERR %s\n", pnx_last_error(ctx)); return 2; }
+        printf("hist %llu %llu cnt %u %u\n", (unsigned long long)hist[0], (unsigned long long)hist[1], cnt[1], cnt[2]);
+        pnx_free(ctx);
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lpanacus_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.decode()
+    rc = int(out.split("|")[0])
+    if torch.cuda.is_available():
+        assert rc == 0 and "hist 0 2 cnt 1 1" in out
+    else:
+        assert rc == capi.PNX_ENODEV and "no CPU fallback" in out
