@@ -102,14 +102,16 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
 // path; K1's per-step in-tile check then catches every misplaced step.
 __global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
                                   const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                                  uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
+                                  uint32_t n_tiles, uint32_t tile_items, uint32_t coarse, uint32_t stride,
                                   uint64_t *__restrict__ B, uint8_t *path_class) {
+    // this launch fills the boundaries t with t % stride == 0 inside brackets of `coarse` tiles
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t per = (uint64_t)n_tiles + 1;
-    if (gid >= per * n_paths) return;
-    const uint32_t p = (uint32_t)(gid / per);
-    const uint32_t t = (uint32_t)(gid % per);
-    if (t % coarse == 0 || t == n_tiles) return;  // done by pass A
+    const uint64_t per_s = (per + stride - 1) / stride;
+    if (gid >= per_s * n_paths) return;
+    const uint32_t p = (uint32_t)(gid / per_s);
+    const uint32_t t = (uint32_t)(gid % per_s) * stride;
+    if (t % coarse == 0 || t >= n_tiles) return;  // done by the coarser level
     const uint32_t t0 = t - t % coarse;
     const uint32_t t1 = t0 + coarse < n_tiles ? t0 + coarse : n_tiles;
     const uint64_t s = path_off[p], e = path_off[p + 1];
@@ -195,17 +197,27 @@ int launch_tile_index(pnx_ctx *ctx) {
     if (nb == 0) return PNX_OK;
     prof_begin(ctx, PNX_K_INDEX);
     {
+        // hierarchical: every (coarse*8)-th boundary by full binary search, every coarse-th by
+        // interpolation inside those brackets, the rest by interpolation inside coarse brackets
         const uint32_t coarse = ctx->index_coarse ? ctx->index_coarse : 1;
-        const uint32_t n_coarse = (ctx->n_tiles + coarse - 1) / coarse + 1;
-        const uint64_t na = (uint64_t)n_coarse * ctx->n_paths;
+        const uint32_t top = coarse > 1 ? coarse * 8 : 1;
+        const uint32_t n_top = (ctx->n_tiles + top - 1) / top + 1;
+        const uint64_t na = (uint64_t)n_top * ctx->n_paths;
         hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                           ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p);
-        if (coarse > 1)
+                           ctx->n_tiles, tile_items, top, (uint64_t *)ctx->d_tile_idx.p);
+        if (coarse > 1) {
+            const uint64_t per = (uint64_t)ctx->n_tiles + 1;
+            const uint64_t nb1 = ((per + coarse - 1) / coarse) * ctx->n_paths;
+            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
+                               ctx->n_tiles, tile_items, top, coarse, (uint64_t *)ctx->d_tile_idx.p,
+                               (uint8_t *)ctx->d_path_class.p);
             hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                               ctx->n_tiles, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p,
+                               ctx->n_tiles, tile_items, coarse, 1u, (uint64_t *)ctx->d_tile_idx.p,
                                (uint8_t *)ctx->d_path_class.p);
+        }
     }
     uint64_t nc = (uint64_t)ctx->n_paths * ctx->n_tiles;
     hipLaunchKernelGGL(k_tile_index_check, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0,
@@ -473,7 +485,9 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
     return *reinterpret_cast<const uint4 *>(p);
 }
 
-template <int NPL, int WT, bool WRITE_M, bool NT, int CW>
+// RUNS = false compiles the run consumption out: the kernel of graphs whose paths are all
+// tile-monotone keeps its low register count (occupancy 5+ waves/SIMD, all tiles resident)
+template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS>
 __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
@@ -490,8 +504,8 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     if (tile >= n_tiles) return;
     uint32_t *bm = bm_all[wave];
     const uint32_t tile_lo = tile * TILE;
-    uint64_t run_c = rv.tile_off ? rv.tile_off[tile] : 0;
-    const uint64_t run_end = rv.tile_off ? rv.tile_off[tile + 1] : 0;
+    uint64_t run_c = RUNS && rv.tile_off ? rv.tile_off[tile] : 0;
+    const uint64_t run_end = RUNS && rv.tile_off ? rv.tile_off[tile + 1] : 0;
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
@@ -515,7 +529,7 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
 
     auto flush = [&](uint32_t g) {
-        if (run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
+        if (RUNS && run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -578,16 +592,26 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         }
     };
 
+    // one extra iteration (k == n_ordered) closes the last group, so the flush code -- and the
+    // run consumption inlined in it -- exists once in the kernel (register pressure)
     uint32_t cur_g = n_ordered ? ord_group[0] : 0;
     if (n_ordered) issue(0);
-    for (uint32_t k = 0; k < n_ordered; ++k) {
+    for (uint32_t k = 0; k <= n_ordered; ++k) {
+        const bool last = k == n_ordered;
+        const uint32_t g = last ? 0xFFFFFFFFu : ord_group[k];
+        // With runs the group change comes first: while the previous group is folded and its
+        // runs are streamed only the prefetched segment is live, not a second copy of it.
+        // Without runs the next segment is issued first, so its loads also cover the fold.
+        if (RUNS && g != cur_g && n_ordered) {
+            flush(cur_g);
+            cur_g = g;
+        }
         uint4 cur[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        const uint64_t lo = n_lo, hi = n_hi;
-        const uint32_t g = ord_group[k];
+        const uint64_t lo = last ? 0 : n_lo, hi = last ? 0 : n_hi;
         if (k + 1 < n_ordered) issue(k + 1);
-        if (g != cur_g) {
+        if (!RUNS && g != cur_g && n_ordered) {
             flush(cur_g);
             cur_g = g;
         }
@@ -616,7 +640,6 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
             }
         }
     }
-    if (n_ordered) flush(cur_g);
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) {
@@ -673,6 +696,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     if (ctx->n_runs && ctx->runs_sorted)
         rv = RunView{(const uint64_t *)ctx->d_srun_start.p, (const uint32_t *)ctx->d_srun_len.p,
                      (const uint32_t *)ctx->d_srun_group.p, (const uint64_t *)ctx->d_run_tile_off.p};
+    const bool has_runs = rv.tile_off != nullptr;
     auto launch = [&](auto kern, int cw) {
         const unsigned grid = (ctx->n_tiles + cw - 1) / cw;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
@@ -686,15 +710,20 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     };
     switch (ctx->cover_variant) {
         case 1:
-            if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, false, COVER_WAVES>, COVER_WAVES);
-            else launch(k_tile_cover_pipe<NPL, WT, false, false, COVER_WAVES>, COVER_WAVES);
+            if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, false, COVER_WAVES, true>, COVER_WAVES);
+            else launch(k_tile_cover_pipe<NPL, WT, false, false, COVER_WAVES, true>, COVER_WAVES);
             break;
         case 2:
+            if (has_runs) {
+                if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4, true>, 4);
+                else launch(k_tile_cover_pipe<NPL, WT, false, true, 4, true>, 4);
+                break;
+            }
             switch (ctx->cover_waves) {
-                case 1: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 1>, 1); else launch(k_tile_cover_pipe<NPL, WT, false, true, 1>, 1); break;
-                case 2: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 2>, 2); else launch(k_tile_cover_pipe<NPL, WT, false, true, 2>, 2); break;
-                case 8: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 8>, 8); else launch(k_tile_cover_pipe<NPL, WT, false, true, 8>, 8); break;
-                default: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4>, 4); else launch(k_tile_cover_pipe<NPL, WT, false, true, 4>, 4); break;
+                case 1: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 1, false>, 1); else launch(k_tile_cover_pipe<NPL, WT, false, true, 1, false>, 1); break;
+                case 2: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 2, false>, 2); else launch(k_tile_cover_pipe<NPL, WT, false, true, 2, false>, 2); break;
+                case 8: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 8, false>, 8); else launch(k_tile_cover_pipe<NPL, WT, false, true, 8, false>, 8); break;
+                default: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4, false>, 4); else launch(k_tile_cover_pipe<NPL, WT, false, true, 4, false>, 4); break;
             }
             break;
         default:
