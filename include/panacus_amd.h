@@ -123,6 +123,26 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
 int pnx_ordered_growth_device(pnx_ctx *ctx, uint64_t **d_out); /* R*T*G u64 */
 int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
 
+/* ---- group x group intersections ("next" row: similarity) ----------------------------------
+ * Replaces the accumulation loop of Similarity::set_table (src/analyses/similarity.rs:119-150),
+ * which walks AbacusByGroup's (r, c) and sums, for every item, node_len (bp) or 1 (node / edge)
+ * into path_lens[x] and path_similarities[(x, y)] for all ordered pairs of the item's groups:
+ *   inter  G*G u64, row-major: inter[a*G + b] = sum over items present in groups a and b,
+ *          inter[a*G + a] = path_lens[a].  Weighted (bp) iff weights are resident and enabled.
+ * The Jaccard table (f32 division, similarity.rs:153-165) and the output live above the ABI.
+ */
+int pnx_group_intersections(pnx_ctx *ctx, uint64_t *inter);
+int pnx_group_intersections_device(pnx_ctx *ctx, uint64_t **d_inter); /* G*G u64 in HBM */
+
+/* ---- presence matrix export ("next" row: table) ------------------------------------------------
+ * The group x item presence matrix that stands in for AbacusByGroup's (r, c)
+ * (abacus.rs:791-986) as plain bit rows: bit (i % 64) of word bits[g*row_words + i/64] is set
+ * iff item i occurs in group g (excluded items never).  row_words = pnx_presence_row_words()
+ * >= ceil((n_items + 1) / 64); padding bits are 0.  This is what AbacusByGroup::to_tsv
+ * (abacus.rs:1056-1178) prints. */
+uint64_t pnx_presence_row_words(pnx_ctx *ctx);
+int pnx_presence(pnx_ctx *ctx, uint64_t *bits /* n_groups * row_words */);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of the kernels, recorded on the context's own stream.  Slots: */
 enum {
@@ -132,7 +152,8 @@ enum {
     PNX_K_HIST = 3,    /* histogram of the coverage vector                 */
     PNX_K_MASK = 4,    /* threshold masks / weight planes for growth       */
     PNX_K_GROWTH = 5,  /* ordered / permuted growth kernel                 */
-    PNX_K_COUNT = 6
+    PNX_K_PAIRS = 6,   /* group x group intersection kernel                */
+    PNX_K_COUNT = 7
 };
 int pnx_profile_enable(pnx_ctx *ctx, int on);
 /* accumulated milliseconds and launch counts per slot since the last reset */

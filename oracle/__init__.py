@@ -82,6 +82,10 @@ def lib() -> C.CDLL:
         L.orc_by_group.argtypes = [u64p, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u8p, u64p, C.POINTER(u64p)]
         L.orc_ordered_growth.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_int, C.c_double,
                                          C.c_int, C.c_double, u32p, f64p]
+        L.orc_similarity.restype = C.c_int
+        L.orc_similarity.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, u32p, u64p, u64p,
+                                     C.POINTER(C.c_float)]
+        L.orc_table_row.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]
         for name in ("orc_growth_union", "orc_growth_core"):
             getattr(L, name).argtypes = [u64p, C.c_uint64, C.c_int, C.c_double, f64p]
         L.orc_growth_quorum.argtypes = [u64p, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_double, f64p]
@@ -257,6 +261,39 @@ def ordered_growth(r, c, n_groups, coverage_thr=(ABSOLUTE, 1), quorum_thr=(RELAT
                              coverage_thr[0], float(coverage_thr[1]), quorum_thr[0],
                              float(quorum_thr[1]), _p(w, C.c_uint32), _p(out, C.c_double))
     return out[:n_groups]
+
+
+def similarity(r, c, n_groups, node_lens=None):
+    """Similarity::set_table before clustering (similarity.rs:119-165):
+    (inter[G, G] u64, path_lens[G] u64, jaccard[G, G] f32); raises where the reference panics."""
+    r, c = _u64(r), _u64(c)
+    if len(c) == 0:
+        c = np.zeros(1, dtype=np.uint64)
+    w = None if node_lens is None else np.ascontiguousarray(node_lens, dtype=np.uint32)
+    G = int(n_groups)
+    inter = np.zeros((G, G), dtype=np.uint64)
+    lens = np.zeros(G, dtype=np.uint64)
+    table = np.zeros((G, G), dtype=np.float32)
+    rc = lib().orc_similarity(_p(r, C.c_uint64), _p(c, C.c_uint64), len(r) - 2, G, _p(w, C.c_uint32),
+                              _p(inter, C.c_uint64), _p(lens, C.c_uint64), _p(table, C.c_float))
+    if rc:
+        raise KeyError("a group holds no item: the reference panics on path_lens[&i]")
+    return inter, lens, table
+
+
+def table_rows(r, c, n_groups, node_lens=None) -> np.ndarray:
+    """Body of AbacusByGroup::to_tsv without `total` (abacus.rs:1093-1112): [n_items, G] u64,
+    row i-1 = item i."""
+    r, c = _u64(r), _u64(c)
+    if len(c) == 0:
+        c = np.zeros(1, dtype=np.uint64)
+    n_items = len(r) - 2
+    out = np.zeros((n_items, int(n_groups)), dtype=np.uint64)
+    for i in range(1, n_items + 1):
+        bp = 1 if node_lens is None else int(node_lens[i])
+        lib().orc_table_row(_p(r, C.c_uint64), _p(c, C.c_uint64), i, int(n_groups), bp,
+                            out[i - 1].ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
 
 
 def pansyn(seed: int, n_nodes: int, n_paths: int):

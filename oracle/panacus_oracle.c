@@ -1349,6 +1349,53 @@ int orc_graph_exclude_flags(orc_graph *g, int count_type, const char *exclude_fi
 
 /* ------------------------------------------------------------------------------------ */
 /* pansyn-v1: counter-based synthetic pangenome generator (integer-only)      */
+/* Similarity::set_table up to the Jaccard table, similarity.rs:119-165.  The reference keeps
+ * the sums in HashMaps keyed by (x << 64 | y); dense arrays hold the same numbers. */
+int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint64_t n_groups,
+                   const uint32_t *node_lens, uint64_t *inter, uint64_t *lens, float *table) {
+    const uint64_t G = n_groups;
+    uint8_t *seen = xmalloc(G ? G : 1);
+    memset(seen, 0, G ? G : 1);
+    for (uint64_t k = 0; k < G * G; k++) inter[k] = 0;
+    for (uint64_t g = 0; g < G; g++) lens[g] = 0;
+    /* tuple_windows over r: index = item id, 0..=n_items (similarity.rs:125,130) */
+    for (uint64_t index = 0; index <= n_items; index++) {
+        const uint64_t w = node_lens ? node_lens[index] : 1; /* :131,134-138 */
+        for (uint64_t a = r[index]; a < r[index + 1]; a++) {
+            const uint64_t x = c[a];
+            lens[x] += w;
+            seen[x] = 1;
+            for (uint64_t b = r[index]; b < r[index + 1]; b++) inter[x * G + c[b]] += w; /* :139-149 */
+        }
+    }
+    int rc = 0;
+    for (uint64_t g = 0; g < G; g++)
+        if (!seen[g]) rc = -1; /* path_lens[&(i as u64)] on a missing key panics (:163) */
+    if (rc == 0 && table)
+        for (uint64_t i = 0; i < G; i++)
+            for (uint64_t j = 0; j < G; j++) {
+                const uint64_t x = inter[i * G + j];
+                table[i * G + j] = (float)x / (float)(lens[i] + lens[j] - x); /* :162-163 */
+            }
+    free(seen);
+    return rc;
+}
+
+/* AbacusByGroup::to_tsv, node/bp branch without `total` and without multiplicities
+ * (abacus.rs:1093-1112) */
+void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,
+                   uint64_t bp, uint64_t *out) {
+    uint64_t k = r[i];
+    const uint64_t end = r[i + 1];
+    for (uint64_t j = 0; j < n_groups; j++) {
+        if (k == end || j < c[k]) out[j] = 0;
+        else if (j == c[k]) {
+            out[j] = bp;
+            k++;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 uint64_t pansyn_splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ULL;

@@ -107,6 +107,17 @@ void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
                         uint64_t n_groups, int cov_kind, double cov_val, int quo_kind,
                         double quo_val, const uint32_t *weights, double *out);
 
+/* Similarity::set_table before clustering (src/analyses/similarity.rs:119-165): inter[a*G+b] =
+   number (or bp, when node_lens != NULL) of items whose group slice holds both a and b,
+   lens[a] = path_lens[a], table[a*G+b] = inter as f32 / (lens[a] + lens[b] - inter) as f32.
+   Returns -1 when a group has no item (the reference's `path_lens[&i]` panics), else 0. */
+int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint64_t n_groups,
+                   const uint32_t *node_lens, uint64_t *inter, uint64_t *lens, float *table);
+/* one row of AbacusByGroup::to_tsv without `total` (abacus.rs:1093-1112): out[j] = bp (or 1)
+   when group j holds item i, else 0 */
+void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,
+                   uint64_t bp, uint64_t *out);
+
 /* ---- synthetic pangenome generator pansyn-v1 (DESIGN.md section "pansyn-v1") ---- */
 uint64_t pansyn_splitmix64(uint64_t x);
 uint32_t pansyn_node_len(uint64_t seed, uint64_t i);

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
-K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_COUNT = range(7)
-KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth"]
+K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
+KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
 CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS = 1, 2, 3, 4, 5, 6, 7
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
-    "pnx_profile_reset", "pnx_config", "pnx_info",
+    "pnx_profile_reset", "pnx_config", "pnx_info", "pnx_group_intersections",
+    "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence",
 ]
 
 
@@ -77,6 +78,11 @@ def load() -> C.CDLL:
     L.pnx_ordered_growth_async.argtypes = [vp, u32p, C.c_uint32, u32p, u32p, C.c_uint32]
     L.pnx_ordered_growth_device.argtypes = [vp, C.POINTER(vp)]
     L.pnx_ordered_growth_fetch.argtypes = [vp, u64p]
+    L.pnx_group_intersections.argtypes = [vp, u64p]
+    L.pnx_group_intersections_device.argtypes = [vp, C.POINTER(vp)]
+    L.pnx_presence_row_words.argtypes = [vp]
+    L.pnx_presence_row_words.restype = C.c_uint64
+    L.pnx_presence.argtypes = [vp, u64p]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
     L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
     L.pnx_profile_reset.argtypes = [vp]
@@ -223,6 +229,29 @@ class Context:
         d = C.c_void_p()
         self._ck(self._L.pnx_ordered_growth_device(self._h, C.byref(d)))
         return d.value
+
+    # ---- "next" rows: similarity / table ----
+    def group_intersections(self) -> np.ndarray:
+        """inter[a, b] = items (or bp, when weighted) shared by groups a and b; diagonal = path_lens
+        (Similarity::set_table, similarity.rs:119-150)."""
+        G = int(self.info().n_groups)
+        out = np.zeros((G, G), dtype=np.uint64)
+        self._ck(self._L.pnx_group_intersections(self._h, _ptr(out, C.c_uint64)))
+        return out
+
+    def group_intersections_device(self) -> int:
+        d = C.c_void_p()
+        self._ck(self._L.pnx_group_intersections_device(self._h, C.byref(d)))
+        return d.value
+
+    def presence(self) -> np.ndarray:
+        """[G, row_words] u64 plain bit rows: bit i % 64 of word i // 64 = item i in the group."""
+        G = int(self.info().n_groups)
+        rw = int(self._L.pnx_presence_row_words(self._h))
+        out = np.zeros((G, rw), dtype=np.uint64)
+        if G and rw:
+            self._ck(self._L.pnx_presence(self._h, _ptr(out, C.c_uint64)))
+        return out
 
     # ---- measurement / tunables ----
     def profile_enable(self, on=True):

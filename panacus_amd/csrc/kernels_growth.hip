@@ -387,6 +387,39 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
 }
 
 // ------------------------------------------------------------------------------------------
+// bit planes of the resident weights in presence layout (built once per upload)
+int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch) {
+    if (ctx->wplanes_valid) return PNX_OK;
+    const uint32_t NB = ctx->n_blocks;
+    int rc;
+    DevBuf tmp;
+    uint32_t *d_max = d_scratch;
+    if (!d_max) {
+        if ((rc = ensure(ctx, tmp, sizeof(uint32_t)))) return rc;
+        d_max = (uint32_t *)tmp.p;
+    }
+    hipError_t e = hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream);
+    uint32_t mx = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_max_u32, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_weights.p,
+                           (uint64_t)1, (uint64_t)ctx->n_items + 1, d_max);
+        e = hipMemcpyAsync(&mx, d_max, sizeof mx, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(tmp);
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "weight planes: %s", hipGetErrorString(e));
+    uint32_t planes = 0;
+    while (planes < 32 && (mx >> planes) != 0) ++planes;
+    if (planes == 0) planes = 1;
+    ctx->n_wplanes = planes;
+    if ((rc = ensure(ctx, ctx->d_wplanes, (size_t)planes * NB * BLOCK_WORDS * sizeof(uint32_t)))) return rc;
+    if (NB)
+        hipLaunchKernelGGL(k_weight_planes, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_weights.p, ctx->n_items, NB, planes, (uint32_t *)ctx->d_wplanes.p);
+    ctx->wplanes_valid = true;
+    return PNX_OK;
+}
+
 int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     const uint32_t G = ctx->n_groups, R = ctx->g_R, T = ctx->g_T, NB = ctx->n_blocks;
     int rc;
@@ -428,23 +461,7 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                            (const uint32_t *)ctx->d_countable.p, ctx->n_items, NB, (const uint32_t *)d_aux,
                            (uint32_t)cvals.size(), (uint32_t *)ctx->d_cmask.p);
     }
-    if (ctx->weighted && !ctx->wplanes_valid) {
-        uint32_t *d_max = d_aux + 32;
-        PNX_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_max_u32, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_weights.p,
-                           (uint64_t)1, (uint64_t)ctx->n_items + 1, d_max);
-        uint32_t mx = 0;
-        PNX_HIP(ctx, hipMemcpyAsync(&mx, d_max, sizeof mx, hipMemcpyDeviceToHost, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        uint32_t planes = 0;
-        while (planes < 32 && (mx >> planes) != 0) ++planes;
-        if (planes == 0) planes = 1;
-        ctx->n_wplanes = planes;
-        if ((rc = ensure(ctx, ctx->d_wplanes, (size_t)planes * NB * BLOCK_WORDS * sizeof(uint32_t)))) return rc;
-        hipLaunchKernelGGL(k_weight_planes, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_weights.p, ctx->n_items, NB, planes, (uint32_t *)ctx->d_wplanes.p);
-        ctx->wplanes_valid = true;
-    }
+    if (ctx->weighted && (rc = ensure_weight_planes(ctx, d_aux + 32))) return rc;
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
 

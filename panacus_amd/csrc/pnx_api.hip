@@ -231,7 +231,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->tk[1].d_flags, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off})
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain})
         release(*b);
     for (auto &t : ctx->tk) {
         if (t.h_hist) (void)hipHostFree(t.h_hist);
@@ -498,6 +498,58 @@ int pnx_ordered_growth(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms, co
     int rc = pnx_ordered_growth_async(ctx, perms, n_perms, cov_thr, quorum_tab, n_thr);
     if (rc) return rc;
     return pnx_ordered_growth_fetch(ctx, out);
+}
+
+// the presence matrix of the current order, resident and verified
+static int ensure_presence(pnx_ctx *ctx, const char *who) {
+    if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "%s needs pnx_set_csr and pnx_set_order first", who);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = settle_all(ctx))) return rc;
+    if (!(ctx->hist_valid && ctx->M_valid)) {
+        ctx->growth_needs_M = true;
+        if ((rc = pnx_hist_async(ctx))) return rc;
+        if ((rc = settle_all(ctx))) return rc;
+    }
+    return PNX_OK;
+}
+
+int pnx_group_intersections_device(pnx_ctx *ctx, uint64_t **d_inter) {
+    if (!ctx) return PNX_EINVAL;
+    int rc = ensure_presence(ctx, "pnx_group_intersections");
+    if (rc) return rc;
+    if ((rc = launch_pair_intersections(ctx))) return rc;
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (d_inter) *d_inter = (uint64_t *)ctx->d_inter.p;
+    return PNX_OK;
+}
+
+int pnx_group_intersections(pnx_ctx *ctx, uint64_t *inter) {
+    if (!ctx) return PNX_EINVAL;
+    uint64_t *d = nullptr;
+    int rc = pnx_group_intersections_device(ctx, &d);
+    if (rc) return rc;
+    const size_t n = (size_t)ctx->n_groups * ctx->n_groups;
+    if (inter && n) {
+        PNX_HIP(ctx, hipMemcpyAsync(inter, d, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PNX_OK;
+}
+
+uint64_t pnx_presence_row_words(pnx_ctx *ctx) { return ctx ? (uint64_t)ctx->n_blocks * 32u : 0; }
+
+int pnx_presence(pnx_ctx *ctx, uint64_t *bits) {
+    if (!ctx) return PNX_EINVAL;
+    if (!bits) return ctx->fail(PNX_EINVAL, "pnx_presence: bits is NULL");
+    int rc = ensure_presence(ctx, "pnx_presence");
+    if (rc) return rc;
+    if ((rc = launch_presence_plain(ctx, ctx->d_plain))) return rc;
+    const size_t n = (size_t)ctx->n_groups * ctx->n_blocks * 32;
+    if (n) PNX_HIP(ctx, hipMemcpyAsync(bits, ctx->d_plain.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    release(ctx->d_plain);
+    return PNX_OK;
 }
 
 int pnx_profile_enable(pnx_ctx *ctx, int on) {

@@ -121,6 +121,9 @@ struct pnx_ctx {
     bool wplanes_valid = false;
     bool growth_pending = false;
 
+    // ---- pairwise intersections / plain presence export (kernels_pairs.hip) ----
+    pnx::DevBuf d_inter, d_pair_partial, d_plain;
+
     pnx::Profile prof;
 
     int fail(int code, const char *fmt, ...) {
@@ -162,6 +165,10 @@ int build_run_index(pnx_ctx *ctx);
 int sort_run_index(pnx_ctx *ctx);
 // kernels_growth.hip
 int launch_growth(pnx_ctx *ctx, bool identity_perm);
+int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p in presence layout
+// kernels_pairs.hip
+int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
+int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
 // pansyn.hip
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                            int with_weights);

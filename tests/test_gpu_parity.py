@@ -566,6 +566,83 @@ def test_edge_paths_of_sorted_links_take_the_tile_route(ctx, tmp_path):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties (the oracle is too slow / too big here)
 # ---------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# "next" rows: similarity intersections (K5) and the presence export behind `table` (K6)
+# ---------------------------------------------------------------------------------------------
+def _oracle_pairs(items, pre, n, path_groups, G, w=None, exclude=None):
+    pi = np.arange(len(pre) - 1, dtype=np.uint64)
+    r, c = orc.by_group(items, pre, pi, np.asarray(path_groups, dtype=np.uint64), n, exclude)
+    return r, c
+
+
+@pytest.mark.parametrize("count", [orc.NODE, orc.BP, orc.EDGE])
+def test_group_intersections_chrM(ctx, golden_dir, count):
+    g, pi, gi, names, items, pre, n, w = _load_gfa(ctx, os.path.join(golden_dir, "chrM_test.gfa"), count,
+                                                   orc.GROUP_SAMPLE)
+    r, c = orc.by_group(items, pre, pi, gi, n)
+    exp, lens, _ = orc.similarity(r, c, len(names), node_lens=w)
+    got = ctx.group_intersections()
+    assert got.tolist() == exp.tolist()
+    assert np.diag(got).tolist() == lens.tolist()
+
+
+@pytest.mark.parametrize("n,p,paths_per_group,weighted", [(5_000, 7, 1, False), (70_000, 70, 1, False),
+                                                          (70_000, 70, 1, True), (40_000, 130, 1, False),
+                                                          (30_000, 48, 2, True)])
+def test_group_intersections_vs_oracle(ctx, n, p, paths_per_group, weighted):
+    items, pre, lens = orc.pansyn(21, n, p)
+    w = lens if weighted else None
+    excl = np.zeros(n + 1, dtype=np.uint8)
+    excl[5::97] = 1
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=excl)
+    pg = (np.arange(p) // paths_per_group).astype(np.uint64)
+    G = int(pg.max()) + 1
+    ctx.set_order(np.arange(p, dtype=np.uint64), pg, G)
+    r, c = _oracle_pairs(items, pre, n, pg, G, exclude=excl)
+    exp, _, _ = orc.similarity(r, c, G, node_lens=w)
+    got = ctx.group_intersections()
+    assert (got == exp).all()
+    # repeatable, and a new order gives a new matrix
+    assert (ctx.group_intersections() == exp).all()
+    ctx.set_order(np.arange(p - 1, dtype=np.uint64), pg[: p - 1], int(pg[: p - 1].max()) + 1)
+    G2 = int(pg[: p - 1].max()) + 1
+    r2, c2 = orc.by_group(items, pre, np.arange(p - 1, dtype=np.uint64), pg[: p - 1], n, excl)
+    exp2, _, _ = orc.similarity(r2, c2, G2, node_lens=w)
+    assert (ctx.group_intersections() == exp2).all()
+
+
+def test_group_intersections_wide_weights(ctx):
+    """weights above 2^16 use the high accumulator planes"""
+    n, p = 9_000, 9
+    items, pre, lens = orc.pansyn(5, n, p)
+    w = lens.copy()
+    w[1::3] = w[1::3] * 70_001 + 1_000_000  # up to ~3.5e9 < 2^32
+    w = np.minimum(w.astype(np.uint64), 0xFFFFFFFF).astype(np.uint32)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    r, c = _oracle_pairs(items, pre, n, pg, p)
+    exp, _, _ = orc.similarity(r, c, p, node_lens=w)
+    assert (ctx.group_intersections() == exp).all()
+
+
+def test_presence_export_matches_by_group(ctx):
+    n, p = 10_000, 19
+    items, pre, _ = orc.pansyn(8, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pg = (np.arange(p) // 2).astype(np.uint64)
+    G = int(pg.max()) + 1
+    ctx.set_order(np.arange(p, dtype=np.uint64), pg, G)
+    bits = ctx.presence()
+    assert bits.shape[0] == G and bits.shape[1] * 64 >= n + 1
+    r, c = _oracle_pairs(items, pre, n, pg, G)
+    exp = orc.table_rows(r, c, G)  # [n, G] 0/1
+    got = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, : n + 1]
+    assert got[:, 0].sum() == 0
+    assert (got[:, 1:].T == exp).all()
+    assert np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, n + 1:].sum() == 0
+
+
 def test_full_size_cfg3_properties():
     """configs[2]: 10M nodes x 256 paths.  Every item lands in exactly one bin; the histogram is
     the bincount of the coverage vector; core nodes reach G; visiting order does not matter."""
