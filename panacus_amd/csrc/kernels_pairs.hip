@@ -27,6 +27,12 @@ constexpr int PAIR_KS = 32;   // words per staging step
 constexpr int PAIR_LD = 68;   // LDS stride of one word slice ([word][row]); 272 B keeps b128 reads aligned
 constexpr uint32_t PAIR_WCHUNK_MAX = 1024;  // weighted: 16 planes * 32 items * 2^15 * 1024 words < 2^32
 
+// popc(x) + acc in one instruction (the compiler otherwise pairs popcounts into v_add3_u32)
+__device__ static inline uint32_t popc_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 __device__ static inline uint32_t lshl_add(uint32_t v, uint32_t s, uint32_t acc) { return (v << s) + acc; }
 
 template <bool WEIGHTED>
@@ -52,13 +58,16 @@ __global__ __launch_bounds__(256) void k_pair_intersect(const uint32_t *__restri
     const uint32_t ra = (wave >> 1) * 32u + (lane >> 3) * 4u;  // first A row of the micro-tile
     const uint32_t rb = (wave & 1u) * 32u + (lane & 7u) * 4u;  // first B row
 
+    // rows past G are clamped to a valid row and masked to zero after the (unconditional,
+    // 16-byte) load
     const uint32_t ga0 = ti * PAIR_T, gb0 = tj * PAIR_T;
-    const uint32_t *rowA0 = M + (uint64_t)(ga0 + ld_row < G ? ga0 + ld_row : 0) * row_words + ld_k;
-    const uint32_t *rowA1 = M + (uint64_t)(ga0 + ld_row + 32 < G ? ga0 + ld_row + 32 : 0) * row_words + ld_k;
-    const uint32_t *rowB0 = M + (uint64_t)(gb0 + ld_row < G ? gb0 + ld_row : 0) * row_words + ld_k;
-    const uint32_t *rowB1 = M + (uint64_t)(gb0 + ld_row + 32 < G ? gb0 + ld_row + 32 : 0) * row_words + ld_k;
-    const bool okA0 = ga0 + ld_row < G, okA1 = ga0 + ld_row + 32 < G;
-    const bool okB0 = gb0 + ld_row < G, okB1 = gb0 + ld_row + 32 < G;
+    auto row_ptr = [&](uint32_t g) {
+        return reinterpret_cast<const uint4 *>(M + (uint64_t)(g < G ? g : G - 1) * row_words + ld_k);
+    };
+    const uint4 *rowA0 = row_ptr(ga0 + ld_row), *rowA1 = row_ptr(ga0 + ld_row + 32);
+    const uint4 *rowB0 = row_ptr(gb0 + ld_row), *rowB1 = row_ptr(gb0 + ld_row + 32);
+    const uint32_t mA0 = ga0 + ld_row < G ? ~0u : 0u, mA1 = ga0 + ld_row + 32 < G ? ~0u : 0u;
+    const uint32_t mB0 = gb0 + ld_row < G ? ~0u : 0u, mB1 = gb0 + ld_row + 32 < G ? ~0u : 0u;
 
     uint32_t acc[4][4], acc_hi[WEIGHTED ? 4 : 1][WEIGHTED ? 4 : 1];
 #pragma unroll
@@ -69,14 +78,14 @@ __global__ __launch_bounds__(256) void k_pair_intersect(const uint32_t *__restri
             if (WEIGHTED) acc_hi[i][j] = 0;
         }
 
-    const uint4 zero = make_uint4(0, 0, 0, 0);
-    uint4 va0, va1, vb0 = zero, vb1 = zero;
+    uint4 va0, va1, vb0 = make_uint4(0, 0, 0, 0), vb1 = vb0;
+    auto masked = [](uint4 v, uint32_t m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); };
     auto fetch = [&](uint64_t w) {
-        va0 = okA0 ? *reinterpret_cast<const uint4 *>(rowA0 + w) : zero;
-        va1 = okA1 ? *reinterpret_cast<const uint4 *>(rowA1 + w) : zero;
+        va0 = rowA0[w >> 2];
+        va1 = rowA1[w >> 2];
         if (!diag) {
-            vb0 = okB0 ? *reinterpret_cast<const uint4 *>(rowB0 + w) : zero;
-            vb1 = okB1 ? *reinterpret_cast<const uint4 *>(rowB1 + w) : zero;
+            vb0 = rowB0[w >> 2];
+            vb1 = rowB1[w >> 2];
         }
     };
     auto put4 = [&](uint32_t *s, uint32_t row, const uint4 &v) {
@@ -86,11 +95,11 @@ __global__ __launch_bounds__(256) void k_pair_intersect(const uint32_t *__restri
         s[(ld_k + 3) * PAIR_LD + row] = v.w;
     };
     auto stage = [&](int buf) {
-        put4(sA[buf], ld_row, va0);
-        put4(sA[buf], ld_row + 32, va1);
+        put4(sA[buf], ld_row, masked(va0, mA0));
+        put4(sA[buf], ld_row + 32, masked(va1, mA1));
         if (!diag) {
-            put4(sB[buf], ld_row, vb0);
-            put4(sB[buf], ld_row + 32, vb1);
+            put4(sB[buf], ld_row, masked(vb0, mB0));
+            put4(sB[buf], ld_row + 32, masked(vb1, mB1));
         }
     };
 
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256) void k_pair_intersect(const uint32_t *__restri
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] += __popc(a[i] & b[j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = popc_acc(a[i] & b[j], acc[i][j]);
             } else {
                 uint32_t x[4][4];
 #pragma unroll

@@ -21,7 +21,7 @@ namespace {
 
 struct Options {
     std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file, subset_file, exclude_file;
-    bool add_hist = false, by_sample = false, by_haplotype = false;
+    bool add_hist = false, by_sample = false, by_haplotype = false, total = false;
     int threads = 0, device = 0;
     // synth
     uint64_t seed = 42;
@@ -32,11 +32,12 @@ struct Options {
 
 const char *USAGE =
     "panacus-amd -- MI355X-native hist / growth / histgrowth / ordered-histgrowth\n"
-    "usage: panacus-amd <hist|growth|histgrowth|ordered-histgrowth> [options] <GFA_FILE | HIST.tsv>\n"
+    "usage: panacus-amd <hist|growth|histgrowth|ordered-histgrowth|similarity|table> [options] <GFA_FILE | HIST.tsv>\n"
     "  -c, --count <node|bp|edge|all>   graph quantity to be counted [node]\n"
     "  -l, --coverage <LIST>            coverage thresholds, e.g. 1,2 [1]\n"
     "  -q, --quorum <LIST>              quorum thresholds in [0,1], e.g. 0,0.5 [0]\n"
     "  -a, --hist                       also include the histogram (growth, histgrowth)\n"
+    "  -a, --total                      table: one column with the number of groups per item (required)\n"
     "  -g, --groupby <FILE>             path-to-group mapping (2-column TSV)\n"
     "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
     "  -S, --groupby-sample             merge paths of the same sample\n"
@@ -45,6 +46,7 @@ const char *USAGE =
     "  -e, --exclude <FILE>             drop the listed paths/groups and every node/edge/bp they touch\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
     "      --device <N>                 GPU ordinal [0]\n"
+    "  similarity prints the Jaccard table in group order (the reference's dendrogram ordering is not applied)\n"
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
     "                                        write a pansyn-v1 synthetic pangenome as GFA\n";
 
@@ -250,6 +252,62 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     return metadata_comments(cmdline) + write_ordered_table(headers, cols, order.groups);
 }
 
+// Similarity::set_table up to the Jaccard table (similarity.rs:119-165) + get_table_string
+// (:224-239).  The intersections come from the GPU; the f32 division happens here exactly as in
+// the reference.  Rows and columns stay in group order: the reference then reorders them by a
+// kodama dendrogram (:166-182), which is outside this path.
+std::string cmd_similarity(const Options &o, const std::string &cmdline) {
+    CountType ct = count_types(o.count, false)[0];
+    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    const size_t G = order.groups.size();
+    Device dev(o.device);
+    upload(dev, *g, ct, order, masking(o));
+    std::vector<uint64_t> inter(G * G, 0);
+    if (G) dev.check(pnx_group_intersections(dev.ctx, inter.data()));
+    for (size_t a = 0; a < G; ++a)
+        if (inter[a * G + a] == 0)  // path_lens[&a] on a missing key panics in the reference (:163)
+            throw std::runtime_error("group " + order.groups[a] + " covers no item: the reference panics here");
+    std::string res = metadata_comments(cmdline) + "group";
+    for (const auto &name : order.groups) res += "\t" + name;
+    res += "\n";
+    for (size_t i = 0; i < G; ++i) {
+        res += order.groups[i];
+        for (size_t j = 0; j < G; ++j) {
+            const uint64_t x = inter[i * G + j];
+            const float v = (float)x / (float)(inter[i * G + i] + inter[j * G + j] - x);
+            res += "\t" + format_f32(v);
+        }
+        res += "\n";
+    }
+    return res;
+}
+
+// AbacusByGroup::to_tsv with `total` (abacus.rs:1056-1140): one row per item with the number of
+// groups holding it = the coverage vector of pnx_hist.  Without --total the reference prints
+// per-group multiplicities (AbacusByGroup.v), which the presence matrix does not carry.
+std::string cmd_table(const Options &o, const std::string &cmdline) {
+    if (!o.total) throw std::runtime_error("table: only --total is supported (per-group multiplicities are outside the GPU path)");
+    CountType ct = count_types(o.count, false)[0];
+    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    const uint64_t n = g->number_of_items(ct);
+    Device dev(o.device);
+    upload(dev, *g, ct, order, masking(o));
+    std::vector<uint32_t> countable(n + 1, 0);
+    std::vector<uint64_t> hist(order.groups.size() + 1, 0);
+    dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+    std::string res = metadata_comments(cmdline);
+    res += ct == COUNT_EDGE ? "edge\ttotal\n" : "node\ttotal\n";
+    std::vector<std::string> labels;
+    if (ct == COUNT_EDGE) labels = g->edge_labels();
+    for (uint64_t i = 1; i <= n; ++i) {
+        res += ct == COUNT_EDGE ? labels[i] : g->node_name((uint32_t)i);
+        res += "\t" + std::to_string(countable[i]) + "\n";
+    }
+    return res;
+}
+
 bool ends_with(const std::string &s, const std::string &suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
@@ -286,7 +344,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--links") o.links = true;
             else if (a == "--sequences") o.sequences = true;
-            else if (a == "-a" || a == "--hist") o.add_hist = true;
+            else if (a == "-a" || a == "--hist" || a == "--total") o.add_hist = o.total = true;
             else if (a == "-S" || a == "--groupby-sample") o.by_sample = true;
             else if (a == "-H" || a == "--groupby-haplotype") o.by_haplotype = true;
             else if (a == "-s" || a == "--subset") o.subset_file = value("--subset");
@@ -310,6 +368,8 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
         else if (o.cmd == "histgrowth") table = cmd_histgrowth(o, cmdline, false);
         else if (o.cmd == "growth") table = ends_with(o.file, "tsv") ? cmd_growth_from_hist(o, cmdline) : cmd_histgrowth(o, cmdline, true);
         else if (o.cmd == "ordered-histgrowth") table = cmd_ordered(o, cmdline);
+        else if (o.cmd == "similarity") table = cmd_similarity(o, cmdline);
+        else if (o.cmd == "table") table = cmd_table(o, cmdline);
         else throw std::runtime_error("unknown subcommand '" + o.cmd + "'\n" + USAGE);
         out = table + "\n";  // writeln!(out, "{table}") in src/lib.rs:322
         return 0;

@@ -325,6 +325,7 @@ struct GraphStorage::Impl {
     std::vector<Span> step_fields;    // per path: the step / walk column
     std::vector<uint8_t> is_walk;     // per path
     NameMap names;
+    std::vector<Span> node_names;     // per node id - 1: the name field of its S line
     bool nice = false;                // segment names are the integers 1..N in file order
     bool has_edges = false;
     EdgeMap edges;
@@ -452,6 +453,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                                          " occurs multiple times in GFA");
     }
     g->node_count_ = s_lines.size();
+    im.node_names = std::move(name_of);
 
     // --- P / W lines: path identity + the span of the step column ---
     const size_t P = im.p_lines.size();
@@ -794,6 +796,26 @@ void read_path_list(const std::string &file, const std::vector<PathSegment> &pat
 }
 
 }  // namespace
+
+std::string GraphStorage::node_name(uint32_t id) const {
+    const Impl &im = *impl_;
+    if (id == 0 || id > im.node_names.size()) throw std::runtime_error("node id out of range");
+    const Span sp = im.node_names[id - 1];
+    return std::string(im.image.data() + sp.b, sp.e - sp.b);
+}
+
+std::vector<std::string> GraphStorage::edge_labels() const {
+    const Impl &im = *impl_;
+    if (!im.has_edges) throw std::runtime_error("edge labels need the edge index");
+    std::vector<std::string> out(edge_count_ + 1);
+    for (const auto &sl : im.edges.tab) {
+        if (!sl.id) continue;
+        const uint32_t u = (uint32_t)(sl.uv >> 32), v = (uint32_t)sl.uv;
+        const char o1 = (sl.oo >> 1) & 1 ? '<' : '>', o2 = sl.oo & 1 ? '<' : '>';
+        out[sl.id] = std::string(1, o1) + node_name(u) + std::string(1, o2) + node_name(v);
+    }
+    return out;
+}
 
 std::vector<uint8_t> GraphStorage::exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
                                                  const std::string &group_file, const std::string &exclude_file) const {

@@ -72,6 +72,11 @@ public:
     std::vector<uint8_t> exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
                                        const std::string &group_file, const std::string &exclude_file) const;
 
+    // labels of AbacusByGroup::to_tsv (abacus.rs:1072-1140): the segment name of a node id, and
+    // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id
+    std::string node_name(uint32_t id) const;
+    std::vector<std::string> edge_labels() const;  // [0] unused
+
     struct Impl;
 
 private:

@@ -200,6 +200,16 @@ uint64_t pnh_format_f64(double x, char *buf, uint64_t cap) {
     return s.size();
 }
 
+uint64_t pnh_format_f32(float x, char *buf, uint64_t cap) {
+    std::string s = pnh::format_f32(x);
+    if (cap) {
+        size_t n = std::min<size_t>(s.size(), cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
 
 }  // extern "C"

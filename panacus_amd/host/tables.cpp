@@ -8,17 +8,19 @@
 
 namespace pnh {
 
-// Rust's Display for f64: shortest digits that round-trip, never scientific notation,
+// Rust's Display for floats: shortest digits that round-trip, never scientific notation,
 // integers without a fractional part, "NaN", "inf".
-std::string format_f64(double x) {
+namespace {
+template <typename F, typename Parse>
+std::string format_float(F x, int max_prec, Parse parse) {
     if (std::isnan(x)) return "NaN";
     if (std::isinf(x)) return x > 0 ? "inf" : "-inf";
-    if (x == 0.0) return std::signbit(x) ? "-0" : "0";
+    if (x == 0) return std::signbit(x) ? "-0" : "0";
     char buf[64];
     int prec = 1;
-    for (; prec <= 17; ++prec) {
-        std::snprintf(buf, sizeof buf, "%.*e", prec - 1, x);
-        if (std::strtod(buf, nullptr) == x) break;
+    for (; prec <= max_prec; ++prec) {
+        std::snprintf(buf, sizeof buf, "%.*e", prec - 1, (double)x);
+        if (parse(buf) == x) break;
     }
     // buf = [-]d.ddddde[+-]XX
     std::string s(buf);
@@ -40,6 +42,14 @@ std::string format_f64(double x) {
         out = "0." + std::string((size_t)(-exp10 - 1), '0') + digits;
     }
     return neg ? "-" + out : out;
+}
+}  // namespace
+
+std::string format_f64(double x) {
+    return format_float<double>(x, 17, [](const char *b) { return std::strtod(b, nullptr); });
+}
+std::string format_f32(float x) {
+    return format_float<float>(x, 9, [](const char *b) { return std::strtof(b, nullptr); });
 }
 
 std::string threshold_string(Threshold t) {

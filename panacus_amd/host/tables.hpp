@@ -14,6 +14,7 @@
 namespace pnh {
 
 std::string format_f64(double x);            // Rust `{}` for f64
+std::string format_f32(float x);             // Rust `{}` for f32 (shortest digits that round-trip as f32)
 std::string threshold_string(Threshold t);   // Threshold::get_string, src/util.rs:343-348
 const char *count_name(CountType c);          // src/util.rs:57-69
 bool parse_count_name(const std::string &s, CountType &c);

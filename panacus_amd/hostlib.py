@@ -233,3 +233,13 @@ def format_f64(x: float) -> str:
     buf = C.create_string_buffer(512)
     L.pnh_format_f64(float(x), buf, 512)
     return buf.value.decode()
+
+
+def format_f32(x) -> str:
+    """Rust `{}` of an f32 (the cells of the similarity table)."""
+    L = load()
+    L.pnh_format_f32.restype = C.c_uint64
+    L.pnh_format_f32.argtypes = [C.c_float, C.c_char_p, C.c_uint64]
+    buf = C.create_string_buffer(512)
+    L.pnh_format_f32(float(x), buf, 512)
+    return buf.value.decode()

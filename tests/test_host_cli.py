@@ -24,6 +24,20 @@ def test_format_f64_like_rust():
         assert th.format_f64(x) == s
 
 
+def test_format_f32_like_rust():
+    # Rust prints the shortest decimal that round-trips as f32
+    for x, s in [(1.0, "1"), (0.5, "0.5"), (np.float32(1) / np.float32(3), "0.33333334"), (np.float32(0.1), "0.1"),
+                 (np.float32(2) / np.float32(3), "0.6666667"), (np.float32(1e-7), "0.0000001"),
+                 (np.float32(16777216.0), "16777216"), (float("nan"), "NaN"), (0.0, "0")]:
+        assert hl.format_f32(x) == s
+    rng = np.random.default_rng(3)
+    for v in rng.random(200).astype(np.float32):
+        t = hl.format_f32(v)
+        assert np.float32(t) == v and "e" not in t
+        # no shorter decimal round-trips
+        assert np.float32(t[:-1]) != v or t[-2] == "."
+
+
 def test_threshold_container():
     tc = th.ThresholdContainer.parse_params("0,0.5,1.0", "1")
     assert [t.value for t in tc.coverage] == [1, 1, 1]
@@ -203,3 +217,42 @@ def test_cli_subset_exclude(tmp_path):
         exp = orc.ordered_growth(r_, c_, len(gnames), (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.3), g.node_lens)
         rows = [x.split("\t") for x in _body(out).split("\n")[4:] if x]
         assert [x[0] for x in rows] == gnames and [x[1] for x in rows] == [str(int(v)) for v in exp]
+
+
+@pytest.mark.gpu
+def test_cli_similarity_chrM(golden_dir):
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+        rc, out, err = hl.run_cli(["similarity", "-S", "-c", cname, gfa])
+        assert rc == 0, err
+        g = orc.Graph(gfa, index_edges=True)
+        pi, gi, names = g.path_order(orc.GROUP_SAMPLE)
+        items, pre = g.item_table(ct)
+        r, c = orc.by_group(items, pre, pi, gi, g.n_items(ct))
+        _, _, tab = orc.similarity(r, c, len(names), g.node_lens if ct == orc.BP else None)
+        rows = [x.split("\t") for x in _body(out).split("\n") if x]
+        assert rows[0] == ["group"] + names
+        for i, name in enumerate(names):
+            assert rows[1 + i] == [name] + [hl.format_f32(v) for v in tab[i]]
+        assert out.endswith("\n\n")
+
+
+@pytest.mark.gpu
+def test_cli_table_total_chrM(golden, golden_dir):
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    rc, out, err = hl.run_cli(["table", "--total", "-S", gfa])
+    assert rc == 0, err
+    rows = [x.split("\t") for x in _body(out).split("\n") if x]
+    assert rows[0] == ["node", "total"]
+    # abacus.rs:1487-1496: coverage of node id i; segment names of chrM_test.gfa in S-line order
+    names = [l.split("\t")[1] for l in open(gfa) if l.startswith("S\t")]
+    assert [r[0] for r in rows[1:]] == names
+    assert [int(r[1]) for r in rows[1:]] == golden["chrM_sample_node"]["countable"][1:]
+    rc, out, err = hl.run_cli(["table", "--total", "-S", "-c", "edge", gfa])
+    assert rc == 0, err
+    rows = [x.split("\t") for x in _body(out).split("\n") if x]
+    assert rows[0] == ["edge", "total"]
+    assert [int(r[1]) for r in rows[1:]] == golden["chrM_sample_edge"]["countable"][1:]
+    assert all(r[0][0] in "<>" for r in rows[1:])
+    rc, out, err = hl.run_cli(["table", "-S", gfa])
+    assert rc == 1 and "--total" in err
