@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <memory>
 
@@ -141,8 +142,18 @@ struct Job {
                     }
                     q[j] += L(n - i - m + 1 + j);
                     q[j] -= L(m - j);
-                    sum_q += std::exp2(q[j] + m_fact[m] - n_fall[m]);
                     add = true;
+                    // sum_q += exp2(x).  The libm call is skipped where its result provably
+                    // cannot change the running sum: exp2(x) <= 2^(floor(x)+1) (+1 ulp), so for
+                    // x + 56 <= exponent(sum_q) the addend is below half an ulp of a normal sum_q
+                    // and the rounded sum is sum_q itself; far below the subnormals it is +0.
+                    const double x = q[j] + m_fact[m] - n_fall[m];
+                    if (x < -1100.0) continue;
+                    uint64_t sb;
+                    std::memcpy(&sb, &sum_q, sizeof sb);
+                    const int64_t es = (int64_t)((sb >> 52) & 0x7FF);  // biased exponent, 0 = zero / subnormal
+                    if (es > 0 && x + 56.0 <= (double)(es - 1023)) continue;
+                    sum_q += std::exp2(x);
                 }
             }
             if (add) t2[m] = std::exp2(lh[i] + std::log2(sum_q));

@@ -49,3 +49,16 @@ def test_all_pairs_in_one_region_bitwise():
         got = hostlib.calc_growths(h, [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs])
         for (c, q), g in zip(pairs, got):
             assert g.tobytes() == orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes(), (n, c, q)
+
+
+def test_quorum_large_n_bitwise():
+    """n where the tails of the quorum sums are far below half an ulp of the running sum (the
+    host skips those libm calls): still bit-identical with the serial restatement"""
+    rng = np.random.default_rng(11)
+    n = 420
+    h = rng.integers(1, 10**6, size=n + 1).astype(np.uint64)
+    h[17] = 0
+    for c, q in ((1, 0.5), (1, 0.05), (3, 0.95), (40, 0.3)):
+        a = hostlib.calc_growth(h, Threshold(ABSOLUTE, c), Threshold(RELATIVE, q))
+        b = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+        assert a.tobytes() == b.tobytes(), (c, q)
