@@ -195,13 +195,22 @@ def main():
     if args.warmup:
         run(args.warmup)
     barrier()
+    # timed region: HIP events (on the context's stream) around the dominant kernel only; the
+    # other kernels are timed in a short untimed tail so that their event records do not sit
+    # between the kernels of the measured passes
     ctx.profile_enable(True)
+    ctx.profile_select([capi.K_COVER])
     ctx.profile_reset()
     t0 = time.perf_counter()
     h, growths = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
+    ctx.profile_select(None)
+    ctx.profile_reset()
+    run(5)
+    barrier()
+    prof_tail = ctx.profile_read()
     ctx.profile_enable(False)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -228,12 +237,12 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * N * P / (dt / args.steps) / 1e6
         cover_ms, cover_n = prof["cover"]
-        index_ms, index_n = prof["index"]
-        hist_ms, hist_n = prof["hist"]
+        index_ms, index_n = prof_tail["index"]
+        hist_ms, hist_n = prof_tail["hist"]
         cover_avg_ms = cover_ms / max(cover_n, 1)
         B = algorithmic_bytes_hist(S, P, N, P)
         achieved = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
-        device_ms = (cover_ms + index_ms + hist_ms) / max(cover_n, 1)
+        device_ms = cover_avg_ms + index_ms / max(index_n, 1) + hist_ms / max(hist_n, 1)
         traffic, traffic_src = pmc_traffic_from_profiles(N, P)
         out = {
             "metric": "histgrowth_throughput",
@@ -271,7 +280,7 @@ def main():
             "breakdown_ms": {
                 "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
-                "host_closed_form_growth": growth_ms,
+                "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(),
                 "single_pass_latency": latency_ms,
             },
             "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,

@@ -156,6 +156,10 @@ enum {
     PNX_K_COUNT = 7
 };
 int pnx_profile_enable(pnx_ctx *ctx, int on);
+/* restrict the timing to the slots whose bit (1u << slot) is set (default: all).  Every timed
+ * slot costs two event records per launch on the stream; a throughput run that only needs the
+ * dominant kernel selects that one slot. */
+int pnx_profile_select(pnx_ctx *ctx, uint32_t slot_mask);
 /* accumulated milliseconds and launch counts per slot since the last reset */
 int pnx_profile_read(pnx_ctx *ctx, double ms[PNX_K_COUNT], uint64_t launches[PNX_K_COUNT]);
 int pnx_profile_reset(pnx_ctx *ctx);

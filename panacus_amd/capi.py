@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
-    "pnx_profile_reset", "pnx_config", "pnx_info", "pnx_group_intersections",
+    "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence",
 ]
 
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
+    L.pnx_profile_select.argtypes = [vp, C.c_uint32]
     L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
     L.pnx_profile_reset.argtypes = [vp]
     L.pnx_config.argtypes = [vp, C.c_int, C.c_int64]
@@ -256,6 +257,11 @@ class Context:
     # ---- measurement / tunables ----
     def profile_enable(self, on=True):
         self._ck(self._L.pnx_profile_enable(self._h, int(on)))
+
+    def profile_select(self, slots=None):
+        """time only the given slot indices (None = all)"""
+        mask = 0xFFFFFFFF if slots is None else sum(1 << int(k) for k in slots)
+        self._ck(self._L.pnx_profile_select(self._h, mask))
 
     def profile_read(self):
         ms = (C.c_double * K_COUNT)()

@@ -76,12 +76,13 @@ __device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a,
 __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
                                     const uint64_t *__restrict__ path_off, uint32_t n_paths,
                                     uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
-                                    uint64_t *__restrict__ B) {
+                                    uint64_t *__restrict__ B, uint8_t *__restrict__ path_class) {
     const uint32_t n_coarse = (n_tiles + coarse - 1) / coarse + 1;  // t = 0, c, 2c, ..., n_tiles
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (uint64_t)n_coarse * n_paths) return;
     const uint32_t p = (uint32_t)(gid / n_coarse);
     uint32_t t = (uint32_t)(gid % n_coarse) * coarse;
+    if (t == 0) path_class[p] = 0;  // the later passes of the index only ever raise it
     if (t > n_tiles) t = n_tiles;
     const uint64_t s = path_off[p], e = path_off[p + 1];
     uint64_t *out = B + (uint64_t)p * (n_tiles + 1) + t;
@@ -193,7 +194,6 @@ int launch_tile_index(pnx_ctx *ctx) {
     int rc;
     if ((rc = ensure(ctx, ctx->d_tile_idx, nb * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_class, ctx->n_paths ? ctx->n_paths : 1))) return rc;
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_path_class.p, 0, ctx->n_paths ? ctx->n_paths : 1, ctx->stream));
     if (nb == 0) return PNX_OK;
     prof_begin(ctx, PNX_K_INDEX);
     {
@@ -205,7 +205,8 @@ int launch_tile_index(pnx_ctx *ctx) {
         const uint64_t na = (uint64_t)n_top * ctx->n_paths;
         hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                           ctx->n_tiles, tile_items, top, (uint64_t *)ctx->d_tile_idx.p);
+                           ctx->n_tiles, tile_items, top, (uint64_t *)ctx->d_tile_idx.p,
+                           (uint8_t *)ctx->d_path_class.p);
         if (coarse > 1) {
             const uint64_t per = (uint64_t)ctx->n_tiles + 1;
             const uint64_t nb1 = ((per + coarse - 1) / coarse) * ctx->n_paths;
@@ -703,10 +704,10 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_tile_idx.p,
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
-                           use_m ? (const uint8_t *)ctx->d_grp_general.p : (const uint8_t *)nullptr,
+                           use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
-                           (uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->cur->d_flags.p, rv);
+                           (uint32_t *)ctx->d_countable.p, ctx->cur->d_flags, rv);
     };
     switch (ctx->cover_variant) {
         case 1:
@@ -749,30 +750,33 @@ int launch_cover_pass(pnx_ctx *ctx) {
     if (ctx->n_runs && !ctx->runs_sorted && (rc = sort_run_index(ctx))) return rc;
     const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
     const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
-    if ((rc = ensure(ctx, ctx->cur->d_flags, 8 * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->d_grp_general, ctx->n_groups ? ctx->n_groups : 1))) return rc;
+    Ticket *tk = ctx->cur;
+    const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
+    tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
+    if ((rc = ensure(ctx, tk->d_block, tk->block_bytes))) return rc;
+    tk->d_flags = (uint32_t *)tk->d_block.p;
+    tk->d_hist = (uint64_t *)((char *)tk->d_block.p + 8 * sizeof(uint32_t));
+    tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;
     if ((rc = ensure(ctx, ctx->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->cur->d_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t)))) return rc;
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
 
-    PNX_HIP(ctx, hipMemsetAsync(ctx->cur->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_grp_general.p, 0, ctx->n_groups ? ctx->n_groups : 1, ctx->stream));
-    PNX_HIP(ctx, hipMemsetAsync(ctx->cur->d_hist.p, 0, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t), ctx->stream));
+    // flags, histogram and per-group "general" marks of this pass: one clear
+    PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->stream));
 
     if (ctx->n_ordered) {
         prof_begin(ctx, PNX_K_SCATTER);
         hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
                            (const uint8_t *)ctx->d_path_class.p, (const uint32_t *)ctx->d_ord_path.p,
                            (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
-                           (uint8_t *)ctx->d_grp_general.p, (uint32_t *)ctx->cur->d_flags.p);
+                           ctx->cur->d_grp_general, ctx->cur->d_flags);
         if (use_m && m_words) {
             hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->stream,
-                               (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->cur->d_flags.p);
+                               (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->cur->d_flags);
             hipLaunchKernelGGL(k_scatter_general, dim3(2048), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
                                (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                                ctx->n_ordered, (const uint8_t *)ctx->d_path_class.p, (uint32_t *)ctx->d_M.p,
-                               (uint64_t)ctx->n_blocks * BLOCK_WORDS, (const uint32_t *)ctx->cur->d_flags.p);
+                               (uint64_t)ctx->n_blocks * BLOCK_WORDS, (const uint32_t *)ctx->cur->d_flags);
         }
         prof_end(ctx);
         PNX_HIP(ctx, hipGetLastError());
@@ -793,7 +797,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_countable.p, (const uint32_t *)ctx->d_weights.p,
-                               ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->cur->d_hist.p);
+                               ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->cur->d_hist);
         };
         if (ctx->weighted) { if (lds) go(k_hist<true, true>); else go(k_hist<true, false>); }
         else { if (lds) go(k_hist<false, true>); else go(k_hist<false, false>); }

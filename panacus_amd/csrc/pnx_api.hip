@@ -45,14 +45,16 @@ static hipEvent_t prof_event(pnx_ctx *ctx) {
 }
 
 void prof_begin(pnx_ctx *ctx, int slot) {
-    if (!ctx->prof.on) return;
+    ctx->prof.open = ctx->prof.on && ((ctx->prof.mask >> slot) & 1u);
+    if (!ctx->prof.open) return;
     Profile::Pending pd{prof_event(ctx), prof_event(ctx), slot};
     (void)hipEventRecord(pd.a, ctx->stream);
     ctx->prof.pending.push_back(pd);
 }
 
 void prof_end(pnx_ctx *ctx) {
-    if (!ctx->prof.on || ctx->prof.pending.empty()) return;
+    if (!ctx->prof.open || ctx->prof.pending.empty()) return;
+    ctx->prof.open = false;
     (void)hipEventRecord(ctx->prof.pending.back().b, ctx->stream);
 }
 
@@ -103,17 +105,17 @@ static void set_geometry(pnx_ctx *ctx) {
 }
 
 static int stage_results(pnx_ctx *ctx, Ticket *t) {
-    const size_t nh = (size_t)ctx->n_groups + 1;
-    if (t->h_cap < nh) {
-        if (t->h_hist) (void)hipHostFree(t->h_hist);
-        t->h_hist = nullptr;
-        PNX_HIP(ctx, hipHostMalloc((void **)&t->h_hist, nh * sizeof(uint64_t), hipHostMallocDefault));
-        t->h_cap = nh;
+    const size_t bytes = 8 * sizeof(uint32_t) + ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
+    if (t->h_cap < bytes) {
+        if (t->h_block) (void)hipHostFree(t->h_block);
+        t->h_block = nullptr;
+        PNX_HIP(ctx, hipHostMalloc(&t->h_block, bytes, hipHostMallocDefault));
+        t->h_cap = bytes;
     }
-    if (!t->h_flags) PNX_HIP(ctx, hipHostMalloc((void **)&t->h_flags, 8 * sizeof(uint32_t), hipHostMallocDefault));
+    t->h_flags = (uint32_t *)t->h_block;
+    t->h_hist = (uint64_t *)((char *)t->h_block + 8 * sizeof(uint32_t));
     if (!t->done) PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
-    PNX_HIP(ctx, hipMemcpyAsync(t->h_hist, t->d_hist.p, nh * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipMemcpyAsync(t->h_flags, t->d_flags.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PNX_HIP(ctx, hipEventRecord(t->done, ctx->stream));
     return PNX_OK;
 }
@@ -226,16 +228,14 @@ void pnx_free(pnx_ctx *ctx) {
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_path_class, &ctx->d_grp_general, &ctx->d_flags,
-                      &ctx->d_countable, &ctx->tk[0].d_hist, &ctx->tk[0].d_flags, &ctx->tk[1].d_hist,
-                      &ctx->tk[1].d_flags, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_path_class, &ctx->d_flags,
+                      &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain})
         release(*b);
     for (auto &t : ctx->tk) {
-        if (t.h_hist) (void)hipHostFree(t.h_hist);
-        if (t.h_flags) (void)hipHostFree(t.h_flags);
+        if (t.h_block) (void)hipHostFree(t.h_block);
         if (t.done) (void)hipEventDestroy(t.done);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -391,7 +391,7 @@ int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
     int rc = settle_oldest(ctx);  // the oldest pass in flight (a younger one keeps running)
     if (rc) return rc;
     if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
-    if (d_hist) *d_hist = (uint64_t *)ctx->last_done->d_hist.p;
+    if (d_hist) *d_hist = ctx->last_done->d_hist;
     if (d_countable) *d_countable = (uint32_t *)ctx->d_countable.p;  // shared by all passes
     return PNX_OK;
 }
@@ -555,6 +555,12 @@ int pnx_presence(pnx_ctx *ctx, uint64_t *bits) {
 int pnx_profile_enable(pnx_ctx *ctx, int on) {
     if (!ctx) return PNX_EINVAL;
     ctx->prof.on = on != 0;
+    return PNX_OK;
+}
+
+int pnx_profile_select(pnx_ctx *ctx, uint32_t slot_mask) {
+    if (!ctx) return PNX_EINVAL;
+    ctx->prof.mask = slot_mask;
     return PNX_OK;
 }
 

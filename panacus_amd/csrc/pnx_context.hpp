@@ -35,16 +35,25 @@ struct DevBuf {
 // host has looked at pass k: each owns its result counters in HBM, a pinned staging copy and
 // the event that marks "results of this pass are on the host".
 struct Ticket {
-    DevBuf d_hist, d_flags;   // (G+1) u64 ; u32[8]: [0] violations, [1] #general paths in the order
-    uint64_t *h_hist = nullptr;
+    // one device block [flags: u32[8] | hist: (G+1) u64 | group flags: G u8] so that a pass needs
+    // one memset and one device-to-host copy; flags[0] violations, [1] #general paths in the order
+    DevBuf d_block;
+    uint32_t *d_flags = nullptr;
+    uint64_t *d_hist = nullptr;
+    uint8_t *d_grp_general = nullptr;
+    size_t block_bytes = 0;
+    void *h_block = nullptr;  // pinned copy of flags + hist
+    size_t h_cap = 0;         // bytes of h_block
     uint32_t *h_flags = nullptr;
-    size_t h_cap = 0;         // entries of h_hist
+    uint64_t *h_hist = nullptr;
     hipEvent_t done = nullptr;
     bool in_flight = false;
 };
 
 struct Profile {
     bool on = false;
+    bool open = false;          // a prof_begin of a selected slot awaits its prof_end
+    uint32_t mask = 0xFFFFFFFFu;  // slots that are timed (pnx_profile_select)
     double ms[PNX_K_COUNT] = {0};
     uint64_t launches[PNX_K_COUNT] = {0};
     // pending (start, stop, slot) event triples, resolved at the next sync
@@ -88,7 +97,6 @@ struct pnx_ctx {
     bool cache_index = true;
     pnx::DevBuf d_tile_idx;    // n_paths * (n_tiles + 1) u64
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
-    pnx::DevBuf d_grp_general; // n_groups u8
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
 

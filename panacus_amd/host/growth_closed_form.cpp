@@ -11,10 +11,14 @@
 #include "growth_closed_form.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 
 #include "thread_pool.hpp"
 
@@ -55,6 +59,53 @@ struct Log2Table {
 
 enum Branch { UNION, CORE, QUORUM };
 
+// The (n+1)^2 term arrays are recycled across calls: fresh 8 MB allocations are mmap'ed by
+// malloc and first touched by all workers at once, and those page faults (plus the munmap
+// shoot-downs) cost several times the arithmetic at n = 1024.
+class ScratchPool {
+public:
+    struct Buf {
+        double *p = nullptr;
+        size_t cap = 0;
+    };
+    static ScratchPool &instance() {
+        static ScratchPool pool;
+        return pool;
+    }
+    Buf take(size_t n) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t k = 0; k < free_.size(); ++k)
+                if (free_[k].cap >= n && free_[k].cap <= 2 * n + 1024) {
+                    Buf b = free_[k];
+                    free_.erase(free_.begin() + (long)k);
+                    return b;
+                }
+        }
+        Buf b;
+        b.p = new double[n];
+        b.cap = n;
+        return b;
+    }
+    void give(Buf b) {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> g(mu_);
+        if (free_.size() >= 16) {  // bounded: drop the smallest
+            size_t s = 0;
+            for (size_t k = 1; k < free_.size(); ++k)
+                if (free_[k].cap < free_[s].cap) s = k;
+            if (free_[s].cap < b.cap) std::swap(free_[s], b);
+            delete[] b.p;
+            return;
+        }
+        free_.push_back(b);
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<Buf> free_;
+};
+
 struct Job {
     Branch branch;
     uint64_t n, c;
@@ -66,7 +117,8 @@ struct Job {
     double tot = 0.0;
     // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
     // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
-    std::unique_ptr<double[]> term1, term2;  // left uninitialised: every entry that is read is written by its row
+    ScratchPool::Buf buf1, buf2;
+    double *term1 = nullptr, *term2 = nullptr;  // left uninitialised: every entry that is read is written by its row
     std::vector<double> out;
 
     Job(Branch b, const std::vector<uint64_t> &h, Threshold cov, Threshold quo, std::shared_ptr<Log2Table> tab)
@@ -92,17 +144,27 @@ struct Job {
             for (uint64_t i = c; i <= n; ++i) t += hist[i];
             tot = (double)t;
         }
-        term1.reset(new double[(n + 1) * (n + 1)]);
-        if (b == QUORUM) term2.reset(new double[(n + 1) * (n + 1)]);
+        buf1 = ScratchPool::instance().take((n + 1) * (n + 1));
+        term1 = buf1.p;
+        if (b == QUORUM) {
+            buf2 = ScratchPool::instance().take((n + 1) * (n + 1));
+            term2 = buf2.p;
+        }
         out.assign(n, 0.0);
     }
+    ~Job() {
+        ScratchPool::instance().give(buf1);
+        ScratchPool::instance().give(buf2);
+    }
+    Job(const Job &) = delete;
+    Job &operator=(const Job &) = delete;
 
     uint64_t n_rows() const { return n + 1; }
 
     // everything the reference computes for histogram index i, for all m
     void run_row(uint64_t i, std::vector<double> &q) const {
         const Log2Table &L = *lg;
-        double *t1 = term1.get() + i * (n + 1);
+        double *t1 = term1 + i * (n + 1);
         double pm = 0.0;
         if (branch == UNION) {
             // hist.rs:102-111: for i in c..n-m+1 { perc_mult[i] += log2(n-m-i+1); y += exp2(..) }
@@ -121,7 +183,7 @@ struct Job {
             }
         if (branch != QUORUM || i >= n) return;
         // hist.rs:163-183, row i of Q
-        double *t2 = term2.get() + i * (n + 1);
+        double *t2 = term2 + i * (n + 1);
         q.assign(n + 1, 0.0);
         const double nan = std::nan("");
         for (uint64_t m = 1; m <= n; ++m) {
@@ -190,6 +252,10 @@ Branch dispatch(uint64_t n, Threshold quorum) {  // Hist::calc_growth, hist.rs:5
 }
 
 std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &jobs, unsigned n_threads) {
+    static const bool timing = std::getenv("PANACUS_AMD_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_begin = now();
     // flatten (job, row-chunk) into one task list; quorum rows cost ~i^2, so they are cut finer
     struct Task {
         Job *job;
@@ -221,6 +287,7 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
     } else {
         ThreadPool::instance().parallel_for(tasks.size(), body, n_threads);
     }
+    const auto t_rows = now();
     // epilogue: one task per (job, block of m)
     struct Fin {
         Job *job;
@@ -237,6 +304,9 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
     } else {
         ThreadPool::instance().parallel_for(fins.size(), fin_body, n_threads);
     }
+    if (timing)
+        std::fprintf(stderr, "[host growth] rows %.3f ms (%zu tasks), finish %.3f ms (%zu tasks)\n",
+                     ms(t_begin, t_rows), tasks.size(), ms(t_rows, now()), fins.size());
     std::vector<std::vector<double>> out;
     for (auto &j : jobs) out.push_back(std::move(j->out));
     return out;
@@ -252,8 +322,12 @@ std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &h
     const uint64_t n = hist.size() - 1;
     auto tab = std::make_shared<Log2Table>(2 * n + 2);
     std::vector<std::unique_ptr<Job>> jobs;
+    const auto t0 = std::chrono::steady_clock::now();
     for (size_t t = 0; t < coverage.size(); ++t)
         jobs.emplace_back(new Job(dispatch(n, quorum[t]), hist, coverage[t], quorum[t], tab));
+    if (std::getenv("PANACUS_AMD_HOST_TIMING"))
+        std::fprintf(stderr, "[host growth] setup %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return run_jobs(jobs, n_threads);
 }
 

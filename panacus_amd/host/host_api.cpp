@@ -210,6 +210,10 @@ uint64_t pnh_format_f32(float x, char *buf, uint64_t cap) {
     return s.size();
 }
 
+// threads of the host pool (caller included) and the CPUs the cgroup quota leaves to this process
+uint32_t pnh_pool_threads(void) { return pnh::ThreadPool::instance().size(); }
+uint32_t pnh_usable_cpus(void) { return pnh::ThreadPool::usable_cpus(); }
+
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
 
 }  // extern "C"

@@ -2,7 +2,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -18,8 +20,37 @@ ThreadPool &ThreadPool::instance() {
     return pool;
 }
 
-ThreadPool::ThreadPool() {
+// CPUs this process may actually use: the affinity mask, cut down to the CFS bandwidth quota of
+// its cgroup (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1).  Running more busy
+// threads than the quota gets the whole cgroup throttled for the rest of the 100 ms period --
+// including the thread that drives the GPU.
+unsigned ThreadPool::usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    auto read_two = [](const char *path, double &a, double &b) {
+        FILE *f = std::fopen(path, "r");
+        if (!f) return false;
+        char x[64] = {0}, y[64] = {0};
+        const int k = std::fscanf(f, "%63s %63s", x, y);
+        std::fclose(f);
+        if (k < 1 || std::strcmp(x, "max") == 0) return false;
+        a = std::atof(x);
+        b = k >= 2 ? std::atof(y) : 0.0;
+        return a > 0;
+    };
+    double quota = 0, period = 0;
+    if (read_two("/sys/fs/cgroup/cpu.max", quota, period) && period > 0) {
+        n = std::min(n, std::max(1u, (unsigned)(quota / period)));
+    } else {
+        double q1 = 0, p1 = 0, dummy = 0;
+        if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, dummy) &&
+            read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, dummy) && p1 > 0)
+            n = std::min(n, std::max(1u, (unsigned)(q1 / p1)));
+    }
+    return n;
+}
+
+ThreadPool::ThreadPool() {
+    unsigned n = usable_cpus();
     if (const char *e = std::getenv("PANACUS_AMD_THREADS")) {
         int v = std::atoi(e);
         if (v > 0) n = (unsigned)v;
@@ -48,7 +79,7 @@ void ThreadPool::stop() {
 
 void ThreadPool::set_threads(unsigned n) {
     std::lock_guard<std::mutex> call(call_mu_);
-    if (n == 0) n = std::max(1u, std::thread::hardware_concurrency());
+    if (n == 0) n = usable_cpus();
     stop();
     start(n - 1);
 }
@@ -79,7 +110,7 @@ void ThreadPool::worker_loop(unsigned id) {
         while ((e = epoch_.load(std::memory_order_acquire)) == seen) {
             PNH_PAUSE();
             if ((++spins & 1023) == 0 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) {
+                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1);
                 cv_work_.wait(lk, [&]() { return epoch_.load() != seen; });

@@ -22,7 +22,8 @@ public:
     // runs fn(task) for task in [0, n_tasks) on up to max_threads threads (caller included);
     // returns when all tasks are done.  Not re-entrant; calls are serialised.
     void parallel_for(size_t n_tasks, const std::function<void(size_t)> &fn, unsigned max_threads = 0);
-    void set_threads(unsigned n);  // like `panacus -t N` (src/lib.rs:110-127); 0 = all cores
+    void set_threads(unsigned n);  // like `panacus -t N` (src/lib.rs:110-127); 0 = all usable cores
+    static unsigned usable_cpus(); // hardware threads, limited by the cgroup's CPU bandwidth quota
     ~ThreadPool();
 
 private:

@@ -243,3 +243,10 @@ def format_f32(x) -> str:
     buf = C.create_string_buffer(512)
     L.pnh_format_f32(float(x), buf, 512)
     return buf.value.decode()
+
+
+def pool_threads() -> int:
+    """threads of the host worker pool (hardware threads cut down to the cgroup CPU quota, max 64)"""
+    L = load()
+    L.pnh_pool_threads.restype = C.c_uint32
+    return int(L.pnh_pool_threads())
