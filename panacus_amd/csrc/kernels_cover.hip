@@ -72,7 +72,67 @@ __device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a,
     return lo;
 }
 
-// K0 pass A: exact boundaries for every `coarse`-th tile (and the last one), full binary search
+// Boundary of one tile inside the bracket [lo, hi) of a path (absolute step indices): the number
+// of steps "before" key, + lo.  `num / den` is the fraction of the bracket's id range that lies
+// before the boundary.
+// First guess by position.  Every probe then reads one aligned 64-byte sector (16 ids).  If the
+// boundary lies inside it we are done; otherwise the id at the sector's edge tells how many ids
+// are still missing, and the bracket's own density (steps per id) turns that into the next
+// guess -- the error shrinks from ~sqrt(bracket) to ~sqrt(error) per probe, ~2.3 probes per
+// boundary instead of ~4 with galloping and ~22 with a plain binary search over a whole path.
+// Whatever the data, [lo, hi) only ever shrinks around the answer of a monotone path and the
+// search ends in a binary search of what is left, so the result is always inside the bracket.
+__device__ static inline uint64_t locate_boundary(const uint32_t *__restrict__ items, uint64_t lo, uint64_t hi,
+                                                  bool asc, uint64_t key, uint64_t num, uint64_t den,
+                                                  uint32_t tile_items, int max_probes) {
+    if (lo >= hi) return lo;
+    uint64_t pos = lo + (uint64_t)((double)(hi - lo) * (double)num / (double)den);
+    const float dens = (float)(hi - lo) / ((float)den * (float)tile_items);  // steps per id
+    for (int it = 0; it < max_probes && lo < hi; ++it) {
+        if (pos >= hi) pos = hi - 1;
+        if (pos < lo) pos = lo;
+        const uint64_t s0 = pos & ~(uint64_t)15;
+        const uint64_t a0 = s0 > lo ? s0 : lo, a1 = s0 + 16 < hi ? s0 + 16 : hi;  // [a0, a1) of the sector
+        const uint4 *sec = reinterpret_cast<const uint4 *>(items + s0);
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // only the quads that overlap [a0, a1) are read (the sector may stick out of the path)
+            if (s0 + 4 * q + 4 > a0 && s0 + 4 * q < a1) {
+                const uint4 x = sec[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            } else {
+                v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0;
+            }
+        }
+        uint32_t cnt = 0, v_first = 0, v_last = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint64_t i = s0 + q;
+            if (i >= a0 && i < a1) {
+                cnt += (asc ? before_key<true>(v[q], key) : before_key<false>(v[q], key)) ? 1u : 0u;
+                if (i == a0) v_first = v[q];
+                if (i == a1 - 1) v_last = v[q];
+            }
+        }
+        if (cnt == 0) {  // everything here is at or past the boundary: it lies at or left of a0
+            hi = a0;
+            const float gap = asc ? (float)v_first - (float)key : (float)key - (float)v_first;
+            const uint64_t back = (uint64_t)(gap > 0.f ? gap * dens : 0.f) + 1;
+            pos = a0 > lo + back ? a0 - back : lo;
+        } else if (cnt == (uint32_t)(a1 - a0)) {  // everything here is before it
+            lo = a1;
+            const float gap = asc ? (float)key - (float)v_last : (float)v_last - (float)key;
+            pos = a1 + (uint64_t)(gap > 0.f ? gap * dens : 0.f);
+        } else {
+            return a0 + cnt;
+        }
+    }
+    if (lo < hi) lo = asc ? bsearch_before<true>(items, lo, hi, key) : bsearch_before<false>(items, lo, hi, key);
+    return lo;
+}
+
+// K0 pass A: every `coarse`-th tile boundary (and the last one), located inside the whole path
 __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
                                     const uint64_t *__restrict__ path_off, uint32_t n_paths,
                                     uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
@@ -91,8 +151,13 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
         return;
     }
     const bool asc = items[s] <= items[e - 1];
-    const uint64_t key = (uint64_t)t * tile_items;
-    *out = asc ? bsearch_before<true>(items, s, e, key) : bsearch_before<false>(items, s, e, key);
+    // the two ends need no search (ids lie in [0, n_tiles * tile_items)); the others are located
+    // inside the whole path as one bracket
+    if (t == 0) *out = asc ? s : e;
+    else if (t == n_tiles) *out = asc ? e : s;
+    else
+        *out = locate_boundary(items, s, e, asc, (uint64_t)t * tile_items, asc ? (uint64_t)t : (uint64_t)(n_tiles - t),
+                               (uint64_t)n_tiles, tile_items, 6);
 }
 
 // K0 pass B: the boundaries in between, by interpolation inside the bracket of the two
@@ -133,43 +198,8 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
         row[t] = asc ? lo : hi;
         return;
     }
-    const uint64_t key = (uint64_t)t * tile_items;
-    if (lo < hi) {
-        // ascending: boundary of tile t sits (t-t0)/(t1-t0) into the bracket; descending: from the other end
-        const uint64_t num = asc ? (uint64_t)(t - t0) : (uint64_t)(t1 - t);
-        uint64_t pos = lo + (hi - lo) * num / (t1 - t0);
-        if (pos >= hi) pos = hi - 1;
-        uint64_t w = 16;
-        if (asc ? before_key<true>(items[pos], key) : before_key<false>(items[pos], key)) {
-            lo = pos + 1;
-            for (;;) {
-                const uint64_t q = lo + w - 1;
-                if (q >= hi) break;
-                if (asc ? before_key<true>(items[q], key) : before_key<false>(items[q], key)) {
-                    lo = q + 1;
-                    w <<= 1;
-                } else {
-                    hi = q;
-                    break;
-                }
-            }
-        } else {
-            hi = pos;
-            for (;;) {
-                if (hi - lo < w) break;
-                const uint64_t q = hi - w;
-                if (asc ? before_key<true>(items[q], key) : before_key<false>(items[q], key)) {
-                    lo = q + 1;
-                    break;
-                } else {
-                    hi = q;
-                    w <<= 1;
-                }
-            }
-        }
-        lo = asc ? bsearch_before<true>(items, lo, hi, key) : bsearch_before<false>(items, lo, hi, key);
-    }
-    row[t] = lo;
+    row[t] = locate_boundary(items, lo, hi, asc, (uint64_t)t * tile_items, asc ? (uint64_t)(t - t0) : (uint64_t)(t1 - t),
+                             (uint64_t)(t1 - t0), tile_items, 4);
 }
 
 // boundaries of a tile-monotone path are monotone; anything else goes the scatter route

@@ -192,7 +192,7 @@ int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32
     ctx->h_path_off.assign((size_t)n_paths + 1, 0);
     for (uint32_t p = 0; p < n_paths; ++p) ctx->h_path_off[p + 1] = ctx->h_path_off[p] + len[p];
     const uint64_t S = ctx->h_path_off[n_paths];
-    if ((rc = ensure(ctx, ctx->d_items, S * 4)) || (rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * 8))) {
+    if ((rc = ensure(ctx, ctx->d_items, S * 4 + 64)) || (rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * 8))) {
         cleanup();
         return rc;
     }

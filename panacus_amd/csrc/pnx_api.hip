@@ -258,7 +258,7 @@ int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, u
     ctx->have_csr = false;
     ctx->have_order = false;
     int rc;
-    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t)))) return rc;
     if (S) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_items.p, items, S * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, path_off, ((size_t)n_paths + 1) * sizeof(uint64_t),

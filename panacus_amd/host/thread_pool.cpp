@@ -110,7 +110,7 @@ void ThreadPool::worker_loop(unsigned id) {
         while ((e = epoch_.load(std::memory_order_acquire)) == seen) {
             PNH_PAUSE();
             if ((++spins & 1023) == 0 &&
-                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+                std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(60)) {
                 std::unique_lock<std::mutex> lk(mu_);
                 sleepers_.fetch_add(1);
                 cv_work_.wait(lk, [&]() { return epoch_.load() != seen; });
