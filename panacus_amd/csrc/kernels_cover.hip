@@ -22,6 +22,8 @@
 //   * paths that are not tile-monotone (edge ids, cyclic walks) are detected, not assumed
 //     away: they take the scatter route (global atomicOr into the presence matrix, merged by
 //     K1 at flush time) and the pass is re-run when a violation is first seen.
+#include <cstdlib>
+
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -230,7 +232,12 @@ int launch_tile_index(pnx_ctx *ctx) {
         // hierarchical: every (coarse*8)-th boundary by full binary search, every coarse-th by
         // interpolation inside those brackets, the rest by interpolation inside coarse brackets
         const uint32_t coarse = ctx->index_coarse ? ctx->index_coarse : 1;
-        const uint32_t top = coarse > 1 ? coarse * 8 : 1;
+        static const uint32_t top_factor = []() {
+            const char *e = std::getenv("PNX_INDEX_TOP_FACTOR");  // tuning knob: 1 = two levels only
+            const long v = e ? std::atol(e) : 1;
+            return (uint32_t)(v >= 1 && v <= 64 ? v : 1);
+        }();
+        const uint32_t top = coarse > 1 ? coarse * top_factor : 1;
         const uint32_t n_top = (ctx->n_tiles + top - 1) / top + 1;
         const uint64_t na = (uint64_t)n_top * ctx->n_paths;
         hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -240,7 +247,8 @@ int launch_tile_index(pnx_ctx *ctx) {
         if (coarse > 1) {
             const uint64_t per = (uint64_t)ctx->n_tiles + 1;
             const uint64_t nb1 = ((per + coarse - 1) / coarse) * ctx->n_paths;
-            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, ctx->stream,
+            if (top > coarse)
+                hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
                                ctx->n_tiles, tile_items, top, coarse, (uint64_t *)ctx->d_tile_idx.p,
                                (uint8_t *)ctx->d_path_class.p);
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
 constexpr uint32_t HIST_LDS_BINS = 4096;
 
 template <bool WEIGHTED, bool USE_LDS>
-__global__ __launch_bounds__(256) void k_hist(const uint32_t *__restrict__ countable,
+__global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ countable,
                                               const uint32_t *__restrict__ weights,
                                               uint32_t n_items, uint32_t n_groups,
                                               unsigned long long *hist) {
@@ -701,13 +709,50 @@ __global__ __launch_bounds__(256) void k_hist(const uint32_t *__restrict__ count
         for (uint32_t i = threadIdx.x; i <= n_groups; i += blockDim.x) sh[i] = 0;
         __syncthreads();
     }
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // item 0 is skipped
+    // The bins 0, 1 and n_groups (uncovered, private and core items) hold most items of a
+    // pangenome; adding them through LDS atomics would serialise up to 64 lanes on one address,
+    // so each lane keeps them in registers and the wave folds them once at the end.
+    unsigned long long hot0 = 0, hot1 = 0, hotg = 0;
+    auto add = [&](uint32_t c, unsigned long long w) {
+        if (c > n_groups) return;  // abacus.rs:752 / :771: coverage beyond #groups is ignored
+        if (c == 0) hot0 += w;
+        else if (c == 1) hot1 += w;
+        else if (c == n_groups) hotg += w;
+        else if (USE_LDS) atomicAdd(&sh[c], w);
+        else atomicAdd(&hist[c], w);
+    };
+    // items 1..n_items, four per lane and step (16-byte loads); quad q covers items 4q..4q+3
+    const uint64_t n_quads = ((uint64_t)n_items + 4) / 4;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i <= n_items; i += stride) {
-        const uint32_t c = countable[i];
-        if (c <= n_groups) {  // abacus.rs:752 / :771: coverage beyond #groups is ignored
-            const unsigned long long w = WEIGHTED ? weights[i] : 1ull;
-            if (USE_LDS) atomicAdd(&sh[c], w); else atomicAdd(&hist[c], w);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += stride) {
+        const uint64_t i0 = 4 * q;
+        if (i0 + 3 <= n_items) {
+            const uint4 c4 = *reinterpret_cast<const uint4 *>(countable + i0);
+            uint4 w4 = make_uint4(1, 1, 1, 1);
+            if (WEIGHTED) w4 = *reinterpret_cast<const uint4 *>(weights + i0);
+            if (i0 != 0) add(c4.x, w4.x);  // item 0 is the sentinel
+            add(c4.y, w4.y);
+            add(c4.z, w4.z);
+            add(c4.w, w4.w);
+        } else {
+            for (uint64_t i = i0 ? i0 : 1; i <= n_items; ++i) add(countable[i], WEIGHTED ? weights[i] : 1u);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        hot0 += __shfl_down(hot0, o);
+        hot1 += __shfl_down(hot1, o);
+        hotg += __shfl_down(hotg, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        // n_groups == 1 (or 0): the hot bins coincide, every item went to exactly one of them
+        if (USE_LDS) {
+            if (hot0) atomicAdd(&sh[0], hot0);
+            if (hot1) atomicAdd(&sh[1], hot1);
+            if (hotg) atomicAdd(&sh[n_groups], hotg);
+        } else {
+            if (hot0) atomicAdd(&hist[0], hot0);
+            if (hot1) atomicAdd(&hist[1], hot1);
+            if (hotg) atomicAdd(&hist[n_groups], hotg);
         }
     }
     if (USE_LDS) {
@@ -821,11 +866,13 @@ int launch_cover_pass(pnx_ctx *ctx) {
 
     prof_begin(ctx, PNX_K_HIST);
     {
-        uint64_t want = ((uint64_t)ctx->n_items + 255) / 256;
-        unsigned grid = (unsigned)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+        // one workgroup of 16 waves per CU at most: every workgroup ends with one global atomic
+        // per non-empty bin, and those serialise per address
+        uint64_t want = ((uint64_t)ctx->n_items / 4 + 1024) / 1024;
+        unsigned grid = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
         const bool lds = ctx->n_groups + 1 <= HIST_LDS_BINS;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, ctx->stream,
                                (const uint32_t *)ctx->d_countable.p, (const uint32_t *)ctx->d_weights.p,
                                ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->cur->d_hist);
         };
