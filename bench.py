@@ -117,6 +117,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: panacus_amd has no CPU fallback")
+    blocking = world > 1 or os.environ.get("PANACUS_BENCH_BLOCKING") == "1"
+    if blocking:
+        # Several ranks share the host (and possibly one cgroup CPU quota): waits must sleep, not
+        # spin, or the waiting ranks eat the CPU time rank 0 needs for the closed forms.  The flag
+        # has to be set before the HIP context of the device exists.
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipSetDevice(local_rank)
+            hip.hipSetDeviceFlags(0x4)  # hipDeviceScheduleBlockingSync
+        except OSError:
+            pass
     torch.cuda.set_device(local_rank)
     dist = None
     # PANACUS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL all-reduce on the device
@@ -139,6 +151,8 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
     ctx.config(capi.CFG_CACHE_INDEX, 0)
+    if blocking:
+        ctx.config(capi.CFG_BLOCKING_SYNC, 1)
     if args.index_coarse is not None:
         ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
     if args.cover_waves is not None:
@@ -151,20 +165,46 @@ def main():
     info = ctx.info()
     S = int(info.n_steps)
 
+    # multi-GPU: the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind
+    # the pass on the library's own stream (a collective on another stream would have to wait
+    # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
     hist_views = {}
+    if use_dist:
+        ext = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
+        ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
+                 "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
+                 "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(2)]
+        ring_pos = {"enq": 0, "fin": 0}
 
     def enqueue():
         ctx.hist_async()
-
-    def settle():
-        """wait for the OLDEST enqueued pass; multi-GPU: sum the per-shard counters over RCCL"""
         if use_dist:
-            d_hist, _ = ctx.hist_device()  # counters of that pass, still in HBM
+            d_hist = ctx.hist_enqueued()
             t = hist_views.get(d_hist)
             if t is None:
                 t = hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
-            dist.all_reduce(t)  # RCCL, int64 sum == uint64 sum for counts < 2^63
-            return t.cpu().numpy().view(np.uint64)
+            slot = ring[ring_pos["enq"] % 2]
+            ring_pos["enq"] += 1
+            with torch.cuda.stream(ext):
+                slot["tmp"].copy_(t)
+                dist.all_reduce(slot["tmp"])  # RCCL, int64 sum == uint64 sum for counts < 2^63
+                slot["host"].copy_(slot["tmp"], non_blocking=True)
+                slot["ev"].record(ext)
+            slot["reruns"] = int(ctx.info().n_reruns)
+
+    def settle():
+        """wait for the OLDEST enqueued pass; multi-GPU: its all-reduced counters"""
+        if use_dist:
+            slot = ring[ring_pos["fin"] % 2]
+            ring_pos["fin"] += 1
+            slot["ev"].synchronize()
+            _, h_local = ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
+            if int(ctx.info().n_reruns) != slot["reruns"]:
+                # the pass had to be run again (a path was reclassified): reduce the final counters
+                t = torch.from_numpy(h_local.view(np.int64)).to(f"cuda:{local_rank}")
+                dist.all_reduce(t)
+                return t.cpu().numpy().view(np.uint64)
+            return slot["host"].numpy().view(np.uint64).copy()
         _, h = ctx.hist_fetch(want_countable=False)
         return h
 
@@ -280,7 +320,7 @@ def main():
             "breakdown_ms": {
                 "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
-                "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(),
+                "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
                 "single_pass_latency": latency_ms,
             },
             "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,
@@ -293,10 +333,24 @@ def main():
                 out["cpu_baseline"] = cb
             except Exception as e:  # the oracle is optional test infrastructure
                 out["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(out))
     if use_dist:
+        # torch objects that were used on the library's stream (pinned buffers record it when they
+        # are freed) must go before the stream does
+        ring.clear()
+        hist_views.clear()
+        del ext
+        torch.cuda.synchronize()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; push it out before the one JSON line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

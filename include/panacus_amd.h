@@ -99,6 +99,11 @@ int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
 int pnx_hist_async(pnx_ctx *ctx);
 int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable);
 int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
+/* device counters of the pass enqueued LAST, without waiting for it: for work that the caller
+ * enqueues behind the pass on pnx_stream() (e.g. the RCCL all-reduce of a multi-GPU host).
+ * The values are only final if the pass verifies; pnx_info().n_reruns tells whether a later
+ * pnx_hist_fetch / pnx_hist_device had to run it again. */
+int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist);
 int pnx_sync(pnx_ctx *ctx);
 /* raw hipStream_t of the context (for RCCL / event interop in the host layer) */
 void *pnx_stream(pnx_ctx *ctx);
@@ -178,6 +183,9 @@ enum {
     PNX_CFG_USE_WEIGHTS = 7,   /* weights were uploaded: 1 = count them (bp), 0 = count items (node) on the
                                   same resident CSR -- `hist -c all` uploads the graph once */
     PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the coverage kernel: 1, 2, 4 [default], 8 */
+    PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
+                                  event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
+                                  e.g. several ranks under one cgroup CPU quota */
     PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain, 1 software-pipelined (two segments
                                   in flight per wave), 2 pipelined + non-temporal CSR loads */
 };
@@ -197,6 +205,7 @@ typedef struct {
     uint32_t n_run_paths;    /* ... of which cut into per-tile runs (no atomics) */
     uint32_t n_scatter_paths;/* ... of which left to the atomic scatter route */
     uint64_t n_runs;         /* size of the run index */
+    uint64_t n_reruns;       /* passes that failed their verification and were run again so far */
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

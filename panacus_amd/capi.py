@@ -17,12 +17,12 @@ LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
 K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
 KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
-CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS = 1, 2, 3, 4, 5, 6, 7
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn",
-    "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch",
+    "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
@@ -40,7 +40,8 @@ class PnxInfo(C.Structure):
     _fields_ = [("n_steps", C.c_uint64), ("n_items", C.c_uint32), ("n_paths", C.c_uint32),
                 ("n_ordered", C.c_uint32), ("n_groups", C.c_uint32), ("n_tiles", C.c_uint32),
                 ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32),
-                ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64)]
+                ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
+                ("n_reruns", C.c_uint64)]
 
 
 _lib = None
@@ -71,6 +72,7 @@ def load() -> C.CDLL:
     L.pnx_hist_async.argtypes = [vp]
     L.pnx_hist_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.pnx_hist_fetch.argtypes = [vp, u32p, u64p]
+    L.pnx_hist_enqueued.argtypes = [vp, C.POINTER(vp)]
     L.pnx_sync.argtypes = [vp]
     L.pnx_stream.argtypes = [vp]
     L.pnx_stream.restype = vp
@@ -188,6 +190,12 @@ class Context:
         dh, dc = C.c_void_p(), C.c_void_p()
         self._ck(self._L.pnx_hist_device(self._h, C.byref(dh), C.byref(dc)))
         return dh.value, dc.value
+
+    def hist_enqueued(self) -> int:
+        """device pointer of the (G+1) u64 counters of the pass enqueued last (no wait)"""
+        d = C.c_void_p()
+        self._ck(self._L.pnx_hist_enqueued(self._h, C.byref(d)))
+        return d.value
 
     def sync(self):
         self._ck(self._L.pnx_sync(self._h))

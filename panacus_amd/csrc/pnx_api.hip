@@ -114,7 +114,14 @@ static int stage_results(pnx_ctx *ctx, Ticket *t) {
     }
     t->h_flags = (uint32_t *)t->h_block;
     t->h_hist = (uint64_t *)((char *)t->h_block + 8 * sizeof(uint32_t));
-    if (!t->done) PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+    if (t->done && t->done_blocking != ctx->blocking_sync) {
+        (void)hipEventDestroy(t->done);
+        t->done = nullptr;
+    }
+    if (!t->done) {
+        PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
+        t->done_blocking = ctx->blocking_sync;
+    }
     PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     PNX_HIP(ctx, hipEventRecord(t->done, ctx->stream));
     return PNX_OK;
@@ -161,6 +168,7 @@ static int settle_oldest(pnx_ctx *ctx) {
         // a younger pass (if any) ran with the same stale classification; it fails and is
         // re-run at its own settle
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->n_reruns += 1;
         int rc;
         if (need_build) {
             // cut the non-monotone paths into runs (tile route) or leave them to the scatter route
@@ -385,6 +393,13 @@ int pnx_sync(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist) {
+    if (!ctx || !d_hist) return PNX_EINVAL;
+    if (ctx->tk_count == 0) return ctx->fail(PNX_EINVAL, "no coverage pass is in flight");
+    *d_hist = ctx->tk[ctx->tk_next ^ 1].d_hist;
+    return PNX_OK;
+}
+
 int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
     if (!ctx) return PNX_EINVAL;
     PNX_HIP(ctx, hipSetDevice(ctx->device));
@@ -599,6 +614,7 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_run_paths = ctx->n_run_paths;
     out->n_scatter_paths = ctx->n_scatter_paths;
     out->n_runs = ctx->n_runs;
+    out->n_reruns = ctx->n_reruns;
     out->weighted = ctx->weighted ? 1 : 0;
     return PNX_OK;
 }
@@ -642,6 +658,9 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             if (value < 1 || value > 4096) return ctx->fail(PNX_EINVAL, "index_coarse must be in 1..4096");
             ctx->index_coarse = (uint32_t)value;
             ctx->index_valid = false;
+            return PNX_OK;
+        case PNX_CFG_BLOCKING_SYNC:
+            ctx->blocking_sync = value != 0;
             return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:
             ctx->keep_M_user = value != 0;

@@ -47,6 +47,7 @@ struct Ticket {
     uint32_t *h_flags = nullptr;
     uint64_t *h_hist = nullptr;
     hipEvent_t done = nullptr;
+    bool done_blocking = false;
     bool in_flight = false;
 };
 
@@ -120,6 +121,8 @@ struct pnx_ctx {
     bool want_M = false;        // the pass being enqueued also writes the presence matrix
     bool keep_M_user = false;   // PNX_CFG_KEEP_PRESENCE
     bool growth_needs_M = false;
+    uint64_t n_reruns = 0;
+    bool blocking_sync = false;  // PNX_CFG_BLOCKING_SYNC: wait for a pass asleep instead of spinning
 
     // ---- growth ----
     pnx::DevBuf d_perms, d_cov_thr, d_qtab, d_cmask, d_wplanes, d_growth_out, d_thr_meta;

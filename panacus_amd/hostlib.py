@@ -250,3 +250,10 @@ def pool_threads() -> int:
     L = load()
     L.pnh_pool_threads.restype = C.c_uint32
     return int(L.pnh_pool_threads())
+
+
+def usable_cpus() -> int:
+    """hardware threads of this process cut down to its cgroup CPU bandwidth quota"""
+    L = load()
+    L.pnh_usable_cpus.restype = C.c_uint32
+    return int(L.pnh_usable_cpus())
