@@ -671,6 +671,53 @@ def test_full_size_cfg3_properties():
         assert np.all(cnt2[1:] <= cnt[1:]) and np.all(2 * cnt2[1:].astype(np.int64) >= cnt[1:])
 
 
+def _pansyn_coverage_of(seed, nodes, n_nodes, n_paths):
+    """coverage (# paths holding the node) straight from the pansyn-v1 definition, vectorised"""
+    M = (1 << 64) - 1
+
+    def sm(x):  # splitmix64 on uint64 arrays (wrap-around arithmetic)
+        z = (x + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    from panacus_amd.pansyn import key
+    nodes = np.asarray(nodes, dtype=np.uint64)
+    thr = np.array([orc.lib().pansyn_node_thr(seed, int(i), n_paths) for i in nodes], dtype=np.uint64)
+    cov = np.zeros(len(nodes), dtype=np.int64)
+    with np.errstate(over="ignore"):
+        k5 = np.uint64(key(seed, 5))
+        for p in range(n_paths):
+            kp = sm(np.array([k5 + np.uint64(p)], dtype=np.uint64))[0]
+            h = sm(kp + nodes)
+            cov += ((h >> np.uint64(11)) < thr)
+    return cov
+
+
+def test_more_than_2_to_32_steps():
+    """S > 2^32 path steps (17 GB of CSR): every step index is 64-bit.  The coverage of sampled
+    nodes is checked against the generator's definition, the rest through the histogram."""
+    from panacus_amd import capi
+    n, p = 9_000_000, 1300
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(7, n, p)
+        assert c.info().n_steps > (1 << 32)
+        order = np.arange(p, dtype=np.uint32)
+        c.set_order(order, order, p)
+        cnt, h = c.hist()
+        assert int(h.sum()) == n and c.info().n_general_paths == 0
+        assert np.array_equal(np.bincount(cnt[1:], minlength=p + 1).astype(np.uint64), h)
+        rng = np.random.default_rng(5)
+        sample = np.unique(np.concatenate([rng.integers(1, n + 1, size=600), [1, 2047, 2048, 2049, n - 1, n]]))
+        exp = _pansyn_coverage_of(7, sample, n, p)
+        assert np.array_equal(cnt[sample].astype(np.int64), exp)
+        # the last path starts beyond step 2^32: dropping it lowers exactly its nodes by one
+        c.set_order(order[:-1], order[:-1], p - 1)
+        cnt2, h2 = c.hist()
+        d = cnt[1:].astype(np.int64) - cnt2[1:].astype(np.int64)
+        assert d.min() >= 0 and d.max() == 1 and int(h2.sum()) == n
+
+
 def test_full_size_cfg4_properties():
     """configs[3]: 10M nodes x 512 paths, permuted ordered growth.  For q = 0 every order ends at
     the same total, curves are non-decreasing, and the mean first step equals the mean group
