@@ -349,12 +349,35 @@ __device__ static inline void fold_steps(uint32_t *bm, const uint4 &v, uint64_t 
 }
 
 // stream the runs of group g that fall into this wave's tile (called right before g is folded)
+// 64 run descriptors held one per lane, so that walking the runs of a tile costs one batch of
+// loads per 64 runs instead of three dependent loads per run
+struct RunWindow {
+    uint64_t base;   // cursor of lane 0's descriptor (wave-uniform)
+    uint64_t start;  // per lane
+    uint32_t len, group;
+};
+
+__device__ static inline void run_window_load(const RunView &rv, RunWindow &w, uint64_t base, uint64_t end,
+                                              uint32_t lane) {
+    w.base = base;
+    const uint64_t i = base + lane;
+    const bool ok = i < end;
+    w.group = ok ? rv.group[i] : 0xFFFFFFFFu;
+    w.len = ok ? rv.len[i] : 0u;
+    w.start = ok ? rv.start[i] : 0ull;
+}
+
 template <uint32_t TILE>
-__device__ static inline void consume_runs(const RunView &rv, uint64_t &cursor, uint64_t cursor_end, uint32_t g,
-                                           const uint32_t *__restrict__ items, uint32_t *bm, uint32_t lane,
+__device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint64_t &cursor, uint64_t cursor_end,
+                                           uint32_t g, const uint32_t *__restrict__ items, uint32_t *bm, uint32_t lane,
                                            uint32_t tile_lo, uint32_t *flags) {
-    while (cursor < cursor_end && rv.group[cursor] == g) {
-        const uint64_t lo = rv.start[cursor], hi = lo + rv.len[cursor];
+    while (cursor < cursor_end) {
+        if (cursor - w.base >= 64) run_window_load(rv, w, cursor, cursor_end, lane);
+        const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(cursor - w.base));
+        if ((uint32_t)__builtin_amdgcn_readlane((int)w.group, k) != g) break;
+        const uint64_t lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w.start >> 32), k) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w.start, k);
+        const uint64_t hi = lo + (uint32_t)__builtin_amdgcn_readlane((int)w.len, k);
         uint32_t viol = 0;
         for (uint64_t base = lo & ~3ull; base < hi; base += 256ull * COVER_UNROLL) {
             uint4 v[COVER_UNROLL];
@@ -391,6 +414,12 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
     const uint32_t tile_lo = tile * TILE;
     uint64_t run_c = rv.tile_off ? rv.tile_off[tile] : 0;
     const uint64_t run_end = rv.tile_off ? rv.tile_off[tile + 1] : 0;
+    RunWindow run_w;
+    run_w.base = run_c;
+    run_w.start = 0;
+    run_w.len = 0;
+    run_w.group = 0xFFFFFFFFu;
+    if (run_c < run_end) run_window_load(rv, run_w, run_c, run_end, lane);
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
@@ -416,7 +445,7 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
 
     // fold the LDS bitmap of the finished group into the bit-sliced counters
     auto flush = [&](uint32_t g) {
-        if (run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
+        if (run_c < run_end) consume_runs<TILE>(rv, run_w, run_c, run_end, g, items, bm, lane, tile_lo, flags);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -545,6 +574,12 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     const uint32_t tile_lo = tile * TILE;
     uint64_t run_c = RUNS && rv.tile_off ? rv.tile_off[tile] : 0;
     const uint64_t run_end = RUNS && rv.tile_off ? rv.tile_off[tile + 1] : 0;
+    RunWindow run_w;
+    run_w.base = run_c;
+    run_w.start = 0;
+    run_w.len = 0;
+    run_w.group = 0xFFFFFFFFu;
+    if (RUNS && run_c < run_end) run_window_load(rv, run_w, run_c, run_end, lane);
 
 #pragma unroll
     for (int w = 0; w < WT; ++w) bm[w * BLOCK_WORDS + lane] = 0;
@@ -568,7 +603,7 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
 
     auto flush = [&](uint32_t g) {
-        if (RUNS && run_c < run_end) consume_runs<TILE>(rv, run_c, run_end, g, items, bm, lane, tile_lo, flags);
+        if (RUNS && run_c < run_end) consume_runs<TILE>(rv, run_w, run_c, run_end, g, items, bm, lane, tile_lo, flags);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
