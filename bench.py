@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--cover-variant", type=int, default=None)
     ap.add_argument("--index-coarse", type=int, default=None)
     ap.add_argument("--cover-waves", type=int, default=None)
+    ap.add_argument("--cover-split", type=int, default=None)
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
@@ -157,6 +158,8 @@ def main():
         ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
     if args.cover_waves is not None:
         ctx.config(capi.CFG_COVER_WAVES, args.cover_waves)
+    if args.cover_split is not None:
+        ctx.config(capi.CFG_COVER_SPLIT, args.cover_split)
     if args.cover_variant is not None:
         ctx.config(capi.CFG_COVER_VARIANT, args.cover_variant)
     ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)

@@ -183,6 +183,8 @@ enum {
     PNX_CFG_USE_WEIGHTS = 7,   /* weights were uploaded: 1 = count them (bp), 0 = count items (node) on the
                                   same resident CSR -- `hist -c all` uploads the graph once */
     PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the coverage kernel: 1, 2, 4 [default], 8 */
+    PNX_CFG_COVER_SPLIT = 9,   /* waves per item tile of the coverage kernel (each takes a group-aligned part of
+                                  the visiting order): 0 = chosen from #tiles and #CUs [default], 1, 2, 4, 8 */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */

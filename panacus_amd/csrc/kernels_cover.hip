@@ -322,6 +322,10 @@ constexpr int COVER_WAVES = 4;   // waves (= tiles) per workgroup
 constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane
 
 // runs of the run-route paths, sorted by (tile, group); see kernels_runs.hip
+struct SplitPts {  // cut points of the visiting order for the split coverage kernel
+    uint32_t k[9];
+};
+
 struct RunView {
     const uint64_t *start;
     const uint32_t *len;
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
-    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv) {
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv, SplitPts) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
     __shared__ uint32_t bm_all[COVER_WAVES][WT * BLOCK_WORDS];
 
@@ -554,26 +558,50 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 }
 
 // RUNS = false compiles the run consumption out: the kernel of graphs whose paths are all
-// tile-monotone keeps its low register count (occupancy 5+ waves/SIMD, all tiles resident)
-template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS>
+// tile-monotone keeps its low register count (occupancy 5+ waves/SIMD, all tiles resident).
+// SPLIT > 1 gives every tile SPLIT waves of one workgroup; each takes a contiguous, group-aligned
+// part of the visiting order (SplitPts, cut by the host) with private counters, and the first one
+// adds the others' bit-sliced counters (ripple-carry through LDS) before the write-out.  The
+// parallelism of the kernel is then tiles x SPLIT instead of tiles: 10 M items are only 4883
+// tiles for 6144 wave slots, and one wave per tile is a long serial chain of segments.
+template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1>
 __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
-    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv) {
+    uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv,
+    SplitPts sp) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
     constexpr int U = COVER_UNROLL;
+    constexpr int TPW = CW / SPLIT;  // tiles per workgroup
+    static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
     __shared__ uint32_t bm_all[CW][WT * BLOCK_WORDS];
+    __shared__ uint32_t xch[SPLIT > 1 ? TPW * (SPLIT - 1) * NPL * WT * 64 : 1];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t tile = blockIdx.x * CW + wave;
-    if (tile >= n_tiles) return;
+    const uint32_t part = SPLIT > 1 ? wave % SPLIT : 0;
+    const uint32_t tile_raw = blockIdx.x * TPW + wave / SPLIT;
+    if (SPLIT == 1 && tile_raw >= n_tiles) return;
+    const bool active = tile_raw < n_tiles;  // SPLIT > 1: idle waves still meet the barrier
+    const uint32_t tile = active ? tile_raw : n_tiles - 1;
+    const uint32_t k_lo = SPLIT > 1 ? (active ? sp.k[part] : 0u) : 0u;
+    const uint32_t k_hi = SPLIT > 1 ? (active ? sp.k[part + 1] : 0u) : n_ordered;
     uint32_t *bm = bm_all[wave];
     const uint32_t tile_lo = tile * TILE;
     uint64_t run_c = RUNS && rv.tile_off ? rv.tile_off[tile] : 0;
     const uint64_t run_end = RUNS && rv.tile_off ? rv.tile_off[tile + 1] : 0;
+    if (RUNS && SPLIT > 1 && part > 0 && k_lo < k_hi && run_c < run_end) {
+        // the tile's runs are sorted by group: start at the first run of this part's groups
+        const uint32_t g_first = ord_group[k_lo];
+        uint64_t a = run_c, b = run_end;
+        while (a < b) {
+            const uint64_t mid = (a + b) >> 1;
+            if (rv.group[mid] < g_first) a = mid + 1; else b = mid;
+        }
+        run_c = a;
+    }
     RunWindow run_w;
     run_w.base = run_c;
     run_w.start = 0;
@@ -668,15 +696,16 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
 
     // one extra iteration (k == n_ordered) closes the last group, so the flush code -- and the
     // run consumption inlined in it -- exists once in the kernel (register pressure)
-    uint32_t cur_g = n_ordered ? ord_group[0] : 0;
-    if (n_ordered) issue(0);
-    for (uint32_t k = 0; k <= n_ordered; ++k) {
-        const bool last = k == n_ordered;
+    const bool some = k_lo < k_hi;
+    uint32_t cur_g = some ? ord_group[k_lo] : 0;
+    if (some) issue(k_lo);
+    for (uint32_t k = k_lo; k <= k_hi; ++k) {
+        const bool last = k == k_hi;
         const uint32_t g = last ? 0xFFFFFFFFu : ord_group[k];
         // With runs the group change comes first: while the previous group is folded and its
         // runs are streamed only the prefetched segment is live, not a second copy of it.
         // Without runs the next segment is issued first, so its loads also cover the fold.
-        if (RUNS && g != cur_g && n_ordered) {
+        if (RUNS && g != cur_g && some) {
             flush(cur_g);
             cur_g = g;
         }
@@ -684,8 +713,8 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         const uint64_t lo = last ? 0 : n_lo, hi = last ? 0 : n_hi;
-        if (k + 1 < n_ordered) issue(k + 1);
-        if (!RUNS && g != cur_g && n_ordered) {
+        if (k + 1 < k_hi) issue(k + 1);
+        if (!RUNS && g != cur_g && some) {
             flush(cur_g);
             cur_g = g;
         }
@@ -715,6 +744,30 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         }
     }
 
+    if (SPLIT > 1) {
+        // parts 1.. hand their counters to part 0 of the tile
+        uint32_t *xt = xch + (size_t)(wave / SPLIT) * (SPLIT - 1) * NPL * WT * 64;
+        if (part > 0) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k)
+#pragma unroll
+                for (int w = 0; w < WT; ++w) xt[((part - 1) * NPL * WT + k * WT + w) * 64 + lane] = cnt[k][w];
+        }
+        __syncthreads();
+        if (part > 0 || !active) return;
+        for (int q = 0; q < SPLIT - 1; ++q) {
+#pragma unroll
+            for (int w = 0; w < WT; ++w) {
+                uint32_t carry = 0;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const uint32_t a = cnt[k][w], b = xt[(q * NPL * WT + k * WT + w) * 64 + lane];
+                    cnt[k][w] = a ^ b ^ carry;
+                    carry = (a & b) | (carry & (a ^ b));
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int w = 0; w < WT; ++w) {
         const uint32_t blk = tile * WT + w;
@@ -808,8 +861,16 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
         rv = RunView{(const uint64_t *)ctx->d_srun_start.p, (const uint32_t *)ctx->d_srun_len.p,
                      (const uint32_t *)ctx->d_srun_group.p, (const uint64_t *)ctx->d_run_tile_off.p};
     const bool has_runs = rv.tile_off != nullptr;
-    auto launch = [&](auto kern, int cw) {
-        const unsigned grid = (ctx->n_tiles + cw - 1) / cw;
+    SplitPts sp{};
+    auto launch = [&](auto kern, int cw, int split = 1) {
+        const unsigned tpw = (unsigned)(cw / split);
+        const unsigned grid = (ctx->n_tiles + tpw - 1) / tpw;
+        // group-aligned cut points of the visiting order
+        for (int j = 0; j <= split; ++j) {
+            uint64_t t = (uint64_t)ctx->n_ordered * j / split;
+            while (t > 0 && t < ctx->n_ordered && ctx->h_ord_group[t] == ctx->h_ord_group[t - 1]) ++t;
+            sp.k[j] = (uint32_t)t;
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_tile_idx.p,
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
@@ -817,14 +878,41 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
-                           (uint32_t *)ctx->d_countable.p, ctx->cur->d_flags, rv);
+                           (uint32_t *)ctx->d_countable.p, ctx->cur->d_flags, rv, sp);
     };
+    // waves per tile: enough waves to fill the chip about six times over
+    int split = 1;
+    if (WT == 1 && ctx->cover_variant == 2) {
+        split = ctx->cover_split;
+        if (split == 0) {
+            const uint64_t want = 6ull * (uint64_t)ctx->prop.multiProcessorCount * (has_runs ? 20 : 24);
+            split = 1;
+            while (split < 8 && (uint64_t)ctx->n_tiles * split < want && (uint32_t)split * 2 <= ctx->n_groups) split *= 2;
+        }
+    }
     switch (ctx->cover_variant) {
         case 1:
             if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, false, COVER_WAVES, true>, COVER_WAVES);
             else launch(k_tile_cover_pipe<NPL, WT, false, false, COVER_WAVES, true>, COVER_WAVES);
             break;
         case 2:
+            if constexpr (WT == 1) {
+                if (split > 1) {
+                    auto go = [&](auto k2, auto k4, auto k8) {
+                        if (split == 2) launch(k2, 4, 2);
+                        else if (split == 4) launch(k4, 4, 4);
+                        else launch(k8, 8, 8);
+                    };
+                    if (has_runs) {
+                        if (write_m) go(k_tile_cover_pipe<NPL, 1, true, true, 4, true, 2>, k_tile_cover_pipe<NPL, 1, true, true, 4, true, 4>, k_tile_cover_pipe<NPL, 1, true, true, 8, true, 8>);
+                        else go(k_tile_cover_pipe<NPL, 1, false, true, 4, true, 2>, k_tile_cover_pipe<NPL, 1, false, true, 4, true, 4>, k_tile_cover_pipe<NPL, 1, false, true, 8, true, 8>);
+                    } else {
+                        if (write_m) go(k_tile_cover_pipe<NPL, 1, true, true, 4, false, 2>, k_tile_cover_pipe<NPL, 1, true, true, 4, false, 4>, k_tile_cover_pipe<NPL, 1, true, true, 8, false, 8>);
+                        else go(k_tile_cover_pipe<NPL, 1, false, true, 4, false, 2>, k_tile_cover_pipe<NPL, 1, false, true, 4, false, 4>, k_tile_cover_pipe<NPL, 1, false, true, 8, false, 8>);
+                    }
+                    break;
+                }
+            }
             if (has_runs) {
                 if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4, true>, 4);
                 else launch(k_tile_cover_pipe<NPL, WT, false, true, 4, true>, 4);
