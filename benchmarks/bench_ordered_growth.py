@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pairs", default="1:0,2:0,1:0.5", help="coverage:quorum pairs")
+    ap.add_argument("--bp", action="store_true", help="count bp (node lengths as weights) instead of nodes")
     args = ap.parse_args()
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -44,7 +45,7 @@ def main():
     N, P, R = args.nodes, args.paths, args.orders
     pairs = [(int(a.split(':')[0]), float(a.split(':')[1])) for a in args.pairs.split(',')]
     ctx = capi.Context(local_rank)
-    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
+    ctx.set_csr_pansyn(args.seed, N, P, with_weights=args.bp)
     order = np.arange(P, dtype=np.uint32)
     ctx.set_order(order, order, P)
     cov = [coverage_abs(Threshold(ABSOLUTE, c), P) for c, _ in pairs]
@@ -84,7 +85,8 @@ def main():
         b_growth = R * (8 * P * n_words + 8 * len(pairs) * P)
         gms, gn = prof["growth"]
         print(json.dumps({
-            "metric": "ordered_growth_permuted", "workload": f"{R} random orders x {len(pairs)} threshold pairs, "
+            "metric": "ordered_growth_permuted", "count": "bp" if args.bp else "node",
+            "workload": f"{R} random orders x {len(pairs)} threshold pairs, "
             f"{N} nodes x {P} groups (BASELINE.json configs[3])", "n_gpus": world, "scaling": "strong",
             "seconds_per_call": dt, "orders_per_s": R / dt, "M_node_group_orders_per_s": N * P * R / dt / 1e6,
             "presence_pack_s": t_pack, "growth_kernels_ms_per_call_rank0": gms / max(args.reps, 1),

@@ -236,13 +236,13 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
     const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
     uint32_t blocks_per_chunk, const uint32_t *__restrict__ cmask, GrowthTabs tabs,
     const uint32_t *__restrict__ dmask /* T x G: 0 or ~0 */, uint32_t T,
-    const uint32_t *__restrict__ wplanes, uint32_t n_planes, unsigned long long *out) {
+    const uint32_t *__restrict__ weights, uint32_t n_items, unsigned long long *out) {
     constexpr int NA = N0 + NQ;
     constexpr int B = GROW_PREFETCH;  // ranks per batch
     extern __shared__ unsigned long long smem[];
     unsigned long long *acc = smem;                                           // [NA][G]
     uint32_t *stage_all = reinterpret_cast<uint32_t *>(acc + (size_t)NA * G);  // [waves][NA][B/2]
-    uint32_t *wp_all = stage_all + GROW_WAVES * NA * (B / 2);                  // [waves][planes][64]
+    uint32_t *wp_all = stage_all + GROW_WAVES * NA * (B / 2);                  // [waves][32][64] item weights
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -265,10 +265,46 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
             if (mi >= 0) mask[a] = cmask[((uint64_t)mi * n_blocks + blk) * BLOCK_WORDS + lane];
         }
         if (WEIGHTED) {
-            for (uint32_t p = 0; p < n_planes; ++p)
-                wp[p * 64 + lane] = wplanes[((uint64_t)p * n_blocks + blk) * BLOCK_WORDS + lane];
+            // weights of this block in presence layout: item (bit b, lane) at wp[b * 64 + lane]
+            for (uint32_t b = 0; b < 32; ++b) {
+                const uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
+                wp[b * 64 + lane] = (node >= 1 && node <= n_items) ? weights[node] : 0u;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        // bp: every accumulator is kept in DELTA form -- an item only changes res[j] at a rank
+        // where its bit of `val` flips (q = 0: once, when it is first seen; q > 0: where ok
+        // flips), so the weights of the few flipping items are added (or, wrapping, subtracted)
+        // with LDS atomics and a finishing kernel takes the running sums.
+        uint32_t prevv[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) prevv[qi] = 0;
+        auto wsum = [&](uint32_t m) {
+            unsigned long long d = 0;
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                d += wp[b * 64 + lane];
+            }
+            return d;
+        };
+        auto weighted_rank = [&](const uint32_t (&val)[NA > 0 ? NA : 1], uint32_t j) {
+#pragma unroll
+            for (int a = 0; a < N0; ++a) {
+                const unsigned long long d = wsum(val[a]);
+                if (d) atomicAdd(&acc[(size_t)a * G + j], d);
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                const uint32_t cur = val[N0 + qi];
+                const uint32_t up = cur & ~prevv[qi], dn = prevv[qi] & ~cur;
+                prevv[qi] = cur;
+                if (up | dn) {
+                    const unsigned long long d = wsum(up) - wsum(dn);
+                    if (d) atomicAdd(&acc[(size_t)(N0 + qi) * G + j], d);
+                }
+            }
+        };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
         uint32_t seen = 0;
         uint32_t sl[NQ > 0 ? NQ : 1][NPL1];
@@ -347,13 +383,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
                 for (int u = 0; u < B; ++u) {
                     uint32_t val[NA > 0 ? NA : 1];
                     rank_step(x[u], jb + u, val);
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const unsigned long long sv = weighted_popc(val[a], wp, n_planes, lane);
-                        const uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
-                        const uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
-                        if (lane == 63) atomicAdd(&acc[(size_t)a * G + jb + u], (unsigned long long)lo + ((unsigned long long)mi << 24));
-                    }
+                    weighted_rank(val, jb + u);
                 }
             }
         }
@@ -361,14 +391,11 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
             const uint32_t xv = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb] + voff));
             uint32_t val[NA > 0 ? NA : 1];
             rank_step(xv, jb, val);
+            if (WEIGHTED) {
+                weighted_rank(val, jb);
+            } else {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                if (WEIGHTED) {
-                    const unsigned long long sv = weighted_popc(val[a], wp, n_planes, lane);
-                    const uint32_t lo = wave_sum_to_lane63((uint32_t)(sv & 0xFFFFFFu));
-                    const uint32_t mi = wave_sum_to_lane63((uint32_t)((sv >> 24) & 0xFFFFFFu));
-                    if (lane == 63) atomicAdd(&acc[(size_t)a * G + jb], (unsigned long long)lo + ((unsigned long long)mi << 24));
-                } else {
+                for (int a = 0; a < NA; ++a) {
                     const uint32_t tot = wave_sum_to_lane63((uint32_t)__popc(val[a]));
                     if (lane == 63 && tot) atomicAdd(&acc[(size_t)a * G + jb], (unsigned long long)tot);
                 }
@@ -525,6 +552,8 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     while (bits < 32 && (G >> bits) != 0) ++bits;
     std::vector<uint32_t> is_delta(T, 0);
     for (uint32_t t : q0) is_delta[t] = 1;
+    if (ctx->weighted)  // bp: the fused kernel keeps the slack-form pairs in delta form too
+        for (uint32_t t : qslack) is_delta[t] = 1;
     prof_begin(ctx, PNX_K_GROWTH);
     {   // fused launches: up to GROW_Q0_MAX q == 0 pairs + up to 2 slack pairs each
         size_t i0 = 0, iq = 0;
@@ -549,7 +578,8 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
                 hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
                                    (const uint32_t *)ctx->d_M.p, NB, G, d_rowoff, R, bpc, (const uint32_t *)ctx->d_cmask.p,
-                                   tabs, d_dmask, T, d_wpl, n_planes, (unsigned long long *)ctx->d_growth_out.p);
+                                   tabs, d_dmask, T, (const uint32_t *)ctx->d_weights.p, ctx->n_items,
+                                   (unsigned long long *)ctx->d_growth_out.p);
             };
 #define PNX_GROW_NQ(NPL1, N0V, W)                                                                 \
     do {                                                                                          \
