@@ -230,7 +230,9 @@ struct GrowthTabs {
     uint32_t qq_slot[2];
 };
 
-template <int NPL1, int N0, int NQ, bool WEIGHTED>
+// WMODE: 0 = items count 1, 1 = weights below 2^16 (staged as u16: 4 KB of LDS per wave),
+//        2 = any u32 weights (8 KB per wave)
+template <int NPL1, int N0, int NQ, int WMODE>
 __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
     const uint32_t *__restrict__ M, uint32_t n_blocks, uint32_t G,
     const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
     const uint32_t *__restrict__ dmask /* T x G: 0 or ~0 */, uint32_t T,
     const uint32_t *__restrict__ weights, uint32_t n_items, unsigned long long *out) {
     constexpr int NA = N0 + NQ;
+    constexpr bool WEIGHTED = WMODE != 0;
     constexpr int B = GROW_PREFETCH;  // ranks per batch
     extern __shared__ unsigned long long smem[];
     unsigned long long *acc = smem;                                           // [NA][G]
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
     const uint32_t r = blockIdx.x % R, chunk = blockIdx.x / R;
     const uint32_t *ro = rowoff + (uint64_t)r * G;
     uint32_t *stage = stage_all + wave * NA * (B / 2);
-    uint32_t *wp = wp_all + (size_t)wave * WPLANES_MAX * 64;
+    uint32_t *wp = wp_all + (size_t)wave * (WMODE == 1 ? 1024 : 2048);
+    uint16_t *wp16 = reinterpret_cast<uint16_t *>(wp);
     const char *Mb = reinterpret_cast<const char *>(M);
 
     for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) acc[i] = 0;
@@ -268,7 +272,8 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
             // weights of this block in presence layout: item (bit b, lane) at wp[b * 64 + lane]
             for (uint32_t b = 0; b < 32; ++b) {
                 const uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
-                wp[b * 64 + lane] = (node >= 1 && node <= n_items) ? weights[node] : 0u;
+                const uint32_t wv = (node >= 1 && node <= n_items) ? weights[node] : 0u;
+                if (WMODE == 1) wp16[b * 64 + lane] = (uint16_t)wv; else wp[b * 64 + lane] = wv;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
@@ -279,30 +284,43 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
         uint32_t prevv[NQ > 0 ? NQ : 1];
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) prevv[qi] = 0;
-        auto wsum = [&](uint32_t m) {
-            unsigned long long d = 0;
-            while (m) {
-                const uint32_t b = (uint32_t)__builtin_ctz(m);
-                m &= m - 1;
-                d += wp[b * 64 + lane];
-            }
-            return d;
-        };
+        // one bit loop per rank for all accumulators (branch-free inside: the scalar unit is the
+        // scarce resource of this kernel), then one LDS atomic per accumulator that changed
         auto weighted_rank = [&](const uint32_t (&val)[NA > 0 ? NA : 1], uint32_t j) {
+            uint32_t up[NA > 0 ? NA : 1], dn[NA > 0 ? NA : 1];
+            uint32_t any = 0;
 #pragma unroll
             for (int a = 0; a < N0; ++a) {
-                const unsigned long long d = wsum(val[a]);
-                if (d) atomicAdd(&acc[(size_t)a * G + j], d);
+                up[a] = val[a];
+                dn[a] = 0;
+                any |= up[a];
             }
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const uint32_t cur = val[N0 + qi];
-                const uint32_t up = cur & ~prevv[qi], dn = prevv[qi] & ~cur;
+                up[N0 + qi] = cur & ~prevv[qi];
+                dn[N0 + qi] = prevv[qi] & ~cur;
                 prevv[qi] = cur;
-                if (up | dn) {
-                    const unsigned long long d = wsum(up) - wsum(dn);
-                    if (d) atomicAdd(&acc[(size_t)(N0 + qi) * G + j], d);
+                any |= up[N0 + qi] | dn[N0 + qi];
+            }
+            if (any) {
+                unsigned long long d[NA > 0 ? NA : 1];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) d[a] = 0;
+                uint32_t m = any;
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    const unsigned long long w = WMODE == 1 ? (uint32_t)wp16[b * 64 + lane] : wp[b * 64 + lane];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) {
+                        d[a] += ((up[a] >> b) & 1u) ? w : 0ull;
+                        if (a >= N0) d[a] -= ((dn[a] >> b) & 1u) ? w : 0ull;
+                    }
                 }
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    if (d[a]) atomicAdd(&acc[(size_t)a * G + j], d[a]);
             }
         };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
@@ -500,7 +518,9 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     const uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
     n_chunks = (NB + bpc - 1) / bpc;
     const uint64_t row_words = (uint64_t)NB * BLOCK_WORDS;
-    const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;
+    const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;  // comparison kernel
+    const bool w16 = ctx->weighted && ctx->n_wplanes <= 16;  // every weight < 2^16
+    const size_t wl_bytes = ctx->weighted ? (size_t)GROW_WAVES * 2048 * (w16 ? 2 : 4) : 0;                  // fused kernel
     const uint32_t *d_wpl = ctx->weighted ? (const uint32_t *)ctx->d_wplanes.p : nullptr;
     const uint32_t n_planes = ctx->weighted ? ctx->n_wplanes : 0;
 
@@ -569,7 +589,7 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                 tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
-            const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wp_bytes;
+            const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wl_bytes;
             if (shmem > 150 * 1024)
                 return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %d threshold pairs exceed the LDS accumulators",
                                  G, n0 + nq);
@@ -599,7 +619,9 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     } while (0)
 #define PNX_GROW_DISPATCH(NPL1)                                                                   \
     do {                                                                                          \
-        if (ctx->weighted) PNX_GROW_N0(NPL1, true); else PNX_GROW_N0(NPL1, false);                \
+        if (!ctx->weighted) PNX_GROW_N0(NPL1, 0);                                                 \
+        else if (w16) PNX_GROW_N0(NPL1, 1);                                                       \
+        else PNX_GROW_N0(NPL1, 2);                                                                \
     } while (0)
             // planes for s in [-G, G]: bits(G) + 1 (sign)
             if (bits + 1 <= 9) PNX_GROW_DISPATCH(9);

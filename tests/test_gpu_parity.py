@@ -276,6 +276,29 @@ def test_ordered_growth_vs_oracle(ctx, weighted):
         assert out1[0, t].tolist() == [int(x) for x in exp]
 
 
+def test_ordered_growth_wide_weights(ctx):
+    """weights >= 2^16 take the u32 staging of the growth kernel; sums exceed 2^32"""
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 12_000, 20
+    items, pre, lens = orc.pansyn(17, n, p)
+    w = (lens.astype(np.uint64) * 60_001 + 70_000).clip(0, 0xFFFFFFFF).astype(np.uint32)
+    w[0] = 0
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5), (1, 0.25)]
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), p) for c, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), p) for _, q in pairs])
+    perms = random_orders(3, 3, p)
+    out = ctx.ordered_growth(cov, qt, perms)
+    assert int(out.max()) > (1 << 32)
+    for r in range(3):
+        for t, (c, q) in enumerate(pairs):
+            exp = _oracle_growth(items, pre, n, p, pg, perms[r], c, q, w)
+            assert out[r, t].tolist() == [int(x) for x in exp], (r, c, q)
+
+
 def test_ordered_growth_many_groups(ctx):
     from panacus_amd.pansyn import random_orders
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
