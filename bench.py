@@ -203,10 +203,11 @@ def main():
             slot["ev"].synchronize()
             _, h_local = ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
             if int(ctx.info().n_reruns) != slot["reruns"]:
-                # the pass had to be run again (a path was reclassified): reduce the final counters
-                t = torch.from_numpy(h_local.view(np.int64)).to(f"cuda:{local_rank}")
-                dist.all_reduce(t)
-                return t.cpu().numpy().view(np.uint64)
+                # A pass that fails its verification is run again by the library, and its reduced
+                # counters would be stale.  It cannot happen here (pansyn paths are tile-monotone);
+                # a host for arbitrary graphs settles the first pass before it pipelines.  Failing
+                # is better than an unmatched collective.
+                raise RuntimeError("a coverage pass was re-run inside the pipelined multi-GPU loop")
             return slot["host"].numpy().view(np.uint64).copy()
         _, h = ctx.hist_fetch(want_countable=False)
         return h
