@@ -49,6 +49,15 @@ def main():
         out = subprocess.run([exe, "hist", "-c", "bp", gfa], stdout=subprocess.PIPE, check=True).stdout.decode()
         t_cli = time.perf_counter() - t0
         cli_hist = [int(r.split("\t")[1]) for r in out.split("\n") if r and r[0].isdigit()]
+        # the same with the binary cache: first run writes <gfa>.pcsr, second run reads it
+        t0 = time.perf_counter()
+        subprocess.run([exe, "hist", "-c", "bp", "--cache", gfa], stdout=subprocess.PIPE, check=True)
+        t_cli_cache_write = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out2 = subprocess.run([exe, "hist", "-c", "bp", "--cache", gfa], stdout=subprocess.PIPE, check=True).stdout.decode()
+        t_cli_cached = time.perf_counter() - t0
+        cached_hist = [int(r.split("\t")[1]) for r in out2.split("\n") if r and r[0].isdigit()]
+        cache_mb = os.path.getsize(gfa + ".pcsr") / 1e6
         # oracle: serial restatement from the same file
         t0 = time.perf_counter()
         og = orc.Graph(gfa)
@@ -59,12 +68,13 @@ def main():
         cov = orc.coverage(oitems, opre, opi, ogi, og.n_nodes)
         oh = orc.hist(cov, len(onames), og.node_lens)
         t_ocount = time.perf_counter() - t0
-        ok = h.tolist() == oh.tolist() == cli_hist
+        ok = h.tolist() == oh.tolist() == cli_hist == cached_hist
         print(json.dumps({
             "workload": f"hist -c bp on synthetic GFA, {n} nodes x {p} paths ({size / 1e6:.0f} MB text, {len(items)} steps)",
             "bit_exact_vs_oracle": ok, "synth_s": t_synth,
             "product_s": {"gfa_load_index": t_load, "csr_build": t_csr, "h2d_upload+order": t_h2d,
-                          "hist_first_call": t_hist_first, "hist_steady": t_hist, "cli_whole_process": t_cli},
+                          "hist_first_call": t_hist_first, "hist_steady": t_hist, "cli_whole_process": t_cli,
+                          "cli_cache_write_run": t_cli_cache_write, "cli_from_cache": t_cli_cached, "cache_MB": cache_mb},
             "oracle_s": {"parse_twice_serial": t_oparse, "coverage+hist_serial": t_ocount},
             "parse_MB_per_s": size / 1e6 / (t_load + t_csr),
         }))

@@ -21,7 +21,7 @@ namespace {
 
 struct Options {
     std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file, subset_file, exclude_file;
-    bool add_hist = false, by_sample = false, by_haplotype = false, total = false;
+    bool add_hist = false, by_sample = false, by_haplotype = false, total = false, cache = false;
     int threads = 0, device = 0;
     // synth
     uint64_t seed = 42;
@@ -44,6 +44,8 @@ const char *USAGE =
     "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
     "  -s, --subset <FILE>              count only the listed paths/groups (1-column list)\n"
     "  -e, --exclude <FILE>             drop the listed paths/groups and every node/edge/bp they touch\n"
+    "      --cache                      keep / reuse the parsed graph in <GFA_FILE>.pcsr (checked against the\n"
+    "                                   GFA's size, mtime and a content hash)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
     "      --device <N>                 GPU ordinal [0]\n"
     "  similarity prints the Jaccard table in group order (the reference's dendrogram ordering is not applied)\n"
@@ -61,6 +63,16 @@ struct Device {  // RAII over pnx_ctx
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     }
 };
+
+// GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
+std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges) {
+    if (!o.cache) return GraphStorage::from_gfa(o.file, index_edges);
+    const std::string cache_file = o.file + ".pcsr";
+    if (auto g = GraphStorage::from_cache(cache_file, o.file, index_edges)) return g;
+    auto g = GraphStorage::from_gfa(o.file, index_edges);
+    g->save_cache(cache_file, o.file);
+    return g;
+}
 
 std::vector<CountType> count_types(const std::string &c, bool allow_all) {
     std::string l;
@@ -81,11 +93,15 @@ struct Masking {  // -g/-S/-H grouping + -e list, needed to derive the ActiveTab
 };
 
 void upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk) {
-    ItemTable tab = g.item_table(ct);
+    ItemTable tab;
+    const ItemTableView view = g.item_table_view(ct, tab);
     const uint64_t n_items = g.number_of_items(ct);
     std::vector<uint8_t> excl;
-    if (!mk.exclude_file.empty()) excl = g.exclude_flags(ct, tab, mk.mode, mk.group_file, mk.exclude_file);
-    dev.check(pnx_set_csr(dev.ctx, tab.items.data(), tab.id_prefsum.data(), (uint32_t)g.path_segments().size(),
+    if (!mk.exclude_file.empty()) {
+        if (tab.id_prefsum.empty()) tab = g.item_table(ct);  // cached graph: the flags want an owned table
+        excl = g.exclude_flags(ct, tab, mk.mode, mk.group_file, mk.exclude_file);
+    }
+    dev.check(pnx_set_csr(dev.ctx, view.items, view.id_prefsum, (uint32_t)g.path_segments().size(),
                           (uint32_t)n_items, ct == COUNT_BP ? g.node_lens().data() : nullptr,
                           excl.empty() ? nullptr : excl.data()));
     dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
@@ -162,7 +178,7 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     std::vector<CountType> cts = count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
-    auto g = GraphStorage::from_gfa(o.file, edges);
+    auto g = load_graph(o, edges);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     Device dev(o.device);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
@@ -181,7 +197,7 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     std::vector<CountType> cts = growth_cmd ? std::vector<CountType>{COUNT_NODE} : count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
-    auto g = GraphStorage::from_gfa(o.file, edges);
+    auto g = load_graph(o, edges);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     Device dev(o.device);
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
@@ -225,7 +241,7 @@ std::string cmd_growth_from_hist(const Options &o, const std::string &cmdline) {
 std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
     CountType ct = count_types(o.count, false)[0];
-    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint32_t G = (uint32_t)order.groups.size();
     const uint32_t T = (uint32_t)tc.coverage.size();
@@ -258,7 +274,7 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
 // kodama dendrogram (:166-182), which is outside this path.
 std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     CountType ct = count_types(o.count, false)[0];
-    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const size_t G = order.groups.size();
     Device dev(o.device);
@@ -289,7 +305,7 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
 std::string cmd_table(const Options &o, const std::string &cmdline) {
     if (!o.total) throw std::runtime_error("table: only --total is supported (per-group multiplicities are outside the GPU path)");
     CountType ct = count_types(o.count, false)[0];
-    auto g = GraphStorage::from_gfa(o.file, ct == COUNT_EDGE);
+    auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint64_t n = g->number_of_items(ct);
     Device dev(o.device);
@@ -342,6 +358,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "--paths") o.paths = (uint32_t)std::strtoul(value("--paths").c_str(), nullptr, 10);
             else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
+            else if (a == "--cache") o.cache = true;
             else if (a == "--links") o.links = true;
             else if (a == "--sequences") o.sequences = true;
             else if (a == "-a" || a == "--hist" || a == "--total") o.add_hist = o.total = true;

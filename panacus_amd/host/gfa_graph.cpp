@@ -330,6 +330,16 @@ struct GraphStorage::Impl {
     bool has_edges = false;
     EdgeMap edges;
 
+    // filled instead of the fields above when the graph comes from a .pcsr cache
+    bool cached = false;                 // image = the mapped .pcsr file, the arrays below point into it
+    const uint32_t *c_items[2] = {nullptr, nullptr};    // [0] node, [1] edge ItemTable
+    const uint64_t *c_prefsum[2] = {nullptr, nullptr};
+    uint64_t c_n_items[2] = {0, 0};
+    const char *c_name_blob = nullptr;   // node names, concatenated
+    const uint64_t *c_name_off = nullptr;  // node_count + 1
+    const uint64_t *c_edge_uv = nullptr; // per edge id (0 unused): (u << 32) | v
+    const uint8_t *c_edge_oo = nullptr;  // per edge id: (o1 << 1) | o2
+
     uint32_t node_id(const char *p, size_t len) const {
         if (nice) {
             uint64_t v = 0;
@@ -544,11 +554,34 @@ struct Chunk {
 
 }  // namespace
 
+ItemTableView GraphStorage::item_table_view(CountType count, ItemTable &storage) const {
+    const Impl &im = *impl_;
+    if (im.cached) {
+        if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+        const int k = count == COUNT_EDGE ? 1 : 0;
+        return ItemTableView{im.c_items[k], im.c_prefsum[k], im.c_n_items[k]};
+    }
+    storage = item_table(count);
+    return ItemTableView{storage.items.data(), storage.id_prefsum.data(), storage.items.size()};
+}
+
 ItemTable GraphStorage::item_table(CountType count) const {
     const Impl &im = *impl_;
     const Image &s = im.image;
     const size_t P = paths_.size();
     if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    if (im.cached) {  // parallel copy out of the mapping (item_table_view() avoids even that)
+        const int k = count == COUNT_EDGE ? 1 : 0;
+        ItemTable t;
+        t.id_prefsum.assign(im.c_prefsum[k], im.c_prefsum[k] + P + 1);
+        t.items.resize(im.c_n_items[k]);
+        const size_t n = im.c_n_items[k], CH = 1 << 22;
+        ThreadPool::instance().parallel_for((n + CH - 1) / CH, [&](size_t c) {
+            const size_t b = c * CH, e = std::min(n, b + CH);
+            std::memcpy(t.items.data() + b, im.c_items[k] + b, (e - b) * sizeof(uint32_t));
+        });
+        return t;
+    }
     constexpr size_t CHUNK = 64 * 1024;
 
     std::vector<Chunk> chunks;
@@ -797,8 +830,246 @@ void read_path_list(const std::string &file, const std::vector<PathSegment> &pat
 
 }  // namespace
 
+// ---- .pcsr cache ---------------------------------------------------------------------------
+namespace {
+constexpr char PCSR_MAGIC[8] = {'P', 'C', 'S', 'R', '0', '0', '0', '2'};
+
+struct GfaKey {
+    uint64_t size = 0, mtime_ns = 0, hash = 0;
+};
+
+bool gfa_key(const std::string &gfa_file, GfaKey &k) {
+    struct stat st;
+    if (::stat(gfa_file.c_str(), &st) != 0) return false;
+    k.size = (uint64_t)st.st_size;
+    k.mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+    int fd = ::open(gfa_file.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    const size_t MiB = 1 << 20;
+    std::vector<char> buf(MiB);
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ k.size;
+    ssize_t got = ::pread(fd, buf.data(), MiB, 0);
+    if (got > 0) h = hash_bytes(buf.data(), (size_t)got) ^ (h << 1);
+    if (k.size > MiB) {
+        got = ::pread(fd, buf.data(), MiB, (off_t)(k.size - MiB));
+        if (got > 0) h ^= hash_bytes(buf.data(), (size_t)got) * 0xD6E8FEB86659FD93ull;
+    }
+    ::close(fd);
+    k.hash = h;
+    return true;
+}
+
+// every section is padded to 8 bytes, so that the arrays of a mapped cache are aligned
+struct Writer {
+    FILE *f;
+    bool ok = true;
+    void raw(const void *p, size_t n) {
+        if (n && std::fwrite(p, 1, n, f) != n) ok = false;
+        static const char zeros[8] = {0};
+        const size_t pad = (8 - n % 8) % 8;
+        if (pad && std::fwrite(zeros, 1, pad, f) != pad) ok = false;
+    }
+    void u64(uint64_t v) { raw(&v, 8); }
+    template <typename T>
+    void vec(const std::vector<T> &v) { arr(v.data(), v.size()); }
+    template <typename T>
+    void arr(const T *p, size_t n) {
+        u64(n);
+        raw(p, n * sizeof(T));
+    }
+    void str(const std::string &s) {
+        u64(s.size());
+        raw(s.data(), s.size());
+    }
+};
+
+// cursor over the mapped cache file
+struct Reader {
+    const char *p;
+    uint64_t remaining;
+    bool ok = true;
+    const char *take(uint64_t n) {
+        const uint64_t padded = (n + 7) & ~7ull;
+        if (!ok || padded > remaining) {
+            ok = false;
+            return nullptr;
+        }
+        const char *r = p;
+        p += padded;
+        remaining -= padded;
+        return r;
+    }
+    uint64_t u64() {
+        const char *q = take(8);
+        uint64_t v = 0;
+        if (q) std::memcpy(&v, q, 8);
+        return v;
+    }
+    template <typename T>
+    const T *view(uint64_t &n) {  // array that stays in the mapping
+        n = u64();
+        if (!ok || n > remaining / sizeof(T)) {
+            ok = false;
+            return nullptr;
+        }
+        return reinterpret_cast<const T *>(take(n * sizeof(T)));
+    }
+    template <typename T>
+    void vec(std::vector<T> &v) {
+        uint64_t n = 0;
+        const T *q = view<T>(n);
+        if (ok) v.assign(q, q + n);
+    }
+    void str(std::string &s) {
+        uint64_t n = 0;
+        const char *q = view<char>(n);
+        if (ok) s.assign(q, n);
+    }
+};
+}  // namespace
+
+void GraphStorage::save_cache(const std::string &cache_file, const std::string &gfa_file) const {
+    const Impl &im = *impl_;
+    GfaKey key;
+    if (!gfa_key(gfa_file, key)) throw std::runtime_error("cannot stat " + gfa_file);
+    const std::string tmp = cache_file + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    Writer w{f};
+    w.raw(PCSR_MAGIC, 8);
+    w.u64(key.size);
+    w.u64(key.mtime_ns);
+    w.u64(key.hash);
+    w.u64(node_count_);
+    w.u64(im.has_edges ? 1 : 0);
+    w.u64(edge_count_);
+    w.vec(node_lens_);
+    // node names
+    std::string blob;
+    std::vector<uint64_t> off(node_count_ + 1, 0);
+    for (uint64_t i = 1; i <= node_count_; ++i) {
+        blob += node_name((uint32_t)i);
+        off[i] = blob.size();
+    }
+    w.str(blob);
+    w.vec(off);
+    // path segments, field by field
+    w.u64(paths_.size());
+    for (const auto &p : paths_) {
+        w.str(p.sample);
+        w.u64((p.has_haplotype ? 1u : 0u) | (p.has_seqid ? 2u : 0u) | (p.has_start ? 4u : 0u) | (p.has_end ? 8u : 0u));
+        w.str(p.haplotype);
+        w.str(p.seqid);
+        w.u64(p.start);
+        w.u64(p.end);
+    }
+    const ItemTable nt = item_table(COUNT_NODE);
+    w.vec(nt.items);
+    w.vec(nt.id_prefsum);
+    if (im.has_edges) {
+        const ItemTable et = item_table(COUNT_EDGE);
+        w.vec(et.items);
+        w.vec(et.id_prefsum);
+        std::vector<uint64_t> uv(edge_count_ + 1, 0);
+        std::vector<uint8_t> oo(edge_count_ + 1, 0);
+        if (im.cached) {
+            uv.assign(im.c_edge_uv, im.c_edge_uv + edge_count_ + 1);
+            oo.assign(im.c_edge_oo, im.c_edge_oo + edge_count_ + 1);
+        } else {
+            for (const auto &sl : im.edges.tab)
+                if (sl.id) {
+                    uv[sl.id] = sl.uv;
+                    oo[sl.id] = sl.oo;
+                }
+        }
+        w.vec(uv);
+        w.vec(oo);
+    }
+    const bool ok = w.ok && std::fclose(f) == 0;
+    if (!ok || std::rename(tmp.c_str(), cache_file.c_str()) != 0) {
+        std::remove(tmp.c_str());
+        throw std::runtime_error("cannot write " + cache_file);
+    }
+}
+
+std::unique_ptr<GraphStorage> GraphStorage::from_cache(const std::string &cache_file, const std::string &gfa_file,
+                                                       bool need_edges) {
+    GfaKey key;
+    if (!gfa_key(gfa_file, key)) return nullptr;
+    struct stat st;
+    if (::stat(cache_file.c_str(), &st) != 0 || st.st_size < 64) return nullptr;
+    {   // header check before the whole file is mapped
+        FILE *f = std::fopen(cache_file.c_str(), "rb");
+        if (!f) return nullptr;
+        char head[32];
+        const size_t got = std::fread(head, 1, 32, f);
+        std::fclose(f);
+        uint64_t k[3];
+        std::memcpy(k, head + 8, 24);
+        if (got != 32 || std::memcmp(head, PCSR_MAGIC, 8) != 0 || k[0] != key.size || k[1] != key.mtime_ns ||
+            k[2] != key.hash)
+            return nullptr;
+    }
+    std::unique_ptr<GraphStorage> g(new GraphStorage());
+    Impl &im = *g->impl_;
+    try {
+        im.image.open(cache_file);  // mmap, populated
+    } catch (const std::exception &) {
+        return nullptr;
+    }
+    Reader r{im.image.data(), im.image.size()};
+    r.take(32);
+    im.cached = true;
+    g->node_count_ = r.u64();
+    im.has_edges = r.u64() != 0;
+    g->edge_count_ = r.u64();
+    if (!r.ok || (need_edges && !im.has_edges)) return nullptr;
+    r.vec(g->node_lens_);
+    uint64_t n_blob = 0, n_off = 0;
+    im.c_name_blob = r.view<char>(n_blob);
+    im.c_name_off = r.view<uint64_t>(n_off);
+    const uint64_t P = r.u64();
+    if (!r.ok || P > r.remaining / 8) return nullptr;
+    g->paths_.resize(P);
+    for (uint64_t k = 0; k < P && r.ok; ++k) {
+        PathSegment &p = g->paths_[k];
+        r.str(p.sample);
+        const uint64_t fl = r.u64();
+        p.has_haplotype = fl & 1;
+        p.has_seqid = fl & 2;
+        p.has_start = fl & 4;
+        p.has_end = fl & 8;
+        r.str(p.haplotype);
+        r.str(p.seqid);
+        p.start = r.u64();
+        p.end = r.u64();
+    }
+    uint64_t n_pre[2] = {0, 0}, n_uv = 0, n_oo = 0;
+    im.c_items[0] = r.view<uint32_t>(im.c_n_items[0]);
+    im.c_prefsum[0] = r.view<uint64_t>(n_pre[0]);
+    if (im.has_edges) {
+        im.c_items[1] = r.view<uint32_t>(im.c_n_items[1]);
+        im.c_prefsum[1] = r.view<uint64_t>(n_pre[1]);
+        im.c_edge_uv = r.view<uint64_t>(n_uv);
+        im.c_edge_oo = r.view<uint8_t>(n_oo);
+    }
+    bool shapes = r.ok && g->node_lens_.size() == g->node_count_ + 1 && n_off == g->node_count_ + 1 &&
+                  n_pre[0] == P + 1 &&
+                  (!im.has_edges || (n_pre[1] == P + 1 && n_uv == g->edge_count_ + 1 && n_oo == g->edge_count_ + 1));
+    if (shapes) {
+        shapes = im.c_name_off[g->node_count_] <= n_blob && im.c_prefsum[0][P] == im.c_n_items[0] &&
+                 (!im.has_edges || im.c_prefsum[1][P] == im.c_n_items[1]);
+    }
+    if (!shapes) return nullptr;
+    return g;
+}
+
 std::string GraphStorage::node_name(uint32_t id) const {
     const Impl &im = *impl_;
+    if (im.cached) {
+        if (id == 0 || id > node_count_) throw std::runtime_error("node id out of range");
+        return std::string(im.c_name_blob + im.c_name_off[id - 1], im.c_name_off[id] - im.c_name_off[id - 1]);
+    }
     if (id == 0 || id > im.node_names.size()) throw std::runtime_error("node id out of range");
     const Span sp = im.node_names[id - 1];
     return std::string(im.image.data() + sp.b, sp.e - sp.b);
@@ -808,6 +1079,14 @@ std::vector<std::string> GraphStorage::edge_labels() const {
     const Impl &im = *impl_;
     if (!im.has_edges) throw std::runtime_error("edge labels need the edge index");
     std::vector<std::string> out(edge_count_ + 1);
+    if (im.cached) {
+        for (uint64_t id = 1; id <= edge_count_; ++id) {
+            const uint32_t u = (uint32_t)(im.c_edge_uv[id] >> 32), v = (uint32_t)im.c_edge_uv[id];
+            const char o1 = (im.c_edge_oo[id] >> 1) & 1 ? '<' : '>', o2 = im.c_edge_oo[id] & 1 ? '<' : '>';
+            out[id] = std::string(1, o1) + node_name(u) + std::string(1, o2) + node_name(v);
+        }
+        return out;
+    }
     for (const auto &sl : im.edges.tab) {
         if (!sl.id) continue;
         const uint32_t u = (uint32_t)(sl.uv >> 32), v = (uint32_t)sl.uv;

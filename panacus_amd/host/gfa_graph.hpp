@@ -42,6 +42,12 @@ struct ItemTable {  // src/util.rs:81-93, u32 items for the device
     std::vector<uint64_t> id_prefsum;  // n_paths + 1
 };
 
+struct ItemTableView {  // an ItemTable by pointers: into a mapped .pcsr cache, or into `storage`
+    const uint32_t *items = nullptr;
+    const uint64_t *id_prefsum = nullptr;
+    uint64_t n_steps = 0;
+};
+
 struct PathOrder {  // result of GraphMask::get_path_order + group-id assignment
     std::vector<uint32_t> path_idx, group_id;
     std::vector<std::string> groups;
@@ -60,6 +66,8 @@ public:
 
     // parse_gfa_paths_walks[_multiple] without subset/exclude
     ItemTable item_table(CountType count) const;
+    // the same without a copy when the graph comes from a cache; `storage` holds the table otherwise
+    ItemTableView item_table_view(CountType count, ItemTable &storage) const;
 
     // GraphMask::load_groups + get_path_order (+ optional -O order file, -s subset list,
     // -e exclude list; lists name whole paths or groups, coordinate columns are rejected)
@@ -76,6 +84,16 @@ public:
     // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id
     std::string node_name(uint32_t id) const;
     std::vector<std::string> edge_labels() const;  // [0] unused
+
+    // ---- binary cache of the parsed graph (".pcsr") ---------------------------
+    // Everything the commands need from the GFA -- node lengths and names, path names, the node
+    // ItemTable and (if the edge index was built) the edge ItemTable and edge ends -- in one
+    // file that is read back with a few large reads instead of a parse.  The cache is tied to
+    // the GFA by its size, modification time and a hash of its first and last MiB.
+    void save_cache(const std::string &cache_file, const std::string &gfa_file) const;
+    // nullptr when the file is missing, stale, of another version, or lacks the edge index asked for
+    static std::unique_ptr<GraphStorage> from_cache(const std::string &cache_file, const std::string &gfa_file,
+                                                    bool need_edges);
 
     struct Impl;
 

@@ -29,6 +29,25 @@ void *pnh_graph_load(const char *gfa_file, int index_edges) {
         return nullptr;
     }
 }
+// .pcsr cache (gfa_graph.hpp): 0 on success
+int pnh_graph_save_cache(const void *g, const char *cache_file, const char *gfa_file) {
+    try {
+        static_cast<const pnh::GraphStorage *>(g)->save_cache(cache_file, gfa_file);
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return 1;
+    }
+}
+// NULL when the cache is missing, stale or lacks the edge index asked for
+void *pnh_graph_from_cache(const char *cache_file, const char *gfa_file, int need_edges) {
+    try {
+        return pnh::GraphStorage::from_cache(cache_file, gfa_file, need_edges != 0).release();
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return nullptr;
+    }
+}
 void pnh_graph_free(void *g) { delete static_cast<pnh::GraphStorage *>(g); }
 uint64_t pnh_graph_n_nodes(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_count(); }
 uint64_t pnh_graph_n_edges(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->edge_count(); }

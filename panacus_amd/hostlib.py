@@ -93,6 +93,9 @@ def _bind_graph(L):
     L.pnh_graph_load.restype = C.c_void_p
     L.pnh_graph_load.argtypes = [C.c_char_p, C.c_int]
     L.pnh_graph_free.argtypes = [C.c_void_p]
+    L.pnh_graph_save_cache.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.pnh_graph_from_cache.restype = C.c_void_p
+    L.pnh_graph_from_cache.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     for n in ("pnh_graph_n_nodes", "pnh_graph_n_edges", "pnh_graph_n_paths"):
         getattr(L, n).restype = C.c_uint64
         getattr(L, n).argtypes = [C.c_void_p]
@@ -119,6 +122,22 @@ class GfaGraph:
         self._h = self._L.pnh_graph_load(os.fsencode(gfa_file), int(index_edges))
         if not self._h:
             raise ValueError(self._L.pnh_last_error().decode())
+
+    @classmethod
+    def from_cache(cls, cache_file: str, gfa_file: str, need_edges: bool = False):
+        """the graph from a .pcsr cache, or None when the cache is missing / stale / without edges"""
+        L = load()
+        _bind_graph(L)
+        h = L.pnh_graph_from_cache(os.fsencode(cache_file), os.fsencode(gfa_file), int(need_edges))
+        if not h:
+            return None
+        g = cls.__new__(cls)
+        g._L, g._h = L, h
+        return g
+
+    def save_cache(self, cache_file: str, gfa_file: str):
+        if self._L.pnh_graph_save_cache(self._h, os.fsencode(cache_file), os.fsencode(gfa_file)):
+            raise OSError(self._L.pnh_last_error().decode())
 
     def close(self):
         if getattr(self, "_h", None):

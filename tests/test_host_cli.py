@@ -256,3 +256,23 @@ def test_cli_table_total_chrM(golden, golden_dir):
     assert all(r[0][0] in "<>" for r in rows[1:])
     rc, out, err = hl.run_cli(["table", "-S", gfa])
     assert rc == 1 and "--total" in err
+
+
+@pytest.mark.gpu
+def test_cli_cache_gives_identical_tables(golden_dir, tmp_path):
+    import shutil
+    gfa = str(tmp_path / "chrM_test.gfa")
+    shutil.copy(os.path.join(golden_dir, "chrM_test.gfa"), gfa)
+    for args in (["hist", "-S", "-c", "all"], ["histgrowth", "-H", "-c", "edge", "-l", "1,2", "-q", "0,0.5"],
+                 ["ordered-histgrowth", "-S", "-c", "bp"], ["table", "--total", "-S", "-c", "edge"],
+                 ["similarity", "-S", "-c", "bp"]):
+        rc, plain, err = hl.run_cli(args + [gfa])
+        assert rc == 0, err
+        if os.path.exists(gfa + ".pcsr"):
+            os.remove(gfa + ".pcsr")
+        rc, first, err = hl.run_cli(args + ["--cache", gfa])   # parses and writes the cache
+        assert rc == 0, err
+        assert os.path.exists(gfa + ".pcsr")
+        rc, second, err = hl.run_cli(args + ["--cache", gfa])  # served from the cache
+        assert rc == 0, err
+        assert _body(plain) == _body(first) == _body(second)

@@ -195,3 +195,61 @@ def test_subset_and_exclude_lists_match_oracle(golden_dir, tmp_path):
         bed = tmp_path / "bed.txt"
         bed.write_text(names[0] + "\t0\t100\n")
         a.path_order(hl.GROUP_PATHID, None, None, str(bed), None)
+
+
+def _same_graph(a, b, edges):
+    assert (a.n_nodes, a.n_paths) == (b.n_nodes, b.n_paths)
+    assert np.array_equal(a.node_lens, b.node_lens)
+    assert a.path_names() == b.path_names()
+    for ct in (hl.NODE, hl.EDGE) if edges else (hl.NODE,):
+        ia, pa = a.item_table(ct)
+        ib, pb = b.item_table(ct)
+        assert np.array_equal(pa, pb) and np.array_equal(ia, ib)
+    for mode in (hl.GROUP_PATHID, hl.GROUP_SAMPLE, hl.GROUP_HAPLOTYPE):
+        pa, ga, na = a.path_order(mode)
+        pb, gb, nb = b.path_order(mode)
+        assert na == nb and np.array_equal(pa, pb) and np.array_equal(ga, gb)
+
+
+@pytest.mark.parametrize("name", FIX)
+def test_pcsr_cache_roundtrip(golden_dir, tmp_path, name):
+    """the binary cache gives back exactly the parsed graph, and is refused when it is stale"""
+    import shutil
+    gfa = str(tmp_path / name)
+    shutil.copy(os.path.join(golden_dir, name), gfa)
+    cache = gfa + ".pcsr"
+    g = hl.GfaGraph(gfa, index_edges=True)
+    assert hl.GfaGraph.from_cache(cache, gfa, True) is None  # no cache yet
+    g.save_cache(cache, gfa)
+    c = hl.GfaGraph.from_cache(cache, gfa, True)
+    assert c is not None and c.n_edges == g.n_edges
+    _same_graph(c, g, edges=True)
+    # a cache written without the edge index does not serve an edge request
+    g2 = hl.GfaGraph(gfa, index_edges=False)
+    g2.save_cache(cache, gfa)
+    assert hl.GfaGraph.from_cache(cache, gfa, True) is None
+    c2 = hl.GfaGraph.from_cache(cache, gfa, False)
+    _same_graph(c2, g2, edges=False)
+    # the GFA changes (content and mtime): the cache is stale
+    with open(gfa, "a") as f:
+        f.write("S\textra\tACGT\n")
+    os.utime(gfa, ns=(1, 1))
+    assert hl.GfaGraph.from_cache(cache, gfa, False) is None
+    # a truncated or foreign file is not a cache
+    with open(cache, "wb") as f:
+        f.write(b"PCSR0002" + b"\x00" * 11)
+    assert hl.GfaGraph.from_cache(cache, gfa, False) is None
+
+
+def test_pcsr_cache_cli_growth_from_cache(golden_dir, tmp_path):
+    """`--cache` writes <gfa>.pcsr on the first run (checked here without a GPU through the graph API)"""
+    import shutil
+    gfa = str(tmp_path / "t_groups.gfa")
+    shutil.copy(os.path.join(golden_dir, "t_groups.gfa"), gfa)
+    g = hl.GfaGraph(gfa, index_edges=False)
+    g.save_cache(gfa + ".pcsr", gfa)
+    c = hl.GfaGraph.from_cache(gfa + ".pcsr", gfa, False)
+    items, pre = c.item_table(hl.NODE)
+    pi, gi, names = c.path_order(hl.GROUP_PATHID)
+    cov = orc.coverage(items.astype(np.uint64), pre, pi.astype(np.uint64), gi.astype(np.uint64), c.n_nodes)
+    assert orc.hist(cov, len(names)).tolist() == [5, 0, 10, 0, 0, 0, 0]
