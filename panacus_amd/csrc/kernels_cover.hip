@@ -565,7 +565,7 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 // parallelism of the kernel is then tiles x SPLIT instead of tiles: 10 M items are only 4883
 // tiles for 6144 wave slots, and one wave per tile is a long serial chain of segments.
 template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1>
-__global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
+__global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
     const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
@@ -674,34 +674,92 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
     };
 
     const uint64_t brow = (uint64_t)n_tiles + 1;
-    // prefetch state of the NEXT entry
+    // ---- window of 64 order entries, one per lane -------------------------------------------
+    // Entry k = win_base + lane: its segment [w_lo, w_lo + w_len) of this tile and its group.
+    // The dependent loads (order -> path -> boundary pair) are paid once per 64 entries instead of
+    // once per entry, and only the INTERESTING entries -- a non-empty segment or the first entry
+    // of a group -- are visited at all: in an assembly-shaped pangenome (thousands of contig
+    // paths, each touching a few per cent of the tiles) almost every (path, tile) pair is empty.
+    uint64_t w_lo = 0;
+    uint32_t w_len = 0, w_g = 0xFFFFFFFFu;
+    uint32_t win_base = k_lo;
+    uint64_t todo = 0;  // interesting entries of the window that are still to be visited
+    auto load_window = [&](uint32_t base, uint32_t prev_group) {
+        win_base = base;
+        const uint32_t k = base + lane;
+        const bool in = k < k_hi;
+        const uint32_t p = in ? ord_path[k] : 0u;
+        w_g = in ? ord_group[k] : 0xFFFFFFFFu;
+        uint64_t ba = 0, bb = 0;
+        if (in && path_class[p] == 0) {
+            ba = B[(uint64_t)p * brow + tile];
+            bb = B[(uint64_t)p * brow + tile + 1];
+        }
+        w_lo = ba < bb ? ba : bb;
+        const uint64_t len = (ba < bb ? bb : ba) - w_lo;
+        w_len = (uint32_t)len;
+        if (len > 0xFFFFFFFFull) {  // not a segment this kernel can stream: hand the path to the general routes
+            w_len = 0;
+            path_class[p] = 1;
+            atomicAdd(&flags[0], 1u);
+        }
+        uint32_t pg = __shfl_up(w_g, 1);
+        if (lane == 0) pg = prev_group;
+        todo = __ballot(in && (w_len != 0 || w_g != pg));
+    };
+    // scalars of one entry out of the window
+    auto entry = [&](uint32_t k, uint64_t &lo, uint64_t &hi, uint32_t &g) {
+        const uint32_t i = __builtin_amdgcn_readfirstlane(k - win_base);
+        lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_lo >> 32), i) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_lo, i);
+        hi = lo + (uint32_t)__builtin_amdgcn_readlane((int)w_len, i);
+        g = (uint32_t)__builtin_amdgcn_readlane((int)w_g, i);
+    };
+    // next interesting entry at or after the window position; false when the part is exhausted
+    auto next_entry = [&](uint32_t &k) {
+        while (todo == 0) {
+            const uint32_t nb = win_base + 64;
+            if (nb >= k_hi || nb < win_base) return false;
+            load_window(nb, (uint32_t)__builtin_amdgcn_readlane((int)w_g, 63));
+        }
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        k = win_base + i;
+        return true;
+    };
+
+    // prefetch state of the NEXT interesting entry
     uint4 nxt[U];
-    uint64_t n_lo = 0, n_hi = 0;
-    bool n_act = false;
-    auto issue = [&](uint32_t k) {
-        const uint32_t p = ord_path[k];
-        n_act = path_class[p] == 0;
-        const uint64_t ba = B[(uint64_t)p * brow + tile], bb = B[(uint64_t)p * brow + tile + 1];
-        n_lo = ba < bb ? ba : bb;
-        n_hi = ba < bb ? bb : ba;
-        if (!n_act) n_hi = n_lo;
-        const uint64_t base = n_lo & ~3ull;
+    auto issue = [&](uint64_t lo, uint64_t hi) {
+        const uint64_t base = lo & ~3ull;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
             nxt[u] = make_uint4(0, 0, 0, 0);
-            if (j < n_hi) nxt[u] = load_steps<NT>(items + j);
+            if (j < hi) nxt[u] = load_steps<NT>(items + j);
         }
     };
 
-    // one extra iteration (k == n_ordered) closes the last group, so the flush code -- and the
-    // run consumption inlined in it -- exists once in the kernel (register pressure)
+    // One extra (sentinel) iteration closes the last group, so the flush code -- and the run
+    // consumption inlined in it -- exists once in the kernel (register pressure).
     const bool some = k_lo < k_hi;
-    uint32_t cur_g = some ? ord_group[k_lo] : 0;
-    if (some) issue(k_lo);
-    for (uint32_t k = k_lo; k <= k_hi; ++k) {
-        const bool last = k == k_hi;
-        const uint32_t g = last ? 0xFFFFFFFFu : ord_group[k];
+    uint32_t k = k_lo, cur_g = 0;
+    uint64_t e_lo = 0, e_hi = 0;
+    uint32_t e_g = 0xFFFFFFFFu;
+    bool have = false;
+    if (some) {
+        load_window(k_lo, 0xFFFFFFFFu);  // the first entry of the part always counts as a group change
+        have = next_entry(k);
+        if (have) {
+            entry(k, e_lo, e_hi, e_g);
+            cur_g = e_g;
+            issue(e_lo, e_hi);
+        }
+    }
+    for (;;) {
+        const bool last = !have;
+        const uint32_t g = last ? 0xFFFFFFFFu : e_g;
+        const uint32_t k_cur = k;
         // With runs the group change comes first: while the previous group is folded and its
         // runs are streamed only the prefetched segment is live, not a second copy of it.
         // Without runs the next segment is issued first, so its loads also cover the fold.
@@ -712,8 +770,14 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
         uint4 cur[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        const uint64_t lo = last ? 0 : n_lo, hi = last ? 0 : n_hi;
-        if (k + 1 < k_hi) issue(k + 1);
+        const uint64_t lo = last ? 0 : e_lo, hi = last ? 0 : e_hi;
+        if (!last) {
+            have = next_entry(k);
+            if (have) {
+                entry(k, e_lo, e_hi, e_g);
+                issue(e_lo, e_hi);
+            }
+        }
         if (!RUNS && g != cur_g && some) {
             flush(cur_g);
             cur_g = g;
@@ -737,11 +801,12 @@ __global__ __launch_bounds__(CW * 64) void k_tile_cover_pipe(
             }
             if (__any(viol)) {
                 if (lane == 0) {
-                    path_class[ord_path[k]] = 1;
+                    path_class[ord_path[k_cur]] = 1;
                     atomicAdd(&flags[0], 1u);
                 }
             }
         }
+        if (last) break;
     }
 
     if (SPLIT > 1) {

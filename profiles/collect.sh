@@ -35,6 +35,7 @@ timeout 900 python $REPO/benchmarks/bench_ordered_growth.py --reps 2 --bp > $OUT
 timeout 600 python $REPO/benchmarks/bench_gfa_end_to_end.py 1000000 64 > $OUT/${R}_gfa_end_to_end.jsonl 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_gfa_end_to_end.py 4000000 128 >> $OUT/${R}_gfa_end_to_end.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_run_route.py > $OUT/${R}_run_route_bench.json 2>/dev/null
+timeout 900 python $REPO/benchmarks/bench_contig_paths.py > $OUT/${R}_contig_paths_bench.json 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py > $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 rm -rf /tmp/p_s; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_s -o sim -- \
