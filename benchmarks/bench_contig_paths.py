@@ -43,6 +43,7 @@ def main():
     grp = np.unique(grp, return_inverse=True)[1].astype(np.uint32)
     n_groups = int(grp.max()) + 1
     ctx = capi.Context(0)
+    ctx.config(capi.CFG_CACHE_INDEX, 0)  # a command line run builds the index once per pass: time it
     ctx.set_csr(items, pre, N)
     ctx.set_order(order, grp, n_groups)
     cnt, h = ctx.hist()

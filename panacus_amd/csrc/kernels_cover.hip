@@ -85,11 +85,10 @@ __device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a,
 // Whatever the data, [lo, hi) only ever shrinks around the answer of a monotone path and the
 // search ends in a binary search of what is left, so the result is always inside the bracket.
 __device__ static inline uint64_t locate_boundary(const uint32_t *__restrict__ items, uint64_t lo, uint64_t hi,
-                                                  bool asc, uint64_t key, uint64_t num, uint64_t den,
-                                                  uint32_t tile_items, int max_probes) {
+                                                  bool asc, uint64_t key, double frac /* of the bracket before the boundary */,
+                                                  float dens /* steps per id inside the bracket */, int max_probes) {
     if (lo >= hi) return lo;
-    uint64_t pos = lo + (uint64_t)((double)(hi - lo) * (double)num / (double)den);
-    const float dens = (float)(hi - lo) / ((float)den * (float)tile_items);  // steps per id
+    uint64_t pos = lo + (uint64_t)((double)(hi - lo) * frac);
     for (int it = 0; it < max_probes && lo < hi; ++it) {
         if (pos >= hi) pos = hi - 1;
         if (pos < lo) pos = lo;
@@ -157,9 +156,20 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
     // inside the whole path as one bracket
     if (t == 0) *out = asc ? s : e;
     else if (t == n_tiles) *out = asc ? e : s;
-    else
-        *out = locate_boundary(items, s, e, asc, (uint64_t)t * tile_items, asc ? (uint64_t)t : (uint64_t)(n_tiles - t),
-                               (uint64_t)n_tiles, tile_items, 6);
+    else {
+        // the path's own id range gives the first guess and the density: a contig-like path covers
+        // a few per cent of the id space, and the tiles outside its range need no probe at all
+        const uint64_t key = (uint64_t)t * tile_items;
+        const uint64_t id_a = items[s], id_b = items[e - 1];  // first and last id (asc: smallest, largest)
+        const uint64_t id_min = asc ? id_a : id_b, id_max = asc ? id_b : id_a;
+        if (key <= id_min) *out = asc ? s : e;       // no step lies before tile t (asc) / all do (desc)
+        else if (key > id_max) *out = asc ? e : s;
+        else {
+            const double range = (double)(id_max - id_min + 1);
+            const double below = (double)(key - id_min) / range;  // share of the ids that are < key
+            *out = locate_boundary(items, s, e, asc, key, asc ? below : 1.0 - below, (float)((double)(e - s) / range), 6);
+        }
+    }
 }
 
 // K0 pass B: the boundaries in between, by interpolation inside the bracket of the two
@@ -200,8 +210,9 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
         row[t] = asc ? lo : hi;
         return;
     }
-    row[t] = locate_boundary(items, lo, hi, asc, (uint64_t)t * tile_items, asc ? (uint64_t)(t - t0) : (uint64_t)(t1 - t),
-                             (uint64_t)(t1 - t0), tile_items, 4);
+    row[t] = locate_boundary(items, lo, hi, asc, (uint64_t)t * tile_items,
+                             (double)(asc ? t - t0 : t1 - t) / (double)(t1 - t0),
+                             (float)(hi - lo) / ((float)(t1 - t0) * (float)tile_items), 4);
 }
 
 // boundaries of a tile-monotone path are monotone; anything else goes the scatter route
