@@ -133,36 +133,64 @@ __device__ static inline uint64_t locate_boundary(const uint32_t *__restrict__ i
     return lo;
 }
 
-// K0 pass A: every `coarse`-th tile boundary (and the last one), located inside the whole path
-__global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
-                                    const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                                    uint32_t n_tiles, uint32_t tile_items, uint32_t coarse,
-                                    uint64_t *__restrict__ B, uint8_t *__restrict__ path_class) {
-    const uint32_t n_coarse = (n_tiles + coarse - 1) / coarse + 1;  // t = 0, c, 2c, ..., n_tiles
-    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_coarse * n_paths) return;
-    const uint32_t p = (uint32_t)(gid / n_coarse);
-    uint32_t t = (uint32_t)(gid % n_coarse) * coarse;
-    if (t == 0) path_class[p] = 0;  // the later passes of the index only ever raise it
-    if (t > n_tiles) t = n_tiles;
+// The index is SPARSE: a path only has boundaries for the tiles between its first and its last
+// id (TileIdx: first tile, number of tiles spanned, offset of its row).  An assembly-shaped
+// pangenome has thousands of contig paths that each span a few per cent of the id space; a dense
+// paths x tiles table would be 20-100 times larger there, and as slow to fill.  Row of path p:
+// off[p] + j, j = 0..span, = boundary of tile first + j; the two ends are the ends of the path, so
+// the segments of a path always partition it, whatever its ids do in between.
+struct TileIdx {
+    const uint64_t *B;
+    const uint64_t *off;     // n_paths + 1
+    const uint32_t *tfirst;  // n_paths
+    const uint32_t *tspan;   // n_paths, 0 = empty path
+};
+
+__global__ void k_path_spans(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                             uint32_t n_paths, uint32_t tile_items, uint32_t *__restrict__ tfirst,
+                             uint32_t *__restrict__ tspan) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
     const uint64_t s = path_off[p], e = path_off[p + 1];
-    uint64_t *out = B + (uint64_t)p * (n_tiles + 1) + t;
+    if (e == s) {
+        tfirst[p] = 0;
+        tspan[p] = 0;
+        return;
+    }
+    const uint32_t a = items[s], b = items[e - 1];
+    const uint32_t t0 = (a < b ? a : b) / tile_items, t1 = (a < b ? b : a) / tile_items;
+    tfirst[p] = t0;
+    tspan[p] = t1 - t0 + 1;
+}
+
+// K0 pass A: every `coarse`-th boundary of a path's row (and the last one), located inside the
+// whole path.  Workgroups are numbered path-major: blockIdx = p * bpp + chunk.
+__global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                    uint32_t bpp, uint32_t tile_items, uint32_t coarse, uint64_t *__restrict__ B,
+                                    TileIdx ix, uint8_t *__restrict__ path_class) {
+    const uint32_t p = blockIdx.x / bpp;
+    const uint32_t c = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+    const uint32_t span = ix.tspan[p];
+    if (c == 0) path_class[p] = 0;  // the later passes of the index only ever raise it
+    const uint32_t n_coarse = (span + coarse - 1) / coarse + 1;  // j = 0, c, 2c, ..., span
+    if (c >= n_coarse) return;
+    uint32_t j = c * coarse;
+    if (j > span) j = span;
+    const uint64_t s = path_off[p], e = path_off[p + 1];
+    uint64_t *out = B + ix.off[p] + j;
     if (e == s) {
         *out = s;
         return;
     }
     const bool asc = items[s] <= items[e - 1];
-    // the two ends need no search (ids lie in [0, n_tiles * tile_items)); the others are located
-    // inside the whole path as one bracket
-    if (t == 0) *out = asc ? s : e;
-    else if (t == n_tiles) *out = asc ? e : s;
+    if (j == 0) *out = asc ? s : e;
+    else if (j == span) *out = asc ? e : s;
     else {
-        // the path's own id range gives the first guess and the density: a contig-like path covers
-        // a few per cent of the id space, and the tiles outside its range need no probe at all
-        const uint64_t key = (uint64_t)t * tile_items;
+        // the path's own id range gives the first guess and the density
+        const uint64_t key = (uint64_t)(ix.tfirst[p] + j) * tile_items;
         const uint64_t id_a = items[s], id_b = items[e - 1];  // first and last id (asc: smallest, largest)
         const uint64_t id_min = asc ? id_a : id_b, id_max = asc ? id_b : id_a;
-        if (key <= id_min) *out = asc ? s : e;       // no step lies before tile t (asc) / all do (desc)
+        if (key <= id_min) *out = asc ? s : e;       // no step lies before the tile (asc) / all do (desc)
         else if (key > id_max) *out = asc ? e : s;
         else {
             const double range = (double)(id_max - id_min + 1);
@@ -172,34 +200,27 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items,
     }
 }
 
-// K0 pass B: the boundaries in between, by interpolation inside the bracket of the two
-// enclosing coarse boundaries + galloping + a short binary search.  For a tile-monotone
-// path this touches 2-4 cache lines instead of ~10 (the probes of a full binary search are
-// what made the one-pass index HBM-bound).  For any other path the result is still a
-// monotone sequence inside the bracket, so the (path, tile) segments always partition the
-// path; K1's per-step in-tile check then catches every misplaced step.
-__global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
-                                  const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                                  uint32_t n_tiles, uint32_t tile_items, uint32_t coarse, uint32_t stride,
-                                  uint64_t *__restrict__ B, uint8_t *path_class) {
-    // this launch fills the boundaries t with t % stride == 0 inside brackets of `coarse` tiles
-    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t per = (uint64_t)n_tiles + 1;
-    const uint64_t per_s = (per + stride - 1) / stride;
-    if (gid >= per_s * n_paths) return;
-    const uint32_t p = (uint32_t)(gid / per_s);
-    const uint32_t t = (uint32_t)(gid % per_s) * stride;
-    if (t % coarse == 0 || t >= n_tiles) return;  // done by the coarser level
-    const uint32_t t0 = t - t % coarse;
-    const uint32_t t1 = t0 + coarse < n_tiles ? t0 + coarse : n_tiles;
+// K0 pass B: the boundaries in between, inside the bracket of the two enclosing coarse
+// boundaries.  For a path that is not tile-monotone the result is still a monotone sequence
+// inside the bracket, so the (path, tile) segments always partition the path; K1's per-step
+// in-tile check then catches every misplaced step.
+__global__ void k_tile_index_fine(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                  uint32_t bpp, uint32_t tile_items, uint32_t coarse, uint64_t *__restrict__ B,
+                                  TileIdx ix, uint8_t *path_class) {
+    const uint32_t p = blockIdx.x / bpp;
+    const uint32_t j = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+    const uint32_t span = ix.tspan[p];
+    if (j % coarse == 0 || j >= span) return;  // done by the coarse level
+    const uint32_t j0 = j - j % coarse;
+    const uint32_t j1 = j0 + coarse < span ? j0 + coarse : span;
     const uint64_t s = path_off[p], e = path_off[p + 1];
-    uint64_t *row = B + (uint64_t)p * per;
+    uint64_t *row = B + ix.off[p];
     if (e == s) {
-        row[t] = s;
+        row[j] = s;
         return;
     }
     const bool asc = items[s] <= items[e - 1];
-    uint64_t lo = row[t0], hi = row[t1];  // ascending: lo <= hi ; descending: lo >= hi
+    uint64_t lo = row[j0], hi = row[j1];  // ascending: lo <= hi ; descending: lo >= hi
     if (!asc) {
         uint64_t tmp = lo;
         lo = hi;
@@ -207,73 +228,92 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items,
     }
     if (lo > hi) {  // coarse boundaries out of order: not tile-monotone
         path_class[p] = 1;
-        row[t] = asc ? lo : hi;
+        row[j] = asc ? lo : hi;
         return;
     }
-    row[t] = locate_boundary(items, lo, hi, asc, (uint64_t)t * tile_items,
-                             (double)(asc ? t - t0 : t1 - t) / (double)(t1 - t0),
-                             (float)(hi - lo) / ((float)(t1 - t0) * (float)tile_items), 4);
+    row[j] = locate_boundary(items, lo, hi, asc, (uint64_t)(ix.tfirst[p] + j) * tile_items,
+                             (double)(asc ? j - j0 : j1 - j) / (double)(j1 - j0),
+                             (float)(hi - lo) / ((float)(j1 - j0) * (float)tile_items), 4);
 }
 
-// boundaries of a tile-monotone path are monotone; anything else goes the scatter route
-__global__ void k_tile_index_check(const uint32_t *__restrict__ items,
-                                   const uint64_t *__restrict__ path_off,
-                                   const uint64_t *__restrict__ B, uint32_t n_paths,
-                                   uint32_t n_tiles, uint8_t *path_class) {
-    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (uint64_t)n_tiles * n_paths) return;
-    uint32_t p = (uint32_t)(gid / n_tiles);
-    uint32_t t = (uint32_t)(gid % n_tiles);
-    uint64_t s = path_off[p], e = path_off[p + 1];
+// boundaries of a tile-monotone path are monotone; anything else goes the general routes
+__global__ void k_tile_index_check(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                   uint32_t bpp, TileIdx ix, uint8_t *path_class) {
+    const uint32_t p = blockIdx.x / bpp;
+    const uint32_t j = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+    if (j >= ix.tspan[p]) return;
+    const uint64_t s = path_off[p], e = path_off[p + 1];
     if (e == s) return;
-    bool asc = items[s] <= items[e - 1];
-    uint64_t a = B[(uint64_t)p * (n_tiles + 1) + t], b = B[(uint64_t)p * (n_tiles + 1) + t + 1];
+    const bool asc = items[s] <= items[e - 1];
+    const uint64_t a = ix.B[ix.off[p] + j], b = ix.B[ix.off[p] + j + 1];
     if (asc ? (a > b) : (a < b)) path_class[p] = 1;
+}
+
+// tile spans of the paths and the row offsets of the sparse index: once per graph / tile size
+static int ensure_path_spans(pnx_ctx *ctx) {
+    if (ctx->spans_valid) return PNX_OK;
+    const uint32_t P = ctx->n_paths;
+    const uint32_t tile_items = ctx->tile_blocks * BLOCK_ITEMS;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_tfirst, (P ? P : 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tspan, (P ? P : 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_idx_off, ((size_t)P + 1) * sizeof(uint64_t)))) return rc;
+    std::vector<uint32_t> span(P);
+    std::vector<uint64_t> off((size_t)P + 1, 0);
+    if (P) {
+        hipLaunchKernelGGL(k_path_spans, dim3((P + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, P, tile_items,
+                           (uint32_t *)ctx->d_tfirst.p, (uint32_t *)ctx->d_tspan.p);
+        PNX_HIP(ctx, hipMemcpyAsync(span.data(), ctx->d_tspan.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    uint32_t mx = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        off[p + 1] = off[p] + span[p] + 1;
+        mx = span[p] > mx ? span[p] : mx;
+    }
+    ctx->max_span = mx;
+    ctx->idx_entries = off[P];
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_idx_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `off` is a local
+    ctx->spans_valid = true;
+    return PNX_OK;
+}
+
+static TileIdx tile_idx_view(const pnx_ctx *ctx) {
+    return TileIdx{(const uint64_t *)ctx->d_tile_idx.p, (const uint64_t *)ctx->d_idx_off.p,
+                   (const uint32_t *)ctx->d_tfirst.p, (const uint32_t *)ctx->d_tspan.p};
 }
 
 int launch_tile_index(pnx_ctx *ctx) {
     const uint32_t tile_items = ctx->tile_blocks * BLOCK_ITEMS;
-    uint64_t nb = (uint64_t)ctx->n_paths * (ctx->n_tiles + 1);
     int rc;
-    if ((rc = ensure(ctx, ctx->d_tile_idx, nb * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure_path_spans(ctx))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tile_idx, (ctx->idx_entries ? ctx->idx_entries : 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_class, ctx->n_paths ? ctx->n_paths : 1))) return rc;
-    if (nb == 0) return PNX_OK;
+    if (ctx->n_paths == 0) return PNX_OK;
+    const TileIdx ix = tile_idx_view(ctx);
     prof_begin(ctx, PNX_K_INDEX);
     {
-        // hierarchical: every (coarse*8)-th boundary by full binary search, every coarse-th by
-        // interpolation inside those brackets, the rest by interpolation inside coarse brackets
+        // two levels: every coarse-th boundary of a row is located inside the whole path, the
+        // rest inside those brackets
         const uint32_t coarse = ctx->index_coarse ? ctx->index_coarse : 1;
-        static const uint32_t top_factor = []() {
-            const char *e = std::getenv("PNX_INDEX_TOP_FACTOR");  // tuning knob: 1 = two levels only
-            const long v = e ? std::atol(e) : 1;
-            return (uint32_t)(v >= 1 && v <= 64 ? v : 1);
-        }();
-        const uint32_t top = coarse > 1 ? coarse * top_factor : 1;
-        const uint32_t n_top = (ctx->n_tiles + top - 1) / top + 1;
-        const uint64_t na = (uint64_t)n_top * ctx->n_paths;
-        hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                           ctx->n_tiles, tile_items, top, (uint64_t *)ctx->d_tile_idx.p,
+        const uint32_t n_coarse_max = (ctx->max_span + coarse - 1) / coarse + 1;
+        const uint32_t bpp_c = (n_coarse_max + 255) / 256;
+        const uint32_t bpp_f = (ctx->max_span + 1 + 255) / 256;
+        if ((uint64_t)bpp_f * ctx->n_paths > 0x7FFFFFFFull)
+            return ctx->fail(PNX_ELIMIT, "tile index: %u paths x %u tiles exceed the grid", ctx->n_paths, ctx->max_span);
+        hipLaunchKernelGGL(k_tile_index_coarse, dim3(ctx->n_paths * bpp_c), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, tile_items,
+                           coarse, (uint64_t *)ctx->d_tile_idx.p, ix, (uint8_t *)ctx->d_path_class.p);
+        if (coarse > 1)
+            hipLaunchKernelGGL(k_tile_index_fine, dim3(ctx->n_paths * bpp_f), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, tile_items,
+                               coarse, (uint64_t *)ctx->d_tile_idx.p, ix, (uint8_t *)ctx->d_path_class.p);
+        hipLaunchKernelGGL(k_tile_index_check, dim3(ctx->n_paths * bpp_f), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ix,
                            (uint8_t *)ctx->d_path_class.p);
-        if (coarse > 1) {
-            const uint64_t per = (uint64_t)ctx->n_tiles + 1;
-            const uint64_t nb1 = ((per + coarse - 1) / coarse) * ctx->n_paths;
-            if (top > coarse)
-                hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb1 + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                               ctx->n_tiles, tile_items, top, coarse, (uint64_t *)ctx->d_tile_idx.p,
-                               (uint8_t *)ctx->d_path_class.p);
-            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, ctx->n_paths,
-                               ctx->n_tiles, tile_items, coarse, 1u, (uint64_t *)ctx->d_tile_idx.p,
-                               (uint8_t *)ctx->d_path_class.p);
-        }
     }
-    uint64_t nc = (uint64_t)ctx->n_paths * ctx->n_tiles;
-    hipLaunchKernelGGL(k_tile_index_check, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0,
-                       ctx->stream, (const uint32_t *)ctx->d_items.p,
-                       (const uint64_t *)ctx->d_path_off.p, (const uint64_t *)ctx->d_tile_idx.p,
-                       ctx->n_paths, ctx->n_tiles, (uint8_t *)ctx->d_path_class.p);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;
@@ -413,7 +453,7 @@ __device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint
 
 template <int NPL, int WT, bool WRITE_M>
 __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
-    const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
+    const uint32_t *__restrict__ items, TileIdx ix,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
@@ -487,7 +527,6 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 
-    const uint64_t brow = (uint64_t)n_tiles + 1;
     uint32_t cur_g = n_ordered ? ord_group[0] : 0;
     for (uint32_t k = 0; k < n_ordered; ++k) {
         const uint32_t p = ord_path[k];
@@ -497,7 +536,9 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
             cur_g = g;
         }
         if (path_class[p]) continue;  // scatter route
-        const uint64_t ba = B[(uint64_t)p * brow + tile], bb = B[(uint64_t)p * brow + tile + 1];
+        const uint32_t jt = tile - ix.tfirst[p];  // wraps for tiles before the path's first one
+        if (jt >= ix.tspan[p]) continue;          // the path does not reach this tile
+        const uint64_t ba = ix.B[ix.off[p] + jt], bb = ix.B[ix.off[p] + jt + 1];
         const uint64_t lo = ba < bb ? ba : bb, hi = ba < bb ? bb : ba;
         uint32_t viol = 0;
         for (uint64_t base = lo & ~3ull; base < hi; base += 256ull * COVER_UNROLL) {
@@ -577,7 +618,7 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 // tiles for 6144 wave slots, and one wave per tile is a long serial chain of segments.
 template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1>
 __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
-    const uint32_t *__restrict__ items, const uint64_t *__restrict__ B,
+    const uint32_t *__restrict__ items, TileIdx ix,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
@@ -684,7 +725,6 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
         }
     };
 
-    const uint64_t brow = (uint64_t)n_tiles + 1;
     // ---- window of 64 order entries, one per lane -------------------------------------------
     // Entry k = win_base + lane: its segment [w_lo, w_lo + w_len) of this tile and its group.
     // The dependent loads (order -> path -> boundary pair) are paid once per 64 entries instead of
@@ -703,8 +743,12 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
         w_g = in ? ord_group[k] : 0xFFFFFFFFu;
         uint64_t ba = 0, bb = 0;
         if (in && path_class[p] == 0) {
-            ba = B[(uint64_t)p * brow + tile];
-            bb = B[(uint64_t)p * brow + tile + 1];
+            const uint32_t jt = tile - ix.tfirst[p];  // wraps for tiles before the path's first one
+            if (jt < ix.tspan[p]) {
+                const uint64_t *row = ix.B + ix.off[p] + jt;
+                ba = row[0];
+                bb = row[1];
+            }
         }
         w_lo = ba < bb ? ba : bb;
         const uint64_t len = (ba < bb ? bb : ba) - w_lo;
@@ -948,7 +992,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
             sp.k[j] = (uint32_t)t;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_tile_idx.p,
+                           (const uint32_t *)ctx->d_items.p, tile_idx_view(ctx),
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
                            use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,

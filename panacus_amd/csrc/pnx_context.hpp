@@ -97,7 +97,11 @@ struct pnx_ctx {
     uint32_t n_blocks = 0, n_tiles = 0;
     bool index_valid = false;
     bool cache_index = true;
-    pnx::DevBuf d_tile_idx;    // n_paths * (n_tiles + 1) u64
+    pnx::DevBuf d_tile_idx;    // sparse: sum over paths of (tiles spanned + 1) u64
+    pnx::DevBuf d_tfirst, d_tspan, d_idx_off;  // per path: first tile, tiles spanned, row offset (n_paths + 1)
+    bool spans_valid = false;  // the three arrays above match the resident CSR and tile size
+    uint32_t max_span = 0;
+    uint64_t idx_entries = 0;
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
