@@ -236,18 +236,10 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items, const uint
                              (float)(hi - lo) / ((float)(j1 - j0) * (float)tile_items), 4);
 }
 
-// boundaries of a tile-monotone path are monotone; anything else goes the general routes
-__global__ void k_tile_index_check(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
-                                   uint32_t bpp, TileIdx ix, uint8_t *path_class) {
-    const uint32_t p = blockIdx.x / bpp;
-    const uint32_t j = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
-    if (j >= ix.tspan[p]) return;
-    const uint64_t s = path_off[p], e = path_off[p + 1];
-    if (e == s) return;
-    const bool asc = items[s] <= items[e - 1];
-    const uint64_t a = ix.B[ix.off[p] + j], b = ix.B[ix.off[p] + j + 1];
-    if (asc ? (a > b) : (a < b)) path_class[p] = 1;
-}
+// No separate monotonicity check of the finished rows is needed: the two ends of a row are the
+// ends of the path, so the union of [min, max) over consecutive boundaries covers every step at
+// least once, and K1 verifies every step it consumes against its tile -- a path whose boundaries
+// are out of order is caught there (a step lands in a foreign tile) or is harmlessly OR-ed twice.
 
 // tile spans of the paths and the row offsets of the sparse index: once per graph / tile size
 static int ensure_path_spans(pnx_ctx *ctx) {
@@ -310,9 +302,6 @@ int launch_tile_index(pnx_ctx *ctx) {
             hipLaunchKernelGGL(k_tile_index_fine, dim3(ctx->n_paths * bpp_f), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, tile_items,
                                coarse, (uint64_t *)ctx->d_tile_idx.p, ix, (uint8_t *)ctx->d_path_class.p);
-        hipLaunchKernelGGL(k_tile_index_check, dim3(ctx->n_paths * bpp_f), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ix,
-                           (uint8_t *)ctx->d_path_class.p);
     }
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
