@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
+    ap.add_argument("--no-quorum-offload", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -211,6 +212,11 @@ def main():
             return slot["host"].numpy().view(np.uint64).copy()
         _, h = ctx.hist_fetch(want_countable=False)
         return h
+
+    # large group counts: the O(n^3) inner sums of the quorum closed form run on the GPU
+    # (bit-identical, see csrc/kernels_closed_form.hip); below 512 groups the host is faster
+    if rank == 0 and not args.no_quorum_offload:
+        hostlib.set_quorum_offload(ctx, 512)
 
     def growth(h):
         if rank != 0:
@@ -345,6 +351,7 @@ def main():
         del ext
         torch.cuda.synchronize()
         dist.destroy_process_group()
+    hostlib.set_quorum_offload(None)
     ctx.close()
     if rank == 0:
         # RCCL writes a version banner through C stdio; push it out before the one JSON line

@@ -148,6 +148,23 @@ int pnx_group_intersections_device(pnx_ctx *ctx, uint64_t **d_inter); /* G*G u64
 uint64_t pnx_presence_row_words(pnx_ctx *ctx);
 int pnx_presence(pnx_ctx *ctx, uint64_t *bits /* n_groups * row_words */);
 
+/* ---- closed-form growth, quorum branch (row a7) -------------------------------------------------
+ * The O(n^3) inner sums of Hist::calc_growth_quorum (src/graph_broker/hist.rs:138-187):
+ *   sum_q[i*(n+1) + m] = sum over the admissible j of exp2(q[i][j] + m_fact[m] - n_fall[m])
+ * (:164-176; NaN where no j is admissible, i.e. the reference's `add` stays false), computed in
+ * the reference's order of operations with a bit-exact restatement of the platform libm's exp2
+ * (csrc/exp2_exact.hpp).  The caller (the host closed form) supplies everything that involves
+ * log2, computed with libm: log2_tab[v] = log2(v) for v = 0..2n+1, m_fact[m] and n_fall[m] as the
+ * reference's running sums (:148-149,155), m_quorum[m] = ceil(m * quorum) (:150), c (:142).
+ * It finishes every (i, m) itself with exp2(log2(h[i]) + log2(sum_q)) (:178-180).
+ * Synchronous; runs on the context's stream behind whatever is enqueued there. */
+int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum /* n+1 */,
+                    const double *log2_tab /* 2n+2 */, const double *m_fact /* n+1 */,
+                    const double *n_fall /* n+1 */, double *sum_q /* (n+1)*(n+1) */);
+/* y[k] = exp2(x[k]) with the device restatement of libm's exp2 (test hook: bit-equality with
+ * the host libm is what the quorum offload rests on) */
+int pnx_exp2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
+
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of the kernels, recorded on the context's own stream.  Slots: */
 enum {

@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         L.orc_by_group.argtypes = [u64p, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u8p, u64p, C.POINTER(u64p)]
         L.orc_ordered_growth.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_int, C.c_double,
                                          C.c_int, C.c_double, u32p, f64p]
+        L.orc_exp2.argtypes = [f64p, f64p, C.c_uint64]
         L.orc_similarity.restype = C.c_int
         L.orc_similarity.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, u32p, u64p, u64p,
                                      C.POINTER(C.c_float)]
@@ -261,6 +262,14 @@ def ordered_growth(r, c, n_groups, coverage_thr=(ABSOLUTE, 1), quorum_thr=(RELAT
                              coverage_thr[0], float(coverage_thr[1]), quorum_thr[0],
                              float(quorum_thr[1]), _p(w, C.c_uint32), _p(out, C.c_double))
     return out[:n_groups]
+
+
+def exp2(x) -> np.ndarray:
+    """libm exp2 (numpy's own exp2 is a different implementation and differs in the last bit)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_exp2(_p(x, C.c_double), _p(y, C.c_double), x.size)
+    return y
 
 
 def similarity(r, c, n_groups, node_lens=None):

@@ -118,6 +118,9 @@ int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint6
 void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,
                    uint64_t bp, uint64_t *out);
 
+/* y[k] = exp2(x[k]) with the platform libm -- what Rust's f64::exp2 calls (hist.rs:104,131,175,179) */
+void orc_exp2(const double *x, double *y, uint64_t n);
+
 /* ---- synthetic pangenome generator pansyn-v1 (DESIGN.md section "pansyn-v1") ---- */
 uint64_t pansyn_splitmix64(uint64_t x);
 uint32_t pansyn_node_len(uint64_t seed, uint64_t i);

@@ -22,7 +22,7 @@ LIB_HIP = os.path.join(HERE, "libpanacus_hip.so")
 LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
-HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_runs.hip", "kernels_growth.hip", "kernels_pairs.hip", "pansyn.hip"]
+HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_runs.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_closed_form.hip", "pansyn.hip"]
 HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "commands.cpp", "host_api.cpp"]
 
 
@@ -49,7 +49,8 @@ def _run(cmd):
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(ROOT, "include", "panacus_amd.h")]
+    hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(ROOT, "include", "panacus_amd.h"),
+            os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc")]
     objs = []
     procs = []
     for src in HIP_SOURCES:
@@ -59,6 +60,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(o, [s] + hdrs):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
                    "-Wno-unused-result"]
+            if src == "kernels_closed_form.hip":
+                cmd.append("-ffp-contract=off")  # the restated exp2 must not be fused into FMAs
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
-    "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence",
+    "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
+    "pnx_exp2_exact",
 ]
 
 
@@ -85,6 +86,9 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.argtypes = [vp]
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
+    f64p = C.POINTER(C.c_double)
+    L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, f64p]
+    L.pnx_exp2_exact.argtypes = [vp, f64p, f64p, C.c_uint64]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
     L.pnx_profile_select.argtypes = [vp, C.c_uint32]
     L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
@@ -261,6 +265,13 @@ class Context:
         if G and rw:
             self._ck(self._L.pnx_presence(self._h, _ptr(out, C.c_uint64)))
         return out
+
+    def exp2_exact(self, x) -> np.ndarray:
+        """device restatement of the platform libm's exp2 (bit-exact by construction; test hook)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        self._ck(self._L.pnx_exp2_exact(self._h, _ptr(x, C.c_double), _ptr(y, C.c_double), x.size))
+        return y
 
     # ---- measurement / tunables ----
     def profile_enable(self, on=True):

@@ -241,7 +241,8 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain})
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);

@@ -140,6 +140,9 @@ struct pnx_ctx {
     // ---- pairwise intersections / plain presence export (kernels_pairs.hip) ----
     pnx::DevBuf d_inter, d_pair_partial, d_plain;
 
+    // ---- closed-form quorum sums (kernels_closed_form.hip): scratch kept across calls ----
+    pnx::DevBuf d_cf[6];
+
     pnx::Profile prof;
 
     int fail(int code, const char *fmt, ...) {

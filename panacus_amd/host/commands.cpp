@@ -57,8 +57,12 @@ struct Device {  // RAII over pnx_ctx
     explicit Device(int ordinal) {
         int rc = pnx_init(&ctx, ordinal);
         if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
+        set_quorum_offload(ctx);  // quorum closed form with >= 512 groups: inner sums on this GPU
     }
-    ~Device() { pnx_free(ctx); }
+    ~Device() {
+        set_quorum_offload(nullptr);
+        pnx_free(ctx);
+    }
     void check(int rc) const {
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     }

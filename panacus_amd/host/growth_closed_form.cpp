@@ -20,7 +20,13 @@
 #include <memory>
 #include <mutex>
 
+#include "../csrc/exp2_exact.hpp"
 #include "thread_pool.hpp"
+
+// libpanacus_hip (include/panacus_amd.h); declared here so that this file needs no HIP headers
+struct pnx_ctx;
+extern "C" int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
+                               const double *m_fact, const double *n_fall, double *sum_q);
 
 namespace pnh {
 
@@ -58,6 +64,45 @@ struct Log2Table {
 };
 
 enum Branch { UNION, CORE, QUORUM };
+
+// ---- device offload of the quorum branch's inner sums ------------------------------------------
+// pnx_quorum_sums evaluates the O(n^3) exp2 terms with a restatement of the platform libm's exp2
+// (csrc/exp2_exact.hpp).  It is only used after that restatement has reproduced std::exp2 bit for
+// bit on a sample of arguments of the kind the closed form produces -- on a libm that computes
+// exp2 differently the test fails and everything stays on the host.
+const uint64_t EXP2_TAB[256] = {
+#include "../csrc/exp2_table.inc"
+};
+
+bool exp2_restatement_matches_libm() {
+    static const bool ok = []() {
+        uint64_t s = 0x2545F4914F6CDD1Dull;
+        auto next = [&]() {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            return (double)(s >> 11) * (1.0 / 9007199254740992.0);
+        };
+        for (int k = 0; k < 400000; ++k) {
+            const double u = next();
+            double x;
+            switch (k & 3) {
+                case 0: x = -1100.0 * u; break;   // the whole range of the terms, incl. subnormal results
+                case 1: x = -60.0 * u; break;     // where the sums are decided
+                case 2: x = -1080.0 + 10.0 * u; break;
+                default: x = 40.0 * u - 20.0; break;
+            }
+            const double a = pnx_exp2::exp2_exact(x, EXP2_TAB), b = std::exp2(x);
+            if (std::memcmp(&a, &b, sizeof a) != 0) return false;
+        }
+        return true;
+    }();
+    return ok;
+}
+
+std::mutex g_offload_mu;
+pnx_ctx *g_offload_ctx = nullptr;
+uint64_t g_offload_min_n = 512;
 
 // The (n+1)^2 term arrays are recycled across calls: fresh 8 MB allocations are mmap'ed by
 // malloc and first touched by all workers at once, and those page faults (plus the munmap
@@ -117,6 +162,7 @@ struct Job {
     double tot = 0.0;
     // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
     // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
+    std::vector<double> sumq;  // from the device: (n+1) x (n+1), NaN = no admissible j; empty = host path
     ScratchPool::Buf buf1, buf2;
     double *term1 = nullptr, *term2 = nullptr;  // left uninitialised: every entry that is read is written by its row
     std::vector<double> out;
@@ -184,8 +230,15 @@ struct Job {
         if (branch != QUORUM || i >= n) return;
         // hist.rs:163-183, row i of Q
         double *t2 = term2 + i * (n + 1);
-        q.assign(n + 1, 0.0);
         const double nan = std::nan("");
+        if (!sumq.empty()) {  // inner sums came from the device; hist.rs:178-180 stays here
+            for (uint64_t m = 1; m <= n; ++m) {
+                const double sq = sumq[i * (n + 1) + m];
+                t2[m] = sq == sq ? std::exp2(lh[i] + std::log2(sq)) : nan;
+            }
+            return;
+        }
+        q.assign(n + 1, 0.0);
         for (uint64_t m = 1; m <= n; ++m) {
             t2[m] = nan;
             if (i < m_quorum[m]) continue;  // the reference loops "for i in m_quorum..n"
@@ -275,6 +328,25 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
         auto w = [](const Task &t) { return t.job->branch == QUORUM ? (double)t.hi * (double)t.hi : 1.0; };
         return w(a) > w(b);
     });
+    {   // quorum jobs that are large enough: inner sums on the GPU
+        pnx_ctx *off = nullptr;
+        uint64_t min_n = 0;
+        {
+            std::lock_guard<std::mutex> g(g_offload_mu);
+            off = g_offload_ctx;
+            min_n = g_offload_min_n;
+        }
+        if (off)
+            for (auto &j : jobs) {
+                if (j->branch != QUORUM || j->n < min_n || j->n > 8192 || !exp2_restatement_matches_libm()) continue;
+                std::vector<uint32_t> mq(j->n + 1);
+                for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
+                j->sumq.resize((j->n + 1) * (j->n + 1));
+                if (pnx_quorum_sums(off, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
+                                    j->n_fall.data(), j->sumq.data()) != 0)
+                    j->sumq.clear();  // any device error: the host path is always available
+            }
+    }
     auto body = [&](size_t k) {
         thread_local std::vector<double> q;
         const Task &t = tasks[k];
@@ -313,6 +385,14 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
 }
 
 }  // namespace
+
+void set_quorum_offload(void *pnx_context, uint64_t min_n) {
+    std::lock_guard<std::mutex> g(g_offload_mu);
+    g_offload_ctx = static_cast<pnx_ctx *>(pnx_context);
+    g_offload_min_n = min_n;
+}
+
+bool quorum_offload_usable() { return exp2_restatement_matches_libm(); }
 
 std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &hist,
                                                   const std::vector<Threshold> &coverage,

@@ -233,6 +233,10 @@ uint64_t pnh_format_f32(float x, char *buf, uint64_t cap) {
 uint32_t pnh_pool_threads(void) { return pnh::ThreadPool::instance().size(); }
 uint32_t pnh_usable_cpus(void) { return pnh::ThreadPool::usable_cpus(); }
 
+// quorum closed form: inner sums on the GPU of `pnx_context` for n >= min_n (NULL = host only)
+void pnh_set_quorum_offload(void *pnx_context, uint64_t min_n) { pnh::set_quorum_offload(pnx_context, min_n); }
+int pnh_quorum_offload_usable(void) { return pnh::quorum_offload_usable() ? 1 : 0; }
+
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
 
 }  // extern "C"

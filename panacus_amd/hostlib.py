@@ -276,3 +276,17 @@ def usable_cpus() -> int:
     L = load()
     L.pnh_usable_cpus.restype = C.c_uint32
     return int(L.pnh_usable_cpus())
+
+
+def set_quorum_offload(ctx=None, min_n: int = 512):
+    """Quorum closed form with n >= min_n: the O(n^3) inner sums run on the GPU of `ctx`
+    (a capi.Context), bit-identical to the host path; None switches it off."""
+    L = load()
+    L.pnh_set_quorum_offload.argtypes = [C.c_void_p, C.c_uint64]
+    L.pnh_set_quorum_offload(None if ctx is None else ctx._h, int(min_n))
+
+
+def quorum_offload_usable() -> bool:
+    """True iff the restated exp2 reproduces this platform's libm bit for bit"""
+    L = load()
+    return bool(L.pnh_quorum_offload_usable())

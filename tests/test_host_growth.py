@@ -62,3 +62,9 @@ def test_quorum_large_n_bitwise():
         a = hostlib.calc_growth(h, Threshold(ABSOLUTE, c), Threshold(RELATIVE, q))
         b = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
         assert a.tobytes() == b.tobytes(), (c, q)
+
+
+def test_exp2_restatement_matches_this_libm():
+    """the device path of the quorum closed form rests on this; on a libm with another exp2 the
+    library detects it and stays on the host"""
+    assert hostlib.quorum_offload_usable()
