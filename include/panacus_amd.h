@@ -156,11 +156,13 @@ int pnx_presence(pnx_ctx *ctx, uint64_t *bits /* n_groups * row_words */);
  * (csrc/exp2_exact.hpp).  The caller (the host closed form) supplies everything that involves
  * log2, computed with libm: log2_tab[v] = log2(v) for v = 0..2n+1, m_fact[m] and n_fall[m] as the
  * reference's running sums (:148-149,155), m_quorum[m] = ceil(m * quorum) (:150), c (:142).
- * It finishes every (i, m) itself with exp2(log2(h[i]) + log2(sum_q)) (:178-180).
+ * The caller finishes every (i, m) itself with exp2(log2(h[i]) + log2(sum_q)) (:178-180).
  * Synchronous; runs on the context's stream behind whatever is enqueued there. */
 int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum /* n+1 */,
                     const double *log2_tab /* 2n+2 */, const double *m_fact /* n+1 */,
-                    const double *n_fall /* n+1 */, double *sum_q /* (n+1)*(n+1) */);
+                    const double *n_fall /* n+1 */,
+                    const double **sum_q /* out: (n+1)*(n+1) doubles in pinned host memory owned by the
+                                            context, valid until the next call on it */);
 /* y[k] = exp2(x[k]) with the device restatement of libm's exp2 (test hook: bit-equality with
  * the host libm is what the quorum offload rests on) */
 int pnx_exp2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);

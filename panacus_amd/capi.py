@@ -87,7 +87,7 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
     f64p = C.POINTER(C.c_double)
-    L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, f64p]
+    L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
     L.pnx_exp2_exact.argtypes = [vp, f64p, f64p, C.c_uint64]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
     L.pnx_profile_select.argtypes = [vp, C.c_uint32]

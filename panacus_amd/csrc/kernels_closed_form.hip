@@ -100,7 +100,7 @@ using namespace pnx;
 extern "C" {
 
 int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
-                    const double *m_fact, const double *n_fall, double *sum_q) {
+                    const double *m_fact, const double *n_fall, const double **sum_q) {
     if (!ctx) return PNX_EINVAL;
     if (!m_quorum || !log2_tab || !m_fact || !n_fall || !sum_q || n == 0 || n > 8192)
         return ctx->fail(PNX_EINVAL, "pnx_quorum_sums: bad arguments");
@@ -111,8 +111,8 @@ int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quor
     DevBuf &d_mq = ctx->d_cf[0], &d_L = ctx->d_cf[1], &d_mf = ctx->d_cf[2], &d_nf = ctx->d_cf[3],
            &d_terms = ctx->d_cf[4], &d_sum = ctx->d_cf[5];
     auto cleanup = []() {};
-    // rows per slab: about 1 GiB of terms at a time
-    uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 30) / (np1 * np1 * sizeof(double)));
+    // rows per slab: up to 12 GiB of terms at a time (n = 1024: all rows in one launch, 16 K waves)
+    uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)12 << 30) / (np1 * np1 * sizeof(double)));
     if (slab > n) slab = n;
     int rc;
     if ((rc = ensure(ctx, d_mq, np1 * sizeof(uint32_t))) || (rc = ensure(ctx, d_L, (2 * np1) * sizeof(double))) ||
@@ -137,10 +137,21 @@ int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quor
                            (const uint32_t *)d_mq.p, (const double *)d_terms.p, (double *)d_sum.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(sum_q, d_sum.p, np1 * np1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    // results go to pinned host memory owned by the context (8 MB at n = 1024: a pageable copy
+    // would cost as much as the kernels)
+    const size_t out_bytes = np1 * np1 * sizeof(double);
+    if (e == hipSuccess && ctx->h_cf_cap < out_bytes) {
+        if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
+        ctx->h_cf = nullptr;
+        ctx->h_cf_cap = 0;
+        e = hipHostMalloc(&ctx->h_cf, out_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) ctx->h_cf_cap = out_bytes;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_cf, d_sum.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     cleanup();
     if (e != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_quorum_sums: %s", hipGetErrorString(e));
+    *sum_q = (const double *)ctx->h_cf;
     return PNX_OK;
 }
 

@@ -244,6 +244,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
+    if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);
         if (t.done) (void)hipEventDestroy(t.done);

@@ -142,6 +142,8 @@ struct pnx_ctx {
 
     // ---- closed-form quorum sums (kernels_closed_form.hip): scratch kept across calls ----
     pnx::DevBuf d_cf[6];
+    void *h_cf = nullptr;  // pinned: the (n+1)^2 sums handed back to the caller
+    size_t h_cf_cap = 0;
 
     pnx::Profile prof;
 

@@ -26,7 +26,7 @@
 // libpanacus_hip (include/panacus_amd.h); declared here so that this file needs no HIP headers
 struct pnx_ctx;
 extern "C" int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
-                               const double *m_fact, const double *n_fall, double *sum_q);
+                               const double *m_fact, const double *n_fall, const double **sum_q);
 
 namespace pnh {
 
@@ -162,7 +162,7 @@ struct Job {
     double tot = 0.0;
     // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
     // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
-    std::vector<double> sumq;  // from the device: (n+1) x (n+1), NaN = no admissible j; empty = host path
+    const double *sumq = nullptr;  // from the device (pinned, owned by the context): (n+1) x (n+1), NaN = no admissible j
     ScratchPool::Buf buf1, buf2;
     double *term1 = nullptr, *term2 = nullptr;  // left uninitialised: every entry that is read is written by its row
     std::vector<double> out;
@@ -231,7 +231,7 @@ struct Job {
         // hist.rs:163-183, row i of Q
         double *t2 = term2 + i * (n + 1);
         const double nan = std::nan("");
-        if (!sumq.empty()) {  // inner sums came from the device; hist.rs:178-180 stays here
+        if (sumq) {  // inner sums came from the device; hist.rs:178-180 stays here
             for (uint64_t m = 1; m <= n; ++m) {
                 const double sq = sumq[i * (n + 1) + m];
                 t2[m] = sq == sq ? std::exp2(lh[i] + std::log2(sq)) : nan;
@@ -336,15 +336,19 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
             off = g_offload_ctx;
             min_n = g_offload_min_n;
         }
+        bool offloaded = false;
         if (off)
             for (auto &j : jobs) {
                 if (j->branch != QUORUM || j->n < min_n || j->n > 8192 || !exp2_restatement_matches_libm()) continue;
                 std::vector<uint32_t> mq(j->n + 1);
                 for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
-                j->sumq.resize((j->n + 1) * (j->n + 1));
+                if (offloaded) break;  // the context holds one result buffer: one offloaded job per region
+                const double *res = nullptr;
                 if (pnx_quorum_sums(off, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
-                                    j->n_fall.data(), j->sumq.data()) != 0)
-                    j->sumq.clear();  // any device error: the host path is always available
+                                    j->n_fall.data(), &res) == 0) {
+                    j->sumq = res;  // any device error: the host path is always available
+                    offloaded = true;
+                }
             }
     }
     auto body = [&](size_t k) {
