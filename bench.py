@@ -218,22 +218,28 @@ def main():
     if rank == 0 and not args.no_quorum_offload:
         hostlib.set_quorum_offload(ctx, 512)
 
-    def growth(h):
-        if rank != 0:
-            return None
-        return hostlib.calc_growths(h, thr, args.growth_threads)
+    def growth_begin(h):
+        """rank 0: set the closed forms up and enqueue their device part (if any) behind the pass
+        that is running"""
+        return hostlib.calc_growths_begin(h, thr, args.growth_threads) if rank == 0 else None
+
+    def growth_end(pending):
+        return hostlib.calc_growths_end(pending) if rank == 0 else None
 
     def run(n_steps):
-        """n_steps complete histgrowth passes.  Consecutive passes are independent, so pass k+1
-        is enqueued on the GPU before the host fetches pass k and evaluates its closed forms
-        (two passes in flight); every pass is finished inside the call."""
+        """n_steps complete histgrowth passes.  Consecutive passes are independent, so two are kept
+        in flight: while the host evaluates the closed forms of pass k, pass k+1 runs and pass k+2 is
+        already enqueued behind it; every pass is finished inside the call."""
         h = growths = None
         enqueue()
+        if n_steps > 1:
+            enqueue()
         for k in range(n_steps):
-            if k + 1 < n_steps:
-                enqueue()
             h = settle()
-            growths = growth(h)
+            pending = growth_begin(h)
+            if k + 2 < n_steps:
+                enqueue()
+            growths = growth_end(pending)
         return h, growths
 
     def barrier():

@@ -163,6 +163,12 @@ int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quor
                     const double *n_fall /* n+1 */,
                     const double **sum_q /* out: (n+1)*(n+1) doubles in pinned host memory owned by the
                                             context, valid until the next call on it */);
+/* the same in two halves: _async enqueues the work on the context's stream and returns (the input
+ * arrays are copied before it returns); _fetch waits for exactly that work -- not for anything the
+ * caller enqueued on the stream afterwards -- and hands out the result */
+int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
+                          const double *m_fact, const double *n_fall);
+int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q);
 /* y[k] = exp2(x[k]) with the device restatement of libm's exp2 (test hook: bit-equality with
  * the host libm is what the quorum offload rests on) */
 int pnx_exp2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
-    "pnx_exp2_exact",
+    "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact",
 ]
 
 

@@ -12,6 +12,9 @@
 //   K7b  one wave per (i, m): adds the terms of its j range in ascending j with a single
 //        lane, sequentially -- the reference's order of additions
 // The host then finishes each (i, m) with libm: exp2(log2(h[i]) + log2(sum_q)) (:178-180).
+#include <algorithm>
+#include <cstring>
+
 #include "exp2_exact.hpp"
 #include "pnx_context.hpp"
 
@@ -99,60 +102,75 @@ using namespace pnx;
 
 extern "C" {
 
-int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
-                    const double *m_fact, const double *n_fall, const double **sum_q) {
+int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
+                          const double *m_fact, const double *n_fall) {
     if (!ctx) return PNX_EINVAL;
-    if (!m_quorum || !log2_tab || !m_fact || !n_fall || !sum_q || n == 0 || n > 8192)
+    if (!m_quorum || !log2_tab || !m_fact || !n_fall || n == 0 || n > 8192)
         return ctx->fail(PNX_EINVAL, "pnx_quorum_sums: bad arguments");
+    if (ctx->cf_pending) return ctx->fail(PNX_EINVAL, "pnx_quorum_sums_async: the previous result has not been fetched");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     const size_t np1 = (size_t)n + 1;
-    // scratch of the closed form lives in the context: a fresh 1 GiB hipMalloc + hipFree per call
-    // costs more than the kernels
-    DevBuf &d_mq = ctx->d_cf[0], &d_L = ctx->d_cf[1], &d_mf = ctx->d_cf[2], &d_nf = ctx->d_cf[3],
-           &d_terms = ctx->d_cf[4], &d_sum = ctx->d_cf[5];
-    auto cleanup = []() {};
+    // scratch of the closed form lives in the context: a fresh hipMalloc + hipFree of gigabytes per
+    // call costs more than the kernels
+    DevBuf &d_in = ctx->d_cf[0], &d_terms = ctx->d_cf[4], &d_sum = ctx->d_cf[5];
     // rows per slab: up to 12 GiB of terms at a time (n = 1024: all rows in one launch, 16 K waves)
     uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)12 << 30) / (np1 * np1 * sizeof(double)));
     if (slab > n) slab = n;
-    int rc;
-    if ((rc = ensure(ctx, d_mq, np1 * sizeof(uint32_t))) || (rc = ensure(ctx, d_L, (2 * np1) * sizeof(double))) ||
-        (rc = ensure(ctx, d_mf, np1 * sizeof(double))) || (rc = ensure(ctx, d_nf, np1 * sizeof(double))) ||
-        (rc = ensure(ctx, d_terms, (size_t)slab * np1 * np1 * sizeof(double))) ||
-        (rc = ensure(ctx, d_sum, np1 * np1 * sizeof(double)))) {
-        cleanup();
-        return rc;
-    }
-    hipError_t e = hipMemcpyAsync(d_mq.p, m_quorum, np1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_L.p, log2_tab, 2 * np1 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_mf.p, m_fact, np1 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nf.p, n_fall, np1 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_sum.p, 0xFF, np1 * np1 * sizeof(double), ctx->stream);  // NaN everywhere
-    for (uint32_t i0 = 0; e == hipSuccess && i0 < n; i0 += slab) {
-        const uint32_t i1 = std::min(n, i0 + slab);
-        hipLaunchKernelGGL(k_quorum_terms, dim3(i1 - i0, (n + 63) / 64), dim3(64), 0, ctx->stream, n, c, i0, i1,
-                           (const uint32_t *)d_mq.p, (const double *)d_L.p, (const double *)d_mf.p,
-                           (const double *)d_nf.p, (double *)d_terms.p);
-        const uint64_t n_pairs = (uint64_t)(i1 - i0) * n;
-        hipLaunchKernelGGL(k_quorum_sums, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, ctx->stream, n, c, i0, i1,
-                           (const uint32_t *)d_mq.p, (const double *)d_terms.p, (double *)d_sum.p);
-        e = hipGetLastError();
-    }
-    // results go to pinned host memory owned by the context (8 MB at n = 1024: a pageable copy
-    // would cost as much as the kernels)
+    // inputs: [log2 table 2(n+1) | m_fact n+1 | n_fall n+1 | m_quorum n+1 (u32)] staged in pinned memory
+    const size_t in_bytes = (4 * np1) * sizeof(double) + np1 * sizeof(uint32_t);
     const size_t out_bytes = np1 * np1 * sizeof(double);
-    if (e == hipSuccess && ctx->h_cf_cap < out_bytes) {
+    int rc;
+    if ((rc = ensure(ctx, d_in, in_bytes)) || (rc = ensure(ctx, d_terms, (size_t)slab * np1 * np1 * sizeof(double))) ||
+        (rc = ensure(ctx, d_sum, out_bytes)))
+        return rc;
+    if (ctx->h_cf_cap < out_bytes + in_bytes) {
         if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
         ctx->h_cf = nullptr;
         ctx->h_cf_cap = 0;
-        e = hipHostMalloc(&ctx->h_cf, out_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) ctx->h_cf_cap = out_bytes;
+        PNX_HIP(ctx, hipHostMalloc(&ctx->h_cf, out_bytes + in_bytes, hipHostMallocDefault));
+        ctx->h_cf_cap = out_bytes + in_bytes;
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_cf, d_sum.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    cleanup();
-    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_quorum_sums: %s", hipGetErrorString(e));
+    if (!ctx->ev_cf) PNX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_cf, hipEventDisableTiming));
+    char *h_in = (char *)ctx->h_cf + out_bytes;
+    std::memcpy(h_in, log2_tab, 2 * np1 * sizeof(double));
+    std::memcpy(h_in + 2 * np1 * sizeof(double), m_fact, np1 * sizeof(double));
+    std::memcpy(h_in + 3 * np1 * sizeof(double), n_fall, np1 * sizeof(double));
+    std::memcpy(h_in + 4 * np1 * sizeof(double), m_quorum, np1 * sizeof(uint32_t));
+    PNX_HIP(ctx, hipMemcpyAsync(d_in.p, h_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const double *d_L = (const double *)d_in.p, *d_mf = d_L + 2 * np1, *d_nf = d_L + 3 * np1;
+    const uint32_t *d_mq = (const uint32_t *)(d_L + 4 * np1);
+    PNX_HIP(ctx, hipMemsetAsync(d_sum.p, 0xFF, out_bytes, ctx->stream));  // NaN everywhere
+    for (uint32_t i0 = 0; i0 < n; i0 += slab) {
+        const uint32_t i1 = std::min(n, i0 + slab);
+        hipLaunchKernelGGL(k_quorum_terms, dim3(i1 - i0, (n + 63) / 64), dim3(64), 0, ctx->stream, n, c, i0, i1, d_mq,
+                           d_L, d_mf, d_nf, (double *)d_terms.p);
+        const uint64_t n_pairs = (uint64_t)(i1 - i0) * n;
+        hipLaunchKernelGGL(k_quorum_sums, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, ctx->stream, n, c, i0, i1,
+                           d_mq, (const double *)d_terms.p, (double *)d_sum.p);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    // results go to pinned host memory owned by the context (8 MB at n = 1024: a pageable copy
+    // would cost as much as the kernels)
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->h_cf, d_sum.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipEventRecord(ctx->ev_cf, ctx->stream));
+    ctx->cf_pending = true;
+    return PNX_OK;
+}
+
+int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q) {
+    if (!ctx || !sum_q) return PNX_EINVAL;
+    if (!ctx->cf_pending) return ctx->fail(PNX_EINVAL, "pnx_quorum_sums_fetch: nothing was enqueued");
+    ctx->cf_pending = false;
+    PNX_HIP(ctx, hipEventSynchronize(ctx->ev_cf));
     *sum_q = (const double *)ctx->h_cf;
     return PNX_OK;
+}
+
+int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
+                    const double *m_fact, const double *n_fall, const double **sum_q) {
+    int rc = pnx_quorum_sums_async(ctx, n, c, m_quorum, log2_tab, m_fact, n_fall);
+    if (rc) return rc;
+    return pnx_quorum_sums_fetch(ctx, sum_q);
 }
 
 int pnx_exp2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n) {

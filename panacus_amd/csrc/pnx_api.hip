@@ -245,6 +245,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
+    if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);
         if (t.done) (void)hipEventDestroy(t.done);

@@ -142,8 +142,10 @@ struct pnx_ctx {
 
     // ---- closed-form quorum sums (kernels_closed_form.hip): scratch kept across calls ----
     pnx::DevBuf d_cf[6];
-    void *h_cf = nullptr;  // pinned: the (n+1)^2 sums handed back to the caller
+    void *h_cf = nullptr;  // pinned: the (n+1)^2 sums handed back to the caller, then the staged inputs
     size_t h_cf_cap = 0;
+    hipEvent_t ev_cf = nullptr;
+    bool cf_pending = false;
 
     pnx::Profile prof;
 

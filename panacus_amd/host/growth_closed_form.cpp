@@ -25,8 +25,9 @@
 
 // libpanacus_hip (include/panacus_amd.h); declared here so that this file needs no HIP headers
 struct pnx_ctx;
-extern "C" int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
-                               const double *m_fact, const double *n_fall, const double **sum_q);
+extern "C" int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum,
+                                     const double *log2_tab, const double *m_fact, const double *n_fall);
+extern "C" int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q);
 
 namespace pnh {
 
@@ -304,6 +305,40 @@ Branch dispatch(uint64_t n, Threshold quorum) {  // Hist::calc_growth, hist.rs:5
     return QUORUM;
 }
 
+// Quorum jobs that are large enough: enqueue the inner sums on the GPU.  The context keeps one
+// result buffer, so one job per region is offloaded; the others (and any failure) take the host path.
+struct Offload {
+    pnx_ctx *ctx = nullptr;
+    Job *job = nullptr;
+};
+
+Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
+    Offload o;
+    uint64_t min_n = 0;
+    {
+        std::lock_guard<std::mutex> g(g_offload_mu);
+        o.ctx = g_offload_ctx;
+        min_n = g_offload_min_n;
+    }
+    if (!o.ctx) return o;
+    for (auto &j : jobs) {
+        if (j->branch != QUORUM || j->n < min_n || j->n > 8192 || !exp2_restatement_matches_libm()) continue;
+        std::vector<uint32_t> mq(j->n + 1);
+        for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
+        if (pnx_quorum_sums_async(o.ctx, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
+                                  j->n_fall.data()) == 0)
+            o.job = j.get();
+        break;
+    }
+    return o;
+}
+
+void finish_offload(const Offload &o) {
+    if (!o.job) return;
+    const double *res = nullptr;
+    if (pnx_quorum_sums_fetch(o.ctx, &res) == 0) o.job->sumq = res;  // any device error: the host path
+}
+
 std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &jobs, unsigned n_threads) {
     static const bool timing = std::getenv("PANACUS_AMD_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -328,29 +363,6 @@ std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &job
         auto w = [](const Task &t) { return t.job->branch == QUORUM ? (double)t.hi * (double)t.hi : 1.0; };
         return w(a) > w(b);
     });
-    {   // quorum jobs that are large enough: inner sums on the GPU
-        pnx_ctx *off = nullptr;
-        uint64_t min_n = 0;
-        {
-            std::lock_guard<std::mutex> g(g_offload_mu);
-            off = g_offload_ctx;
-            min_n = g_offload_min_n;
-        }
-        bool offloaded = false;
-        if (off)
-            for (auto &j : jobs) {
-                if (j->branch != QUORUM || j->n < min_n || j->n > 8192 || !exp2_restatement_matches_libm()) continue;
-                std::vector<uint32_t> mq(j->n + 1);
-                for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
-                if (offloaded) break;  // the context holds one result buffer: one offloaded job per region
-                const double *res = nullptr;
-                if (pnx_quorum_sums(off, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
-                                    j->n_fall.data(), &res) == 0) {
-                    j->sumq = res;  // any device error: the host path is always available
-                    offloaded = true;
-                }
-            }
-    }
     auto body = [&](size_t k) {
         thread_local std::vector<double> q;
         const Task &t = tasks[k];
@@ -398,21 +410,42 @@ void set_quorum_offload(void *pnx_context, uint64_t min_n) {
 
 bool quorum_offload_usable() { return exp2_restatement_matches_libm(); }
 
+struct GrowthRun {
+    std::vector<uint64_t> hist;  // the jobs refer to it
+    std::vector<std::unique_ptr<Job>> jobs;
+    size_t n_pairs = 0;
+    unsigned n_threads = 0;
+    Offload off;
+};
+
+GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::vector<Threshold> &coverage,
+                                  const std::vector<Threshold> &quorum, unsigned n_threads) {
+    std::unique_ptr<GrowthRun> run(new GrowthRun);
+    run->hist = hist;
+    run->n_pairs = coverage.size();
+    run->n_threads = n_threads;
+    if (hist.size() >= 2) {
+        const uint64_t n = hist.size() - 1;
+        auto tab = std::make_shared<Log2Table>(2 * n + 2);
+        for (size_t t = 0; t < coverage.size(); ++t)
+            run->jobs.emplace_back(new Job(dispatch(n, quorum[t]), run->hist, coverage[t], quorum[t], tab));
+        run->off = start_offload(run->jobs);
+    }
+    return run.release();
+}
+
+std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *handle) {
+    std::unique_ptr<GrowthRun> run(handle);
+    if (!run) return {};
+    if (run->hist.size() < 2) return std::vector<std::vector<double>>(run->n_pairs);
+    finish_offload(run->off);
+    return run_jobs(run->jobs, run->n_threads);
+}
+
 std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &hist,
                                                   const std::vector<Threshold> &coverage,
                                                   const std::vector<Threshold> &quorum, unsigned n_threads) {
-    std::vector<std::vector<double>> res;
-    if (hist.size() < 2) return std::vector<std::vector<double>>(coverage.size());
-    const uint64_t n = hist.size() - 1;
-    auto tab = std::make_shared<Log2Table>(2 * n + 2);
-    std::vector<std::unique_ptr<Job>> jobs;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (size_t t = 0; t < coverage.size(); ++t)
-        jobs.emplace_back(new Job(dispatch(n, quorum[t]), hist, coverage[t], quorum[t], tab));
-    if (std::getenv("PANACUS_AMD_HOST_TIMING"))
-        std::fprintf(stderr, "[host growth] setup %.3f ms\n",
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    return run_jobs(jobs, n_threads);
+    return calc_all_growths_end(calc_all_growths_begin(hist, coverage, quorum, n_threads));
 }
 
 static std::vector<double> one(Branch b, const std::vector<uint64_t> &hist, Threshold c, Threshold q, unsigned n_threads) {
@@ -420,6 +453,7 @@ static std::vector<double> one(Branch b, const std::vector<uint64_t> &hist, Thre
     auto tab = std::make_shared<Log2Table>(2 * (hist.size() - 1) + 2);
     std::vector<std::unique_ptr<Job>> jobs;
     jobs.emplace_back(new Job(b, hist, c, q, tab));
+    finish_offload(start_offload(jobs));
     return run_jobs(jobs, n_threads)[0];
 }
 

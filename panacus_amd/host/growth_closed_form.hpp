@@ -35,6 +35,14 @@ std::vector<std::vector<double>> calc_all_growths(const std::vector<uint64_t> &h
                                                   const std::vector<Threshold> &coverage,
                                                   const std::vector<Threshold> &quorum, unsigned n_threads = 0);
 
+// The same in two halves: _begin sets the jobs up and enqueues the device part (if any) and
+// returns; _end waits for it and does the host part.  A host that pipelines passes enqueues its next
+// device pass in between.  Every handle must be passed to _end exactly once.
+struct GrowthRun;
+GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::vector<Threshold> &coverage,
+                                  const std::vector<Threshold> &quorum, unsigned n_threads = 0);
+std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *run);
+
 // n = hist.size() - 1 values (the caller prepends the NaN row, hist.rs:83-85)
 std::vector<double> calc_growth(const std::vector<uint64_t> &hist, Threshold coverage, Threshold quorum,
                                 unsigned n_threads = 0);

@@ -175,6 +175,25 @@ int64_t pnh_calc_all_growths(const uint64_t *hist, uint64_t hist_len, const int 
     return (int64_t)n;
 }
 
+// the same in two halves (growth_closed_form.hpp): _begin returns a handle after the device part (if
+// any) has been enqueued, _end waits for it, does the host part and releases the handle
+void *pnh_calc_all_growths_begin(const uint64_t *hist, uint64_t hist_len, const int *cov_kind, const double *cov_val,
+                                 const int *quo_kind, const double *quo_val, uint32_t n_pairs, unsigned n_threads) {
+    std::vector<uint64_t> h(hist, hist + (hist ? hist_len : 0));
+    std::vector<pnh::Threshold> cov, quo;
+    for (uint32_t t = 0; t < n_pairs; ++t) {
+        cov.push_back(pnh::Threshold{cov_kind[t], cov_val[t]});
+        quo.push_back(pnh::Threshold{quo_kind[t], quo_val[t]});
+    }
+    return pnh::calc_all_growths_begin(h, cov, quo, n_threads);
+}
+int64_t pnh_calc_all_growths_end(void *handle, uint64_t n, uint32_t n_pairs, double *out) {
+    std::vector<std::vector<double>> g = pnh::calc_all_growths_end(static_cast<pnh::GrowthRun *>(handle));
+    for (uint32_t t = 0; t < n_pairs && t < g.size(); ++t)
+        std::memcpy(out + (size_t)t * n, g[t].data(), std::min<size_t>(g[t].size(), n) * sizeof(double));
+    return (int64_t)n;
+}
+
 void pnh_set_threads(unsigned n) { pnh::ThreadPool::instance().set_threads(n); }
 unsigned pnh_get_threads(void) { return pnh::ThreadPool::instance().size(); }
 

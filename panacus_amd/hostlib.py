@@ -72,6 +72,34 @@ def calc_growths(hist, pairs, n_threads: int = 0):
     return [out[t, :n].copy() for t in range(T)]
 
 
+def calc_growths_begin(hist, pairs, n_threads: int = 0):
+    """First half of calc_growths: sets the jobs up and enqueues the device part of the quorum
+    closed form (set_quorum_offload) if there is one.  Pass the result to calc_growths_end."""
+    L = load()
+    L.pnh_calc_all_growths_begin.restype = C.c_void_p
+    L.pnh_calc_all_growths_begin.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32, C.c_uint]
+    h = np.ascontiguousarray(hist, dtype=np.uint64)
+    T = len(pairs)
+    ck = (C.c_int * T)(*[c.kind for c, _ in pairs])
+    cv = (C.c_double * T)(*[float(c.value) for c, _ in pairs])
+    qk = (C.c_int * T)(*[q.kind for _, q in pairs])
+    qv = (C.c_double * T)(*[float(q.value) for _, q in pairs])
+    handle = L.pnh_calc_all_growths_begin(h.ctypes.data_as(C.POINTER(C.c_uint64)), len(h), ck, cv, qk, qv, T, n_threads)
+    return (handle, T, max(len(h) - 1, 0))
+
+
+def calc_growths_end(pending):
+    """Second half: waits for the device part, finishes on the host threads. -> list of curves"""
+    handle, T, n = pending
+    L = load()
+    L.pnh_calc_all_growths_end.restype = C.c_int64
+    L.pnh_calc_all_growths_end.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]
+    out = np.zeros((T, max(n, 1)), dtype=np.float64)
+    L.pnh_calc_all_growths_end(handle, n, T, out.ctypes.data_as(C.POINTER(C.c_double)))
+    return [out[t, :n].copy() for t in range(T)]
+
+
 def calc_all_growths(hist, thresholds, n_threads: int = 0):
     """Hist::calc_all_growths (hist.rs:68-87): one curve per (coverage, quorum) pair, NaN row 0."""
     curves = calc_growths(hist, list(zip(thresholds.coverage, thresholds.quorum)), n_threads)
