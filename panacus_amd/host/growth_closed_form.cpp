@@ -164,6 +164,7 @@ struct Job {
     // term1[i][m]: the perc_mult-type term (union / core / quorum's "100 %" part)
     // term2[i][m]: the quorum branch's [m_quorum, 100 %) part; NaN = "no admissible j" (add == false)
     const double *sumq = nullptr;  // from the device (pinned, owned by the context): (n+1) x (n+1), NaN = no admissible j
+    std::vector<double> sumq_own;  // ... or a copy of it, when several jobs of a region are offloaded
     ScratchPool::Buf buf1, buf2;
     double *term1 = nullptr, *term2 = nullptr;  // left uninitialised: every entry that is read is written by its row
     std::vector<double> out;
@@ -312,6 +313,10 @@ struct Offload {
     Job *job = nullptr;
 };
 
+bool offload_eligible(const Job &j, uint64_t min_n) {
+    return j.branch == QUORUM && j.n >= min_n && j.n <= 8192 && exp2_restatement_matches_libm();
+}
+
 Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
     Offload o;
     uint64_t min_n = 0;
@@ -322,7 +327,7 @@ Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
     }
     if (!o.ctx) return o;
     for (auto &j : jobs) {
-        if (j->branch != QUORUM || j->n < min_n || j->n > 8192 || !exp2_restatement_matches_libm()) continue;
+        if (!offload_eligible(*j, min_n)) continue;
         std::vector<uint32_t> mq(j->n + 1);
         for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
         if (pnx_quorum_sums_async(o.ctx, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
@@ -333,10 +338,39 @@ Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
     return o;
 }
 
-void finish_offload(const Offload &o) {
+
+// waits for the enqueued job; further eligible jobs of the region follow one at a time (the
+// context has one result buffer, so results are copied out when there is more than one)
+void finish_offload(const Offload &o, std::vector<std::unique_ptr<Job>> &jobs) {
     if (!o.job) return;
+    uint64_t min_n = 0;
+    {
+        std::lock_guard<std::mutex> g(g_offload_mu);
+        min_n = g_offload_min_n;
+    }
+    std::vector<Job *> more;
+    for (auto &j : jobs)
+        if (j.get() != o.job && offload_eligible(*j, min_n)) more.push_back(j.get());
     const double *res = nullptr;
-    if (pnx_quorum_sums_fetch(o.ctx, &res) == 0) o.job->sumq = res;  // any device error: the host path
+    if (pnx_quorum_sums_fetch(o.ctx, &res) != 0) return;  // any device error: the host path
+    auto keep = [&](Job *j) {
+        if (more.empty()) {
+            j->sumq = res;
+        } else {
+            j->sumq_own.assign(res, res + (j->n + 1) * (j->n + 1));
+            j->sumq = j->sumq_own.data();
+        }
+    };
+    keep(o.job);
+    for (Job *j : more) {
+        std::vector<uint32_t> mq(j->n + 1);
+        for (uint64_t m = 0; m <= j->n; ++m) mq[m] = (uint32_t)j->m_quorum[m];
+        if (pnx_quorum_sums_async(o.ctx, (uint32_t)j->n, (uint32_t)j->c, mq.data(), j->lg->v.data(), j->m_fact.data(),
+                                  j->n_fall.data()) != 0 ||
+            pnx_quorum_sums_fetch(o.ctx, &res) != 0)
+            continue;
+        keep(j);
+    }
 }
 
 std::vector<std::vector<double>> run_jobs(std::vector<std::unique_ptr<Job>> &jobs, unsigned n_threads) {
@@ -438,7 +472,7 @@ std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *handle) {
     std::unique_ptr<GrowthRun> run(handle);
     if (!run) return {};
     if (run->hist.size() < 2) return std::vector<std::vector<double>>(run->n_pairs);
-    finish_offload(run->off);
+    finish_offload(run->off, run->jobs);
     return run_jobs(run->jobs, run->n_threads);
 }
 
@@ -453,7 +487,7 @@ static std::vector<double> one(Branch b, const std::vector<uint64_t> &hist, Thre
     auto tab = std::make_shared<Log2Table>(2 * (hist.size() - 1) + 2);
     std::vector<std::unique_ptr<Job>> jobs;
     jobs.emplace_back(new Job(b, hist, c, q, tab));
-    finish_offload(start_offload(jobs));
+    finish_offload(start_offload(jobs), jobs);
     return run_jobs(jobs, n_threads)[0];
 }
 
