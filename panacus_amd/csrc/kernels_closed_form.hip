@@ -47,7 +47,9 @@ __global__ __launch_bounds__(64) void k_quorum_terms(uint32_t n, uint32_t c, uin
     for (uint32_t m = j + 1; m <= n; ++m) {
         uint32_t jlo, jhi;
         j_range(n, c, m_quorum[m], i, m, jlo, jhi);
-        if (j < jlo || j >= jhi) continue;
+        // the lower bound only rises with m (m_quorum and i + m - n do), and j < m, j <= i hold in
+        // this loop: once j falls below it, no later m is admissible
+        if (j < jlo || j >= jhi) break;
         if (q == 0.0) {  // choose(i, j), hist.rs:21-36: res += log2(i - a); res -= log2(a + 1)
             const uint32_t k = j > i - j ? i - j : j;
             double res = 0.0;
