@@ -53,7 +53,12 @@ def _random_graph(rng, n, p):
     return items, pre
 
 
-@pytest.mark.parametrize("seed", range(64))
+import os
+
+N_SEEDS = int(os.environ.get("PANACUS_FUZZ_SEEDS", "64"))  # more seeds for a soak run
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_graph_matches_oracle(ctx, seed):
     from panacus_amd import capi
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
