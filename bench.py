@@ -94,8 +94,8 @@ def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_re
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--paths", type=int, default=256)
     ap.add_argument("--seed", type=int, default=42)
