@@ -8,20 +8,25 @@
 // (abacus.rs:859-986).
 //
 // Design (HBM-bound integer set work; no MFMA):
-//   * the item id space is cut into tiles of WT*2048 ids; ONE WAVE owns one tile for the
-//     whole kernel, so no global atomics and no inter-workgroup traffic exist on the fast
-//     path, and a workgroup (4 waves) never needs __syncthreads();
-//   * K0 finds, for every (path, tile boundary), where the path's steps cross the boundary
-//     (binary search; exact for tile-monotone paths, verified by K1);
-//   * K1 streams each (path, tile) segment of the CSR exactly once with 16 B/lane coalesced
-//     loads, ORs presence bits into a per-wave 256 B LDS bitmap (ds_or_b32; dedupes repeated
-//     visits inside a group for free), and at every group change folds the bitmap into
-//     bit-sliced vertical counters held in registers (carry-save ripple adder: NPL planes);
+//   * the item id space is cut into tiles of WT*2048 ids; a tile is owned by ONE WAVE (or, split,
+//     by the SPLIT waves of one workgroup, each with a group-aligned part of the visiting order)
+//     for the whole kernel, so no global atomics and no inter-workgroup traffic exist on the fast
+//     path; the split waves meet once, at the very end, to add their counters;
+//   * K0 finds, for every path and every tile boundary inside the path's id range, where the
+//     path's steps cross the boundary (value-interpolating sector search; exact for
+//     tile-monotone paths, verified by K1);
+//   * K1 keeps 64 entries of the visiting order per wave (segment start, length, group), visits
+//     the non-empty segments and the group changes only, streams each (path, tile) segment of the
+//     CSR exactly once with 16 B/lane non-temporal loads, ORs presence bits into a per-wave 256 B
+//     LDS bitmap (ds_or_b32; dedupes repeated visits inside a group for free), and at every
+//     group change folds the bitmap into bit-sliced vertical counters held in registers
+//     (carry-save ripple adder: NPL planes);
 //   * at the end the counters are unpacked to the u32 coverage vector with coalesced
 //     stores; K2 turns it into the (optionally bp-weighted) histogram in LDS;
-//   * paths that are not tile-monotone (edge ids, cyclic walks) are detected, not assumed
-//     away: they take the scatter route (global atomicOr into the presence matrix, merged by
-//     K1 at flush time) and the pass is re-run when a violation is first seen.
+//   * paths that are not tile-monotone are detected, not assumed away: nearly monotone ones are
+//     cut into per-tile runs (kernels_runs.hip) that the tile's wave consumes at flush time,
+//     short-run ones (edge ids) take the scatter route (global atomicOr into the presence
+//     matrix, merged by K1 at flush time); the pass is re-run when a violation is first seen.
 #include <cstdlib>
 
 #include "pnx_context.hpp"
@@ -54,10 +59,11 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: tile boundary index (two passes, see k_tile_index_coarse / k_tile_index_fine).  B[p][t] = path_off[p] + (#steps of p "before" tile t), where
-// "before" means id < t*tile_items for an ascending path and id >= t*tile_items for a
-// descending one (direction = first step vs last step).  For a tile-monotone path the steps
-// of tile t are exactly [min(B[t],B[t+1]), max(B[t],B[t+1])).
+// K0: tile boundary index (two passes, see k_tile_index_coarse / k_tile_index_fine).  The
+// boundary of tile t in path p = path_off[p] + (#steps of p "before" tile t), where "before"
+// means id < t*tile_items for an ascending path and id >= t*tile_items for a descending one
+// (direction = first step vs last step).  For a tile-monotone path the steps of tile t are
+// exactly [min(B[t],B[t+1]), max(B[t],B[t+1])).
 // ------------------------------------------------------------------------------------------
 template <bool ASC>
 __device__ static inline bool before_key(uint32_t v, uint64_t key) {
