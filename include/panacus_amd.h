@@ -202,19 +202,18 @@ enum {
     PNX_CFG_TILE_BLOCKS = 2,   /* 1 or 2 blocks of 2048 items per coverage tile (default 1) */
     PNX_CFG_KEEP_PRESENCE = 3, /* 1: pnx_hist also leaves the presence bit matrix in HBM
                                   (default 0; pnx_ordered_growth turns it on by itself) */
-    PNX_CFG_INDEX_COARSE = 5,  /* every n-th tile boundary is found by a full binary search, the
-                                  ones in between by interpolation inside that bracket [8];
-                                  1 = plain binary search for all */
+    PNX_CFG_INDEX_COARSE = 5,  /* every n-th tile boundary of a path is located inside the whole path, the
+                                  ones in between inside that bracket [8]; 1 = one level */
     PNX_CFG_USE_WEIGHTS = 7,   /* weights were uploaded: 1 = count them (bp), 0 = count items (node) on the
                                   same resident CSR -- `hist -c all` uploads the graph once */
-    PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the coverage kernel: 1, 2, 4 [default], 8 */
+    PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the unsplit coverage kernel: 1, 2, 4 [default], 8 */
     PNX_CFG_COVER_SPLIT = 9,   /* waves per item tile of the coverage kernel (each takes a group-aligned part of
                                   the visiting order): 0 = chosen from #tiles and #CUs [default], 1, 2, 4, 8 */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */
-    PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain, 1 software-pipelined (two segments
-                                  in flight per wave), 2 pipelined + non-temporal CSR loads */
+    PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain (the simple form, kept as a cross-check), 1 software-
+                                  pipelined, 2 [default] pipelined + non-temporal CSR loads + split tiles */
 };
 int pnx_config(pnx_ctx *ctx, int key, int64_t value);
 
