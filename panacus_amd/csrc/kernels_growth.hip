@@ -33,6 +33,7 @@ constexpr int GROW_WAVES = 4;
 constexpr int GROW_PREFETCH = 16;  // row slices in flight per wave
 constexpr int GROW_Q0_MAX = 4;     // q == 0 threshold pairs handled by one launch
 constexpr int WPLANES_MAX = 32;
+constexpr int GROW_EVQ = 128;  // bp: flip events queued per wave before they are applied
 
 // full-wave sum, result valid in lane 63 (gfx9 DPP: row_shr within rows of 16, then row_bcast)
 __device__ static inline uint32_t wave_sum_to_lane63(uint32_t v) {
@@ -254,6 +255,9 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
     uint32_t *stage = stage_all + wave * NA * (B / 2);
     uint32_t *wp = wp_all + (size_t)wave * (WMODE == 1 ? 1024 : 2048);
     uint16_t *wp16 = reinterpret_cast<uint16_t *>(wp);
+    constexpr int EVW = 1 + NA + NQ;  // event: (rank << 8 | lane), up mask per accumulator, down mask per quorum pair
+    uint32_t *evq = wp_all + (size_t)GROW_WAVES * (WMODE == 1 ? 1024 : 2048) + (size_t)wave * GROW_EVQ * EVW;
+    uint32_t qn = 0;  // events in the queue (wave-uniform)
     const char *Mb = reinterpret_cast<const char *>(M);
 
     for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) acc[i] = 0;
@@ -284,43 +288,80 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
         uint32_t prevv[NQ > 0 ? NQ : 1];
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) prevv[qi] = 0;
-        // one bit loop per rank for all accumulators (branch-free inside: the scalar unit is the
-        // scarce resource of this kernel), then one LDS atomic per accumulator that changed
+        // A lane whose masks flip at this rank queues ONE event (rank, lane, masks); the queue is
+        // applied by all 64 lanes in parallel -- one event per lane -- when it fills up and at the
+        // end of the block.  The rank loop itself stays free of per-lane loops: flips are rare
+        // (about two events per item and order), so doing them where they occur would make every
+        // rank pay for the slowest lane.
+        auto apply_events = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t e = lane; e < qn; e += 64) {
+                const uint32_t *ev = evq + (size_t)e * EVW;
+                const uint32_t hdr = ev[0];
+                const uint32_t j = hdr >> 8, el = hdr & 63u;
+                uint32_t up[NA > 0 ? NA : 1], dn[NQ > 0 ? NQ : 1];
+                uint32_t any = 0;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    up[a] = ev[1 + a];
+                    any |= up[a];
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    dn[qi] = ev[1 + NA + qi];
+                    any |= dn[qi];
+                }
+                unsigned long long d[NA > 0 ? NA : 1];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) d[a] = 0;
+                while (any) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(any);
+                    any &= any - 1;
+                    const unsigned long long w = WMODE == 1 ? (uint32_t)wp16[b * 64 + el] : wp[b * 64 + el];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) d[a] += ((up[a] >> b) & 1u) ? w : 0ull;
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) d[N0 + qi] -= ((dn[qi] >> b) & 1u) ? w : 0ull;
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+                    if (d[a]) atomicAdd(&acc[(size_t)a * G + j], d[a]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qn = 0;
+        };
         auto weighted_rank = [&](const uint32_t (&val)[NA > 0 ? NA : 1], uint32_t j) {
-            uint32_t up[NA > 0 ? NA : 1], dn[NA > 0 ? NA : 1];
+            uint32_t up[NA > 0 ? NA : 1], dn[NQ > 0 ? NQ : 1];
             uint32_t any = 0;
 #pragma unroll
             for (int a = 0; a < N0; ++a) {
                 up[a] = val[a];
-                dn[a] = 0;
                 any |= up[a];
             }
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
                 const uint32_t cur = val[N0 + qi];
                 up[N0 + qi] = cur & ~prevv[qi];
-                dn[N0 + qi] = prevv[qi] & ~cur;
+                dn[qi] = prevv[qi] & ~cur;
                 prevv[qi] = cur;
-                any |= up[N0 + qi] | dn[N0 + qi];
+                any |= up[N0 + qi] | dn[qi];
             }
-            if (any) {
-                unsigned long long d[NA > 0 ? NA : 1];
+            const unsigned long long bal = __ballot(any != 0);
+            if (bal) {
+                if (any) {
+                    const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    uint32_t *ev = evq + (size_t)pos * EVW;
+                    ev[0] = (j << 8) | lane;
 #pragma unroll
-                for (int a = 0; a < NA; ++a) d[a] = 0;
-                uint32_t m = any;
-                while (m) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1;
-                    const unsigned long long w = WMODE == 1 ? (uint32_t)wp16[b * 64 + lane] : wp[b * 64 + lane];
+                    for (int a = 0; a < NA; ++a) ev[1 + a] = up[a];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        d[a] += ((up[a] >> b) & 1u) ? w : 0ull;
-                        if (a >= N0) d[a] -= ((dn[a] >> b) & 1u) ? w : 0ull;
-                    }
+                    for (int qi = 0; qi < NQ; ++qi) ev[1 + NA + qi] = dn[qi];
                 }
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-                    if (d[a]) atomicAdd(&acc[(size_t)a * G + j], d[a]);
+                qn += (uint32_t)__builtin_popcountll(bal);
+                if (qn > (uint32_t)(GROW_EVQ - 64)) apply_events();
             }
         };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
@@ -419,6 +460,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
                 }
             }
         }
+        if (WEIGHTED && qn) apply_events();  // the next block brings its own weights
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) {
@@ -589,7 +631,8 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
                 tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
-            const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wl_bytes;
+            const size_t evq_bytes = ctx->weighted ? (size_t)GROW_WAVES * GROW_EVQ * (1 + n0 + 2 * nq) * 4 : 0;
+            const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wl_bytes + evq_bytes;
             if (shmem > 150 * 1024)
                 return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %d threshold pairs exceed the LDS accumulators",
                                  G, n0 + nq);
