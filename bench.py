@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
     ap.add_argument("--no-quorum-offload", action="store_true")
+    ap.add_argument("--quorum-offload-min-n", type=int, default=512)
     args = ap.parse_args()
 
     import torch
@@ -216,7 +217,7 @@ def main():
     # large group counts: the O(n^3) inner sums of the quorum closed form run on the GPU
     # (bit-identical, see csrc/kernels_closed_form.hip); below 512 groups the host is faster
     if rank == 0 and not args.no_quorum_offload:
-        hostlib.set_quorum_offload(ctx, 512)
+        hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
 
     def growth_begin(h):
         """rank 0: set the closed forms up and enqueue their device part (if any) behind the pass

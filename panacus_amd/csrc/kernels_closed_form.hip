@@ -34,13 +34,38 @@ __host__ __device__ static inline void j_range(uint32_t n, uint32_t c, uint32_t 
     if (i < mq || i >= n || jlo > jhi) jhi = jlo;                 // empty
 }
 
-// terms[(i_local * (n + 1) + m) * (n + 1) + j]
-__global__ __launch_bounds__(64) void k_quorum_terms(uint32_t n, uint32_t c, uint32_t i0, uint32_t i1,
-                                                      const uint32_t *__restrict__ m_quorum,
-                                                      const double *__restrict__ L, const double *__restrict__ m_fact,
-                                                      const double *__restrict__ n_fall, double *__restrict__ terms) {
+// terms[(i_local * (n + 1) + m) * (n + 1) + j].  One workgroup = one i and 256 consecutive j; the
+// four small tables every step of the m loop reads (log2, m_fact, n_fall, m_quorum) are staged in
+// LDS first when they fit (LDS_TABLES): the loop is a chain of dependent table reads, and from
+// global memory it ran at their latency (1.26 ms for n = 1024).
+template <bool LDS_TABLES>
+__global__ __launch_bounds__(256) void k_quorum_terms(uint32_t n, uint32_t c, uint32_t i0, uint32_t i1,
+                                                       const uint32_t *__restrict__ g_mq,
+                                                       const double *__restrict__ g_L, const double *__restrict__ g_mf,
+                                                       const double *__restrict__ g_nf, double *__restrict__ terms) {
+    extern __shared__ double sh_tab[];
+    __shared__ uint64_t s_exp2[256];  // the exp2 table is read twice per term at a lane-dependent index
+    s_exp2[threadIdx.x] = c_exp2_tab[threadIdx.x];
+    if (!LDS_TABLES) __syncthreads();
     const uint32_t i = i0 + blockIdx.x;
-    const uint32_t j = blockIdx.y * 64 + threadIdx.x;
+    const uint32_t j = blockIdx.y * 256 + threadIdx.x;
+    const double *L = g_L, *m_fact = g_mf, *n_fall = g_nf;
+    const uint32_t *m_quorum = g_mq;
+    if (LDS_TABLES) {
+        double *sL = sh_tab, *smf = sL + 2 * (n + 1), *snf = smf + (n + 1);
+        uint32_t *smq = reinterpret_cast<uint32_t *>(snf + (n + 1));
+        for (uint32_t k = threadIdx.x; k < 2 * (n + 1); k += 256) sL[k] = g_L[k];
+        for (uint32_t k = threadIdx.x; k <= n; k += 256) {
+            smf[k] = g_mf[k];
+            snf[k] = g_nf[k];
+            smq[k] = g_mq[k];
+        }
+        __syncthreads();
+        L = sL;
+        m_fact = smf;
+        n_fall = snf;
+        m_quorum = smq;
+    }
     if (i >= i1 || j > i || j >= n) return;
     double q = 0.0;
     double *row = terms + (size_t)(i - i0) * (n + 1) * (n + 1);
@@ -62,35 +87,59 @@ __global__ __launch_bounds__(64) void k_quorum_terms(uint32_t n, uint32_t c, uin
         q = pnx_exp2::add(q, L[n - i - m + 1 + j]);  // hist.rs:171
         q = pnx_exp2::sub(q, L[m - j]);              // hist.rs:172
         const double x = pnx_exp2::sub(pnx_exp2::add(q, m_fact[m]), n_fall[m]);
-        row[(size_t)m * (n + 1) + j] = pnx_exp2::exp2_exact(x, c_exp2_tab);
+        row[(size_t)m * (n + 1) + j] = pnx_exp2::exp2_exact(x, s_exp2);
     }
 }
 
-// sum_q[i * (n + 1) + m], NaN where no j is admissible (add == false)
-__global__ __launch_bounds__(256) void k_quorum_sums(uint32_t n, uint32_t c, uint32_t i0, uint32_t i1,
-                                                      const uint32_t *__restrict__ m_quorum,
-                                                      const double *__restrict__ terms, double *__restrict__ sum_q) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t n_pairs = (uint64_t)(i1 - i0) * n;  // m = 1..n
-    if (wid >= n_pairs) return;
-    const uint32_t i = i0 + (uint32_t)(wid / n), m = (uint32_t)(wid % n) + 1;
-    uint32_t jlo, jhi;
-    j_range(n, c, m_quorum[m], i, m, jlo, jhi);
-    const double *row = terms + ((size_t)(i - i0) * (n + 1) + m) * (n + 1);
-    double s = 0.0;
-    for (uint32_t b = jlo; b < jhi; b += 64) {
-        const uint32_t j = b + lane;
-        const double t = j < jhi ? row[j] : 0.0;
-        const uint32_t cnt = jhi - b < 64 ? jhi - b : 64;
-        // one lane adds the 64 terms in ascending j: the reference's order
-        for (uint32_t u = 0; u < cnt; ++u) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pnx_exp2::as_u64(t), u);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pnx_exp2::as_u64(t) >> 32), u);
-            s = pnx_exp2::add(s, pnx_exp2::as_f64(((uint64_t)hi << 32) | lo));
-        }
+// sum_q[i * (n + 1) + m], NaN where no j is admissible (add == false).  One wave = one i and 64
+// consecutive m, one lane per m: every lane adds the terms of its own m in ascending j -- the
+// reference's order -- but the terms come in through LDS in tiles of 64 m x 32 j, so that the
+// global reads are whole 256-byte row pieces (a lane walking its own row would touch 8 bytes of
+// every 64-byte sector, and one wave per (i, m) spends three instructions per term).
+constexpr int QS_J = 32;
+__global__ __launch_bounds__(64) void k_quorum_sums(uint32_t n, uint32_t c, uint32_t i0, uint32_t i1,
+                                                     const uint32_t *__restrict__ m_quorum,
+                                                     const double *__restrict__ terms, double *__restrict__ sum_q) {
+    __shared__ double tile[64][QS_J + 1];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = i0 + blockIdx.x;
+    const uint32_t m0 = blockIdx.y * 64 + 1;  // m = m0 .. m0 + 63
+    if (i >= i1) return;
+    const uint32_t m = m0 + lane;
+    uint32_t jlo = 0, jhi = 0;
+    if (m <= n) j_range(n, c, m_quorum[m], i, m, jlo, jhi);
+    // union of the j ranges of the 64 lanes
+    uint32_t lo_all = jlo < jhi ? jlo : 0xFFFFFFFFu, hi_all = jlo < jhi ? jhi : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lo_all, o), b = __shfl_xor(hi_all, o);
+        lo_all = a < lo_all ? a : lo_all;
+        hi_all = b > hi_all ? b : hi_all;
     }
-    if (lane == 0) sum_q[(size_t)i * (n + 1) + m] = jlo < jhi ? s : pnx_exp2::as_f64(0x7ff8000000000000ull);
+    const double *base = terms + (size_t)(i - i0) * (n + 1) * (n + 1);
+    double s = 0.0;
+    const uint32_t half = lane >> 5, jj = lane & 31u;
+    for (uint32_t jb = lo_all & ~(uint32_t)(QS_J - 1); jb < hi_all; jb += QS_J) {
+        // rows r and r + 1 per step: lanes 0..31 / 32..63 read 32 consecutive j of one row each
+        for (uint32_t r = 0; r < 64; r += 2) {
+            const uint32_t rr = r + half, mr = m0 + rr;
+            // only the entries K7a wrote are read: the range of row rr, known to lane rr
+            const uint32_t rlo = __shfl(jlo, rr), rhi = __shfl(jhi, rr);
+            const uint32_t j = jb + jj;
+            double v = 0.0;
+            if (mr <= n && j >= rlo && j < rhi) v = base[(size_t)mr * (n + 1) + j];
+            tile[rr][jj] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+        for (uint32_t k = 0; k < (uint32_t)QS_J; ++k) {
+            const uint32_t j = jb + k;
+            if (j >= jlo && j < jhi) s = pnx_exp2::add(s, tile[lane][k]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (m <= n) sum_q[(size_t)i * (n + 1) + m] = jlo < jhi ? s : pnx_exp2::as_f64(0x7ff8000000000000ull);
 }
 
 __global__ void k_exp2_exact(const double *__restrict__ x, double *__restrict__ y, uint64_t n) {
@@ -144,11 +193,19 @@ int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *
     PNX_HIP(ctx, hipMemsetAsync(d_sum.p, 0xFF, out_bytes, ctx->stream));  // NaN everywhere
     for (uint32_t i0 = 0; i0 < n; i0 += slab) {
         const uint32_t i1 = std::min(n, i0 + slab);
-        hipLaunchKernelGGL(k_quorum_terms, dim3(i1 - i0, (n + 63) / 64), dim3(64), 0, ctx->stream, n, c, i0, i1, d_mq,
-                           d_L, d_mf, d_nf, (double *)d_terms.p);
-        const uint64_t n_pairs = (uint64_t)(i1 - i0) * n;
-        hipLaunchKernelGGL(k_quorum_sums, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, ctx->stream, n, c, i0, i1,
-                           d_mq, (const double *)d_terms.p, (double *)d_sum.p);
+        const size_t tab_bytes = (4 * np1) * sizeof(double) + np1 * sizeof(uint32_t);
+        if (tab_bytes <= 96 * 1024) {
+            if (tab_bytes > 64 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quorum_terms<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes);
+            hipLaunchKernelGGL(k_quorum_terms<true>, dim3(i1 - i0, (n + 255) / 256), dim3(256), tab_bytes, ctx->stream, n,
+                               c, i0, i1, d_mq, d_L, d_mf, d_nf, (double *)d_terms.p);
+        } else {
+            hipLaunchKernelGGL(k_quorum_terms<false>, dim3(i1 - i0, (n + 255) / 256), dim3(256), 0, ctx->stream, n, c, i0,
+                               i1, d_mq, d_L, d_mf, d_nf, (double *)d_terms.p);
+        }
+        hipLaunchKernelGGL(k_quorum_sums, dim3(i1 - i0, (n + 63) / 64), dim3(64), 0, ctx->stream, n, c, i0, i1, d_mq,
+                           (const double *)d_terms.p, (double *)d_sum.p);
         PNX_HIP(ctx, hipGetLastError());
     }
     // results go to pinned host memory owned by the context (8 MB at n = 1024: a pageable copy
