@@ -338,6 +338,8 @@ def main():
                 "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
                 "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
+                "quorum_inner_sums_on_gpu": bool(not args.no_quorum_offload and P >= args.quorum_offload_min_n
+                                                 and hostlib.quorum_offload_usable()),
                 "single_pass_latency": latency_ms,
             },
             "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,
