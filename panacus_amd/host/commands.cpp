@@ -57,7 +57,9 @@ struct Device {  // RAII over pnx_ctx
     explicit Device(int ordinal) {
         int rc = pnx_init(&ctx, ordinal);
         if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
-        set_quorum_offload(ctx);  // quorum closed form with >= 512 groups: inner sums on this GPU
+        // quorum closed form with >= 512 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
+        // the whole closed form on the host threads; the results are the same bits either way)
+        if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(ctx);
     }
     ~Device() {
         set_quorum_offload(nullptr);
