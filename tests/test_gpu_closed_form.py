@@ -68,3 +68,35 @@ def test_quorum_growth_offload_large_n(ctx):
         hostlib.set_quorum_offload(None)
     for a, b in zip(got, host_only):
         assert a.tobytes() == b.tobytes()
+
+
+def test_cli_histgrowth_many_groups_uses_the_offload(tmp_path):
+    """520 paths: the CLI's quorum closed form takes the GPU path; output == oracle, and == the
+    host-only run (PANACUS_AMD_HOST_GROWTH=1)"""
+    import math
+    import os
+    from panacus_amd import hostlib as hl
+    gfa = str(tmp_path / "many.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "3000", "--paths", "520", "--seed", "3", "-o", gfa])
+    assert rc == 0, err
+    args = ["histgrowth", "-c", "node", "-l", "1,2", "-q", "0.5,0.1", "-a", gfa]
+    rc, out, err = hl.run_cli(args)
+    assert rc == 0, err
+    os.environ["PANACUS_AMD_HOST_GROWTH"] = "1"
+    try:
+        rc, out_host, err = hl.run_cli(args)
+    finally:
+        del os.environ["PANACUS_AMD_HOST_GROWTH"]
+    assert rc == 0, err
+    body = lambda t: [l.split("\t") for l in t.split("\n") if l and not l.startswith("#")]
+    rows, rows_host = body(out), body(out_host)
+    assert rows == rows_host
+    g = orc.Graph(gfa)
+    pi, gi, names = g.path_order(orc.GROUP_PATHID)
+    assert len(names) == 520
+    items, pre = g.item_table(orc.NODE)
+    h = orc.hist(orc.coverage(items, pre, pi, gi, g.n_nodes), 520)
+    assert [int(r[1]) for r in rows[4:]] == h.tolist()
+    for k, (c, q) in enumerate(((1, 0.5), (2, 0.1))):
+        exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+        assert [r[2 + k] for r in rows[5:]] == [hl.format_f64(math.floor(x)) for x in exp], (c, q)
