@@ -152,6 +152,12 @@ struct TileIdx {
     const uint32_t *tspan;   // n_paths, 0 = empty path
 };
 
+// the same per entry of the visiting order (filled by k_count_general for every pass)
+struct OrdIdx {
+    uint32_t *tfirst, *tspan;  // n_ordered each
+    uint64_t *off;             // n_ordered
+};
+
 __global__ void k_path_spans(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                              uint32_t n_paths, uint32_t tile_items, uint32_t *__restrict__ tfirst,
                              uint32_t *__restrict__ tspan) {
@@ -278,6 +284,10 @@ static int ensure_path_spans(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+static OrdIdx ord_idx_view(const pnx_ctx *ctx) {
+    return OrdIdx{(uint32_t *)ctx->d_ord_tfirst.p, (uint32_t *)ctx->d_ord_tspan.p, (uint64_t *)ctx->d_ord_off.p};
+}
+
 static TileIdx tile_idx_view(const pnx_ctx *ctx) {
     return TileIdx{(const uint64_t *)ctx->d_tile_idx.p, (const uint64_t *)ctx->d_idx_off.p,
                    (const uint32_t *)ctx->d_tfirst.p, (const uint32_t *)ctx->d_tspan.p};
@@ -317,13 +327,22 @@ int launch_tile_index(pnx_ctx *ctx) {
 // ------------------------------------------------------------------------------------------
 // general (non tile-monotone) paths: bookkeeping + scatter route
 // ------------------------------------------------------------------------------------------
+// Also lays the index of the ordered paths out in VISITING order (first tile, tiles spanned --
+// 0 unless the path takes the tile route -- and row offset): the coverage kernel scans the order
+// 64 entries at a time, and reading these per entry through the path id would be three dependent
+// scattered gathers per window.
+
 __global__ void k_count_general(const uint8_t *__restrict__ path_class,
                                 const uint32_t *__restrict__ ord_path,
                                 const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
-                                uint8_t *grp_general, uint32_t *flags) {
+                                uint8_t *grp_general, uint32_t *flags, TileIdx ix, OrdIdx oi) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_ordered) return;
-    const uint8_t cls = path_class[ord_path[k]];
+    const uint32_t p = ord_path[k];
+    const uint8_t cls = path_class[p];
+    oi.tfirst[k] = ix.tfirst[p];
+    oi.tspan[k] = cls == 0 ? ix.tspan[p] : 0u;
+    oi.off[k] = ix.off[p];
     if (cls == 1) atomicAdd(&flags[2], 1u);        // not classified yet: this pass cannot be valid
     else if (cls == 2) atomicAdd(&flags[3], 1u);   // run route
     else if (cls == 3) {                           // scatter route: K1 merges the row of M
@@ -448,7 +467,7 @@ __device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint
 
 template <int NPL, int WT, bool WRITE_M>
 __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
-    const uint32_t *__restrict__ items, TileIdx ix,
+    const uint32_t *__restrict__ items, TileIdx ix, OrdIdx,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
@@ -613,7 +632,7 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 // tiles for 6144 wave slots, and one wave per tile is a long serial chain of segments.
 template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1>
 __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
-    const uint32_t *__restrict__ items, TileIdx ix,
+    const uint32_t *__restrict__ items, TileIdx ix, OrdIdx oi,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
@@ -734,13 +753,12 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
         win_base = base;
         const uint32_t k = base + lane;
         const bool in = k < k_hi;
-        const uint32_t p = in ? ord_path[k] : 0u;
         w_g = in ? ord_group[k] : 0xFFFFFFFFu;
         uint64_t ba = 0, bb = 0;
-        if (in && path_class[p] == 0) {
-            const uint32_t jt = tile - ix.tfirst[p];  // wraps for tiles before the path's first one
-            if (jt < ix.tspan[p]) {
-                const uint64_t *row = ix.B + ix.off[p] + jt;
+        if (in) {
+            const uint32_t jt = tile - oi.tfirst[k];  // wraps for tiles before the path's first one
+            if (jt < oi.tspan[k]) {                   // 0 for paths that are not on the tile route
+                const uint64_t *row = ix.B + oi.off[k] + jt;
                 ba = row[0];
                 bb = row[1];
             }
@@ -750,7 +768,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
         w_len = (uint32_t)len;
         if (len > 0xFFFFFFFFull) {  // not a segment this kernel can stream: hand the path to the general routes
             w_len = 0;
-            path_class[p] = 1;
+            path_class[ord_path[k]] = 1;
             atomicAdd(&flags[0], 1u);
         }
         uint32_t pg = __shfl_up(w_g, 1);
@@ -987,7 +1005,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
             sp.k[j] = (uint32_t)t;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, tile_idx_view(ctx),
+                           (const uint32_t *)ctx->d_items.p, tile_idx_view(ctx), ord_idx_view(ctx),
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
                            use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,
@@ -1072,6 +1090,10 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;
     if ((rc = ensure(ctx, ctx->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
+    const size_t no = ctx->n_ordered ? ctx->n_ordered : 1;
+    if ((rc = ensure(ctx, ctx->d_ord_tfirst, no * sizeof(uint32_t))) || (rc = ensure(ctx, ctx->d_ord_tspan, no * sizeof(uint32_t))) ||
+        (rc = ensure(ctx, ctx->d_ord_off, no * sizeof(uint64_t))))
+        return rc;
 
     // flags, histogram and per-group "general" marks of this pass: one clear
     PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->stream));
@@ -1081,7 +1103,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
         hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
                            (const uint8_t *)ctx->d_path_class.p, (const uint32_t *)ctx->d_ord_path.p,
                            (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
-                           ctx->cur->d_grp_general, ctx->cur->d_flags);
+                           ctx->cur->d_grp_general, ctx->cur->d_flags, tile_idx_view(ctx), ord_idx_view(ctx));
         if (use_m && m_words) {
             hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->stream,
                                (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->cur->d_flags);

@@ -237,7 +237,7 @@ void pnx_free(pnx_ctx *ctx) {
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_flags,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_ord_tfirst, &ctx->d_ord_tspan, &ctx->d_ord_off, &ctx->d_path_class, &ctx->d_flags,
                       &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
