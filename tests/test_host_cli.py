@@ -276,3 +276,21 @@ def test_cli_cache_gives_identical_tables(golden_dir, tmp_path):
         rc, second, err = hl.run_cli(args + ["--cache", gfa])  # served from the cache
         assert rc == 0, err
         assert _body(plain) == _body(first) == _body(second)
+
+
+@pytest.mark.gpu
+def test_multi_gpu_tool_matches_cli(golden_dir, tmp_path):
+    """tools/histgrowth_multi_gpu.py with one process == `panacus-amd histgrowth -a` (the N > 1 path adds
+    node-range shards and one all-reduce, covered by tests/test_distributed_gloo.py)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("hmg", os.path.join(root, "tools", "histgrowth_multi_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    for cname in ("node", "bp", "edge"):
+        out_file = str(tmp_path / f"t_{cname}.tsv")
+        text = mod.main(["-c", cname, "-l", "1,2", "-q", "0,0.5", "-S", "-o", out_file, gfa])
+        rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5", "-S", gfa])
+        assert rc == 0, err
+        assert text == _body(out).rstrip("\n") + "\n"
