@@ -209,6 +209,9 @@ enum {
     PNX_CFG_COVER_WAVES = 6,   /* waves (= item tiles) per workgroup of the unsplit coverage kernel: 1, 2, 4 [default], 8 */
     PNX_CFG_COVER_SPLIT = 9,   /* waves per item tile of the coverage kernel (each takes a group-aligned part of
                                   the visiting order): 0 = chosen from #tiles and #CUs [default], 1, 2, 4, 8 */
+    PNX_CFG_INDEX_BY_ENTRY = 10, /* thread numbering of the index kernels: 0 = automatic [default], 1 = one thread per
+                                  entry of the sparse index (graphs whose paths span very different numbers of
+                                  tiles), 2 = path-major (graphs whose paths all span about the same) */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */

@@ -175,19 +175,50 @@ __global__ void k_path_spans(const uint32_t *__restrict__ items, const uint64_t 
     tspan[p] = t1 - t0 + 1;
 }
 
+// Which (path, row position) a thread of the index kernels works on.  Dense graphs (every path
+// spans about as many tiles as the longest one) number their workgroups path-major: blockIdx =
+// p * bpp + chunk.  Skewed graphs (a few paths span the whole id space, thousands span a few
+// tiles) would launch paths x longest-span threads that way, so there (bpp == 0) a thread is one
+// entry of the sparse index and finds its path by binary search in the row offsets.
+__device__ static inline bool index_slot(const TileIdx &ix, uint32_t bpp, uint32_t n_paths, uint64_t n_entries,
+                                         uint32_t &p, uint32_t &j) {
+    if (bpp) {
+        p = blockIdx.x / bpp;
+        j = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+        return true;
+    }
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return false;
+    uint32_t lo = 0, hi = n_paths;  // last p with off[p] <= e
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ix.off[mid] <= e) lo = mid; else hi = mid;
+    }
+    p = lo;
+    j = (uint32_t)(e - ix.off[lo]);
+    return true;
+}
+
 // K0 pass A: every `coarse`-th boundary of a path's row (and the last one), located inside the
 // whole path.  Workgroups are numbered path-major: blockIdx = p * bpp + chunk.
 __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
-                                    uint32_t bpp, uint32_t tile_items, uint32_t coarse, uint64_t *__restrict__ B,
-                                    TileIdx ix, uint8_t *__restrict__ path_class) {
-    const uint32_t p = blockIdx.x / bpp;
-    const uint32_t c = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+                                    uint32_t bpp, uint32_t n_paths, uint64_t n_entries, uint32_t tile_items,
+                                    uint32_t coarse, uint64_t *__restrict__ B, TileIdx ix,
+                                    uint8_t *__restrict__ path_class) {
+    uint32_t p, c;
+    if (!index_slot(ix, bpp, n_paths, n_entries, p, c)) return;
     const uint32_t span = ix.tspan[p];
     if (c == 0) path_class[p] = 0;  // the later passes of the index only ever raise it
-    const uint32_t n_coarse = (span + coarse - 1) / coarse + 1;  // j = 0, c, 2c, ..., span
-    if (c >= n_coarse) return;
-    uint32_t j = c * coarse;
-    if (j > span) j = span;
+    uint32_t j;
+    if (bpp) {  // slot c = the c-th coarse boundary
+        const uint32_t n_coarse = (span + coarse - 1) / coarse + 1;  // j = 0, c, 2c, ..., span
+        if (c >= n_coarse) return;
+        j = c * coarse;
+        if (j > span) j = span;
+    } else {    // slot c = row position: only the coarse ones are filled here
+        j = c;
+        if (j % coarse != 0 && j != span) return;
+    }
     const uint64_t s = path_off[p], e = path_off[p + 1];
     uint64_t *out = B + ix.off[p] + j;
     if (e == s) {
@@ -217,10 +248,10 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const ui
 // inside the bracket, so the (path, tile) segments always partition the path; K1's per-step
 // in-tile check then catches every misplaced step.
 __global__ void k_tile_index_fine(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
-                                  uint32_t bpp, uint32_t tile_items, uint32_t coarse, uint64_t *__restrict__ B,
-                                  TileIdx ix, uint8_t *path_class) {
-    const uint32_t p = blockIdx.x / bpp;
-    const uint32_t j = (blockIdx.x % bpp) * blockDim.x + threadIdx.x;
+                                  uint32_t bpp, uint32_t n_paths, uint64_t n_entries, uint32_t tile_items,
+                                  uint32_t coarse, uint64_t *__restrict__ B, TileIdx ix, uint8_t *path_class) {
+    uint32_t p, j;
+    if (!index_slot(ix, bpp, n_paths, n_entries, p, j)) return;
     const uint32_t span = ix.tspan[p];
     if (j % coarse == 0 || j >= span) return;  // done by the coarse level
     const uint32_t j0 = j - j % coarse;
@@ -307,17 +338,27 @@ int launch_tile_index(pnx_ctx *ctx) {
         // rest inside those brackets
         const uint32_t coarse = ctx->index_coarse ? ctx->index_coarse : 1;
         const uint32_t n_coarse_max = (ctx->max_span + coarse - 1) / coarse + 1;
-        const uint32_t bpp_c = (n_coarse_max + 255) / 256;
-        const uint32_t bpp_f = (ctx->max_span + 1 + 255) / 256;
-        if ((uint64_t)bpp_f * ctx->n_paths > 0x7FFFFFFFull)
+        uint32_t bpp_c = (n_coarse_max + 255) / 256;
+        uint32_t bpp_f = (ctx->max_span + 1 + 255) / 256;
+        // path-major numbering launches paths x longest-row threads: fine when the rows are about
+        // equally long, hopeless when a few paths span everything and most span little
+        const uint64_t entry_blocks = (ctx->idx_entries + 255) / 256;
+        const bool by_entry = ctx->index_by_entry == 1 ||
+                              (ctx->index_by_entry == 0 && (uint64_t)bpp_f * ctx->n_paths > 4 * entry_blocks + 1024);
+        if (by_entry) bpp_c = bpp_f = 0;
+        const uint64_t grid_c = by_entry ? entry_blocks : (uint64_t)ctx->n_paths * bpp_c;
+        const uint64_t grid_f = by_entry ? entry_blocks : (uint64_t)ctx->n_paths * bpp_f;
+        if (grid_f > 0x7FFFFFFFull || grid_c > 0x7FFFFFFFull)
             return ctx->fail(PNX_ELIMIT, "tile index: %u paths x %u tiles exceed the grid", ctx->n_paths, ctx->max_span);
-        hipLaunchKernelGGL(k_tile_index_coarse, dim3(ctx->n_paths * bpp_c), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, tile_items,
-                           coarse, (uint64_t *)ctx->d_tile_idx.p, ix, (uint8_t *)ctx->d_path_class.p);
+        hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, ctx->n_paths,
+                           ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
+                           (uint8_t *)ctx->d_path_class.p);
         if (coarse > 1)
-            hipLaunchKernelGGL(k_tile_index_fine, dim3(ctx->n_paths * bpp_f), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, tile_items,
-                               coarse, (uint64_t *)ctx->d_tile_idx.p, ix, (uint8_t *)ctx->d_path_class.p);
+            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ctx->n_paths,
+                               ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
+                               (uint8_t *)ctx->d_path_class.p);
     }
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());

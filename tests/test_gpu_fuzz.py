@@ -94,6 +94,7 @@ def test_random_graph_matches_oracle(ctx, seed):
     gi = np.array(order_groups, dtype=np.uint64)
     G = len(seen)
     ctx.config(capi.CFG_TILE_BLOCKS, 1 + seed % 2 if seed % 5 == 0 else 1)
+    ctx.config(capi.CFG_INDEX_BY_ENTRY, seed % 3)  # automatic / per entry / path-major index kernels
     ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=excl)
     ctx.set_order(pi, gi, G)
     cnt, h = ctx.hist()
@@ -132,3 +133,4 @@ def test_random_graph_matches_oracle(ctx, seed):
             exp = orc.ordered_growth(rr, cc, G, (orc.ABSOLUTE, a), (orc.RELATIVE, q), w)
             assert out[ri, t].tolist() == [int(x) for x in exp], ("growth", ri, a, q)
     ctx.config(capi.CFG_TILE_BLOCKS, 1)
+    ctx.config(capi.CFG_INDEX_BY_ENTRY, 0)
