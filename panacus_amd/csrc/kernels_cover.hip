@@ -27,6 +27,7 @@
 //     cut into per-tile runs (kernels_runs.hip) that the tile's wave consumes at flush time,
 //     short-run ones (edge ids) take the scatter route (global atomicOr into the presence
 //     matrix, merged by K1 at flush time); the pass is re-run when a violation is first seen.
+#include <algorithm>
 #include <cstdlib>
 
 #include "pnx_context.hpp"
@@ -156,6 +157,7 @@ struct TileIdx {
 struct OrdIdx {
     uint32_t *tfirst, *tspan;  // n_ordered each
     uint64_t *off;             // n_ordered
+    uint32_t *win_lo, *win_hi; // per 64 entries: the tiles [lo, hi) reached by their tile-route paths
 };
 
 __global__ void k_path_spans(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
@@ -299,7 +301,9 @@ static int ensure_path_spans(pnx_ctx *ctx) {
         hipLaunchKernelGGL(k_path_spans, dim3((P + 255) / 256), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, P, tile_items,
                            (uint32_t *)ctx->d_tfirst.p, (uint32_t *)ctx->d_tspan.p);
+        ctx->h_tfirst.resize(P);
         PNX_HIP(ctx, hipMemcpyAsync(span.data(), ctx->d_tspan.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->h_tfirst.data(), ctx->d_tfirst.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     uint32_t mx = 0;
@@ -315,8 +319,41 @@ static int ensure_path_spans(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+// Within a group the order of the paths does not matter for any result (coverage counts groups,
+// the presence matrix and the runs are per group), so the paths of every group are put in the
+// order of their first tile once per (graph, order): 64 consecutive entries then reach a narrow
+// band of tiles, and a coverage wave can skip the windows whose band misses its tile.
+static int normalize_order(pnx_ctx *ctx) {
+    if (ctx->order_normalized) return PNX_OK;
+    const size_t n = ctx->h_ord_path.size();
+    if (n == ctx->n_ordered && n > 1 && ctx->h_tfirst.size() == ctx->n_paths) {
+        bool changed = false;
+        size_t a = 0;
+        while (a < n) {
+            size_t b = a + 1;
+            while (b < n && ctx->h_ord_group[b] == ctx->h_ord_group[a]) ++b;
+            auto key_less = [&](uint32_t x, uint32_t y) {
+                return ctx->h_tfirst[x] != ctx->h_tfirst[y] ? ctx->h_tfirst[x] < ctx->h_tfirst[y] : x < y;
+            };
+            if (b - a > 1 && !std::is_sorted(ctx->h_ord_path.begin() + a, ctx->h_ord_path.begin() + b, key_less)) {
+                std::sort(ctx->h_ord_path.begin() + a, ctx->h_ord_path.begin() + b, key_less);
+                changed = true;
+            }
+            a = b;
+        }
+        if (changed) {
+            PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_path.p, ctx->h_ord_path.data(), n * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice, ctx->stream));
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    ctx->order_normalized = true;
+    return PNX_OK;
+}
+
 static OrdIdx ord_idx_view(const pnx_ctx *ctx) {
-    return OrdIdx{(uint32_t *)ctx->d_ord_tfirst.p, (uint32_t *)ctx->d_ord_tspan.p, (uint64_t *)ctx->d_ord_off.p};
+    return OrdIdx{(uint32_t *)ctx->d_ord_tfirst.p, (uint32_t *)ctx->d_ord_tspan.p, (uint64_t *)ctx->d_ord_off.p,
+                  (uint32_t *)ctx->d_win_lo.p, (uint32_t *)ctx->d_win_hi.p};
 }
 
 static TileIdx tile_idx_view(const pnx_ctx *ctx) {
@@ -378,6 +415,25 @@ __global__ void k_count_general(const uint8_t *__restrict__ path_class,
                                 const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                 uint8_t *grp_general, uint32_t *flags, TileIdx ix, OrdIdx oi) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    {   // band of tiles of this wave's 64 entries (tile-route paths only)
+        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        if (k < n_ordered) {
+            const uint32_t p0 = ord_path[k];
+            if (path_class[p0] == 0 && ix.tspan[p0]) {
+                lo = ix.tfirst[p0];
+                hi = lo + ix.tspan[p0];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if ((threadIdx.x & 63) == 0 && (k >> 6) < (n_ordered + 63) / 64) {
+            oi.win_lo[k >> 6] = lo;
+            oi.win_hi[k >> 6] = hi;
+        }
+    }
     if (k >= n_ordered) return;
     const uint32_t p = ord_path[k];
     const uint8_t cls = path_class[p];
@@ -1133,8 +1189,11 @@ int launch_cover_pass(pnx_ctx *ctx) {
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
     const size_t no = ctx->n_ordered ? ctx->n_ordered : 1;
     if ((rc = ensure(ctx, ctx->d_ord_tfirst, no * sizeof(uint32_t))) || (rc = ensure(ctx, ctx->d_ord_tspan, no * sizeof(uint32_t))) ||
-        (rc = ensure(ctx, ctx->d_ord_off, no * sizeof(uint64_t))))
+        (rc = ensure(ctx, ctx->d_ord_off, no * sizeof(uint64_t))) ||
+        (rc = ensure(ctx, ctx->d_win_lo, ((no + 63) / 64) * sizeof(uint32_t))) ||
+        (rc = ensure(ctx, ctx->d_win_hi, ((no + 63) / 64) * sizeof(uint32_t))))
         return rc;
+    if ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx))) return rc;
 
     // flags, histogram and per-group "general" marks of this pass: one clear
     PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->stream));

@@ -101,6 +101,7 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->n_tiles = (ctx->n_blocks + ctx->tile_blocks - 1) / ctx->tile_blocks;
     ctx->index_valid = false;
     ctx->spans_valid = false;
+    ctx->order_normalized = false;
     ctx->wplanes_valid = false;
     ctx->last_general_paths = 0;
 }
@@ -237,7 +238,7 @@ void pnx_free(pnx_ctx *ctx) {
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_ord_tfirst, &ctx->d_ord_tspan, &ctx->d_ord_off, &ctx->d_path_class, &ctx->d_flags,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_ord_tfirst, &ctx->d_ord_tspan, &ctx->d_ord_off, &ctx->d_win_lo, &ctx->d_win_hi, &ctx->d_path_class, &ctx->d_flags,
                       &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
@@ -360,6 +361,7 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_group.p, group_id, (size_t)n_ordered * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned
     }
+    ctx->order_normalized = false;
     ctx->h_ord_path.assign(path_idx, path_idx + n_ordered);
     ctx->h_ord_group.assign(group_id, group_id + n_ordered);
     ctx->runs_sorted = false;  // run keys carry the group of the path

@@ -101,6 +101,9 @@ struct pnx_ctx {
     pnx::DevBuf d_tile_idx;    // sparse: sum over paths of (tiles spanned + 1) u64
     pnx::DevBuf d_tfirst, d_tspan, d_idx_off;  // per path: first tile, tiles spanned, row offset (n_paths + 1)
     pnx::DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off;  // the same per entry of the visiting order (rebuilt every pass)
+    pnx::DevBuf d_win_lo, d_win_hi;  // per 64 entries of the order: the tiles [lo, hi) their tile-route paths reach
+    std::vector<uint32_t> h_tfirst;  // host copy (order normalisation)
+    bool order_normalized = false;   // the paths of every group are sorted by their first tile
     bool spans_valid = false;  // the three arrays above match the resident CSR and tile size
     uint32_t max_span = 0;
     uint64_t idx_entries = 0;
