@@ -212,6 +212,9 @@ enum {
     PNX_CFG_INDEX_BY_ENTRY = 10, /* thread numbering of the index kernels: 0 = automatic [default], 1 = one thread per
                                   entry of the sparse index (graphs whose paths span very different numbers of
                                   tiles), 2 = path-major (graphs whose paths all span about the same) */
+    PNX_CFG_COVER_SKIP = 11,   /* plain histogram passes: skip the 64-entry windows of the order whose paths do not
+                                  reach a wave's tile: 0 = when the order has >= 4096 entries [default], 1 = always,
+                                  2 = never */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */

@@ -727,8 +727,13 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 // adds the others' bit-sliced counters (ripple-carry through LDS) before the write-out.  The
 // parallelism of the kernel is then tiles x SPLIT instead of tiles: 10 M items are only 4883
 // tiles for 6144 wave slots, and one wave per tile is a long serial chain of segments.
-template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1>
-__global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
+// SKIP (plain histogram passes only: no presence matrix, no runs, no scatter merge): a group that has
+// no segment in the tile needs no visit at all, so only non-empty segments are entries, and the
+// windows (aligned to 64 entries of the order) whose band of tiles misses the tile are never loaded
+// -- 64 bands are tested per step.  With the paths of a group sorted by their first tile
+// (normalize_order) a wave of a 100 000-contig graph loads a handful of windows per group.
+template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1, bool SKIP = false>
+__global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
     const uint32_t *__restrict__ items, TileIdx ix, OrdIdx oi,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
     auto load_window = [&](uint32_t base, uint32_t prev_group) {
         win_base = base;
         const uint32_t k = base + lane;
-        const bool in = k < k_hi;
+        const bool in = k < k_hi && (!SKIP || k >= k_lo);
         w_g = in ? ord_group[k] : 0xFFFFFFFFu;
         uint64_t ba = 0, bb = 0;
         if (in) {
@@ -868,9 +873,27 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
             path_class[ord_path[k]] = 1;
             atomicAdd(&flags[0], 1u);
         }
-        uint32_t pg = __shfl_up(w_g, 1);
-        if (lane == 0) pg = prev_group;
-        todo = __ballot(in && (w_len != 0 || w_g != pg));
+        if (SKIP) {
+            todo = __ballot(in && w_len != 0);
+        } else {
+            uint32_t pg = __shfl_up(w_g, 1);
+            if (lane == 0) pg = prev_group;
+            todo = __ballot(in && (w_len != 0 || w_g != pg));
+        }
+    };
+    // SKIP: first window at or after w_from whose band of tiles contains this tile
+    auto seek_window = [&](uint32_t w_from, uint32_t &w_out) {
+        const uint32_t w_end = (k_hi + 63) >> 6;
+        for (uint32_t w = w_from; w < w_end; w += 64) {
+            const uint32_t wi = w + lane;
+            const bool hit = wi < w_end && oi.win_lo[wi] <= tile && tile < oi.win_hi[wi];
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                w_out = w + (uint32_t)__builtin_ctzll(hm);
+                return true;
+            }
+        }
+        return false;
     };
     // scalars of one entry out of the window
     auto entry = [&](uint32_t k, uint64_t &lo, uint64_t &hi, uint32_t &g) {
@@ -883,6 +906,12 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
     // next interesting entry at or after the window position; false when the part is exhausted
     auto next_entry = [&](uint32_t &k) {
         while (todo == 0) {
+            if (SKIP) {
+                uint32_t w;
+                if (!seek_window((win_base >> 6) + 1, w)) return false;
+                load_window(w << 6, 0u);
+                continue;
+            }
             const uint32_t nb = win_base + 64;
             if (nb >= k_hi || nb < win_base) return false;
             load_window(nb, (uint32_t)__builtin_amdgcn_readlane((int)w_g, 63));
@@ -913,7 +942,17 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && NPL <= 12 && SPLIT > 1) ? 6 : 1)
     uint32_t e_g = 0xFFFFFFFFu;
     bool have = false;
     if (some) {
-        load_window(k_lo, 0xFFFFFFFFu);  // the first entry of the part always counts as a group change
+        if (SKIP) {
+            uint32_t w;
+            if (seek_window(k_lo >> 6, w)) {
+                load_window(w << 6, 0u);
+            } else {
+                win_base = ((k_hi + 63) >> 6) << 6;  // nothing reaches this tile
+                todo = 0;
+            }
+        } else {
+            load_window(k_lo, 0xFFFFFFFFu);  // the first entry of the part always counts as a group change
+        }
         have = next_entry(k);
         if (have) {
             entry(k, e_lo, e_hi, e_g);
@@ -1110,6 +1149,10 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
                            (uint32_t *)ctx->d_countable.p, ctx->cur->d_flags, rv, sp);
     };
+    // window skipping pays when the order is long (thousands of paths); with a few hundred dense
+    // paths every window is needed and the plain form keeps its lower register count
+    const bool skip = !write_m && !use_m && !has_runs &&
+                      (ctx->cover_skip == 1 || (ctx->cover_skip == 0 && ctx->n_ordered >= 4096));
     // waves per tile: enough waves to fill the chip about six times over
     int split = 1;
     if (WT == 1 && ctx->cover_variant == 2) {
@@ -1138,6 +1181,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                         else go(k_tile_cover_pipe<NPL, 1, false, true, 4, true, 2>, k_tile_cover_pipe<NPL, 1, false, true, 4, true, 4>, k_tile_cover_pipe<NPL, 1, false, true, 8, true, 8>);
                     } else {
                         if (write_m) go(k_tile_cover_pipe<NPL, 1, true, true, 4, false, 2>, k_tile_cover_pipe<NPL, 1, true, true, 4, false, 4>, k_tile_cover_pipe<NPL, 1, true, true, 8, false, 8>);
+                        else if (skip) go(k_tile_cover_pipe<NPL, 1, false, true, 4, false, 2, true>, k_tile_cover_pipe<NPL, 1, false, true, 4, false, 4, true>, k_tile_cover_pipe<NPL, 1, false, true, 8, false, 8, true>);
                         else go(k_tile_cover_pipe<NPL, 1, false, true, 4, false, 2>, k_tile_cover_pipe<NPL, 1, false, true, 4, false, 4>, k_tile_cover_pipe<NPL, 1, false, true, 8, false, 8>);
                     }
                     break;
@@ -1152,7 +1196,11 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
                 case 1: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 1, false>, 1); else launch(k_tile_cover_pipe<NPL, WT, false, true, 1, false>, 1); break;
                 case 2: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 2, false>, 2); else launch(k_tile_cover_pipe<NPL, WT, false, true, 2, false>, 2); break;
                 case 8: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 8, false>, 8); else launch(k_tile_cover_pipe<NPL, WT, false, true, 8, false>, 8); break;
-                default: if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4, false>, 4); else launch(k_tile_cover_pipe<NPL, WT, false, true, 4, false>, 4); break;
+                default:
+                    if (write_m) launch(k_tile_cover_pipe<NPL, WT, true, true, 4, false>, 4);
+                    else if (skip) launch(k_tile_cover_pipe<NPL, WT, false, true, 4, false, 1, true>, 4);
+                    else launch(k_tile_cover_pipe<NPL, WT, false, true, 4, false>, 4);
+                    break;
             }
             break;
         default:

@@ -669,6 +669,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return ctx->fail(PNX_EINVAL, "cover split must be 0 (auto), 1, 2, 4 or 8");
             ctx->cover_split = (int)value;
             return PNX_OK;
+        case PNX_CFG_COVER_SKIP:
+            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover_skip must be 0 (auto), 1 or 2");
+            ctx->cover_skip = (int)value;
+            return PNX_OK;
         case PNX_CFG_INDEX_BY_ENTRY:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "index_by_entry must be 0 (auto), 1 or 2");
             ctx->index_by_entry = (int)value;

@@ -95,6 +95,7 @@ def test_random_graph_matches_oracle(ctx, seed):
     G = len(seen)
     ctx.config(capi.CFG_TILE_BLOCKS, 1 + seed % 2 if seed % 5 == 0 else 1)
     ctx.config(capi.CFG_INDEX_BY_ENTRY, seed % 3)  # automatic / per entry / path-major index kernels
+    ctx.config(capi.CFG_COVER_SKIP, 1 if seed % 2 else 0)  # window skipping in the plain hist pass
     ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=excl)
     ctx.set_order(pi, gi, G)
     cnt, h = ctx.hist()
@@ -134,3 +135,4 @@ def test_random_graph_matches_oracle(ctx, seed):
             assert out[ri, t].tolist() == [int(x) for x in exp], ("growth", ri, a, q)
     ctx.config(capi.CFG_TILE_BLOCKS, 1)
     ctx.config(capi.CFG_INDEX_BY_ENTRY, 0)
+    ctx.config(capi.CFG_COVER_SKIP, 0)
