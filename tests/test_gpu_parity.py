@@ -230,6 +230,44 @@ def test_rejects_bad_input(ctx):
         ctx.set_order(np.array([3], np.uint32), np.array([0], np.uint32), 1)  # path index out of range
 
 
+def test_rejects_bad_calls_of_the_later_entry_points():
+    """every entry point fails with a message instead of crashing: wrong order of calls, null
+    pointers, out-of-range sizes, unknown tunables"""
+    import ctypes as C
+    from panacus_amd import capi
+    from panacus_amd.capi import PnxError
+    with capi.Context(0) as c:
+        L, h = c._L, c._h
+        with pytest.raises(PnxError):   # nothing uploaded yet
+            c.group_intersections()
+        with pytest.raises(PnxError):
+            c.hist_enqueued()
+        with pytest.raises(PnxError):
+            c.config(capi.CFG_COVER_SPLIT, 3)
+        with pytest.raises(PnxError):
+            c.config(capi.CFG_COVER_SKIP, 7)
+        with pytest.raises(PnxError):
+            c.config(capi.CFG_INDEX_BY_ENTRY, -1)
+        with pytest.raises(PnxError):
+            c.config(999, 1)
+        assert L.pnx_presence(h, None) != 0
+        assert L.pnx_quorum_sums(h, 0, 1, None, None, None, None, None) != 0
+        out = C.POINTER(C.c_double)()
+        assert L.pnx_quorum_sums_fetch(h, C.byref(out)) != 0      # nothing was enqueued
+        z = np.zeros(4, dtype=np.float64)
+        u = np.zeros(2, dtype=np.uint32)
+        f64p, u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+        assert L.pnx_quorum_sums_async(h, 100000, 1, u.ctypes.data_as(u32p), z.ctypes.data_as(f64p),
+                                       z.ctypes.data_as(f64p), z.ctypes.data_as(f64p)) != 0  # n too large
+        assert b"pnx_quorum_sums" in L.pnx_last_error(h)
+        # a context that failed a call is still usable
+        c.set_csr(np.array([1, 2, 2, 3], np.uint32), np.array([0, 2, 4], np.uint64), 3)
+        c.set_order(np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), 2)
+        assert c.group_intersections().tolist() == [[2, 1], [1, 2]]
+        assert c.hist()[1].tolist() == [0, 2, 1]
+    assert capi.load().pnx_hist(None, None, None) != 0  # NULL context
+
+
 # ---------------------------------------------------------------------------------------------
 # ordered / permuted growth parity
 # ---------------------------------------------------------------------------------------------
