@@ -147,6 +147,10 @@ public:
         free_.push_back(b);
     }
 
+    ~ScratchPool() {
+        for (Buf &b : free_) delete[] b.p;
+    }
+
 private:
     std::mutex mu_;
     std::vector<Buf> free_;
