@@ -365,6 +365,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--cache") o.cache = true;
+            else if (a == "-m" || a == "--method") (void)value("--method");  // similarity: accepted, the table stays in group order
             else if (a == "--links") o.links = true;
             else if (a == "--sequences") o.sequences = true;
             else if (a == "-a" || a == "--hist" || a == "--total") o.add_hist = o.total = true;
