@@ -57,12 +57,32 @@ namespace {
 // log2 of the integers 0..m as f64: the same libm call on the same argument the reference
 // makes, hoisted out of the loops (log2(0) = -inf, which the formulas rely on).
 struct Log2Table {
-    std::vector<double> v;
-    explicit Log2Table(uint64_t m) : v(m + 1) {
+    std::vector<double> v, rev;  // rev[t] = v[max - t]: a descending walk over v becomes an ascending one
+    explicit Log2Table(uint64_t m) : v(m + 1), rev(m + 1) {
         for (uint64_t i = 0; i <= m; ++i) v[i] = std::log2((double)i);
+        for (uint64_t i = 0; i <= m; ++i) rev[i] = v[m - i];
     }
     double operator()(uint64_t i) const { return v[i]; }
 };
+
+// One step m of row i of the quorum recurrences for all admissible j at once (hist.rs:167-175
+// without the exp2): q[j] is seeded with choose(i, j) where it is still 0.0, advanced by the two
+// log2 terms, and x[j] = (q[j] + m_fact) - n_fall is left for the summation.  Element-wise IEEE
+// additions in the reference's order -- the compiler may use any vector width, never an FMA.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx2", "default"), optimize("O3")))
+#endif
+void quorum_step(double *__restrict q, const double *__restrict ch, const double *__restrict la,
+                 const double *__restrict lb, double mf, double nf, double *__restrict x, uint64_t jlo, uint64_t jhi) {
+    for (uint64_t j = jlo; j < jhi; ++j) {
+        double qj = q[j];
+        qj = qj == 0.0 ? ch[j] : qj;
+        qj = qj + la[j];
+        qj = qj - lb[j];
+        q[j] = qj;
+        x[j] = (qj + mf) - nf;
+    }
+}
 
 enum Branch { UNION, CORE, QUORUM };
 
@@ -244,40 +264,46 @@ struct Job {
             }
             return;
         }
-        q.assign(n + 1, 0.0);
+        // q | choose(i, .) | x of the current step
+        q.assign(3 * (n + 1), 0.0);
+        double *qq = q.data(), *ch = qq + (n + 1), *xs = ch + (n + 1);
+        const uint64_t K = L.v.size() - 1;
+        uint64_t ch_hi = 0;  // choose(i, j) is known for the js that were admissible so far
         for (uint64_t m = 1; m <= n; ++m) {
             t2[m] = nan;
             if (i < m_quorum[m]) continue;  // the reference loops "for i in m_quorum..n"
-            double sum_q = 0.0;
-            bool add = false;
-            for (uint64_t j = std::max(m_quorum[m], c); j < m; ++j) {
-                if (n + j + 1 > i + m && j <= i) {
-                    if (q[j] == 0.0) {  // choose(i, j), hist.rs:21-36, log2 served from the table
-                        uint64_t k = j > i - j ? i - j : j;
-                        double res = 0.0;
-                        for (uint64_t a = 0; a < k; ++a) {
-                            res += L(i - a);
-                            res -= L(a + 1);
-                        }
-                        q[j] = res;
-                    }
-                    q[j] += L(n - i - m + 1 + j);
-                    q[j] -= L(m - j);
-                    add = true;
-                    // sum_q += exp2(x).  The libm call is skipped where its result provably
-                    // cannot change the running sum: exp2(x) <= 2^(floor(x)+1) (+1 ulp), so for
-                    // x + 56 <= exponent(sum_q) the addend is below half an ulp of a normal sum_q
-                    // and the rounded sum is sum_q itself; far below the subnormals it is +0.
-                    const double x = q[j] + m_fact[m] - n_fall[m];
-                    if (x < -1100.0) continue;
-                    uint64_t sb;
-                    std::memcpy(&sb, &sum_q, sizeof sb);
-                    const int64_t es = (int64_t)((sb >> 52) & 0x7FF);  // biased exponent, 0 = zero / subnormal
-                    if (es > 0 && x + 56.0 <= (double)(es - 1023)) continue;
-                    sum_q += std::exp2(x);
+            // for j in max(m_quorum, c)..m { if n + j + 1 > i + m && j <= i {..} }  (hist.rs:164-166)
+            uint64_t jlo = std::max(m_quorum[m], c);
+            if (i + m > n + jlo) jlo = i + m - n;
+            const uint64_t jhi = std::min(m, i + 1);
+            if (jlo >= jhi) continue;  // add stays false
+            for (uint64_t j = std::max(ch_hi, jlo); j < jhi; ++j) {  // choose(i, j), hist.rs:21-36
+                const uint64_t k = j > i - j ? i - j : j;
+                double res = 0.0;
+                for (uint64_t a = 0; a < k; ++a) {
+                    res += L(i - a);
+                    res -= L(a + 1);
                 }
+                ch[j] = res;
             }
-            if (add) t2[m] = std::exp2(lh[i] + std::log2(sum_q));
+            ch_hi = std::max(ch_hi, jhi);
+            // q[j] += log2(n - i - m + 1 + j); q[j] -= log2(m - j); x = q[j] + m_fact - n_fall
+            quorum_step(qq, ch, L.v.data() + (n - i - m + 1), L.rev.data() + (K - m), m_fact[m], n_fall[m], xs, jlo, jhi);
+            double sum_q = 0.0;
+            for (uint64_t j = jlo; j < jhi; ++j) {
+                // sum_q += exp2(x).  The libm call is skipped where its result provably cannot change
+                // the running sum: exp2(x) <= 2^(floor(x)+1) (+1 ulp), so for x + 56 <= exponent(sum_q)
+                // the addend is below half an ulp of a normal sum_q and the rounded sum is sum_q itself;
+                // far below the subnormals it is +0.
+                const double x = xs[j];
+                if (x < -1100.0) continue;
+                uint64_t sb;
+                std::memcpy(&sb, &sum_q, sizeof sb);
+                const int64_t es = (int64_t)((sb >> 52) & 0x7FF);  // biased exponent, 0 = zero / subnormal
+                if (es > 0 && x + 56.0 <= (double)(es - 1023)) continue;
+                sum_q += std::exp2(x);
+            }
+            t2[m] = std::exp2(lh[i] + std::log2(sum_q));
         }
     }
 
