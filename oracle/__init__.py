@@ -67,6 +67,13 @@ def lib() -> C.CDLL:
                                                   u64p, u64p, u64p]
         L.orc_graph_exclude_flags.restype = C.c_int
         L.orc_graph_exclude_flags.argtypes = [C.c_void_p, C.c_int, C.c_char_p, u8p]
+        L.orc_graph_masked_table.restype = C.c_int64
+        L.orc_graph_masked_table.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.POINTER(C.c_uint64)),
+                                             C.POINTER(C.c_uint64), u8p, C.POINTER(C.POINTER(C.c_uint64)),
+                                             C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]
+        L.orc_hist_apply_uncovered.restype = None
+        L.orc_hist_apply_uncovered.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                               C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_graph_group_name.restype = C.c_char_p
         L.orc_graph_group_name.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_graph_item_table.restype = C.c_int64
@@ -175,6 +182,31 @@ class Graph:
             raise ValueError(lib().orc_graph_last_error().decode())
         return flags
 
+    def masked_table(self, count_type: int, subset_file=None, exclude_file=None):
+        """ItemTable, exclude flags and uncovered bps under -s / -e BED lists (call path_order first).
+        -> (items[u64], prefsum[u64, P+1], exclude[u8, n_items+1], uncov_ids[u64], uncov_bps[u64])"""
+        pre = np.zeros(self.n_paths + 1, dtype=np.uint64)
+        flags = np.zeros(self.n_items(count_type) + 1, dtype=np.uint8)
+        ptr, uid, ubp = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        nu = C.c_uint64(0)
+        n = lib().orc_graph_masked_table(self._h, count_type,
+                                         os.fsencode(subset_file) if subset_file else None,
+                                         os.fsencode(exclude_file) if exclude_file else None,
+                                         C.byref(ptr), _p(pre, C.c_uint64), _p(flags, C.c_uint8),
+                                         C.byref(uid), C.byref(ubp), C.byref(nu))
+        if n < 0:
+            raise ValueError(lib().orc_graph_last_error().decode())
+        items = np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+        lib().orc_free(ptr)
+        k = nu.value
+        ids = np.ctypeslib.as_array(uid, shape=(max(k, 1),))[:k].copy() if uid else np.zeros(0, np.uint64)
+        bps = np.ctypeslib.as_array(ubp, shape=(max(k, 1),))[:k].copy() if ubp else np.zeros(0, np.uint64)
+        if uid:
+            lib().orc_free(uid)
+        if ubp:
+            lib().orc_free(ubp)
+        return items, pre, flags, ids, bps
+
     def item_table(self, count_type: int):
         """-> (items[u64], prefsum[u64, P+1])  (the reference's ItemTable, util.rs:81-93)"""
         pre = np.zeros(self.n_paths + 1, dtype=np.uint64)
@@ -194,6 +226,16 @@ def coverage(items, prefsum, path_idx, group_id, n_items, exclude=None) -> np.nd
     lib().orc_coverage(_p(items, C.c_uint64), _p(prefsum, C.c_uint64), _p(path_idx, C.c_uint64),
                        _p(group_id, C.c_uint64), len(path_idx), n_items, _p(ex, C.c_uint8),
                        _p(out, C.c_uint32))
+    return out
+
+
+def hist_apply_uncovered(countable, uncov_ids, uncov_bps, hist_in) -> np.ndarray:
+    """construct_hist_bps' fix-up for partially covered nodes (abacus.rs:779-785)."""
+    countable = np.ascontiguousarray(countable, dtype=np.uint32)
+    ids, bps = _u64(uncov_ids), _u64(uncov_bps)
+    out = _u64(hist_in).copy()
+    lib().orc_hist_apply_uncovered(_p(countable, C.c_uint32), _p(ids, C.c_uint64), _p(bps, C.c_uint64), len(ids),
+                                   _p(out, C.c_uint64))
     return out
 
 

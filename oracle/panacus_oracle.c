@@ -9,6 +9,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -596,38 +597,154 @@ void orc_graph_free(orc_graph *g) {
 /* GraphMask::load_groups (abacus.rs:242-308) + get_path_order (310-347) + group ids     */
 /* (555-559).  Subset/exclude lists are not restated (no golden outputs in the reference) */
 /* ------------------------------------------------------------------------------------ */
-/* reads a 1-column path/group list (parse_bed_to_path_segments, io.rs:35-119; coordinate
- * columns are not restated) and marks the paths it names: complement_with_group_assignments
- * (abacus.rs:152-206) -- a name that is a path selects that path, a name that is a group
- * selects all paths of the group.  When `exact_coords` is set a path entry only matches a
- * graph path whose coordinates are equal too (HashSet<&PathSegment> in abacus.rs:329-336).
- * visit (optional) receives the entries in file order as path indices. */
-static int read_path_list(const orc_graph *g, const char *file, const smap *key2path, char **keys,
-                          int exact_coords, uint8_t *mark, uint64_t **visit, uint64_t *nvisit) {
+/* parse_bed_to_path_segments with use_block_info = true (io.rs:35-119): 1 column = a name,
+ * >= 3 columns = name, start, end (from_str_start_end overrides coordinates parsed from the
+ * name), exactly 12 columns = one segment per block.  Returns -1 where the reference panics. */
+typedef struct {
+    pathseg *v;
+    size_t n, cap;
+} segvec;
+static void segvec_push(segvec *a, pathseg p) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 16;
+        a->v = xrealloc(a->v, a->cap * sizeof *a->v);
+    }
+    a->v[a->n++] = p;
+}
+static void segvec_free(segvec *a) {
+    for (size_t i = 0; i < a->n; i++) pathseg_free(&a->v[i]);
+    free(a->v);
+    memset(a, 0, sizeof *a);
+}
+/* usize::from_str: digits with an optional leading '+' */
+static int parse_usize_rust(const char *s, size_t n, uint64_t *out) {
+    if (n > 0 && s[0] == '+') {
+        s++;
+        n--;
+    }
+    return parse_usize(s, n, out);
+}
+/* "a,b,c,".split(',').filter_map(|s| usize::from_str(s.trim()).ok()) */
+static size_t parse_usize_list(const char *s, size_t n, uint64_t **out) {
+    size_t cnt = 0, cap = 0, i = 0;
+    *out = NULL;
+    for (;;) {
+        size_t e = i;
+        while (e < n && s[e] != ',') e++;
+        size_t b = i, t = e;
+        while (b < t && isspace((unsigned char)s[b])) b++;
+        while (t > b && isspace((unsigned char)s[t - 1])) t--;
+        uint64_t v;
+        if (parse_usize_rust(s + b, t - b, &v)) {
+            if (cnt == cap) {
+                cap = cap ? cap * 2 : 8;
+                *out = xrealloc(*out, cap * sizeof **out);
+            }
+            (*out)[cnt++] = v;
+        }
+        if (e >= n) break;
+        i = e + 1;
+    }
+    return cnt;
+}
+static pathseg pathseg_with_coords(const char *name, size_t n, uint64_t st, uint64_t en) {
+    pathseg ps = pathseg_from_str(name, n);
+    ps.has_start = ps.has_end = 1;
+    ps.start = st;
+    ps.end = en;
+    return ps;
+}
+static int parse_bed(const char *file, segvec *out) {
     FILE *f = fopen(file, "rb");
     if (!f) {
         set_err("cannot open list file %s", file);
         return -1;
     }
     char *line = NULL;
-    size_t lcap = 0, vcap = 0;
+    size_t lcap = 0;
     ssize_t n;
+    int lineno = 0, rc = 0;
+    while ((n = getline(&line, &lcap, f)) > 0) {
+        lineno++;
+        /* BufRead::lines strips \n and \r\n */
+        if (n > 0 && line[n - 1] == '\n') {
+            n--;
+            if (n > 0 && line[n - 1] == '\r') n--;
+        }
+        size_t fb[13], fe[13], nf = 0, pos = 0, total = 0;
+        for (;;) {
+            size_t e = field_end(line, pos, (size_t)n);
+            if (nf < 13) {
+                fb[nf] = pos;
+                fe[nf] = e;
+                nf++;
+            }
+            total++;
+            if (e >= (size_t)n) break;
+            pos = e + 1;
+        }
+        const char *name = line + fb[0];
+        size_t nn = fe[0] - fb[0];
+        if ((nn >= 8 && memcmp(name, "browser ", 8) == 0) || (nn >= 6 && memcmp(name, "track ", 6) == 0) ||
+            (nn >= 1 && name[0] == '#'))
+            continue;
+        if (total == 1) {
+            segvec_push(out, pathseg_from_str(name, nn));
+        } else if (total >= 3) {
+            uint64_t st, en;
+            if (!parse_usize_rust(line + fb[1], fe[1] - fb[1], &st) || !parse_usize_rust(line + fb[2], fe[2] - fb[2], &en)) {
+                set_err("error line %d: start/end is not an usize", lineno);
+                rc = -1;
+                break;
+            }
+            if (total == 12) {
+                uint64_t bc = 0, *sizes, *starts;
+                if (!parse_usize_rust(line + fb[9], fe[9] - fb[9], &bc)) bc = 0; /* unwrap_or(0) */
+                size_t ns = parse_usize_list(line + fb[10], fe[10] - fb[10], &sizes);
+                size_t nt = parse_usize_list(line + fb[11], fe[11] - fb[11], &starts);
+                if (bc != ns || bc != nt) {
+                    set_err("error in block sizes/starts in line %d: counts do not match", lineno);
+                    free(sizes);
+                    free(starts);
+                    rc = -1;
+                    break;
+                }
+                for (size_t k = 0; k < ns; k++)
+                    segvec_push(out, pathseg_with_coords(name, nn, st + starts[k], st + starts[k] + sizes[k]));
+                free(sizes);
+                free(starts);
+            } else {
+                segvec_push(out, pathseg_with_coords(name, nn, st, en));
+            }
+        } else {
+            set_err("error in line %d: row must have either 1, 3, or 12 columns, but has 2", lineno);
+            rc = -1;
+            break;
+        }
+    }
+    free(line);
+    fclose(f);
+    return rc;
+}
+
+/* reads a path/group list (BED, see parse_bed) and marks the paths it names:
+ * complement_with_group_assignments (abacus.rs:152-206) -- a name that is a path selects that
+ * path, a name that is a group selects all paths of the group (and must not carry coordinates).
+ * When `exact_coords` is set a path entry only matches a graph path whose coordinates are
+ * equal too (HashSet<&PathSegment> in abacus.rs:329-336).  visit (optional) receives the
+ * entries in file order as path indices. */
+static int read_path_list(const orc_graph *g, const char *file, const smap *key2path, char **keys,
+                          int exact_coords, uint8_t *mark, uint64_t **visit, uint64_t *nvisit) {
+    segvec segs = {0};
+    if (parse_bed(file, &segs) != 0) {
+        segvec_free(&segs);
+        return -1;
+    }
+    size_t vcap = 0;
     uint64_t P = g->n_paths;
     (void)keys;
-    while ((n = getline(&line, &lcap, f)) > 0) {
-        if (n > 0 && line[n - 1] == '\n') n--;
-        if (n > 0 && line[n - 1] == '\r') n--;
-        size_t e = field_end(line, 0, (size_t)n);
-        if ((e >= 8 && memcmp(line, "browser ", 8) == 0) || (e >= 6 && memcmp(line, "track ", 6) == 0) ||
-            (e >= 1 && line[0] == '#'))
-            continue;
-        if (e < (size_t)n) {
-            set_err("path lists with coordinate columns are not supported");
-            free(line);
-            fclose(f);
-            return -1;
-        }
-        pathseg ps = pathseg_from_str(line, e);
+    for (size_t si = 0; si < segs.n; si++) {
+        const pathseg ps = segs.v[si];
         char *k = pathseg_clearkey(&ps);
         uint64_t pi;
         if (smap_get(key2path, k, strlen(k), &pi)) {
@@ -652,7 +769,16 @@ static int read_path_list(const orc_graph *g, const char *file, const smap *key2
             }
         } else {
             char *id = pathseg_id(&ps);
-            int hit = 0;
+            int hit = 0, is_group = 0;
+            for (uint64_t i = 0; i < P && !is_group; i++)
+                is_group = g->path_group[i] && strcmp(g->path_group[i], id) == 0;
+            if (is_group && ps.has_start && ps.has_end) {
+                set_err("invalid coordinate \"%s\": group identifiers are not allowed to have start/stop information!", id);
+                free(id);
+                free(k);
+                segvec_free(&segs);
+                return -1;
+            }
             for (uint64_t i = 0; i < P; i++)
                 if (g->path_group[i] && strcmp(g->path_group[i], id) == 0) {
                     /* group members come from the keys of `groups`, i.e. WITHOUT coordinates */
@@ -670,10 +796,8 @@ static int read_path_list(const orc_graph *g, const char *file, const smap *key2
             free(id);
         }
         free(k);
-        pathseg_free(&ps);
     }
-    free(line);
-    fclose(f);
+    segvec_free(&segs);
     return 0;
 }
 
@@ -957,6 +1081,60 @@ static void u64vec_push(u64vec *a, uint64_t x) {
     a->v[a->n++] = x;
 }
 
+/* the step column of a P line / the walk of a W line as (segment id, orientation) pairs:
+ * parse_path_seq_to_item_vec / parse_walk_seq_to_item_vec (util.rs:797-850, 963-1046) */
+static int parse_steps(const orc_graph *g, const char *line, size_t n, u64vec *sids, u64vec *oris) {
+    sids->n = 0;
+    oris->n = 0;
+    size_t pos, end;
+    if (line[0] == 'P') {
+        size_t s0 = field_end(line, 0, n) + 1;
+        pos = field_end(line, s0, n) + 1;
+        end = pos;
+        while (end < n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
+        /* steps "name+,name-": get_segment_id util.rs:1017-1031 */
+        while (pos < end) {
+            size_t e = pos;
+            while (e < end && line[e] != ',') e++;
+            if (e > pos) {
+                char o = line[e - 1];
+                uint64_t id;
+                if ((o != '+' && o != '-') || !smap_get(&g->node2id, line + pos, e - 1 - pos, &id)) {
+                    set_err("unknown node %.*s", (int)(e - pos), line + pos);
+                    return -1;
+                }
+                u64vec_push(sids, id);
+                u64vec_push(oris, o == '+' ? 0 : 1);
+            }
+            pos = e + 1;
+        }
+    } else {
+        pathseg ps;
+        if (!parse_walk_ident(line, n, &ps, &pos)) {
+            set_err("malformed W line");
+            return -1;
+        }
+        pathseg_free(&ps);
+        end = pos;
+        while (end < n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
+        /* walk ">name<name": get_walk_segment_id util.rs:1033-1046 */
+        while (pos < end) {
+            size_t e = pos + 1;
+            while (e < end && line[e] != '>' && line[e] != '<') e++;
+            char o = line[pos];
+            uint64_t id;
+            if ((o != '>' && o != '<') || !smap_get(&g->node2id, line + pos + 1, e - pos - 1, &id)) {
+                set_err("unknown node %.*s", (int)(e - pos), line + pos);
+                return -1;
+            }
+            u64vec_push(sids, id);
+            u64vec_push(oris, o == '>' ? 0 : 1);
+            pos = e;
+        }
+    }
+    return 0;
+}
+
 int64_t orc_graph_item_table(const orc_graph *g, int count_type, uint64_t **items_out,
                              uint64_t *prefsum) {
     if (count_type == ORC_EDGE && !g->has_edges) {
@@ -978,54 +1156,7 @@ int64_t orc_graph_item_table(const orc_graph *g, int count_type, uint64_t **item
     ssize_t n;
     while ((n = getline(&line, &lcap, f)) > 0) {
         if (line[0] != 'P' && line[0] != 'W') continue;
-        sids.n = 0;
-        oris.n = 0;
-        size_t pos, end;
-        if (line[0] == 'P') {
-            size_t s0 = field_end(line, 0, (size_t)n) + 1;
-            pos = field_end(line, s0, (size_t)n) + 1;
-            end = pos;
-            while (end < (size_t)n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
-            /* steps "name+,name-": get_segment_id util.rs:1017-1031 */
-            while (pos < end) {
-                size_t e = pos;
-                while (e < end && line[e] != ',') e++;
-                if (e > pos) {
-                    char o = line[e - 1];
-                    uint64_t id;
-                    if ((o != '+' && o != '-') || !smap_get(&g->node2id, line + pos, e - 1 - pos, &id)) {
-                        set_err("unknown node %.*s", (int)(e - pos), line + pos);
-                        goto fail;
-                    }
-                    u64vec_push(&sids, id);
-                    u64vec_push(&oris, o == '+' ? 0 : 1);
-                }
-                pos = e + 1;
-            }
-        } else {
-            pathseg ps;
-            if (!parse_walk_ident(line, (size_t)n, &ps, &pos)) {
-                set_err("malformed W line");
-                goto fail;
-            }
-            pathseg_free(&ps);
-            end = pos;
-            while (end < (size_t)n && line[end] != '\t' && line[end] != '\n' && line[end] != '\r') end++;
-            /* walk ">name<name": get_walk_segment_id util.rs:1033-1046 */
-            while (pos < end) {
-                size_t e = pos + 1;
-                while (e < end && line[e] != '>' && line[e] != '<') e++;
-                char o = line[pos];
-                uint64_t id;
-                if ((o != '>' && o != '<') || !smap_get(&g->node2id, line + pos + 1, e - pos - 1, &id)) {
-                    set_err("unknown node %.*s", (int)(e - pos), line + pos);
-                    goto fail;
-                }
-                u64vec_push(&sids, id);
-                u64vec_push(&oris, o == '>' ? 0 : 1);
-                pos = e;
-            }
-        }
+        if (parse_steps(g, line, (size_t)n, &sids, &oris) != 0) goto fail;
         uint64_t added = 0;
         if (count_type == ORC_EDGE) {
             /* util.rs:723-795 with include=[(0,usize::MAX)], exclude=[], offset = path start */
@@ -1345,6 +1476,472 @@ int orc_graph_exclude_flags(orc_graph *g, int count_type, const char *exclude_fi
     free(pre);
     free(ex);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Subset / exclude with BED coordinates: parse_gfa_paths_walks             */
+/* (util.rs:208-366; the _multiple variant :22-206 makes the same decisions per count),    */
+/* update_tables (:569-722), update_tables_edgecount (:723-795), ActiveTable and           */
+/* IntervalContainer (src/util.rs:118-310), quantify_uncovered_bps (abacus.rs:1187-1229).   */
+/* usize arithmetic wraps like the reference's release build (no overflow checks).         */
+/* No reference-produced output exists for these options: parity unpinned.                 */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t s, e;
+} ival;
+typedef struct {
+    ival *v;
+    size_t n, cap;
+} ivec;
+static void ivec_insert(ivec *a, size_t i, ival x) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 4;
+        a->v = xrealloc(a->v, a->cap * sizeof *a->v);
+    }
+    memmove(a->v + i + 1, a->v + i, (a->n - i) * sizeof *a->v);
+    a->v[i] = x;
+    a->n++;
+}
+static void ivec_remove(ivec *a, size_t i) {
+    memmove(a->v + i, a->v + i + 1, (a->n - i - 1) * sizeof *a->v);
+    a->n--;
+}
+static void ivec_clear(ivec *a) {
+    free(a->v);
+    memset(a, 0, sizeof *a);
+}
+/* IntervalContainer::add (src/util.rs:215-258); an absent key is an empty list here */
+static void icont_add(ivec *x, uint64_t start, uint64_t end) {
+    if (x->n == 0) {
+        ivec_insert(x, 0, (ival){start, end});
+        return;
+    }
+    /* binary_search_by_key(&start, |(y, _)| y).unwrap_or_else(|z| z): starts are unique */
+    size_t i = 0;
+    while (i < x->n && x->v[i].s < start) i++;
+    if (i > 0 && x->v[i - 1].e >= start) {
+        if (x->v[i - 1].e < end) {
+            uint64_t stop = end;
+            while (i < x->n && x->v[i].s <= end) {
+                if (x->v[i].e > stop) stop = x->v[i].e;
+                ivec_remove(x, i);
+            }
+            x->v[i - 1].e = stop;
+        }
+    } else if (i < x->n && x->v[i].e >= start && x->v[i].s <= end) {
+        if (start < x->v[i].s) x->v[i].s = start;
+        uint64_t stop = x->v[i].e > end ? x->v[i].e : end;
+        while (i + 1 < x->n && x->v[i + 1].s <= end) {
+            if (x->v[i + 1].e > stop) stop = x->v[i + 1].e;
+            ivec_remove(x, i + 1);
+        }
+        x->v[i].e = stop;
+    } else {
+        ivec_insert(x, i, (ival){start, end});
+    }
+}
+/* IntervalContainer::total_coverage (src/util.rs:272-305); ex == NULL is `None` */
+static uint64_t icont_total_coverage(const ivec *v, const ival *ex, size_t nex, int have_ex) {
+    uint64_t res = 0;
+    if (!have_ex) {
+        for (size_t k = 0; k < v->n; k++) res = res + v->v[k].e - v->v[k].s;
+        return res;
+    }
+    size_t i = 0;
+    for (size_t k = 0; k < v->n; k++) {
+        const uint64_t start = v->v[k].s, end = v->v[k].e;
+        while (i < nex && ex[i].e <= start) i++;
+        if (i < nex && ex[i].s < end) {
+            uint64_t m = ex[i].s - 1; /* wraps for 0 like the release build */
+            if (end < m) m = end;
+            res += m - start;
+            if (ex[i].e < end) res += end - ex[i].e + 1;
+        } else {
+            res += end - start;
+        }
+    }
+    return res;
+}
+/* ActiveTable (src/util.rs:118-207): items[] + optional annotation per item */
+typedef struct {
+    uint8_t *items;
+    ivec *ann; /* NULL = without annotation */
+} active_table;
+static void active_annotate(active_table *t, uint64_t id, uint64_t item_len, uint64_t start, uint64_t end) {
+    ivec *m = &t->ann[id];
+    if (end - start == item_len) {
+        t->items[id] = 1;
+        ivec_clear(m);
+    } else {
+        if (start <= end) icont_add(m, start, end);
+        /* m.get(&id).unwrap()[0]: the reference panics when nothing was ever added */
+        if (m->n > 0 && m->v[0].s == 0 && m->v[0].e == item_len) {
+            ivec_clear(m);
+            t->items[id] = 1;
+        }
+    }
+}
+/* GraphMask::build_subpath_map (abacus.rs:354-382): id -> sorted, merged intervals */
+typedef struct {
+    smap idx;
+    ivec *lists;
+    size_t n, cap;
+} subpath_map;
+static int ival_cmp(const void *a, const void *b) {
+    const ival *x = a, *y = b;
+    if (x->s != y->s) return x->s < y->s ? -1 : 1;
+    if (x->e != y->e) return x->e < y->e ? -1 : 1;
+    return 0;
+}
+static void subpath_map_add(subpath_map *m, const char *id, ival x) {
+    uint64_t k;
+    if (!smap_get(&m->idx, id, strlen(id), &k)) {
+        if (m->n == m->cap) {
+            m->cap = m->cap ? m->cap * 2 : 16;
+            m->lists = xrealloc(m->lists, m->cap * sizeof *m->lists);
+        }
+        k = m->n++;
+        memset(&m->lists[k], 0, sizeof m->lists[k]);
+        smap_put(&m->idx, id, strlen(id), k);
+    }
+    ivec *l = &m->lists[k];
+    ivec_insert(l, l->n, x);
+}
+static void subpath_map_finish(subpath_map *m) {
+    for (size_t k = 0; k < m->n; k++) {
+        ivec *v = &m->lists[k];
+        qsort(v->v, v->n, sizeof *v->v, ival_cmp);
+        size_t w = 0; /* HashSet: drop exact duplicates */
+        for (size_t i = 0; i < v->n; i++)
+            if (w == 0 || ival_cmp(&v->v[w - 1], &v->v[i]) != 0) v->v[w++] = v->v[i];
+        v->n = w;
+        size_t i = 1;
+        while (i < v->n) {
+            if (v->v[i - 1].e >= v->v[i].s) {
+                ival x = v->v[i];
+                ivec_remove(v, i);
+                if (x.e > v->v[i - 1].e) v->v[i - 1].e = x.e;
+            } else {
+                i++;
+            }
+        }
+    }
+}
+static const ivec *subpath_map_get(const subpath_map *m, const char *id) {
+    uint64_t k;
+    return smap_get(&m->idx, id, strlen(id), &k) ? &m->lists[k] : NULL;
+}
+static void subpath_map_free(subpath_map *m) {
+    for (size_t k = 0; k < m->n; k++) ivec_clear(&m->lists[k]);
+    free(m->lists);
+    smap_free(&m->idx);
+}
+/* load_coord_list_file + complement_with_group_assignments (abacus.rs:152-210) into a
+ * subpath map.  Needs the group names of a preceding orc_graph_path_order* call. */
+static int load_subpath_map(const orc_graph *g, const char *file, subpath_map *out) {
+    segvec segs = {0};
+    smap_init(&out->idx, 64);
+    out->lists = NULL;
+    out->n = out->cap = 0;
+    if (parse_bed(file, &segs) != 0) {
+        segvec_free(&segs);
+        return -1;
+    }
+    const uint64_t P = g->n_paths;
+    char **keys = xcalloc(P ? P : 1, sizeof *keys);
+    for (uint64_t i = 0; i < P; i++) keys[i] = pathseg_clearkey(&g->paths[i]);
+    int rc = 0;
+    for (size_t si = 0; si < segs.n && rc == 0; si++) {
+        const pathseg *ps = &segs.v[si];
+        char *k = pathseg_clearkey(ps);
+        char *id = pathseg_id(ps);
+        int is_path = 0, is_group = 0;
+        for (uint64_t i = 0; i < P && !is_path; i++) is_path = strcmp(keys[i], k) == 0;
+        if (is_path) {
+            ival x = {0, UINT64_MAX};
+            if (ps->has_start && ps->has_end) x = (ival){ps->start, ps->end};
+            subpath_map_add(out, id, x);
+        } else {
+            for (uint64_t i = 0; i < P && !is_group; i++)
+                is_group = g->path_group && g->path_group[i] && strcmp(g->path_group[i], id) == 0;
+            if (is_group && ps->has_start && ps->has_end) {
+                set_err("invalid coordinate \"%s\": group identifiers are not allowed to have start/stop information!", id);
+                rc = -1;
+            } else if (is_group) {
+                for (uint64_t i = 0; i < P; i++)
+                    if (strcmp(g->path_group[i], id) == 0) {
+                        char *pid = pathseg_id(&g->paths[i]);
+                        subpath_map_add(out, pid, (ival){0, UINT64_MAX});
+                        free(pid);
+                    }
+            } /* else: unknown path/group -> logged and skipped */
+        }
+        free(k);
+        free(id);
+    }
+    for (uint64_t i = 0; i < P; i++) free(keys[i]);
+    free(keys);
+    segvec_free(&segs);
+    if (rc == 0) subpath_map_finish(out);
+    return rc;
+}
+/* intersects / is_contained (src/util.rs:370-398) over sorted, disjoint intervals */
+static int ivs_intersects(const ival *v, size_t n, ival el) {
+    for (size_t k = 0; k < n; k++)
+        if (v[k].s <= el.e && v[k].e >= el.s) return 1;
+    return 0;
+}
+static int ivs_is_contained(const ival *v, size_t n, ival el) {
+    for (size_t k = 0; k < n; k++)
+        if (v[k].s <= el.s && v[k].e >= el.e) return 1;
+    return 0;
+}
+
+int64_t orc_graph_masked_table(const orc_graph *g, int count_type, const char *subset_file, const char *exclude_file,
+                               uint64_t **items_out, uint64_t *prefsum, uint8_t *exclude,
+                               uint64_t **uncov_ids, uint64_t **uncov_bps, uint64_t *n_uncov) {
+    *items_out = NULL;
+    if (uncov_ids) *uncov_ids = NULL;
+    if (uncov_bps) *uncov_bps = NULL;
+    if (n_uncov) *n_uncov = 0;
+    if (count_type == ORC_EDGE && !g->has_edges) {
+        set_err("graph was loaded without edge index");
+        return -1;
+    }
+    const uint64_t n_items = count_type == ORC_EDGE ? g->n_edges : g->n_nodes;
+    subpath_map inc, exc;
+    int have_inc = 0, have_exc = 0;
+    if (subset_file) {
+        if (load_subpath_map(g, subset_file, &inc) != 0) {
+            subpath_map_free(&inc);
+            return -1;
+        }
+        have_inc = 1;
+    }
+    if (exclude_file) {
+        if (load_subpath_map(g, exclude_file, &exc) != 0) {
+            subpath_map_free(&exc);
+            if (have_inc) subpath_map_free(&inc);
+            return -1;
+        }
+        have_exc = 1;
+    }
+    /* load_optional_subsetting (abacus.rs:384-425) */
+    ivec *covered = NULL; /* subset_covered_bps: bp count with a subset only */
+    if (count_type == ORC_BP && have_inc) covered = xcalloc(n_items + 1, sizeof *covered);
+    active_table ex = {NULL, NULL};
+    if (have_exc) {
+        ex.items = xcalloc(n_items + 1, 1);
+        if (count_type == ORC_BP) ex.ann = xcalloc(n_items + 1, sizeof *ex.ann);
+    }
+
+    int64_t ret = -1;
+    FILE *f = fopen(g->gfa_file, "rb");
+    if (!f) {
+        set_err("cannot open %s", g->gfa_file);
+        goto done;
+    }
+    u64vec items = {0}, sids = {0}, oris = {0};
+    uint64_t num_path = 0;
+    prefsum[0] = 0;
+    char *line = NULL;
+    size_t lcap = 0;
+    ssize_t n;
+    const ival complete = {0, UINT64_MAX};
+    int failed = 0;
+    while ((n = getline(&line, &lcap, f)) > 0) {
+        if (line[0] != 'P' && line[0] != 'W') continue;
+        const pathseg *ps = &g->paths[num_path];
+        char *id = pathseg_id(ps);
+        const ival *ic = &complete, *ec = NULL;
+        size_t nic = 1, nec = 0;
+        if (have_inc) {
+            const ivec *l = subpath_map_get(&inc, id);
+            ic = l ? l->v : NULL;
+            nic = l ? l->n : 0;
+        }
+        if (have_exc) {
+            const ivec *l = subpath_map_get(&exc, id);
+            ec = l ? l->v : NULL;
+            nec = l ? l->n : 0;
+        }
+        free(id);
+        const ival span = (ps->has_start && ps->has_end) ? (ival){ps->start, ps->end} : complete;
+        uint64_t added = 0;
+        /* neither part of the subset nor of the exclude list: an empty entry (util.rs:272-286) */
+        if (have_inc && !ivs_intersects(ic, nic, span) && !ivs_intersects(ec, nec, span)) {
+            prefsum[num_path + 1] = prefsum[num_path];
+            num_path++;
+            continue;
+        }
+        if (parse_steps(g, line, (size_t)n, &sids, &oris) != 0) {
+            failed = 1;
+            break;
+        }
+        if (count_type != ORC_EDGE && (!have_inc || ivs_is_contained(ic, nic, span)) &&
+            (!have_exc || ivs_is_contained(ec, nec, span))) {
+            /* whole path (util.rs:288-315, 1186-1250): every step is pushed; with exclude
+             * coordinates for this path all of its nodes are flagged as excluded */
+            for (size_t k = 0; k < sids.n; k++) {
+                u64vec_push(&items, sids.v[k]);
+                if (nec > 0) ex.items[sids.v[k]] = 1;
+            }
+            added = sids.n;
+        } else if (count_type != ORC_EDGE) {
+            /* update_tables, util.rs:569-722 */
+            size_t i = 0, j = 0;
+            uint64_t p = span.s;
+            for (size_t k = 0; k < sids.n; k++) {
+                const uint64_t sid = sids.v[k];
+                const uint64_t l = g->node_lens[sid];
+                int stop_here = 0;
+                while (i < nic && ic[i].s < p + l && !stop_here) {
+                    if (ic[i].e > p) {
+                        uint64_t a = ic[i].s > p ? ic[i].s - p : 0, b;
+                        if (ic[i].e < p + l) {
+                            i++;
+                            b = ic[i - 1].e - p;
+                        } else {
+                            stop_here = 1;
+                            b = l;
+                        }
+                        if (oris.v[k]) { /* backward: mirror the interval inside the node */
+                            const uint64_t a2 = l - b, b2 = l - a;
+                            a = a2;
+                            b = b2;
+                        }
+                        u64vec_push(&items, sid);
+                        added++;
+                        if (covered) {
+                            if (b - a == l)
+                                ivec_clear(&covered[sid]);
+                            else
+                                icont_add(&covered[sid], a, b);
+                        }
+                    } else {
+                        i++;
+                    }
+                }
+                stop_here = 0;
+                while (j < nec && ec[j].s < p + l && !stop_here) {
+                    if (ec[j].e > p) {
+                        uint64_t a = ec[j].s > p ? ec[j].s - p : 0, b;
+                        if (ec[j].e < p + l) {
+                            j++;
+                            b = ec[j - 1].e - p;
+                        } else {
+                            stop_here = 1;
+                            b = l;
+                        }
+                        if (oris.v[k]) {
+                            const uint64_t a2 = l - b, b2 = l - a;
+                            a = a2;
+                            b = b2;
+                        }
+                        if (ex.items) {
+                            if (ex.ann)
+                                active_annotate(&ex, sid, l, a, b);
+                            else
+                                ex.items[sid] = 1;
+                        }
+                    } else {
+                        j++;
+                    }
+                }
+                if (i >= nic && j >= nec) break;
+                p += l;
+            }
+        } else if (sids.n > 0) {
+            /* update_tables_edgecount, util.rs:723-795 */
+            size_t i = 0, j = 0;
+            uint64_t p = span.s + g->node_lens[sids.v[0]];
+            for (size_t k = 0; k + 1 < sids.n; k++) {
+                while (i < nic && ic[i].e <= p) i++;
+                while (j < nec && ec[j].e <= p) j++;
+                const uint64_t l = g->node_lens[sids.v[k + 1]];
+                edge_t e = edge_canonical(sids.v[k], (uint8_t)oris.v[k], sids.v[k + 1], (uint8_t)oris.v[k + 1]);
+                const uint64_t eid = emap_get(&g->edge2id, e);
+                if (!eid) {
+                    set_err("unknown edge %c%llu%c%llu", e.o1 ? '<' : '>', (unsigned long long)e.u,
+                            e.o2 ? '<' : '>', (unsigned long long)e.v);
+                    failed = 1;
+                    break;
+                }
+                if (i < nic && ic[i].s < p + l) {
+                    u64vec_push(&items, eid);
+                    added++;
+                }
+                if (ex.items && j < nec && ec[j].s < p + l)
+                    ex.items[eid] = 1;
+                else if (i >= nic && j >= nec)
+                    break;
+                p += l;
+            }
+            if (failed) break;
+        }
+        prefsum[num_path + 1] = prefsum[num_path] + added;
+        num_path++;
+    }
+    free(line);
+    free(sids.v);
+    free(oris.v);
+    fclose(f);
+    if (failed) {
+        free(items.v);
+        goto done;
+    }
+    if (exclude) {
+        memset(exclude, 0, n_items + 1);
+        if (ex.items) memcpy(exclude, ex.items, n_items + 1);
+    }
+    /* quantify_uncovered_bps, abacus.rs:1187-1229 */
+    if (covered && uncov_ids && uncov_bps && n_uncov) {
+        u64vec ids = {0}, bps = {0};
+        for (uint64_t sid = 1; sid <= n_items; sid++) {
+            if (covered[sid].n == 0) continue;                   /* not a key of the container */
+            if (ex.items && ex.items[sid]) continue;             /* completely excluded */
+            const uint64_t l = g->node_lens[sid];
+            ival whole = {0, l};
+            const ival *av = NULL;
+            size_t an = 0;
+            if (ex.items) { /* get_active_intervals: items[sid] is false here */
+                av = ex.ann ? ex.ann[sid].v : NULL;
+                an = ex.ann ? ex.ann[sid].n : 0;
+            }
+            (void)whole;
+            const uint64_t cov = icont_total_coverage(&covered[sid], av, an, ex.items != NULL);
+            if (cov > l) continue; /* "oops, total coverage is larger than node length": skipped */
+            u64vec_push(&ids, sid);
+            u64vec_push(&bps, l - cov);
+        }
+        *uncov_ids = ids.v ? ids.v : xmalloc(8);
+        *uncov_bps = bps.v ? bps.v : xmalloc(8);
+        *n_uncov = ids.n;
+    }
+    *items_out = items.v ? items.v : xmalloc(8);
+    ret = (int64_t)items.n;
+done:
+    if (covered) {
+        for (uint64_t k = 0; k <= n_items; k++) ivec_clear(&covered[k]);
+        free(covered);
+    }
+    if (ex.ann) {
+        for (uint64_t k = 0; k <= n_items; k++) ivec_clear(&ex.ann[k]);
+        free(ex.ann);
+    }
+    free(ex.items);
+    if (have_inc) subpath_map_free(&inc);
+    if (have_exc) subpath_map_free(&exc);
+    return ret;
+}
+
+/* construct_hist_bps' fix-up (abacus.rs:779-785): hist[countable[id]] -= uncov; hist[0] += uncov */
+void orc_hist_apply_uncovered(const uint32_t *countable, const uint64_t *uncov_ids, const uint64_t *uncov_bps,
+                              uint64_t n_uncov, uint64_t *hist) {
+    for (uint64_t k = 0; k < n_uncov; k++) {
+        hist[countable[uncov_ids[k]]] -= uncov_bps[k];
+        hist[0] += uncov_bps[k];
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */

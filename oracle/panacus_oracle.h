@@ -67,6 +67,22 @@ int64_t orc_graph_path_order_masked(orc_graph *g, int group_mode, const char *gr
                                     uint64_t *path_idx, uint64_t *group_id, uint64_t *n_out);
 int orc_graph_exclude_flags(orc_graph *g, int count_type, const char *exclude_file, uint8_t *flags);
 
+/* ---- subset / exclude lists with BED coordinates ----
+ * parse_gfa_paths_walks with GraphMask.include_coords / exclude_coords (graph_broker/util.rs:208-366,
+ * 569-795; src/util.rs:118-310): the ItemTable restricted to the subset intervals (paths outside the
+ * subset get an empty entry), the ActiveTable.items flags of the exclude list (`exclude`, n_items+1
+ * bytes, may be NULL) and -- for ORC_BP with a subset -- quantify_uncovered_bps (abacus.rs:1187-1229)
+ * as parallel arrays sorted by node id (malloc'ed; free with orc_free).  Either file may be NULL.
+ * Group names in the lists resolve against the last orc_graph_path_order* call.
+ * Returns the number of items or -1.  PARITY UNPINNED: the reference holds the BED inputs
+ * (test/bed_chrM) but no expected output; this restatement is the definition. */
+int64_t orc_graph_masked_table(const orc_graph *g, int count_type, const char *subset_file, const char *exclude_file,
+                               uint64_t **items, uint64_t *prefsum, uint8_t *exclude, uint64_t **uncov_ids,
+                               uint64_t **uncov_bps, uint64_t *n_uncov);
+/* the uncovered-bp fix-up of construct_hist_bps (abacus.rs:779-785), wrapping like the release build */
+void orc_hist_apply_uncovered(const uint32_t *countable, const uint64_t *uncov_ids, const uint64_t *uncov_bps,
+                              uint64_t n_uncov, uint64_t *hist);
+
 /* ---- ItemTable (src/util.rs:81-93; graph_broker/util.rs:22-206, 723-795) ----
  * Returns number of items; *items is malloc'ed (caller frees with orc_free), prefsum has
  * n_paths+1 entries (caller array). count_type ORC_NODE/ORC_BP give node ids, ORC_EDGE edge ids */

@@ -42,8 +42,8 @@ const char *USAGE =
     "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
     "  -S, --groupby-sample             merge paths of the same sample\n"
     "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
-    "  -s, --subset <FILE>              count only the listed paths/groups (1-column list)\n"
-    "  -e, --exclude <FILE>             drop the listed paths/groups and every node/edge/bp they touch\n"
+    "  -s, --subset <FILE>              count only the listed paths/groups or path intervals (BED: 1, 3 or 12 columns)\n"
+    "  -e, --exclude <FILE>             drop the listed paths/groups/intervals and every node/edge/bp they touch\n"
     "      --cache                      keep / reuse the parsed graph in <GFA_FILE>.pcsr (checked against the\n"
     "                                   GFA's size, mtime and a content hash)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
@@ -72,7 +72,8 @@ struct Device {  // RAII over pnx_ctx
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
 std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges) {
-    if (!o.cache) return GraphStorage::from_gfa(o.file, index_edges);
+    // subset / exclude lists are applied while walking the path lines: they need the GFA text
+    if (!o.cache || !o.subset_file.empty() || !o.exclude_file.empty()) return GraphStorage::from_gfa(o.file, index_edges);
     const std::string cache_file = o.file + ".pcsr";
     if (auto g = GraphStorage::from_cache(cache_file, o.file, index_edges)) return g;
     auto g = GraphStorage::from_gfa(o.file, index_edges);
@@ -93,32 +94,62 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 }
 
 // upload graph + order for one count type
-struct Masking {  // -g/-S/-H grouping + -e list, needed to derive the ActiveTable per count type
+struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a count type is cut down by
     GroupMode mode = GROUP_PATHID;
-    std::string group_file, exclude_file;
+    std::string group_file, subset_file, exclude_file;
+    bool any() const { return !subset_file.empty() || !exclude_file.empty(); }
 };
 
-void upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk) {
-    ItemTable tab;
-    const ItemTableView view = g.item_table_view(ct, tab);
+using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncovered_bps (abacus.rs:1187-1229)
+
+// Returns the uncovered bp of partially covered nodes (bp counts under a subset list, else empty).
+// growth_weights: upload node_len - uncovered as the bp weight of such nodes, which is what
+// AbacusByGroup::calc_growth adds (abacus.rs:1013-1023); the histogram instead takes plain node
+// lengths and is corrected afterwards (construct_hist_bps, abacus.rs:779-785).
+Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
+                 bool growth_weights = false) {
     const uint64_t n_items = g.number_of_items(ct);
-    std::vector<uint8_t> excl;
-    if (!mk.exclude_file.empty()) {
-        if (tab.id_prefsum.empty()) tab = g.item_table(ct);  // cached graph: the flags want an owned table
-        excl = g.exclude_flags(ct, tab, mk.mode, mk.group_file, mk.exclude_file);
+    const uint32_t n_paths = (uint32_t)g.path_segments().size();
+    Uncovered uncovered;
+    if (mk.any()) {
+        MaskedTable m = g.masked_table(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
+        std::vector<uint32_t> w;
+        if (ct == COUNT_BP && growth_weights && !m.uncovered.empty()) {
+            w = g.node_lens();
+            for (const auto &u : m.uncovered) w[u.first] = u.second > w[u.first] ? 0 : (uint32_t)(w[u.first] - u.second);
+        }
+        const uint32_t none = 0;  // a valid pointer for an empty table
+        dev.check(pnx_set_csr(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
+                              (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
+                              m.exclude.empty() ? nullptr : m.exclude.data()));
+        uncovered = std::move(m.uncovered);
+    } else {
+        ItemTable tab;
+        const ItemTableView view = g.item_table_view(ct, tab);
+        dev.check(pnx_set_csr(dev.ctx, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
+                              ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
     }
-    dev.check(pnx_set_csr(dev.ctx, view.items, view.id_prefsum, (uint32_t)g.path_segments().size(),
-                          (uint32_t)n_items, ct == COUNT_BP ? g.node_lens().data() : nullptr,
-                          excl.empty() ? nullptr : excl.data()));
     dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
                             (uint32_t)order.groups.size()));
+    return uncovered;
 }
 
 std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order,
                                   const Masking &mk) {
-    upload(dev, g, ct, order, mk);
+    const Uncovered uncovered = upload(dev, g, ct, order, mk);
     std::vector<uint64_t> hist(order.groups.size() + 1, 0);
-    dev.check(pnx_hist(dev.ctx, nullptr, hist.data()));
+    if (uncovered.empty()) {
+        dev.check(pnx_hist(dev.ctx, nullptr, hist.data()));
+        return hist;
+    }
+    // "subtract uncovered bps", abacus.rs:779-785: the bp a subset interval leaves out of a node
+    // move from the node's coverage bin to bin 0 (usize arithmetic of a release build)
+    std::vector<uint32_t> countable(g.number_of_items(ct) + 1, 0);
+    dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+    for (const auto &u : uncovered) {
+        hist[countable[u.first]] -= u.second;
+        hist[0] += u.second;
+    }
     return hist;
 }
 
@@ -132,7 +163,7 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
         have_node = have_node || c == COUNT_NODE;
         have_bp = have_bp || c == COUNT_BP;
     }
-    if (have_node && have_bp) {
+    if (have_node && have_bp && !mk.any()) {  // with -s/-e lists the two count types exclude differently
         upload(dev, g, COUNT_BP, order, mk);
         for (size_t k = 0; k < cts.size(); ++k) {
             if (cts[k] == COUNT_EDGE) continue;
@@ -169,6 +200,7 @@ Masking masking(const Options &o) {
     Masking m;
     m.mode = group_mode(o);
     m.group_file = o.group_file;
+    m.subset_file = o.subset_file;
     m.exclude_file = o.exclude_file;
     return m;
 }
@@ -252,7 +284,7 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     const uint32_t G = (uint32_t)order.groups.size();
     const uint32_t T = (uint32_t)tc.coverage.size();
     Device dev(o.device);
-    upload(dev, *g, ct, order, masking(o));
+    upload(dev, *g, ct, order, masking(o), true);
     // AbacusByGroup::calc_growth prologue (abacus.rs:997-998, 1009) in f64 on the host
     std::vector<uint32_t> cov(T), qtab((size_t)T * G);
     for (uint32_t t = 0; t < T; ++t) {

@@ -565,23 +565,19 @@ ItemTableView GraphStorage::item_table_view(CountType count, ItemTable &storage)
     return ItemTableView{storage.items.data(), storage.id_prefsum.data(), storage.items.size()};
 }
 
-ItemTable GraphStorage::item_table(CountType count) const {
-    const Impl &im = *impl_;
+namespace {
+struct Steps {  // every path's steps as node ids (+ orientations), file order
+    std::vector<uint32_t> ids;
+    std::vector<uint8_t> ori;  // 0 forward, 1 backward; empty unless asked for
+    std::vector<uint64_t> pref;
+};
+}  // namespace
+
+static void parse_all_steps(const GraphStorage::Impl &im, const std::vector<PathSegment> &paths_, uint64_t node_count_,
+                            bool want_ori, Steps &out) {
     const Image &s = im.image;
     const size_t P = paths_.size();
-    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
-    if (im.cached) {  // parallel copy out of the mapping (item_table_view() avoids even that)
-        const int k = count == COUNT_EDGE ? 1 : 0;
-        ItemTable t;
-        t.id_prefsum.assign(im.c_prefsum[k], im.c_prefsum[k] + P + 1);
-        t.items.resize(im.c_n_items[k]);
-        const size_t n = im.c_n_items[k], CH = 1 << 22;
-        ThreadPool::instance().parallel_for((n + CH - 1) / CH, [&](size_t c) {
-            const size_t b = c * CH, e = std::min(n, b + CH);
-            std::memcpy(t.items.data() + b, im.c_items[k] + b, (e - b) * sizeof(uint32_t));
-        });
-        return t;
-    }
+    const CountType count = want_ori ? COUNT_EDGE : COUNT_NODE;
     constexpr size_t CHUNK = 64 * 1024;
 
     std::vector<Chunk> chunks;
@@ -677,6 +673,34 @@ ItemTable GraphStorage::item_table(CountType count) const {
         while (e < s.size() && s[e] != ',' && s[e] != '\t' && s[e] != '\n' && e - i < 64) ++e;
         throw std::runtime_error("unknown node " + s.substr(i, e - i));
     }
+
+    out.ids = std::move(ids);
+    out.ori = std::move(ori);
+    out.pref = std::move(node_pref);
+}
+
+ItemTable GraphStorage::item_table(CountType count) const {
+    const Impl &im = *impl_;
+    const size_t P = paths_.size();
+    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    if (im.cached) {  // parallel copy out of the mapping (item_table_view() avoids even that)
+        const int k = count == COUNT_EDGE ? 1 : 0;
+        ItemTable t;
+        t.id_prefsum.assign(im.c_prefsum[k], im.c_prefsum[k] + P + 1);
+        t.items.resize(im.c_n_items[k]);
+        const size_t n = im.c_n_items[k], CH = 1 << 22;
+        ThreadPool::instance().parallel_for((n + CH - 1) / CH, [&](size_t c) {
+            const size_t b = c * CH, e = std::min(n, b + CH);
+            std::memcpy(t.items.data() + b, im.c_items[k] + b, (e - b) * sizeof(uint32_t));
+        });
+        return t;
+    }
+    Steps steps;
+    parse_all_steps(im, paths_, node_count_, count == COUNT_EDGE, steps);
+    std::vector<uint32_t> &ids = steps.ids;
+    std::vector<uint8_t> &ori = steps.ori;
+    std::vector<uint64_t> &node_pref = steps.pref;
+    ThreadPool &pool = ThreadPool::instance();
 
     ItemTable t;
     if (count != COUNT_EDGE) {
@@ -784,8 +808,87 @@ std::vector<std::string> load_groups(const std::vector<PathSegment> &paths, cons
     return group;
 }
 
-// a 1-column list of paths / groups (parse_bed_to_path_segments, io.rs:35-119, without the
-// coordinate forms) resolved like complement_with_group_assignments (abacus.rs:152-206).
+// usize::from_str: decimal digits with an optional leading '+'
+bool parse_usize_field(std::string_view f, uint64_t &out) {
+    if (!f.empty() && f[0] == '+') f.remove_prefix(1);
+    return parse_u64(f, out);
+}
+
+// "1,2,3,".split(',').filter_map(|s| usize::from_str(s.trim()).ok())
+std::vector<uint64_t> parse_usize_list(std::string_view f) {
+    std::vector<uint64_t> out;
+    size_t i = 0;
+    for (;;) {
+        size_t e = f.find(',', i);
+        if (e == std::string_view::npos) e = f.size();
+        std::string_view t = f.substr(i, e - i);
+        while (!t.empty() && std::isspace((unsigned char)t.front())) t.remove_prefix(1);
+        while (!t.empty() && std::isspace((unsigned char)t.back())) t.remove_suffix(1);
+        uint64_t v;
+        if (parse_usize_field(t, v)) out.push_back(v);
+        if (e >= f.size()) break;
+        i = e + 1;
+    }
+    return out;
+}
+
+// parse_bed_to_path_segments with block info (io.rs:35-119): a name alone, or name / start / end
+// (the columns override coordinates in the name), or BED12 with one segment per block
+std::vector<PathSegment> parse_bed(const std::string &file) {
+    std::vector<PathSegment> out;
+    int lineno = 0;
+    for (std::string l : read_lines(file)) {
+        ++lineno;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        std::vector<std::string_view> fields;
+        {
+            std::string_view v(l);
+            size_t i = 0;
+            for (;;) {
+                size_t e = v.find('\t', i);
+                if (e == std::string_view::npos) {
+                    fields.push_back(v.substr(i));
+                    break;
+                }
+                fields.push_back(v.substr(i, e - i));
+                i = e + 1;
+            }
+        }
+        const std::string_view name = fields[0];
+        if (name.rfind("browser ", 0) == 0 || name.rfind("track ", 0) == 0 || (!name.empty() && name[0] == '#')) continue;
+        auto with_coords = [&](uint64_t st, uint64_t en) {
+            PathSegment ps = PathSegment::from_str(name);
+            ps.has_start = ps.has_end = true;
+            ps.start = st;
+            ps.end = en;
+            out.push_back(std::move(ps));
+        };
+        if (fields.size() == 1) {
+            out.push_back(PathSegment::from_str(name));
+        } else if (fields.size() >= 3) {
+            uint64_t st, en;
+            if (!parse_usize_field(fields[1], st) || !parse_usize_field(fields[2], en))
+                throw std::runtime_error("error line " + std::to_string(lineno) + ": start / end is not an usize");
+            if (fields.size() == 12) {
+                uint64_t bc = 0;
+                if (!parse_usize_field(fields[9], bc)) bc = 0;
+                const std::vector<uint64_t> sizes = parse_usize_list(fields[10]), starts = parse_usize_list(fields[11]);
+                if (bc != sizes.size() || bc != starts.size())
+                    throw std::runtime_error("error in block sizes/starts in line " + std::to_string(lineno) +
+                                             ": counts do not match");
+                for (size_t k = 0; k < sizes.size(); ++k) with_coords(st + starts[k], st + starts[k] + sizes[k]);
+            } else {
+                with_coords(st, en);
+            }
+        } else {
+            throw std::runtime_error("error in line " + std::to_string(lineno) +
+                                     ": row must have either 1, 3, or 12 columns, but has 2");
+        }
+    }
+    return out;
+}
+
+// a BED list of paths / groups resolved like complement_with_group_assignments (abacus.rs:152-206).
 // mark[i] = path i is named; visit = entries in file order as path indices (first path of a group).
 // exact_coords: a path entry only matches graph paths with equal coordinates, and group members
 // only match paths without coordinates (HashSet<&PathSegment> comparison, abacus.rs:329-336).
@@ -799,12 +902,7 @@ void read_path_list(const std::string &file, const std::vector<PathSegment> &pat
         by_key[key[i]].push_back((uint32_t)i);
         by_group[group[i]].push_back((uint32_t)i);
     }
-    for (std::string l : read_lines(file)) {
-        if (!l.empty() && l.back() == '\r') l.pop_back();
-        if (l.rfind("browser ", 0) == 0 || l.rfind("track ", 0) == 0 || (!l.empty() && l[0] == '#')) continue;
-        if (l.find('\t') != std::string::npos)
-            throw std::runtime_error("path lists with coordinate columns (BED) are not supported yet");
-        PathSegment ps = PathSegment::from_str(l);
+    for (const PathSegment &ps : parse_bed(file)) {
         auto pk = by_key.find(ps.clear_key());
         if (pk != by_key.end()) {
             for (uint32_t i : pk->second) {
@@ -817,6 +915,9 @@ void read_path_list(const std::string &file, const std::vector<PathSegment> &pat
         } else {
             auto bg = by_group.find(ps.id());
             if (bg == by_group.end()) continue;  // unknown path/group: logged and skipped by the reference
+            if (ps.has_start && ps.has_end)
+                throw std::runtime_error("invalid coordinate \"" + ps.display() +
+                                         "\": group identifiers are not allowed to have start/stop information!");
             bool first = true;
             for (uint32_t i : bg->second) {
                 if (exact_coords && (paths[i].has_start || paths[i].has_end)) continue;
@@ -1109,6 +1210,281 @@ std::vector<uint8_t> GraphStorage::exclude_flags(CountType count, const ItemTabl
         if (ex[p])
             for (uint64_t j = table.id_prefsum[p]; j < table.id_prefsum[p + 1]; ++j) flags[table.items[j]] = 1;
     return flags;
+}
+
+// ------------------------------------------------------------------------------------------
+// subset / exclude lists with coordinates
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Iv {
+    uint64_t s, e;  // [s, e), path or node coordinates
+    bool operator<(const Iv &o) const { return s != o.s ? s < o.s : e < o.e; }
+    bool operator==(const Iv &o) const { return s == o.s && e == o.e; }
+};
+constexpr uint64_t USIZE_MAX = ~0ull;
+using IvMap = std::unordered_map<std::string, std::vector<Iv>>;
+
+// the coordinate list of a BED file per path id: load_coord_list_file +
+// complement_with_group_assignments (abacus.rs:152-210) + build_subpath_map (:354-382).
+// Entries without coordinates and group members stand for the whole path, (0, usize::MAX).
+IvMap load_subpath_map(const std::string &file, const std::vector<PathSegment> &paths, const std::vector<std::string> &key,
+                       const std::vector<std::string> &group) {
+    std::unordered_map<std::string, bool> known_key;
+    std::unordered_map<std::string, std::vector<uint32_t>> by_group;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        known_key.emplace(key[i], true);
+        by_group[group[i]].push_back((uint32_t)i);
+    }
+    IvMap m;
+    for (const PathSegment &ps : parse_bed(file)) {
+        if (known_key.count(ps.clear_key())) {
+            m[ps.id()].push_back(ps.has_start && ps.has_end ? Iv{ps.start, ps.end} : Iv{0, USIZE_MAX});
+            continue;
+        }
+        auto bg = by_group.find(ps.id());
+        if (bg == by_group.end()) continue;  // unknown path/group: logged and skipped
+        if (ps.has_start && ps.has_end)
+            throw std::runtime_error("invalid coordinate \"" + ps.display() +
+                                     "\": group identifiers are not allowed to have start/stop information!");
+        for (uint32_t i : bg->second) m[paths[i].id()].push_back(Iv{0, USIZE_MAX});
+    }
+    for (auto &kv : m) {  // a set of intervals, sorted, overlapping or touching ones joined
+        std::vector<Iv> &v = kv.second;
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        std::vector<Iv> out;
+        for (const Iv &x : v) {
+            if (!out.empty() && out.back().e >= x.s)
+                out.back().e = std::max(out.back().e, x.e);
+            else
+                out.push_back(x);
+        }
+        v.swap(out);
+    }
+    return m;
+}
+
+// intersects / is_contained (src/util.rs:370-398) on sorted disjoint intervals
+bool any_touching(const std::vector<Iv> *v, Iv el) {
+    if (!v) return false;
+    for (const Iv &x : *v)
+        if (x.s <= el.e && x.e >= el.s) return true;
+    return false;
+}
+bool any_containing(const std::vector<Iv> *v, Iv el) {
+    if (!v) return false;
+    for (const Iv &x : *v)
+        if (x.s <= el.s && x.e >= el.e) return true;
+    return false;
+}
+
+// IntervalContainer (src/util.rs:209-310) for one node: a sorted union of [s, e) pieces where
+// touching pieces are joined, which is what its `add` maintains
+struct Pieces {
+    std::vector<Iv> v;
+    void add(uint64_t s, uint64_t e) {
+        size_t lo = 0;
+        while (lo < v.size() && v[lo].e < s) ++lo;  // wholly before, not even touching
+        size_t hi = lo;
+        while (hi < v.size() && v[hi].s <= e) {
+            s = std::min(s, v[hi].s);
+            e = std::max(e, v[hi].e);
+            ++hi;
+        }
+        v.erase(v.begin() + (ptrdiff_t)lo, v.begin() + (ptrdiff_t)hi);
+        v.insert(v.begin() + (ptrdiff_t)lo, Iv{s, e});
+    }
+};
+
+// IntervalContainer::total_coverage (src/util.rs:272-305) in the reference's own arithmetic
+// (usize, wrapping as in a release build): the bp of `v` outside the exclude pieces `ex`
+uint64_t total_coverage(const std::vector<Iv> &v, const std::vector<Iv> *ex) {
+    uint64_t res = 0;
+    size_t i = 0;
+    for (const Iv &x : v) {
+        if (!ex) {
+            res += x.e - x.s;
+            continue;
+        }
+        while (i < ex->size() && (*ex)[i].e <= x.s) ++i;
+        if (i < ex->size() && (*ex)[i].s < x.e) {
+            res += std::min((*ex)[i].s - 1, x.e) - x.s;
+            if ((*ex)[i].e < x.e) res += x.e - (*ex)[i].e + 1;
+        } else {
+            res += x.e - x.s;
+        }
+    }
+    return res;
+}
+
+// The pieces of one node [p, p + l) that a sorted interval list selects, in node coordinates
+// (mirrored for a backward step); `cur` walks the list along the path and stays on an interval
+// that reaches the end of the node (update_tables, util.rs:626-660 / 662-704).
+template <typename F>
+inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, uint64_t l, bool backward, F &&emit) {
+    while (cur < list.size() && list[cur].s < p + l) {
+        const Iv &x = list[cur];
+        if (x.e <= p) {  // lies before the node
+            ++cur;
+            continue;
+        }
+        uint64_t a = x.s > p ? x.s - p : 0;
+        const bool ends_inside = x.e < p + l;
+        uint64_t b = ends_inside ? x.e - p : l;
+        if (backward) {
+            const uint64_t ma = l - b, mb = l - a;
+            a = ma;
+            b = mb;
+        }
+        emit(a, b);
+        if (!ends_inside) return;
+        ++cur;
+    }
+}
+
+}  // namespace
+
+bool GraphStorage::from_cache_file() const { return impl_->cached; }
+
+MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const std::string &group_file,
+                                       const std::string &subset_file, const std::string &exclude_file) const {
+    const Impl &im = *impl_;
+    if (im.cached) throw std::runtime_error("subset / exclude lists need the GFA text: load the graph without the cache");
+    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    const size_t P = paths_.size();
+    const uint64_t n_items = number_of_items(count);
+    std::vector<std::string> key(P);
+    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+    const std::vector<std::string> group = load_groups(paths_, key, mode, group_file);
+    const bool have_inc = !subset_file.empty(), have_exc = !exclude_file.empty();
+    IvMap inc, exc;
+    if (have_inc) inc = load_subpath_map(subset_file, paths_, key, group);
+    if (have_exc) exc = load_subpath_map(exclude_file, paths_, key, group);
+
+    Steps steps;
+    parse_all_steps(im, paths_, node_count_, true, steps);
+
+    MaskedTable out;
+    out.table.id_prefsum.assign(P + 1, 0);
+    if (have_exc) out.exclude.assign(n_items + 1, 0);
+    // bp only: partially covered / partially excluded nodes (load_optional_subsetting, abacus.rs:384-425)
+    const bool track_cov = count == COUNT_BP && have_inc, annotate = count == COUNT_BP && have_exc;
+    std::unordered_map<uint32_t, Pieces> covered, partly_excluded;
+    const std::vector<Iv> complete = {Iv{0, USIZE_MAX}}, none;
+
+    // how each path is treated (util.rs:240-300)
+    enum { SKIP, WHOLE, WALK };
+    std::vector<uint8_t> how(P);
+    std::vector<const std::vector<Iv> *> ic(P), ec(P);
+    for (size_t k = 0; k < P; ++k) {
+        const std::string id = paths_[k].id();
+        ic[k] = &complete;
+        ec[k] = &none;
+        if (have_inc) {
+            auto it = inc.find(id);
+            ic[k] = it == inc.end() ? &none : &it->second;
+        }
+        if (have_exc) {
+            auto it = exc.find(id);
+            if (it != exc.end()) ec[k] = &it->second;
+        }
+        const Iv span = paths_[k].has_start && paths_[k].has_end ? Iv{paths_[k].start, paths_[k].end} : Iv{0, USIZE_MAX};
+        if (have_inc && !any_touching(ic[k], span) && !any_touching(ec[k], span))
+            how[k] = SKIP;
+        else if (count != COUNT_EDGE && (!have_inc || any_containing(ic[k], span)) && (!have_exc || any_containing(ec[k], span)))
+            how[k] = WHOLE;
+        else
+            how[k] = WALK;
+    }
+
+    std::vector<uint32_t> &items = out.table.items;
+    for (size_t k = 0; k < P; ++k) {
+        const uint64_t b = steps.pref[k], e = steps.pref[k + 1];
+        const uint32_t *ids = steps.ids.data() + b;
+        const uint8_t *ori = steps.ori.data() + b;
+        const uint64_t len = e - b;
+        if (how[k] == WHOLE) {
+            items.insert(items.end(), ids, ids + len);
+            if (!ec[k]->empty())  // every node of an excluded path is excluded as a whole (util.rs:1171-1181)
+                for (uint64_t j = 0; j < len; ++j) out.exclude[ids[j]] = 1;
+        } else if (how[k] == WALK && count != COUNT_EDGE) {
+            size_t ci = 0, cj = 0;
+            uint64_t p = paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0;
+            for (uint64_t j = 0; j < len; ++j) {
+                const uint32_t sid = ids[j];
+                const uint64_t l = node_lens_[sid];
+                node_pieces(*ic[k], ci, p, l, ori[j] != 0, [&](uint64_t a, uint64_t bb) {
+                    items.push_back(sid);  // once per piece, like the reference
+                    if (!track_cov) return;
+                    if (bb - a == l)
+                        covered.erase(sid);  // seen in full: earlier partial sightings are dropped
+                    else
+                        covered[sid].add(a, bb);
+                });
+                node_pieces(*ec[k], cj, p, l, ori[j] != 0, [&](uint64_t a, uint64_t bb) {
+                    if (!annotate) {
+                        out.exclude[sid] = 1;
+                        return;
+                    }
+                    // ActiveTable::activate_n_annotate (src/util.rs:147-181)
+                    if (bb - a == l) {
+                        out.exclude[sid] = 1;
+                        partly_excluded.erase(sid);
+                        return;
+                    }
+                    Pieces &pc = partly_excluded[sid];
+                    pc.add(a, bb);
+                    if (pc.v[0] == Iv{0, l}) {
+                        partly_excluded.erase(sid);
+                        out.exclude[sid] = 1;
+                    }
+                });
+                if (ci >= ic[k]->size() && cj >= ec[k]->size()) break;  // nothing left to meet
+                p += l;
+            }
+        } else if (how[k] == WALK && len > 0) {
+            // update_tables_edgecount (util.rs:723-795): an edge sits at the start of its second node
+            size_t ci = 0, cj = 0;
+            uint64_t p = (paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0) + node_lens_[ids[0]];
+            for (uint64_t j = 0; j + 1 < len; ++j) {
+                while (ci < ic[k]->size() && (*ic[k])[ci].e <= p) ++ci;
+                while (cj < ec[k]->size() && (*ec[k])[cj].e <= p) ++cj;
+                const uint64_t l = node_lens_[ids[j + 1]];
+                uint64_t uv;
+                uint8_t oo;
+                canonical(ids[j], ori[j], ids[j + 1], ori[j + 1], uv, oo);
+                const uint32_t eid = im.edges.find(uv, oo);
+                if (!eid) throw std::runtime_error("unknown edge in path " + paths_[k].display());
+                if (ci < ic[k]->size() && (*ic[k])[ci].s < p + l) items.push_back(eid);
+                if (have_exc && cj < ec[k]->size() && (*ec[k])[cj].s < p + l)
+                    out.exclude[eid] = 1;
+                else if (ci >= ic[k]->size() && cj >= ec[k]->size())
+                    break;
+                p += l;
+            }
+        }
+        out.table.id_prefsum[k + 1] = items.size();
+    }
+
+    // quantify_uncovered_bps (abacus.rs:1187-1229)
+    if (track_cov) {
+        for (const auto &kv : covered) {
+            const uint32_t sid = kv.first;
+            if (have_exc && out.exclude[sid]) continue;  // excluded as a whole: never counted
+            const uint64_t l = node_lens_[sid];
+            std::vector<Iv> ex_pieces;
+            if (have_exc) {
+                auto it = partly_excluded.find(sid);
+                if (it != partly_excluded.end()) ex_pieces = it->second.v;
+            }
+            const uint64_t cov = total_coverage(kv.second.v, have_exc ? &ex_pieces : nullptr);
+            if (cov > l) continue;  // "oops, total coverage is larger than node length": left alone
+            out.uncovered.emplace_back(sid, l - cov);
+        }
+        std::sort(out.uncovered.begin(), out.uncovered.end());
+    }
+    return out;
 }
 
 PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file, const std::string &order_file,

@@ -10,8 +10,8 @@
 // Design differences (not behaviour): the file is read ONCE into memory (plain or gzip) and
 // all passes run over that buffer; names are hashed as string_views into it; path steps
 // are parsed in parallel over the worker pool; ids narrow to u32 (the device ABI's width).
-// Subset / exclude lists (-s/-e) are supported for whole paths / groups; BED coordinate
-// columns are rejected.
+// Subset / exclude lists (-s/-e) are BED files: whole paths / groups (1 column) or intervals on
+// paths (3 or 12 columns), see masked_table().
 #pragma once
 #include <cstdint>
 #include <memory>
@@ -48,6 +48,16 @@ struct ItemTableView {  // an ItemTable by pointers: into a mapped .pcsr cache, 
     uint64_t n_steps = 0;
 };
 
+// parse_gfa_paths_walks under GraphMask.include_coords / exclude_coords (graph_broker/util.rs:
+// 208-366): what a count type's abacus is built from when -s / -e lists are given
+struct MaskedTable {
+    ItemTable table;               // steps inside the subset intervals; paths outside it have an empty entry
+    std::vector<uint8_t> exclude;  // ActiveTable.items, n_items + 1; empty without an exclude list
+    // quantify_uncovered_bps (abacus.rs:1187-1229): (node id, bp outside the subset intervals) of
+    // partially covered nodes, ascending ids; only for COUNT_BP with a subset list
+    std::vector<std::pair<uint32_t, uint64_t>> uncovered;
+};
+
 struct PathOrder {  // result of GraphMask::get_path_order + group-id assignment
     std::vector<uint32_t> path_idx, group_id;
     std::vector<std::string> groups;
@@ -69,10 +79,19 @@ public:
     // the same without a copy when the graph comes from a cache; `storage` holds the table otherwise
     ItemTableView item_table_view(CountType count, ItemTable &storage) const;
 
+    // ItemTable, exclude flags and uncovered bps under BED subset / exclude lists (either may be
+    // empty).  Node counts exclude a node that any exclude interval touches, bp counts only when
+    // the intervals cover all of it (ActiveTable with annotation, src/util.rs:118-207); edges
+    // follow update_tables_edgecount (util.rs:723-795).  Needs the GFA text (not a .pcsr cache).
+    MaskedTable masked_table(CountType count, GroupMode mode, const std::string &group_file,
+                             const std::string &subset_file, const std::string &exclude_file) const;
+
     // GraphMask::load_groups + get_path_order (+ optional -O order file, -s subset list,
-    // -e exclude list; lists name whole paths or groups, coordinate columns are rejected)
+    // -e exclude list: BED files naming paths, groups or intervals on paths)
     PathOrder path_order(GroupMode mode, const std::string &group_file, const std::string &order_file,
                          const std::string &subset_file = "", const std::string &exclude_file = "") const;
+
+    bool from_cache_file() const;
 
     // ActiveTable.items of a whole-path exclude list for `count` (src/util.rs:118-124;
     // graph_broker/util.rs:1171-1181, 785-787): n_items + 1 flags, every item that lies on an

@@ -105,6 +105,38 @@ int pnh_graph_exclude_flags(const void *g, int count_type, int group_mode, const
     }
 }
 
+// ItemTable / exclude flags / uncovered bps under BED subset and exclude lists (GraphStorage::masked_table).
+// Two calls: with items == NULL the sizes are returned (*n_steps, *n_uncovered); then the caller's arrays are
+// filled (prefsum n_paths + 1, exclude n_items + 1 -- zeros without an exclude list, uncovered as id / bp arrays).
+int pnh_graph_masked_table(const void *g, int count_type, int group_mode, const char *group_file, const char *subset_file,
+                           const char *exclude_file, uint64_t *n_steps, uint64_t *n_uncovered, uint32_t *items,
+                           uint64_t *prefsum, uint8_t *exclude, uint32_t *uncov_ids, uint64_t *uncov_bps) {
+    try {
+        const pnh::GraphStorage *gs = static_cast<const pnh::GraphStorage *>(g);
+        pnh::MaskedTable m = gs->masked_table((pnh::CountType)count_type, (pnh::GroupMode)group_mode, group_file ? group_file : "",
+                                              subset_file ? subset_file : "", exclude_file ? exclude_file : "");
+        if (!items) {
+            *n_steps = m.table.items.size();
+            *n_uncovered = m.uncovered.size();
+            return 0;
+        }
+        if (*n_steps != m.table.items.size() || *n_uncovered != m.uncovered.size()) throw std::runtime_error("size mismatch");
+        std::copy(m.table.items.begin(), m.table.items.end(), items);
+        std::copy(m.table.id_prefsum.begin(), m.table.id_prefsum.end(), prefsum);
+        const uint64_t n = gs->number_of_items((pnh::CountType)count_type);
+        std::fill(exclude, exclude + n + 1, (uint8_t)0);
+        std::copy(m.exclude.begin(), m.exclude.end(), exclude);
+        for (size_t k = 0; k < m.uncovered.size(); ++k) {
+            uncov_ids[k] = m.uncovered[k].first;
+            uncov_bps[k] = m.uncovered[k].second;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
 // visiting order; group names are returned '\n'-joined in names_buf. Returns #groups or -1.
 int64_t pnh_graph_path_order(const void *g, int group_mode, const char *group_file, const char *order_file,
                              const char *subset_file, const char *exclude_file, uint32_t *path_idx,

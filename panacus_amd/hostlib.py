@@ -138,6 +138,9 @@ def _bind_graph(L):
                                        u64p, C.c_char_p, C.c_uint64]
     L.pnh_graph_exclude_flags.restype = C.c_int
     L.pnh_graph_exclude_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
+    L.pnh_graph_masked_table.restype = C.c_int
+    L.pnh_graph_masked_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, u64p, u64p, u32p,
+                                         u64p, C.POINTER(C.c_uint8), u32p, u64p]
     L._graph_bound = True
 
 
@@ -226,6 +229,29 @@ class GfaGraph:
         if rc != 0:
             raise ValueError(self._L.pnh_last_error().decode())
         return flags
+
+    def masked_table(self, count_type, subset_file=None, exclude_file=None, group_mode=GROUP_PATHID, group_file=None):
+        """ItemTable, exclude flags and uncovered bps under BED -s / -e lists (coordinates allowed).
+        -> (items[u32], prefsum[u64], exclude[u8, n_items+1], uncov_ids[u32], uncov_bps[u64])"""
+        enc = lambda f: os.fsencode(f) if f else None  # noqa: E731
+        n_steps, n_unc = C.c_uint64(0), C.c_uint64(0)
+        args = (self._h, count_type, group_mode, enc(group_file), enc(subset_file), enc(exclude_file))
+        if self._L.pnh_graph_masked_table(*args, C.byref(n_steps), C.byref(n_unc), None, None, None, None, None) != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        items = np.zeros(max(n_steps.value, 1), dtype=np.uint32)
+        pre = np.zeros(self.n_paths + 1, dtype=np.uint64)
+        flags = np.zeros(self.n_items(count_type) + 1, dtype=np.uint8)
+        ids = np.zeros(max(n_unc.value, 1), dtype=np.uint32)
+        bps = np.zeros(max(n_unc.value, 1), dtype=np.uint64)
+        rc = self._L.pnh_graph_masked_table(*args, C.byref(n_steps), C.byref(n_unc),
+                                            items.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            pre.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            bps.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        return items[: n_steps.value], pre, flags, ids[: n_unc.value], bps[: n_unc.value]
 
     def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None, subset_file=None,
                    exclude_file=None):

@@ -219,6 +219,97 @@ def test_cli_subset_exclude(tmp_path):
         assert [x[0] for x in rows] == gnames and [x[1] for x in rows] == [str(int(v)) for v in exp]
 
 
+def _oracle_masked(g, ct, gm, sf, ef):
+    """hist (with the uncovered-bp fix-up) and ordered growth inputs of the oracle under -s / -e lists"""
+    pi, gi, gnames = g.path_order(gm, None, None, sf, ef)
+    items, pre, fl, ids, bps = g.masked_table(ct, sf, ef)
+    excl = fl if ef else None
+    cov = orc.coverage(items, pre, pi, gi, g.n_items(ct), excl)
+    h = orc.hist(cov, len(gnames), g.node_lens if ct == orc.BP else None)
+    h = orc.hist_apply_uncovered(cov, ids, bps, h)
+    w = None
+    if ct == orc.BP:  # AbacusByGroup::calc_growth adds node_len - uncovered (abacus.rs:1013-1023)
+        w = g.node_lens.copy()
+        for i, u in zip(ids, bps):
+            w[i] = 0 if u > w[i] else w[i] - u
+    r_, c_ = orc.by_group(items, pre, pi, gi, g.n_items(ct), excl)
+    return gnames, h, r_, c_, w
+
+
+def _check_cli_masked(g, path, extra, gm, sf, ef):
+    for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+        gnames, h, r_, c_, w = _oracle_masked(g, ct, gm, sf, ef)
+        rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5"] + extra + [path])
+        assert rc == 0, err
+        rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+        assert [int(r[1]) for r in rows] == h.tolist(), (extra, cname)
+        if len(gnames) > 0:
+            exp = orc.growth(h, (orc.ABSOLUTE, 2), (orc.RELATIVE, 0.5))
+            assert [r[3] for r in rows[1:]] == [hl.format_f64(math.floor(x)) for x in exp]
+            rc, out, err = hl.run_cli(["ordered-histgrowth", "-c", cname, "-l", "1,2", "-q", "0.3,0"] + extra + [path])
+            assert rc == 0, err
+            rows = [x.split("\t") for x in _body(out).split("\n")[4:] if x]
+            assert [x[0] for x in rows] == gnames
+            for k, (c, q) in enumerate(((1, 0.3), (2, 0.0))):
+                exp = orc.ordered_growth(r_, c_, len(gnames), (orc.ABSOLUTE, c), (orc.RELATIVE, q), w)
+                assert [x[1 + k] for x in rows] == [str(int(v)) for v in exp], (extra, cname, k)
+    # all count types in one call take the same per-type masks
+    rc, out, err = hl.run_cli(["hist", "-c", "all"] + extra + [path])
+    assert rc == 0, err
+    rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+    head = _body(out).split("\n")[1].split("\t")[1:]
+    for col, cname in enumerate(head):
+        ct = {"node": orc.NODE, "bp": orc.BP, "edge": orc.EDGE}[cname]
+        assert [int(r[1 + col]) for r in rows] == _oracle_masked(g, ct, gm, sf, ef)[1].tolist(), (extra, cname)
+
+
+@pytest.mark.gpu
+def test_cli_bed_intervals_chrM(golden_dir):
+    """-s / -e BED lists with coordinates through the CLI on the GPU against the oracle
+    pipeline, on the reference's own BED inputs (test/bed_chrM; no expected outputs exist upstream)."""
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    bed = os.path.join(golden_dir, "bed_chrM")
+    g = orc.Graph(gfa, index_edges=True)
+    for sf, ef in (("inclusion.bed3", None), (None, "exclusion.bed3"), ("inclusion.bed3", "exclusion.bed3"),
+                   ("inclusion_sub.bed1", "exclusion.bed3"), ("inclusion.bed1", None)):
+        sf, ef = sf and os.path.join(bed, sf), ef and os.path.join(bed, ef)
+        extra = (["-s", sf] if sf else []) + (["-e", ef] if ef else [])
+        _check_cli_masked(g, gfa, extra, orc.GROUP_PATHID, sf, ef)
+        _check_cli_masked(g, gfa, extra + ["-S"], orc.GROUP_SAMPLE, sf, ef)
+
+
+@pytest.mark.gpu
+def test_cli_bed_intervals_synthetic(tmp_path):
+    """random intervals over a generated graph: partially covered and partially excluded nodes"""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "3000", "--paths", "8", "--links", "-o", path])
+    assert rc == 0, err
+    g = orc.Graph(path, index_edges=True)
+    names = [n.split(":")[0] for n in g.path_names()]
+    items, pre = g.item_table(orc.NODE)
+    bp = [int(g.node_lens[items[pre[k]:pre[k + 1]]].sum()) for k in range(g.n_paths)]
+    rng = np.random.default_rng(11)
+    n_unc = 0
+    for rep in range(4):
+        def rows(n_rows):
+            out_rows = []
+            for _ in range(n_rows):
+                k = int(rng.integers(0, len(names)))
+                lo = int(rng.integers(0, bp[k]))
+                out_rows.append(f"{names[k]}\t{lo}\t{lo + int(rng.integers(1, bp[k] // 3 + 2))}")
+            return "\n".join(out_rows) + "\n"
+        sub, exc = tmp_path / f"s{rep}.bed", tmp_path / f"e{rep}.bed"
+        sub.write_text(rows(6))
+        exc.write_text(rows(3))
+        for sf, ef in ((str(sub), None), (None, str(exc)), (str(sub), str(exc))):
+            extra = (["-s", sf] if sf else []) + (["-e", ef] if ef else [])
+            _check_cli_masked(g, path, extra, orc.GROUP_PATHID, sf, ef)
+            if sf:
+                g.path_order(orc.GROUP_PATHID, None, None, sf, ef)
+                n_unc += len(g.masked_table(orc.BP, sf, ef)[3])
+    assert n_unc > 0  # the uncovered-bp fix-up was exercised
+
+
 @pytest.mark.gpu
 def test_cli_similarity_chrM(golden_dir):
     gfa = os.path.join(golden_dir, "chrM_test.gfa")

@@ -191,10 +191,32 @@ def test_subset_and_exclude_lists_match_oracle(golden_dir, tmp_path):
     # subset by explicit paths keeps only those paths, in list order (duplicates ignored)
     pa, ga, na = a.path_order(hl.GROUP_PATHID, None, None, str(sub), None)
     assert pa.tolist() == [8, 1, 4]
-    with pytest.raises(ValueError):
-        bed = tmp_path / "bed.txt"
-        bed.write_text(names[0] + "\t0\t100\n")
-        a.path_order(hl.GROUP_PATHID, None, None, str(bed), None)
+    # whole-path lists through the interval machinery give the same flags, and the full steps of
+    # exactly the listed paths
+    for ct in (hl.NODE, hl.BP, hl.EDGE):
+        items, pre = a.item_table(hl.EDGE if ct == hl.EDGE else hl.NODE)
+        mi, mp, mf, ui, ub = a.masked_table(ct, str(sub), str(exc))
+        oi, op, of_, oui, oub = b.masked_table(ct, str(sub), str(exc))
+        assert np.array_equal(mi.astype(np.uint64), oi) and np.array_equal(mp, op) and np.array_equal(mf, of_)
+        assert len(ui) == 0 and len(oui) == 0
+        assert np.array_equal(mf, a.exclude_flags(hl.EDGE if ct == hl.EDGE else hl.NODE, str(exc)))
+        for k in range(a.n_paths):
+            want = items[pre[k]:pre[k + 1]] if k in (8, 1, 4) else items[:0]
+            assert np.array_equal(mi[mp[k]:mp[k + 1]], want), (ct, k)
+    # malformed lists: two columns; a group name with coordinates
+    bed = tmp_path / "bed.txt"
+    bed.write_text(names[0] + "\t100\n")
+    for g in (a, b):
+        with pytest.raises(ValueError):
+            g.path_order(hl.GROUP_PATHID, None, None, str(bed), None)
+    bed.write_text("s3\t0\t100\n")
+    for g in (a, b):
+        with pytest.raises(ValueError):
+            g.path_order(hl.GROUP_SAMPLE, None, None, str(bed), None)
+    b.path_order(hl.GROUP_SAMPLE)
+    for g, kw in ((a, {"group_mode": hl.GROUP_SAMPLE}), (b, {})):
+        with pytest.raises(ValueError):
+            g.masked_table(hl.NODE, str(bed), None, **kw)
 
 
 def _same_graph(a, b, edges):
