@@ -16,7 +16,9 @@
  *   - docs/chr22.hprc-v1.0-pggb.histgrowth.html:266-276 (hist -> growth, 660 values)
  * Ordered growth (abacus.rs:989-1032) and subset/exclude have no numeric golden in the
  * reference repo; ordered growth is a literal restatement cross-checked by the
- * "mean over all orders == closed-form union" identity.
+ * "mean over all orders == closed-form union" identity; subset/exclude (whole paths and BED
+ * intervals) is a literal restatement checked against hand-derived tables
+ * (tests/test_oracle_bed.py) -- PARITY UNPINNED for those options.
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * reference root).
