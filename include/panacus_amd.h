@@ -148,6 +148,15 @@ int pnx_group_intersections_device(pnx_ctx *ctx, uint64_t **d_inter); /* G*G u64
 uint64_t pnx_presence_row_words(pnx_ctx *ctx);
 int pnx_presence(pnx_ctx *ctx, uint64_t *bits /* n_groups * row_words */);
 
+/* Per-group visit counts of the items item_lo .. item_hi-1 (ids; 0 <= lo <= hi <= n_items + 1):
+ *   out[g * (item_hi - item_lo) + (i - item_lo)] = number of steps the paths of group g take on item i
+ * (0 for excluded items and for paths outside the visiting order) = AbacusByGroup.v
+ * (compute_column_values with report_values, abacus.rs:901-986) without the (r, c) indirection:
+ * v[k] for the slot of (item i, group c[k]).  This is the factor AbacusByGroup::to_tsv multiplies
+ * into its per-group columns (abacus.rs:1093-1112).  The caller walks the item range in slices
+ * that fit its memory. */
+int pnx_group_visit_counts(pnx_ctx *ctx, uint32_t item_lo, uint32_t item_hi, uint32_t *out);
+
 /* ---- closed-form growth, quorum branch (row a7) -------------------------------------------------
  * The O(n^3) inner sums of Hist::calc_growth_quorum (src/graph_broker/hist.rs:138-187):
  *   sum_q[i*(n+1) + m] = sum over the admissible j of exp2(q[i][j] + m_fact[m] - n_fall[m])

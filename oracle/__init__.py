@@ -94,6 +94,12 @@ def lib() -> C.CDLL:
         L.orc_similarity.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, u32p, u64p, u64p,
                                      C.POINTER(C.c_float)]
         L.orc_table_row.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, u64p]
+        u32p_ = C.POINTER(C.c_uint32)
+        L.orc_by_group_values.restype = C.c_int64
+        L.orc_by_group_values.argtypes = [u64p, u64p, u64p, u64p, C.c_uint64, C.c_uint64, u8p, u64p, C.POINTER(u64p),
+                                          C.POINTER(u32p_)]
+        L.orc_table_row_values.restype = C.c_int
+        L.orc_table_row_values.argtypes = [u64p, u64p, u32p_, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, u64p]
         for name in ("orc_growth_union", "orc_growth_core"):
             getattr(L, name).argtypes = [u64p, C.c_uint64, C.c_int, C.c_double, f64p]
         L.orc_growth_quorum.argtypes = [u64p, C.c_uint64, C.c_int, C.c_double, C.c_int, C.c_double, f64p]
@@ -292,6 +298,22 @@ def by_group(items, prefsum, path_idx, group_id, n_items, exclude=None):
     return r, c
 
 
+def by_group_values(items, prefsum, path_idx, group_id, n_items, exclude=None):
+    """AbacusByGroup r, c, v with report_values (abacus.rs:859-986)."""
+    items, prefsum, path_idx, group_id = map(_u64, (items, prefsum, path_idx, group_id))
+    r = np.zeros(n_items + 2, dtype=np.uint64)
+    ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+    ptr, vptr = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+    nnz = lib().orc_by_group_values(_p(items, C.c_uint64), _p(prefsum, C.c_uint64), _p(path_idx, C.c_uint64),
+                                    _p(group_id, C.c_uint64), len(path_idx), n_items, _p(ex, C.c_uint8),
+                                    _p(r, C.c_uint64), C.byref(ptr), C.byref(vptr))
+    c = np.ctypeslib.as_array(ptr, shape=(max(nnz, 1),))[:nnz].copy()
+    v = np.ctypeslib.as_array(vptr, shape=(max(nnz, 1),))[:nnz].copy()
+    lib().orc_free(ptr)
+    lib().orc_free(vptr)
+    return r, c, v
+
+
 def ordered_growth(r, c, n_groups, coverage_thr=(ABSOLUTE, 1), quorum_thr=(RELATIVE, 0.0),
                    weights=None) -> np.ndarray:
     """AbacusByGroup::calc_growth (abacus.rs:989-1032)."""
@@ -344,6 +366,26 @@ def table_rows(r, c, n_groups, node_lens=None) -> np.ndarray:
         bp = 1 if node_lens is None else int(node_lens[i])
         lib().orc_table_row(_p(r, C.c_uint64), _p(c, C.c_uint64), i, int(n_groups), bp,
                             out[i - 1].ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out
+
+
+def table_rows_values(r, c, v, n_groups, bps=None, is_edge=False) -> np.ndarray:
+    """Body of AbacusByGroup::to_tsv without `total` with multiplicities (abacus.rs:1098-1108, 1158-1166):
+    [n_items, G] u64; bps[i] = the bp factor of item i (node_len - uncovered), None = 1.
+    Raises where the reference's edge branch indexes past the end of v."""
+    r, c = _u64(r), _u64(c)
+    v = np.ascontiguousarray(v, dtype=np.uint32)
+    nnz = len(c)
+    if nnz == 0:
+        c, v = np.zeros(1, dtype=np.uint64), np.zeros(1, dtype=np.uint32)
+    n_items = len(r) - 2
+    out = np.zeros((n_items, int(n_groups)), dtype=np.uint64)
+    for i in range(1, n_items + 1):
+        bp = 1 if bps is None else int(bps[i])
+        rc = lib().orc_table_row_values(_p(r, C.c_uint64), _p(c, C.c_uint64), _p(v, C.c_uint32), nnz, i, int(n_groups), bp,
+                                        int(is_edge), out[i - 1].ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc != 0:
+            raise IndexError("v[j] out of range (the reference panics)")
     return out
 
 

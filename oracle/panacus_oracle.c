@@ -1368,9 +1368,9 @@ int64_t orc_growth(const uint64_t *hist, uint64_t hist_len, int cov_kind, double
 /* compute_column_values (901-986, report_values=false) restated with the same           */
 /* "last slot is the write cursor" trick so that any quirk of it is reproduced.           */
 /* ------------------------------------------------------------------------------------ */
-int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
-                     const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
-                     const uint8_t *exclude, uint64_t *r, uint64_t **c_out) {
+static int64_t by_group_impl(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                             const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                             const uint8_t *exclude, uint64_t *r, uint64_t **c_out, uint32_t **v_out) {
     uint64_t *last = xmalloc((n_items + 1) * sizeof *last);
     for (uint64_t i = 0; i <= n_items; i++) last[i] = UINT64_MAX;
     for (uint64_t i = 0; i < n_items + 2; i++) r[i] = 0;
@@ -1394,6 +1394,8 @@ int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint6
     uint64_t nnz = r[n_items + 1];
     uint64_t *c = xmalloc((nnz ? nnz : 1) * sizeof *c);
     for (uint64_t i = 0; i < nnz; i++) c[i] = UINT64_MAX;
+    /* report_values (abacus.rs:907-916): one counter per slot */
+    uint32_t *v = v_out ? xcalloc(nnz ? nnz : 1, sizeof *v) : NULL;
     for (uint64_t k = 0; k < n_ordered; k++) {
         uint64_t start = prefsum[path_idx[k]], end = prefsum[path_idx[k] + 1];
         uint64_t grp = group_id[k];
@@ -1405,18 +1407,36 @@ int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint6
             if (c[cv_end - 1] == UINT64_MAX) {
                 c[cv_start] = grp;
                 if (cv_start < cv_end - 1) c[cv_end - 1] = 0;
+                if (v) v[cv_start] += 1;
             } else if (cv_start + p < cv_end - 1) {
                 if (c[cv_start + p] < grp) {
                     c[cv_end - 1] += 1;
                     p += 1;
                     c[cv_start + p] = grp;
                 }
+                if (v) v[cv_start + p] += 1;
+            } else if (v) {
+                v[cv_end - 1] += 1; /* "make sure it points to the last element and not beyond" */
             }
         }
     }
     *c_out = c;
+    if (v_out) *v_out = v;
     return (int64_t)nnz;
 }
+
+int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                     const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                     const uint8_t *exclude, uint64_t *r, uint64_t **c_out) {
+    return by_group_impl(items, prefsum, path_idx, group_id, n_ordered, n_items, exclude, r, c_out, NULL);
+}
+
+int64_t orc_by_group_values(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                            const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                            const uint8_t *exclude, uint64_t *r, uint64_t **c_out, uint32_t **v_out) {
+    return by_group_impl(items, prefsum, path_idx, group_id, n_ordered, n_items, exclude, r, c_out, v_out);
+}
+
 
 /* AbacusByGroup::calc_growth, abacus.rs:989-1032 */
 void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
@@ -1991,6 +2011,28 @@ void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_
             k++;
         }
     }
+}
+
+/* the same with AbacusByGroup.v (abacus.rs:1098-1108 for node/bp, :1158-1166 for edge).  The edge
+   branch indexes v by the GROUP id j instead of the slot k -- restated as it is; returns -1 where
+   that runs past the end of v (the reference panics). */
+int orc_table_row_values(const uint64_t *r, const uint64_t *c, const uint32_t *v, uint64_t nnz, uint64_t i,
+                         uint64_t n_groups, uint64_t bp, int is_edge, uint64_t *out) {
+    uint64_t k = r[i];
+    const uint64_t end = r[i + 1];
+    for (uint64_t j = 0; j < n_groups; j++) {
+        if (k == end || j < c[k]) out[j] = 0;
+        else if (j == c[k]) {
+            if (is_edge) {
+                if (j >= nnz) return -1;
+                out[j] = v[j];
+            } else {
+                out[j] = (uint64_t)v[k] * bp;
+            }
+            k++;
+        }
+    }
+    return 0;
 }
 
 void orc_exp2(const double *x, double *y, uint64_t n) {

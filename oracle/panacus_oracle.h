@@ -120,6 +120,10 @@ void orc_growth_quorum(const uint64_t *hist, uint64_t n, int cov_kind, double co
 int64_t orc_by_group(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
                      const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
                      const uint8_t *exclude, uint64_t *r, uint64_t **c);
+/* the same with report_values (abacus.rs:901-986): *v has one u32 per slot of c */
+int64_t orc_by_group_values(const uint64_t *items, const uint64_t *prefsum, const uint64_t *path_idx,
+                            const uint64_t *group_id, uint64_t n_ordered, uint64_t n_items,
+                            const uint8_t *exclude, uint64_t *r, uint64_t **c, uint32_t **v);
 /* AbacusByGroup::calc_growth (abacus.rs:989-1032); weights NULL => node/edge; out n_groups */
 void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
                         uint64_t n_groups, int cov_kind, double cov_val, int quo_kind,
@@ -135,6 +139,11 @@ int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint6
    when group j holds item i, else 0 */
 void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,
                    uint64_t bp, uint64_t *out);
+
+/* one row of AbacusByGroup::to_tsv without `total` when v is present (abacus.rs:1098-1108, 1158-1166):
+   node/bp: out[j] = v[k] * bp; edge: out[j] = v[j] (the reference indexes by group id; -1 = its panic) */
+int orc_table_row_values(const uint64_t *r, const uint64_t *c, const uint32_t *v, uint64_t nnz, uint64_t i,
+                         uint64_t n_groups, uint64_t bp, int is_edge, uint64_t *out);
 
 /* y[k] = exp2(x[k]) with the platform libm -- what Rust's f64::exp2 calls (hist.rs:104,131,175,179) */
 void orc_exp2(const double *x, double *y, uint64_t n);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
-    "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact",
+    "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts",
 ]
 
 
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.argtypes = [vp]
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
+    L.pnx_group_visit_counts.argtypes = [vp, C.c_uint32, C.c_uint32, u32p]
     f64p = C.POINTER(C.c_double)
     L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
     L.pnx_exp2_exact.argtypes = [vp, f64p, f64p, C.c_uint64]
@@ -264,6 +265,14 @@ class Context:
         out = np.zeros((G, rw), dtype=np.uint64)
         if G and rw:
             self._ck(self._L.pnx_presence(self._h, _ptr(out, C.c_uint64)))
+        return out
+
+    def group_visit_counts(self, item_lo: int, item_hi: int) -> np.ndarray:
+        """[G, item_hi - item_lo] u32: steps of each group's paths on the items lo..hi-1 (AbacusByGroup.v, dense)."""
+        G = int(self.info().n_groups)
+        out = np.zeros((G, max(item_hi - item_lo, 0)), dtype=np.uint32)
+        buf = out if out.size else np.zeros(1, dtype=np.uint32)
+        self._ck(self._L.pnx_group_visit_counts(self._h, item_lo, item_hi, _ptr(buf, C.c_uint32)))
         return out
 
     def exp2_exact(self, x) -> np.ndarray:

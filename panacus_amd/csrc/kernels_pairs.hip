@@ -261,6 +261,61 @@ int launch_pair_intersections(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// K8: per-group visit counts of an item range -- AbacusByGroup.v (abacus.rs:901-986) laid out
+// densely.  v[k] of the reference is the number of steps that the paths of group c[k] take on the
+// item (the "pointer game" of compute_column_values adds one per step to the slot of the step's
+// group).  One thread per step; the path of a step comes from a search in path_off per workgroup
+// and a short forward walk per thread.  Output-bound command (`table`): plain global atomics.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_visit_counts(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                                      uint32_t n_paths, const uint32_t *__restrict__ path_group,
+                                                      const uint8_t *__restrict__ exclude, uint32_t lo, uint32_t hi,
+                                                      uint32_t *__restrict__ out) {
+    const uint64_t S = path_off[n_paths];
+    const uint64_t base = (uint64_t)blockIdx.x * 1024;
+    __shared__ uint32_t p0;
+    if (threadIdx.x == 0) {  // last path whose first step is <= base
+        uint32_t a = 0, b = n_paths;
+        while (b - a > 1) {
+            const uint32_t m = a + (b - a) / 2;
+            if (path_off[m] <= base) a = m; else b = m;
+        }
+        p0 = a;
+    }
+    __syncthreads();
+    uint32_t p = p0;
+    const uint32_t width = hi - lo;
+    for (int r = 0; r < 4; ++r) {
+        const uint64_t s = base + (uint64_t)r * 256 + threadIdx.x;
+        if (s >= S) return;
+        while (p + 1 < n_paths && path_off[p + 1] <= s) ++p;  // empty paths are stepped over
+        const uint32_t g = path_group[p];
+        if (g == 0xFFFFFFFFu) continue;  // the path is not in the visiting order
+        const uint32_t id = items[s];
+        if (id < lo || id >= hi) continue;
+        if (exclude && exclude[id]) continue;
+        atomicAdd(&out[(uint64_t)g * width + (id - lo)], 1u);
+    }
+}
+
+int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out) {
+    const uint64_t cells = (uint64_t)ctx->n_groups * (hi - lo);
+    int rc;
+    if ((rc = ensure(ctx, out, (cells ? cells : 1) * sizeof(uint32_t)))) return rc;
+    if (!cells) return PNX_OK;
+    PNX_HIP(ctx, hipMemsetAsync(out.p, 0, cells * sizeof(uint32_t), ctx->stream));
+    const uint64_t blocks = (ctx->n_steps + 1023) / 1024;
+    if (blocks > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "visit counts: too many steps for one launch");
+    if (blocks)
+        hipLaunchKernelGGL(k_visit_counts, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_items.p,
+                           (const uint64_t *)ctx->d_path_off.p, ctx->n_paths, (const uint32_t *)d_path_group.p,
+                           ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, lo, hi,
+                           (uint32_t *)out.p);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out) {
     const uint32_t G = ctx->n_groups, NB = ctx->n_blocks;
     const size_t words = (size_t)G * NB * 32;

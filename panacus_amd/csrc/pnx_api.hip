@@ -573,6 +573,33 @@ int pnx_presence(pnx_ctx *ctx, uint64_t *bits) {
     return PNX_OK;
 }
 
+int pnx_group_visit_counts(pnx_ctx *ctx, uint32_t item_lo, uint32_t item_hi, uint32_t *out) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "pnx_group_visit_counts needs pnx_set_csr and pnx_set_order first");
+    if (!out) return ctx->fail(PNX_EINVAL, "pnx_group_visit_counts: out is NULL");
+    if (item_lo > item_hi || (uint64_t)item_hi > (uint64_t)ctx->n_items + 1)
+        return ctx->fail(PNX_EINVAL, "pnx_group_visit_counts: item range [%u, %u) outside 0..%u", item_lo, item_hi, ctx->n_items + 1);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = settle_all(ctx);
+    if (rc) return rc;
+    // group of every path (0xFFFFFFFF: not in the visiting order)
+    std::vector<uint32_t> pg(ctx->n_paths ? ctx->n_paths : 1, 0xFFFFFFFFu);
+    for (uint32_t k = 0; k < ctx->n_ordered; ++k) pg[ctx->h_ord_path[k]] = ctx->h_ord_group[k];
+    DevBuf d_pg, d_out;
+    if ((rc = ensure(ctx, d_pg, pg.size() * sizeof(uint32_t)))) return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(d_pg.p, pg.data(), pg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_visit_counts(ctx, item_lo, item_hi, d_pg, d_out);
+    const size_t cells = (size_t)ctx->n_groups * (item_hi - item_lo);
+    if (!rc && cells) {
+        hipError_t e = hipMemcpyAsync(out, d_out.p, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = ctx->fail(PNX_EHIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    release(d_pg);
+    release(d_out);
+    return rc;
+}
+
 int pnx_profile_enable(pnx_ctx *ctx, int on) {
     if (!ctx) return PNX_EINVAL;
     ctx->prof.on = on != 0;

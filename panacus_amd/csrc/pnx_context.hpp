@@ -198,6 +198,7 @@ int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p i
 // kernels_pairs.hip
 int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
+int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // -> n_groups x (hi - lo) u32
 // pansyn.hip
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                            int with_weights);

@@ -37,7 +37,7 @@ const char *USAGE =
     "  -l, --coverage <LIST>            coverage thresholds, e.g. 1,2 [1]\n"
     "  -q, --quorum <LIST>              quorum thresholds in [0,1], e.g. 0,0.5 [0]\n"
     "  -a, --hist                       also include the histogram (growth, histgrowth)\n"
-    "  -a, --total                      table: one column with the number of groups per item (required)\n"
+    "  -a, --total                      table: one column with the number of groups per item instead of one per group\n"
     "  -g, --groupby <FILE>             path-to-group mapping (2-column TSV)\n"
     "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
     "  -S, --groupby-sample             merge paths of the same sample\n"
@@ -337,27 +337,74 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     return res;
 }
 
-// AbacusByGroup::to_tsv with `total` (abacus.rs:1056-1140): one row per item with the number of
-// groups holding it = the coverage vector of pnx_hist.  Without --total the reference prints
-// per-group multiplicities (AbacusByGroup.v), which the presence matrix does not carry.
+// AbacusByGroup::to_tsv (abacus.rs:1056-1178): one row per item.  With `total` the number of groups
+// holding it = the coverage vector of pnx_hist; otherwise one column per group with the number of
+// steps the group's paths take on the item (AbacusByGroup.v, from pnx_group_visit_counts) times the
+// item's bp (node_len - uncovered for bp counts, else 1).
 std::string cmd_table(const Options &o, const std::string &cmdline) {
-    if (!o.total) throw std::runtime_error("table: only --total is supported (per-group multiplicities are outside the GPU path)");
     CountType ct = count_types(o.count, false)[0];
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint64_t n = g->number_of_items(ct);
+    const size_t G = order.groups.size();
     Device dev(o.device);
-    upload(dev, *g, ct, order, masking(o));
-    std::vector<uint32_t> countable(n + 1, 0);
-    std::vector<uint64_t> hist(order.groups.size() + 1, 0);
-    dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+    const Uncovered uncovered = upload(dev, *g, ct, order, masking(o));
     std::string res = metadata_comments(cmdline);
-    res += ct == COUNT_EDGE ? "edge\ttotal\n" : "node\ttotal\n";
+    res += ct == COUNT_EDGE ? "edge" : "node";
     std::vector<std::string> labels;
     if (ct == COUNT_EDGE) labels = g->edge_labels();
-    for (uint64_t i = 1; i <= n; ++i) {
-        res += ct == COUNT_EDGE ? labels[i] : g->node_name((uint32_t)i);
-        res += "\t" + std::to_string(countable[i]) + "\n";
+    auto label = [&](uint64_t i) { return ct == COUNT_EDGE ? labels[i] : g->node_name((uint32_t)i); };
+    if (o.total) {
+        res += "\ttotal\n";
+        std::vector<uint32_t> countable(n + 1, 0);
+        std::vector<uint64_t> hist(G + 1, 0);
+        dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+        for (uint64_t i = 1; i <= n; ++i) res += label(i) + "\t" + std::to_string(countable[i]) + "\n";
+        return res;
+    }
+    for (const auto &name : order.groups) res += "\t" + name;
+    res += "\n";
+    std::vector<uint64_t> bp;  // per item: the factor of the node/bp branch (abacus.rs:1087-1092)
+    if (ct == COUNT_BP) {
+        bp.assign(g->node_lens().begin(), g->node_lens().end());
+        for (const auto &u : uncovered) bp[u.first] -= u.second;  // usize arithmetic, like the reference
+    }
+    // item slices that keep the G x slice counter block around 1 GiB
+    const uint64_t slice = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / std::max<size_t>(G, 1)));
+    std::vector<uint32_t> counts;
+    // the edge branch prints v[j] -- the j-th slot of the flat value array, j = the GROUP id
+    // (abacus.rs:1162) -- instead of the slot of (edge, group): the first G slots in (item, group) order
+    std::vector<uint32_t> first_slots;
+    if (ct == COUNT_EDGE && G) {
+        for (uint64_t lo = 1; lo <= n && first_slots.size() < G; lo += slice) {
+            const uint64_t hi = std::min(n + 1, lo + slice);
+            counts.assign(G * (hi - lo), 0);
+            dev.check(pnx_group_visit_counts(dev.ctx, (uint32_t)lo, (uint32_t)hi, counts.data()));
+            for (uint64_t i = lo; i < hi && first_slots.size() < G; ++i)
+                for (size_t j = 0; j < G && first_slots.size() < G; ++j)
+                    if (counts[j * (hi - lo) + (i - lo)]) first_slots.push_back(counts[j * (hi - lo) + (i - lo)]);
+        }
+    }
+    for (uint64_t lo = 1; lo <= n; lo += slice) {
+        const uint64_t hi = std::min(n + 1, lo + slice);
+        counts.assign(G * (hi - lo), 0);
+        if (G) dev.check(pnx_group_visit_counts(dev.ctx, (uint32_t)lo, (uint32_t)hi, counts.data()));
+        for (uint64_t i = lo; i < hi; ++i) {
+            res += label(i);
+            for (size_t j = 0; j < G; ++j) {
+                const uint32_t v = counts[j * (hi - lo) + (i - lo)];
+                if (!v) {
+                    res += "\t0";
+                } else if (ct == COUNT_EDGE) {
+                    if (j >= first_slots.size())
+                        throw std::runtime_error("table -c edge: the reference indexes v by group id here and runs past its end (panic)");
+                    res += "\t" + std::to_string(first_slots[j]);
+                } else {
+                    res += "\t" + std::to_string((uint64_t)v * (ct == COUNT_BP ? bp[i] : 1));
+                }
+            }
+            res += "\n";
+        }
     }
     return res;
 }

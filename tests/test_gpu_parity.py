@@ -704,6 +704,43 @@ def test_presence_export_matches_by_group(ctx):
     assert np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, n + 1:].sum() == 0
 
 
+def test_group_visit_counts_match_by_group_values(ctx):
+    """pnx_group_visit_counts == AbacusByGroup.v (the pointer game of abacus.rs:901-986, restated
+    literally in the oracle), in item slices, with excluded items, unordered and empty paths."""
+    n, p = 6000, 13
+    items, pre, _ = orc.pansyn(21, n, p)
+    # make path 3 empty and leave path 5 out of the order
+    keep = np.ones(len(items), dtype=bool)
+    keep[pre[3]:pre[4]] = False
+    lens = np.diff(pre).astype(np.int64)
+    lens[3] = 0
+    items, pre = items[keep], np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    rng = np.random.default_rng(4)
+    excl = (rng.random(n + 1) < 0.1).astype(np.uint8)
+    ctx.set_csr(items.astype(np.uint32), pre, n, exclude=excl)
+    paths = np.array([q for q in range(p) if q != 5], dtype=np.uint64)
+    pg = (np.arange(len(paths)) // 3).astype(np.uint64)
+    G = int(pg.max()) + 1
+    ctx.set_order(paths, pg, G)
+    r, c, v = orc.by_group_values(items, pre, paths, pg, n, excl)
+    dense = np.zeros((G, n + 1), dtype=np.uint32)
+    for i in range(1, n + 1):
+        dense[c[r[i]:r[i + 1]].astype(np.int64), i] = v[r[i]:r[i + 1]]
+    assert int(v.max()) > 1
+    for lo, hi in ((0, n + 1), (1, 2), (17, 4000), (n, n + 1), (5, 5)):
+        got = ctx.group_visit_counts(lo, hi)
+        assert got.shape == (G, hi - lo) and np.array_equal(got, dense[:, lo:hi]), (lo, hi)
+    # brute force: steps per (group, item)
+    brute = np.zeros((G, n + 1), dtype=np.uint32)
+    for q, g_ in zip(paths, pg):
+        np.add.at(brute[int(g_)], items[pre[int(q)]:pre[int(q) + 1]].astype(np.int64), 1)
+    brute[:, excl.astype(bool)] = 0
+    assert np.array_equal(brute, dense)
+    from panacus_amd import capi
+    with pytest.raises(capi.PnxError):
+        ctx.group_visit_counts(3, n + 3)
+
+
 def test_full_size_cfg3_properties():
     """configs[2]: 10M nodes x 256 paths.  Every item lands in exactly one bin; the histogram is
     the bincount of the coverage vector; core nodes reach G; visiting order does not matter."""

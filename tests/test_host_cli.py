@@ -345,8 +345,47 @@ def test_cli_table_total_chrM(golden, golden_dir):
     assert rows[0] == ["edge", "total"]
     assert [int(r[1]) for r in rows[1:]] == golden["chrM_sample_edge"]["countable"][1:]
     assert all(r[0][0] in "<>" for r in rows[1:])
-    rc, out, err = hl.run_cli(["table", "-S", gfa])
-    assert rc == 1 and "--total" in err
+
+
+@pytest.mark.gpu
+def test_cli_table_per_group(golden_dir, tmp_path):
+    """`table` without --total (abacus.rs:1093-1112, 1150-1168): per group the number of steps on the
+    item (AbacusByGroup.v) times its bp; the edge branch prints v[group id] (restated as it is)."""
+    cases = [(os.path.join(golden_dir, "chrM_test.gfa"), ["-S"], orc.GROUP_SAMPLE, None, None),
+             (os.path.join(golden_dir, "t_groups.gfa"), [], orc.GROUP_PATHID, None, None),
+             (os.path.join(golden_dir, "chrM_test.gfa"), ["-s", os.path.join(golden_dir, "bed_chrM", "inclusion.bed3"),
+                                                          "-e", os.path.join(golden_dir, "bed_chrM", "exclusion.bed3")],
+              orc.GROUP_PATHID, os.path.join(golden_dir, "bed_chrM", "inclusion.bed3"),
+              os.path.join(golden_dir, "bed_chrM", "exclusion.bed3"))]
+    syn = str(tmp_path / "syn.gfa")  # duplicated steps inside paths: multiplicities > 1
+    rc, out, err = hl.run_cli(["synth", "--nodes", "5000", "--paths", "9", "--links", "-o", syn])
+    assert rc == 0, err
+    cases.append((syn, ["-S"], orc.GROUP_SAMPLE, None, None))
+    saw_multi = False
+    for gfa, extra, gm, sf, ef in cases:
+        g = orc.Graph(gfa, index_edges=True)
+        for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+            pi, gi, names = g.path_order(gm, None, None, sf, ef)
+            items, pre, fl, ids, ubp = g.masked_table(ct, sf, ef)
+            r, c, v = orc.by_group_values(items, pre, pi, gi, g.n_items(ct), fl if ef else None)
+            saw_multi = saw_multi or (len(v) and int(v.max()) > 1)
+            bps = None
+            if ct == orc.BP:
+                bps = g.node_lens.astype(np.uint64)
+                bps[ids] -= ubp
+            rc, out, err = hl.run_cli(["table", "-c", cname] + extra + [gfa])
+            try:
+                exp = orc.table_rows_values(r, c, v, len(names), bps, ct == orc.EDGE)
+            except IndexError:
+                assert rc == 1 and "panic" in err
+                continue
+            assert rc == 0, err
+            rows = [x.split("\t") for x in _body(out).split("\n") if x]
+            assert rows[0] == ["edge" if ct == orc.EDGE else "node"] + names
+            assert len(rows) - 1 == g.n_items(ct)
+            got = np.array([[int(x) for x in row[1:]] for row in rows[1:]], dtype=np.uint64).reshape(len(rows) - 1, len(names))
+            assert np.array_equal(got, exp), (gfa, cname)
+    assert saw_multi
 
 
 @pytest.mark.gpu
