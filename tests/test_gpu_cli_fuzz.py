@@ -59,3 +59,65 @@ def test_cli_on_random_gfa(tmp_path, seed):
         for k, (c, q) in enumerate(((1, 0.0), (2, 0.3))):
             exp = orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, q), g.node_lens)
             assert [x[1 + k] for x in rows] == [hl.format_f64(float(v)) for v in exp], (flag, c, q)
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_cli_bed_lists_and_table_on_random_gfa(tmp_path, seed):
+    """-s / -e BED lists (paths, groups, intervals) through hist / ordered-histgrowth / table"""
+    from test_host_gfa_fuzz import _random_bed
+    rng = np.random.default_rng(13000 + seed)
+    gfa = str(tmp_path / "r.gfa")
+    _random_gfa(rng, gfa, crlf=False)
+    try:
+        g = orc.Graph(gfa, index_edges=True)
+    except Exception:
+        pytest.skip("generator produced a graph the reference rejects")
+    items0, pre0 = g.item_table(orc.NODE)
+    path_bp = [int(g.node_lens[items0[pre0[k]:pre0[k + 1]]].sum()) for k in range(g.n_paths)]
+    flag, mode = [("", orc.GROUP_PATHID), ("-S", orc.GROUP_SAMPLE), ("-H", orc.GROUP_HAPLOTYPE)][seed % 3]
+    _, _, gnames = g.path_order(mode)
+    sf = ef = None
+    if rng.random() < 0.8:
+        sf = str(tmp_path / "s.bed")
+        _random_bed(rng, sf, g.path_names(), path_bp, gnames if mode != orc.GROUP_PATHID else [])
+    if rng.random() < 0.8 or sf is None:
+        ef = str(tmp_path / "e.bed")
+        _random_bed(rng, ef, g.path_names(), path_bp, gnames if mode != orc.GROUP_PATHID else [])
+    extra = ([flag] if flag else []) + (["-s", sf] if sf else []) + (["-e", ef] if ef else [])
+    pi, gi, names = g.path_order(mode, None, None, sf, ef)
+    G = len(names)
+    rc, out, err = hl.run_cli(["hist", "-c", "all"] + extra + [gfa])
+    assert rc == 0, err
+    rows = _body(out)
+    colmap = {rows[1][j]: j for j in range(1, len(rows[0]))}
+    for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+        items, pre, fl, ids, ubp = g.masked_table(ct, sf, ef)
+        excl = fl if ef else None
+        cov = orc.coverage(items, pre, pi, gi, g.n_items(ct), excl)
+        h = orc.hist_apply_uncovered(cov, ids, ubp, orc.hist(cov, G, g.node_lens if ct == orc.BP else None))
+        assert [int(r[colmap[cname]]) for r in rows[4:]] == h.tolist(), (extra, cname)
+        r_, c_, v_ = orc.by_group_values(items, pre, pi, gi, g.n_items(ct), excl)
+        bps = None
+        if ct == orc.BP:
+            bps = g.node_lens.astype(np.uint64)
+            bps[ids] -= ubp
+        if G:
+            w = None if bps is None else bps.astype(np.uint32)
+            rc, out2, err = hl.run_cli(["ordered-histgrowth", "-c", cname, "-l", "1,2", "-q", "0,0.4"] + extra + [gfa])
+            assert rc == 0, err
+            orows = _body(out2)[4:]
+            assert [r[0] for r in orows] == names
+            for k, (c, q) in enumerate(((1, 0.0), (2, 0.4))):
+                exp = orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, q), w)
+                assert [x[1 + k] for x in orows] == [hl.format_f64(float(x)) for x in exp], (extra, cname, k)
+        rc, out3, err = hl.run_cli(["table", "-c", cname] + extra + [gfa])
+        try:
+            exp = orc.table_rows_values(r_, c_, v_, G, bps, ct == orc.EDGE)
+        except IndexError:
+            assert rc == 1 and "panic" in err
+            continue
+        assert rc == 0, err
+        trows = _body(out3)
+        assert trows[0][1:] == names and len(trows) - 1 == g.n_items(ct)
+        got = np.array([[int(x) for x in row[1:]] for row in trows[1:]], dtype=np.uint64).reshape(len(trows) - 1, G)
+        assert np.array_equal(got, exp), (extra, cname)
