@@ -10,6 +10,8 @@
 #include <math.h>
 #include <stdarg.h>
 #include <ctype.h>
+#include <regex.h>
+#include <sys/stat.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -727,6 +729,32 @@ static int parse_bed(const char *file, segvec *out) {
     return rc;
 }
 
+/* GraphMask::load_coord_list (abacus.rs:212-240): the text is a BED file if such a file exists,
+ * otherwise a regular expression over the displayed path names (`re.is_match(&path.to_string())`,
+ * an unanchored search); the matching graph paths, with their own coordinates, are the list.
+ * The reference uses the Rust `regex` crate; POSIX extended syntax is used here, which agrees with
+ * it on literals, anchors, classes, alternation and greedy repetition. */
+static int load_coord_list(const orc_graph *g, const char *text, segvec *out) {
+    struct stat st;
+    if (stat(text, &st) == 0 && S_ISREG(st.st_mode)) return parse_bed(text, out);
+    regex_t re;
+    if (regcomp(&re, text, REG_EXTENDED | REG_NOSUB) != 0) {
+        set_err("string %s is not valid! Neither as a file name nor as a regex", text);
+        return -1;
+    }
+    for (uint64_t i = 0; i < g->n_paths; i++)
+        if (regexec(&re, g->path_disp[i], 0, NULL, 0) == 0) {
+            const pathseg *q = &g->paths[i]; /* .cloned() */
+            pathseg c = *q;
+            c.sample = xstrndup(q->sample, strlen(q->sample));
+            c.haplotype = q->haplotype ? xstrndup(q->haplotype, strlen(q->haplotype)) : NULL;
+            c.seqid = q->seqid ? xstrndup(q->seqid, strlen(q->seqid)) : NULL;
+            segvec_push(out, c);
+        }
+    regfree(&re);
+    return 0;
+}
+
 /* reads a path/group list (BED, see parse_bed) and marks the paths it names:
  * complement_with_group_assignments (abacus.rs:152-206) -- a name that is a path selects that
  * path, a name that is a group selects all paths of the group (and must not carry coordinates).
@@ -736,7 +764,7 @@ static int parse_bed(const char *file, segvec *out) {
 static int read_path_list(const orc_graph *g, const char *file, const smap *key2path, char **keys,
                           int exact_coords, uint8_t *mark, uint64_t **visit, uint64_t *nvisit) {
     segvec segs = {0};
-    if (parse_bed(file, &segs) != 0) {
+    if (load_coord_list(g, file, &segs) != 0) {
         segvec_free(&segs);
         return -1;
     }
@@ -1663,7 +1691,7 @@ static int load_subpath_map(const orc_graph *g, const char *file, subpath_map *o
     smap_init(&out->idx, 64);
     out->lists = NULL;
     out->n = out->cap = 0;
-    if (parse_bed(file, &segs) != 0) {
+    if (load_coord_list(g, file, &segs) != 0) {
         segvec_free(&segs);
         return -1;
     }

@@ -42,8 +42,9 @@ const char *USAGE =
     "  -H, --groupby-haplotype          merge paths of the same haplotype\n"
     "  -S, --groupby-sample             merge paths of the same sample\n"
     "  -O, --order <FILE>               order of paths/groups (ordered-histgrowth)\n"
-    "  -s, --subset <FILE>              count only the listed paths/groups or path intervals (BED: 1, 3 or 12 columns)\n"
-    "  -e, --exclude <FILE>             drop the listed paths/groups/intervals and every node/edge/bp they touch\n"
+    "  -s, --subset <FILE|REGEX>        count only the listed paths/groups or path intervals (BED: 1, 3 or 12 columns;\n"
+    "                                   a value that is not a file is a regular expression over the path names)\n"
+    "  -e, --exclude <FILE|REGEX>       drop the listed paths/groups/intervals and every node/edge/bp they touch\n"
     "      --cache                      keep / reuse the parsed graph in <GFA_FILE>.pcsr (checked against the\n"
     "                                   GFA's size, mtime and a content hash)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"

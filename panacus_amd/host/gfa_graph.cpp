@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <regex>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -888,6 +889,25 @@ std::vector<PathSegment> parse_bed(const std::string &file) {
     return out;
 }
 
+// GraphMask::load_coord_list (abacus.rs:212-240): a BED file if `text` names one, otherwise a regular
+// expression searched in the displayed path names; the matching paths themselves are the list.
+// (Rust `regex` syntax in the reference, ECMAScript here: the same for literals, anchors, classes,
+// alternation and repetition.)
+std::vector<PathSegment> load_coord_list(const std::string &text, const std::vector<PathSegment> &paths) {
+    struct stat st;
+    if (::stat(text.c_str(), &st) == 0 && S_ISREG(st.st_mode)) return parse_bed(text);
+    std::regex re;
+    try {
+        re = std::regex(text, std::regex::ECMAScript);
+    } catch (const std::regex_error &) {
+        throw std::runtime_error("string " + text + " is not valid! Neither as a file name nor as a regex");
+    }
+    std::vector<PathSegment> out;
+    for (const PathSegment &p : paths)
+        if (std::regex_search(p.display(), re)) out.push_back(p);
+    return out;
+}
+
 // a BED list of paths / groups resolved like complement_with_group_assignments (abacus.rs:152-206).
 // mark[i] = path i is named; visit = entries in file order as path indices (first path of a group).
 // exact_coords: a path entry only matches graph paths with equal coordinates, and group members
@@ -902,7 +922,7 @@ void read_path_list(const std::string &file, const std::vector<PathSegment> &pat
         by_key[key[i]].push_back((uint32_t)i);
         by_group[group[i]].push_back((uint32_t)i);
     }
-    for (const PathSegment &ps : parse_bed(file)) {
+    for (const PathSegment &ps : load_coord_list(file, paths)) {
         auto pk = by_key.find(ps.clear_key());
         if (pk != by_key.end()) {
             for (uint32_t i : pk->second) {
@@ -1237,7 +1257,7 @@ IvMap load_subpath_map(const std::string &file, const std::vector<PathSegment> &
         by_group[group[i]].push_back((uint32_t)i);
     }
     IvMap m;
-    for (const PathSegment &ps : parse_bed(file)) {
+    for (const PathSegment &ps : load_coord_list(file, paths)) {
         if (known_key.count(ps.clear_key())) {
             m[ps.id()].push_back(ps.has_start && ps.has_end ? Iv{ps.start, ps.end} : Iv{0, USIZE_MAX});
             continue;

@@ -203,6 +203,19 @@ def test_subset_and_exclude_lists_match_oracle(golden_dir, tmp_path):
         for k in range(a.n_paths):
             want = items[pre[k]:pre[k + 1]] if k in (8, 1, 4) else items[:0]
             assert np.array_equal(mi[mp[k]:mp[k + 1]], want), (ct, k)
+    # a -s / -e value that is not a file is a regular expression over the path names (abacus.rs:212-240)
+    for pat in ("^s1#", "#1#", "s[02]#0", "s3#|s4#1", "nothing_matches_this"):
+        for sf, ef in ((pat, None), (None, pat), (pat, str(exc))):
+            pa, ga, na = a.path_order(hl.GROUP_SAMPLE, None, None, sf, ef)
+            pb, gb, nb = b.path_order(hl.GROUP_SAMPLE, None, None, sf, ef)
+            assert na == nb and np.array_equal(pa, pb) and np.array_equal(ga, gb), (sf, ef)
+            x = b.masked_table(hl.NODE, sf, ef)
+            y = a.masked_table(hl.NODE, sf, ef, hl.GROUP_SAMPLE)
+            for u, v in zip(x, y):
+                assert np.array_equal(np.asarray(u, dtype=np.uint64), np.asarray(v, dtype=np.uint64)), (sf, ef)
+    import re
+    pa, _, _ = a.path_order(hl.GROUP_PATHID, None, None, "^s1#", None)
+    assert sorted(pa.tolist()) == [k for k, nm in enumerate(names) if re.search("^s1#", nm)] and len(pa) > 0
     # malformed lists: two columns; a group name with coordinates
     bed = tmp_path / "bed.txt"
     bed.write_text(names[0] + "\t100\n")
