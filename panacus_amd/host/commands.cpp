@@ -107,10 +107,27 @@ using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncov
 // growth_weights: upload node_len - uncovered as the bp weight of such nodes, which is what
 // AbacusByGroup::calc_growth adds (abacus.rs:1013-1023); the histogram instead takes plain node
 // lengths and is corrected afterwards (construct_hist_bps, abacus.rs:779-785).
+// renumber the steps (and the per-item flags) of an edge table by GraphStorage::edge_relabel
+void renumber_edges(const std::vector<uint32_t> &new_id, std::vector<uint32_t> &items, std::vector<uint8_t> &exclude) {
+    if (new_id.empty()) return;  // already ranked
+    const size_t n = items.size(), CH = 1 << 20;
+    ThreadPool::instance().parallel_for((n + CH - 1) / CH, [&](size_t c) {
+        const size_t e = std::min(n, (c + 1) * CH);
+        for (size_t k = c * CH; k < e; ++k) items[k] = new_id[items[k]];
+    });
+    if (exclude.empty()) return;
+    std::vector<uint8_t> moved(exclude.size(), 0);
+    for (size_t id = 1; id < exclude.size(); ++id) moved[new_id[id]] = exclude[id];
+    exclude.swap(moved);
+}
+
+// per_item_output: the caller prints rows per item id (`table`), so the ids of the reference are kept;
+// otherwise edge ids are renumbered for the device (see GraphStorage::edge_relabel)
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
-                 bool growth_weights = false) {
+                 bool growth_weights = false, bool per_item_output = false) {
     const uint64_t n_items = g.number_of_items(ct);
     const uint32_t n_paths = (uint32_t)g.path_segments().size();
+    const bool renumber = ct == COUNT_EDGE && !per_item_output && n_items > 0;
     Uncovered uncovered;
     if (mk.any()) {
         MaskedTable m = g.masked_table(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
@@ -119,11 +136,19 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
             w = g.node_lens();
             for (const auto &u : m.uncovered) w[u.first] = u.second > w[u.first] ? 0 : (uint32_t)(w[u.first] - u.second);
         }
+        if (renumber) renumber_edges(g.edge_relabel(), m.table.items, m.exclude);
         const uint32_t none = 0;  // a valid pointer for an empty table
         dev.check(pnx_set_csr(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
                               (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
                               m.exclude.empty() ? nullptr : m.exclude.data()));
         uncovered = std::move(m.uncovered);
+    } else if (renumber) {
+        ItemTable tab = g.item_table(ct);
+        std::vector<uint8_t> no_flags;
+        renumber_edges(g.edge_relabel(), tab.items, no_flags);
+        const uint32_t none = 0;
+        dev.check(pnx_set_csr(dev.ctx, tab.items.empty() ? &none : tab.items.data(), tab.id_prefsum.data(), n_paths,
+                              (uint32_t)n_items, nullptr, nullptr));
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
@@ -349,7 +374,7 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
     const uint64_t n = g->number_of_items(ct);
     const size_t G = order.groups.size();
     Device dev(o.device);
-    const Uncovered uncovered = upload(dev, *g, ct, order, masking(o));
+    const Uncovered uncovered = upload(dev, *g, ct, order, masking(o), false, true);
     std::string res = metadata_comments(cmdline);
     res += ct == COUNT_EDGE ? "edge" : "node";
     std::vector<std::string> labels;

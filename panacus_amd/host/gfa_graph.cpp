@@ -1217,6 +1217,45 @@ std::vector<std::string> GraphStorage::edge_labels() const {
     return out;
 }
 
+std::vector<uint32_t> GraphStorage::edge_relabel() const {
+    const Impl &im = *impl_;
+    if (!im.has_edges) throw std::runtime_error("edge renumbering needs the edge index");
+    struct Key {
+        uint64_t uv;
+        uint32_t id;
+        uint8_t oo;
+    };
+    std::vector<Key> keys(edge_count_);
+    if (im.cached) {
+        for (uint64_t id = 1; id <= edge_count_; ++id) keys[id - 1] = Key{im.c_edge_uv[id], (uint32_t)id, im.c_edge_oo[id]};
+    } else {
+        for (const auto &sl : im.edges.tab)
+            if (sl.id) keys[sl.id - 1] = Key{sl.uv, sl.id, sl.oo};
+    }
+    auto less = [](const Key &a, const Key &b) { return a.uv != b.uv ? a.uv < b.uv : a.oo < b.oo; };
+    if (std::is_sorted(keys.begin(), keys.end(), less)) return {};  // the file's link order already is the rank
+    // sorted pieces in parallel, then pairwise merges
+    ThreadPool &pool = ThreadPool::instance();
+    const size_t n = keys.size();
+    size_t pieces = 1;
+    while (pieces < pool.size() && n / (pieces * 2) >= (1u << 16)) pieces *= 2;
+    auto bound = [&](size_t k) { return n / pieces * k + std::min(k, n % pieces); };
+    pool.parallel_for(pieces, [&](size_t k) { std::sort(keys.begin() + (ptrdiff_t)bound(k), keys.begin() + (ptrdiff_t)bound(k + 1), less); });
+    for (size_t width = 1; width < pieces; width *= 2) {
+        const size_t n_merges = pieces / (2 * width);
+        pool.parallel_for(n_merges, [&](size_t m) {
+            const size_t a = bound(2 * width * m), mid = bound(2 * width * m + width), b = bound(2 * width * (m + 1));
+            std::inplace_merge(keys.begin() + (ptrdiff_t)a, keys.begin() + (ptrdiff_t)mid, keys.begin() + (ptrdiff_t)b, less);
+        });
+    }
+    std::vector<uint32_t> new_id(edge_count_ + 1, 0);
+    pool.parallel_for((n + 65535) / 65536, [&](size_t c) {
+        const size_t e = std::min(n, (c + 1) * 65536);
+        for (size_t r = c * 65536; r < e; ++r) new_id[keys[r].id] = (uint32_t)r + 1;
+    });
+    return new_id;
+}
+
 std::vector<uint8_t> GraphStorage::exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
                                                  const std::string &group_file, const std::string &exclude_file) const {
     const size_t P = paths_.size();

@@ -99,6 +99,15 @@ public:
     std::vector<uint8_t> exclude_flags(CountType count, const ItemTable &table, GroupMode mode,
                                        const std::string &group_file, const std::string &exclude_file) const;
 
+    // A renumbering of the edges for the device: new_id[old id] ([0] = 0) = rank of the edge by its
+    // canonical (smaller node, larger node, orientations).  The reference numbers edges in the order
+    // of the L lines (graph.rs:282-295), so the edge steps of a path are only as ordered as the link
+    // section of the file; ranked like this they rise and fall with the node ids of the path, and
+    // the coverage kernel can take them tile by tile.  Histograms and growth curves do not depend
+    // on item numbering (items only meet in counters); per-item output (`table`) keeps the ids.
+    // Empty when the ids already are that rank (L lines sorted by their canonical ends).
+    std::vector<uint32_t> edge_relabel() const;
+
     // labels of AbacusByGroup::to_tsv (abacus.rs:1072-1140): the segment name of a node id, and
     // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id
     std::string node_name(uint32_t id) const;

@@ -137,6 +137,21 @@ int pnh_graph_masked_table(const void *g, int count_type, int group_mode, const 
     }
 }
 
+// GraphStorage::edge_relabel: new_id has n_edges + 1 entries
+int pnh_graph_edge_relabel(const void *g, uint32_t *new_id) {
+    try {
+        const pnh::GraphStorage *gs = static_cast<const pnh::GraphStorage *>(g);
+        std::vector<uint32_t> r = gs->edge_relabel();
+        if (r.empty())  // already ranked: the identity
+            for (uint64_t id = 0; id <= gs->edge_count(); ++id) new_id[id] = (uint32_t)id;
+        std::copy(r.begin(), r.end(), new_id);
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
 // visiting order; group names are returned '\n'-joined in names_buf. Returns #groups or -1.
 int64_t pnh_graph_path_order(const void *g, int group_mode, const char *group_file, const char *order_file,
                              const char *subset_file, const char *exclude_file, uint32_t *path_idx,

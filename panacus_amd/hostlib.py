@@ -141,6 +141,8 @@ def _bind_graph(L):
     L.pnh_graph_masked_table.restype = C.c_int
     L.pnh_graph_masked_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, u64p, u64p, u32p,
                                          u64p, C.POINTER(C.c_uint8), u32p, u64p]
+    L.pnh_graph_edge_relabel.restype = C.c_int
+    L.pnh_graph_edge_relabel.argtypes = [C.c_void_p, u32p]
     L._graph_bound = True
 
 
@@ -252,6 +254,14 @@ class GfaGraph:
         if rc != 0:
             raise ValueError(self._L.pnh_last_error().decode())
         return items[: n_steps.value], pre, flags, ids[: n_unc.value], bps[: n_unc.value]
+
+    def edge_relabel(self) -> np.ndarray:
+        """new_id[old edge id] = rank by canonical (smaller node, larger node, orientations); [0] = 0.
+        What the CLI renumbers edge steps by before the upload (hist / growth do not depend on ids)."""
+        out = np.zeros(self.n_edges + 1, dtype=np.uint32)
+        if self._L.pnh_graph_edge_relabel(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))) != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        return out
 
     def path_order(self, group_mode=GROUP_PATHID, group_file=None, order_file=None, subset_file=None,
                    exclude_file=None):

@@ -41,4 +41,5 @@ timeout 600 python $REPO/benchmarks/bench_similarity.py --bp >> $OUT/${R}_simila
 rm -rf /tmp/p_s; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_s -o sim -- \
     python $REPO/benchmarks/bench_similarity.py --check-nodes 0 > /dev/null 2>&1
 python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_s)" $OUT/${R}_similarity_cfg4_kernel_stats.csv > /dev/null
+timeout 600 python $REPO/benchmarks/bench_edge_counts.py > $OUT/${R}_edge_counts_bench.jsonl 2>/dev/null
 ls -la $OUT

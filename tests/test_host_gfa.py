@@ -288,3 +288,35 @@ def test_pcsr_cache_cli_growth_from_cache(golden_dir, tmp_path):
     pi, gi, names = c.path_order(hl.GROUP_PATHID)
     cov = orc.coverage(items.astype(np.uint64), pre, pi.astype(np.uint64), gi.astype(np.uint64), c.n_nodes)
     assert orc.hist(cov, len(names)).tolist() == [5, 0, 10, 0, 0, 0, 0]
+
+
+def test_edge_relabel_is_a_rank_by_canonical_ends(golden_dir, tmp_path):
+    """GraphStorage::edge_relabel: a permutation of 1..E under which the edge steps of a path whose
+    node ids rise (fall) rise (fall) too, whatever the order of the L lines."""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "3000", "--paths", "6", "--links", "-o", path])
+    assert rc == 0, err
+    lines = open(path).read().split("\n")
+    links = [l for l in lines if l.startswith("L\t")]
+    rng = np.random.default_rng(2)
+    shuf = str(tmp_path / "shuf.gfa")
+    with open(shuf, "w") as f:
+        f.write("\n".join([l for l in lines if l and not l.startswith("L\t")] + [links[i] for i in rng.permutation(len(links))]) + "\n")
+    for gfa in (path, shuf, os.path.join(golden_dir, "chrM_test.gfa")):
+        g = hl.GfaGraph(gfa, index_edges=True)
+        new_id = g.edge_relabel()
+        assert new_id[0] == 0 and sorted(new_id[1:].tolist()) == list(range(1, g.n_edges + 1))
+        nodes, npre = g.item_table(hl.NODE)
+        edges, epre = g.item_table(hl.EDGE)
+        for k in range(g.n_paths):
+            nd = nodes[npre[k]:npre[k + 1]].astype(np.int64)
+            ed = new_id[edges[epre[k]:epre[k + 1]]].astype(np.int64)
+            if len(nd) > 2 and (np.diff(nd) > 0).all():
+                assert (np.diff(ed) > 0).all()
+            if len(nd) > 2 and (np.diff(nd) < 0).all():
+                assert (np.diff(ed) < 0).all()
+    # the two files hold the same graph: identical histograms need identical multisets of renumbered steps
+    a, b = hl.GfaGraph(path, index_edges=True), hl.GfaGraph(shuf, index_edges=True)
+    ea, pa = a.item_table(hl.EDGE)
+    eb, pb = b.item_table(hl.EDGE)
+    assert np.array_equal(pa, pb) and np.array_equal(a.edge_relabel()[ea], b.edge_relabel()[eb])
