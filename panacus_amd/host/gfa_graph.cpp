@@ -1457,17 +1457,25 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
             how[k] = WALK;
     }
 
-    std::vector<uint32_t> &items = out.table.items;
-    for (size_t k = 0; k < P; ++k) {
+    // Paths that are walked node by node go first, one after the other in file order (their
+    // bookkeeping of partly covered nodes depends on it); whole paths are plain copies.
+    std::vector<std::vector<uint32_t>> walked(P);
+    std::atomic<int64_t> bad_edge_path{-1};
+    auto flag = [&](uint32_t id) { __atomic_store_n(&out.exclude[id], (uint8_t)1, __ATOMIC_RELAXED); };
+    auto walk_path = [&](size_t k) {
         const uint64_t b = steps.pref[k], e = steps.pref[k + 1];
         const uint32_t *ids = steps.ids.data() + b;
         const uint8_t *ori = steps.ori.data() + b;
         const uint64_t len = e - b;
+        std::vector<uint32_t> &items = walked[k];
         if (how[k] == WHOLE) {
-            items.insert(items.end(), ids, ids + len);
             if (!ec[k]->empty())  // every node of an excluded path is excluded as a whole (util.rs:1171-1181)
-                for (uint64_t j = 0; j < len; ++j) out.exclude[ids[j]] = 1;
+                for (uint64_t j = 0; j < len; ++j) flag(ids[j]);
         } else if (how[k] == WALK && count != COUNT_EDGE) {
+            if (ic[k] == &complete && ec[k]->empty()) {  // nothing to cut and nothing to flag: a whole path after all
+                how[k] = WHOLE;
+                return;
+            }
             size_t ci = 0, cj = 0;
             uint64_t p = paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0;
             for (uint64_t j = 0; j < len; ++j) {
@@ -1483,12 +1491,12 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
                 });
                 node_pieces(*ec[k], cj, p, l, ori[j] != 0, [&](uint64_t a, uint64_t bb) {
                     if (!annotate) {
-                        out.exclude[sid] = 1;
+                        flag(sid);
                         return;
                     }
                     // ActiveTable::activate_n_annotate (src/util.rs:147-181)
                     if (bb - a == l) {
-                        out.exclude[sid] = 1;
+                        flag(sid);
                         partly_excluded.erase(sid);
                         return;
                     }
@@ -1496,7 +1504,7 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
                     pc.add(a, bb);
                     if (pc.v[0] == Iv{0, l}) {
                         partly_excluded.erase(sid);
-                        out.exclude[sid] = 1;
+                        flag(sid);
                     }
                 });
                 if (ci >= ic[k]->size() && cj >= ec[k]->size()) break;  // nothing left to meet
@@ -1514,17 +1522,37 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
                 uint8_t oo;
                 canonical(ids[j], ori[j], ids[j + 1], ori[j + 1], uv, oo);
                 const uint32_t eid = im.edges.find(uv, oo);
-                if (!eid) throw std::runtime_error("unknown edge in path " + paths_[k].display());
+                if (!eid) {
+                    bad_edge_path.store((int64_t)k);
+                    return;
+                }
                 if (ci < ic[k]->size() && (*ic[k])[ci].s < p + l) items.push_back(eid);
                 if (have_exc && cj < ec[k]->size() && (*ec[k])[cj].s < p + l)
-                    out.exclude[eid] = 1;
+                    flag(eid);
                 else if (ci >= ic[k]->size() && cj >= ec[k]->size())
                     break;
                 p += l;
             }
         }
-        out.table.id_prefsum[k + 1] = items.size();
+    };
+    // bp counts keep per-node interval state across paths (file order matters); node and edge
+    // counts only set flags, so their paths are independent
+    if (count == COUNT_BP) {
+        for (size_t k = 0; k < P; ++k) walk_path(k);
+    } else {
+        ThreadPool::instance().parallel_for(P, walk_path);
     }
+    if (bad_edge_path.load() >= 0) throw std::runtime_error("unknown edge in path " + paths_[(size_t)bad_edge_path.load()].display());
+    for (size_t k = 0; k < P; ++k)
+        out.table.id_prefsum[k + 1] = out.table.id_prefsum[k] + (how[k] == WHOLE ? steps.pref[k + 1] - steps.pref[k] : walked[k].size());
+    out.table.items.resize(out.table.id_prefsum[P]);
+    ThreadPool::instance().parallel_for(P, [&](size_t k) {
+        uint32_t *dst = out.table.items.data() + out.table.id_prefsum[k];
+        if (how[k] == WHOLE)
+            std::copy(steps.ids.begin() + (ptrdiff_t)steps.pref[k], steps.ids.begin() + (ptrdiff_t)steps.pref[k + 1], dst);
+        else
+            std::copy(walked[k].begin(), walked[k].end(), dst);
+    });
 
     // quantify_uncovered_bps (abacus.rs:1187-1229)
     if (track_cov) {
