@@ -235,6 +235,7 @@ void pnx_free(pnx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_cf) (void)hipStreamSynchronize(ctx->stream_cf);
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
@@ -252,6 +253,7 @@ void pnx_free(pnx_ctx *ctx) {
         if (t.done) (void)hipEventDestroy(t.done);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream_cf) (void)hipStreamDestroy(ctx->stream_cf);
     delete ctx;
 }
 

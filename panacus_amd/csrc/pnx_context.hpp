@@ -71,6 +71,7 @@ struct Profile {
 struct pnx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream_cf = nullptr;  // closed-form kernels (K7): independent of the coverage passes
     std::string err;
     hipDeviceProp_t prop;
 
