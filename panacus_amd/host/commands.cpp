@@ -396,7 +396,9 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
         for (const auto &u : uncovered) bp[u.first] -= u.second;  // usize arithmetic, like the reference
     }
     // item slices that keep the G x slice counter block around 1 GiB
-    const uint64_t slice = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / std::max<size_t>(G, 1)));
+    uint64_t slice = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / std::max<size_t>(G, 1)));
+    if (const char *e = std::getenv("PANACUS_AMD_TABLE_SLICE"))  // test hook: items per slice
+        if (std::atoll(e) > 0) slice = (uint64_t)std::atoll(e);
     std::vector<uint32_t> counts;
     // the edge branch prints v[j] -- the j-th slot of the flat value array, j = the GROUP id
     // (abacus.rs:1162) -- instead of the slot of (edge, group): the first G slots in (item, group) order

@@ -386,6 +386,34 @@ def test_cli_table_per_group(golden_dir, tmp_path):
             got = np.array([[int(x) for x in row[1:]] for row in rows[1:]], dtype=np.uint64).reshape(len(rows) - 1, len(names))
             assert np.array_equal(got, exp), (gfa, cname)
     assert saw_multi
+    # the item range is walked in slices: a tiny slice gives the same table
+    full = hl.run_cli(["table", "-c", "bp", "-S", syn])
+    os.environ["PANACUS_AMD_TABLE_SLICE"] = "37"
+    try:
+        sliced = hl.run_cli(["table", "-c", "bp", "-S", syn])
+        sliced_e = hl.run_cli(["table", "-c", "edge", "-S", syn])
+    finally:
+        del os.environ["PANACUS_AMD_TABLE_SLICE"]
+    assert full[0] == 0 and _body(full[1]) == _body(sliced[1])
+    assert _body(sliced_e[1]) == _body(hl.run_cli(["table", "-c", "edge", "-S", syn])[1])
+
+
+@pytest.mark.gpu
+def test_cli_empty_selection(golden_dir):
+    """a subset that names nothing: no groups, every item uncovered (one histogram row), and the
+    growth commands print just their headers"""
+    gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    rc, out, err = hl.run_cli(["hist", "-c", "all", "-s", "matches_no_path_at_all", gfa])
+    assert rc == 0, err
+    rows = [r.split("\t") for r in _body(out).split("\n") if r]
+    assert len(rows) == 5 and rows[4][0] == "0"
+    g = orc.Graph(gfa, index_edges=True)
+    col = {name: j for j, name in enumerate(rows[1])}
+    assert int(rows[4][col["node"]]) == g.n_nodes and int(rows[4][col["edge"]]) == g.n_edges
+    assert int(rows[4][col["bp"]]) == int(g.node_lens.sum())
+    rc, out, err = hl.run_cli(["ordered-histgrowth", "-s", "matches_no_path_at_all", gfa])
+    assert rc == 0, err
+    assert len([r for r in _body(out).split("\n") if r]) == 4
 
 
 @pytest.mark.gpu
