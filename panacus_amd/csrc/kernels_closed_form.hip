@@ -39,9 +39,9 @@ __host__ __device__ static inline void j_range(uint32_t n, uint32_t c, uint32_t 
 }
 
 // terms[(i_local * (n + 1) + m) * ld + j], ld = term_ld(n).  One workgroup = one i and 256 consecutive j; the
-// four small tables every step of the m loop reads (log2, m_fact, n_fall, m_quorum) are staged in
-// LDS first when they fit (LDS_TABLES): the loop is a chain of dependent table reads, and from
-// global memory it ran at their latency (1.26 ms for n = 1024).
+// log2 table, which every step of the m loop reads at two lane-dependent indices, is staged in LDS
+// first when it fits (LDS_TABLES): from global memory the loop ran at the latency of those reads
+// (1.26 ms for n = 1024).
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(256) void k_quorum_terms(uint32_t n, uint32_t c, uint32_t i0, uint32_t i1,
                                                        const uint32_t *__restrict__ g_mq,
@@ -56,43 +56,49 @@ __global__ __launch_bounds__(256) void k_quorum_terms(uint32_t n, uint32_t c, ui
     const double *L = g_L, *m_fact = g_mf, *n_fall = g_nf;
     const uint32_t *m_quorum = g_mq;
     if (LDS_TABLES) {
-        double *sL = sh_tab, *smf = sL + 2 * (n + 1), *snf = smf + (n + 1);
-        uint32_t *smq = reinterpret_cast<uint32_t *>(snf + (n + 1));
+        // only the log2 table is read at lane-dependent indices; m_fact[m], n_fall[m] and m_quorum[m]
+        // are wave-uniform reads (see the loop) and come through the scalar cache
+        double *sL = sh_tab;
         for (uint32_t k = threadIdx.x; k < 2 * (n + 1); k += 256) sL[k] = g_L[k];
-        for (uint32_t k = threadIdx.x; k <= n; k += 256) {
-            smf[k] = g_mf[k];
-            snf[k] = g_nf[k];
-            smq[k] = g_mq[k];
-        }
         __syncthreads();
         L = sL;
-        m_fact = smf;
-        n_fall = snf;
-        m_quorum = smq;
     }
-    if (i >= i1 || j > i || j >= n) return;
+    // The m loop is wave-uniform (it starts at the first j of the wave + 1 and a lane joins at its
+    // own j + 1): i and m then live in scalar registers, and the admissible range, m_quorum[m],
+    // m_fact[m] and n_fall[m] are computed / read once per wave and step instead of once per lane.
+    const uint32_t wave_j0 = blockIdx.y * 256 + ((uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) & ~63u);
+    bool alive = i < i1 && j <= i && j < n;
     double q = 0.0;
     const size_t ld = term_ld(n);
-    double *row = terms + (size_t)(i - i0) * (n + 1) * ld;
-    for (uint32_t m = j + 1; m <= n; ++m) {
+    double *row = terms + (size_t)(i < i1 ? i - i0 : 0) * (n + 1) * ld;
+    // choose(i, j), hist.rs:21-36 (res += log2(i - a); res -= log2(a + 1)): what q is seeded with
+    // whenever it is 0.0 (hist.rs:167-169).  All lanes compute theirs together, before the walk.
+    double seed = 0.0;
+    if (alive) {
+        const uint32_t k = j > i - j ? i - j : j;
+        for (uint32_t a = 0; a < k; ++a) {
+            seed = pnx_exp2::add(seed, L[i - a]);
+            seed = pnx_exp2::sub(seed, L[a + 1]);
+        }
+    }
+    for (uint32_t m = wave_j0 + 1; m <= n; ++m) {
+        if (!__builtin_amdgcn_ballot_w64(alive)) break;
         uint32_t jlo, jhi;
         j_range(n, c, m_quorum[m], i, m, jlo, jhi);
-        // the lower bound only rises with m (m_quorum and i + m - n do), and j < m, j <= i hold in
-        // this loop: once j falls below it, no later m is admissible
-        if (j < jlo || j >= jhi) break;
-        if (q == 0.0) {  // choose(i, j), hist.rs:21-36: res += log2(i - a); res -= log2(a + 1)
-            const uint32_t k = j > i - j ? i - j : j;
-            double res = 0.0;
-            for (uint32_t a = 0; a < k; ++a) {
-                res = pnx_exp2::add(res, L[i - a]);
-                res = pnx_exp2::sub(res, L[a + 1]);
+        const double mf = m_fact[m], nf = n_fall[m];
+        if (alive && m > j) {
+            // the lower bound only rises with m (m_quorum and i + m - n do), and j < m, j <= i hold
+            // here: once j falls below it, no later m is admissible
+            if (j < jlo || j >= jhi) {
+                alive = false;
+            } else {
+                if (q == 0.0) q = seed;
+                q = pnx_exp2::add(q, L[n - i - m + 1 + j]);  // hist.rs:171
+                q = pnx_exp2::sub(q, L[m - j]);              // hist.rs:172
+                const double x = pnx_exp2::sub(pnx_exp2::add(q, mf), nf);
+                row[(size_t)m * ld + j] = pnx_exp2::exp2_exact(x, s_exp2);
             }
-            q = res;
         }
-        q = pnx_exp2::add(q, L[n - i - m + 1 + j]);  // hist.rs:171
-        q = pnx_exp2::sub(q, L[m - j]);              // hist.rs:172
-        const double x = pnx_exp2::sub(pnx_exp2::add(q, m_fact[m]), n_fall[m]);
-        row[(size_t)m * ld + j] = pnx_exp2::exp2_exact(x, s_exp2);
     }
 }
 
@@ -211,7 +217,7 @@ int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *
     PNX_HIP(ctx, hipMemsetAsync(d_sum.p, 0xFF, out_bytes, st));  // NaN everywhere
     for (uint32_t i0 = 0; i0 < n; i0 += slab) {
         const uint32_t i1 = std::min(n, i0 + slab);
-        const size_t tab_bytes = (4 * np1) * sizeof(double) + np1 * sizeof(uint32_t);
+        const size_t tab_bytes = (2 * np1) * sizeof(double);  // the log2 table
         if (tab_bytes <= 96 * 1024) {
             if (tab_bytes > 64 * 1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quorum_terms<true>),
