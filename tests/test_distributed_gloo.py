@@ -97,3 +97,55 @@ def test_shard_planner_edges():
     it, off, n = pd.shard_csr(items, np.array([0, 5, 8], np.uint64), 2, 4)
     assert it.tolist() == [1, 2, 2] and off.tolist() == [0, 1, 3] and n == 2
     assert pd.plan_node_shards(items, 9, 1).tolist() == [1, 10]
+
+
+def _perm_worker(rank, world, port, q):
+    """permutation sharding: every rank holds the whole graph, evaluates the orders
+    r = rank, rank + world, ... and the zero-initialised [R][T][G] result is all-reduced"""
+    import torch.distributed as dist
+    from panacus_amd.pansyn import random_orders
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, p, R = 4000, 10, 5
+        items, pre, _ = orc.pansyn(3, n, p)
+        perms = random_orders(3, R, p)
+        pairs = ((1, 0.0), (2, 0.5))
+        out = np.zeros((R, len(pairs), p), dtype=np.uint64)
+        for r in pd.split_orders(R, world, rank):
+            pi = perms[r].astype(np.uint64)               # group (= path) visited at each rank position
+            gi = np.arange(p, dtype=np.uint64)
+            r_, c_ = orc.by_group(items, pre, pi, gi, n)
+            for t, (c, qq) in enumerate(pairs):
+                out[r, t] = orc.ordered_growth(r_, c_, p, (orc.ABSOLUTE, c), (orc.RELATIVE, qq)).astype(np.uint64)
+        total = pd.allreduce_counters(out.reshape(-1)).reshape(out.shape)
+        q.put((rank, total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_permutation_sharding():
+    from panacus_amd.pansyn import random_orders
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_perm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    outs = dict(q.get(timeout=120) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(outs[0], outs[1])  # every rank ends with the full result
+    n, p, R = 4000, 10, 5
+    items, pre, _ = orc.pansyn(3, n, p)
+    perms = random_orders(3, R, p)
+    for r in range(R):
+        pi = perms[r].astype(np.uint64)
+        r_, c_ = orc.by_group(items, pre, pi, np.arange(p, dtype=np.uint64), n)
+        for t, (c, qq) in enumerate(((1, 0.0), (2, 0.5))):
+            exp = orc.ordered_growth(r_, c_, p, (orc.ABSOLUTE, c), (orc.RELATIVE, qq))
+            assert outs[0][r, t].tolist() == [int(x) for x in exp]
+    # an order is a permutation of the groups, and different orders differ
+    assert all(sorted(perms[r].tolist()) == list(range(p)) for r in range(R)) and len({tuple(x) for x in perms.tolist()}) > 1
