@@ -3,6 +3,7 @@
 // ItemTable and the visiting order to the GPU through the C ABI, format the results.
 #include "commands.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -121,6 +122,29 @@ void renumber_edges(const std::vector<uint32_t> &new_id, std::vector<uint32_t> &
     exclude.swap(moved);
 }
 
+// Do the edge ids of the file already rise and fall along the paths (L lines written in the order
+// of their ends, as odgi / vg / pggb do)?  Then the renumbering -- a sort of all edges -- buys
+// nothing.  Looks at the first steps of a few paths: the share of adjacent steps that go against
+// the direction of their path's majority.
+bool edge_ids_follow_paths(const ItemTable &tab) {
+    uint64_t with = 0, against = 0;
+    const size_t P = tab.id_prefsum.size() - 1;
+    size_t looked = 0;
+    for (size_t k = 0; k < P && looked < 16; ++k) {
+        const uint64_t b = tab.id_prefsum[k], e = std::min<uint64_t>(tab.id_prefsum[k + 1], b + 4096);
+        if (e - b < 64) continue;
+        ++looked;
+        uint64_t up = 0, down = 0;
+        for (uint64_t j = b; j + 1 < e; ++j) {
+            up += tab.items[j + 1] > tab.items[j];
+            down += tab.items[j + 1] < tab.items[j];
+        }
+        with += std::max(up, down);
+        against += std::min(up, down);
+    }
+    return looked == 0 || against * 20 <= with + against;  // <= 5 % of the steps run against the path
+}
+
 // per_item_output: the caller prints rows per item id (`table`), so the ids of the reference are kept;
 // otherwise edge ids are renumbered for the device (see GraphStorage::edge_relabel)
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
@@ -136,7 +160,7 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
             w = g.node_lens();
             for (const auto &u : m.uncovered) w[u.first] = u.second > w[u.first] ? 0 : (uint32_t)(w[u.first] - u.second);
         }
-        if (renumber) renumber_edges(g.edge_relabel(), m.table.items, m.exclude);
+        if (renumber && !edge_ids_follow_paths(m.table)) renumber_edges(g.edge_relabel(), m.table.items, m.exclude);
         const uint32_t none = 0;  // a valid pointer for an empty table
         dev.check(pnx_set_csr(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
                               (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
@@ -145,7 +169,7 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     } else if (renumber) {
         ItemTable tab = g.item_table(ct);
         std::vector<uint8_t> no_flags;
-        renumber_edges(g.edge_relabel(), tab.items, no_flags);
+        if (!edge_ids_follow_paths(tab)) renumber_edges(g.edge_relabel(), tab.items, no_flags);
         const uint32_t none = 0;
         dev.check(pnx_set_csr(dev.ctx, tab.items.empty() ? &none : tab.items.data(), tab.id_prefsum.data(), n_paths,
                               (uint32_t)n_items, nullptr, nullptr));

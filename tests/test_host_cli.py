@@ -452,3 +452,37 @@ def test_multi_gpu_tool_matches_cli(golden_dir, tmp_path):
         rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5", "-S", gfa])
         assert rc == 0, err
         assert text == _body(out).rstrip("\n") + "\n"
+
+
+@pytest.mark.gpu
+def test_cli_edge_counts_do_not_depend_on_link_order(tmp_path):
+    """edge ids follow the L lines (graph.rs:282-295); the CLI renumbers them for the device when
+    they do not follow the paths.  Sorted and shuffled link sections give the oracle's numbers."""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "20000", "--paths", "12", "--links", "-o", path])
+    assert rc == 0, err
+    lines = open(path).read().split("\n")
+    links = [l for l in lines if l.startswith("L\t")]
+    rng = np.random.default_rng(7)
+    shuf = str(tmp_path / "shuf.gfa")
+    with open(shuf, "w") as f:
+        f.write("\n".join([l for l in lines if l and not l.startswith("L\t")] + [links[i] for i in rng.permutation(len(links))]) + "\n")
+    outs = []
+    for gfa in (path, shuf):
+        g = orc.Graph(gfa, index_edges=True)
+        pi, gi, names = g.path_order(orc.GROUP_SAMPLE)
+        items, pre = g.item_table(orc.EDGE)
+        cov = orc.coverage(items, pre, pi, gi, g.n_edges)
+        h = orc.hist(cov, len(names))
+        rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", "edge", "-S", "-l", "1,2", "-q", "0,0.5", gfa])
+        assert rc == 0, err
+        rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+        assert [int(r[1]) for r in rows] == h.tolist()
+        rc, out2, err = hl.run_cli(["ordered-histgrowth", "-c", "edge", "-S", "-l", "1", "-q", "0.3", gfa])
+        assert rc == 0, err
+        r_, c_ = orc.by_group(items, pre, pi, gi, g.n_edges)
+        exp = orc.ordered_growth(r_, c_, len(names), (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.3))
+        orows = [x.split("\t") for x in _body(out2).split("\n")[4:] if x]
+        assert [x[1] for x in orows] == [str(int(v)) for v in exp]
+        outs.append((_body(out), _body(out2)))
+    assert outs[0] == outs[1]
