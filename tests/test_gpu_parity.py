@@ -757,6 +757,17 @@ def test_full_size_cfg3_properties():
         assert int(cnt[1:].astype(np.uint64).sum()) <= c.info().n_steps
         # 20 % of the nodes are in every path (pansyn "core"), 45 % in about one path
         assert abs(int(h[p]) / n - 0.20) < 0.01
+        # direct parity on a prefix: node i of pansyn(seed, N, P) does not depend on N, so the first
+        # million nodes have the coverage the oracle computes on the (seed, 1 M, P) graph
+        n_pre = 1_000_000
+        items, pre, _ = orc.pansyn(42, n_pre, p)
+        pi = np.arange(p, dtype=np.uint64)
+        assert np.array_equal(cnt[1:n_pre + 1], orc.coverage(items, pre, pi, pi, n_pre)[1:])
+        del items
+        # ... and sampled nodes anywhere, from the generator's definition
+        rng = np.random.default_rng(1)
+        nodes = np.unique(np.concatenate([rng.integers(1, n + 1, size=1500), [1, n, n - 1, 2048, 2049, 4_999_999]]))
+        assert np.array_equal(cnt[nodes].astype(np.int64), _pansyn_coverage_of(42, nodes, n, p))
         rng = np.random.default_rng(0)
         perm = rng.permutation(p).astype(np.uint32)
         c.set_order(perm, order, p)  # same groups visited in another order
