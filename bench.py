@@ -107,6 +107,10 @@ def main():
     ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="contexts (streams) over the one resident graph whose passes alternate.  1 [default]: one "
+                         "stream, the coverage kernel is timed alone (what `roofline` is defined on); 2: +11 %% passes/s, "
+                         "but two coverage kernels then overlap and a launch takes 1.1 ms (DESIGN.md section 5)")
     ap.add_argument("--no-quorum-offload", action="store_true")
     ap.add_argument("--quorum-offload-min-n", type=int, default=512)
     args = ap.parse_args()
@@ -151,68 +155,98 @@ def main():
     pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]  # -l 1,2,1 -q 0,0,0.5
     thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
 
-    ctx = capi.Context(local_rank)
-    ctx.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
-    ctx.config(capi.CFG_CACHE_INDEX, 0)
-    if blocking:
-        ctx.config(capi.CFG_BLOCKING_SYNC, 1)
-    if args.index_coarse is not None:
-        ctx.config(capi.CFG_INDEX_COARSE, args.index_coarse)
-    if args.cover_waves is not None:
-        ctx.config(capi.CFG_COVER_WAVES, args.cover_waves)
-    if args.cover_split is not None:
-        ctx.config(capi.CFG_COVER_SPLIT, args.cover_split)
-    if args.cover_variant is not None:
-        ctx.config(capi.CFG_COVER_VARIANT, args.cover_variant)
-    ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
-    order = np.arange(P, dtype=np.uint32)
-    ctx.set_order(order, order, P)
+    def make_context(owner=None):
+        c = capi.Context(local_rank)
+        c.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
+        c.config(capi.CFG_CACHE_INDEX, 0)
+        if blocking:
+            c.config(capi.CFG_BLOCKING_SYNC, 1)
+        if args.index_coarse is not None:
+            c.config(capi.CFG_INDEX_COARSE, args.index_coarse)
+        if args.cover_waves is not None:
+            c.config(capi.CFG_COVER_WAVES, args.cover_waves)
+        if args.cover_split is not None:
+            c.config(capi.CFG_COVER_SPLIT, args.cover_split)
+        if args.cover_variant is not None:
+            c.config(capi.CFG_COVER_VARIANT, args.cover_variant)
+        if owner is None:
+            c.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
+        else:
+            c.share_csr(owner)  # the same ItemTable in HBM, no copy
+        order = np.arange(P, dtype=np.uint32)
+        c.set_order(order, order, P)
+        return c
+
+    class Lane:
+        """One context = one stream with two passes in flight.  Two lanes over the same resident
+        graph alternate their passes, so that the short latency-bound kernels of one lane's pass
+        (tile index, histogram, the result copy) run beside the coverage kernel of the other's."""
+
+        def __init__(self, ctx, group):
+            self.ctx = ctx
+            self.group = group
+            self.hist_views = {}
+            if use_dist:
+                # the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind the
+                # pass on the library's own stream (a collective on another stream would have to wait
+                # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
+                self.ext = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
+                self.ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
+                              "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
+                              "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(2)]
+                self.enq = self.fin = 0
+
+        def enqueue(self):
+            ctx = self.ctx
+            ctx.hist_async()
+            if use_dist:
+                d_hist = ctx.hist_enqueued()
+                t = self.hist_views.get(d_hist)
+                if t is None:
+                    t = self.hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
+                slot = self.ring[self.enq % 2]
+                self.enq += 1
+                with torch.cuda.stream(self.ext):
+                    slot["tmp"].copy_(t)
+                    dist.all_reduce(slot["tmp"], group=self.group)  # RCCL, int64 sum == uint64 sum for counts < 2^63
+                    slot["host"].copy_(slot["tmp"], non_blocking=True)
+                    slot["ev"].record(self.ext)
+                slot["reruns"] = int(ctx.info().n_reruns)
+
+        def settle(self):
+            """wait for the OLDEST enqueued pass of this lane; multi-GPU: its all-reduced counters"""
+            ctx = self.ctx
+            if use_dist:
+                slot = self.ring[self.fin % 2]
+                self.fin += 1
+                slot["ev"].synchronize()
+                ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
+                if int(ctx.info().n_reruns) != slot["reruns"]:
+                    # A pass that fails its verification is run again by the library, and its reduced
+                    # counters would be stale.  It cannot happen here (pansyn paths are tile-monotone);
+                    # a host for arbitrary graphs settles the first pass before it pipelines.  Failing
+                    # is better than an unmatched collective.
+                    raise RuntimeError("a coverage pass was re-run inside the pipelined multi-GPU loop")
+                return slot["host"].numpy().view(np.uint64).copy()
+            _, h = ctx.hist_fetch(want_countable=False)
+            return h
+
+        def close(self):
+            if use_dist:
+                # torch objects that were used on the library's stream (pinned buffers record it when
+                # they are freed) must go before the stream does
+                self.ring.clear()
+                self.hist_views.clear()
+                del self.ext
+
+    n_lanes = max(1, args.lanes)
+    ctx = make_context()
+    all_lanes = lanes = [Lane(ctx, None)]
+    for _ in range(1, n_lanes):
+        # every lane has its own communicator: its collectives are ordered on its own stream
+        lanes.append(Lane(make_context(ctx), dist.new_group() if use_dist else None))
     info = ctx.info()
     S = int(info.n_steps)
-
-    # multi-GPU: the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind
-    # the pass on the library's own stream (a collective on another stream would have to wait
-    # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
-    hist_views = {}
-    if use_dist:
-        ext = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
-        ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
-                 "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
-                 "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(2)]
-        ring_pos = {"enq": 0, "fin": 0}
-
-    def enqueue():
-        ctx.hist_async()
-        if use_dist:
-            d_hist = ctx.hist_enqueued()
-            t = hist_views.get(d_hist)
-            if t is None:
-                t = hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
-            slot = ring[ring_pos["enq"] % 2]
-            ring_pos["enq"] += 1
-            with torch.cuda.stream(ext):
-                slot["tmp"].copy_(t)
-                dist.all_reduce(slot["tmp"])  # RCCL, int64 sum == uint64 sum for counts < 2^63
-                slot["host"].copy_(slot["tmp"], non_blocking=True)
-                slot["ev"].record(ext)
-            slot["reruns"] = int(ctx.info().n_reruns)
-
-    def settle():
-        """wait for the OLDEST enqueued pass; multi-GPU: its all-reduced counters"""
-        if use_dist:
-            slot = ring[ring_pos["fin"] % 2]
-            ring_pos["fin"] += 1
-            slot["ev"].synchronize()
-            _, h_local = ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
-            if int(ctx.info().n_reruns) != slot["reruns"]:
-                # A pass that fails its verification is run again by the library, and its reduced
-                # counters would be stale.  It cannot happen here (pansyn paths are tile-monotone);
-                # a host for arbitrary graphs settles the first pass before it pipelines.  Failing
-                # is better than an unmatched collective.
-                raise RuntimeError("a coverage pass was re-run inside the pipelined multi-GPU loop")
-            return slot["host"].numpy().view(np.uint64).copy()
-        _, h = ctx.hist_fetch(want_countable=False)
-        return h
 
     # large group counts: the O(n^3) inner sums of the quorum closed form run on the GPU
     # (bit-identical, see csrc/kernels_closed_form.hip); below 512 groups the host is faster
@@ -227,19 +261,24 @@ def main():
     def growth_end(pending):
         return hostlib.calc_growths_end(pending) if rank == 0 else None
 
-    def run(n_steps):
-        """n_steps complete histgrowth passes.  Consecutive passes are independent, so two are kept
-        in flight: while the host evaluates the closed forms of pass k, pass k+1 runs and pass k+2 is
-        already enqueued behind it; every pass is finished inside the call."""
+    def run(n_steps, lanes=None):
+        """n_steps complete histgrowth passes, dealt round-robin to the lanes.  Consecutive passes
+        are independent; every lane keeps two of its own in flight: while the host evaluates the
+        closed forms of pass k, later passes run and the next one of that lane is already enqueued
+        behind them.  Every pass is finished inside the call."""
         h = growths = None
-        enqueue()
-        if n_steps > 1:
-            enqueue()
+        lanes = all_lanes if lanes is None else lanes
+        L = len(lanes)
+        enqueued = 0
+        for _ in range(min(n_steps, 2 * L)):
+            lanes[enqueued % L].enqueue()
+            enqueued += 1
         for k in range(n_steps):
-            h = settle()
+            h = lanes[k % L].settle()
             pending = growth_begin(h)
-            if k + 2 < n_steps:
-                enqueue()
+            if enqueued < n_steps:
+                lanes[enqueued % L].enqueue()
+                enqueued += 1
             growths = growth_end(pending)
         return h, growths
 
@@ -247,7 +286,8 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        for ln in lanes:
+            ln.ctx.sync()
 
     if args.warmup:
         run(args.warmup)
@@ -255,17 +295,23 @@ def main():
     # timed region: HIP events (on the context's stream) around the dominant kernel only; the
     # other kernels are timed in a short untimed tail so that their event records do not sit
     # between the kernels of the measured passes
-    ctx.profile_enable(True)
-    ctx.profile_select([capi.K_COVER])
-    ctx.profile_reset()
+    for ln in lanes:
+        ln.ctx.profile_enable(True)
+        ln.ctx.profile_select([capi.K_COVER])
+        ln.ctx.profile_reset()
     t0 = time.perf_counter()
     h, growths = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile_select(None)
-    ctx.profile_reset()
-    run(5)
+    prof = {"cover": (0.0, 0)}
+    for ln in lanes:  # the coverage kernel of every lane, as it ran beside the other lanes' short kernels
+        ms, cnt = ln.ctx.profile_read()["cover"]
+        prof["cover"] = (prof["cover"][0] + ms, prof["cover"][1] + cnt)
+        ln.ctx.profile_select(None)
+        ln.ctx.profile_reset()
+        if ln.ctx is not ctx:
+            ln.ctx.profile_enable(False)
+    run(5, lanes[:1])  # index and histogram kernels on their own (one lane)
     barrier()
     prof_tail = ctx.profile_read()
     ctx.profile_enable(False)
@@ -337,6 +383,7 @@ def main():
             "breakdown_ms": {
                 "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_avg_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
+                "lanes": len(lanes),
                 "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
                 "quorum_inner_sums_on_gpu": bool(not args.no_quorum_offload and P >= args.quorum_offload_min_n
                                                  and hostlib.quorum_offload_usable()),
@@ -352,16 +399,14 @@ def main():
                 out["cpu_baseline"] = cb
             except Exception as e:  # the oracle is optional test infrastructure
                 out["cpu_baseline"] = {"error": str(e)}
+    for ln in lanes:
+        ln.close()
     if use_dist:
-        # torch objects that were used on the library's stream (pinned buffers record it when they
-        # are freed) must go before the stream does
-        ring.clear()
-        hist_views.clear()
-        del ext
         torch.cuda.synchronize()
         dist.destroy_process_group()
     hostlib.set_quorum_offload(None)
-    ctx.close()
+    for ln in reversed(lanes):  # borrowers of the resident graph before its owner
+        ln.ctx.close()
     if rank == 0:
         # RCCL writes a version banner through C stdio; push it out before the one JSON line
         try:

@@ -69,6 +69,13 @@ int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, u
 int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                        int with_weights);
 
+/* dst reads the graph that is resident in src -- the same ItemTable in HBM, no copy -- with its own
+ * stream, index, counters and results.  Two contexts on one device let the short kernels of one
+ * pass (index, histogram) run beside the coverage kernel of another pass over the same graph.
+ * src must outlive dst's use of the graph and must not upload another graph meanwhile; src cannot
+ * itself be a borrower.  dst then needs its own pnx_set_order. */
+int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src);
+
 /* Read the resident graph back (tests / caching): any pointer may be NULL.
  * n_steps receives S; items needs S entries, path_off n_paths+1, weights n_items+1. */
 int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path_off,

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
-    "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts",
+    "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
 ]
 
 
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.argtypes = [vp]
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
+    L.pnx_share_csr.argtypes = [vp, vp]
     L.pnx_group_visit_counts.argtypes = [vp, C.c_uint32, C.c_uint32, u32p]
     f64p = C.POINTER(C.c_double)
     L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
@@ -266,6 +267,13 @@ class Context:
         if G and rw:
             self._ck(self._L.pnx_presence(self._h, _ptr(out, C.c_uint64)))
         return out
+
+    def share_csr(self, src: "Context"):
+        """read the graph resident in `src` (same device) without a copy; keep `src` open meanwhile"""
+        self._ck(self._L.pnx_share_csr(self._h, src._h))
+        self._csr_owner = src  # keeps the owner alive as long as this context
+        self.n_items = src.n_items
+        self.n_groups = 0
 
     def group_visit_counts(self, item_lo: int, item_hi: int) -> np.ndarray:
         """[G, item_hi - item_lo] u32: steps of each group's paths on the items lo..hi-1 (AbacusByGroup.v, dense)."""

@@ -12,11 +12,12 @@ namespace pnx {
 int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
-    if (b.cap >= bytes) return PNX_OK;
+    if (!b.borrowed && b.cap >= bytes) return PNX_OK;
     if (b.p) {
-        (void)hipFree(b.p);
+        if (!b.borrowed) (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
+        b.borrowed = false;
     }
     hipError_t e = hipMalloc(&b.p, bytes + 256);  // +256: vector loads may over-read a tail
     if (e != hipSuccess) {
@@ -28,9 +29,10 @@ int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes) {
 }
 
 void release(DevBuf &b) {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.borrowed) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+    b.borrowed = false;
 }
 
 static hipEvent_t prof_event(pnx_ctx *ctx) {
@@ -320,6 +322,39 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
     ctx->have_exclude = false;
     set_geometry(ctx);
     ctx->have_csr = true;
+    return PNX_OK;
+}
+
+int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
+    if (!dst) return PNX_EINVAL;
+    if (!src || src == dst) return dst->fail(PNX_EINVAL, "pnx_share_csr: needs another context as the source");
+    if (!src->have_csr) return dst->fail(PNX_EINVAL, "pnx_share_csr: the source holds no graph");
+    if (src->device != dst->device) return dst->fail(PNX_EINVAL, "pnx_share_csr: the contexts are on different devices");
+    if (src->d_items.borrowed) return dst->fail(PNX_EINVAL, "pnx_share_csr: the source itself borrows its graph");
+    PNX_HIP(dst, hipSetDevice(dst->device));
+    PNX_HIP(dst, hipStreamSynchronize(src->stream));  // its upload is complete
+    invalidate_results(dst);
+    dst->have_csr = false;
+    dst->have_order = false;
+    auto borrow = [](DevBuf &d, const DevBuf &s) {
+        release(d);
+        d.p = s.p;
+        d.cap = 0;
+        d.borrowed = s.p != nullptr;
+    };
+    borrow(dst->d_items, src->d_items);
+    borrow(dst->d_path_off, src->d_path_off);
+    borrow(dst->d_weights, src->d_weights);
+    borrow(dst->d_exclude, src->d_exclude);
+    dst->h_path_off = src->h_path_off;
+    dst->weighted = src->weighted;
+    dst->have_weights = src->have_weights;
+    dst->have_exclude = src->have_exclude;
+    dst->n_items = src->n_items;
+    dst->n_paths = src->n_paths;
+    dst->n_steps = src->n_steps;
+    set_geometry(dst);
+    dst->have_csr = true;
     return PNX_OK;
 }
 

@@ -29,6 +29,7 @@ constexpr uint32_t BLOCK_WORDS = 64;
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;  // p belongs to another context (pnx_share_csr): never freed here
 };
 
 // One enqueued coverage pass.  Two tickets exist so that pass k+1 can be enqueued before the

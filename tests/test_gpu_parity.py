@@ -741,6 +741,83 @@ def test_group_visit_counts_match_by_group_values(ctx):
         ctx.group_visit_counts(3, n + 3)
 
 
+def test_two_contexts_share_one_resident_graph():
+    """pnx_share_csr: a second context reads the first one's ItemTable in place -- own order, own
+    stream, own results; passes of the two are enqueued interleaved"""
+    from panacus_amd import capi
+    n, p = 40_000, 24
+    items, pre, lens = orc.pansyn(19, n, p)
+    rng = np.random.default_rng(3)
+    excl = (rng.random(n + 1) < 0.05).astype(np.uint8)
+    a, b = capi.Context(0), capi.Context(0)
+    try:
+        with pytest.raises(capi.PnxError):
+            b.share_csr(a)                      # nothing resident yet
+        a.set_csr(items.astype(np.uint32), pre, n, weights=lens, exclude=excl)
+        with pytest.raises(capi.PnxError):
+            a.share_csr(a)
+        b.share_csr(a)
+        with pytest.raises(capi.PnxError):
+            capi.Context(0).share_csr(b)        # a borrower cannot lend
+        pa = np.arange(p, dtype=np.uint64)
+        ga = pa // 2
+        pb = pa[::-1].copy()
+        gb = np.arange(p, dtype=np.uint64) // 3
+        a.set_order(pa, ga, int(ga.max()) + 1)
+        b.set_order(pb, gb, int(gb.max()) + 1)
+        for c in (a, b, a, b):
+            c.hist_async()
+        outs = {"a": [], "b": []}
+        for name, c in (("a", a), ("b", b), ("a", a), ("b", b)):
+            outs[name].append(c.hist_fetch(want_countable=True))
+        for name, (pi, gi) in (("a", (pa, ga)), ("b", (pb, gb))):
+            G = int(gi.max()) + 1
+            cov = orc.coverage(items, pre, pi, gi, n, excl)
+            h = orc.hist(cov, G, lens)
+            for cnt, hh in outs[name]:
+                assert np.array_equal(cnt, cov) and np.array_equal(hh, h), name
+        # the borrower can take a graph of its own afterwards; the lender is untouched
+        items2, pre2, _ = orc.pansyn(20, 5000, 6)
+        b.set_csr(items2.astype(np.uint32), pre2, 5000)
+        o = np.arange(6, dtype=np.uint64)
+        b.set_order(o, o, 6)
+        cnt2, h2 = b.hist()
+        assert np.array_equal(cnt2, orc.coverage(items2, pre2, o, o, 5000))
+        cnt, hh = a.hist()
+        assert np.array_equal(hh, orc.hist(orc.coverage(items, pre, pa, ga, n, excl), int(ga.max()) + 1, lens))
+    finally:
+        b.close()
+        a.close()
+
+
+def test_bench_contract_line_small(tmp_path):
+    """bench.py end to end on a small shape: one JSON line with the contract's fields; one and two
+    lanes (contexts sharing the resident graph) and the forced single-rank RCCL path agree on the
+    checks"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2"], {}), (["--lanes", "2"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
+        e = dict(os.environ, MASTER_PORT="29577", **env)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nodes", "200000", "--paths", "64", "--steps", "12",
+                            "--warmup", "2", "--no-cpu-baseline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        lines = [l for l in r.stdout.decode().split("\n") if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["steps"] == 12 and d["n_gpus"] == 1 and d["roofline"]["launches"] == 12
+        assert d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 200000
+        outs.append(d["checks"])
+    assert outs[0] == outs[1] == outs[2]
+
+
 def test_full_size_cfg3_properties():
     """configs[2]: 10M nodes x 256 paths.  Every item lands in exactly one bin; the histogram is
     the bincount of the coverage vector; core nodes reach G; visiting order does not matter."""
