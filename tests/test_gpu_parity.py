@@ -796,12 +796,17 @@ def test_bench_contract_line_small(tmp_path):
     checks"""
     import json
     import os
+    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2"], {}), (["--lanes", "2"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
-        e = dict(os.environ, MASTER_PORT="29577", **env)
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nodes", "200000", "--paths", "64", "--steps", "12",
                             "--warmup", "2", "--no-cpu-baseline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e,
                            timeout=600)
