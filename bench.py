@@ -14,6 +14,18 @@ shard of the same shape (weak scaling: the global graph has N x 10M nodes, seeds
 the per-rank histograms are summed with an RCCL all-reduce on the device counters, and
 rank 0 evaluates the closed forms.
 
+Besides the headline the same JSON line carries:
+  * "permuted_growth" -- BASELINE.json configs[3]: ordered-histgrowth over R = 128 random group
+    orders on a 10M-node / 512-path graph, STRONG scaling: the R orders are dealt to the ranks
+    (permutation sharding, presence matrix replicated), every rank's out[R/N][T][G] is summed
+    into the full out[R][T][G] with an RCCL all-reduce enqueued behind the growth kernels on the
+    library's own stream, on the device buffer (pnx_ordered_growth_enqueued).  For N > 1 rank 0
+    also times all R orders alone, so that `speedup_vs_1` comes from one run on one box.
+  * "shape_10Mx1k" (N = 1 only) -- north_star's 10M-node / 1k-path histgrowth shape with its
+    kernel breakdown.
+  * "cpu_baseline" (N = 1 only) -- the oracle (serial port of the reference's loops; closed forms
+    one thread per threshold pair like hist.rs:68-81) on the FULL headline workload.
+
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
@@ -44,15 +56,21 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
+PMC_ROUND = "r02"
+
+
 def pmc_traffic_from_profiles(nodes, paths):
-    """HBM bytes per k_tile_cover launch from the committed rocprofv3 PMC summaries
-    (profiles/, separate --pmc FETCH_SIZE / WRITE_SIZE passes on this same workload).
-    gfx950 reports half of the bytes of wide streaming reads, hence 2 x FETCH_SIZE."""
+    """HBM bytes per k_tile_cover launch REPLAYED from the committed rocprofv3 PMC summaries
+    (profiles/, separate --pmc FETCH_SIZE / WRITE_SIZE passes on this same workload) -- counters
+    cannot be read from inside this process, so this is a cross-reference, not a measurement of
+    this run (`traffic_source` says so).  gfx950 reports half of the bytes of wide streaming
+    reads, hence 2 x FETCH_SIZE."""
     if (nodes, paths) != (10_000_000, 256):
         return None, None
     vals = {}
+    rnd = PMC_ROUND if os.path.exists(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_hist_cfg3_pmc_FETCH_SIZE.csv")) else "r01"
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"r01_hist_cfg3_pmc_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"{rnd}_hist_cfg3_pmc_{name}.csv")
         if not os.path.exists(path):
             return None, None
         for line in open(path):
@@ -60,35 +78,283 @@ def pmc_traffic_from_profiles(nodes, paths):
                 vals[name] = float(line.rsplit(",", 2)[1])
     if len(vals) != 2:
         return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r01_hist_cfg3_pmc_{FETCH,WRITE}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        f"replayed from the committed profiles/{rnd}_hist_cfg3_pmc_{{FETCH,WRITE}}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, KiB), not measured in this run"
 
 
-def cpu_baseline(sample_nodes, n_paths, pairs, seed=42, min_seconds=10.0, max_reps=40):
-    """The oracle (a plain-C port of the reference's serial loops) on a bounded sample of the
-    same workload, timed on this host: coverage + hist + closed-form growth, repeated until
-    about `min_seconds` of CPU work has been measured."""
+def cpu_baseline(ctx, n_nodes, n_paths, pairs, seed=42, passes=3, sample_nodes=None):
+    """The oracle (a plain-C port of the reference's loops, u64 items like the reference) on the
+    headline workload, timed on this host: the serial coverage loop (abacus.rs:719-744 is serial in
+    the reference too, despite its comment) + construct_hist + the closed-form growth curves, one
+    thread per (coverage, quorum) pair as the reference's rayon par_iter does (hist.rs:68-81).
+    The input is the graph that is resident on the GPU, read back once (generating 10^9 steps with
+    the serial CPU generator would take minutes); `sample_nodes` < n_nodes (hosts short of memory: the u64 steps of the headline graph are
+    7.8 GB) times a smaller pansyn graph instead and says so."""
+    import threading
+
     import oracle as orc
-    items, pre, _ = orc.pansyn(seed, sample_nodes, n_paths)
+    n = n_nodes
+    if sample_nodes is not None and sample_nodes < n_nodes:
+        n = sample_nodes
+        items, pre, _ = orc.pansyn(seed, n, n_paths)  # the CPU generator (bit-identical to the device one)
+    else:
+        items32, pre, _ = ctx.get_csr()
+        items = items32.astype(np.uint64)  # the reference's ItemIdSize
+        del items32
     pi = np.arange(n_paths, dtype=np.uint64)
-    reps, total = 0, 0.0
-    while reps < max_reps and (total < min_seconds or reps == 0):
+    growths = [None] * len(pairs)
+
+    def one_pair(k):
+        c, q = pairs[k]
+        growths[k] = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+
+    total = 0.0
+    t_cov = t_growth = 0.0
+    for _ in range(passes):
         t0 = time.perf_counter()
-        cov = orc.coverage(items, pre, pi, pi, sample_nodes)
+        cov = orc.coverage(items, pre, pi, pi, n)
         h = orc.hist(cov, n_paths)
-        for c, q in pairs:
-            orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
-        total += time.perf_counter() - t0
-        reps += 1
-    dt = total / reps
+        t1 = time.perf_counter()
+        th = [threading.Thread(target=one_pair, args=(k,)) for k in range(len(pairs))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        t2 = time.perf_counter()
+        total += t2 - t0
+        t_cov += t1 - t0
+        t_growth += t2 - t1
+    dt = total / passes
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        model = "unknown"
     return {
-        "value": sample_nodes * n_paths / dt / 1e6,
+        "value": n * n_paths / dt / 1e6,
         "unit": "M node*paths/s",
-        "cores": 1,
+        "cores": len(pairs),
         "kind": "port",
-        "sample": f"pansyn-v1 seed {seed}, {sample_nodes} nodes x {n_paths} paths "
-                  f"({len(items)} steps); serial coverage+hist+closed-form growth, "
-                  f"{reps} passes, {dt:.3f} s each ({total:.1f} s of CPU work)",
-    }, h
+        "sample": f"pansyn-v1 seed {seed}, {n} nodes x {n_paths} paths ({len(items)} steps"
+                  f"{'' if n == n_nodes else ', a SMALLER graph than the headline workload'}); {passes} passes, {dt:.3f} s each: "
+                  f"serial coverage+hist {t_cov / passes:.3f} s (1 thread, as the reference), closed-form growth "
+                  f"{t_growth / passes:.3f} s ({len(pairs)} threads, one per threshold pair as hist.rs:68-81)",
+        "host": {"nproc": os.cpu_count(), "cpu_model": model},
+    }, h, growths
+
+
+def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking):
+    """BASELINE.json configs[3], strong scaling by permutation sharding (module docstring)."""
+    from panacus_amd import capi
+    from panacus_amd.distributed import split_orders
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+
+    N, P, R, reps = args.pg_nodes, args.pg_paths, args.pg_orders, max(1, args.pg_reps)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    T = len(pairs)
+    dev = f"cuda:{local_rank}"
+    ctx = capi.Context(local_rank)
+    if blocking:
+        ctx.config(capi.CFG_BLOCKING_SYNC, 1)
+    ctx.config(capi.CFG_KEEP_PRESENCE, 1)
+    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)  # the SAME graph on every rank
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), P) for c, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), P) for _, q in pairs])
+    perms = random_orders(args.seed, R, P)
+    mine = list(split_orders(R, world, rank))
+    my_perms = perms[mine] if mine else perms[:0]
+
+    def sync_all():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    # presence matrix (K0, K1 with the row stores, K2): built once per rank, then resident
+    ctx.hist(want_countable=False)   # first call: allocations, index spans
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    ctx.hist(want_countable=False)
+    pack_s = time.perf_counter() - t0
+    pk = ctx.profile_read()
+    info = ctx.info()
+
+    # ---- all R orders on one GPU: the single-GPU time (every rank could; rank 0's is reported) ----
+    ctx.ordered_growth(cov, qt, perms[:1])  # masks, first launch
+    ctx.profile_reset()
+    single = None
+    t1 = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            single = ctx.ordered_growth(cov, qt, perms)
+        t1 = (time.perf_counter() - t0) / reps
+    k1 = ctx.profile_read()["growth"]
+    ctx.profile_reset()
+
+    if not use_dist:
+        dt, full_host, ar_ms, gk_ms = t1, single, 0.0, k1[0] / max(k1[1], 1)
+    else:
+        # ---- the sharded call: my orders -> full[R][T][G] (zeros elsewhere) -> RCCL all-reduce, all on
+        # the library's stream and on device buffers; rank 0 then copies the 8*R*T*G bytes to the host
+        ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
+        full = torch.zeros((R, T, P), dtype=torch.int64, device=dev)
+        host = torch.zeros((R, T, P), dtype=torch.int64).pin_memory()
+        ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        done = torch.cuda.Event(blocking=blocking)
+        idx = torch.tensor(mine, dtype=torch.int64, device=dev)
+        views = {}
+
+        def call(k):
+            if mine:
+                ctx.ordered_growth_async(cov, qt, my_perms)
+                d_out = ctx.ordered_growth_enqueued()
+                t = views.get(d_out)
+                if t is None:
+                    t = views[d_out] = torch.as_tensor(_DevArray(d_out, len(mine) * T * P), device=dev).view(len(mine), T, P)
+            with torch.cuda.stream(ext):
+                ev_a[k].record(ext)
+                full.zero_()
+                if mine:
+                    full.index_copy_(0, idx, t)
+                dist.all_reduce(full)  # RCCL; int64 sum == u64 sum (counts < 2^63)
+                ev_b[k].record(ext)
+                if rank == 0:
+                    host.copy_(full, non_blocking=True)
+                done.record(ext)
+            done.synchronize()
+
+        call(reps)  # warm-up (communicator, first launches)
+        sync_all()
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            call(k)
+        sync_all()
+        dt = (time.perf_counter() - t0) / reps
+        gk = ctx.profile_read()["growth"]
+        ar_ms = sum(ev_a[k].elapsed_time(ev_b[k]) for k in range(reps)) / reps
+        red = torch.tensor([dt, gk[0] / max(gk[1], 1), ar_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dt, gk_ms, ar_ms = (float(x) for x in red.tolist())
+        full_host = host.numpy().view(np.uint64).copy() if rank == 0 else None
+        views.clear()
+        del ext, full, host, idx
+    ctx.profile_enable(False)
+
+    out = None
+    if rank == 0:
+        if not np.array_equal(full_host, single):
+            raise SystemExit("permuted growth: the sharded result differs from the single-GPU result")
+        n_words = (N + 1 + 63) // 64
+        b_growth = R * (8 * P * n_words + 8 * T * P)       # SURVEY 8(d), all R orders
+        b_pack = 4 * int(info.n_steps) + 8 * P * n_words   # SURVEY 8(d)
+        cover_ms = pk["cover"][0] / max(pk["cover"][1], 1)
+        out = {
+            "workload": f"ordered-histgrowth -c node -l 1,2,1 -q 0,0,0.5 over {R} random group orders (pansyn stream 7, seed "
+                        f"{args.seed}), {N} nodes x {P} paths (BASELINE.json configs[3])",
+            "n_gpus": world, "scaling": "strong",
+            "sharding": "orders: rank r evaluates orders r, r+N, ...; presence matrix replicated on every rank; "
+                        "RCCL all-reduce (sum) of out[R][T][G] on the device buffer, enqueued on the library's stream",
+            "orders": R, "threshold_pairs": pairs, "orders_per_rank_max": (R + world - 1) // world, "reps": reps,
+            "seconds_per_call": dt, "orders_per_s": R / dt,
+            "M_node_group_orders_per_s": N * P * R / dt / 1e6,
+            "seconds_per_call_1gpu": t1, "speedup_vs_1": t1 / dt,
+            "growth_kernel_ms_rank_max": gk_ms, "growth_kernel_ms_1gpu": k1[0] / max(k1[1], 1),
+            "allreduce_ms": ar_ms,
+            "collective_path": "rccl via torch.distributed (nccl backend) on pnx_stream()" if use_dist else "none (one rank)",
+            "presence_pack_ms": pack_s * 1e3, "presence_pack_cover_kernel_ms": cover_ms,
+            "presence_pack_algorithmic_bytes": b_pack,
+            "presence_pack_cover_kernel_GBps": b_pack / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
+            "seconds_per_call_incl_pack": dt + pack_s, "speedup_vs_1_incl_pack": (t1 + pack_s) / (dt + pack_s),
+            "algorithmic_bytes": b_growth, "algorithmic_GBps": b_growth / dt / 1e9,
+            "steps_in_csr": int(info.n_steps),
+            "checks": {"sharded_equals_single_gpu": True,
+                       "growth_last": [int(full_host[0, t, -1]) for t in range(T)]},
+        }
+    if use_dist:
+        torch.cuda.synchronize()
+    ctx.close()
+    return out
+
+
+def shape_1k_block(args, local_rank):
+    """north_star's shape: histgrowth on a 10M-node / 1k-path pansyn graph, one GPU, same step as the
+    headline (index rebuilt every pass, closed forms included; the O(n^3) quorum sums of n = 1024 run
+    on the GPU, bit-identical), with the kernel breakdown."""
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    N, P, steps = args.k1_nodes, args.k1_paths, max(2, args.k1_steps)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    ctx = capi.Context(local_rank)
+    ctx.config(capi.CFG_CACHE_INDEX, 0)
+    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
+    offload = not args.no_quorum_offload and P >= args.quorum_offload_min_n
+    if not args.no_quorum_offload:
+        hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
+
+    def run(n):
+        h = growths = None
+        enq = 0
+        for _ in range(min(n, 2)):
+            ctx.hist_async()
+            enq += 1
+        for _ in range(n):
+            _, h = ctx.hist_fetch(want_countable=False)
+            pending = hostlib.calc_growths_begin(h, thr, args.growth_threads)
+            if enq < n:
+                ctx.hist_async()
+                enq += 1
+            growths = hostlib.calc_growths_end(pending)
+        return h, growths
+
+    run(3)
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_select([capi.K_COVER])
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    h, growths = run(steps)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    cover = ctx.profile_read()["cover"]
+    ctx.profile_select(None)
+    ctx.profile_reset()
+    run(4)
+    ctx.sync()
+    tail = ctx.profile_read()
+    ctx.profile_enable(False)
+    info = ctx.info()
+    S = int(info.n_steps)
+    B = algorithmic_bytes_hist(S, P, N, P)
+    cover_ms = cover[0] / max(cover[1], 1)
+    index_ms = tail["index"][0] / max(tail["index"][1], 1)
+    hist_ms = tail["hist"][0] / max(tail["hist"][1], 1)
+    if int(h.sum()) != N:
+        raise SystemExit(f"shape_10Mx1k: histogram sums to {int(h.sum())}, expected {N}")
+    hostlib.set_quorum_offload(None)
+    ctx.close()
+    return {
+        "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 seed {args.seed}, {N} nodes x {P} paths (north_star's shape)",
+        "steps": steps, "ms_per_step": dt * 1e3, "value": N * P / dt / 1e6, "unit": "M node*paths/s",
+        "steps_in_csr": S, "algorithmic_bytes_per_pass": B,
+        "breakdown_ms": {"tile_index": index_ms, "tile_cover": cover_ms, "hist": hist_ms,
+                         "device_total": index_ms + cover_ms + hist_ms,
+                         "quorum_inner_sums_on_gpu": bool(offload and hostlib.quorum_offload_usable())},
+        "roofline_frac_tile_cover": B / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
+        "roofline_frac_device_pass": B / ((index_ms + cover_ms + hist_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "roofline_frac_whole_step": B / dt / 1e9 / HBM_PEAK_GBS,
+        "checks": {"hist_sum": int(h.sum()), "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
+    }
 
 
 def main():
@@ -104,7 +370,18 @@ def main():
     ap.add_argument("--index-coarse", type=int, default=None)
     ap.add_argument("--cover-waves", type=int, default=None)
     ap.add_argument("--cover-split", type=int, default=None)
-    ap.add_argument("--cpu-sample-nodes", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample-nodes", type=int, default=0,
+                    help="0 [default]: the CPU baseline runs on the full headline graph; > 0: on a pansyn graph of that many nodes")
+    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--no-permuted-growth", action="store_true")
+    ap.add_argument("--pg-nodes", type=int, default=10_000_000)
+    ap.add_argument("--pg-paths", type=int, default=512)
+    ap.add_argument("--pg-orders", type=int, default=128)
+    ap.add_argument("--pg-reps", type=int, default=5)
+    ap.add_argument("--no-shape-1k", action="store_true")
+    ap.add_argument("--k1-nodes", type=int, default=10_000_000)
+    ap.add_argument("--k1-paths", type=int, default=1024)
+    ap.add_argument("--k1-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--growth-threads", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=1,
@@ -395,18 +672,44 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb, _ = cpu_baseline(min(args.cpu_sample_nodes, N), P, pairs, args.seed)
+                cb, h_cpu, g_cpu = cpu_baseline(ctx, N, P, pairs, args.seed, passes=args.cpu_passes,
+                                                sample_nodes=args.cpu_sample_nodes or None)
+                if not args.cpu_sample_nodes:
+                    # same workload on both sides: the results must agree bit for bit
+                    cb["agrees_with_gpu"] = bool(np.array_equal(h_cpu, h) and
+                                                 all(a.tobytes() == b.tobytes() for a, b in zip(g_cpu, growths)))
+                    if not cb["agrees_with_gpu"]:
+                        raise SystemExit("bench: histogram / growth of the GPU path differ from the CPU oracle")
                 out["cpu_baseline"] = cb
+            except SystemExit:
+                raise
             except Exception as e:  # the oracle is optional test infrastructure
-                out["cpu_baseline"] = {"error": str(e)}
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    # a wrong histogram must not produce a valid-looking line: every rank leaves together
+    ok = 1 if (rank != 0 or int(h.sum()) == world * N) else 0
+    if use_dist:
+        okt = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = int(okt.item())
+    if not ok:
+        raise SystemExit(f"bench: the histogram does not sum to the number of items ({world * N})")
     for ln in lanes:
         ln.close()
-    if use_dist:
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
     hostlib.set_quorum_offload(None)
     for ln in reversed(lanes):  # borrowers of the resident graph before its owner
         ln.ctx.close()
+
+    # ---- BASELINE.json configs[3]: permuted growth, strong scaling (every rank takes part) ----
+    if not args.no_permuted_growth:
+        pg = permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking)
+        if rank == 0:
+            out["permuted_growth"] = pg
+    # ---- north_star's 10M x 1k shape (one GPU) ----
+    if world == 1 and not args.no_shape_1k:
+        out["shape_10Mx1k"] = shape_1k_block(args, local_rank)
+    if use_dist:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
     if rank == 0:
         # RCCL writes a version banner through C stdio; push it out before the one JSON line
         try:

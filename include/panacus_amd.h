@@ -133,6 +133,11 @@ int pnx_ordered_growth(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms,
 int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms,
                              const uint32_t *cov_thr, const uint32_t *quorum_tab, uint32_t n_thr);
 int pnx_ordered_growth_device(pnx_ctx *ctx, uint64_t **d_out); /* R*T*G u64 */
+/* result buffer of the growth call enqueued LAST by pnx_ordered_growth_async, without waiting for
+ * it: for work the caller enqueues behind the call on pnx_stream() -- the RCCL all-reduce of a
+ * host that shards the orders (or the item ranges) over several GPUs.  The buffer is reused by
+ * the next growth call on the context. */
+int pnx_ordered_growth_enqueued(pnx_ctx *ctx, uint64_t **d_out);
 int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
 
 /* ---- group x group intersections ("next" row: similarity) ----------------------------------

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
-    "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_profile_enable", "pnx_profile_read",
+    "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     L.pnx_ordered_growth_async.argtypes = [vp, u32p, C.c_uint32, u32p, u32p, C.c_uint32]
     L.pnx_ordered_growth_device.argtypes = [vp, C.POINTER(vp)]
     L.pnx_ordered_growth_fetch.argtypes = [vp, u64p]
+    L.pnx_ordered_growth_enqueued.argtypes = [vp, C.POINTER(vp)]
     L.pnx_group_intersections.argtypes = [vp, u64p]
     L.pnx_group_intersections_device.argtypes = [vp, C.POINTER(vp)]
     L.pnx_presence_row_words.argtypes = [vp]
@@ -145,6 +146,11 @@ class Context:
         path_off = np.ascontiguousarray(path_off, dtype=np.uint64)
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
         ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+        # the ABI takes no length for `items`: the library copies path_off[n_paths] ids from it
+        if len(path_off) < 1:
+            raise ValueError("path_off must hold n_paths+1 offsets (at least one)")
+        if int(path_off[-1]) != len(items):
+            raise ValueError(f"path_off[-1] = {int(path_off[-1])} but items has {len(items)} entries")
         if w is not None and len(w) != n_items + 1:
             raise ValueError("weights must have n_items+1 entries")
         if ex is not None and len(ex) != n_items + 1:
@@ -239,6 +245,12 @@ class Context:
         out = np.zeros(shape, dtype=np.uint64)
         self._ck(self._L.pnx_ordered_growth_fetch(self._h, _ptr(out, C.c_uint64)))
         return out
+
+    def ordered_growth_enqueued(self) -> int:
+        """device pointer of the R*T*G u64 result of the growth call enqueued last (no wait)"""
+        d = C.c_void_p()
+        self._ck(self._L.pnx_ordered_growth_enqueued(self._h, C.byref(d)))
+        return d.value
 
     def ordered_growth_device(self) -> int:
         d = C.c_void_p()

@@ -15,7 +15,7 @@
 #include <cstdint>
 #include <cstring>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PNX_HD __host__ __device__
 #else
 #define PNX_HD

@@ -1227,6 +1227,8 @@ int launch_cover_pass(pnx_ctx *ctx) {
     const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
     const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
     Ticket *tk = ctx->cur;
+    tk->used_m = use_m;
+    tk->wrote_m = ctx->want_M;
     const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
     if ((rc = ensure(ctx, tk->d_block, tk->block_bytes))) return rc;

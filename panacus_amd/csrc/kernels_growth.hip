@@ -107,17 +107,26 @@ __device__ static inline unsigned long long weighted_popc(uint32_t bits, const u
     return s;
 }
 
-// out rows flagged as "delta" become running sums over the ranks
-__global__ void k_growth_prefix(unsigned long long *out, uint32_t G, uint32_t T, const uint32_t *__restrict__ is_delta) {
+// out rows flagged as "delta" become running sums over the ranks (wrapping u64 adds: the bp
+// deltas of the quorum pairs may be negative).  One wave per row: 64 ranks per step, an inclusive
+// scan over the lanes by shuffles, the carry in a scalar.
+__global__ __launch_bounds__(64) void k_growth_prefix(unsigned long long *out, uint32_t G, uint32_t T,
+                                                      const uint32_t *__restrict__ is_delta) {
     const uint32_t row = blockIdx.x;  // r * T + t
     if (!is_delta[row % T]) return;
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        unsigned long long *o = out + (uint64_t)row * G;
-        for (uint32_t j = 0; j < G; ++j) {
-            run += o[j];
-            o[j] = run;
+    const uint32_t lane = threadIdx.x;
+    unsigned long long *o = out + (uint64_t)row * G;
+    unsigned long long carry = 0;
+    for (uint32_t j0 = 0; j0 < G; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        unsigned long long v = j < G ? o[j] : 0ull;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long u = __shfl_up(v, d);
+            if (lane >= (uint32_t)d) v += u;
         }
+        v += carry;
+        if (j < G) o[j] = v;
+        carry = __shfl(v, 63);
     }
 }
 
@@ -507,7 +516,7 @@ int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch) {
     return PNX_OK;
 }
 
-int launch_growth(pnx_ctx *ctx, bool identity_perm) {
+int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity then*/) {
     const uint32_t G = ctx->n_groups, R = ctx->g_R, T = ctx->g_T, NB = ctx->n_blocks;
     int rc;
     const size_t out_n = (size_t)R * T * G;
@@ -516,13 +525,9 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
 
     // host copies of the thresholds: cov_thr[T] then is_q0[T]
     const std::vector<uint32_t> &meta = ctx->h_thr_meta;
-    if (meta.size() != 2 * (size_t)T) return ctx->fail(PNX_EINVAL, "internal: threshold table missing");
-    if (identity_perm) {
-        std::vector<uint32_t> id(G);
-        for (uint32_t j = 0; j < G; ++j) id[j] = j;
-        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_perms.p, id.data(), (size_t)G * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    const std::vector<uint32_t> &qt = ctx->h_qtab, &pm = ctx->h_perms;
+    if (meta.size() != 2 * (size_t)T || qt.size() != (size_t)T * G || pm.size() != (size_t)R * G)
+        return ctx->fail(PNX_EINVAL, "internal: growth tables missing");
 
     // distinct coverage thresholds >= 2 need a mask; c <= 1 is implied by presence
     std::vector<uint32_t> cvals;
@@ -534,21 +539,72 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
         if (k == cvals.size()) cvals.push_back(meta[t]);
         mask_of[t] = (int32_t)k;
     }
-    prof_begin(ctx, PNX_K_MASK);
-    // layout of d_cmask: [n_c masks][NB][64] u32, then scratch words for cvals / pair tables
-    const size_t mask_words = cvals.size() * (size_t)NB * BLOCK_WORDS;
-    // aux: [0..31] cvals, [32] max weight, [64..64+T) delta flags, then 8 words per q0 launch
     if (cvals.size() > 32) return ctx->fail(PNX_ELIMIT, "at most 32 distinct coverage thresholds >= 2 per call");
-    const size_t aux_words = 64 + (size_t)T + 8 * (((size_t)T + GROW_Q0_MAX - 1) / GROW_Q0_MAX);
-    if ((rc = ensure(ctx, ctx->d_cmask, (mask_words + aux_words) * sizeof(uint32_t)))) return rc;
-    uint32_t *d_aux = (uint32_t *)ctx->d_cmask.p + mask_words;
-    if (!cvals.empty()) {
-        PNX_HIP(ctx, hipMemcpyAsync(d_aux, cvals.data(), cvals.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_cov_masks, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_countable.p, ctx->n_items, NB, (const uint32_t *)d_aux,
-                           (uint32_t)cvals.size(), (uint32_t *)ctx->d_cmask.p);
+
+    // q > 0 pairs whose table rises by 0 or 1 per rank (always true for q in [0,1]) take the
+    // slack form; anything else falls back to the plane-by-plane comparison kernel
+    std::vector<uint32_t> q0, qslack, qgeneral, dtab((size_t)T * G, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+        if (meta[T + t]) { q0.push_back(t); continue; }
+        bool unit = true;
+        uint32_t prev = 0;
+        for (uint32_t j = 0; j < G && unit; ++j) {
+            const uint32_t v = qt[(size_t)t * G + j];
+            unit = v >= prev && v - prev <= 1;
+            dtab[(size_t)t * G + j] = v - prev;
+            prev = v;
+        }
+        (unit ? qslack : qgeneral).push_back(t);
     }
-    if (ctx->weighted && (rc = ensure_weight_planes(ctx, d_aux + 32))) return rc;
+    const uint64_t row_words = (uint64_t)NB * BLOCK_WORDS;
+    const uint64_t m_bytes = (uint64_t)G * row_words * 4;
+    const bool use_fused = m_bytes < (1ull << 32);
+    if (!use_fused) {
+        // presence matrix >= 4 GiB: the 32-bit row offsets do not reach; every pair takes the
+        // comparison kernel (64-bit addressing)
+        for (uint32_t t : q0) qgeneral.push_back(t);
+        for (uint32_t t : qslack) qgeneral.push_back(t);
+        q0.clear();
+        qslack.clear();
+    }
+    std::vector<uint32_t> is_delta(T, 0);
+    for (uint32_t t : q0) is_delta[t] = 1;
+    if (ctx->weighted)  // bp: the fused kernel keeps the slack-form pairs in delta form too
+        for (uint32_t t : qslack) is_delta[t] = 1;
+
+    // ONE upload of every small table of the call, staged in a vector that lives until the next
+    // growth call: dmask[T][G] (0 / ~0 per rank) | rowoff[R][G] (byte offset of the row of rank j) |
+    // is_delta[T] | cvals[32]
+    std::vector<uint32_t> &tabs_h = ctx->h_growth_tabs;
+    const size_t o_rowoff = (size_t)T * G, o_isd = o_rowoff + (size_t)R * G, o_cv = o_isd + T;
+    tabs_h.assign(o_cv + 32, 0u);
+    for (size_t i = 0; i < (size_t)T * G; ++i) tabs_h[i] = dtab[i] ? 0xFFFFFFFFu : 0u;
+    if (use_fused)
+        for (size_t i = 0; i < pm.size(); ++i) tabs_h[o_rowoff + i] = (uint32_t)((uint64_t)pm[i] * row_words * 4);
+    for (uint32_t t = 0; t < T; ++t) tabs_h[o_isd + t] = is_delta[t];
+    for (size_t k = 0; k < cvals.size(); ++k) tabs_h[o_cv + k] = cvals[k];
+    if ((rc = ensure(ctx, ctx->d_thr_meta, tabs_h.size() * sizeof(uint32_t) + 16))) return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_thr_meta.p, tabs_h.data(), tabs_h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t *d_dmask = (const uint32_t *)ctx->d_thr_meta.p;
+    const uint32_t *d_rowoff = d_dmask + o_rowoff;
+    const uint32_t *d_isd = d_dmask + o_isd;
+    const uint32_t *d_cvals = d_dmask + o_cv;
+    if (!qgeneral.empty()) {  // the comparison kernel reads the order and the quorum tables themselves
+        if ((rc = ensure(ctx, ctx->d_perms, pm.size() * sizeof(uint32_t)))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_perms.p, pm.data(), pm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_qtab.p, qt.data(), qt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+
+    prof_begin(ctx, PNX_K_MASK);
+    // layout of d_cmask: [n_c masks][NB][64] u32, then one scratch word (max weight)
+    const size_t mask_words = cvals.size() * (size_t)NB * BLOCK_WORDS;
+    if ((rc = ensure(ctx, ctx->d_cmask, (mask_words + 64) * sizeof(uint32_t)))) return rc;
+    uint32_t *d_aux = (uint32_t *)ctx->d_cmask.p + mask_words;
+    if (!cvals.empty())
+        hipLaunchKernelGGL(k_cov_masks, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_countable.p, ctx->n_items, NB, d_cvals,
+                           (uint32_t)cvals.size(), (uint32_t *)ctx->d_cmask.p);
+    if (ctx->weighted && (rc = ensure_weight_planes(ctx, d_aux))) return rc;
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
 
@@ -559,63 +615,14 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     const uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
     n_chunks = (NB + bpc - 1) / bpc;
-    const uint64_t row_words = (uint64_t)NB * BLOCK_WORDS;
     const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;  // comparison kernel
     const bool w16 = ctx->weighted && ctx->n_wplanes <= 16;  // every weight < 2^16
     const size_t wl_bytes = ctx->weighted ? (size_t)GROW_WAVES * 2048 * (w16 ? 2 : 4) : 0;                  // fused kernel
     const uint32_t *d_wpl = ctx->weighted ? (const uint32_t *)ctx->d_wplanes.p : nullptr;
     const uint32_t n_planes = ctx->weighted ? ctx->n_wplanes : 0;
 
-    // q > 0 pairs whose table rises by 0 or 1 per rank (always true for q in [0,1]) take the
-    // slack form; anything else falls back to the plane-by-plane comparison kernel
-    std::vector<uint32_t> q0, qslack, qgeneral, is_delta_general, dtab((size_t)T * G, 0);
-    {
-        std::vector<uint32_t> qt((size_t)T * G);
-        PNX_HIP(ctx, hipMemcpyAsync(qt.data(), ctx->d_qtab.p, qt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t t = 0; t < T; ++t) {
-            if (meta[T + t]) { q0.push_back(t); continue; }
-            bool unit = true;
-            uint32_t prev = 0;
-            for (uint32_t j = 0; j < G && unit; ++j) {
-                const uint32_t v = qt[(size_t)t * G + j];
-                unit = v >= prev && v - prev <= 1;
-                dtab[(size_t)t * G + j] = v - prev;
-                prev = v;
-            }
-            (unit ? qslack : qgeneral).push_back(t);
-        }
-    }
-    // device tables: dmask[T][G] (0 / ~0 per rank) then rowoff[R][G] (byte offset of the row of rank j)
-    const uint64_t m_bytes = (uint64_t)G * row_words * 4;
-    const bool use_fused = m_bytes < (1ull << 32);
-    std::vector<uint32_t> tabs_h((size_t)T * G + (size_t)R * G);
-    for (size_t i = 0; i < (size_t)T * G; ++i) tabs_h[i] = dtab[i] ? 0xFFFFFFFFu : 0u;
-    if (use_fused) {
-        std::vector<uint32_t> pm((size_t)R * G);
-        PNX_HIP(ctx, hipMemcpyAsync(pm.data(), ctx->d_perms.p, pm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < pm.size(); ++i) tabs_h[(size_t)T * G + i] = (uint32_t)((uint64_t)pm[i] * row_words * 4);
-    } else {
-        // presence matrix >= 4 GiB: the 32-bit row offsets do not reach; every pair takes the
-        // comparison kernel (64-bit addressing)
-        for (uint32_t t : q0) qgeneral.push_back(t);
-        for (uint32_t t : qslack) qgeneral.push_back(t);
-        q0.clear();
-        qslack.clear();
-    }
-    if ((rc = ensure(ctx, ctx->d_thr_meta, tabs_h.size() * sizeof(uint32_t) + 16))) return rc;
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_thr_meta.p, tabs_h.data(), tabs_h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint32_t *d_dmask = (const uint32_t *)ctx->d_thr_meta.p;
-    const uint32_t *d_rowoff = d_dmask + (size_t)T * G;
-
     uint32_t bits = 1;
     while (bits < 32 && (G >> bits) != 0) ++bits;
-    std::vector<uint32_t> is_delta(T, 0);
-    for (uint32_t t : q0) is_delta[t] = 1;
-    if (ctx->weighted)  // bp: the fused kernel keeps the slack-form pairs in delta form too
-        for (uint32_t t : qslack) is_delta[t] = 1;
     prof_begin(ctx, PNX_K_GROWTH);
     {   // fused launches: up to GROW_Q0_MAX q == 0 pairs + up to 2 slack pairs each
         size_t i0 = 0, iq = 0;
@@ -703,13 +710,9 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm) {
             else go(k_growth_quorum<16, false>);
         }
     }
-    {   // deltas -> running sums
-        uint32_t *d_isd = d_aux + 64;
-        PNX_HIP(ctx, hipMemcpyAsync(d_isd, is_delta.data(), (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hipLaunchKernelGGL(k_growth_prefix, dim3(R * T), dim3(64), 0, ctx->stream,
-                           (unsigned long long *)ctx->d_growth_out.p, G, T, (const uint32_t *)d_isd);
-    }
+    // deltas -> running sums (one wave per (order, pair) row)
+    hipLaunchKernelGGL(k_growth_prefix, dim3(R * T), dim3(64), 0, ctx->stream,
+                       (unsigned long long *)ctx->d_growth_out.p, G, T, d_isd);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;

@@ -153,7 +153,7 @@ static int settle_oldest(pnx_ctx *ctx) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         PNX_HIP(ctx, hipEventSynchronize(t->done));
         prof_resolve(ctx, false);
-        const bool used_m = ctx->want_M || ctx->last_general_paths > 0;
+        const bool used_m = t->used_m;  // as launched, not as the context stands now
         // [0] tile-monotonicity violations found by K1, [1] scatter-route paths in the order,
         // [2] non-monotone paths that are not classified yet, [4] internal run-index check
         const bool need_build = t->h_flags[0] != 0 || t->h_flags[2] != 0;
@@ -166,7 +166,7 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->tk_count -= 1;
             ctx->last_done = t;
             ctx->hist_valid = true;
-            ctx->M_valid = ctx->want_M && ctx->tk_count == 0;
+            ctx->M_valid = t->wrote_m && ctx->tk_count == 0;
             return PNX_OK;
         }
         // a younger pass (if any) ran with the same stale classification; it fails and is
@@ -498,6 +498,11 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
         }
     }
     int rc;
+    // a growth call that is still running owns the staging vectors and the result buffer
+    if (ctx->growth_pending) {
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->growth_pending = false;
+    }
     // the presence matrix must exist for the current order
     if ((rc = settle_all(ctx))) return rc;
     if (!(ctx->hist_valid && ctx->M_valid)) {
@@ -506,18 +511,18 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
         if ((rc = settle_all(ctx))) return rc;
     }
     const size_t RG = (size_t)n_perms * G, TG = (size_t)n_thr * G;
-    if ((rc = ensure(ctx, ctx->d_perms, (RG ? RG : 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_cov_thr, n_thr * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_qtab, (TG ? TG : 1) * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_growth_out, (RG ? RG : 1) * n_thr * sizeof(uint64_t)))) return rc;
-    if (perms && RG)
-        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_perms.p, perms, RG * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_cov_thr.p, cov_thr, n_thr * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (TG) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_qtab.p, quorum_tab, TG * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host arrays are caller-owned
+    // host copies: the launch code derives its device tables from these (nothing is read back)
+    if (perms) ctx->h_perms.assign(perms, perms + RG);
+    else {
+        ctx->h_perms.resize(G);
+        for (uint32_t j = 0; j < G; ++j) ctx->h_perms[j] = j;
+    }
+    ctx->h_qtab.assign(quorum_tab, quorum_tab + TG);
     ctx->g_R = n_perms;
     ctx->g_T = n_thr;
-    // thresholds are needed on the host too (mask selection, q == 0 detection)
     ctx->h_thr_meta.assign(cov_thr, cov_thr + n_thr);
     for (uint32_t t = 0; t < n_thr; ++t) {
         bool q0 = true;
@@ -526,6 +531,13 @@ int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_per
     }
     if ((rc = launch_growth(ctx, perms == nullptr))) return rc;
     ctx->growth_pending = true;
+    return PNX_OK;
+}
+
+int pnx_ordered_growth_enqueued(pnx_ctx *ctx, uint64_t **d_out) {
+    if (!ctx || !d_out) return PNX_EINVAL;
+    if (!ctx->g_R || !ctx->growth_pending) return ctx->fail(PNX_EINVAL, "no growth call is in flight");
+    *d_out = (uint64_t *)ctx->d_growth_out.p;
     return PNX_OK;
 }
 

@@ -50,6 +50,9 @@ struct Ticket {
     hipEvent_t done = nullptr;
     bool done_blocking = false;
     bool in_flight = false;
+    // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
+    // time the pass is settled): it merged the scatter rows of M / it wrote the presence matrix
+    bool used_m = false, wrote_m = false;
 };
 
 struct Profile {
@@ -141,6 +144,10 @@ struct pnx_ctx {
     pnx::DevBuf d_perms, d_cov_thr, d_qtab, d_cmask, d_wplanes, d_growth_out, d_thr_meta;
     uint32_t g_R = 0, g_T = 0;
     std::vector<uint32_t> h_thr_meta;  // cov_thr[T] then is_q0[T]
+    // host copies of the call's tables (the launch code needs them; nothing is read back from the
+    // device) and the staging vectors of its uploads -- they live until the next growth call, which
+    // first waits for this one, so no upload ever needs its own synchronisation
+    std::vector<uint32_t> h_perms, h_qtab, h_growth_tabs, h_growth_aux;
     uint32_t n_wplanes = 0;
     bool wplanes_valid = false;
     bool growth_pending = false;

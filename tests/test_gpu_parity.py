@@ -791,36 +791,53 @@ def test_two_contexts_share_one_resident_graph():
 
 
 def test_bench_contract_line_small(tmp_path):
-    """bench.py end to end on a small shape: one JSON line with the contract's fields; one and two
-    lanes (contexts sharing the resident graph) and the forced single-rank RCCL path agree on the
-    checks"""
+    """bench.py end to end on small shapes: one JSON line with the contract's fields plus the
+    permuted_growth / shape_10Mx1k / cpu_baseline blocks; one and two lanes (contexts sharing the
+    resident graph) and the forced single-rank RCCL path agree on the checks"""
     import json
     import os
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2"], {}), (["--lanes", "2"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
+    outs, pgs = [], []
+    small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--cpu-passes", "1",
+             "--pg-nodes", "150000", "--pg-paths", "40", "--pg-orders", "10", "--pg-reps", "2",
+             "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4"]
+    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {}),
+                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
         sock = socket.socket()
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
         sock.close()
         e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
-        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--nodes", "200000", "--paths", "64", "--steps", "12",
-                            "--warmup", "2", "--no-cpu-baseline"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e,
-                           timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=e, timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         lines = [l for l in r.stdout.decode().split("\n") if l.startswith("{")]
         assert len(lines) == 1
         d = json.loads(lines[0])
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                  "vs_baseline", "dtype", "data", "config", "roofline"):
+                  "vs_baseline", "dtype", "data", "config", "roofline", "permuted_growth"):
             assert k in d, k
         assert d["steps"] == 12 and d["n_gpus"] == 1 and d["roofline"]["launches"] == 12
         assert d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 200000
+        pg = d["permuted_growth"]
+        for k in ("seconds_per_call", "orders_per_s", "speedup_vs_1", "growth_kernel_ms_rank_max", "allreduce_ms",
+                  "presence_pack_ms", "scaling", "sharding", "n_gpus"):
+            assert k in pg, k
+        assert pg["scaling"] == "strong" and pg["orders"] == 10 and pg["checks"]["sharded_equals_single_gpu"]
+        assert pg["seconds_per_call"] > 0 and pg["growth_kernel_ms_rank_max"] > 0
+        if env:
+            assert pg["allreduce_ms"] > 0 and "rccl" in pg["collective_path"]
+        else:
+            cb, k1 = d["cpu_baseline"], d["shape_10Mx1k"]
+            assert cb["agrees_with_gpu"] is True and cb["kind"] == "port" and cb["cores"] == 3 and cb["value"] > 0
+            assert k1["checks"]["hist_sum"] == 150000 and k1["breakdown_ms"]["tile_cover"] > 0
         outs.append(d["checks"])
+        pgs.append(pg["checks"])
     assert outs[0] == outs[1] == outs[2]
+    assert pgs[0] == pgs[1] == pgs[2]
 
 
 def test_full_size_cfg3_properties():

@@ -455,6 +455,54 @@ def test_multi_gpu_tool_matches_cli(golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
+def test_multi_gpu_tool_two_ranks_non_monotone_paths(tmp_path):
+    """Two ranks (node-range shards, both on GPU 0, counters reduced over gloo) on a GFA whose paths are
+    NOT tile-monotone: the first coverage pass of every rank only classifies the paths and is re-run by
+    the library, so a host that reduced the counters of the first attempt would print a wrong table
+    (round-1 advisor finding).  The tool must settle the pass first: its table equals the single-GPU CLI."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "30000", "--paths", "10", "-o", src])
+    assert rc == 0, err
+    gfa = str(tmp_path / "bumpy.gfa")
+    with open(src) as f, open(gfa, "w") as g:
+        for line in f:
+            if line.startswith("P\t"):
+                cols = line.rstrip("\n").split("\t")
+                steps = cols[2].split(",")
+                for a in range(100, len(steps) - 60, 300):   # a 40-step window reversed every 300 steps
+                    steps[a:a + 40] = steps[a:a + 40][::-1]
+                cols[2] = ",".join(steps)
+                line = "\t".join(cols) + "\n"
+            g.write(line)
+    for cname in ("node", "bp"):
+        rc, ref, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5", gfa])
+        assert rc == 0, err
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        out_file = str(tmp_path / f"two_{cname}.tsv")
+        procs = []
+        for r in range(2):
+            e = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                     MASTER_PORT=str(port), PANACUS_DIST_BACKEND="gloo", PANACUS_TOOL_REPORT_RERUNS="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "histgrowth_multi_gpu.py"), "-c", cname,
+                                           "-l", "1,2", "-q", "0,0.5", "-o", out_file, gfa], env=e,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        errs = []
+        for pr in procs:
+            o, e2 = pr.communicate(timeout=600)
+            assert pr.returncode == 0, e2.decode()[-2000:]
+            errs.append(e2.decode())
+        assert "reruns=0" not in errs[0] and "reruns=" in errs[0]   # the scenario really happened on rank 0
+        assert open(out_file).read() == _body(ref).rstrip("\n") + "\n"
+
+
+@pytest.mark.gpu
 def test_cli_edge_counts_do_not_depend_on_link_order(tmp_path):
     """edge ids follow the L lines (graph.rs:282-295); the CLI renumbers them for the device when
     they do not follow the paths.  Sorted and shuffled link sections give the oracle's numbers."""

@@ -38,14 +38,20 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = torch = None
+    # PANACUS_DIST_BACKEND=gloo reduces the fetched host counters over gloo instead (tests: two ranks
+    # on one GPU, which RCCL refuses)
+    backend = os.environ.get("PANACUS_DIST_BACKEND", "nccl")
     if world > 1:  # torch is only the carrier of the collective
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from panacus_amd import capi, hostlib as hl
     from panacus_amd.distributed import plan_node_shards, shard_csr, shard_weights
@@ -67,25 +73,33 @@ def main(argv=None):
     ctx = capi.Context(local_rank)
     ctx.set_csr(it_r, off_r, n_r, weights=shard_weights(weights, lo, hi))
     ctx.set_order(pi, gi, G)
+    # A one-shot host for ARBITRARY graphs verifies the pass BEFORE it reduces: a real GFA may hold
+    # paths that are not tile-monotone; the first pass then only classifies them, the library builds
+    # the run index and runs the pass again inside pnx_hist_fetch -- counters reduced from the first
+    # attempt would be incomplete (bench.py pipelines instead, on paths known to be monotone, and
+    # fails loudly on a re-run).
     ctx.hist_async()
-    if world > 1:
-        # the collective goes behind the pass on the library's stream (see bench.py)
+    _, h = ctx.hist_fetch(want_countable=False)   # settled: verified, re-run if it had to be
+    if world > 1 and backend == "nccl":
+        # RCCL all-reduce of the verified pass's device counters, on the library's stream
         ext = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
 
         class _Dev:
             def __init__(self, ptr, n):
                 self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
-        t = torch.as_tensor(_Dev(ctx.hist_enqueued(), G + 1), device=f"cuda:{local_rank}")
+        d_hist, _ = ctx.hist_device()
+        t = torch.as_tensor(_Dev(d_hist, G + 1), device=f"cuda:{local_rank}")
         with torch.cuda.stream(ext):
             tot = t.clone()
             dist.all_reduce(tot)
             host = tot.cpu()
-        ctx.hist_fetch(want_countable=False)
+        ext.synchronize()
         h = host.numpy().view(np.uint64).copy()
         del t, tot, ext
-    else:
-        _, h = ctx.hist_fetch(want_countable=False)
+    elif world > 1:
+        from panacus_amd.distributed import allreduce_counters
+        h = allreduce_counters(h)
     # every shard counts its own sentinel-free items; items in no group of any shard are bin 0
     text = None
     if rank == 0:
@@ -107,10 +121,13 @@ def main(argv=None):
                 f.write(text)
         else:
             sys.stdout.write(text)
+    reruns = int(ctx.info().n_reruns)
     if world > 1:
         torch.cuda.synchronize()
         dist.destroy_process_group()
     ctx.close()
+    if os.environ.get("PANACUS_TOOL_REPORT_RERUNS") and rank == 0:
+        sys.stderr.write(f"reruns={reruns}\n")
     return text
 
 
