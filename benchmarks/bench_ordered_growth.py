@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pairs", default="1:0,2:0,1:0.5", help="coverage:quorum pairs")
     ap.add_argument("--bp", action="store_true", help="count bp (node lengths as weights) instead of nodes")
+    ap.add_argument("--warm-full", action="store_true", help="warm up with all orders (profiling: every growth launch is then the same)")
     args = ap.parse_args()
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -57,7 +58,7 @@ def main():
     t0 = time.perf_counter()
     ctx.hist(want_countable=False)           # builds the presence matrix (K0, K1 with WRITE_M, K2)
     t_pack = time.perf_counter() - t0
-    ctx.ordered_growth(cov, qt, my_perms[:1])  # warm-up (masks, first launch)
+    ctx.ordered_growth(cov, qt, my_perms if args.warm_full else my_perms[:1])  # warm-up (masks, first launch)
     ctx.profile_enable(True)
     ctx.profile_reset()
     if world > 1:

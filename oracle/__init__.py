@@ -354,6 +354,23 @@ def similarity(r, c, n_groups, node_lens=None):
     return inter, lens, table
 
 
+CLUSTER_METHODS = ["single", "complete", "average", "weighted", "ward", "centroid", "median"]
+
+
+def similarity_order(table, method="centroid"):
+    """Similarity::set_table after the Jaccard table (similarity.rs:166-182) -> (reordered table,
+    perm) with perm[k] = input index of the group in row / column k."""
+    t = np.ascontiguousarray(table, dtype=np.float32).copy()
+    n = t.shape[0]
+    perm = np.zeros(max(n, 1), dtype=np.uint64)
+    L = lib()
+    L.orc_similarity_order.restype = C.c_int
+    L.orc_similarity_order.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    if L.orc_similarity_order(_p(t, C.c_float), n, CLUSTER_METHODS.index(method), _p(perm, C.c_uint64)):
+        raise IndexError("no groups: calculate_distances underflows in the reference (similarity.rs:248)")
+    return t, perm[:n]
+
+
 def table_rows(r, c, n_groups, node_lens=None) -> np.ndarray:
     """Body of AbacusByGroup::to_tsv without `total` (abacus.rs:1093-1112): [n_items, G] u64,
     row i-1 = item i."""

@@ -2026,6 +2026,286 @@ int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint6
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Similarity::set_table after the Jaccard table (similarity.rs:166-182): Euclidean distances   */
+/* between the table's rows, hierarchical clustering, rows / columns / labels reordered.        */
+/*                                                                                              */
+/* The clustering is `kodama::linkage` (crate kodama 0.3.0, Cargo.toml:34 -- a third-party      */
+/* dependency that is NOT in the reference tree).  kodama is a port of Muellner's fastcluster   */
+/* (D. Muellner, "Modern hierarchical, agglomerative clustering algorithms", arXiv:1109.2378):  */
+/*   Method::Single                       -> minimum spanning tree (Prim from observation 0)    */
+/*   Complete / Average / Weighted / Ward -> nearest-neighbour chain                            */
+/*   Centroid / Median                    -> the "generic" algorithm = merge the globally       */
+/*                                           closest pair of active clusters at every step      */
+/* with the Lance-Williams updates of kodama's method.rs in f32, Ward / Centroid / Median on    */
+/* squared distances.  MST and NN-chain steps are then stably sorted by dissimilarity; clusters  */
+/* get SciPy labels (observation i = i, the cluster made by step k = n + k) and every step lists */
+/* its smaller label first.  Restated from the published algorithm; ties between EQUAL          */
+/* dissimilarities are broken towards the lower index here (kodama's generic algorithm breaks    */
+/* them by the layout of its binary heap, which is not reproduced): parity unpinned, the        */
+/* reference holds no similarity output to pin it to.                                           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t c1, c2;
+    float d;
+} orc_step;
+
+static inline size_t cond_idx(size_t n, size_t i, size_t j) { /* i < j */
+    return n * i - i * (i + 1) / 2 + (j - i - 1);
+}
+static inline float *cond_at(float *dis, size_t n, size_t a, size_t b) {
+    return a < b ? &dis[cond_idx(n, a, b)] : &dis[cond_idx(n, b, a)];
+}
+
+/* similarity.rs:238-254: f32 throughout; (v1 - v2).powf(2.0) == the correctly rounded square */
+static void sim_distances(const float *table, size_t n, float *condensed) {
+    size_t k = 0;
+    for (size_t row = 0; row + 1 < n; row++)
+        for (size_t col = row + 1; col < n; col++) {
+            float sum = 0.0f;
+            for (size_t x = 0; x < n; x++) {
+                const float d = table[row * n + x] - table[col * n + x];
+                sum += d * d;
+            }
+            condensed[k++] = sqrtf(sum);
+        }
+}
+
+/* kodama method.rs: a = d(x, removed cluster), *b = d(x, kept cluster) */
+static void lw_update(int method, float a, float *b, float merged, size_t sa, size_t sb, size_t sx) {
+    const float fa = (float)sa, fb = (float)sb, fx = (float)sx;
+    switch (method) {
+        case 0: if (a < *b) *b = a; break;                                 /* single */
+        case 1: if (a > *b) *b = a; break;                                 /* complete */
+        case 2: *b = (fa * a + fb * *b) / (fa + fb); break;                /* average */
+        case 3: *b = 0.5f * (a + *b); break;                               /* weighted */
+        case 4: {                                                          /* ward (squared) */
+            const float num = ((fx + fa) * a) + ((fx + fb) * *b) - (fx * merged);
+            *b = num / (fa + fb + fx);
+            break;
+        }
+        case 5: {                                                          /* centroid (squared) */
+            const float fab = fa + fb;
+            *b = (((fa * a) + (fb * *b)) / fab) - ((fa * fb * merged) / (fab * fab));
+            break;
+        }
+        default: *b = (0.5f * (a + *b)) - (merged * 0.25f); break;         /* median (squared) */
+    }
+}
+
+/* merge `a` into `b` (a is removed, b keeps the merged cluster) */
+static void lw_merge(int method, float *dis, size_t n, uint8_t *active, size_t *sizes, size_t a, size_t b, float merged) {
+    active[a] = 0;
+    for (size_t x = 0; x < n; x++) {
+        if (!active[x] || x == b) continue;
+        lw_update(method, *cond_at(dis, n, x, a), cond_at(dis, n, x, b), merged, sizes[a], sizes[b], sizes[x]);
+    }
+    sizes[b] += sizes[a];
+}
+
+static size_t link_mst(float *dis, size_t n, orc_step *steps) {
+    uint8_t *active = xmalloc(n);
+    float *mind = xmalloc(n * sizeof *mind);
+    for (size_t i = 0; i < n; i++) {
+        active[i] = 1;
+        mind[i] = INFINITY;
+    }
+    size_t cluster = 0, ns = 0;
+    active[0] = 0;
+    for (size_t it = 0; it + 1 < n; it++) {
+        size_t min_obs = n;
+        float min_dist = 0.0f;
+        for (size_t x = 0; x < n; x++) {
+            if (!active[x]) continue;
+            const float d = *cond_at(dis, n, x, cluster);
+            if (d < mind[x]) mind[x] = d;
+            if (min_obs == n || mind[x] < min_dist) {
+                min_obs = x;
+                min_dist = mind[x];
+            }
+        }
+        steps[ns++] = (orc_step){min_obs, cluster, min_dist};
+        active[min_obs] = 0;
+        cluster = min_obs;
+    }
+    free(active);
+    free(mind);
+    return ns;
+}
+
+static size_t link_nnchain(int method, float *dis, size_t n, orc_step *steps) {
+    uint8_t *active = xmalloc(n);
+    size_t *sizes = xmalloc(n * sizeof *sizes), *chain = xmalloc((n + 1) * sizeof *chain), clen = 0, ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        active[i] = 1;
+        sizes[i] = 1;
+    }
+    for (size_t it = 0; it + 1 < n; it++) {
+        size_t a, b;
+        float min;
+        if (clen < 4) {
+            a = 0;
+            while (!active[a]) a++;
+            clen = 0;
+            chain[clen++] = a;
+            b = a + 1;
+            while (!active[b]) b++;
+            min = dis[cond_idx(n, a, b)];
+            for (size_t i = b + 1; i < n; i++)
+                if (active[i] && dis[cond_idx(n, a, i)] < min) {
+                    min = dis[cond_idx(n, a, i)];
+                    b = i;
+                }
+        } else {
+            clen -= 2;
+            b = chain[--clen];
+            a = chain[clen - 1];
+            min = *cond_at(dis, n, a, b);
+        }
+        for (;;) {
+            chain[clen++] = b;
+            for (size_t x = 0; x < n; x++) {
+                if (!active[x] || x == b) continue;
+                const float d = *cond_at(dis, n, x, b);
+                if (d < min) {
+                    min = d;
+                    a = x;
+                }
+            }
+            b = a;
+            a = chain[clen - 1];
+            if (b == chain[clen - 2]) break;
+        }
+        steps[ns++] = (orc_step){a, b, min};
+        if (a > b) {
+            const size_t t = a;
+            a = b;
+            b = t;
+        }
+        lw_merge(method, dis, n, active, sizes, a, b, min);
+    }
+    free(active);
+    free(sizes);
+    free(chain);
+    return ns;
+}
+
+/* stable sort by dissimilarity + SciPy labels through a union-find (kodama: LinkageUnionFind::relabel) */
+static void link_relabel(orc_step *steps, size_t ns, size_t n) {
+    for (size_t i = 1; i < ns; i++) { /* insertion sort: stable */
+        const orc_step s = steps[i];
+        size_t j = i;
+        while (j > 0 && steps[j - 1].d > s.d) {
+            steps[j] = steps[j - 1];
+            j--;
+        }
+        steps[j] = s;
+    }
+    size_t *parent = xmalloc((2 * n) * sizeof *parent);
+    for (size_t i = 0; i < 2 * n; i++) parent[i] = i;
+    size_t next = n;
+    for (size_t i = 0; i < ns; i++) {
+        size_t r1 = steps[i].c1, r2 = steps[i].c2;
+        while (parent[r1] != r1) r1 = parent[r1];
+        while (parent[r2] != r2) r2 = parent[r2];
+        parent[r1] = parent[r2] = next++;
+        steps[i].c1 = r1 < r2 ? r1 : r2;
+        steps[i].c2 = r1 < r2 ? r2 : r1;
+    }
+    free(parent);
+}
+
+/* centroid / median: the closest active pair at every step, labels assigned as the merges happen */
+static size_t link_generic(int method, float *dis, size_t n, orc_step *steps) {
+    uint8_t *active = xmalloc(n);
+    size_t *sizes = xmalloc(n * sizeof *sizes), *label = xmalloc(n * sizeof *label), ns = 0;
+    for (size_t i = 0; i < n; i++) {
+        active[i] = 1;
+        sizes[i] = 1;
+        label[i] = i;
+    }
+    for (size_t it = 0; it + 1 < n; it++) {
+        size_t a = n, b = n;
+        float min = 0.0f;
+        for (size_t i = 0; i < n; i++) {
+            if (!active[i]) continue;
+            for (size_t j = i + 1; j < n; j++) {
+                if (!active[j]) continue;
+                const float d = dis[cond_idx(n, i, j)];
+                if (a == n || d < min) {
+                    min = d;
+                    a = i;
+                    b = j;
+                }
+            }
+        }
+        const size_t l1 = label[a], l2 = label[b];
+        steps[ns++] = (orc_step){l1 < l2 ? l1 : l2, l1 < l2 ? l2 : l1, min};
+        lw_merge(method, dis, n, active, sizes, a, b, min);
+        label[b] = n + it;
+    }
+    free(active);
+    free(sizes);
+    free(label);
+    return ns;
+}
+
+/* table: n x n f32 (the Jaccard table in group order); method: 0 single, 1 complete, 2 average,
+ * 3 weighted, 4 ward, 5 centroid (the reference's default, analysis_parameter.rs:287-291), 6 median.
+ * perm_out[k] = the group (index in the input order) that ends up in row / column k of the printed
+ * table; table is reordered in place like the reference does (rows, then every row). */
+int orc_similarity_order(float *table, uint64_t n_groups, int method, uint64_t *perm_out) {
+    const size_t n = (size_t)n_groups;
+    if (n == 0) return -1; /* `table.len() - 1` underflows in calculate_distances (similarity.rs:248) */
+    const size_t nd = n * (n - 1) / 2;
+    float *dis = xmalloc((nd ? nd : 1) * sizeof *dis);
+    sim_distances(table, n, dis);
+    if (method >= 4)
+        for (size_t k = 0; k < nd; k++) dis[k] = dis[k] * dis[k];
+    orc_step *steps = xmalloc((n ? n : 1) * sizeof *steps);
+    size_t ns;
+    if (method == 0) ns = link_mst(dis, n, steps);
+    else if (method <= 4) ns = link_nnchain(method, dis, n, steps);
+    else ns = link_generic(method, dis, n, steps);
+    if (method <= 4) link_relabel(steps, ns, n);
+    /* get_order_from_dendrogram (similarity.rs:205-217) */
+    size_t *leaf = xmalloc((n ? n : 1) * sizeof *leaf), nl = 0;
+    for (size_t i = 0; i < ns; i++) {
+        if (steps[i].c1 < n) leaf[nl++] = steps[i].c1;
+        if (steps[i].c2 < n) leaf[nl++] = steps[i].c2;
+    }
+    /* :172-174: enumerate, sort by the observation, keep the positions = the inverse permutation */
+    size_t *order = xmalloc((n ? n : 1) * sizeof *order);
+    for (size_t k = 0; k < nl; k++) order[leaf[k]] = k;
+    /* sort_by_indices (:194-203) applied to the rows, to every row, and to the labels (:175-179);
+     * an index list shorter than the table (n = 1: no steps at all) leaves it untouched */
+    size_t *who = xmalloc(n * sizeof *who), *ind = xmalloc(n * sizeof *ind);
+    for (size_t i = 0; i < n; i++) who[i] = i;
+    for (size_t i = 0; i < nl; i++) ind[i] = order[i];
+    for (size_t i = 0; i < nl; i++)
+        while (i != ind[i]) {
+            const size_t ni = ind[i], t = ind[i];
+            ind[i] = ind[ni];
+            ind[ni] = t;
+            const size_t w = who[i];
+            who[i] = who[ni];
+            who[ni] = w;
+        }
+    float *tmp = xmalloc(n * n * sizeof *tmp);
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < n; j++) tmp[i * n + j] = table[who[i] * n + who[j]];
+    memcpy(table, tmp, n * n * sizeof *tmp);
+    for (size_t i = 0; i < n; i++) perm_out[i] = who[i];
+    free(tmp);
+    free(who);
+    free(ind);
+    free(order);
+    free(leaf);
+    free(steps);
+    free(dis);
+    return 0;
+}
+
 /* AbacusByGroup::to_tsv, node/bp branch without `total` and without multiplicities
  * (abacus.rs:1093-1112) */
 void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,

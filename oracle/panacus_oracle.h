@@ -135,6 +135,12 @@ void orc_ordered_growth(const uint64_t *r, const uint64_t *c, uint64_t n_items,
    Returns -1 when a group has no item (the reference's `path_lens[&i]` panics), else 0. */
 int orc_similarity(const uint64_t *r, const uint64_t *c, uint64_t n_items, uint64_t n_groups,
                    const uint32_t *node_lens, uint64_t *inter, uint64_t *lens, float *table);
+/* Similarity::set_table after the Jaccard table (similarity.rs:166-217): f32 Euclidean distances
+   between the rows, kodama::linkage (crate kodama 0.3.0, absent from the reference tree: restated
+   from its published algorithm, see the .c file), get_order_from_dendrogram, sort_by_indices.
+   method: 0 single, 1 complete, 2 average, 3 weighted, 4 ward, 5 centroid (default), 6 median.
+   Reorders `table` (n x n) in place; perm_out[k] = input index of the group in row k. */
+int orc_similarity_order(float *table, uint64_t n_groups, int method, uint64_t *perm_out);
 /* one row of AbacusByGroup::to_tsv without `total` (abacus.rs:1093-1112): out[j] = bp (or 1)
    when group j holds item i, else 0 */
 void orc_table_row(const uint64_t *r, const uint64_t *c, uint64_t i, uint64_t n_groups,

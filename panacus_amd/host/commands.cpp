@@ -13,6 +13,7 @@
 #include "../../include/panacus_amd.h"
 #include "gfa_graph.hpp"
 #include "growth_closed_form.hpp"
+#include "linkage.hpp"
 #include "synth_gfa.hpp"
 #include "tables.hpp"
 #include "thread_pool.hpp"
@@ -22,6 +23,7 @@ namespace {
 
 struct Options {
     std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file, subset_file, exclude_file;
+    std::string method = "centroid";  // similarity: ClusterMethod::default() (analysis_parameter.rs:287-291)
     bool add_hist = false, by_sample = false, by_haplotype = false, total = false, cache = false;
     int threads = 0, device = 0;
     // synth
@@ -50,7 +52,8 @@ const char *USAGE =
     "                                   GFA's size, mtime and a content hash)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
     "      --device <N>                 GPU ordinal [0]\n"
-    "  similarity prints the Jaccard table in group order (the reference's dendrogram ordering is not applied)\n"
+    "  -m, --method <single|complete|average|weighted|ward|centroid|median>\n"
+    "                                   similarity: linkage that orders rows and columns of the table [centroid]\n"
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
     "                                        write a pansyn-v1 synthetic pangenome as GFA\n";
 
@@ -356,12 +359,15 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     return metadata_comments(cmdline) + write_ordered_table(headers, cols, order.groups);
 }
 
-// Similarity::set_table up to the Jaccard table (similarity.rs:119-165) + get_table_string
-// (:224-239).  The intersections come from the GPU; the f32 division happens here exactly as in
-// the reference.  Rows and columns stay in group order: the reference then reorders them by a
-// kodama dendrogram (:166-182), which is outside this path.
+// Similarity::set_table (similarity.rs:119-190) + get_table_string (:224-239).  The intersections
+// come from the GPU; the f32 division, the Euclidean row distances, the linkage (-m, default
+// centroid) and the reordering of rows, columns and labels happen here exactly as in the
+// reference (linkage.hpp).
 std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     CountType ct = count_types(o.count, false)[0];
+    ClusterMethod method;
+    if (!parse_cluster_method(o.method, method))
+        throw std::runtime_error("invalid value '" + o.method + "' for --method (single, complete, average, weighted, ward, centroid, median)");
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const size_t G = order.groups.size();
@@ -372,16 +378,19 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     for (size_t a = 0; a < G; ++a)
         if (inter[a * G + a] == 0)  // path_lens[&a] on a missing key panics in the reference (:163)
             throw std::runtime_error("group " + order.groups[a] + " covers no item: the reference panics here");
-    std::string res = metadata_comments(cmdline) + "group";
-    for (const auto &name : order.groups) res += "\t" + name;
-    res += "\n";
-    for (size_t i = 0; i < G; ++i) {
-        res += order.groups[i];
+    std::vector<float> table(G * G);
+    for (size_t i = 0; i < G; ++i)
         for (size_t j = 0; j < G; ++j) {
             const uint64_t x = inter[i * G + j];
-            const float v = (float)x / (float)(inter[i * G + i] + inter[j * G + j] - x);
-            res += "\t" + format_f32(v);
+            table[i * G + j] = (float)x / (float)(inter[i * G + i] + inter[j * G + j] - x);
         }
+    const std::vector<size_t> perm = similarity_order(table, G, method);
+    std::string res = metadata_comments(cmdline) + "group";
+    for (size_t k = 0; k < G; ++k) res += "\t" + order.groups[perm[k]];
+    res += "\n";
+    for (size_t i = 0; i < G; ++i) {
+        res += order.groups[perm[i]];
+        for (size_t j = 0; j < G; ++j) res += "\t" + format_f32(table[perm[i] * G + perm[j]]);
         res += "\n";
     }
     return res;
@@ -496,7 +505,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--cache") o.cache = true;
-            else if (a == "-m" || a == "--method") (void)value("--method");  // similarity: accepted, the table stays in group order
+            else if (a == "-m" || a == "--method") o.method = value("--method");
             else if (a == "--links") o.links = true;
             else if (a == "--sequences") o.sequences = true;
             else if (a == "-a" || a == "--hist" || a == "--total") o.add_hist = o.total = true;

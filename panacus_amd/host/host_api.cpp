@@ -12,6 +12,7 @@
 #include "gfa_graph.hpp"
 #include "tables.hpp"
 #include "growth_closed_form.hpp"
+#include "linkage.hpp"
 #include "thread_pool.hpp"
 
 static thread_local std::string g_host_err;
@@ -304,5 +305,37 @@ void pnh_set_quorum_offload(void *pnx_context, uint64_t min_n) { pnh::set_quorum
 int pnh_quorum_offload_usable(void) { return pnh::quorum_offload_usable() ? 1 : 0; }
 
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
+
+// ---- similarity: dendrogram order of the Jaccard table (linkage.hpp) ----
+// perm[k] = input index of the group in row / column k; method as pnh::ClusterMethod (0..6); 0 on success
+int pnh_similarity_order(const float *table, uint64_t n, int method, uint64_t *perm) {
+    try {
+        if (method < 0 || method > 6) throw std::runtime_error("unknown cluster method");
+        std::vector<float> t(table, table + n * n);
+        std::vector<size_t> p = pnh::similarity_order(t, (size_t)n, (pnh::ClusterMethod)method);
+        for (size_t k = 0; k < p.size(); ++k) perm[k] = p[k];
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return 1;
+    }
+}
+// kodama::linkage on a condensed matrix: n - 1 steps (c1, c2 as SciPy labels, dissimilarity); 0 on success
+int pnh_linkage(const float *condensed, uint64_t n, int method, uint64_t *c1, uint64_t *c2, float *dissimilarity) {
+    try {
+        if (method < 0 || method > 6) throw std::runtime_error("unknown cluster method");
+        std::vector<float> d(condensed, condensed + n * (n ? n - 1 : 0) / 2);
+        std::vector<pnh::LinkStep> st = pnh::linkage(d, (size_t)n, (pnh::ClusterMethod)method);
+        for (size_t k = 0; k < st.size(); ++k) {
+            c1[k] = st[k].c1;
+            c2[k] = st[k].c2;
+            dissimilarity[k] = st[k].dissimilarity;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return 1;
+    }
+}
 
 }  // extern "C"

@@ -328,6 +328,41 @@ def format_f32(x) -> str:
     return buf.value.decode()
 
 
+CLUSTER_METHODS = ["single", "complete", "average", "weighted", "ward", "centroid", "median"]
+
+
+def similarity_order(table, method="centroid") -> np.ndarray:
+    """perm[k] = input index of the group printed in row / column k of `similarity`
+    (similarity.rs:166-182: Euclidean row distances, kodama linkage, dendrogram order)."""
+    L = load()
+    t = np.ascontiguousarray(table, dtype=np.float32)
+    n = t.shape[0]
+    perm = np.zeros(n, dtype=np.uint64)
+    L.pnh_similarity_order.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    L.pnh_last_error.restype = C.c_char_p
+    if L.pnh_similarity_order(t.ctypes.data_as(C.POINTER(C.c_float)), n, CLUSTER_METHODS.index(method),
+                              perm.ctypes.data_as(C.POINTER(C.c_uint64))):
+        raise RuntimeError(L.pnh_last_error().decode())
+    return perm
+
+
+def linkage(condensed, n, method="centroid"):
+    """kodama::linkage restated on the host: (c1[n-1], c2[n-1], dissimilarity[n-1]) with SciPy labels"""
+    L = load()
+    d = np.ascontiguousarray(condensed, dtype=np.float32)
+    c1 = np.zeros(max(n - 1, 1), dtype=np.uint64)
+    c2 = np.zeros(max(n - 1, 1), dtype=np.uint64)
+    ds = np.zeros(max(n - 1, 1), dtype=np.float32)
+    u64p = C.POINTER(C.c_uint64)
+    L.pnh_linkage.argtypes = [C.POINTER(C.c_float), C.c_uint64, C.c_int, u64p, u64p, C.POINTER(C.c_float)]
+    L.pnh_last_error.restype = C.c_char_p
+    if L.pnh_linkage(d.ctypes.data_as(C.POINTER(C.c_float)), n, CLUSTER_METHODS.index(method), c1.ctypes.data_as(u64p),
+                     c2.ctypes.data_as(u64p), ds.ctypes.data_as(C.POINTER(C.c_float))):
+        raise RuntimeError(L.pnh_last_error().decode())
+    k = max(n - 1, 0)
+    return c1[:k], c2[:k], ds[:k]
+
+
 def pool_threads() -> int:
     """threads of the host worker pool (hardware threads cut down to the cgroup CPU quota, max 64)"""
     L = load()

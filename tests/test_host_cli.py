@@ -312,20 +312,53 @@ def test_cli_bed_intervals_synthetic(tmp_path):
 
 @pytest.mark.gpu
 def test_cli_similarity_chrM(golden_dir):
+    """`similarity` = the Jaccard table of the groups, rows and columns in the dendrogram order of
+    -m/--method (default centroid) like Similarity::set_table (similarity.rs:119-190): every method,
+    every count type, against the oracle's table and permutation"""
     gfa = os.path.join(golden_dir, "chrM_test.gfa")
+    g = orc.Graph(gfa, index_edges=True)
+    seen_orders = set()
     for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
-        rc, out, err = hl.run_cli(["similarity", "-S", "-c", cname, gfa])
-        assert rc == 0, err
-        g = orc.Graph(gfa, index_edges=True)
-        pi, gi, names = g.path_order(orc.GROUP_SAMPLE)
+        for grp, gmode in (("-S", orc.GROUP_SAMPLE), ("-H", orc.GROUP_HAPLOTYPE)):
+            pi, gi, names = g.path_order(gmode)
+            items, pre = g.item_table(ct)
+            r, c = orc.by_group(items, pre, pi, gi, g.n_items(ct))
+            _, _, tab = orc.similarity(r, c, len(names), g.node_lens if ct == orc.BP else None)
+            for method in [None] + orc.CLUSTER_METHODS:
+                rc, out, err = hl.run_cli(["similarity", grp, "-c", cname] + (["-m", method.upper()] if method else []) + [gfa])
+                assert rc == 0, err
+                tab2, perm = orc.similarity_order(tab, method or "centroid")
+                labels = [names[int(k)] for k in perm]
+                rows = [x.split("\t") for x in _body(out).split("\n") if x]
+                assert rows[0] == ["group"] + labels
+                for i, name in enumerate(labels):
+                    assert rows[1 + i] == [name] + [hl.format_f32(v) for v in tab2[i]]
+                assert out.endswith("\n\n")
+                seen_orders.add(tuple(labels))
+    assert len(seen_orders) > 1   # the clustering really reorders something on this graph
+    rc, out, err = hl.run_cli(["similarity", "-S", "-m", "upgma", gfa])
+    assert rc != 0 and "--method" in err
+
+
+@pytest.mark.gpu
+def test_cli_similarity_synthetic_groups(tmp_path):
+    """24 groups of a synthetic pangenome: the CLI's order equals the oracle's for every method"""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "6000", "--paths", "48", "-o", path])
+    assert rc == 0, err
+    g = orc.Graph(path, index_edges=False)
+    pi, gi, names = g.path_order(orc.GROUP_SAMPLE)
+    for cname, ct in (("node", orc.NODE), ("bp", orc.BP)):
         items, pre = g.item_table(ct)
         r, c = orc.by_group(items, pre, pi, gi, g.n_items(ct))
         _, _, tab = orc.similarity(r, c, len(names), g.node_lens if ct == orc.BP else None)
-        rows = [x.split("\t") for x in _body(out).split("\n") if x]
-        assert rows[0] == ["group"] + names
-        for i, name in enumerate(names):
-            assert rows[1 + i] == [name] + [hl.format_f32(v) for v in tab[i]]
-        assert out.endswith("\n\n")
+        for method in orc.CLUSTER_METHODS:
+            rc, out, err = hl.run_cli(["similarity", "-S", "-c", cname, "--method", method, path])
+            assert rc == 0, err
+            tab2, perm = orc.similarity_order(tab, method)
+            rows = [x.split("\t") for x in _body(out).split("\n") if x]
+            assert rows[0] == ["group"] + [names[int(k)] for k in perm]
+            assert [row[1:] for row in rows[1:]] == [[hl.format_f32(v) for v in tab2[i]] for i in range(len(names))]
 
 
 @pytest.mark.gpu
