@@ -236,6 +236,8 @@ enum {
     PNX_CFG_COVER_SKIP = 11,   /* plain histogram passes: skip the 64-entry windows of the order whose paths do not
                                   reach a wave's tile: 0 = when the order has >= 4096 entries [default], 1 = always,
                                   2 = never */
+    PNX_CFG_INDEX_PROBE = 12,  /* ids read by the second and later probes of an index search: 16 [default] = one 64-byte
+                                  sector, 32 = one 128-byte line (fewer rounds per wave, more requests: measured slower) */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */

@@ -82,60 +82,80 @@ __device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a,
 }
 
 // Boundary of one tile inside the bracket [lo, hi) of a path (absolute step indices): the number
-// of steps "before" key, + lo.  `num / den` is the fraction of the bracket's id range that lies
-// before the boundary.
-// First guess by position.  Every probe then reads one aligned 64-byte sector (16 ids).  If the
-// boundary lies inside it we are done; otherwise the id at the sector's edge tells how many ids
-// are still missing, and the bracket's own density (steps per id) turns that into the next
-// guess -- the error shrinks from ~sqrt(bracket) to ~sqrt(error) per probe, ~2.3 probes per
-// boundary instead of ~4 with galloping and ~22 with a plain binary search over a whole path.
+// of steps "before" key, + lo.  `frac` is the share of the bracket that lies before the boundary.
+// First guess by position.  Every probe reads one aligned window of W ids.  If the boundary lies
+// inside the window we are done; otherwise the smallest / largest id seen tells how many ids are
+// still missing, and the bracket's own density (steps per id) turns that into the next guess -- the
+// error shrinks from ~sqrt(bracket) to ~sqrt(error) per probe.
+// Measured, not guessed: the index is bound by the RATE of L1->L2 requests --
+// 44 G requests/s against the ~50 G/s that benchmarks/micro/random_sector_rate.hip reaches with wave-
+// local 64-byte probes -- not by round trips: 32-id windows for the later probes (fewer rounds per
+// wave, more lines per probe) and windows centred on the guess (fewer probes, two lines each) both
+// lost to plain aligned 16-id sectors.
 // Whatever the data, [lo, hi) only ever shrinks around the answer of a monotone path and the
 // search ends in a binary search of what is left, so the result is always inside the bracket.
+template <int W, bool CENTERED>
+__device__ static inline bool probe_window(const uint32_t *__restrict__ items, uint64_t &lo, uint64_t &hi, uint64_t &pos,
+                                           bool asc, uint32_t key32, float dens, uint64_t &found) {
+    if (pos >= hi) pos = hi - 1;
+    if (pos < lo) pos = lo;
+    // the positional first guess is off by a few sectors anyway: an aligned window; the later guesses
+    // are good to a few steps, and an aligned window would still lose the boundary whenever the guess
+    // sits near a window edge: those windows are centred on the guess (16-byte aligned start)
+    const uint64_t s0 = CENTERED ? (pos > W / 2 ? (pos - W / 2) & ~(uint64_t)3 : 0) : pos & ~(uint64_t)(W - 1);
+    const uint64_t a0 = s0 > lo ? s0 : lo, a1 = s0 + W < hi ? s0 + W : hi;  // [a0, a1) of the window
+    const uint32_t o0 = (uint32_t)(a0 - s0), o1 = (uint32_t)(a1 - s0);      // the same, relative to s0
+    const uint4 *win = reinterpret_cast<const uint4 *>(items + s0);
+    uint4 x[W / 4];
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+        // only the quads that overlap [a0, a1) are read (the window may stick out of the path)
+        x[q] = make_uint4(0, 0, 0, 0);
+        if ((uint32_t)(4 * q + 4) > o0 && (uint32_t)(4 * q) < o1) x[q] = win[q];
+    }
+    uint32_t cnt = 0, vmin = 0xFFFFFFFFu, vmax = 0;
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+        const uint32_t v[4] = {x[q].x, x[q].y, x[q].z, x[q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = (uint32_t)(4 * q + e);
+            const bool in = i >= o0 && i < o1;
+            const bool bef = asc ? v[e] < key32 : v[e] >= key32;
+            cnt += (in && bef) ? 1u : 0u;
+            vmin = in && v[e] < vmin ? v[e] : vmin;
+            vmax = in && v[e] > vmax ? v[e] : vmax;
+        }
+    }
+    if (cnt == 0) {  // everything here is at or past the boundary: it lies at or left of a0
+        hi = a0;
+        // asc: all ids >= key, the nearest is the smallest; desc: all ids < key, the nearest is the largest
+        const float gap = asc ? (float)vmin - (float)key32 : (float)key32 - (float)vmax;
+        const uint64_t back = (uint64_t)(gap > 0.f ? gap * dens : 0.f) + 1;
+        pos = a0 > lo + back ? a0 - back : lo;
+        return false;
+    }
+    if (cnt == o1 - o0) {  // everything here is before it
+        lo = a1;
+        const float gap = asc ? (float)key32 - (float)vmax : (float)vmin - (float)key32;
+        pos = a1 + (uint64_t)(gap > 0.f ? gap * dens : 0.f);
+        return false;
+    }
+    found = a0 + cnt;
+    return true;
+}
+
+template <int W1, int W2, bool CENTER2 = false>
 __device__ static inline uint64_t locate_boundary(const uint32_t *__restrict__ items, uint64_t lo, uint64_t hi,
                                                   bool asc, uint64_t key, double frac /* of the bracket before the boundary */,
                                                   float dens /* steps per id inside the bracket */, int max_probes) {
     if (lo >= hi) return lo;
     uint64_t pos = lo + (uint64_t)((double)(hi - lo) * frac);
-    for (int it = 0; it < max_probes && lo < hi; ++it) {
-        if (pos >= hi) pos = hi - 1;
-        if (pos < lo) pos = lo;
-        const uint64_t s0 = pos & ~(uint64_t)15;
-        const uint64_t a0 = s0 > lo ? s0 : lo, a1 = s0 + 16 < hi ? s0 + 16 : hi;  // [a0, a1) of the sector
-        const uint4 *sec = reinterpret_cast<const uint4 *>(items + s0);
-        uint32_t v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // only the quads that overlap [a0, a1) are read (the sector may stick out of the path)
-            if (s0 + 4 * q + 4 > a0 && s0 + 4 * q < a1) {
-                const uint4 x = sec[q];
-                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-            } else {
-                v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0;
-            }
-        }
-        uint32_t cnt = 0, v_first = 0, v_last = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const uint64_t i = s0 + q;
-            if (i >= a0 && i < a1) {
-                cnt += (asc ? before_key<true>(v[q], key) : before_key<false>(v[q], key)) ? 1u : 0u;
-                if (i == a0) v_first = v[q];
-                if (i == a1 - 1) v_last = v[q];
-            }
-        }
-        if (cnt == 0) {  // everything here is at or past the boundary: it lies at or left of a0
-            hi = a0;
-            const float gap = asc ? (float)v_first - (float)key : (float)key - (float)v_first;
-            const uint64_t back = (uint64_t)(gap > 0.f ? gap * dens : 0.f) + 1;
-            pos = a0 > lo + back ? a0 - back : lo;
-        } else if (cnt == (uint32_t)(a1 - a0)) {  // everything here is before it
-            lo = a1;
-            const float gap = asc ? (float)key - (float)v_last : (float)v_last - (float)key;
-            pos = a1 + (uint64_t)(gap > 0.f ? gap * dens : 0.f);
-        } else {
-            return a0 + cnt;
-        }
-    }
+    const uint32_t key32 = key > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)key;  // ids are < 2^32 - 1
+    uint64_t found = 0;
+    if (probe_window<W1, false>(items, lo, hi, pos, asc, key32, dens, found)) return found;
+    for (int it = 1; it < max_probes && lo < hi; ++it)
+        if (probe_window<W2, CENTER2>(items, lo, hi, pos, asc, key32, dens, found)) return found;
     if (lo < hi) lo = asc ? bsearch_before<true>(items, lo, hi, key) : bsearch_before<false>(items, lo, hi, key);
     return lo;
 }
@@ -203,6 +223,7 @@ __device__ static inline bool index_slot(const TileIdx &ix, uint32_t bpp, uint32
 
 // K0 pass A: every `coarse`-th boundary of a path's row (and the last one), located inside the
 // whole path.  Workgroups are numbered path-major: blockIdx = p * bpp + chunk.
+template <int W1, int W2>
 __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                     uint32_t bpp, uint32_t n_paths, uint64_t n_entries, uint32_t tile_items,
                                     uint32_t coarse, uint64_t *__restrict__ B, TileIdx ix,
@@ -240,7 +261,7 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const ui
         else {
             const double range = (double)(id_max - id_min + 1);
             const double below = (double)(key - id_min) / range;  // share of the ids that are < key
-            *out = locate_boundary(items, s, e, asc, key, asc ? below : 1.0 - below, (float)((double)(e - s) / range), 6);
+            *out = locate_boundary<W1, W2>(items, s, e, asc, key, asc ? below : 1.0 - below, (float)((double)(e - s) / range), 6);
         }
     }
 }
@@ -249,6 +270,7 @@ __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const ui
 // boundaries.  For a path that is not tile-monotone the result is still a monotone sequence
 // inside the bracket, so the (path, tile) segments always partition the path; K1's per-step
 // in-tile check then catches every misplaced step.
+template <int W1, int W2>
 __global__ void k_tile_index_fine(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                   uint32_t bpp, uint32_t n_paths, uint64_t n_entries, uint32_t tile_items,
                                   uint32_t coarse, uint64_t *__restrict__ B, TileIdx ix, uint8_t *path_class) {
@@ -276,7 +298,7 @@ __global__ void k_tile_index_fine(const uint32_t *__restrict__ items, const uint
         row[j] = asc ? lo : hi;
         return;
     }
-    row[j] = locate_boundary(items, lo, hi, asc, (uint64_t)(ix.tfirst[p] + j) * tile_items,
+    row[j] = locate_boundary<W1, W2>(items, lo, hi, asc, (uint64_t)(ix.tfirst[p] + j) * tile_items,
                              (double)(asc ? j - j0 : j1 - j) / (double)(j1 - j0),
                              (float)(hi - lo) / ((float)(j1 - j0) * (float)tile_items), 4);
 }
@@ -387,15 +409,20 @@ int launch_tile_index(pnx_ctx *ctx) {
         const uint64_t grid_f = by_entry ? entry_blocks : (uint64_t)ctx->n_paths * bpp_f;
         if (grid_f > 0x7FFFFFFFull || grid_c > 0x7FFFFFFFull)
             return ctx->fail(PNX_ELIMIT, "tile index: %u paths x %u tiles exceed the grid", ctx->n_paths, ctx->max_span);
-        hipLaunchKernelGGL(k_tile_index_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, ctx->n_paths,
-                           ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
-                           (uint8_t *)ctx->d_path_class.p);
-        if (coarse > 1)
-            hipLaunchKernelGGL(k_tile_index_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ctx->n_paths,
+        auto go = [&](auto k_coarse, auto k_fine) {
+            hipLaunchKernelGGL(k_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, ctx->n_paths,
                                ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
                                (uint8_t *)ctx->d_path_class.p);
+            if (coarse > 1)
+                hipLaunchKernelGGL(k_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->stream,
+                                   (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ctx->n_paths,
+                                   ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
+                                   (uint8_t *)ctx->d_path_class.p);
+        };
+        // ids per probe, first / later probes (PNX_CFG_INDEX_PROBE): 16 = 16/16 [default], 32 = 16/32
+        if (ctx->index_probe_ids == 32) go(k_tile_index_coarse<16, 32>, k_tile_index_fine<16, 32>);
+        else go(k_tile_index_coarse<16, 16>, k_tile_index_fine<16, 16>);
     }
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());

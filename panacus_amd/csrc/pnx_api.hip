@@ -754,6 +754,11 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             ctx->index_by_entry = (int)value;
             ctx->index_valid = false;
             return PNX_OK;
+        case PNX_CFG_INDEX_PROBE:
+            if (value != 16 && value != 32) return ctx->fail(PNX_EINVAL, "index probe must be 16 or 32 ids");
+            ctx->index_probe_ids = (int)value;
+            ctx->index_valid = false;
+            return PNX_OK;
         case PNX_CFG_BLOCKING_SYNC:
             ctx->blocking_sync = value != 0;
             return PNX_OK;

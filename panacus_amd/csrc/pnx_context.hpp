@@ -97,6 +97,7 @@ struct pnx_ctx {
     uint32_t tile_blocks = 1;  // blocks per coverage tile (WT)
     uint32_t index_coarse = 8; // every index_coarse-th tile boundary is searched exactly (K0 pass A)
     int cover_waves = 4;       // waves (= tiles) per workgroup of the pipelined coverage kernel
+    int index_probe_ids = 16;  // ids per later probe of the index search: 16 (one 64-byte sector) or 32
     int index_by_entry = 0;    // K0 thread numbering: 0 = automatic, 1 = one thread per index entry, 2 = path-major
     int cover_skip = 0;        // window skipping of the coverage kernel: 0 = automatic, 1 = whenever legal, 2 = never
     int cover_split = 0;       // waves per tile of the coverage kernel: 0 = automatic, 1, 2, 4, 8
