@@ -62,6 +62,12 @@ const char *pnx_version(void);
 int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
                 uint32_t n_items, const uint32_t *weights, const uint8_t *exclude);
 
+/* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
+ * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)
+ * without uploading the ItemTable again -- a host that evaluates several -e lists on one graph, or
+ * masks a generated graph.  exclude holds n_items+1 flags; an excluded item is counted in no group. */
+int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude);
+
 /* Synthetic graph generated directly in HBM by the pansyn-v1 generator: the
  * bench/test input of BASELINE.json configs 2-4.  Equivalent to pnx_set_csr on the arrays
  * the CPU generator produces for (seed, n_nodes, n_paths). with_weights != 0 also derives

@@ -21,7 +21,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn",
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn", "pnx_set_exclude",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
@@ -67,6 +67,7 @@ def load() -> C.CDLL:
     L.pnx_version.restype = C.c_char_p
     L.pnx_set_csr.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.pnx_set_exclude.argtypes = [vp, u8p]
     L.pnx_get_csr.argtypes = [vp, u64p, u32p, u64p, u32p]
     L.pnx_set_order.argtypes = [vp, u32p, u32p, C.c_uint32, C.c_uint32]
     L.pnx_hist.argtypes = [vp, u32p, u64p]
@@ -158,6 +159,13 @@ class Context:
         self._ck(self._L.pnx_set_csr(self._h, _ptr(items, C.c_uint32), _ptr(path_off, C.c_uint64),
                                      len(path_off) - 1, n_items, _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = n_items
+
+    def set_exclude(self, exclude=None):
+        """replace the exclusion flags (n_items+1 u8, None = no exclusion) of the resident graph"""
+        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+        if ex is not None and len(ex) != self.n_items + 1:
+            raise ValueError("exclude must have n_items+1 entries")
+        self._ck(self._L.pnx_set_exclude(self._h, _ptr(ex, C.c_uint8)))
 
     def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))

@@ -309,6 +309,22 @@ int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, u
     return PNX_OK;
 }
 
+int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_set_exclude before a graph is resident");
+    if (ctx->d_exclude.borrowed) return ctx->fail(PNX_EINVAL, "pnx_set_exclude: this context borrows its graph (pnx_share_csr)");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    invalidate_results(ctx);  // coverage, histogram and presence matrix all change
+    if (exclude) {
+        int rc = ensure(ctx, ctx->d_exclude, (size_t)ctx->n_items + 1);
+        if (rc) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, exclude, (size_t)ctx->n_items + 1, hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the flags are caller-owned
+    }
+    ctx->have_exclude = exclude != nullptr;
+    return PNX_OK;
+}
+
 int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
     if (!ctx) return PNX_EINVAL;
     if (n_nodes == 0 || n_paths == 0) return ctx->fail(PNX_EINVAL, "n_nodes and n_paths must be > 0");

@@ -468,6 +468,67 @@ def test_growth_arbitrary_quorum_table(ctx):
         assert out[0, t].tolist() == exp.tolist(), t
 
 
+def _prefix_set_growth(X, w, deg_ok, q):
+    """AbacusByGroup::calc_growth (abacus.rs:1001-1010) WITHOUT the walk over k: X[rank, item] is the
+    presence of the item in the group visited at that rank.  For every rank j: cnt = how many of the
+    ranks 0..j hold the item, last = the last of them; the item counts iff it has been seen and
+    cnt >= ceil((last + 1) * q).  Vectorised over items with cumulative sums / maxima."""
+    G, n = X.shape
+    cnt = np.cumsum(X, axis=0, dtype=np.int64)
+    ranks = np.arange(G, dtype=np.int64)[:, None]
+    last = np.maximum.accumulate(np.where(X > 0, ranks, -1), axis=0)
+    need = np.ceil((last + 1.0) * q).astype(np.int64)
+    ok = (last >= 0) & (cnt >= need) & deg_ok[None, :]
+    return (ok * w[None, :].astype(np.int64)).sum(axis=1)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ordered_growth_rule_from_the_presence_matrix(ctx, weighted):
+    """The reference holds no number for ordered growth (tests/ordered_histgrowth.rs:14 checks a header),
+    so the q > 0 rule -- the bound uses the rank of the LAST containing group, `c[k] + 1` -- is pinned
+    by checks that do not restate its loop:
+      (ii) for any (c, q) and any order, res[j] equals a brute force over PREFIX SETS taken from the
+           device's own presence export (K6): counts and last-seen ranks from cumulative sums;
+      (i)  q = 1: an item counts at rank j iff it is in EVERY group visited up to its last sighting, so
+           res[G-1] = weight of the items whose groups are exactly the ranks 0..deg-1 -- in particular
+           >= hist[G] * w (items of all groups) and, at rank 0, the size of the first group;
+      (iii) q = 0: the curve is the running union."""
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 30_000, 28
+    items, pre, lens = orc.pansyn(77, n, p)
+    w_all = lens if weighted else None
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w_all)
+    path_groups = (np.arange(p) * 3 // 4 // 2).astype(np.uint64)  # uneven groups
+    G = int(path_groups.max()) + 1
+    ctx.set_order(np.arange(p, dtype=np.uint64), path_groups, G)
+    cntv, h = ctx.hist()
+    bits = ctx.presence()
+    X0 = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, 1: n + 1].astype(np.int64)  # [group, item]
+    assert np.array_equal(X0.sum(axis=0), cntv[1:].astype(np.int64))
+    w = (lens[1:].astype(np.int64) if weighted else np.ones(n, dtype=np.int64))
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5), (3, 0.3), (1, 1.0), (2, 1.0), (1, 0.05), (G, 0.7)]
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), G) for c, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for _, q in pairs])
+    perms = np.concatenate([np.arange(G, dtype=np.uint32)[None, :], random_orders(5, 6, G)])
+    out = ctx.ordered_growth(cov, qt, perms)
+    deg = X0.sum(axis=0)
+    for r in range(len(perms)):
+        X = X0[perms[r].astype(np.int64)]          # rows in visiting order
+        for t, (c, q) in enumerate(pairs):
+            exp = _prefix_set_growth(X, w, deg >= max(1, c), q)
+            assert out[r, t].tolist() == exp.tolist(), (r, c, q)
+        # (i) q = 1 (pair index 4, c = 1)
+        first_absent = np.where((X == 0).any(axis=0), (X == 0).argmax(axis=0), G)
+        prefix_items = (deg >= 1) & (first_absent == deg)          # groups are exactly ranks 0..deg-1
+        assert int(out[r, 4, -1]) == int(w[prefix_items].sum())
+        assert int(out[r, 4, -1]) >= int(w[deg == G].sum())
+        assert int(out[r, 4, 0]) == int(w[X[0] > 0].sum())
+        # (iii) q = 0: running union
+        seen = np.maximum.accumulate(X, axis=0)
+        assert out[r, 0].tolist() == (seen * w[None, :]).sum(axis=1).tolist()
+
+
 def test_two_passes_in_flight(ctx):
     """pnx_hist_async may be called twice before the first result is fetched; results come back
     oldest first and are identical; a third enqueue is refused; a violation found in an
@@ -924,6 +985,54 @@ def test_more_than_2_to_32_steps():
         cnt2, h2 = c.hist()
         d = cnt[1:].astype(np.int64) - cnt2[1:].astype(np.int64)
         assert d.min() >= 0 and d.max() == 1 and int(h2.sum()) == n
+
+
+def test_full_size_cfg4_all_orders_and_masked_prefix_parity():
+    """configs[3] at full size, all 128 orders.  Direct oracle parity at 10 M x 512 would take the
+    serial loop hours, but items are independent: with exclude[i] = (i > 200 000) the full-size run
+    must equal the oracle on the 200 000-node prefix graph -- which IS pansyn(42, 200 000, 512), the
+    generator being counter-based per (path, node) -- bit for bit, for node and bp counts."""
+    from panacus_amd import capi
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p, m, R = 10_000_000, 512, 200_000, 128
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    cov = [coverage_abs(Threshold(ABSOLUTE, cc), p) for cc, _ in pairs]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), p) for _, q in pairs])
+    perms = random_orders(42, R, p)
+    items, pre, lens = orc.pansyn(42, m, p)
+    pg = np.arange(p, dtype=np.uint64)
+    check = [0, 1, 2, 17, 63, 64, 100, 127]
+    excl = np.zeros(n + 1, dtype=np.uint8)
+    excl[m + 1:] = 1
+    with capi.Context(0) as c:
+        for weighted in (False, True):
+            c.set_csr_pansyn(42, n, p, with_weights=weighted)
+            order = np.arange(p, dtype=np.uint32)
+            c.set_order(order, order, p)
+            w = lens if weighted else None
+            if not weighted:
+                # all 128 orders on the whole graph: the q = 0 curves end at the same totals, whatever the order
+                cnt, h = c.hist()
+                full = c.ordered_growth(cov, qt, perms)
+                assert full.shape == (R, 3, p)
+                assert np.all(full[:, 0, -1] == n - int(h[0])) and np.all(full[:, 1, -1] == n - int(h[0]) - int(h[1]))
+                assert np.all(np.diff(full[:, :2].astype(np.int64), axis=2) >= 0)
+                # mean over the orders of the first step = mean group size
+                sizes = np.array([int((cnt[1:] > 0).sum())])  # sanity anchor only
+                assert sizes[0] == n - int(h[0])
+            c.set_exclude(excl)
+            cnt, h = c.hist()
+            ocov = orc.coverage(items, pre, pg, pg, m)
+            assert np.array_equal(cnt[: m + 1], ocov) and not cnt[m + 1:].any()
+            oh = orc.hist(ocov, p, w)
+            assert np.array_equal(h[1:], oh[1:])  # bin 0 additionally holds the excluded items
+            out = c.ordered_growth(cov, qt, perms)
+            for r in check:
+                for t, (cv, q) in enumerate(pairs):
+                    exp = _oracle_growth(items, pre, m, p, pg, perms[r], cv, q, w)
+                    assert out[r, t].tolist() == [int(x) for x in exp], (weighted, r, cv, q)
+            c.set_exclude(None)
 
 
 def test_full_size_cfg4_properties():

@@ -311,6 +311,38 @@ def test_cli_bed_intervals_synthetic(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_cfg2_full_size_hist_bp(tmp_path):
+    """BASELINE configs[1] at its stated size: `hist -c bp` on a synthetic 1 M-node / 64-path GFA FILE
+    (0.3 GB of text with sequences), the whole CLI path (parse -> ItemTable -> GPU -> TSV), bit-exact
+    against the oracle on the same file; the .pcsr cache gives the same table."""
+    path = str(tmp_path / "cfg2.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "1000000", "--paths", "64", "--sequences", "-o", path])
+    assert rc == 0, err
+    g = orc.Graph(path, index_edges=False)
+    assert g.n_nodes == 1_000_000
+    pi, gi, names = g.path_order(orc.GROUP_PATHID)
+    assert len(names) == 64
+    items, pre = g.item_table(orc.BP)
+    cov = orc.coverage(items, pre, pi, gi, g.n_nodes)
+    exp_bp = orc.hist(cov, 64, g.node_lens)
+    exp_node = orc.hist(cov, 64)
+    rc, out, err = hl.run_cli(["hist", "-c", "bp", path])
+    assert rc == 0, err
+    lines = _body(out).split("\n")
+    assert lines[0] == "panacus\thist" and lines[1] == "count\tbp"
+    rows = [r.split("\t") for r in lines[4:] if r]
+    assert [int(r[0]) for r in rows] == list(range(65))
+    assert [int(r[1]) for r in rows] == exp_bp.tolist()
+    assert sum(int(r[1]) for r in rows) == int(g.node_lens.sum())
+    rc, out2, err = hl.run_cli(["hist", "-c", "bp", "--cache", path])
+    assert rc == 0, err
+    rc, out3, err = hl.run_cli(["hist", "-c", "node", "--cache", path])
+    assert rc == 0, err
+    assert _body(out2) == _body(out)
+    assert [int(r.split("\t")[1]) for r in _body(out3).split("\n")[4:] if r] == exp_node.tolist()
+
+
+@pytest.mark.gpu
 def test_cli_similarity_chrM(golden_dir):
     """`similarity` = the Jaccard table of the groups, rows and columns in the dendrogram order of
     -m/--method (default centroid) like Similarity::set_table (similarity.rs:119-190): every method,
