@@ -3,8 +3,10 @@
 coverage kernel (edge ids follow the first-seen order of the L lines, graph.rs:282-295, so the
 steps of a path are only as monotone as the link order of the file) and what a pass costs next to
 the node pass of the same graph.  L lines sorted by (from, to) as odgi / pggb write them, and the
-same links shuffled; "edge_renumbered" = ids ranked by (smaller node, larger node) as the CLI uploads
-them (GraphStorage::edge_relabel).  Prints one JSON line per case."""
+same links shuffled; "edge" = the reference's ids through plain pnx_set_csr; "edge_keyed" = the same ids
+plus one sort key per edge (its canonical ends) through pnx_set_csr_keyed, which renumbers them on the
+device -- what the CLI uploads; "edge_renumbered" = ids ranked on the host (GraphStorage::edge_relabel)
+before a plain upload, the round-1 route.  Prints one JSON line per case."""
 import json
 import os
 import subprocess
@@ -39,22 +41,34 @@ def main():
             pi, gi, names = g.path_order()
             res = {"workload": f"{n} nodes x {p} paths, {g.n_edges} edges, {name}"}
             with capi.Context(0) as ctx:
-                for cname, ct in (("node", hl.NODE), ("edge", hl.EDGE), ("edge_renumbered", hl.EDGE)):
+                for cname, ct in (("node", hl.NODE), ("edge", hl.EDGE), ("edge_keyed", hl.EDGE), ("edge_renumbered", hl.EDGE)):
                     items, pre = g.item_table(ct)
-                    if cname == "edge_renumbered":  # what the CLI uploads
+                    keys = None
+                    if cname == "edge_renumbered":
                         t0 = time.perf_counter()
                         new_id = g.edge_relabel()
                         res["renumber_host_ms"] = (time.perf_counter() - t0) * 1e3
                         items = new_id[items]
-                    ctx.set_csr(items, pre, g.n_items(ct))
+                    if cname == "edge_keyed":  # what the CLI uploads
+                        keys = g.edge_keys()
+                        ctx.set_csr(items, pre, g.n_items(ct))      # warm: allocations
+                        t0 = time.perf_counter()
+                        ctx.set_csr(items, pre, g.n_items(ct))
+                        t_plain = time.perf_counter() - t0
+                    t0 = time.perf_counter()
+                    ctx.set_csr(items, pre, g.n_items(ct), item_key=keys)
+                    if cname == "edge_keyed":
+                        res["relabel_on_device_ms"] = (time.perf_counter() - t0 - t_plain) * 1e3
                     ctx.set_order(pi, gi, len(names))
+                    t0 = time.perf_counter()
                     ctx.hist(want_countable=False)
+                    first_ms = (time.perf_counter() - t0) * 1e3
                     t0 = time.perf_counter()
                     for _ in range(5):
                         _, h = ctx.hist(want_countable=False)
                     dt = (time.perf_counter() - t0) / 5
                     info = ctx.info()
-                    res[cname] = {"steps": int(len(items)), "hist_ms": dt * 1e3, "general_paths": int(info.n_general_paths),
+                    res[cname] = {"steps": int(len(items)), "hist_ms": dt * 1e3, "first_hist_ms": first_ms, "general_paths": int(info.n_general_paths),
                                   "run_paths": int(info.n_run_paths), "scatter_paths": int(info.n_scatter_paths),
                                   "runs": int(info.n_runs), "hist_sum": int(h.sum())}
             print(json.dumps(res), flush=True)

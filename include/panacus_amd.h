@@ -62,6 +62,20 @@ const char *pnx_version(void);
 int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
                 uint32_t n_items, const uint32_t *weights, const uint8_t *exclude);
 
+/* The same upload with one sort key per item (item_key[0] ignored, n_items+1 entries): a hint that the
+ * steps of a path rise or fall with the KEY of their items even where they do not with the ids.  The
+ * reference numbers edges in the order of the L lines (graph.rs:282-295); with a shuffled link section
+ * the edge steps of a path are then random and take the slow atomic route here.  The key of an edge
+ * is its canonical pair of ends, (smaller node id << 32) | larger node id, which the reference's host
+ * holds in edge2id (graph.rs:276-306).  The library renumbers the items internally by ascending key
+ * (stable; on the device: one radix sort of n_items pairs and one pass over the resident steps);
+ * every per-item result -- countable, pnx_presence, pnx_group_visit_counts, pnx_get_csr -- is still
+ * reported in the CALLER's ids, and no other result depends on item numbering.  Keys that already
+ * rise with the ids cost one check.  item_key == NULL is pnx_set_csr. */
+int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                      uint32_t n_items, const uint32_t *weights, const uint8_t *exclude,
+                      const uint64_t *item_key);
+
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
  * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)
  * without uploading the ItemTable again -- a host that evaluates several -e lists on one graph, or

@@ -21,7 +21,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_pansyn", "pnx_set_exclude",
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_exclude",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     L.pnx_last_error.restype = C.c_char_p
     L.pnx_version.restype = C.c_char_p
     L.pnx_set_csr.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p]
+    L.pnx_set_csr_keyed.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u64p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
     L.pnx_get_csr.argtypes = [vp, u64p, u32p, u64p, u32p]
@@ -142,7 +143,9 @@ class Context:
             raise PnxError(rc, self._L.pnx_last_error(self._h).decode())
 
     # ---- graph ----
-    def set_csr(self, items, path_off, n_items, weights=None, exclude=None):
+    def set_csr(self, items, path_off, n_items, weights=None, exclude=None, item_key=None):
+        """item_key (n_items+1 u64, optional): sort keys the paths follow (edges: canonical ends); the
+        library then renumbers the items internally, results stay in the caller's ids"""
         items = np.ascontiguousarray(items, dtype=np.uint32)
         path_off = np.ascontiguousarray(path_off, dtype=np.uint64)
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
@@ -156,8 +159,15 @@ class Context:
             raise ValueError("weights must have n_items+1 entries")
         if ex is not None and len(ex) != n_items + 1:
             raise ValueError("exclude must have n_items+1 entries")
-        self._ck(self._L.pnx_set_csr(self._h, _ptr(items, C.c_uint32), _ptr(path_off, C.c_uint64),
-                                     len(path_off) - 1, n_items, _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
+        if item_key is not None:
+            key = np.ascontiguousarray(item_key, dtype=np.uint64)
+            if len(key) != n_items + 1:
+                raise ValueError("item_key must have n_items+1 entries")
+            self._ck(self._L.pnx_set_csr_keyed(self._h, _ptr(items, C.c_uint32), _ptr(path_off, C.c_uint64), len(path_off) - 1,
+                                               n_items, _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8), _ptr(key, C.c_uint64)))
+        else:
+            self._ck(self._L.pnx_set_csr(self._h, _ptr(items, C.c_uint32), _ptr(path_off, C.c_uint64),
+                                         len(path_off) - 1, n_items, _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = n_items
 
     def set_exclude(self, exclude=None):

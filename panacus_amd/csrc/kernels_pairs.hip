@@ -270,8 +270,9 @@ int launch_pair_intersections(pnx_ctx *ctx) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_visit_counts(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                                       uint32_t n_paths, const uint32_t *__restrict__ path_group,
-                                                      const uint8_t *__restrict__ exclude, uint32_t lo, uint32_t hi,
-                                                      uint32_t *__restrict__ out) {
+                                                      const uint8_t *__restrict__ exclude,
+                                                      const uint32_t *__restrict__ old_of_new /* internal -> caller id, or nullptr */,
+                                                      uint32_t lo, uint32_t hi, uint32_t *__restrict__ out) {
     const uint64_t S = path_off[n_paths];
     const uint64_t base = (uint64_t)blockIdx.x * 1024;
     __shared__ uint32_t p0;
@@ -292,10 +293,11 @@ __global__ __launch_bounds__(256) void k_visit_counts(const uint32_t *__restrict
         while (p + 1 < n_paths && path_off[p + 1] <= s) ++p;  // empty paths are stepped over
         const uint32_t g = path_group[p];
         if (g == 0xFFFFFFFFu) continue;  // the path is not in the visiting order
-        const uint32_t id = items[s];
-        if (id < lo || id >= hi) continue;
+        const uint32_t id = items[s];  // internal numbering, like the exclusion flags
         if (exclude && exclude[id]) continue;
-        atomicAdd(&out[(uint64_t)g * width + (id - lo)], 1u);
+        const uint32_t cid = old_of_new ? old_of_new[id] : id;  // the slice [lo, hi) is in the caller's ids
+        if (cid < lo || cid >= hi) continue;
+        atomicAdd(&out[(uint64_t)g * width + (cid - lo)], 1u);
     }
 }
 
@@ -310,7 +312,8 @@ int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_g
     if (blocks)
         hipLaunchKernelGGL(k_visit_counts, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_items.p,
                            (const uint64_t *)ctx->d_path_off.p, ctx->n_paths, (const uint32_t *)d_path_group.p,
-                           ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, lo, hi,
+                           ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
+                           ctx->relabeled ? (const uint32_t *)ctx->d_old_of_new.p : (const uint32_t *)nullptr, lo, hi,
                            (uint32_t *)out.p);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;

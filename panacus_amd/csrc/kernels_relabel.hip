@@ -1,0 +1,185 @@
+// kernels_relabel.hip -- internal renumbering of the items by a caller-supplied sort key.
+//
+// The coverage kernels want the steps of a path to rise (or fall) with the item ids: a path is then
+// one contiguous segment per 2048-id tile.  Node ids do that by construction (S lines are written
+// along the graph).  EDGE ids do not: the reference numbers edges in the order of the L lines
+// (src/graph_broker/graph.rs:282-295), so the edge steps of a path are only as ordered as the link
+// section of the file -- with shuffled L lines every path lands on the atomic scatter route (15 x
+// slower).  No result of the hot path depends on item numbering, so the library may renumber the
+// items internally when the caller hands it one u64 key per item whose order the paths follow (for
+// an edge: its canonical ends (smaller node id << 32 | larger node id), which the reference's host
+// holds anyway in edge2id, graph.rs:276-306).  Everything here runs on the device: a stable radix
+// sort of the (key, id) pairs, the inverse map, one pass that rewrites the resident steps, the
+// permutation of the weights and exclusion flags -- and the maps that bring per-item results
+// (coverage vector, presence rows, visit counts, the CSR read-back) back to the CALLER's ids.
+#include <cstring>  // rocprim's texture iterator calls memset
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "pnx_context.hpp"
+
+namespace pnx {
+
+__global__ void k_iota_u32(uint32_t *out, uint32_t n, uint32_t first) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = first + i;
+}
+
+// keys[1..n] non-decreasing?  (then the caller's ids already are the rank: nothing to do)
+__global__ void k_keys_sorted(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i < n && keys[i] > keys[i + 1]) *flag = 1u;
+}
+
+__global__ void k_invert_map(const uint32_t *__restrict__ old_of_new, uint32_t n, uint32_t *__restrict__ new_of_old) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;  // r = 0 is the reserved element
+    if (r <= n) new_of_old[old_of_new[r]] = r;
+}
+
+__global__ void k_map_steps(uint32_t *__restrict__ items, uint64_t n_steps, const uint32_t *__restrict__ map) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, n_quads = n_steps / 4;
+    uint4 *v = reinterpret_cast<uint4 *>(items);
+    for (; q < n_quads; q += stride) {
+        uint4 x = v[q];
+        x.x = map[x.x];
+        x.y = map[x.y];
+        x.z = map[x.z];
+        x.w = map[x.w];
+        v[q] = x;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_steps & 3)) {
+        const uint64_t j = n_quads * 4 + threadIdx.x;
+        items[j] = map[items[j]];
+    }
+}
+
+template <typename T>
+__global__ void k_gather(const T *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n_plus_1, T *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_plus_1) dst[i] = src[idx[i]];
+}
+
+// plain presence rows (bit i of row g = item i) from internal to caller ids: one thread per output word
+__global__ void k_presence_permute(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+                                   uint64_t row_words, uint32_t n_groups, uint32_t n_items,
+                                   const uint32_t *__restrict__ new_of_old) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= row_words * n_groups) return;
+    const uint64_t g = t / row_words, w = t % row_words;
+    const unsigned long long *row = in + g * row_words;
+    unsigned long long bits = 0;
+    for (uint32_t b = 0; b < 64; ++b) {
+        const uint64_t old = w * 64 + b;
+        if (old == 0 || old > n_items) continue;
+        const uint32_t nw = new_of_old[old];
+        bits |= ((row[nw >> 6] >> (nw & 63u)) & 1ull) << b;
+    }
+    out[t] = bits;
+}
+
+static unsigned grid_for(uint64_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// Called by pnx_set_csr_keyed after the plain upload (items, weights, exclude resident in caller ids).
+int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys) {
+    const uint32_t n = ctx->n_items;
+    ctx->relabeled = false;
+    if (n < 2 || ctx->n_steps == 0) return PNX_OK;
+    int rc;
+    DevBuf d_keys, d_keys2, d_ids, d_tmp;
+    auto cleanup = [&]() {
+        for (DevBuf *b : {&d_keys, &d_keys2, &d_ids, &d_tmp}) release(*b);
+    };
+    if ((rc = ensure(ctx, d_keys, ((size_t)n + 2) * 8)) || (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_keys.p, h_keys, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream);
+    uint32_t unsorted = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_keys_sorted, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const uint64_t *)d_keys.p, n,
+                           (uint32_t *)ctx->d_flags.p);
+        e = hipMemcpyAsync(&unsorted, ctx->d_flags.p, sizeof unsorted, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // also: h_keys is caller-owned
+    if (e != hipSuccess) {
+        cleanup();
+        return ctx->fail(PNX_EHIP, "item keys: %s", hipGetErrorString(e));
+    }
+    if (!unsorted) {
+        cleanup();
+        return PNX_OK;
+    }
+    if ((rc = ensure(ctx, d_keys2, ((size_t)n + 2) * 8)) || (rc = ensure(ctx, d_ids, ((size_t)n + 2) * 4)) ||
+        (rc = ensure(ctx, ctx->d_old_of_new, ((size_t)n + 2) * 4)) || (rc = ensure(ctx, ctx->d_new_of_old, ((size_t)n + 2) * 4))) {
+        cleanup();
+        return rc;
+    }
+    // ids 1..n sorted by key (stable LSD radix sort: equal keys keep the caller's order); slot 0 stays 0
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (uint32_t *)d_ids.p + 1, n, 1u);
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_old_of_new.p, 0, sizeof(uint32_t), ctx->stream));
+    size_t tmp_bytes = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)d_keys.p + 1, (uint64_t *)d_keys2.p + 1, (uint32_t *)d_ids.p + 1,
+                                  (uint32_t *)ctx->d_old_of_new.p + 1, (size_t)n, 0, 64, ctx->stream);
+    if (e == hipSuccess && (rc = ensure(ctx, d_tmp, tmp_bytes)) == PNX_OK)
+        e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, (uint64_t *)d_keys.p + 1, (uint64_t *)d_keys2.p + 1,
+                                      (uint32_t *)d_ids.p + 1, (uint32_t *)ctx->d_old_of_new.p + 1, (size_t)n, 0, 64, ctx->stream);
+    if (e != hipSuccess || rc) {
+        cleanup();
+        return rc ? rc : ctx->fail(PNX_EHIP, "item key sort failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_invert_map, dim3(grid_for((uint64_t)n + 1)), dim3(256), 0, ctx->stream,
+                       (const uint32_t *)ctx->d_old_of_new.p, n, (uint32_t *)ctx->d_new_of_old.p);
+    // the resident steps, weights and flags move to the internal numbering
+    hipLaunchKernelGGL(k_map_steps, dim3(4096), dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_items.p, ctx->n_steps,
+                       (const uint32_t *)ctx->d_new_of_old.p);
+    if (ctx->have_weights) {
+        // d_keys2 is free again: stage the permuted weights there
+        hipLaunchKernelGGL(k_gather<uint32_t>, dim3(grid_for((uint64_t)n + 1)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_weights.p, (const uint32_t *)ctx->d_old_of_new.p, n + 1, (uint32_t *)d_keys2.p);
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_weights.p, d_keys2.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (ctx->have_exclude) {
+        hipLaunchKernelGGL(k_gather<uint8_t>, dim3(grid_for((uint64_t)n + 1)), dim3(256), 0, ctx->stream,
+                           (const uint8_t *)ctx->d_exclude.p, (const uint32_t *)ctx->d_old_of_new.p, n + 1, (uint8_t *)d_keys.p);
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, d_keys.p, (size_t)n + 1, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "item relabel failed: %s", hipGetErrorString(e));
+    ctx->relabeled = true;
+    return PNX_OK;
+}
+
+// per-item u32 / u8 arrays between the two numberings (enqueued on the stream)
+int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_caller) {
+    hipLaunchKernelGGL(k_gather<uint32_t>, dim3(grid_for((uint64_t)ctx->n_items + 1)), dim3(256), 0, ctx->stream, d_internal,
+                       (const uint32_t *)ctx->d_new_of_old.p, ctx->n_items + 1, d_caller);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal) {
+    hipLaunchKernelGGL(k_gather<uint8_t>, dim3(grid_for((uint64_t)ctx->n_items + 1)), dim3(256), 0, ctx->stream, d_caller,
+                       (const uint32_t *)ctx->d_old_of_new.p, ctx->n_items + 1, d_internal);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps) {
+    hipLaunchKernelGGL(k_map_steps, dim3(4096), dim3(256), 0, ctx->stream, d_items_copy, n_steps, (const uint32_t *)ctx->d_old_of_new.p);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out) {
+    const uint64_t row_words = (uint64_t)ctx->n_blocks * 32, words = row_words * ctx->n_groups;
+    int rc = ensure(ctx, out, (words ? words : 1) * sizeof(uint64_t));
+    if (rc || !words) return rc;
+    hipLaunchKernelGGL(k_presence_permute, dim3(grid_for(words)), dim3(256), 0, ctx->stream, (const unsigned long long *)in.p,
+                       (unsigned long long *)out.p, row_words, ctx->n_groups, ctx->n_items, (const uint32_t *)ctx->d_new_of_old.p);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+}  // namespace pnx

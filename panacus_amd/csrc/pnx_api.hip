@@ -245,7 +245,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
@@ -259,8 +259,8 @@ void pnx_free(pnx_ctx *ctx) {
     delete ctx;
 }
 
-int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
-                uint32_t n_items, const uint32_t *weights, const uint8_t *exclude) {
+static int set_csr_impl(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                        uint32_t n_items, const uint32_t *weights, const uint8_t *exclude, const uint64_t *item_key) {
     if (!ctx) return PNX_EINVAL;
     if (!path_off) return ctx->fail(PNX_EINVAL, "path_off is NULL");
     if (n_items >= 0xFFFFFFFEu || n_paths >= 0xFFFFFFFEu)
@@ -305,8 +305,20 @@ int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, u
     PNX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_flags.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (bad) return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+    ctx->relabeled = false;
+    if (item_key && (rc = relabel_by_keys(ctx, item_key))) return rc;
     ctx->have_csr = true;
     return PNX_OK;
+}
+
+int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                uint32_t n_items, const uint32_t *weights, const uint8_t *exclude) {
+    return set_csr_impl(ctx, items, path_off, n_paths, n_items, weights, exclude, nullptr);
+}
+
+int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                      uint32_t n_items, const uint32_t *weights, const uint8_t *exclude, const uint64_t *item_key) {
+    return set_csr_impl(ctx, items, path_off, n_paths, n_items, weights, exclude, item_key);
 }
 
 int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude) {
@@ -318,8 +330,19 @@ int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude) {
     if (exclude) {
         int rc = ensure(ctx, ctx->d_exclude, (size_t)ctx->n_items + 1);
         if (rc) return rc;
-        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, exclude, (size_t)ctx->n_items + 1, hipMemcpyHostToDevice, ctx->stream));
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the flags are caller-owned
+        if (ctx->relabeled) {  // the resident flags live in the internal numbering
+            DevBuf tmp;
+            if ((rc = ensure(ctx, tmp, (size_t)ctx->n_items + 1))) return rc;
+            hipError_t e = hipMemcpyAsync(tmp.p, exclude, (size_t)ctx->n_items + 1, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) rc = to_internal_ids_u8(ctx, (const uint8_t *)tmp.p, (uint8_t *)ctx->d_exclude.p);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            release(tmp);
+            if (e != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_set_exclude: %s", hipGetErrorString(e));
+            if (rc) return rc;
+        } else {
+            PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, exclude, (size_t)ctx->n_items + 1, hipMemcpyHostToDevice, ctx->stream));
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the flags are caller-owned
+        }
     }
     ctx->have_exclude = exclude != nullptr;
     return PNX_OK;
@@ -336,6 +359,7 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
     int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights);
     if (rc) return rc;
     ctx->have_exclude = false;
+    ctx->relabeled = false;
     set_geometry(ctx);
     ctx->have_csr = true;
     return PNX_OK;
@@ -362,6 +386,9 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_path_off, src->d_path_off);
     borrow(dst->d_weights, src->d_weights);
     borrow(dst->d_exclude, src->d_exclude);
+    borrow(dst->d_new_of_old, src->d_new_of_old);
+    borrow(dst->d_old_of_new, src->d_old_of_new);
+    dst->relabeled = src->relabeled;
     dst->h_path_off = src->h_path_off;
     dst->weighted = src->weighted;
     dst->have_weights = src->have_weights;
@@ -379,15 +406,35 @@ int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path
     if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "no graph is resident");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     if (n_steps) *n_steps = ctx->n_steps;
-    if (items && ctx->n_steps)
-        PNX_HIP(ctx, hipMemcpyAsync(items, ctx->d_items.p, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (path_off) std::copy(ctx->h_path_off.begin(), ctx->h_path_off.end(), path_off);
-    if (weights) {
-        if (!ctx->weighted) return ctx->fail(PNX_EINVAL, "no weights are resident");
-        PNX_HIP(ctx, hipMemcpyAsync(weights, ctx->d_weights.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+    DevBuf tmp_items, tmp_w;  // a relabelled graph is handed back in the caller's ids
+    int rc = PNX_OK;
+    hipError_t e = hipSuccess;
+    if (items && ctx->n_steps) {
+        const void *src = ctx->d_items.p;
+        if (ctx->relabeled) {
+            if ((rc = ensure(ctx, tmp_items, ctx->n_steps * sizeof(uint32_t) + 64))) return rc;
+            e = hipMemcpyAsync(tmp_items.p, ctx->d_items.p, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) rc = steps_to_caller_ids(ctx, (uint32_t *)tmp_items.p, ctx->n_steps);
+            src = tmp_items.p;
+        }
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(items, src, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     }
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (path_off) std::copy(ctx->h_path_off.begin(), ctx->h_path_off.end(), path_off);
+    if (weights && !rc && e == hipSuccess) {
+        if (!ctx->weighted) rc = ctx->fail(PNX_EINVAL, "no weights are resident");
+        const void *src = ctx->d_weights.p;
+        if (!rc && ctx->relabeled) {
+            if (!(rc = ensure(ctx, tmp_w, ((size_t)ctx->n_items + 1) * sizeof(uint32_t))))
+                rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->d_weights.p, (uint32_t *)tmp_w.p);
+            src = tmp_w.p;
+        }
+        if (!rc) e = hipMemcpyAsync(weights, src, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    release(tmp_items);
+    release(tmp_w);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_get_csr: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return PNX_OK;
 }
 
@@ -466,7 +513,15 @@ int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
     if (rc) return rc;
     if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
     if (d_hist) *d_hist = ctx->last_done->d_hist;
-    if (d_countable) *d_countable = (uint32_t *)ctx->d_countable.p;  // shared by all passes
+    if (d_countable) {
+        *d_countable = (uint32_t *)ctx->d_countable.p;  // shared by all passes
+        if (ctx->relabeled) {  // the caller's ids: a gathered copy, enqueued behind whatever runs
+            if ((rc = ensure(ctx, ctx->d_countable_ext, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
+            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            *d_countable = (uint32_t *)ctx->d_countable_ext.p;
+        }
+    }
     return PNX_OK;
 }
 
@@ -480,7 +535,14 @@ int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
     if (countable) {
         // the coverage vector is shared by all passes: let a younger pass finish before reading it
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PNX_HIP(ctx, hipMemcpy(countable, ctx->d_countable.p, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const void *src = ctx->d_countable.p;
+        if (ctx->relabeled) {
+            if ((rc = ensure(ctx, ctx->d_countable_ext, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
+            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            src = ctx->d_countable_ext.p;
+        }
+        PNX_HIP(ctx, hipMemcpy(countable, src, ((size_t)ctx->n_items + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return PNX_OK;
 }
@@ -632,9 +694,17 @@ int pnx_presence(pnx_ctx *ctx, uint64_t *bits) {
     if (rc) return rc;
     if ((rc = launch_presence_plain(ctx, ctx->d_plain))) return rc;
     const size_t n = (size_t)ctx->n_groups * ctx->n_blocks * 32;
-    if (n) PNX_HIP(ctx, hipMemcpyAsync(bits, ctx->d_plain.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DevBuf d_perm;
+    const void *src = ctx->d_plain.p;
+    if (ctx->relabeled && n) {
+        if ((rc = presence_to_caller_ids(ctx, ctx->d_plain, d_perm))) return rc;
+        src = d_perm.p;
+    }
+    hipError_t e = n ? hipMemcpyAsync(bits, src, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
     release(ctx->d_plain);
+    release(d_perm);
+    if (e != hipSuccess || e2 != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_presence: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return PNX_OK;
 }
 

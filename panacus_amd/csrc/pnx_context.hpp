@@ -86,6 +86,10 @@ struct pnx_ctx {
     bool have_weights = false;  // weights are resident (weighted = resident AND enabled)
     pnx::DevBuf d_items, d_path_off, d_weights, d_exclude;
     std::vector<uint64_t> h_path_off;
+    // internal renumbering of the items by a caller key (kernels_relabel.hip): resident steps, weights and
+    // flags are in INTERNAL ids; per-item results are mapped back to the caller's ids on the way out
+    bool relabeled = false;
+    pnx::DevBuf d_new_of_old, d_old_of_new, d_countable_ext;  // n_items + 1 u32 each
 
     // ---- visiting order (a2) ----
     uint32_t n_ordered = 0, n_groups = 0;
@@ -208,7 +212,13 @@ int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p i
 // kernels_pairs.hip
 int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
-int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // -> n_groups x (hi - lo) u32
+int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // lo, hi: caller ids  // -> n_groups x (hi - lo) u32
+// kernels_relabel.hip
+int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys);
+int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_caller);
+int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal);
+int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
+int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                            int with_weights);

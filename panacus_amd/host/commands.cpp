@@ -111,50 +111,17 @@ using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncov
 // growth_weights: upload node_len - uncovered as the bp weight of such nodes, which is what
 // AbacusByGroup::calc_growth adds (abacus.rs:1013-1023); the histogram instead takes plain node
 // lengths and is corrected afterwards (construct_hist_bps, abacus.rs:779-785).
-// renumber the steps (and the per-item flags) of an edge table by GraphStorage::edge_relabel
-void renumber_edges(const std::vector<uint32_t> &new_id, std::vector<uint32_t> &items, std::vector<uint8_t> &exclude) {
-    if (new_id.empty()) return;  // already ranked
-    const size_t n = items.size(), CH = 1 << 20;
-    ThreadPool::instance().parallel_for((n + CH - 1) / CH, [&](size_t c) {
-        const size_t e = std::min(n, (c + 1) * CH);
-        for (size_t k = c * CH; k < e; ++k) items[k] = new_id[items[k]];
-    });
-    if (exclude.empty()) return;
-    std::vector<uint8_t> moved(exclude.size(), 0);
-    for (size_t id = 1; id < exclude.size(); ++id) moved[new_id[id]] = exclude[id];
-    exclude.swap(moved);
-}
-
-// Do the edge ids of the file already rise and fall along the paths (L lines written in the order
-// of their ends, as odgi / vg / pggb do)?  Then the renumbering -- a sort of all edges -- buys
-// nothing.  Looks at the first steps of a few paths: the share of adjacent steps that go against
-// the direction of their path's majority.
-bool edge_ids_follow_paths(const ItemTable &tab) {
-    uint64_t with = 0, against = 0;
-    const size_t P = tab.id_prefsum.size() - 1;
-    size_t looked = 0;
-    for (size_t k = 0; k < P && looked < 16; ++k) {
-        const uint64_t b = tab.id_prefsum[k], e = std::min<uint64_t>(tab.id_prefsum[k + 1], b + 4096);
-        if (e - b < 64) continue;
-        ++looked;
-        uint64_t up = 0, down = 0;
-        for (uint64_t j = b; j + 1 < e; ++j) {
-            up += tab.items[j + 1] > tab.items[j];
-            down += tab.items[j + 1] < tab.items[j];
-        }
-        with += std::max(up, down);
-        against += std::min(up, down);
-    }
-    return looked == 0 || against * 20 <= with + against;  // <= 5 % of the steps run against the path
-}
-
-// per_item_output: the caller prints rows per item id (`table`), so the ids of the reference are kept;
-// otherwise edge ids are renumbered for the device (see GraphStorage::edge_relabel)
+// Edge tables go up with one sort key per edge (its canonical ends): the reference numbers edges in the
+// order of the L lines, and the library renumbers them internally on the device when that order does
+// not follow the paths (pnx_set_csr_keyed); every per-item result still comes back in the reference's
+// ids, so `table -c edge` needs no special case.
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
-                 bool growth_weights = false, bool per_item_output = false) {
+                 bool growth_weights = false, bool /*per_item_output*/ = false) {
     const uint64_t n_items = g.number_of_items(ct);
     const uint32_t n_paths = (uint32_t)g.path_segments().size();
-    const bool renumber = ct == COUNT_EDGE && !per_item_output && n_items > 0;
+    std::vector<uint64_t> keys;
+    if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
+    const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
     Uncovered uncovered;
     if (mk.any()) {
         MaskedTable m = g.masked_table(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
@@ -163,24 +130,16 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
             w = g.node_lens();
             for (const auto &u : m.uncovered) w[u.first] = u.second > w[u.first] ? 0 : (uint32_t)(w[u.first] - u.second);
         }
-        if (renumber && !edge_ids_follow_paths(m.table)) renumber_edges(g.edge_relabel(), m.table.items, m.exclude);
         const uint32_t none = 0;  // a valid pointer for an empty table
-        dev.check(pnx_set_csr(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
-                              (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
-                              m.exclude.empty() ? nullptr : m.exclude.data()));
+        dev.check(pnx_set_csr_keyed(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
+                                    (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
+                                    m.exclude.empty() ? nullptr : m.exclude.data(), key_ptr));
         uncovered = std::move(m.uncovered);
-    } else if (renumber) {
-        ItemTable tab = g.item_table(ct);
-        std::vector<uint8_t> no_flags;
-        if (!edge_ids_follow_paths(tab)) renumber_edges(g.edge_relabel(), tab.items, no_flags);
-        const uint32_t none = 0;
-        dev.check(pnx_set_csr(dev.ctx, tab.items.empty() ? &none : tab.items.data(), tab.id_prefsum.data(), n_paths,
-                              (uint32_t)n_items, nullptr, nullptr));
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
-        dev.check(pnx_set_csr(dev.ctx, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
-                              ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
+        dev.check(pnx_set_csr_keyed(dev.ctx, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
+                                    ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr, key_ptr));
     }
     dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
                             (uint32_t)order.groups.size()));

@@ -1217,6 +1217,19 @@ std::vector<std::string> GraphStorage::edge_labels() const {
     return out;
 }
 
+std::vector<uint64_t> GraphStorage::edge_keys() const {
+    const Impl &im = *impl_;
+    if (!im.has_edges) throw std::runtime_error("edge keys need the edge index");
+    std::vector<uint64_t> keys(edge_count_ + 1, 0);
+    if (im.cached) {
+        for (uint64_t id = 1; id <= edge_count_; ++id) keys[id] = im.c_edge_uv[id];
+    } else {
+        for (const auto &sl : im.edges.tab)
+            if (sl.id) keys[sl.id] = sl.uv;
+    }
+    return keys;
+}
+
 std::vector<uint32_t> GraphStorage::edge_relabel() const {
     const Impl &im = *impl_;
     if (!im.has_edges) throw std::runtime_error("edge renumbering needs the edge index");

@@ -107,6 +107,10 @@ public:
     // on item numbering (items only meet in counters); per-item output (`table`) keeps the ids.
     // Empty when the ids already are that rank (L lines sorted by their canonical ends).
     std::vector<uint32_t> edge_relabel() const;
+    // one sort key per edge id (index 0 unused): its canonical ends, (smaller node id << 32) | larger
+    // node id (Edge::canonical, graph.rs:142-148) -- the `item_key` of pnx_set_csr_keyed: the edge
+    // steps of a path rise and fall with these keys as its node steps do with the node ids
+    std::vector<uint64_t> edge_keys() const;
 
     // labels of AbacusByGroup::to_tsv (abacus.rs:1072-1140): the segment name of a node id, and
     // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id

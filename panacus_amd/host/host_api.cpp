@@ -138,6 +138,18 @@ int pnh_graph_masked_table(const void *g, int count_type, int group_mode, const 
     }
 }
 
+// GraphStorage::edge_keys: n_edges + 1 entries (the item_key of pnx_set_csr_keyed)
+int pnh_graph_edge_keys(const void *g, uint64_t *keys) {
+    try {
+        std::vector<uint64_t> k = static_cast<const pnh::GraphStorage *>(g)->edge_keys();
+        std::copy(k.begin(), k.end(), keys);
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
 // GraphStorage::edge_relabel: new_id has n_edges + 1 entries
 int pnh_graph_edge_relabel(const void *g, uint32_t *new_id) {
     try {

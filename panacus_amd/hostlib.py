@@ -255,6 +255,16 @@ class GfaGraph:
             raise ValueError(self._L.pnh_last_error().decode())
         return items[: n_steps.value], pre, flags, ids[: n_unc.value], bps[: n_unc.value]
 
+    def edge_keys(self) -> np.ndarray:
+        """key[edge id] = (smaller node id << 32) | larger node id of the canonical edge; [0] = 0: the
+        `item_key` of pnx_set_csr_keyed (capi.Context.set_csr(..., item_key=...))"""
+        out = np.zeros(self.n_edges + 1, dtype=np.uint64)
+        self._L.pnh_graph_edge_keys.restype = C.c_int
+        self._L.pnh_graph_edge_keys.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        if self._L.pnh_graph_edge_keys(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))) != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        return out
+
     def edge_relabel(self) -> np.ndarray:
         """new_id[old edge id] = rank by canonical (smaller node, larger node, orientations); [0] = 0.
         What the CLI renumbers edge steps by before the upload (hist / growth do not depend on ids)."""

@@ -529,6 +529,88 @@ def test_ordered_growth_rule_from_the_presence_matrix(ctx, weighted):
         assert out[r, 0].tolist() == (seen * w[None, :]).sum(axis=1).tolist()
 
 
+def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path):
+    """pnx_set_csr_keyed: edge steps numbered like the reference does (order of the L lines, here
+    shuffled) + one key per edge (its canonical ends).  The library renumbers the edges internally on
+    the device, so the paths take the tile route instead of the atomic scatter route -- and the
+    coverage vector, the presence rows, the visit counts and the CSR read-back are all in the
+    reference's edge ids, equal to the oracle's."""
+    from panacus_amd import hostlib as hl
+    src = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "40000", "--paths", "10", "--links", "-o", src])
+    assert rc == 0, err
+    lines = open(src).read().split("\n")
+    links = [l for l in lines if l.startswith("L\t")]
+    rng = np.random.default_rng(3)
+    shuf = str(tmp_path / "shuf.gfa")
+    with open(shuf, "w") as f:
+        f.write("\n".join([l for l in lines if l and not l.startswith("L\t")] + [links[i] for i in rng.permutation(len(links))]) + "\n")
+    g = orc.Graph(shuf, index_edges=True)
+    hg = hl.GfaGraph(shuf, index_edges=True)
+    pi, gi, names = g.path_order(orc.GROUP_SAMPLE)
+    G = len(names)
+    items, pre = g.item_table(orc.EDGE)
+    hitems, hpre = hg.item_table(hl.EDGE)
+    assert np.array_equal(items, hitems.astype(np.uint64))          # same (reference) edge ids on both sides
+    n = g.n_edges
+    keys = hg.edge_keys()
+    excl = (rng.random(n + 1) < 0.03).astype(np.uint8)
+    excl[0] = 0
+    # without keys: the reference's ids do not follow the paths -> scatter route
+    ctx.set_csr(hitems, hpre, n, exclude=excl)
+    ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
+    cnt_plain, h_plain = ctx.hist()
+    assert ctx.info().n_scatter_paths > 0
+    # with keys: tile route, same answers
+    ctx.set_csr(hitems, hpre, n, exclude=excl, item_key=keys)
+    ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
+    cnt, h = ctx.hist()
+    info = ctx.info()
+    assert info.n_scatter_paths == 0
+    ocov = orc.coverage(items, pre, pi, gi, n, excl)
+    assert np.array_equal(cnt, ocov) and np.array_equal(cnt, cnt_plain)
+    assert np.array_equal(h, orc.hist(ocov, G)) and np.array_equal(h, h_plain)
+    # presence rows in the caller's ids
+    bits = ctx.presence()
+    got = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, : n + 1]
+    r, c = orc.by_group(items, pre, pi, gi, n, excl)
+    assert np.array_equal(got[:, 1:].T, orc.table_rows(r, c, G))
+    # visit counts of a slice of caller ids
+    lo, hi = 1000, 9000
+    vc = ctx.group_visit_counts(lo, hi)
+    path_group = np.full(len(pre) - 1, -1, dtype=np.int64)
+    path_group[pi.astype(np.int64)] = gi.astype(np.int64)
+    exp = np.zeros((G, hi - lo), dtype=np.int64)
+    for p_ in range(len(pre) - 1):
+        if path_group[p_] < 0:
+            continue
+        ids = items[int(pre[p_]):int(pre[p_ + 1])].astype(np.int64)
+        ids = ids[(ids >= lo) & (ids < hi) & (excl[ids] == 0)]
+        np.add.at(exp[path_group[p_]], ids - lo, 1)
+    assert np.array_equal(vc.astype(np.int64), exp)
+    # the CSR comes back as it was uploaded; a new exclusion list is taken in caller ids
+    back, off, _ = ctx.get_csr()
+    assert np.array_equal(back, hitems) and np.array_equal(off, hpre)
+    excl2 = (rng.random(n + 1) < 0.2).astype(np.uint8)
+    excl2[0] = 0
+    ctx.set_exclude(excl2)
+    cnt2, h2 = ctx.hist()
+    assert np.array_equal(cnt2, orc.coverage(items, pre, pi, gi, n, excl2))
+    # ordered growth and the intersections do not depend on numbering
+    ctx.set_exclude(None)
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    out = ctx.ordered_growth([coverage_abs(Threshold(ABSOLUTE, 1), G)], quorum_table(Threshold(RELATIVE, 0.4), G)[None, :])
+    r0, c0 = orc.by_group(items, pre, pi, gi, n)
+    assert out[0, 0].tolist() == [int(x) for x in orc.ordered_growth(r0, c0, G, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.4))]
+    exp_inter, _, _ = orc.similarity(r0, c0, G)
+    assert np.array_equal(ctx.group_intersections(), exp_inter)
+    # keys that already rise with the ids: nothing is renumbered, nothing changes
+    ctx.set_csr(hitems, hpre, n, item_key=np.arange(n + 1, dtype=np.uint64))
+    ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
+    cnt3, _ = ctx.hist()
+    assert np.array_equal(cnt3, orc.coverage(items, pre, pi, gi, n))
+
+
 def test_two_passes_in_flight(ctx):
     """pnx_hist_async may be called twice before the first result is fetched; results come back
     oldest first and are identical; a third enqueue is refused; a violation found in an
