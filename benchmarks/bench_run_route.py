@@ -50,7 +50,14 @@ def main():
     ctx.set_order(order, order, p)
     t0 = time.perf_counter()
     ctx.hist(want_countable=False)
-    out["run_index_first_call_ms"] = (time.perf_counter() - t0) * 1e3
+    out["run_index_first_call_ms"] = (time.perf_counter() - t0) * 1e3   # incl. first-use costs: buffers, code objects
+    # the same graph uploaded again: what the first hist of a graph costs once the context is warm = one failed
+    # optimistic pass + the device-side build (count, classify, scan, emit, sort) + the re-run
+    ctx.set_csr(jit, off, n)
+    ctx.set_order(order, order, p)
+    t0 = time.perf_counter()
+    ctx.hist(want_countable=False)
+    out["run_index_first_call_warm_ms"] = (time.perf_counter() - t0) * 1e3
     ms, prof, h1 = timed(ctx)
     info = ctx.info()
     out["near_monotone"] = {"ms": ms, "kernels_ms": prof, "run_paths": int(info.n_run_paths),

@@ -11,9 +11,11 @@
 // along the walk) stay on the scatter route, where sorting one record per step would cost more
 // than the atomics.
 //
-// The build is host-driven (it needs sizes on the host for allocation and for rocPRIM's sort);
-// it only happens when a pass has flagged unclassified general paths, and it is cached with
-// the tile index (the sort by group is redone when the visiting order changes).
+// The build runs on the device: counting, classification (run route vs scatter route), a scan for
+// the offsets, emission and the sort are a chain of launches on the context's stream; the host
+// reads back one number (how many runs) to size their arrays.  It only happens when a pass has
+// flagged unclassified general paths, and it is cached with the tile index (the sort by group is
+// redone when the visiting order changes).
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -29,12 +31,32 @@ namespace pnx {
 constexpr uint32_t RUN_CHUNK = 4096;      // steps per chunk (one wave walks one chunk)
 constexpr uint32_t RUN_MIN_AVG_LEN = 16;  // paths with shorter average runs stay on the scatter route
 
+// Chunk c of the graph = RUN_CHUNK consecutive steps of one path; chunk_off[p] = number of chunks of
+// the paths before p (a prefix sum over ceil(len / RUN_CHUNK), fixed per graph).  The kernels below
+// run over the chunks of ALL paths and leave at once for paths that take another route: the host
+// never builds a work list, so the whole build is a chain of launches on the stream.
 struct RunChunk {
     uint64_t start;   // first step (absolute index into items)
     uint64_t pstart;  // first step of the path
     uint32_t len;     // steps in this chunk
     uint32_t path;
 };
+
+__device__ static inline RunChunk chunk_of(uint64_t c, const uint64_t *__restrict__ chunk_off,
+                                           const uint64_t *__restrict__ path_off, uint32_t n_paths) {
+    uint32_t lo = 0, hi = n_paths;  // last p with chunk_off[p] <= c (empty paths own no chunk)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    RunChunk ch;
+    ch.path = lo;
+    ch.pstart = path_off[lo];
+    ch.start = ch.pstart + (c - chunk_off[lo]) * RUN_CHUNK;
+    const uint64_t left = path_off[lo + 1] - ch.start;
+    ch.len = (uint32_t)(left < RUN_CHUNK ? left : RUN_CHUNK);
+    return ch;
+}
 
 // flag = this step starts a run (first step of the path, or a different tile than the step before)
 __device__ static inline bool run_starts(const uint32_t *__restrict__ items, uint64_t j, uint64_t pstart,
@@ -44,13 +66,20 @@ __device__ static inline bool run_starts(const uint32_t *__restrict__ items, uin
     return j == pstart || (cur >> tile_shift) != (prev >> tile_shift);
 }
 
-__global__ __launch_bounds__(256) void k_runs_count(const uint32_t *__restrict__ items,
-                                                    const RunChunk *__restrict__ chunks, uint32_t n_chunks,
-                                                    uint32_t tile_shift, uint32_t *__restrict__ counts) {
+// counts[c] = runs that start in chunk c (0 for chunks of paths that need no classification);
+// runs_of_path[p] += the same
+__global__ __launch_bounds__(256) void k_runs_count(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                                    const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
+                                                    const uint8_t *__restrict__ path_class, uint32_t tile_shift,
+                                                    uint32_t *__restrict__ counts, unsigned long long *__restrict__ runs_of_path) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
-    const RunChunk ch = chunks[c];
+    const RunChunk ch = chunk_of(c, chunk_off, path_off, n_paths);
+    if (path_class[ch.path] == 0) {  // tile-monotone: served by the boundary index
+        if (lane == 0) counts[c] = 0;
+        return;
+    }
     uint32_t total = 0;
     for (uint32_t it = 0; it < ch.len; it += 64) {
         const uint64_t j = ch.start + it + lane;
@@ -59,20 +88,54 @@ __global__ __launch_bounds__(256) void k_runs_count(const uint32_t *__restrict__
         const bool f = run_starts(items, j, ch.pstart, cur, lane, tile_shift) && in;
         total += (uint32_t)__popcll(__ballot(f));
     }
-    if (lane == 0) counts[c] = total;
+    if (lane == 0) {
+        counts[c] = total;
+        atomicAdd(&runs_of_path[ch.path], (unsigned long long)total);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_runs_emit(const uint32_t *__restrict__ items,
-                                                   const RunChunk *__restrict__ chunks, uint32_t n_chunks,
-                                                   const uint64_t *__restrict__ offs /* UINT64_MAX = skip */,
+// every path that is not tile-monotone: run route (2) if its runs are long enough, else scatter route (3);
+// meta[0] = scatter paths, meta[1] = run-route paths
+__global__ void k_runs_classify(const uint64_t *__restrict__ path_off, uint32_t n_paths,
+                                const unsigned long long *__restrict__ runs_of_path, uint8_t *__restrict__ path_class,
+                                unsigned long long *__restrict__ meta) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths || path_class[p] == 0) return;
+    const uint64_t len = path_off[p + 1] - path_off[p];
+    const unsigned long long runs = runs_of_path[p];
+    // an empty path has nothing to do on either route
+    const uint8_t cls = (len == 0 || runs * RUN_MIN_AVG_LEN <= len || runs <= 64) ? 2 : 3;
+    path_class[p] = cls;
+    atomicAdd(&meta[cls == 3 ? 0 : 1], 1ull);
+}
+
+// counts of the chunks whose path did not end up on the run route are dropped; the rest widen to u64 for the scan
+__global__ void k_runs_mask_counts(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ path_off,
+                                   const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
+                                   const uint8_t *__restrict__ path_class, uint64_t *__restrict__ wide) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const RunChunk ch = chunk_of(c, chunk_off, path_off, n_paths);
+    wide[c] = path_class[ch.path] == 2 ? counts[c] : 0;
+}
+
+// meta[2] = total number of runs = offs[last] + wide[last]
+__global__ void k_runs_total(const uint64_t *__restrict__ offs, const uint64_t *__restrict__ wide, uint64_t n_chunks,
+                             unsigned long long *__restrict__ meta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) meta[2] = n_chunks ? offs[n_chunks - 1] + wide[n_chunks - 1] : 0;
+}
+
+__global__ __launch_bounds__(256) void k_runs_emit(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                                   const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
+                                                   const uint8_t *__restrict__ path_class, const uint64_t *__restrict__ offs,
                                                    uint32_t tile_shift, uint64_t *__restrict__ r_start,
                                                    uint32_t *__restrict__ r_tile, uint32_t *__restrict__ r_path) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
+    const RunChunk ch = chunk_of(c, chunk_off, path_off, n_paths);
+    if (path_class[ch.path] != 2) return;
     uint64_t off = offs[c];
-    if (off == 0xFFFFFFFFFFFFFFFFull) return;
-    const RunChunk ch = chunks[c];
     for (uint32_t it = 0; it < ch.len; it += 64) {
         const uint64_t j = ch.start + it + lane;
         const bool in = it + lane < ch.len;
@@ -136,15 +199,17 @@ __global__ void k_runs_tile_off(const uint64_t *__restrict__ keys_sorted, uint64
     tile_off[t] = lo;
 }
 
-// ------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------
-static int sync_copy(pnx_ctx *ctx, void *dst, const void *src, size_t n, hipMemcpyKind kind) {
-    PNX_HIP(ctx, hipMemcpyAsync(dst, src, n, kind, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PNX_OK;
+// group of every path in the current visiting order (filled over a 0xFF memset = "not visited")
+__global__ void k_group_of_path(const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
+                                uint32_t n_ordered, uint32_t *__restrict__ gop) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_ordered) gop[ord_path[k]] = ord_group[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// host side: the build is a chain of launches on the context's stream with ONE read-back (the
+// number of runs, to size their arrays); every scratch buffer lives in the context and only grows
+// ------------------------------------------------------------------------------------------
 // (re)sort the runs by (tile, group) for the current visiting order
 int sort_run_index(pnx_ctx *ctx) {
     ctx->runs_sorted = false;
@@ -156,23 +221,18 @@ int sort_run_index(pnx_ctx *ctx) {
         ctx->runs_sorted = true;
         return PNX_OK;
     }
-    // path -> group of the current order
-    std::vector<uint32_t> gop(ctx->n_paths, 0xFFFFFFFFu);
-    for (size_t k = 0; k < ctx->h_ord_path.size(); ++k) gop[ctx->h_ord_path[k]] = ctx->h_ord_group[k];
-    DevBuf d_gop, d_keys, d_keys2, d_idx, d_idx2, d_tmp;
-    auto cleanup = [&]() {
-        for (DevBuf *b : {&d_gop, &d_keys, &d_keys2, &d_idx, &d_idx2, &d_tmp}) release(*b);
-    };
-    if ((rc = ensure(ctx, d_gop, gop.size() * 4)) || (rc = ensure(ctx, d_keys, n * 8)) || (rc = ensure(ctx, d_keys2, n * 8)) ||
+    const size_t P = ctx->n_paths ? ctx->n_paths : 1;
+    DevBuf &d_gop = ctx->d_rs[0], &d_keys = ctx->d_rs[1], &d_keys2 = ctx->d_rs[2], &d_idx = ctx->d_rs[3], &d_idx2 = ctx->d_rs[4],
+           &d_tmp = ctx->d_rs[5];
+    if ((rc = ensure(ctx, d_gop, P * 4)) || (rc = ensure(ctx, d_keys, n * 8)) || (rc = ensure(ctx, d_keys2, n * 8)) ||
         (rc = ensure(ctx, d_idx, n * 4)) || (rc = ensure(ctx, d_idx2, n * 4)) || (rc = ensure(ctx, ctx->d_srun_start, n * 8)) ||
-        (rc = ensure(ctx, ctx->d_srun_len, n * 4)) || (rc = ensure(ctx, ctx->d_srun_group, n * 4))) {
-        cleanup();
+        (rc = ensure(ctx, ctx->d_srun_len, n * 4)) || (rc = ensure(ctx, ctx->d_srun_group, n * 4)))
         return rc;
-    }
-    if ((rc = sync_copy(ctx, d_gop.p, gop.data(), gop.size() * 4, hipMemcpyHostToDevice))) {
-        cleanup();
-        return rc;
-    }
+    PNX_HIP(ctx, hipMemsetAsync(d_gop.p, 0xFF, P * 4, ctx->stream));
+    if (ctx->n_ordered)
+        hipLaunchKernelGGL(k_group_of_path, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
+                           (uint32_t *)d_gop.p);
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_runs_keys, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_run_tile.p,
                        (const uint32_t *)ctx->d_run_path.p, (const uint32_t *)d_gop.p, n, (uint64_t *)d_keys.p,
@@ -183,20 +243,16 @@ int sort_run_index(pnx_ctx *ctx) {
     if (e == hipSuccess && (rc = ensure(ctx, d_tmp, tmp_bytes)) == PNX_OK)
         e = rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, (uint64_t *)d_keys.p, (uint64_t *)d_keys2.p,
                                       (uint32_t *)d_idx.p, (uint32_t *)d_idx2.p, n, 0, 64, ctx->stream);
-    if (e != hipSuccess || rc) {
-        cleanup();
-        return rc ? rc : ctx->fail(PNX_EHIP, "run index sort failed: %s", hipGetErrorString(e));
-    }
+    if (rc) return rc;
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "run index sort failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_runs_gather, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t *)d_keys2.p,
                        (const uint32_t *)d_idx2.p, (const uint64_t *)ctx->d_run_start.p,
                        (const uint32_t *)ctx->d_run_len.p, n, (uint64_t *)ctx->d_srun_start.p,
                        (uint32_t *)ctx->d_srun_len.p, (uint32_t *)ctx->d_srun_group.p);
     hipLaunchKernelGGL(k_runs_tile_off, dim3((ctx->n_tiles + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                        (const uint64_t *)d_keys2.p, n, ctx->n_tiles, (uint64_t *)ctx->d_run_tile_off.p);
-    e = hipStreamSynchronize(ctx->stream);
-    cleanup();
-    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "run index sort failed: %s", hipGetErrorString(e));
-    ctx->runs_sorted = true;
+    PNX_HIP(ctx, hipGetLastError());
+    ctx->runs_sorted = true;  // the coverage pass is enqueued behind these launches on the same stream
     return PNX_OK;
 }
 
@@ -208,99 +264,76 @@ int build_run_index(pnx_ctx *ctx) {
     uint32_t tile_shift = 0;
     while ((1u << tile_shift) < tile_items) ++tile_shift;
     int rc;
-    std::vector<uint8_t> cls(P ? P : 1, 0);
-    if (P && (rc = sync_copy(ctx, cls.data(), ctx->d_path_class.p, P, hipMemcpyDeviceToHost))) return rc;
-
-    // chunks over all general paths
-    std::vector<RunChunk> chunks;
-    std::vector<uint32_t> general;
-    for (uint32_t p = 0; p < P; ++p) {
-        if (!cls[p]) continue;
-        general.push_back(p);
-        const uint64_t s = ctx->h_path_off[p], e = ctx->h_path_off[p + 1];
-        for (uint64_t b = s; b < e; b += RUN_CHUNK)
-            chunks.push_back(RunChunk{b, s, (uint32_t)std::min<uint64_t>(RUN_CHUNK, e - b), p});
-        if (e == s) cls[p] = 2;  // empty path: nothing to do on either route
-    }
     ctx->n_runs = 0;
     ctx->n_scatter_paths = 0;
-    if (chunks.size() >= 0xFFFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many general path chunks");
-    const uint32_t n_chunks = (uint32_t)chunks.size();
-    std::vector<uint32_t> counts(n_chunks ? n_chunks : 1, 0);
-    DevBuf d_chunks, d_counts, d_offs;
-    auto cleanup = [&]() {
-        release(d_chunks);
-        release(d_counts);
-        release(d_offs);
-    };
-    if (n_chunks) {
-        if ((rc = ensure(ctx, d_chunks, (size_t)n_chunks * sizeof(RunChunk))) || (rc = ensure(ctx, d_counts, (size_t)n_chunks * 4)) ||
-            (rc = ensure(ctx, d_offs, (size_t)n_chunks * 8)) ||
-            (rc = sync_copy(ctx, d_chunks.p, chunks.data(), (size_t)n_chunks * sizeof(RunChunk), hipMemcpyHostToDevice))) {
-            cleanup();
-            return rc;
-        }
-        prof_begin(ctx, PNX_K_SCATTER);
-        hipLaunchKernelGGL(k_runs_count, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const RunChunk *)d_chunks.p, n_chunks, tile_shift,
-                           (uint32_t *)d_counts.p);
-        prof_end(ctx);
-        if ((rc = sync_copy(ctx, counts.data(), d_counts.p, (size_t)n_chunks * 4, hipMemcpyDeviceToHost))) {
-            cleanup();
-            return rc;
-        }
+    ctx->n_run_paths = 0;
+    if (P == 0) return sort_run_index(ctx);
+    // chunk prefix of the graph (host knows path_off): once per upload
+    if (!ctx->chunk_off_valid) {
+        ctx->h_chunk_off.assign((size_t)P + 1, 0);
+        for (uint32_t p = 0; p < P; ++p)
+            ctx->h_chunk_off[p + 1] = ctx->h_chunk_off[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + RUN_CHUNK - 1) / RUN_CHUNK;
+        if ((rc = ensure(ctx, ctx->d_chunk_off, ((size_t)P + 1) * 8))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_off.p, ctx->h_chunk_off.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->chunk_off_valid = true;  // h_chunk_off stays alive with the context
     }
-    // per-path totals -> class; offsets of the run-route chunks
-    std::vector<uint64_t> runs_of(P, 0);
-    for (uint32_t c = 0; c < n_chunks; ++c) runs_of[chunks[c].path] += counts[c];
-    for (uint32_t p : general) {
-        const uint64_t len = ctx->h_path_off[p + 1] - ctx->h_path_off[p];
-        if (len == 0) continue;
-        cls[p] = (runs_of[p] * RUN_MIN_AVG_LEN <= len || runs_of[p] <= 64) ? 2 : 3;
-        if (cls[p] == 3) ctx->n_scatter_paths += 1;
-    }
-    std::vector<uint64_t> offs(n_chunks ? n_chunks : 1, 0xFFFFFFFFFFFFFFFFull);
-    uint64_t n_runs = 0;
-    for (uint32_t c = 0; c < n_chunks; ++c)
-        if (cls[chunks[c].path] == 2) {
-            offs[c] = n_runs;
-            n_runs += counts[c];
-        }
-    if (n_runs >= 0xFFFFFFFFull) {
-        cleanup();
-        return ctx->fail(PNX_ELIMIT, "more than 2^32-1 runs in the run index");
-    }
-    if (P && (rc = sync_copy(ctx, ctx->d_path_class.p, cls.data(), P, hipMemcpyHostToDevice))) {
-        cleanup();
+    const uint64_t n_chunks = ctx->h_chunk_off[P];
+    if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many path chunks for the run index");
+    DevBuf &d_counts = ctx->d_rb[0], &d_wide = ctx->d_rb[1], &d_offs = ctx->d_rb[2], &d_rop = ctx->d_rb[3], &d_meta = ctx->d_rb[4],
+           &d_scan_tmp = ctx->d_rb[5];
+    const size_t nc = n_chunks ? n_chunks : 1;
+    if ((rc = ensure(ctx, d_counts, nc * 4)) || (rc = ensure(ctx, d_wide, nc * 8)) || (rc = ensure(ctx, d_offs, nc * 8)) ||
+        (rc = ensure(ctx, d_rop, (size_t)P * 8)) || (rc = ensure(ctx, d_meta, 4 * 8)))
         return rc;
+    PNX_HIP(ctx, hipMemsetAsync(d_rop.p, 0, (size_t)P * 8, ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(d_meta.p, 0, 4 * 8, ctx->stream));
+    const uint32_t *items = (const uint32_t *)ctx->d_items.p;
+    const uint64_t *path_off = (const uint64_t *)ctx->d_path_off.p, *chunk_off = (const uint64_t *)ctx->d_chunk_off.p;
+    uint8_t *cls = (uint8_t *)ctx->d_path_class.p;
+    prof_begin(ctx, PNX_K_SCATTER);
+    if (n_chunks)
+        hipLaunchKernelGGL(k_runs_count, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, ctx->stream, items, path_off, chunk_off, P,
+                           n_chunks, (const uint8_t *)cls, tile_shift, (uint32_t *)d_counts.p, (unsigned long long *)d_rop.p);
+    hipLaunchKernelGGL(k_runs_classify, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, path_off, P,
+                       (const unsigned long long *)d_rop.p, cls, (unsigned long long *)d_meta.p);
+    if (n_chunks) {
+        hipLaunchKernelGGL(k_runs_mask_counts, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)d_counts.p, path_off, chunk_off, P, n_chunks, (const uint8_t *)cls, (uint64_t *)d_wide.p);
+        size_t tmp_bytes = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, (uint64_t *)d_wide.p, (uint64_t *)d_offs.p, (uint64_t)0, (size_t)n_chunks,
+                                               rocprim::plus<uint64_t>(), ctx->stream);
+        if (e == hipSuccess && (rc = ensure(ctx, d_scan_tmp, tmp_bytes)) == PNX_OK)
+            e = rocprim::exclusive_scan(d_scan_tmp.p, tmp_bytes, (uint64_t *)d_wide.p, (uint64_t *)d_offs.p, (uint64_t)0, (size_t)n_chunks,
+                                        rocprim::plus<uint64_t>(), ctx->stream);
+        if (rc) return rc;
+        if (e != hipSuccess) return ctx->fail(PNX_EHIP, "run index scan failed: %s", hipGetErrorString(e));
     }
+    hipLaunchKernelGGL(k_runs_total, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)d_offs.p, (const uint64_t *)d_wide.p, n_chunks,
+                       (unsigned long long *)d_meta.p);
+    prof_end(ctx);
+    // the one read-back: how many runs (their arrays must be sized), how many paths on either route
+    unsigned long long meta[4] = {0, 0, 0, 0};
+    PNX_HIP(ctx, hipMemcpyAsync(meta, d_meta.p, sizeof meta, hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n_runs = meta[2];
+    if (n_runs >= 0xFFFFFFFFull) return ctx->fail(PNX_ELIMIT, "more than 2^32-1 runs in the run index");
+    ctx->n_scatter_paths = (uint32_t)meta[0];
+    ctx->n_run_paths = (uint32_t)meta[1];
     if (n_runs) {
         if ((rc = ensure(ctx, ctx->d_run_start, n_runs * 8)) || (rc = ensure(ctx, ctx->d_run_len, n_runs * 4)) ||
-            (rc = ensure(ctx, ctx->d_run_tile, n_runs * 4)) || (rc = ensure(ctx, ctx->d_run_path, n_runs * 4)) ||
-            (rc = sync_copy(ctx, d_offs.p, offs.data(), (size_t)n_chunks * 8, hipMemcpyHostToDevice))) {
-            cleanup();
+            (rc = ensure(ctx, ctx->d_run_tile, n_runs * 4)) || (rc = ensure(ctx, ctx->d_run_path, n_runs * 4)))
             return rc;
-        }
         prof_begin(ctx, PNX_K_SCATTER);
-        hipLaunchKernelGGL(k_runs_emit, dim3((n_chunks + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, (const RunChunk *)d_chunks.p, n_chunks,
-                           (const uint64_t *)d_offs.p, tile_shift, (uint64_t *)ctx->d_run_start.p,
+        hipLaunchKernelGGL(k_runs_emit, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, ctx->stream, items, path_off, chunk_off, P,
+                           n_chunks, (const uint8_t *)cls, (const uint64_t *)d_offs.p, tile_shift, (uint64_t *)ctx->d_run_start.p,
                            (uint32_t *)ctx->d_run_tile.p, (uint32_t *)ctx->d_run_path.p);
         hipLaunchKernelGGL(k_runs_len, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint64_t *)ctx->d_run_start.p, (const uint32_t *)ctx->d_run_path.p,
-                           (const uint64_t *)ctx->d_path_off.p, n_runs, (uint32_t *)ctx->d_run_len.p);
+                           (const uint64_t *)ctx->d_run_start.p, (const uint32_t *)ctx->d_run_path.p, path_off, n_runs,
+                           (uint32_t *)ctx->d_run_len.p);
         prof_end(ctx);
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            cleanup();
-            return ctx->fail(PNX_EHIP, "run index build failed: %s", hipGetErrorString(e));
-        }
+        PNX_HIP(ctx, hipGetLastError());
     }
-    cleanup();
     ctx->n_runs = n_runs;
-    ctx->n_run_paths = 0;
-    for (uint32_t p : general)
-        if (cls[p] == 2) ctx->n_run_paths += 1;
     return sort_run_index(ctx);
 }
 

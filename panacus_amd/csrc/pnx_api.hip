@@ -99,6 +99,7 @@ static void drop_run_index(pnx_ctx *ctx) {
 
 static void set_geometry(pnx_ctx *ctx) {
     drop_run_index(ctx);
+    ctx->chunk_off_valid = false;
     ctx->n_blocks = (uint32_t)(((uint64_t)ctx->n_items + 1 + BLOCK_ITEMS - 1) / BLOCK_ITEMS);
     ctx->n_tiles = (ctx->n_blocks + ctx->tile_blocks - 1) / ctx->tile_blocks;
     ctx->index_valid = false;
@@ -245,7 +246,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);

@@ -129,6 +129,10 @@ struct pnx_ctx {
     uint64_t n_runs = 0;
     uint32_t n_run_paths = 0, n_scatter_paths = 0;
     bool runs_sorted = false;
+    pnx::DevBuf d_chunk_off;            // n_paths + 1 u64: chunks (4096 steps) of the paths before p
+    std::vector<uint64_t> h_chunk_off;  // its host copy (staging of the upload; chunk total)
+    bool chunk_off_valid = false;
+    pnx::DevBuf d_rb[6], d_rs[6];       // scratch of the build / of the sort: kept, only ever grown
 
     // ---- results ----
     pnx::DevBuf d_countable;  // n_items + 1 u32
