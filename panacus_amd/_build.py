@@ -23,7 +23,7 @@ LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
 HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_closed_form.hip", "pansyn.hip"]
-HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "commands.cpp", "host_api.cpp"]
+HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "mini_yaml.cpp", "report.cpp", "commands.cpp", "host_api.cpp"]
 
 
 def _hipcc() -> str:

@@ -15,27 +15,18 @@
 #include "growth_closed_form.hpp"
 #include "linkage.hpp"
 #include "synth_gfa.hpp"
+#include "commands_internal.hpp"
 #include "tables.hpp"
 #include "thread_pool.hpp"
 
 namespace pnh {
-namespace {
-
-struct Options {
-    std::string cmd, file, count = "node", coverage = "1", quorum = "0", group_file, order_file, subset_file, exclude_file;
-    std::string method = "centroid";  // similarity: ClusterMethod::default() (analysis_parameter.rs:287-291)
-    bool add_hist = false, by_sample = false, by_haplotype = false, total = false, cache = false;
-    int threads = 0, device = 0;
-    // synth
-    uint64_t seed = 42;
-    uint32_t nodes = 0, paths = 0;
-    std::string out_file;
-    bool links = false, sequences = false;
-};
+namespace cli {
 
 const char *USAGE =
     "panacus-amd -- MI355X-native hist / growth / histgrowth / ordered-histgrowth\n"
     "usage: panacus-amd <hist|growth|histgrowth|ordered-histgrowth|similarity|table> [options] <GFA_FILE | HIST.tsv>\n"
+    "       panacus-amd report [-j|--json] [-d|--dry-run] <CONFIG.yaml>   run the analyses of a YAML config (one graph\n"
+    "                                        upload per run and count type); --json prints the reference's report sections\n"
     "  -c, --count <node|bp|edge|all>   graph quantity to be counted [node]\n"
     "  -l, --coverage <LIST>            coverage thresholds, e.g. 1,2 [1]\n"
     "  -q, --quorum <LIST>              quorum thresholds in [0,1], e.g. 0,0.5 [0]\n"
@@ -50,6 +41,7 @@ const char *USAGE =
     "  -e, --exclude <FILE|REGEX>       drop the listed paths/groups/intervals and every node/edge/bp they touch\n"
     "      --cache                      keep / reuse the parsed graph in <GFA_FILE>.pcsr (checked against the\n"
     "                                   GFA's size, mtime and a content hash)\n"
+    "  -j, --json                       print the analysis as the reference's report JSON (AnalysisSection list)\n"
     "  -t, --threads <N>                host threads (0 = all) [0]\n"
     "      --device <N>                 GPU ordinal [0]\n"
     "  -m, --method <single|complete|average|weighted|ward|centroid|median>\n"
@@ -57,23 +49,20 @@ const char *USAGE =
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
     "                                        write a pansyn-v1 synthetic pangenome as GFA\n";
 
-struct Device {  // RAII over pnx_ctx
-    pnx_ctx *ctx = nullptr;
-    explicit Device(int ordinal) {
-        int rc = pnx_init(&ctx, ordinal);
-        if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
-        // quorum closed form with >= 512 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
-        // the whole closed form on the host threads; the results are the same bits either way)
-        if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(ctx);
-    }
-    ~Device() {
-        set_quorum_offload(nullptr);
-        pnx_free(ctx);
-    }
-    void check(int rc) const {
-        if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
-    }
-};
+Device::Device(int ordinal) {
+    int rc = pnx_init(&ctx, ordinal);
+    if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
+    // quorum closed form with >= 512 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
+    // the whole closed form on the host threads; the results are the same bits either way)
+    if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(ctx);
+}
+Device::~Device() {
+    set_quorum_offload(nullptr);
+    pnx_free(ctx);
+}
+void Device::check(int rc) const {
+    if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
+}
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
 std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges) {
@@ -99,13 +88,6 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 }
 
 // upload graph + order for one count type
-struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a count type is cut down by
-    GroupMode mode = GROUP_PATHID;
-    std::string group_file, subset_file, exclude_file;
-    bool any() const { return !subset_file.empty() || !exclude_file.empty(); }
-};
-
-using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncovered_bps (abacus.rs:1187-1229)
 
 // Returns the uncovered bp of partially covered nodes (bp counts under a subset list, else empty).
 // growth_weights: upload node_len - uncovered as the bp weight of such nodes, which is what
@@ -116,7 +98,7 @@ using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncov
 // not follow the paths (pnx_set_csr_keyed); every per-item result still comes back in the reference's
 // ids, so `table -c edge` needs no special case.
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
-                 bool growth_weights = false, bool /*per_item_output*/ = false) {
+                 bool growth_weights, bool /*per_item_output*/) {
     const uint64_t n_items = g.number_of_items(ct);
     const uint32_t n_paths = (uint32_t)g.path_segments().size();
     std::vector<uint64_t> keys;
@@ -207,7 +189,6 @@ void growth_headers(std::vector<std::vector<std::string>> &headers, const char *
         headers.push_back({what, count_name(ct), threshold_string(tc.coverage[t]), threshold_string(tc.quorum[t])});
 }
 
-GroupMode group_mode(const Options &o);
 Masking masking(const Options &o) {
     Masking m;
     m.mode = group_mode(o);
@@ -288,15 +269,8 @@ std::string cmd_growth_from_hist(const Options &o, const std::string &cmdline) {
     return res + write_table(headers, cols);
 }
 
-std::string cmd_ordered(const Options &o, const std::string &cmdline) {
-    ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
-    CountType ct = count_types(o.count, false)[0];
-    auto g = load_graph(o, ct == COUNT_EDGE);
-    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
-    const uint32_t G = (uint32_t)order.groups.size();
+std::vector<std::vector<double>> device_ordered_growth(const Device &dev, const ThresholdContainer &tc, uint32_t G) {
     const uint32_t T = (uint32_t)tc.coverage.size();
-    Device dev(o.device);
-    upload(dev, *g, ct, order, masking(o), true);
     // AbacusByGroup::calc_growth prologue (abacus.rs:997-998, 1009) in f64 on the host
     std::vector<uint32_t> cov(T), qtab((size_t)T * G);
     for (uint32_t t = 0; t < T; ++t) {
@@ -306,12 +280,26 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     }
     std::vector<uint64_t> res((size_t)T * G, 0);
     if (G) dev.check(pnx_ordered_growth(dev.ctx, nullptr, 1, cov.data(), qtab.data(), T, res.data()));
+    std::vector<std::vector<double>> out(T, std::vector<double>(G));
+    for (uint32_t t = 0; t < T; ++t)
+        for (uint32_t j = 0; j < G; ++j) out[t][j] = (double)res[(size_t)t * G + j];
+    return out;
+}
+
+std::string cmd_ordered(const Options &o, const std::string &cmdline) {
+    ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
+    CountType ct = count_types(o.count, false)[0];
+    auto g = load_graph(o, ct == COUNT_EDGE);
+    PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    const uint32_t G = (uint32_t)order.groups.size();
+    Device dev(o.device);
+    upload(dev, *g, ct, order, masking(o), true);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
-    for (uint32_t t = 0; t < T; ++t) {
+    for (auto &res : device_ordered_growth(dev, tc, G)) {
         std::vector<double> col(G + 1);
         col[0] = std::numeric_limits<double>::quiet_NaN();
-        for (uint32_t j = 0; j < G; ++j) col[j + 1] = (double)res[(size_t)t * G + j];
+        for (uint32_t j = 0; j < G; ++j) col[j + 1] = res[j];
         cols.push_back(std::move(col));
     }
     growth_headers(headers, "ordered-growth", ct, tc);
@@ -322,6 +310,40 @@ std::string cmd_ordered(const Options &o, const std::string &cmdline) {
 // come from the GPU; the f32 division, the Euclidean row distances, the linkage (-m, default
 // centroid) and the reordering of rows, columns and labels happen here exactly as in the
 // reference (linkage.hpp).
+SimilarityResult device_similarity(const Device &dev, const std::vector<std::string> &groups, const std::string &method_name) {
+    ClusterMethod method;
+    if (!parse_cluster_method(method_name, method))
+        throw std::runtime_error("invalid value '" + method_name + "' for --method (single, complete, average, weighted, ward, centroid, median)");
+    const size_t G = groups.size();
+    std::vector<uint64_t> inter(G * G, 0);
+    if (G) dev.check(pnx_group_intersections(dev.ctx, inter.data()));
+    for (size_t a = 0; a < G; ++a)
+        if (inter[a * G + a] == 0)  // path_lens[&a] on a missing key panics in the reference (:163)
+            throw std::runtime_error("group " + groups[a] + " covers no item: the reference panics here");
+    SimilarityResult r;
+    r.table.resize(G * G);
+    for (size_t i = 0; i < G; ++i)
+        for (size_t j = 0; j < G; ++j) {
+            const uint64_t x = inter[i * G + j];
+            r.table[i * G + j] = (float)x / (float)(inter[i * G + i] + inter[j * G + j] - x);
+        }
+    r.perm = similarity_order(r.table, G, method);
+    return r;
+}
+
+std::string similarity_table_string(const SimilarityResult &r, const std::vector<std::string> &groups) {
+    const size_t G = groups.size();
+    std::string res = "group";
+    for (size_t k = 0; k < G; ++k) res += "\t" + groups[r.perm[k]];
+    res += "\n";
+    for (size_t i = 0; i < G; ++i) {
+        res += groups[r.perm[i]];
+        for (size_t j = 0; j < G; ++j) res += "\t" + format_f32(r.table[r.perm[i] * G + r.perm[j]]);
+        res += "\n";
+    }
+    return res;
+}
+
 std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     CountType ct = count_types(o.count, false)[0];
     ClusterMethod method;
@@ -329,30 +351,9 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
         throw std::runtime_error("invalid value '" + o.method + "' for --method (single, complete, average, weighted, ward, centroid, median)");
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
-    const size_t G = order.groups.size();
     Device dev(o.device);
     upload(dev, *g, ct, order, masking(o));
-    std::vector<uint64_t> inter(G * G, 0);
-    if (G) dev.check(pnx_group_intersections(dev.ctx, inter.data()));
-    for (size_t a = 0; a < G; ++a)
-        if (inter[a * G + a] == 0)  // path_lens[&a] on a missing key panics in the reference (:163)
-            throw std::runtime_error("group " + order.groups[a] + " covers no item: the reference panics here");
-    std::vector<float> table(G * G);
-    for (size_t i = 0; i < G; ++i)
-        for (size_t j = 0; j < G; ++j) {
-            const uint64_t x = inter[i * G + j];
-            table[i * G + j] = (float)x / (float)(inter[i * G + i] + inter[j * G + j] - x);
-        }
-    const std::vector<size_t> perm = similarity_order(table, G, method);
-    std::string res = metadata_comments(cmdline) + "group";
-    for (size_t k = 0; k < G; ++k) res += "\t" + order.groups[perm[k]];
-    res += "\n";
-    for (size_t i = 0; i < G; ++i) {
-        res += order.groups[perm[i]];
-        for (size_t j = 0; j < G; ++j) res += "\t" + format_f32(table[perm[i] * G + perm[j]]);
-        res += "\n";
-    }
-    return res;
+    return metadata_comments(cmdline) + similarity_table_string(device_similarity(dev, order.groups, o.method), order.groups);
 }
 
 // AbacusByGroup::to_tsv (abacus.rs:1056-1178): one row per item.  With `total` the number of groups
@@ -433,7 +434,9 @@ bool ends_with(const std::string &s, const std::string &suf) {
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
-}  // namespace
+}  // namespace cli
+
+using namespace cli;
 
 int run_cli(const std::vector<std::string> &argv, std::string &out, std::string &err) {
     std::string cmdline;
@@ -465,6 +468,8 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--cache") o.cache = true;
             else if (a == "-m" || a == "--method") o.method = value("--method");
+            else if (a == "-j" || a == "--json") o.json = true;
+            else if (a == "-d" || a == "--dry-run") o.dry_run = true;
             else if (a == "--links") o.links = true;
             else if (a == "--sequences") o.sequences = true;
             else if (a == "-a" || a == "--hist" || a == "--total") o.add_hist = o.total = true;
@@ -484,10 +489,18 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
                   " paths, " + std::to_string(steps) + " steps\n";
             return 0;
         }
+        if (o.cmd == "report" && o.file.empty()) {  // src/commands/report.rs:47-66
+            out = "\n# Missing YAML file!\n#\n# Example YAML:\n# To get started copy this into a .yaml file and edit it\n\n"
+                  "- graph: ../graphs/test_graph.gfa\n  grouping: Haplotype\n  analyses:\n    - !Hist\n      count_type: Bp\n"
+                  "    - !Growth\n      coverage: 1,1,2\n      quorum: 0,0.9,0\n\n";
+            return 0;
+        }
         if (o.file.empty()) throw std::runtime_error("missing input file");
         if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
         std::string table;
-        if (o.cmd == "hist") table = cmd_hist(o, cmdline);
+        if (o.cmd == "report") table = cmd_report(o, cmdline);
+        else if (o.json) table = cmd_json(o, cmdline);
+        else if (o.cmd == "hist") table = cmd_hist(o, cmdline);
         else if (o.cmd == "histgrowth") table = cmd_histgrowth(o, cmdline, false);
         else if (o.cmd == "growth") table = ends_with(o.file, "tsv") ? cmd_growth_from_hist(o, cmdline) : cmd_histgrowth(o, cmdline, true);
         else if (o.cmd == "ordered-histgrowth") table = cmd_ordered(o, cmdline);

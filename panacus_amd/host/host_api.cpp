@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "commands.hpp"
+#include "commands_internal.hpp"
 #include "gfa_graph.hpp"
 #include "tables.hpp"
 #include "growth_closed_form.hpp"
@@ -348,6 +349,26 @@ int pnh_linkage(const float *condensed, uint64_t n, int method, uint64_t *c1, ui
         g_host_err = e.what();
         return 1;
     }
+}
+
+// a float as the report JSON prints it (serde_json / ryu); returns the length
+uint64_t pnh_json_f64(double x, char *buf, uint64_t cap) {
+    const std::string s = pnh::cli::json_number_f64(x);
+    if (cap) {
+        const size_t n = std::min<size_t>(s.size(), cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
+}
+uint64_t pnh_json_f32(float x, char *buf, uint64_t cap) {
+    const std::string s = pnh::cli::json_number_f32(x);
+    if (cap) {
+        const size_t n = std::min<size_t>(s.size(), cap - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size();
 }
 
 }  // extern "C"

@@ -338,6 +338,25 @@ def format_f32(x) -> str:
     return buf.value.decode()
 
 
+def json_f64(x: float) -> str:
+    """an f64 as the report JSON prints it (serde_json / ryu)"""
+    L = load()
+    L.pnh_json_f64.restype = C.c_uint64
+    L.pnh_json_f64.argtypes = [C.c_double, C.c_char_p, C.c_uint64]
+    buf = C.create_string_buffer(64)
+    L.pnh_json_f64(float(x), buf, 64)
+    return buf.value.decode()
+
+
+def json_f32(x) -> str:
+    L = load()
+    L.pnh_json_f32.restype = C.c_uint64
+    L.pnh_json_f32.argtypes = [C.c_float, C.c_char_p, C.c_uint64]
+    buf = C.create_string_buffer(64)
+    L.pnh_json_f32(float(x), buf, 64)
+    return buf.value.decode()
+
+
 CLUSTER_METHODS = ["single", "complete", "average", "weighted", "ward", "centroid", "median"]
 
 

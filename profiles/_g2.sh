@@ -1,6 +1,5 @@
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r02b
-echo skip > gpurun_out/r02b/pytest.log
+( time python -m pytest tests/test_host_report.py tests/test_host_cli.py -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/r02b/pytest.log 2>&1
 cat gpurun_out/r02b/pytest.log
-python benchmarks/bench_run_route.py > gpurun_out/r02b/run_route.json 2>gpurun_out/r02b/rr.err; cat gpurun_out/r02b/run_route.json; tail -3 gpurun_out/r02b/rr.err
