@@ -160,6 +160,29 @@ int pnx_ordered_growth_device(pnx_ctx *ctx, uint64_t **d_out); /* R*T*G u64 */
 int pnx_ordered_growth_enqueued(pnx_ctx *ctx, uint64_t **d_out);
 int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
 
+/* ---- multi-GPU: one process per GPU, an RCCL communicator owned by the context ------------------
+ * The reference has no collective (a single-process rayon program); every quantity of the hot path
+ * is a sum over items, so the items shard by id range over the GPUs of a node (or the orders of a
+ * permuted-growth call do) and the only exchange is an all-reduce (sum) of small u64 counter arrays
+ * over xGMI.  Rank 0 calls pnx_comm_unique_id and the HOST carries the 128 bytes to the other
+ * processes (file, pipe, MPI, ...); then every rank calls pnx_comm_init(id, rank, world).  From then on
+ *   - every coverage pass of the context is followed, on pnx_stream() and before its counters are
+ *     copied to the host, by an all-reduce of its verification flags and histogram: pnx_hist,
+ *     pnx_hist_fetch, pnx_hist_device return the GLOBAL histogram, and a pass that has to be run again
+ *     (paths that are not tile-monotone) is run again by EVERY rank, so the collectives stay matched.
+ *     Every rank therefore makes the same sequence of pnx_hist* calls.  countable stays local (it is the
+ *     rank's own item range).  PNX_CFG_COMM_REDUCE_HIST = 0 switches this off (hosts that shard the
+ *     orders instead of the items);
+ *   - pnx_comm_allreduce_u64 sums any device buffer in place over the ranks, enqueued on pnx_stream():
+ *     e.g. the buffer of pnx_ordered_growth_enqueued.
+ * librccl.so is opened with dlopen by the first of these calls; a single-GPU process never loads it.
+ * PNX_ENODEV: librccl.so cannot be loaded. */
+#define PNX_COMM_ID_BYTES 128
+int pnx_comm_unique_id(uint8_t id[PNX_COMM_ID_BYTES]);
+int pnx_comm_init(pnx_ctx *ctx, const uint8_t id[PNX_COMM_ID_BYTES], int rank, int world);
+int pnx_comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n);
+int pnx_comm_free(pnx_ctx *ctx);   /* also done by pnx_free */
+
 /* ---- group x group intersections ("next" row: similarity) ----------------------------------
  * Replaces the accumulation loop of Similarity::set_table (src/analyses/similarity.rs:119-150),
  * which walks AbacusByGroup's (r, c) and sums, for every item, node_len (bp) or 1 (node / edge)
@@ -258,6 +281,8 @@ enum {
                                   2 = never */
     PNX_CFG_INDEX_PROBE = 12,  /* ids read by the second and later probes of an index search: 16 [default] = one 64-byte
                                   sector, 32 = one 128-byte line (fewer rounds per wave, more requests: measured slower) */
+    PNX_CFG_COMM_REDUCE_HIST = 13, /* with a communicator (pnx_comm_init): 1 [default] every coverage pass is followed by the
+                                  all-reduce of its flags + histogram, 0 the caller reduces what it needs itself */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */

@@ -22,7 +22,7 @@ LIB_HIP = os.path.join(HERE, "libpanacus_hip.so")
 LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
-HIP_SOURCES = ["pnx_api.hip", "kernels_cover.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_closed_form.hip", "pansyn.hip"]
+HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "kernels_cover.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_closed_form.hip", "pansyn.hip"]
 HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "mini_yaml.cpp", "report.cpp", "commands.cpp", "host_api.cpp"]
 
 
@@ -73,7 +73,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         if verbose and out.strip():
             print(out)
     if force or procs or _newer(LIB_HIP, objs):
-        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs)
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs + ["-ldl"])
     return LIB_HIP
 
 

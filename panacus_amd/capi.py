@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
 K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
 KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
-CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
+    "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free",
 ]
 
 
@@ -90,6 +91,10 @@ def load() -> C.CDLL:
     L.pnx_presence_row_words.restype = C.c_uint64
     L.pnx_presence.argtypes = [vp, u64p]
     L.pnx_share_csr.argtypes = [vp, vp]
+    L.pnx_comm_unique_id.argtypes = [u8p]
+    L.pnx_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
+    L.pnx_comm_allreduce_u64.argtypes = [vp, vp, C.c_size_t]
+    L.pnx_comm_free.argtypes = [vp]
     L.pnx_group_visit_counts.argtypes = [vp, C.c_uint32, C.c_uint32, u32p]
     f64p = C.POINTER(C.c_double)
     L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
@@ -297,6 +302,28 @@ class Context:
         if G and rw:
             self._ck(self._L.pnx_presence(self._h, _ptr(out, C.c_uint64)))
         return out
+
+    # ---- multi-GPU (RCCL communicator owned by the context) ----
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128 bytes that rank 0 hands to the other processes (any transport) for comm_init"""
+        L = load()
+        buf = (C.c_uint8 * 128)()
+        rc = L.pnx_comm_unique_id(buf)
+        if rc != PNX_OK:
+            raise PnxError(rc, "pnx_comm_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self._L.pnx_comm_init(self._h, buf, rank, world))
+
+    def comm_allreduce_u64(self, d_ptr: int, n: int):
+        """in-place sum over the ranks of n u64 at device pointer d_ptr, enqueued on the context's stream"""
+        self._ck(self._L.pnx_comm_allreduce_u64(self._h, C.c_void_p(d_ptr), n))
+
+    def comm_free(self):
+        self._ck(self._L.pnx_comm_free(self._h))
 
     def share_csr(self, src: "Context"):
         """read the graph resident in `src` (same device) without a copy; keep `src` open meanwhile"""

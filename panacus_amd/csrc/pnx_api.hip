@@ -139,6 +139,7 @@ static int enqueue_pass(pnx_ctx *ctx) {
     ctx->cur = t;
     int rc = launch_cover_pass(ctx);
     if (rc) return rc;
+    if ((rc = comm_reduce_pass(ctx, t))) return rc;  // multi-GPU: global flags + histogram (no-op without a communicator)
     if ((rc = stage_results(ctx, t))) return rc;
     t->in_flight = true;
     ctx->tk_next ^= 1;
@@ -184,6 +185,8 @@ static int settle_oldest(pnx_ctx *ctx) {
         }
         ctx->cur = t;
         if ((rc = launch_cover_pass(ctx))) return rc;
+        // the flags were reduced over all ranks, so every rank is here: the collectives stay matched
+        if ((rc = comm_reduce_pass(ctx, t))) return rc;
         if ((rc = stage_results(ctx, t))) return rc;
     }
     return ctx->fail(PNX_EHIP, "coverage pass did not converge (internal error)");
@@ -237,6 +240,7 @@ int pnx_init(pnx_ctx **out, int device) {
 void pnx_free(pnx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)pnx_comm_free(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream_cf) (void)hipStreamSynchronize(ctx->stream_cf);
     prof_resolve(ctx);
@@ -848,6 +852,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             return PNX_OK;
         case PNX_CFG_BLOCKING_SYNC:
             ctx->blocking_sync = value != 0;
+            return PNX_OK;
+        case PNX_CFG_COMM_REDUCE_HIST:
+            if (ctx->tk_count) return ctx->fail(PNX_EINVAL, "PNX_CFG_COMM_REDUCE_HIST cannot change while a pass is in flight");
+            ctx->comm_reduce_hist = value != 0;
             return PNX_OK;
         case PNX_CFG_KEEP_PRESENCE:
             ctx->keep_M_user = value != 0;

@@ -171,6 +171,11 @@ struct pnx_ctx {
     hipEvent_t ev_cf = nullptr;
     bool cf_pending = false;
 
+    // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----
+    void *comm = nullptr;          // ncclComm_t
+    int comm_rank = 0, comm_world = 1;
+    bool comm_reduce_hist = false; // every coverage pass is followed by an all-reduce of its flags + histogram
+
     pnx::Profile prof;
 
     int fail(int code, const char *fmt, ...) {
@@ -217,6 +222,9 @@ int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p i
 int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
 int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // lo, hi: caller ids  // -> n_groups x (hi - lo) u32
+// pnx_comm.hip
+int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n);
+int comm_reduce_pass(pnx_ctx *ctx, Ticket *t);
 // kernels_relabel.hip
 int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys);
 int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_caller);

@@ -90,3 +90,28 @@ def gather_countable(local: np.ndarray, cuts: np.ndarray, rank: int, device=None
 def split_orders(n_orders: int, world: int, rank: int) -> range:
     """Permutation sharding for permuted growth: rank r evaluates orders r, r+world, ..."""
     return range(rank, n_orders, world)
+
+
+def native_comm_init(ctx, rank: int, world: int, id_file: str, timeout_s: float = 120.0):
+    """Give `ctx` the library's own RCCL communicator (pnx_comm_init): rank 0 asks the library for the
+    128-byte id and publishes it through `id_file` (written under a temporary name and renamed, so a
+    reader never sees half of it); the other ranks wait for the file.  No torch involved -- the same
+    three steps a Rust host takes."""
+    import os
+    import time
+    if rank == 0:
+        uid = type(ctx).comm_unique_id()
+        tmp = f"{id_file}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, id_file)
+    else:
+        t0 = time.time()
+        while not (os.path.exists(id_file) and os.path.getsize(id_file) == 128):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"no communicator id at {id_file} after {timeout_s} s")
+            time.sleep(0.01)
+        with open(id_file, "rb") as f:
+            uid = f.read()
+    ctx.comm_init(uid, rank, world)
+    return uid

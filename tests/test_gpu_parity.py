@@ -611,6 +611,55 @@ def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path):
     assert np.array_equal(cnt3, orc.coverage(items, pre, pi, gi, n))
 
 
+def test_native_rccl_communicator_single_rank(tmp_path):
+    """pnx_comm_*: the library's own RCCL communicator (dlopen of librccl.so).  With one rank the sums
+    are identities, but every call takes the real path: id, ncclCommInitRank, the all-reduce of flags +
+    histogram behind every coverage pass (also behind the re-run of a pass whose paths are not
+    tile-monotone), and pnx_comm_allreduce_u64 on the buffer of a growth call in flight."""
+    from panacus_amd import capi
+    from panacus_amd.distributed import native_comm_init
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p = 50_000, 12
+    items, pre, lens = orc.pansyn(61, n, p)
+    jit = items.copy()
+    for k in range(p):   # nearly monotone paths: a window reversed every 300 steps
+        seg = jit[int(pre[k]):int(pre[k + 1])]
+        m = (len(seg) // 300) * 300
+        v = seg[:m].reshape(-1, 300)
+        v[:, :40] = v[:, :40][:, ::-1].copy()
+    pi = np.arange(p, dtype=np.uint64)
+    ocov = orc.coverage(jit, pre, pi, pi, n)
+    oh = orc.hist(ocov, p)
+    with capi.Context(0) as c:
+        with pytest.raises(capi.PnxError):
+            c.comm_allreduce_u64(0, 4)                       # no communicator yet
+        with pytest.raises(capi.PnxError):
+            c.comm_init(bytes(128), 3, 2)                    # rank outside the world
+        uid = native_comm_init(c, 0, 1, str(tmp_path / "comm.id"))
+        assert len(uid) == 128 and os.path.getsize(str(tmp_path / "comm.id")) == 128
+        with pytest.raises(capi.PnxError):
+            c.comm_init(uid, 0, 1)                           # one communicator per context
+        c.set_csr(jit.astype(np.uint32), pre, n)
+        c.set_order(pi, pi, p)
+        cnt, h = c.hist()                                    # first pass classifies, is re-run: two collectives
+        assert c.info().n_reruns >= 1 and c.info().n_run_paths == p
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+        c.hist_async()
+        c.hist_async()
+        assert np.array_equal(c.hist_fetch()[1], oh) and np.array_equal(c.hist_fetch()[1], oh)
+        cov = [coverage_abs(Threshold(ABSOLUTE, 1), p)]
+        qt = quorum_table(Threshold(RELATIVE, 0.3), p)[None, :]
+        shape = c.ordered_growth_async(cov, qt)
+        c.comm_allreduce_u64(c.ordered_growth_enqueued(), int(np.prod(shape)))
+        out = c.ordered_growth_fetch(shape)
+        r, cc = orc.by_group(jit, pre, pi, pi, n)
+        assert out[0, 0].tolist() == [int(x) for x in orc.ordered_growth(r, cc, p, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.3))]
+        c.config(capi.CFG_COMM_REDUCE_HIST, 0)
+        assert np.array_equal(c.hist()[1], oh)
+        c.comm_free()
+        assert np.array_equal(c.hist()[1], oh)
+
+
 def test_two_passes_in_flight(ctx):
     """pnx_hist_async may be called twice before the first result is fetched; results come back
     oldest first and are identical; a third enqueue is refused; a violation found in an

@@ -517,6 +517,15 @@ def test_multi_gpu_tool_matches_cli(golden_dir, tmp_path):
         rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5", "-S", gfa])
         assert rc == 0, err
         assert text == _body(out).rstrip("\n") + "\n"
+    # the same through the library's own RCCL communicator (one rank; no torch involved)
+    os.environ.update(PANACUS_DIST_BACKEND="native", PANACUS_NATIVE_SINGLE="1", PANACUS_COMM_ID_FILE=str(tmp_path / "c.id"))
+    try:
+        text = mod.main(["-c", "bp", "-l", "1,2", "-q", "0,0.5", "-S", "-o", str(tmp_path / "n.tsv"), gfa])
+    finally:
+        for k in ("PANACUS_DIST_BACKEND", "PANACUS_NATIVE_SINGLE", "PANACUS_COMM_ID_FILE"):
+            del os.environ[k]
+    rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", "bp", "-l", "1,2", "-q", "0,0.5", "-S", gfa])
+    assert text == _body(out).rstrip("\n") + "\n"
 
 
 @pytest.mark.gpu

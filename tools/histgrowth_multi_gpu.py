@@ -2,6 +2,14 @@
 """`histgrowth` of a GFA file on all GPUs of a node: one process per GPU, node-range shards,
 one RCCL all-reduce of the histogram counters.
 
+PANACUS_DIST_BACKEND selects who carries the collective:
+  native  the library's own RCCL communicator (pnx_comm_init; no torch at all): the all-reduce of the
+          flags + histogram follows every coverage pass on the library's stream, re-runs stay matched
+          across ranks.  The 128-byte id travels through PANACUS_COMM_ID_FILE
+          [default /tmp/panacus_comm_<MASTER_PORT>.id]
+  nccl    [default] torch.distributed over RCCL, on the verified device counters
+  gloo    torch.distributed over gloo, on the fetched host counters (tests: two ranks on one GPU)
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         tools/histgrowth_multi_gpu.py -c bp -l 1,2 -q 0,0.5 [-S|-H|-g FILE] graph.gfa
 
@@ -41,7 +49,7 @@ def main(argv=None):
     # PANACUS_DIST_BACKEND=gloo reduces the fetched host counters over gloo instead (tests: two ranks
     # on one GPU, which RCCL refuses)
     backend = os.environ.get("PANACUS_DIST_BACKEND", "nccl")
-    if world > 1:  # torch is only the carrier of the collective
+    if world > 1 and backend != "native":  # torch is only the carrier of the collective
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -73,6 +81,10 @@ def main(argv=None):
     ctx = capi.Context(local_rank)
     ctx.set_csr(it_r, off_r, n_r, weights=shard_weights(weights, lo, hi))
     ctx.set_order(pi, gi, G)
+    if backend == "native" and (world > 1 or os.environ.get("PANACUS_NATIVE_SINGLE") == "1"):
+        from panacus_amd.distributed import native_comm_init
+        id_file = os.environ.get("PANACUS_COMM_ID_FILE") or f"/tmp/panacus_comm_{os.environ.get('MASTER_PORT', '29544')}.id"
+        native_comm_init(ctx, rank, world, id_file)
     # A one-shot host for ARBITRARY graphs verifies the pass BEFORE it reduces: a real GFA may hold
     # paths that are not tile-monotone; the first pass then only classifies them, the library builds
     # the run index and runs the pass again inside pnx_hist_fetch -- counters reduced from the first
@@ -97,9 +109,10 @@ def main(argv=None):
         ext.synchronize()
         h = host.numpy().view(np.uint64).copy()
         del t, tot, ext
-    elif world > 1:
+    elif world > 1 and backend != "native":
         from panacus_amd.distributed import allreduce_counters
         h = allreduce_counters(h)
+    # native: pnx_hist_fetch already returned the global histogram
     # every shard counts its own sentinel-free items; items in no group of any shard are bin 0
     text = None
     if rank == 0:
@@ -122,7 +135,7 @@ def main(argv=None):
         else:
             sys.stdout.write(text)
     reruns = int(ctx.info().n_reruns)
-    if world > 1:
+    if world > 1 and backend != "native":
         torch.cuda.synchronize()
         dist.destroy_process_group()
     ctx.close()
