@@ -210,6 +210,12 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         done = torch.cuda.Event(blocking=blocking)
         idx = torch.tensor(mine, dtype=torch.int64, device=dev)
         views = {}
+        native = args.collective == "native"
+        if native:
+            ctx.config(capi.CFG_COMM_REDUCE_HIST, 0)  # orders are sharded here, not items: nothing to reduce per pass
+            uid = [capi.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], rank, world)
 
         def call(k):
             if mine:
@@ -223,7 +229,10 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
                 full.zero_()
                 if mine:
                     full.index_copy_(0, idx, t)
-                dist.all_reduce(full)  # RCCL; int64 sum == u64 sum (counts < 2^63)
+                if native:
+                    ctx.comm_allreduce_u64(full.data_ptr(), full.numel())  # the library's communicator, same stream
+                else:
+                    dist.all_reduce(full)  # RCCL; int64 sum == u64 sum (counts < 2^63)
                 ev_b[k].record(ext)
                 if rank == 0:
                     host.copy_(full, non_blocking=True)
@@ -244,6 +253,8 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         dt, gk_ms, ar_ms = (float(x) for x in red.tolist())
         full_host = host.numpy().view(np.uint64).copy() if rank == 0 else None
+        if native:
+            ctx.comm_free()
         views.clear()
         del ext, full, host, idx
     ctx.profile_enable(False)
@@ -268,7 +279,8 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
             "seconds_per_call_1gpu": t1, "speedup_vs_1": t1 / dt,
             "growth_kernel_ms_rank_max": gk_ms, "growth_kernel_ms_1gpu": k1[0] / max(k1[1], 1),
             "allreduce_ms": ar_ms,
-            "collective_path": "rccl via torch.distributed (nccl backend) on pnx_stream()" if use_dist else "none (one rank)",
+            "collective_path": ("none (one rank)" if not use_dist else "rccl through the library's own communicator (pnx_comm_allreduce_u64) on pnx_stream()"
+                                if args.collective == "native" else "rccl via torch.distributed (nccl backend) on pnx_stream()"),
             "presence_pack_ms": pack_s * 1e3, "presence_pack_cover_kernel_ms": cover_ms,
             "presence_pack_algorithmic_bytes": b_pack,
             "presence_pack_cover_kernel_GBps": b_pack / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
@@ -388,6 +400,9 @@ def main():
                     help="contexts (streams) over the one resident graph whose passes alternate.  1 [default]: one "
                          "stream, the coverage kernel is timed alone (what `roofline` is defined on); 2: +11 %% passes/s, "
                          "but two coverage kernels then overlap and a launch takes 1.1 ms (DESIGN.md section 5)")
+    ap.add_argument("--collective", choices=["torch", "native"], default="torch",
+                    help="who carries the RCCL all-reduce when there is one: torch.distributed's nccl backend [default] or the "
+                         "library's own communicator (pnx_comm_init; the id travels through torch's store)")
     ap.add_argument("--no-quorum-offload", action="store_true")
     ap.add_argument("--quorum-offload-min-n", type=int, default=512)
     args = ap.parse_args()
@@ -463,7 +478,14 @@ def main():
             self.ctx = ctx
             self.group = group
             self.hist_views = {}
-            if use_dist:
+            self.native = use_dist and args.collective == "native"
+            if self.native:
+                # the library reduces flags + histogram behind every pass by itself (pnx_comm_init): the lane
+                # is then the plain single-GPU pipeline
+                uid = [type(ctx).comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(uid[0], rank, world)
+            elif use_dist:
                 # the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind the
                 # pass on the library's own stream (a collective on another stream would have to wait
                 # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
@@ -476,7 +498,7 @@ def main():
         def enqueue(self):
             ctx = self.ctx
             ctx.hist_async()
-            if use_dist:
+            if use_dist and not self.native:
                 d_hist = ctx.hist_enqueued()
                 t = self.hist_views.get(d_hist)
                 if t is None:
@@ -493,7 +515,7 @@ def main():
         def settle(self):
             """wait for the OLDEST enqueued pass of this lane; multi-GPU: its all-reduced counters"""
             ctx = self.ctx
-            if use_dist:
+            if use_dist and not self.native:
                 slot = self.ring[self.fin % 2]
                 self.fin += 1
                 slot["ev"].synchronize()
@@ -509,7 +531,9 @@ def main():
             return h
 
         def close(self):
-            if use_dist:
+            if self.native:
+                self.ctx.comm_free()
+            elif use_dist:
                 # torch objects that were used on the library's stream (pinned buffers record it when
                 # they are freed) must go before the stream does
                 self.ring.clear()
@@ -643,6 +667,7 @@ def main():
                 "nodes_per_gpu": N, "paths": P, "groups": P, "steps_in_csr": S, "seed": args.seed,
                 "threshold_pairs": pairs, "tile_items": int(info.tile_items),
                 "parallelism": "node-range shards, RCCL all-reduce of hist counters" if world > 1 else "single GPU",
+                "collective": args.collective if use_dist else None,
             },
             "roofline": {
                 "bound": "hbm",

@@ -23,6 +23,7 @@
 //   * bp counts use bit planes of the weights: sum_i w_i b_i = sum_p 2^p popc(b & W_p).
 // Orders are independent, so R orders shard over workgroups (and over GPUs: permutation
 // sharding, DESIGN.md "Multi-GPU").
+#include <cstdlib>
 #include <type_traits>
 
 #include "pnx_context.hpp"
@@ -231,7 +232,9 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
 //   * per-rank popcounts (<= 32 per lane) are packed two per register for the 16 ranks of
 //     a batch and reduced over the wave once per batch (8 packed DPP reductions instead of
 //     16), then lanes 0..15 add the 16 totals to the workgroup's LDS accumulators.
-// Workgroups of one block chunk carry consecutive blockIdx for all R orders.
+// Workgroups of one block chunk carry consecutive blockIdx for all R orders.  (Giving all R orders of a
+// chunk to ONE XCD -- chunk % 8, so that its L2 serves a row to R orders for one fetch -- was measured:
+// 18.8 against 18.2 ms on cfg4; the kernel is bound by VALU issue, not by the rows.)
 // ------------------------------------------------------------------------------------------
 struct GrowthTabs {
     int32_t q0_midx[GROW_Q0_MAX];   // mask index per q == 0 pair, -1 = none
@@ -243,7 +246,7 @@ struct GrowthTabs {
 // WMODE: 0 = items count 1, 1 = weights below 2^16 (staged as u16: 4 KB of LDS per wave),
 //        2 = any u32 weights (8 KB per wave)
 template <int NPL1, int N0, int NQ, int WMODE>
-__global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_fused(
+__global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1) void k_growth_fused(
     const uint32_t *__restrict__ M, uint32_t n_blocks, uint32_t G,
     const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
     uint32_t blocks_per_chunk, const uint32_t *__restrict__ cmask, GrowthTabs tabs,
@@ -609,7 +612,12 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
     PNX_HIP(ctx, hipGetLastError());
 
     // geometry: chunk-major grid (all R orders of a block chunk are neighbours in blockIdx)
-    uint32_t n_chunks = std::max<uint32_t>(4096 / R, (NB + 63) / 64);
+    // enough workgroups for several rounds over the chip's wave slots (a short last round costs little
+    // then), but not so many that the per-workgroup work -- clearing and flushing the LDS accumulators --
+    // shows: R orders x n_chunks ~ 8 x (CUs x 6 workgroups of 4 waves)
+    uint32_t target_wgs = 8u * (uint32_t)ctx->prop.multiProcessorCount * 6u;
+    if (const char *e = std::getenv("PNX_GROWTH_WGS")) target_wgs = (uint32_t)std::atoi(e);  // experiments
+    uint32_t n_chunks = std::max<uint32_t>(target_wgs / R, (NB + 63) / 64);
     if (n_chunks < 1) n_chunks = 1;
     const uint32_t max_chunks = (NB + GROW_WAVES - 1) / GROW_WAVES;
     if (n_chunks > max_chunks) n_chunks = max_chunks;

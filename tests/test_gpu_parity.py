@@ -997,7 +997,8 @@ def test_bench_contract_line_small(tmp_path):
              "--pg-nodes", "150000", "--pg-paths", "40", "--pg-orders", "10", "--pg-reps", "2",
              "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4"]
     for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {}),
-                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
+                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {"PANACUS_BENCH_FORCE_DIST": "1"}),
+                       (["--lanes", "1", "--no-cpu-baseline", "--no-shape-1k", "--collective", "native"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
         sock = socket.socket()
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -1028,8 +1029,8 @@ def test_bench_contract_line_small(tmp_path):
             assert k1["checks"]["hist_sum"] == 150000 and k1["breakdown_ms"]["tile_cover"] > 0
         outs.append(d["checks"])
         pgs.append(pg["checks"])
-    assert outs[0] == outs[1] == outs[2]
-    assert pgs[0] == pgs[1] == pgs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert pgs[0] == pgs[1] == pgs[2] == pgs[3]
 
 
 def test_full_size_cfg3_properties():
