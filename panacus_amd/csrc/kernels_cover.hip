@@ -29,8 +29,10 @@
 //     matrix, merged by K1 at flush time); the pass is re-run when a violation is first seen.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pnx_context.hpp"
+#include "step_chunks.hpp"
 
 namespace pnx {
 
@@ -56,6 +58,73 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
     hipLaunchKernelGGL(k_validate_items, dim3(grid), dim3(256), 0, ctx->stream,
                        (const uint32_t *)ctx->d_items.p, ctx->n_steps, ctx->n_items, d_bad);
     PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// step preparation: once per upload, one streaming pass over the steps
+//   * items16[j] = items[j] mod 4096.  A coverage wave owns one tile of 2048 (or 4096) ids, so inside
+//     its tile a step needs 11 (12) bits; the coverage kernel streams these 2-byte steps -- HALF the
+//     bytes of the u32 ItemTable, which stays resident for everything that needs whole ids (the index
+//     search, the run index, the scatter route, the read-back);
+//   * an EXACT classification of every path: tile-monotone (the sequence of 2048-id tiles of its
+//     steps never turns around; any disorder inside a tile is fine) or not.  A 2-byte step cannot
+//     tell which tile it came from, so the coverage kernel can no longer verify the boundary index
+//     step by step as it did in round 1 -- instead nothing is left to verify: for a tile-monotone
+//     path the boundary search is exact by construction, and every other path goes to the run /
+//     scatter routes before the first pass looks at it.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_steps(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                                       const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
+                                                       uint16_t *__restrict__ items16, uint8_t *__restrict__ path_dir) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const RunChunk ch = chunk_of(c, chunk_off, path_off, n_paths);
+    uint32_t dir = 0;  // bit 0: a step enters a higher tile than its predecessor, bit 1: a lower one
+    for (uint32_t it = 0; it < ch.len; it += 64) {
+        const uint64_t j = ch.start + it + lane;
+        const bool in = it + lane < ch.len;
+        const uint32_t cur = in ? items[j] : 0;
+        uint32_t prev = __shfl_up(cur, 1);
+        if (lane == 0 && in && j > ch.pstart) prev = items[j - 1];
+        if (in) {
+            items16[j] = (uint16_t)(cur & 4095u);
+            if (j > ch.pstart) {
+                const uint32_t tc = cur / BLOCK_ITEMS, tp = prev / BLOCK_ITEMS;
+                dir |= (tc > tp ? 1u : 0u) | (tc < tp ? 2u : 0u);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) dir |= __shfl_xor(dir, o);
+    if (lane == 0 && dir) atomicOr(reinterpret_cast<unsigned int *>(path_dir) + (ch.path >> 2), dir << ((ch.path & 3u) * 8u));
+}
+
+__global__ void k_mono_class(uint8_t *__restrict__ path_dir, uint32_t n_paths) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_paths) path_dir[p] = path_dir[p] == 3 ? 1 : 0;  // both directions seen: not tile-monotone
+}
+
+int prepare_steps(pnx_ctx *ctx) {
+    if (ctx->steps_prepared) return PNX_OK;
+    const uint32_t P = ctx->n_paths;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_items16, ctx->n_steps * sizeof(uint16_t) + 64)) ||
+        (rc = ensure(ctx, ctx->d_path_mono, ((size_t)(P ? P : 1) + 3) / 4 * 4)))
+        return rc;
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_path_mono.p, 0, ((size_t)(P ? P : 1) + 3) / 4 * 4, ctx->stream));
+    if (P && ctx->n_steps) {
+        if ((rc = ensure_chunk_off(ctx))) return rc;
+        const uint64_t n_chunks = ctx->h_chunk_off[P];
+        if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many path chunks");
+        hipLaunchKernelGGL(k_prepare_steps, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
+                           (const uint64_t *)ctx->d_chunk_off.p, P, n_chunks, (uint16_t *)ctx->d_items16.p,
+                           (uint8_t *)ctx->d_path_mono.p);
+        hipLaunchKernelGGL(k_mono_class, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_path_mono.p, P);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    ctx->steps_prepared = true;
     return PNX_OK;
 }
 
@@ -227,11 +296,11 @@ template <int W1, int W2>
 __global__ void k_tile_index_coarse(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                     uint32_t bpp, uint32_t n_paths, uint64_t n_entries, uint32_t tile_items,
                                     uint32_t coarse, uint64_t *__restrict__ B, TileIdx ix,
-                                    uint8_t *__restrict__ path_class) {
+                                    uint8_t *__restrict__ path_class, const uint8_t *__restrict__ path_mono) {
     uint32_t p, c;
     if (!index_slot(ix, bpp, n_paths, n_entries, p, c)) return;
     const uint32_t span = ix.tspan[p];
-    if (c == 0) path_class[p] = 0;  // the later passes of the index only ever raise it
+    if (c == 0) path_class[p] = path_mono[p];  // 0 tile-monotone (exact, prepare_steps), 1 = to be put on the run / scatter route
     uint32_t j;
     if (bpp) {  // slot c = the c-th coarse boundary
         const uint32_t n_coarse = (span + coarse - 1) / coarse + 1;  // j = 0, c, 2c, ..., span
@@ -386,6 +455,7 @@ static TileIdx tile_idx_view(const pnx_ctx *ctx) {
 int launch_tile_index(pnx_ctx *ctx) {
     const uint32_t tile_items = ctx->tile_blocks * BLOCK_ITEMS;
     int rc;
+    if ((rc = prepare_steps(ctx))) return rc;
     if ((rc = ensure_path_spans(ctx))) return rc;
     if ((rc = ensure(ctx, ctx->d_tile_idx, (ctx->idx_entries ? ctx->idx_entries : 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_class, ctx->n_paths ? ctx->n_paths : 1))) return rc;
@@ -413,7 +483,7 @@ int launch_tile_index(pnx_ctx *ctx) {
             hipLaunchKernelGGL(k_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->stream,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, ctx->n_paths,
                                ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
-                               (uint8_t *)ctx->d_path_class.p);
+                               (uint8_t *)ctx->d_path_class.p, (const uint8_t *)ctx->d_path_mono.p);
             if (coarse > 1)
                 hipLaunchKernelGGL(k_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->stream,
                                    (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ctx->n_paths,
@@ -508,7 +578,8 @@ __global__ void k_scatter_general(const uint32_t *__restrict__ items,
 // K1: tile coverage kernel (the dominant kernel of hist / histgrowth)
 // ------------------------------------------------------------------------------------------
 constexpr int COVER_WAVES = 4;   // waves (= tiles) per workgroup
-constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane
+constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane (u32 steps: the plain cross-check kernel)
+constexpr int COVER_UNROLL16 = 2;  // the same for the 2-byte steps: 2 x 64 lanes x 8 steps = 1024 steps per batch
 
 // runs of the run-route paths, sorted by (tile, group); see kernels_runs.hip
 struct SplitPts {  // cut points of the visiting order for the split coverage kernel
@@ -560,6 +631,41 @@ __device__ static inline void run_window_load(const RunView &rv, RunWindow &w, u
     w.start = ok ? rv.start[i] : 0ull;
 }
 
+// 16 bytes of 2-byte steps
+template <bool NT>
+__device__ static inline uint4 load_steps16(const uint16_t *p) {
+    if (NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+// OR the presence bits of the 8 steps of one 16-byte load into the wave's LDS bitmap.  The load holds the
+// positions jrel .. jrel + 7 of a segment whose valid steps are [rlo, rhi) (all relative to the 16-byte
+// aligned start of the segment's first load).  A step is 12 bits: word (id % 64), bit (id / 64 % 32) and,
+// for two-block tiles, the block (id / 2048 % 2); which tile it lies in is known from the segment, not
+// from the step (prepare_steps).  Steps outside [rlo, rhi) -- the neighbours of the segment's two ends in
+// their 16-byte groups -- OR a zero.
+template <int WT>
+__device__ static inline void fold8(uint32_t *bm, const uint4 &v, uint32_t jrel, uint32_t rlo, uint32_t rhi) {
+    const int a = (int)rlo - (int)jrel, b = (int)rhi - (int)jrel;
+    const uint32_t na = a <= 0 ? 0u : (a >= 8 ? 8u : (uint32_t)a), nb = b <= 0 ? 0u : (b >= 8 ? 8u : (uint32_t)b);
+    const uint32_t valid = ((1u << nb) - 1u) & ~((1u << na) - 1u);
+    if (valid == 0) return;
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t n0 = d[e], n1 = d[e] >> 16;
+        const uint32_t w0 = (n0 & 63u) + (WT == 2 ? ((n0 >> 11) & 1u) << 6 : 0u);
+        const uint32_t w1 = (n1 & 63u) + (WT == 2 ? ((n1 >> 11) & 1u) << 6 : 0u);
+        atomicOr(&bm[w0], ((valid >> (2 * e)) & 1u) << ((n0 >> 6) & 31u));
+        atomicOr(&bm[w1], ((valid >> (2 * e + 1)) & 1u) << ((n1 >> 6) & 31u));
+    }
+}
+
+// the plain cross-check kernel streams the u32 steps and checks every one against its tile
 template <uint32_t TILE>
 __device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint64_t &cursor, uint64_t cursor_end,
                                            uint32_t g, const uint32_t *__restrict__ items, uint32_t *bm, uint32_t lane,
@@ -585,6 +691,35 @@ __device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint
                 fold_steps<TILE>(bm, v[u], base + (uint64_t)u * 256 + lane * 4u, lo, hi, tile_lo, viol);
         }
         if (__any(viol) && lane == 0) atomicAdd(&flags[4], 1u);  // cannot happen: runs are built per tile
+        ++cursor;
+    }
+}
+
+// the runs of group g in this wave's tile, as 2-byte steps (a run lies inside one tile by construction)
+template <int WT>
+__device__ static inline void consume_runs16(const RunView &rv, RunWindow &w, uint64_t &cursor, uint64_t cursor_end,
+                                             uint32_t g, const uint16_t *__restrict__ items16, uint32_t *bm, uint32_t lane) {
+    constexpr int U = COVER_UNROLL16;
+    while (cursor < cursor_end) {
+        if (cursor - w.base >= 64) run_window_load(rv, w, cursor, cursor_end, lane);
+        const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(cursor - w.base));
+        if ((uint32_t)__builtin_amdgcn_readlane((int)w.group, k) != g) break;
+        const uint64_t lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w.start >> 32), k) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w.start, k);
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w.len, k);
+        const uint64_t base = lo & ~7ull;
+        const uint32_t rlo = (uint32_t)(lo - base), rhi = rlo + len;
+        for (uint32_t off = 0; off < rhi; off += 512u * U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t jrel = off + (uint32_t)u * 512u + lane * 8u;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (jrel < rhi) v[u] = *reinterpret_cast<const uint4 *>(items16 + base + jrel);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fold8<WT>(bm, v[u], off + (uint32_t)u * 512u + lane * 8u, rlo, rhi);
+        }
         ++cursor;
     }
 }
@@ -737,16 +872,6 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
 // two segments in flight and the HBM latency of one segment hides behind the VALU/LDS work
 // of the previous one.  NT selects non-temporal loads for the CSR stream (read exactly once).
 // ------------------------------------------------------------------------------------------
-template <bool NT>
-__device__ static inline uint4 load_steps(const uint32_t *p) {
-    if (NT) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const uint4 *>(p);
-}
-
 // RUNS = false compiles the run consumption out: the kernel of graphs whose paths are all
 // tile-monotone keeps its low register count (occupancy 5+ waves/SIMD, all tiles resident).
 // SPLIT > 1 gives every tile SPLIT waves of one workgroup; each takes a contiguous, group-aligned
@@ -761,14 +886,14 @@ __device__ static inline uint4 load_steps(const uint32_t *p) {
 // (normalize_order) a wave of a 100 000-contig graph loads a handful of windows per group.
 template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1, bool SKIP = false>
 __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
-    const uint32_t *__restrict__ items, TileIdx ix, OrdIdx oi,
+    const uint16_t *__restrict__ items16, TileIdx ix, OrdIdx oi,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
     uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv,
     SplitPts sp) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
-    constexpr int U = COVER_UNROLL;
+    constexpr int U = COVER_UNROLL16;
     constexpr int TPW = CW / SPLIT;  // tiles per workgroup
     static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
     __shared__ uint32_t bm_all[CW][WT * BLOCK_WORDS];
@@ -826,7 +951,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
         for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
 
     auto flush = [&](uint32_t g) {
-        if (RUNS && run_c < run_end) consume_runs<TILE>(rv, run_w, run_c, run_end, g, items, bm, lane, tile_lo, flags);
+        if (RUNS && run_c < run_end) consume_runs16<WT>(rv, run_w, run_c, run_end, g, items16, bm, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -851,21 +976,6 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-
-    auto fold = [&](const uint4 &v, uint64_t j, uint64_t lo, uint64_t hi, uint32_t &viol) {
-        const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint64_t idx = j + e;
-            if (idx >= lo && idx < hi) {
-                const uint32_t n = ids[e] - tile_lo;
-                if (n < TILE)
-                    atomicOr(&bm[(n & 63u) + ((n >> 11) << 6)], 1u << ((n >> 6) & 31u));
-                else
-                    viol = 1;
-            }
-        }
     };
 
     // ---- window of 64 order entries, one per lane -------------------------------------------
@@ -895,7 +1005,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
         w_lo = ba < bb ? ba : bb;
         const uint64_t len = (ba < bb ? bb : ba) - w_lo;
         w_len = (uint32_t)len;
-        if (len > 0xFFFFFFFFull) {  // not a segment this kernel can stream: hand the path to the general routes
+        if (len > 0x7FFFFFF0ull) {  // not a segment this kernel can stream (32-bit positions): hand the path to the general routes
             w_len = 0;
             path_class[ord_path[k]] = 1;
             atomicAdd(&flags[0], 1u);
@@ -952,12 +1062,12 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
     // prefetch state of the NEXT interesting entry
     uint4 nxt[U];
     auto issue = [&](uint64_t lo, uint64_t hi) {
-        const uint64_t base = lo & ~3ull;
+        const uint64_t base = lo & ~7ull;  // 8 steps = 16 bytes
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t j = base + (uint64_t)u * 256 + lane * 4u;
+            const uint64_t j = base + (uint64_t)u * 512 + lane * 8u;
             nxt[u] = make_uint4(0, 0, 0, 0);
-            if (j < hi) nxt[u] = load_steps<NT>(items + j);
+            if (j < hi) nxt[u] = load_steps16<NT>(items16 + j);
         }
     };
 
@@ -990,7 +1100,6 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
     for (;;) {
         const bool last = !have;
         const uint32_t g = last ? 0xFFFFFFFFu : e_g;
-        const uint32_t k_cur = k;
         // With runs the group change comes first: while the previous group is folded and its
         // runs are streamed only the prefetched segment is live, not a second copy of it.
         // Without runs the next segment is issued first, so its loads also cover the fold.
@@ -1014,27 +1123,21 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
             cur_g = g;
         }
         if (hi > lo) {
-            uint32_t viol = 0;
-            const uint64_t base = lo & ~3ull;
+            const uint64_t base = lo & ~7ull;
+            const uint32_t rlo = (uint32_t)(lo - base), rhi = (uint32_t)(hi - base);
 #pragma unroll
-            for (int u = 0; u < U; ++u) fold(cur[u], base + (uint64_t)u * 256 + lane * 4u, lo, hi, viol);
-            // long segments (> U*256 steps): the tail is streamed directly
-            for (uint64_t b2 = base + 256ull * U; b2 < hi; b2 += 256ull * U) {
+            for (int u = 0; u < U; ++u) fold8<WT>(bm, cur[u], (uint32_t)u * 512u + lane * 8u, rlo, rhi);
+            // long segments (> U*512 steps): the tail is streamed directly
+            for (uint32_t off = 512u * U; off < rhi; off += 512u * U) {
                 uint4 v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint64_t j = b2 + (uint64_t)u * 256 + lane * 4u;
+                    const uint32_t jrel = off + (uint32_t)u * 512u + lane * 8u;
                     v[u] = make_uint4(0, 0, 0, 0);
-                    if (j < hi) v[u] = load_steps<NT>(items + j);
+                    if (jrel < rhi) v[u] = load_steps16<NT>(items16 + base + jrel);
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) fold(v[u], b2 + (uint64_t)u * 256 + lane * 4u, lo, hi, viol);
-            }
-            if (__any(viol)) {
-                if (lane == 0) {
-                    path_class[ord_path[k_cur]] = 1;
-                    atomicAdd(&flags[0], 1u);
-                }
+                for (int u = 0; u < U; ++u) fold8<WT>(bm, v[u], off + (uint32_t)u * 512u + lane * 8u, rlo, rhi);
             }
         }
         if (last) break;
@@ -1149,6 +1252,13 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ coun
 // ------------------------------------------------------------------------------------------
 // one full pass for the current order: general bookkeeping -> scatter -> K1 -> K2
 // ------------------------------------------------------------------------------------------
+template <typename F>
+struct first_param;
+template <typename A0, typename... As>
+struct first_param<void (*)(A0, As...)> {
+    using type = A0;
+};
+
 template <int NPL, int WT>
 static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     const uint64_t row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
@@ -1159,6 +1269,9 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     const bool has_runs = rv.tile_off != nullptr;
     SplitPts sp{};
     auto launch = [&](auto kern, int cw, int split = 1) {
+        // the pipelined kernels stream the 2-byte steps, the plain cross-check kernel the u32 ItemTable
+        using items_ptr_t = typename first_param<decltype(kern)>::type;
+        const void *items_ptr = std::is_same<items_ptr_t, const uint16_t *>::value ? ctx->d_items16.p : ctx->d_items.p;
         const unsigned tpw = (unsigned)(cw / split);
         const unsigned grid = (ctx->n_tiles + tpw - 1) / tpw;
         // group-aligned cut points of the visiting order
@@ -1168,7 +1281,7 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
             sp.k[j] = (uint32_t)t;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_items.p, tile_idx_view(ctx), ord_idx_view(ctx),
+                           static_cast<items_ptr_t>(items_ptr), tile_idx_view(ctx), ord_idx_view(ctx),
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
                            use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,

@@ -25,38 +25,11 @@
 #include <rocprim/rocprim.hpp>
 
 #include "pnx_context.hpp"
+#include "step_chunks.hpp"
 
 namespace pnx {
 
-constexpr uint32_t RUN_CHUNK = 4096;      // steps per chunk (one wave walks one chunk)
 constexpr uint32_t RUN_MIN_AVG_LEN = 16;  // paths with shorter average runs stay on the scatter route
-
-// Chunk c of the graph = RUN_CHUNK consecutive steps of one path; chunk_off[p] = number of chunks of
-// the paths before p (a prefix sum over ceil(len / RUN_CHUNK), fixed per graph).  The kernels below
-// run over the chunks of ALL paths and leave at once for paths that take another route: the host
-// never builds a work list, so the whole build is a chain of launches on the stream.
-struct RunChunk {
-    uint64_t start;   // first step (absolute index into items)
-    uint64_t pstart;  // first step of the path
-    uint32_t len;     // steps in this chunk
-    uint32_t path;
-};
-
-__device__ static inline RunChunk chunk_of(uint64_t c, const uint64_t *__restrict__ chunk_off,
-                                           const uint64_t *__restrict__ path_off, uint32_t n_paths) {
-    uint32_t lo = 0, hi = n_paths;  // last p with chunk_off[p] <= c (empty paths own no chunk)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (chunk_off[mid] <= c) lo = mid; else hi = mid;
-    }
-    RunChunk ch;
-    ch.path = lo;
-    ch.pstart = path_off[lo];
-    ch.start = ch.pstart + (c - chunk_off[lo]) * RUN_CHUNK;
-    const uint64_t left = path_off[lo + 1] - ch.start;
-    ch.len = (uint32_t)(left < RUN_CHUNK ? left : RUN_CHUNK);
-    return ch;
-}
 
 // flag = this step starts a run (first step of the path, or a different tile than the step before)
 __device__ static inline bool run_starts(const uint32_t *__restrict__ items, uint64_t j, uint64_t pstart,
@@ -256,6 +229,20 @@ int sort_run_index(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+// chunk prefix of the graph (the host knows path_off): once per upload
+int ensure_chunk_off(pnx_ctx *ctx) {
+    if (ctx->chunk_off_valid) return PNX_OK;
+    const uint32_t P = ctx->n_paths;
+    ctx->h_chunk_off.assign((size_t)P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p)
+        ctx->h_chunk_off[p + 1] = ctx->h_chunk_off[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + RUN_CHUNK - 1) / RUN_CHUNK;
+    int rc = ensure(ctx, ctx->d_chunk_off, ((size_t)P + 1) * 8);
+    if (rc) return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_off.p, ctx->h_chunk_off.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->chunk_off_valid = true;  // h_chunk_off stays alive with the context
+    return PNX_OK;
+}
+
 // classify every path that is not tile-monotone (path_class 1, 2 or 3 on the device) into
 // run route (2) or scatter route (3) and build the run list of the run-route paths
 int build_run_index(pnx_ctx *ctx) {
@@ -268,15 +255,7 @@ int build_run_index(pnx_ctx *ctx) {
     ctx->n_scatter_paths = 0;
     ctx->n_run_paths = 0;
     if (P == 0) return sort_run_index(ctx);
-    // chunk prefix of the graph (host knows path_off): once per upload
-    if (!ctx->chunk_off_valid) {
-        ctx->h_chunk_off.assign((size_t)P + 1, 0);
-        for (uint32_t p = 0; p < P; ++p)
-            ctx->h_chunk_off[p + 1] = ctx->h_chunk_off[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + RUN_CHUNK - 1) / RUN_CHUNK;
-        if ((rc = ensure(ctx, ctx->d_chunk_off, ((size_t)P + 1) * 8))) return rc;
-        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_off.p, ctx->h_chunk_off.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->chunk_off_valid = true;  // h_chunk_off stays alive with the context
-    }
+    if ((rc = ensure_chunk_off(ctx))) return rc;
     const uint64_t n_chunks = ctx->h_chunk_off[P];
     if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many path chunks for the run index");
     DevBuf &d_counts = ctx->d_rb[0], &d_wide = ctx->d_rb[1], &d_offs = ctx->d_rb[2], &d_rop = ctx->d_rb[3], &d_meta = ctx->d_rb[4],

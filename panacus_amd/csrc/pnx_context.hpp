@@ -85,6 +85,13 @@ struct pnx_ctx {
     bool have_csr = false, weighted = false, have_exclude = false;
     bool have_weights = false;  // weights are resident (weighted = resident AND enabled)
     pnx::DevBuf d_items, d_path_off, d_weights, d_exclude;
+    // derived once per upload by one streaming pass (prepare_steps, kernels_cover.hip), shared by borrowers:
+    //   d_items16   S x u16: the step ids modulo 4096 -- inside its tile a step needs no more, and the
+    //               coverage kernel streams these 2 bytes per step instead of 4;
+    //   d_path_mono P x u8: 1 = the path is NOT tile-monotone (its 2048-id tile sequence goes both up
+    //               and down), decided exactly; 0 = the boundary index serves it
+    pnx::DevBuf d_items16, d_path_mono;
+    bool steps_prepared = false;
     std::vector<uint64_t> h_path_off;
     // internal renumbering of the items by a caller key (kernels_relabel.hip): resident steps, weights and
     // flags are in INTERNAL ids; per-item results are mapped back to the caller's ids on the way out
@@ -210,9 +217,11 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
 // kernels_cover.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
+int prepare_steps(pnx_ctx *ctx);  // d_items16 + d_path_mono (no-op when done)
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
 // kernels_runs.hip
+int ensure_chunk_off(pnx_ctx *ctx);
 int build_run_index(pnx_ctx *ctx);
 int sort_run_index(pnx_ctx *ctx);
 // kernels_growth.hip
