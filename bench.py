@@ -404,7 +404,7 @@ def main():
                     help="who carries the RCCL all-reduce when there is one: torch.distributed's nccl backend [default] or the "
                          "library's own communicator (pnx_comm_init; the id travels through torch's store)")
     ap.add_argument("--no-quorum-offload", action="store_true")
-    ap.add_argument("--quorum-offload-min-n", type=int, default=512)
+    ap.add_argument("--quorum-offload-min-n", type=int, default=256)
     args = ap.parse_args()
 
     import torch

@@ -123,7 +123,7 @@ bool exp2_restatement_matches_libm() {
 
 std::mutex g_offload_mu;
 pnx_ctx *g_offload_ctx = nullptr;
-uint64_t g_offload_min_n = 512;
+uint64_t g_offload_min_n = 256;
 
 // The (n+1)^2 term arrays are recycled across calls: fresh 8 MB allocations are mmap'ed by
 // malloc and first touched by all workers at once, and those page faults (plus the munmap

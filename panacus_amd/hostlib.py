@@ -406,7 +406,7 @@ def usable_cpus() -> int:
     return int(L.pnh_usable_cpus())
 
 
-def set_quorum_offload(ctx=None, min_n: int = 512):
+def set_quorum_offload(ctx=None, min_n: int = 256):
     """Quorum closed form with n >= min_n: the O(n^3) inner sums run on the GPU of `ctx`
     (a capi.Context), bit-identical to the host path; None switches it off."""
     L = load()
