@@ -132,7 +132,9 @@ int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
  * pnx_hist_fetch / pnx_hist_device had to run it again. */
 int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist);
 int pnx_sync(pnx_ctx *ctx);
-/* raw hipStream_t of the context (for RCCL / event interop in the host layer) */
+/* raw hipStream_t of the context (for RCCL / event interop in the host layer): the stream of the coverage
+ * kernels and of every growth / intersection call.  The counters of a pass are written on an internal
+ * stream; pnx_hist_enqueued makes pnx_stream() wait for them. */
 void *pnx_stream(pnx_ctx *ctx);
 
 /* ---- ordered / permuted growth ------------------------------------------------------------
@@ -281,6 +283,9 @@ enum {
                                   2 = never */
     PNX_CFG_INDEX_PROBE = 12,  /* ids read by the second and later probes of an index search: 16 [default] = one 64-byte
                                   sector, 32 = one 128-byte line (fewer rounds per wave, more requests: measured slower) */
+    PNX_CFG_OVERLAP_PHASES = 14, /* 1 [default]: a plain histogram pass runs as three phases on three streams chained by events
+                                  (index | coverage kernel | histogram + copy of the counters), so that the index of pass k+1
+                                  and the histogram of pass k-1 run beside the coverage kernel of pass k; 0: one stream */
     PNX_CFG_COMM_REDUCE_HIST = 13, /* with a communicator (pnx_comm_init): 1 [default] every coverage pass is followed by the
                                   all-reduce of its flags + histogram, 0 the caller reduces what it needs itself */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP

@@ -124,6 +124,7 @@ int prepare_steps(pnx_ctx *ctx) {
         hipLaunchKernelGGL(k_mono_class, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_path_mono.p, P);
         PNX_HIP(ctx, hipGetLastError());
     }
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // once per upload; the passes read this from other streams too
     ctx->steps_prepared = true;
     return PNX_OK;
 }
@@ -443,12 +444,17 @@ static int normalize_order(pnx_ctx *ctx) {
 }
 
 static OrdIdx ord_idx_view(const pnx_ctx *ctx) {
-    return OrdIdx{(uint32_t *)ctx->d_ord_tfirst.p, (uint32_t *)ctx->d_ord_tspan.p, (uint64_t *)ctx->d_ord_off.p,
-                  (uint32_t *)ctx->d_win_lo.p, (uint32_t *)ctx->d_win_hi.p};
+    const Ticket *t = ctx->cur;
+    return OrdIdx{(uint32_t *)t->d_ord_tfirst.p, (uint32_t *)t->d_ord_tspan.p, (uint64_t *)t->d_ord_off.p,
+                  (uint32_t *)t->d_win_lo.p, (uint32_t *)t->d_win_hi.p};
 }
 
-static TileIdx tile_idx_view(const pnx_ctx *ctx) {
-    return TileIdx{(const uint64_t *)ctx->d_tile_idx.p, (const uint64_t *)ctx->d_idx_off.p,
+// the boundary table of the pass being enqueued: the context's when it is kept across passes, the
+// pass's own when every pass rebuilds it (the next pass then builds its table beside this pass's K1)
+static DevBuf &tile_idx_buf(pnx_ctx *ctx) { return ctx->cache_index ? ctx->d_tile_idx : ctx->cur->d_tile_idx_own; }
+
+static TileIdx tile_idx_view(pnx_ctx *ctx) {
+    return TileIdx{(const uint64_t *)tile_idx_buf(ctx).p, (const uint64_t *)ctx->d_idx_off.p,
                    (const uint32_t *)ctx->d_tfirst.p, (const uint32_t *)ctx->d_tspan.p};
 }
 
@@ -457,11 +463,12 @@ int launch_tile_index(pnx_ctx *ctx) {
     int rc;
     if ((rc = prepare_steps(ctx))) return rc;
     if ((rc = ensure_path_spans(ctx))) return rc;
-    if ((rc = ensure(ctx, ctx->d_tile_idx, (ctx->idx_entries ? ctx->idx_entries : 1) * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, tile_idx_buf(ctx), (ctx->idx_entries ? ctx->idx_entries : 1) * sizeof(uint64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_class, ctx->n_paths ? ctx->n_paths : 1))) return rc;
     if (ctx->n_paths == 0) return PNX_OK;
     const TileIdx ix = tile_idx_view(ctx);
-    prof_begin(ctx, PNX_K_INDEX);
+    uint64_t *d_B = (uint64_t *)tile_idx_buf(ctx).p;
+    prof_begin(ctx, PNX_K_INDEX, ctx->s_pre);
     {
         // two levels: every coarse-th boundary of a row is located inside the whole path, the
         // rest inside those brackets
@@ -480,14 +487,14 @@ int launch_tile_index(pnx_ctx *ctx) {
         if (grid_f > 0x7FFFFFFFull || grid_c > 0x7FFFFFFFull)
             return ctx->fail(PNX_ELIMIT, "tile index: %u paths x %u tiles exceed the grid", ctx->n_paths, ctx->max_span);
         auto go = [&](auto k_coarse, auto k_fine) {
-            hipLaunchKernelGGL(k_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_coarse, dim3((unsigned)grid_c), dim3(256), 0, ctx->s_pre,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_c, ctx->n_paths,
-                               ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
+                               ctx->idx_entries, tile_items, coarse, d_B, ix,
                                (uint8_t *)ctx->d_path_class.p, (const uint8_t *)ctx->d_path_mono.p);
             if (coarse > 1)
-                hipLaunchKernelGGL(k_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(k_fine, dim3((unsigned)grid_f), dim3(256), 0, ctx->s_pre,
                                    (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, bpp_f, ctx->n_paths,
-                                   ctx->idx_entries, tile_items, coarse, (uint64_t *)ctx->d_tile_idx.p, ix,
+                                   ctx->idx_entries, tile_items, coarse, d_B, ix,
                                    (uint8_t *)ctx->d_path_class.p);
         };
         // ids per probe, first / later probes (PNX_CFG_INDEX_PROBE): 16 = 16/16 [default], 32 = 16/32
@@ -1280,14 +1287,14 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
             while (t > 0 && t < ctx->n_ordered && ctx->h_ord_group[t] == ctx->h_ord_group[t - 1]) ++t;
             sp.k[j] = (uint32_t)t;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->stream,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->s_main,
                            static_cast<items_ptr_t>(items_ptr), tile_idx_view(ctx), ord_idx_view(ctx),
                            (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                            ctx->n_ordered, (uint8_t *)ctx->d_path_class.p,
                            use_m ? (const uint8_t *)ctx->cur->d_grp_general : (const uint8_t *)nullptr,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr,
                            ctx->n_items, ctx->n_tiles, ctx->n_blocks, (uint32_t *)ctx->d_M.p, row_words,
-                           (uint32_t *)ctx->d_countable.p, ctx->cur->d_flags, rv, sp);
+                           (uint32_t *)ctx->cur->d_countable.p, ctx->cur->d_flags, rv, sp);
     };
     // window skipping pays when the order is long (thousands of paths); with a few hundred dense
     // paths every window is needed and the plain form keeps its lower register count
@@ -1375,29 +1382,34 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->d_flags = (uint32_t *)tk->d_block.p;
     tk->d_hist = (uint64_t *)((char *)tk->d_block.p + 8 * sizeof(uint32_t));
     tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;
-    if ((rc = ensure(ctx, ctx->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, tk->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
     const size_t no = ctx->n_ordered ? ctx->n_ordered : 1;
-    if ((rc = ensure(ctx, ctx->d_ord_tfirst, no * sizeof(uint32_t))) || (rc = ensure(ctx, ctx->d_ord_tspan, no * sizeof(uint32_t))) ||
-        (rc = ensure(ctx, ctx->d_ord_off, no * sizeof(uint64_t))) ||
-        (rc = ensure(ctx, ctx->d_win_lo, ((no + 63) / 64) * sizeof(uint32_t))) ||
-        (rc = ensure(ctx, ctx->d_win_hi, ((no + 63) / 64) * sizeof(uint32_t))))
+    if ((rc = ensure(ctx, tk->d_ord_tfirst, no * sizeof(uint32_t))) || (rc = ensure(ctx, tk->d_ord_tspan, no * sizeof(uint32_t))) ||
+        (rc = ensure(ctx, tk->d_ord_off, no * sizeof(uint64_t))) ||
+        (rc = ensure(ctx, tk->d_win_lo, ((no + 63) / 64) * sizeof(uint32_t))) ||
+        (rc = ensure(ctx, tk->d_win_hi, ((no + 63) / 64) * sizeof(uint32_t))))
         return rc;
     if ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx))) return rc;
+    if (!tk->ev_pre) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_pre, hipEventDisableTiming));
+    if (!tk->ev_cov) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_cov, hipEventDisableTiming));
+    const bool phased = ctx->s_pre != ctx->s_main;  // three streams chained by events (see pnx_context.hpp)
 
+    // ---- phase 1 (s_pre, behind this pass's K0 if it has one): counters cleared, the index of the
+    // ordered paths laid out in visiting order
     // flags, histogram and per-group "general" marks of this pass: one clear
-    PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->stream));
+    PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
 
     if (ctx->n_ordered) {
-        prof_begin(ctx, PNX_K_SCATTER);
-        hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->stream,
+        prof_begin(ctx, PNX_K_SCATTER, ctx->s_pre);
+        hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->s_pre,
                            (const uint8_t *)ctx->d_path_class.p, (const uint32_t *)ctx->d_ord_path.p,
                            (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->cur->d_grp_general, ctx->cur->d_flags, tile_idx_view(ctx), ord_idx_view(ctx));
-        if (use_m && m_words) {
-            hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->stream,
+        if (use_m && m_words) {  // never phased: s_pre == s_main
+            hipLaunchKernelGGL(k_zero_if_general, dim3(2048), dim3(256), 0, ctx->s_pre,
                                (uint4 *)ctx->d_M.p, m_words / 4, (const uint32_t *)ctx->cur->d_flags);
-            hipLaunchKernelGGL(k_scatter_general, dim3(2048), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_scatter_general, dim3(2048), dim3(256), 0, ctx->s_pre,
                                (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
                                (const uint32_t *)ctx->d_ord_path.p, (const uint32_t *)ctx->d_ord_group.p,
                                ctx->n_ordered, (const uint8_t *)ctx->d_path_class.p, (uint32_t *)ctx->d_M.p,
@@ -1406,15 +1418,25 @@ int launch_cover_pass(pnx_ctx *ctx) {
         prof_end(ctx);
         PNX_HIP(ctx, hipGetLastError());
     }
+    if (phased) {
+        PNX_HIP(ctx, hipEventRecord(tk->ev_pre, ctx->s_pre));
+        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_main, tk->ev_pre, 0));
+    }
 
-    prof_begin(ctx, PNX_K_COVER);
+    // ---- phase 2 (s_main): the coverage kernel
+    prof_begin(ctx, PNX_K_COVER, ctx->s_main);
     if (ctx->tile_blocks == 2) rc = launch_cover_wt<2>(ctx, ctx->want_M, use_m);
     else rc = launch_cover_wt<1>(ctx, ctx->want_M, use_m);
     prof_end(ctx);
     if (rc) return rc;
     PNX_HIP(ctx, hipGetLastError());
+    if (phased) {
+        PNX_HIP(ctx, hipEventRecord(tk->ev_cov, ctx->s_main));
+        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_post, tk->ev_cov, 0));
+    }
 
-    prof_begin(ctx, PNX_K_HIST);
+    // ---- phase 3 (s_post): the histogram of the coverage vector
+    prof_begin(ctx, PNX_K_HIST, ctx->s_post);
     {
         // one workgroup of 16 waves per CU at most: every workgroup ends with one global atomic
         // per non-empty bin, and those serialise per address
@@ -1422,8 +1444,8 @@ int launch_cover_pass(pnx_ctx *ctx) {
         unsigned grid = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
         const bool lds = ctx->n_groups + 1 <= HIST_LDS_BINS;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, ctx->stream,
-                               (const uint32_t *)ctx->d_countable.p, (const uint32_t *)ctx->d_weights.p,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, ctx->s_post,
+                               (const uint32_t *)tk->d_countable.p, (const uint32_t *)ctx->d_weights.p,
                                ctx->n_items, ctx->n_groups, (unsigned long long *)ctx->cur->d_hist);
         };
         if (ctx->weighted) { if (lds) go(k_hist<true, true>); else go(k_hist<true, false>); }

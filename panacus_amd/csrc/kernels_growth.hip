@@ -605,7 +605,7 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
     uint32_t *d_aux = (uint32_t *)ctx->d_cmask.p + mask_words;
     if (!cvals.empty())
         hipLaunchKernelGGL(k_cov_masks, dim3((NB + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const uint32_t *)ctx->d_countable.p, ctx->n_items, NB, d_cvals,
+                           (const uint32_t *)ctx->d_countable_done->p, ctx->n_items, NB, d_cvals,
                            (uint32_t)cvals.size(), (uint32_t *)ctx->d_cmask.p);
     if (ctx->weighted && (rc = ensure_weight_planes(ctx, d_aux))) return rc;
     prof_end(ctx);

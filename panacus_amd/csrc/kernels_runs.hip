@@ -225,7 +225,8 @@ int sort_run_index(pnx_ctx *ctx) {
     hipLaunchKernelGGL(k_runs_tile_off, dim3((ctx->n_tiles + 1 + 255) / 256), dim3(256), 0, ctx->stream,
                        (const uint64_t *)d_keys2.p, n, ctx->n_tiles, (uint64_t *)ctx->d_run_tile_off.p);
     PNX_HIP(ctx, hipGetLastError());
-    ctx->runs_sorted = true;  // the coverage pass is enqueued behind these launches on the same stream
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the passes read the sorted runs from other streams too
+    ctx->runs_sorted = true;
     return PNX_OK;
 }
 

@@ -46,18 +46,41 @@ static hipEvent_t prof_event(pnx_ctx *ctx) {
     return e;
 }
 
-void prof_begin(pnx_ctx *ctx, int slot) {
+void prof_begin(pnx_ctx *ctx, int slot, hipStream_t stream) {
     ctx->prof.open = ctx->prof.on && ((ctx->prof.mask >> slot) & 1u);
     if (!ctx->prof.open) return;
+    ctx->prof.open_stream = stream ? stream : ctx->stream;
     Profile::Pending pd{prof_event(ctx), prof_event(ctx), slot};
-    (void)hipEventRecord(pd.a, ctx->stream);
+    (void)hipEventRecord(pd.a, ctx->prof.open_stream);
     ctx->prof.pending.push_back(pd);
 }
 
 void prof_end(pnx_ctx *ctx) {
     if (!ctx->prof.open || ctx->prof.pending.empty()) return;
     ctx->prof.open = false;
-    (void)hipEventRecord(ctx->prof.pending.back().b, ctx->stream);
+    (void)hipEventRecord(ctx->prof.pending.back().b, ctx->prof.open_stream);
+}
+
+int drain_streams(pnx_ctx *ctx) {
+    for (hipStream_t st : {ctx->stream_pre, ctx->stream, ctx->stream_post})
+        if (st) PNX_HIP(ctx, hipStreamSynchronize(st));
+    return PNX_OK;
+}
+
+// which streams the pass being enqueued uses (pnx_context.hpp): three chained ones for a plain
+// histogram pass, one when the pass also writes or merges the presence matrix
+static int choose_pass_streams(pnx_ctx *ctx) {
+    const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
+    const bool phased = ctx->overlap_phases && ctx->cover_variant == 2 && !use_m;
+    if (ctx->tk_count && phased != ctx->last_pass_phased) {
+        int rc = drain_streams(ctx);  // a pass in flight took the other arrangement: let it finish on the device
+        if (rc) return rc;
+    }
+    ctx->last_pass_phased = phased;
+    ctx->s_main = ctx->stream;
+    ctx->s_pre = phased ? ctx->stream_pre : ctx->stream;
+    ctx->s_post = phased ? ctx->stream_post : ctx->stream;
+    return PNX_OK;
 }
 
 int prof_resolve(pnx_ctx *ctx, bool wait) {
@@ -80,7 +103,8 @@ int prof_resolve(pnx_ctx *ctx, bool wait) {
 }
 
 static void invalidate_results(pnx_ctx *ctx) {
-    if (ctx->tk_count) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->tk_count) (void)drain_streams(ctx);
+    ctx->d_countable_done = nullptr;
     for (auto &t : ctx->tk) t.in_flight = false;
     ctx->tk_count = 0;
     ctx->tk_oldest = ctx->tk_next;
@@ -127,16 +151,14 @@ static int stage_results(pnx_ctx *ctx, Ticket *t) {
         PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
         t->done_blocking = ctx->blocking_sync;
     }
-    PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipEventRecord(t->done, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->s_post));
+    PNX_HIP(ctx, hipEventRecord(t->done, ctx->s_post));
     return PNX_OK;
 }
 
 // enqueue one pass into the next free ticket
 static int enqueue_pass(pnx_ctx *ctx) {
-    if (ctx->tk_count >= 2) return ctx->fail(PNX_EINVAL, "two coverage passes are already in flight; fetch one first");
-    Ticket *t = &ctx->tk[ctx->tk_next];
-    ctx->cur = t;
+    Ticket *t = ctx->cur;  // chosen by pnx_hist_async (its index may already be in the making)
     int rc = launch_cover_pass(ctx);
     if (rc) return rc;
     if ((rc = comm_reduce_pass(ctx, t))) return rc;  // multi-GPU: global flags + histogram (no-op without a communicator)
@@ -167,13 +189,15 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->tk_oldest ^= 1;
             ctx->tk_count -= 1;
             ctx->last_done = t;
+            ctx->d_countable_done = &t->d_countable;
             ctx->hist_valid = true;
             ctx->M_valid = t->wrote_m && ctx->tk_count == 0;
             return PNX_OK;
         }
         // a younger pass (if any) ran with the same stale classification; it fails and is
         // re-run at its own settle
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int drc = drain_streams(ctx);
+        if (drc) return drc;
         ctx->n_reruns += 1;
         int rc;
         if (need_build) {
@@ -184,6 +208,7 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->last_general_paths = t->h_flags[1];  // > 0: the re-run allocates and merges M
         }
         ctx->cur = t;
+        if ((rc = choose_pass_streams(ctx))) return rc;
         if ((rc = launch_cover_pass(ctx))) return rc;
         // the flags were reduced over all ranks, so every rank is here: the collectives stay matched
         if ((rc = comm_reduce_pass(ctx, t))) return rc;
@@ -228,7 +253,9 @@ int pnx_init(pnx_ctx **out, int device) {
     if (!ctx) return PNX_ENOMEM;
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream_pre, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking)) != hipSuccess) {
         g_init_err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         delete ctx;
         return PNX_EHIP;
@@ -241,13 +268,13 @@ void pnx_free(pnx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)pnx_comm_free(ctx);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)drain_streams(ctx);
     if (ctx->stream_cf) (void)hipStreamSynchronize(ctx->stream_cf);
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_ord_tfirst, &ctx->d_ord_tspan, &ctx->d_ord_off, &ctx->d_win_lo, &ctx->d_win_hi, &ctx->d_path_class, &ctx->d_flags,
-                      &ctx->d_countable, &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_flags,
+                      &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_items16, &ctx->d_path_mono, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
@@ -258,7 +285,13 @@ void pnx_free(pnx_ctx *ctx) {
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);
         if (t.done) (void)hipEventDestroy(t.done);
+        if (t.ev_pre) (void)hipEventDestroy(t.ev_pre);
+        if (t.ev_cov) (void)hipEventDestroy(t.ev_cov);
+        for (DevBuf *b : {&t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own})
+            release(*b);
     }
+    if (ctx->stream_pre) (void)hipStreamDestroy(ctx->stream_pre);
+    if (ctx->stream_post) (void)hipStreamDestroy(ctx->stream_post);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->stream_cf) (void)hipStreamDestroy(ctx->stream_cf);
     delete ctx;
@@ -491,15 +524,20 @@ int pnx_hist_async(pnx_ctx *ctx) {
     if (!ctx) return PNX_EINVAL;
     if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "pnx_hist needs pnx_set_csr and pnx_set_order first");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->tk_count >= 2) return ctx->fail(PNX_EINVAL, "two coverage passes are already in flight; fetch one first");
     int rc;
+    // the presence matrix is only written when asked for (config) or when a growth call needs it
+    ctx->want_M = ctx->keep_M_user || ctx->growth_needs_M;
+    ctx->growth_needs_M = false;
+    ctx->cur = &ctx->tk[ctx->tk_next];
+    if ((rc = choose_pass_streams(ctx))) return rc;
     if (!ctx->index_valid || !ctx->cache_index) {
+        // a kept index is shared by the passes: nothing may still be reading it while it is rebuilt
+        if (ctx->cache_index && ctx->tk_count && (rc = drain_streams(ctx))) return rc;
         drop_run_index(ctx);  // path classes are reset with the index
         if ((rc = launch_tile_index(ctx))) return rc;
         ctx->index_valid = true;
     }
-    // the presence matrix is only written when asked for (config) or when a growth call needs it
-    ctx->want_M = ctx->keep_M_user || ctx->growth_needs_M;
-    ctx->growth_needs_M = false;
     ctx->hist_valid = false;
     return enqueue_pass(ctx);
 }
@@ -509,7 +547,7 @@ int pnx_sync(pnx_ctx *ctx) {
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     int rc = settle_all(ctx);
     if (rc) return rc;
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = drain_streams(ctx))) return rc;
     prof_resolve(ctx);
     ctx->growth_pending = false;
     return PNX_OK;
@@ -518,7 +556,10 @@ int pnx_sync(pnx_ctx *ctx) {
 int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist) {
     if (!ctx || !d_hist) return PNX_EINVAL;
     if (ctx->tk_count == 0) return ctx->fail(PNX_EINVAL, "no coverage pass is in flight");
-    *d_hist = ctx->tk[ctx->tk_next ^ 1].d_hist;
+    Ticket *t = &ctx->tk[ctx->tk_next ^ 1];
+    *d_hist = t->d_hist;
+    // the counters are written on an internal stream: whatever the caller now enqueues on pnx_stream() waits for them
+    if (ctx->last_pass_phased) PNX_HIP(ctx, hipStreamWaitEvent(ctx->stream, t->done, 0));
     return PNX_OK;
 }
 
@@ -530,10 +571,10 @@ int pnx_hist_device(pnx_ctx *ctx, uint64_t **d_hist, uint32_t **d_countable) {
     if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
     if (d_hist) *d_hist = ctx->last_done->d_hist;
     if (d_countable) {
-        *d_countable = (uint32_t *)ctx->d_countable.p;  // shared by all passes
-        if (ctx->relabeled) {  // the caller's ids: a gathered copy, enqueued behind whatever runs
+        *d_countable = (uint32_t *)ctx->last_done->d_countable.p;  // the settled pass's own vector
+        if (ctx->relabeled) {  // the caller's ids: a gathered copy
             if ((rc = ensure(ctx, ctx->d_countable_ext, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
-            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
+            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->last_done->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
             PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             *d_countable = (uint32_t *)ctx->d_countable_ext.p;
         }
@@ -549,12 +590,11 @@ int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
     if (!ctx->hist_valid || !ctx->last_done) return ctx->fail(PNX_EINVAL, "no histogram has been computed");
     if (hist) std::memcpy(hist, ctx->last_done->h_hist, ((size_t)ctx->n_groups + 1) * sizeof(uint64_t));
     if (countable) {
-        // the coverage vector is shared by all passes: let a younger pass finish before reading it
-        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        const void *src = ctx->d_countable.p;
+        // every pass has its own coverage vector; this is the settled pass's
+        const void *src = ctx->last_done->d_countable.p;
         if (ctx->relabeled) {
             if ((rc = ensure(ctx, ctx->d_countable_ext, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
-            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
+            if ((rc = to_caller_ids_u32(ctx, (const uint32_t *)ctx->last_done->d_countable.p, (uint32_t *)ctx->d_countable_ext.p))) return rc;
             PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
             src = ctx->d_countable_ext.p;
         }
@@ -822,7 +862,7 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
         case PNX_CFG_USE_WEIGHTS:
             if (value && !ctx->have_weights) return ctx->fail(PNX_EINVAL, "no weights are resident");
             if (ctx->weighted != (value != 0)) {
-                if (ctx->tk_count) (void)hipStreamSynchronize(ctx->stream);
+                if (ctx->tk_count) (void)drain_streams(ctx);
                 for (auto &t : ctx->tk) t.in_flight = false;
                 ctx->tk_count = 0;
                 ctx->tk_oldest = ctx->tk_next;
@@ -863,6 +903,9 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             return PNX_OK;
         case PNX_CFG_BLOCKING_SYNC:
             ctx->blocking_sync = value != 0;
+            return PNX_OK;
+        case PNX_CFG_OVERLAP_PHASES:
+            ctx->overlap_phases = value != 0;
             return PNX_OK;
         case PNX_CFG_COMM_REDUCE_HIST:
             if (ctx->tk_count) return ctx->fail(PNX_EINVAL, "PNX_CFG_COMM_REDUCE_HIST cannot change while a pass is in flight");

@@ -74,10 +74,10 @@ __global__ void k_clip_flags(uint32_t *flags) {
     if (threadIdx.x < 8 && flags[threadIdx.x] > (1u << 20)) flags[threadIdx.x] = 1u << 20;
 }
 
-int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n) {
+int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n, hipStream_t stream) {
     if (!ctx->comm) return ctx->fail(PNX_EINVAL, "no communicator: call pnx_comm_init first");
     if (n == 0) return PNX_OK;
-    ncclResult_t r = rccl().AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
+    ncclResult_t r = rccl().AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, (ncclComm_t)ctx->comm, stream ? stream : ctx->stream);
     if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllReduce", r);
     return PNX_OK;
 }
@@ -85,8 +85,8 @@ int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n) {
 // flags (u32[8] = 4 words) + histogram ((G+1) words) of the pass in `t`, in place, behind the pass
 int comm_reduce_pass(pnx_ctx *ctx, Ticket *t) {
     if (!ctx->comm || !ctx->comm_reduce_hist) return PNX_OK;
-    hipLaunchKernelGGL(k_clip_flags, dim3(1), dim3(64), 0, ctx->stream, t->d_flags);
-    return comm_allreduce_u64(ctx, (uint64_t *)t->d_block.p, 4 + (size_t)ctx->n_groups + 1);
+    hipLaunchKernelGGL(k_clip_flags, dim3(1), dim3(64), 0, ctx->s_post, t->d_flags);
+    return comm_allreduce_u64(ctx, (uint64_t *)t->d_block.p, 4 + (size_t)ctx->n_groups + 1, ctx->s_post);
 }
 
 }  // namespace pnx
@@ -136,7 +136,7 @@ int pnx_comm_free(pnx_ctx *ctx) {
     if (!ctx) return PNX_EINVAL;
     if (!ctx->comm) return PNX_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)drain_streams(ctx);
     ncclResult_t r = rccl().CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->comm_world = 1;

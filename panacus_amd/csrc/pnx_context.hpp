@@ -50,6 +50,11 @@ struct Ticket {
     hipEvent_t done = nullptr;
     bool done_blocking = false;
     bool in_flight = false;
+    // per-pass working set (so that the index of pass k+1 can be built, and the histogram of pass k-1
+    // taken, while the coverage kernel of pass k runs): the order-aligned index arrays, the coverage
+    // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
+    DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
+    hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
     // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
     // time the pass is settled): it merged the scatter rows of M / it wrote the presence matrix
     bool used_m = false, wrote_m = false;
@@ -58,6 +63,7 @@ struct Ticket {
 struct Profile {
     bool on = false;
     bool open = false;          // a prof_begin of a selected slot awaits its prof_end
+    hipStream_t open_stream = nullptr;
     uint32_t mask = 0xFFFFFFFFu;  // slots that are timed (pnx_profile_select)
     double ms[PNX_K_COUNT] = {0};
     uint64_t launches[PNX_K_COUNT] = {0};
@@ -76,6 +82,15 @@ struct pnx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream_cf = nullptr;  // closed-form kernels (K7): independent of the coverage passes
+    // A plain histogram pass is three phases on three streams chained by events: the index (K0, the
+    // order-aligned copy) on stream_pre, the coverage kernel on `stream`, the histogram + the copy of the
+    // counters to the host on stream_post -- so K0 of pass k+1 and K2 of pass k-1 run beside K1 of pass k,
+    // and the K1s follow each other without the short kernels in between.  s_* = the streams of the
+    // pass being enqueued (all three = `stream` when the pass also writes / merges the presence matrix).
+    hipStream_t stream_pre = nullptr, stream_post = nullptr;
+    hipStream_t s_pre = nullptr, s_main = nullptr, s_post = nullptr;
+    bool overlap_phases = true;  // PNX_CFG_OVERLAP_PHASES
+    bool last_pass_phased = false;
     std::string err;
     hipDeviceProp_t prop;
 
@@ -116,10 +131,9 @@ struct pnx_ctx {
     uint32_t n_blocks = 0, n_tiles = 0;
     bool index_valid = false;
     bool cache_index = true;
-    pnx::DevBuf d_tile_idx;    // sparse: sum over paths of (tiles spanned + 1) u64
+    pnx::DevBuf d_tile_idx;    // sparse: sum over paths of (tiles spanned + 1) u64 (kept across passes: PNX_CFG_CACHE_INDEX)
     pnx::DevBuf d_tfirst, d_tspan, d_idx_off;  // per path: first tile, tiles spanned, row offset (n_paths + 1)
-    pnx::DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off;  // the same per entry of the visiting order (rebuilt every pass)
-    pnx::DevBuf d_win_lo, d_win_hi;  // per 64 entries of the order: the tiles [lo, hi) their tile-route paths reach
+    // (the same per entry of the visiting order, and the window bands, are rebuilt every pass: Ticket)
     std::vector<uint32_t> h_tfirst;  // host copy (order normalisation)
     bool order_normalized = false;   // the paths of every group are sorted by their first tile
     bool spans_valid = false;  // the three arrays above match the resident CSR and tile size
@@ -142,7 +156,7 @@ struct pnx_ctx {
     pnx::DevBuf d_rb[6], d_rs[6];       // scratch of the build / of the sort: kept, only ever grown
 
     // ---- results ----
-    pnx::DevBuf d_countable;  // n_items + 1 u32
+    pnx::DevBuf *d_countable_done = nullptr;  // coverage vector (n_items + 1 u32) of the pass settled last
     pnx::Ticket tk[2];        // in-flight / finished passes (ring)
     int tk_next = 0, tk_oldest = 0, tk_count = 0;
     pnx::Ticket *cur = nullptr;        // the ticket the launch functions write to
@@ -210,9 +224,10 @@ namespace pnx {
 int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes);
 void release(DevBuf &b);
 
-// profiling brackets around a kernel launch on ctx->stream
-void prof_begin(pnx_ctx *ctx, int slot);
+// profiling brackets around a kernel launch (on `stream`, default ctx->stream)
+void prof_begin(pnx_ctx *ctx, int slot, hipStream_t stream = nullptr);
 void prof_end(pnx_ctx *ctx);
+int drain_streams(pnx_ctx *ctx);  // waits for everything enqueued on the context's pass streams
 int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
 // kernels_cover.hip
@@ -232,7 +247,7 @@ int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
 int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // lo, hi: caller ids  // -> n_groups x (hi - lo) u32
 // pnx_comm.hip
-int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n);
+int comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n, hipStream_t stream = nullptr);
 int comm_reduce_pass(pnx_ctx *ctx, Ticket *t);
 // kernels_relabel.hip
 int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys);
