@@ -513,7 +513,7 @@ def main():
                 # the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind the
                 # pass on the library's own stream (a collective on another stream would have to wait
                 # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
-                self.ext = torch.cuda.ExternalStream(ctx.stream(), device=f"cuda:{local_rank}")
+                self.ext = {}  # torch views of the library's streams
                 self.ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
                               "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
                               "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(2)]
@@ -523,17 +523,22 @@ def main():
             ctx = self.ctx
             ctx.hist_async()
             if use_dist and not self.native:
-                d_hist = ctx.hist_enqueued()
+                # the collective follows the counters on the stream of the pass's histogram phase: the coverage
+                # kernel of the next pass is not held back
+                d_hist, st = ctx.hist_enqueued_on()
+                ext = self.ext.get(st)
+                if ext is None:
+                    ext = self.ext[st] = torch.cuda.ExternalStream(st, device=f"cuda:{local_rank}")
                 t = self.hist_views.get(d_hist)
                 if t is None:
                     t = self.hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
                 slot = self.ring[self.enq % 2]
                 self.enq += 1
-                with torch.cuda.stream(self.ext):
+                with torch.cuda.stream(ext):
                     slot["tmp"].copy_(t)
                     dist.all_reduce(slot["tmp"], group=self.group)  # RCCL, int64 sum == uint64 sum for counts < 2^63
                     slot["host"].copy_(slot["tmp"], non_blocking=True)
-                    slot["ev"].record(self.ext)
+                    slot["ev"].record(ext)
                 slot["reruns"] = int(ctx.info().n_reruns)
 
         def settle(self):
@@ -562,7 +567,7 @@ def main():
                 # they are freed) must go before the stream does
                 self.ring.clear()
                 self.hist_views.clear()
-                del self.ext
+                self.ext.clear()
 
     n_lanes = max(1, args.lanes)
     ctx = make_context()

@@ -131,6 +131,10 @@ int pnx_hist_fetch(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
  * The values are only final if the pass verifies; pnx_info().n_reruns tells whether a later
  * pnx_hist_fetch / pnx_hist_device had to run it again. */
 int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist);
+/* the same, together with the stream on which these counters are produced (the histogram phase of the pass): work
+ * enqueued THERE -- the collective of a multi-GPU host, its copy to the host -- follows the counters without holding
+ * back the coverage kernel of the next pass on pnx_stream(). */
+int pnx_hist_enqueued_on(pnx_ctx *ctx, uint64_t **d_hist, void **stream);
 int pnx_sync(pnx_ctx *ctx);
 /* raw hipStream_t of the context (for RCCL / event interop in the host layer): the stream of the coverage
  * kernels and of every growth / intersection call.  The counters of a pass are written on an internal

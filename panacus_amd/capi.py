@@ -22,7 +22,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_exclude",
-    "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued",
+    "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued", "pnx_hist_enqueued_on",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     L.pnx_hist_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.pnx_hist_fetch.argtypes = [vp, u32p, u64p]
     L.pnx_hist_enqueued.argtypes = [vp, C.POINTER(vp)]
+    L.pnx_hist_enqueued_on.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.pnx_sync.argtypes = [vp]
     L.pnx_stream.argtypes = [vp]
     L.pnx_stream.restype = vp
@@ -231,6 +232,12 @@ class Context:
         d = C.c_void_p()
         self._ck(self._L.pnx_hist_enqueued(self._h, C.byref(d)))
         return d.value
+
+    def hist_enqueued_on(self):
+        """(device pointer of the counters of the pass enqueued last, the stream they are produced on)"""
+        d, st = C.c_void_p(), C.c_void_p()
+        self._ck(self._L.pnx_hist_enqueued_on(self._h, C.byref(d), C.byref(st)))
+        return d.value, st.value
 
     def sync(self):
         self._ck(self._L.pnx_sync(self._h))

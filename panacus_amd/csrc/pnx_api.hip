@@ -612,6 +612,14 @@ int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist) {
 
 void *pnx_stream(pnx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int pnx_hist_enqueued_on(pnx_ctx *ctx, uint64_t **d_hist, void **stream) {
+    if (!ctx || !d_hist || !stream) return PNX_EINVAL;
+    if (ctx->tk_count == 0) return ctx->fail(PNX_EINVAL, "no coverage pass is in flight");
+    *d_hist = ctx->tk[ctx->tk_next ^ 1].d_hist;
+    *stream = (void *)(ctx->last_pass_phased ? ctx->stream_post : ctx->stream);
+    return PNX_OK;
+}
+
 int pnx_ordered_growth_async(pnx_ctx *ctx, const uint32_t *perms, uint32_t n_perms, const uint32_t *cov_thr,
                              const uint32_t *quorum_tab, uint32_t n_thr) {
     if (!ctx) return PNX_EINVAL;
