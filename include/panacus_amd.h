@@ -82,6 +82,78 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  * masks a generated graph.  exclude holds n_items+1 flags; an excluded item is counted in no group. */
 int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude);
 
+/* ---- subset / exclude INTERVALS cut on the device ----------------------------
+ * Replaces the walk of parse_path_seq_update_tables / parse_walk_seq_update_tables / update_tables /
+ * update_tables_edgecount (src/graph_broker/util.rs:412-795) under GraphMask.include_coords /
+ * exclude_coords: every path is walked in bp coordinates, the steps that an include interval touches
+ * form the ItemTable (a node once per interval piece, an edge once), items that an exclude interval
+ * touches are flagged (ActiveTable, src/util.rs:118-207).  The O(S) walk -- a segmented prefix sum of
+ * node lengths, two interval searches per step, a stream compaction -- runs on the device and its result
+ * becomes the resident graph (as after pnx_set_csr_keyed); what depends on the FILE ORDER of partial
+ * sightings (IntervalContainer bookkeeping of partly covered / partly excluded nodes, bp counts only,
+ * src/util.rs:147-181,209-310; quantify_uncovered_bps, abacus.rs:1187-1229) comes back as a short event
+ * list -- at most two entries per interval -- for the host to replay.
+ *   walk_node      S node ids of all paths / walks in file order (the node ItemTable)
+ *   walk_backward  S orientation flags (1 = '-' / '<'), NULL = all forward
+ *   walk_off       n_paths+1 offsets into walk_node
+ *   path_start     n_paths: bp coordinate of a path's first base (PathSegment.start, else 0)
+ *   path_mode      n_paths: PNX_WALK_SKIP (no interval touches the path: no items), PNX_WALK_WHOLE (taken
+ *                  whole, no per-node bookkeeping; its items are flagged if its exclude list is non-empty:
+ *                  util.rs:1171-1181), PNX_WALK_CUT (walked against its interval lists)
+ *   node_len       n_nodes+1 node lengths
+ *   edge_item/edge_off  NULL for node / bp counts; for edge counts the edge ItemTable (edge id of every
+ *                  consecutive step pair) and its n_paths+1 offsets
+ *   inc_*, exc_*   per path [off[p], off[p+1]) [start, end) pairs (2 u64 each), sorted by start, every interval
+ *                  starting BEYOND the end of its predecessor (GraphMask's interval sets: overlapping and
+ *                  touching rows joined; a row with start > end is passed as it is and acts, as in the
+ *                  reference, only on a node that holds both ends); "whole path" = (0, UINT64_MAX);
+ *                  exc_off == NULL: no exclude list
+ *   count_type     0 node, 1 bp, 2 edge (bp: partial pieces are reported, exclusion only by full cover)
+ *   track_covered  bp with a subset list: report partial include pieces + the last full sighting
+ * Events (bp only; unordered, sort by (step, piece)): kind 0 = include piece (a, b) of node `item` that does
+ * not cover the node, last_full = 1 + the largest global step index at which a CUT path saw the node in
+ * full (0: never); kind 2 = partial exclude piece; `flagged` = the node's exclusion flag after the walk. */
+enum { PNX_WALK_SKIP = 0, PNX_WALK_WHOLE = 1, PNX_WALK_CUT = 2 };
+typedef struct pnx_walks {
+    const uint32_t *walk_node;
+    const uint8_t *walk_backward;
+    const uint64_t *walk_off;
+    const uint64_t *path_start;
+    const uint8_t *path_mode;
+    uint32_t n_paths, n_nodes;
+    const uint32_t *node_len;
+    const uint32_t *edge_item;
+    const uint64_t *edge_off;
+    uint32_t n_items;
+    int count_type;
+    int track_covered;
+    const uint64_t *inc_off, *inc_iv;
+    const uint64_t *exc_off, *exc_iv;
+} pnx_walks;
+typedef struct pnx_piece_event {
+    uint64_t step;      /* global index of the step in walk_node */
+    uint64_t last_full; /* kind 0 only */
+    uint32_t path, item;
+    uint32_t a, b;      /* the piece, node coordinates (mirrored on a backward step) */
+    uint32_t piece;     /* index of the piece among the step's pieces */
+    uint8_t kind, flagged, pad[2];
+} pnx_piece_event;
+/* weights / item_key as in pnx_set_csr_keyed.  events may be NULL when cap == 0; *n_events receives the
+ * number of events found (> cap: PNX_ELIMIT, nothing installed).  The exclusion flags are always
+ * installed when exc_off != NULL. */
+int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *walks, const uint32_t *weights, const uint64_t *item_key,
+                    pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
+/* Replace the weights of the resident graph (n_items+1 values, caller ids): bp growth under a subset list
+ * weighs a partly covered node by node_len - uncovered (abacus.rs:1013-1023), known only after the events
+ * of pnx_set_csr_cut were replayed. */
+int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights);
+/* Set the exclusion flag of n more items (caller ids): partial exclude pieces that join to cover a node
+ * (ActiveTable::activate_n_annotate, src/util.rs:147-181). */
+int pnx_exclude_items(pnx_ctx *ctx, const uint32_t *ids, uint32_t n);
+
+/* The exclusion flags of the resident graph in the caller's ids (n_items+1 bytes; zeros when there are none). */
+int pnx_get_exclude(pnx_ctx *ctx, uint8_t *exclude);
+
 /* Synthetic graph generated directly in HBM by the pansyn-v1 generator: the
  * bench/test input of BASELINE.json configs 2-4.  Equivalent to pnx_set_csr on the arrays
  * the CPU generator produces for (seed, n_nodes, n_paths). with_weights != 0 also derives

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free",
+    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude",
 ]
 
 
@@ -45,6 +46,24 @@ class PnxInfo(C.Structure):
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
                 ("n_reruns", C.c_uint64)]
 
+
+class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
+    _fields_ = [("walk_node", C.POINTER(C.c_uint32)), ("walk_backward", C.POINTER(C.c_uint8)),
+                ("walk_off", C.POINTER(C.c_uint64)), ("path_start", C.POINTER(C.c_uint64)),
+                ("path_mode", C.POINTER(C.c_uint8)), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("node_len", C.POINTER(C.c_uint32)), ("edge_item", C.POINTER(C.c_uint32)),
+                ("edge_off", C.POINTER(C.c_uint64)), ("n_items", C.c_uint32), ("count_type", C.c_int),
+                ("track_covered", C.c_int), ("inc_off", C.POINTER(C.c_uint64)), ("inc_iv", C.POINTER(C.c_uint64)),
+                ("exc_off", C.POINTER(C.c_uint64)), ("exc_iv", C.POINTER(C.c_uint64))]
+
+
+class PnxPieceEvent(C.Structure):  # pnx_piece_event
+    _fields_ = [("step", C.c_uint64), ("last_full", C.c_uint64), ("path", C.c_uint32), ("item", C.c_uint32),
+                ("a", C.c_uint32), ("b", C.c_uint32), ("piece", C.c_uint32), ("kind", C.c_uint8),
+                ("flagged", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+WALK_SKIP, WALK_WHOLE, WALK_CUT = 0, 1, 2
 
 _lib = None
 
@@ -70,6 +89,10 @@ def load() -> C.CDLL:
     L.pnx_set_csr_keyed.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u64p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
+    L.pnx_get_exclude.argtypes = [vp, u8p]
+    L.pnx_set_weights.argtypes = [vp, u32p]
+    L.pnx_exclude_items.argtypes = [vp, u32p, C.c_uint32]
+    L.pnx_set_csr_cut.argtypes = [vp, C.POINTER(PnxWalks), u32p, u64p, C.POINTER(PnxPieceEvent), C.c_uint64, u64p]
     L.pnx_get_csr.argtypes = [vp, u64p, u32p, u64p, u32p]
     L.pnx_set_order.argtypes = [vp, u32p, u32p, C.c_uint32, C.c_uint32]
     L.pnx_hist.argtypes = [vp, u32p, u64p]
@@ -182,6 +205,78 @@ class Context:
         if ex is not None and len(ex) != self.n_items + 1:
             raise ValueError("exclude must have n_items+1 entries")
         self._ck(self._L.pnx_set_exclude(self._h, _ptr(ex, C.c_uint8)))
+
+    def get_exclude(self) -> np.ndarray:
+        ex = np.zeros(self.info().n_items + 1, dtype=np.uint8)
+        self._ck(self._L.pnx_get_exclude(self._h, _ptr(ex, C.c_uint8)))
+        return ex
+
+    def set_weights(self, weights):
+        w = np.ascontiguousarray(weights, dtype=np.uint32)
+        if len(w) != self.n_items + 1:
+            raise ValueError("weights must have n_items+1 entries")
+        self._ck(self._L.pnx_set_weights(self._h, _ptr(w, C.c_uint32)))
+
+    def exclude_items(self, ids):
+        v = np.ascontiguousarray(ids, dtype=np.uint32)
+        self._ck(self._L.pnx_exclude_items(self._h, _ptr(v, C.c_uint32), len(v)))
+
+    def set_csr_cut(self, walk_node, walk_off, node_len, path_mode, inc, exc=None, path_start=None, walk_backward=None,
+                    count_type=0, edge_item=None, edge_off=None, n_items=None, weights=None, item_key=None,
+                    track_covered=False, max_events=None):
+        """pnx_set_csr_cut: inc / exc = per path a list of (start, end) pairs (sorted, disjoint, not touching;
+        exc None = no exclude list).  -> list of event dicts (bp counts)"""
+        keep = []
+
+        def arr(x, dt):
+            a = np.ascontiguousarray(x, dtype=dt)
+            if len(a) == 0:
+                a = np.zeros(1, dtype=dt)
+            keep.append(a)
+            return a
+
+        P = len(walk_off) - 1
+
+        def lists(ls):
+            off = np.zeros(P + 1, dtype=np.uint64)
+            flat = []
+            for k in range(P):
+                for s, e in ls[k]:
+                    flat += [int(s), int(e)]
+                off[k + 1] = len(flat) // 2
+            return arr(off, np.uint64), arr(np.array(flat, dtype=np.uint64), np.uint64)
+
+        n_nodes = len(node_len) - 1
+        w = PnxWalks()
+        w.walk_node = _ptr(arr(walk_node, np.uint32), C.c_uint32)
+        w.walk_backward = None if walk_backward is None else _ptr(arr(walk_backward, np.uint8), C.c_uint8)
+        w.walk_off = _ptr(arr(walk_off, np.uint64), C.c_uint64)
+        w.path_start = _ptr(arr(np.zeros(P, dtype=np.uint64) if path_start is None else path_start, np.uint64), C.c_uint64)
+        w.path_mode = _ptr(arr(path_mode, np.uint8), C.c_uint8)
+        w.n_paths, w.n_nodes = P, n_nodes
+        w.node_len = _ptr(arr(node_len, np.uint32), C.c_uint32)
+        if edge_off is not None:
+            w.edge_item = _ptr(arr(edge_item, np.uint32), C.c_uint32)
+            w.edge_off = _ptr(arr(edge_off, np.uint64), C.c_uint64)
+        w.n_items = n_nodes if n_items is None else n_items
+        w.count_type = count_type
+        w.track_covered = int(track_covered)
+        io, ii = lists(inc)
+        w.inc_off, w.inc_iv = _ptr(io, C.c_uint64), _ptr(ii, C.c_uint64)
+        n_iv = int(io[-1])
+        if exc is not None:
+            eo, ei = lists(exc)
+            w.exc_off, w.exc_iv = _ptr(eo, C.c_uint64), _ptr(ei, C.c_uint64)
+            n_iv += int(eo[-1])
+        cap = 2 * n_iv + 16 if max_events is None else max_events
+        ev = (PnxPieceEvent * max(cap, 1))()
+        n_ev = C.c_uint64(0)
+        wt = None if weights is None else arr(weights, np.uint32)
+        key = None if item_key is None else arr(item_key, np.uint64)
+        self._ck(self._L.pnx_set_csr_cut(self._h, C.byref(w), _ptr(wt, C.c_uint32), _ptr(key, C.c_uint64), ev, cap, C.byref(n_ev)))
+        self.n_items = int(w.n_items)
+        return [dict(step=e.step, last_full=e.last_full, path=e.path, item=e.item, a=e.a, b=e.b, piece=e.piece,
+                     kind=e.kind, flagged=e.flagged) for e in ev[: n_ev.value]]
 
     def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))

@@ -1,0 +1,513 @@
+// kernels_cut.hip -- subset / exclude INTERVALS applied to the walks on the device.
+//
+// What the reference does on the host while it parses a P / W line under GraphMask.include_coords /
+// exclude_coords (src/graph_broker/util.rs:412-795: parse_path_seq_update_tables,
+// parse_walk_seq_update_tables, update_tables, update_tables_edgecount): walk the path in bp
+// coordinates, keep the steps that an include interval touches (a node once per interval piece, an
+// edge once), flag the items an exclude interval touches (ActiveTable, src/util.rs:118-207).  Per
+// step that is: its bp position (a prefix sum of node lengths along the path), two searches in the
+// path's sorted interval lists, and an append -- O(S) work with no dependence between steps once the
+// positions are known.  Here:
+//
+//   k_cut_chunk_bp      one block per chunk of CUT_CHUNK steps: the bp length of the chunk
+//   (rocprim scan)      chunk lengths -> bp position of every chunk start
+//   k_cut<COUNT>        positions inside the chunk (block scan), pieces per step, exclusion flags,
+//                       partial pieces -> event list, items per chunk
+//   (rocprim scan)      items per chunk -> output offset of every chunk (= the new id_prefsum)
+//   k_cut<EMIT>         the same walk again, writing the items; full sightings of partly covered nodes
+//   k_cut_close_events  last full sighting + final flag of every event's node
+//
+// The only part of the reference's bookkeeping that depends on the FILE ORDER of sightings -- the
+// IntervalContainer of partly covered / partly excluded nodes (bp counts; src/util.rs:147-181,
+// 209-310) -- concerns at most two nodes per interval: those come back to the host as events and are
+// replayed there in order (host/gfa_graph.cpp).  Everything else (the ItemTable, the flags) stays
+// in HBM and becomes the resident graph.
+#include <cstring>  // rocprim's texture iterator calls memset
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include "pnx_context.hpp"
+
+namespace pnx {
+
+constexpr uint32_t CUT_CHUNK = 2048;  // steps per block
+constexpr uint32_t CUT_THREADS = 256;
+constexpr uint32_t CUT_PER_THREAD = CUT_CHUNK / CUT_THREADS;
+
+struct CutArgs {
+    const uint32_t *node;       // S
+    const uint8_t *backward;    // S or null
+    const uint64_t *off;        // P + 1
+    const uint64_t *chunk_off;  // P + 1
+    const uint64_t *start;      // P
+    const uint8_t *mode;        // P
+    const uint32_t *len;        // n_nodes + 1
+    const uint32_t *edge_item;  // edge ItemTable or null
+    const uint64_t *edge_off;   // P + 1 or null
+    const uint64_t *inc_off, *inc_iv, *exc_off, *exc_iv;  // exc_off null: no exclude list
+    const uint64_t *chunk_base;  // bp before every chunk (exclusive scan over all chunks)
+    uint64_t *chunk_cnt;         // COUNT: items of the chunk
+    const uint64_t *chunk_out;   // EMIT: output offset of the chunk
+    uint32_t *out_items;         // EMIT
+    uint8_t *flags;              // n_items + 1 or null
+    uint8_t *is_partial;         // n_nodes + 1 or null (track_covered)
+    unsigned long long *last_full;  // n_nodes + 1 or null
+    pnx_piece_event *events;
+    unsigned long long *n_events;
+    uint64_t cap;
+    uint32_t n_paths, n_nodes;
+    int count_type;  // 0 node, 1 bp, 2 edge
+};
+
+struct CutChunk {
+    uint64_t start, pend;  // first step of the chunk, end of its path
+    uint32_t len, path;
+};
+
+__device__ static inline CutChunk cut_chunk_of(uint64_t c, const CutArgs &a) {
+    uint32_t lo = 0, hi = a.n_paths;  // last p with chunk_off[p] <= c (empty paths own no chunk)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.chunk_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    CutChunk ch;
+    ch.path = lo;
+    ch.start = a.off[lo] + (c - a.chunk_off[lo]) * CUT_CHUNK;
+    ch.pend = a.off[lo + 1];
+    const uint64_t left = ch.pend - ch.start;
+    ch.len = (uint32_t)(left < CUT_CHUNK ? left : CUT_CHUNK);
+    return ch;
+}
+
+// exclusive scan over the 256 threads of a block; *total = the block's sum
+template <typename T>
+__device__ static inline T block_excl_scan(T v, T *lds /* CUT_THREADS / 64 + 1 */, T *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    T incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const T o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+    }
+    __syncthreads();  // lds may still be read from an earlier scan
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    T base = 0, sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < CUT_THREADS / 64; ++w) {
+        if (w < wave) base += lds[w];
+        sum += lds[w];
+    }
+    *total = sum;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(CUT_THREADS) void k_cut_chunk_bp(CutArgs a, uint64_t *__restrict__ chunk_bp, uint32_t *bad) {
+    __shared__ unsigned long long lds[CUT_THREADS / 64 + 1];
+    const CutChunk ch = cut_chunk_of(blockIdx.x, a);
+    unsigned long long s = 0;
+    for (uint32_t j = threadIdx.x; j < ch.len; j += CUT_THREADS) {
+        const uint32_t id = a.node[ch.start + j];
+        if (id == 0 || id > a.n_nodes) {
+            *bad = 1u;
+            continue;
+        }
+        s += a.len[id];
+    }
+    unsigned long long total;
+    block_excl_scan<unsigned long long>(s, lds, &total);
+    if (threadIdx.x == 0) chunk_bp[blockIdx.x] = total;
+}
+
+// The intervals that can touch [p, q): a list is sorted by start, an interval starts beyond the end of
+// its predecessor, so the candidates are a contiguous range [lo, hi) -- hi = first interval that starts at
+// or after q, lo by walking back while ends lie beyond p.  A BED row may have start > end (the reference
+// does not reject it; its walk then emits a piece only for a node that holds both ends): such an interval
+// breaks the monotony of the ends, so the walk back steps over it instead of stopping.  Callers test
+// `end > p` per candidate.
+__device__ static inline uint32_t first_start_from(const uint64_t *iv, uint32_t n, uint64_t q) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (iv[2 * mid] >= q) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ static inline void touching_range(const uint64_t *iv, uint32_t n, uint64_t p, uint64_t q, uint32_t &lo, uint32_t &hi) {
+    hi = first_start_from(iv, n, q);
+    lo = hi;
+    uint32_t x = hi;
+    while (x > 0) {
+        const uint64_t s = iv[2 * (x - 1)], e = iv[2 * (x - 1) + 1];
+        if (e > p)
+            lo = x - 1;
+        else if (s <= e)
+            break;  // a proper interval that ends at or before p: so does everything before it
+        --x;
+    }
+}
+
+__device__ static inline void push_event(const CutArgs &a, uint64_t step, uint32_t path, uint32_t item, uint64_t pa, uint64_t pb,
+                                         uint32_t piece, uint8_t kind) {
+    const unsigned long long at = atomicAdd(a.n_events, 1ull);
+    if (at >= a.cap) return;
+    pnx_piece_event e;
+    e.step = step;
+    e.last_full = 0;
+    e.path = path;
+    e.item = item;
+    e.a = (uint32_t)pa;
+    e.b = (uint32_t)pb;
+    e.piece = piece;
+    e.kind = kind;
+    e.flagged = 0;
+    e.pad[0] = e.pad[1] = 0;
+    a.events[at] = e;
+}
+
+// the piece of node [p, p + l) that interval [s, e) selects, node coordinates (update_tables, util.rs:626-704)
+__device__ static inline void piece_of(uint64_t s, uint64_t e, uint64_t p, uint64_t l, bool backward, uint64_t &pa, uint64_t &pb) {
+    pa = s > p ? s - p : 0;
+    pb = e < p + l ? e - p : l;
+    if (backward) {
+        const uint64_t ma = l - pb, mb = l - pa;
+        pa = ma;
+        pb = mb;
+    }
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(CUT_THREADS) void k_cut(CutArgs a) {
+    __shared__ unsigned long long lds64[CUT_THREADS / 64 + 1];
+    __shared__ uint32_t lds32[CUT_THREADS / 64 + 1];
+    const CutChunk ch = cut_chunk_of(blockIdx.x, a);
+    const uint32_t k = ch.path;
+    const uint8_t mode = a.mode[k];
+    if (mode == PNX_WALK_SKIP) {
+        if (!EMIT && threadIdx.x == 0) a.chunk_cnt[blockIdx.x] = 0;
+        return;
+    }
+    const bool edge = a.count_type == 2, bp = a.count_type == 1;
+    const uint32_t t0 = threadIdx.x * CUT_PER_THREAD;
+    uint32_t id[CUT_PER_THREAD + 1];
+    uint32_t l[CUT_PER_THREAD + 1];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i <= CUT_PER_THREAD; ++i) {  // one step beyond: an edge needs the length of its second node
+        const uint64_t j = ch.start + t0 + i;
+        const bool in_chunk = i < CUT_PER_THREAD && t0 + i < ch.len;
+        const bool in = in_chunk || (edge && t0 + i <= ch.len && j < ch.pend);
+        id[i] = in ? a.node[j] : 0;
+        l[i] = in ? a.len[id[i]] : 0;
+        if (in_chunk) mine += l[i];
+    }
+    unsigned long long chunk_total;
+    const unsigned long long before = block_excl_scan<unsigned long long>(mine, lds64, &chunk_total);
+    uint64_t p = a.start[k] + (a.chunk_base[blockIdx.x] - a.chunk_base[a.chunk_off[k]]) + before;
+
+    const uint64_t *inc = a.inc_iv + 2 * a.inc_off[k];
+    const uint32_t n_inc = (uint32_t)(a.inc_off[k + 1] - a.inc_off[k]);
+    const uint64_t *exc = a.exc_off ? a.exc_iv + 2 * a.exc_off[k] : nullptr;
+    const uint32_t n_exc = a.exc_off ? (uint32_t)(a.exc_off[k + 1] - a.exc_off[k]) : 0;
+    const uint64_t e0 = edge ? a.edge_off[k] - a.off[k] : 0;  // edge (j, j + 1) of the path is edge_item[j + e0]
+
+    uint32_t cnt[CUT_PER_THREAD];
+    uint32_t my_cnt = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < CUT_PER_THREAD; ++i) {
+        cnt[i] = 0;
+        const uint64_t j = ch.start + t0 + i;
+        const bool have = edge ? j + 1 < ch.pend && t0 + i < ch.len : t0 + i < ch.len;
+        if (have) {
+            if (edge) {
+                // update_tables_edgecount (util.rs:723-795): the edge sits at the start of its second node
+                const uint64_t q = p + l[i], ql = l[i + 1];
+                const uint32_t item = a.edge_item[j + e0];
+                if (mode == PNX_WALK_WHOLE) {
+                    cnt[i] = 1;
+                    if (!EMIT && n_exc) a.flags[item] = 1;
+                } else {
+                    uint32_t lo, hi;  // the first interval that ends beyond q starts before the end of the node?
+                    touching_range(inc, n_inc, q, q + ql, lo, hi);
+                    cnt[i] = lo < hi ? 1u : 0u;
+                    if (!EMIT && n_exc) {
+                        touching_range(exc, n_exc, q, q + ql, lo, hi);
+                        if (lo < hi) a.flags[item] = 1;
+                    }
+                }
+            } else if (mode == PNX_WALK_WHOLE) {
+                cnt[i] = 1;
+                if (!EMIT && n_exc) a.flags[id[i]] = 1;  // every node of an excluded path (util.rs:1171-1181)
+            } else {
+                const uint64_t ll = l[i];
+                const bool back = a.backward && a.backward[j];
+                uint32_t lo, hi;
+                touching_range(inc, n_inc, p, p + ll, lo, hi);
+                uint32_t piece = 0;
+                for (uint32_t x = lo; x < hi; ++x) {
+                    if (inc[2 * x + 1] <= p) continue;
+                    if (a.is_partial) {  // bp under a subset list: partly covered nodes
+                        uint64_t pa, pb;
+                        piece_of(inc[2 * x], inc[2 * x + 1], p, ll, back, pa, pb);
+                        const bool full = pb - pa == ll;
+                        if (!EMIT && !full) {
+                            a.is_partial[id[i]] = 1;
+                            push_event(a, j, k, id[i], pa, pb, piece, 0);
+                        }
+                        if (EMIT && full && a.is_partial[id[i]]) atomicMax(a.last_full + id[i], (unsigned long long)j + 1ull);
+                    }
+                    ++piece;
+                }
+                cnt[i] = piece;
+                if (!EMIT && n_exc) {
+                    touching_range(exc, n_exc, p, p + ll, lo, hi);
+                    piece = 0;
+                    for (uint32_t x = lo; x < hi; ++x) {
+                        if (exc[2 * x + 1] <= p) continue;
+                        if (!bp) {  // node counts: any touch excludes the node
+                            a.flags[id[i]] = 1;
+                            break;
+                        }
+                        uint64_t pa, pb;  // ActiveTable::activate_n_annotate (src/util.rs:147-181)
+                        piece_of(exc[2 * x], exc[2 * x + 1], p, ll, back, pa, pb);
+                        if (pb - pa == ll)
+                            a.flags[id[i]] = 1;
+                        else
+                            push_event(a, j, k, id[i], pa, pb, piece, 2);
+                        ++piece;
+                    }
+                }
+            }
+        }
+        my_cnt += cnt[i];
+        p += l[i];
+    }
+    uint32_t total;
+    const uint32_t at = block_excl_scan<uint32_t>(my_cnt, lds32, &total);
+    if (!EMIT) {
+        if (threadIdx.x == 0) a.chunk_cnt[blockIdx.x] = total;
+        return;
+    }
+    uint64_t w = a.chunk_out[blockIdx.x] + at;
+#pragma unroll
+    for (uint32_t i = 0; i < CUT_PER_THREAD; ++i) {
+        if (!cnt[i]) continue;
+        const uint32_t item = edge ? a.edge_item[ch.start + t0 + i + e0] : id[i];
+        for (uint32_t r = 0; r < cnt[i]; ++r) a.out_items[w++] = item;
+    }
+}
+
+// id_prefsum of the cut table: the output offset of every path's first chunk
+__global__ void k_cut_path_off(const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ chunk_out, uint64_t n_chunks,
+                               uint64_t total, uint32_t n_paths, uint64_t *__restrict__ out_off) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > n_paths) return;
+    const uint64_t c = chunk_off[p];
+    out_off[p] = p == n_paths || c >= n_chunks ? total : chunk_out[c];
+}
+
+__global__ void k_cut_close_events(pnx_piece_event *ev, uint64_t n, const unsigned long long *last_full, const uint8_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t item = ev[i].item;
+    if (ev[i].kind == 0 && last_full) ev[i].last_full = last_full[item];
+    ev[i].flagged = flags ? flags[item] : 0;
+}
+
+__global__ void k_flag_items(uint8_t *flags, const uint32_t *ids, uint32_t n, const uint32_t *new_of_old, uint32_t n_items, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = ids[i];
+    if (id == 0 || id > n_items) {
+        *bad = 1u;
+        return;
+    }
+    flags[new_of_old ? new_of_old[id] : id] = 1;
+}
+
+template <typename T>
+static int scan_u64(pnx_ctx *ctx, const T *in, uint64_t *out, size_t n, DevBuf &tmp) {
+    size_t bytes = 0;
+    PNX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    int rc = ensure(ctx, tmp, bytes ? bytes : 8);
+    if (rc) return rc;
+    PNX_HIP(ctx, rocprim::exclusive_scan(tmp.p, bytes, in, out, (uint64_t)0, n, rocprim::plus<uint64_t>(), ctx->stream));
+    return PNX_OK;
+}
+
+namespace {
+struct Scratch {  // freed on every way out
+    std::vector<DevBuf *> all;
+    DevBuf node, back, off, chunk_off, start, mode, len, eitem, eoff, inc_off, inc_iv, exc_off, exc_iv, chunk_bp, chunk_base,
+        chunk_cnt, chunk_out, is_partial, last_full, events, counters, tmp, out_off;
+    Scratch() {
+        all = {&node, &back, &off, &chunk_off, &start, &mode, &len, &eitem, &eoff, &inc_off, &inc_iv, &exc_off, &exc_iv, &chunk_bp,
+               &chunk_base, &chunk_cnt, &chunk_out, &is_partial, &last_full, &events, &counters, &tmp, &out_off};
+    }
+    ~Scratch() {
+        for (DevBuf *b : all) release(*b);
+    }
+};
+}  // namespace
+
+// Cuts the walks; on success ctx->d_items / d_path_off / h_path_off / d_exclude hold the cut table
+// (n_steps set), the events are on the host.  The caller (pnx_api.hip) finishes the upload.
+int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events) {
+    const uint32_t P = w->n_paths;
+    const uint64_t S = w->walk_off[P];
+    const bool edge = w->count_type == 2;
+    Scratch s;
+    int rc;
+    std::vector<uint64_t> h_chunk_off((size_t)P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p) h_chunk_off[p + 1] = h_chunk_off[p] + (w->walk_off[p + 1] - w->walk_off[p] + CUT_CHUNK - 1) / CUT_CHUNK;
+    const uint64_t C = h_chunk_off[P];
+    if (C >= 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "pnx_set_csr_cut: more than 2^31 chunks of %u steps", CUT_CHUNK);
+    const uint64_t n_inc = w->inc_off[P], n_exc = w->exc_off ? w->exc_off[P] : 0;
+    const uint64_t E = edge ? w->edge_off[P] : 0;
+
+    auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        int r = ensure(ctx, b, bytes ? bytes : 8);
+        if (r) return r;
+        if (bytes) PNX_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PNX_OK;
+    };
+    if ((rc = up(s.node, w->walk_node, S * 4))) return rc;
+    if (w->walk_backward && (rc = up(s.back, w->walk_backward, S))) return rc;
+    if ((rc = up(s.off, w->walk_off, ((size_t)P + 1) * 8))) return rc;
+    if ((rc = up(s.chunk_off, h_chunk_off.data(), ((size_t)P + 1) * 8))) return rc;
+    if ((rc = up(s.start, w->path_start, (size_t)P * 8))) return rc;
+    if ((rc = up(s.mode, w->path_mode, P))) return rc;
+    if ((rc = up(s.len, w->node_len, ((size_t)w->n_nodes + 1) * 4))) return rc;
+    if (edge) {
+        if ((rc = up(s.eitem, w->edge_item, E * 4))) return rc;
+        if ((rc = up(s.eoff, w->edge_off, ((size_t)P + 1) * 8))) return rc;
+    }
+    if ((rc = up(s.inc_off, w->inc_off, ((size_t)P + 1) * 8))) return rc;
+    if ((rc = up(s.inc_iv, w->inc_iv, n_inc * 16))) return rc;
+    if (w->exc_off) {
+        if ((rc = up(s.exc_off, w->exc_off, ((size_t)P + 1) * 8))) return rc;
+        if ((rc = up(s.exc_iv, w->exc_iv, n_exc * 16))) return rc;
+    }
+    if ((rc = ensure(ctx, s.chunk_bp, (C + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, s.chunk_base, (C + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, s.chunk_cnt, (C + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, s.chunk_out, (C + 1) * 8))) return rc;
+    if ((rc = ensure(ctx, s.counters, 64))) return rc;
+    PNX_HIP(ctx, hipMemsetAsync(s.counters.p, 0, 64, ctx->stream));
+    if ((rc = ensure(ctx, s.events, (cap ? cap : 1) * sizeof(pnx_piece_event)))) return rc;
+    const bool track = w->track_covered && w->count_type == 1;
+    if (track) {
+        if ((rc = ensure(ctx, s.is_partial, (size_t)w->n_nodes + 1))) return rc;
+        if ((rc = ensure(ctx, s.last_full, ((size_t)w->n_nodes + 1) * 8))) return rc;
+        PNX_HIP(ctx, hipMemsetAsync(s.is_partial.p, 0, (size_t)w->n_nodes + 1, ctx->stream));
+        PNX_HIP(ctx, hipMemsetAsync(s.last_full.p, 0, ((size_t)w->n_nodes + 1) * 8, ctx->stream));
+    }
+    if (w->exc_off) {
+        if ((rc = ensure(ctx, ctx->d_exclude, (size_t)w->n_items + 1))) return rc;
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_exclude.p, 0, (size_t)w->n_items + 1, ctx->stream));
+    }
+
+    CutArgs a{};
+    a.node = (const uint32_t *)s.node.p;
+    a.backward = w->walk_backward ? (const uint8_t *)s.back.p : nullptr;
+    a.off = (const uint64_t *)s.off.p;
+    a.chunk_off = (const uint64_t *)s.chunk_off.p;
+    a.start = (const uint64_t *)s.start.p;
+    a.mode = (const uint8_t *)s.mode.p;
+    a.len = (const uint32_t *)s.len.p;
+    a.edge_item = edge ? (const uint32_t *)s.eitem.p : nullptr;
+    a.edge_off = edge ? (const uint64_t *)s.eoff.p : nullptr;
+    a.inc_off = (const uint64_t *)s.inc_off.p;
+    a.inc_iv = (const uint64_t *)s.inc_iv.p;
+    a.exc_off = w->exc_off ? (const uint64_t *)s.exc_off.p : nullptr;
+    a.exc_iv = w->exc_off ? (const uint64_t *)s.exc_iv.p : nullptr;
+    a.chunk_base = (const uint64_t *)s.chunk_base.p;
+    a.chunk_cnt = (uint64_t *)s.chunk_cnt.p;
+    a.chunk_out = (const uint64_t *)s.chunk_out.p;
+    a.flags = w->exc_off ? (uint8_t *)ctx->d_exclude.p : nullptr;
+    a.is_partial = track ? (uint8_t *)s.is_partial.p : nullptr;
+    a.last_full = track ? (unsigned long long *)s.last_full.p : nullptr;
+    a.events = (pnx_piece_event *)s.events.p;
+    a.n_events = (unsigned long long *)s.counters.p;
+    a.cap = cap;
+    a.n_paths = P;
+    a.n_nodes = w->n_nodes;
+    a.count_type = w->count_type;
+    uint32_t *d_bad = (uint32_t *)((char *)s.counters.p + 8);
+
+    uint64_t total = 0;
+    if (C) {
+        hipLaunchKernelGGL(k_cut_chunk_bp, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a, (uint64_t *)s.chunk_bp.p, d_bad);
+        PNX_HIP(ctx, hipGetLastError());
+        uint32_t bad = 0;
+        PNX_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the walk gathers node_len[id]: ids must be valid first
+        if (bad) return ctx->fail(PNX_EINVAL, "walk_node contains ids outside 1..n_nodes");
+        PNX_HIP(ctx, hipMemsetAsync((uint64_t *)s.chunk_bp.p + C, 0, 8, ctx->stream));
+        if ((rc = scan_u64(ctx, (const uint64_t *)s.chunk_bp.p, (uint64_t *)s.chunk_base.p, C + 1, s.tmp))) return rc;
+        hipLaunchKernelGGL(k_cut<false>, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a);
+        PNX_HIP(ctx, hipGetLastError());
+        PNX_HIP(ctx, hipMemsetAsync((uint64_t *)s.chunk_cnt.p + C, 0, 8, ctx->stream));
+        if ((rc = scan_u64(ctx, (const uint64_t *)s.chunk_cnt.p, (uint64_t *)s.chunk_out.p, C + 1, s.tmp))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(&total, (uint64_t *)s.chunk_out.p + C, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    unsigned long long found = 0;
+    PNX_HIP(ctx, hipMemcpyAsync(&found, s.counters.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_events) *n_events = found;
+    if (found > cap) return ctx->fail(PNX_ELIMIT, "pnx_set_csr_cut: %llu piece events, room for %llu", found, (unsigned long long)cap);
+
+    if ((rc = ensure(ctx, ctx->d_items, total * sizeof(uint32_t) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)P + 1) * sizeof(uint64_t)))) return rc;
+    a.out_items = (uint32_t *)ctx->d_items.p;
+    if (C) {
+        hipLaunchKernelGGL(k_cut<true>, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_cut_path_off, dim3((P + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)s.chunk_off.p,
+                       (const uint64_t *)s.chunk_out.p, C, total, P, (uint64_t *)ctx->d_path_off.p);
+    PNX_HIP(ctx, hipGetLastError());
+    ctx->h_path_off.assign((size_t)P + 1, 0);
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->h_path_off.data(), ctx->d_path_off.p, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (found) {
+        hipLaunchKernelGGL(k_cut_close_events, dim3((uint32_t)((found + 255) / 256)), dim3(256), 0, ctx->stream, a.events, (uint64_t)found,
+                           a.last_full, a.flags);
+        PNX_HIP(ctx, hipGetLastError());
+        PNX_HIP(ctx, hipMemcpyAsync(events, a.events, found * sizeof(pnx_piece_event), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_steps = total;
+    return PNX_OK;
+}
+
+int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n) {
+    if (!n) return PNX_OK;
+    DevBuf ids, bad;
+    int rc = ensure(ctx, ids, (size_t)n * 4);
+    if (!rc) rc = ensure(ctx, bad, 8);
+    hipError_t e = hipSuccess;
+    uint32_t h_bad = 0;
+    if (!rc) {
+        e = hipMemcpyAsync(ids.p, h_ids, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(bad.p, 0, 8, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_flag_items, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_exclude.p,
+                               (const uint32_t *)ids.p, n, ctx->relabeled ? (const uint32_t *)ctx->d_new_of_old.p : nullptr, ctx->n_items,
+                               (uint32_t *)bad.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    release(ids);
+    release(bad);
+    if (rc) return rc;
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_exclude_items: %s", hipGetErrorString(e));
+    if (h_bad) return ctx->fail(PNX_EINVAL, "pnx_exclude_items: ids outside 1..n_items");
+    return PNX_OK;
+}
+
+}  // namespace pnx

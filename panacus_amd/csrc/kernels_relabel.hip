@@ -161,8 +161,20 @@ int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_call
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;
 }
+int to_caller_ids_u8(pnx_ctx *ctx, const uint8_t *d_internal, uint8_t *d_caller) {
+    hipLaunchKernelGGL(k_gather<uint8_t>, dim3(grid_for((uint64_t)ctx->n_items + 1)), dim3(256), 0, ctx->stream, d_internal,
+                       (const uint32_t *)ctx->d_new_of_old.p, ctx->n_items + 1, d_caller);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
 int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal) {
     hipLaunchKernelGGL(k_gather<uint8_t>, dim3(grid_for((uint64_t)ctx->n_items + 1)), dim3(256), 0, ctx->stream, d_caller,
+                       (const uint32_t *)ctx->d_old_of_new.p, ctx->n_items + 1, d_internal);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_internal) {
+    hipLaunchKernelGGL(k_gather<uint32_t>, dim3(grid_for((uint64_t)ctx->n_items + 1)), dim3(256), 0, ctx->stream, d_caller,
                        (const uint32_t *)ctx->d_old_of_new.p, ctx->n_items + 1, d_internal);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;

@@ -297,38 +297,27 @@ void pnx_free(pnx_ctx *ctx) {
     delete ctx;
 }
 
-static int set_csr_impl(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
-                        uint32_t n_items, const uint32_t *weights, const uint8_t *exclude, const uint64_t *item_key) {
-    if (!ctx) return PNX_EINVAL;
-    if (!path_off) return ctx->fail(PNX_EINVAL, "path_off is NULL");
-    if (n_items >= 0xFFFFFFFEu || n_paths >= 0xFFFFFFFEu)
-        return ctx->fail(PNX_ELIMIT, "n_items and n_paths must be < 2^32-2");
-    PNX_HIP(ctx, hipSetDevice(ctx->device));
-    if (path_off[0] != 0) return ctx->fail(PNX_EINVAL, "path_off[0] must be 0");
-    for (uint32_t p = 0; p < n_paths; ++p)
-        if (path_off[p + 1] < path_off[p]) return ctx->fail(PNX_EINVAL, "path_off is not non-decreasing at path %u", p);
-    const uint64_t S = path_off[n_paths];
-    if (S && !items) return ctx->fail(PNX_EINVAL, "items is NULL");
+// what every upload starts with: results, order and derived step data of the old graph are void
+static void begin_upload(pnx_ctx *ctx) {
     invalidate_results(ctx);
     ctx->have_csr = false;
     ctx->have_order = false;
     ctx->steps_prepared = false;
     if (ctx->d_items16.borrowed) release(ctx->d_items16);
     if (ctx->d_path_mono.borrowed) release(ctx->d_path_mono);
+}
+
+// ... and ends with: d_items / d_path_off / h_path_off (and d_exclude when exclude_resident) are in place
+static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_items, const uint32_t *weights,
+                         const uint8_t *exclude, bool exclude_resident, const uint64_t *item_key) {
     int rc;
-    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t) + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t)))) return rc;
-    if (S) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_items.p, items, S * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, path_off, ((size_t)n_paths + 1) * sizeof(uint64_t),
-                                hipMemcpyHostToDevice, ctx->stream));
-    ctx->h_path_off.assign(path_off, path_off + n_paths + 1);
     ctx->weighted = ctx->have_weights = weights != nullptr;
     if (weights) {
         if ((rc = ensure(ctx, ctx->d_weights, ((size_t)n_items + 1) * sizeof(uint32_t)))) return rc;
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_weights.p, weights, ((size_t)n_items + 1) * sizeof(uint32_t),
                                     hipMemcpyHostToDevice, ctx->stream));
     }
-    ctx->have_exclude = exclude != nullptr;
+    ctx->have_exclude = exclude != nullptr || exclude_resident;
     if (exclude) {
         if ((rc = ensure(ctx, ctx->d_exclude, (size_t)n_items + 1))) return rc;
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, exclude, (size_t)n_items + 1, hipMemcpyHostToDevice, ctx->stream));
@@ -350,6 +339,114 @@ static int set_csr_impl(pnx_ctx *ctx, const uint32_t *items, const uint64_t *pat
     if (item_key && (rc = relabel_by_keys(ctx, item_key))) return rc;
     ctx->have_csr = true;
     return PNX_OK;
+}
+
+static int set_csr_impl(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
+                        uint32_t n_items, const uint32_t *weights, const uint8_t *exclude, const uint64_t *item_key) {
+    if (!ctx) return PNX_EINVAL;
+    if (!path_off) return ctx->fail(PNX_EINVAL, "path_off is NULL");
+    if (n_items >= 0xFFFFFFFEu || n_paths >= 0xFFFFFFFEu)
+        return ctx->fail(PNX_ELIMIT, "n_items and n_paths must be < 2^32-2");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    if (path_off[0] != 0) return ctx->fail(PNX_EINVAL, "path_off[0] must be 0");
+    for (uint32_t p = 0; p < n_paths; ++p)
+        if (path_off[p + 1] < path_off[p]) return ctx->fail(PNX_EINVAL, "path_off is not non-decreasing at path %u", p);
+    const uint64_t S = path_off[n_paths];
+    if (S && !items) return ctx->fail(PNX_EINVAL, "items is NULL");
+    begin_upload(ctx);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t)))) return rc;
+    if (S) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_items.p, items, S * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, path_off, ((size_t)n_paths + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    ctx->h_path_off.assign(path_off, path_off + n_paths + 1);
+    return finish_upload(ctx, S, n_paths, n_items, weights, exclude, false, item_key);
+}
+
+// subset / exclude intervals cut on the device (kernels_cut.hip), then the upload is finished as usual
+int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, const uint64_t *item_key,
+                    pnx_piece_event *events, uint64_t cap, uint64_t *n_events) {
+    if (!ctx) return PNX_EINVAL;
+    if (n_events) *n_events = 0;
+    if (!w || !w->walk_off || !w->path_start || !w->path_mode || !w->node_len || !w->inc_off)
+        return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: NULL argument");
+    if (w->count_type < 0 || w->count_type > 2) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: count_type must be 0, 1 or 2");
+    if (w->n_items >= 0xFFFFFFFEu || w->n_paths >= 0xFFFFFFFEu || w->n_nodes >= 0xFFFFFFFEu)
+        return ctx->fail(PNX_ELIMIT, "n_items, n_nodes and n_paths must be < 2^32-2");
+    if (w->count_type == 2 ? (!w->edge_off || (w->edge_off[w->n_paths] && !w->edge_item)) : w->n_items != w->n_nodes)
+        return ctx->fail(PNX_EINVAL, w->count_type == 2 ? "pnx_set_csr_cut: edge counts need the edge ItemTable"
+                                                          : "pnx_set_csr_cut: n_items must equal n_nodes for node / bp counts");
+    if (cap && !events) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: events is NULL");
+    if (w->walk_off[0] != 0 || w->inc_off[0] != 0 || (w->exc_off && w->exc_off[0] != 0))
+        return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: offsets must start at 0");
+    for (uint32_t p = 0; p < w->n_paths; ++p) {
+        if (w->walk_off[p + 1] < w->walk_off[p] || w->inc_off[p + 1] < w->inc_off[p] || (w->exc_off && w->exc_off[p + 1] < w->exc_off[p]))
+            return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: offsets are not non-decreasing at path %u", p);
+        if (w->path_mode[p] > PNX_WALK_CUT) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: path_mode[%u] = %u", p, w->path_mode[p]);
+        const uint64_t len = w->walk_off[p + 1] - w->walk_off[p];
+        if (w->count_type == 2 && w->edge_off[p + 1] - w->edge_off[p] != (len ? len - 1 : 0))
+            return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: path %u has %llu steps but %llu edges", p, (unsigned long long)len,
+                             (unsigned long long)(w->edge_off[p + 1] - w->edge_off[p]));
+        for (int which = 0; which < 2; ++which) {  // sorted by start, each starts beyond its predecessor's end
+            const uint64_t *off = which ? w->exc_off : w->inc_off, *iv = which ? w->exc_iv : w->inc_iv;
+            if (!off) continue;
+            for (uint64_t i = off[p]; i < off[p + 1]; ++i)
+                if (i > off[p] && (iv[2 * i] < iv[2 * i - 2] || iv[2 * i] <= iv[2 * i - 1]))
+                    return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: the %s intervals of path %u are not sorted and disjoint",
+                                     which ? "exclude" : "include", p);
+        }
+    }
+    if (w->walk_off[w->n_paths] && !w->walk_node) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: walk_node is NULL");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    begin_upload(ctx);
+    int rc = pnx::cut_walks(ctx, w, events, cap, n_events);
+    if (rc) return rc;
+    return finish_upload(ctx, ctx->n_steps, w->n_paths, w->n_items, weights, nullptr, w->exc_off != nullptr, item_key);
+}
+
+int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_set_weights before a graph is resident");
+    if (!weights) return ctx->fail(PNX_EINVAL, "pnx_set_weights: weights is NULL");
+    if (ctx->d_weights.borrowed) return ctx->fail(PNX_EINVAL, "pnx_set_weights: this context borrows its graph (pnx_share_csr)");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    invalidate_results(ctx);
+    const size_t bytes = ((size_t)ctx->n_items + 1) * sizeof(uint32_t);
+    int rc = ensure(ctx, ctx->d_weights, bytes);
+    if (rc) return rc;
+    if (ctx->relabeled) {
+        DevBuf tmp;
+        if ((rc = ensure(ctx, tmp, bytes))) return rc;
+        hipError_t e = hipMemcpyAsync(tmp.p, weights, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) rc = to_internal_ids_u32(ctx, (const uint32_t *)tmp.p, (uint32_t *)ctx->d_weights.p);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        release(tmp);
+        if (e != hipSuccess || e2 != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_set_weights: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        if (rc) return rc;
+    } else {
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_weights.p, weights, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->weighted = ctx->have_weights = true;
+    return PNX_OK;
+}
+
+int pnx_exclude_items(pnx_ctx *ctx, const uint32_t *ids, uint32_t n) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_exclude_items before a graph is resident");
+    if (n && !ids) return ctx->fail(PNX_EINVAL, "pnx_exclude_items: ids is NULL");
+    if (ctx->d_exclude.borrowed) return ctx->fail(PNX_EINVAL, "pnx_exclude_items: this context borrows its graph (pnx_share_csr)");
+    if (!n) return PNX_OK;
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    invalidate_results(ctx);
+    if (!ctx->have_exclude) {
+        int rc = ensure(ctx, ctx->d_exclude, (size_t)ctx->n_items + 1);
+        if (rc) return rc;
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_exclude.p, 0, (size_t)ctx->n_items + 1, ctx->stream));
+        ctx->have_exclude = true;
+    }
+    return pnx::flag_items(ctx, ids, n);
 }
 
 int pnx_set_csr(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_off, uint32_t n_paths,
@@ -386,6 +483,33 @@ int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude) {
         }
     }
     ctx->have_exclude = exclude != nullptr;
+    return PNX_OK;
+}
+
+int pnx_get_exclude(pnx_ctx *ctx, uint8_t *exclude) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "no graph is resident");
+    if (!exclude) return ctx->fail(PNX_EINVAL, "pnx_get_exclude: exclude is NULL");
+    const size_t n = (size_t)ctx->n_items + 1;
+    if (!ctx->have_exclude) {
+        std::fill(exclude, exclude + n, (uint8_t)0);
+        return PNX_OK;
+    }
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->relabeled) {
+        PNX_HIP(ctx, hipMemcpyAsync(exclude, ctx->d_exclude.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PNX_OK;
+    }
+    DevBuf tmp;  // internal -> caller ids: caller[i] = internal[new_of_old[i]]
+    int rc = ensure(ctx, tmp, n);
+    if (rc) return rc;
+    rc = to_caller_ids_u8(ctx, (const uint8_t *)ctx->d_exclude.p, (uint8_t *)tmp.p);
+    hipError_t e = rc ? hipSuccess : hipMemcpyAsync(exclude, tmp.p, n, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    release(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return ctx->fail(PNX_EHIP, "pnx_get_exclude: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return PNX_OK;
 }
 

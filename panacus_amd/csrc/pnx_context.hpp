@@ -253,6 +253,11 @@ int comm_reduce_pass(pnx_ctx *ctx, Ticket *t);
 int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys);
 int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_caller);
 int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal);
+int to_caller_ids_u8(pnx_ctx *ctx, const uint8_t *d_internal, uint8_t *d_caller);
+int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_internal);
+// kernels_cut.hip
+int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
+int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n);
 int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
 int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip

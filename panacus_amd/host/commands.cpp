@@ -97,6 +97,60 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 // order of the L lines, and the library renumbers them internally on the device when that order does
 // not follow the paths (pnx_set_csr_keyed); every per-item result still comes back in the reference's
 // ids, so `table -c edge` needs no special case.
+// -s / -e lists: the walks are cut ON THE DEVICE (pnx_set_csr_cut; graph_broker/util.rs:412-795) and stay
+// there as the resident graph; the host replays the few partial pieces (bp counts) and hands the late
+// exclusion flags and -- for growth -- the weights of partly covered nodes back to the library.
+Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Masking &mk, bool growth_weights) {
+    auto check = [&](int rc) {
+        if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
+    };
+    const uint64_t n_items = g.number_of_items(ct);
+    std::vector<uint64_t> keys;
+    if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
+    const WalkCut cut = g.walk_cut(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
+    const uint32_t none32 = 0;
+    const uint8_t none8 = 0;
+    const uint64_t none64 = 0;
+    pnx_walks w{};
+    w.walk_node = cut.walk_node.empty() ? &none32 : cut.walk_node.data();
+    w.walk_backward = cut.walk_backward.empty() ? nullptr : cut.walk_backward.data();
+    w.walk_off = cut.walk_off.data();
+    w.path_start = cut.path_start.empty() ? &none64 : cut.path_start.data();
+    w.path_mode = cut.path_mode.empty() ? &none8 : cut.path_mode.data();
+    w.n_paths = (uint32_t)cut.path_mode.size();
+    w.n_nodes = (uint32_t)g.node_count();
+    w.node_len = g.node_lens().data();
+    if (ct == COUNT_EDGE) {
+        w.edge_item = cut.edges.items.empty() ? &none32 : cut.edges.items.data();
+        w.edge_off = cut.edges.id_prefsum.data();
+    }
+    w.n_items = (uint32_t)n_items;
+    w.count_type = (int)ct;
+    w.track_covered = cut.track_covered ? 1 : 0;
+    w.inc_off = cut.inc_off.data();
+    w.inc_iv = cut.inc_iv.empty() ? &none64 : cut.inc_iv.data();
+    if (!cut.exc_off.empty()) {
+        w.exc_off = cut.exc_off.data();
+        w.exc_iv = cut.exc_iv.empty() ? &none64 : cut.exc_iv.data();
+    }
+    static_assert(sizeof(PieceEvent) == sizeof(pnx_piece_event), "PieceEvent mirrors pnx_piece_event");
+    std::vector<PieceEvent> events(cut.max_events);
+    uint64_t n_events = 0;
+    check(pnx_set_csr_cut(ctx, &w, ct == COUNT_BP ? g.node_lens().data() : nullptr, keys.empty() ? nullptr : keys.data(),
+                          reinterpret_cast<pnx_piece_event *>(events.data()), events.size(), &n_events));
+    events.resize(n_events);
+    Uncovered uncovered;
+    std::vector<uint32_t> late_flags;
+    g.replay_piece_events(cut, std::move(events), uncovered, late_flags);
+    if (!late_flags.empty()) check(pnx_exclude_items(ctx, late_flags.data(), (uint32_t)late_flags.size()));
+    if (ct == COUNT_BP && growth_weights && !uncovered.empty()) {
+        std::vector<uint32_t> wts = g.node_lens();
+        for (const auto &u : uncovered) wts[u.first] = u.second > wts[u.first] ? 0 : (uint32_t)(wts[u.first] - u.second);
+        check(pnx_set_weights(ctx, wts.data()));
+    }
+    return uncovered;
+}
+
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
                  bool growth_weights, bool /*per_item_output*/) {
     const uint64_t n_items = g.number_of_items(ct);
@@ -106,17 +160,7 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
     Uncovered uncovered;
     if (mk.any()) {
-        MaskedTable m = g.masked_table(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
-        std::vector<uint32_t> w;
-        if (ct == COUNT_BP && growth_weights && !m.uncovered.empty()) {
-            w = g.node_lens();
-            for (const auto &u : m.uncovered) w[u.first] = u.second > w[u.first] ? 0 : (uint32_t)(w[u.first] - u.second);
-        }
-        const uint32_t none = 0;  // a valid pointer for an empty table
-        dev.check(pnx_set_csr_keyed(dev.ctx, m.table.items.empty() ? &none : m.table.items.data(), m.table.id_prefsum.data(), n_paths,
-                                    (uint32_t)n_items, ct == COUNT_BP ? (w.empty() ? g.node_lens().data() : w.data()) : nullptr,
-                                    m.exclude.empty() ? nullptr : m.exclude.data(), key_ptr));
-        uncovered = std::move(m.uncovered);
+        uncovered = upload_cut(dev.ctx, g, ct, mk, growth_weights);
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);

@@ -48,6 +48,8 @@ std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges);
 std::vector<CountType> count_types(const std::string &c, bool allow_all);
 GroupMode group_mode(const Options &o);
 Masking masking(const Options &o);
+// the device-side cut of the walks under -s / -e lists (pnx_set_csr_cut) + the host's replay of the partial pieces
+Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Masking &mk, bool growth_weights);
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
                  bool growth_weights = false, bool per_item_output = false);
 std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphStorage &g, const std::vector<CountType> &cts,

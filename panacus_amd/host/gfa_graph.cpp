@@ -1419,6 +1419,54 @@ inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, ui
 
 bool GraphStorage::from_cache_file() const { return impl_->cached; }
 
+namespace {
+// how each path is treated under the lists (parse_gfa_paths_walks, util.rs:240-300)
+enum { SKIP = 0, WHOLE = 1, WALK = 2 };  // = PNX_WALK_SKIP / _WHOLE / _CUT of the device ABI
+struct MaskSetup {
+    bool have_inc = false, have_exc = false;
+    IvMap inc, exc;
+    std::vector<Iv> complete = {Iv{0, USIZE_MAX}}, none;
+    std::vector<uint8_t> how;
+    std::vector<const std::vector<Iv> *> ic, ec;
+};
+}  // namespace
+
+static void mask_setup(MaskSetup &ms, const std::vector<PathSegment> &paths_, CountType count, GroupMode mode,
+                       const std::string &group_file, const std::string &subset_file, const std::string &exclude_file) {
+    const size_t P = paths_.size();
+    std::vector<std::string> key(P);
+    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
+    const std::vector<std::string> group = load_groups(paths_, key, mode, group_file);
+    ms.have_inc = !subset_file.empty();
+    ms.have_exc = !exclude_file.empty();
+    if (ms.have_inc) ms.inc = load_subpath_map(subset_file, paths_, key, group);
+    if (ms.have_exc) ms.exc = load_subpath_map(exclude_file, paths_, key, group);
+    ms.how.assign(P, SKIP);
+    ms.ic.assign(P, nullptr);
+    ms.ec.assign(P, nullptr);
+    for (size_t k = 0; k < P; ++k) {
+        const std::string id = paths_[k].id();
+        ms.ic[k] = &ms.complete;
+        ms.ec[k] = &ms.none;
+        if (ms.have_inc) {
+            auto it = ms.inc.find(id);
+            ms.ic[k] = it == ms.inc.end() ? &ms.none : &it->second;
+        }
+        if (ms.have_exc) {
+            auto it = ms.exc.find(id);
+            if (it != ms.exc.end()) ms.ec[k] = &it->second;
+        }
+        const Iv span = paths_[k].has_start && paths_[k].has_end ? Iv{paths_[k].start, paths_[k].end} : Iv{0, USIZE_MAX};
+        if (ms.have_inc && !any_touching(ms.ic[k], span) && !any_touching(ms.ec[k], span))
+            ms.how[k] = SKIP;
+        else if (count != COUNT_EDGE && (!ms.have_inc || any_containing(ms.ic[k], span)) &&
+                 (!ms.have_exc || any_containing(ms.ec[k], span)))
+            ms.how[k] = WHOLE;
+        else
+            ms.how[k] = WALK;
+    }
+}
+
 MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const std::string &group_file,
                                        const std::string &subset_file, const std::string &exclude_file) const {
     const Impl &im = *impl_;
@@ -1426,13 +1474,12 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
     if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
     const size_t P = paths_.size();
     const uint64_t n_items = number_of_items(count);
-    std::vector<std::string> key(P);
-    for (size_t i = 0; i < P; ++i) key[i] = paths_[i].clear_key();
-    const std::vector<std::string> group = load_groups(paths_, key, mode, group_file);
-    const bool have_inc = !subset_file.empty(), have_exc = !exclude_file.empty();
-    IvMap inc, exc;
-    if (have_inc) inc = load_subpath_map(subset_file, paths_, key, group);
-    if (have_exc) exc = load_subpath_map(exclude_file, paths_, key, group);
+    MaskSetup ms;
+    mask_setup(ms, paths_, count, mode, group_file, subset_file, exclude_file);
+    const bool have_inc = ms.have_inc, have_exc = ms.have_exc;
+    std::vector<uint8_t> &how = ms.how;
+    const std::vector<const std::vector<Iv> *> &ic = ms.ic, &ec = ms.ec;
+    const std::vector<Iv> &complete = ms.complete;
 
     Steps steps;
     parse_all_steps(im, paths_, node_count_, true, steps);
@@ -1443,32 +1490,6 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
     // bp only: partially covered / partially excluded nodes (load_optional_subsetting, abacus.rs:384-425)
     const bool track_cov = count == COUNT_BP && have_inc, annotate = count == COUNT_BP && have_exc;
     std::unordered_map<uint32_t, Pieces> covered, partly_excluded;
-    const std::vector<Iv> complete = {Iv{0, USIZE_MAX}}, none;
-
-    // how each path is treated (util.rs:240-300)
-    enum { SKIP, WHOLE, WALK };
-    std::vector<uint8_t> how(P);
-    std::vector<const std::vector<Iv> *> ic(P), ec(P);
-    for (size_t k = 0; k < P; ++k) {
-        const std::string id = paths_[k].id();
-        ic[k] = &complete;
-        ec[k] = &none;
-        if (have_inc) {
-            auto it = inc.find(id);
-            ic[k] = it == inc.end() ? &none : &it->second;
-        }
-        if (have_exc) {
-            auto it = exc.find(id);
-            if (it != exc.end()) ec[k] = &it->second;
-        }
-        const Iv span = paths_[k].has_start && paths_[k].has_end ? Iv{paths_[k].start, paths_[k].end} : Iv{0, USIZE_MAX};
-        if (have_inc && !any_touching(ic[k], span) && !any_touching(ec[k], span))
-            how[k] = SKIP;
-        else if (count != COUNT_EDGE && (!have_inc || any_containing(ic[k], span)) && (!have_exc || any_containing(ec[k], span)))
-            how[k] = WHOLE;
-        else
-            how[k] = WALK;
-    }
 
     // Paths that are walked node by node go first, one after the other in file order (their
     // bookkeeping of partly covered nodes depends on it); whole paths are plain copies.
@@ -1585,6 +1606,105 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
         std::sort(out.uncovered.begin(), out.uncovered.end());
     }
     return out;
+}
+
+WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
+                               const std::string &exclude_file) const {
+    const Impl &im = *impl_;
+    if (im.cached) throw std::runtime_error("subset / exclude lists need the GFA text: load the graph without the cache");
+    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    const size_t P = paths_.size();
+    MaskSetup ms;
+    mask_setup(ms, paths_, count, mode, group_file, subset_file, exclude_file);
+    WalkCut w;
+    w.count = count;
+    {
+        Steps steps;
+        parse_all_steps(im, paths_, node_count_, true, steps);
+        w.walk_node.swap(steps.ids);
+        w.walk_backward.swap(steps.ori);
+        w.walk_off.swap(steps.pref);
+    }
+    if (count == COUNT_EDGE) w.edges = item_table(COUNT_EDGE);
+    w.path_start.assign(P, 0);
+    w.path_mode.assign(P, SKIP);
+    w.inc_off.assign(P + 1, 0);
+    if (ms.have_exc) w.exc_off.assign(P + 1, 0);
+    for (size_t k = 0; k < P; ++k) {
+        w.path_start[k] = paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0;
+        uint8_t how = ms.how[k];
+        // nothing to cut and nothing to flag: a whole path after all (no per-node bookkeeping either)
+        if (how == WALK && count != COUNT_EDGE && ms.ic[k] == &ms.complete && ms.ec[k]->empty()) how = WHOLE;
+        w.path_mode[k] = how;
+        if (how != SKIP)
+            for (const Iv &x : *ms.ic[k]) {
+                w.inc_iv.push_back(x.s);
+                w.inc_iv.push_back(x.e);
+            }
+        w.inc_off[k + 1] = w.inc_iv.size() / 2;
+        if (ms.have_exc) {
+            if (how != SKIP)
+                for (const Iv &x : *ms.ec[k]) {
+                    w.exc_iv.push_back(x.s);
+                    w.exc_iv.push_back(x.e);
+                }
+            w.exc_off[k + 1] = w.exc_iv.size() / 2;
+        }
+    }
+    w.track_covered = count == COUNT_BP && ms.have_inc;
+    w.max_events = count == COUNT_BP ? 2 * (w.inc_iv.size() / 2 + w.exc_iv.size() / 2) + 16 : 0;
+    return w;
+}
+
+void GraphStorage::replay_piece_events(const WalkCut &cut, std::vector<PieceEvent> events,
+                                       std::vector<std::pair<uint32_t, uint64_t>> &uncovered,
+                                       std::vector<uint32_t> &late_flags) const {
+    uncovered.clear();
+    late_flags.clear();
+    if (cut.count != COUNT_BP || events.empty()) return;
+    const bool have_exc = !cut.exc_off.empty();
+    // the order of the reference's walk: path by path, step by step, piece by piece
+    std::sort(events.begin(), events.end(), [](const PieceEvent &x, const PieceEvent &y) {
+        return x.step != y.step ? x.step < y.step : (x.kind != y.kind ? x.kind < y.kind : x.piece < y.piece);
+    });
+    std::unordered_map<uint32_t, Pieces> covered, partly_excluded;
+    std::unordered_map<uint32_t, bool> flagged;  // nodes of events: excluded as a whole by the device's walk
+    for (const PieceEvent &e : events) {
+        flagged[e.item] = e.flagged != 0;
+        if (e.kind == 0) {
+            // a later full sighting drops every earlier partial one (covered.remove, util.rs:640-643)
+            if (e.step + 1 > e.last_full) covered[e.item].add(e.a, e.b);
+        } else if (!e.flagged) {
+            partly_excluded[e.item].add(e.a, e.b);
+        }
+    }
+    // ActiveTable::activate_n_annotate (src/util.rs:147-181): pieces that join to the whole node exclude it
+    for (auto it = partly_excluded.begin(); it != partly_excluded.end();) {
+        const uint64_t l = node_lens_[it->first];
+        if (it->second.v.size() == 1 && it->second.v[0] == Iv{0, l}) {
+            late_flags.push_back(it->first);
+            flagged[it->first] = true;
+            it = partly_excluded.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    std::sort(late_flags.begin(), late_flags.end());
+    // quantify_uncovered_bps (abacus.rs:1187-1229)
+    for (const auto &kv : covered) {
+        const uint32_t sid = kv.first;
+        if (have_exc && flagged[sid]) continue;
+        const uint64_t l = node_lens_[sid];
+        std::vector<Iv> ex_pieces;
+        if (have_exc) {
+            auto it = partly_excluded.find(sid);
+            if (it != partly_excluded.end()) ex_pieces = it->second.v;
+        }
+        const uint64_t cov = total_coverage(kv.second.v, have_exc ? &ex_pieces : nullptr);
+        if (cov > l) continue;
+        uncovered.emplace_back(sid, l - cov);
+    }
+    std::sort(uncovered.begin(), uncovered.end());
 }
 
 PathOrder GraphStorage::path_order(GroupMode mode, const std::string &group_file, const std::string &order_file,

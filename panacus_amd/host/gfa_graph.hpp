@@ -58,6 +58,26 @@ struct MaskedTable {
     std::vector<std::pair<uint32_t, uint64_t>> uncovered;
 };
 
+// The same cut prepared for the DEVICE (pnx_set_csr_cut, include/panacus_amd.h): the walks with their
+// orientations, how each path is treated, and the interval lists per path -- everything the O(S) walk
+// needs, nothing it produces.  The device returns the cut ItemTable in HBM plus one event per partial
+// piece; replay_piece_events() turns those into `uncovered` and the late exclusion flags.
+struct WalkCut {
+    CountType count = COUNT_NODE;
+    std::vector<uint32_t> walk_node;
+    std::vector<uint8_t> walk_backward, path_mode;
+    std::vector<uint64_t> walk_off, path_start;
+    ItemTable edges;  // edge counts: the edge of every consecutive step pair
+    std::vector<uint64_t> inc_off, inc_iv, exc_off, exc_iv;  // exc_off empty: no exclude list
+    bool track_covered = false;  // bp with a subset list
+    uint64_t max_events = 0;     // two per interval
+};
+struct PieceEvent {  // = pnx_piece_event
+    uint64_t step, last_full;
+    uint32_t path, item, a, b, piece;
+    uint8_t kind, flagged, pad[2];
+};
+
 struct PathOrder {  // result of GraphMask::get_path_order + group-id assignment
     std::vector<uint32_t> path_idx, group_id;
     std::vector<std::string> groups;
@@ -85,6 +105,14 @@ public:
     // follow update_tables_edgecount (util.rs:723-795).  Needs the GFA text (not a .pcsr cache).
     MaskedTable masked_table(CountType count, GroupMode mode, const std::string &group_file,
                              const std::string &subset_file, const std::string &exclude_file) const;
+
+    WalkCut walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
+                     const std::string &exclude_file) const;
+    // IntervalContainer bookkeeping of the partly covered / partly excluded nodes from the device's events
+    // (src/util.rs:147-181,209-310; quantify_uncovered_bps, abacus.rs:1187-1229): `uncovered` as in
+    // MaskedTable, `late_flags` = nodes whose partial exclude pieces join to cover them
+    void replay_piece_events(const WalkCut &cut, std::vector<PieceEvent> events,
+                             std::vector<std::pair<uint32_t, uint64_t>> &uncovered, std::vector<uint32_t> &late_flags) const;
 
     // GraphMask::load_groups + get_path_order (+ optional -O order file, -s subset list,
     // -e exclude list: BED files naming paths, groups or intervals on paths)

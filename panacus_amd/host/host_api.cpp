@@ -139,6 +139,32 @@ int pnh_graph_masked_table(const void *g, int count_type, int group_mode, const 
     }
 }
 
+// The device-side cut (pnx_set_csr_cut through upload_cut of commands.cpp) into the caller's context `ctx`
+// (a pnx_ctx*): the cut table becomes that context's resident graph; uncovered bps come back as id / bp arrays
+// (at most *n_uncovered entries on entry; the count on return).
+int pnh_graph_cut_upload(const void *g, void *ctx, int count_type, int group_mode, const char *group_file, const char *subset_file,
+                         const char *exclude_file, int growth_weights, uint64_t *n_uncovered, uint32_t *uncov_ids, uint64_t *uncov_bps) {
+    try {
+        const pnh::GraphStorage *gs = static_cast<const pnh::GraphStorage *>(g);
+        pnh::cli::Masking mk;
+        mk.mode = (pnh::GroupMode)group_mode;
+        mk.group_file = group_file ? group_file : "";
+        mk.subset_file = subset_file ? subset_file : "";
+        mk.exclude_file = exclude_file ? exclude_file : "";
+        const pnh::cli::Uncovered u = pnh::cli::upload_cut(static_cast<pnx_ctx *>(ctx), *gs, (pnh::CountType)count_type, mk, growth_weights != 0);
+        if (u.size() > *n_uncovered) throw std::runtime_error("room for fewer uncovered entries than found");
+        *n_uncovered = u.size();
+        for (size_t k = 0; k < u.size(); ++k) {
+            uncov_ids[k] = u[k].first;
+            uncov_bps[k] = u[k].second;
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return -1;
+    }
+}
+
 // GraphStorage::edge_keys: n_edges + 1 entries (the item_key of pnx_set_csr_keyed)
 int pnh_graph_edge_keys(const void *g, uint64_t *keys) {
     try {

@@ -138,6 +138,9 @@ def _bind_graph(L):
                                        u64p, C.c_char_p, C.c_uint64]
     L.pnh_graph_exclude_flags.restype = C.c_int
     L.pnh_graph_exclude_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint8)]
+    L.pnh_graph_cut_upload.restype = C.c_int
+    L.pnh_graph_cut_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.pnh_graph_masked_table.restype = C.c_int
     L.pnh_graph_masked_table.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, u64p, u64p, u32p,
                                          u64p, C.POINTER(C.c_uint8), u32p, u64p]
@@ -254,6 +257,23 @@ class GfaGraph:
         if rc != 0:
             raise ValueError(self._L.pnh_last_error().decode())
         return items[: n_steps.value], pre, flags, ids[: n_unc.value], bps[: n_unc.value]
+
+    def cut_upload(self, ctx, count_type, subset_file=None, exclude_file=None, group_mode=GROUP_PATHID, group_file=None,
+                   growth_weights=False):
+        """The walks cut by the -s / -e lists ON THE DEVICE into the capi.Context `ctx` (pnx_set_csr_cut + the host's
+        replay of the partial pieces) -> (uncov_ids[u32], uncov_bps[u64]); the cut table is ctx's resident graph."""
+        enc = lambda f: os.fsencode(f) if f else None  # noqa: E731
+        cap = self.n_items(count_type) + 1
+        n_unc = C.c_uint64(cap)
+        ids = np.zeros(cap, dtype=np.uint32)
+        bps = np.zeros(cap, dtype=np.uint64)
+        rc = self._L.pnh_graph_cut_upload(self._h, ctx._h, count_type, group_mode, enc(group_file), enc(subset_file),
+                                          enc(exclude_file), int(growth_weights), C.byref(n_unc),
+                                          ids.ctypes.data_as(C.POINTER(C.c_uint32)), bps.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc != 0:
+            raise ValueError(self._L.pnh_last_error().decode())
+        ctx.n_items = self.n_items(count_type)
+        return ids[: n_unc.value], bps[: n_unc.value]
 
     def edge_keys(self) -> np.ndarray:
         """key[edge id] = (smaller node id << 32) | larger node id of the canonical edge; [0] = 0: the
