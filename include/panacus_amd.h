@@ -364,6 +364,13 @@ enum {
                                   and the histogram of pass k-1 run beside the coverage kernel of pass k; 0: one stream */
     PNX_CFG_COMM_REDUCE_HIST = 13, /* with a communicator (pnx_comm_init): 1 [default] every coverage pass is followed by the
                                   all-reduce of its flags + histogram, 0 the caller reduces what it needs itself */
+    PNX_CFG_SORT_SHUFFLED = 15, /* 1 [default]: a path whose steps jump between item tiles at random (more than one tile
+                                  change per 16 steps: edge ids without a key, ids unrelated to the walk) is SORTED by id
+                                  once, on the device, when the graph is prepared -- every result of this library depends
+                                  on the SET of items a path visits, not on their order, and a sorted path takes the tile
+                                  route (25 x faster than the atomic scatter route such a path would otherwise take);
+                                  pnx_get_csr still returns the steps in the caller's order.  0: leave such paths to the
+                                  scatter route.  Takes effect at the next upload. */
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */
@@ -387,6 +394,8 @@ typedef struct {
     uint32_t n_scatter_paths;/* ... of which left to the atomic scatter route */
     uint64_t n_runs;         /* size of the run index */
     uint64_t n_reruns;       /* passes that failed their verification and were run again so far */
+    uint32_t n_sorted_paths; /* paths whose steps were sorted by id at preparation (PNX_CFG_SORT_SHUFFLED) */
+    uint32_t reserved;
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

@@ -29,7 +29,13 @@
 //     matrix, merged by K1 at flush time); the pass is re-run when a violation is first seen.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>  // rocprim's texture iterator calls memset
 #include <type_traits>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
 
 #include "pnx_context.hpp"
 #include "step_chunks.hpp"
@@ -76,12 +82,14 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_steps(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                                        const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
-                                                       uint16_t *__restrict__ items16, uint8_t *__restrict__ path_dir) {
+                                                       uint16_t *__restrict__ items16, uint8_t *__restrict__ path_dir,
+                                                       uint32_t *__restrict__ path_changes) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const RunChunk ch = chunk_of(c, chunk_off, path_off, n_paths);
     uint32_t dir = 0;  // bit 0: a step enters a higher tile than its predecessor, bit 1: a lower one
+    uint32_t changes = 0;  // steps that lie in another tile than their predecessor
     for (uint32_t it = 0; it < ch.len; it += 64) {
         const uint64_t j = ch.start + it + lane;
         const bool in = it + lane < ch.len;
@@ -93,11 +101,115 @@ __global__ __launch_bounds__(256) void k_prepare_steps(const uint32_t *__restric
             if (j > ch.pstart) {
                 const uint32_t tc = cur / BLOCK_ITEMS, tp = prev / BLOCK_ITEMS;
                 dir |= (tc > tp ? 1u : 0u) | (tc < tp ? 2u : 0u);
+                changes += tc != tp ? 1u : 0u;
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) dir |= __shfl_xor(dir, o);
-    if (lane == 0 && dir) atomicOr(reinterpret_cast<unsigned int *>(path_dir) + (ch.path >> 2), dir << ((ch.path & 3u) * 8u));
+    for (int o = 32; o > 0; o >>= 1) {
+        dir |= __shfl_xor(dir, o);
+        changes += __shfl_xor(changes, o);
+    }
+    if (lane == 0 && dir) {
+        atomicOr(reinterpret_cast<unsigned int *>(path_dir) + (ch.path >> 2), dir << ((ch.path & 3u) * 8u));
+        atomicAdd(path_changes + ch.path, changes);
+    }
+}
+
+// ---- shuffled paths: sorted by id, once (PNX_CFG_SORT_SHUFFLED) ---------------------------------
+// slot s = the s-th sorted path; compact index i runs over the steps of all of them
+__device__ static inline uint32_t slot_of(const uint64_t *__restrict__ coff, uint32_t n_slots, uint64_t i) {
+    uint32_t lo = 0, hi = n_slots;  // last s with coff[s] <= i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (coff[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_sort_keys(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off, const uint64_t *__restrict__ coff,
+                            const uint32_t *__restrict__ slot_path, uint32_t n_slots, uint64_t total, uint32_t id_bits,
+                            uint64_t *__restrict__ keys, uint32_t *__restrict__ unsorted) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t s = slot_of(coff, n_slots, i);
+    const uint32_t v = items[path_off[slot_path[s]] + (i - coff[s])];
+    unsorted[i] = v;
+    keys[i] = ((uint64_t)s << id_bits) | v;
+}
+// sorted slot-major, every slot keeps its range: position i still belongs to slot_of(i)
+__global__ void k_sort_write_back(uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off, const uint64_t *__restrict__ coff,
+                                  const uint32_t *__restrict__ slot_path, uint32_t n_slots, uint64_t total, uint32_t id_bits,
+                                  const uint64_t *__restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t s = slot_of(coff, n_slots, i);
+    items[path_off[slot_path[s]] + (i - coff[s])] = (uint32_t)(keys[i] & ((1ull << id_bits) - 1ull));
+}
+__global__ void k_restore_order(uint32_t *__restrict__ items_copy, const uint64_t *__restrict__ path_off, const uint64_t *__restrict__ coff,
+                                const uint32_t *__restrict__ slot_path, uint32_t n_slots, uint64_t total,
+                                const uint32_t *__restrict__ unsorted) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t s = slot_of(coff, n_slots, i);
+    items_copy[path_off[slot_path[s]] + (i - coff[s])] = unsorted[i];
+}
+
+int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy) {
+    if (!ctx->n_sorted_paths || !ctx->n_unsorted) return PNX_OK;
+    hipLaunchKernelGGL(k_restore_order, dim3((unsigned)((ctx->n_unsorted + 255) / 256)), dim3(256), 0, ctx->stream, d_items_copy,
+                       (const uint64_t *)ctx->d_path_off.p, (const uint64_t *)ctx->d_sorted_coff.p, (const uint32_t *)ctx->d_sorted_path.p,
+                       ctx->n_sorted_paths, ctx->n_unsorted, (const uint32_t *)ctx->d_unsorted.p);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+// sorts the steps of the listed paths in place (ids ascending), keeping their original order in d_unsorted
+static int sort_paths_in_place(pnx_ctx *ctx, const std::vector<uint32_t> &paths) {
+    const uint32_t n_slots = (uint32_t)paths.size();
+    std::vector<uint64_t> coff((size_t)n_slots + 1, 0);
+    for (uint32_t s = 0; s < n_slots; ++s) coff[s + 1] = coff[s] + (ctx->h_path_off[paths[s] + 1] - ctx->h_path_off[paths[s]]);
+    const uint64_t total = coff[n_slots];
+    if ((total + 255) / 256 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many steps on shuffled paths to sort them");
+    uint32_t id_bits = 1, slot_bits = 1;
+    while ((1ull << id_bits) <= (uint64_t)ctx->n_items) ++id_bits;
+    while ((1ull << slot_bits) < (uint64_t)n_slots) ++slot_bits;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_unsorted, total * 4 + 16)) || (rc = ensure(ctx, ctx->d_sorted_coff, ((size_t)n_slots + 1) * 8)) ||
+        (rc = ensure(ctx, ctx->d_sorted_path, (size_t)n_slots * 4)))
+        return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_sorted_coff.p, coff.data(), coff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_sorted_path.p, paths.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, ctx->stream));
+    DevBuf k_in, k_out, tmp;
+    auto done = [&](int r) {
+        release(k_in);
+        release(k_out);
+        release(tmp);
+        return r;
+    };
+    if ((rc = ensure(ctx, k_in, total * 8 + 16)) || (rc = ensure(ctx, k_out, total * 8 + 16))) return done(rc);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
+                       (const uint64_t *)ctx->d_sorted_coff.p, (const uint32_t *)ctx->d_sorted_path.p, n_slots, total, id_bits,
+                       (uint64_t *)k_in.p, (uint32_t *)ctx->d_unsorted.p);
+    size_t bytes = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, bytes, (const uint64_t *)k_in.p, (uint64_t *)k_out.p, (size_t)total, 0u,
+                                            id_bits + slot_bits, ctx->stream);
+    if (e == hipSuccess && !(rc = ensure(ctx, tmp, bytes ? bytes : 8)))
+        e = rocprim::radix_sort_keys(tmp.p, bytes, (const uint64_t *)k_in.p, (uint64_t *)k_out.p, (size_t)total, 0u, id_bits + slot_bits,
+                                     ctx->stream);
+    if (rc) return done(rc);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sort_write_back, dim3(grid), dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_items.p,
+                           (const uint64_t *)ctx->d_path_off.p, (const uint64_t *)ctx->d_sorted_coff.p,
+                           (const uint32_t *)ctx->d_sorted_path.p, n_slots, total, id_bits, (const uint64_t *)k_out.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // coff / paths are the caller's, the key buffers go away
+    if (e != hipSuccess) return done(ctx->fail(PNX_EHIP, "sorting the shuffled paths failed: %s", hipGetErrorString(e)));
+    ctx->n_sorted_paths = n_slots;
+    ctx->n_unsorted = total;
+    ctx->spans_valid = false;        // first / last step of those paths changed
+    ctx->order_normalized = false;
+    return done(PNX_OK);
 }
 
 __global__ void k_mono_class(uint8_t *__restrict__ path_dir, uint32_t n_paths) {
@@ -109,21 +221,60 @@ int prepare_steps(pnx_ctx *ctx) {
     if (ctx->steps_prepared) return PNX_OK;
     const uint32_t P = ctx->n_paths;
     int rc;
-    if ((rc = ensure(ctx, ctx->d_items16, ctx->n_steps * sizeof(uint16_t) + 64)) ||
-        (rc = ensure(ctx, ctx->d_path_mono, ((size_t)(P ? P : 1) + 3) / 4 * 4)))
+    const size_t mono_bytes = ((size_t)(P ? P : 1) + 3) / 4 * 4;
+    if ((rc = ensure(ctx, ctx->d_items16, ctx->n_steps * sizeof(uint16_t) + 64)) || (rc = ensure(ctx, ctx->d_path_mono, mono_bytes)))
         return rc;
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_path_mono.p, 0, ((size_t)(P ? P : 1) + 3) / 4 * 4, ctx->stream));
-    if (P && ctx->n_steps) {
-        if ((rc = ensure_chunk_off(ctx))) return rc;
+    DevBuf d_changes;
+    if ((rc = ensure(ctx, d_changes, (size_t)(P ? P : 1) * 4))) return rc;
+    // a graph that is lent out (pnx_share_csr) is prepared by its owner before the first borrower reads it
+    bool may_sort = ctx->sort_shuffled && !ctx->d_items.borrowed && ctx->n_sorted_paths == 0;
+    for (int round = 0; round < 2; ++round) {
+        hipError_t e = hipMemsetAsync(ctx->d_path_mono.p, 0, mono_bytes, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_changes.p, 0, (size_t)(P ? P : 1) * 4, ctx->stream);
+        if (e != hipSuccess) {
+            release(d_changes);
+            return ctx->fail(PNX_EHIP, "prepare_steps: %s", hipGetErrorString(e));
+        }
+        if (!P || !ctx->n_steps) break;
+        if ((rc = ensure_chunk_off(ctx))) {
+            release(d_changes);
+            return rc;
+        }
         const uint64_t n_chunks = ctx->h_chunk_off[P];
-        if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many path chunks");
+        if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) {
+            release(d_changes);
+            return ctx->fail(PNX_ELIMIT, "too many path chunks");
+        }
         hipLaunchKernelGGL(k_prepare_steps, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
                            (const uint64_t *)ctx->d_chunk_off.p, P, n_chunks, (uint16_t *)ctx->d_items16.p,
-                           (uint8_t *)ctx->d_path_mono.p);
+                           (uint8_t *)ctx->d_path_mono.p, (uint32_t *)d_changes.p);
         hipLaunchKernelGGL(k_mono_class, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_path_mono.p, P);
-        PNX_HIP(ctx, hipGetLastError());
+        if (!may_sort) break;
+        // paths that jump between tiles at random: more than one tile change per RUN_MIN_AVG_LEN steps (what the run
+        // index would refuse, kernels_runs.hip).  They are sorted once, then this pass runs again over the new order.
+        std::vector<uint8_t> mono(P);
+        std::vector<uint32_t> changes(P), shuffled;
+        e = hipMemcpyAsync(mono.data(), ctx->d_path_mono.p, P, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(changes.data(), d_changes.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            release(d_changes);
+            return ctx->fail(PNX_EHIP, "prepare_steps: %s", hipGetErrorString(e));
+        }
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint64_t len = ctx->h_path_off[p + 1] - ctx->h_path_off[p], runs = (uint64_t)changes[p] + 1;
+            if (mono[p] && runs * RUN_MIN_AVG_LEN > len && runs > 64) shuffled.push_back(p);
+        }
+        may_sort = false;
+        if (shuffled.empty()) break;
+        if ((rc = sort_paths_in_place(ctx, shuffled))) {
+            release(d_changes);
+            return rc;
+        }
     }
+    release(d_changes);
+    PNX_HIP(ctx, hipGetLastError());
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // once per upload; the passes read this from other streams too
     ctx->steps_prepared = true;
     return PNX_OK;

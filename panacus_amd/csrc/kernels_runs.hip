@@ -29,7 +29,6 @@
 
 namespace pnx {
 
-constexpr uint32_t RUN_MIN_AVG_LEN = 16;  // paths with shorter average runs stay on the scatter route
 
 // flag = this step starts a run (first step of the path, or a different tile than the step before)
 __device__ static inline bool run_starts(const uint32_t *__restrict__ items, uint64_t j, uint64_t pstart,

@@ -273,7 +273,7 @@ void pnx_free(pnx_ctx *ctx) {
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_flags,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_unsorted, &ctx->d_sorted_coff, &ctx->d_sorted_path, &ctx->d_flags,
                       &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
@@ -305,6 +305,13 @@ static void begin_upload(pnx_ctx *ctx) {
     ctx->steps_prepared = false;
     if (ctx->d_items16.borrowed) release(ctx->d_items16);
     if (ctx->d_path_mono.borrowed) release(ctx->d_path_mono);
+    if (ctx->d_unsorted.borrowed) {
+        release(ctx->d_unsorted);
+        release(ctx->d_sorted_coff);
+        release(ctx->d_sorted_path);
+    }
+    ctx->n_sorted_paths = 0;
+    ctx->n_unsorted = 0;
 }
 
 // ... and ends with: d_items / d_path_off / h_path_off (and d_exclude when exclude_resident) are in place
@@ -518,12 +525,7 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
     if (n_nodes == 0 || n_paths == 0) return ctx->fail(PNX_EINVAL, "n_nodes and n_paths must be > 0");
     if (n_nodes >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes must be < 2^32-2");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
-    invalidate_results(ctx);
-    ctx->have_csr = false;
-    ctx->have_order = false;
-    ctx->steps_prepared = false;
-    if (ctx->d_items16.borrowed) release(ctx->d_items16);
-    if (ctx->d_path_mono.borrowed) release(ctx->d_path_mono);
+    begin_upload(ctx);
     int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights);
     if (rc) return rc;
     ctx->have_exclude = false;
@@ -559,6 +561,11 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_items16, src->d_items16);
     borrow(dst->d_path_mono, src->d_path_mono);
     dst->steps_prepared = true;
+    borrow(dst->d_unsorted, src->d_unsorted);
+    borrow(dst->d_sorted_coff, src->d_sorted_coff);
+    borrow(dst->d_sorted_path, src->d_sorted_path);
+    dst->n_sorted_paths = src->n_sorted_paths;
+    dst->n_unsorted = src->n_unsorted;
     borrow(dst->d_new_of_old, src->d_new_of_old);
     borrow(dst->d_old_of_new, src->d_old_of_new);
     dst->relabeled = src->relabeled;
@@ -584,10 +591,11 @@ int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path
     hipError_t e = hipSuccess;
     if (items && ctx->n_steps) {
         const void *src = ctx->d_items.p;
-        if (ctx->relabeled) {
+        if (ctx->relabeled || ctx->n_sorted_paths) {  // the caller's ids, the caller's order
             if ((rc = ensure(ctx, tmp_items, ctx->n_steps * sizeof(uint32_t) + 64))) return rc;
             e = hipMemcpyAsync(tmp_items.p, ctx->d_items.p, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) rc = steps_to_caller_ids(ctx, (uint32_t *)tmp_items.p, ctx->n_steps);
+            if (e == hipSuccess) rc = restore_step_order(ctx, (uint32_t *)tmp_items.p);
+            if (e == hipSuccess && !rc && ctx->relabeled) rc = steps_to_caller_ids(ctx, (uint32_t *)tmp_items.p, ctx->n_steps);
             src = tmp_items.p;
         }
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(items, src, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
@@ -969,6 +977,8 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_general_paths = ctx->n_run_paths + ctx->n_scatter_paths;
     out->n_run_paths = ctx->n_run_paths;
     out->n_scatter_paths = ctx->n_scatter_paths;
+    out->n_sorted_paths = ctx->n_sorted_paths;
+    out->reserved = 0;
     out->n_runs = ctx->n_runs;
     out->n_reruns = ctx->n_reruns;
     out->weighted = ctx->weighted ? 1 : 0;
@@ -1035,6 +1045,9 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             return PNX_OK;
         case PNX_CFG_BLOCKING_SYNC:
             ctx->blocking_sync = value != 0;
+            return PNX_OK;
+        case PNX_CFG_SORT_SHUFFLED:
+            ctx->sort_shuffled = value != 0;
             return PNX_OK;
         case PNX_CFG_OVERLAP_PHASES:
             ctx->overlap_phases = value != 0;

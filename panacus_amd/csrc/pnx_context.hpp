@@ -139,6 +139,13 @@ struct pnx_ctx {
     bool spans_valid = false;  // the three arrays above match the resident CSR and tile size
     uint32_t max_span = 0;
     uint64_t idx_entries = 0;
+    // paths sorted by id at preparation (PNX_CFG_SORT_SHUFFLED): their steps in the caller's order, kept for pnx_get_csr
+    pnx::DevBuf d_unsorted;      // n_unsorted u32, the sorted paths one after the other
+    pnx::DevBuf d_sorted_coff;   // n_sorted_paths + 1 u64: offsets into d_unsorted
+    pnx::DevBuf d_sorted_path;   // n_sorted_paths u32: which path
+    uint32_t n_sorted_paths = 0;
+    uint64_t n_unsorted = 0;
+    bool sort_shuffled = true;
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
@@ -233,6 +240,7 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 // kernels_cover.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
 int prepare_steps(pnx_ctx *ctx);  // d_items16 + d_path_mono (no-op when done)
+int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);  // sorted paths back in the caller's order (pnx_get_csr)
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
 // kernels_runs.hip

@@ -11,6 +11,9 @@
 namespace pnx {
 
 constexpr uint32_t RUN_CHUNK = 4096;  // steps per chunk (one wave walks one chunk)
+// a path whose runs (stretches of consecutive steps inside one tile) average fewer steps than this is not worth a run
+// index: it is sorted by id at preparation (kernels_cover.hip), or takes the atomic scatter route
+constexpr uint32_t RUN_MIN_AVG_LEN = 16;
 
 struct RunChunk {
     uint64_t start;   // first step (absolute index into items)

@@ -180,7 +180,18 @@ def test_hist_ragged_and_empty_paths(ctx):
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
 
 
-def test_hist_unsorted_paths_take_scatter_route(ctx):
+@pytest.fixture
+def sort_shuffled(request, ctx):
+    """PNX_CFG_SORT_SHUFFLED for one test (1 = default: shuffled paths are sorted by id when the graph is
+    prepared; 0: they take the atomic scatter route), restored afterwards on the shared context"""
+    from panacus_amd import capi
+    ctx.config(capi.CFG_SORT_SHUFFLED, request.param)
+    yield request.param
+    ctx.config(capi.CFG_SORT_SHUFFLED, 1)
+
+
+@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
+def test_hist_unsorted_paths_sorted_or_on_the_scatter_route(ctx, sort_shuffled):
     n, p = 30_000, 10
     items, pre, lens = orc.pansyn(11, n, p)
     rng = np.random.default_rng(5)
@@ -198,7 +209,13 @@ def test_hist_unsorted_paths_take_scatter_route(ctx):
     cnt, h = ctx.hist()
     ocov, oh = _oracle_hist(items, pre, pi, gi, n, 5)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
-    assert ctx.info().n_general_paths >= 3
+    info = ctx.info()
+    # the three shuffled paths: sorted once (tile route) or left to the atomic route; the one with a single outlier
+    # is cut into runs either way
+    assert (info.n_sorted_paths, info.n_scatter_paths) == ((3, 0) if sort_shuffled else (0, 3)) and info.n_run_paths == 1
+    got, off, _ = ctx.get_csr()  # the caller's order, whatever the library did with its copy
+    assert np.array_equal(got, items.astype(np.uint32)) and np.array_equal(off, pre)
+    assert ctx.info().n_general_paths == (1 if sort_shuffled else 4)
     # second call (classification cached) gives the same answer
     cnt2, h2 = ctx.hist()
     assert np.array_equal(cnt2, ocov) and np.array_equal(h2, oh)
@@ -356,8 +373,9 @@ def test_ordered_growth_many_groups(ctx):
             assert out[r, t].tolist() == [int(x) for x in exp]
 
 
-def test_growth_after_scatter_route(ctx):
-    """edge-like (unsorted) paths: the presence matrix comes from the scatter route"""
+@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
+def test_growth_after_scatter_route(ctx, sort_shuffled):
+    """edge-like (unsorted) paths: sorted at preparation, or the presence matrix comes from the scatter route"""
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
     n, p = 9000, 8
     items, pre, lens = orc.pansyn(21, n, p)
@@ -556,17 +574,19 @@ def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path):
     keys = hg.edge_keys()
     excl = (rng.random(n + 1) < 0.03).astype(np.uint8)
     excl[0] = 0
-    # without keys: the reference's ids do not follow the paths -> scatter route
+    # without keys: the reference's ids do not follow the paths -> such paths are sorted at preparation
     ctx.set_csr(hitems, hpre, n, exclude=excl)
     ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
     cnt_plain, h_plain = ctx.hist()
-    assert ctx.info().n_scatter_paths > 0
+    assert ctx.info().n_sorted_paths > 0 and ctx.info().n_scatter_paths == 0
+    back, back_off, _ = ctx.get_csr()
+    assert np.array_equal(back, hitems) and np.array_equal(back_off, hpre)
     # with keys: tile route, same answers
     ctx.set_csr(hitems, hpre, n, exclude=excl, item_key=keys)
     ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
     cnt, h = ctx.hist()
     info = ctx.info()
-    assert info.n_scatter_paths == 0
+    assert info.n_scatter_paths == 0 and info.n_sorted_paths == 0
     ocov = orc.coverage(items, pre, pi, gi, n, excl)
     assert np.array_equal(cnt, ocov) and np.array_equal(cnt, cnt_plain)
     assert np.array_equal(h, orc.hist(ocov, G)) and np.array_equal(h, h_plain)
@@ -709,7 +729,8 @@ def _jitter(items, pre, paths, rng, width=40, every=300):
     return items
 
 
-def test_run_route_near_monotone_paths(ctx):
+@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
+def test_run_route_near_monotone_paths(ctx, sort_shuffled):
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
     n, p = 120_000, 16
     items, pre, lens = orc.pansyn(41, n, p)
@@ -724,7 +745,8 @@ def test_run_route_near_monotone_paths(ctx):
     ocov, oh = _oracle_hist(items, pre, pi, gi, n, 8, lens)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
-    assert info.n_run_paths == 5 and info.n_scatter_paths == 1 and info.n_runs > 0
+    assert info.n_run_paths == 5 and info.n_runs > 0
+    assert (info.n_sorted_paths, info.n_scatter_paths) == ((1, 0) if sort_shuffled else (0, 1))
     # a different visiting order / grouping re-sorts the runs
     order = pi[::-1].copy()
     g2 = np.arange(p, dtype=np.uint64)
