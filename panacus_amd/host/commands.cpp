@@ -47,7 +47,9 @@ const char *USAGE =
     "  -m, --method <single|complete|average|weighted|ward|centroid|median>\n"
     "                                   similarity: linkage that orders rows and columns of the table [centroid]\n"
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
-    "                                        write a pansyn-v1 synthetic pangenome as GFA\n";
+    "                                        write a pansyn-v1 synthetic pangenome as GFA\n"
+    "       panacus-amd synth --shape pggb --nodes N --samples M [--seed S] [--sequences] -o FILE.gfa\n"
+    "                                        write a pggb-shaped pangenome (contig paths, inversions, duplications)\n";
 
 Device::Device(int ordinal) {
     int rc = pnx_init(&ctx, ordinal);
@@ -509,6 +511,8 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "--nodes") o.nodes = (uint32_t)std::strtoul(value("--nodes").c_str(), nullptr, 10);
             else if (a == "--paths") o.paths = (uint32_t)std::strtoul(value("--paths").c_str(), nullptr, 10);
             else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
+            else if (a == "--shape") o.shape = value("--shape");
+            else if (a == "--samples") o.samples = (uint32_t)std::strtoul(value("--samples").c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--cache") o.cache = true;
             else if (a == "-m" || a == "--method") o.method = value("--method");
@@ -525,7 +529,18 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (o.file.empty()) o.file = a;
             else throw std::runtime_error("unexpected argument " + a);
         }
+        if (o.cmd == "synth" && o.shape == "pggb") {
+            if (!o.nodes || !o.samples || o.out_file.empty()) throw std::runtime_error("synth --shape pggb needs --nodes, --samples and -o");
+            if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
+            uint32_t np = 0;
+            uint64_t ne = 0;
+            const uint64_t steps = write_pggb_like_gfa(o.out_file, o.seed, o.nodes, o.samples, o.sequences, &np, &ne);
+            out = "wrote " + o.out_file + ": " + std::to_string(o.nodes) + " nodes, " + std::to_string(ne) + " edges, " +
+                  std::to_string(np) + " paths, " + std::to_string(steps) + " steps\n";
+            return 0;
+        }
         if (o.cmd == "synth") {
+            if (!o.shape.empty() && o.shape != "pansyn") throw std::runtime_error("unknown --shape " + o.shape);
             if (!o.nodes || !o.paths || o.out_file.empty()) throw std::runtime_error("synth needs --nodes, --paths and -o");
             if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
             uint64_t steps = write_pansyn_gfa(o.out_file, o.seed, o.nodes, o.paths, o.links, o.sequences);

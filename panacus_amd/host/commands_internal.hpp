@@ -22,8 +22,8 @@ struct Options {
     int threads = 0, device = 0;
     // synth
     uint64_t seed = 42;
-    uint32_t nodes = 0, paths = 0;
-    std::string out_file;
+    uint32_t nodes = 0, paths = 0, samples = 0;
+    std::string out_file, shape;
     bool links = false, sequences = false;
 };
 

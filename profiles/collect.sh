@@ -61,6 +61,7 @@ timeout 600 python $REPO/benchmarks/bench_similarity.py > $OUT/${R}_similarity_c
 timeout 600 python $REPO/benchmarks/bench_similarity.py --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_edge_counts.py > $OUT/${R}_edge_counts_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_subset_cut.py > $OUT/${R}_subset_cut_bench.json 2>/dev/null
+timeout 900 python $REPO/benchmarks/bench_pggb_shape.py > $OUT/${R}_pggb_shape_bench.json 2>/dev/null
 # 6. two lanes over one resident graph (documented alternative, not the headline)
 timeout 600 python $REPO/bench.py --lanes 2 $HEAD_ONLY > $OUT/${R}_hist_cfg3_lanes2_bench.json 2>/dev/null
 ls -la $OUT

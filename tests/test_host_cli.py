@@ -608,3 +608,66 @@ def test_cli_edge_counts_do_not_depend_on_link_order(tmp_path):
         assert [x[1] for x in orows] == [str(int(v)) for v in exp]
         outs.append((_body(out), _body(out2)))
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_cli_pggb_shaped_graph_example_commands(tmp_path):
+    """BASELINE configs[4] (HPRC chr22 pggb) is a 402 MB download that is not in the container; this is its
+    structural stand-in (`synth --shape pggb`: contig paths per haplotype, 2-part reference names, inversions with
+    '-' steps, tandem duplications -> paths on the tile, run and sorted routes at once) through the commands of
+    examples/pangenome_growth_pggb.md:13-22 and test/integrated_test.R:95-137, against the oracle pipeline."""
+    gfa = str(tmp_path / "pggb.gfa")
+    rc, out, err = hl.run_cli(["synth", "--shape", "pggb", "--nodes", "150000", "--samples", "10", "-o", gfa])
+    assert rc == 0, err
+    g = orc.Graph(gfa, index_edges=True)
+    names = g.path_names()
+    assert names[0] == "chm13#chr22" and names[1] == "grch38#chr22" and len(names) > 100
+    items, pre = g.item_table(orc.NODE)
+    assert any(np.any(np.diff(items[pre[k]:pre[k + 1]].astype(np.int64)) < 0) for k in range(2, len(names)))  # back-steps exist
+    haps = tmp_path / "haplotypes.txt"
+    haps.write_text("".join(n + "\n" for n in names if not n.startswith(("grch38", "chm13"))))
+    body = lambda text: [l.split("\t") for l in text.split("\n") if l and not l.startswith("#")]  # noqa: E731
+    # 1. the example: histgrowth -l 1,2,1,1,1 -q 0,0,1,0.5,0.1 -S -a -s haplotypes (node), and the same for bp / edge
+    pairs = [(1, 0.0, "0"), (2, 0.0, "0"), (1, 1.0, "1"), (1, 0.5, "0.5"), (1, 0.1, "0.1")]
+    pi, gi, gnames = g.path_order(orc.GROUP_SAMPLE, None, None, str(haps), None)
+    G = len(gnames)
+    assert G == 10
+    for cname, ct in (("node", orc.NODE), ("bp", orc.BP), ("edge", orc.EDGE)):
+        rc, out, err = hl.run_cli(["histgrowth", "-c", cname, "-l", "1,2,1,1,1", "-q", "0,0,1,0.5,0.1", "-S", "-a", "-s", str(haps), gfa])
+        assert rc == 0, err
+        rows = body(out)
+        m_items, m_pre, fl, ids, ubp = g.masked_table(ct, str(haps), None)
+        cov = orc.coverage(m_items, m_pre, pi, gi, g.n_items(ct), None)
+        h = orc.hist_apply_uncovered(cov, ids, ubp, orc.hist(cov, G, g.node_lens if ct == orc.BP else None))
+        assert [int(r[1]) for r in rows[4:]] == h.tolist(), cname
+        for k, (c, q, qs) in enumerate(pairs):
+            exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+            assert (rows[2][2 + k], rows[3][2 + k]) == (str(c), qs)
+            assert [r[2 + k] for r in rows[5:]] == [hl.format_f64(math.floor(x)) for x in exp], (cname, c, q)
+    # 2. integrated_test.R's grid on the whole graph: -S / -H, node / edge, -q 0,0.5,1.0 -l 0,1,2
+    for flag, mode in (("-S", orc.GROUP_SAMPLE), ("-H", orc.GROUP_HAPLOTYPE)):
+        pi, gi, gnames = g.path_order(mode)
+        G = len(gnames)
+        for cname, ct in (("node", orc.NODE), ("edge", orc.EDGE)):
+            rc, out, err = hl.run_cli(["histgrowth", "-c", cname, flag, "-q", "0,0.5,1.0", "-l", "0,1,2", "-a", gfa])
+            assert rc == 0, err
+            rows = body(out)
+            t_items, t_pre = g.item_table(ct)
+            cov = orc.coverage(t_items, t_pre, pi, gi, g.n_items(ct))
+            h = orc.hist(cov, G)
+            assert [int(r[1]) for r in rows[4:]] == h.tolist(), (flag, cname)
+            for k, (c, q) in enumerate(((0, 0.0), (1, 0.5), (2, 1.0))):
+                exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+                assert [r[2 + k] for r in rows[5:]] == [hl.format_f64(math.floor(x)) for x in exp], (flag, cname, c, q)
+    # 3. ordered growth in file order of the samples + the similarity table, bp
+    pi, gi, gnames = g.path_order(orc.GROUP_SAMPLE)
+    G = len(gnames)
+    rc, out, err = hl.run_cli(["ordered-histgrowth", "-c", "bp", "-S", "-l", "1,2", "-q", "0,0.5", gfa])
+    assert rc == 0, err
+    rows = body(out)[4:]
+    assert [r[0] for r in rows] == gnames
+    t_items, t_pre = g.item_table(orc.BP)
+    r_, c_ = orc.by_group(t_items, t_pre, pi, gi, g.n_nodes)
+    for k, (c, q) in enumerate(((1, 0.0), (2, 0.5))):
+        exp = orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, q), g.node_lens)
+        assert [x[1 + k] for x in rows] == [hl.format_f64(float(v)) for v in exp], (c, q)
