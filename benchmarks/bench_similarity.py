@@ -25,10 +25,12 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--bp", action="store_true", help="weighted by node length (16 weight planes)")
     ap.add_argument("--check-nodes", type=int, default=200_000, help="oracle check on a small graph first (0 = skip)")
+    ap.add_argument("--variant", type=int, default=1, help="PNX_CFG_PAIRS_VARIANT: 1 = int8 MFMA [default], 0 = AND + popcount")
     args = ap.parse_args()
     from panacus_amd import capi
 
     ctx = capi.Context(0)
+    ctx.config(capi.CFG_PAIRS_VARIANT, args.variant)
     if args.check_nodes:
         import oracle as orc
         n, p = args.check_nodes, min(args.paths, 96)
@@ -64,8 +66,16 @@ def main():
     valu_ops = pair_words * (1 + 3 * planes if args.bp else 2)
     # 256 CUs x 4 SIMD x 16 lanes at 2.4 GHz
     peak_ops = 256 * 4 * 16 * 2.4e9
+    # matrix cores: 128 x 128 tiles on and above the diagonal, one int8 MAC per (pair, item, 7-bit digit of the weight)
+    side128 = (P + 127) // 128
+    digits = 3 if args.bp else 1  # pansyn weights < 2^16
+    mfma_ops = 2 * (side128 * (side128 + 1) // 2) * 128 * 128 * row_words * 32 * digits
+    peak_i8 = 5.0e15  # dense int8 = 2 x the 2.5 PFLOP/s bf16 peak (the guide's 32x32x32 i8 micro-benchmark floor: 4.4e15)
     out = {
         "benchmark": "group_intersections", "nodes": N, "groups": P, "weighted": bool(args.bp),
+        "variant": "int8 MFMA" if args.variant == 1 else "AND + popcount",
+        "mfma_ops": mfma_ops if args.variant == 1 else None,
+        "mfma_frac_of_peak": (mfma_ops / (k_ms * 1e-3) / peak_i8) if args.variant == 1 else None,
         "steps_in_csr": int(info.n_steps), "kernel_ms": k_ms, "wall_ms_per_call": wall * 1e3,
         "pair_words_per_s": pair_words / (k_ms * 1e-3),
         "item_pairs_per_s": pair_words * 32 / (k_ms * 1e-3),

@@ -364,6 +364,9 @@ enum {
                                   and the histogram of pass k-1 run beside the coverage kernel of pass k; 0: one stream */
     PNX_CFG_COMM_REDUCE_HIST = 13, /* with a communicator (pnx_comm_init): 1 [default] every coverage pass is followed by the
                                   all-reduce of its flags + histogram, 0 the caller reduces what it needs itself */
+    PNX_CFG_PAIRS_VARIANT = 16, /* group x group intersections (pnx_group_intersections): 1 [default] = int8 MFMA on the matrix
+                                  cores (presence bits x 7-bit digits of the weights), 0 = AND + popcount on the vector ALUs
+                                  (one pass per bit plane of the weights; kept as a cross-check) */
     PNX_CFG_SORT_SHUFFLED = 15, /* 1 [default]: a path whose steps jump between item tiles at random (more than one tile
                                   change per 16 steps: edge ids without a key, ids unrelated to the walk) is SORTED by id
                                   once, on the device, when the graph is prepared -- every result of this library depends

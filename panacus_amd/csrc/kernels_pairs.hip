@@ -227,6 +227,7 @@ int launch_pair_intersections(pnx_ctx *ctx) {
         PNX_HIP(ctx, hipMemsetAsync(ctx->d_inter.p, 0, (size_t)G * G * sizeof(uint64_t), ctx->stream));
         return PNX_OK;
     }
+    if (ctx->pairs_variant == 1) return launch_pair_intersections_mfma(ctx);
     const uint64_t row_words = (uint64_t)NB * BLOCK_WORDS;
     const uint32_t n_side = (G + PAIR_T - 1) / PAIR_T;
     if ((uint64_t)n_side * n_side > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many groups for the pair kernel");

@@ -130,6 +130,7 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->spans_valid = false;
     ctx->order_normalized = false;
     ctx->wplanes_valid = false;
+    ctx->wdigits_valid = false;
     ctx->last_general_paths = 0;
 }
 
@@ -273,7 +274,7 @@ void pnx_free(pnx_ctx *ctx) {
     prof_resolve(ctx);
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
-                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_unsorted, &ctx->d_sorted_coff, &ctx->d_sorted_path, &ctx->d_flags,
+                      &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_wdigits, &ctx->d_unsorted, &ctx->d_sorted_coff, &ctx->d_sorted_path, &ctx->d_flags,
                       &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
@@ -1045,6 +1046,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             return PNX_OK;
         case PNX_CFG_BLOCKING_SYNC:
             ctx->blocking_sync = value != 0;
+            return PNX_OK;
+        case PNX_CFG_PAIRS_VARIANT:
+            if (value != 0 && value != 1) return ctx->fail(PNX_EINVAL, "PNX_CFG_PAIRS_VARIANT must be 0 or 1");
+            ctx->pairs_variant = (int)value;
             return PNX_OK;
         case PNX_CFG_SORT_SHUFFLED:
             ctx->sort_shuffled = value != 0;

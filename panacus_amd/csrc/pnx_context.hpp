@@ -187,6 +187,9 @@ struct pnx_ctx {
     std::vector<uint32_t> h_perms, h_qtab, h_growth_tabs, h_growth_aux;
     uint32_t n_wplanes = 0;
     bool wplanes_valid = false;
+    pnx::DevBuf d_wdigits;       // 7-bit digits of the weights, one byte per item in presence order (kernels_pairs_mfma.hip)
+    bool wdigits_valid = false;
+    int pairs_variant = 1;       // PNX_CFG_PAIRS_VARIANT: 0 vector ALUs (AND + popcount), 1 matrix cores (int8 MFMA)
     bool growth_pending = false;
 
     // ---- pairwise intersections / plain presence export (kernels_pairs.hip) ----
@@ -252,6 +255,7 @@ int launch_growth(pnx_ctx *ctx, bool identity_perm);
 int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p in presence layout
 // kernels_pairs.hip
 int launch_pair_intersections(pnx_ctx *ctx);  // -> ctx->d_inter (G x G u64)
+int launch_pair_intersections_mfma(pnx_ctx *ctx);  // kernels_pairs_mfma.hip
 int launch_presence_plain(pnx_ctx *ctx, DevBuf &out);
 int launch_visit_counts(pnx_ctx *ctx, uint32_t lo, uint32_t hi, DevBuf &d_path_group, DevBuf &out);  // lo, hi: caller ids  // -> n_groups x (hi - lo) u32
 // pnx_comm.hip

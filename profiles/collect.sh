@@ -50,6 +50,16 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_A
     python $REPO/profiles/summarize_pmc.py "$(db /tmp/p_pmc)" $OUT/${R}_growth_cfg4_pmc_$N.csv > /dev/null
 done
 
+# 4b. K5 on the matrix cores (similarity, bp): kernel stats and the MFMA / VALU counters
+rm -rf /tmp/p_s; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_s -o sim -- \
+    python $REPO/benchmarks/bench_similarity.py --bp --check-nodes 0 --reps 3 > /dev/null 2>&1
+python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_s)" $OUT/${R}_similarity_cfg4_kernel_stats.csv > /dev/null
+for C in "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
+    rm -rf /tmp/p_pmc; timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/p_pmc -o pmc -- \
+        python $REPO/benchmarks/bench_similarity.py --bp --check-nodes 0 --reps 1 > /dev/null 2>&1
+    python $REPO/profiles/summarize_pmc.py "$(db /tmp/p_pmc)" $OUT/${R}_similarity_cfg4_pmc_SQ_mfma.csv > /dev/null
+done
+
 # 5. the side benches
 timeout 600 python $REPO/benchmarks/bench_tile_index.py --coarse 8 --probe 16,32 > $OUT/${R}_tile_index_bench.jsonl 2>/dev/null
 timeout 300 $REPO/benchmarks/micro/random_sector_rate > $OUT/${R}_random_sector_rate.jsonl 2>/dev/null
@@ -59,6 +69,8 @@ timeout 600 python $REPO/benchmarks/bench_run_route.py > $OUT/${R}_run_route_ben
 timeout 900 python $REPO/benchmarks/bench_contig_paths.py > $OUT/${R}_contig_paths_bench.json 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py > $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
+timeout 600 python $REPO/benchmarks/bench_similarity.py --variant 0 >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
+timeout 600 python $REPO/benchmarks/bench_similarity.py --variant 0 --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_edge_counts.py > $OUT/${R}_edge_counts_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_subset_cut.py > $OUT/${R}_subset_cut_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_pggb_shape.py > $OUT/${R}_pggb_shape_bench.json 2>/dev/null

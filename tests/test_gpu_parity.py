@@ -861,10 +861,20 @@ def test_group_intersections_chrM(ctx, golden_dir, count):
     assert np.diag(got).tolist() == lens.tolist()
 
 
+@pytest.fixture
+def pairs_variant(request, ctx):
+    """PNX_CFG_PAIRS_VARIANT for one test: 1 = int8 MFMA [default], 0 = AND + popcount on the vector ALUs"""
+    from panacus_amd import capi
+    ctx.config(capi.CFG_PAIRS_VARIANT, request.param)
+    yield request.param
+    ctx.config(capi.CFG_PAIRS_VARIANT, 1)
+
+
+@pytest.mark.parametrize("pairs_variant", [1, 0], indirect=True)
 @pytest.mark.parametrize("n,p,paths_per_group,weighted", [(5_000, 7, 1, False), (70_000, 70, 1, False),
                                                           (70_000, 70, 1, True), (40_000, 130, 1, False),
-                                                          (30_000, 48, 2, True)])
-def test_group_intersections_vs_oracle(ctx, n, p, paths_per_group, weighted):
+                                                          (30_000, 48, 2, True), (20_000, 300, 1, True)])
+def test_group_intersections_vs_oracle(ctx, n, p, paths_per_group, weighted, pairs_variant):
     items, pre, lens = orc.pansyn(21, n, p)
     w = lens if weighted else None
     excl = np.zeros(n + 1, dtype=np.uint8)
@@ -886,8 +896,9 @@ def test_group_intersections_vs_oracle(ctx, n, p, paths_per_group, weighted):
     assert (ctx.group_intersections() == exp2).all()
 
 
-def test_group_intersections_wide_weights(ctx):
-    """weights above 2^16 use the high accumulator planes"""
+@pytest.mark.parametrize("pairs_variant", [1, 0], indirect=True)
+def test_group_intersections_wide_weights(ctx, pairs_variant):
+    """weights above 2^16 use the high accumulator planes (vector kernel) / a second launch for digits 3, 4 (MFMA)"""
     n, p = 9_000, 9
     items, pre, lens = orc.pansyn(5, n, p)
     w = lens.copy()
