@@ -102,7 +102,15 @@ int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude);
  *                  util.rs:1171-1181), PNX_WALK_CUT (walked against its interval lists)
  *   node_len       n_nodes+1 node lengths
  *   edge_item/edge_off  NULL for node / bp counts; for edge counts the edge ItemTable (edge id of every
- *                  consecutive step pair) and its n_paths+1 offsets
+ *                  consecutive step pair) and its n_paths+1 offsets -- OR, instead (edge_item == NULL):
+ *   edge_uv/edge_oo     the edges themselves, n_items+1 entries indexed by edge id ([0] unused): canonical ends
+ *                  (smaller node id << 32 | larger) and orientations (o1 << 1 | o2, 1 = backward) as
+ *                  Edge::canonical writes them (graph.rs:142-148; the keys of the reference's edge2id).  The
+ *                  library then looks the edge of every consecutive step pair up itself -- a hash table in HBM,
+ *                  one probe sequence per step -- which replaces the per-step edge2id lookups of
+ *                  parse_path_seq_to_item_vec / update_tables_edgecount (util.rs:1048-1091, 723-795); a step
+ *                  pair without an edge fails the call (the reference panics, util.rs:1080).  edge_uv also
+ *                  serves as item_key when none is given.
  *   inc_*, exc_*   per path [off[p], off[p+1]) [start, end) pairs (2 u64 each), sorted by start, every interval
  *                  starting BEYOND the end of its predecessor (GraphMask's interval sets: overlapping and
  *                  touching rows joined; a row with start > end is passed as it is and acts, as in the
@@ -124,6 +132,8 @@ typedef struct pnx_walks {
     const uint32_t *node_len;
     const uint32_t *edge_item;
     const uint64_t *edge_off;
+    const uint64_t *edge_uv;
+    const uint8_t *edge_oo;
     uint32_t n_items;
     int count_type;
     int track_covered;

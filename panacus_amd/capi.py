@@ -52,7 +52,8 @@ class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
                 ("walk_off", C.POINTER(C.c_uint64)), ("path_start", C.POINTER(C.c_uint64)),
                 ("path_mode", C.POINTER(C.c_uint8)), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("node_len", C.POINTER(C.c_uint32)), ("edge_item", C.POINTER(C.c_uint32)),
-                ("edge_off", C.POINTER(C.c_uint64)), ("n_items", C.c_uint32), ("count_type", C.c_int),
+                ("edge_off", C.POINTER(C.c_uint64)), ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)),
+                ("n_items", C.c_uint32), ("count_type", C.c_int),
                 ("track_covered", C.c_int), ("inc_off", C.POINTER(C.c_uint64)), ("inc_iv", C.POINTER(C.c_uint64)),
                 ("exc_off", C.POINTER(C.c_uint64)), ("exc_iv", C.POINTER(C.c_uint64))]
 
@@ -223,7 +224,7 @@ class Context:
 
     def set_csr_cut(self, walk_node, walk_off, node_len, path_mode, inc, exc=None, path_start=None, walk_backward=None,
                     count_type=0, edge_item=None, edge_off=None, n_items=None, weights=None, item_key=None,
-                    track_covered=False, max_events=None):
+                    track_covered=False, max_events=None, edge_uv=None, edge_oo=None):
         """pnx_set_csr_cut: inc / exc = per path a list of (start, end) pairs (sorted, disjoint, not touching;
         exc None = no exclude list).  -> list of event dicts (bp counts)"""
         keep = []
@@ -258,6 +259,9 @@ class Context:
         if edge_off is not None:
             w.edge_item = _ptr(arr(edge_item, np.uint32), C.c_uint32)
             w.edge_off = _ptr(arr(edge_off, np.uint64), C.c_uint64)
+        if edge_uv is not None:
+            w.edge_uv = _ptr(arr(edge_uv, np.uint64), C.c_uint64)
+            w.edge_oo = _ptr(arr(edge_oo, np.uint8), C.c_uint8)
         w.n_items = n_nodes if n_items is None else n_items
         w.count_type = count_type
         w.track_covered = int(track_covered)

@@ -178,6 +178,77 @@ __device__ static inline void piece_of(uint64_t s, uint64_t e, uint64_t p, uint6
     }
 }
 
+// ---- edge ids of the step pairs, looked up on the device ------------------------------------------
+// (uv, oo) -> edge id: open addressing over two arrays; a key may sit in several slots (same ends, other
+// orientations), so neither insert nor lookup stops at an equal key with the wrong orientation
+struct EdgeTab {
+    unsigned long long *key;  // 0 = empty (uv >= 2^32: node ids start at 1)
+    uint32_t *val;            // id << 2 | oo
+    uint64_t mask;
+};
+__device__ static inline uint64_t edge_hash(uint64_t uv, uint32_t oo) {
+    uint64_t x = (uv ^ ((uint64_t)oo << 62)) * 0x9FB21C651E98DF25ull;
+    return x ^ (x >> 31);
+}
+__global__ void k_edge_tab_insert(const uint64_t *__restrict__ uv, const uint8_t *__restrict__ oo, uint32_t n_edges, EdgeTab t,
+                                  uint32_t *bad) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (id > n_edges) return;
+    const unsigned long long k = uv[id];
+    const uint32_t o = oo[id] & 3u;
+    if ((k >> 32) == 0 || (uint32_t)k == 0 || (k >> 32) > (uint32_t)k) {  // canonical: 1 <= smaller <= larger
+        *bad = 1u;
+        return;
+    }
+    uint64_t slot = edge_hash(k, o) & t.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(t.key + slot, 0ull, k);
+        if (prev == 0ull) {
+            t.val[slot] = (id << 2) | o;
+            return;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+}
+// Edge::canonical (graph.rs:142-148) of the step pair (u, o1) -> (v, o2)
+__device__ static inline void canonical_edge(uint32_t u, uint32_t o1, uint32_t v, uint32_t o2, uint64_t &uv, uint32_t &oo) {
+    if (u > v || (u == v && o1 == 1)) {
+        uv = ((uint64_t)v << 32) | u;
+        oo = ((o2 ^ 1u) << 1) | (o1 ^ 1u);
+    } else {
+        uv = ((uint64_t)u << 32) | v;
+        oo = (o1 << 1) | o2;
+    }
+}
+// one thread per step: the edge to its successor in the same path -> edge_item[edge_off[path] + local index]
+__global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeTab t, uint32_t *__restrict__ out, unsigned long long *bad_step) {
+    const CutChunk ch = cut_chunk_of(blockIdx.x, a);
+    const uint64_t e0 = a.edge_off[ch.path] - a.off[ch.path];
+    for (uint32_t x = threadIdx.x; x < ch.len; x += CUT_THREADS) {
+        const uint64_t j = ch.start + x;
+        if (j + 1 >= ch.pend) continue;
+        uint64_t uv;
+        uint32_t oo;
+        canonical_edge(a.node[j], a.backward ? a.backward[j] & 1u : 0u, a.node[j + 1], a.backward ? a.backward[j + 1] & 1u : 0u, uv, oo);
+        uint64_t slot = edge_hash(uv, oo) & t.mask;
+        uint32_t id = 0;
+        for (;;) {
+            const unsigned long long k = t.key[slot];
+            if (k == 0ull) break;
+            if (k == uv) {
+                const uint32_t v = t.val[slot];
+                if ((v & 3u) == oo) {
+                    id = v >> 2;
+                    break;
+                }
+            }
+            slot = (slot + 1) & t.mask;
+        }
+        if (!id) atomicMin(bad_step, (unsigned long long)j);
+        out[j + e0] = id;
+    }
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(CUT_THREADS) void k_cut(CutArgs a) {
     __shared__ unsigned long long lds64[CUT_THREADS / 64 + 1];
@@ -341,10 +412,10 @@ namespace {
 struct Scratch {  // freed on every way out
     std::vector<DevBuf *> all;
     DevBuf node, back, off, chunk_off, start, mode, len, eitem, eoff, inc_off, inc_iv, exc_off, exc_iv, chunk_bp, chunk_base,
-        chunk_cnt, chunk_out, is_partial, last_full, events, counters, tmp, out_off;
+        chunk_cnt, chunk_out, is_partial, last_full, events, counters, tmp, out_off, e_uv, e_oo, tab_key, tab_val;
     Scratch() {
         all = {&node, &back, &off, &chunk_off, &start, &mode, &len, &eitem, &eoff, &inc_off, &inc_iv, &exc_off, &exc_iv, &chunk_bp,
-               &chunk_base, &chunk_cnt, &chunk_out, &is_partial, &last_full, &events, &counters, &tmp, &out_off};
+               &chunk_base, &chunk_cnt, &chunk_out, &is_partial, &last_full, &events, &counters, &tmp, &out_off, &e_uv, &e_oo, &tab_key, &tab_val};
     }
     ~Scratch() {
         for (DevBuf *b : all) release(*b);
@@ -365,7 +436,18 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     const uint64_t C = h_chunk_off[P];
     if (C >= 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "pnx_set_csr_cut: more than 2^31 chunks of %u steps", CUT_CHUNK);
     const uint64_t n_inc = w->inc_off[P], n_exc = w->exc_off ? w->exc_off[P] : 0;
-    const uint64_t E = edge ? w->edge_off[P] : 0;
+    // edge counts without a ready-made edge ItemTable: the library looks the edges up itself (below)
+    const bool lookup = edge && !w->edge_item;
+    std::vector<uint64_t> h_eoff;
+    if (lookup) {
+        h_eoff.assign((size_t)P + 1, 0);
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint64_t len = w->walk_off[p + 1] - w->walk_off[p];
+            h_eoff[p + 1] = h_eoff[p] + (len ? len - 1 : 0);
+        }
+    }
+    const uint64_t *edge_off = lookup ? h_eoff.data() : w->edge_off;
+    const uint64_t E = edge ? edge_off[P] : 0;
 
     auto up = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         int r = ensure(ctx, b, bytes ? bytes : 8);
@@ -381,8 +463,12 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     if ((rc = up(s.mode, w->path_mode, P))) return rc;
     if ((rc = up(s.len, w->node_len, ((size_t)w->n_nodes + 1) * 4))) return rc;
     if (edge) {
-        if ((rc = up(s.eitem, w->edge_item, E * 4))) return rc;
-        if ((rc = up(s.eoff, w->edge_off, ((size_t)P + 1) * 8))) return rc;
+        if (lookup) {
+            if ((rc = ensure(ctx, s.eitem, E * 4 + 16))) return rc;
+        } else if ((rc = up(s.eitem, w->edge_item, E * 4))) {
+            return rc;
+        }
+        if ((rc = up(s.eoff, edge_off, ((size_t)P + 1) * 8))) return rc;
     }
     if ((rc = up(s.inc_off, w->inc_off, ((size_t)P + 1) * 8))) return rc;
     if ((rc = up(s.inc_iv, w->inc_iv, n_inc * 16))) return rc;
@@ -438,13 +524,45 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     uint32_t *d_bad = (uint32_t *)((char *)s.counters.p + 8);
 
     uint64_t total = 0;
+    EdgeTab tab{};
+    unsigned long long *d_bad_step = (unsigned long long *)((char *)s.counters.p + 16);
+    if (lookup && w->n_items) {  // the edges into a hash table in HBM (load factor <= 1/2)
+        uint64_t slots = 1024;
+        while (slots < 2ull * w->n_items) slots <<= 1;
+        if ((rc = up(s.e_uv, w->edge_uv, ((size_t)w->n_items + 1) * 8)) || (rc = up(s.e_oo, w->edge_oo, (size_t)w->n_items + 1)) ||
+            (rc = ensure(ctx, s.tab_key, slots * 8)) || (rc = ensure(ctx, s.tab_val, slots * 4)))
+            return rc;
+        PNX_HIP(ctx, hipMemsetAsync(s.tab_key.p, 0, slots * 8, ctx->stream));
+        tab.key = (unsigned long long *)s.tab_key.p;
+        tab.val = (uint32_t *)s.tab_val.p;
+        tab.mask = slots - 1;
+        hipLaunchKernelGGL(k_edge_tab_insert, dim3((w->n_items + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)s.e_uv.p,
+                           (const uint8_t *)s.e_oo.p, w->n_items, tab, d_bad + 1);
+        PNX_HIP(ctx, hipGetLastError());
+    }
     if (C) {
         hipLaunchKernelGGL(k_cut_chunk_bp, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a, (uint64_t *)s.chunk_bp.p, d_bad);
         PNX_HIP(ctx, hipGetLastError());
-        uint32_t bad = 0;
-        PNX_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t bad[2] = {0, 0};
+        PNX_HIP(ctx, hipMemcpyAsync(bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the walk gathers node_len[id]: ids must be valid first
-        if (bad) return ctx->fail(PNX_EINVAL, "walk_node contains ids outside 1..n_nodes");
+        if (bad[0]) return ctx->fail(PNX_EINVAL, "walk_node contains ids outside 1..n_nodes");
+        if (bad[1]) return ctx->fail(PNX_EINVAL, "edge_uv holds an entry that is not canonical (1 <= smaller end <= larger end)");
+        if (lookup && E) {
+            if (!w->n_items) return ctx->fail(PNX_EINVAL, "unknown edge in path: the graph has no edges");
+            PNX_HIP(ctx, hipMemsetAsync(d_bad_step, 0xFF, 8, ctx->stream));
+            hipLaunchKernelGGL(k_edge_items, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a, tab, (uint32_t *)s.eitem.p, d_bad_step);
+            PNX_HIP(ctx, hipGetLastError());
+            unsigned long long bad_step = 0;
+            PNX_HIP(ctx, hipMemcpyAsync(&bad_step, d_bad_step, 8, hipMemcpyDeviceToHost, ctx->stream));
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (bad_step != ~0ull) {
+                uint32_t p = 0;
+                while (p + 1 < P && w->walk_off[p + 1] <= bad_step) ++p;
+                return ctx->fail(PNX_EINVAL, "unknown edge in path %u (steps %llu, %llu)", p, bad_step - w->walk_off[p],
+                                 bad_step - w->walk_off[p] + 1);
+            }
+        }
         PNX_HIP(ctx, hipMemsetAsync((uint64_t *)s.chunk_bp.p + C, 0, 8, ctx->stream));
         if ((rc = scan_u64(ctx, (const uint64_t *)s.chunk_bp.p, (uint64_t *)s.chunk_base.p, C + 1, s.tmp))) return rc;
         hipLaunchKernelGGL(k_cut<false>, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a);

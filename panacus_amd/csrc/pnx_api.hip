@@ -382,7 +382,8 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
     if (w->count_type < 0 || w->count_type > 2) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: count_type must be 0, 1 or 2");
     if (w->n_items >= 0xFFFFFFFEu || w->n_paths >= 0xFFFFFFFEu || w->n_nodes >= 0xFFFFFFFEu)
         return ctx->fail(PNX_ELIMIT, "n_items, n_nodes and n_paths must be < 2^32-2");
-    if (w->count_type == 2 ? (!w->edge_off || (w->edge_off[w->n_paths] && !w->edge_item)) : w->n_items != w->n_nodes)
+    const bool edge_lookup = w->count_type == 2 && !w->edge_item && w->edge_uv && w->edge_oo;
+    if (w->count_type == 2 ? (!edge_lookup && (!w->edge_off || (w->edge_off[w->n_paths] && !w->edge_item))) : w->n_items != w->n_nodes)
         return ctx->fail(PNX_EINVAL, w->count_type == 2 ? "pnx_set_csr_cut: edge counts need the edge ItemTable"
                                                           : "pnx_set_csr_cut: n_items must equal n_nodes for node / bp counts");
     if (cap && !events) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: events is NULL");
@@ -393,7 +394,7 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
             return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: offsets are not non-decreasing at path %u", p);
         if (w->path_mode[p] > PNX_WALK_CUT) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: path_mode[%u] = %u", p, w->path_mode[p]);
         const uint64_t len = w->walk_off[p + 1] - w->walk_off[p];
-        if (w->count_type == 2 && w->edge_off[p + 1] - w->edge_off[p] != (len ? len - 1 : 0))
+        if (w->count_type == 2 && !edge_lookup && w->edge_off[p + 1] - w->edge_off[p] != (len ? len - 1 : 0))
             return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: path %u has %llu steps but %llu edges", p, (unsigned long long)len,
                              (unsigned long long)(w->edge_off[p + 1] - w->edge_off[p]));
         for (int which = 0; which < 2; ++which) {  // sorted by start, each starts beyond its predecessor's end
@@ -410,7 +411,8 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
     begin_upload(ctx);
     int rc = pnx::cut_walks(ctx, w, events, cap, n_events);
     if (rc) return rc;
-    return finish_upload(ctx, ctx->n_steps, w->n_paths, w->n_items, weights, nullptr, w->exc_off != nullptr, item_key);
+    return finish_upload(ctx, ctx->n_steps, w->n_paths, w->n_items, weights, nullptr, w->exc_off != nullptr,
+                         item_key ? item_key : (edge_lookup ? w->edge_uv : nullptr));
 }
 
 int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {

@@ -107,8 +107,6 @@ Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Ma
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     };
     const uint64_t n_items = g.number_of_items(ct);
-    std::vector<uint64_t> keys;
-    if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
     const WalkCut cut = g.walk_cut(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
     const uint32_t none32 = 0;
     const uint8_t none8 = 0;
@@ -122,9 +120,9 @@ Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Ma
     w.n_paths = (uint32_t)cut.path_mode.size();
     w.n_nodes = (uint32_t)g.node_count();
     w.node_len = g.node_lens().data();
-    if (ct == COUNT_EDGE) {
-        w.edge_item = cut.edges.items.empty() ? &none32 : cut.edges.items.data();
-        w.edge_off = cut.edges.id_prefsum.data();
+    if (ct == COUNT_EDGE) {  // the library looks the edge of every step pair up itself and ranks the edges by their ends
+        w.edge_uv = cut.edge_uv.data();
+        w.edge_oo = cut.edge_oo.data();
     }
     w.n_items = (uint32_t)n_items;
     w.count_type = (int)ct;
@@ -138,7 +136,7 @@ Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Ma
     static_assert(sizeof(PieceEvent) == sizeof(pnx_piece_event), "PieceEvent mirrors pnx_piece_event");
     std::vector<PieceEvent> events(cut.max_events);
     uint64_t n_events = 0;
-    check(pnx_set_csr_cut(ctx, &w, ct == COUNT_BP ? g.node_lens().data() : nullptr, keys.empty() ? nullptr : keys.data(),
+    check(pnx_set_csr_cut(ctx, &w, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr,
                           reinterpret_cast<pnx_piece_event *>(events.data()), events.size(), &n_events));
     events.resize(n_events);
     Uncovered uncovered;
@@ -157,15 +155,18 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
                  bool growth_weights, bool /*per_item_output*/) {
     const uint64_t n_items = g.number_of_items(ct);
     const uint32_t n_paths = (uint32_t)g.path_segments().size();
-    std::vector<uint64_t> keys;
-    if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
-    const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
     Uncovered uncovered;
-    if (mk.any()) {
+    // -s / -e lists: the walks are cut on the device.  Edge counts take the same entry even without lists (every path
+    // "cut" by the whole-path interval): the node walks go up and the library finds the edge of every step pair in a hash
+    // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
+    if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file())) {
         uncovered = upload_cut(dev.ctx, g, ct, mk, growth_weights);
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
+        std::vector<uint64_t> keys;  // a cached edge table: ranked by the canonical ends of its edges (pnx_set_csr_keyed)
+        if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
+        const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
         dev.check(pnx_set_csr_keyed(dev.ctx, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
                                     ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr, key_ptr));
     }

@@ -519,23 +519,52 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     if (index_edges) {
         im.has_edges = true;
         im.edges.init(l_lines.size());
-        uint32_t next = 1;
-        for (const Span ln : l_lines) {
+        // the lines are parsed in parallel (two name lookups each); ids are given in file order afterwards
+        const size_t n_l = l_lines.size();
+        std::vector<uint64_t> l_uv(n_l);
+        std::vector<uint8_t> l_oo(n_l);
+        std::atomic<int64_t> bad_line{-1};
+        std::atomic<int> bad_kind{0};
+        const size_t L_CHUNK = 8192;
+        ThreadPool::instance().parallel_for((n_l + L_CHUNK - 1) / L_CHUNK, [&](size_t c) {
+            const size_t hi = std::min(n_l, (c + 1) * L_CHUNK);
+            for (size_t k = c * L_CHUNK; k < hi; ++k) {
+                const Span ln = l_lines[k];
+                size_t a0 = ln.b + 2, a1 = field_end(s, a0, ln.e);
+                if (a1 + 2 >= ln.e) {
+                    bad_kind.store(1);
+                    bad_line.store((int64_t)k);
+                    return;
+                }
+                const uint32_t u = im.node_id(s.data() + a0, a1 - a0);
+                const uint8_t o1 = s[a1 + 1] == '+' ? 0 : 1;
+                size_t b0 = a1 + 3, b1 = field_end(s, b0, ln.e);
+                if (b1 + 1 >= ln.e) {
+                    bad_kind.store(1);
+                    bad_line.store((int64_t)k);
+                    return;
+                }
+                const uint32_t v = im.node_id(s.data() + b0, b1 - b0);
+                const uint8_t o2 = s[b1 + 1] == '+' ? 0 : 1;
+                if (!u || u > g->node_count_ || !v || v > g->node_count_) {
+                    bad_kind.store(!u || u > g->node_count_ ? 2 : 3);
+                    bad_line.store((int64_t)k);
+                    return;
+                }
+                canonical(u, o1, v, o2, l_uv[k], l_oo[k]);
+            }
+        });
+        if (bad_line.load() >= 0) {
+            const Span ln = l_lines[(size_t)bad_line.load()];
+            if (bad_kind.load() == 1) throw std::runtime_error("malformed L line");
             size_t a0 = ln.b + 2, a1 = field_end(s, a0, ln.e);
-            if (a1 + 2 >= ln.e) throw std::runtime_error("malformed L line");
-            uint32_t u = im.node_id(s.data() + a0, a1 - a0);
-            uint8_t o1 = s[a1 + 1] == '+' ? 0 : 1;
+            if (bad_kind.load() == 2) throw std::runtime_error("unknown node " + s.substr(a0, a1 - a0));
             size_t b0 = a1 + 3, b1 = field_end(s, b0, ln.e);
-            if (b1 + 1 >= ln.e) throw std::runtime_error("malformed L line");
-            uint32_t v = im.node_id(s.data() + b0, b1 - b0);
-            uint8_t o2 = s[b1 + 1] == '+' ? 0 : 1;
-            if (!u || u > g->node_count_) throw std::runtime_error("unknown node " + s.substr(a0, a1 - a0));
-            if (!v || v > g->node_count_) throw std::runtime_error("unknown node " + s.substr(b0, b1 - b0));
-            uint64_t uv;
-            uint8_t oo;
-            canonical(u, o1, v, o2, uv, oo);
-            if (im.edges.insert(uv, oo, next)) ++next;  // duplicated edges are skipped (graph.rs:296)
+            throw std::runtime_error("unknown node " + s.substr(b0, b1 - b0));
         }
+        uint32_t next = 1;
+        for (size_t k = 0; k < n_l; ++k)
+            if (im.edges.insert(l_uv[k], l_oo[k], next)) ++next;  // duplicated edges are skipped (graph.rs:296)
         g->edge_count_ = next - 1;
     }
     return g;
@@ -1230,6 +1259,25 @@ std::vector<uint64_t> GraphStorage::edge_keys() const {
     return keys;
 }
 
+void GraphStorage::edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo) const {
+    const Impl &im = *impl_;
+    if (!im.has_edges) throw std::runtime_error("edge ends need the edge index");
+    uv.assign(edge_count_ + 1, 0);
+    oo.assign(edge_count_ + 1, 0);
+    if (im.cached) {
+        for (uint64_t id = 1; id <= edge_count_; ++id) {
+            uv[id] = im.c_edge_uv[id];
+            oo[id] = im.c_edge_oo[id];
+        }
+        return;
+    }
+    for (const auto &sl : im.edges.tab)
+        if (sl.id) {
+            uv[sl.id] = sl.uv;
+            oo[sl.id] = sl.oo;
+        }
+}
+
 std::vector<uint32_t> GraphStorage::edge_relabel() const {
     const Impl &im = *impl_;
     if (!im.has_edges) throw std::runtime_error("edge renumbering needs the edge index");
@@ -1625,7 +1673,7 @@ WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::strin
         w.walk_backward.swap(steps.ori);
         w.walk_off.swap(steps.pref);
     }
-    if (count == COUNT_EDGE) w.edges = item_table(COUNT_EDGE);
+    if (count == COUNT_EDGE) edge_ends(w.edge_uv, w.edge_oo);
     w.path_start.assign(P, 0);
     w.path_mode.assign(P, SKIP);
     w.inc_off.assign(P + 1, 0);

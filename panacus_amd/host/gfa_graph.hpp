@@ -67,7 +67,8 @@ struct WalkCut {
     std::vector<uint32_t> walk_node;
     std::vector<uint8_t> walk_backward, path_mode;
     std::vector<uint64_t> walk_off, path_start;
-    ItemTable edges;  // edge counts: the edge of every consecutive step pair
+    std::vector<uint64_t> edge_uv;  // edge counts: the edges by id ([0] unused), canonical ends + orientations --
+    std::vector<uint8_t> edge_oo;   // the device looks the edge of every consecutive step pair up itself
     std::vector<uint64_t> inc_off, inc_iv, exc_off, exc_iv;  // exc_off empty: no exclude list
     bool track_covered = false;  // bp with a subset list
     uint64_t max_events = 0;     // two per interval
@@ -139,6 +140,8 @@ public:
     // node id (Edge::canonical, graph.rs:142-148) -- the `item_key` of pnx_set_csr_keyed: the edge
     // steps of a path rise and fall with these keys as its node steps do with the node ids
     std::vector<uint64_t> edge_keys() const;
+    // the edges by id ([0] unused): canonical ends (= edge_keys) and orientations (o1 << 1 | o2, 1 = backward)
+    void edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo) const;
 
     // labels of AbacusByGroup::to_tsv (abacus.rs:1072-1140): the segment name of a node id, and
     // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id

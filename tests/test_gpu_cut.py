@@ -254,3 +254,36 @@ def test_cut_larger_graph_against_host_walk(tmp_path):
             assert np.array_equal(uid, h_ids) and np.array_equal(ub, h_bps), ct
             n_unc += len(uid)
     assert n_unc > 0
+
+
+def test_edge_items_looked_up_on_the_device(tmp_path):
+    """edge counts: the node walks go up, the library finds the edge of every step pair in its hash table (pnx_walks.edge_uv /
+    edge_oo instead of a ready-made edge ItemTable): same table as the host's lookups, on a graph with inversions ('-'
+    steps), duplications and shuffled links; an unknown edge fails the call"""
+    path = str(tmp_path / "pggb.gfa")
+    rc, out, err = hl.run_cli(["synth", "--shape", "pggb", "--nodes", "60000", "--samples", "5", "-o", path])
+    assert rc == 0, err
+    lines = open(path).read().split("\n")
+    links = [l for l in lines if l.startswith("L")]
+    rest = [l for l in lines if l and not l.startswith("L")]
+    np.random.default_rng(3).shuffle(links)
+    path2 = str(tmp_path / "shuffled.gfa")
+    open(path2, "w").write("\n".join(rest + links) + "\n")
+    for gfa in (path, path2):
+        hg = hl.GfaGraph(gfa, index_edges=True)
+        items, pre = hg.item_table(hl.EDGE)
+        with capi.Context() as ctx:
+            hg.cut_upload(ctx, hl.EDGE)  # no lists: every path taken with the whole-path interval
+            got, off, _ = ctx.get_csr()
+            assert np.array_equal(off, pre) and np.array_equal(got, items), gfa
+    # a walk that uses an edge the graph does not have
+    node_len = np.array([0, 3, 4, 5, 6], dtype=np.uint32)
+    uv = np.array([0, (1 << 32) | 2, (2 << 32) | 3], dtype=np.uint64)
+    oo = np.zeros(3, dtype=np.uint8)
+    with capi.Context() as ctx:
+        mode = np.array([capi.WALK_CUT], dtype=np.uint8)
+        ev = ctx.set_csr_cut([1, 2, 3], [0, 3], node_len, mode, [[(0, MAXU)]], count_type=2, edge_uv=uv, edge_oo=oo, n_items=2)
+        got, off, _ = ctx.get_csr()
+        assert got.tolist() == [1, 2] and off.tolist() == [0, 2] and not ev
+        with pytest.raises(capi.PnxError, match="unknown edge in path 0"):
+            ctx.set_csr_cut([1, 2, 4], [0, 3], node_len, mode, [[(0, MAXU)]], count_type=2, edge_uv=uv, edge_oo=oo, n_items=2)
