@@ -270,6 +270,10 @@ struct Image {
         unsigned char magic[2] = {0, 0};
         ssize_t got = ::pread(fd, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            if (open_bgzf(fd)) {  // block gzip (bgzip, htslib): the blocks are inflated in parallel
+                ::close(fd);
+                return;
+            }
             ::close(fd);
             gzFile g = gzopen(path.c_str(), "rb");
             if (!g) throw std::runtime_error("cannot open " + path);
@@ -300,6 +304,95 @@ struct Image {
             p = static_cast<const char *>(map);
         }
         ::close(fd);
+    }
+    // BGZF (the block gzip of bgzip / htslib, SAM specification section 4.1): a series of gzip members of at most 64 KiB,
+    // each with an extra field "BC" that holds its compressed size, so the members can be found without inflating and
+    // inflated independently -- one raw-deflate stream per block, all blocks in parallel over the worker pool.  A plain
+    // gzip stream has no such index and is inflated serially (below).  Returns false if the file is not BGZF.
+    bool open_bgzf(int fd) {
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 28) return false;
+        const size_t zn = (size_t)st.st_size;
+        void *zmap = mmap(nullptr, zn, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (zmap == MAP_FAILED) return false;
+        const unsigned char *z = static_cast<const unsigned char *>(zmap);
+        struct Block {
+            size_t data, data_len, out;
+            uint32_t isize, crc;
+        };
+        std::vector<Block> blocks;
+        size_t at = 0, total = 0;
+        bool ok = true;
+        while (at < zn) {
+            // ID1 ID2 CM FLG MTIME(4) XFL OS XLEN(2) | extra subfields | deflate data | CRC32 ISIZE
+            if (at + 18 > zn || z[at] != 0x1f || z[at + 1] != 0x8b || z[at + 2] != 8 || !(z[at + 3] & 4)) {
+                ok = false;
+                break;
+            }
+            const size_t xlen = z[at + 10] | ((size_t)z[at + 11] << 8);
+            size_t x = at + 12, xend = x + xlen, bsize = 0;
+            if (xend > zn) {
+                ok = false;
+                break;
+            }
+            while (x + 4 <= xend) {
+                const size_t slen = z[x + 2] | ((size_t)z[x + 3] << 8);
+                if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2 && x + 6 <= xend) bsize = (z[x + 4] | ((size_t)z[x + 5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (!bsize || at + bsize > zn || bsize < xlen + 20 || (z[at + 3] & ~4)) {  // other header flags: not what bgzip writes
+                ok = false;
+                break;
+            }
+            const unsigned char *tail = z + at + bsize - 8;
+            Block b;
+            b.data = at + 12 + xlen;
+            b.data_len = bsize - xlen - 20;
+            b.crc = tail[0] | (tail[1] << 8) | (tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            b.isize = tail[4] | (tail[5] << 8) | (tail[6] << 16) | ((uint32_t)tail[7] << 24);
+            b.out = total;
+            total += b.isize;
+            blocks.push_back(b);
+            at += bsize;
+        }
+        if (!ok || blocks.empty()) {
+            munmap(zmap, zn);
+            if (!blocks.empty()) throw std::runtime_error("damaged BGZF file (block " + std::to_string(blocks.size()) + ")");
+            return false;
+        }
+        owned.resize(total);
+        std::atomic<int64_t> bad{-1};
+        const size_t GROUP = 16;  // blocks per task
+        ThreadPool::instance().parallel_for((blocks.size() + GROUP - 1) / GROUP, [&](size_t t) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) {
+                bad.store((int64_t)(t * GROUP));
+                return;
+            }
+            const size_t hi = std::min(blocks.size(), (t + 1) * GROUP);
+            for (size_t k = t * GROUP; k < hi; ++k) {
+                const Block &b = blocks[k];
+                if (!b.isize) continue;
+                inflateReset(&zs);
+                zs.next_in = const_cast<unsigned char *>(z + b.data);
+                zs.avail_in = (uInt)b.data_len;
+                zs.next_out = reinterpret_cast<unsigned char *>(&owned[b.out]);
+                zs.avail_out = b.isize;
+                const int r = inflate(&zs, Z_FINISH);
+                if (r != Z_STREAM_END || zs.avail_out != 0 ||
+                    crc32(0L, reinterpret_cast<const unsigned char *>(&owned[b.out]), b.isize) != b.crc) {
+                    bad.store((int64_t)k);
+                    break;
+                }
+            }
+            inflateEnd(&zs);
+        });
+        munmap(zmap, zn);
+        if (bad.load() >= 0) throw std::runtime_error("damaged BGZF block " + std::to_string(bad.load()));
+        p = owned.data();
+        n = owned.size();
+        return true;
     }
     ~Image() {
         if (map) munmap(map, map_len);

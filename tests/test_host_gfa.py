@@ -320,3 +320,50 @@ def test_edge_relabel_is_a_rank_by_canonical_ends(golden_dir, tmp_path):
     ea, pa = a.item_table(hl.EDGE)
     eb, pb = b.item_table(hl.EDGE)
     assert np.array_equal(pa, pb) and np.array_equal(a.edge_relabel()[ea], b.edge_relabel()[eb])
+
+
+def _write_bgzf(data: bytes, path: str, block=60_000):
+    """the block gzip of bgzip / htslib (SAM spec 4.1): gzip members with a BC extra field, then the empty EOF block"""
+    import struct
+    import zlib
+
+    def member(chunk: bytes) -> bytes:
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = comp.compress(chunk) + comp.flush()
+        bsize = len(payload) + 25  # header 18 + payload + trailer 8, minus 1
+        head = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        return head + payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    with open(path, "wb") as f:
+        for at in range(0, len(data), block):
+            f.write(member(data[at:at + block]))
+        f.write(member(b""))
+
+
+def test_bgzf_input_is_inflated_block_by_block(tmp_path, golden_dir):
+    """a bgzip'ed GFA gives the same graph as the plain file (blocks inflated in parallel), a plain .gz still works,
+    a damaged block is reported"""
+    import gzip
+    plain = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--shape", "pggb", "--nodes", "20000", "--samples", "4", "-o", plain])
+    assert rc == 0, err
+    data = open(plain, "rb").read()
+    bg = str(tmp_path / "syn.bgzf.gfa.gz")
+    _write_bgzf(data, bg)
+    assert gzip.open(bg, "rb").read() == data  # a valid multi-member gzip file
+    gz = str(tmp_path / "syn.gfa.gz")
+    with gzip.open(gz, "wb", compresslevel=1) as f:
+        f.write(data)
+    a = hl.GfaGraph(plain, index_edges=True)
+    for other in (bg, gz):
+        b = hl.GfaGraph(other, index_edges=True)
+        assert (a.n_nodes, a.n_edges, a.n_paths) == (b.n_nodes, b.n_edges, b.n_paths)
+        assert a.path_names() == b.path_names() and np.array_equal(a.node_lens, b.node_lens)
+        for ct in (hl.NODE, hl.EDGE):
+            x, y = a.item_table(ct), b.item_table(ct)
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    raw = bytearray(open(bg, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.gfa.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        hl.GfaGraph(bad)
