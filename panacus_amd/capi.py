@@ -297,6 +297,13 @@ class Context:
                                      _ptr(w, C.c_uint32)))
         return items[: n.value], off, w
 
+    def get_weights(self) -> np.ndarray:
+        """the resident weights (n_items+1 u32, caller ids) without the steps"""
+        n = C.c_uint64(0)
+        w = np.zeros(self.info().n_items + 1, dtype=np.uint32)
+        self._ck(self._L.pnx_get_csr(self._h, C.byref(n), None, None, _ptr(w, C.c_uint32)))
+        return w
+
     def set_order(self, path_idx, group_id, n_groups=None):
         pi = np.ascontiguousarray(path_idx, dtype=np.uint32)
         gi = np.ascontiguousarray(group_id, dtype=np.uint32)
