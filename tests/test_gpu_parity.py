@@ -1054,6 +1054,8 @@ def test_bench_contract_line_small(tmp_path):
             assert k in pg, k
         assert pg["scaling"] == "strong" and pg["orders"] == 10 and pg["checks"]["sharded_equals_single_gpu"]
         assert pg["seconds_per_call"] > 0 and pg["growth_kernel_ms_rank_max"] > 0
+        sim = pg["similarity_intersections"]
+        assert sim["kernel_ms"] > 0 and sim["checks"]["symmetric"] and sim["checks"]["diagonal_sum"] > 0
         if env:
             assert pg["allreduce_ms"] > 0 and "rccl" in pg["collective_path"]
         if "--no-cpu-baseline" not in extra:
