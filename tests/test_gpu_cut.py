@@ -287,3 +287,50 @@ def test_edge_items_looked_up_on_the_device(tmp_path):
         assert got.tolist() == [1, 2] and off.tolist() == [0, 2] and not ev
         with pytest.raises(capi.PnxError, match="unknown edge in path 0"):
             ctx.set_csr_cut([1, 2, 4], [0, 3], node_len, mode, [[(0, MAXU)]], count_type=2, edge_uv=uv, edge_oo=oo, n_items=2)
+
+
+def test_cut_at_cfg3_size():
+    """BASELINE configs[2]'s graph (10 M nodes x 256 paths, 0.98 G steps, 478 k chunks) through the device cut: the
+    whole-path interval reproduces the table; one interval per path keeps exactly the steps whose node starts before the
+    interval's end and ends after its start -- checked for sampled paths against numpy prefix sums; exclusion flags =
+    the nodes those steps visit (node counts: any touch)."""
+    n, p = 10_000_000, 256
+    with capi.Context() as src:
+        src.set_csr_pansyn(42, n, p, with_weights=True)
+        items, off, lens = src.get_csr(want_weights=True)
+    mode = np.full(p, capi.WALK_CUT, dtype=np.uint8)
+    with capi.Context() as ctx:
+        ev = ctx.set_csr_cut(items, off, lens, mode, [[(0, MAXU)]] * p, count_type=0)
+        assert not ev and ctx.info().n_steps == len(items)
+        got, goff, _ = ctx.get_csr()
+        assert np.array_equal(goff, off) and np.array_equal(got, items)
+        del got
+        # one interval per path, somewhere in its middle; every 3rd path also has an exclude interval
+        rng = np.random.default_rng(17)
+        sample = [0, 15, 100, 255]  # 15: a descending path
+        inc, exc = [], []
+        pos = {}
+        for k in range(p):
+            seg = items[int(off[k]):int(off[k + 1])]
+            if k in sample:
+                pos[k] = np.concatenate([[0], np.cumsum(lens[seg].astype(np.uint64))])
+                total = int(pos[k][-1])
+            else:
+                total = int(lens[seg].sum(dtype=np.uint64))
+            a = int(rng.integers(0, total // 2))
+            b = a + int(rng.integers(1, total // 3))
+            inc.append([(a, b)])
+            exc.append([(b - 1000, b + 1000)] if k % 3 == 0 else [])
+        ctx.set_csr_cut(items, off, lens, mode, inc, exc, count_type=0)
+        got, goff, _ = ctx.get_csr()
+        flags = ctx.get_exclude()
+        for k in sample:
+            seg = items[int(off[k]):int(off[k + 1])]
+            st, en = pos[k][:-1], pos[k][1:]
+            (a, b), = inc[k]
+            keep = (st < b) & (en > a)
+            assert np.array_equal(got[int(goff[k]):int(goff[k + 1])], seg[keep]), k
+            if exc[k]:
+                (c, d), = exc[k]
+                assert flags[seg[(st < d) & (en > c)]].all(), k
+        assert int(goff[-1]) == len(got) and 0 < len(got) < len(items)
