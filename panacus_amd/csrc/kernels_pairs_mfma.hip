@@ -22,9 +22,9 @@
 // Tiling: a workgroup of 4 waves owns a 128 x 128 tile of group pairs (only tiles on or above the diagonal)
 // over a chunk of words, each wave a 64 x 64 quarter = 2 x 2 MFMA tiles x PL digits (<= 3: 192 accumulator
 // registers); 32 words of the 128 + 128 rows and their digits are staged in LDS per step, double buffered.
-// Per word a wave spends 24 VALU ops on A (bit field, multiply by 0x204081, mask: 4 bits -> 4 bytes), 40 on
-// the 0xFF masks of B, 8 per digit -- against 4 PL MFMAs of 32 cycles (8 passes), so with two workgroups
-// per CU the matrix pipe of one wave runs beside the expansion of the other.
+// Per word a wave does 8 table lookups in LDS (8 bits -> 8 bytes each: 0 / 1 bytes for A, 0x00 / 0xFF masks for B) and
+// 8 ANDs per digit -- against 4 PL MFMAs of 32 cycles, so with two workgroups per CU the matrix pipe of one wave runs
+// beside the lookups of the other.
 #include <hip/hip_runtime.h>
 
 #include "pnx_context.hpp"
@@ -60,18 +60,21 @@ __global__ void k_weight_digits(const uint32_t *__restrict__ weights, uint32_t n
     }
 }
 
-// 16 bits -> 16 bytes of 0 / 1 (four bits at a time: n * 0x204081 puts bit i of n at bit 8 i)
-__device__ static inline v4i expand01(uint32_t word, uint32_t shift) {
+// 16 bits -> 16 bytes through a 256-entry table in LDS (8 bits -> 8 bytes per ds_read_b64): two lookups per operand
+// instead of 12 (20) vector instructions -- the expansion, not the matrix pipe, bounded the first version of this kernel
+__device__ static inline v4i expand16(const uint2 *__restrict__ tab, uint32_t word, uint32_t shift) {
+    const uint2 lo = tab[(word >> shift) & 0xFFu], hi = tab[(word >> (shift + 8u)) & 0xFFu];
     v4i r;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) r[d] = (int)(__umul24(__builtin_amdgcn_ubfe(word, shift + 4u * d, 4u), 0x204081u) & 0x01010101u);
+    r[0] = (int)lo.x;
+    r[1] = (int)lo.y;
+    r[2] = (int)hi.x;
+    r[3] = (int)hi.y;
     return r;
 }
-__device__ static inline v4i bytes_ff(v4i m) {  // 0 / 1 bytes -> 0x00 / 0xFF bytes
-    v4i r;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) r[d] = (int)(((uint32_t)m[d] << 8) - (uint32_t)m[d]);
-    return r;
+// entry b of the table: byte i = bit i of b times `one` (1 for the A operand, 0xFF for the masks of B)
+__device__ static inline uint2 spread8(uint32_t b, uint32_t one) {
+    const uint32_t lo = ((b & 0xFu) * 0x204081u) & 0x01010101u, hi = (((b >> 4) & 0xFu) * 0x204081u) & 0x01010101u;
+    return make_uint2(lo * one, hi * one);
 }
 
 // PL digits [plane_base, plane_base + PL) of the weights (WEIGHTED), or the plain product (PL = 1)
@@ -91,6 +94,10 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
     auto sA = [&](int b) { return lds_pairs + b * (MF_KS * MF_LD); };
     auto sB = [&](int b) { return lds_pairs + (2 + b) * (MF_KS * MF_LD); };
     auto sW = [&](int b) { return lds_pairs + 4 * MF_KS * MF_LD + b * (PL * MF_KS * 8); };
+    uint2 *tab01 = reinterpret_cast<uint2 *>(lds_pairs + 4 * MF_KS * MF_LD + 2 * PL * MF_KS * 8);
+    uint2 *tabff = tab01 + 256;
+    tab01[threadIdx.x] = spread8(threadIdx.x, 1u);      // 256 threads, 256 entries each
+    tabff[threadIdx.x] = spread8(threadIdx.x, 0xFFu);
 
     const uint32_t t = threadIdx.x;
     const uint32_t ld_row = t >> 3, ld_k = (t & 7u) * 4u;  // staging: rows ld_row + 32 q, words ld_k .. ld_k + 3
@@ -161,19 +168,19 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
         if (more) fetch(w + MF_KS);
         const uint32_t *a_s = sA(buf) + ra;
         const uint32_t *b_s = (diag ? sA(buf) : sB(buf)) + rb;
-#pragma unroll 2
+#pragma unroll 4
         for (int k = 0; k < MF_KS; ++k) {
             const uint32_t a0 = a_s[k * MF_LD], a1 = a_s[k * MF_LD + 32];
             const uint32_t b0 = b_s[k * MF_LD], b1 = b_s[k * MF_LD + 32];
-            const v4i fa[2] = {expand01(a0, 16u * h), expand01(a1, 16u * h)};
-            const v4i mb[2] = {expand01(b0, 16u * h), expand01(b1, 16u * h)};
+            const v4i fa[2] = {expand16(tab01, a0, 16u * h), expand16(tab01, a1, 16u * h)};
             if (!WEIGHTED) {
+                const v4i mb[2] = {expand16(tab01, b0, 16u * h), expand16(tab01, b1, 16u * h)};
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], mb[j], acc[0][i][j], 0, 0, 0);
             } else {
-                const v4i ff[2] = {bytes_ff(mb[0]), bytes_ff(mb[1])};
+                const v4i ff[2] = {expand16(tabff, b0, 16u * h), expand16(tabff, b1, 16u * h)};
 #pragma unroll
                 for (int p = 0; p < PL; ++p) {
                     const v4i dg = *reinterpret_cast<const v4i *>(sW(buf) + p * MF_KS * 8 + k * 8 + 4 * h);
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void k_pair_mfma_reduce(const unsigned long lo
     }
 }
 
-static size_t mfma_lds_bytes(uint32_t pl) { return (size_t)(4 * MF_KS * MF_LD + 2 * pl * MF_KS * 8) * sizeof(uint32_t); }
+static size_t mfma_lds_bytes(uint32_t pl) { return (size_t)(4 * MF_KS * MF_LD + 2 * pl * MF_KS * 8 + 2 * 256 * 2) * sizeof(uint32_t); }
 
 int launch_pair_intersections_mfma(pnx_ctx *ctx) {
     const uint32_t G = ctx->n_groups, NB = ctx->n_blocks;
