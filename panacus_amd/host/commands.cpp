@@ -51,19 +51,31 @@ const char *USAGE =
     "       panacus-amd synth --shape pggb --nodes N --samples M [--seed S] [--sequences] -o FILE.gfa\n"
     "                                        write a pggb-shaped pangenome (contig paths, inversions, duplications)\n";
 
-Device::Device(int ordinal) {
-    int rc = pnx_init(&ctx, ordinal);
-    if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
-    // quorum closed form with >= 512 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
-    // the whole closed form on the host threads; the results are the same bits either way)
-    if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(ctx);
+Device::Device(int ordinal)
+    : init_(std::async(std::launch::async, [ordinal]() -> pnx_ctx * {
+          pnx_ctx *c = nullptr;
+          const int rc = pnx_init(&c, ordinal);
+          if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
+          // quorum closed form with >= 256 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
+          // the whole closed form on the host threads; the results are the same bits either way)
+          if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(c);
+          return c;
+      })) {}
+pnx_ctx *Device::ctx() const {
+    if (init_.valid()) ctx_ = init_.get();  // throws what the initialisation threw
+    return ctx_;
 }
 Device::~Device() {
+    try {
+        (void)ctx();
+    } catch (...) {
+    }
+    if (!ctx_) return;
     set_quorum_offload(nullptr);
-    pnx_free(ctx);
+    pnx_free(ctx_);
 }
 void Device::check(int rc) const {
-    if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
+    if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx()));
 }
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
@@ -102,7 +114,9 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 // -s / -e lists: the walks are cut ON THE DEVICE (pnx_set_csr_cut; graph_broker/util.rs:412-795) and stay
 // there as the resident graph; the host replays the few partial pieces (bp counts) and hands the late
 // exclusion flags and -- for growth -- the weights of partly covered nodes back to the library.
-Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Masking &mk, bool growth_weights) {
+Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStorage &g, CountType ct, const Masking &mk,
+                     bool growth_weights) {
+    pnx_ctx *ctx = nullptr;  // asked for after the host's share of the work (the GPU may still be coming up beside it)
     auto check = [&](int rc) {
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     };
@@ -136,6 +150,7 @@ Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Ma
     static_assert(sizeof(PieceEvent) == sizeof(pnx_piece_event), "PieceEvent mirrors pnx_piece_event");
     std::vector<PieceEvent> events(cut.max_events);
     uint64_t n_events = 0;
+    ctx = get_ctx();
     check(pnx_set_csr_cut(ctx, &w, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr,
                           reinterpret_cast<pnx_piece_event *>(events.data()), events.size(), &n_events));
     events.resize(n_events);
@@ -160,17 +175,17 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     // "cut" by the whole-path interval): the node walks go up and the library finds the edge of every step pair in a hash
     // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
     if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file())) {
-        uncovered = upload_cut(dev.ctx, g, ct, mk, growth_weights);
+        uncovered = upload_cut([&dev]() { return dev.ctx(); }, g, ct, mk, growth_weights);
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
         std::vector<uint64_t> keys;  // a cached edge table: ranked by the canonical ends of its edges (pnx_set_csr_keyed)
         if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
         const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
-        dev.check(pnx_set_csr_keyed(dev.ctx, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
+        dev.check(pnx_set_csr_keyed(dev.ctx(), view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
                                     ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr, key_ptr));
     }
-    dev.check(pnx_set_order(dev.ctx, order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
+    dev.check(pnx_set_order(dev.ctx(), order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
                             (uint32_t)order.groups.size()));
     return uncovered;
 }
@@ -180,13 +195,13 @@ std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, Coun
     const Uncovered uncovered = upload(dev, g, ct, order, mk);
     std::vector<uint64_t> hist(order.groups.size() + 1, 0);
     if (uncovered.empty()) {
-        dev.check(pnx_hist(dev.ctx, nullptr, hist.data()));
+        dev.check(pnx_hist(dev.ctx(), nullptr, hist.data()));
         return hist;
     }
     // "subtract uncovered bps", abacus.rs:779-785: the bp a subset interval leaves out of a node
     // move from the node's coverage bin to bin 0 (usize arithmetic of a release build)
     std::vector<uint32_t> countable(g.number_of_items(ct) + 1, 0);
-    dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+    dev.check(pnx_hist(dev.ctx(), countable.data(), hist.data()));
     for (const auto &u : uncovered) {
         hist[countable[u.first]] -= u.second;
         hist[0] += u.second;
@@ -208,9 +223,9 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
         upload(dev, g, COUNT_BP, order, mk);
         for (size_t k = 0; k < cts.size(); ++k) {
             if (cts[k] == COUNT_EDGE) continue;
-            dev.check(pnx_config(dev.ctx, PNX_CFG_USE_WEIGHTS, cts[k] == COUNT_BP ? 1 : 0));
+            dev.check(pnx_config(dev.ctx(), PNX_CFG_USE_WEIGHTS, cts[k] == COUNT_BP ? 1 : 0));
             out[k].assign(order.groups.size() + 1, 0);
-            dev.check(pnx_hist(dev.ctx, nullptr, out[k].data()));
+            dev.check(pnx_hist(dev.ctx(), nullptr, out[k].data()));
         }
     }
     for (size_t k = 0; k < cts.size(); ++k)
@@ -256,9 +271,9 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     std::vector<CountType> cts = count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
+    const Device dev(o.device);  // the GPU comes up while the graph is read
     auto g = load_graph(o, edges);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
-    Device dev(o.device);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
@@ -275,9 +290,9 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     std::vector<CountType> cts = growth_cmd ? std::vector<CountType>{COUNT_NODE} : count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
+    const Device dev(o.device);  // the GPU comes up while the graph is read
     auto g = load_graph(o, edges);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
-    Device dev(o.device);
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
@@ -326,7 +341,7 @@ std::vector<std::vector<double>> device_ordered_growth(const Device &dev, const 
         for (uint32_t r = 0; r < G; ++r) qtab[(size_t)t * G + r] = (uint32_t)std::ceil(((double)r + 1.0) * q);
     }
     std::vector<uint64_t> res((size_t)T * G, 0);
-    if (G) dev.check(pnx_ordered_growth(dev.ctx, nullptr, 1, cov.data(), qtab.data(), T, res.data()));
+    if (G) dev.check(pnx_ordered_growth(dev.ctx(), nullptr, 1, cov.data(), qtab.data(), T, res.data()));
     std::vector<std::vector<double>> out(T, std::vector<double>(G));
     for (uint32_t t = 0; t < T; ++t)
         for (uint32_t j = 0; j < G; ++j) out[t][j] = (double)res[(size_t)t * G + j];
@@ -336,10 +351,10 @@ std::vector<std::vector<double>> device_ordered_growth(const Device &dev, const 
 std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
     CountType ct = count_types(o.count, false)[0];
+    const Device dev(o.device);  // the GPU comes up while the graph is read
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint32_t G = (uint32_t)order.groups.size();
-    Device dev(o.device);
     upload(dev, *g, ct, order, masking(o), true);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
@@ -363,7 +378,7 @@ SimilarityResult device_similarity(const Device &dev, const std::vector<std::str
         throw std::runtime_error("invalid value '" + method_name + "' for --method (single, complete, average, weighted, ward, centroid, median)");
     const size_t G = groups.size();
     std::vector<uint64_t> inter(G * G, 0);
-    if (G) dev.check(pnx_group_intersections(dev.ctx, inter.data()));
+    if (G) dev.check(pnx_group_intersections(dev.ctx(), inter.data()));
     for (size_t a = 0; a < G; ++a)
         if (inter[a * G + a] == 0)  // path_lens[&a] on a missing key panics in the reference (:163)
             throw std::runtime_error("group " + groups[a] + " covers no item: the reference panics here");
@@ -396,9 +411,9 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     ClusterMethod method;
     if (!parse_cluster_method(o.method, method))
         throw std::runtime_error("invalid value '" + o.method + "' for --method (single, complete, average, weighted, ward, centroid, median)");
+    const Device dev(o.device);  // the GPU comes up while the graph is read
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
-    Device dev(o.device);
     upload(dev, *g, ct, order, masking(o));
     return metadata_comments(cmdline) + similarity_table_string(device_similarity(dev, order.groups, o.method), order.groups);
 }
@@ -409,11 +424,11 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
 // item's bp (node_len - uncovered for bp counts, else 1).
 std::string cmd_table(const Options &o, const std::string &cmdline) {
     CountType ct = count_types(o.count, false)[0];
+    const Device dev(o.device);  // the GPU comes up while the graph is read
     auto g = load_graph(o, ct == COUNT_EDGE);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
     const uint64_t n = g->number_of_items(ct);
     const size_t G = order.groups.size();
-    Device dev(o.device);
     const Uncovered uncovered = upload(dev, *g, ct, order, masking(o), false, true);
     std::string res = metadata_comments(cmdline);
     res += ct == COUNT_EDGE ? "edge" : "node";
@@ -424,7 +439,7 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
         res += "\ttotal\n";
         std::vector<uint32_t> countable(n + 1, 0);
         std::vector<uint64_t> hist(G + 1, 0);
-        dev.check(pnx_hist(dev.ctx, countable.data(), hist.data()));
+        dev.check(pnx_hist(dev.ctx(), countable.data(), hist.data()));
         for (uint64_t i = 1; i <= n; ++i) res += label(i) + "\t" + std::to_string(countable[i]) + "\n";
         return res;
     }
@@ -447,7 +462,7 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
         for (uint64_t lo = 1; lo <= n && first_slots.size() < G; lo += slice) {
             const uint64_t hi = std::min(n + 1, lo + slice);
             counts.assign(G * (hi - lo), 0);
-            dev.check(pnx_group_visit_counts(dev.ctx, (uint32_t)lo, (uint32_t)hi, counts.data()));
+            dev.check(pnx_group_visit_counts(dev.ctx(), (uint32_t)lo, (uint32_t)hi, counts.data()));
             for (uint64_t i = lo; i < hi && first_slots.size() < G; ++i)
                 for (size_t j = 0; j < G && first_slots.size() < G; ++j)
                     if (counts[j * (hi - lo) + (i - lo)]) first_slots.push_back(counts[j * (hi - lo) + (i - lo)]);
@@ -456,7 +471,7 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
     for (uint64_t lo = 1; lo <= n; lo += slice) {
         const uint64_t hi = std::min(n + 1, lo + slice);
         counts.assign(G * (hi - lo), 0);
-        if (G) dev.check(pnx_group_visit_counts(dev.ctx, (uint32_t)lo, (uint32_t)hi, counts.data()));
+        if (G) dev.check(pnx_group_visit_counts(dev.ctx(), (uint32_t)lo, (uint32_t)hi, counts.data()));
         for (uint64_t i = lo; i < hi; ++i) {
             res += label(i);
             for (size_t j = 0; j < G; ++j) {

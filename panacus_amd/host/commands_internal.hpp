@@ -2,6 +2,8 @@
 // share: parsed options, the RAII device handle, upload and histogram helpers.
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <future>
 #include <memory>
 #include <string>
 #include <utility>
@@ -27,13 +29,20 @@ struct Options {
     bool links = false, sequences = false;
 };
 
-struct Device {  // RAII over pnx_ctx
-    pnx_ctx *ctx = nullptr;
+// RAII over pnx_ctx.  pnx_init -- HIP runtime start-up, streams, code objects: 0.15-0.2 s -- runs on a thread of its own
+// from the constructor on, i.e. beside the GFA parse every command starts with; the first use of ctx() joins it and
+// rethrows an initialisation error (no GPU: no CPU fallback).
+struct Device {
     explicit Device(int ordinal);
     ~Device();
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;
+    pnx_ctx *ctx() const;
     void check(int rc) const;
+
+private:
+    mutable std::future<pnx_ctx *> init_;
+    mutable pnx_ctx *ctx_ = nullptr;
 };
 
 struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a count type is cut down by
@@ -49,7 +58,8 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all);
 GroupMode group_mode(const Options &o);
 Masking masking(const Options &o);
 // the device-side cut of the walks under -s / -e lists (pnx_set_csr_cut) + the host's replay of the partial pieces
-Uncovered upload_cut(pnx_ctx *ctx, const GraphStorage &g, CountType ct, const Masking &mk, bool growth_weights);
+Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStorage &g, CountType ct, const Masking &mk,
+                     bool growth_weights);
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
                  bool growth_weights = false, bool per_item_output = false);
 std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphStorage &g, const std::vector<CountType> &cts,

@@ -151,7 +151,7 @@ int pnh_graph_cut_upload(const void *g, void *ctx, int count_type, int group_mod
         mk.group_file = group_file ? group_file : "";
         mk.subset_file = subset_file ? subset_file : "";
         mk.exclude_file = exclude_file ? exclude_file : "";
-        const pnh::cli::Uncovered u = pnh::cli::upload_cut(static_cast<pnx_ctx *>(ctx), *gs, (pnh::CountType)count_type, mk, growth_weights != 0);
+        const pnh::cli::Uncovered u = pnh::cli::upload_cut([ctx]() { return static_cast<pnx_ctx *>(ctx); }, *gs, (pnh::CountType)count_type, mk, growth_weights != 0);
         if (u.size() > *n_uncovered) throw std::runtime_error("room for fewer uncovered entries than found");
         *n_uncovered = u.size();
         for (size_t k = 0; k < u.size(); ++k) {

@@ -466,6 +466,7 @@ struct RunState {
         lo.file = run.graph;
         lo.subset_file = run.subset;
         lo.exclude_file = run.exclude;
+        dev.reset(new Device(opts.device));  // the GPU comes up while the graph is read
         graph = load_graph(lo, need_edges);
         mk.mode = run.grouping == 1 ? GROUP_SAMPLE : run.grouping == 2 ? GROUP_HAPLOTYPE : run.grouping == 3 ? GROUP_FILE : GROUP_PATHID;
         mk.group_file = run.group_file;
@@ -477,7 +478,6 @@ struct RunState {
         else if (run.grouping) run_name = run.graph + "-" + run.subset + "-" + gname[run.grouping] + (run.grouping == 3 ? run.group_file : "");
         else run_name = run.graph + "-" + run.subset;
         run_id = replace_chars(lower(run_name), " _#/\"");
-        dev.reset(new Device(opts.device));
     }
 
     void ensure_hists() {
