@@ -439,6 +439,8 @@ int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->weighted = ctx->have_weights = true;
+    ctx->wplanes_valid = false;  // bit planes (K4) and 7-bit digits (K5) are derived from the weights
+    ctx->wdigits_valid = false;
     return PNX_OK;
 }
 

@@ -912,6 +912,30 @@ def test_group_intersections_wide_weights(ctx, pairs_variant):
     assert (ctx.group_intersections() == exp).all()
 
 
+@pytest.mark.parametrize("pairs_variant", [1, 0], indirect=True)
+def test_set_weights_replaces_everything_derived_from_the_weights(ctx, pairs_variant):
+    """pnx_set_weights after the weight planes (ordered growth) and digits (similarity) of the old weights were built:
+    both must follow the new weights, also when those need more digits"""
+    from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
+    n, p = 12_000, 10
+    items, pre, lens = orc.pansyn(31, n, p)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens)
+    pg = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pg, pg, p)
+    qt = np.stack([quorum_table(Threshold(RELATIVE, 0.0), p)])
+    r, c = _oracle_pairs(items, pre, n, pg, p)
+    for w in (lens, (lens.astype(np.uint64) * 977 + 5).astype(np.uint32), np.minimum(lens, 3).astype(np.uint32)):
+        if w is not lens:
+            ctx.set_weights(w)
+        exp, _, _ = orc.similarity(r, c, p, node_lens=w)
+        assert (ctx.group_intersections() == exp).all()
+        out = ctx.ordered_growth([1], qt)
+        g = orc.ordered_growth(r, c, p, (orc.ABSOLUTE, 1), (orc.RELATIVE, 0.0), w)
+        assert out[0, 0].tolist() == [int(x) for x in g]
+        _, h = ctx.hist()
+        assert int(h[1:].sum()) == int(w[1:][np.bincount(items.astype(np.int64), minlength=n + 1)[1:] > 0].astype(np.uint64).sum())
+
+
 def test_presence_export_matches_by_group(ctx):
     n, p = 10_000, 19
     items, pre, _ = orc.pansyn(8, n, p)
