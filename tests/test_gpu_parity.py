@@ -936,6 +936,25 @@ def test_set_weights_replaces_everything_derived_from_the_weights(ctx, pairs_var
         assert int(h[1:].sum()) == int(w[1:][np.bincount(items.astype(np.int64), minlength=n + 1)[1:] > 0].astype(np.uint64).sum())
 
 
+@pytest.mark.parametrize("pairs_variant", [1, 0], indirect=True)
+def test_group_intersections_equal_the_matrix_product_of_the_presence_export(ctx, pairs_variant):
+    """inter = B diag(w) B^T computed by numpy from the device's own presence export (K6): a check of K5 that shares
+    nothing with the oracle's walk over (r, c) slices (`similarity` has no golden output upstream)"""
+    n, p = 25_000, 37
+    items, pre, lens = orc.pansyn(13, n, p)
+    excl = np.zeros(n + 1, dtype=np.uint8)
+    excl[3::41] = 1
+    pg = (np.arange(p) // 2).astype(np.uint64)
+    G = int(pg.max()) + 1
+    for w in (None, lens):
+        ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=excl)
+        ctx.set_order(np.arange(p, dtype=np.uint64), pg, G)
+        got = ctx.group_intersections()
+        B = np.unpackbits(ctx.presence().view(np.uint8), axis=1, bitorder="little")[:, : n + 1].astype(np.uint64)
+        ww = np.ones(n + 1, dtype=np.uint64) if w is None else w.astype(np.uint64)
+        assert np.array_equal(got, (B * ww) @ B.T)
+
+
 def test_presence_export_matches_by_group(ctx):
     n, p = 10_000, 19
     items, pre, _ = orc.pansyn(8, n, p)
