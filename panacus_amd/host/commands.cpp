@@ -71,7 +71,7 @@ Device::~Device() {
     } catch (...) {
     }
     if (!ctx_) return;
-    set_quorum_offload(nullptr);
+    release_quorum_offload(ctx_);  // the next run's context may be registered already (report runner)
     pnx_free(ctx_);
 }
 void Device::check(int rc) const {

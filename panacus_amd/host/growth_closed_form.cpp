@@ -472,6 +472,11 @@ void set_quorum_offload(void *pnx_context, uint64_t min_n) {
     g_offload_min_n = min_n;
 }
 
+void release_quorum_offload(void *pnx_context) {
+    std::lock_guard<std::mutex> g(g_offload_mu);
+    if (g_offload_ctx == static_cast<pnx_ctx *>(pnx_context)) g_offload_ctx = nullptr;
+}
+
 bool quorum_offload_usable() { return exp2_restatement_matches_libm(); }
 
 struct GrowthRun {

@@ -27,6 +27,8 @@ double choose_log2(uint64_t n, uint64_t k);  // hist.rs:21-36
 // (pnx_quorum_sums, bit-identical by construction and guarded by a run-time check of the exp2
 // restatement against libm).  nullptr switches it off.  The context must outlive the calls.
 void set_quorum_offload(void *pnx_context, uint64_t min_n = 256);
+// forget the context if it is the registered one (a context that goes away while a newer one is already registered)
+void release_quorum_offload(void *pnx_context);
 bool quorum_offload_usable();
 
 // Hist::calc_all_growths (hist.rs:68-87) without the NaN row: one curve per (coverage, quorum)
