@@ -57,13 +57,13 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
 
 
 def layout_bytes_hist(S, P, N, G, weighted=False):
-    """What the coverage kernel HAS to move with this library's layout: it streams the 2-byte steps
-    (ids modulo 4096, built once per upload -- DESIGN.md section 3), not the u32 ItemTable."""
-    return 2 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
+    """What the coverage kernel HAS to move with this library's layout: it streams the packed 12-bit steps
+    (ids modulo 4096, 8 steps per 12 bytes, built once per upload -- DESIGN.md section 3), not the u32 ItemTable."""
+    return 3 * S // 2 + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
 ROOFLINE_NOTE = ("achieved / frac follow the contract: SURVEY 8(d)'s ALGORITHMIC bytes (4 B per path step) over the kernel's launch "
-                 "time -- they exceed the HBM peak because the kernel does not read those bytes: it streams a 2-byte-per-step copy "
+                 "time -- they exceed the HBM peak because the kernel does not read those bytes: it streams a 12-bit-per-step copy "
                  "of the ItemTable that the library derives once per upload (traffic = the PMC bytes of the committed profile); "
                  "achieved_on_layout_bytes / frac_on_layout_bytes price the same launch on the bytes this layout has to move")
 
@@ -293,7 +293,7 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         n_words = (N + 1 + 63) // 64
         b_growth = R * (8 * P * n_words + 8 * T * P)       # SURVEY 8(d), all R orders
         b_pack = 4 * int(info.n_steps) + 8 * P * n_words
-        b_pack_layout = 2 * int(info.n_steps) + 8 * P * n_words  # 2-byte steps in, presence rows out
+        b_pack_layout = 3 * int(info.n_steps) // 2 + 8 * P * n_words  # packed 12-bit steps in, presence rows out
         cover_ms = pk["cover"][0] / max(pk["cover"][1], 1)
         out = {
             "workload": f"ordered-histgrowth -c node -l 1,2,1 -q 0,0,0.5 over {R} random group orders (pansyn stream 7, seed "

@@ -69,12 +69,12 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
 
 // ------------------------------------------------------------------------------------------
 // step preparation: once per upload, one streaming pass over the steps
-//   * items16[j] = items[j] mod 4096.  A coverage wave owns one tile of 2048 (or 4096) ids, so inside
-//     its tile a step needs 11 (12) bits; the coverage kernel streams these 2-byte steps -- HALF the
-//     bytes of the u32 ItemTable, which stays resident for everything that needs whole ids (the index
-//     search, the run index, the scatter route, the read-back);
+//   * steps12: the step ids modulo 4096, 12 bits each, 8 steps per 12 bytes (k_pack12).  A coverage wave owns one
+//     tile of 2048 (or 4096) ids, so inside its tile a step needs 11 (12) bits; the coverage kernel streams these
+//     packed steps -- 1.5 bytes per step against the 4 of the u32 ItemTable, which stays resident for everything
+//     that needs whole ids (the index search, the run index, the scatter route, the read-back);
 //   * an EXACT classification of every path: tile-monotone (the sequence of 2048-id tiles of its
-//     steps never turns around; any disorder inside a tile is fine) or not.  A 2-byte step cannot
+//     steps never turns around; any disorder inside a tile is fine) or not.  A packed step cannot
 //     tell which tile it came from, so the coverage kernel can no longer verify the boundary index
 //     step by step as it did in round 1 -- instead nothing is left to verify: for a tile-monotone
 //     path the boundary search is exact by construction, and every other path goes to the run /
@@ -82,8 +82,7 @@ int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_steps(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                                        const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
-                                                       uint16_t *__restrict__ items16, uint8_t *__restrict__ path_dir,
-                                                       uint32_t *__restrict__ path_changes) {
+                                                       uint8_t *__restrict__ path_dir, uint32_t *__restrict__ path_changes) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
@@ -97,7 +96,6 @@ __global__ __launch_bounds__(256) void k_prepare_steps(const uint32_t *__restric
         uint32_t prev = __shfl_up(cur, 1);
         if (lane == 0 && in && j > ch.pstart) prev = items[j - 1];
         if (in) {
-            items16[j] = (uint16_t)(cur & 4095u);
             if (j > ch.pstart) {
                 const uint32_t tc = cur / BLOCK_ITEMS, tp = prev / BLOCK_ITEMS;
                 dir |= (tc > tp ? 1u : 0u) | (tc < tp ? 2u : 0u);
@@ -212,6 +210,28 @@ static int sort_paths_in_place(pnx_ctx *ctx, const std::vector<uint32_t> &paths)
     return done(PNX_OK);
 }
 
+// steps12: 8 consecutive steps (by global step index) = 8 x 12 bits = three dwords; step e of a group sits at bit 12 e.
+// One thread per group.  The last group of the table is padded with zeros.
+__global__ void k_pack12(const uint32_t *__restrict__ items, uint64_t n_steps, uint32_t *__restrict__ steps12) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t j0 = g * 8;
+    if (j0 >= n_steps) return;
+    uint32_t v[8];
+    if (j0 + 8 <= n_steps) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(items + j0), b = *reinterpret_cast<const uint4 *>(items + j0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = j0 + e < n_steps ? items[j0 + e] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] &= 4095u;
+    uint32_t *out = steps12 + g * 3;
+    out[0] = v[0] | (v[1] << 12) | (v[2] << 24);
+    out[1] = (v[2] >> 8) | (v[3] << 4) | (v[4] << 16) | (v[5] << 28);
+    out[2] = (v[5] >> 4) | (v[6] << 8) | (v[7] << 20);
+}
+
 __global__ void k_mono_class(uint8_t *__restrict__ path_dir, uint32_t n_paths) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n_paths) path_dir[p] = path_dir[p] == 3 ? 1 : 0;  // both directions seen: not tile-monotone
@@ -222,7 +242,8 @@ int prepare_steps(pnx_ctx *ctx) {
     const uint32_t P = ctx->n_paths;
     int rc;
     const size_t mono_bytes = ((size_t)(P ? P : 1) + 3) / 4 * 4;
-    if ((rc = ensure(ctx, ctx->d_items16, ctx->n_steps * sizeof(uint16_t) + 64)) || (rc = ensure(ctx, ctx->d_path_mono, mono_bytes)))
+    const uint64_t n_groups8 = (ctx->n_steps + 7) / 8;
+    if ((rc = ensure(ctx, ctx->d_steps12, n_groups8 * 12 + 64)) || (rc = ensure(ctx, ctx->d_path_mono, mono_bytes)))
         return rc;
     DevBuf d_changes;
     if ((rc = ensure(ctx, d_changes, (size_t)(P ? P : 1) * 4))) return rc;
@@ -247,7 +268,7 @@ int prepare_steps(pnx_ctx *ctx) {
         }
         hipLaunchKernelGGL(k_prepare_steps, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, ctx->stream,
                            (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p,
-                           (const uint64_t *)ctx->d_chunk_off.p, P, n_chunks, (uint16_t *)ctx->d_items16.p,
+                           (const uint64_t *)ctx->d_chunk_off.p, P, n_chunks,
                            (uint8_t *)ctx->d_path_mono.p, (uint32_t *)d_changes.p);
         hipLaunchKernelGGL(k_mono_class, dim3((P + 255) / 256), dim3(256), 0, ctx->stream, (uint8_t *)ctx->d_path_mono.p, P);
         if (!may_sort) break;
@@ -274,6 +295,11 @@ int prepare_steps(pnx_ctx *ctx) {
         }
     }
     release(d_changes);
+    if (n_groups8) {  // the packed steps of the FINAL order (after a sort of shuffled paths)
+        if ((n_groups8 + 255) / 256 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many steps to pack");
+        hipLaunchKernelGGL(k_pack12, dim3((unsigned)((n_groups8 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_items.p,
+                           ctx->n_steps, (uint32_t *)ctx->d_steps12.p);
+    }
     PNX_HIP(ctx, hipGetLastError());
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // once per upload; the passes read this from other streams too
     ctx->steps_prepared = true;
@@ -737,7 +763,7 @@ __global__ void k_scatter_general(const uint32_t *__restrict__ items,
 // ------------------------------------------------------------------------------------------
 constexpr int COVER_WAVES = 4;   // waves (= tiles) per workgroup
 constexpr int COVER_UNROLL = 4;  // 16-byte loads in flight per lane (u32 steps: the plain cross-check kernel)
-constexpr int COVER_UNROLL16 = 2;  // the same for the 2-byte steps: 2 x 64 lanes x 8 steps = 1024 steps per batch
+constexpr int COVER_UNROLL12 = 2;  // the same for the packed steps: 2 x 64 lanes x 8 steps = 1024 steps per batch
 
 // runs of the run-route paths, sorted by (tile, group); see kernels_runs.hip
 struct SplitPts {  // cut points of the visiting order for the split coverage kernel
@@ -789,37 +815,47 @@ __device__ static inline void run_window_load(const RunView &rv, RunWindow &w, u
     w.start = ok ? rv.start[i] : 0ull;
 }
 
-// 16 bytes of 2-byte steps
+// the packed steps: a distinct pointer type, so that a kernel's first parameter tells which table it streams
+struct step12_word {
+    uint32_t w;
+};
+struct Steps8 {  // 8 steps = 96 bits
+    uint32_t d0, d1, d2;
+};
+
+// 12 bytes = 8 packed steps (group j / 8 of the table; j is a multiple of 8)
 template <bool NT>
-__device__ static inline uint4 load_steps16(const uint16_t *p) {
-    if (NT) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-        return make_uint4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const uint4 *>(p);
+__device__ static inline Steps8 load_steps12(const step12_word *tab, uint64_t j) {
+    typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+    const u32x3 *p = reinterpret_cast<const u32x3 *>(reinterpret_cast<const uint32_t *>(tab) + (j >> 3) * 3);
+    u32x3 v;
+    if (NT) v = __builtin_nontemporal_load(p);
+    else v = *p;
+    return Steps8{v.x, v.y, v.z};
 }
 
-// OR the presence bits of the 8 steps of one 16-byte load into the wave's LDS bitmap.  The load holds the
-// positions jrel .. jrel + 7 of a segment whose valid steps are [rlo, rhi) (all relative to the 16-byte
+// OR the presence bits of the 8 steps of one 12-byte load into the wave's LDS bitmap.  The load holds the
+// positions jrel .. jrel + 7 of a segment whose valid steps are [rlo, rhi) (all relative to the 8-step
 // aligned start of the segment's first load).  A step is 12 bits: word (id % 64), bit (id / 64 % 32) and,
 // for two-block tiles, the block (id / 2048 % 2); which tile it lies in is known from the segment, not
 // from the step (prepare_steps).  Steps outside [rlo, rhi) -- the neighbours of the segment's two ends in
-// their 16-byte groups -- OR a zero.
+// their groups -- OR a zero.  Steps 2 and 5 straddle two dwords (v_alignbit).
 template <int WT>
-__device__ static inline void fold8(uint32_t *bm, const uint4 &v, uint32_t jrel, uint32_t rlo, uint32_t rhi) {
+__device__ static inline void fold8(uint32_t *bm, const Steps8 &v, uint32_t jrel, uint32_t rlo, uint32_t rhi) {
     const int a = (int)rlo - (int)jrel, b = (int)rhi - (int)jrel;
     const uint32_t na = a <= 0 ? 0u : (a >= 8 ? 8u : (uint32_t)a), nb = b <= 0 ? 0u : (b >= 8 ? 8u : (uint32_t)b);
     const uint32_t valid = ((1u << nb) - 1u) & ~((1u << na) - 1u);
     if (valid == 0) return;
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t x2 = __builtin_amdgcn_alignbit(v.d1, v.d0, 24), x5 = __builtin_amdgcn_alignbit(v.d2, v.d1, 28);
+    // (dword, bit offset) of the 8 steps
+    const uint32_t src[8] = {v.d0, v.d0, x2, v.d1, v.d1, x5, v.d2, v.d2};
+    constexpr uint32_t off[8] = {0, 12, 0, 4, 16, 0, 8, 20};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t n0 = d[e], n1 = d[e] >> 16;
-        const uint32_t w0 = (n0 & 63u) + (WT == 2 ? ((n0 >> 11) & 1u) << 6 : 0u);
-        const uint32_t w1 = (n1 & 63u) + (WT == 2 ? ((n1 >> 11) & 1u) << 6 : 0u);
-        atomicOr(&bm[w0], ((valid >> (2 * e)) & 1u) << ((n0 >> 6) & 31u));
-        atomicOr(&bm[w1], ((valid >> (2 * e + 1)) & 1u) << ((n1 >> 6) & 31u));
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t word = __builtin_amdgcn_ubfe(src[e], off[e], 6u) +
+                              (WT == 2 ? __builtin_amdgcn_ubfe(src[e], off[e] + 11u, 1u) << 6 : 0u);
+        const uint32_t bit = __builtin_amdgcn_ubfe(src[e], off[e] + 6u, 5u);
+        atomicOr(&bm[word], ((valid >> e) & 1u) << bit);
     }
 }
 
@@ -853,11 +889,11 @@ __device__ static inline void consume_runs(const RunView &rv, RunWindow &w, uint
     }
 }
 
-// the runs of group g in this wave's tile, as 2-byte steps (a run lies inside one tile by construction)
+// the runs of group g in this wave's tile, as packed steps (a run lies inside one tile by construction)
 template <int WT>
-__device__ static inline void consume_runs16(const RunView &rv, RunWindow &w, uint64_t &cursor, uint64_t cursor_end,
-                                             uint32_t g, const uint16_t *__restrict__ items16, uint32_t *bm, uint32_t lane) {
-    constexpr int U = COVER_UNROLL16;
+__device__ static inline void consume_runs12(const RunView &rv, RunWindow &w, uint64_t &cursor, uint64_t cursor_end,
+                                             uint32_t g, const step12_word *__restrict__ steps12, uint32_t *bm, uint32_t lane) {
+    constexpr int U = COVER_UNROLL12;
     while (cursor < cursor_end) {
         if (cursor - w.base >= 64) run_window_load(rv, w, cursor, cursor_end, lane);
         const uint32_t k = __builtin_amdgcn_readfirstlane((uint32_t)(cursor - w.base));
@@ -868,12 +904,12 @@ __device__ static inline void consume_runs16(const RunView &rv, RunWindow &w, ui
         const uint64_t base = lo & ~7ull;
         const uint32_t rlo = (uint32_t)(lo - base), rhi = rlo + len;
         for (uint32_t off = 0; off < rhi; off += 512u * U) {
-            uint4 v[U];
+            Steps8 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t jrel = off + (uint32_t)u * 512u + lane * 8u;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (jrel < rhi) v[u] = *reinterpret_cast<const uint4 *>(items16 + base + jrel);
+                v[u] = Steps8{0, 0, 0};
+                if (jrel < rhi) v[u] = load_steps12<false>(steps12, base + jrel);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) fold8<WT>(bm, v[u], off + (uint32_t)u * 512u + lane * 8u, rlo, rhi);
@@ -1044,14 +1080,14 @@ __global__ __launch_bounds__(COVER_WAVES * 64) void k_tile_cover(
 // (normalize_order) a wave of a 100 000-contig graph loads a handful of windows per group.
 template <int NPL, int WT, bool WRITE_M, bool NT, int CW, bool RUNS, int SPLIT = 1, bool SKIP = false>
 __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1) ? 6 : 1) void k_tile_cover_pipe(
-    const uint16_t *__restrict__ items16, TileIdx ix, OrdIdx oi,
+    const step12_word *__restrict__ steps12, TileIdx ix, OrdIdx oi,
     const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
     uint32_t n_ordered, uint8_t *path_class, const uint8_t *__restrict__ grp_general,
     const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles, uint32_t n_blocks,
     uint32_t *M, uint64_t row_words, uint32_t *__restrict__ countable, uint32_t *flags, RunView rv,
     SplitPts sp) {
     constexpr uint32_t TILE = WT * BLOCK_ITEMS;
-    constexpr int U = COVER_UNROLL16;
+    constexpr int U = COVER_UNROLL12;
     constexpr int TPW = CW / SPLIT;  // tiles per workgroup
     static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
     __shared__ uint32_t bm_all[CW][WT * BLOCK_WORDS];
@@ -1109,7 +1145,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
         for (int w = 0; w < WT; ++w) cnt[k][w] = 0;
 
     auto flush = [&](uint32_t g) {
-        if (RUNS && run_c < run_end) consume_runs16<WT>(rv, run_w, run_c, run_end, g, items16, bm, lane);
+        if (RUNS && run_c < run_end) consume_runs12<WT>(rv, run_w, run_c, run_end, g, steps12, bm, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const bool merge = grp_general != nullptr && grp_general[g] != 0;
@@ -1218,14 +1254,14 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
     };
 
     // prefetch state of the NEXT interesting entry
-    uint4 nxt[U];
+    Steps8 nxt[U];
     auto issue = [&](uint64_t lo, uint64_t hi) {
-        const uint64_t base = lo & ~7ull;  // 8 steps = 16 bytes
+        const uint64_t base = lo & ~7ull;  // 8 steps = 12 bytes
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t j = base + (uint64_t)u * 512 + lane * 8u;
-            nxt[u] = make_uint4(0, 0, 0, 0);
-            if (j < hi) nxt[u] = load_steps16<NT>(items16 + j);
+            nxt[u] = Steps8{0, 0, 0};
+            if (j < hi) nxt[u] = load_steps12<NT>(steps12, j);
         }
     };
 
@@ -1265,7 +1301,7 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
             flush(cur_g);
             cur_g = g;
         }
-        uint4 cur[U];
+        Steps8 cur[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         const uint64_t lo = last ? 0 : e_lo, hi = last ? 0 : e_hi;
@@ -1287,12 +1323,12 @@ __global__ __launch_bounds__(CW * 64, (!RUNS && !SKIP && NPL <= 12 && SPLIT > 1)
             for (int u = 0; u < U; ++u) fold8<WT>(bm, cur[u], (uint32_t)u * 512u + lane * 8u, rlo, rhi);
             // long segments (> U*512 steps): the tail is streamed directly
             for (uint32_t off = 512u * U; off < rhi; off += 512u * U) {
-                uint4 v[U];
+                Steps8 v[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t jrel = off + (uint32_t)u * 512u + lane * 8u;
-                    v[u] = make_uint4(0, 0, 0, 0);
-                    if (jrel < rhi) v[u] = load_steps16<NT>(items16 + base + jrel);
+                    v[u] = Steps8{0, 0, 0};
+                    if (jrel < rhi) v[u] = load_steps12<NT>(steps12, base + jrel);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) fold8<WT>(bm, v[u], off + (uint32_t)u * 512u + lane * 8u, rlo, rhi);
@@ -1427,9 +1463,9 @@ static void launch_cover_t(pnx_ctx *ctx, bool write_m, bool use_m) {
     const bool has_runs = rv.tile_off != nullptr;
     SplitPts sp{};
     auto launch = [&](auto kern, int cw, int split = 1) {
-        // the pipelined kernels stream the 2-byte steps, the plain cross-check kernel the u32 ItemTable
+        // the pipelined kernels stream the packed 12-bit steps, the plain cross-check kernel the u32 ItemTable
         using items_ptr_t = typename first_param<decltype(kern)>::type;
-        const void *items_ptr = std::is_same<items_ptr_t, const uint16_t *>::value ? ctx->d_items16.p : ctx->d_items.p;
+        const void *items_ptr = std::is_same<items_ptr_t, const step12_word *>::value ? ctx->d_steps12.p : ctx->d_items.p;
         const unsigned tpw = (unsigned)(cw / split);
         const unsigned grid = (ctx->n_tiles + tpw - 1) / tpw;
         // group-aligned cut points of the visiting order

@@ -278,7 +278,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_items16, &ctx->d_path_mono, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
@@ -304,7 +304,7 @@ static void begin_upload(pnx_ctx *ctx) {
     ctx->have_csr = false;
     ctx->have_order = false;
     ctx->steps_prepared = false;
-    if (ctx->d_items16.borrowed) release(ctx->d_items16);
+    if (ctx->d_steps12.borrowed) release(ctx->d_steps12);
     if (ctx->d_path_mono.borrowed) release(ctx->d_path_mono);
     if (ctx->d_unsorted.borrowed) {
         release(ctx->d_unsorted);
@@ -547,7 +547,7 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     if (src->device != dst->device) return dst->fail(PNX_EINVAL, "pnx_share_csr: the contexts are on different devices");
     if (src->d_items.borrowed) return dst->fail(PNX_EINVAL, "pnx_share_csr: the source itself borrows its graph");
     PNX_HIP(dst, hipSetDevice(dst->device));
-    // the 2-byte steps and the path classes are derived data of the graph: made once, by the owner
+    // the packed steps and the path classes are derived data of the graph: made once, by the owner
     if (int prc = prepare_steps(src)) return dst->fail(prc, "pnx_share_csr: %s", src->err.c_str());
     PNX_HIP(dst, hipStreamSynchronize(src->stream));  // its upload is complete
     invalidate_results(dst);
@@ -563,7 +563,7 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_path_off, src->d_path_off);
     borrow(dst->d_weights, src->d_weights);
     borrow(dst->d_exclude, src->d_exclude);
-    borrow(dst->d_items16, src->d_items16);
+    borrow(dst->d_steps12, src->d_steps12);
     borrow(dst->d_path_mono, src->d_path_mono);
     dst->steps_prepared = true;
     borrow(dst->d_unsorted, src->d_unsorted);

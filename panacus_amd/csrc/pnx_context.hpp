@@ -101,11 +101,12 @@ struct pnx_ctx {
     bool have_weights = false;  // weights are resident (weighted = resident AND enabled)
     pnx::DevBuf d_items, d_path_off, d_weights, d_exclude;
     // derived once per upload by one streaming pass (prepare_steps, kernels_cover.hip), shared by borrowers:
-    //   d_items16   S x u16: the step ids modulo 4096 -- inside its tile a step needs no more, and the
-    //               coverage kernel streams these 2 bytes per step instead of 4;
+    //   d_steps12   ceil(S / 8) x 12 bytes: the step ids modulo 4096, 12 bits each, 8 steps per three dwords --
+    //               inside its tile a step needs no more, and the coverage kernel streams these 1.5 bytes per
+    //               step instead of 4;
     //   d_path_mono P x u8: 1 = the path is NOT tile-monotone (its 2048-id tile sequence goes both up
     //               and down), decided exactly; 0 = the boundary index serves it
-    pnx::DevBuf d_items16, d_path_mono;
+    pnx::DevBuf d_steps12, d_path_mono;
     bool steps_prepared = false;
     std::vector<uint64_t> h_path_off;
     // internal renumbering of the items by a caller key (kernels_relabel.hip): resident steps, weights and
@@ -242,7 +243,7 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
 // kernels_cover.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
-int prepare_steps(pnx_ctx *ctx);  // d_items16 + d_path_mono (no-op when done)
+int prepare_steps(pnx_ctx *ctx);  // d_steps12 + d_path_mono (no-op when done)
 int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);  // sorted paths back in the caller's order (pnx_get_csr)
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
