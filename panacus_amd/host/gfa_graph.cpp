@@ -1492,21 +1492,39 @@ bool any_containing(const std::vector<Iv> *v, Iv el) {
     return false;
 }
 
-// IntervalContainer (src/util.rs:209-310) for one node: a sorted union of [s, e) pieces where
-// touching pieces are joined, which is what its `add` maintains
+// IntervalContainer (src/util.rs:209-310) for one node.  `add` follows the reference's own steps (util.rs:215-258:
+// position by start, then one of three cases) instead of a generic interval union: for proper pieces the two are the
+// same, but a BED row with start > end makes update_tables hand over a piece with a > b (a node that holds both ends
+// of such a row), and what the container then holds is whatever these steps make of it.
 struct Pieces {
     std::vector<Iv> v;
-    void add(uint64_t s, uint64_t e) {
-        size_t lo = 0;
-        while (lo < v.size() && v[lo].e < s) ++lo;  // wholly before, not even touching
-        size_t hi = lo;
-        while (hi < v.size() && v[hi].s <= e) {
-            s = std::min(s, v[hi].s);
-            e = std::max(e, v[hi].e);
-            ++hi;
+    void add(uint64_t start, uint64_t end) {
+        if (v.empty()) {
+            v.push_back(Iv{start, end});
+            return;
         }
-        v.erase(v.begin() + (ptrdiff_t)lo, v.begin() + (ptrdiff_t)hi);
-        v.insert(v.begin() + (ptrdiff_t)lo, Iv{s, e});
+        size_t i = 0;  // binary_search_by_key(&start, |(y, _)| y).unwrap_or_else(|z| z): starts are unique and sorted
+        while (i < v.size() && v[i].s < start) ++i;
+        if (i > 0 && v[i - 1].e >= start) {
+            if (v[i - 1].e < end) {
+                uint64_t stop = end;
+                while (i < v.size() && v[i].s <= end) {
+                    stop = std::max(stop, v[i].e);
+                    v.erase(v.begin() + (ptrdiff_t)i);
+                }
+                v[i - 1].e = stop;
+            }  // else: enclosed in the previous piece
+        } else if (i < v.size() && v[i].e >= start && v[i].s <= end) {
+            v[i].s = std::min(v[i].s, start);
+            uint64_t stop = std::max(v[i].e, end);
+            while (i + 1 < v.size() && v[i + 1].s <= end) {
+                stop = std::max(stop, v[i + 1].e);
+                v.erase(v.begin() + (ptrdiff_t)i + 1);
+            }
+            v[i].e = stop;
+        } else {
+            v.insert(v.begin() + (ptrdiff_t)i, Iv{start, end});
+        }
     }
 };
 
@@ -1675,10 +1693,13 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
                         partly_excluded.erase(sid);
                         return;
                     }
-                    Pieces &pc = partly_excluded[sid];
-                    pc.add(a, bb);
-                    if (pc.v[0] == Iv{0, l}) {
-                        partly_excluded.erase(sid);
+                    // activate_n_annotate (src/util.rs:147-181): a piece with start > end is reported and not added
+                    // (the reference then unwraps the node's list, which panics if nothing was ever added: not modelled)
+                    auto it = a <= bb ? partly_excluded.try_emplace(sid).first : partly_excluded.find(sid);
+                    if (it == partly_excluded.end()) return;
+                    if (a <= bb) it->second.add(a, bb);
+                    if (!it->second.v.empty() && it->second.v[0] == Iv{0, l}) {
+                        partly_excluded.erase(it);
                         flag(sid);
                     }
                 });
@@ -1815,14 +1836,14 @@ void GraphStorage::replay_piece_events(const WalkCut &cut, std::vector<PieceEven
         if (e.kind == 0) {
             // a later full sighting drops every earlier partial one (covered.remove, util.rs:640-643)
             if (e.step + 1 > e.last_full) covered[e.item].add(e.a, e.b);
-        } else if (!e.flagged) {
+        } else if (!e.flagged && e.a <= e.b) {  // activate_n_annotate drops a piece with start > end (src/util.rs:163-170)
             partly_excluded[e.item].add(e.a, e.b);
         }
     }
     // ActiveTable::activate_n_annotate (src/util.rs:147-181): pieces that join to the whole node exclude it
     for (auto it = partly_excluded.begin(); it != partly_excluded.end();) {
         const uint64_t l = node_lens_[it->first];
-        if (it->second.v.size() == 1 && it->second.v[0] == Iv{0, l}) {
+        if (!it->second.v.empty() && it->second.v[0] == Iv{0, l}) {
             late_flags.push_back(it->first);
             flagged[it->first] = true;
             it = partly_excluded.erase(it);

@@ -22,6 +22,22 @@ N_SEEDS = int(os.environ.get("PANACUS_FUZZ_SEEDS", "12"))
 MAXU = (1 << 64) - 1
 
 
+def _keep_failure(gfa, sf, ef, note):
+    """PANACUS_KEEP_FAILURES=<dir>: the inputs of a failing random case are copied there (soak runs)"""
+    keep = os.environ.get("PANACUS_KEEP_FAILURES")
+    if not keep:
+        return
+    import shutil
+    import uuid
+    d = os.path.join(keep, uuid.uuid4().hex[:8])
+    os.makedirs(d, exist_ok=True)
+    for f in (gfa, sf, ef):
+        if f:
+            shutil.copy(f, d)
+    with open(os.path.join(d, "note.txt"), "w") as f:
+        f.write(note + "\n")
+
+
 def _compare_with_oracle(g, hg, gfa, sf, ef, mode=orc.GROUP_PATHID):
     g.path_order(mode, None, None, sf, ef)
     for ct in (orc.NODE, orc.BP, orc.EDGE):
@@ -29,6 +45,12 @@ def _compare_with_oracle(g, hg, gfa, sf, ef, mode=orc.GROUP_PATHID):
         with capi.Context() as ctx:
             uid, ub = hg.cut_upload(ctx, ct, sf, ef, mode)
             got_items, got_off, _ = ctx.get_csr()
+            ok = (np.array_equal(got_off, pre) and np.array_equal(got_items.astype(np.uint64), items.astype(np.uint64)) and
+                  np.array_equal(ctx.get_exclude()[1:], fl[1:]) and
+                  np.array_equal(uid.astype(np.uint64), ids.astype(np.uint64)) and np.array_equal(ub, ubp))
+            if not ok:
+                _keep_failure(gfa, sf, ef, f"ct={ct} mode={mode} sf={sf} ef={ef} oracle_unc={ids.tolist()}/{ubp.tolist()} "
+                                           f"device_unc={uid.tolist()}/{ub.tolist()}")
             assert np.array_equal(got_off, pre), (ct, sf, ef)
             assert np.array_equal(got_items.astype(np.uint64), items.astype(np.uint64)), (ct, sf, ef)
             assert np.array_equal(ctx.get_exclude()[1:], fl[1:]), (ct, sf, ef)
@@ -334,3 +356,11 @@ def test_cut_at_cfg3_size():
                 (c, d), = exc[k]
                 assert flags[seg[(st < d) & (en > c)]].all(), k
         assert int(goff[-1]) == len(got) and 0 < len(got) < len(items)
+
+
+def test_cut_rows_with_start_beyond_end(golden_dir):
+    """the two soak-run cases of tests/golden/bed_inverted (BED rows with start > end inside one node) through the device"""
+    base = os.path.join(golden_dir, "bed_inverted")
+    for d, mode in (("6cd09061", orc.GROUP_PATHID), ("8438eb63", orc.GROUP_SAMPLE)):
+        gfa, sf, ef = (os.path.join(base, d, f) for f in ("r.gfa", "subset.bed", "exclude.bed"))
+        _compare_with_oracle(orc.Graph(gfa, index_edges=True), hl.GfaGraph(gfa, index_edges=True), gfa, sf, ef, mode)

@@ -43,7 +43,8 @@ def _random_gfa(rng, path, crlf):
     rng.shuffle(links)
     for a, o1, b, o2 in links:
         lines.append(f"L\t{a}\t{o1}\t{b}\t{o2}\t0M")
-    have = {(a, o1, b, o2) for a, o1, b, o2 in links}
+    have = list(links)  # iterated below: a list, so that a seed gives the same file in every process (a set of str
+    # tuples iterates in hash order, and str hashes are randomised per process)
 
     def flip(o):
         return "-" if o == "+" else "+"
@@ -151,6 +152,8 @@ def _random_bed(rng, path, names, path_bp, groups):
                 lo = 0
             if rng.random() < 0.15:
                 hi = span + int(rng.integers(0, 3))
+            if rng.random() < 0.06 and lo > 2:  # start > end, close together: both ends inside one node now and then
+                hi = lo - int(rng.integers(1, min(lo, 12)))
             rows.append(f"{ids[k]}\t{lo}\t{hi}" + ("\textra" if rng.random() < 0.1 else ""))
     with open(path, "w") as f:
         f.write("\n".join(rows) + "\n")

@@ -130,3 +130,24 @@ def test_host_matches_oracle_on_bed_fixtures(golden_dir, tiny, ct):
         x, y = b.masked_table(ct, sf, ef), a.masked_table(ct, sf, ef)
         for u, v in zip(x, y):
             assert np.array_equal(np.asarray(u, dtype=np.uint64), np.asarray(v, dtype=np.uint64)), (path, sf, ef)
+
+
+def test_rows_with_start_beyond_end(golden_dir):
+    """BED rows with start > end inside one node (found by a soak run, tests/golden/bed_inverted/README.md): the exclude
+    side drops such a piece (activate_n_annotate, src/util.rs:163-170), the include side hands it to
+    IntervalContainer::add as it is -- host walk == oracle, and the uncovered bp are the ones the soak run disagreed on"""
+    import numpy as np
+    from panacus_amd import hostlib as hl
+    base = os.path.join(golden_dir, "bed_inverted")
+    expect = {"6cd09061": (orc.GROUP_PATHID, [10], [7]), "8438eb63": (orc.GROUP_SAMPLE, [5, 53], [12, 6])}
+    for d, (mode, ids, bps) in expect.items():
+        gfa, sf, ef = (os.path.join(base, d, f) for f in ("r.gfa", "subset.bed", "exclude.bed"))
+        g = orc.Graph(gfa, index_edges=True)
+        hg = hl.GfaGraph(gfa, index_edges=True)
+        g.path_order(mode, None, None, sf, ef)
+        for ct in (orc.NODE, orc.BP, orc.EDGE):
+            a, b = g.masked_table(ct, sf, ef), hg.masked_table(ct, sf, ef, mode)
+            for x, y in zip(a, b):
+                assert np.array_equal(np.asarray(x).astype(np.uint64), np.asarray(y).astype(np.uint64)), (d, ct)
+            if ct == orc.BP:
+                assert a[3].tolist() == ids and a[4].tolist() == bps
