@@ -1665,10 +1665,6 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
             if (!ec[k]->empty())  // every node of an excluded path is excluded as a whole (util.rs:1171-1181)
                 for (uint64_t j = 0; j < len; ++j) flag(ids[j]);
         } else if (how[k] == WALK && count != COUNT_EDGE) {
-            if (ic[k] == &complete && ec[k]->empty()) {  // nothing to cut and nothing to flag: a whole path after all
-                how[k] = WHOLE;
-                return;
-            }
             size_t ci = 0, cj = 0;
             uint64_t p = paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0;
             for (uint64_t j = 0; j < len; ++j) {
@@ -1794,9 +1790,9 @@ WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::strin
     if (ms.have_exc) w.exc_off.assign(P + 1, 0);
     for (size_t k = 0; k < P; ++k) {
         w.path_start[k] = paths_[k].has_start && paths_[k].has_end ? paths_[k].start : 0;
-        uint8_t how = ms.how[k];
-        // nothing to cut and nothing to flag: a whole path after all (no per-node bookkeeping either)
-        if (how == WALK && count != COUNT_EDGE && ms.ic[k] == &ms.complete && ms.ec[k]->empty()) how = WHOLE;
+        // (a walked path with the whole-path interval and nothing to exclude is NOT the same as a path taken whole:
+        // the walk drops zero-length nodes at coordinate 0, update_tables' `include_coords[i].0 < p + l`, util.rs:625)
+        const uint8_t how = ms.how[k];
         w.path_mode[k] = how;
         if (how != SKIP)
             for (const Iv &x : *ms.ic[k]) {

@@ -28,7 +28,8 @@ def _random_gfa(rng, path, crlf):
     lines = ["H\tVN:Z:1.0"]
     for i, nm in enumerate(names):
         if rng.random() < 0.5:
-            seq = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 30))))
+            # now and then an EMPTY sequence field: a node of length 0 (graph.rs:343-349 takes the field's length)
+            seq = "" if rng.random() < 0.04 else "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 30))))
             lines.append(f"S\t{nm}\t{seq}")
         else:
             lines.append(f"S\t{nm}\t*\tLN:i:{int(rng.integers(1, 500))}")

@@ -151,3 +151,24 @@ def test_rows_with_start_beyond_end(golden_dir):
                 assert np.array_equal(np.asarray(x).astype(np.uint64), np.asarray(y).astype(np.uint64)), (d, ct)
             if ct == orc.BP:
                 assert a[3].tolist() == ids and a[4].tolist() == bps
+
+
+def test_walked_path_drops_leading_zero_length_nodes(tmp_path):
+    """update_tables keeps a node only if an include interval starts BEFORE its end (`include_coords[i].0 < p + l`,
+    graph_broker/util.rs:625): with an exclude list that does not name a path, the path is walked against the whole-path
+    interval (0, usize::MAX) and a zero-length node at coordinate 0 is dropped -- unlike a path taken whole (no lists)"""
+    import numpy as np
+    from panacus_amd import hostlib as hl
+    gfa = tmp_path / "z.gfa"
+    gfa.write_text("H\tVN:Z:1.0\nS\ta\t\nS\tb\tACGT\nS\tc\t\nP\tp1\ta+,b+,c+\t*\nP\tp2\tb+\t*\n")
+    ex = tmp_path / "e.bed"
+    ex.write_text("p2\n")
+    g = orc.Graph(str(gfa))
+    hg = hl.GfaGraph(str(gfa))
+    assert g.node_lens.tolist() == [0, 0, 4, 0] and np.array_equal(hg.node_lens, g.node_lens)
+    assert g.item_table(orc.NODE)[0].tolist() == [1, 2, 3, 2]       # no lists: every step
+    g.path_order(orc.GROUP_PATHID, None, None, None, str(ex))
+    for ct in (orc.NODE, orc.BP):
+        o, h = g.masked_table(ct, None, str(ex)), hg.masked_table(ct, None, str(ex))
+        assert o[0].tolist() == [2, 3, 2] and o[1].tolist() == [0, 2, 3]  # a (length 0 at coordinate 0) is gone, c stays
+        assert np.array_equal(h[0].astype(np.uint64), o[0].astype(np.uint64)) and np.array_equal(h[1], o[1])
