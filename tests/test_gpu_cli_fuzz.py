@@ -84,7 +84,13 @@ def test_cli_bed_lists_and_table_on_random_gfa(tmp_path, seed):
         ef = str(tmp_path / "e.bed")
         _random_bed(rng, ef, g.path_names(), path_bp, gnames if mode != orc.GROUP_PATHID else [])
     extra = ([flag] if flag else []) + (["-s", sf] if sf else []) + (["-e", ef] if ef else [])
-    pi, gi, names = g.path_order(mode, None, None, sf, ef)
+    try:
+        pi, gi, names = g.path_order(mode, None, None, sf, ef)
+        g.masked_table(orc.NODE, sf, ef)
+    except ValueError:  # a row the reference panics on (two columns, a coordinate that is no number): the CLI refuses it too
+        rc, out, err = hl.run_cli(["hist", "-c", "all"] + extra + [gfa])
+        assert rc != 0 and err
+        return
     G = len(names)
     rc, out, err = hl.run_cli(["hist", "-c", "all"] + extra + [gfa])
     assert rc == 0, err

@@ -39,9 +39,19 @@ def _keep_failure(gfa, sf, ef, note):
 
 
 def _compare_with_oracle(g, hg, gfa, sf, ef, mode=orc.GROUP_PATHID):
-    g.path_order(mode, None, None, sf, ef)
+    try:
+        g.path_order(mode, None, None, sf, ef)
+    except ValueError:
+        with pytest.raises(ValueError):
+            hg.path_order(mode, None, None, sf, ef)
+        return
     for ct in (orc.NODE, orc.BP, orc.EDGE):
-        items, pre, fl, ids, ubp = g.masked_table(ct, sf, ef)
+        try:
+            items, pre, fl, ids, ubp = g.masked_table(ct, sf, ef)
+        except ValueError:  # a row the reference panics on: the device path must refuse it as well
+            with capi.Context() as ctx, pytest.raises(ValueError):
+                hg.cut_upload(ctx, ct, sf, ef, mode)
+            continue
         with capi.Context() as ctx:
             uid, ub = hg.cut_upload(ctx, ct, sf, ef, mode)
             got_items, got_off, _ = ctx.get_csr()

@@ -132,8 +132,10 @@ def _random_bed(rng, path, names, path_bp, groups):
             rows.append(ids[k])
         elif kind < 0.3 and groups:
             rows.append(groups[int(rng.integers(0, len(groups)))])
-        elif kind < 0.36:
+        elif kind < 0.34:
             rows.append("nobody#1#knows")
+        elif kind < 0.36:  # odd rows: two columns, a coordinate that is no number, a huge coordinate
+            rows.append([f"{ids[k]}\t7", f"{ids[k]}\tx\t9", f"{ids[k]}\t3\t99999999999999"][int(rng.integers(0, 3))])
         elif kind < 0.42:
             rows.append("# a comment" if rng.random() < 0.5 else "track name=x")
         elif kind < 0.5:
@@ -194,7 +196,12 @@ def test_random_bed_lists_match_oracle(tmp_path, seed):
         ph = a.path_order(mode, None, None, sf, ef)
         assert po[2] == ph[2] and np.array_equal(po[0], ph[0]) and np.array_equal(po[1], ph[1])
         for ct in (hl.NODE, hl.BP, hl.EDGE):
-            x = b.masked_table(ct, sf, ef)
+            try:
+                x = b.masked_table(ct, sf, ef)
+            except ValueError:  # a row the reference panics on (two columns, a coordinate that is no number)
+                with pytest.raises(ValueError):
+                    a.masked_table(ct, sf, ef, mode)
+                continue
             y = a.masked_table(ct, sf, ef, mode)
             for k, (u, v) in enumerate(zip(x, y)):
                 assert np.array_equal(np.asarray(u, dtype=np.uint64), np.asarray(v, dtype=np.uint64)), (ct, k, sf, ef)
