@@ -7,6 +7,7 @@ process, page cache warm:
   a. `histgrowth -S -q 0,0.5,1.0 -l 0,1,2`          (test/integrated_test.R:123: "~17 s" for the reference, node)
   b. the same with `-c edge`                        (test/integrated_test.R:136: "~79 s")
   c. `histgrowth -l 1,2,1,1,1 -q 0,0,1,0.5,0.1 -S -a -s haplotypes.txt`   (examples/pangenome_growth_pggb.md:21)
+  d. `ordered-histgrowth -c bp -S`, e. `similarity -c bp -S`, f. `table -c node -S --total`   (SURVEY 8f rows on the same file)
 and the oracle (serial CPU restatement) on command a, whose table the CLI's must equal byte for byte.
 The reference's timings are developer comments on unstated hardware, on the REAL file: orientation, not a baseline."""
 import argparse
@@ -64,6 +65,12 @@ def main():
         del names
         out["c_example_subset_s"] = min(run(["histgrowth", "-l", "1,2,1,1,1", "-q", "0,0,1,0.5,0.1", "-S", "-a", "-s", haps, gfa])[0]
                                         for _ in range(2))
+        # the "next" rows on the same file: ordered growth in file order of the samples, similarity (bp), table --total
+        out["d_ordered_histgrowth_bp_s"] = min(run(["ordered-histgrowth", "-c", "bp", "-S", "-l", "1,2", "-q", "0,0.5", gfa])[0] for _ in range(2))
+        t_sim, sim_out = run(["similarity", "-c", "bp", "-S", gfa])
+        out["e_similarity_bp_s"] = t_sim
+        out["e_similarity_rows"] = len(body(sim_out))
+        out["f_table_total_node_s"] = run(["table", "-c", "node", "-S", "--total", gfa])[0]
         out["cached_histgrowth_node_s"] = None
         run(["histgrowth", "--cache"] + grid + [gfa])
         out["cached_histgrowth_node_s"] = min(run(["histgrowth", "--cache"] + grid + [gfa])[0] for _ in range(2))
