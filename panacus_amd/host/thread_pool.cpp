@@ -94,7 +94,12 @@ void ThreadPool::drain(const std::function<void(size_t)> &fn, size_t n_tasks, ui
         const size_t idx = (size_t)(t & 0xFFFFFFFFull);
         if (idx >= n_tasks) return;
         if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
-        fn(idx);
+        try {
+            fn(idx);
+        } catch (...) {  // kept for the caller: a task must never unwind through the pool (the job would never complete)
+            std::lock_guard<std::mutex> lk(err_mu_);
+            if (!first_error_) first_error_ = std::current_exception();
+        }
         done_.fetch_add(1, std::memory_order_release);
     }
 }
@@ -147,6 +152,12 @@ void ThreadPool::parallel_for(size_t n_tasks, const std::function<void(size_t)> 
     if (sleepers_.load() > 0) cv_work_.notify_all();
     drain(fn, n_tasks, job);
     while (done_.load(std::memory_order_acquire) < n_tasks) PNH_PAUSE();
+    std::exception_ptr err;
+    {
+        std::lock_guard<std::mutex> lk(err_mu_);
+        std::swap(err, first_error_);
+    }
+    if (err) std::rethrow_exception(err);
 }
 
 }  // namespace pnh

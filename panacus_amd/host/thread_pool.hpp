@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -45,6 +46,8 @@ private:
     size_t n_tasks_ = 0;
     unsigned active_limit_ = 0;
     std::atomic<bool> quit_{false};
+    std::mutex err_mu_;
+    std::exception_ptr first_error_;  // the first exception a task of the current job threw; rethrown by parallel_for
 };
 
 }  // namespace pnh
