@@ -151,7 +151,12 @@ void ThreadPool::parallel_for(size_t n_tasks, const std::function<void(size_t)> 
     }
     if (sleepers_.load() > 0) cv_work_.notify_all();
     drain(fn, n_tasks, job);
-    while (done_.load(std::memory_order_acquire) < n_tasks) PNH_PAUSE();
+    // the last tasks run on other threads: spin briefly (jobs here are sub-millisecond), then give the CPU away -- under a
+    // CFS quota shared with other busy processes a spinning waiter takes the time its own workers need
+    for (unsigned spins = 0; done_.load(std::memory_order_acquire) < n_tasks;) {
+        if (++spins < 4096) PNH_PAUSE();
+        else std::this_thread::yield();
+    }
     std::exception_ptr err;
     {
         std::lock_guard<std::mutex> lk(err_mu_);
