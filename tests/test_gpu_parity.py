@@ -1277,3 +1277,48 @@ def test_full_size_cfg4_properties():
         # identity order == reference ordered-histgrowth semantics, q = 0: distinct items so far
         ident = c.ordered_growth(cov[:1], qt[:1])
         assert int(ident[0, 0, -1]) == n - int(h[0])
+
+
+def test_full_size_cfg4_similarity_against_the_presence_rows():
+    """configs[3]'s matrix (10 M items x 512 groups) through K5 (int8 MFMA): every diagonal entry and 96 random pairs
+    against popcounts of the device's own presence export (node counts); for bp, sampled pairs against the weighted
+    sums of the same rows, with weights wide enough for three 7-bit digits -- and the masked-prefix parity against the
+    oracle (items are independent: exclude[i] = (i > 100 000) must give the oracle's matrix of the prefix graph)"""
+    from panacus_amd import capi
+    n, p, m = 10_000_000, 512, 100_000
+    rng = np.random.default_rng(4)
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, p, size=(96, 2))]
+    order = np.arange(p, dtype=np.uint32)
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(42, n, p, with_weights=True)
+        c.set_order(order, order, p)
+        w = c.get_weights()
+        # node counts
+        c.config(capi.CFG_USE_WEIGHTS, 0)
+        inter = c.group_intersections()
+        rows = c.presence()  # [G, words] u64, bit i % 64 of word i / 64 = item i
+        assert (inter == inter.T).all()
+        assert np.array_equal(np.diag(inter), np.bitwise_count(rows).sum(axis=1, dtype=np.uint64))
+        for a, b in pairs:
+            assert int(inter[a, b]) == int(np.bitwise_count(rows[a] & rows[b]).sum(dtype=np.uint64)), (a, b)
+        # bp, weights scaled into the three-digit range (pansyn lengths < 2^14; x 9 + 3 < 2^17)
+        c.config(capi.CFG_USE_WEIGHTS, 1)
+        w3 = (w.astype(np.uint64) * 9 + 3).astype(np.uint32)
+        w3[0] = 0
+        c.set_weights(w3)
+        inter = c.group_intersections()
+        wq = np.zeros(rows.shape[1] * 64, dtype=np.uint64)
+        wq[: n + 1] = w3
+        for a, b in pairs[:10]:
+            bits = np.unpackbits((rows[a] & rows[b]).view(np.uint8), bitorder="little")
+            assert int(inter[a, b]) == int(wq[bits.astype(bool)].sum(dtype=np.uint64)), (a, b)
+        # masked prefix against the oracle
+        excl = np.zeros(n + 1, dtype=np.uint8)
+        excl[m + 1:] = 1
+        c.set_exclude(excl)
+        inter = c.group_intersections()
+    items, pre, lens = orc.pansyn(42, m, p)
+    pg = np.arange(p, dtype=np.uint64)
+    r, cc = orc.by_group(items, pre, pg, pg, m)
+    exp, _, _ = orc.similarity(r, cc, p, node_lens=(lens.astype(np.uint64) * 9 + 3).astype(np.uint32))
+    assert np.array_equal(inter, exp)
