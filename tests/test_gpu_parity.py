@@ -1322,3 +1322,32 @@ def test_full_size_cfg4_similarity_against_the_presence_rows():
     r, cc = orc.by_group(items, pre, pg, pg, m)
     exp, _, _ = orc.similarity(r, cc, p, node_lens=(lens.astype(np.uint64) * 9 + 3).astype(np.uint32))
     assert np.array_equal(inter, exp)
+
+
+def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order():
+    """2 M nodes x 32 paths (25 M steps), every path shuffled: the preparation sorts them (no scatter route, no run index),
+    the coverage vector equals the one of the unshuffled graph, a second order gives the same, and pnx_get_csr still
+    returns the caller's order"""
+    from panacus_amd import capi
+    n, p = 2_000_000, 32
+    order = np.arange(p, dtype=np.uint32)
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(7, n, p)
+        c.set_order(order, order // 2, p // 2)
+        cnt0, h0 = c.hist()
+        items, off, _ = c.get_csr()
+        sh = items.copy()
+        rng = np.random.default_rng(1)
+        for k in range(p):
+            rng.shuffle(sh[int(off[k]):int(off[k + 1])])
+        c.set_csr(sh, off, n)
+        c.set_order(order, order // 2, p // 2)
+        cnt, h = c.hist()
+        info = c.info()
+        assert info.n_sorted_paths == p and info.n_scatter_paths == 0 and info.n_run_paths == 0 and info.n_reruns == 0
+        assert np.array_equal(cnt, cnt0) and np.array_equal(h, h0)
+        c.set_order(order[::-1].copy(), (order // 2)[::-1].max() - (order // 2)[::-1], p // 2)
+        cnt2, h2 = c.hist()
+        assert np.array_equal(cnt2, cnt0) and np.array_equal(h2, h0)
+        back, back_off, _ = c.get_csr()
+        assert np.array_equal(back, sh) and np.array_equal(back_off, off)
