@@ -74,6 +74,14 @@ timeout 600 python $REPO/benchmarks/bench_similarity.py --variant 0 --bp >> $OUT
 timeout 600 python $REPO/benchmarks/bench_edge_counts.py > $OUT/${R}_edge_counts_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_subset_cut.py > $OUT/${R}_subset_cut_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_pggb_shape.py > $OUT/${R}_pggb_shape_bench.json 2>/dev/null
+# 5b. which kernels a pggb-shaped graph of chr22's size takes (contig paths, back-steps: tile route + run index) -- the CLI under rocprofv3
+PGGB=/tmp/pggb_collect.gfa
+timeout 300 $REPO/panacus_amd/panacus-amd synth --shape pggb --nodes 3760000 --samples 44 -o $PGGB > /dev/null 2>&1
+rm -rf /tmp/p_cli; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cli -o cli -- \
+    $REPO/panacus_amd/panacus-amd histgrowth -S -q 0,0.5,1.0 -l 0,1,2 $PGGB > /dev/null 2>&1
+python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cli)" $OUT/${R}_pggb_cli_kernel_stats.csv > /dev/null
+rm -f $PGGB
+
 # 6. two lanes over one resident graph (documented alternative, not the headline)
 timeout 600 python $REPO/bench.py --lanes 2 $HEAD_ONLY > $OUT/${R}_hist_cfg3_lanes2_bench.json 2>/dev/null
 ls -la $OUT
