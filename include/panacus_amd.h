@@ -178,6 +178,11 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
  * itself be a borrower.  dst then needs its own pnx_set_order. */
 int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src);
 
+/* Derive now what the first coverage pass over the resident graph would derive by itself (default: the path rows, one
+ * read of the steps; PNX_CFG_COVER_VARIANT 0-2: the packed steps and path classes).  pnx_set_csr* has already done it
+ * (the same read validates the ids); pnx_set_csr_pansyn leaves it to the first pass.  Idempotent; synchronous. */
+int pnx_prepare(pnx_ctx *ctx);
+
 /* Read the resident graph back (tests / caching): any pointer may be NULL.
  * n_steps receives S; items needs S entries, path_off n_paths+1, weights n_items+1. */
 int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path_off,
@@ -387,8 +392,18 @@ enum {
     PNX_CFG_BLOCKING_SYNC = 8, /* 1: the wait for a pass (pnx_hist_fetch / _device) sleeps on a blocking HIP
                                   event instead of spinning [0]; for hosts with fewer CPUs than busy threads,
                                   e.g. several ranks under one cgroup CPU quota */
-    PNX_CFG_COVER_VARIANT = 4  /* coverage kernel: 0 plain (the simple form, kept as a cross-check), 1 software-
-                                  pipelined, 2 [default] pipelined + non-temporal CSR loads + split tiles */
+    PNX_CFG_COVER_VARIANT = 4, /* coverage pass: 3 [default] over PATH ROWS -- the path x item presence table that one read of
+                                  the steps derives per upload (256 bytes per path and item tile of 2048 ids; pnx_prepare),
+                                  after which a pass never touches the steps again; 0 / 1 / 2: over the steps themselves
+                                  (0 plain u32 steps, every step checked against its tile; 1 software-pipelined packed
+                                  12-bit steps; 2 the same + non-temporal loads + split tiles -- round 2's default), kept
+                                  as independent cross-checks.  The environment variable PNX_COVER_VARIANT sets the
+                                  default of a new context (cross-check runs of a whole host) */
+    PNX_CFG_ROWS_LAYOUT = 17,  /* layout of the path rows: 0 [default] chosen from the shape, 1 tile-major over all
+                                  (tile, path) pairs, 2 path-major over the tiles each path spans.  Takes effect when the
+                                  rows are next derived */
+    PNX_CFG_DROP_DERIVED = 18  /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
+                                  tile index); the next pass or pnx_prepare derives it again.  Measurement only */
 };
 int pnx_config(pnx_ctx *ctx, int key, int64_t value);
 
@@ -408,7 +423,8 @@ typedef struct {
     uint64_t n_runs;         /* size of the run index */
     uint64_t n_reruns;       /* passes that failed their verification and were run again so far */
     uint32_t n_sorted_paths; /* paths whose steps were sorted by id at preparation (PNX_CFG_SORT_SHUFFLED) */
-    uint32_t reserved;
+    uint32_t rows_tile_major;/* layout of the path rows: 1 tile-major over all (tile, path) pairs, 0 path-major over the spans */
+    uint64_t n_rows;         /* path rows resident (256 bytes each; 0 until they are derived) */
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
 K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
 KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
-CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT, CFG_ROWS_LAYOUT, CFG_DROP_DERIVED = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free",
-    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude",
+    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
 ]
 
 
@@ -44,7 +44,8 @@ class PnxInfo(C.Structure):
                 ("n_ordered", C.c_uint32), ("n_groups", C.c_uint32), ("n_tiles", C.c_uint32),
                 ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32),
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
-                ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("rows_tile_major", C.c_uint32),
+                ("n_rows", C.c_uint64)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
@@ -90,6 +91,7 @@ def load() -> C.CDLL:
     L.pnx_set_csr_keyed.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u64p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
+    L.pnx_prepare.argtypes = [vp]
     L.pnx_get_exclude.argtypes = [vp, u8p]
     L.pnx_set_weights.argtypes = [vp, u32p]
     L.pnx_exclude_items.argtypes = [vp, u32p, C.c_uint32]
@@ -285,6 +287,9 @@ class Context:
     def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
         self.n_items = n_nodes
+
+    def prepare(self):
+        self._ck(self._L.pnx_prepare(self._h))
 
     def get_csr(self, want_weights=False):
         n = C.c_uint64(0)

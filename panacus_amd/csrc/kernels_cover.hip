@@ -1557,8 +1557,9 @@ static int launch_cover_wt(pnx_ctx *ctx, bool write_m, bool use_m) {
 
 int launch_cover_pass(pnx_ctx *ctx) {
     int rc;
-    if (ctx->n_runs && !ctx->runs_sorted && (rc = sort_run_index(ctx))) return rc;
-    const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
+    const bool rows = use_rows(ctx);
+    if (!rows && ctx->n_runs && !ctx->runs_sorted && (rc = sort_run_index(ctx))) return rc;
+    const bool use_m = ctx->want_M || (!rows && ctx->last_general_paths > 0);
     const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
     Ticket *tk = ctx->cur;
     tk->used_m = use_m;
@@ -1577,7 +1578,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
         (rc = ensure(ctx, tk->d_win_lo, ((no + 63) / 64) * sizeof(uint32_t))) ||
         (rc = ensure(ctx, tk->d_win_hi, ((no + 63) / 64) * sizeof(uint32_t))))
         return rc;
-    if ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx))) return rc;
+    if (!rows && ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx)))) return rc;
     if (!tk->ev_pre) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_pre, hipEventDisableTiming));
     if (!tk->ev_cov) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_cov, hipEventDisableTiming));
     const bool phased = ctx->s_pre != ctx->s_main;  // three streams chained by events (see pnx_context.hpp)
@@ -1587,6 +1588,10 @@ int launch_cover_pass(pnx_ctx *ctx) {
     // flags, histogram and per-group "general" marks of this pass: one clear
     PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
 
+    if (rows) {
+        // ---- phases 1 + 2 over path rows (kernels_rows.hip): no boundary index, no routes
+        if ((rc = launch_rows_phases(ctx, ctx->want_M))) return rc;
+    } else {
     if (ctx->n_ordered) {
         prof_begin(ctx, PNX_K_SCATTER, ctx->s_pre);
         hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->s_pre,
@@ -1617,6 +1622,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
     prof_end(ctx);
     if (rc) return rc;
     PNX_HIP(ctx, hipGetLastError());
+    }
     if (phased) {
         PNX_HIP(ctx, hipEventRecord(tk->ev_cov, ctx->s_main));
         PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_post, tk->ev_cov, 0));

@@ -1,0 +1,690 @@
+// kernels_rows.hip -- path rows: the path x item presence table, and the coverage pass over it (gfx950).
+//
+// Every result of the hot path -- AbacusByTotal::coverage (src/graph_broker/abacus.rs:719-744), the
+// histograms built from it (abacus.rs:746-787), AbacusByGroup's (r, c) (abacus.rs:859-986) -- depends on
+// the SET of items a path visits, never on the order or the multiplicity of its steps.  So the steps of a
+// graph are turned, ONCE per upload and in ONE streaming read of the u32 ItemTable, into "path rows":
+//
+//   row (p, t) = 256 bytes = the 2048 presence bits of path p on item tile t, in the block layout of the
+//                presence matrix (pnx_context.hpp: item n -> word n % 64, bit (n % 2048) / 64),
+//                for every tile t between the smallest and the largest id on the path.
+//
+// A coverage pass then never touches the steps again: a wave owns one item tile, walks the visiting order,
+// loads one coalesced 256-byte row per (path, tile), ORs the rows of a group in a register and folds the
+// group into bit-sliced counters -- no LDS atomics, no boundary search, no per-step work, and no special
+// routes: a path whose ids jump around (edge ids in L-line order, shuffled ids) has rows like any other.
+// cfg3 (10 M items x 256 paths, 0.98 G steps): 0.32 GB of rows against 3.9 GB of steps.
+//
+//   k_rows_build   one wave per 4096-step chunk of a path: 16-byte loads, presence bits ORed into an LDS
+//                  window of 8 tiles anchored at the chunk's own ids, flushed with one global atomic OR per
+//                  non-empty row word; a step outside the window (paths that are not sorted by id) goes
+//                  straight to its row with a global atomic.  Also validates every id (the reference
+//                  panics on unknown nodes, graph_broker/util.rs:1021) and records the id range of every
+//                  path -- so an upload costs exactly one read of its steps.
+//   k_rows_order   per pass: row base / tile span of the paths laid out in visiting order (+ the bands of
+//                  tiles reached by every 64 entries, for window skipping).
+//   k_rows_cover   the coverage kernel (K1) described above.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "pnx_context.hpp"
+#include "step_chunks.hpp"
+
+namespace pnx {
+
+constexpr int ROWS_WIN = 8;  // tiles in the LDS window of a build wave
+constexpr int ROWS_U = 4;    // 16-byte loads in flight per lane (build)
+constexpr uint32_t NO_ROW = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------------
+// build: steps -> rows (SCAN_ONLY: only take the id range of every path)
+// ------------------------------------------------------------------------------------------
+// The ids are validated through the id range: the smallest id of a path must be >= 1, the largest <= n_items
+// (ensure_rows).  A row write can still never leave the table: the window flush skips tiles past the last one,
+// the direct route checks the id.
+constexpr uint32_t ROWS_CHUNKS_PER_WAVE = 4;  // a wave takes 4 consecutive 4096-step chunks (they may belong to several paths)
+
+template <bool SCAN_ONLY>
+__global__ __launch_bounds__(256) void k_rows_build(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
+                                                    const uint64_t *__restrict__ chunk_off, uint32_t n_paths, uint64_t n_chunks,
+                                                    uint32_t n_items, uint32_t n_tiles, uint32_t *__restrict__ rows,
+                                                    const uint32_t *__restrict__ row_base, uint32_t tstride,
+                                                    uint32_t *__restrict__ id_min, uint32_t *__restrict__ id_max) {
+    __shared__ uint32_t win_all[4][ROWS_WIN * 64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t c_first = ((uint64_t)blockIdx.x * 4 + wave) * ROWS_CHUNKS_PER_WAVE;
+    if (c_first >= n_chunks) return;  // whole wave; no workgroup barrier is used
+    const uint64_t c_end = c_first + ROWS_CHUNKS_PER_WAVE < n_chunks ? c_first + ROWS_CHUNKS_PER_WAVE : n_chunks;
+    uint32_t *win = win_all[wave];
+    if (!SCAN_ONLY) {
+#pragma unroll
+        for (int w = 0; w < ROWS_WIN; ++w) win[w * 64 + lane] = 0;
+    }
+    RunChunk ch = chunk_of(c_first, chunk_off, path_off, n_paths);
+    uint32_t path = __builtin_amdgcn_readfirstlane(ch.path);
+    uint64_t path_c_end = chunk_off[path + 1];  // first chunk of the next path
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    auto close_path = [&]() {  // id range of the steps seen on `path`
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (lane == 0) {
+            atomicMin(id_min + path, mn);
+            atomicMax(id_max + path, mx);
+        }
+        mn = 0xFFFFFFFFu;
+        mx = 0u;
+    };
+    for (uint64_t c = c_first; c < c_end; ++c) {
+        if (c != c_first) {
+            if (c >= path_c_end) {  // the next path that has steps
+                close_path();
+                do {
+                    ++path;
+                    path_c_end = chunk_off[path + 1];
+                } while (c >= path_c_end);
+                ch.pstart = path_off[path];
+                ch.start = ch.pstart;
+            } else {
+                ch.start += RUN_CHUNK;
+            }
+            const uint64_t left = path_off[path + 1] - ch.start;
+            ch.len = (uint32_t)(left < RUN_CHUNK ? left : RUN_CHUNK);
+        }
+        const uint32_t base = SCAN_ONLY ? 0u : row_base[path];
+        // how many steps fit one window: the chunk's own id range says how many ids a step advances
+        uint32_t sub = ch.len;
+        uint32_t a = 0, b = 0;
+        if (!SCAN_ONLY) {
+            a = __builtin_amdgcn_readfirstlane(items[ch.start]);
+            b = __builtin_amdgcn_readfirstlane(items[ch.start + ch.len - 1]);
+            const float span = (float)(a > b ? a - b : b - a) + 1.0f;
+            const float room = (float)((ROWS_WIN - 2) * BLOCK_ITEMS);
+            if (span > room) {
+                const uint32_t s = (uint32_t)((float)ch.len * (room / span)) & ~255u;
+                sub = s < 256u ? 256u : s;
+            }
+            sub = __builtin_amdgcn_readfirstlane(sub);
+        }
+        for (uint32_t s0 = 0; s0 < ch.len; s0 += sub) {
+            const uint32_t sl = ch.len - s0 < sub ? ch.len - s0 : sub;
+            const uint64_t first = ch.start + s0;
+            uint32_t t0 = 0;
+            if (!SCAN_ONLY) {
+                // anchor: the tile of the smaller end of the piece, one tile of margin below it
+                uint32_t e0 = a, e1 = b;
+                if (sub != ch.len) {
+                    e0 = __builtin_amdgcn_readfirstlane(items[first]);
+                    e1 = __builtin_amdgcn_readfirstlane(items[first + sl - 1]);
+                }
+                t0 = (e0 < e1 ? e0 : e1) / BLOCK_ITEMS;
+                t0 = t0 ? t0 - 1u : 0u;
+            }
+            const uint32_t id0 = t0 * BLOCK_ITEMS;
+            const uint64_t j_al = first & ~3ull;
+            const uint32_t head = (uint32_t)(first - j_al);  // steps of the first load that belong to the predecessor
+            const uint32_t n_al = head + sl;                 // steps from j_al to the end of the piece
+            for (uint32_t r0 = 0; r0 < n_al; r0 += 256u * ROWS_U) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 v[ROWS_U];
+#pragma unroll
+                for (int u = 0; u < ROWS_U; ++u) {
+                    const uint32_t r = r0 + (uint32_t)u * 256u + lane * 4u;
+                    v[u] = u32x4{0, 0, 0, 0};
+                    if (r < n_al) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(items + j_al + r));
+                }
+#pragma unroll
+                for (int u = 0; u < ROWS_U; ++u) {
+                    const uint32_t r = r0 + (uint32_t)u * 256u + lane * 4u;
+                    const uint32_t ids[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (r + (uint32_t)e - head < sl) {  // unsigned: also false for the steps before the piece
+                            const uint32_t id = ids[e];
+                            mn = id < mn ? id : mn;
+                            mx = id > mx ? id : mx;
+                            if (!SCAN_ONLY) {
+                                const uint32_t n = id - id0;
+                                const uint32_t bit = 1u << ((id >> 6) & 31u);
+                                if (n < (uint32_t)ROWS_WIN * BLOCK_ITEMS)
+                                    atomicOr(&win[(n >> 11) * 64u + (n & 63u)], bit);
+                                else if (id - 1u < n_items)  // outside the window: a path that is not sorted by id
+                                    atomicOr(rows + (uint64_t)(uint32_t)(base + (id >> 11) * tstride) * 64u + (id & 63u), bit);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!SCAN_ONLY) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int w = 0; w < ROWS_WIN; ++w) {
+                    const uint32_t x = win[w * 64 + lane];
+                    if (x) {
+                        win[w * 64 + lane] = 0;
+                        if (t0 + (uint32_t)w < n_tiles)
+                            atomicOr(rows + (uint64_t)(uint32_t)(base + (t0 + (uint32_t)w) * tstride) * 64u + lane, x);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
+    }
+    close_path();
+}
+
+// id range -> (first tile, tiles spanned); an empty path spans nothing
+__global__ void k_rows_spans(const uint32_t *__restrict__ id_min, const uint32_t *__restrict__ id_max, uint32_t n_paths, uint32_t n_items,
+                             uint32_t *__restrict__ tfirst, uint32_t *__restrict__ tspan) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    const uint32_t b = id_max[p] < n_items ? id_max[p] : n_items, a = id_min[p] < b ? id_min[p] : b;  // (a rejected upload may hold anything)
+    const bool some = id_max[p] != 0u;
+    tfirst[p] = some ? a / BLOCK_ITEMS : 0u;
+    tspan[p] = some ? b / BLOCK_ITEMS - a / BLOCK_ITEMS + 1u : 0u;
+}
+
+__global__ void k_rows_iota(uint32_t *__restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// The rows of the resident graph (no-op when they exist).  validate: fail with PNX_EINVAL on ids outside 1..n_items.
+int ensure_rows(pnx_ctx *ctx, bool validate) {
+    if (ctx->rows_valid) return PNX_OK;
+    const uint32_t P = ctx->n_paths;
+    const uint64_t S = ctx->n_steps;
+    const uint32_t n_tiles = ctx->n_blocks;  // a row is one block of 2048 items
+    int rc;
+    const size_t p1 = P ? P : 1;
+    if ((rc = ensure(ctx, ctx->d_id_minmax, 2 * p1 * 4)) || (rc = ensure(ctx, ctx->d_row_base, p1 * 4)) ||
+        (rc = ensure(ctx, ctx->d_rt_first, p1 * 4)) || (rc = ensure(ctx, ctx->d_rt_span, p1 * 4)))
+        return rc;
+    uint32_t *d_min = (uint32_t *)ctx->d_id_minmax.p, *d_max = d_min + p1;
+    hipStream_t st = ctx->stream;
+    PNX_HIP(ctx, hipMemsetAsync(d_min, 0xFF, p1 * 4, st));
+    PNX_HIP(ctx, hipMemsetAsync(d_max, 0, p1 * 4, st));
+    ctx->h_id_minmax.assign(2 * p1, 0);
+    ctx->h_rt_first.assign(P, 0);
+    ctx->h_rt_span.assign(P, 0);
+    uint64_t n_chunks = 0;
+    if (P && S) {
+        if ((rc = ensure_chunk_off(ctx))) return rc;
+        n_chunks = ctx->h_chunk_off[P];
+        if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "too many path chunks");
+    }
+    const uint32_t *items = (const uint32_t *)ctx->d_items.p;
+    const uint64_t *path_off = (const uint64_t *)ctx->d_path_off.p, *chunk_off = (const uint64_t *)ctx->d_chunk_off.p;
+    const uint64_t n_waves = (n_chunks + ROWS_CHUNKS_PER_WAVE - 1) / ROWS_CHUNKS_PER_WAVE;
+    const unsigned grid = (unsigned)((n_waves + 3) / 4);
+    auto spans_from_minmax = [&]() {
+        uint64_t total = 0;
+        uint32_t mx = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t hi = ctx->h_id_minmax[p1 + p], b = std::min(hi, ctx->n_items), a = std::min(ctx->h_id_minmax[p], b);
+            ctx->h_rt_first[p] = hi ? a / BLOCK_ITEMS : 0;
+            ctx->h_rt_span[p] = hi ? b / BLOCK_ITEMS - a / BLOCK_ITEMS + 1 : 0;
+            total += ctx->h_rt_span[p];
+            mx = std::max(mx, ctx->h_rt_span[p]);
+        }
+        ctx->rows_max_span = mx;
+        return total;
+    };
+    auto check_ids = [&]() {  // every id in 1..n_items (the id ranges were taken over ALL steps)
+        if (!validate) return PNX_OK;
+        for (uint32_t p = 0; p < P; ++p)
+            if (ctx->h_id_minmax[p] != 0xFFFFFFFFu && (ctx->h_id_minmax[p] == 0 || ctx->h_id_minmax[p1 + p] > ctx->n_items))
+                return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+        return PNX_OK;
+    };
+
+    // layout: tile-major over all (tile, path) pairs when that table is no larger than the steps it replaces,
+    // else path-major over the tiles every path really spans (thousands of contig paths, each on a few tiles)
+    const uint64_t dense_rows = (uint64_t)P * n_tiles;
+    bool dense = ctx->rows_layout == 1 || (ctx->rows_layout == 0 && dense_rows * 256 <= std::max<uint64_t>(4 * S, 64ull << 20));
+    if (dense_rows >= 0xFFFFFFFFull) dense = false;
+    prof_begin(ctx, PNX_K_INDEX);
+    if (!dense && n_chunks) {
+        // the spans decide the allocation: one extra read of the steps (ids validated, id ranges taken)
+        hipLaunchKernelGGL(k_rows_build<true>, dim3(grid), dim3(256), 0, st, items, path_off, chunk_off, P, n_chunks, ctx->n_items,
+                           n_tiles, (uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, d_min, d_max);
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->h_id_minmax.data(), d_min, 2 * p1 * 4, hipMemcpyDeviceToHost, st));
+        PNX_HIP(ctx, hipStreamSynchronize(st));
+        if ((rc = check_ids())) {
+            prof_end(ctx);
+            return rc;
+        }
+    }
+    uint64_t n_rows;
+    if (dense) {
+        n_rows = dense_rows;
+        ctx->row_tstride = P;
+        if (P) hipLaunchKernelGGL(k_rows_iota, dim3((P + 255) / 256), dim3(256), 0, st, (uint32_t *)ctx->d_row_base.p, P);
+    } else {
+        n_rows = spans_from_minmax();
+        if (n_rows >= 0xFFFFFFFFull) {
+            prof_end(ctx);
+            return ctx->fail(PNX_ELIMIT, "the paths span %llu item tiles in all; at most 2^32-2 are supported", (unsigned long long)n_rows);
+        }
+        ctx->row_tstride = 1;
+        ctx->h_row_base.resize(p1);
+        uint32_t off = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            ctx->h_row_base[p] = off - ctx->h_rt_first[p];  // row(p, t) = base + t, modulo 2^32
+            off += ctx->h_rt_span[p];
+        }
+        if (P) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_row_base.p, ctx->h_row_base.data(), (size_t)P * 4, hipMemcpyHostToDevice, st));
+    }
+    if ((rc = ensure(ctx, ctx->d_rows, n_rows * 256 + 256))) {
+        prof_end(ctx);
+        return rc;
+    }
+    ctx->n_rows = n_rows;
+    if (n_rows) PNX_HIP(ctx, hipMemsetAsync(ctx->d_rows.p, 0, n_rows * 256, st));
+    if (n_chunks) {
+        if (!dense) {  // the scan has filled the id ranges already
+            PNX_HIP(ctx, hipMemsetAsync(d_min, 0xFF, p1 * 4, st));
+            PNX_HIP(ctx, hipMemsetAsync(d_max, 0, p1 * 4, st));
+        }
+        hipLaunchKernelGGL(k_rows_build<false>, dim3(grid), dim3(256), 0, st, items, path_off, chunk_off, P, n_chunks, ctx->n_items,
+                           n_tiles, (uint32_t *)ctx->d_rows.p, (const uint32_t *)ctx->d_row_base.p, ctx->row_tstride, d_min, d_max);
+    }
+    if (P)
+        hipLaunchKernelGGL(k_rows_spans, dim3((P + 255) / 256), dim3(256), 0, st, d_min, d_max, P, ctx->n_items, (uint32_t *)ctx->d_rt_first.p,
+                           (uint32_t *)ctx->d_rt_span.p);
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->h_id_minmax.data(), d_min, 2 * p1 * 4, hipMemcpyDeviceToHost, st));
+    PNX_HIP(ctx, hipStreamSynchronize(st));  // once per upload; the passes read the rows from other streams too
+    if ((rc = check_ids())) return rc;
+    spans_from_minmax();
+    ctx->rows_tile_major = dense;
+    ctx->rows_valid = true;
+    ctx->order_normalized = false;
+    return PNX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// per pass: the rows of the ordered paths laid out in visiting order
+// ------------------------------------------------------------------------------------------
+struct RowOrd {
+    uint32_t *tfirst, *tspan, *base;  // n_ordered each
+    uint32_t *win_lo, *win_hi;        // per 64 entries: the tiles [lo, hi) their paths reach
+};
+
+__global__ void k_rows_order(const uint32_t *__restrict__ ord_path, uint32_t n_ordered, const uint32_t *__restrict__ tfirst,
+                             const uint32_t *__restrict__ tspan, const uint32_t *__restrict__ row_base, RowOrd oi) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+    if (k < n_ordered) {
+        const uint32_t p = ord_path[k];
+        const uint32_t f = tfirst[p], s = tspan[p];
+        oi.tfirst[k] = f;
+        oi.tspan[k] = s;
+        oi.base[k] = row_base[p];
+        if (s) {
+            lo = f;
+            hi = f + s;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && (k >> 6) < (n_ordered + 63) / 64) {
+        oi.win_lo[k >> 6] = lo;
+        oi.win_hi[k >> 6] = hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 over rows
+// ------------------------------------------------------------------------------------------
+struct RowSplit {  // cut points of the visiting order for the split kernel
+    uint32_t k[9];
+};
+
+constexpr int ROWS_D = 8;  // rows in flight per wave and buffer (two buffers)
+
+// One wave owns one item tile (SPLIT > 1: one group-aligned part of the visiting order on one tile; the parts
+// add their counters through LDS at the end).  64 entries of the order sit in the lanes (row index, group);
+// only the entries that have a row in this tile -- or open a group -- are visited (SKIP: only rows, and the
+// 64-entry windows whose band of tiles misses the tile are never loaded).  Rows are fetched ROWS_D at a time
+// into one register buffer while the other is consumed.
+template <int NPL, bool WRITE_M, int CW, int SPLIT, bool SKIP>
+__global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restrict__ rows, uint32_t tstride, RowOrd oi,
+                                                        const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
+                                                        const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
+                                                        uint32_t *__restrict__ M, uint64_t row_words,
+                                                        uint32_t *__restrict__ countable, RowSplit sp) {
+    constexpr int TPW = CW / SPLIT;  // tiles per workgroup
+    static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
+    static_assert(!(SKIP && WRITE_M), "a pass that writes the presence matrix visits every group");
+    __shared__ uint32_t xch[SPLIT > 1 ? TPW * (SPLIT - 1) * NPL * 64 : 1];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t part = SPLIT > 1 ? wave % SPLIT : 0;
+    const uint32_t tile_raw = blockIdx.x * TPW + wave / SPLIT;
+    if (SPLIT == 1 && tile_raw >= n_tiles) return;
+    const bool active = tile_raw < n_tiles;  // SPLIT > 1: idle waves still meet the barrier
+    const uint32_t tile = active ? tile_raw : n_tiles - 1;
+    const uint32_t k_lo = SPLIT > 1 ? (active ? sp.k[part] : 0u) : 0u;
+    const uint32_t k_hi = SPLIT > 1 ? (active ? sp.k[part + 1] : 0u) : n_ordered;
+
+    // exclusion word in presence layout (ActiveTable, src/util.rs:118-124)
+    uint32_t excl = 0;
+    if (exclude) {
+        for (uint32_t b = 0; b < 32; ++b) {
+            const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
+            if (node <= n_items && exclude[node]) excl |= 1u << b;
+        }
+    }
+    // Bit-sliced counters: plane k of lane L holds bit k of the count of the 32 items behind word L.  A group is
+    // not rippled through all planes by itself: eight groups are first compressed by a tree of carry-save adders
+    // (3 inputs -> sum + carry, two 3-input bit operations each) into the three low planes and ONE carry word of
+    // weight 8, which alone ripples through the planes above -- 4 vector instructions per group instead of 3 NPL.
+    uint32_t cnt[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) cnt[k] = 0;
+    uint32_t acc = 0;  // OR of the rows of the current group
+    uint32_t t0 = 0, tA = 0, fA = 0;  // pending: a single group, a carry of weight 2, a carry of weight 4
+    uint32_t nfl = 0;                 // groups folded so far (wave-uniform)
+    auto csa = [](uint32_t &hi, uint32_t &lo, uint32_t a, uint32_t b, uint32_t c) {
+        const uint32_t u = a ^ b;
+        hi = (a & b) | (u & c);
+        lo = u ^ c;
+    };
+    auto ripple = [&](uint32_t carry, int from) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            if (k >= from) {
+                const uint32_t t = cnt[k] & carry;
+                cnt[k] ^= carry;
+                carry = t;
+            }
+        }
+    };
+    auto flush = [&](uint32_t g) {
+        const uint32_t x = acc & ~excl;
+        acc = 0;
+        if (WRITE_M) M[(uint64_t)g * row_words + (uint64_t)tile * BLOCK_WORDS + lane] = x;
+        const uint32_t step = nfl & 7u;
+        ++nfl;
+        if ((step & 1u) == 0u) {
+            t0 = x;
+        } else if (step == 1u || step == 5u) {
+            csa(tA, cnt[0], cnt[0], t0, x);
+        } else {
+            uint32_t tB, fB;
+            csa(tB, cnt[0], cnt[0], t0, x);
+            if (step == 3u) {
+                csa(fA, cnt[1], cnt[1], tA, tB);
+            } else {
+                uint32_t e;
+                csa(fB, cnt[1], cnt[1], tA, tB);
+                csa(e, cnt[2], cnt[2], fA, fB);
+                ripple(e, 3);
+            }
+        }
+    };
+    auto settle = [&]() {  // fold what is still pending after the last group
+        const uint32_t r = nfl & 7u;
+        if (r & 1u) ripple(t0, 0);
+        if (r & 2u) ripple(tA, 1);
+        if (r & 4u) ripple(fA, 2);
+    };
+
+    // ---- window of 64 order entries, one per lane ----
+    uint32_t w_row = NO_ROW, w_g = 0xFFFFFFFFu;
+    uint32_t win_base = k_lo;
+    uint64_t todo = 0;
+    auto load_window = [&](uint32_t base, uint32_t prev_group) {
+        win_base = base;
+        const uint32_t k = base + lane;
+        const bool in = k < k_hi && (!SKIP || k >= k_lo);
+        w_g = in ? ord_group[k] : 0xFFFFFFFFu;
+        w_row = NO_ROW;
+        if (in) {
+            const uint32_t jt = tile - oi.tfirst[k];  // wraps for tiles before the path's first one
+            if (jt < oi.tspan[k]) w_row = oi.base[k] + tile * tstride;
+        }
+        if (SKIP) {
+            todo = __ballot(w_row != NO_ROW);
+        } else {
+            uint32_t pg = __shfl_up(w_g, 1);
+            if (lane == 0) pg = prev_group;
+            todo = __ballot(in && (w_row != NO_ROW || w_g != pg));
+        }
+    };
+    auto seek_window = [&](uint32_t w_from, uint32_t &w_out) {
+        const uint32_t w_end = (k_hi + 63) >> 6;
+        for (uint32_t w = w_from; w < w_end; w += 64) {
+            const uint32_t wi = w + lane;
+            const bool hit = wi < w_end && oi.win_lo[wi] <= tile && tile < oi.win_hi[wi];
+            const unsigned long long hm = __ballot(hit);
+            if (hm) {
+                w_out = w + (uint32_t)__builtin_ctzll(hm);
+                return true;
+            }
+        }
+        return false;
+    };
+    // makes the window hold an entry to visit; false when the part is exhausted
+    auto refill = [&]() {
+        while (todo == 0) {
+            if (SKIP) {
+                uint32_t w;
+                if (!seek_window((win_base >> 6) + 1, w)) return false;
+                load_window(w << 6, 0u);
+                continue;
+            }
+            const uint32_t nb = win_base + 64;
+            if (nb >= k_hi || nb < win_base) return false;
+            load_window(nb, (uint32_t)__builtin_amdgcn_readlane((int)w_g, 63));
+        }
+        return true;
+    };
+    bool more = k_lo < k_hi;
+    if (more) {
+        if (SKIP) {
+            uint32_t w;
+            if (seek_window(k_lo >> 6, w)) load_window(w << 6, 0u);
+            else more = false;
+        } else {
+            load_window(k_lo, 0xFFFFFFFFu);  // the first entry of the part always opens a group
+        }
+    }
+    uint32_t cur_g = 0xFFFFFFFFu;
+    // up to ROWS_D entries of the current window into (v, g): group (0xFFFFFFFF: none) and row words (0: the entry
+    // only opens a group)
+    auto fetch = [&](uint32_t (&v)[ROWS_D], uint32_t (&g)[ROWS_D]) {
+#pragma unroll
+        for (int j = 0; j < ROWS_D; ++j) {
+            v[j] = 0;
+            g[j] = 0xFFFFFFFFu;
+            if (todo) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)w_row, i);
+                g[j] = (uint32_t)__builtin_amdgcn_readlane((int)w_g, i);
+                if (row != NO_ROW) v[j] = __builtin_nontemporal_load(rows + (uint64_t)row * 64u + lane);
+            }
+        }
+    };
+    auto consume = [&](const uint32_t (&v)[ROWS_D], const uint32_t (&g)[ROWS_D]) {
+#pragma unroll
+        for (int j = 0; j < ROWS_D; ++j) {
+            if (g[j] != 0xFFFFFFFFu) {
+                if (g[j] != cur_g) {
+                    if (cur_g != 0xFFFFFFFFu) flush(cur_g);
+                    cur_g = g[j];
+                }
+                acc |= v[j];
+            }
+        }
+    };
+    {
+        uint32_t va[ROWS_D], ga[ROWS_D], vb[ROWS_D], gb[ROWS_D];
+        bool have_a = more && refill();
+        if (have_a) fetch(va, ga);
+        while (have_a) {
+            const bool have_b = refill();
+            if (have_b) fetch(vb, gb);
+            consume(va, ga);
+            if (!have_b) break;
+            have_a = refill();
+            if (have_a) fetch(va, ga);
+            consume(vb, gb);
+        }
+        if (cur_g != 0xFFFFFFFFu) flush(cur_g);
+        settle();
+    }
+
+    if (SPLIT > 1) {
+        // parts 1.. hand their counters to part 0 of the tile
+        uint32_t *xt = xch + (size_t)(wave / SPLIT) * (SPLIT - 1) * NPL * 64;
+        if (part > 0) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) xt[((part - 1) * NPL + k) * 64 + lane] = cnt[k];
+        }
+        __syncthreads();
+        if (part > 0 || !active) return;
+        for (int q = 0; q < SPLIT - 1; ++q) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const uint32_t a = cnt[k], b = xt[(q * NPL + k) * 64 + lane];
+                cnt[k] = a ^ b ^ carry;
+                carry = (a & b) | (carry & (a ^ b));
+            }
+        }
+    }
+    // unpack the bit-sliced counters: one coalesced 256-byte store per bit position
+    for (uint32_t b = 0; b < 32; ++b) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
+        const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
+        // countable[0] is the reference's reserved element (abacus.rs:549-551)
+        if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+    }
+}
+
+// Within a group the order of the paths does not matter for any result, so the paths of every group are put
+// in the order of their first tile once per (graph, order): 64 consecutive entries then reach a narrow band of
+// tiles, and a coverage wave skips the windows whose band misses its tile.
+static int normalize_order_rows(pnx_ctx *ctx) {
+    if (ctx->order_normalized) return PNX_OK;
+    const size_t n = ctx->h_ord_path.size();
+    if (n == ctx->n_ordered && n > 1 && ctx->h_rt_first.size() == ctx->n_paths) {
+        bool changed = false;
+        size_t a = 0;
+        const auto &tf = ctx->h_rt_first;
+        while (a < n) {
+            size_t b = a + 1;
+            while (b < n && ctx->h_ord_group[b] == ctx->h_ord_group[a]) ++b;
+            auto key_less = [&](uint32_t x, uint32_t y) { return tf[x] != tf[y] ? tf[x] < tf[y] : x < y; };
+            if (b - a > 1 && !std::is_sorted(ctx->h_ord_path.begin() + a, ctx->h_ord_path.begin() + b, key_less)) {
+                std::sort(ctx->h_ord_path.begin() + a, ctx->h_ord_path.begin() + b, key_less);
+                changed = true;
+            }
+            a = b;
+        }
+        if (changed) {
+            PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ord_path.p, ctx->h_ord_path.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    ctx->order_normalized = true;
+    return PNX_OK;
+}
+
+template <int NPL>
+static void launch_rows_cover_t(pnx_ctx *ctx, bool write_m) {
+    Ticket *tk = ctx->cur;
+    const RowOrd oi{(uint32_t *)tk->d_ord_tfirst.p, (uint32_t *)tk->d_ord_tspan.p, (uint32_t *)tk->d_ord_off.p,
+                    (uint32_t *)tk->d_win_lo.p, (uint32_t *)tk->d_win_hi.p};
+    const uint64_t row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
+    const uint32_t n_tiles = ctx->n_blocks;
+    RowSplit sp{};
+    auto launch = [&](auto kern, int cw, int split) {
+        const unsigned tpw = (unsigned)(cw / split);
+        const unsigned grid = (n_tiles + tpw - 1) / tpw;
+        for (int j = 0; j <= split; ++j) {  // group-aligned cut points of the visiting order
+            uint64_t t = (uint64_t)ctx->n_ordered * j / split;
+            while (t > 0 && t < ctx->n_ordered && ctx->h_ord_group[t] == ctx->h_ord_group[t - 1]) ++t;
+            sp.k[j] = (uint32_t)t;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->s_main, (const uint32_t *)ctx->d_rows.p, ctx->row_tstride, oi,
+                           (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
+                           ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, n_tiles,
+                           (uint32_t *)ctx->d_M.p, row_words, (uint32_t *)tk->d_countable.p, sp);
+    };
+    const bool skip = !write_m && (ctx->cover_skip == 1 || (ctx->cover_skip == 0 && ctx->n_ordered >= 4096));
+    int split = ctx->cover_split;
+    if (split == 0) {  // enough waves to fill the chip a few times over, and no part shorter than 32 entries
+        const uint64_t want = (uint64_t)ctx->prop.multiProcessorCount * 4 * 8 * 2;
+        split = 1;
+        while (split < 8 && (uint64_t)n_tiles * split < want && (uint32_t)split * 2 <= ctx->n_groups &&
+               ctx->n_ordered / (uint32_t)(split * 2) >= 32)
+            split *= 2;
+    }
+    if ((uint32_t)split > ctx->n_groups) split = 1;
+    auto go = [&](auto k1, auto k2, auto k4, auto k8) {
+        if (split == 2) launch(k2, 4, 2);
+        else if (split == 4) launch(k4, 4, 4);
+        else if (split == 8) launch(k8, 8, 8);
+        else launch(k1, 4, 1);
+    };
+    if (write_m) go(k_rows_cover<NPL, true, 4, 1, false>, k_rows_cover<NPL, true, 4, 2, false>, k_rows_cover<NPL, true, 4, 4, false>, k_rows_cover<NPL, true, 8, 8, false>);
+    else if (skip) go(k_rows_cover<NPL, false, 4, 1, true>, k_rows_cover<NPL, false, 4, 2, true>, k_rows_cover<NPL, false, 4, 4, true>, k_rows_cover<NPL, false, 8, 8, true>);
+    else go(k_rows_cover<NPL, false, 4, 1, false>, k_rows_cover<NPL, false, 4, 2, false>, k_rows_cover<NPL, false, 4, 4, false>, k_rows_cover<NPL, false, 8, 8, false>);
+}
+
+// phases 1 + 2 of a pass over rows (the histogram phase is shared with the step routes: launch_cover_pass)
+int launch_rows_phases(pnx_ctx *ctx, bool write_m) {
+    Ticket *tk = ctx->cur;
+    int rc;
+    if ((rc = normalize_order_rows(ctx))) return rc;
+    const bool phased = ctx->s_pre != ctx->s_main;
+    if (ctx->n_ordered) {
+        prof_begin(ctx, PNX_K_SCATTER, ctx->s_pre);
+        const RowOrd oi{(uint32_t *)tk->d_ord_tfirst.p, (uint32_t *)tk->d_ord_tspan.p, (uint32_t *)tk->d_ord_off.p,
+                        (uint32_t *)tk->d_win_lo.p, (uint32_t *)tk->d_win_hi.p};
+        hipLaunchKernelGGL(k_rows_order, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->s_pre, (const uint32_t *)ctx->d_ord_path.p,
+                           ctx->n_ordered, (const uint32_t *)ctx->d_rt_first.p, (const uint32_t *)ctx->d_rt_span.p,
+                           (const uint32_t *)ctx->d_row_base.p, oi);
+        prof_end(ctx);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    if (phased) {
+        PNX_HIP(ctx, hipEventRecord(tk->ev_pre, ctx->s_pre));
+        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_main, tk->ev_pre, 0));
+    }
+    uint32_t bits = 1;  // planes needed to count up to n_groups inclusive
+    while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;
+    prof_begin(ctx, PNX_K_COVER, ctx->s_main);
+    if (bits <= 8) launch_rows_cover_t<8>(ctx, write_m);
+    else if (bits <= 12) launch_rows_cover_t<12>(ctx, write_m);
+    else if (bits <= 16) launch_rows_cover_t<16>(ctx, write_m);
+    else if (bits <= 24) launch_rows_cover_t<24>(ctx, write_m);
+    else {
+        prof_end(ctx);
+        return ctx->fail(PNX_ELIMIT, "more than 2^24-1 groups are not supported (got %u)", ctx->n_groups);
+    }
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+}  // namespace pnx

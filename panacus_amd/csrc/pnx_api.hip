@@ -1,5 +1,6 @@
 // pnx_api.hip -- extern "C" entry points of libpanacus_hip.so (see include/panacus_amd.h).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -70,8 +71,8 @@ int drain_streams(pnx_ctx *ctx) {
 // which streams the pass being enqueued uses (pnx_context.hpp): three chained ones for a plain
 // histogram pass, one when the pass also writes or merges the presence matrix
 static int choose_pass_streams(pnx_ctx *ctx) {
-    const bool use_m = ctx->want_M || ctx->last_general_paths > 0;
-    const bool phased = ctx->overlap_phases && ctx->cover_variant == 2 && !use_m;
+    const bool use_m = ctx->want_M || (!use_rows(ctx) && ctx->last_general_paths > 0);
+    const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m;
     if (ctx->tk_count && phased != ctx->last_pass_phased) {
         int rc = drain_streams(ctx);  // a pass in flight took the other arrangement: let it finish on the device
         if (rc) return rc;
@@ -132,6 +133,7 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->wplanes_valid = false;
     ctx->wdigits_valid = false;
     ctx->last_general_paths = 0;
+    ctx->rows_valid = false;
 }
 
 static int stage_results(pnx_ctx *ctx, Ticket *t) {
@@ -261,6 +263,9 @@ int pnx_init(pnx_ctx **out, int device) {
         delete ctx;
         return PNX_EHIP;
     }
+    if (const char *v = getenv("PNX_COVER_VARIANT")) {  // default of PNX_CFG_COVER_VARIANT (cross-check runs of a whole host)
+        if (v[0] >= '0' && v[0] <= '3' && v[1] == 0) ctx->cover_variant = v[0] - '0';
+    }
     *out = ctx;
     return PNX_OK;
 }
@@ -278,7 +283,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
-                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
+                      &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
                       &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5]})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
@@ -306,6 +311,8 @@ static void begin_upload(pnx_ctx *ctx) {
     ctx->steps_prepared = false;
     if (ctx->d_steps12.borrowed) release(ctx->d_steps12);
     if (ctx->d_path_mono.borrowed) release(ctx->d_path_mono);
+    for (pnx::DevBuf *b : {&ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span})
+        if (b->borrowed) release(*b);
     if (ctx->d_unsorted.borrowed) {
         release(ctx->d_unsorted);
         release(ctx->d_sorted_coff);
@@ -335,16 +342,20 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
     ctx->n_steps = S;
     set_geometry(ctx);
 
-    // every step id must be a valid item (the reference panics on unknown nodes, util.rs:1021)
+    // every step id must be a valid item (the reference panics on unknown nodes, util.rs:1021).  Over path rows the
+    // check rides on the one read of the steps that builds the rows; a renumbering needs it before it starts.
     if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
-    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
-    if ((rc = launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
-    uint32_t bad = 0;
-    PNX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_flags.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (bad) return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+    if (item_key || !use_rows(ctx)) {
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+        if ((rc = launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
+        uint32_t bad = 0;
+        PNX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_flags.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+    }
     ctx->relabeled = false;
     if (item_key && (rc = relabel_by_keys(ctx, item_key))) return rc;
+    if (use_rows(ctx) && (rc = ensure_rows(ctx, true))) return rc;
     ctx->have_csr = true;
     return PNX_OK;
 }
@@ -548,7 +559,7 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     if (src->d_items.borrowed) return dst->fail(PNX_EINVAL, "pnx_share_csr: the source itself borrows its graph");
     PNX_HIP(dst, hipSetDevice(dst->device));
     // the packed steps and the path classes are derived data of the graph: made once, by the owner
-    if (int prc = prepare_steps(src)) return dst->fail(prc, "pnx_share_csr: %s", src->err.c_str());
+    if (int prc = use_rows(src) ? ensure_rows(src, false) : prepare_steps(src)) return dst->fail(prc, "pnx_share_csr: %s", src->err.c_str());
     PNX_HIP(dst, hipStreamSynchronize(src->stream));  // its upload is complete
     invalidate_results(dst);
     dst->have_csr = false;
@@ -565,7 +576,7 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_exclude, src->d_exclude);
     borrow(dst->d_steps12, src->d_steps12);
     borrow(dst->d_path_mono, src->d_path_mono);
-    dst->steps_prepared = true;
+    dst->steps_prepared = src->steps_prepared;
     borrow(dst->d_unsorted, src->d_unsorted);
     borrow(dst->d_sorted_coff, src->d_sorted_coff);
     borrow(dst->d_sorted_path, src->d_sorted_path);
@@ -582,7 +593,32 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     dst->n_paths = src->n_paths;
     dst->n_steps = src->n_steps;
     set_geometry(dst);
+    if (src->rows_valid) {  // the path rows are derived data of the graph as well
+        borrow(dst->d_rows, src->d_rows);
+        borrow(dst->d_row_base, src->d_row_base);
+        borrow(dst->d_id_minmax, src->d_id_minmax);
+        borrow(dst->d_rt_first, src->d_rt_first);
+        borrow(dst->d_rt_span, src->d_rt_span);
+        dst->h_id_minmax = src->h_id_minmax;
+        dst->h_rt_first = src->h_rt_first;
+        dst->h_rt_span = src->h_rt_span;
+        dst->row_tstride = src->row_tstride;
+        dst->rows_max_span = src->rows_max_span;
+        dst->n_rows = src->n_rows;
+        dst->rows_tile_major = src->rows_tile_major;
+        dst->rows_valid = true;
+    }
     dst->have_csr = true;
+    return PNX_OK;
+}
+
+int pnx_prepare(pnx_ctx *ctx) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_prepare before a graph is resident");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = use_rows(ctx) ? ensure_rows(ctx, false) : prepare_steps(ctx);
+    if (rc) return rc;
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PNX_OK;
 }
 
@@ -668,7 +704,9 @@ int pnx_hist_async(pnx_ctx *ctx) {
     ctx->growth_needs_M = false;
     ctx->cur = &ctx->tk[ctx->tk_next];
     if ((rc = choose_pass_streams(ctx))) return rc;
-    if (!ctx->index_valid || !ctx->cache_index) {
+    if (use_rows(ctx)) {
+        if ((rc = ensure_rows(ctx, false))) return rc;  // once per upload (pnx_set_csr has done it already)
+    } else if (!ctx->index_valid || !ctx->cache_index) {
         // a kept index is shared by the passes: nothing may still be reading it while it is rebuilt
         if (ctx->cache_index && ctx->tk_count && (rc = drain_streams(ctx))) return rc;
         drop_run_index(ctx);  // path classes are reset with the index
@@ -983,7 +1021,12 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_run_paths = ctx->n_run_paths;
     out->n_scatter_paths = ctx->n_scatter_paths;
     out->n_sorted_paths = ctx->n_sorted_paths;
-    out->reserved = 0;
+    out->rows_tile_major = ctx->rows_valid && ctx->rows_tile_major ? 1 : 0;
+    out->n_rows = ctx->rows_valid ? ctx->n_rows : 0;
+    if (use_rows(ctx)) {  // a row is one block of 2048 items, whatever PNX_CFG_TILE_BLOCKS says
+        out->n_tiles = ctx->n_blocks;
+        out->tile_items = BLOCK_ITEMS;
+    }
     out->n_runs = ctx->n_runs;
     out->n_reruns = ctx->n_reruns;
     out->weighted = ctx->weighted ? 1 : 0;
@@ -1022,8 +1065,23 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             ctx->cover_waves = (int)value;
             return PNX_OK;
         case PNX_CFG_COVER_VARIANT:
-            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover variant must be 0, 1 or 2");
+            if (value < 0 || value > 3) return ctx->fail(PNX_EINVAL, "cover variant must be 0, 1, 2 or 3");
+            if ((int)value != ctx->cover_variant && ctx->have_csr) {
+                invalidate_results(ctx);
+                ctx->index_valid = false;
+            }
             ctx->cover_variant = (int)value;
+            return PNX_OK;
+        case PNX_CFG_ROWS_LAYOUT:
+            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows layout must be 0 (auto), 1 (tile-major) or 2 (path-major)");
+            ctx->rows_layout = (int)value;
+            return PNX_OK;
+        case PNX_CFG_DROP_DERIVED:
+            if (ctx->d_rows.borrowed || ctx->d_steps12.borrowed) return ctx->fail(PNX_EINVAL, "this context borrows its graph (pnx_share_csr)");
+            if (ctx->have_csr) invalidate_results(ctx);
+            ctx->rows_valid = false;
+            ctx->index_valid = false;
+            if (ctx->n_sorted_paths == 0) ctx->steps_prepared = false;  // sorted paths stay sorted: their caller order is kept once
             return PNX_OK;
         case PNX_CFG_INDEX_COARSE:
             if (value < 1 || value > 4096) return ctx->fail(PNX_EINVAL, "index_coarse must be in 1..4096");

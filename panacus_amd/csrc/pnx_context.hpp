@@ -128,7 +128,8 @@ struct pnx_ctx {
     int index_by_entry = 0;    // K0 thread numbering: 0 = automatic, 1 = one thread per index entry, 2 = path-major
     int cover_skip = 0;        // window skipping of the coverage kernel: 0 = automatic, 1 = whenever legal, 2 = never
     int cover_split = 0;       // waves per tile of the coverage kernel: 0 = automatic, 1, 2, 4, 8
-    int cover_variant = 2;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads
+    int cover_variant = 3;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads (all three over the
+                               // steps), 3 = over path rows (kernels_rows.hip)
     uint32_t n_blocks = 0, n_tiles = 0;
     bool index_valid = false;
     bool cache_index = true;
@@ -150,6 +151,18 @@ struct pnx_ctx {
     pnx::DevBuf d_path_class;  // n_paths u8: 0 = tile-monotone, 1 = general (scatter route)
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
+
+    // ---- path rows: the path x item presence table (kernels_rows.hip), derived once per upload ----
+    pnx::DevBuf d_rows;       // n_rows x 256 bytes: row (p, t) = the presence bits of path p on item tile t (block layout)
+    pnx::DevBuf d_row_base;   // n_paths u32: row (p, t) sits at row_base[p] + t * row_tstride (modulo 2^32)
+    pnx::DevBuf d_id_minmax;  // 2 x n_paths u32: smallest / largest id on every path
+    pnx::DevBuf d_rt_first, d_rt_span;  // n_paths u32 each: first tile / tiles spanned, from the id range
+    std::vector<uint32_t> h_id_minmax, h_rt_first, h_rt_span, h_row_base;
+    uint32_t row_tstride = 0;   // n_paths: tile-major over all (tile, path) pairs; 1: path-major over the spans
+    uint32_t rows_max_span = 0;
+    uint64_t n_rows = 0;
+    bool rows_valid = false, rows_tile_major = false;
+    int rows_layout = 0;        // PNX_CFG_ROWS_LAYOUT: 0 = chosen from the shape, 1 = tile-major, 2 = path-major
 
     // ---- run index: tile route for non-monotone paths (kernels_runs.hip) ----
     // path_class: 0 tile-monotone (K0 index), 1 not monotone & unclassified, 2 run route, 3 scatter route
@@ -247,6 +260,10 @@ int prepare_steps(pnx_ctx *ctx);  // d_steps12 + d_path_mono (no-op when done)
 int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);  // sorted paths back in the caller's order (pnx_get_csr)
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
+// kernels_rows.hip
+inline bool use_rows(const pnx_ctx *ctx) { return ctx->cover_variant == 3; }
+int ensure_rows(pnx_ctx *ctx, bool validate);          // d_rows & co. (no-op when they exist)
+int launch_rows_phases(pnx_ctx *ctx, bool write_m);    // phases 1 + 2 of a pass over rows
 // kernels_runs.hip
 int ensure_chunk_off(pnx_ctx *ctx);
 int build_run_index(pnx_ctx *ctx);

@@ -181,6 +181,16 @@ def test_hist_ragged_and_empty_paths(ctx):
 
 
 @pytest.fixture
+def route(request, ctx):
+    """PNX_CFG_COVER_VARIANT for one test: 3 = over path rows (the default), 2 = over the packed steps with the
+    boundary index, the run index and the sort of shuffled paths (round 2's default, kept as a cross-check)"""
+    from panacus_amd import capi
+    ctx.config(capi.CFG_COVER_VARIANT, request.param)
+    yield request.param
+    ctx.config(capi.CFG_COVER_VARIANT, 3)
+
+
+@pytest.fixture
 def sort_shuffled(request, ctx):
     """PNX_CFG_SORT_SHUFFLED for one test (1 = default: shuffled paths are sorted by id when the graph is
     prepared; 0: they take the atomic scatter route), restored afterwards on the shared context"""
@@ -190,8 +200,8 @@ def sort_shuffled(request, ctx):
     ctx.config(capi.CFG_SORT_SHUFFLED, 1)
 
 
-@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
-def test_hist_unsorted_paths_sorted_or_on_the_scatter_route(ctx, sort_shuffled):
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+def test_hist_unsorted_paths_sorted_or_on_the_scatter_route(ctx, route, sort_shuffled):
     n, p = 30_000, 10
     items, pre, lens = orc.pansyn(11, n, p)
     rng = np.random.default_rng(5)
@@ -210,12 +220,15 @@ def test_hist_unsorted_paths_sorted_or_on_the_scatter_route(ctx, sort_shuffled):
     ocov, oh = _oracle_hist(items, pre, pi, gi, n, 5)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
-    # the three shuffled paths: sorted once (tile route) or left to the atomic route; the one with a single outlier
-    # is cut into runs either way
-    assert (info.n_sorted_paths, info.n_scatter_paths) == ((3, 0) if sort_shuffled else (0, 3)) and info.n_run_paths == 1
+    if route == 2:
+        # the three shuffled paths: sorted once (tile route) or left to the atomic route; the one with a single outlier
+        # is cut into runs either way
+        assert (info.n_sorted_paths, info.n_scatter_paths) == ((3, 0) if sort_shuffled else (0, 3)) and info.n_run_paths == 1
+        assert ctx.info().n_general_paths == (1 if sort_shuffled else 4)
+    else:  # path rows: no routes, nothing sorted, nothing run again
+        assert (info.n_sorted_paths, info.n_scatter_paths, info.n_run_paths) == (0, 0, 0) and info.n_rows > 0
     got, off, _ = ctx.get_csr()  # the caller's order, whatever the library did with its copy
     assert np.array_equal(got, items.astype(np.uint32)) and np.array_equal(off, pre)
-    assert ctx.info().n_general_paths == (1 if sort_shuffled else 4)
     # second call (classification cached) gives the same answer
     cnt2, h2 = ctx.hist()
     assert np.array_equal(cnt2, ocov) and np.array_equal(h2, oh)
@@ -373,8 +386,8 @@ def test_ordered_growth_many_groups(ctx):
             assert out[r, t].tolist() == [int(x) for x in exp]
 
 
-@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
-def test_growth_after_scatter_route(ctx, sort_shuffled):
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+def test_growth_after_scatter_route(ctx, route, sort_shuffled):
     """edge-like (unsorted) paths: sorted at preparation, or the presence matrix comes from the scatter route"""
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
     n, p = 9000, 8
@@ -425,8 +438,7 @@ def test_properties_large(ctx):
 # ---------------------------------------------------------------------------------------------
 # every kernel variant / index setting gives the same exact answer
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [0, 1, 2])
-@pytest.mark.parametrize("coarse", [1, 3, 8, 64])
+@pytest.mark.parametrize("variant,coarse", [(v, c) for v in (0, 1, 2) for c in (1, 3, 8, 64)] + [(3, 8)])
 def test_variants_agree_with_oracle(ctx, variant, coarse):
     from panacus_amd import capi
     n, p = 150_000, 20
@@ -454,7 +466,7 @@ def test_variants_agree_with_oracle(ctx, variant, coarse):
         cnt, h = ctx.hist()
         assert h.tolist() == [0, 0, 6000] and cnt[1:].tolist() == [2] * 6000
     finally:
-        ctx.config(capi.CFG_COVER_VARIANT, 2)
+        ctx.config(capi.CFG_COVER_VARIANT, 3)
         ctx.config(capi.CFG_INDEX_COARSE, 8)
 
 
@@ -547,7 +559,8 @@ def test_ordered_growth_rule_from_the_presence_matrix(ctx, weighted):
         assert out[r, 0].tolist() == (seen * w[None, :]).sum(axis=1).tolist()
 
 
-def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path):
+@pytest.mark.parametrize("route", [3, 2], indirect=True)
+def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path, route):
     """pnx_set_csr_keyed: edge steps numbered like the reference does (order of the L lines, here
     shuffled) + one key per edge (its canonical ends).  The library renumbers the edges internally on
     the device, so the paths take the tile route instead of the atomic scatter route -- and the
@@ -578,7 +591,7 @@ def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path):
     ctx.set_csr(hitems, hpre, n, exclude=excl)
     ctx.set_order(pi.astype(np.uint32), gi.astype(np.uint32), G)
     cnt_plain, h_plain = ctx.hist()
-    assert ctx.info().n_sorted_paths > 0 and ctx.info().n_scatter_paths == 0
+    assert (ctx.info().n_sorted_paths > 0) == (route == 2) and ctx.info().n_scatter_paths == 0
     back, back_off, _ = ctx.get_csr()
     assert np.array_equal(back, hitems) and np.array_equal(back_off, hpre)
     # with keys: tile route, same answers
@@ -661,7 +674,12 @@ def test_native_rccl_communicator_single_rank(tmp_path):
             c.comm_init(uid, 0, 1)                           # one communicator per context
         c.set_csr(jit.astype(np.uint32), pre, n)
         c.set_order(pi, pi, p)
-        cnt, h = c.hist()                                    # first pass classifies, is re-run: two collectives
+        cnt, h = c.hist()                                    # over path rows: one pass, one collective
+        assert c.info().n_reruns == 0 and np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+        c.config(capi.CFG_COVER_VARIANT, 2)
+        c.set_csr(jit.astype(np.uint32), pre, n)
+        c.set_order(pi, pi, p)
+        cnt, h = c.hist()                                    # over the steps: first pass classifies, is re-run: two collectives
         assert c.info().n_reruns >= 1 and c.info().n_run_paths == p
         assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
         c.hist_async()
@@ -729,14 +747,15 @@ def _jitter(items, pre, paths, rng, width=40, every=300):
     return items
 
 
-@pytest.mark.parametrize("sort_shuffled", [1, 0], indirect=True)
-def test_run_route_near_monotone_paths(ctx, sort_shuffled):
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+def test_run_route_near_monotone_paths(ctx, route, sort_shuffled):
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
     n, p = 120_000, 16
     items, pre, lens = orc.pansyn(41, n, p)
     rng = np.random.default_rng(9)
     items = _jitter(items, pre, [0, 3, 4, 9, 15], rng)
     rng.shuffle(items[pre[6]:pre[7]])  # one path with random ids: scatter route
+    reruns = ctx.info().n_reruns
     ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens)
     pi = np.arange(p, dtype=np.uint64)
     gi = (pi // 2).astype(np.uint64)
@@ -745,8 +764,11 @@ def test_run_route_near_monotone_paths(ctx, sort_shuffled):
     ocov, oh = _oracle_hist(items, pre, pi, gi, n, 8, lens)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
-    assert info.n_run_paths == 5 and info.n_runs > 0
-    assert (info.n_sorted_paths, info.n_scatter_paths) == ((1, 0) if sort_shuffled else (0, 1))
+    if route == 2:
+        assert info.n_run_paths == 5 and info.n_runs > 0
+        assert (info.n_sorted_paths, info.n_scatter_paths) == ((1, 0) if sort_shuffled else (0, 1))
+    else:
+        assert (info.n_run_paths, info.n_runs, info.n_sorted_paths, info.n_scatter_paths, info.n_reruns - reruns) == (0, 0, 0, 0, 0)
     # a different visiting order / grouping re-sorts the runs
     order = pi[::-1].copy()
     g2 = np.arange(p, dtype=np.uint64)
@@ -770,8 +792,8 @@ def test_run_route_near_monotone_paths(ctx, sort_shuffled):
         assert out[0, t].tolist() == [int(x) for x in exp]
 
 
-@pytest.mark.parametrize("tile_blocks", [1, 2])
-def test_run_route_all_paths_and_rebuild(ctx, tile_blocks):
+@pytest.mark.parametrize("route,tile_blocks", [(3, 1), (2, 1), (2, 2)], indirect=["route"])
+def test_run_route_all_paths_and_rebuild(ctx, route, tile_blocks):
     from panacus_amd import capi
     n, p = 50_000, 9
     items, pre, lens = orc.pansyn(43, n, p)
@@ -786,7 +808,7 @@ def test_run_route_all_paths_and_rebuild(ctx, tile_blocks):
         for _ in range(3):
             cnt, h = ctx.hist()
             assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
-        assert ctx.info().n_run_paths == p and ctx.info().n_scatter_paths == 0
+        assert ctx.info().n_run_paths == (p if route == 2 else 0) and ctx.info().n_scatter_paths == 0
         ctx.hist_async()
         ctx.hist_async()
         _, h1 = ctx.hist_fetch()
@@ -1324,7 +1346,8 @@ def test_full_size_cfg4_similarity_against_the_presence_rows():
     assert np.array_equal(inter, exp)
 
 
-def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order():
+@pytest.mark.parametrize("variant", [3, 2])
+def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order(variant):
     """2 M nodes x 32 paths (25 M steps), every path shuffled: the preparation sorts them (no scatter route, no run index),
     the coverage vector equals the one of the unshuffled graph, a second order gives the same, and pnx_get_csr still
     returns the caller's order"""
@@ -1332,6 +1355,7 @@ def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order():
     n, p = 2_000_000, 32
     order = np.arange(p, dtype=np.uint32)
     with capi.Context(0) as c:
+        c.config(capi.CFG_COVER_VARIANT, variant)
         c.set_csr_pansyn(7, n, p)
         c.set_order(order, order // 2, p // 2)
         cnt0, h0 = c.hist()
@@ -1344,7 +1368,7 @@ def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order():
         c.set_order(order, order // 2, p // 2)
         cnt, h = c.hist()
         info = c.info()
-        assert info.n_sorted_paths == p and info.n_scatter_paths == 0 and info.n_run_paths == 0 and info.n_reruns == 0
+        assert info.n_sorted_paths == (p if variant == 2 else 0) and info.n_scatter_paths == 0 and info.n_run_paths == 0 and info.n_reruns == 0
         assert np.array_equal(cnt, cnt0) and np.array_equal(h, h0)
         c.set_order(order[::-1].copy(), (order // 2)[::-1].max() - (order // 2)[::-1], p // 2)
         cnt2, h2 = c.hist()

@@ -563,7 +563,8 @@ def test_multi_gpu_tool_two_ranks_non_monotone_paths(tmp_path):
         procs = []
         for r in range(2):
             e = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                     MASTER_PORT=str(port), PANACUS_DIST_BACKEND="gloo", PANACUS_TOOL_REPORT_RERUNS="1")
+                     MASTER_PORT=str(port), PANACUS_DIST_BACKEND="gloo", PANACUS_TOOL_REPORT_RERUNS="1",
+                     PNX_COVER_VARIANT="2")   # over the steps: the route on which a first pass is run again
             procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "histgrowth_multi_gpu.py"), "-c", cname,
                                            "-l", "1,2", "-q", "0,0.5", "-o", out_file, gfa], env=e,
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE))
