@@ -2,11 +2,16 @@
 """bench.py -- histgrowth throughput of the MI355X hot path (BASELINE.json metric).
 
 One "step" = one full histgrowth pass over one synthetic pangenome resident in HBM:
-  tile index (K0) -> tile coverage (K1) -> histogram (K2) on the GPU, the (G+1)-bin
-  histogram back to the host, then the exact closed-form growth curves (f64, host threads)
-  for the configured (coverage, quorum) pairs -- i.e. `panacus histgrowth -c node -l 1,2,1
-  -q 0,0,0.5` after the GFA has been turned into the CSR.  The tile index is rebuilt in every
-  step (PNX_CFG_CACHE_INDEX = 0), so nothing is cached across the timed passes.
+  rows of the ordered paths laid out in visiting order -> coverage over the path rows (K1) -> histogram (K2)
+  on the GPU, the (G+1)-bin histogram back to the host, then the exact closed-form growth curves (f64, host
+  threads + K7) for the configured (coverage, quorum) pairs -- i.e. `panacus histgrowth -c node -l 1,2,1
+  -q 0,0,0.5` after the GFA has been turned into the CSR.  Resident when the timed region starts: the u32
+  ItemTable and the PATH ROWS that one read of it derives per upload; nothing that depends
+  on the visiting order or on an earlier pass.  What that derivation costs is part of the same JSON line:
+  `cold` = prepare_ms (steps -> rows) and cold_first_pass_ms (resident u32 steps -> first histogram on the host).
+
+`python bench.py --gpus N` launches its N ranks itself (one process per GPU, rendezvous on 127.0.0.1) unless
+RANK / WORLD_SIZE are already in the environment (torch.distributed.run, the driver's way).
 
 Workload at N = 1: BASELINE.json configs[2] ("histgrowth ... on 10M-node / 256-path
 synthetic"), generator pansyn-v1 seed 42.  With --gpus N each rank owns one node-range
@@ -56,42 +61,100 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
-def layout_bytes_hist(S, P, N, G, weighted=False):
-    """What the coverage kernel HAS to move with this library's layout: it streams the packed 12-bit steps
-    (ids modulo 4096, 8 steps per 12 bytes, built once per upload -- DESIGN.md section 3), not the u32 ItemTable."""
-    return 3 * S // 2 + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
+def moved_bytes_hist(rows_in_order, N, G, weighted=False):
+    """What a coverage pass over path rows HAS to move through HBM: the 256-byte rows of the ordered paths on the
+    tiles they span (read once), the coverage vector (written by K1; K2 reads it back, and the weights if bp), the
+    counters.  The steps themselves are not touched by a pass."""
+    return 256 * rows_in_order + 4 * (N + 1) + 8 * (G + 1)
 
 
-ROOFLINE_NOTE = ("achieved / frac follow the contract: SURVEY 8(d)'s ALGORITHMIC bytes (4 B per path step) over the kernel's launch "
-                 "time -- they exceed the HBM peak because the kernel does not read those bytes: it streams a 12-bit-per-step copy "
-                 "of the ItemTable that the library derives once per upload (traffic = the PMC bytes of the committed profile); "
-                 "achieved_on_layout_bytes / frac_on_layout_bytes price the same launch on the bytes this layout has to move")
+ROOFLINE_NOTE = ("frac = achieved / peak on the bytes the timed kernel MOVES (256-byte path rows in, coverage vector out), its "
+                 "launch time measured with HIP events in this run; frac_algorithmic prices the same launch on SURVEY 8(d)'s "
+                 "algorithmic bytes (4 B per path step) -- it exceeds 1 because a pass over path rows does not read the steps: "
+                 "they are read ONCE per upload, by the kernel that derives the rows (see `cold`: that read is priced there, "
+                 "on the same algorithmic bytes).  traffic = HBM bytes of the same kernel from rocprofv3 PMC passes driven by "
+                 "this run (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; gfx950 reports half of wide streaming reads)")
 
 
-PMC_ROUND = "r02"
+def pmc_leg(argv_child, kernels, counters_sets, timeout=240):
+    """HBM / SQ counters of the named kernels, measured by THIS run: one child `bench.py` per counter set under
+    `rocprofv3 --kernel-trace --pmc ...` (counter passes only -- no trace domains mixed in), per-launch averages read
+    from the rocpd database.  Returns ({kernel: {counter: avg}}, note); ({}, why) when rocprofv3 is unusable."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    out = {}
+    tmp_root = tempfile.mkdtemp(prefix="pnx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PANACUS_BENCH_CHILD="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        for i, cs in enumerate(counters_sets):
+            d = os.path.join(tmp_root, f"p{i}")
+            cmd = [exe, "--kernel-trace", "--pmc"] + cs + ["-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + argv_child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return out, f"rocprofv3 pass {cs} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-300:]}"
+            db = sqlite3.connect(dbs[0])
+            agg = {}
+            for kname, cname, val in db.execute("select kernel_name, counter_name, value from counters_collection"):
+                for want in kernels:
+                    if want in kname:
+                        a = agg.setdefault((want, cname), [0, 0.0])
+                        a[0] += 1
+                        a[1] += val
+            db.close()
+            for (want, cname), (n, tot) in agg.items():
+                out.setdefault(want, {})[cname] = tot / n
+                out[want]["launches_" + cname] = n
+    except Exception as e:  # profiling is evidence, not the measurement
+        return out, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp_root, ignore_errors=True)
+    return out, "measured by this run: rocprofv3 --kernel-trace --pmc passes over child runs of this script on the same workload"
 
 
-def pmc_traffic_from_profiles(nodes, paths):
-    """HBM bytes per k_tile_cover launch REPLAYED from the committed rocprofv3 PMC summaries
-    (profiles/, separate --pmc FETCH_SIZE / WRITE_SIZE passes on this same workload) -- counters
-    cannot be read from inside this process, so this is a cross-reference, not a measurement of
-    this run (`traffic_source` says so).  gfx950 reports half of the bytes of wide streaming
-    reads, hence 2 x FETCH_SIZE."""
-    if (nodes, paths) != (10_000_000, 256):
-        return None, None
-    vals = {}
-    rnd = PMC_ROUND if os.path.exists(os.path.join(ROOT, "profiles", f"{PMC_ROUND}_hist_cfg3_pmc_FETCH_SIZE.csv")) else "r01"
-    for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_hist_cfg3_pmc_{name}.csv")
-        if not os.path.exists(path):
-            return None, None
-        for line in open(path):
-            if "k_tile_cover" in line and f",{name}," in line:
-                vals[name] = float(line.rsplit(",", 2)[1])
-    if len(vals) != 2:
-        return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
-        f"replayed from the committed profiles/{rnd}_hist_cfg3_pmc_{{FETCH,WRITE}}_SIZE.csv (2*FETCH_SIZE + WRITE_SIZE, KiB), not measured in this run"
+def launch_ranks(n, force_dist):
+    """`bench.py --gpus N` without a launcher: start the N ranks (one process per GPU), hand them RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*, pass rank 0's stdout through.  Fails loudly when fewer than N devices are visible."""
+    import ctypes
+    import socket
+    import subprocess
+    have = -1
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        cnt = ctypes.c_int(0)
+        if hip.hipGetDeviceCount(ctypes.byref(cnt)) == 0:
+            have = cnt.value
+    except OSError:
+        pass
+    if have < 0:
+        import torch
+        have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible to this process -- nothing was measured")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PANACUS_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if force_dist:
+            env["PANACUS_BENCH_FORCE_DIST"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
 
 
 def cpu_baseline(ctx, n_nodes, n_paths, pairs, seed=42, passes=3, sample_nodes=None):
@@ -184,8 +247,19 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         torch.cuda.synchronize()
         ctx.sync()
 
-    # presence matrix (K0, K1 with the row stores, K2): built once per rank, then resident
-    ctx.hist(want_countable=False)   # first call: allocations, index spans
+    # what every rank has to derive before it can evaluate an order: the path rows (one read of the steps) ...
+    ctx.prepare()                    # first call: allocations
+    prep = []
+    for _ in range(3):
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        sync_all()
+        t0 = time.perf_counter()
+        ctx.prepare()
+        prep.append(time.perf_counter() - t0)
+    prepare_s = sorted(prep)[len(prep) // 2]
+    ctx.set_order(order, order, P)
+    # ... and the presence matrix of the groups (K1 over the rows with the row stores, K2): built once per rank, then resident
+    ctx.hist(want_countable=False)   # first call: allocations
     ctx.profile_enable(True)
     ctx.profile_reset()
     sync_all()
@@ -293,7 +367,7 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         n_words = (N + 1 + 63) // 64
         b_growth = R * (8 * P * n_words + 8 * T * P)       # SURVEY 8(d), all R orders
         b_pack = 4 * int(info.n_steps) + 8 * P * n_words
-        b_pack_layout = 3 * int(info.n_steps) // 2 + 8 * P * n_words  # packed 12-bit steps in, presence rows out
+        b_pack_layout = 256 * int(info.n_rows_in_order) + 8 * P * n_words + 4 * (N + 1)  # path rows in; presence rows + coverage vector out
         cover_ms = pk["cover"][0] / max(pk["cover"][1], 1)
         out = {
             "workload": f"ordered-histgrowth -c node -l 1,2,1 -q 0,0,0.5 over {R} random group orders (pansyn stream 7, seed "
@@ -309,11 +383,14 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
             "allreduce_ms": ar_ms,
             "collective_path": ("none (one rank)" if not use_dist else "rccl through the library's own communicator (pnx_comm_allreduce_u64) on pnx_stream()"
                                 if args.collective == "native" else "rccl via torch.distributed (nccl backend) on pnx_stream()"),
+            "prepare_ms": prepare_s * 1e3,
             "presence_pack_ms": pack_s * 1e3, "presence_pack_cover_kernel_ms": cover_ms,
-            "presence_pack_algorithmic_bytes": b_pack, "presence_pack_layout_bytes": b_pack_layout,
-            "presence_pack_cover_kernel_GBps_on_layout_bytes": b_pack_layout / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
-            "presence_pack_cover_kernel_GBps": b_pack / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
-            "seconds_per_call_incl_pack": dt + pack_s, "speedup_vs_1_incl_pack": (t1 + pack_s) / (dt + pack_s),
+            "presence_pack_algorithmic_bytes": b_pack, "presence_pack_moved_bytes": b_pack_layout,
+            "presence_pack_cover_kernel_GBps_on_moved_bytes": b_pack_layout / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
+            # a COLD call: every rank derives the rows and packs the presence matrix itself (replicated work: it does not scale)
+            "seconds_per_call_incl_pack": dt + pack_s + prepare_s,
+            "speedup_vs_1_incl_pack": (t1 + pack_s + prepare_s) / (dt + pack_s + prepare_s),
+            "incl_pack_note": "incl_pack = prepare (steps -> path rows) + presence pack + the growth call, all replicated on every rank",
             "algorithmic_bytes": b_growth, "algorithmic_GBps": b_growth / dt / 1e9,
             "steps_in_csr": int(info.n_steps),
             "similarity_intersections": sim,
@@ -324,6 +401,29 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         torch.cuda.synchronize()
     ctx.close()
     return out
+
+
+def cold_numbers(ctx, order, G, reps=3):
+    """What an upload costs before its first histogram: prepare_ms = the steps resident in HBM -> path rows (one read of
+    the steps, synchronous); cold_first_pass_ms = the same + the first pass + its histogram on the host (pnx_hist on a
+    graph whose derived data were dropped).  Medians of `reps` runs on a warm context (buffers exist)."""
+    from panacus_amd import capi
+    ctx.sync()
+    prep, cold = [], []
+    for _ in range(reps):
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        t0 = time.perf_counter()
+        ctx.prepare()
+        prep.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(reps):
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        ctx.set_order(order, order, G)
+        t0 = time.perf_counter()
+        ctx.hist(want_countable=False)
+        cold.append((time.perf_counter() - t0) * 1e3)
+    info = ctx.info()
+    return {"prepare_ms": sorted(prep)[reps // 2], "cold_first_pass_ms": sorted(cold)[reps // 2],
+            "rows": int(info.n_rows), "rows_bytes": 256 * int(info.n_rows), "rows_tile_major": bool(info.rows_tile_major)}
 
 
 def shape_1k_block(args, local_rank):
@@ -344,17 +444,26 @@ def shape_1k_block(args, local_rank):
     if not args.no_quorum_offload:
         hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
 
+    on_device = offload and hostlib.device_growth_usable()
+
+    def enqueue():
+        """one pass; with the whole closed forms on the device, the curves follow it there (the histogram does not
+        visit the host in between)"""
+        ctx.hist_async()
+        return hostlib.calc_growths_begin_on_device(P, thr) if on_device else None
+
     def run(n):
         h = growths = None
+        queue = []
         enq = 0
         for _ in range(min(n, 2)):
-            ctx.hist_async()
+            queue.append(enqueue())
             enq += 1
         for _ in range(n):
             _, h = ctx.hist_fetch(want_countable=False)
-            pending = hostlib.calc_growths_begin(h, thr, args.growth_threads)
+            pending = queue.pop(0) or hostlib.calc_growths_begin(h, thr, args.growth_threads)
             if enq < n:
-                ctx.hist_async()
+                queue.append(enqueue())
                 enq += 1
             growths = hostlib.calc_growths_end(pending)
         return h, growths
@@ -379,11 +488,12 @@ def shape_1k_block(args, local_rank):
     info = ctx.info()
     S = int(info.n_steps)
     B = algorithmic_bytes_hist(S, P, N, P)
-    B_layout = layout_bytes_hist(S, P, N, P)
+    B_layout = moved_bytes_hist(int(info.n_rows_in_order), N, P)
     cover_beside_ms = cover[0] / max(cover[1], 1)
     cover_ms = tail["cover"][0] / max(tail["cover"][1], 1)
-    index_ms = tail["index"][0] / max(tail["index"][1], 1)
+    index_ms = tail["scatter"][0] / max(tail["scatter"][1], 1)
     hist_ms = tail["hist"][0] / max(tail["hist"][1], 1)
+    cold = cold_numbers(ctx, order, P)
     if int(h.sum()) != N:
         raise SystemExit(f"shape_10Mx1k: histogram sums to {int(h.sum())}, expected {N}")
     hostlib.set_quorum_offload(None)
@@ -391,16 +501,18 @@ def shape_1k_block(args, local_rank):
     return {
         "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 seed {args.seed}, {N} nodes x {P} paths (north_star's shape)",
         "steps": steps, "ms_per_step": dt * 1e3, "value": N * P / dt / 1e6, "unit": "M node*paths/s",
-        "steps_in_csr": S, "algorithmic_bytes_per_pass": B, "layout_bytes_per_pass": B_layout,
-        "breakdown_ms": {"tile_index": index_ms, "tile_cover": cover_ms, "hist": hist_ms,
+        "steps_in_csr": S, "algorithmic_bytes_per_pass": B, "moved_bytes_per_pass": B_layout,
+        "cold": cold,
+        "breakdown_ms": {"rows_order": index_ms, "rows_cover": cover_ms, "hist": hist_ms,
                          "device_total": index_ms + cover_ms + hist_ms,
-                         "tile_cover_beside_the_other_phases": cover_beside_ms,
-                         "quorum_inner_sums_on_gpu": bool(offload and hostlib.quorum_offload_usable())},
-        "roofline_frac_tile_cover": B / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
-        "roofline_frac_device_pass": B / ((index_ms + cover_ms + hist_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "roofline_frac_whole_step": B / dt / 1e9 / HBM_PEAK_GBS,
-        "frac_on_layout_bytes_tile_cover": B_layout / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
-        "frac_on_layout_bytes_whole_step": B_layout / dt / 1e9 / HBM_PEAK_GBS,
+                         "rows_cover_beside_the_other_phases": cover_beside_ms,
+                         "quorum_inner_sums_on_gpu": bool(offload and hostlib.quorum_offload_usable()),
+                         "closed_forms_on_gpu": bool(on_device)},
+        "roofline_frac_rows_cover": B_layout / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
+        "roofline_frac_whole_step": B_layout / dt / 1e9 / HBM_PEAK_GBS,
+        "frac_algorithmic_rows_cover": B / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
+        "frac_algorithmic_whole_step": B / dt / 1e9 / HBM_PEAK_GBS,
+        "frac_algorithmic_cold_first_pass": B / (cold["cold_first_pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "checks": {"hist_sum": int(h.sum()), "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
     }
 
@@ -443,15 +555,25 @@ def main():
                     help="run the three phases of a pass (index | coverage kernel | histogram) on one stream instead of three")
     ap.add_argument("--no-quorum-offload", action="store_true")
     ap.add_argument("--quorum-offload-min-n", type=int, default=256)
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 counter passes (child runs of this script) that measure roofline.traffic and roofline_valu")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-path block (prepare_ms, cold_first_pass_ms)")
+    ap.add_argument("--rows-layout", type=int, default=None)
     args = ap.parse_args()
+
+    force_dist = os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or force_dist):
+        launch_ranks(args.gpus, force_dist)  # does not return
 
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if torch.cuda.is_available() and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) visible")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: panacus_amd has no CPU fallback")
     blocking = world > 1 or os.environ.get("PANACUS_BENCH_BLOCKING") == "1"
@@ -501,6 +623,8 @@ def main():
             c.config(capi.CFG_COVER_SPLIT, args.cover_split)
         if args.cover_variant is not None:
             c.config(capi.CFG_COVER_VARIANT, args.cover_variant)
+        if args.rows_layout is not None:
+            c.config(capi.CFG_ROWS_LAYOUT, args.rows_layout)
         if owner is None:
             c.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
         else:
@@ -518,6 +642,7 @@ def main():
             self.ctx = ctx
             self.group = group
             self.hist_views = {}
+            self.pending = []  # closed forms enqueued behind the passes in flight (None: the host starts them when it has the histogram)
             self.native = use_dist and args.collective == "native"
             if self.native:
                 # the library reduces flags + histogram behind every pass by itself (pnx_comm_init): the lane
@@ -538,6 +663,11 @@ def main():
         def enqueue(self):
             ctx = self.ctx
             ctx.hist_async()
+            if growth_on_device and self.ctx is all_lanes[0].ctx and (not use_dist or self.native):
+                # the closed forms follow the pass on the device, from its own (all-reduced) counters
+                self.pending.append(hostlib.calc_growths_begin_on_device(P, thr))
+            else:
+                self.pending.append(None)
             if use_dist and not self.native:
                 # the collective follows the counters on the stream of the pass's histogram phase: the coverage
                 # kernel of the next pass is not held back
@@ -587,17 +717,33 @@ def main():
 
     n_lanes = max(1, args.lanes)
     ctx = make_context()
-    all_lanes = lanes = [Lane(ctx, None)]
+    growth_on_device = False  # set below, once the offload context is known
+    all_lanes = lanes = []
+    lanes.append(Lane(ctx, None))
     for _ in range(1, n_lanes):
         # every lane has its own communicator: its collectives are ordered on its own stream
         lanes.append(Lane(make_context(ctx), dist.new_group() if use_dist else None))
+    S = int(ctx.info().n_steps)
+    try:
+        n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        clock_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6
+    except Exception:
+        n_cus, clock_ghz = 256, 2.4
+    # ---- the cold path of an upload, measured before anything else is resident: steps -> path rows, and the first histogram
+    cold = None
+    if not args.no_cold:
+        ctx.hist(want_countable=False)  # allocations, code objects
+        cold = cold_numbers(ctx, np.arange(P, dtype=np.uint32), P)
+    else:
+        ctx.prepare()
     info = ctx.info()
-    S = int(info.n_steps)
+    rows_in_order = int(info.n_rows_in_order)
 
     # large group counts: the O(n^3) inner sums of the quorum closed form run on the GPU
     # (bit-identical, see csrc/kernels_closed_form.hip); below 512 groups the host is faster
     if rank == 0 and not args.no_quorum_offload:
         hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
+        growth_on_device = P >= args.quorum_offload_min_n and P <= 2048 and hostlib.device_growth_usable()
 
     def growth_begin(h):
         """rank 0: set the closed forms up and enqueue their device part (if any) behind the pass
@@ -621,7 +767,7 @@ def main():
             enqueued += 1
         for k in range(n_steps):
             h = lanes[k % L].settle()
-            pending = growth_begin(h)
+            pending = lanes[k % L].pending.pop(0) or growth_begin(h)
             if enqueued < n_steps:
                 lanes[enqueued % L].enqueue()
                 enqueued += 1
@@ -688,16 +834,57 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * N * P / (dt / args.steps) / 1e6
         cover_ms, cover_n = prof["cover"]
-        index_ms, index_n = prof_tail["index"]
+        index_ms, index_n = prof_tail["scatter"]   # k_rows_order: the rows of the ordered paths in visiting order
         hist_ms, hist_n = prof_tail["hist"]
         cover_avg_ms = cover_ms / max(cover_n, 1)
         B = algorithmic_bytes_hist(S, P, N, P)
-        B_layout = layout_bytes_hist(S, P, N, P)
-        achieved = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
-        achieved_layout = B_layout / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
+        B_moved = moved_bytes_hist(rows_in_order, N, P)
+        achieved_alg = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
+        achieved = B_moved / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
         cover_alone_ms = prof_tail["cover"][0] / max(prof_tail["cover"][1], 1)
         device_ms = cover_alone_ms + index_ms / max(index_n, 1) + hist_ms / max(hist_n, 1)
-        traffic, traffic_src = pmc_traffic_from_profiles(N, P)
+        if cold is not None:
+            # a pass that kept nothing would read the steps every time; the cheapest full read of the steps measured here is the
+            # derivation itself, so: prepare + k * step <= k * prepare  <=>  k >= prepare / (prepare - step)
+            cold["value_cold_first_pass"] = world * N * P / (cold["cold_first_pass_ms"] * 1e-3) / 1e6
+            cold["frac_algorithmic_cold_first_pass"] = B / (cold["cold_first_pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            cold["frac_algorithmic_prepare"] = 4 * S / (cold["prepare_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            cold["passes_to_break_even"] = (int(np.ceil(cold["prepare_ms"] / (cold["prepare_ms"] - ms_per_step)))
+                                            if cold["prepare_ms"] > ms_per_step else None)
+            cold["note"] = ("prepare_ms: the u32 steps resident in HBM -> path rows (one read of the steps, ids validated on the way), "
+                            "synchronous; cold_first_pass_ms: pnx_hist on a graph whose derived data were dropped = prepare + one pass + "
+                            "the histogram on the host; frac_algorithmic_*: SURVEY 8(d)'s algorithmic bytes over those times -- the read "
+                            "of the steps is priced HERE, not in `roofline`; passes_to_break_even: against re-reading the steps in "
+                            "every pass, taking the derivation itself as the cheapest full read of the steps")
+        # counters of the dominant kernel (and of the kernel that derives the rows), measured by child runs under rocprofv3
+        traffic = traffic_src = None
+        valu = None
+        cold_traffic = None
+        if world == 1 and not args.no_pmc and os.environ.get("PANACUS_BENCH_CHILD") != "1":
+            child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--nodes", str(N), "--paths", str(P), "--seed", str(args.seed),
+                     "--no-permuted-growth", "--no-shape-1k", "--no-cpu-baseline", "--no-pmc"]
+            for flag, val in (("--cover-split", args.cover_split), ("--rows-layout", args.rows_layout), ("--cover-variant", args.cover_variant)):
+                if val is not None:
+                    child += [flag, str(val)]
+            pm, traffic_src = pmc_leg(child, ["k_rows_cover", "k_rows_build<false>"], [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]])
+            kc = pm.get("k_rows_cover", {})
+            if "FETCH_SIZE" in kc and "WRITE_SIZE" in kc:
+                traffic = (2.0 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024.0
+            if "SQ_INSTS_VALU" in kc:
+                # a wave64 vector instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md): peak = CUs x 4 SIMDs x clock / 2
+                peak_wi = n_cus * 4 * clock_ghz * 1e9 / 2.0
+                wi = kc["SQ_INSTS_VALU"]
+                valu = {"bound": "valu", "kernel": "k_rows_cover", "wave_instructions_per_launch": wi,
+                        "achieved": wi / (cover_avg_ms * 1e-3), "peak": peak_wi, "unit": "wave64 VALU instr/s", "frac": wi / (cover_avg_ms * 1e-3) / peak_wi,
+                        "scalar_instructions_per_launch": kc.get("SQ_INSTS_SALU"), "lds_instructions_per_launch": kc.get("SQ_INSTS_LDS"),
+                        "per_row": wi * 64 / max(rows_in_order, 1) / 64, "compute_units": n_cus, "clock_ghz": clock_ghz}
+            kb = pm.get("k_rows_build<false>", {})
+            if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
+                cold_traffic = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+                if cold is not None:
+                    cold["build_kernel_traffic_bytes"] = cold_traffic
+                    cold["build_kernel_valu_wave_instructions"] = kb.get("SQ_INSTS_VALU")
+                    cold["build_kernel_lds_instructions"] = kb.get("SQ_INSTS_LDS")
         out = {
             "metric": "histgrowth_throughput",
             "value": value,
@@ -721,37 +908,39 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_tile_cover",
+                "kernel": "k_rows_cover",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": B,
+                "moved_bytes_per_launch": B_moved,
                 "avg_launch_ms": cover_avg_ms,
                 "launches": cover_n,
-                "layout_bytes_per_launch": B_layout,
-                "achieved_on_layout_bytes": achieved_layout,
-                "frac_on_layout_bytes": achieved_layout / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": B,
+                "achieved_algorithmic": achieved_alg,
+                "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
                 "avg_launch_ms_alone": cover_alone_ms,
-                "note": ROOFLINE_NOTE + "; avg_launch_ms is measured over the timed steps, where the index of the next pass and the "
-                        "histogram of the previous one run beside the kernel on their own streams; avg_launch_ms_alone is the same "
+                "note": ROOFLINE_NOTE + "; avg_launch_ms is measured over the timed steps, where the order layout of the next pass and "
+                        "the histogram of the previous one run beside the kernel on their own streams; avg_launch_ms_alone is the same "
                         "kernel with the phases on one stream (5 extra passes)",
             },
+            "roofline_valu": valu,
+            "cold": cold,
             "breakdown_ms": {
-                "tile_index": index_ms / max(index_n, 1), "tile_cover": cover_alone_ms,
+                "rows_order": index_ms / max(index_n, 1), "rows_cover": cover_alone_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
-                "tile_cover_beside_the_other_phases": cover_avg_ms,
+                "rows_cover_beside_the_other_phases": cover_avg_ms,
                 "lanes": len(lanes),
                 "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
                 "quorum_inner_sums_on_gpu": bool(not args.no_quorum_offload and P >= args.quorum_offload_min_n
                                                  and hostlib.quorum_offload_usable()),
+                "closed_forms_on_gpu": bool(growth_on_device),
                 "single_pass_latency": latency_ms,
             },
-            "hbm_gbs_whole_device_pass": B / (device_ms * 1e-3) / 1e9 if device_ms > 0 else 0.0,
+            "hbm_gbs_whole_step_moved_bytes": B_moved / (ms_per_step * 1e-3) / 1e9,
             "hbm_gbs_whole_step_algorithmic": B / (ms_per_step * 1e-3) / 1e9,
-            "hbm_gbs_whole_step_layout_bytes": B_layout / (ms_per_step * 1e-3) / 1e9,
             "checks": {"hist_sum": int(h.sum()), "expected_hist_sum": world * N,
                        "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
         }

@@ -326,9 +326,29 @@ int pnx_quorum_sums(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quor
 int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum, const double *log2_tab,
                           const double *m_fact, const double *n_fall);
 int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q);
-/* y[k] = exp2(x[k]) with the device restatement of libm's exp2 (test hook: bit-equality with
- * the host libm is what the quorum offload rests on) */
+/* y[k] = exp2(x[k]) / log2(x[k]) with the device restatements of libm's exp2 and log2 (test hooks: bit-equality with
+ * the host libm is what the closed forms on the device rest on) */
 int pnx_exp2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
+int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
+
+/* ---- closed-form growth on the device, from the histogram to the curve (row a7) ---------------------------
+ * Replaces Hist::calc_growth_union / calc_growth_core / calc_growth_quorum (src/graph_broker/hist.rs:89-187) for
+ * n_pairs threshold pairs of one histogram: f64 throughout, every log2 / exp2 / addition in the reference's order
+ * (restatements of the platform libm's log2 and exp2: csrc/log2_exact.hpp, csrc/exp2_exact.hpp; the caller checks them
+ * against its own libm first -- the host library does).  The caller resolves what is not arithmetic (Hist::calc_growth,
+ * hist.rs:51-66): per pair the branch, cov_abs = max(1, coverage.to_absolute(n)) (core: of n + 1, hist.rs:118) and
+ * quorum_rel = quorum.to_relative(n) (quorum branch only).
+ *   hist   n+1 bins on the host, or NULL: the device counters of the coverage pass enqueued LAST (n must be the number of
+ *          groups) -- the curves then follow the pass without the histogram ever visiting the host
+ *   out    n_pairs x n values: out[t*n + m-1] = growth at m groups (the reference's vector without its leading NaN)
+ * _async enqueues the work on a stream of its own (inputs are copied before it returns); up to TWO calls may be in flight;
+ * _fetch waits for the OLDEST one. */
+enum { PNX_GROWTH_UNION = 0, PNX_GROWTH_CORE = 1, PNX_GROWTH_QUORUM = 2 };
+#define PNX_GROWTH_MAX_N 2048
+#define PNX_GROWTH_MAX_PAIRS 16
+int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,
+                                 const uint32_t *cov_abs, const double *quorum_rel);
+int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of the kernels, recorded on the context's own stream.  Slots: */
@@ -425,6 +445,7 @@ typedef struct {
     uint32_t n_sorted_paths; /* paths whose steps were sorted by id at preparation (PNX_CFG_SORT_SHUFFLED) */
     uint32_t rows_tile_major;/* layout of the path rows: 1 tile-major over all (tile, path) pairs, 0 path-major over the spans */
     uint64_t n_rows;         /* path rows resident (256 bytes each; 0 until they are derived) */
+    uint64_t n_rows_in_order;/* rows one pass over the current visiting order reads (sum of the tile spans of its paths) */
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         L.orc_ordered_growth.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_int, C.c_double,
                                          C.c_int, C.c_double, u32p, f64p]
         L.orc_exp2.argtypes = [f64p, f64p, C.c_uint64]
+        L.orc_log2.argtypes = [f64p, f64p, C.c_uint64]
         L.orc_similarity.restype = C.c_int
         L.orc_similarity.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, u32p, u64p, u64p,
                                      C.POINTER(C.c_float)]
@@ -333,6 +334,14 @@ def exp2(x) -> np.ndarray:
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.zeros_like(x)
     lib().orc_exp2(_p(x, C.c_double), _p(y, C.c_double), x.size)
+    return y
+
+
+def log2(x) -> np.ndarray:
+    """libm log2 (numpy's own log2 is a different implementation)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_log2(_p(x, C.c_double), _p(y, C.c_double), x.size)
     return y
 
 

@@ -2347,6 +2347,10 @@ void orc_exp2(const double *x, double *y, uint64_t n) {
     for (uint64_t k = 0; k < n; k++) y[k] = exp2(x[k]);
 }
 
+void orc_log2(const double *x, double *y, uint64_t n) {
+    for (uint64_t k = 0; k < n; ++k) y[k] = log2(x[k]);
+}
+
 /* ------------------------------------------------------------------------------------ */
 uint64_t pansyn_splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ULL;

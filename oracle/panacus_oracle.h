@@ -153,6 +153,8 @@ int orc_table_row_values(const uint64_t *r, const uint64_t *c, const uint32_t *v
 
 /* y[k] = exp2(x[k]) with the platform libm -- what Rust's f64::exp2 calls (hist.rs:104,131,175,179) */
 void orc_exp2(const double *x, double *y, uint64_t n);
+/* y[k] = log2(x[k]) with the platform libm -- what Rust's f64::log2 calls (hist.rs:28-32,100-106,171-179) */
+void orc_log2(const double *x, double *y, uint64_t n);
 
 /* ---- synthetic pangenome generator pansyn-v1 (DESIGN.md section "pansyn-v1") ---- */
 uint64_t pansyn_splitmix64(uint64_t x);

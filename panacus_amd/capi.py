@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
+    "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch",
 ]
 
 
@@ -45,7 +46,7 @@ class PnxInfo(C.Structure):
                 ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32),
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
                 ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("rows_tile_major", C.c_uint32),
-                ("n_rows", C.c_uint64)]
+                ("n_rows", C.c_uint64), ("n_rows_in_order", C.c_uint64)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
@@ -126,6 +127,9 @@ def load() -> C.CDLL:
     f64p = C.POINTER(C.c_double)
     L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
     L.pnx_exp2_exact.argtypes = [vp, f64p, f64p, C.c_uint64]
+    L.pnx_log2_exact.argtypes = [vp, f64p, f64p, C.c_uint64]
+    L.pnx_growth_closed_form_async.argtypes = [vp, u64p, C.c_uint32, C.c_uint32, u32p, u32p, f64p]
+    L.pnx_growth_closed_form_fetch.argtypes = [vp, f64p]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
     L.pnx_profile_select.argtypes = [vp, C.c_uint32]
     L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
@@ -466,6 +470,27 @@ class Context:
         return y
 
     # ---- measurement / tunables ----
+    def log2_exact(self, x) -> np.ndarray:
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(a)
+        self._ck(self._L.pnx_log2_exact(self._h, _ptr(a, C.c_double), _ptr(y, C.c_double), len(a)))
+        return y
+
+    def growth_closed_form_async(self, hist, n, branch, cov_abs, quorum_rel):
+        """pnx_growth_closed_form_async; hist None = the counters of the pass enqueued last"""
+        h = None if hist is None else np.ascontiguousarray(hist, dtype=np.uint64)
+        br = np.ascontiguousarray(branch, dtype=np.uint32)
+        cv = np.ascontiguousarray(cov_abs, dtype=np.uint32)
+        q = np.ascontiguousarray(quorum_rel, dtype=np.float64)
+        self._ck(self._L.pnx_growth_closed_form_async(self._h, _ptr(h, C.c_uint64), n, len(br), _ptr(br, C.c_uint32), _ptr(cv, C.c_uint32),
+                                                      _ptr(q, C.c_double)))
+        return (len(br), n)
+
+    def growth_closed_form_fetch(self, shape) -> np.ndarray:
+        out = np.zeros(shape, dtype=np.float64)
+        self._ck(self._L.pnx_growth_closed_form_fetch(self._h, _ptr(out, C.c_double)))
+        return out
+
     def profile_enable(self, on=True):
         self._ck(self._L.pnx_profile_enable(self._h, int(on)))
 

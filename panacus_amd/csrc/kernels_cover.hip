@@ -1586,6 +1586,10 @@ int launch_cover_pass(pnx_ctx *ctx) {
     // ---- phase 1 (s_pre, behind this pass's K0 if it has one): counters cleared, the index of the
     // ordered paths laid out in visiting order
     // flags, histogram and per-group "general" marks of this pass: one clear
+    if (tk->has_reader) {
+        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_pre, tk->ev_reader, 0));
+        tk->has_reader = false;
+    }
     PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
 
     if (rows) {

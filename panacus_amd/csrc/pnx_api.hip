@@ -288,11 +288,22 @@ void pnx_free(pnx_ctx *ctx) {
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
+    for (auto &g : ctx->gslot) {
+        if (g.stream) (void)hipStreamSynchronize(g.stream);
+        if (g.h_io) (void)hipHostFree(g.h_io);
+        if (g.done) (void)hipEventDestroy(g.done);
+        for (DevBuf &b : g.d_gc) release(b);
+        release(g.d_terms);
+        release(g.d_sum);
+        release(g.d_io);
+        if (g.stream) (void)hipStreamDestroy(g.stream);
+    }
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);
         if (t.done) (void)hipEventDestroy(t.done);
         if (t.ev_pre) (void)hipEventDestroy(t.ev_pre);
         if (t.ev_cov) (void)hipEventDestroy(t.ev_cov);
+        if (t.ev_reader) (void)hipEventDestroy(t.ev_reader);
         for (DevBuf *b : {&t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own})
             release(*b);
     }
@@ -1023,6 +1034,9 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_sorted_paths = ctx->n_sorted_paths;
     out->rows_tile_major = ctx->rows_valid && ctx->rows_tile_major ? 1 : 0;
     out->n_rows = ctx->rows_valid ? ctx->n_rows : 0;
+    out->n_rows_in_order = 0;
+    if (ctx->rows_valid && ctx->have_order && ctx->h_rt_span.size() == ctx->n_paths)
+        for (uint32_t k = 0; k < ctx->n_ordered; ++k) out->n_rows_in_order += ctx->h_rt_span[ctx->h_ord_path[k]];
     if (use_rows(ctx)) {  // a row is one block of 2048 items, whatever PNX_CFG_TILE_BLOCKS says
         out->n_tiles = ctx->n_blocks;
         out->tile_items = BLOCK_ITEMS;

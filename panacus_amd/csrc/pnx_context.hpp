@@ -55,6 +55,8 @@ struct Ticket {
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
+    hipEvent_t ev_reader = nullptr;  // a closed-form call copied the counters out of d_block (pnx_growth_closed_form_async):
+    bool has_reader = false;         // the next pass on this ticket clears the block only after that copy
     // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
     // time the pass is settled): it merged the scatter rows of M / it wrote the presence matrix
     bool used_m = false, wrote_m = false;
@@ -215,6 +217,21 @@ struct pnx_ctx {
     size_t h_cf_cap = 0;
     hipEvent_t ev_cf = nullptr;
     bool cf_pending = false;
+    // ---- whole closed forms on the device (pnx_growth_closed_form_*): two slots, each with its own stream and scratch, so
+    // that the (latency-bound) kernel chains of two calls in flight run beside each other ----
+    struct GrowthSlot {
+        hipStream_t stream = nullptr;
+        pnx::DevBuf d_gc[8];       // log2 tables, per-pair running sums, term arrays
+        pnx::DevBuf d_terms, d_sum;  // quorum branch: terms of the inner sums, the sums
+        pnx::DevBuf d_io;          // [pairs | hist] in, out[T][n] behind them
+        void *h_io = nullptr;      // pinned mirror
+        size_t h_cap = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+        uint32_t n = 0, n_pairs = 0;
+        size_t out_off = 0;
+    } gslot[2];
+    int gslot_next = 0, gslot_oldest = 0, gslot_count = 0;
 
     // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----
     void *comm = nullptr;          // ncclComm_t

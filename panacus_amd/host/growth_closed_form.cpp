@@ -22,12 +22,16 @@
 
 #include "../csrc/exp2_exact.hpp"
 #include "thread_pool.hpp"
+#include "../csrc/log2_exact.hpp"
 
 // libpanacus_hip (include/panacus_amd.h); declared here so that this file needs no HIP headers
 struct pnx_ctx;
 extern "C" int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum,
                                      const double *log2_tab, const double *m_fact, const double *n_fall);
 extern "C" int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q);
+extern "C" int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,
+                                            const uint32_t *cov_abs, const double *quorum_rel);
+extern "C" int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out);
 
 namespace pnh {
 
@@ -115,6 +119,39 @@ bool exp2_restatement_matches_libm() {
             }
             const double a = pnx_exp2::exp2_exact(x, EXP2_TAB), b = std::exp2(x);
             if (std::memcmp(&a, &b, sizeof a) != 0) return false;
+        }
+        return true;
+    }();
+    return ok;
+}
+
+const uint64_t LOG2_TAB[274] = {
+#include "../csrc/log2_table.inc"
+};
+
+// the same for log2 (csrc/log2_exact.hpp; its table comes out of the image's libm, tools/gen_log2_table.py): with both
+// restatements confirmed the WHOLE closed form can run on the device (pnx_growth_closed_form_*)
+bool log2_restatement_matches_libm() {
+    static const bool ok = []() {
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < 400000; ++k) {
+            s ^= s << 13;
+            s ^= s >> 7;
+            s ^= s << 17;
+            double x;
+            uint64_t u;
+            switch (k & 7) {
+                case 0: u = s & 0x7FFFFFFFFFFFFFFFull; std::memcpy(&x, &u, 8); break;        // any non-negative bit pattern
+                case 1: x = (double)(s >> 40); break;                                          // histogram bins, small integers
+                case 2: x = (double)(s >> 11); break;
+                case 3: x = 1.0 + ((double)(int64_t)(s >> 11) - 4503599627370496.0) * 0x1p-57; break;  // around 1
+                case 4: u = (s & 0x000FFFFFFFFFFFFFull) | ((uint64_t)(1023 - 60 + (s >> 58) * 2) << 52); std::memcpy(&x, &u, 8); break;
+                case 5: u = s & 0x000FFFFFFFFFFFFFull; std::memcpy(&x, &u, 8); break;          // subnormal sums
+                case 6: x = (double)(k >> 3); break;
+                default: u = (s & 0x000FFFFFFFFFFFFFull) | 0x3FE0000000000000ull; std::memcpy(&x, &u, 8); break;
+            }
+            const double a = pnx_exp2::log2_exact(x, LOG2_TAB), b = std::log2(x);
+            if (std::memcmp(&a, &b, sizeof a) != 0 && !(a != a && b != b)) return false;
         }
         return true;
     }();
@@ -478,35 +515,99 @@ void release_quorum_offload(void *pnx_context) {
 }
 
 bool quorum_offload_usable() { return exp2_restatement_matches_libm(); }
+bool device_growth_usable() { return exp2_restatement_matches_libm() && log2_restatement_matches_libm(); }
+void log2_restated(const double *x, double *y, uint64_t n) {
+    for (uint64_t k = 0; k < n; ++k) y[k] = pnx_exp2::log2_exact(x[k], LOG2_TAB);
+}
 
 struct GrowthRun {
     std::vector<uint64_t> hist;  // the jobs refer to it
+    std::vector<Threshold> coverage, quorum;
     std::vector<std::unique_ptr<Job>> jobs;
     size_t n_pairs = 0;
+    uint64_t n = 0;
     unsigned n_threads = 0;
     Offload off;
+    pnx_ctx *dev = nullptr;  // the whole closed form was enqueued on this context (pnx_growth_closed_form_async)
 };
+
+namespace {
+void host_jobs(GrowthRun &run) {
+    auto tab = std::make_shared<Log2Table>(2 * run.n + 2);
+    for (size_t t = 0; t < run.n_pairs; ++t)
+        run.jobs.emplace_back(new Job(dispatch(run.n, run.quorum[t]), run.hist, run.coverage[t], run.quorum[t], tab));
+}
+
+// Whole closed forms on the device: with a context set (set_quorum_offload), both libm restatements confirmed, and n
+// in the range the device path takes.  hist == nullptr: the counters of the context's last coverage pass.
+bool start_device_growth(GrowthRun &run, const uint64_t *hist) {
+    pnx_ctx *ctx = nullptr;
+    uint64_t min_n = 0;
+    {
+        std::lock_guard<std::mutex> g(g_offload_mu);
+        ctx = g_offload_ctx;
+        min_n = g_offload_min_n;
+    }
+    const uint64_t n = run.n;
+    if (!ctx || n < min_n || n < 2 || n > 2048 || run.n_pairs == 0 || run.n_pairs > 16 || !device_growth_usable()) return false;
+    std::vector<uint32_t> br(run.n_pairs), cv(run.n_pairs);
+    std::vector<double> qr(run.n_pairs, 0.0);
+    for (size_t t = 0; t < run.n_pairs; ++t) {
+        const Branch b = dispatch(n, run.quorum[t]);  // Hist::calc_growth, hist.rs:51-66
+        br[t] = b == UNION ? 0u : (b == CORE ? 1u : 2u);
+        cv[t] = (uint32_t)std::max<uint64_t>(1, run.coverage[t].to_absolute(b == CORE ? n + 1 : n));  // hist.rs:91, :118, :142
+        if (b == QUORUM) qr[t] = run.quorum[t].to_relative(n);
+    }
+    if (pnx_growth_closed_form_async(ctx, hist, (uint32_t)n, (uint32_t)run.n_pairs, br.data(), cv.data(), qr.data()) != 0) return false;
+    run.dev = ctx;
+    return true;
+}
+}  // namespace
 
 GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::vector<Threshold> &coverage,
                                   const std::vector<Threshold> &quorum, unsigned n_threads) {
     std::unique_ptr<GrowthRun> run(new GrowthRun);
     run->hist = hist;
+    run->coverage = coverage;
+    run->quorum = quorum;
     run->n_pairs = coverage.size();
     run->n_threads = n_threads;
     if (hist.size() >= 2) {
-        const uint64_t n = hist.size() - 1;
-        auto tab = std::make_shared<Log2Table>(2 * n + 2);
-        for (size_t t = 0; t < coverage.size(); ++t)
-            run->jobs.emplace_back(new Job(dispatch(n, quorum[t]), run->hist, coverage[t], quorum[t], tab));
-        run->off = start_offload(run->jobs);
+        run->n = hist.size() - 1;
+        if (!start_device_growth(*run, run->hist.data())) {
+            host_jobs(*run);
+            run->off = start_offload(run->jobs);
+        }
     }
+    return run.release();
+}
+
+// the curves of the histogram of the coverage pass enqueued LAST on the offload context (n groups), without the histogram
+// visiting the host; nullptr when the device path cannot take it (the caller then fetches the histogram and uses _begin)
+GrowthRun *calc_all_growths_begin_on_device(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum) {
+    std::unique_ptr<GrowthRun> run(new GrowthRun);
+    run->coverage = coverage;
+    run->quorum = quorum;
+    run->n_pairs = coverage.size();
+    run->n = n;
+    if (!start_device_growth(*run, nullptr)) return nullptr;
     return run.release();
 }
 
 std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *handle) {
     std::unique_ptr<GrowthRun> run(handle);
     if (!run) return {};
-    if (run->hist.size() < 2) return std::vector<std::vector<double>>(run->n_pairs);
+    if (run->n < 1) return std::vector<std::vector<double>>(run->n_pairs);
+    if (run->dev) {
+        std::vector<double> flat(run->n_pairs * run->n);
+        if (pnx_growth_closed_form_fetch(run->dev, flat.data()) == 0) {
+            std::vector<std::vector<double>> out(run->n_pairs);
+            for (size_t t = 0; t < run->n_pairs; ++t) out[t].assign(flat.begin() + t * run->n, flat.begin() + (t + 1) * run->n);
+            return out;
+        }
+        if (run->hist.size() < 2) return std::vector<std::vector<double>>(run->n_pairs);  // no histogram on the host to fall back on
+        host_jobs(*run);  // a device error: the host path
+    }
     finish_offload(run->off, run->jobs);
     return run_jobs(run->jobs, run->n_threads);
 }

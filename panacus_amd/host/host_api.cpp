@@ -272,6 +272,7 @@ void *pnh_calc_all_growths_begin(const uint64_t *hist, uint64_t hist_len, const 
         cov.push_back(pnh::Threshold{cov_kind[t], cov_val[t]});
         quo.push_back(pnh::Threshold{quo_kind[t], quo_val[t]});
     }
+    if (!hist && hist_len >= 2) return pnh::calc_all_growths_begin_on_device(hist_len - 1, cov, quo);  // the device's own counters
     return pnh::calc_all_growths_begin(h, cov, quo, n_threads);
 }
 int64_t pnh_calc_all_growths_end(void *handle, uint64_t n, uint32_t n_pairs, double *out) {
@@ -342,6 +343,9 @@ uint32_t pnh_usable_cpus(void) { return pnh::ThreadPool::usable_cpus(); }
 // quorum closed form: inner sums on the GPU of `pnx_context` for n >= min_n (NULL = host only)
 void pnh_set_quorum_offload(void *pnx_context, uint64_t min_n) { pnh::set_quorum_offload(pnx_context, min_n); }
 int pnh_quorum_offload_usable(void) { return pnh::quorum_offload_usable() ? 1 : 0; }
+int pnh_device_growth_usable(void) { return pnh::device_growth_usable() ? 1 : 0; }
+// y[k] = log2(x[k]) by the restatement of libm's log2 (csrc/log2_exact.hpp), on the host: what the self-test compares
+void pnh_log2_restated(const double *x, double *y, uint64_t n) { pnh::log2_restated(x, y, n); }
 
 double pnh_choose_log2(uint64_t n, uint64_t k) { return pnh::choose_log2(n, k); }
 

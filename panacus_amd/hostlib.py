@@ -89,6 +89,23 @@ def calc_growths_begin(hist, pairs, n_threads: int = 0):
     return (handle, T, max(len(h) - 1, 0))
 
 
+def calc_growths_begin_on_device(n_groups: int, pairs):
+    """The curves of the histogram of the coverage pass enqueued LAST on the offload context (set_quorum_offload),
+    computed on the device without the histogram visiting the host.  None when the device path cannot take it (no
+    context, libm restatements not confirmed, n out of range): fetch the histogram and use calc_growths_begin."""
+    L = load()
+    L.pnh_calc_all_growths_begin.restype = C.c_void_p
+    L.pnh_calc_all_growths_begin.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32, C.c_uint]
+    T = len(pairs)
+    ck = (C.c_int * T)(*[c.kind for c, _ in pairs])
+    cv = (C.c_double * T)(*[float(c.value) for c, _ in pairs])
+    qk = (C.c_int * T)(*[q.kind for _, q in pairs])
+    qv = (C.c_double * T)(*[float(q.value) for _, q in pairs])
+    handle = L.pnh_calc_all_growths_begin(None, n_groups + 1, ck, cv, qk, qv, T, 0)
+    return (handle, T, n_groups) if handle else None
+
+
 def calc_growths_end(pending):
     """Second half: waits for the device part, finishes on the host threads. -> list of curves"""
     handle, T, n = pending
@@ -432,6 +449,24 @@ def set_quorum_offload(ctx=None, min_n: int = 256):
     L = load()
     L.pnh_set_quorum_offload.argtypes = [C.c_void_p, C.c_uint64]
     L.pnh_set_quorum_offload(None if ctx is None else ctx._h, int(min_n))
+
+
+def device_growth_usable() -> bool:
+    """True iff the restated log2 and exp2 both reproduce this platform's libm bit for bit (whole closed forms may then
+    run on the device)"""
+    L = load()
+    return bool(L.pnh_device_growth_usable())
+
+
+def log2_restated(x) -> np.ndarray:
+    """log2 by the restatement of libm's algorithm (csrc/log2_exact.hpp) on the host"""
+    L = load()
+    L.pnh_log2_restated.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64]
+    L.pnh_log2_restated.restype = None
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(a)
+    L.pnh_log2_restated(a.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double)), len(a))
+    return y
 
 
 def quorum_offload_usable() -> bool:

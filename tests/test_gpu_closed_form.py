@@ -100,3 +100,89 @@ def test_cli_histgrowth_many_groups_uses_the_offload(tmp_path):
     for k, (c, q) in enumerate(((1, 0.5), (2, 0.1))):
         exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
         assert [r[2 + k] for r in rows[5:]] == [hl.format_f64(math.floor(x)) for x in exp], (c, q)
+
+
+def _log2_arguments():
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 2**63, size=1_000_000, dtype=np.uint64)
+    near1 = 1.0 + (rng.random(500_000) - 0.5) * 2.0 ** -4
+    return np.concatenate([
+        bits.view(np.float64),                                            # any non-negative bit pattern: subnormals, inf, NaN
+        rng.integers(0, 2**24, size=500_000).astype(np.float64),          # histogram bins, small integers
+        rng.integers(0, 2**53, size=500_000).astype(np.float64),
+        near1, np.exp2(2000.0 * rng.random(500_000) - 1000.0),            # the sums of the quorum branch
+        np.arange(0, 5000, dtype=np.float64),
+        np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                  1.0 - float.fromhex('0x1.5b51p-5'), 1.0 + float.fromhex('0x1.6ab2p-5'), np.nextafter(1.0, 0), np.nextafter(1.0, 2)])])
+
+
+def test_device_log2_equals_libm_bitwise(ctx):
+    from panacus_amd import hostlib
+    assert hostlib.device_growth_usable()
+    x = _log2_arguments()
+    exp = orc.log2(x)
+    for got in (ctx.log2_exact(x), hostlib.log2_restated(x)):
+        nan_both = np.isnan(got) & np.isnan(exp)
+        bad = np.flatnonzero((got.view(np.uint64) != exp.view(np.uint64)) & ~nan_both)
+        assert bad.size == 0, (x[bad[:5]], got[bad[:5]], exp[bad[:5]])
+
+
+@pytest.mark.parametrize("n", [2, 5, 44, 130, 256, 301])
+def test_whole_closed_forms_on_the_device_bitwise(ctx, n):
+    """pnx_growth_closed_form: union, core and quorum curves from the histogram to the value on the device == the serial
+    restatement of hist.rs:89-187 == the host path, bit for bit; also straight from the counters of a coverage pass"""
+    from panacus_amd import hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    rng = np.random.default_rng(100 + n)
+    h = rng.integers(0, 10**7, size=n + 1).astype(np.uint64)
+    h[rng.integers(0, n + 1, size=2)] = 0
+    pairs = [(1, 0.5), (0, 0.1), (2, 0.9), (max(1, n // 3), 0.3), (1, 2.0 / n), (1, 0.0), (2, 0.0), (1, 1.0), (3, 1.0), (n + 5, 0.0),
+             (n, 0.5), (1, 0.999)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    host_only = hostlib.calc_growths(h, thr)
+    hostlib.set_quorum_offload(ctx, min_n=1)
+    try:
+        pending = hostlib.calc_growths_begin(h, thr)
+        pending2 = hostlib.calc_growths_begin(h[::-1].copy(), thr[:3])   # two calls in flight
+        got = hostlib.calc_growths_end(pending)
+        got2 = hostlib.calc_growths_end(pending2)
+    finally:
+        hostlib.set_quorum_offload(None)
+    for (c, q), a, b in zip(pairs, got, host_only):
+        exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+        assert a.tobytes() == exp.tobytes(), (n, c, q)
+        assert b.tobytes() == exp.tobytes(), (n, c, q)
+    for (c, q), a in zip(pairs[:3], got2):
+        assert a.tobytes() == orc.growth(h[::-1].copy(), (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes()
+
+
+def test_closed_forms_follow_the_pass_on_the_device(ctx):
+    """hist == NULL: the curves are computed from the device counters of the pass enqueued last, two passes in flight"""
+    from panacus_amd import hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    n, p = 200_000, 96
+    items, pre, _ = orc.pansyn(13, n, p)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5), (1, 1.0)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    ctx.set_csr_pansyn(13, n, p)
+    hostlib.set_quorum_offload(ctx, min_n=1)
+    try:
+        orders = [(np.arange(p, dtype=np.uint32), np.arange(p, dtype=np.uint32), p),
+                  (np.arange(p, dtype=np.uint32), (np.arange(p) // 3).astype(np.uint32), p // 3)]
+        for pi, gi, G in orders:
+            ctx.set_order(pi, gi, G)
+            ctx.hist_async()
+            g1 = hostlib.calc_growths_begin_on_device(G, thr)
+            ctx.hist_async()
+            g2 = hostlib.calc_growths_begin_on_device(G, thr)
+            assert g1 is not None and g2 is not None
+            _, h1 = ctx.hist_fetch()
+            _, h2 = ctx.hist_fetch()
+            c1, c2 = hostlib.calc_growths_end(g1), hostlib.calc_growths_end(g2)
+            oh = orc.hist(orc.coverage(items, pre, pi.astype(np.uint64), gi.astype(np.uint64), n), G)
+            assert np.array_equal(h1, oh) and np.array_equal(h2, oh)
+            for (c, q), a, b in zip(pairs, c1, c2):
+                exp = orc.growth(oh, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+                assert a.tobytes() == exp.tobytes() and b.tobytes() == exp.tobytes(), (G, c, q)
+    finally:
+        hostlib.set_quorum_offload(None)

@@ -1094,14 +1094,16 @@ def test_bench_contract_line_small(tmp_path):
     small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--cpu-passes", "1",
              "--pg-nodes", "150000", "--pg-paths", "40", "--pg-orders", "10", "--pg-reps", "2",
              "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4"]
-    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {}),
-                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k"], {"PANACUS_BENCH_FORCE_DIST": "1"}),
-                       (["--lanes", "1", "--no-cpu-baseline", "--no-shape-1k", "--collective", "native"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
+    # FORCE_DIST without RANK / WORLD_SIZE in the environment: bench.py launches its rank(s) itself (the --gpus N path)
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {}),
+                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {"PANACUS_BENCH_FORCE_DIST": "1"}),
+                       (["--lanes", "1", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc", "--collective", "native"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
         sock = socket.socket()
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
         sock.close()
-        e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
+        e = dict(clean, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env)
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + small + extra, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, env=e, timeout=900)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
@@ -1113,6 +1115,14 @@ def test_bench_contract_line_small(tmp_path):
             assert k in d, k
         assert d["steps"] == 12 and d["n_gpus"] == 1 and d["roofline"]["launches"] == 12
         assert d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 200000
+        rf, cold = d["roofline"], d["cold"]
+        assert rf["kernel"] == "k_rows_cover" and 0 < rf["frac"] < 1 and rf["moved_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["frac_algorithmic"] > rf["frac"]
+        assert cold["prepare_ms"] > 0 and cold["cold_first_pass_ms"] > cold["prepare_ms"] and cold["rows"] > 0
+        if "--no-pmc" not in extra:   # the counter passes are driven by the run itself; on a box without rocprofv3 the line says why
+            assert (rf["traffic"] is not None and rf["traffic"] > 0 and d["roofline_valu"]["frac"] > 0) or "rocprofv3" in rf["traffic_source"], rf["traffic_source"]
+        else:
+            assert rf["traffic"] is None and d["roofline_valu"] is None
         pg = d["permuted_growth"]
         for k in ("seconds_per_call", "orders_per_s", "speedup_vs_1", "growth_kernel_ms_rank_max", "allreduce_ms",
                   "presence_pack_ms", "scaling", "sharding", "n_gpus"):
@@ -1126,11 +1136,18 @@ def test_bench_contract_line_small(tmp_path):
         if "--no-cpu-baseline" not in extra:
             cb, k1 = d["cpu_baseline"], d["shape_10Mx1k"]
             assert cb["agrees_with_gpu"] is True and cb["kind"] == "port" and cb["cores"] == 3 and cb["value"] > 0
-            assert k1["checks"]["hist_sum"] == 150000 and k1["breakdown_ms"]["tile_cover"] > 0
+            assert k1["checks"]["hist_sum"] == 150000 and k1["breakdown_ms"]["rows_cover"] > 0 and k1["cold"]["prepare_ms"] > 0
         outs.append(d["checks"])
         pgs.append(pg["checks"])
     assert outs[0] == outs[1] == outs[2] == outs[3]
     assert pgs[0] == pgs[1] == pgs[2] == pgs[3]
+    # more ranks than devices: a clear failure, not a silent single-GPU run
+    import torch
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(want)] + small, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=clean, timeout=300)
+    assert r.returncode != 0 and f"--gpus {want}" in r.stderr.decode() and "device(s) visible" in r.stderr.decode()
+    assert not [l for l in r.stdout.decode().split("\n") if l.startswith("{")]
 
 
 def test_full_size_cfg3_properties():

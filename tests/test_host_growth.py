@@ -68,3 +68,20 @@ def test_exp2_restatement_matches_this_libm():
     """the device path of the quorum closed form rests on this; on a libm with another exp2 the
     library detects it and stays on the host"""
     assert hostlib.quorum_offload_usable()
+
+
+def test_log2_restatement_matches_libm_bitwise():
+    """csrc/log2_exact.hpp (the restated glibc log2, table from tools/gen_log2_table.py) against the platform libm: what
+    lets whole closed forms run on the device (hostlib.device_growth_usable is the run-time form of this test)"""
+    import oracle as orc
+    from panacus_amd import hostlib
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.integers(0, 2**63, size=400_000, dtype=np.uint64).view(np.float64),
+                        rng.integers(0, 2**30, size=200_000).astype(np.float64),
+                        1.0 + (rng.random(200_000) - 0.5) * 2.0 ** -4,
+                        np.exp2(2000.0 * rng.random(200_000) - 1000.0),
+                        np.array([0.0, 1.0, np.inf, 5e-324, 2.2250738585072014e-308, np.nextafter(1.0, 0), np.nextafter(1.0, 2)])])
+    got, exp = hostlib.log2_restated(x), orc.log2(x)
+    both_nan = np.isnan(got) & np.isnan(exp)
+    assert not ((got.view(np.uint64) != exp.view(np.uint64)) & ~both_nan).any()
+    assert hostlib.device_growth_usable()
