@@ -149,8 +149,13 @@ typedef struct pnx_piece_event {
     uint8_t kind, flagged, pad[2];
 } pnx_piece_event;
 /* weights / item_key as in pnx_set_csr_keyed.  events may be NULL when cap == 0; *n_events receives the
- * number of events found (> cap: PNX_ELIMIT, nothing installed).  The exclusion flags are always
- * installed when exc_off != NULL. */
+ * number of events found (> cap: PNX_ELIMIT).  The exclusion flags are always installed when exc_off != NULL.
+ * Interval contract (checked, PNX_EINVAL): within a path the rows are sorted by start and every row starts BEYOND the
+ * end of its predecessor -- touching rows such as [0,5) [5,10) must be merged by the caller, as GraphMask's interval
+ * sets do; a row with start > end is accepted as it is (it acts, as in the reference, only on a node that holds both
+ * ends) and then only its start is compared with its neighbours.  The first row of a path has no predecessor.
+ * Any failure after the arguments were accepted (PNX_ELIMIT: more events than cap / than the library's own tables hold,
+ * PNX_ENOMEM, PNX_EHIP, a step pair without an edge) leaves the context WITHOUT a resident graph: upload again. */
 int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *walks, const uint32_t *weights, const uint64_t *item_key,
                     pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
 /* Replace the weights of the resident graph (n_items+1 values, caller ids): bp growth under a subset list
@@ -259,8 +264,9 @@ int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
  * permuted-growth call do) and the only exchange is an all-reduce (sum) of small u64 counter arrays
  * over xGMI.  Rank 0 calls pnx_comm_unique_id and the HOST carries the 128 bytes to the other
  * processes (file, pipe, MPI, ...); then every rank calls pnx_comm_init(id, rank, world).  From then on
- *   - every coverage pass of the context is followed, on pnx_stream() and before its counters are
- *     copied to the host, by an all-reduce of its verification flags and histogram: pnx_hist,
+ *   - every coverage pass of the context is followed, on the stream of its histogram phase (pnx_hist_enqueued_on; that
+ *     is pnx_stream() only with PNX_CFG_OVERLAP_PHASES off) and before its counters are copied to the host, by an
+ *     all-reduce of its verification flags and histogram: pnx_hist,
  *     pnx_hist_fetch, pnx_hist_device return the GLOBAL histogram, and a pass that has to be run again
  *     (paths that are not tile-monotone) is run again by EVERY rank, so the collectives stay matched.
  *     Every rank therefore makes the same sequence of pnx_hist* calls.  countable stays local (it is the
@@ -268,12 +274,19 @@ int pnx_ordered_growth_fetch(pnx_ctx *ctx, uint64_t *out);
  *     orders instead of the items);
  *   - pnx_comm_allreduce_u64 sums any device buffer in place over the ranks, enqueued on pnx_stream():
  *     e.g. the buffer of pnx_ordered_growth_enqueued.
- * librccl.so is opened with dlopen by the first of these calls; a single-GPU process never loads it.
- * PNX_ENODEV: librccl.so cannot be loaded. */
+ *     PNX_CFG_COMM_REDUCE_HIST may be set before or after pnx_comm_init (pnx_comm_init does not touch it), but every
+ *     rank must have the same value before its next pass: with it on, EVERY rank has to enqueue the same passes --
+ *     also the pass that pnx_ordered_growth* runs by itself when the presence matrix is not resident.
+ * librccl.so is opened with dlopen by the first of these calls; a single-GPU process never loads it.  Search order:
+ * the path in the environment variable PNX_RCCL_LIB, the loader's own search (librccl.so.1), /opt/rocm/lib, the copies
+ * PyTorch ships in <site-packages>/torch/lib.  PNX_ENODEV: librccl.so cannot be loaded (the message lists what was tried). */
 #define PNX_COMM_ID_BYTES 128
 int pnx_comm_unique_id(uint8_t id[PNX_COMM_ID_BYTES]);
 int pnx_comm_init(pnx_ctx *ctx, const uint8_t id[PNX_COMM_ID_BYTES], int rank, int world);
 int pnx_comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n);
+/* returns once every rank of the communicator has called it (a one-word all-reduce on pnx_stream(), waited for): e.g.
+ * before the host removes the file through which the id travelled */
+int pnx_comm_barrier(pnx_ctx *ctx);
 int pnx_comm_free(pnx_ctx *ctx);   /* also done by pnx_free */
 
 /* ---- group x group intersections ("next" row: similarity) ----------------------------------

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
-    "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free",
+    "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch",
 ]
@@ -123,6 +123,7 @@ def load() -> C.CDLL:
     L.pnx_comm_init.argtypes = [vp, u8p, C.c_int, C.c_int]
     L.pnx_comm_allreduce_u64.argtypes = [vp, vp, C.c_size_t]
     L.pnx_comm_free.argtypes = [vp]
+    L.pnx_comm_barrier.argtypes = [vp]
     L.pnx_group_visit_counts.argtypes = [vp, C.c_uint32, C.c_uint32, u32p]
     f64p = C.POINTER(C.c_double)
     L.pnx_quorum_sums.argtypes = [vp, C.c_uint32, C.c_uint32, u32p, f64p, f64p, f64p, C.POINTER(f64p)]
@@ -443,6 +444,9 @@ class Context:
     def comm_allreduce_u64(self, d_ptr: int, n: int):
         """in-place sum over the ranks of n u64 at device pointer d_ptr, enqueued on the context's stream"""
         self._ck(self._L.pnx_comm_allreduce_u64(self._h, C.c_void_p(d_ptr), n))
+
+    def comm_barrier(self):
+        self._ck(self._L.pnx_comm_barrier(self._h))
 
     def comm_free(self):
         self._ck(self._L.pnx_comm_free(self._h))

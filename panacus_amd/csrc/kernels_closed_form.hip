@@ -371,43 +371,74 @@ __global__ __launch_bounds__(256) void k_cf_term2(uint32_t n, const double *__re
                                   : pnx_exp2::as_f64(0x7ff8000000000000ull);
 }
 
-// one lane per m adds its terms in ascending i -- the reference's order -- reading whole lines ([i][m] layout).  The loop
-// over i is wave-uniform and the loads of 64 rows are issued together (unconditionally, at clamped rows) before their
-// additions: the sum is a chain of dependent additions either way, the loads need not be.
-template <int D>
+// One lane per m adds its terms in ascending i -- the reference's order.  The sum is a chain of dependent additions, so
+// the memory latency must stay off it: a workgroup of 4 waves serves 64 values of m; all four fetch the next 128 rows
+// of the column strip ([i][m] layout: whole 512-byte lines) into registers and park them in LDS, while the first wave
+// walks the previous 128 rows out of LDS, one addition per step.
+constexpr int CF_CHUNK = 128;  // rows per LDS buffer (2 buffers x 128 x 64 x 8 B = 128 KB)
+
 __device__ static inline double cf_column_sum(const double *__restrict__ col, size_t ld, uint32_t lo, uint32_t hi, uint32_t n_rows,
-                                              bool skip_nan) {
-    // [lo, hi) of this lane; the wave walks the union of its lanes' ranges
-    uint32_t wlo = lo < hi ? lo : 0xFFFFFFFFu, whi = lo < hi ? hi : 0u;
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(wlo, o), b = __shfl_xor(whi, o);
-        wlo = a < wlo ? a : wlo;
-        whi = b > whi ? b : whi;
+                                              bool skip_nan, double *buf /* 2 x CF_CHUNK x 64 */) {
+    __shared__ uint32_t s_range[2];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // [lo, hi) of this lane (wave 0 holds the lanes' ranges); the workgroup walks the union
+    __syncthreads();  // a previous call of the workgroup is over: its range and its buffers are free
+    if (threadIdx.x == 0) {
+        s_range[0] = 0xFFFFFFFFu;
+        s_range[1] = 0u;
     }
+    __syncthreads();
+    if (wave == 0 && lo < hi) {
+        atomicMin(&s_range[0], lo);
+        atomicMax(&s_range[1], hi);
+    }
+    __syncthreads();
+    const uint32_t wlo = s_range[0], whi = s_range[1];
     double y = 0.0;
     if (wlo >= whi) return y;
-    for (uint32_t i0 = wlo; i0 < whi; i0 += D) {
-        double v[D];  // D rows in flight: one memory latency per D steps of the chain
+    constexpr int RPW = CF_CHUNK / 4;  // rows per wave and chunk
+    double v[RPW];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t i = i0 + (uint32_t)k;
-            v[k] = col[(size_t)(i < n_rows ? i : n_rows - 1) * ld];
+        for (int k = 0; k < RPW; ++k) {
+            const uint32_t i = i0 + wave * RPW + (uint32_t)k;
+            v[k] = col[(size_t)(i < n_rows ? i : n_rows - 1) * ld];  // unconditional, at a clamped row
         }
+    };
+    auto park = [&](double *b) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t i = i0 + (uint32_t)k;
-            const bool on = i >= lo && i < hi && (!skip_nan || v[k] == v[k]);
-            y = pnx_exp2::add(y, on ? v[k] : 0.0);  // y + 0.0 is y (y is never -0.0: it starts at +0.0 and the terms are >= +0.0)
+        for (int k = 0; k < RPW; ++k) b[(wave * RPW + (uint32_t)k) * 64 + lane] = v[k];
+    };
+    fetch(wlo);
+    park(buf);
+    __syncthreads();
+    uint32_t which = 0;
+    for (uint32_t i0 = wlo; i0 < whi; i0 += CF_CHUNK, which ^= 1u) {
+        const bool more = i0 + CF_CHUNK < whi;
+        if (more) fetch(i0 + CF_CHUNK);
+        if (wave == 0) {
+            const double *b = buf + which * (CF_CHUNK * 64);
+#pragma unroll 16
+            for (uint32_t k = 0; k < (uint32_t)CF_CHUNK; ++k) {
+                const uint32_t i = i0 + k;
+                const double x = b[k * 64 + lane];
+                const bool on = i >= lo && i < hi && (!skip_nan || x == x);
+                y = pnx_exp2::add(y, on ? x : 0.0);  // y + 0.0 is y (y is never -0.0: it starts at +0.0 and the terms are >= +0.0)
+            }
         }
+        if (more) park(buf + (which ^ 1u) * (CF_CHUNK * 64));
+        __syncthreads();
     }
     return y;
 }
 
-__global__ __launch_bounds__(64) void k_cf_finish(uint32_t n, const uint32_t *__restrict__ branch, const uint32_t *__restrict__ cov,
-                                                  const uint32_t *__restrict__ m_quorum, const double *__restrict__ tot,
-                                                  const double *__restrict__ term1, const double *__restrict__ term2,
-                                                  double *__restrict__ out) {
-    const uint32_t m_raw = blockIdx.x * 64 + threadIdx.x + 1, t = blockIdx.y;
+__global__ __launch_bounds__(256) void k_cf_finish(uint32_t n, const uint32_t *__restrict__ branch, const uint32_t *__restrict__ cov,
+                                                   const uint32_t *__restrict__ m_quorum, const double *__restrict__ tot,
+                                                   const double *__restrict__ term1, const double *__restrict__ term2,
+                                                   double *__restrict__ out) {
+    extern __shared__ double s_buf[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m_raw = blockIdx.x * 64 + lane + 1, t = blockIdx.y;
     const bool in = m_raw <= n;
     const uint32_t m = in ? m_raw : n;
     const size_t np1 = (size_t)n + 1;
@@ -416,16 +447,16 @@ __global__ __launch_bounds__(64) void k_cf_finish(uint32_t n, const uint32_t *__
     // union: i in c .. n - m; core / quorum: i in max(m, c) .. n
     const uint32_t lo = br == CF_UNION ? c : (m > c ? m : c);
     const uint32_t hi = br == CF_UNION ? (n >= m ? n - m + 1 : 0u) : n + 1;
-    double y = cf_column_sum<64>(t1, np1, in ? lo : 1u, in ? hi : 0u, n + 1, false);
+    double y = cf_column_sum(t1, np1, in ? lo : 1u, in ? hi : 0u, n + 1, false, s_buf);
     if (br == CF_UNION) {
         y = pnx_exp2::sub(tot[t], y);
     } else if (br == CF_QUORUM) {
         const double *t2 = term2 + t * np1 * np1 + m;
         // hist.rs:163, :180-182: i in m_quorum .. n - 1, only where a j was admissible (NaN = add stayed false)
-        const double yr = cf_column_sum<64>(t2, np1, in ? m_quorum[t * np1 + m] : 1u, in ? n : 0u, n + 1, true);
+        const double yr = cf_column_sum(t2, np1, in ? m_quorum[t * np1 + m] : 1u, in ? n : 0u, n + 1, true, s_buf);
         y = pnx_exp2::add(y, yr);
     }
-    if (in) out[(size_t)t * n + m - 1] = y;
+    if (in && threadIdx.x < 64) out[(size_t)t * n + m - 1] = y;
 }
 
 __global__ void k_log2_exact(const double *__restrict__ x, double *__restrict__ y, uint64_t n) {
@@ -631,7 +662,14 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
         hipLaunchKernelGGL(k_cf_term2, dim3((unsigned)((np1 + 255) / 256), n), dim3(256), 0, st, n, (const double *)d_lh.p, (const double *)d_sum.p,
                            (double *)d_t2.p + t * np1 * np1);
     }
-    hipLaunchKernelGGL(k_cf_finish, dim3((n + 63) / 64, n_pairs), dim3(64), 0, st, n, d_br, d_cov, (const uint32_t *)d_mq.p,
+    {
+        static bool once = false;  // 128 KB of LDS per workgroup: beyond the default limit
+        if (!once) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CF_CHUNK * 64 * 8);
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL(k_cf_finish, dim3((n + 63) / 64, n_pairs), dim3(256), 2 * CF_CHUNK * 64 * 8, st, n, d_br, d_cov, (const uint32_t *)d_mq.p,
                        (const double *)d_tot.p, (const double *)d_t1.p, (const double *)d_t2.p, d_out);
     PNX_HIP(ctx, hipGetLastError());
     PNX_HIP(ctx, hipMemcpyAsync(h + in_bytes, d_out, out_bytes, hipMemcpyDeviceToHost, st));

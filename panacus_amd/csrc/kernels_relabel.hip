@@ -88,10 +88,15 @@ int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys) {
     ctx->relabeled = false;
     if (n < 2 || ctx->n_steps == 0) return PNX_OK;
     int rc;
-    DevBuf d_keys, d_keys2, d_ids, d_tmp;
-    auto cleanup = [&]() {
-        for (DevBuf *b : {&d_keys, &d_keys2, &d_ids, &d_tmp}) release(*b);
-    };
+    // scratch of this call: released on every way out (the PNX_HIP early returns included)
+    struct Scratch {
+        DevBuf keys, keys2, ids, tmp;
+        ~Scratch() {
+            for (DevBuf *b : {&keys, &keys2, &ids, &tmp}) release(*b);
+        }
+    } sc;
+    DevBuf &d_keys = sc.keys, &d_keys2 = sc.keys2, &d_ids = sc.ids, &d_tmp = sc.tmp;
+    auto cleanup = [] {};  // (kept for the explicit paths below; the destructor does the work)
     if ((rc = ensure(ctx, d_keys, ((size_t)n + 2) * 8)) || (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) {
         cleanup();
         return rc;
@@ -147,8 +152,7 @@ int relabel_by_keys(pnx_ctx *ctx, const uint64_t *h_keys) {
                            (const uint8_t *)ctx->d_exclude.p, (const uint32_t *)ctx->d_old_of_new.p, n + 1, (uint8_t *)d_keys.p);
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_exclude.p, d_keys.p, (size_t)n + 1, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    e = hipStreamSynchronize(ctx->stream);
-    cleanup();
+    e = hipStreamSynchronize(ctx->stream);  // before the scratch goes away
     if (e != hipSuccess) return ctx->fail(PNX_EHIP, "item relabel failed: %s", hipGetErrorString(e));
     ctx->relabeled = true;
     return PNX_OK;

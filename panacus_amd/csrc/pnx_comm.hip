@@ -17,8 +17,12 @@
 // librccl.so is opened with dlopen on the first use: a single-GPU process never loads it, and
 // libpanacus_hip.so keeps libamdhip64 as its only link-time dependency.
 #include <dlfcn.h>
+#include <glob.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include <rccl/rccl.h>  // types and enums only: the entry points are resolved at run time
 
@@ -39,12 +43,27 @@ struct RcclApi {
 static RcclApi &rccl() {
     static RcclApi api;
     if (api.lib || !api.err.empty()) return api;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // PNX_RCCL_LIB (a path) first; then the loader's own search (finds a copy that is already mapped, e.g. by torch);
+    // then ROCm's; then the copies PyTorch wheels ship in <site-packages>/torch/lib -- a host without torch in the
+    // process (the Rust host of INTEGRATION.md) still finds the library of the image
+    std::vector<std::string> names;
+    if (const char *env = getenv("PNX_RCCL_LIB")) names.push_back(env);
+    for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(n);
+    for (const char *pat : {"/usr/local/lib/python3*/dist-packages/torch/lib/librccl.so*", "/usr/lib/python3*/site-packages/torch/lib/librccl.so*",
+                            "/usr/local/lib/python3*/site-packages/torch/lib/librccl.so*", "/opt/conda/lib/python3*/site-packages/torch/lib/librccl.so*"}) {
+        glob_t g;
+        if (glob(pat, 0, nullptr, &g) == 0)
+            for (size_t k = 0; k < g.gl_pathc; ++k) names.push_back(g.gl_pathv[k]);
+        globfree(&g);
+    }
+    std::string tried;
+    for (const std::string &name : names) {
+        api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
         if (api.lib) break;
+        tried += (tried.empty() ? "" : ", ") + name;
     }
     if (!api.lib) {
-        api.err = std::string("cannot load librccl.so: ") + dlerror();
+        api.err = "cannot load librccl.so (set PNX_RCCL_LIB to its path); tried: " + tried;
         return api;
     }
     auto sym = [&](const char *n) {
@@ -120,8 +139,7 @@ int pnx_comm_init(pnx_ctx *ctx, const uint8_t id[PNX_COMM_ID_BYTES], int rank, i
     if (r != ncclSuccess) return rccl_fail(ctx, "ncclCommInitRank", r);
     ctx->comm = comm;
     ctx->comm_rank = rank;
-    ctx->comm_world = world;
-    ctx->comm_reduce_hist = true;
+    ctx->comm_world = world;  // (PNX_CFG_COMM_REDUCE_HIST keeps whatever the caller configured, before or after this call)
     return PNX_OK;
 }
 
@@ -130,6 +148,18 @@ int pnx_comm_allreduce_u64(pnx_ctx *ctx, uint64_t *d_buf, size_t n) {
     if (!d_buf && n) return ctx->fail(PNX_EINVAL, "pnx_comm_allreduce_u64: NULL buffer");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     return comm_allreduce_u64(ctx, d_buf, n);
+}
+
+int pnx_comm_barrier(pnx_ctx *ctx) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->comm) return ctx->fail(PNX_EINVAL, "no communicator: call pnx_comm_init first");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->d_comm_word, 8);
+    if (rc) return rc;
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_comm_word.p, 0, 8, ctx->stream));
+    if ((rc = comm_allreduce_u64(ctx, (uint64_t *)ctx->d_comm_word.p, 1))) return rc;
+    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PNX_OK;
 }
 
 int pnx_comm_free(pnx_ctx *ctx) {

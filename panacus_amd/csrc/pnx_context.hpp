@@ -235,8 +235,9 @@ struct pnx_ctx {
 
     // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----
     void *comm = nullptr;          // ncclComm_t
+    pnx::DevBuf d_comm_word;       // one word for pnx_comm_barrier
     int comm_rank = 0, comm_world = 1;
-    bool comm_reduce_hist = false; // every coverage pass is followed by an all-reduce of its flags + histogram
+    bool comm_reduce_hist = true;  // with a communicator: every coverage pass is followed by an all-reduce of its flags + histogram
 
     pnx::Profile prof;
 

@@ -92,26 +92,79 @@ def split_orders(n_orders: int, world: int, rank: int) -> range:
     return range(rank, n_orders, world)
 
 
-def native_comm_init(ctx, rank: int, world: int, id_file: str, timeout_s: float = 120.0):
+def default_comm_id_file() -> str:
+    """Where the ranks of ONE launch meet when nobody named a file: a name that is private to the launch -- the launcher's
+    pid (every rank is its child) and, under torchrun, its run id -- in the user's runtime directory rather than in /tmp.
+    A launcher that can do better hands its children PANACUS_COMM_ID_FILE inside a directory it created (bench.py does)."""
+    import os
+    explicit = os.environ.get("PANACUS_COMM_ID_FILE")
+    if explicit:
+        return explicit
+    base = os.environ.get("XDG_RUNTIME_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "panacus_amd")
+    os.makedirs(base, mode=0o700, exist_ok=True)
+    tag = f"{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.environ.get('MASTER_PORT', '0')}"
+    return os.path.join(base, f"comm_{tag}.id")
+
+
+def native_comm_init(ctx, rank: int, world: int, id_file: str | None = None, timeout_s: float = 120.0):
     """Give `ctx` the library's own RCCL communicator (pnx_comm_init): rank 0 asks the library for the
-    128-byte id and publishes it through `id_file` (written under a temporary name and renamed, so a
-    reader never sees half of it); the other ranks wait for the file.  No torch involved -- the same
-    three steps a Rust host takes."""
+    128-byte id and publishes it through `id_file` (created exclusively under a temporary name and renamed, so a
+    reader never sees half of it and a planted file is never followed); the other ranks wait for the file.  Once
+    every rank holds the communicator -- one all-reduce through it proves that -- rank 0 removes the file, so a later
+    launch can never pick up this launch's id.  No torch involved: the same steps a Rust host takes."""
     import os
     import time
+    if id_file is None:
+        id_file = default_comm_id_file()
     if rank == 0:
         uid = type(ctx).comm_unique_id()
+        try:
+            os.unlink(id_file)  # a stale file of an earlier launch that died
+        except FileNotFoundError:
+            pass
         tmp = f"{id_file}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
         os.replace(tmp, id_file)
     else:
         t0 = time.time()
-        while not (os.path.exists(id_file) and os.path.getsize(id_file) == 128):
+        uid = b""
+        while True:
+            try:
+                st = os.stat(id_file, follow_symlinks=False)
+                # only a file written after this launch began can be this launch's (a stale one is also unlinked by rank 0)
+                if st.st_size == 128 and st.st_mtime >= _LAUNCH_T0 - 1.0:
+                    with open(id_file, "rb") as f:
+                        uid = f.read()
+                    if len(uid) == 128:
+                        break
+            except FileNotFoundError:
+                pass
             if time.time() - t0 > timeout_s:
                 raise TimeoutError(f"no communicator id at {id_file} after {timeout_s} s")
             time.sleep(0.01)
-        with open(id_file, "rb") as f:
-            uid = f.read()
     ctx.comm_init(uid, rank, world)
+    ctx.comm_barrier()  # every rank holds the communicator once this returns
+    if rank == 0:
+        try:
+            os.unlink(id_file)
+        except FileNotFoundError:
+            pass
     return uid
+
+
+def _process_start_time() -> float:
+    import os
+    import time
+    try:
+        with open(f"/proc/{os.getpid()}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return time.time()
+
+
+_LAUNCH_T0 = _process_start_time()

@@ -6,7 +6,7 @@ PANACUS_DIST_BACKEND selects who carries the collective:
   native  the library's own RCCL communicator (pnx_comm_init; no torch at all): the all-reduce of the
           flags + histogram follows every coverage pass on the library's stream, re-runs stay matched
           across ranks.  The 128-byte id travels through PANACUS_COMM_ID_FILE
-          [default /tmp/panacus_comm_<MASTER_PORT>.id]
+          [default: a name private to the launch in $XDG_RUNTIME_DIR or ~/.cache/panacus_amd, removed once every rank has it]
   nccl    [default] torch.distributed over RCCL, on the verified device counters
   gloo    torch.distributed over gloo, on the fetched host counters (tests: two ranks on one GPU)
 
@@ -83,8 +83,7 @@ def main(argv=None):
     ctx.set_order(pi, gi, G)
     if backend == "native" and (world > 1 or os.environ.get("PANACUS_NATIVE_SINGLE") == "1"):
         from panacus_amd.distributed import native_comm_init
-        id_file = os.environ.get("PANACUS_COMM_ID_FILE") or f"/tmp/panacus_comm_{os.environ.get('MASTER_PORT', '29544')}.id"
-        native_comm_init(ctx, rank, world, id_file)
+        native_comm_init(ctx, rank, world)  # PANACUS_COMM_ID_FILE, or a name private to this launch (distributed.default_comm_id_file)
     # A one-shot host for ARBITRARY graphs verifies the pass BEFORE it reduces: a real GFA may hold
     # paths that are not tile-monotone; the first pass then only classifies them, the library builds
     # the run index and runs the pass again inside pnx_hist_fetch -- counters reduced from the first
