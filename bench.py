@@ -437,6 +437,8 @@ def shape_1k_block(args, local_rank):
     thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
     ctx = capi.Context(local_rank)
     ctx.config(capi.CFG_CACHE_INDEX, 0)
+    depth = max(1, min(4, args.depth))
+    ctx.config(capi.CFG_MAX_IN_FLIGHT, depth)
     ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
     order = np.arange(P, dtype=np.uint32)
     ctx.set_order(order, order, P)
@@ -456,7 +458,7 @@ def shape_1k_block(args, local_rank):
         h = growths = None
         queue = []
         enq = 0
-        for _ in range(min(n, 2)):
+        for _ in range(min(n, depth if P <= 511 else 2)):
             queue.append(enqueue())
             enq += 1
         for _ in range(n):
@@ -559,6 +561,9 @@ def main():
                     help="skip the rocprofv3 counter passes (child runs of this script) that measure roofline.traffic and roofline_valu")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-path block (prepare_ms, cold_first_pass_ms)")
     ap.add_argument("--rows-layout", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=4,
+                    help="passes a context keeps in flight (PNX_CFG_MAX_IN_FLIGHT, 1..4): the latency of a step -- pass, closed forms on "
+                         "their own streams, the host's share -- is several times the duration of a pass")
     args = ap.parse_args()
 
     force_dist = os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
@@ -611,6 +616,7 @@ def main():
         c = capi.Context(local_rank)
         c.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
         c.config(capi.CFG_CACHE_INDEX, 0)
+        c.config(capi.CFG_MAX_IN_FLIGHT, max(1, min(4, args.depth)))
         if blocking:
             c.config(capi.CFG_BLOCKING_SYNC, 1)
         if args.no_overlap:
@@ -657,7 +663,7 @@ def main():
                 self.ext = {}  # torch views of the library's streams
                 self.ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
                               "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
-                              "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(2)]
+                              "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(depth)]
                 self.enq = self.fin = 0
 
         def enqueue(self):
@@ -678,7 +684,7 @@ def main():
                 t = self.hist_views.get(d_hist)
                 if t is None:
                     t = self.hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
-                slot = self.ring[self.enq % 2]
+                slot = self.ring[self.enq % depth]
                 self.enq += 1
                 with torch.cuda.stream(ext):
                     slot["tmp"].copy_(t)
@@ -691,7 +697,7 @@ def main():
             """wait for the OLDEST enqueued pass of this lane; multi-GPU: its all-reduced counters"""
             ctx = self.ctx
             if use_dist and not self.native:
-                slot = self.ring[self.fin % 2]
+                slot = self.ring[self.fin % depth]
                 self.fin += 1
                 slot["ev"].synchronize()
                 ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
@@ -716,6 +722,7 @@ def main():
                 self.ext.clear()
 
     n_lanes = max(1, args.lanes)
+    depth = max(1, min(4, args.depth))
     ctx = make_context()
     growth_on_device = False  # set below, once the offload context is known
     all_lanes = lanes = []
@@ -762,7 +769,7 @@ def main():
         lanes = all_lanes if lanes is None else lanes
         L = len(lanes)
         enqueued = 0
-        for _ in range(min(n_steps, 2 * L)):
+        for _ in range(min(n_steps, depth * L)):
             lanes[enqueued % L].enqueue()
             enqueued += 1
         for k in range(n_steps):
@@ -932,7 +939,7 @@ def main():
                 "rows_order": index_ms / max(index_n, 1), "rows_cover": cover_alone_ms,
                 "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
                 "rows_cover_beside_the_other_phases": cover_avg_ms,
-                "lanes": len(lanes),
+                "lanes": len(lanes), "passes_in_flight": depth,
                 "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
                 "quorum_inner_sums_on_gpu": bool(not args.no_quorum_offload and P >= args.quorum_offload_min_n
                                                  and hostlib.quorum_offload_usable()),

@@ -41,6 +41,7 @@ extern "C" {
 #define PNX_ELIMIT (-5)   /* input exceeds an implementation limit (stated in the message) */
 
 typedef struct pnx_ctx pnx_ctx;
+#define PNX_MAX_IN_FLIGHT 4 /* upper bound of PNX_CFG_MAX_IN_FLIGHT */
 
 /* ---- lifetime ------------------------------------------------------------------------ */
 /* device = HIP device ordinal visible to this process (LOCAL_RANK for torchrun launches). */
@@ -209,8 +210,8 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
 int pnx_hist(pnx_ctx *ctx, uint32_t *countable, uint64_t *hist);
 
 /* Split form for pipelining and multi-GPU: pnx_hist_async enqueues one pass on the context's
- * stream (kernels + an async copy of the counters into pinned host memory).  Up to TWO
- * passes may be in flight, so pass k+1 can be enqueued before pass k is looked at;
+ * stream (kernels + an async copy of the counters into pinned host memory).  Up to PNX_CFG_MAX_IN_FLIGHT (default 2,
+ * at most PNX_MAX_IN_FLIGHT = 4) passes may be in flight, so pass k+1 can be enqueued before pass k is looked at;
  * pnx_hist_fetch / pnx_hist_device wait for and return the OLDEST pass in flight (or the last
  * finished one).  pnx_hist_device exposes that pass's counters in HBM (n_groups+1 u64, owned
  * by the pass) so the caller can all-reduce them with RCCL; d_countable (n_items+1 u32) is
@@ -354,7 +355,8 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
  *   hist   n+1 bins on the host, or NULL: the device counters of the coverage pass enqueued LAST (n must be the number of
  *          groups) -- the curves then follow the pass without the histogram ever visiting the host
  *   out    n_pairs x n values: out[t*n + m-1] = growth at m groups (the reference's vector without its leading NaN)
- * _async enqueues the work on a stream of its own (inputs are copied before it returns); up to TWO calls may be in flight;
+ * _async enqueues the work on a stream of its own (inputs are copied before it returns); up to PNX_CFG_MAX_IN_FLIGHT calls may be in flight
+ * (two once the quorum branch's scratch passes 1 GiB per call: n > 511);
  * _fetch waits for the OLDEST one. */
 enum { PNX_GROWTH_UNION = 0, PNX_GROWTH_CORE = 1, PNX_GROWTH_QUORUM = 2 };
 #define PNX_GROWTH_MAX_N 2048
@@ -435,7 +437,11 @@ enum {
     PNX_CFG_ROWS_LAYOUT = 17,  /* layout of the path rows: 0 [default] chosen from the shape, 1 tile-major over all
                                   (tile, path) pairs, 2 path-major over the tiles each path spans.  Takes effect when the
                                   rows are next derived */
-    PNX_CFG_DROP_DERIVED = 18  /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
+    PNX_CFG_MAX_IN_FLIGHT = 19, /* coverage passes (pnx_hist_async) and closed-form calls (pnx_growth_closed_form_async) that may
+                                  be in flight at once: 1 .. PNX_MAX_IN_FLIGHT [2].  Each pass in flight owns a coverage vector
+                                  (4 (n_items + 1) bytes) and its counters; a host whose per-pass latency (pass + closed forms
+                                  + its own work) exceeds the duration of a pass keeps more of them in flight */
+    PNX_CFG_DROP_DERIVED = 18, /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
                                   tile index); the next pass or pnx_prepare derives it again.  Measurement only */
 };
 int pnx_config(pnx_ctx *ctx, int key, int64_t value);

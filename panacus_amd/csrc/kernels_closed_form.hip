@@ -405,12 +405,18 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
             v[k] = col[(size_t)(i < n_rows ? i : n_rows - 1) * ld];  // unconditional, at a clamped row
         }
     };
-    auto park = [&](double *b) {
+    // parked already masked (outside the lane's range, or NaN = "no admissible j": +0.0, and y + 0.0 is y -- y is never
+    // -0.0: it starts at +0.0 and the terms are >= +0.0), so that the walk is one LDS read and one addition per step
+    auto park = [&](double *b, uint32_t i0) {
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) b[(wave * RPW + (uint32_t)k) * 64 + lane] = v[k];
+        for (int k = 0; k < RPW; ++k) {
+            const uint32_t i = i0 + wave * RPW + (uint32_t)k;
+            const bool on = i >= lo && i < hi && (!skip_nan || v[k] == v[k]);
+            b[(wave * RPW + (uint32_t)k) * 64 + lane] = on ? v[k] : 0.0;
+        }
     };
     fetch(wlo);
-    park(buf);
+    park(buf, wlo);
     __syncthreads();
     uint32_t which = 0;
     for (uint32_t i0 = wlo; i0 < whi; i0 += CF_CHUNK, which ^= 1u) {
@@ -418,15 +424,10 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
         if (more) fetch(i0 + CF_CHUNK);
         if (wave == 0) {
             const double *b = buf + which * (CF_CHUNK * 64);
-#pragma unroll 16
-            for (uint32_t k = 0; k < (uint32_t)CF_CHUNK; ++k) {
-                const uint32_t i = i0 + k;
-                const double x = b[k * 64 + lane];
-                const bool on = i >= lo && i < hi && (!skip_nan || x == x);
-                y = pnx_exp2::add(y, on ? x : 0.0);  // y + 0.0 is y (y is never -0.0: it starts at +0.0 and the terms are >= +0.0)
-            }
+#pragma unroll 32
+            for (uint32_t k = 0; k < (uint32_t)CF_CHUNK; ++k) y = pnx_exp2::add(y, b[k * 64 + lane]);
         }
-        if (more) park(buf + (which ^ 1u) * (CF_CHUNK * 64));
+        if (more) park(buf + (which ^ 1u) * (CF_CHUNK * 64), i0 + CF_CHUNK);
         __syncthreads();
     }
     return y;
@@ -585,14 +586,19 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
                          PNX_GROWTH_MAX_PAIRS);
     for (uint32_t t = 0; t < n_pairs; ++t)
         if (branch[t] > PNX_GROWTH_QUORUM || cov_abs[t] == 0) return ctx->fail(PNX_EINVAL, "pnx_growth_closed_form: bad threshold pair %u", t);
-    if (ctx->gslot_count >= 2) return ctx->fail(PNX_EINVAL, "two closed-form calls are already in flight; fetch one first");
+    // (two slots once a slot's scratch passes 1 GiB: the terms of the quorum branch are (n + 1)^3 doubles per slot)
+    const int slot_cap = ((size_t)n + 1) * (n + 1) * (n + 1) * 8 > ((size_t)1 << 30) ? std::min(2, ctx->max_in_flight) : ctx->max_in_flight;
+    if (ctx->gslot_count && slot_cap != ctx->gslot_cap)
+        return ctx->fail(PNX_EINVAL, "closed-form calls of very different sizes cannot be in flight together; fetch the pending ones first");
+    if (ctx->gslot_count >= slot_cap) return ctx->fail(PNX_EINVAL, "%d closed-form calls are already in flight; fetch one first", slot_cap);
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     Ticket *src = nullptr;
     if (!hist) {  // the counters of the pass enqueued last, straight from the device
         if (ctx->tk_count == 0 || n != ctx->n_groups) return ctx->fail(PNX_EINVAL, "pnx_growth_closed_form: hist == NULL needs a coverage pass in flight with n groups");
-        src = &ctx->tk[ctx->tk_next ^ 1];
+        src = &ctx->tk[ctx->tk_last()];
     }
     const size_t np1 = (size_t)n + 1, T = n_pairs;
+    if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;  // (keeps the low slots in use when the cap is below the ring)
     pnx_ctx::GrowthSlot &g = ctx->gslot[ctx->gslot_next];
     if (!g.stream) PNX_HIP(ctx, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     hipStream_t st = g.stream;
@@ -678,8 +684,9 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
     g.n = n;
     g.n_pairs = n_pairs;
     g.out_off = in_bytes;
-    ctx->gslot_next ^= 1;
+    ctx->gslot_next = (ctx->gslot_next + 1) % slot_cap;
     ctx->gslot_count += 1;
+    ctx->gslot_cap = slot_cap;
     return PNX_OK;
 }
 
@@ -690,7 +697,7 @@ int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out) {
     PNX_HIP(ctx, hipEventSynchronize(g.done));
     std::memcpy(out, (const char *)g.h_io + g.out_off, (size_t)g.n_pairs * g.n * 8);
     g.pending = false;
-    ctx->gslot_oldest ^= 1;
+    ctx->gslot_oldest = (ctx->gslot_oldest + 1) % ctx->gslot_cap;
     ctx->gslot_count -= 1;
     return PNX_OK;
 }

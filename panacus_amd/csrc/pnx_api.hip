@@ -167,7 +167,7 @@ static int enqueue_pass(pnx_ctx *ctx) {
     if ((rc = comm_reduce_pass(ctx, t))) return rc;  // multi-GPU: global flags + histogram (no-op without a communicator)
     if ((rc = stage_results(ctx, t))) return rc;
     t->in_flight = true;
-    ctx->tk_next ^= 1;
+    ctx->tk_next = (ctx->tk_next + 1) % pnx_ctx::N_TICKETS;
     ctx->tk_count += 1;
     return PNX_OK;
 }
@@ -189,7 +189,7 @@ static int settle_oldest(pnx_ctx *ctx) {
         if (!bad) {
             ctx->last_general_paths = t->h_flags[1];
             t->in_flight = false;
-            ctx->tk_oldest ^= 1;
+            ctx->tk_oldest = (ctx->tk_oldest + 1) % pnx_ctx::N_TICKETS;
             ctx->tk_count -= 1;
             ctx->last_done = t;
             ctx->d_countable_done = &t->d_countable;
@@ -280,7 +280,7 @@ void pnx_free(pnx_ctx *ctx) {
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ctx->d_items, &ctx->d_path_off, &ctx->d_weights, &ctx->d_exclude, &ctx->d_ord_path,
                       &ctx->d_ord_group, &ctx->d_tile_idx, &ctx->d_tfirst, &ctx->d_tspan, &ctx->d_idx_off, &ctx->d_path_class, &ctx->d_wdigits, &ctx->d_unsorted, &ctx->d_sorted_coff, &ctx->d_sorted_path, &ctx->d_flags,
-                      &ctx->tk[0].d_block, &ctx->tk[1].d_block, &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
+                      &ctx->d_M, &ctx->d_perms, &ctx->d_cov_thr, &ctx->d_qtab,
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
@@ -304,7 +304,7 @@ void pnx_free(pnx_ctx *ctx) {
         if (t.ev_pre) (void)hipEventDestroy(t.ev_pre);
         if (t.ev_cov) (void)hipEventDestroy(t.ev_cov);
         if (t.ev_reader) (void)hipEventDestroy(t.ev_reader);
-        for (DevBuf *b : {&t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own})
+        for (DevBuf *b : {&t.d_block, &t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own})
             release(*b);
     }
     if (ctx->stream_pre) (void)hipStreamDestroy(ctx->stream_pre);
@@ -708,7 +708,8 @@ int pnx_hist_async(pnx_ctx *ctx) {
     if (!ctx) return PNX_EINVAL;
     if (!ctx->have_csr || !ctx->have_order) return ctx->fail(PNX_EINVAL, "pnx_hist needs pnx_set_csr and pnx_set_order first");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->tk_count >= 2) return ctx->fail(PNX_EINVAL, "two coverage passes are already in flight; fetch one first");
+    if (ctx->tk_count >= ctx->max_in_flight)
+        return ctx->fail(PNX_EINVAL, "%d coverage passes are already in flight; fetch one first", ctx->max_in_flight);
     int rc;
     // the presence matrix is only written when asked for (config) or when a growth call needs it
     ctx->want_M = ctx->keep_M_user || ctx->growth_needs_M;
@@ -742,7 +743,7 @@ int pnx_sync(pnx_ctx *ctx) {
 int pnx_hist_enqueued(pnx_ctx *ctx, uint64_t **d_hist) {
     if (!ctx || !d_hist) return PNX_EINVAL;
     if (ctx->tk_count == 0) return ctx->fail(PNX_EINVAL, "no coverage pass is in flight");
-    Ticket *t = &ctx->tk[ctx->tk_next ^ 1];
+    Ticket *t = &ctx->tk[ctx->tk_last()];
     *d_hist = t->d_hist;
     // the counters are written on an internal stream: whatever the caller now enqueues on pnx_stream() waits for them
     if (ctx->last_pass_phased) PNX_HIP(ctx, hipStreamWaitEvent(ctx->stream, t->done, 0));
@@ -801,7 +802,7 @@ void *pnx_stream(pnx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int pnx_hist_enqueued_on(pnx_ctx *ctx, uint64_t **d_hist, void **stream) {
     if (!ctx || !d_hist || !stream) return PNX_EINVAL;
     if (ctx->tk_count == 0) return ctx->fail(PNX_EINVAL, "no coverage pass is in flight");
-    *d_hist = ctx->tk[ctx->tk_next ^ 1].d_hist;
+    *d_hist = ctx->tk[ctx->tk_last()].d_hist;
     *stream = (void *)(ctx->last_pass_phased ? ctx->stream_post : ctx->stream);
     return PNX_OK;
 }
@@ -1085,6 +1086,11 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
                 ctx->index_valid = false;
             }
             ctx->cover_variant = (int)value;
+            return PNX_OK;
+        case PNX_CFG_MAX_IN_FLIGHT:
+            if (value < 1 || value > PNX_MAX_IN_FLIGHT) return ctx->fail(PNX_EINVAL, "PNX_CFG_MAX_IN_FLIGHT must be in 1..%d", PNX_MAX_IN_FLIGHT);
+            if (ctx->tk_count || ctx->gslot_count) return ctx->fail(PNX_EINVAL, "PNX_CFG_MAX_IN_FLIGHT cannot change while work is in flight");
+            ctx->max_in_flight = (int)value;
             return PNX_OK;
         case PNX_CFG_ROWS_LAYOUT:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows layout must be 0 (auto), 1 (tile-major) or 2 (path-major)");

@@ -32,7 +32,7 @@ struct DevBuf {
     bool borrowed = false;  // p belongs to another context (pnx_share_csr): never freed here
 };
 
-// One enqueued coverage pass.  Two tickets exist so that pass k+1 can be enqueued before the
+// One enqueued coverage pass.  Several tickets exist so that pass k+1 (.. k+3) can be enqueued before the
 // host has looked at pass k: each owns its result counters in HBM, a pinned staging copy and
 // the event that marks "results of this pass are on the host".
 struct Ticket {
@@ -180,8 +180,11 @@ struct pnx_ctx {
 
     // ---- results ----
     pnx::DevBuf *d_countable_done = nullptr;  // coverage vector (n_items + 1 u32) of the pass settled last
-    pnx::Ticket tk[2];        // in-flight / finished passes (ring)
+    static constexpr int N_TICKETS = PNX_MAX_IN_FLIGHT;
+    pnx::Ticket tk[N_TICKETS];  // in-flight / finished passes (ring)
     int tk_next = 0, tk_oldest = 0, tk_count = 0;
+    int max_in_flight = 2;      // PNX_CFG_MAX_IN_FLIGHT: passes (and closed-form calls) the caller may keep in flight
+    int tk_last() const { return (tk_next + N_TICKETS - 1) % N_TICKETS; }  // the pass enqueued last
     pnx::Ticket *cur = nullptr;        // the ticket the launch functions write to
     pnx::Ticket *last_done = nullptr;  // holds the last verified histogram
     pnx::DevBuf d_M;          // n_groups * n_blocks * 64 u32 presence matrix
@@ -230,8 +233,8 @@ struct pnx_ctx {
         bool pending = false;
         uint32_t n = 0, n_pairs = 0;
         size_t out_off = 0;
-    } gslot[2];
-    int gslot_next = 0, gslot_oldest = 0, gslot_count = 0;
+    } gslot[PNX_MAX_IN_FLIGHT];
+    int gslot_next = 0, gslot_oldest = 0, gslot_count = 0, gslot_cap = 2;  // ring over the first gslot_cap slots
 
     // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----
     void *comm = nullptr;          // ncclComm_t

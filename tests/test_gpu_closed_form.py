@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
+from panacus_amd import capi
 
 pytestmark = pytest.mark.gpu
 
@@ -45,6 +46,8 @@ def test_quorum_growth_offload_bitwise(ctx, n):
         got = hostlib.calc_growths(h, thr)
     finally:
         hostlib.set_quorum_offload(None)
+        ctx.sync()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
     host_only = hostlib.calc_growths(h, thr)
     for (c, q), a, b in zip(pairs, got, host_only):
         exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
@@ -66,6 +69,8 @@ def test_quorum_growth_offload_large_n(ctx):
         got = hostlib.calc_growths(h, thr)
     finally:
         hostlib.set_quorum_offload(None)
+        ctx.sync()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
     for a, b in zip(got, host_only):
         assert a.tobytes() == b.tobytes()
 
@@ -148,6 +153,8 @@ def test_whole_closed_forms_on_the_device_bitwise(ctx, n):
         got2 = hostlib.calc_growths_end(pending2)
     finally:
         hostlib.set_quorum_offload(None)
+        ctx.sync()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
     for (c, q), a, b in zip(pairs, got, host_only):
         exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
         assert a.tobytes() == exp.tobytes(), (n, c, q)
@@ -158,7 +165,7 @@ def test_whole_closed_forms_on_the_device_bitwise(ctx, n):
 
 def test_closed_forms_follow_the_pass_on_the_device(ctx):
     """hist == NULL: the curves are computed from the device counters of the pass enqueued last, two passes in flight"""
-    from panacus_amd import hostlib
+    from panacus_amd import capi, hostlib
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
     n, p = 200_000, 96
     items, pre, _ = orc.pansyn(13, n, p)
@@ -167,6 +174,21 @@ def test_closed_forms_follow_the_pass_on_the_device(ctx):
     ctx.set_csr_pansyn(13, n, p)
     hostlib.set_quorum_offload(ctx, min_n=1)
     try:
+        # four passes and their closed forms in flight
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 4)
+        pi = np.arange(p, dtype=np.uint32)
+        ctx.set_order(pi, pi, p)
+        pend = []
+        for _ in range(4):
+            ctx.hist_async()
+            pend.append(hostlib.calc_growths_begin_on_device(p, thr))
+        assert all(x is not None for x in pend) and hostlib.calc_growths_begin_on_device(p, thr) is None   # a fifth: refused
+        oh = orc.hist(orc.coverage(items, pre, pi.astype(np.uint64), pi.astype(np.uint64), n), p)
+        for x in pend:
+            assert np.array_equal(ctx.hist_fetch()[1], oh)
+            for (c, q), a in zip(pairs, hostlib.calc_growths_end(x)):
+                assert a.tobytes() == orc.growth(oh, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
         orders = [(np.arange(p, dtype=np.uint32), np.arange(p, dtype=np.uint32), p),
                   (np.arange(p, dtype=np.uint32), (np.arange(p) // 3).astype(np.uint32), p // 3)]
         for pi, gi, G in orders:
@@ -186,3 +208,5 @@ def test_closed_forms_follow_the_pass_on_the_device(ctx):
                 assert a.tobytes() == exp.tobytes() and b.tobytes() == exp.tobytes(), (G, c, q)
     finally:
         hostlib.set_quorum_offload(None)
+        ctx.sync()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)

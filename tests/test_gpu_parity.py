@@ -732,6 +732,24 @@ def test_two_passes_in_flight(ctx):
     ctx.hist_async()
     cnt, h = ctx.hist()
     assert np.array_equal(h, oh2) and np.array_equal(cnt, ocov2)
+    # PNX_CFG_MAX_IN_FLIGHT: four passes (each with its own coverage vector and counters), oldest first, a fifth refused
+    ctx.config(capi.CFG_MAX_IN_FLIGHT, 4)
+    try:
+        orders = [pi, pi[::-1].copy(), np.roll(pi, 3), pi]
+        for k in range(4):
+            ctx.hist_async()
+        with pytest.raises(capi.PnxError):
+            ctx.hist_async()
+        with pytest.raises(capi.PnxError):
+            ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)   # not while passes are in flight
+        for k in range(4):
+            cnt, h = ctx.hist_fetch(want_countable=True)
+            assert np.array_equal(h, oh2) and np.array_equal(cnt, ocov2), k
+        with pytest.raises(capi.PnxError):
+            ctx.config(capi.CFG_MAX_IN_FLIGHT, 5)
+    finally:
+        ctx.sync()
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
 
 
 # ---------------------------------------------------------------------------------------------
