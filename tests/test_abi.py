@@ -56,11 +56,10 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
-def test_plain_c_program_links_and_fails_loudly(tmp_path):
+def _plain_c_host(tmp_path):
     """A C host (the shape of the Rust FFI) links against libpanacus_hip.so; without a GPU
     pnx_init returns PNX_ENODEV and a message, it never falls back to a CPU path."""
     import subprocess
-    import torch
     src = tmp_path / "host.c"
     src.write_text(r'''
 #include <stdio.h>
@@ -87,8 +86,22 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                            "-L", libdir, "-lpanacus_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, check=True).stdout.decode()
-    rc = int(out.split("|")[0])
+    return int(out.split("|")[0]), out
+
+
+def test_plain_c_program_links_and_fails_loudly(tmp_path):
+    """without a GPU: PNX_ENODEV and a message -- never a CPU path (on a GPU box the same host computes, see the gpu test)"""
+    import torch
+    rc, out = _plain_c_host(tmp_path)
     if torch.cuda.is_available():
         assert rc == 0 and "hist 0 2 cnt 1 1" in out
     else:
         assert rc == capi.PNX_ENODEV and "no CPU fallback" in out
+
+
+@pytest.mark.gpu
+def test_plain_c_program_computes_on_the_gpu(tmp_path):
+    """the same C host on a GPU box: upload, order, histogram through nothing but the C ABI"""
+    rc, out = _plain_c_host(tmp_path)
+    assert rc == 0 and "hist 0 2 cnt 1 1" in out, out
+

@@ -1,0 +1,111 @@
+"""More than one GPU: one process per device, node-range shards or order shards, the exchange an RCCL all-reduce of
+small u64 counters over xGMI.  These tests need at least TWO visible devices and skip otherwise
+(the build box and the 1-GPU test boxes have one); the same host code runs with two ranks over gloo in
+tests/test_distributed_gloo.py and tests/test_host_cli.py, and with one rank through RCCL in tests/test_gpu_parity.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from panacus_amd import hostlib as hl
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _devices():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+needs_two = pytest.mark.skipif(_devices() < 2, reason="needs at least two visible GPUs")
+
+
+def _body(text):
+    return "\n".join(l for l in text.split("\n") if not l.startswith("#"))
+
+
+def _clean_env(**extra):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(extra)
+    return e
+
+
+def _bumpy_gfa(tmp_path):
+    """paths that are NOT tile-monotone (a 40-step window reversed every 300 steps)"""
+    src = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "60000", "--paths", "12", "-o", src])
+    assert rc == 0, err
+    gfa = str(tmp_path / "bumpy.gfa")
+    with open(src) as f, open(gfa, "w") as g:
+        for line in f:
+            if line.startswith("P\t"):
+                cols = line.rstrip("\n").split("\t")
+                steps = cols[2].split(",")
+                for a in range(100, len(steps) - 60, 300):
+                    steps[a:a + 40] = steps[a:a + 40][::-1]
+                cols[2] = ",".join(steps)
+                line = "\t".join(cols) + "\n"
+            g.write(line)
+    return gfa
+
+
+@needs_two
+@pytest.mark.parametrize("backend,variant", [("native", "3"), ("native", "2"), ("nccl", "3")])
+def test_two_gpus_node_range_shards_equal_one_gpu(tmp_path, backend, variant):
+    """histgrowth of one GFA on two GPUs (node-range shards; the library's own communicator reduces flags + histogram
+    behind every pass -- with PNX_COVER_VARIANT=2 also behind the RE-RUN of a pass whose paths are not tile-monotone,
+    which every rank must take together) prints the table of the single-GPU CLI"""
+    import socket
+    gfa = _bumpy_gfa(tmp_path)
+    for cname in ("node", "bp"):
+        rc, ref, err = hl.run_cli(["histgrowth", "-a", "-c", cname, "-l", "1,2", "-q", "0,0.5", gfa])
+        assert rc == 0, err
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        out_file = str(tmp_path / f"two_{backend}_{variant}_{cname}.tsv")
+        procs = []
+        for r in range(2):
+            e = _clean_env(RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                           PANACUS_DIST_BACKEND=backend, PANACUS_TOOL_REPORT_RERUNS="1", PNX_COVER_VARIANT=variant,
+                           PANACUS_COMM_ID_FILE=str(tmp_path / f"comm_{backend}_{variant}_{cname}.id"),
+                           HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "histgrowth_multi_gpu.py"), "-c", cname,
+                                           "-l", "1,2", "-q", "0,0.5", "-o", out_file, gfa], env=e,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        errs = []
+        for pr in procs:
+            o, e2 = pr.communicate(timeout=600)
+            assert pr.returncode == 0, e2.decode()[-2000:]
+            errs.append(e2.decode())
+        if variant == "2":
+            assert "reruns=0" not in errs[0] and "reruns=" in errs[0]   # the re-run really happened, on both ranks together
+        assert open(out_file).read() == _body(ref).rstrip("\n") + "\n"
+        assert not os.path.exists(str(tmp_path / f"comm_{backend}_{variant}_{cname}.id"))   # the id file does not outlive the launch
+
+
+@needs_two
+@pytest.mark.parametrize("collective", ["torch", "native"])
+def test_bench_launches_its_ranks_and_shards_the_orders(collective):
+    """`bench.py --gpus 2` starts two ranks by itself; the JSON line says n_gpus = 2, the weak-scaling histogram covers
+    both shards, and the order-sharded permuted growth equals the single-GPU result bit for bit (the bench fails otherwise)"""
+    small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--pg-nodes", "150000", "--pg-paths", "40",
+             "--pg-orders", "10", "--pg-reps", "2", "--no-pmc", "--collective", collective]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=_clean_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 400000
+    pg = d["permuted_growth"]
+    assert pg["n_gpus"] == 2 and pg["scaling"] == "strong" and pg["checks"]["sharded_equals_single_gpu"] and pg["allreduce_ms"] > 0
+    assert pg["orders_per_rank_max"] == 5 and "rccl" in pg["collective_path"]

@@ -1191,6 +1191,13 @@ def test_full_size_cfg3_properties():
         pi = np.arange(p, dtype=np.uint64)
         assert np.array_equal(cnt[1:n_pre + 1], orc.coverage(items, pre, pi, pi, n_pre)[1:])
         del items
+        # ... and the WHOLE graph: the resident steps read back, widened to the reference's u64 items, through the serial
+        # restatement of abacus.rs:719-787 (about a second of CPU time) -- coverage vector and histogram bit for bit
+        items32, off, _ = c.get_csr()
+        ocov = orc.coverage(items32.astype(np.uint64), off, pi, pi, n)
+        del items32
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, p))
+        del ocov
         # ... and sampled nodes anywhere, from the generator's definition
         rng = np.random.default_rng(1)
         nodes = np.unique(np.concatenate([rng.integers(1, n + 1, size=1500), [1, n, n - 1, 2048, 2049, 4_999_999]]))
