@@ -77,6 +77,34 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
                       uint32_t n_items, const uint32_t *weights, const uint8_t *exclude,
                       const uint64_t *item_key);
 
+/* ---- the ItemTable straight from GFA text: step columns tokenised on the device ------------------
+ * Replaces parse_path_seq_to_item_vec / parse_walk_seq_to_item_vec (src/graph_broker/util.rs:1021-1091) and the
+ * per-step lookups in the node2id map that graph.rs:308-375 builds: the caller finds the P / W lines (it needs their
+ * headers anyway) and hands over the TEXT of the step columns; the library splits them at ',' (P: `name+`, `name-`) or
+ * at '>' / '<' (W), converts the names and leaves the node ItemTable resident -- as after pnx_set_csr, for node and
+ * bp counts.  Segment names must be decimal numbers:
+ *   id_of_name == NULL  the number IS the node id (the reference's `nice: true`, graph.rs:224-229: names 1..N in file order)
+ *   id_of_name != NULL  node id = id_of_name[number] for number < n_names, 0 = no such segment
+ * A step that is not of that form, or names a segment the graph does not have, fails the call with PNX_EINVAL (the
+ * reference panics, util.rs:1021); graphs with other names keep the host's parser and pnx_set_csr.
+ *   text / text_bytes    host bytes that contain every step column -- any superset, e.g. the whole mapped file.  NULL: the
+ *                        bytes handed to pnx_gfa_text_upload before (which lets a host start the copy while it is still
+ *                        looking for the lines; the copy is the larger part of the call)
+ *   col_begin, col_end   per path the byte range [begin, end) of its step column inside text
+ *   is_walk              per path: 1 = W line, 0 = P line
+ * pnx_gfa_text_upload copies synchronously; the library frees its copy of the text at the end of pnx_set_csr_gfa. */
+typedef struct pnx_gfa_steps {
+    const char *text;
+    uint64_t text_bytes;
+    uint32_t n_paths, n_nodes;
+    const uint64_t *col_begin, *col_end;
+    const uint8_t *is_walk;
+    const uint32_t *id_of_name;
+    uint64_t n_names;
+} pnx_gfa_steps;
+int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
+int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
+
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
  * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)
  * without uploading the ItemTable again -- a host that evaluates several -e lists on one graph, or

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
-    "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch",
+    "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
 ]
 
 
@@ -58,6 +58,12 @@ class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
                 ("n_items", C.c_uint32), ("count_type", C.c_int),
                 ("track_covered", C.c_int), ("inc_off", C.POINTER(C.c_uint64)), ("inc_iv", C.POINTER(C.c_uint64)),
                 ("exc_off", C.POINTER(C.c_uint64)), ("exc_iv", C.POINTER(C.c_uint64))]
+
+
+class PnxGfaSteps(C.Structure):  # pnx_gfa_steps
+    _fields_ = [("text", C.c_char_p), ("text_bytes", C.c_uint64), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("col_begin", C.POINTER(C.c_uint64)), ("col_end", C.POINTER(C.c_uint64)), ("is_walk", C.POINTER(C.c_uint8)),
+                ("id_of_name", C.POINTER(C.c_uint32)), ("n_names", C.c_uint64)]
 
 
 class PnxPieceEvent(C.Structure):  # pnx_piece_event
@@ -93,6 +99,8 @@ def load() -> C.CDLL:
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
     L.pnx_prepare.argtypes = [vp]
+    L.pnx_gfa_text_upload.argtypes = [vp, C.c_char_p, C.c_uint64]
+    L.pnx_set_csr_gfa.argtypes = [vp, C.POINTER(PnxGfaSteps), u32p, u8p]
     L.pnx_get_exclude.argtypes = [vp, u8p]
     L.pnx_set_weights.argtypes = [vp, u32p]
     L.pnx_exclude_items.argtypes = [vp, u32p, C.c_uint32]
@@ -291,6 +299,26 @@ class Context:
 
     def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
+        self.n_items = n_nodes
+
+    def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False):
+        """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device"""
+        cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
+        ce = np.ascontiguousarray(col_end, dtype=np.uint64)
+        wk = np.ascontiguousarray(is_walk, dtype=np.uint8)
+        names = None if id_of_name is None else np.ascontiguousarray(id_of_name, dtype=np.uint32)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+        ex = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+        g = PnxGfaSteps()
+        if upload_first:
+            self._ck(self._L.pnx_gfa_text_upload(self._h, text, len(text)))
+            g.text, g.text_bytes = None, 0
+        else:
+            g.text, g.text_bytes = text, len(text)
+        g.n_paths, g.n_nodes = len(cb), n_nodes
+        g.col_begin, g.col_end, g.is_walk = _ptr(cb, C.c_uint64), _ptr(ce, C.c_uint64), _ptr(wk, C.c_uint8)
+        g.id_of_name, g.n_names = _ptr(names, C.c_uint32), (0 if names is None else len(names))
+        self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = n_nodes
 
     def prepare(self):

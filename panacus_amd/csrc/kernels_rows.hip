@@ -674,9 +674,9 @@ int launch_rows_phases(pnx_ctx *ctx, bool write_m) {
     uint32_t bits = 1;  // planes needed to count up to n_groups inclusive
     while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;
     prof_begin(ctx, PNX_K_COVER, ctx->s_main);
-    if (bits <= 8) launch_rows_cover_t<8>(ctx, write_m);
-    else if (bits <= 12) launch_rows_cover_t<12>(ctx, write_m);
-    else if (bits <= 16) launch_rows_cover_t<16>(ctx, write_m);
+    // (two widths only: with the carry-save tree in front, unused planes cost a fraction of an instruction per group,
+    // and every instance less is code the first pass of a process does not have to load)
+    if (bits <= 12) launch_rows_cover_t<12>(ctx, write_m);
     else if (bits <= 24) launch_rows_cover_t<24>(ctx, write_m);
     else {
         prof_end(ctx);

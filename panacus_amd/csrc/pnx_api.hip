@@ -284,7 +284,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -435,6 +435,37 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
     if (rc) return rc;
     return finish_upload(ctx, ctx->n_steps, w->n_paths, w->n_items, weights, nullptr, w->exc_off != nullptr,
                          item_key ? item_key : (edge_lookup ? w->edge_uv : nullptr));
+}
+
+int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes) {
+    if (!ctx) return PNX_EINVAL;
+    if (!text && text_bytes) return ctx->fail(PNX_EINVAL, "pnx_gfa_text_upload: text is NULL");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    return gfa_text_upload(ctx, text, text_bytes);
+}
+
+int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weights, const uint8_t *exclude) {
+    if (!ctx) return PNX_EINVAL;
+    if (!g || (g->n_paths && (!g->col_begin || !g->col_end || !g->is_walk)))
+        return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: NULL argument");
+    if (g->n_nodes >= 0xFFFFFFFEu || g->n_paths >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes and n_paths must be < 2^32-2");
+    const uint64_t bytes = g->text ? g->text_bytes : ctx->gfa_text_bytes;
+    if (!g->text && !ctx->d_gfa_text.p) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: no text (pass it, or call pnx_gfa_text_upload first)");
+    for (uint32_t p = 0; p < g->n_paths; ++p)
+        if (g->col_begin[p] > g->col_end[p] || g->col_end[p] > bytes)
+            return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: the step column of path %u lies outside the text", p);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    begin_upload(ctx);
+    int rc;
+    if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
+        (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
+        return rc;
+    rc = gfa_tokenise(ctx, g, nullptr);
+    release(ctx->d_gfa_text);
+    ctx->gfa_text_host = nullptr;
+    ctx->gfa_text_bytes = 0;
+    if (rc) return rc;
+    return finish_upload(ctx, ctx->n_steps, g->n_paths, g->n_nodes, weights, exclude, false, nullptr);
 }
 
 int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {

@@ -154,6 +154,11 @@ struct pnx_ctx {
     pnx::DevBuf d_flags;       // scratch flag block (upload validation)
     uint32_t last_general_paths = 0;  // scatter-route paths known to be in the order (=> M is needed)
 
+    // ---- GFA text in HBM (kernels_gfa.hip): the bytes whose step columns pnx_set_csr_gfa tokenises ----
+    pnx::DevBuf d_gfa_text;
+    const char *gfa_text_host = nullptr;  // what was uploaded (pnx_gfa_text_upload), to recognise it again
+    uint64_t gfa_text_bytes = 0;
+
     // ---- path rows: the path x item presence table (kernels_rows.hip), derived once per upload ----
     pnx::DevBuf d_rows;       // n_rows x 256 bytes: row (p, t) = the presence bits of path p on item tile t (block layout)
     pnx::DevBuf d_row_base;   // n_paths u32: row (p, t) sits at row_base[p] + t * row_tstride (modulo 2^32)
@@ -281,6 +286,11 @@ int prepare_steps(pnx_ctx *ctx);  // d_steps12 + d_path_mono (no-op when done)
 int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);  // sorted paths back in the caller's order (pnx_get_csr)
 int launch_tile_index(pnx_ctx *ctx);
 int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
+// kernels_gfa.hip
+int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes);
+int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward);  // -> d_items, d_path_off, h_path_off, n_steps
+// kernels_hist.hip
+int launch_hist(pnx_ctx *ctx, Ticket *tk);  // K2 of the pass in `tk`, on the stream of its histogram phase
 // kernels_rows.hip
 inline bool use_rows(const pnx_ctx *ctx) { return ctx->cover_variant == 3; }
 int ensure_rows(pnx_ctx *ctx, bool validate);          // d_rows & co. (no-op when they exist)

@@ -19,6 +19,10 @@
 #include "tables.hpp"
 #include "thread_pool.hpp"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
 namespace pnh {
 namespace cli {
 
@@ -51,26 +55,89 @@ const char *USAGE =
     "       panacus-amd synth --shape pggb --nodes N --samples M [--seed S] [--sequences] -o FILE.gfa\n"
     "                                        write a pggb-shaped pangenome (contig paths, inversions, duplications)\n";
 
-Device::Device(int ordinal)
-    : init_(std::async(std::launch::async, [ordinal]() -> pnx_ctx * {
-          pnx_ctx *c = nullptr;
-          const int rc = pnx_init(&c, ordinal);
-          if (rc != PNX_OK) throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
-          // quorum closed form with >= 256 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
-          // the whole closed form on the host threads; the results are the same bits either way)
-          if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(c);
-          return c;
-      })) {}
+struct Device::TextSlot {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool decided = false, uploaded = false;
+    const char *data = nullptr;
+    size_t size = 0;
+    std::shared_ptr<const void> keep;
+};
+
+Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>()) {
+    if (!expect_text) text_->decided = true;
+    std::shared_ptr<TextSlot> slot = text_;
+    init_ = std::async(std::launch::async, [ordinal, slot]() -> pnx_ctx * {
+        pnx_ctx *c = nullptr;
+        const int rc = pnx_init(&c, ordinal);
+        if (rc != PNX_OK) {
+            std::lock_guard<std::mutex> g(slot->mu);
+            slot->keep.reset();
+            throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
+        }
+        // quorum closed form with >= 256 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
+        // the whole closed form on the host threads; the results are the same bits either way)
+        if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(c);
+        phase_mark("GPU context up");
+        // the bytes of the GFA, as soon as the parser has them: copied to HBM beside the parse
+        std::unique_lock<std::mutex> lk(slot->mu);
+        slot->cv.wait(lk, [&] { return slot->decided; });
+        if (slot->data) {
+            const char *d = slot->data;
+            const size_t n = slot->size;
+            lk.unlock();
+            const bool ok = pnx_gfa_text_upload(c, d, n) == PNX_OK;  // (a failure only means: the main thread uploads again)
+            lk.lock();
+            slot->uploaded = ok;
+            slot->keep.reset();
+            phase_mark("GFA text in HBM");
+        }
+        return c;
+    });
+}
+void Device::offer_text(const char *data, size_t size, std::shared_ptr<const void> keep) const {
+    std::lock_guard<std::mutex> g(text_->mu);
+    if (text_->decided) return;
+    text_->data = data;
+    text_->size = size;
+    text_->keep = std::move(keep);
+    text_->decided = true;
+    text_->cv.notify_all();
+}
+void Device::no_text() const {
+    std::lock_guard<std::mutex> g(text_->mu);
+    if (text_->decided) return;
+    text_->decided = true;
+    text_->cv.notify_all();
+}
+bool Device::text_uploaded() const {
+    (void)ctx();
+    std::lock_guard<std::mutex> g(text_->mu);
+    return text_->uploaded;
+}
 pnx_ctx *Device::ctx() const {
     if (init_.valid()) ctx_ = init_.get();  // throws what the initialisation threw
     return ctx_;
 }
+namespace {
+std::atomic<bool> g_exit_after_command{false};
+}
+bool process_exits_after_command() { return g_exit_after_command.load(); }
+void set_process_exits_after_command(bool on) { g_exit_after_command.store(on); }
+void finish_command(std::unique_ptr<GraphStorage> &g, const Device &dev) {
+    phase_mark("table ready");
+    if (!process_exits_after_command()) return;
+    (void)g.release();
+    dev.leak();
+}
+
 Device::~Device() {
+    no_text();  // (a command that failed before it offered any: the thread must not wait for ever)
     try {
         (void)ctx();
     } catch (...) {
     }
-    if (!ctx_) return;
+    if (!ctx_ || leaked_) return;
     release_quorum_offload(ctx_);  // the next run's context may be registered already (report runner)
     pnx_free(ctx_);
 }
@@ -79,9 +146,24 @@ void Device::check(int rc) const {
 }
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
-std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges) {
+bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &cts) {
+    if (o.cache || !o.subset_file.empty() || !o.exclude_file.empty() || std::getenv("PANACUS_AMD_HOST_PARSE")) return false;
+    for (CountType c : cts)
+        if (c != COUNT_EDGE) return true;
+    return false;
+}
+
+std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev) {
+    struct Decide {  // whatever happens below, the device thread learns that no (further) text is coming
+        const Device *d;
+        ~Decide() {
+            if (d) d->no_text();
+        }
+    } decide{dev};
+    GraphStorage::TextHook hook = nullptr;
+    if (dev) hook = [dev](const char *p, size_t n, std::shared_ptr<const void> keep) { dev->offer_text(p, n, std::move(keep)); };
     // subset / exclude lists are applied while walking the path lines: they need the GFA text
-    if (!o.cache || !o.subset_file.empty() || !o.exclude_file.empty()) return GraphStorage::from_gfa(o.file, index_edges);
+    if (!o.cache || !o.subset_file.empty() || !o.exclude_file.empty()) return GraphStorage::from_gfa(o.file, index_edges, false, hook);
     const std::string cache_file = o.file + ".pcsr";
     if (auto g = GraphStorage::from_cache(cache_file, o.file, index_edges)) return g;
     auto g = GraphStorage::from_gfa(o.file, index_edges);
@@ -176,14 +258,38 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
     if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file())) {
         uncovered = upload_cut([&dev]() { return dev.ctx(); }, g, ct, mk, growth_weights);
+    } else if (ct != COUNT_EDGE && g.steps_tokenisable_on_device() && !std::getenv("PANACUS_AMD_HOST_PARSE")) {
+        // numeric segment names: the node ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is
+        // parsed on the host, no ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it
+        std::vector<uint64_t> cb, ce;
+        std::vector<uint8_t> wk;
+        g.step_columns(cb, ce, wk);
+        const bool there = dev.text_uploaded();
+        pnx_gfa_steps st{};
+        st.text = there ? nullptr : g.text_data();
+        st.text_bytes = there ? 0 : g.text_size();
+        st.n_paths = n_paths;
+        st.n_nodes = (uint32_t)n_items;
+        st.col_begin = cb.data();
+        st.col_end = ce.data();
+        st.is_walk = wk.data();
+        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
+        st.n_names = g.id_of_name().size();
+        phase_mark(there ? "columns ready (text was uploaded beside the parse)" : "columns ready");
+        dev.check(pnx_set_csr_gfa(dev.ctx(), &st, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
+        phase_mark("pnx_set_csr_gfa (tokenise + rows)");
     } else {
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
         std::vector<uint64_t> keys;  // a cached edge table: ranked by the canonical ends of its edges (pnx_set_csr_keyed)
         if (ct == COUNT_EDGE && n_items > 0) keys = g.edge_keys();
         const uint64_t *key_ptr = keys.empty() ? nullptr : keys.data();
-        dev.check(pnx_set_csr_keyed(dev.ctx(), view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
+        phase_mark("item table ready");
+        pnx_ctx *c = dev.ctx();
+        phase_mark("wait for the GPU context");
+        dev.check(pnx_set_csr_keyed(c, view.items, view.id_prefsum, n_paths, (uint32_t)n_items,
                                     ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr, key_ptr));
+        phase_mark("pnx_set_csr (H2D + rows)");
     }
     dev.check(pnx_set_order(dev.ctx(), order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
                             (uint32_t)order.groups.size()));
@@ -196,6 +302,7 @@ std::vector<uint64_t> device_hist(const Device &dev, const GraphStorage &g, Coun
     std::vector<uint64_t> hist(order.groups.size() + 1, 0);
     if (uncovered.empty()) {
         dev.check(pnx_hist(dev.ctx(), nullptr, hist.data()));
+        phase_mark("pnx_set_order + pnx_hist");
         return hist;
     }
     // "subtract uncovered bps", abacus.rs:779-785: the bp a subset interval leaves out of a node
@@ -271,8 +378,8 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     std::vector<CountType> cts = count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
-    const Device dev(o.device);  // the GPU comes up while the graph is read
-    auto g = load_graph(o, edges);
+    const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
+    auto g = load_graph(o, edges, &dev);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
@@ -281,7 +388,9 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
         cols.push_back(to_f64(hists[k]));
         headers.push_back({"hist", count_name(cts[k]), "", ""});
     }
-    return metadata_comments(cmdline) + write_table(headers, cols);
+    std::string res = metadata_comments(cmdline) + write_table(headers, cols);
+    finish_command(g, dev);
+    return res;
 }
 
 // histgrowth (and growth on a GFA, which the reference restricts to node counts)
@@ -290,8 +399,8 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     std::vector<CountType> cts = growth_cmd ? std::vector<CountType>{COUNT_NODE} : count_types(o.count, true);
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
-    const Device dev(o.device);  // the GPU comes up while the graph is read
-    auto g = load_graph(o, edges);
+    const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
+    auto g = load_graph(o, edges, &dev);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
@@ -305,7 +414,9 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
         for (auto &col : all_growths(hists[k], tc, (unsigned)o.threads)) cols.push_back(std::move(col));
         growth_headers(headers, "growth", cts[k], tc);
     }
-    return "# " + cmdline + "\n" + write_table(headers, cols);
+    std::string res = "# " + cmdline + "\n" + write_table(headers, cols);
+    finish_command(g, dev);
+    return res;
 }
 
 // growth from a hist TSV (src/lib.rs:160-190, analyses/growth.rs:190-262): no GPU involved

@@ -8,4 +8,8 @@
 namespace pnh {
 // argv[0] = program name. Returns the process exit code; tables go to `out`, diagnostics to `err`.
 int run_cli(const std::vector<std::string> &argv, std::string &out, std::string &err);
+namespace cli {
+void set_process_exits_after_command(bool on);
+}
+
 }  // namespace pnh

@@ -32,18 +32,34 @@ struct Options {
 // RAII over pnx_ctx.  pnx_init -- HIP runtime start-up, streams, code objects: 0.15-0.2 s -- runs on a thread of its own
 // from the constructor on, i.e. beside the GFA parse every command starts with; the first use of ctx() joins it and
 // rethrows an initialisation error (no GPU: no CPU fallback).
+// expect_text: the same thread then waits for the bytes of the GFA (offer_text, from GraphStorage::from_gfa's hook) and copies
+// them to HBM (pnx_gfa_text_upload) -- beside the host's line scan -- for the device tokeniser (pnx_set_csr_gfa).
 struct Device {
-    explicit Device(int ordinal);
+    explicit Device(int ordinal, bool expect_text = false);
     ~Device();
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;
     pnx_ctx *ctx() const;
     void check(int rc) const;
+    void offer_text(const char *data, size_t size, std::shared_ptr<const void> keep) const;
+    void no_text() const;            // nothing will be offered (idempotent; also after an offer: no effect)
+    void leak() const { leaked_ = true; }  // the process is about to exit: leave the context to the driver
+    bool text_uploaded() const;      // after ctx(): the offered text is in HBM
 
 private:
+    struct TextSlot;
+    std::shared_ptr<TextSlot> text_;
     mutable std::future<pnx_ctx *> init_;
     mutable pnx_ctx *ctx_ = nullptr;
+    mutable bool leaked_ = false;
 };
+// A stand-alone CLI process ends right after its one command: the command then does not tear down what the exit of the
+// process reclaims anyway -- the 2 GB mapping of the GFA, the GPU context -- and main() leaves through _exit once the table
+// is written (cli_main.cpp sets this; the in-process entry pnh_run_cli never does).
+bool process_exits_after_command();
+void set_process_exits_after_command(bool on);
+// at the end of a command: under process_exits_after_command() the graph and the device are left as they are
+void finish_command(std::unique_ptr<GraphStorage> &g, const Device &dev);
 
 struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a count type is cut down by
     GroupMode mode = GROUP_PATHID;
@@ -53,7 +69,9 @@ struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a c
 
 using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncovered_bps (abacus.rs:1187-1229)
 
-std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges);
+std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev = nullptr);
+// will this run make its node ItemTable from the raw text on the device, if the graph allows it?  (then the text is worth copying early)
+bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &cts);
 std::vector<CountType> count_types(const std::string &c, bool allow_all);
 GroupMode group_mode(const Options &o);
 Masking masking(const Options &o);

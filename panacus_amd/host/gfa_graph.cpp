@@ -421,6 +421,8 @@ struct GraphStorage::Impl {
     NameMap names;
     std::vector<Span> node_names;     // per node id - 1: the name field of its S line
     bool nice = false;                // segment names are the integers 1..N in file order
+    bool numeric_names = false;       // every segment name is a decimal number (nice, or id_of_name maps it)
+    std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
     bool has_edges = false;
     EdgeMap edges;
 
@@ -452,10 +454,14 @@ GraphStorage::GraphStorage() : impl_(std::make_shared<Impl>()) {}
 GraphStorage::~GraphStorage() = default;
 
 // GraphStorage::from_gfa (graph.rs:195-220): parse_nodes_gfa (308-375) + parse_edge_gfa (276-306)
-std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file, bool index_edges, bool /*nice*/) {
+std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file, bool index_edges, bool /*nice*/,
+                                                     const TextHook &on_text) {
     std::unique_ptr<GraphStorage> g(new GraphStorage());
     Impl &im = *g->impl_;
+    phase_mark("start from_gfa");
     im.image.open(gfa_file);
+    phase_mark("image open (mmap / inflate)");
+    if (on_text) on_text(im.image.data(), im.image.size(), std::static_pointer_cast<const void>(g->impl_));
     const Image &s = im.image;
     const size_t N = s.size();
 
@@ -508,17 +514,21 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             im.p_lines.insert(im.p_lines.end(), f.p.begin(), f.p.end());
         }
     }
+    phase_mark("line scan");
     if (s_lines.size() >= 0xFFFFFFFEull) throw std::runtime_error("more than 2^32-2 segments are not supported");
 
     // --- S lines: ids are 1-based ranks, node_lens[id] = length of the sequence column ---
     g->node_lens_.assign(s_lines.size() + 1, 0);
     std::vector<Span> name_of(s_lines.size());
-    std::atomic<bool> nice_all{true}, malformed{false};
+    std::atomic<bool> nice_all{true}, malformed{false}, numeric_all{true};
+    std::atomic<uint64_t> name_max{0};
+    std::vector<uint32_t> name_val(s_lines.size());  // the name as a number (when it is one)
     {
         const size_t BL = 1u << 16;
         const size_t nb = (s_lines.size() + BL - 1) / BL;
         ThreadPool::instance().parallel_for(nb, [&](size_t blk) {
-            bool nice = true;
+            bool nice = true, numeric = true;
+            uint64_t vmax = 0;
             const size_t k1 = std::min(s_lines.size(), (blk + 1) * BL);
             for (size_t k = blk * BL; k < k1; ++k) {
                 const Span ln = s_lines[k];
@@ -533,17 +543,25 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                 q1 = tb ? (size_t)((const char *)tb - s.data()) : ln.e;
                 if (q1 > q0 && s[q1 - 1] == '\r' && q1 == ln.e) --q1;
                 g->node_lens_[k + 1] = (uint32_t)(q1 - q0);
-                if (nice) {  // is the name exactly the decimal k+1 ?
+                {   // the name as a decimal number (no sign, no leading zero, < 2^32); nice: exactly k + 1
                     uint64_t v = 0;
-                    bool ok = ne > ln.b + 2 && s[ln.b + 2] != '0';
+                    bool ok = ne > ln.b + 2 && ne - (ln.b + 2) <= 10 && (s[ln.b + 2] != '0' || ne == ln.b + 3);
                     for (size_t i = ln.b + 2; ok && i < ne; ++i) {
-                        ok = s[i] >= '0' && s[i] <= '9' && v < 0xFFFFFFFFull;
+                        ok = s[i] >= '0' && s[i] <= '9';
                         v = v * 10 + (uint64_t)(s[i] - '0');
                     }
-                    nice = ok && v == k + 1;
+                    ok = ok && v <= 0xFFFFFFFEull;
+                    nice = nice && ok && v == k + 1;
+                    numeric = numeric && ok;
+                    name_val[k] = ok ? (uint32_t)v : 0u;
+                    if (ok && v > vmax) vmax = v;
                 }
             }
             if (!nice) nice_all.store(false);
+            if (!numeric) numeric_all.store(false);
+            uint64_t cur = name_max.load();
+            while (vmax > cur && !name_max.compare_exchange_weak(cur, vmax)) {
+            }
         });
     }
     if (malformed.load()) throw std::runtime_error("malformed S line");
@@ -558,13 +576,24 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     }
     g->node_count_ = s_lines.size();
     im.node_names = std::move(name_of);
+    // numeric names: name -> id as a plain table (the device tokeniser's lookup), when the numbers are small enough
+    im.numeric_names = !s_lines.empty() && numeric_all.load() && (im.nice || name_max.load() <= 16 * (uint64_t)s_lines.size() + 4096);
+    if (im.numeric_names && !im.nice) {
+        im.id_of_name.assign(name_max.load() + 1, 0);
+        ThreadPool::instance().parallel_for((s_lines.size() + (1u << 16) - 1) >> 16, [&](size_t blk) {
+            const size_t k1 = std::min(s_lines.size(), (blk + 1) << 16);
+            for (size_t k = blk << 16; k < k1; ++k) im.id_of_name[name_val[k]] = (uint32_t)(k + 1);  // (names are unique: checked above)
+        });
+    }
 
+    phase_mark("S lines (names, lengths)");
     // --- P / W lines: path identity + the span of the step column ---
     const size_t P = im.p_lines.size();
     g->paths_.resize(P);
     im.step_fields.resize(P);
     im.is_walk.resize(P);
-    for (size_t k = 0; k < P; ++k) {
+    // (in parallel: finding the end of a step column is a scan over the column, 2 GB in all for a chr22-sized graph)
+    ThreadPool::instance().parallel_for(P, [&](size_t k) {
         const Span ln = im.p_lines[k];
         size_t le = ln.e;
         if (le > ln.b && s[le - 1] == '\r') --le;
@@ -606,8 +635,9 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             im.step_fields[k] = {pos, field_end(s, pos, le)};
             im.is_walk[k] = 1;
         }
-    }
+    });
 
+    phase_mark("P/W headers");
     // --- L lines: edge id = rank of the first occurrence of the canonical form ---
     if (index_edges) {
         im.has_edges = true;
@@ -819,7 +849,9 @@ ItemTable GraphStorage::item_table(CountType count) const {
         return t;
     }
     Steps steps;
+    phase_mark("item_table start");
     parse_all_steps(im, paths_, node_count_, count == COUNT_EDGE, steps);
+    phase_mark("parse_all_steps");
     std::vector<uint32_t> &ids = steps.ids;
     std::vector<uint8_t> &ori = steps.ori;
     std::vector<uint64_t> &node_pref = steps.pref;
@@ -1577,6 +1609,21 @@ inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, ui
 }  // namespace
 
 bool GraphStorage::from_cache_file() const { return impl_->cached; }
+
+bool GraphStorage::steps_tokenisable_on_device() const { return !impl_->cached && impl_->numeric_names; }
+const char *GraphStorage::text_data() const { return impl_->image.data(); }
+size_t GraphStorage::text_size() const { return impl_->image.size(); }
+const std::vector<uint32_t> &GraphStorage::id_of_name() const { return impl_->id_of_name; }
+void GraphStorage::step_columns(std::vector<uint64_t> &col_begin, std::vector<uint64_t> &col_end, std::vector<uint8_t> &is_walk) const {
+    const size_t P = impl_->step_fields.size();
+    col_begin.resize(P);
+    col_end.resize(P);
+    for (size_t k = 0; k < P; ++k) {
+        col_begin[k] = impl_->step_fields[k].b;
+        col_end[k] = impl_->step_fields[k].e;
+    }
+    is_walk = impl_->is_walk;
+}
 
 namespace {
 // how each path is treated under the lists (parse_gfa_paths_walks, util.rs:240-300)

@@ -14,6 +14,7 @@
 // paths (3 or 12 columns), see masked_table().
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <string_view>
@@ -87,7 +88,21 @@ struct PathOrder {  // result of GraphMask::get_path_order + group-id assignment
 class GraphStorage {
 public:
     // throws std::runtime_error on malformed input (the reference panics)
-    static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false);
+    // on_text: called as soon as the bytes of the GFA are in memory (mapped, or inflated) with (data, size, keep) -- before
+    // any line has been looked at -- so that a caller can start copying them to the device beside the parse; the bytes
+    // stay valid for as long as the caller holds `keep`, whatever happens to the GraphStorage
+    using TextHook = std::function<void(const char *, size_t, std::shared_ptr<const void>)>;
+    static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false,
+                                                  const TextHook &on_text = nullptr);
+
+    // ---- for the device tokeniser (pnx_set_csr_gfa): the text and where the step columns are ----
+    // true iff every segment name is a decimal number (the names 1..N in file order, or any numbers small enough for a
+    // table): the node ItemTable can then be made from the raw text on the device
+    bool steps_tokenisable_on_device() const;
+    const char *text_data() const;
+    size_t text_size() const;
+    void step_columns(std::vector<uint64_t> &col_begin, std::vector<uint64_t> &col_end, std::vector<uint8_t> &is_walk) const;
+    const std::vector<uint32_t> &id_of_name() const;  // empty: the name is the id
 
     uint64_t node_count() const { return node_count_; }
     uint64_t edge_count() const { return edge_count_; }

@@ -51,6 +51,10 @@ unsigned ThreadPool::usable_cpus() {
 
 ThreadPool::ThreadPool() {
     unsigned n = usable_cpus();
+    // under a CPU quota the pool leaves room for the threads beside it: the one that brings the GPU up and copies the
+    // GFA text to it while the pool parses (commands.cpp), the HIP runtime's own.  One busy thread too many and the whole
+    // cgroup -- that thread included -- is throttled for the rest of the period.
+    if (n > 4 && n < std::max(1u, std::thread::hardware_concurrency())) n -= 2;
     if (const char *e = std::getenv("PANACUS_AMD_THREADS")) {
         int v = std::atoi(e);
         if (v > 0) n = (unsigned)v;
@@ -163,6 +167,19 @@ void ThreadPool::parallel_for(size_t n_tasks, const std::function<void(size_t)> 
         std::swap(err, first_error_);
     }
     if (err) std::rethrow_exception(err);
+}
+
+void phase_mark(const char *what) {
+    static const bool on = std::getenv("PANACUS_AMD_HOST_TIMING") != nullptr;
+    if (!on) return;
+    static std::mutex mu;
+    static auto t_prev = std::chrono::steady_clock::now(), t0 = t_prev;
+    std::lock_guard<std::mutex> g(mu);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[host phase] %-34s %9.3f ms  (at %9.3f ms)\n", what,
+                 std::chrono::duration<double, std::milli>(now - t_prev).count(),
+                 std::chrono::duration<double, std::milli>(now - t0).count());
+    t_prev = now;
 }
 
 }  // namespace pnh

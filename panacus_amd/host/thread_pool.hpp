@@ -50,4 +50,7 @@ private:
     std::exception_ptr first_error_;  // the first exception a task of the current job threw; rethrown by parallel_for
 };
 
+// PANACUS_AMD_HOST_TIMING=1: one stderr line per phase of the host front end (ms since the previous mark)
+void phase_mark(const char *what);
+
 }  // namespace pnh

@@ -1,0 +1,91 @@
+"""pnx_set_csr_gfa: the step columns of P / W lines tokenised on the device (csrc/kernels_gfa.hip) against a plain
+Python split of the same text -- what parse_path_seq_to_item_vec / parse_walk_seq_to_item_vec
+(src/graph_broker/util.rs:1021-1091) produce on the host -- and the histogram on top against the oracle."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from panacus_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _gfa_text(rng, n_nodes, n_paths, names, walk_share=0.3, long_path=None):
+    """-> (text bytes, col_begin, col_end, is_walk, expected steps per path); names[i] = decimal name of node id i + 1"""
+    parts = [b"H\tVN:Z:1.1\n"]
+    pos = len(parts[0])
+    cb, ce, wk, exp = [], [], [], []
+    for p in range(n_paths):
+        ln = int(rng.integers(1, 400)) if p != long_path else 60_000   # one path far longer than a 16 KB piece
+        ids = rng.integers(1, n_nodes + 1, size=ln)
+        if p % 7 == 3:
+            ids = np.sort(ids)
+        back = rng.random(ln) < 0.3
+        walk = rng.random() < walk_share
+        if walk:
+            head = f"W\ts{p}\t1\tctg\t0\t{ln}\t".encode()
+            col = "".join(("<" if b else ">") + names[i - 1] for i, b in zip(ids, back)).encode()
+            tail = b"\n"
+        else:
+            head = f"P\ts{p}#1#c{p}\t".encode()
+            col = ",".join(names[i - 1] + ("-" if b else "+") for i, b in zip(ids, back)).encode()
+            tail = b"\t*\n"
+        cb.append(pos + len(head))
+        ce.append(pos + len(head) + len(col))
+        wk.append(1 if walk else 0)
+        exp.append(ids.astype(np.uint32))
+        parts += [head, col, tail]
+        pos += len(head) + len(col) + len(tail)
+    return b"".join(parts), np.array(cb, np.uint64), np.array(ce, np.uint64), np.array(wk, np.uint8), exp
+
+
+@pytest.mark.parametrize("nice", [True, False])
+@pytest.mark.parametrize("upload_first", [False, True])
+def test_step_columns_tokenised_on_the_device(ctx, nice, upload_first):
+    rng = np.random.default_rng(5 + nice)
+    n, P = 9000, 60
+    if nice:
+        names = [str(i) for i in range(1, n + 1)]
+        table = None
+    else:   # numeric names in another order, with gaps: the table maps name -> id
+        vals = rng.permutation(4 * n)[:n] + 1
+        names = [str(int(v)) for v in vals]
+        table = np.zeros(4 * n + 2, dtype=np.uint32)
+        table[vals] = np.arange(1, n + 1, dtype=np.uint32)
+    text, cb, ce, wk, exp = _gfa_text(rng, n, P, names, long_path=17)
+    lens = rng.integers(1, 50, size=n + 1).astype(np.uint32)
+    ctx.set_csr_gfa(text, cb, ce, wk, n, id_of_name=table, weights=lens, upload_first=upload_first)
+    items, off, _ = ctx.get_csr()
+    want = np.concatenate(exp)
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum([len(e) for e in exp])]).astype(np.uint64))
+    assert np.array_equal(items, want)
+    pi = np.arange(P, dtype=np.uint64)
+    gi = (pi // 3).astype(np.uint64)
+    ctx.set_order(pi, gi, P // 3)
+    cnt, h = ctx.hist()
+    ocov = orc.coverage(want.astype(np.uint64), off, pi, gi, n)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 3, lens))
+
+
+@pytest.mark.parametrize("bad", ["name", "unknown", "sign", "empty", "walk", "zero"])
+def test_malformed_steps_fail_the_call(ctx, bad):
+    from panacus_amd import capi
+    n = 50
+    col = {"name": b"1+,2-,s3+,4+", "unknown": b"1+,51+,2+", "sign": b"1+,2,3+", "empty": b"1+,,3+", "walk": b">1<2>x3", "zero": b"1+,0+"}[bad]
+    text = b"P\tp\t" + col + b"\t*\n"
+    cb, ce = np.array([4], np.uint64), np.array([4 + len(col)], np.uint64)
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(text, cb, ce, np.array([1 if bad == "walk" else 0], np.uint8), n)
+    assert e.value.code == capi.PNX_EINVAL
+    with pytest.raises(capi.PnxError):
+        ctx.hist()   # nothing is resident after a rejected upload
+    # ... and a column outside the text is refused before anything is touched
+    with pytest.raises(capi.PnxError):
+        ctx.set_csr_gfa(text, cb, ce + np.uint64(100), np.array([0], np.uint8), n)
