@@ -1611,6 +1611,7 @@ inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, ui
 bool GraphStorage::from_cache_file() const { return impl_->cached; }
 
 bool GraphStorage::steps_tokenisable_on_device() const { return !impl_->cached && impl_->numeric_names; }
+bool GraphStorage::names_are_ranks() const { return impl_->cached || impl_->nice; }
 const char *GraphStorage::text_data() const { return impl_->image.data(); }
 size_t GraphStorage::text_size() const { return impl_->image.size(); }
 const std::vector<uint32_t> &GraphStorage::id_of_name() const { return impl_->id_of_name; }

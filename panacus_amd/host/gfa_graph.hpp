@@ -103,6 +103,9 @@ public:
     size_t text_size() const;
     void step_columns(std::vector<uint64_t> &col_begin, std::vector<uint64_t> &col_end, std::vector<uint8_t> &is_walk) const;
     const std::vector<uint32_t> &id_of_name() const;  // empty: the name is the id
+    // every segment name is the decimal rank of its S line (1..N in file order): what the reference's `nice: true`
+    // (graph.rs:224-229: the name parsed as an integer IS the id) needs to mean the same graph.  Unknown (true) for a cache.
+    bool names_are_ranks() const;
 
     uint64_t node_count() const { return node_count_; }
     uint64_t edge_count() const { return edge_count_; }

@@ -424,6 +424,7 @@ struct RunState {
     const Options &opts;
     std::string cmdline;
     std::unique_ptr<GraphStorage> graph;
+    bool graph_names_are_ranks() const { return graph && graph->names_are_ranks(); }
     std::vector<CountType> built;  // the count types GraphBroker::from_gfa builds for this run
     std::string order_file;        // Task::OrderChange persists for the rest of the run
     std::unique_ptr<Device> dev;
@@ -667,9 +668,13 @@ std::string run_all(std::vector<Run> runs, const Options &o, const std::string &
                                  "(the reference's `panacus render` turns JSON files into the HTML page) or --dry-run");
     std::vector<Section> sections;
     for (const Run &r : runs) {
-        if (r.nice) throw std::runtime_error("nice: true (integer segment names used as ids) is not supported");
         RunState st(r, o, cmdline);
         st.prepare();
+        // nice: true (graph.rs:224-229): the reference takes a segment's name, parsed as an integer, for its id while node
+        // lengths stay indexed by the rank of the S line -- the same graph only if the names ARE the ranks 1..N, which is
+        // also what this build detects by itself (and then converts names without a lookup, on the host and on the device)
+        if (r.nice && !st.graph_names_are_ranks())
+            throw std::runtime_error("nice: true needs segment names that are the integers 1..N in the order of the S lines (" + r.graph + ")");
         for (const Analysis &a : r.analyses) {
             switch (a.kind) {
                 case A_HIST: st.hist_sections(sections); break;

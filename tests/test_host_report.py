@@ -244,3 +244,37 @@ def test_json_flag_of_the_classic_subcommands():
     assert json.loads(out)[0]["items"][0]["MultiBar"]["values"] == [[89.0, 106.0, 140.0, 154.0]]
     rc, out, err = hl.run_cli(["table", "--json", CHRM])
     assert rc != 0 and "--json is available" in err
+
+
+@pytest.mark.gpu
+def test_report_nice_true_needs_rank_names(tmp_path):
+    """`nice: true` (graph.rs:224-229: a segment's name, parsed as an integer, is its id): accepted where the names are
+    the ranks 1..N of the S lines -- the same graph, the same sections as without the flag -- and refused elsewhere,
+    where the reference would index node lengths with ids that are not ranks"""
+    import json
+    ok = tmp_path / "ranks.gfa"
+    ok.write_text("H\tVN:Z:1.1\nS\t1\tACGT\nS\t2\tA\nS\t3\tGG\nL\t1\t+\t2\t+\t0M\nL\t2\t+\t3\t+\t0M\n"
+                  "P\ta#1#c\t1+,2+,3+\t*\nP\tb#1#c\t1+,3+\t*\n")
+    other = tmp_path / "other.gfa"
+    other.write_text(ok.read_text().replace("S\t3\t", "S\t7\t").replace("3+", "7+").replace("\t3\t", "\t7\t"))
+    outs = []
+    for nice in ("true", "false"):
+        cfg = tmp_path / f"r_{nice}.yaml"
+        cfg.write_text(f"- graph: {ok}\n  nice: {nice}\n  analyses:\n    - !Hist\n      count_type: Bp\n")
+        rc, out, err = hl.run_cli(["report", "--json", str(cfg)])
+        assert rc == 0, err
+        outs.append(json.loads(out))
+
+    def numbers(x):  # every list of numbers in the sections, in order: the plotted data
+        if isinstance(x, list) and x and all(isinstance(v, (int, float)) for v in x):
+            return [x]
+        if isinstance(x, list):
+            return [y for v in x for y in numbers(v)]
+        if isinstance(x, dict):
+            return [y for v in x.values() for y in numbers(v)]
+        return []
+    assert numbers(outs[0]) == numbers(outs[1]) and numbers(outs[0])
+    cfg = tmp_path / "bad.yaml"
+    cfg.write_text(f"- graph: {other}\n  nice: true\n  analyses:\n    - !Hist\n      count_type: Bp\n")
+    rc, out, err = hl.run_cli(["report", "--json", str(cfg)])
+    assert rc != 0 and "nice: true needs segment names" in err
