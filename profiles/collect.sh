@@ -4,7 +4,7 @@
 # --kernel-trace + counters of one block each; no trace domains mixed in).  Results land in
 # gpurun_out/profiles/ and are copied into profiles/ by hand.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -61,27 +61,27 @@ for C in "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_C
 done
 
 # 5. the side benches
-timeout 600 python $REPO/benchmarks/bench_tile_index.py --coarse 8 --probe 16,32 > $OUT/${R}_tile_index_bench.jsonl 2>/dev/null
-timeout 300 $REPO/benchmarks/micro/random_sector_rate > $OUT/${R}_random_sector_rate.jsonl 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_rows.py --steps 30 > $OUT/${R}_rows_cfg3_bench.json 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_rows.py --paths 1024 --steps 10 --splits 0 > $OUT/${R}_rows_10Mx1024_bench.json 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_closed_form.py > $OUT/${R}_closed_form_bench.json 2>/dev/null
+for N in 256 1024; do
+    rm -rf /tmp/p_cf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cf -o cf -- python $REPO/benchmarks/bench_closed_form.py $N > /dev/null 2>&1
+    python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cf)" $OUT/${R}_closed_form_n${N}_kernel_stats.csv > /dev/null
+done
 timeout 600 python $REPO/benchmarks/bench_gfa_end_to_end.py 1000000 64 > $OUT/${R}_gfa_end_to_end.jsonl 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_gfa_end_to_end.py 4000000 128 >> $OUT/${R}_gfa_end_to_end.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_run_route.py > $OUT/${R}_run_route_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_contig_paths.py > $OUT/${R}_contig_paths_bench.json 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py > $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_similarity.py --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
-timeout 600 python $REPO/benchmarks/bench_similarity.py --variant 0 >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
-timeout 600 python $REPO/benchmarks/bench_similarity.py --variant 0 --bp >> $OUT/${R}_similarity_cfg4_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_edge_counts.py > $OUT/${R}_edge_counts_bench.jsonl 2>/dev/null
 timeout 600 python $REPO/benchmarks/bench_subset_cut.py > $OUT/${R}_subset_cut_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_pggb_shape.py > $OUT/${R}_pggb_shape_bench.json 2>/dev/null
-# 5b. which kernels a pggb-shaped graph of chr22's size takes (contig paths, back-steps: tile route + run index) -- the CLI under rocprofv3
-PGGB=/tmp/pggb_collect.gfa
-timeout 300 $REPO/panacus_amd/panacus-amd synth --shape pggb --nodes 3760000 --samples 44 -o $PGGB > /dev/null 2>&1
+# 5b. the chr22-shaped graph through the CLI: whole-process times with the host's phases, then its kernels under rocprofv3
+timeout 600 bash $REPO/tools/pggb_time.sh > $OUT/${R}_pggb_cli_phases.txt 2>&1
 rm -rf /tmp/p_cli; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cli -o cli -- \
-    $REPO/panacus_amd/panacus-amd histgrowth -S -q 0,0.5,1.0 -l 0,1,2 $PGGB > /dev/null 2>&1
+    $REPO/panacus_amd/panacus-amd histgrowth -S -q 0,0.5,1.0 -l 0,1,2 /tmp/pg/pggb.gfa > /dev/null 2>&1
 python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cli)" $OUT/${R}_pggb_cli_kernel_stats.csv > /dev/null
-rm -f $PGGB
-
-# 6. two lanes over one resident graph (documented alternative, not the headline)
-timeout 600 python $REPO/bench.py --lanes 2 $HEAD_ONLY > $OUT/${R}_hist_cfg3_lanes2_bench.json 2>/dev/null
+timeout 120 $REPO/benchmarks/micro/h2d_rate /tmp/pg/pggb.gfa 16 > $OUT/${R}_h2d_rate.json 2>/dev/null
+rm -rf /tmp/pg
 ls -la $OUT
