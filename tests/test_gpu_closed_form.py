@@ -210,3 +210,33 @@ def test_closed_forms_follow_the_pass_on_the_device(ctx):
         hostlib.set_quorum_offload(None)
         ctx.sync()
         ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
+
+
+def test_reference_vectors_through_the_device_closed_forms(ctx, golden):
+    """the reference's own numbers for hist -> growth -- the three exact-equality f64 vectors of hist.rs:352-398 and the 660
+    floored values of docs/chr22.hprc-v1.0-pggb.histgrowth.html:266-276 -- with every log2 / exp2 / addition taken on the GPU"""
+    import math
+    from panacus_amd import hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    hostlib.set_quorum_offload(ctx, min_n=1)
+    try:
+        ka = golden["growth_known_answers"]
+        # (the reference's tests call the three branch functions directly; so does this, through the ABI: branch 0 / 1 / 2,
+        # coverage max(1, 0) = 1)
+        for branch, kind in enumerate(("union", "core", "quorum")):
+            k = ka[kind]
+            n = len(k["hist"]) - 1
+            shape = ctx.growth_closed_form_async(k["hist"], n, [branch], [1], [k.get("quorum", 0.0)])
+            assert ctx.growth_closed_form_fetch(shape)[0].tolist() == k["expected"], kind
+        rep = golden["chr22_report"]
+        n_vals = 0
+        for count in ("bp", "node", "edge"):
+            h = np.array(rep["hists"][count], dtype=np.uint64)
+            gr = rep["growths"][count]
+            thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in zip(gr["coverage"], gr["quorum"])]
+            for got, curve in zip(hostlib.calc_growths(h, thr), gr["curves"]):
+                assert [int(math.floor(x)) for x in got] == curve
+                n_vals += len(curve)
+        assert n_vals == 660
+    finally:
+        hostlib.set_quorum_offload(None)
