@@ -383,9 +383,15 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
  *   hist   n+1 bins on the host, or NULL: the device counters of the coverage pass enqueued LAST (n must be the number of
  *          groups) -- the curves then follow the pass without the histogram ever visiting the host
  *   out    n_pairs x n values: out[t*n + m-1] = growth at m groups (the reference's vector without its leading NaN)
- * _async enqueues the work on a stream of its own (inputs are copied before it returns); up to PNX_CFG_MAX_IN_FLIGHT calls may be in flight
- * (two once the quorum branch's scratch passes 1 GiB per call: n > 511);
- * _fetch waits for the OLDEST one. */
+ * _async enqueues the work on a stream of its own (inputs are copied before it returns); PNX_CFG_MAX_IN_FLIGHT + 1 calls may
+ * be in flight -- one more than passes, so that a host enqueues pass i + k and its call before it fetches the curves of pass
+ * i; _fetch waits for the OLDEST one.
+ * Everything in the closed forms that does not depend on the histogram -- the log2 table, the running sums n_fall / m_fact,
+ * perc_mult[i][m], and the quorum branch's inner sums over j (hist.rs:164-176), O(n^3) of the work -- is a function of (n, pairs)
+ * alone and is kept by the context as tables (8 (n+1)^2 bytes per pair, twice that with a quorum pair, plus 8 (n+1)^3 bytes of
+ * scratch that the inner sums were built in) until a call arrives with other arguments: a call with the kept arguments is one
+ * kernel that reads the tables.  A call with other arguments first waits for the calls in flight.  Same arithmetic, same order
+ * of operations either way. */
 enum { PNX_GROWTH_UNION = 0, PNX_GROWTH_CORE = 1, PNX_GROWTH_QUORUM = 2 };
 #define PNX_GROWTH_MAX_N 2048
 #define PNX_GROWTH_MAX_PAIRS 16
@@ -465,10 +471,12 @@ enum {
     PNX_CFG_ROWS_LAYOUT = 17,  /* layout of the path rows: 0 [default] chosen from the shape, 1 tile-major over all
                                   (tile, path) pairs, 2 path-major over the tiles each path spans.  Takes effect when the
                                   rows are next derived */
-    PNX_CFG_MAX_IN_FLIGHT = 19, /* coverage passes (pnx_hist_async) and closed-form calls (pnx_growth_closed_form_async) that may
-                                  be in flight at once: 1 .. PNX_MAX_IN_FLIGHT [2].  Each pass in flight owns a coverage vector
+    PNX_CFG_MAX_IN_FLIGHT = 19, /* coverage passes (pnx_hist_async) that may be in flight at once: 1 .. PNX_MAX_IN_FLIGHT [2]
+                                  (closed-form calls, pnx_growth_closed_form_async: one more).  Each pass in flight owns a coverage vector
                                   (4 (n_items + 1) bytes) and its counters; a host whose per-pass latency (pass + closed forms
                                   + its own work) exceeds the duration of a pass keeps more of them in flight */
+    PNX_CFG_DROP_GROWTH_TABLES = 20, /* (value ignored) forget the (n, thresholds) tables of pnx_growth_closed_form_async; the next
+                                  call derives them again.  Measurement only */
     PNX_CFG_DROP_DERIVED = 18, /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
                                   tile index); the next pass or pnx_prepare derives it again.  Measurement only */
 };
@@ -493,6 +501,7 @@ typedef struct {
     uint32_t rows_tile_major;/* layout of the path rows: 1 tile-major over all (tile, path) pairs, 0 path-major over the spans */
     uint64_t n_rows;         /* path rows resident (256 bytes each; 0 until they are derived) */
     uint64_t n_rows_in_order;/* rows one pass over the current visiting order reads (sum of the tile spans of its paths) */
+    uint64_t n_growth_table_builds; /* times pnx_growth_closed_form_async derived its (n, thresholds) tables */
 } pnx_info_t;
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
 

@@ -203,25 +203,28 @@ static int launch_quorum_sums(pnx_ctx *ctx, hipStream_t st, DevBuf &d_terms, uin
 // ------------------------------------------------------------------------------------------
 // K9: the closed forms themselves -- Hist::calc_growth_union / _core / _quorum (hist.rs:89-187) -- on the device,
 // from the histogram to the growth values, in the reference's order of operations with the restated log2 / exp2.
-//   k_cf_setup   L[v] = log2(v) for v = 0 .. 2n+1 (:21-36, :104, :129, :171-172), lh[i] = log2(hist[i]) (:106); per threshold
-//                pair, one lane: n_fall, m_fact (running sums :100, :125, :148-149), m_quorum (:150), tot (:95-97)
-//   k_cf_rows    one lane per histogram index i walks m: perc_mult and the ARGUMENT of the term's exp2 (:102-108, :127-133, :157-160)
-//   k_cf_exp2    the exp2 of every term, one lane per (i, m)
-//   (quorum pairs: K7a, K7b above for the inner sums, then)
-//   k_cf_term2   exp2(log2(hist[i]) + log2(sum_q)) per (i, m) (:178-180)
-//   k_cf_finish  one lane per m adds its terms in ascending i (:107, :132, :159, :180) and closes the value (:110, :135, :183)
-// Term arrays are [i][m]: every kernel reads and writes whole lines (the row walk through an LDS tile).
+// Everything in them that does NOT depend on the histogram is a function of (n, threshold pairs) alone and is kept in
+// the context as "growth tables" until a call comes with other arguments:
+//   k_cf_setup   L[v] = log2(v) for v = 0 .. 2n+1 (:21-36, :104, :129, :171-172); per threshold pair n_fall, m_fact
+//                (running sums :100, :125, :148-149), m_quorum (:150)
+//   k_cf_rows    perc_mult[i][m]: one lane per histogram index i walks m (:102-104, :127-129, :157-158)
+//   K7a, K7b     (quorum pairs) the inner sums over j (:164-176), then
+//   k_cf_lsq     log2(sum_q[i][m]) (:178), NaN where no j was admissible
+// A call with a histogram is then ONE kernel:
+//   k_cf_eval    lh[i] = log2(hist[i]) (:106), tot (:95-97); one lane per m adds exp2((lh[i] + perc_mult[i][m]) - n_fall[m])
+//                (:105-107, :130-132, :159) and, quorum, exp2(lh[i] + lsq[i][m]) (:178-180) in ascending i, and closes the
+//                value (:110, :135, :183).  The exp2 of a term is evaluated by the waves that fetch it, off the chain of
+//                additions.
+// Table arrays are [i][m]: every kernel reads and writes whole lines (the row walk through an LDS tile).
 // ------------------------------------------------------------------------------------------
 enum { CF_UNION = PNX_GROWTH_UNION, CF_CORE = PNX_GROWTH_CORE, CF_QUORUM = PNX_GROWTH_QUORUM };
 
 // one workgroup: the log2 tables, then the two running sums -- the only sequential part: lane 0 walks n_fall, lane 1
 // m_fact, nothing but one LDS read, one addition and one LDS write per step (they depend on n alone, so every pair gets
 // a copy) -- then everything per (pair, m) in parallel again
-__global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, const uint64_t *__restrict__ hist, double *__restrict__ L,
-                                                  double *__restrict__ lh, const uint32_t *__restrict__ branch,
-                                                  const uint32_t *__restrict__ cov, const double *__restrict__ quorum,
-                                                  double *__restrict__ n_fall, double *__restrict__ m_fact,
-                                                  uint32_t *__restrict__ m_quorum, double *__restrict__ tot) {
+__global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, double *__restrict__ L, const uint32_t *__restrict__ branch,
+                                                  const double *__restrict__ quorum, double *__restrict__ n_fall,
+                                                  double *__restrict__ m_fact, uint32_t *__restrict__ m_quorum) {
     extern __shared__ double s_dyn[];  // L: 2 (n + 1) values | n_fall: n + 1 | m_fact: n + 1
     __shared__ uint64_t s_log2[274];
     const uint32_t np1 = n + 1, nl = 2 * np1;
@@ -233,7 +236,6 @@ __global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, 
         s_L[v] = x;
         L[v] = x;
     }
-    for (uint32_t i = threadIdx.x; i <= n; i += 256) lh[i] = pnx_exp2::log2_exact((double)hist[i], s_log2);
     __syncthreads();
     if (threadIdx.x < 2) {
         // hist.rs:100 / :125 / :148: n_fall += log2(n - m + 1); :149: m_fact += log2(m).  Sixteen table values at a time
@@ -267,19 +269,6 @@ __global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, 
         m_fact[k] = quo ? s_mf[m] : 0.0;
         m_quorum[k] = quo && m ? (uint32_t)ceil(pnx_exp2::mul((double)m, quorum[t])) : 0u;  // hist.rs:150
     }
-    // hist.rs:95-97: tot = sum of hist[c..] as integers (exact in any order), converted once
-    __shared__ unsigned long long s_tot[PNX_GROWTH_MAX_PAIRS];
-    if (threadIdx.x < n_pairs) s_tot[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t t = 0; t < n_pairs; ++t) {
-        if (branch[t] != CF_UNION) continue;
-        unsigned long long part = 0;
-        for (uint32_t i = cov[t] + threadIdx.x; i <= n; i += 256) part += hist[i];
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if ((threadIdx.x & 63) == 0 && part) atomicAdd(&s_tot[t], part);
-    }
-    __syncthreads();
-    if (threadIdx.x < n_pairs) tot[threadIdx.x] = (double)s_tot[threadIdx.x];
 }
 
 // One wave = 64 histogram indices i of one pair.  A lane walks m and keeps perc_mult -- the one sequential quantity: a
@@ -339,46 +328,31 @@ __global__ __launch_bounds__(64) void k_cf_rows(uint32_t n, const double *__rest
     }
 }
 
-// term1[t][i][m] <- exp2((log2 h[i] + perc_mult[i][m]) - n_fall[m]) where (i, m) is an entry the sums will read
-// (hist.rs:105-106, :130-131, :159)
-__global__ __launch_bounds__(256) void k_cf_exp2(uint32_t n, const uint32_t *__restrict__ branch, const uint32_t *__restrict__ cov,
-                                                 const double *__restrict__ lh, const double *__restrict__ n_fall,
-                                                 double *__restrict__ term1) {
-    __shared__ uint64_t s_exp2[256];
-    s_exp2[threadIdx.x] = c_exp2_tab[threadIdx.x];
-    __syncthreads();
-    const uint32_t m = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, t = blockIdx.z;
-    const size_t np1 = (size_t)n + 1;
-    if (m < 1 || m > n || i < cov[t]) return;
-    if (branch[t] == CF_UNION ? i + m > n : m > i) return;
-    double *p = term1 + t * np1 * np1 + (size_t)i * np1 + m;
-    *p = pnx_exp2::exp2_exact(pnx_exp2::sub(pnx_exp2::add(lh[i], *p), n_fall[t * np1 + m]), s_exp2);
-}
-
-// term2[i][m] = exp2(log2 h[i] + log2 sum_q[i][m]), NaN where no j was admissible
-__global__ __launch_bounds__(256) void k_cf_term2(uint32_t n, const double *__restrict__ lh, const double *__restrict__ sum_q,
-                                                  double *__restrict__ term2) {
-    __shared__ uint64_t s_exp2[256];
+// lsq[i][m] = log2(sum_q[i][m]) (hist.rs:178), NaN where no j was admissible (sum_q is NaN there)
+__global__ __launch_bounds__(256) void k_cf_lsq(uint32_t n, const double *__restrict__ sum_q, double *__restrict__ lsq) {
     __shared__ uint64_t s_log2[274];
-    s_exp2[threadIdx.x] = c_exp2_tab[threadIdx.x];
     for (uint32_t k = threadIdx.x; k < 274; k += 256) s_log2[k] = c_log2_tab[k];
     __syncthreads();
     const uint32_t m = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     const size_t np1 = (size_t)n + 1;
-    if (m < 1 || m > n || i >= n) return;
+    if (m > n) return;
     const double sq = sum_q[i * np1 + m];
-    term2[i * np1 + m] = sq == sq ? pnx_exp2::exp2_exact(pnx_exp2::add(lh[i], pnx_exp2::log2_exact(sq, s_log2)), s_exp2)
-                                  : pnx_exp2::as_f64(0x7ff8000000000000ull);
+    lsq[i * np1 + m] = sq == sq && m >= 1 && i < n ? pnx_exp2::log2_exact(sq, s_log2) : pnx_exp2::as_f64(0x7ff8000000000000ull);
 }
 
 // One lane per m adds its terms in ascending i -- the reference's order.  The sum is a chain of dependent additions, so
-// the memory latency must stay off it: a workgroup of 4 waves serves 64 values of m; all four fetch the next 128 rows
-// of the column strip ([i][m] layout: whole 512-byte lines) into registers and park them in LDS, while the first wave
-// walks the previous 128 rows out of LDS, one addition per step.
-constexpr int CF_CHUNK = 128;  // rows per LDS buffer (2 buffers x 128 x 64 x 8 B = 128 KB)
+// the memory latency and the exp2 of the terms must stay off it: a workgroup of 8 waves serves 64 values of m; all eight
+// fetch the next 32 rows of the column strip of a table ([i][m] layout: whole 512-byte lines) into registers, turn them
+// into terms and park them in LDS, while the first wave walks the previous 32 rows out of LDS, one addition per step.
+// (32 KB of buffers: the workgroup must find room on a CU beside the workgroups of a coverage pass, which leave about
+// 110 KB of its LDS free -- with 128-row buffers, 128 KB, it could only start when a pass had ended.)
+constexpr int CF_CHUNK = 32;  // rows per LDS buffer (2 buffers x 32 x 64 x 8 B = 32 KB)
+constexpr int CF_WAVES = 8;
 
+// term of row i from the table value v:  QUORUM_PART ? exp2(lh[i] + v), skipped where v is NaN  :  exp2((lh[i] + v) - nf)
+template <bool QUORUM_PART>
 __device__ static inline double cf_column_sum(const double *__restrict__ col, size_t ld, uint32_t lo, uint32_t hi, uint32_t n_rows,
-                                              bool skip_nan, double *buf /* 2 x CF_CHUNK x 64 */) {
+                                              const double *s_lh, double nf, const uint64_t *s_exp2, double *buf /* 2 x CF_CHUNK x 64 */) {
     __shared__ uint32_t s_range[2];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // [lo, hi) of this lane (wave 0 holds the lanes' ranges); the workgroup walks the union
@@ -396,7 +370,7 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
     const uint32_t wlo = s_range[0], whi = s_range[1];
     double y = 0.0;
     if (wlo >= whi) return y;
-    constexpr int RPW = CF_CHUNK / 4;  // rows per wave and chunk
+    constexpr int RPW = CF_CHUNK / CF_WAVES;  // rows per wave and chunk
     double v[RPW];
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
@@ -405,14 +379,19 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
             v[k] = col[(size_t)(i < n_rows ? i : n_rows - 1) * ld];  // unconditional, at a clamped row
         }
     };
-    // parked already masked (outside the lane's range, or NaN = "no admissible j": +0.0, and y + 0.0 is y -- y is never
-    // -0.0: it starts at +0.0 and the terms are >= +0.0), so that the walk is one LDS read and one addition per step
+    // parked as terms, already masked (outside the lane's range, or NaN = "no admissible j": +0.0, and y + 0.0 is y -- y is
+    // never -0.0: it starts at +0.0 and the terms are >= +0.0), so that the walk is one LDS read and one addition per step
     auto park = [&](double *b, uint32_t i0) {
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             const uint32_t i = i0 + wave * RPW + (uint32_t)k;
-            const bool on = i >= lo && i < hi && (!skip_nan || v[k] == v[k]);
-            b[(wave * RPW + (uint32_t)k) * 64 + lane] = on ? v[k] : 0.0;
+            const bool on = i >= lo && i < hi && (!QUORUM_PART || v[k] == v[k]);
+            double term = 0.0;
+            if (on) {
+                const double a = pnx_exp2::add(s_lh[i], v[k]);
+                term = pnx_exp2::exp2_exact(QUORUM_PART ? a : pnx_exp2::sub(a, nf), s_exp2);
+            }
+            b[(wave * RPW + (uint32_t)k) * 64 + lane] = term;
         }
     };
     fetch(wlo);
@@ -424,7 +403,7 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
         if (more) fetch(i0 + CF_CHUNK);
         if (wave == 0) {
             const double *b = buf + which * (CF_CHUNK * 64);
-#pragma unroll 32
+#pragma unroll
             for (uint32_t k = 0; k < (uint32_t)CF_CHUNK; ++k) y = pnx_exp2::add(y, b[k * 64 + lane]);
         }
         if (more) park(buf + (which ^ 1u) * (CF_CHUNK * 64), i0 + CF_CHUNK);
@@ -433,28 +412,45 @@ __device__ static inline double cf_column_sum(const double *__restrict__ col, si
     return y;
 }
 
-__global__ __launch_bounds__(256) void k_cf_finish(uint32_t n, const uint32_t *__restrict__ branch, const uint32_t *__restrict__ cov,
-                                                   const uint32_t *__restrict__ m_quorum, const double *__restrict__ tot,
-                                                   const double *__restrict__ term1, const double *__restrict__ term2,
-                                                   double *__restrict__ out) {
+// dynamic LDS: 2 x CF_CHUNK x 64 doubles of term buffers, then lh[0 .. n]
+__global__ __launch_bounds__(64 * CF_WAVES) void k_cf_eval(uint32_t n, const uint64_t *__restrict__ hist, const uint32_t *__restrict__ branch,
+                                                           const uint32_t *__restrict__ cov, const uint32_t *__restrict__ m_quorum,
+                                                           const double *__restrict__ n_fall, const double *__restrict__ pm,
+                                                           const double *__restrict__ lsq, double *__restrict__ out) {
     extern __shared__ double s_buf[];
+    __shared__ uint64_t s_exp2[256];
+    __shared__ uint64_t s_log2[274];
+    __shared__ unsigned long long s_tot;
+    double *s_lh = s_buf + 2 * CF_CHUNK * 64;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t m_raw = blockIdx.x * 64 + lane + 1, t = blockIdx.y;
+    const uint32_t c = cov[t], br = branch[t];
+    for (uint32_t k = threadIdx.x; k < 256; k += blockDim.x) s_exp2[k] = c_exp2_tab[k];
+    for (uint32_t k = threadIdx.x; k < 274; k += blockDim.x) s_log2[k] = c_log2_tab[k];
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= n; i += blockDim.x) s_lh[i] = pnx_exp2::log2_exact((double)hist[i], s_log2);  // hist.rs:106
+    if (br == CF_UNION) {
+        // hist.rs:95-97: tot = sum of hist[c..] as integers (exact in any order), converted once
+        unsigned long long part = 0;
+        for (uint32_t i = c + threadIdx.x; i <= n; i += blockDim.x) part += hist[i];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0 && part) atomicAdd(&s_tot, part);
+    }
+    // (the first barrier of cf_column_sum orders these writes before any read)
     const bool in = m_raw <= n;
     const uint32_t m = in ? m_raw : n;
     const size_t np1 = (size_t)n + 1;
-    const double *t1 = term1 + t * np1 * np1 + m;
-    const uint32_t c = cov[t], br = branch[t];
     // union: i in c .. n - m; core / quorum: i in max(m, c) .. n
     const uint32_t lo = br == CF_UNION ? c : (m > c ? m : c);
     const uint32_t hi = br == CF_UNION ? (n >= m ? n - m + 1 : 0u) : n + 1;
-    double y = cf_column_sum(t1, np1, in ? lo : 1u, in ? hi : 0u, n + 1, false, s_buf);
+    double y = cf_column_sum<false>(pm + t * np1 * np1 + m, np1, in ? lo : 1u, in ? hi : 0u, n + 1, s_lh, n_fall[t * np1 + m], s_exp2, s_buf);
     if (br == CF_UNION) {
-        y = pnx_exp2::sub(tot[t], y);
+        y = pnx_exp2::sub((double)s_tot, y);
     } else if (br == CF_QUORUM) {
-        const double *t2 = term2 + t * np1 * np1 + m;
         // hist.rs:163, :180-182: i in m_quorum .. n - 1, only where a j was admissible (NaN = add stayed false)
-        const double yr = cf_column_sum(t2, np1, in ? m_quorum[t * np1 + m] : 1u, in ? n : 0u, n + 1, true, s_buf);
+        const double yr = cf_column_sum<true>(lsq + t * np1 * np1 + m, np1, in ? m_quorum[t * np1 + m] : 1u, in ? n : 0u, n + 1, s_lh, 0.0,
+                                              s_exp2, s_buf);
         y = pnx_exp2::add(y, yr);
     }
     if (in && threadIdx.x < 64) out[(size_t)t * n + m - 1] = y;
@@ -578,6 +574,72 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n) {
     return PNX_OK;
 }
 
+// The growth tables of (n, pairs): built on stream_cf when a call comes with arguments other than the kept ones.
+static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel) {
+    pnx_ctx::GrowthTables &g = ctx->gtab;
+    bool same = g.valid && g.n == n && g.T == n_pairs;
+    for (uint32_t t = 0; same && t < n_pairs; ++t)
+        same = g.branch[t] == branch[t] && g.cov[t] == cov_abs[t] && std::memcmp(&g.quorum[t], &quorum_rel[t], sizeof(double)) == 0;
+    if (same) return PNX_OK;
+    // calls in flight read the kept tables: they finish first (a change of thresholds between pipelined calls is the rare case)
+    for (auto &sl : ctx->gslot)
+        if (sl.pending && sl.done) PNX_HIP(ctx, hipEventSynchronize(sl.done));
+    g.valid = false;
+    const size_t np1 = (size_t)n + 1, T = n_pairs;
+    bool any_quorum = false;
+    for (uint32_t t = 0; t < n_pairs; ++t) any_quorum |= branch[t] == PNX_GROWTH_QUORUM;
+    int rc;
+    const size_t par_bytes = T * 8 + T * 4 + T * 4;
+    if ((rc = ensure(ctx, g.d_par, par_bytes)) || (rc = ensure(ctx, g.d_L, 2 * np1 * 8)) || (rc = ensure(ctx, g.d_nf, T * np1 * 8)) ||
+        (rc = ensure(ctx, g.d_mf, T * np1 * 8)) || (rc = ensure(ctx, g.d_mq, T * np1 * 4)) || (rc = ensure(ctx, g.d_pm, T * np1 * np1 * 8)) ||
+        (any_quorum && ((rc = ensure(ctx, g.d_lsq, T * np1 * np1 * 8)) || (rc = ensure(ctx, g.d_sum, np1 * np1 * 8)))))
+        return rc;
+    if (!g.h_par) PNX_HIP(ctx, hipHostMalloc(&g.h_par, PNX_GROWTH_MAX_PAIRS * 16, hipHostMallocDefault));
+    if (!g.ready) PNX_HIP(ctx, hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
+    if (!ctx->stream_cf) PNX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_cf, hipStreamNonBlocking));
+    hipStream_t st = ctx->stream_cf;
+    PNX_HIP(ctx, hipStreamSynchronize(st));  // (the pinned parameter block of the previous build is free)
+    char *h = (char *)g.h_par;
+    double *h_q = (double *)h;
+    uint32_t *h_br = (uint32_t *)(h + T * 8), *h_cov = h_br + T;
+    for (uint32_t t = 0; t < n_pairs; ++t) {
+        h_q[t] = g.quorum[t] = quorum_rel[t];
+        h_br[t] = g.branch[t] = branch[t];
+        h_cov[t] = g.cov[t] = cov_abs[t];
+    }
+    PNX_HIP(ctx, hipMemcpyAsync(g.d_par.p, h, par_bytes, hipMemcpyHostToDevice, st));
+    const double *d_q = (const double *)g.d_par.p;
+    const uint32_t *d_br = (const uint32_t *)((const char *)g.d_par.p + T * 8), *d_cov = d_br + T;
+    const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
+    const size_t lds_eval = (2 * CF_CHUNK * 64 + np1) * sizeof(double);
+    if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval);
+    hipLaunchKernelGGL(k_cf_setup, dim3(1), dim3(256), lds_setup, st, n, n_pairs, (double *)g.d_L.p, d_br, d_q, (double *)g.d_nf.p,
+                       (double *)g.d_mf.p, (uint32_t *)g.d_mq.p);
+    hipLaunchKernelGGL(k_cf_rows, dim3((unsigned)((np1 + 63) / 64), n_pairs), dim3(64), lds_rows, st, n, (const double *)g.d_L.p, d_br, d_cov,
+                       (double *)g.d_pm.p);
+    PNX_HIP(ctx, hipGetLastError());
+    for (uint32_t t = 0; t < n_pairs; ++t) {
+        if (branch[t] != PNX_GROWTH_QUORUM) continue;
+        if ((rc = launch_quorum_sums(ctx, st, g.d_terms, n, cov_abs[t], (const uint32_t *)g.d_mq.p + t * np1, (const double *)g.d_L.p,
+                                     (const double *)g.d_mf.p + t * np1, (const double *)g.d_nf.p + t * np1, (double *)g.d_sum.p)))
+            return rc;
+        hipLaunchKernelGGL(k_cf_lsq, dim3((unsigned)((np1 + 255) / 256), (unsigned)np1), dim3(256), 0, st, n, (const double *)g.d_sum.p,
+                           (double *)g.d_lsq.p + t * np1 * np1);
+    }
+    PNX_HIP(ctx, hipGetLastError());
+    PNX_HIP(ctx, hipEventRecord(g.ready, st));
+    g.n = n;
+    g.T = n_pairs;
+    g.gen += 1;
+    g.n_builds += 1;
+    g.valid = true;
+    return PNX_OK;
+}
+
 int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,
                                  const uint32_t *cov_abs, const double *quorum_rel) {
     if (!ctx) return PNX_EINVAL;
@@ -586,10 +648,9 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
                          PNX_GROWTH_MAX_PAIRS);
     for (uint32_t t = 0; t < n_pairs; ++t)
         if (branch[t] > PNX_GROWTH_QUORUM || cov_abs[t] == 0) return ctx->fail(PNX_EINVAL, "pnx_growth_closed_form: bad threshold pair %u", t);
-    // (two slots once a slot's scratch passes 1 GiB: the terms of the quorum branch are (n + 1)^3 doubles per slot)
-    const int slot_cap = ((size_t)n + 1) * (n + 1) * (n + 1) * 8 > ((size_t)1 << 30) ? std::min(2, ctx->max_in_flight) : ctx->max_in_flight;
-    if (ctx->gslot_count && slot_cap != ctx->gslot_cap)
-        return ctx->fail(PNX_EINVAL, "closed-form calls of very different sizes cannot be in flight together; fetch the pending ones first");
+    // One call more than passes may be in flight: a host that keeps k passes going enqueues pass i + k and its call before it
+    // fetches the curves of pass i.
+    const int slot_cap = ctx->max_in_flight + 1;
     if (ctx->gslot_count >= slot_cap) return ctx->fail(PNX_EINVAL, "%d closed-form calls are already in flight; fetch one first", slot_cap);
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     Ticket *src = nullptr;
@@ -597,88 +658,53 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
         if (ctx->tk_count == 0 || n != ctx->n_groups) return ctx->fail(PNX_EINVAL, "pnx_growth_closed_form: hist == NULL needs a coverage pass in flight with n groups");
         src = &ctx->tk[ctx->tk_last()];
     }
+    int rc;
+    if ((rc = ensure_growth_tables(ctx, n, n_pairs, branch, cov_abs, quorum_rel))) return rc;
+    const pnx_ctx::GrowthTables &tab = ctx->gtab;
     const size_t np1 = (size_t)n + 1, T = n_pairs;
-    if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;  // (keeps the low slots in use when the cap is below the ring)
+    if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;
     pnx_ctx::GrowthSlot &g = ctx->gslot[ctx->gslot_next];
+    // a stream per slot: the calls in flight do not wait for each other, and none of them for a coverage pass
     if (!g.stream) PNX_HIP(ctx, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     hipStream_t st = g.stream;
-    // slot: [quorum f64 T | hist u64 n+1 | branch u32 T | cov u32 T] padded to 8, then out f64 T x n
-    const size_t in_bytes = (T * 8 + np1 * 8 + T * 4 + T * 4 + 7) & ~(size_t)7, out_bytes = T * n * 8;
-    int rc;
-    if ((rc = ensure(ctx, g.d_io, in_bytes + out_bytes))) return rc;
+    // slot: pinned host memory [hist u64 n+1 | out f64 T x n]: the kernel reads and writes it in place (a copy would be one more
+    // short kernel that waits for a free wave slot beside a running pass)
+    const size_t in_bytes = np1 * 8, out_bytes = T * n * 8;
     if (g.h_cap < in_bytes + out_bytes) {
         if (g.h_io) (void)hipHostFree(g.h_io);
         g.h_io = nullptr;
         g.h_cap = 0;
         PNX_HIP(ctx, hipHostMalloc(&g.h_io, in_bytes + out_bytes, hipHostMallocDefault));
         g.h_cap = in_bytes + out_bytes;
+        PNX_HIP(ctx, hipHostGetDevicePointer(&g.d_io_mapped, g.h_io, 0));
     }
     if (!g.done) PNX_HIP(ctx, hipEventCreateWithFlags(&g.done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
-    // the slot's own scratch: the chains of the two calls in flight run beside each other
-    DevBuf &d_L = g.d_gc[0], &d_lh = g.d_gc[1], &d_nf = g.d_gc[2], &d_mf = g.d_gc[3], &d_mq = g.d_gc[4], &d_tot = g.d_gc[5],
-           &d_t1 = g.d_gc[6], &d_t2 = g.d_gc[7], &d_sum = g.d_sum;
-    bool any_quorum = false;
-    for (uint32_t t = 0; t < n_pairs; ++t) any_quorum |= branch[t] == PNX_GROWTH_QUORUM;
-    if ((rc = ensure(ctx, d_L, 2 * np1 * 8)) || (rc = ensure(ctx, d_lh, np1 * 8)) || (rc = ensure(ctx, d_nf, T * np1 * 8)) ||
-        (rc = ensure(ctx, d_mf, T * np1 * 8)) || (rc = ensure(ctx, d_mq, T * np1 * 4)) || (rc = ensure(ctx, d_tot, T * 8)) ||
-        (rc = ensure(ctx, d_t1, T * np1 * np1 * 8)) || (any_quorum && ((rc = ensure(ctx, d_t2, T * np1 * np1 * 8)) || (rc = ensure(ctx, d_sum, np1 * np1 * 8)))))
-        return rc;
     char *h = (char *)g.h_io;
-    double *h_q = (double *)h;
-    uint64_t *h_hist = (uint64_t *)(h + T * 8);
-    uint32_t *h_br = (uint32_t *)(h + T * 8 + np1 * 8), *h_cov = h_br + T;
-    for (uint32_t t = 0; t < n_pairs; ++t) {
-        h_q[t] = quorum_rel[t];
-        h_br[t] = branch[t];
-        h_cov[t] = cov_abs[t];
-    }
-    if (hist) std::memcpy(h_hist, hist, np1 * 8);
-    char *d = (char *)g.d_io.p;
-    const double *d_q = (const double *)d;
-    const uint64_t *d_hist = (const uint64_t *)(d + T * 8);
-    const uint32_t *d_br = (const uint32_t *)(d + T * 8 + np1 * 8), *d_cov = d_br + T;
+    char *d = (char *)g.d_io_mapped;
+    const uint64_t *d_hist = (const uint64_t *)d;
     double *d_out = (double *)(d + in_bytes);
-    PNX_HIP(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    if (g.tab_gen != tab.gen) {  // tables built since this slot's stream last looked
+        PNX_HIP(ctx, hipStreamWaitEvent(st, tab.ready, 0));
+        g.tab_gen = tab.gen;
+    }
     if (src) {
         // the counters are final once the pass's own copy to the host was enqueued behind them (and behind the all-reduce of
-        // a multi-GPU context): stream_cf waits for exactly that point
+        // a multi-GPU context): the slot's stream waits for exactly that point
         PNX_HIP(ctx, hipStreamWaitEvent(st, src->done, 0));
-        PNX_HIP(ctx, hipMemcpyAsync(d + T * 8, src->d_hist, np1 * 8, hipMemcpyDeviceToDevice, st));  // the slot's own copy
+        d_hist = src->d_hist;
+    } else {
+        std::memcpy(h, hist, np1 * 8);
+    }
+    const uint32_t *d_br = (const uint32_t *)((const char *)tab.d_par.p + T * 8), *d_cov = d_br + T;
+    hipLaunchKernelGGL(k_cf_eval, dim3((n + 63) / 64, n_pairs), dim3(64 * CF_WAVES), (2 * CF_CHUNK * 64 + np1) * sizeof(double), st, n, d_hist, d_br,
+                       d_cov, (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p,
+                       d_out);
+    PNX_HIP(ctx, hipGetLastError());
+    if (src) {  // the next pass on that ticket clears its counters only after this read
         if (!src->ev_reader) PNX_HIP(ctx, hipEventCreateWithFlags(&src->ev_reader, hipEventDisableTiming));
         PNX_HIP(ctx, hipEventRecord(src->ev_reader, st));
         src->has_reader = true;
     }
-    const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
-    if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
-    }
-    hipLaunchKernelGGL(k_cf_setup, dim3(1), dim3(256), lds_setup, st, n, n_pairs, d_hist, (double *)d_L.p, (double *)d_lh.p, d_br,
-                       d_cov, d_q, (double *)d_nf.p, (double *)d_mf.p, (uint32_t *)d_mq.p, (double *)d_tot.p);
-    hipLaunchKernelGGL(k_cf_rows, dim3((unsigned)((np1 + 63) / 64), n_pairs), dim3(64), lds_rows, st, n, (const double *)d_L.p, d_br, d_cov,
-                       (double *)d_t1.p);
-    hipLaunchKernelGGL(k_cf_exp2, dim3((unsigned)((np1 + 255) / 256), (unsigned)np1, n_pairs), dim3(256), 0, st, n, d_br, d_cov,
-                       (const double *)d_lh.p, (const double *)d_nf.p, (double *)d_t1.p);
-    PNX_HIP(ctx, hipGetLastError());
-    for (uint32_t t = 0; t < n_pairs; ++t) {
-        if (branch[t] != PNX_GROWTH_QUORUM) continue;
-        if ((rc = launch_quorum_sums(ctx, st, g.d_terms, n, cov_abs[t], (const uint32_t *)d_mq.p + t * np1, (const double *)d_L.p,
-                                     (const double *)d_mf.p + t * np1, (const double *)d_nf.p + t * np1, (double *)d_sum.p)))
-            return rc;
-        hipLaunchKernelGGL(k_cf_term2, dim3((unsigned)((np1 + 255) / 256), n), dim3(256), 0, st, n, (const double *)d_lh.p, (const double *)d_sum.p,
-                           (double *)d_t2.p + t * np1 * np1);
-    }
-    {
-        static bool once = false;  // 128 KB of LDS per workgroup: beyond the default limit
-        if (!once) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_finish), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CF_CHUNK * 64 * 8);
-            once = true;
-        }
-    }
-    hipLaunchKernelGGL(k_cf_finish, dim3((n + 63) / 64, n_pairs), dim3(256), 2 * CF_CHUNK * 64 * 8, st, n, d_br, d_cov, (const uint32_t *)d_mq.p,
-                       (const double *)d_tot.p, (const double *)d_t1.p, (const double *)d_t2.p, d_out);
-    PNX_HIP(ctx, hipGetLastError());
-    PNX_HIP(ctx, hipMemcpyAsync(h + in_bytes, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipEventRecord(g.done, st));
     g.pending = true;
     g.n = n;

@@ -141,6 +141,7 @@ static int stage_results(pnx_ctx *ctx, Ticket *t) {
     if (t->h_cap < bytes) {
         if (t->h_block) (void)hipHostFree(t->h_block);
         t->h_block = nullptr;
+        t->h_cap = 0;
         PNX_HIP(ctx, hipHostMalloc(&t->h_block, bytes, hipHostMallocDefault));
         t->h_cap = bytes;
     }
@@ -241,6 +242,12 @@ const char *pnx_last_error(const pnx_ctx *ctx) { return ctx ? ctx->err.c_str() :
 int pnx_init(pnx_ctx **out, int device) {
     if (!out) return PNX_EINVAL;
     *out = nullptr;
+    // A context runs a pass on three streams and the closed forms of up to four passes on streams of their own.  The HIP
+    // runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues the
+    // histogram phase of a pass queues up behind the closed-form chain of an older one (measured: 0.24 against 0.17 ms per
+    // pipelined step).  Ask for 8 unless the caller has said otherwise; only read by the runtime when it starts, so a
+    // process that initialised HIP earlier sets the variable itself (bench.py does).
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -292,11 +299,13 @@ void pnx_free(pnx_ctx *ctx) {
         if (g.stream) (void)hipStreamSynchronize(g.stream);
         if (g.h_io) (void)hipHostFree(g.h_io);
         if (g.done) (void)hipEventDestroy(g.done);
-        for (DevBuf &b : g.d_gc) release(b);
-        release(g.d_terms);
-        release(g.d_sum);
-        release(g.d_io);
         if (g.stream) (void)hipStreamDestroy(g.stream);
+    }
+    {
+        auto &t = ctx->gtab;
+        for (DevBuf *b : {&t.d_par, &t.d_L, &t.d_nf, &t.d_mf, &t.d_mq, &t.d_pm, &t.d_lsq, &t.d_terms, &t.d_sum}) release(*b);
+        if (t.h_par) (void)hipHostFree(t.h_par);
+        if (t.ready) (void)hipEventDestroy(t.ready);
     }
     for (auto &t : ctx->tk) {
         if (t.h_block) (void)hipHostFree(t.h_block);
@@ -1066,6 +1075,7 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_sorted_paths = ctx->n_sorted_paths;
     out->rows_tile_major = ctx->rows_valid && ctx->rows_tile_major ? 1 : 0;
     out->n_rows = ctx->rows_valid ? ctx->n_rows : 0;
+    out->n_growth_table_builds = ctx->gtab.n_builds;
     out->n_rows_in_order = 0;
     if (ctx->rows_valid && ctx->have_order && ctx->h_rt_span.size() == ctx->n_paths)
         for (uint32_t k = 0; k < ctx->n_ordered; ++k) out->n_rows_in_order += ctx->h_rt_span[ctx->h_ord_path[k]];
@@ -1126,6 +1136,11 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
         case PNX_CFG_ROWS_LAYOUT:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows layout must be 0 (auto), 1 (tile-major) or 2 (path-major)");
             ctx->rows_layout = (int)value;
+            return PNX_OK;
+        case PNX_CFG_DROP_GROWTH_TABLES:
+            for (auto &sl : ctx->gslot)
+                if (sl.pending && sl.done) PNX_HIP(ctx, hipEventSynchronize(sl.done));
+            ctx->gtab.valid = false;
             return PNX_OK;
         case PNX_CFG_DROP_DERIVED:
             if (ctx->d_rows.borrowed || ctx->d_steps12.borrowed) return ctx->fail(PNX_EINVAL, "this context borrows its graph (pnx_share_csr)");

@@ -18,6 +18,7 @@
 // libpanacus_hip.so keeps libamdhip64 as its only link-time dependency.
 #include <dlfcn.h>
 #include <glob.h>
+#include <link.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -43,11 +44,20 @@ struct RcclApi {
 static RcclApi &rccl() {
     static RcclApi api;
     if (api.lib || !api.err.empty()) return api;
-    // PNX_RCCL_LIB (a path) first; then the loader's own search (finds a copy that is already mapped, e.g. by torch);
-    // then ROCm's; then the copies PyTorch wheels ship in <site-packages>/torch/lib -- a host without torch in the
-    // process (the Rust host of INTEGRATION.md) still finds the library of the image
+    // PNX_RCCL_LIB (a path) first; then a copy that is ALREADY MAPPED into the process, whatever its file is called (PyTorch
+    // wheels ship their own librccl.so: two copies of RCCL in one process interpose each other's symbols and the process
+    // dies in a double free when it exits); then the loader's own search; then ROCm's; then the copies of PyTorch wheels in
+    // <site-packages>/torch/lib -- a host without torch in the process (the Rust host of INTEGRATION.md) still finds the
+    // library of the image.  A process that loads torch AFTER this library names torch's copy in PNX_RCCL_LIB
+    // (panacus_amd/capi.py does).
     std::vector<std::string> names;
     if (const char *env = getenv("PNX_RCCL_LIB")) names.push_back(env);
+    dl_iterate_phdr(
+        [](struct dl_phdr_info *info, size_t, void *out) {
+            if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl")) static_cast<std::vector<std::string> *>(out)->push_back(info->dlpi_name);
+            return 0;
+        },
+        &names);
     for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(n);
     for (const char *pat : {"/usr/local/lib/python3*/dist-packages/torch/lib/librccl.so*", "/usr/lib/python3*/site-packages/torch/lib/librccl.so*",
                             "/usr/local/lib/python3*/site-packages/torch/lib/librccl.so*", "/opt/conda/lib/python3*/site-packages/torch/lib/librccl.so*"}) {

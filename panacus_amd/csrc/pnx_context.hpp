@@ -55,8 +55,8 @@ struct Ticket {
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
-    hipEvent_t ev_reader = nullptr;  // a closed-form call copied the counters out of d_block (pnx_growth_closed_form_async):
-    bool has_reader = false;         // the next pass on this ticket clears the block only after that copy
+    hipEvent_t ev_reader = nullptr;  // a closed-form call reads the counters in d_block (pnx_growth_closed_form_async):
+    bool has_reader = false;         // the next pass on this ticket clears the block only after that kernel
     // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
     // time the pass is settled): it merged the scatter rows of M / it wrote the presence matrix
     bool used_m = false, wrote_m = false;
@@ -225,20 +225,32 @@ struct pnx_ctx {
     size_t h_cf_cap = 0;
     hipEvent_t ev_cf = nullptr;
     bool cf_pending = false;
-    // ---- whole closed forms on the device (pnx_growth_closed_form_*): two slots, each with its own stream and scratch, so
-    // that the (latency-bound) kernel chains of two calls in flight run beside each other ----
+    // ---- whole closed forms on the device (pnx_growth_closed_form_*).  What depends on (n, threshold pairs) alone is kept
+    // as tables shared by all calls; a call has a slot with its own stream, so that calls in flight run beside each other
+    struct GrowthTables {
+        bool valid = false;
+        uint32_t n = 0, T = 0;
+        uint32_t branch[PNX_GROWTH_MAX_PAIRS] = {}, cov[PNX_GROWTH_MAX_PAIRS] = {};
+        double quorum[PNX_GROWTH_MAX_PAIRS] = {};
+        pnx::DevBuf d_par;               // [quorum f64 T | branch u32 T | cov u32 T]
+        pnx::DevBuf d_L, d_nf, d_mf, d_mq;  // log2 table, per-pair running sums, m_quorum
+        pnx::DevBuf d_pm, d_lsq;         // perc_mult[t][i][m]; log2 of the quorum branch's inner sums [t][i][m]
+        pnx::DevBuf d_terms, d_sum;      // scratch of a build: terms of the inner sums, the sums
+        void *h_par = nullptr;           // pinned
+        hipEvent_t ready = nullptr;
+        uint64_t gen = 0, n_builds = 0;
+    } gtab;
     struct GrowthSlot {
         hipStream_t stream = nullptr;
-        pnx::DevBuf d_gc[8];       // log2 tables, per-pair running sums, term arrays
-        pnx::DevBuf d_terms, d_sum;  // quorum branch: terms of the inner sums, the sums
-        pnx::DevBuf d_io;          // [pairs | hist] in, out[T][n] behind them
-        void *h_io = nullptr;      // pinned mirror
+        void *h_io = nullptr;      // pinned: hist in, out[T][n] behind it
+        void *d_io_mapped = nullptr;  // the same memory as the device addresses it
         size_t h_cap = 0;
         hipEvent_t done = nullptr;
         bool pending = false;
         uint32_t n = 0, n_pairs = 0;
         size_t out_off = 0;
-    } gslot[PNX_MAX_IN_FLIGHT];
+        uint64_t tab_gen = 0;      // generation of the tables this slot's stream has waited for
+    } gslot[PNX_MAX_IN_FLIGHT + 1];
     int gslot_next = 0, gslot_oldest = 0, gslot_count = 0, gslot_cap = 2;  // ring over the first gslot_cap slots
 
     // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----
