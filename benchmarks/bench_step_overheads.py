@@ -83,6 +83,34 @@ def main():
             c2.hist_async()
             c2.hist_fetch(want_countable=False)
         out["tiny_graph_async_fetch_ms"] = round((time.perf_counter() - t0) / 2000 * 1e3, 4)
+    # the same pipelined loop on a graph whose kernels take no time: what the host and the launch path alone allow
+    with capi.Context(0) as c3:
+        c3.set_csr_pansyn(1, 3000, p)
+        c3.set_order(order, order, p)
+        c3.hist()
+        hostlib.set_quorum_offload(c3, 256)
+        for depth in (1, 4):
+            c3.config(capi.CFG_MAX_IN_FLIGHT, depth)
+            for mode in ("pass_only", "pass+growth"):
+                def enq3():
+                    c3.hist_async()
+                    return hostlib.calc_growths_begin_on_device(p, thr) if mode == "pass+growth" else None
+                q = [enq3() for _ in range(depth)]
+                t0 = time.perf_counter()
+                for k in range(1000):
+                    c3.hist_fetch(want_countable=False)
+                    g = q.pop(0)
+                    q.append(enq3())
+                    if g is not None:
+                        hostlib.calc_growths_end(g)
+                dt = (time.perf_counter() - t0) / 1000 * 1e3
+                for g in q:
+                    c3.hist_fetch(want_countable=False)
+                    if g is not None:
+                        hostlib.calc_growths_end(g)
+                c3.sync()
+                out[f"tiny_depth{depth}_{mode}_ms"] = round(dt, 4)
+        hostlib.set_quorum_offload(None)
     print(json.dumps(out))
 
 

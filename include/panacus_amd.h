@@ -416,6 +416,10 @@ int pnx_profile_enable(pnx_ctx *ctx, int on);
  * slot costs two event records per launch on the stream; a throughput run that only needs the
  * dominant kernel selects that one slot. */
 int pnx_profile_select(pnx_ctx *ctx, uint32_t slot_mask);
+/* time only every `every`-th launch of a selected slot (default 1: all).  The two event records around a kernel keep the
+ * stream from running it back to back with its neighbours (measured: 0.185 against 0.140 ms per pipelined pass with every
+ * coverage kernel timed); a throughput run samples. */
+int pnx_profile_sample(pnx_ctx *ctx, uint32_t every);
 /* accumulated milliseconds and launch counts per slot since the last reset */
 int pnx_profile_read(pnx_ctx *ctx, double ms[PNX_K_COUNT], uint64_t launches[PNX_K_COUNT]);
 int pnx_profile_reset(pnx_ctx *ctx);
@@ -475,6 +479,8 @@ enum {
                                   (closed-form calls, pnx_growth_closed_form_async: one more).  Each pass in flight owns a coverage vector
                                   (4 (n_items + 1) bytes) and its counters; a host whose per-pass latency (pass + closed forms
                                   + its own work) exceeds the duration of a pass keeps more of them in flight */
+    PNX_CFG_HIST_IN_COVER = 21, /* 1: the coverage kernel over path rows adds the histogram itself, no separate histogram kernel
+                                  reads the coverage vector (up to 4095 groups) [1]; 0: K2 as for the step routes (cross-check) */
     PNX_CFG_DROP_GROWTH_TABLES = 20, /* (value ignored) forget the (n, thresholds) tables of pnx_growth_closed_form_async; the next
                                   call derives them again.  Measurement only */
     PNX_CFG_DROP_DERIVED = 18, /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
 K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
 KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
-CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT, CFG_ROWS_LAYOUT, CFG_DROP_DERIVED, CFG_MAX_IN_FLIGHT, CFG_DROP_GROWTH_TABLES = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT, CFG_ROWS_LAYOUT, CFG_DROP_DERIVED, CFG_MAX_IN_FLIGHT, CFG_DROP_GROWTH_TABLES, CFG_HIST_IN_COVER = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
+    "pnx_profile_sample",
 ]
 
 
@@ -141,6 +142,7 @@ def load() -> C.CDLL:
     L.pnx_growth_closed_form_fetch.argtypes = [vp, f64p]
     L.pnx_profile_enable.argtypes = [vp, C.c_int]
     L.pnx_profile_select.argtypes = [vp, C.c_uint32]
+    L.pnx_profile_sample.argtypes = [vp, C.c_uint32]
     L.pnx_profile_read.argtypes = [vp, C.POINTER(C.c_double), u64p]
     L.pnx_profile_reset.argtypes = [vp]
     L.pnx_config.argtypes = [vp, C.c_int, C.c_int64]
@@ -530,6 +532,10 @@ class Context:
         """time only the given slot indices (None = all)"""
         mask = 0xFFFFFFFF if slots is None else sum(1 << int(k) for k in slots)
         self._ck(self._L.pnx_profile_select(self._h, mask))
+
+    def profile_sample(self, every: int):
+        """time only every `every`-th launch of the selected slots"""
+        self._ck(self._L.pnx_profile_sample(self._h, int(every)))
 
     def profile_read(self):
         ms = (C.c_double * K_COUNT)()

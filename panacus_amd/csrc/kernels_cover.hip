@@ -1498,7 +1498,11 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->wrote_m = ctx->want_M;
     const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
+    tk->hist_fused = rows && ctx->hist_in_cover && (size_t)ctx->n_groups + 1 <= HIST_FUSED_MAX_BINS;
+    const size_t rep_off = (tk->block_bytes + 255) & ~(size_t)255;
+    if (tk->hist_fused) tk->block_bytes = rep_off + (size_t)HIST_REPLICAS * hist_bytes;
     if ((rc = ensure(ctx, tk->d_block, tk->block_bytes))) return rc;
+    tk->d_hist_rep = tk->hist_fused ? (uint64_t *)((char *)tk->d_block.p + rep_off) : nullptr;
     tk->d_flags = (uint32_t *)tk->d_block.p;
     tk->d_hist = (uint64_t *)((char *)tk->d_block.p + 8 * sizeof(uint32_t));
     tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;

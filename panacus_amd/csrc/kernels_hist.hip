@@ -4,6 +4,8 @@
 // therefore a code object) of its own: together with kernels_rows.hip it is all a default `hist` run loads.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -76,7 +78,38 @@ __global__ __launch_bounds__(1024) void k_hist(const uint32_t *__restrict__ coun
     }
 }
 
+// hist[b] = sum of the replicas the coverage kernel added to (kernels_rows.hip); host_block: the pass's result block
+// [flags u32[8] | hist] in the ticket's pinned memory, written here so that no copy has to follow
+__global__ __launch_bounds__(1024) void k_hist_publish(const unsigned long long *__restrict__ rep, uint32_t bins,
+                                                       unsigned long long *__restrict__ hist, const uint32_t *__restrict__ flags,
+                                                       uint32_t *__restrict__ host_block) {
+    for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) {
+        unsigned long long s = 0;
+#pragma unroll 8
+        for (uint32_t r = 0; r < HIST_REPLICAS; ++r) s += rep[(size_t)r * bins + b];
+        hist[b] = s;
+        if (host_block) {
+            host_block[8 + 2 * b] = (uint32_t)s;
+            host_block[8 + 2 * b + 1] = (uint32_t)(s >> 32);
+        }
+    }
+    if (host_block && threadIdx.x < 8) host_block[threadIdx.x] = flags[threadIdx.x];
+}
+
 int launch_hist(pnx_ctx *ctx, Ticket *tk) {
+    if (tk->hist_fused) {
+        // the coverage kernel left HIST_REPLICAS partial histograms: add them up, and hand [flags | hist] to the host
+        // (multi-GPU: the all-reduce of the block follows this kernel, the copy to the host follows that)
+        const bool to_host = tk->h_block_mapped && !(ctx->comm && ctx->comm_reduce_hist);
+        tk->host_written = to_host;
+        prof_begin(ctx, PNX_K_HIST, ctx->s_post);
+        hipLaunchKernelGGL(k_hist_publish, dim3(1), dim3(1024), 0, ctx->s_post, (const unsigned long long *)tk->d_hist_rep, ctx->n_groups + 1,
+                           (unsigned long long *)tk->d_hist, (const uint32_t *)tk->d_flags, to_host ? (uint32_t *)tk->h_block_mapped : (uint32_t *)nullptr);
+        prof_end(ctx);
+        PNX_HIP(ctx, hipGetLastError());
+        return PNX_OK;
+    }
+    tk->host_written = false;
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
     {
         // one workgroup of 16 waves per CU at most: every workgroup ends with one global atomic

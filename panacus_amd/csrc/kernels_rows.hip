@@ -353,6 +353,17 @@ struct RowSplit {  // cut points of the visiting order for the split kernel
     uint32_t k[9];
 };
 
+// The histogram of the pass, added by the coverage kernel itself (construct_hist / construct_hist_bps,
+// src/graph_broker/abacus.rs:746-787): a workgroup collects the counts of its tiles in LDS and adds its non-empty bins to
+// ONE OF HIST_REPLICAS copies of the histogram in global memory -- every tile ends with a burst of up to G+1 atomics, and on a
+// single copy they would queue up on the few memory channels that hold it (4883 tiles x 257 bins on 2 KB).  k_hist_publish
+// (kernels_hist.hip) adds the copies up.  rep == nullptr: the kernel only writes the coverage vector (K2 reads it).
+struct RowHist {
+    unsigned long long *rep;  // HIST_REPLICAS x (n_groups + 1)
+    const uint32_t *weights;  // node lengths (bp), or nullptr
+    uint32_t n_groups;
+};
+
 constexpr int ROWS_D = 8;  // rows in flight per wave and buffer (two buffers; 16 makes the compiler keep 232 registers: 0.24 ms)
 
 // One wave owns one item tile (SPLIT > 1: one group-aligned part of the visiting order on one tile; the parts
@@ -365,21 +376,29 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
                                                         const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
                                                         uint32_t *__restrict__ M, uint64_t row_words,
-                                                        uint32_t *__restrict__ countable, RowSplit sp) {
+                                                        uint32_t *__restrict__ countable, RowSplit sp, RowHist hs) {
     constexpr int TPW = CW / SPLIT;  // tiles per workgroup
     static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
     static_assert(!(SKIP && WRITE_M), "a pass that writes the presence matrix visits every group");
     __shared__ uint32_t xch[SPLIT > 1 ? TPW * (SPLIT - 1) * NPL * 64 : 1];
+    extern __shared__ unsigned long long sh_hist[];  // n_groups + 1 bins when the kernel adds the histogram
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t part = SPLIT > 1 ? wave % SPLIT : 0;
     const uint32_t tile_raw = blockIdx.x * TPW + wave / SPLIT;
-    if (SPLIT == 1 && tile_raw >= n_tiles) return;
-    const bool active = tile_raw < n_tiles;  // SPLIT > 1: idle waves still meet the barrier
+    const bool active = tile_raw < n_tiles;  // idle waves still meet the barriers
     const uint32_t tile = active ? tile_raw : n_tiles - 1;
     const uint32_t k_lo = SPLIT > 1 ? (active ? sp.k[part] : 0u) : 0u;
-    const uint32_t k_hi = SPLIT > 1 ? (active ? sp.k[part + 1] : 0u) : n_ordered;
+    const uint32_t k_hi = SPLIT > 1 ? (active ? sp.k[part + 1] : 0u) : (active ? n_ordered : 0u);
+    // The histogram bins of the workgroup.  One tile per workgroup (TPW == 1): they belong to the one wave that finishes the
+    // tile, which clears, fills and flushes them without a barrier while the other waves are gone.  Several tiles: shared.
+    const bool fin = part == 0 && active;
+    uint32_t *sh32 = reinterpret_cast<uint32_t *>(sh_hist);  // node counts: 4-byte bins (a workgroup holds at most 4 x 2048 items)
+    if (hs.rep && TPW > 1) {
+        for (uint32_t b = threadIdx.x; b <= hs.n_groups; b += CW * 64) sh_hist[b] = 0;
+        if (SPLIT == 1) __syncthreads();  // (SPLIT > 1: the barrier of the exchange below orders this before the first add)
+    }
 
     // exclusion word in presence layout (ActiveTable, src/util.rs:118-124)
     uint32_t excl = 0;
@@ -558,25 +577,102 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
             for (int k = 0; k < NPL; ++k) xt[((part - 1) * NPL + k) * 64 + lane] = cnt[k];
         }
         __syncthreads();
-        if (part > 0 || !active) return;
-        for (int q = 0; q < SPLIT - 1; ++q) {
-            uint32_t carry = 0;
+        if (TPW == 1 && !fin) return;
+        if (fin) {
+            for (int q = 0; q < SPLIT - 1; ++q) {
+                uint32_t carry = 0;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                const uint32_t a = cnt[k], b = xt[(q * NPL + k) * 64 + lane];
-                cnt[k] = a ^ b ^ carry;
-                carry = (a & b) | (carry & (a ^ b));
+                for (int k = 0; k < NPL; ++k) {
+                    const uint32_t a = cnt[k], b = xt[(q * NPL + k) * 64 + lane];
+                    cnt[k] = a ^ b ^ carry;
+                    carry = (a & b) | (carry & (a ^ b));
+                }
             }
         }
     }
-    // unpack the bit-sliced counters: one coalesced 256-byte store per bit position
-    for (uint32_t b = 0; b < 32; ++b) {
-        uint32_t v = 0;
+    if (fin) {
+        const bool hist = hs.rep != nullptr, weighted = hs.weights != nullptr;
+        if (hist && TPW == 1) {
+            for (uint32_t b = lane; b <= hs.n_groups; b += 64) sh_hist[b] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        // The bins 0, 1 and n_groups (uncovered, private and core items) hold most items of a pangenome; through LDS atomics
+        // they would serialise up to 64 lanes on one address.  Node counts: the three bins are population counts of bit masks
+        // over the planes -- 32 items of a lane at once --, only the other items go through LDS, one 4-byte add each.  Weighted
+        // (bp): each lane keeps the three sums in registers.
+        unsigned long long hot0 = 0, hot1 = 0, hotg = 0;
+        uint32_t others = 0;
+        if (hist && !weighted) {
+            uint32_t any_hi = 0, any = 0, mg = 0xFFFFFFFFu;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
-        const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
-        // countable[0] is the reference's reserved element (abacus.rs:549-551)
-        if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+            for (int k = 0; k < NPL; ++k) {
+                any |= cnt[k];
+                if (k >= 1) any_hi |= cnt[k];
+                mg &= ((hs.n_groups >> k) & 1u) ? cnt[k] : ~cnt[k];
+            }
+            if (hs.n_groups <= 1 || (NPL < 32 && (hs.n_groups >> NPL) != 0)) mg = 0;  // (bin 1 / bin 0 take those items)
+            uint32_t vm = 0;  // items 1 .. n_items of this word
+            {
+                const uint64_t first = (uint64_t)tile * BLOCK_ITEMS + lane;  // item of bit 0; bit b: first + 64 b
+                if (first <= n_items) {
+                    const uint64_t nb = (n_items - first) / 64 + 1;  // bits with an item <= n_items
+                    vm = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+                    if (first == 0) vm &= ~1u;  // item 0 is the sentinel
+                }
+            }
+            const uint32_t m0 = ~any & vm, m1 = cnt[0] & ~any_hi & vm;
+            mg &= vm & ~m1 & ~m0;
+            hot0 = (uint32_t)__builtin_popcount(m0);
+            hot1 = (uint32_t)__builtin_popcount(m1);
+            hotg = (uint32_t)__builtin_popcount(mg);
+            others = vm & ~(m0 | m1 | mg);
+        }
+        // unpack the bit-sliced counters: one coalesced 256-byte store per bit position
+        for (uint32_t b = 0; b < 32; ++b) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
+            const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
+            // countable[0] is the reference's reserved element (abacus.rs:549-551)
+            if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+            if (hist && !weighted) {
+                if (((others >> b) & 1u) && v < hs.n_groups) atomicAdd(&sh32[v], 1u);  // abacus.rs:752: coverage beyond #groups is ignored
+            } else if (hist && node >= 1 && node <= n_items) {
+                const unsigned long long w = hs.weights[node];
+                if (v == 0) hot0 += w;
+                else if (v == 1) hot1 += w;
+                else if (v == hs.n_groups) hotg += w;
+                else if (v < hs.n_groups) atomicAdd(&sh_hist[v], w);  // abacus.rs:771
+            }
+        }
+        if (hist) {
+            for (int o = 32; o > 0; o >>= 1) {
+                hot0 += __shfl_down(hot0, o);
+                hot1 += __shfl_down(hot1, o);
+                hotg += __shfl_down(hotg, o);
+            }
+            if (lane == 0) {
+                if (weighted) {
+                    if (hot0) atomicAdd(&sh_hist[0], hot0);
+                    if (hot1) atomicAdd(&sh_hist[1], hot1);
+                    if (hotg) atomicAdd(&sh_hist[hs.n_groups], hotg);
+                } else {
+                    if (hot0) atomicAdd(&sh32[0], (uint32_t)hot0);
+                    if (hot1) atomicAdd(&sh32[1], (uint32_t)hot1);
+                    if (hotg) atomicAdd(&sh32[hs.n_groups], (uint32_t)hotg);
+                }
+            }
+        }
+    }
+    if (hs.rep) {
+        if (TPW > 1) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool weighted = hs.weights != nullptr;
+        unsigned long long *dst = hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * (hs.n_groups + 1);
+        for (uint32_t b = TPW > 1 ? threadIdx.x : lane; b <= hs.n_groups; b += TPW > 1 ? CW * 64 : 64) {
+            const unsigned long long x = weighted ? sh_hist[b] : (unsigned long long)sh32[b];
+            if (x) atomicAdd(&dst[b], x);
+        }
     }
 }
 
@@ -625,10 +721,13 @@ static void launch_rows_cover_t(pnx_ctx *ctx, bool write_m) {
             while (t > 0 && t < ctx->n_ordered && ctx->h_ord_group[t] == ctx->h_ord_group[t - 1]) ++t;
             sp.k[j] = (uint32_t)t;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), 0, ctx->s_main, (const uint32_t *)ctx->d_rows.p, ctx->row_tstride, oi,
+        const RowHist hs{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
+                         ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
+        const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(cw * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_rows.p, ctx->row_tstride, oi,
                            (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, n_tiles,
-                           (uint32_t *)ctx->d_M.p, row_words, (uint32_t *)tk->d_countable.p, sp);
+                           (uint32_t *)ctx->d_M.p, row_words, (uint32_t *)tk->d_countable.p, sp, hs);
     };
     const bool skip = !write_m && (ctx->cover_skip == 1 || (ctx->cover_skip == 0 && ctx->n_ordered >= 4096));
     int split = ctx->cover_split;

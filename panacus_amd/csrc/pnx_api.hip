@@ -49,6 +49,7 @@ static hipEvent_t prof_event(pnx_ctx *ctx) {
 
 void prof_begin(pnx_ctx *ctx, int slot, hipStream_t stream) {
     ctx->prof.open = ctx->prof.on && ((ctx->prof.mask >> slot) & 1u);
+    if (ctx->prof.open && ctx->prof.every > 1) ctx->prof.open = (ctx->prof.seen[slot]++ % ctx->prof.every) == 0;
     if (!ctx->prof.open) return;
     ctx->prof.open_stream = stream ? stream : ctx->stream;
     Profile::Pending pd{prof_event(ctx), prof_event(ctx), slot};
@@ -136,17 +137,26 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->rows_valid = false;
 }
 
-static int stage_results(pnx_ctx *ctx, Ticket *t) {
+// the ticket's pinned result block [flags u32[8] | hist (G+1) u64], before the pass is launched: its publishing kernel may
+// write it directly
+static int ensure_host_block(pnx_ctx *ctx, Ticket *t) {
     const size_t bytes = 8 * sizeof(uint32_t) + ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     if (t->h_cap < bytes) {
         if (t->h_block) (void)hipHostFree(t->h_block);
         t->h_block = nullptr;
+        t->h_block_mapped = nullptr;
         t->h_cap = 0;
         PNX_HIP(ctx, hipHostMalloc(&t->h_block, bytes, hipHostMallocDefault));
         t->h_cap = bytes;
+        PNX_HIP(ctx, hipHostGetDevicePointer(&t->h_block_mapped, t->h_block, 0));
     }
     t->h_flags = (uint32_t *)t->h_block;
     t->h_hist = (uint64_t *)((char *)t->h_block + 8 * sizeof(uint32_t));
+    return PNX_OK;
+}
+
+static int stage_results(pnx_ctx *ctx, Ticket *t) {
+    const size_t bytes = 8 * sizeof(uint32_t) + ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     if (t->done && t->done_blocking != ctx->blocking_sync) {
         (void)hipEventDestroy(t->done);
         t->done = nullptr;
@@ -155,7 +165,7 @@ static int stage_results(pnx_ctx *ctx, Ticket *t) {
         PNX_HIP(ctx, hipEventCreateWithFlags(&t->done, hipEventDisableTiming | (ctx->blocking_sync ? hipEventBlockingSync : 0)));
         t->done_blocking = ctx->blocking_sync;
     }
-    PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->s_post));
+    if (!t->host_written) PNX_HIP(ctx, hipMemcpyAsync(t->h_block, t->d_block.p, bytes, hipMemcpyDeviceToHost, ctx->s_post));
     PNX_HIP(ctx, hipEventRecord(t->done, ctx->s_post));
     return PNX_OK;
 }
@@ -163,8 +173,9 @@ static int stage_results(pnx_ctx *ctx, Ticket *t) {
 // enqueue one pass into the next free ticket
 static int enqueue_pass(pnx_ctx *ctx) {
     Ticket *t = ctx->cur;  // chosen by pnx_hist_async (its index may already be in the making)
-    int rc = launch_cover_pass(ctx);
+    int rc = ensure_host_block(ctx, t);
     if (rc) return rc;
+    if ((rc = launch_cover_pass(ctx))) return rc;
     if ((rc = comm_reduce_pass(ctx, t))) return rc;  // multi-GPU: global flags + histogram (no-op without a communicator)
     if ((rc = stage_results(ctx, t))) return rc;
     t->in_flight = true;
@@ -213,6 +224,7 @@ static int settle_oldest(pnx_ctx *ctx) {
         }
         ctx->cur = t;
         if ((rc = choose_pass_streams(ctx))) return rc;
+        if ((rc = ensure_host_block(ctx, t))) return rc;
         if ((rc = launch_cover_pass(ctx))) return rc;
         // the flags were reduced over all ranks, so every rank is here: the collectives stay matched
         if ((rc = comm_reduce_pass(ctx, t))) return rc;
@@ -272,6 +284,9 @@ int pnx_init(pnx_ctx **out, int device) {
     }
     if (const char *v = getenv("PNX_COVER_VARIANT")) {  // default of PNX_CFG_COVER_VARIANT (cross-check runs of a whole host)
         if (v[0] >= '0' && v[0] <= '3' && v[1] == 0) ctx->cover_variant = v[0] - '0';
+    }
+    if (const char *v = getenv("PNX_HIST_IN_COVER")) {  // default of PNX_CFG_HIST_IN_COVER
+        if ((v[0] == '0' || v[0] == '1') && v[1] == 0) ctx->hist_in_cover = v[0] == '1';
     }
     *out = ctx;
     return PNX_OK;
@@ -1038,6 +1053,14 @@ int pnx_profile_select(pnx_ctx *ctx, uint32_t slot_mask) {
     return PNX_OK;
 }
 
+int pnx_profile_sample(pnx_ctx *ctx, uint32_t every) {
+    if (!ctx) return PNX_EINVAL;
+    if (every == 0) return ctx->fail(PNX_EINVAL, "pnx_profile_sample: every must be at least 1");
+    ctx->prof.every = every;
+    for (auto &x : ctx->prof.seen) x = 0;
+    return PNX_OK;
+}
+
 int pnx_profile_read(pnx_ctx *ctx, double ms[PNX_K_COUNT], uint64_t launches[PNX_K_COUNT]) {
     if (!ctx) return PNX_EINVAL;
     int rc = pnx_sync(ctx);
@@ -1136,6 +1159,11 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
         case PNX_CFG_ROWS_LAYOUT:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows layout must be 0 (auto), 1 (tile-major) or 2 (path-major)");
             ctx->rows_layout = (int)value;
+            return PNX_OK;
+        case PNX_CFG_HIST_IN_COVER:
+            if (value > 1) return ctx->fail(PNX_EINVAL, "hist_in_cover must be 0 or 1");
+            if (ctx->tk_count) return ctx->fail(PNX_EINVAL, "PNX_CFG_HIST_IN_COVER cannot change while passes are in flight");
+            ctx->hist_in_cover = value != 0;
             return PNX_OK;
         case PNX_CFG_DROP_GROWTH_TABLES:
             for (auto &sl : ctx->gslot)

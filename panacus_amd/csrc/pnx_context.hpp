@@ -35,6 +35,9 @@ struct DevBuf {
 // One enqueued coverage pass.  Several tickets exist so that pass k+1 (.. k+3) can be enqueued before the
 // host has looked at pass k: each owns its result counters in HBM, a pinned staging copy and
 // the event that marks "results of this pass are on the host".
+constexpr uint32_t HIST_REPLICAS = 64;
+constexpr uint32_t HIST_FUSED_MAX_BINS = 4096;  // 32 KB of LDS per workgroup
+
 struct Ticket {
     // one device block [flags: u32[8] | hist: (G+1) u64 | group flags: G u8] so that a pass needs
     // one memset and one device-to-host copy; flags[0] violations, [1] #general paths in the order
@@ -55,6 +58,12 @@ struct Ticket {
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
+    // rows route, up to HIST_FUSED_MAX_BINS bins: the coverage kernel adds the histogram itself, into HIST_REPLICAS copies at the
+    // end of d_block (cleared with it); k_hist_publish adds them up and writes flags + hist into h_block directly
+    uint64_t *d_hist_rep = nullptr;
+    bool hist_fused = false;
+    void *h_block_mapped = nullptr;  // h_block as the device addresses it
+    bool host_written = false;       // the publishing kernel of the pass wrote flags + hist to h_block itself
     hipEvent_t ev_reader = nullptr;  // a closed-form call reads the counters in d_block (pnx_growth_closed_form_async):
     bool has_reader = false;         // the next pass on this ticket clears the block only after that kernel
     // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
@@ -67,6 +76,8 @@ struct Profile {
     bool open = false;          // a prof_begin of a selected slot awaits its prof_end
     hipStream_t open_stream = nullptr;
     uint32_t mask = 0xFFFFFFFFu;  // slots that are timed (pnx_profile_select)
+    uint32_t every = 1;           // ... every `every`-th launch of them (pnx_profile_sample)
+    uint64_t seen[PNX_K_COUNT] = {0};
     double ms[PNX_K_COUNT] = {0};
     uint64_t launches[PNX_K_COUNT] = {0};
     // pending (start, stop, slot) event triples, resolved at the next sync
@@ -130,6 +141,7 @@ struct pnx_ctx {
     int index_by_entry = 0;    // K0 thread numbering: 0 = automatic, 1 = one thread per index entry, 2 = path-major
     int cover_skip = 0;        // window skipping of the coverage kernel: 0 = automatic, 1 = whenever legal, 2 = never
     int cover_split = 0;       // waves per tile of the coverage kernel: 0 = automatic, 1, 2, 4, 8
+    bool hist_in_cover = true;  // PNX_CFG_HIST_IN_COVER: the coverage kernel over rows adds the histogram itself (0: K2 reads the coverage vector)
     int cover_variant = 3;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads (all three over the
                                // steps), 3 = over path rows (kernels_rows.hip)
     uint32_t n_blocks = 0, n_tiles = 0;
