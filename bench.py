@@ -775,13 +775,22 @@ def main():
         for _ in range(min(n_steps, depth * L)):
             lanes[enqueued % L].enqueue()
             enqueued += 1
+        late = None  # the closed forms of the previous pass: collected one pass late, when they are long done
         for k in range(n_steps):
             h = lanes[k % L].settle()
-            pending = lanes[k % L].pending.pop(0) or growth_begin(h)
+            on_device = lanes[k % L].pending.pop(0)
+            pending = on_device or growth_begin(h)
             if enqueued < n_steps:
                 lanes[enqueued % L].enqueue()
                 enqueued += 1
-            growths = growth_end(pending)
+            if on_device is None:  # host threads (+ one quorum offload at a time): finished here
+                growths = growth_end(pending)
+                continue
+            if late is not None:
+                growths = growth_end(late)
+            late = pending
+        if late is not None:
+            growths = growth_end(late)
         return h, growths
 
     def barrier():

@@ -383,9 +383,9 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
  *   hist   n+1 bins on the host, or NULL: the device counters of the coverage pass enqueued LAST (n must be the number of
  *          groups) -- the curves then follow the pass without the histogram ever visiting the host
  *   out    n_pairs x n values: out[t*n + m-1] = growth at m groups (the reference's vector without its leading NaN)
- * _async enqueues the work on a stream of its own (inputs are copied before it returns); PNX_CFG_MAX_IN_FLIGHT + 1 calls may
- * be in flight -- one more than passes, so that a host enqueues pass i + k and its call before it fetches the curves of pass
- * i; _fetch waits for the OLDEST one.
+ * _async enqueues the work on a stream of its own (inputs are copied before it returns); PNX_CFG_MAX_IN_FLIGHT + 2 calls may
+ * be in flight -- two more than passes, so that a host enqueues pass i + k and its call before it fetches the curves of pass
+ * i - 1; _fetch waits for the OLDEST one.
  * Everything in the closed forms that does not depend on the histogram -- the log2 table, the running sums n_fall / m_fact,
  * perc_mult[i][m], and the quorum branch's inner sums over j (hist.rs:164-176), O(n^3) of the work -- is a function of (n, pairs)
  * alone and is kept by the context as tables (8 (n+1)^2 bytes per pair, twice that with a quorum pair, plus 8 (n+1)^3 bytes of
@@ -476,7 +476,7 @@ enum {
                                   (tile, path) pairs, 2 path-major over the tiles each path spans.  Takes effect when the
                                   rows are next derived */
     PNX_CFG_MAX_IN_FLIGHT = 19, /* coverage passes (pnx_hist_async) that may be in flight at once: 1 .. PNX_MAX_IN_FLIGHT [2]
-                                  (closed-form calls, pnx_growth_closed_form_async: one more).  Each pass in flight owns a coverage vector
+                                  (closed-form calls, pnx_growth_closed_form_async: two more).  Each pass in flight owns a coverage vector
                                   (4 (n_items + 1) bytes) and its counters; a host whose per-pass latency (pass + closed forms
                                   + its own work) exceeds the duration of a pass keeps more of them in flight */
     PNX_CFG_HIST_IN_COVER = 21, /* 1: the coverage kernel over path rows adds the histogram itself, no separate histogram kernel

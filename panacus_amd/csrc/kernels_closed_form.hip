@@ -648,9 +648,10 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
                          PNX_GROWTH_MAX_PAIRS);
     for (uint32_t t = 0; t < n_pairs; ++t)
         if (branch[t] > PNX_GROWTH_QUORUM || cov_abs[t] == 0) return ctx->fail(PNX_EINVAL, "pnx_growth_closed_form: bad threshold pair %u", t);
-    // One call more than passes may be in flight: a host that keeps k passes going enqueues pass i + k and its call before it
-    // fetches the curves of pass i.
-    const int slot_cap = ctx->max_in_flight + 1;
+    // Two calls more than passes may be in flight: a host that keeps k passes going enqueues pass i + k and its call before it
+    // fetches the curves of pass i - 1 -- one pass late, so that it never waits for the evaluation that was started by the
+    // histogram it has just fetched.
+    const int slot_cap = ctx->max_in_flight + 2;
     if (ctx->gslot_count >= slot_cap) return ctx->fail(PNX_EINVAL, "%d closed-form calls are already in flight; fetch one first", slot_cap);
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     Ticket *src = nullptr;

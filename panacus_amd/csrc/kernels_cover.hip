@@ -1501,6 +1501,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->hist_fused = rows && ctx->hist_in_cover && (size_t)ctx->n_groups + 1 <= HIST_FUSED_MAX_BINS;
     const size_t rep_off = (tk->block_bytes + 255) & ~(size_t)255;
     if (tk->hist_fused) tk->block_bytes = rep_off + (size_t)HIST_REPLICAS * hist_bytes;
+    tk->block_bytes = (tk->block_bytes + 15) & ~(size_t)15;
     if ((rc = ensure(ctx, tk->d_block, tk->block_bytes))) return rc;
     tk->d_hist_rep = tk->hist_fused ? (uint64_t *)((char *)tk->d_block.p + rep_off) : nullptr;
     tk->d_flags = (uint32_t *)tk->d_block.p;
@@ -1526,7 +1527,8 @@ int launch_cover_pass(pnx_ctx *ctx) {
         PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_pre, tk->ev_reader, 0));
         tk->has_reader = false;
     }
-    PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
+    // (a pass over rows with paths in the order: the kernel that lays the order out clears the block)
+    if (!(rows && ctx->n_ordered)) PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
 
     if (rows) {
         // ---- phases 1 + 2 over path rows (kernels_rows.hip): no boundary index, no routes

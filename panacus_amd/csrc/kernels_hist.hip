@@ -84,9 +84,11 @@ __global__ __launch_bounds__(1024) void k_hist_publish(const unsigned long long 
                                                        unsigned long long *__restrict__ hist, const uint32_t *__restrict__ flags,
                                                        uint32_t *__restrict__ host_block) {
     for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) {
-        unsigned long long s = 0;
-#pragma unroll 8
-        for (uint32_t r = 0; r < HIST_REPLICAS; ++r) s += rep[(size_t)r * bins + b];
+        unsigned long long v[HIST_REPLICAS], s = 0;  // all loads in flight before the first addition
+#pragma unroll
+        for (uint32_t r = 0; r < HIST_REPLICAS; ++r) v[r] = rep[(size_t)r * bins + b];
+#pragma unroll
+        for (uint32_t r = 0; r < HIST_REPLICAS; ++r) s += v[r];
         hist[b] = s;
         if (host_block) {
             host_block[8 + 2 * b] = (uint32_t)s;

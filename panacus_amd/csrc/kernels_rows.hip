@@ -320,9 +320,13 @@ struct RowOrd {
     uint32_t *win_lo, *win_hi;        // per 64 entries: the tiles [lo, hi) their paths reach
 };
 
+// (also clears the pass's counter block -- flags, histogram, its replicas --: a memset in front of this kernel is two more
+// short kernels in the chain of a pass)
 __global__ void k_rows_order(const uint32_t *__restrict__ ord_path, uint32_t n_ordered, const uint32_t *__restrict__ tfirst,
-                             const uint32_t *__restrict__ tspan, const uint32_t *__restrict__ row_base, RowOrd oi) {
+                             const uint32_t *__restrict__ tspan, const uint32_t *__restrict__ row_base, RowOrd oi,
+                             uint4 *__restrict__ block16, uint32_t n_block16) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t q = k; q < n_block16; q += gridDim.x * blockDim.x) block16[q] = make_uint4(0, 0, 0, 0);
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     if (k < n_ordered) {
         const uint32_t p = ord_path[k];
@@ -762,7 +766,7 @@ int launch_rows_phases(pnx_ctx *ctx, bool write_m) {
                         (uint32_t *)tk->d_win_lo.p, (uint32_t *)tk->d_win_hi.p};
         hipLaunchKernelGGL(k_rows_order, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->s_pre, (const uint32_t *)ctx->d_ord_path.p,
                            ctx->n_ordered, (const uint32_t *)ctx->d_rt_first.p, (const uint32_t *)ctx->d_rt_span.p,
-                           (const uint32_t *)ctx->d_row_base.p, oi);
+                           (const uint32_t *)ctx->d_row_base.p, oi, (uint4 *)tk->d_block.p, (uint32_t)(tk->block_bytes / 16));
         prof_end(ctx);
         PNX_HIP(ctx, hipGetLastError());
     }

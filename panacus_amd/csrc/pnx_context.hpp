@@ -262,7 +262,7 @@ struct pnx_ctx {
         uint32_t n = 0, n_pairs = 0;
         size_t out_off = 0;
         uint64_t tab_gen = 0;      // generation of the tables this slot's stream has waited for
-    } gslot[PNX_MAX_IN_FLIGHT + 1];
+    } gslot[PNX_MAX_IN_FLIGHT + 2];
     int gslot_next = 0, gslot_oldest = 0, gslot_count = 0, gslot_cap = 2;  // ring over the first gslot_cap slots
 
     // ---- multi-GPU (pnx_comm.hip): RCCL communicator, opened with dlopen on first use ----

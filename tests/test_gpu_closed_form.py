@@ -183,16 +183,18 @@ def test_closed_forms_follow_the_pass_on_the_device(ctx):
             ctx.hist_async()
             pend.append(hostlib.calc_growths_begin_on_device(p, thr))
         builds = int(ctx.info().n_growth_table_builds)
-        extra = hostlib.calc_growths_begin_on_device(p, thr)   # one call more than passes may be in flight (the last pass again)
-        assert all(x is not None for x in pend) and extra is not None
-        assert hostlib.calc_growths_begin_on_device(p, thr) is None   # a sixth: refused
+        extra = hostlib.calc_growths_begin_on_device(p, thr)   # two calls more than passes may be in flight (the last pass again)
+        extra2 = hostlib.calc_growths_begin_on_device(p, thr)
+        assert all(x is not None for x in pend) and extra is not None and extra2 is not None
+        assert hostlib.calc_growths_begin_on_device(p, thr) is None   # a seventh: refused
         oh = orc.hist(orc.coverage(items, pre, pi.astype(np.uint64), pi.astype(np.uint64), n), p)
         for x in pend:
             assert np.array_equal(ctx.hist_fetch()[1], oh)
             for (c, q), a in zip(pairs, hostlib.calc_growths_end(x)):
                 assert a.tobytes() == orc.growth(oh, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes()
-        for (c, q), a in zip(pairs, hostlib.calc_growths_end(extra)):
-            assert a.tobytes() == orc.growth(oh, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes()
+        for x in (extra, extra2):
+            for (c, q), a in zip(pairs, hostlib.calc_growths_end(x)):
+                assert a.tobytes() == orc.growth(oh, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes()
         # the (n, thresholds) tables were derived once and read by the calls that followed; other thresholds derive them again,
         # with calls in flight too, and dropping them changes nothing but the time
         assert int(ctx.info().n_growth_table_builds) == builds

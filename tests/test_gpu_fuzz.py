@@ -98,6 +98,7 @@ def test_random_graph_matches_oracle(ctx, seed):
     ctx.config(capi.CFG_COVER_SKIP, 1 if seed % 2 else 0)  # window skipping in the plain hist pass
     ctx.config(capi.CFG_COVER_VARIANT, 2 if seed % 4 == 3 else 3)  # over the steps (round 2's routes) / over path rows
     ctx.config(capi.CFG_ROWS_LAYOUT, seed % 3)             # automatic / tile-major / path-major rows
+    ctx.config(capi.CFG_HIST_IN_COVER, 0 if seed % 7 == 2 else 1)  # histogram by its own kernel / by the coverage kernel over rows
     ctx.config(capi.CFG_COVER_SPLIT, (0, 1, 2, 4, 8)[seed % 5])
     ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=excl)
     ctx.set_order(pi, gi, G)
@@ -141,4 +142,5 @@ def test_random_graph_matches_oracle(ctx, seed):
     ctx.config(capi.CFG_COVER_SKIP, 0)
     ctx.config(capi.CFG_COVER_VARIANT, 3)
     ctx.config(capi.CFG_ROWS_LAYOUT, 0)
+    ctx.config(capi.CFG_HIST_IN_COVER, 1)
     ctx.config(capi.CFG_COVER_SPLIT, 0)

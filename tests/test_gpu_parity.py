@@ -182,12 +182,15 @@ def test_hist_ragged_and_empty_paths(ctx):
 
 @pytest.fixture
 def route(request, ctx):
-    """PNX_CFG_COVER_VARIANT for one test: 3 = over path rows (the default), 2 = over the packed steps with the
-    boundary index, the run index and the sort of shuffled paths (round 2's default, kept as a cross-check)"""
+    """PNX_CFG_COVER_VARIANT for one test: 3 = over path rows, the coverage kernel adds the histogram itself (the default), 30 =
+    over path rows with the separate histogram kernel (PNX_CFG_HIST_IN_COVER 0), 2 = over the packed steps with the boundary
+    index, the run index and the sort of shuffled paths (round 2's default, kept as a cross-check)"""
     from panacus_amd import capi
-    ctx.config(capi.CFG_COVER_VARIANT, request.param)
+    ctx.config(capi.CFG_COVER_VARIANT, 3 if request.param == 30 else request.param)
+    ctx.config(capi.CFG_HIST_IN_COVER, 0 if request.param == 30 else 1)
     yield request.param
     ctx.config(capi.CFG_COVER_VARIANT, 3)
+    ctx.config(capi.CFG_HIST_IN_COVER, 1)
 
 
 @pytest.fixture
@@ -200,7 +203,7 @@ def sort_shuffled(request, ctx):
     ctx.config(capi.CFG_SORT_SHUFFLED, 1)
 
 
-@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (30, 1), (2, 1), (2, 0)], indirect=True)
 def test_hist_unsorted_paths_sorted_or_on_the_scatter_route(ctx, route, sort_shuffled):
     n, p = 30_000, 10
     items, pre, lens = orc.pansyn(11, n, p)
@@ -386,7 +389,7 @@ def test_ordered_growth_many_groups(ctx):
             assert out[r, t].tolist() == [int(x) for x in exp]
 
 
-@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (30, 1), (2, 1), (2, 0)], indirect=True)
 def test_growth_after_scatter_route(ctx, route, sort_shuffled):
     """edge-like (unsorted) paths: sorted at preparation, or the presence matrix comes from the scatter route"""
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
@@ -559,7 +562,7 @@ def test_ordered_growth_rule_from_the_presence_matrix(ctx, weighted):
         assert out[r, 0].tolist() == (seen * w[None, :]).sum(axis=1).tolist()
 
 
-@pytest.mark.parametrize("route", [3, 2], indirect=True)
+@pytest.mark.parametrize("route", [3, 30, 2], indirect=True)
 def test_keyed_upload_reports_everything_in_the_callers_ids(ctx, tmp_path, route):
     """pnx_set_csr_keyed: edge steps numbered like the reference does (order of the L lines, here
     shuffled) + one key per edge (its canonical ends).  The library renumbers the edges internally on
@@ -765,7 +768,7 @@ def _jitter(items, pre, paths, rng, width=40, every=300):
     return items
 
 
-@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (2, 1), (2, 0)], indirect=True)
+@pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (30, 1), (2, 1), (2, 0)], indirect=True)
 def test_run_route_near_monotone_paths(ctx, route, sort_shuffled):
     from panacus_amd.thresholds import RELATIVE, Threshold, quorum_table
     n, p = 120_000, 16
@@ -810,7 +813,7 @@ def test_run_route_near_monotone_paths(ctx, route, sort_shuffled):
         assert out[0, t].tolist() == [int(x) for x in exp]
 
 
-@pytest.mark.parametrize("route,tile_blocks", [(3, 1), (2, 1), (2, 2)], indirect=["route"])
+@pytest.mark.parametrize("route,tile_blocks", [(3, 1), (30, 1), (2, 1), (2, 2)], indirect=["route"])
 def test_run_route_all_paths_and_rebuild(ctx, route, tile_blocks):
     from panacus_amd import capi
     n, p = 50_000, 9

@@ -226,3 +226,52 @@ def test_rows_long_path_many_chunks_and_wide_group_counts(ctx):
         cnt, h = ctx.hist()
         ocov, oh = _oracle_hist(items, pre, pi, gid, n, G)
         assert np.array_equal(cnt, ocov) and np.array_equal(h, oh), G
+
+
+@pytest.mark.parametrize("split", [0, 1, 2, 4, 8])
+def test_histogram_added_by_the_coverage_kernel(ctx, split):
+    """PNX_CFG_HIST_IN_COVER: the coverage kernel over rows adds the histogram itself (construct_hist / construct_hist_bps,
+    abacus.rs:746-787) -- node counts from bit masks over the counter planes, bp through per-lane sums -- against the
+    oracle and against the separate histogram kernel; every width of the split kernel, groups of 1, 2, 3, 64 and one per
+    path, bins that are the hot ones (0, 1, G) or not, excluded nodes, a subset of the paths, a last tile that is not full"""
+    from panacus_amd import capi
+    n, p = 70_001, 48
+    items, pre, lens = orc.pansyn(23, n, p)
+    rng = np.random.default_rng(split)
+    excl = (rng.random(n + 1) < 0.02).astype(np.uint8)
+    try:
+        ctx.config(capi.CFG_COVER_SPLIT, split)
+        for w, ex in ((None, None), (lens, None), (lens, excl), (None, excl)):
+            ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=ex)
+            for G, pi, gid in ((p, np.arange(p), np.arange(p)), (1, np.arange(p), np.zeros(p)), (2, np.arange(p), np.arange(p) % 2),
+                               (3, np.arange(p), np.arange(p) * 3 // p), (16, np.arange(4, p - 3), (np.arange(4, p - 3) - 4) * 16 // (p - 7))):
+                pi, gid = pi.astype(np.uint64), np.sort(gid.astype(np.uint64))
+                ctx.set_order(pi, gid, G)
+                got = {}
+                for fused in (1, 0):
+                    ctx.config(capi.CFG_HIST_IN_COVER, fused)
+                    got[fused] = ctx.hist()
+                ocov = orc.coverage(items, pre, pi, gid, n, ex)
+                oh = orc.hist(ocov, G, w)
+                for fused in (1, 0):
+                    assert np.array_equal(got[fused][0], ocov) and np.array_equal(got[fused][1], oh), (G, fused, w is not None, ex is not None)
+    finally:
+        ctx.config(capi.CFG_COVER_SPLIT, 0)
+        ctx.config(capi.CFG_HIST_IN_COVER, 1)
+
+
+def test_histogram_with_more_bins_than_lds_holds(ctx):
+    """more than 4095 groups: the bins do not fit a workgroup's LDS, the separate histogram kernel takes over (24-plane counters)"""
+    n, p = 30_000, 5000
+    rng = np.random.default_rng(3)
+    lens_p = rng.integers(1, 40, size=p)
+    pre = np.zeros(p + 1, dtype=np.uint64)
+    pre[1:] = np.cumsum(lens_p)
+    items = np.concatenate([np.sort(rng.integers(1, n + 1, size=k)) for k in lens_p]).astype(np.uint64)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(p, dtype=np.uint64)
+    for G, gid in ((p, pi), (4095, pi * 4095 // p), (4096, pi * 4096 // p)):
+        ctx.set_order(pi, gid.astype(np.uint64), G)
+        cnt, h = ctx.hist()
+        ocov = orc.coverage(items, pre, pi, gid.astype(np.uint64), n)
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, G)), G
