@@ -220,18 +220,22 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
 // ------------------------------------------------------------------------------------------
 // fused growth kernel: N0 pairs with q == 0 and NQ pairs with q > 0 share ONE read of the
 // presence rows of an order.
-//   * q > 0 pairs use the slack form s_j = cnt_j - Tq[j], bit-sliced in two's complement
-//     (NPL1 planes).  Tq rises by dT in {0,1} per rank (q <= 1), so per rank s += x (dT = 0)
-//     or s += x - 1 (dT = 1): ONE ripple pass under mask m = x ^ dmask with the plane
-//     complemented by dmask (dmask = 0 / ~0 is wave-uniform and comes from a host table), and
-//     "cnt >= Tq" is the complement of the sign plane -- no plane-by-plane comparison.
+//   * q > 0 pairs use the slack form s_j = cnt_j - Tq[j], bit-sliced.  Tq rises by dT in {0,1} per rank (q <= 1), so per
+//     rank s += x (dT = 0) or s += x - 1 (dT = 1): ONE ripple pass under mask m = x ^ dmask with the plane complemented by
+//     dmask (dmask = 0 / ~0 is wave-uniform and comes from a host table).  Since round 3 the pass runs over FIVE planes
+//     only: s = 16 H + L, L in [0, 31] is rippled per rank, H (two's complement) every eight ranks when L is brought back
+//     into [8, 23]; "cnt >= Tq" is (H >= 0) | (H == -1 & L >= 16) with the two H masks kept between those steps -- 20
+//     instead of 34 vector instructions per rank and pair.
 //   * everything on the per-rank path is branch-free VALU: the first version of this kernel
 //     was bound by the CU's single scalar unit (27 SALU instructions per rank for uniform
 //     branches, exec-mask juggling and 64-bit address arithmetic); row offsets now come
 //     pre-multiplied from the host as 32-bit byte offsets (saddr + voffset addressing).
-//   * per-rank popcounts (<= 32 per lane) are packed two per register for the 16 ranks of
-//     a batch and reduced over the wave once per batch (8 packed DPP reductions instead of
-//     16), then lanes 0..15 add the 16 totals to the workgroup's LDS accumulators.
+//   * per-rank popcounts (<= 32 per lane) are packed two per register for the 16 ranks of a batch and summed over the
+//     wave once per batch by a reduce-scatter: v_permlane32_swap / v_permlane16_swap (gfx950) fold two registers with one
+//     addition each, four DPP steps finish inside the 16-lane rows, and the last lane of every row adds its share of the
+//     totals to the workgroup's LDS accumulators (round 2: six DPP steps on each of the 24 registers, then a round trip
+//     through LDS so that 16 lanes could issue the atomics -- measured as more than half of the kernel's time: 18.4 ms with
+//     it, 8.5 ms with the sums thrown away; now 15.8 ms per 128 orders, 2.33 ms per 16).
 // Workgroups of one block chunk carry consecutive blockIdx for all R orders.  (Giving all R orders of a
 // chunk to ONE XCD -- chunk % 8, so that its L2 serves a row to R orders for one fetch -- was measured:
 // 18.8 against 18.2 ms on cfg4; the kernel is bound by VALU issue, not by the rows.)
@@ -378,14 +382,44 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
         };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
         uint32_t seen = 0;
-        uint32_t sl[NQ > 0 ? NQ : 1][NPL1];
+        // The slack s = cnt - Tq(j) of every item, bit-sliced, in TWO parts: s = 16 H + L with L in [0, 31] (five planes) and
+        // H (NPLH planes, two's complement).  A rank moves s by at most one, so only the five planes of L are rippled per rank;
+        // every eight ranks L is brought back into [8, 23] by moving 16 into or out of H -- one ripple over H per eight ranks
+        // instead of one per rank -- and between two such steps H does not change: s >= 0 <=> H >= 0, or H == -1 and L >= 16,
+        // with "H >= 0" and "H == -1" kept as masks.
+        constexpr int NPLH = NPL1 - 3;
+        uint32_t lo[NQ > 0 ? NQ : 1][5], hi[NQ > 0 ? NQ : 1][NPLH], hpos[NQ > 0 ? NQ : 1], hm1[NQ > 0 ? NQ : 1];
         uint32_t ok[NQ > 0 ? NQ : 1];
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
+        for (int qi = 0; qi < NQ; ++qi) {  // s = 0: H = -1, L = 16
             ok[qi] = 0;
 #pragma unroll
-            for (int k = 0; k < NPL1; ++k) sl[qi][k] = 0;
+            for (int k = 0; k < 4; ++k) lo[qi][k] = 0;
+            lo[qi][4] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < NPLH; ++k) hi[qi][k] = 0xFFFFFFFFu;
+            hpos[qi] = 0;
+            hm1[qi] = 0xFFFFFFFFu;
         }
+        auto renorm = [&]() {
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                const uint32_t l3 = lo[qi][3], l4 = lo[qi][4];
+                const uint32_t dn = ~(l4 | l3);  // L < 8: L += 16, H -= 1
+                uint32_t m = (l4 & l3) | dn;     // L >= 24: L -= 16, H += 1
+                lo[qi][4] = ~l3;
+                uint32_t all = 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < NPLH; ++k) {
+                    const uint32_t t = (hi[qi][k] ^ dn) & m;  // carry where the bit was 1 (up), borrow where it was 0 (down)
+                    hi[qi][k] ^= m;
+                    m = t;
+                    all &= hi[qi][k];
+                }
+                hpos[qi] = ~hi[qi][NPLH - 1];
+                hm1[qi] = all;
+            }
+        };
 
         // one rank: returns the NA per-lane contributions
         auto rank_step = [&](uint32_t xv, uint32_t j, uint32_t (&val)[NA > 0 ? NA : 1]) {
@@ -400,12 +434,12 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                 const uint32_t dm = dmask[(uint64_t)tabs.qq_slot[qi] * G + j];  // wave-uniform
                 uint32_t m = xv ^ dm;  // dT = 0: increment where x ; dT = 1: decrement where !x
 #pragma unroll
-                for (int k = 0; k < NPL1; ++k) {
-                    const uint32_t t = (sl[qi][k] ^ dm) & m;
-                    sl[qi][k] ^= m;
+                for (int k = 0; k < 5; ++k) {
+                    const uint32_t t = (lo[qi][k] ^ dm) & m;
+                    lo[qi][k] ^= m;
                     m = t;
                 }
-                const uint32_t ge = ~sl[qi][NPL1 - 1];  // s >= 0  <=>  cnt >= Tq
+                const uint32_t ge = hpos[qi] | (hm1[qi] & lo[qi][4]);  // s >= 0  <=>  cnt >= Tq
                 ok[qi] = (ok[qi] & ~xv) | (ge & xv);
                 val[N0 + qi] = ok[qi] & mask[N0 + qi];
             }
@@ -422,38 +456,67 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                 for (int u = 0; u < B; ++u) {
                     uint32_t val[NA > 0 ? NA : 1];
                     rank_step(x[u], jb + u, val);
+                    if (NQ > 0 && (u & 7) == 7) renorm();
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
                         const uint32_t c = (uint32_t)__popc(val[a]);
                         if (u & 1) pk[a][u >> 1] |= c << 16; else pk[a][u >> 1] = c;
                     }
                 }
-                // 8 packed wave reductions per accumulator, totals land in lane 63
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int k = 0; k < B / 2; ++k) pk[a][k] = wave_sum_to_lane63(pk[a][k]);
-                if (lane == 63) {
+                // The NA x B/2 packed registers are summed over the 64 lanes by a reduce-SCATTER: v_permlane32_swap puts the upper
+                // half of register i beside the lower half of register i + H, so ONE addition folds both over lane ^ 32 and leaves
+                // each in one half of the wave; v_permlane16_swap does the same for the 16-lane rows.  Row rho then holds 2 NA
+                // registers (i + NA (rho & 1) + 2 NA (rho >> 1)... see below) that four DPP steps sum within the row: 60 vector
+                // instructions per batch instead of six DPP steps on every register (144) and a round trip through LDS.
+                {
+                    constexpr int NREG = NA * (B / 2), H1 = NREG / 2, H2 = NREG / 4;
+                    static_assert(B == 16, "the reduce-scatter below halves NA x 8 registers twice");
+                    uint32_t w[NREG > 0 ? NREG : 1];
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
 #pragma unroll
-                        for (int k = 0; k < B / 2; ++k) stage[a * (B / 2) + k] = pk[a][k];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (lane < (uint32_t)B) {
+                        for (int k = 0; k < B / 2; ++k) w[a * (B / 2) + k] = pk[a][k];
+                    uint32_t w1[H1 > 0 ? H1 : 1], w2[H2 > 0 ? H2 : 1];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const uint32_t w = stage[a * (B / 2) + (lane >> 1)];
-                        const uint32_t c = (lane & 1) ? (w >> 16) : (w & 0xFFFFu);
-                        if (c) atomicAdd(&acc[(size_t)a * G + jb + lane], (unsigned long long)c);
+                    for (int i = 0; i < H1; ++i) {  // lanes 0..31: register i, lanes 32..63: register i + H1, each folded over lane ^ 32
+                        const auto sw = __builtin_amdgcn_permlane32_swap(w[i], w[i + H1], false, false);
+                        w1[i] = sw[0] + sw[1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < H2; ++i) {  // even rows: register i of w1, odd rows: register i + H2, folded over lane ^ 16
+                        const auto sw = __builtin_amdgcn_permlane16_swap(w1[i], w1[i + H2], false, false);
+                        w2[i] = sw[0] + sw[1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < H2; ++i) {  // within the row: the total lands in its last lane
+                        uint32_t v = w2[i];
+                        v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+                        v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+                        v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xe, true);  // row_shr:4
+                        v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xc, true);  // row_shr:8
+                        w2[i] = v;
+                    }
+                    if ((lane & 15u) == 15u) {
+                        // row rho holds the original registers i + H2 (rho & 1) + H1 (rho >> 1), i < H2; register r = a * 8 + k
+                        // carries ranks jb + 2 k (low half) and jb + 2 k + 1 of accumulator a
+                        const uint32_t rho = lane >> 4;
+                        const uint32_t r0 = (uint32_t)H2 * (rho & 1u) + (uint32_t)H1 * (rho >> 1);
+#pragma unroll
+                        for (int i = 0; i < H2; ++i) {
+                            const uint32_t r = r0 + (uint32_t)i, a = r >> 3, k = r & 7u;
+                            const uint32_t c0 = w2[i] & 0xFFFFu, c1 = w2[i] >> 16;
+                            unsigned long long *dst = &acc[(size_t)a * G + jb + 2 * k];
+                            if (c0) atomicAdd(dst, (unsigned long long)c0);
+                            if (c1) atomicAdd(dst + 1, (unsigned long long)c1);
+                        }
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             } else {
 #pragma unroll
                 for (int u = 0; u < B; ++u) {
                     uint32_t val[NA > 0 ? NA : 1];
                     rank_step(x[u], jb + u, val);
+                    if (NQ > 0 && (u & 7) == 7) renorm();
                     weighted_rank(val, jb + u);
                 }
             }
@@ -462,6 +525,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
             const uint32_t xv = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb] + voff));
             uint32_t val[NA > 0 ? NA : 1];
             rank_step(xv, jb, val);
+            if (NQ > 0 && (jb & 7u) == 7u) renorm();
             if (WEIGHTED) {
                 weighted_rank(val, jb);
             } else {
