@@ -45,9 +45,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# more hardware queues than the runtime's default of 4: a context uses three streams per pass plus one per closed-form call in
-# flight, and streams that share a queue serialise (pnx_init asks for the same, but torch starts the runtime first here)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 

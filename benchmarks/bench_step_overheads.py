@@ -7,8 +7,6 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from panacus_amd import capi, hostlib  # noqa: E402
 from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold  # noqa: E402

@@ -254,12 +254,6 @@ const char *pnx_last_error(const pnx_ctx *ctx) { return ctx ? ctx->err.c_str() :
 int pnx_init(pnx_ctx **out, int device) {
     if (!out) return PNX_EINVAL;
     *out = nullptr;
-    // A context runs a pass on three streams and the closed forms of up to four passes on streams of their own.  The HIP
-    // runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with more streams than queues the
-    // histogram phase of a pass queues up behind the closed-form chain of an older one (measured: 0.24 against 0.17 ms per
-    // pipelined step).  Ask for 8 unless the caller has said otherwise; only read by the runtime when it starts, so a
-    // process that initialised HIP earlier sets the variable itself (bench.py does).
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {

@@ -89,21 +89,35 @@ def calc_growths_begin(hist, pairs, n_threads: int = 0):
     return (handle, T, max(len(h) - 1, 0))
 
 
+_PAIR_ARRAYS = {}  # threshold pairs as the four C arrays of pnh_calc_all_growths_begin (a pipelined loop asks with the same pairs every step)
+
+
+def _pair_arrays(pairs):
+    key = tuple((c.kind, float(c.value), q.kind, float(q.value)) for c, q in pairs)
+    a = _PAIR_ARRAYS.get(key)
+    if a is None:
+        T = len(pairs)
+        a = ((C.c_int * T)(*[k[0] for k in key]), (C.c_double * T)(*[k[1] for k in key]),
+             (C.c_int * T)(*[k[2] for k in key]), (C.c_double * T)(*[k[3] for k in key]))
+        if len(_PAIR_ARRAYS) > 64:
+            _PAIR_ARRAYS.clear()
+        _PAIR_ARRAYS[key] = a
+    return a
+
+
 def calc_growths_begin_on_device(n_groups: int, pairs):
     """The curves of the histogram of the coverage pass enqueued LAST on the offload context (set_quorum_offload),
     computed on the device without the histogram visiting the host.  None when the device path cannot take it (no
     context, libm restatements not confirmed, n out of range): fetch the histogram and use calc_growths_begin."""
     L = load()
-    L.pnh_calc_all_growths_begin.restype = C.c_void_p
-    L.pnh_calc_all_growths_begin.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double),
-                                             C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32, C.c_uint]
-    T = len(pairs)
-    ck = (C.c_int * T)(*[c.kind for c, _ in pairs])
-    cv = (C.c_double * T)(*[float(c.value) for c, _ in pairs])
-    qk = (C.c_int * T)(*[q.kind for _, q in pairs])
-    qv = (C.c_double * T)(*[float(q.value) for _, q in pairs])
-    handle = L.pnh_calc_all_growths_begin(None, n_groups + 1, ck, cv, qk, qv, T, 0)
-    return (handle, T, n_groups) if handle else None
+    if not getattr(L, "_begin_bound", False):
+        L.pnh_calc_all_growths_begin.restype = C.c_void_p
+        L.pnh_calc_all_growths_begin.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32, C.c_uint]
+        L._begin_bound = True
+    ck, cv, qk, qv = _pair_arrays(pairs)
+    handle = L.pnh_calc_all_growths_begin(None, n_groups + 1, ck, cv, qk, qv, len(pairs), 0)
+    return (handle, len(pairs), n_groups) if handle else None
 
 
 def calc_growths_end(pending):
