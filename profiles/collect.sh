@@ -50,6 +50,15 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_A
     python $REPO/profiles/summarize_pmc.py "$(db /tmp/p_pmc)" $OUT/${R}_growth_cfg4_pmc_$N.csv > /dev/null
 done
 
+# 4a. the same counters for 16 orders (one rank's share at 8 GPUs)
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+         "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    rm -rf /tmp/p_pmc; timeout 900 rocprofv3 --kernel-trace --pmc $C -d /tmp/p_pmc -o pmc -- \
+        python $REPO/benchmarks/bench_ordered_growth.py --reps 1 --warm-full --orders 16 > /dev/null 2>&1
+    N=$(echo $C | cut -d' ' -f1); [ "$N" = "SQ_WAVES" ] && N=SQ_waves; [ "$N" = "SQ_INSTS_SALU" ] && N=SQ_insts
+    python $REPO/profiles/summarize_pmc.py "$(db /tmp/p_pmc)" $OUT/${R}_growth_cfg4_R16_pmc_$N.csv > /dev/null
+done
+
 # 4b. K5 on the matrix cores (similarity, bp): kernel stats and the MFMA / VALU counters
 rm -rf /tmp/p_s; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_s -o sim -- \
     python $REPO/benchmarks/bench_similarity.py --bp --check-nodes 0 --reps 3 > /dev/null 2>&1
@@ -64,6 +73,7 @@ done
 timeout 300 python $REPO/benchmarks/bench_rows.py --steps 30 > $OUT/${R}_rows_cfg3_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_rows.py --paths 1024 --steps 10 --splits 0 > $OUT/${R}_rows_10Mx1024_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_closed_form.py > $OUT/${R}_closed_form_bench.json 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_step_overheads.py 2>/dev/null | tail -1 > $OUT/${R}_step_overheads.json
 for N in 256 1024; do
     rm -rf /tmp/p_cf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cf -o cf -- python $REPO/benchmarks/bench_closed_form.py $N > /dev/null 2>&1
     python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cf)" $OUT/${R}_closed_form_n${N}_kernel_stats.csv > /dev/null
