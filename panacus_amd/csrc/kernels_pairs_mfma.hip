@@ -27,6 +27,8 @@
 // beside the lookups of the other.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -78,8 +80,10 @@ __device__ static inline uint2 spread8(uint32_t b, uint32_t one) {
 }
 
 // PL digits [plane_base, plane_base + PL) of the weights (WEIGHTED), or the plain product (PL = 1)
-template <bool WEIGHTED, int PL, bool ACCUM>
-__global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict__ M, uint64_t row_words, uint32_t G, uint32_t n_side,
+// KS: words per staging step (32; 16 for the plain product, whose 39 KB of LDS per workgroup then leave room for three
+// workgroups per CU instead of two -- the lookup -> MFMA chain of one wave hides behind more neighbours)
+template <bool WEIGHTED, int PL, bool ACCUM, int KS>
+__global__ __launch_bounds__(256, KS == 32 ? 2 : 3) void k_pair_mfma(const uint32_t *__restrict__ M, uint64_t row_words, uint32_t G, uint32_t n_side,
                                                       uint32_t chunk_words, const uint32_t *__restrict__ digits, uint32_t plane_base,
                                                       unsigned long long *__restrict__ partial) {
     const uint32_t ti = blockIdx.x / n_side, tj = blockIdx.x % n_side;
@@ -91,25 +95,26 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
     const uint64_t w_end = w_begin + chunk_words < row_words ? w_begin + chunk_words : row_words;
 
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_pairs[];  // > 64 KB: dynamic (mfma_lds_bytes)
-    auto sA = [&](int b) { return lds_pairs + b * (MF_KS * MF_LD); };
-    auto sB = [&](int b) { return lds_pairs + (2 + b) * (MF_KS * MF_LD); };
-    auto sW = [&](int b) { return lds_pairs + 4 * MF_KS * MF_LD + b * (PL * MF_KS * 8); };
-    uint2 *tab01 = reinterpret_cast<uint2 *>(lds_pairs + 4 * MF_KS * MF_LD + 2 * PL * MF_KS * 8);
+    auto sA = [&](int b) { return lds_pairs + b * (KS * MF_LD); };
+    auto sB = [&](int b) { return lds_pairs + (2 + b) * (KS * MF_LD); };
+    auto sW = [&](int b) { return lds_pairs + 4 * KS * MF_LD + b * (PL * KS * 8); };
+    uint2 *tab01 = reinterpret_cast<uint2 *>(lds_pairs + 4 * KS * MF_LD + 2 * PL * KS * 8);
     uint2 *tabff = tab01 + 256;
     tab01[threadIdx.x] = spread8(threadIdx.x, 1u);      // 256 threads, 256 entries each
     tabff[threadIdx.x] = spread8(threadIdx.x, 0xFFu);
 
     const uint32_t t = threadIdx.x;
-    const uint32_t ld_row = t >> 3, ld_k = (t & 7u) * 4u;  // staging: rows ld_row + 32 q, words ld_k .. ld_k + 3
+    constexpr uint32_t TPR = KS / 4, RPP = 256 / TPR, NQ = MF_T / RPP;  // threads per row, rows per pass, passes
+    const uint32_t ld_row = t / TPR, ld_k = (t % TPR) * 4u;  // staging: rows ld_row + RPP q, words ld_k .. ld_k + 3
     const uint32_t wave = t >> 6, lane = t & 63u, r = lane & 31u, h = lane >> 5;
     const uint32_t ra = (wave >> 1) * 64u + r, rb = (wave & 1u) * 64u + r;
 
     const uint32_t ga0 = ti * MF_T, gb0 = tj * MF_T;
-    const uint4 *rowA[4], *rowB[4];
-    uint32_t mA[4], mB[4];
+    const uint4 *rowA[NQ], *rowB[NQ];
+    uint32_t mA[NQ], mB[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // rows past G: clamped to a valid row, masked to zero after the load
-        const uint32_t ga = ga0 + ld_row + 32u * q, gb = gb0 + ld_row + 32u * q;
+    for (int q = 0; q < (int)NQ; ++q) {  // rows past G: clamped to a valid row, masked to zero after the load
+        const uint32_t ga = ga0 + ld_row + RPP * q, gb = gb0 + ld_row + RPP * q;
         rowA[q] = reinterpret_cast<const uint4 *>(M + (uint64_t)(ga < G ? ga : G - 1) * row_words + ld_k);
         rowB[q] = reinterpret_cast<const uint4 *>(M + (uint64_t)(gb < G ? gb : G - 1) * row_words + ld_k);
         mA[q] = ga < G ? ~0u : 0u;
@@ -126,11 +131,12 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[p][i][j][e] = 0;
 
-    uint4 va[4], vb[4];
+    uint4 va[NQ], vb[NQ];
     uint32_t vw[WEIGHTED ? PL : 1];
+    static_assert(!WEIGHTED || KS == 32, "the digits of a staging step are fetched one dword per thread");
     auto fetch = [&](uint64_t w) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < (int)NQ; ++q) {
             va[q] = rowA[q][w >> 2];
             if (!diag) vb[q] = rowB[q][w >> 2];
         }
@@ -147,13 +153,13 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            put4(sA(buf), ld_row + 32u * q, va[q], mA[q]);
-            if (!diag) put4(sB(buf), ld_row + 32u * q, vb[q], mB[q]);
+        for (int q = 0; q < (int)NQ; ++q) {
+            put4(sA(buf), ld_row + RPP * q, va[q], mA[q]);
+            if (!diag) put4(sB(buf), ld_row + RPP * q, vb[q], mB[q]);
         }
         if (WEIGHTED) {
 #pragma unroll
-            for (int p = 0; p < PL; ++p) sW(buf)[p * MF_KS * 8 + t] = vw[p];
+            for (int p = 0; p < PL; ++p) sW(buf)[p * KS * 8 + t] = vw[p];
         }
     };
 
@@ -163,13 +169,13 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
     }
     __syncthreads();
     int buf = 0;
-    for (uint64_t w = w_begin; w < w_end; w += MF_KS, buf ^= 1) {
-        const bool more = w + MF_KS < w_end;
-        if (more) fetch(w + MF_KS);
+    for (uint64_t w = w_begin; w < w_end; w += KS, buf ^= 1) {
+        const bool more = w + KS < w_end;
+        if (more) fetch(w + KS);
         const uint32_t *a_s = sA(buf) + ra;
         const uint32_t *b_s = (diag ? sA(buf) : sB(buf)) + rb;
 #pragma unroll 4
-        for (int k = 0; k < MF_KS; ++k) {
+        for (int k = 0; k < KS; ++k) {
             const uint32_t a0 = a_s[k * MF_LD], a1 = a_s[k * MF_LD + 32];
             const uint32_t b0 = b_s[k * MF_LD], b1 = b_s[k * MF_LD + 32];
             const v4i fa[2] = {expand16(tab01, a0, 16u * h), expand16(tab01, a1, 16u * h)};
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_mfma(const uint32_t *__restrict
                 const v4i ff[2] = {expand16(tabff, b0, 16u * h), expand16(tabff, b1, 16u * h)};
 #pragma unroll
                 for (int p = 0; p < PL; ++p) {
-                    const v4i dg = *reinterpret_cast<const v4i *>(sW(buf) + p * MF_KS * 8 + k * 8 + 4 * h);
+                    const v4i dg = *reinterpret_cast<const v4i *>(sW(buf) + p * KS * 8 + k * 8 + 4 * h);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const v4i fb = ff[j] & dg;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void k_pair_mfma_reduce(const unsigned long lo
     }
 }
 
-static size_t mfma_lds_bytes(uint32_t pl) { return (size_t)(4 * MF_KS * MF_LD + 2 * pl * MF_KS * 8 + 2 * 256 * 2) * sizeof(uint32_t); }
+static size_t mfma_lds_bytes(uint32_t pl, uint32_t ks = MF_KS) { return (size_t)(4 * ks * MF_LD + 2 * pl * ks * 8 + 2 * 256 * 2) * sizeof(uint32_t); }
 
 int launch_pair_intersections_mfma(pnx_ctx *ctx) {
     const uint32_t G = ctx->n_groups, NB = ctx->n_blocks;
@@ -280,11 +286,15 @@ int launch_pair_intersections_mfma(pnx_ctx *ctx) {
     const uint32_t *M = (const uint32_t *)ctx->d_M.p, *dg = (const uint32_t *)ctx->d_wdigits.p;
     unsigned long long *part = (unsigned long long *)ctx->d_pair_partial.p;
     if (!ctx->weighted) {
-        const size_t lds = mfma_lds_bytes(1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_mfma<false, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        hipLaunchKernelGGL((k_pair_mfma<false, 1, false>), grid, dim3(256), lds, ctx->stream, M, row_words, G, n_side,
-                           (uint32_t)chunk_words, (const uint32_t *)nullptr, 0u, part);
+        static const bool ks32 = std::getenv("PNX_PAIRS_KS32") != nullptr;  // experiments: round 2's staging depth
+        auto go = [&](auto kern, uint32_t ks) {
+            const size_t lds = mfma_lds_bytes(1, ks);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, M, row_words, G, n_side, (uint32_t)chunk_words,
+                               (const uint32_t *)nullptr, 0u, part);
+        };
+        if (ks32) go(k_pair_mfma<false, 1, false, 32>, 32);
+        else go(k_pair_mfma<false, 1, false, 16>, 16);
     } else {
         for (uint32_t base = 0; base < n_digits; base += 3) {
             const uint32_t pl = n_digits - base < 3 ? n_digits - base : 3;
@@ -294,9 +304,9 @@ int launch_pair_intersections_mfma(pnx_ctx *ctx) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, M, row_words, G, n_side, (uint32_t)chunk_words, dg, base, part);
             };
-            if (pl == 3) first ? go(k_pair_mfma<true, 3, false>) : go(k_pair_mfma<true, 3, true>);
-            else if (pl == 2) first ? go(k_pair_mfma<true, 2, false>) : go(k_pair_mfma<true, 2, true>);
-            else first ? go(k_pair_mfma<true, 1, false>) : go(k_pair_mfma<true, 1, true>);
+            if (pl == 3) first ? go(k_pair_mfma<true, 3, false, 32>) : go(k_pair_mfma<true, 3, true, 32>);
+            else if (pl == 2) first ? go(k_pair_mfma<true, 2, false, 32>) : go(k_pair_mfma<true, 2, true, 32>);
+            else first ? go(k_pair_mfma<true, 1, false, 32>) : go(k_pair_mfma<true, 1, true, 32>);
         }
     }
     hipLaunchKernelGGL(k_pair_mfma_reduce, dim3(n_side * n_side, MF_T * MF_T / 256), dim3(256), 0, ctx->stream,
