@@ -92,6 +92,14 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        looking for the lines; the copy is the larger part of the call)
  *   col_begin, col_end   per path the byte range [begin, end) of its step column inside text
  *   is_walk              per path: 1 = W line, 0 = P line
+ *   edge_uv, edge_oo     NULL for node / bp counts.  Edge counts: the edges of the graph as in pnx_walks -- n_edges + 1
+ *                        entries indexed by edge id ([0] unused), canonical ends (smaller node id << 32 | larger) and
+ *                        orientations (o1 << 1 | o2) as Edge::canonical writes them (graph.rs:142-148), every edge once.
+ *                        The walks (node id + orientation of every step) then never leave the device: the edge of every
+ *                        consecutive step pair is looked up in a hash table in HBM (what parse_path_seq_to_item_vec /
+ *                        parse_walk_seq_to_item_vec do per step with edge2id, util.rs:1048-1091) and the EDGE ItemTable --
+ *                        a path of k steps has k - 1 entries -- becomes the resident graph with n_edges items; a step pair
+ *                        without an edge fails the call (the reference panics, util.rs:1080).  weights must be NULL.
  * pnx_gfa_text_upload copies synchronously; the library frees its copy of the text at the end of pnx_set_csr_gfa. */
 typedef struct pnx_gfa_steps {
     const char *text;
@@ -101,6 +109,9 @@ typedef struct pnx_gfa_steps {
     const uint8_t *is_walk;
     const uint32_t *id_of_name;
     uint64_t n_names;
+    const uint64_t *edge_uv;
+    const uint8_t *edge_oo;
+    uint32_t n_edges;
 } pnx_gfa_steps;
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);

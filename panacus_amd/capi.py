@@ -64,7 +64,8 @@ class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
 class PnxGfaSteps(C.Structure):  # pnx_gfa_steps
     _fields_ = [("text", C.c_char_p), ("text_bytes", C.c_uint64), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("col_begin", C.POINTER(C.c_uint64)), ("col_end", C.POINTER(C.c_uint64)), ("is_walk", C.POINTER(C.c_uint8)),
-                ("id_of_name", C.POINTER(C.c_uint32)), ("n_names", C.c_uint64)]
+                ("id_of_name", C.POINTER(C.c_uint32)), ("n_names", C.c_uint64),
+                ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint32)]
 
 
 class PnxPieceEvent(C.Structure):  # pnx_piece_event
@@ -303,8 +304,10 @@ class Context:
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
         self.n_items = n_nodes
 
-    def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False):
-        """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device"""
+    def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False,
+                    edge_uv=None, edge_oo=None):
+        """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device; with edge_uv / edge_oo
+        (n_edges + 1 entries, [0] unused) the EDGE ItemTable of the same walks"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
         ce = np.ascontiguousarray(col_end, dtype=np.uint64)
         wk = np.ascontiguousarray(is_walk, dtype=np.uint8)
@@ -320,8 +323,11 @@ class Context:
         g.n_paths, g.n_nodes = len(cb), n_nodes
         g.col_begin, g.col_end, g.is_walk = _ptr(cb, C.c_uint64), _ptr(ce, C.c_uint64), _ptr(wk, C.c_uint8)
         g.id_of_name, g.n_names = _ptr(names, C.c_uint32), (0 if names is None else len(names))
+        uv = None if edge_uv is None else np.ascontiguousarray(edge_uv, dtype=np.uint64)
+        oo = None if edge_oo is None else np.ascontiguousarray(edge_oo, dtype=np.uint8)
+        g.edge_uv, g.edge_oo, g.n_edges = _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8), (0 if uv is None else len(uv) - 1)
         self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
-        self.n_items = n_nodes
+        self.n_items = n_nodes if uv is None else len(uv) - 1
 
     def prepare(self):
         self._ck(self._L.pnx_prepare(self._h))

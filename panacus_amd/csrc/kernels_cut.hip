@@ -249,6 +249,41 @@ __global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeTab t
     }
 }
 
+// the same over walks that were tokenised on the device (pnx_set_csr_gfa with edges): one thread per step, its path found
+// by a binary search in the path offsets; out[edge_off[path] + local index] = edge to the successor in the same path
+__global__ __launch_bounds__(256) void k_edge_items_flat(const uint32_t *__restrict__ node, const uint8_t *__restrict__ backward,
+                                                         const uint64_t *__restrict__ path_off, uint32_t n_paths,
+                                                         const uint64_t *__restrict__ edge_off, uint64_t n_steps, EdgeTab t,
+                                                         uint32_t *__restrict__ out, unsigned long long *bad_step) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_steps) return;
+    uint32_t lo = 0, hi = n_paths;  // the path p with path_off[p] <= j < path_off[p + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (path_off[mid] <= j) lo = mid; else hi = mid;
+    }
+    if (j + 1 >= path_off[lo + 1]) return;  // last step of its path
+    uint64_t uv;
+    uint32_t oo;
+    canonical_edge(node[j], backward[j] & 1u, node[j + 1], backward[j + 1] & 1u, uv, oo);
+    uint64_t slot = edge_hash(uv, oo) & t.mask;
+    uint32_t id = 0;
+    for (;;) {
+        const unsigned long long k = t.key[slot];
+        if (k == 0ull) break;
+        if (k == uv) {
+            const uint32_t v = t.val[slot];
+            if ((v & 3u) == oo) {
+                id = v >> 2;
+                break;
+            }
+        }
+        slot = (slot + 1) & t.mask;
+    }
+    if (!id) atomicMin(bad_step, (unsigned long long)j);
+    out[edge_off[lo] + (j - path_off[lo])] = id;
+}
+
 template <bool EMIT>
 __global__ __launch_bounds__(CUT_THREADS) void k_cut(CutArgs a) {
     __shared__ unsigned long long lds64[CUT_THREADS / 64 + 1];
@@ -597,6 +632,64 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     }
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_steps = total;
+    return PNX_OK;
+}
+
+// pnx_set_csr_gfa with edges: the node walks gfa_tokenise left in d_items (+ one orientation byte per step) become the edge
+// ItemTable of the same paths, on the device
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges) {
+    struct Scratch {
+        DevBuf e_uv, e_oo, tab_key, tab_val, eoff, out, counters;
+        ~Scratch() {
+            for (DevBuf *b : {&e_uv, &e_oo, &tab_key, &tab_val, &eoff, &out, &counters}) release(*b);
+        }
+    } s;
+    hipStream_t st = ctx->stream;
+    int rc;
+    const uint64_t S = ctx->n_steps;
+    const size_t p1 = (size_t)n_paths + 1;
+    std::vector<uint64_t> edge_off(p1, 0);
+    for (uint32_t p = 0; p < n_paths; ++p) {
+        const uint64_t len = ctx->h_path_off[p + 1] - ctx->h_path_off[p];
+        edge_off[p + 1] = edge_off[p] + (len ? len - 1 : 0);
+    }
+    const uint64_t Se = edge_off[n_paths];
+    uint64_t slots = 1024;
+    while (slots < 2ull * n_edges) slots <<= 1;
+    if ((rc = ensure(ctx, s.e_uv, ((size_t)n_edges + 1) * 8)) || (rc = ensure(ctx, s.e_oo, (size_t)n_edges + 1)) ||
+        (rc = ensure(ctx, s.tab_key, slots * 8)) || (rc = ensure(ctx, s.tab_val, slots * 4)) || (rc = ensure(ctx, s.eoff, p1 * 8)) ||
+        (rc = ensure(ctx, s.out, (Se ? Se : 1) * sizeof(uint32_t) + 64)) || (rc = ensure(ctx, s.counters, 64)))
+        return rc;
+    PNX_HIP(ctx, hipMemcpyAsync(s.e_uv.p, edge_uv, ((size_t)n_edges + 1) * 8, hipMemcpyHostToDevice, st));
+    PNX_HIP(ctx, hipMemcpyAsync(s.e_oo.p, edge_oo, (size_t)n_edges + 1, hipMemcpyHostToDevice, st));
+    PNX_HIP(ctx, hipMemcpyAsync(s.eoff.p, edge_off.data(), p1 * 8, hipMemcpyHostToDevice, st));
+    PNX_HIP(ctx, hipMemsetAsync(s.tab_key.p, 0, slots * 8, st));
+    PNX_HIP(ctx, hipMemsetAsync(s.counters.p, 0, 64, st));
+    PNX_HIP(ctx, hipMemsetAsync((char *)s.counters.p + 16, 0xFF, 8, st));  // smallest step without an edge
+    EdgeTab tab{(unsigned long long *)s.tab_key.p, (uint32_t *)s.tab_val.p, slots - 1};
+    uint32_t *d_bad = (uint32_t *)s.counters.p;
+    unsigned long long *d_bad_step = (unsigned long long *)((char *)s.counters.p + 16);
+    if (n_edges)
+        hipLaunchKernelGGL(k_edge_tab_insert, dim3((n_edges + 255) / 256), dim3(256), 0, st, (const uint64_t *)s.e_uv.p, (const uint8_t *)s.e_oo.p,
+                           n_edges, tab, d_bad);
+    if (S)
+        hipLaunchKernelGGL(k_edge_items_flat, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, (const uint32_t *)ctx->d_items.p,
+                           (const uint8_t *)d_backward.p, (const uint64_t *)ctx->d_path_off.p, n_paths, (const uint64_t *)s.eoff.p, S, tab,
+                           (uint32_t *)s.out.p, d_bad_step);
+    PNX_HIP(ctx, hipGetLastError());
+    struct {
+        uint32_t bad, pad[3];
+        unsigned long long bad_step;
+    } h{};
+    PNX_HIP(ctx, hipMemcpyAsync(&h, s.counters.p, 24, hipMemcpyDeviceToHost, st));
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, s.eoff.p, p1 * 8, hipMemcpyDeviceToDevice, st));
+    PNX_HIP(ctx, hipStreamSynchronize(st));
+    if (h.bad) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: an edge is not in canonical form (smaller end << 32 | larger, node ids from 1)");
+    if (h.bad_step != ~0ull)
+        return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: step %llu and its successor are not joined by an edge of the graph", h.bad_step);
+    std::swap(ctx->d_items, s.out);  // (the node walks are released with the scratch)
+    ctx->h_path_off = edge_off;
+    ctx->n_steps = Se;
     return PNX_OK;
 }
 

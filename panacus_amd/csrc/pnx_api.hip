@@ -478,12 +478,17 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
         (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
         return rc;
-    rc = gfa_tokenise(ctx, g, nullptr);
+    const bool edges = g->edge_uv != nullptr;
+    if (edges && (!g->edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo, and no weights");
+    DevBuf d_backward;
+    rc = gfa_tokenise(ctx, g, edges ? &d_backward : nullptr);
     release(ctx->d_gfa_text);
     ctx->gfa_text_host = nullptr;
     ctx->gfa_text_bytes = 0;
+    if (rc == PNX_OK && edges) rc = gfa_edge_items(ctx, g->n_paths, d_backward, g->edge_uv, g->edge_oo, g->n_edges);
+    release(d_backward);
     if (rc) return rc;
-    return finish_upload(ctx, ctx->n_steps, g->n_paths, g->n_nodes, weights, exclude, false, nullptr);
+    return finish_upload(ctx, ctx->n_steps, g->n_paths, edges ? g->n_edges : g->n_nodes, weights, exclude, false, nullptr);
 }
 
 int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {

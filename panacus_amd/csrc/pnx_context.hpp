@@ -343,6 +343,7 @@ int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_inte
 // kernels_cut.hip
 int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
 int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n);
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges);
 int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
 int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip

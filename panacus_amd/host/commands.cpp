@@ -113,7 +113,9 @@ void Device::no_text() const {
 bool Device::text_uploaded() const {
     (void)ctx();
     std::lock_guard<std::mutex> g(text_->mu);
-    return text_->uploaded;
+    const bool there = text_->uploaded;
+    text_->uploaded = false;  // one use: pnx_set_csr_gfa frees the library's copy; a second upload of the command passes the text again
+    return there;
 }
 pnx_ctx *Device::ctx() const {
     if (init_.valid()) ctx_ = init_.get();  // throws what the initialisation threw
@@ -146,11 +148,8 @@ void Device::check(int rc) const {
 }
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
-bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &cts) {
-    if (o.cache || !o.subset_file.empty() || !o.exclude_file.empty() || std::getenv("PANACUS_AMD_HOST_PARSE")) return false;
-    for (CountType c : cts)
-        if (c != COUNT_EDGE) return true;
-    return false;
+bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &) {
+    return !(o.cache || !o.subset_file.empty() || !o.exclude_file.empty() || std::getenv("PANACUS_AMD_HOST_PARSE"));
 }
 
 std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev) {
@@ -256,25 +255,36 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     // -s / -e lists: the walks are cut on the device.  Edge counts take the same entry even without lists (every path
     // "cut" by the whole-path interval): the node walks go up and the library finds the edge of every step pair in a hash
     // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
-    if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file())) {
+    const bool on_device = g.steps_tokenisable_on_device() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file() && !on_device)) {
         uncovered = upload_cut([&dev]() { return dev.ctx(); }, g, ct, mk, growth_weights);
-    } else if (ct != COUNT_EDGE && g.steps_tokenisable_on_device() && !std::getenv("PANACUS_AMD_HOST_PARSE")) {
-        // numeric segment names: the node ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is
-        // parsed on the host, no ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it
+    } else if (on_device && !g.from_cache_file()) {
+        // numeric segment names: the ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is parsed
+        // on the host, no ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it.  Edge counts:
+        // the walks stay on the device too, the host hands over the edges of the L lines and the library looks the edge of
+        // every step pair up itself
         std::vector<uint64_t> cb, ce;
         std::vector<uint8_t> wk;
         g.step_columns(cb, ce, wk);
+        std::vector<uint64_t> euv;
+        std::vector<uint8_t> eoo;
+        if (ct == COUNT_EDGE) g.edge_ends(euv, eoo);
         const bool there = dev.text_uploaded();
         pnx_gfa_steps st{};
         st.text = there ? nullptr : g.text_data();
         st.text_bytes = there ? 0 : g.text_size();
         st.n_paths = n_paths;
-        st.n_nodes = (uint32_t)n_items;
+        st.n_nodes = (uint32_t)g.node_count();
         st.col_begin = cb.data();
         st.col_end = ce.data();
         st.is_walk = wk.data();
         st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
         st.n_names = g.id_of_name().size();
+        if (ct == COUNT_EDGE) {
+            st.edge_uv = euv.data();
+            st.edge_oo = eoo.data();
+            st.n_edges = (uint32_t)n_items;
+        }
         phase_mark(there ? "columns ready (text was uploaded beside the parse)" : "columns ready");
         dev.check(pnx_set_csr_gfa(dev.ctx(), &st, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
         phase_mark("pnx_set_csr_gfa (tokenise + rows)");

@@ -44,7 +44,7 @@ struct Device {
     void offer_text(const char *data, size_t size, std::shared_ptr<const void> keep) const;
     void no_text() const;            // nothing will be offered (idempotent; also after an offer: no effect)
     void leak() const { leaked_ = true; }  // the process is about to exit: leave the context to the driver
-    bool text_uploaded() const;      // after ctx(): the offered text is in HBM
+    bool text_uploaded() const;      // after ctx(): the offered text is in HBM -- true ONCE (the upload that uses it consumes the copy)
 
 private:
     struct TextSlot;

@@ -214,6 +214,9 @@ struct EdgeMap {  // canonical (u, o1, v, o2) -> edge id
         mask = cap - 1;
         n = 0;
     }
+    // the same with the table cleared by the pool's threads: 268 MB of first-touch page faults for 6 M edges are 60-80 ms on
+    // one thread
+    void init_parallel(size_t want);
     static uint64_t h(uint64_t uv, uint8_t oo) {
         uint64_t x = (uv ^ ((uint64_t)oo << 62)) * 0x9FB21C651E98DF25ull;
         return x ^ (x >> 31);
@@ -237,6 +240,23 @@ struct EdgeMap {  // canonical (u, o1, v, o2) -> edge id
         return true;
     }
 };
+
+void EdgeMap::init_parallel(size_t want) {
+    size_t cap = 64;
+    while (cap < want * 2) cap <<= 1;
+    std::vector<Slot> fresh;
+    fresh.reserve(cap);  // untouched pages: the pool's threads fault them in, the assignment below then only writes
+    char *base = reinterpret_cast<char *>(fresh.data());
+    const size_t bytes = cap * sizeof(Slot), slice = (size_t)16 << 20;
+    ThreadPool::instance().parallel_for((bytes + slice - 1) / slice, [&](size_t t) {
+        const size_t e = std::min(bytes, (t + 1) * slice);
+        std::memset(base + t * slice, 0, e - t * slice);
+    });
+    fresh.assign(cap, Slot{0, 0, 0});
+    tab.swap(fresh);
+    mask = cap - 1;
+    n = 0;
+}
 
 // Edge::canonical (graph.rs:142-148); orientation 0 = Forward, 1 = Backward
 inline void canonical(uint32_t u, uint8_t o1, uint32_t v, uint8_t o2, uint64_t &uv, uint8_t &oo) {
@@ -425,6 +445,8 @@ struct GraphStorage::Impl {
     std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
     bool has_edges = false;
     EdgeMap edges;
+    std::vector<uint64_t> edge_uv_by_id;  // the edges in id order ([0] unused), kept beside the map: what edge_ends hands out
+    std::vector<uint8_t> edge_oo_by_id;
 
     // filled instead of the fields above when the graph comes from a .pcsr cache
     bool cached = false;                 // image = the mapped .pcsr file, the arrays below point into it
@@ -641,7 +663,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     // --- L lines: edge id = rank of the first occurrence of the canonical form ---
     if (index_edges) {
         im.has_edges = true;
-        im.edges.init(l_lines.size());
+        im.edges.init_parallel(l_lines.size());
         // the lines are parsed in parallel (two name lookups each); ids are given in file order afterwards
         const size_t n_l = l_lines.size();
         std::vector<uint64_t> l_uv(n_l);
@@ -685,10 +707,70 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             size_t b0 = a1 + 3, b1 = field_end(s, b0, ln.e);
             throw std::runtime_error("unknown node " + s.substr(b0, b1 - b0));
         }
+        // The map is filled by all threads at once.  A slot is claimed by a compare-and-swap on its ends; its id field
+        // carries, while the map is built, the TAG of the earliest line with that edge -- (line + 1) << 2 | orientations, 0 =
+        // not written yet -- lowered by an atomic minimum, so that duplicated edges (skipped by the reference, graph.rs:296)
+        // resolve to their first occurrence whatever the threads' order.  Ids are then the ranks of the first occurrences
+        // in file order, as a serial pass would give them.
+        if (n_l >= ((size_t)1 << 30)) throw std::runtime_error("more than 2^30 L lines");
+        std::vector<uint32_t> slot_of(n_l);
+        auto &tab = im.edges.tab;
+        const uint64_t mask = im.edges.mask;
+        ThreadPool::instance().parallel_for((n_l + L_CHUNK - 1) / L_CHUNK, [&](size_t c) {
+            const size_t hi = std::min(n_l, (c + 1) * L_CHUNK);
+            for (size_t k = c * L_CHUNK; k < hi; ++k) {
+                const uint64_t uv = l_uv[k];
+                const uint32_t oo = l_oo[k], tag = (uint32_t)(((k + 1) << 2) | oo);
+                uint64_t j = EdgeMap::h(uv, (uint8_t)oo) & mask;
+                for (;;) {
+                    uint64_t cur = __atomic_load_n(&tab[j].uv, __ATOMIC_ACQUIRE);
+                    bool mine = false;
+                    if (cur == 0) {
+                        uint64_t expected = 0;
+                        mine = __atomic_compare_exchange_n(&tab[j].uv, &expected, uv, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+                        cur = mine ? uv : expected;
+                    }
+                    if (cur == uv) {
+                        uint32_t t = __atomic_load_n(&tab[j].id, __ATOMIC_ACQUIRE);
+                        if (!mine)
+                            while (t == 0) t = __atomic_load_n(&tab[j].id, __ATOMIC_ACQUIRE);  // the claimer writes it next
+                        if (mine || (t & 3u) == oo) {
+                            while ((t == 0 || tag < t) &&
+                                   !__atomic_compare_exchange_n(&tab[j].id, &t, tag, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+                            }
+                            slot_of[k] = (uint32_t)j;
+                            break;
+                        }
+                    }
+                    j = (j + 1) & mask;
+                }
+            }
+        });
+        std::vector<uint32_t> id_of_line(n_l);
+        ThreadPool::instance().parallel_for((n_l + L_CHUNK - 1) / L_CHUNK, [&](size_t c) {  // (random reads of the map: not for one thread)
+            const size_t hi = std::min(n_l, (c + 1) * L_CHUNK);
+            for (size_t k = c * L_CHUNK; k < hi; ++k) id_of_line[k] = tab[slot_of[k]].id == (uint32_t)(((k + 1) << 2) | l_oo[k]) ? 1u : 0u;
+        });
         uint32_t next = 1;
         for (size_t k = 0; k < n_l; ++k)
-            if (im.edges.insert(l_uv[k], l_oo[k], next)) ++next;  // duplicated edges are skipped (graph.rs:296)
+            if (id_of_line[k]) id_of_line[k] = next++;
+        im.edge_uv_by_id.assign(next, 0);
+        im.edge_oo_by_id.assign(next, 0);
+        ThreadPool::instance().parallel_for((n_l + L_CHUNK - 1) / L_CHUNK, [&](size_t c) {
+            const size_t hi = std::min(n_l, (c + 1) * L_CHUNK);
+            for (size_t k = c * L_CHUNK; k < hi; ++k) {
+                const uint32_t id = id_of_line[k];
+                if (!id) continue;
+                auto &sl = tab[slot_of[k]];
+                sl.id = id;
+                sl.oo = l_oo[k];
+                im.edge_uv_by_id[id] = l_uv[k];
+                im.edge_oo_by_id[id] = l_oo[k];
+            }
+        });
+        im.edges.n = next - 1;
         g->edge_count_ = next - 1;
+        phase_mark("L lines (edges)");
     }
     return g;
 }
@@ -1396,11 +1478,23 @@ void GraphStorage::edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo
         }
         return;
     }
-    for (const auto &sl : im.edges.tab)
-        if (sl.id) {
-            uv[sl.id] = sl.uv;
-            oo[sl.id] = sl.oo;
+    if (im.edge_uv_by_id.size() == edge_count_ + 1) {  // kept in id order when the L lines were read
+        uv = im.edge_uv_by_id;
+        oo = im.edge_oo_by_id;
+        return;
+    }
+    // (every id is written by exactly one slot: the slices of the table go to the pool)
+    const size_t n_slots = im.edges.tab.size(), slice = (size_t)1 << 18;
+    ThreadPool::instance().parallel_for((n_slots + slice - 1) / slice, [&](size_t t) {
+        const size_t e = std::min(n_slots, (t + 1) * slice);
+        for (size_t k = t * slice; k < e; ++k) {
+            const auto &sl = im.edges.tab[k];
+            if (sl.id) {
+                uv[sl.id] = sl.uv;
+                oo[sl.id] = sl.oo;
+            }
         }
+    });
 }
 
 std::vector<uint32_t> GraphStorage::edge_relabel() const {

@@ -89,3 +89,91 @@ def test_malformed_steps_fail_the_call(ctx, bad):
     # ... and a column outside the text is refused before anything is touched
     with pytest.raises(capi.PnxError):
         ctx.set_csr_gfa(text, cb, ce + np.uint64(100), np.array([0], np.uint8), n)
+
+
+def _canonical(u, o1, v, o2):
+    """Edge::canonical (graph.rs:142-148)"""
+    if u > v or (u == v and o1 == 1):
+        return (v << 32) | u, ((o2 ^ 1) << 1) | (o1 ^ 1)
+    return (u << 32) | v, (o1 << 1) | o2
+
+
+@pytest.mark.parametrize("nice", [True, False])
+def test_edge_item_table_from_walks_that_stay_on_the_device(ctx, nice):
+    """pnx_set_csr_gfa with edge_uv / edge_oo: the walks are tokenised on the device and the edge of every consecutive step
+    pair is looked up there (parse_path_seq_to_item_vec / parse_walk_seq_to_item_vec with edge2id, util.rs:1048-1091):
+    the resident items are edge ids, a path of k steps has k - 1 of them; coverage and histogram against the oracle"""
+    rng = np.random.default_rng(11 + nice)
+    n, P = 3000, 40
+    if nice:
+        names = [str(i) for i in range(1, n + 1)]
+        table = None
+    else:
+        vals = rng.permutation(3 * n)[:n] + 1
+        names = [str(int(v)) for v in vals]
+        table = np.zeros(3 * n + 2, dtype=np.uint32)
+        table[vals] = np.arange(1, n + 1, dtype=np.uint32)
+    parts, cb, ce, wk, walks = [b"H\tVN:Z:1.1\n"], [], [], [], []
+    pos = len(parts[0])
+    for p in range(P):
+        ln = int(rng.integers(0, 300)) if p % 9 else (1 if p else 0)     # also an empty path and a path of one step
+        ids = rng.integers(1, 60, size=ln).cumsum() % n + 1              # local walks: the same edges come back in other paths
+        back = (rng.random(ln) < 0.3).astype(np.int64)
+        walk = p % 3 == 0
+        if walk:
+            head = f"W\ts{p}\t1\tctg\t0\t{ln}\t".encode()
+            col = "".join(("<" if b else ">") + names[i - 1] for i, b in zip(ids, back)).encode()
+            tail = b"\n"
+        else:
+            head = f"P\ts{p}#1#c{p}\t".encode()
+            col = ",".join(names[i - 1] + ("-" if b else "+") for i, b in zip(ids, back)).encode()
+            tail = b"\t*\n"
+        cb.append(pos + len(head))
+        ce.append(pos + len(head) + len(col))
+        wk.append(1 if walk else 0)
+        walks.append((ids, back))
+        parts += [head, col, tail]
+        pos += len(head) + len(col) + len(tail)
+    text = b"".join(parts)
+    # the edges of the graph: every canonical pair once, ids in order of first appearance; plus edges no path uses
+    edge_id, uv, oo = {}, [0], [0]
+    for ids, back in walks:
+        for a in range(len(ids) - 1):
+            k = _canonical(int(ids[a]), int(back[a]), int(ids[a + 1]), int(back[a + 1]))
+            if k not in edge_id:
+                edge_id[k] = len(uv)
+                uv.append(k[0])
+                oo.append(k[1])
+    for extra in range(50):
+        k = _canonical(n - extra, 0, n - extra, 0)
+        if k not in edge_id:
+            edge_id[k] = len(uv)
+            uv.append(k[0])
+            oo.append(k[1])
+    want = [np.array([edge_id[_canonical(int(ids[a]), int(back[a]), int(ids[a + 1]), int(back[a + 1]))] for a in range(len(ids) - 1)],
+                     dtype=np.uint32) for ids, back in walks]
+    E = len(uv) - 1
+    ctx.set_csr_gfa(text, np.array(cb, np.uint64), np.array(ce, np.uint64), np.array(wk, np.uint8), n, id_of_name=table,
+                    edge_uv=np.array(uv, np.uint64), edge_oo=np.array(oo, np.uint8))
+    items, off, _ = ctx.get_csr()
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum([len(w) for w in want])]).astype(np.uint64))
+    assert np.array_equal(items, np.concatenate(want)) and ctx.info().n_items == E
+    pi = np.arange(P, dtype=np.uint64)
+    gi = (pi // 2).astype(np.uint64)
+    ctx.set_order(pi, gi, P // 2)
+    cnt, h = ctx.hist()
+    ocov = orc.coverage(np.concatenate(want).astype(np.uint64), off, pi, gi, E)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 2))
+    # a step pair the graph has no edge for fails the call (the reference panics, util.rs:1080); so does an edge that is not canonical
+    from panacus_amd import capi
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(text, np.array(cb, np.uint64), np.array(ce, np.uint64), np.array(wk, np.uint8), n, id_of_name=table,
+                        edge_uv=np.array(uv[:-60], np.uint64), edge_oo=np.array(oo[:-60], np.uint8))
+    assert e.value.code == capi.PNX_EINVAL and "not joined by an edge" in str(e.value)
+    bad = np.array(uv, np.uint64)
+    bad[1] = (np.uint64(5) << np.uint64(32)) | np.uint64(2)
+    with pytest.raises(capi.PnxError):
+        ctx.set_csr_gfa(text, np.array(cb, np.uint64), np.array(ce, np.uint64), np.array(wk, np.uint8), n, id_of_name=table,
+                        edge_uv=bad, edge_oo=np.array(oo, np.uint8))
+    with pytest.raises(capi.PnxError):
+        ctx.hist()   # nothing is resident after a rejected upload

@@ -367,3 +367,31 @@ def test_bgzf_input_is_inflated_block_by_block(tmp_path, golden_dir):
     open(bad, "wb").write(bytes(raw))
     with pytest.raises(ValueError):
         hl.GfaGraph(bad)
+
+
+def test_duplicated_links_resolve_to_their_first_line(tmp_path):
+    """the edge map is filled by all threads at once: an edge written several times -- also in its other spelling, b- a- for
+    a+ b+ -- keeps the id of its FIRST line (duplicates are skipped, graph.rs:296), ids are ranks of the first occurrences in
+    file order, exactly as the oracle's serial pass gives them"""
+    path = str(tmp_path / "syn.gfa")
+    rc, out, err = hl.run_cli(["synth", "--nodes", "30000", "--paths", "8", "--links", "-o", path])
+    assert rc == 0, err
+    lines = [l for l in open(path).read().split("\n") if l]
+    links = [l for l in lines if l.startswith("L\t")]
+    rng = np.random.default_rng(5)
+    flip = {"+": "-", "-": "+"}
+    extra = []
+    for i in rng.integers(0, len(links), size=len(links) // 2):
+        _, a, oa, b, ob, cg = links[int(i)].split("\t")
+        extra.append(links[int(i)] if rng.random() < 0.5 else "\t".join(["L", b, flip[ob], a, flip[oa], cg]))
+    mixed = links + extra
+    order = rng.permutation(len(mixed))
+    dup = str(tmp_path / "dup.gfa")
+    with open(dup, "w") as f:
+        f.write("\n".join([l for l in lines if not l.startswith("L\t")] + [mixed[i] for i in order]) + "\n")
+    a = hl.GfaGraph(dup, index_edges=True)
+    b = orc.Graph(dup, index_edges=True)
+    assert a.n_edges == b.n_edges == len(links)
+    ia, pa = a.item_table(hl.EDGE)
+    ib, pb = b.item_table(hl.EDGE)
+    assert np.array_equal(pa, pb) and np.array_equal(ia.astype(np.uint64), ib)
