@@ -149,6 +149,7 @@ void Device::check(int rc) const {
 
 // GraphStorage::from_gfa, or the .pcsr cache next to the GFA when --cache is given
 bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &) {
+    // (with a -s list the text is not sent ahead: whether the list needs the walks is only known once the paths are)
     return !(o.cache || !o.subset_file.empty() || !o.exclude_file.empty() || std::getenv("PANACUS_AMD_HOST_PARSE"));
 }
 
@@ -255,10 +256,14 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     // -s / -e lists: the walks are cut on the device.  Edge counts take the same entry even without lists (every path
     // "cut" by the whole-path interval): the node walks go up and the library finds the edge of every step pair in a hash
     // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
-    const bool on_device = g.steps_tokenisable_on_device() && !std::getenv("PANACUS_AMD_HOST_PARSE");
-    if (mk.any() || (ct == COUNT_EDGE && !g.from_cache_file() && !on_device)) {
+    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    // a -s list that only picks whole paths (names of paths, samples, haplotypes; intervals that contain a path) needs no walk:
+    // the paths it leaves out get an empty step column
+    std::vector<uint8_t> take;
+    const bool path_level = mk.any() && on_device && g.mask_is_path_level(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file, take);
+    if ((mk.any() && !path_level) || (ct == COUNT_EDGE && !g.from_cache_file() && !on_device)) {
         uncovered = upload_cut([&dev]() { return dev.ctx(); }, g, ct, mk, growth_weights);
-    } else if (on_device && !g.from_cache_file()) {
+    } else if (on_device) {
         // numeric segment names: the ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is parsed
         // on the host, no ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it.  Edge counts:
         // the walks stay on the device too, the host hands over the edges of the L lines and the library looks the edge of
@@ -266,6 +271,9 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
         std::vector<uint64_t> cb, ce;
         std::vector<uint8_t> wk;
         g.step_columns(cb, ce, wk);
+        if (path_level)
+            for (size_t k = 0; k < take.size(); ++k)
+                if (!take[k]) ce[k] = cb[k];
         std::vector<uint64_t> euv;
         std::vector<uint8_t> eoo;
         if (ct == COUNT_EDGE) g.edge_ends(euv, eoo);

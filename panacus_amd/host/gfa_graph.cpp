@@ -1908,6 +1908,20 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
     return out;
 }
 
+bool GraphStorage::mask_is_path_level(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
+                                      const std::string &exclude_file, std::vector<uint8_t> &take) const {
+    take.clear();
+    if (!exclude_file.empty() || subset_file.empty() || count == COUNT_EDGE) return false;  // (edges are always walked, see mask_setup)
+    MaskSetup ms;
+    mask_setup(ms, paths_, count, mode, group_file, subset_file, exclude_file);
+    take.assign(paths_.size(), 0);
+    for (size_t k = 0; k < paths_.size(); ++k) {
+        if (ms.how[k] == WALK) return false;
+        take[k] = ms.how[k] == WHOLE ? 1 : 0;
+    }
+    return true;
+}
+
 WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
                                const std::string &exclude_file) const {
     const Impl &im = *impl_;

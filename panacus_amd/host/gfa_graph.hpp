@@ -127,6 +127,11 @@ public:
 
     WalkCut walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
                      const std::string &exclude_file) const;
+    // true when a -s list needs no walking at all for this count type: every path is either taken whole or not touched (a
+    // list of path / sample / haplotype names, or of intervals that contain whole paths) and there is no -e list; take[k]
+    // says which.  The item table of such a run is the plain one with the other paths left empty.
+    bool mask_is_path_level(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
+                            const std::string &exclude_file, std::vector<uint8_t> &take) const;
     // IntervalContainer bookkeeping of the partly covered / partly excluded nodes from the device's events
     // (src/util.rs:147-181,209-310; quantify_uncovered_bps, abacus.rs:1187-1229): `uncovered` as in
     // MaskedTable, `late_flags` = nodes whose partial exclude pieces join to cover them
