@@ -275,3 +275,35 @@ def test_histogram_with_more_bins_than_lds_holds(ctx):
         cnt, h = ctx.hist()
         ocov = orc.coverage(items, pre, pi, gid.astype(np.uint64), n)
         assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, G)), G
+
+
+def test_profile_sampling_times_every_nth_launch(ctx):
+    """pnx_profile_sample: with `every` = 3, seven passes leave three timed launches of the selected kernel (the 1st, 4th and
+    7th); the default times every launch; 0 is refused"""
+    from panacus_amd import capi
+    n, p = 30_000, 12
+    ctx.set_csr_pansyn(3, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    ctx.hist()
+    try:
+        ctx.profile_enable(True)
+        ctx.profile_select([capi.K_COVER])
+        ctx.profile_sample(3)
+        ctx.profile_reset()
+        for _ in range(7):
+            ctx.hist()
+        ms, launches = ctx.profile_read()["cover"]
+        assert launches == 3 and ms > 0
+        ctx.profile_sample(1)
+        ctx.profile_reset()
+        for _ in range(4):
+            ctx.hist()
+        assert ctx.profile_read()["cover"][1] == 4
+        with pytest.raises(capi.PnxError):
+            ctx.profile_sample(0)
+    finally:
+        ctx.profile_sample(1)
+        ctx.profile_select(None)
+        ctx.profile_reset()
+        ctx.profile_enable(False)
