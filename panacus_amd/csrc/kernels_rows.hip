@@ -384,7 +384,7 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
     constexpr int TPW = CW / SPLIT;  // tiles per workgroup
     static_assert(CW % SPLIT == 0, "waves per workgroup must be a multiple of the split");
     static_assert(!(SKIP && WRITE_M), "a pass that writes the presence matrix visits every group");
-    __shared__ uint32_t xch[SPLIT > 1 ? TPW * (SPLIT - 1) * NPL * 64 : 1];
+    __shared__ uint32_t xch[SPLIT > 1 ? TPW * SPLIT * NPL * 64 : 1];
     extern __shared__ unsigned long long sh_hist[];  // n_groups + 1 bins when the kernel adds the histogram
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -395,15 +395,18 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
     const uint32_t tile = active ? tile_raw : n_tiles - 1;
     const uint32_t k_lo = SPLIT > 1 ? (active ? sp.k[part] : 0u) : 0u;
     const uint32_t k_hi = SPLIT > 1 ? (active ? sp.k[part + 1] : 0u) : (active ? n_ordered : 0u);
-    // The histogram bins of the workgroup.  One tile per workgroup (TPW == 1): they belong to the one wave that finishes the
-    // tile, which clears, fills and flushes them without a barrier while the other waves are gone.  Several tiles: shared.
-    const bool fin = part == 0 && active;
+    // The tail of a tile -- counters unpacked into the coverage vector, histogram bins -- is shared by the SPLIT waves of the
+    // tile: every part adds up all parts' counters (they meet in LDS) and then owns 32 / SPLIT of the 32 bit positions.
+    // (With part 0 alone doing it, one wave ran ~1000 instructions while the others had left.)
+    const bool fin = active;
+    constexpr uint32_t BITS = 32 / SPLIT;                  // bit positions per part
+    const uint32_t b_lo = SPLIT > 1 ? part * BITS : 0u;   // this wave's positions: [b_lo, b_lo + BITS)
+    const uint32_t own = SPLIT > 1 ? (BITS == 32 ? 0xFFFFFFFFu : ((1u << BITS) - 1u) << b_lo) : 0xFFFFFFFFu;
     uint32_t *sh32 = reinterpret_cast<uint32_t *>(sh_hist);  // node counts: 4-byte bins (a workgroup holds at most 4 x 2048 items)
-    if (hs.rep && TPW > 1) {
+    if (hs.rep) {
         for (uint32_t b = threadIdx.x; b <= hs.n_groups; b += CW * 64) sh_hist[b] = 0;
         if (SPLIT == 1) __syncthreads();  // (SPLIT > 1: the barrier of the exchange below orders this before the first add)
     }
-
     // exclusion word in presence layout (ActiveTable, src/util.rs:118-124)
     uint32_t excl = 0;
     if (exclude) {
@@ -574,20 +577,18 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
     }
 
     if (SPLIT > 1) {
-        // parts 1.. hand their counters to part 0 of the tile
-        uint32_t *xt = xch + (size_t)(wave / SPLIT) * (SPLIT - 1) * NPL * 64;
-        if (part > 0) {
+        // every part leaves its counters in LDS and adds the others' to its own
+        uint32_t *xt = xch + (size_t)(wave / SPLIT) * SPLIT * NPL * 64;
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) xt[((part - 1) * NPL + k) * 64 + lane] = cnt[k];
-        }
+        for (int k = 0; k < NPL; ++k) xt[(part * NPL + k) * 64 + lane] = cnt[k];
         __syncthreads();
-        if (TPW == 1 && !fin) return;
         if (fin) {
-            for (int q = 0; q < SPLIT - 1; ++q) {
+            for (int q = 1; q < SPLIT; ++q) {
+                const uint32_t src = (part + (uint32_t)q) % SPLIT;
                 uint32_t carry = 0;
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
-                    const uint32_t a = cnt[k], b = xt[(q * NPL + k) * 64 + lane];
+                    const uint32_t a = cnt[k], b = xt[(src * NPL + k) * 64 + lane];
                     cnt[k] = a ^ b ^ carry;
                     carry = (a & b) | (carry & (a ^ b));
                 }
@@ -596,10 +597,6 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
     }
     if (fin) {
         const bool hist = hs.rep != nullptr, weighted = hs.weights != nullptr;
-        if (hist && TPW == 1) {
-            for (uint32_t b = lane; b <= hs.n_groups; b += 64) sh_hist[b] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
         // The bins 0, 1 and n_groups (uncovered, private and core items) hold most items of a pangenome; through LDS atomics
         // they would serialise up to 64 lanes on one address.  Node counts: the three bins are population counts of bit masks
         // over the planes -- 32 items of a lane at once --, only the other items go through LDS, one 4-byte add each.  Weighted
@@ -624,6 +621,7 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
                     if (first == 0) vm &= ~1u;  // item 0 is the sentinel
                 }
             }
+            vm &= own;
             const uint32_t m0 = ~any & vm, m1 = cnt[0] & ~any_hi & vm;
             mg &= vm & ~m1 & ~m0;
             hot0 = (uint32_t)__builtin_popcount(m0);
@@ -631,8 +629,8 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
             hotg = (uint32_t)__builtin_popcount(mg);
             others = vm & ~(m0 | m1 | mg);
         }
-        // unpack the bit-sliced counters: one coalesced 256-byte store per bit position
-        for (uint32_t b = 0; b < 32; ++b) {
+        // unpack the bit-sliced counters: one coalesced 256-byte store per bit position (this part's positions)
+        for (uint32_t b = b_lo; b < b_lo + BITS; ++b) {
             uint32_t v = 0;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
@@ -669,11 +667,10 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
         }
     }
     if (hs.rep) {
-        if (TPW > 1) __syncthreads();
-        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __syncthreads();
         const bool weighted = hs.weights != nullptr;
         unsigned long long *dst = hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * (hs.n_groups + 1);
-        for (uint32_t b = TPW > 1 ? threadIdx.x : lane; b <= hs.n_groups; b += TPW > 1 ? CW * 64 : 64) {
+        for (uint32_t b = threadIdx.x; b <= hs.n_groups; b += CW * 64) {
             const unsigned long long x = weighted ? sh_hist[b] : (unsigned long long)sh32[b];
             if (x) atomicAdd(&dst[b], x);
         }
