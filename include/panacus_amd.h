@@ -115,6 +115,12 @@ typedef struct pnx_gfa_steps {
 } pnx_gfa_steps;
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
+/* The same tokeniser for a run with -s / -e INTERVALS: the walks (node id + orientation of every step) are made from the text
+ * and KEPT in the context instead of becoming the resident graph; walk_off receives their n_paths + 1 offsets.  A following
+ * pnx_set_csr_cut with walk_node == NULL (and that walk_off) cuts them where they are -- nothing of the walks crosses PCIe in
+ * either direction.  They stay valid for further cuts (other count types, other lists) until the next pnx_gfa_walks /
+ * pnx_set_csr_gfa or the end of the context.  The edge fields of `steps` are ignored here (pnx_set_csr_cut has its own). */
+int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *steps, uint64_t *walk_off);
 
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
  * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)
@@ -133,7 +139,8 @@ int pnx_set_exclude(pnx_ctx *ctx, const uint8_t *exclude);
  * sightings (IntervalContainer bookkeeping of partly covered / partly excluded nodes, bp counts only,
  * src/util.rs:147-181,209-310; quantify_uncovered_bps, abacus.rs:1187-1229) comes back as a short event
  * list -- at most two entries per interval -- for the host to replay.
- *   walk_node      S node ids of all paths / walks in file order (the node ItemTable)
+ *   walk_node      S node ids of all paths / walks in file order (the node ItemTable); NULL: the walks a preceding
+ *                  pnx_gfa_walks left on the device (walk_off must be the offsets it returned; walk_backward is ignored)
  *   walk_backward  S orientation flags (1 = '-' / '<'), NULL = all forward
  *   walk_off       n_paths+1 offsets into walk_node
  *   path_start     n_paths: bp coordinate of a path's first base (PathSegment.start, else 0)

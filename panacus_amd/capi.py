@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
-    "pnx_profile_sample",
+    "pnx_profile_sample", "pnx_gfa_walks",
 ]
 
 
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     L.pnx_prepare.argtypes = [vp]
     L.pnx_gfa_text_upload.argtypes = [vp, C.c_char_p, C.c_uint64]
     L.pnx_set_csr_gfa.argtypes = [vp, C.POINTER(PnxGfaSteps), u32p, u8p]
+    L.pnx_gfa_walks.argtypes = [vp, C.POINTER(PnxGfaSteps), C.POINTER(C.c_uint64)]
     L.pnx_get_exclude.argtypes = [vp, u8p]
     L.pnx_set_weights.argtypes = [vp, u32p]
     L.pnx_exclude_items.argtypes = [vp, u32p, C.c_uint32]
@@ -267,7 +268,8 @@ class Context:
 
         n_nodes = len(node_len) - 1
         w = PnxWalks()
-        w.walk_node = _ptr(arr(walk_node, np.uint32), C.c_uint32)
+        # walk_node None: the walks a preceding gfa_walks() left on the device (walk_off = the offsets it returned)
+        w.walk_node = None if walk_node is None else _ptr(arr(walk_node, np.uint32), C.c_uint32)
         w.walk_backward = None if walk_backward is None else _ptr(arr(walk_backward, np.uint8), C.c_uint8)
         w.walk_off = _ptr(arr(walk_off, np.uint64), C.c_uint64)
         w.path_start = _ptr(arr(np.zeros(P, dtype=np.uint64) if path_start is None else path_start, np.uint64), C.c_uint64)
@@ -328,6 +330,22 @@ class Context:
         g.edge_uv, g.edge_oo, g.n_edges = _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8), (0 if uv is None else len(uv) - 1)
         self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = n_nodes if uv is None else len(uv) - 1
+
+    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None) -> np.ndarray:
+        """pnx_gfa_walks: the walks of GFA text tokenised on the device and kept there for set_csr_cut(walk_node=None, ...);
+        -> their n_paths + 1 offsets"""
+        cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
+        ce = np.ascontiguousarray(col_end, dtype=np.uint64)
+        wk = np.ascontiguousarray(is_walk, dtype=np.uint8)
+        names = None if id_of_name is None else np.ascontiguousarray(id_of_name, dtype=np.uint32)
+        g = PnxGfaSteps()
+        g.text, g.text_bytes = text, len(text)
+        g.n_paths, g.n_nodes = len(cb), n_nodes
+        g.col_begin, g.col_end, g.is_walk = _ptr(cb, C.c_uint64), _ptr(ce, C.c_uint64), _ptr(wk, C.c_uint8)
+        g.id_of_name, g.n_names = _ptr(names, C.c_uint32), (0 if names is None else len(names))
+        off = np.zeros(len(cb) + 1, dtype=np.uint64)
+        self._ck(self._L.pnx_gfa_walks(self._h, C.byref(g), _ptr(off, C.c_uint64)))
+        return off
 
     def prepare(self):
         self._ck(self._L.pnx_prepare(self._h))

@@ -490,8 +490,11 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
         if (bytes) PNX_HIP(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return PNX_OK;
     };
-    if ((rc = up(s.node, w->walk_node, S * 4))) return rc;
-    if (w->walk_backward && (rc = up(s.back, w->walk_backward, S))) return rc;
+    const bool dev_walks = !w->walk_node && S;  // left on the device by pnx_gfa_walks (checked by the caller)
+    if (!dev_walks) {
+        if ((rc = up(s.node, w->walk_node, S * 4))) return rc;
+        if (w->walk_backward && (rc = up(s.back, w->walk_backward, S))) return rc;
+    }
     if ((rc = up(s.off, w->walk_off, ((size_t)P + 1) * 8))) return rc;
     if ((rc = up(s.chunk_off, h_chunk_off.data(), ((size_t)P + 1) * 8))) return rc;
     if ((rc = up(s.start, w->path_start, (size_t)P * 8))) return rc;
@@ -531,8 +534,8 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     }
 
     CutArgs a{};
-    a.node = (const uint32_t *)s.node.p;
-    a.backward = w->walk_backward ? (const uint8_t *)s.back.p : nullptr;
+    a.node = dev_walks ? (const uint32_t *)ctx->d_walk_node.p : (const uint32_t *)s.node.p;
+    a.backward = dev_walks ? (const uint8_t *)ctx->d_walk_back.p : (w->walk_backward ? (const uint8_t *)s.back.p : nullptr);
     a.off = (const uint64_t *)s.off.p;
     a.chunk_off = (const uint64_t *)s.chunk_off.p;
     a.start = (const uint64_t *)s.start.p;

@@ -300,7 +300,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -446,7 +446,10 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
                                      which ? "exclude" : "include", p);
         }
     }
-    if (w->walk_off[w->n_paths] && !w->walk_node) return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: walk_node is NULL");
+    if (w->walk_off[w->n_paths] && !w->walk_node &&
+        !(ctx->walks_valid && ctx->h_walk_off.size() == (size_t)w->n_paths + 1 &&
+          std::memcmp(ctx->h_walk_off.data(), w->walk_off, ctx->h_walk_off.size() * sizeof(uint64_t)) == 0))
+        return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: walk_node is NULL and the context holds no walks with these offsets (pnx_gfa_walks)");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
     int rc = pnx::cut_walks(ctx, w, events, cap, n_events);
@@ -478,6 +481,9 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
         (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
         return rc;
+    ctx->walks_valid = false;
+    release(ctx->d_walk_node);
+    release(ctx->d_walk_back);
     const bool edges = g->edge_uv != nullptr;
     if (edges && (!g->edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo, and no weights");
     DevBuf d_backward;
@@ -489,6 +495,35 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     release(d_backward);
     if (rc) return rc;
     return finish_upload(ctx, ctx->n_steps, g->n_paths, edges ? g->n_edges : g->n_nodes, weights, exclude, false, nullptr);
+}
+
+int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {
+    if (!ctx) return PNX_EINVAL;
+    if (!g || !walk_off || (g->n_paths && (!g->col_begin || !g->col_end || !g->is_walk)))
+        return ctx->fail(PNX_EINVAL, "pnx_gfa_walks: NULL argument");
+    if (g->n_nodes >= 0xFFFFFFFEu || g->n_paths >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes and n_paths must be < 2^32-2");
+    const uint64_t bytes = g->text ? g->text_bytes : ctx->gfa_text_bytes;
+    if (!g->text && !ctx->d_gfa_text.p) return ctx->fail(PNX_EINVAL, "pnx_gfa_walks: no text (pass it, or call pnx_gfa_text_upload first)");
+    for (uint32_t p = 0; p < g->n_paths; ++p)
+        if (g->col_begin[p] > g->col_end[p] || g->col_end[p] > bytes)
+            return ctx->fail(PNX_EINVAL, "pnx_gfa_walks: the step column of path %u lies outside the text", p);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    begin_upload(ctx);  // (the tokeniser writes through the resident graph's buffers)
+    ctx->walks_valid = false;
+    int rc;
+    if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
+        (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
+        return rc;
+    rc = gfa_tokenise(ctx, g, &ctx->d_walk_back);
+    release(ctx->d_gfa_text);
+    ctx->gfa_text_host = nullptr;
+    ctx->gfa_text_bytes = 0;
+    if (rc) return rc;
+    std::swap(ctx->d_items, ctx->d_walk_node);
+    ctx->h_walk_off = ctx->h_path_off;
+    std::memcpy(walk_off, ctx->h_walk_off.data(), ((size_t)g->n_paths + 1) * sizeof(uint64_t));
+    ctx->walks_valid = true;
+    return PNX_OK;
 }
 
 int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {

@@ -231,6 +231,11 @@ struct pnx_ctx {
     // ---- pairwise intersections / plain presence export (kernels_pairs.hip) ----
     pnx::DevBuf d_inter, d_pair_partial, d_plain;
 
+    // ---- walks kept on the device for pnx_set_csr_cut (pnx_gfa_walks) ----
+    pnx::DevBuf d_walk_node, d_walk_back;
+    std::vector<uint64_t> h_walk_off;
+    bool walks_valid = false;
+
     // ---- closed-form quorum sums (kernels_closed_form.hip): scratch kept across calls ----
     pnx::DevBuf d_cf[6];
     void *h_cf = nullptr;  // pinned: the (n+1)^2 sums handed back to the caller, then the staged inputs

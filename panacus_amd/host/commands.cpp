@@ -203,13 +203,40 @@ Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStora
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     };
     const uint64_t n_items = g.number_of_items(ct);
-    const WalkCut cut = g.walk_cut(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file);
+    // numeric segment names: the walks are made from the text on the device (pnx_gfa_walks) and cut where they are; the
+    // paths no interval touches get an empty step column.  Otherwise the host's step parser makes them and they go up.
+    const bool dev_walks = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    WalkCut cut = g.walk_cut(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file, !dev_walks);
     const uint32_t none32 = 0;
     const uint8_t none8 = 0;
     const uint64_t none64 = 0;
     pnx_walks w{};
-    w.walk_node = cut.walk_node.empty() ? &none32 : cut.walk_node.data();
-    w.walk_backward = cut.walk_backward.empty() ? nullptr : cut.walk_backward.data();
+    if (dev_walks) {
+        std::vector<uint64_t> cb, ce;
+        std::vector<uint8_t> wk;
+        g.step_columns(cb, ce, wk);
+        for (size_t k = 0; k < cut.path_mode.size(); ++k)
+            if (cut.path_mode[k] == PNX_WALK_SKIP) ce[k] = cb[k];
+        pnx_gfa_steps st{};
+        st.text = g.text_data();
+        st.text_bytes = g.text_size();
+        st.n_paths = (uint32_t)cut.path_mode.size();
+        st.n_nodes = (uint32_t)g.node_count();
+        st.col_begin = cb.data();
+        st.col_end = ce.data();
+        st.is_walk = wk.data();
+        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
+        st.n_names = g.id_of_name().size();
+        cut.walk_off.assign(cut.path_mode.size() + 1, 0);
+        ctx = get_ctx();
+        check(pnx_gfa_walks(ctx, &st, cut.walk_off.data()));
+        phase_mark("pnx_gfa_walks (walks tokenised on the device)");
+        w.walk_node = nullptr;
+        w.walk_backward = nullptr;
+    } else {
+        w.walk_node = cut.walk_node.empty() ? &none32 : cut.walk_node.data();
+        w.walk_backward = cut.walk_backward.empty() ? nullptr : cut.walk_backward.data();
+    }
     w.walk_off = cut.walk_off.data();
     w.path_start = cut.path_start.empty() ? &none64 : cut.path_start.data();
     w.path_mode = cut.path_mode.empty() ? &none8 : cut.path_mode.data();

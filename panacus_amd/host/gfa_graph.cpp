@@ -1923,7 +1923,7 @@ bool GraphStorage::mask_is_path_level(CountType count, GroupMode mode, const std
 }
 
 WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
-                               const std::string &exclude_file) const {
+                               const std::string &exclude_file, bool with_walks) const {
     const Impl &im = *impl_;
     if (im.cached) throw std::runtime_error("subset / exclude lists need the GFA text: load the graph without the cache");
     if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
@@ -1932,7 +1932,7 @@ WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::strin
     mask_setup(ms, paths_, count, mode, group_file, subset_file, exclude_file);
     WalkCut w;
     w.count = count;
-    {
+    if (with_walks) {
         Steps steps;
         parse_all_steps(im, paths_, node_count_, true, steps);
         w.walk_node.swap(steps.ids);

@@ -125,8 +125,10 @@ public:
     MaskedTable masked_table(CountType count, GroupMode mode, const std::string &group_file,
                              const std::string &subset_file, const std::string &exclude_file) const;
 
+    // with_walks = false: everything but walk_node / walk_backward / walk_off (the caller has the walks made on the device,
+    // pnx_gfa_walks, and fills walk_off from there)
     WalkCut walk_cut(CountType count, GroupMode mode, const std::string &group_file, const std::string &subset_file,
-                     const std::string &exclude_file) const;
+                     const std::string &exclude_file, bool with_walks = true) const;
     // true when a -s list needs no walking at all for this count type: every path is either taken whole or not touched (a
     // list of path / sample / haplotype names, or of intervals that contain whole paths) and there is no -e list; take[k]
     // says which.  The item table of such a run is the plain one with the other paths left empty.

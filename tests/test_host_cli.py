@@ -303,7 +303,13 @@ def test_cli_bed_intervals_synthetic(tmp_path):
         exc.write_text(rows(3))
         for sf, ef in ((str(sub), None), (None, str(exc)), (str(sub), str(exc))):
             extra = (["-s", sf] if sf else []) + (["-e", ef] if ef else [])
-            _check_cli_masked(g, path, extra, orc.GROUP_PATHID, sf, ef)
+            _check_cli_masked(g, path, extra, orc.GROUP_PATHID, sf, ef)   # walks tokenised on the device, cut where they are
+            if rep == 0:   # ... and the host's step parser in front of the same cut
+                os.environ["PANACUS_AMD_HOST_PARSE"] = "1"
+                try:
+                    _check_cli_masked(g, path, extra, orc.GROUP_PATHID, sf, ef)
+                finally:
+                    del os.environ["PANACUS_AMD_HOST_PARSE"]
             if sf:
                 g.path_order(orc.GROUP_PATHID, None, None, sf, ef)
                 n_unc += len(g.masked_table(orc.BP, sf, ef)[3])
