@@ -401,7 +401,8 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n);
  *   hist   n+1 bins on the host, or NULL: the device counters of the coverage pass enqueued LAST (n must be the number of
  *          groups) -- the curves then follow the pass without the histogram ever visiting the host
  *   out    n_pairs x n values: out[t*n + m-1] = growth at m groups (the reference's vector without its leading NaN)
- * _async enqueues the work on a stream of its own (inputs are copied before it returns); PNX_CFG_MAX_IN_FLIGHT + 2 calls may
+ * _async enqueues the work (hist given: on a stream of its own, inputs are copied before it returns; hist == NULL: behind
+ * the pass on the stream of its histogram phase); PNX_CFG_MAX_IN_FLIGHT + 2 calls may
  * be in flight -- two more than passes, so that a host enqueues pass i + k and its call before it fetches the curves of pass
  * i - 1; _fetch waits for the OLDEST one.
  * Everything in the closed forms that does not depend on the histogram -- the log2 table, the running sums n_fall / m_fact,

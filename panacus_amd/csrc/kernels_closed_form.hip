@@ -665,9 +665,14 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
     const size_t np1 = (size_t)n + 1, T = n_pairs;
     if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;
     pnx_ctx::GrowthSlot &g = ctx->gslot[ctx->gslot_next];
-    // a stream per slot: the calls in flight do not wait for each other, and none of them for a coverage pass
-    if (!g.stream) PNX_HIP(ctx, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    hipStream_t st = g.stream;
+    // From a host histogram: a stream per slot -- the calls in flight do not wait for each other, and none of them for a
+    // coverage pass.  From the counters of the pass enqueued last: the stream of that pass's histogram phase, right behind the
+    // kernel that publishes the counters -- no event to wait for, and no further stream that the runtime might map onto the
+    // coverage kernel's hardware queue (seen in the timeline: an evaluation, and its wait, between two coverage kernels).
+    static const bool own_stream = getenv("PNX_CF_OWN_STREAM") != nullptr;  // experiments
+    const bool behind_pass = src && !own_stream;
+    if (!behind_pass && !g.stream) PNX_HIP(ctx, hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    hipStream_t st = behind_pass ? ctx->s_post : g.stream;
     // slot: pinned host memory [hist u64 n+1 | out f64 T x n]: the kernel reads and writes it in place (a copy would be one more
     // short kernel that waits for a free wave slot beside a running pass)
     const size_t in_bytes = np1 * 8, out_bytes = T * n * 8;
@@ -691,7 +696,7 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
     if (src) {
         // the counters are final once the pass's own copy to the host was enqueued behind them (and behind the all-reduce of
         // a multi-GPU context): the slot's stream waits for exactly that point
-        PNX_HIP(ctx, hipStreamWaitEvent(st, src->done, 0));
+        if (!behind_pass) PNX_HIP(ctx, hipStreamWaitEvent(st, src->done, 0));
         d_hist = src->d_hist;
     } else {
         std::memcpy(h, hist, np1 * 8);
