@@ -92,6 +92,7 @@ timeout 600 bash $REPO/tools/pggb_time.sh > $OUT/${R}_pggb_cli_phases.txt 2>&1
 rm -rf /tmp/p_cli; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cli -o cli -- \
     $REPO/panacus_amd/panacus-amd histgrowth -S -q 0,0.5,1.0 -l 0,1,2 /tmp/pg/pggb.gfa > /dev/null 2>&1
 python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cli)" $OUT/${R}_pggb_cli_kernel_stats.csv > /dev/null
+[ -x $REPO/benchmarks/micro/h2d_rate ] || hipcc --offload-arch=gfx950 -O2 -o $REPO/benchmarks/micro/h2d_rate $REPO/benchmarks/micro/h2d_rate.hip -lpthread 2>/dev/null
 timeout 120 $REPO/benchmarks/micro/h2d_rate /tmp/pg/pggb.gfa 16 > $OUT/${R}_h2d_rate.json 2>/dev/null
 rm -rf /tmp/pg
 ls -la $OUT
