@@ -636,7 +636,7 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
             for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
             const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
             // countable[0] is the reference's reserved element (abacus.rs:549-551)
-            if (node <= n_items) countable[node] = node ? v : 0xFFFFFFFFu;
+            if (node <= n_items) __builtin_nontemporal_store(node ? v : 0xFFFFFFFFu, countable + node);
             if (hist && !weighted) {
                 if (((others >> b) & 1u) && v < hs.n_groups) atomicAdd(&sh32[v], 1u);  // abacus.rs:752: coverage beyond #groups is ignored
             } else if (hist && node >= 1 && node <= n_items) {
