@@ -119,7 +119,8 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *we
  * and KEPT in the context instead of becoming the resident graph; walk_off receives their n_paths + 1 offsets.  A following
  * pnx_set_csr_cut with walk_node == NULL (and that walk_off) cuts them where they are -- nothing of the walks crosses PCIe in
  * either direction.  They stay valid for further cuts (other count types, other lists) until the next pnx_gfa_walks /
- * pnx_set_csr_gfa or the end of the context.  The edge fields of `steps` are ignored here (pnx_set_csr_cut has its own). */
+ * pnx_set_csr_gfa or the end of the context.  The edge fields of `steps` are ignored here (pnx_set_csr_cut has its own).
+ * Like every upload the call ends the residence of the graph that was resident before it (the tokeniser works in its buffers). */
 int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *steps, uint64_t *walk_off);
 
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
