@@ -503,6 +503,11 @@ enum {
                                   reads the coverage vector (up to 4095 groups) [1]; 0: K2 as for the step routes (cross-check) */
     PNX_CFG_DROP_GROWTH_TABLES = 20, /* (value ignored) forget the (n, thresholds) tables of pnx_growth_closed_form_async; the next
                                   call derives them again.  Measurement only */
+    PNX_CFG_COVER_ROUTE = 22,  /* how a pass over a graph WITHOUT derived path rows reads it (PNX_CFG_COVER_VARIANT 3): 0 [default] the
+                                  first sweep of an upload whose shape suits it takes the ONE-SHOT route -- straight over the steps,
+                                  one read, nothing derived (kernels_band.hip; paths sorted by id, ascending or descending; a path
+                                  that is not makes the pass void and it is run again over path rows) --, a second sweep derives the
+                                  rows; 1: the one-shot route for every pass while no rows exist; 2: path rows only */
     PNX_CFG_DROP_DERIVED = 18, /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
                                   tile index); the next pass or pnx_prepare derives it again.  Measurement only */
 };

@@ -22,7 +22,7 @@ LIB_HIP = os.path.join(HERE, "libpanacus_hip.so")
 LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
-HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "kernels_cover.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_gfa.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
+HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "kernels_cover.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_band.hip", "kernels_gfa.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
 HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "mini_yaml.cpp", "report.cpp", "commands.cpp", "host_api.cpp"]
 
 
@@ -50,7 +50,8 @@ def _run(cmd):
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(CSRC, "step_chunks.hpp"), os.path.join(ROOT, "include", "panacus_amd.h"),
-            os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc")]
+            os.path.join(CSRC, "tile_counters.hpp"), os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc"),
+            os.path.join(CSRC, "log2_exact.hpp"), os.path.join(CSRC, "log2_table.inc")]
     objs = []
     procs = []
     for src in HIP_SOURCES:

@@ -1530,7 +1530,11 @@ int launch_cover_pass(pnx_ctx *ctx) {
     // (a pass over rows with paths in the order: the kernel that lays the order out clears the block)
     if (!(rows && ctx->n_ordered)) PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
 
-    if (rows) {
+    tk->band = rows && ctx->pass_band;
+    if (tk->band) {
+        // ---- phases 1 + 2 straight over the steps, one read (kernels_band.hip): the first sweep of a graph with sorted paths
+        if ((rc = launch_band_phases(ctx, ctx->want_M))) return rc;
+    } else if (rows) {
         // ---- phases 1 + 2 over path rows (kernels_rows.hip): no boundary index, no routes
         if ((rc = launch_rows_phases(ctx, ctx->want_M))) return rc;
     } else {

@@ -135,6 +135,8 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->wdigits_valid = false;
     ctx->last_general_paths = 0;
     ctx->rows_valid = false;
+    ctx->band_failed = false;
+    ctx->n_band_passes = 0;
 }
 
 // the ticket's pinned result block [flags u32[8] | hist (G+1) u64], before the pass is launched: its publishing kernel may
@@ -192,6 +194,23 @@ static int settle_oldest(pnx_ctx *ctx) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         PNX_HIP(ctx, hipEventSynchronize(t->done));
         prof_resolve(ctx, false);
+        if (t->band && t->h_flags[5] != 0) {
+            // the one-shot route met a path that is not sorted by id: the pass is void.  Path rows serve any path (and
+            // validate the ids on the way: an id outside 1..n_items also ends up here).  With a communicator the flags
+            // were reduced over all ranks, so every rank is here and the collectives stay matched.
+            int rc = drain_streams(ctx);
+            if (rc) return rc;
+            ctx->band_failed = true;
+            ctx->pass_band = false;
+            ctx->n_reruns += 1;
+            if ((rc = ensure_rows(ctx, true))) return rc;
+            ctx->cur = t;
+            ctx->want_M = t->wrote_m;
+            if ((rc = choose_pass_streams(ctx)) || (rc = ensure_host_block(ctx, t)) || (rc = launch_cover_pass(ctx)) ||
+                (rc = comm_reduce_pass(ctx, t)) || (rc = stage_results(ctx, t)))
+                return rc;
+            continue;
+        }
         const bool used_m = t->used_m;  // as launched, not as the context stands now
         // [0] tile-monotonicity violations found by K1, [1] scatter-route paths in the order,
         // [2] non-monotone paths that are not classified yet, [4] internal run-index check
@@ -374,7 +393,9 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
     // every step id must be a valid item (the reference panics on unknown nodes, util.rs:1021).  Over path rows the
     // check rides on the one read of the steps that builds the rows; a renumbering needs it before it starts.
     if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
-    if (item_key || !use_rows(ctx)) {
+    // a shape the one-shot route may take (kernels_band.hip) derives no rows at upload: its first sweep reads the steps once
+    const bool defer_rows = use_rows(ctx) && !item_key && ctx->cover_route != 2 && (ctx->cover_route == 1 || band_route_fits(ctx, n_paths));
+    if (item_key || !use_rows(ctx) || defer_rows) {
         PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
         if ((rc = launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
         uint32_t bad = 0;
@@ -384,7 +405,7 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
     }
     ctx->relabeled = false;
     if (item_key && (rc = relabel_by_keys(ctx, item_key))) return rc;
-    if (use_rows(ctx) && (rc = ensure_rows(ctx, true))) return rc;
+    if (use_rows(ctx) && !defer_rows && (rc = ensure_rows(ctx, true))) return rc;
     ctx->have_csr = true;
     return PNX_OK;
 }
@@ -806,7 +827,12 @@ int pnx_hist_async(pnx_ctx *ctx) {
     ctx->cur = &ctx->tk[ctx->tk_next];
     if ((rc = choose_pass_streams(ctx))) return rc;
     if (use_rows(ctx)) {
-        if ((rc = ensure_rows(ctx, false))) return rc;  // once per upload (pnx_set_csr has done it already)
+        // the first sweep of a graph takes the steps themselves when its shape suits the one-shot route (one read, nothing
+        // derived); a second sweep is a caller that keeps sweeping: it derives the path rows, and every later pass is 8x cheaper
+        ctx->pass_band = !ctx->rows_valid && !ctx->band_failed && ctx->n_ordered && ctx->n_steps &&
+                         (ctx->cover_route == 1 || (ctx->cover_route == 0 && ctx->n_band_passes == 0 && band_route_fits(ctx, ctx->n_ordered)));
+        if (ctx->pass_band) ctx->n_band_passes += 1;
+        else if ((rc = ensure_rows(ctx, false))) return rc;  // once per upload
     } else if (!ctx->index_valid || !ctx->cache_index) {
         // a kept index is shared by the passes: nothing may still be reading it while it is rebuilt
         if (ctx->cache_index && ctx->tk_count && (rc = drain_streams(ctx))) return rc;
@@ -1194,6 +1220,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows layout must be 0 (auto), 1 (tile-major) or 2 (path-major)");
             ctx->rows_layout = (int)value;
             return PNX_OK;
+        case PNX_CFG_COVER_ROUTE:
+            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover route must be 0 (auto), 1 (one-shot over the steps) or 2 (path rows)");
+            ctx->cover_route = (int)value;
+            return PNX_OK;
         case PNX_CFG_HIST_IN_COVER:
             if (value > 1) return ctx->fail(PNX_EINVAL, "hist_in_cover must be 0 or 1");
             if (ctx->tk_count) return ctx->fail(PNX_EINVAL, "PNX_CFG_HIST_IN_COVER cannot change while passes are in flight");
@@ -1209,6 +1239,8 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             if (ctx->have_csr) invalidate_results(ctx);
             ctx->rows_valid = false;
             ctx->index_valid = false;
+            ctx->band_failed = false;
+            ctx->n_band_passes = 0;
             if (ctx->n_sorted_paths == 0) ctx->steps_prepared = false;  // sorted paths stay sorted: their caller order is kept once
             return PNX_OK;
         case PNX_CFG_INDEX_COARSE:

@@ -69,6 +69,7 @@ struct Ticket {
     // how the pass was LAUNCHED (the context's want_M / last_general_paths may have changed by the
     // time the pass is settled): it merged the scatter rows of M / it wrote the presence matrix
     bool used_m = false, wrote_m = false;
+    bool band = false;  // the pass took the one-shot route over the steps (kernels_band.hip); flags[5] says whether it held
 };
 
 struct Profile {
@@ -182,6 +183,12 @@ struct pnx_ctx {
     uint64_t n_rows = 0;
     bool rows_valid = false, rows_tile_major = false;
     int rows_layout = 0;        // PNX_CFG_ROWS_LAYOUT: 0 = chosen from the shape, 1 = tile-major, 2 = path-major
+
+    // ---- one-shot route over the steps (kernels_band.hip): the first sweep of a graph whose paths are sorted by id ----
+    int cover_route = 0;         // PNX_CFG_COVER_ROUTE: 0 = chosen per pass, 1 = band route whenever possible, 2 = path rows only
+    bool band_failed = false;    // a band pass found a path that is not sorted by id: this upload takes the rows from now on
+    uint32_t n_band_passes = 0;  // band passes enqueued on this upload (the second sweep of a graph derives the rows)
+    bool pass_band = false;      // the pass being enqueued takes the band route
 
     // ---- run index: tile route for non-monotone paths (kernels_runs.hip) ----
     // path_class: 0 tile-monotone (K0 index), 1 not monotone & unclassified, 2 run route, 3 scatter route
@@ -324,6 +331,9 @@ int launch_hist(pnx_ctx *ctx, Ticket *tk);  // K2 of the pass in `tk`, on the st
 inline bool use_rows(const pnx_ctx *ctx) { return ctx->cover_variant == 3; }
 int ensure_rows(pnx_ctx *ctx, bool validate);          // d_rows & co. (no-op when they exist)
 int launch_rows_phases(pnx_ctx *ctx, bool write_m);    // phases 1 + 2 of a pass over rows
+// kernels_band.hip
+bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries);  // is the one-shot route worth it for this shape?
+int launch_band_phases(pnx_ctx *ctx, bool write_m);            // phases 1 + 2 of a one-shot pass over the steps
 // kernels_runs.hip
 int ensure_chunk_off(pnx_ctx *ctx);
 int build_run_index(pnx_ctx *ctx);
