@@ -24,6 +24,8 @@
 // are never foreign facts: positions outside the segment are masked.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "pnx_context.hpp"
 #include "tile_counters.hpp"
 
@@ -33,65 +35,62 @@ constexpr int BAND_D = 4;              // 16-byte loads in flight per lane
 constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs through the ids downwards
 
 // first j in [0, len] with key(j) >= X, key = id (ascending path) or ~id (descending); keys are non-decreasing on a
-// sorted path -- on any other the result is some position in [0, len] and the coverage kernel finds out
+// sorted path -- on any other the result is some position in [0, len] and the coverage kernel finds out.
+// A probe is one aligned 64-byte sector = 16 steps (four 16-byte loads, one latency): either the sector holds the
+// crossing, or its nearest step becomes one of the two points of the next secant guess (the path's ends at first: ids
+// along a pangenome path are close to evenly spread, so the first guess is off by a few thousand steps of millions, the
+// second by tens, the third lands in the sector) and tightens the bracket; after 8 probes the guess is the midpoint.
+// The chain of dependent reads is what this kernel costs: ~4 probes here against ~14 single-step probes of a plain
+// interpolation + binary search (0.058 -> 0.03 ms on 10 M items x 256 paths).
 template <bool DESC>
-__device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ it, uint64_t len, uint32_t X, uint32_t ka, uint32_t kz) {
-    auto key = [&](uint64_t j) { const uint32_t v = it[j]; return DESC ? ~v : v; };
+__device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ items, uint64_t ps, uint64_t len, uint32_t X, uint32_t ka,
+                                                   uint32_t kz) {
     if (ka >= X) return 0;
     if (kz < X) return len;
     uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
-    uint32_t klo = ka, khi = kz;
-    for (int iter = 0; iter < 4 && hi - lo > 32; ++iter) {
-        const uint64_t range = hi - lo;
-        const double f = (double)(X - klo) / (double)(khi - klo);
-        uint64_t g = lo + (uint64_t)(f * (double)range);
-        g = g <= lo ? lo + 1 : (g >= hi ? hi - 1 : g);
-        uint64_t step = (uint64_t)sqrt((double)range);
-        step = step < 8 ? 8 : step;
-        const uint32_t kg = key(g);
-        if (kg >= X) {  // walk down until a key below X
-            hi = g;
-            khi = kg;
-            for (int s = 0; s < 8 && hi - lo > step; ++s, step += step >> 1) {
-                const uint64_t c = hi - step;
-                const uint32_t kc = key(c);
-                if (kc >= X) {
-                    hi = c;
-                    khi = kc;
-                } else {
-                    lo = c;
-                    klo = kc;
-                    break;
-                }
-            }
-        } else {  // walk up
-            lo = g;
-            klo = kg;
-            for (int s = 0; s < 8 && hi - lo > step; ++s, step += step >> 1) {
-                const uint64_t c = lo + step;
-                const uint32_t kc = key(c);
-                if (kc < X) {
-                    lo = c;
-                    klo = kc;
-                } else {
-                    hi = c;
-                    khi = kc;
-                    break;
-                }
-            }
+    double pa = 0.0, va = (double)ka, pb = (double)(len - 1), vb = (double)kz;  // the two points of the secant
+    for (int iter = 0; hi - lo > 1; ++iter) {
+        uint64_t g = lo + ((hi - lo) >> 1);
+        if (iter < 8 && vb != va) {
+            const double t = pb + ((double)X - vb) * (pb - pa) / (vb - va);
+            g = t <= (double)(lo + 1) ? lo + 1 : (t >= (double)(hi - 1) ? hi - 1 : (uint64_t)t);
         }
-    }
-    while (hi - lo > 1) {
-        const uint64_t m = lo + ((hi - lo) >> 1);
-        if (key(m) >= X) hi = m;
-        else lo = m;
+        const uint64_t a0 = (ps + g) & ~15ull;  // the sector of step g (absolute index of its first step)
+        const uint4 *src = reinterpret_cast<const uint4 *>(items + a0);
+        const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        const uint32_t w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        // steps of the sector that belong to the path and lie inside the bracket: [i0, i1]
+        const uint64_t first = ps + lo + 1, last = ps + hi - 1;  // absolute; first <= ps + g <= last
+        const uint32_t i0 = first > a0 ? (uint32_t)(first - a0) : 0u, i1 = last - a0 < 15 ? (uint32_t)(last - a0) : 15u;
+        uint32_t below = 0, k_first = 0, k_last = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) {
+            const uint32_t key = DESC ? ~w[i] : w[i];
+            if (i == i0) k_first = key;
+            if (i == i1) k_last = key;
+            below += (i >= i0 && i <= i1 && key < X) ? 1u : 0u;
+        }
+        const uint32_t n = i1 - i0 + 1;
+        if (below != 0 && below != n) return a0 + i0 + below - ps;  // the crossing lies in the sector
+        pa = pb;
+        va = vb;
+        if (below == 0) {  // all at or above X
+            hi = a0 + i0 - ps;
+            pb = (double)hi;
+            vb = (double)k_first;
+        } else {
+            lo = a0 + i1 - ps;
+            pb = (double)lo;
+            vb = (double)k_last;
+        }
     }
     return hi;
 }
 
-// bidx[e * n_ordered + k] = absolute step position where entry k's path crosses band edge e (id e * band_items), e = 0 ..
-// n_bands, | BAND_DESC for a descending path: band b of an ascending path is [bidx[b], bidx[b+1]), of a descending one
-// [bidx[b+1], bidx[b]).  (Also clears the pass's counter block: a memset in front is one more kernel in the chain.)
+// bidx[k * (n_bands + 1) + e] = absolute step position where entry k's path crosses band edge e (id e * band_items), e = 0 ..
+// n_bands, | BAND_DESC for a descending path: band b of an ascending path is [bidx[k][b], bidx[k][b+1]), of a descending one
+// [bidx[k][b+1], bidx[k][b]).  The lanes of a wave take consecutive edges of ONE path: their probes stay within a few
+// hundred KB of each other (one or two translation entries per round of probes instead of 64).  (Also clears the pass's counter block: a memset in front is one more kernel in the chain.)
 __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
                                                     const uint32_t *__restrict__ ord_path, uint32_t n_ordered, uint32_t n_bands,
                                                     uint32_t band_items, unsigned long long *__restrict__ bidx,
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     for (uint64_t q = tid; q < n_block16; q += (uint64_t)gridDim.x * blockDim.x) block16[q] = make_uint4(0, 0, 0, 0);
     const uint64_t total = (uint64_t)(n_bands + 1) * n_ordered;
     if (tid >= total) return;
-    const uint32_t k = (uint32_t)(tid % n_ordered), e = (uint32_t)(tid / n_ordered);
+    const uint32_t e = (uint32_t)(tid % (n_bands + 1)), k = (uint32_t)(tid / (n_bands + 1));
     const uint32_t p = ord_path[k];
     const uint64_t ps = path_off[p], pe = path_off[p + 1], len = pe - ps;
     if (len == 0) {
@@ -114,14 +113,14 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     else if (e == n_bands) j = desc ? 0 : len;
     else {
         const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-        j = desc ? band_edge_search<true>(items + ps, len, ~(x - 1u), ~a, ~z) : band_edge_search<false>(items + ps, len, x, a, z);
+        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ~a, ~z) : band_edge_search<false>(items, ps, len, x, a, z);
     }
     bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
 }
 
 // The coverage kernel.  flags[5] |= 1 when a step was found outside the band it was dealt to (or an index entry is
 // inconsistent): the result of the pass is void.
-template <int NPL, int CW, bool WRITE_M>
+template <int NPL, int CW, bool WRITE_M, int LOADV = 1>
 __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restrict__ items, const unsigned long long *__restrict__ bidx,
                                                         const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
@@ -162,14 +161,18 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     // ---- 64 entries of the visiting order in the lanes: their segments on this band (issue side) ----
     uint64_t w_lo = 0;
     uint32_t w_len = 0, swin = NONE;  // swin: which window of 64 entries
-    const unsigned long long *e0 = bidx + (uint64_t)band * n_ordered, *e1 = e0 + n_ordered;
+    uint32_t w_g = NONE;              // ... and their groups: handed to the fold side when it reaches the window
+    const uint32_t n_edges = gridDim.x + 1;  // per entry: n_bands + 1 edge positions
     auto load_swin = [&](uint32_t win) {
         swin = win;
         const uint32_t k = win * 64u + lane;
         uint64_t a = 0, b = 0;
+        w_g = NONE;
         if (k < n_ordered) {
-            a = e0[k];
-            b = e1[k];
+            const unsigned long long *ek = bidx + (uint64_t)k * n_edges + band;
+            a = ek[0];
+            b = ek[1];
+            w_g = ord_group[k];
         }
         const bool desc = (a & BAND_DESC) != 0;
         if (((a ^ b) & BAND_DESC) != 0) bad = true;
@@ -181,47 +184,58 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
             hi = lo;
         }
         uint64_t len = hi - lo;
-        if (len >= (1ull << 31)) {
+        if (len >= (1ull << 29)) {  // (a buffer descriptor holds 2^32 bytes)
             bad = true;
             len = 0;
         }
         w_lo = lo;
         w_len = (uint32_t)len;
     };
-    // ---- ... and their groups (fold side: the issue side may already be one window ahead) ----
+    // ---- the groups of the window being folded (the issue side may already be one window ahead; it has loaded this
+    // window before the first fold in it, and moves on only after that fold: no load on the fold side, whose wait would
+    // drain the next segment's loads in flight) ----
     uint32_t f_g = NONE, fwin = NONE;
 
+    // A segment is read through a buffer descriptor (base = its 16-byte aligned start, size = its bytes): loads beyond its
+    // end return zeros without a branch, so every load is issued unconditionally and the compiler counts them exactly
+    // (s_waitcnt vmcnt(n) per slot instead of a drain in front of every use).
     struct Seg {
-        const uint32_t *base;  // 16-byte aligned, <= first step
-        uint32_t head, nal;    // steps of the first load before the segment; head + length
+        __amdgpu_buffer_rsrc_t rs;
+        const uint32_t *base;
+        uint32_t head, nal;  // steps of the first load before the segment; head + length
+    };
+    auto make_seg = [&](uint64_t lo, uint32_t len) {
+        const uint32_t *base = items + (lo & ~3ull);
+        const uint32_t head = len ? (uint32_t)(lo & 3ull) : 0u, nal = head + len;
+        const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
+        const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
+        void *bp = (void *)(((uintptr_t)b_hi << 32) | b_lo);
+        return Seg{__builtin_amdgcn_make_buffer_rsrc(bp, 0, (int)__builtin_amdgcn_readfirstlane(nal * 4u), 0x00020000), (const uint32_t *)bp, head, nal};
     };
     auto seg_of = [&](uint32_t batch) {
-        Seg s{items, 0u, 0u};
         const uint32_t k = batch * CW + wave;
-        if (k < n_ordered) {
-            if ((k >> 6) != swin) load_swin(k >> 6);
-            const uint32_t l = k & 63u;
-            const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_lo, l);
-            const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_lo >> 32), l);
-            const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w_len, l);
-            const uint64_t lo = ((uint64_t)lo_h << 32) | lo_l;
-            if (len) {
-                s.base = items + (lo & ~3ull);
-                s.head = (uint32_t)(lo & 3ull);
-                s.nal = s.head + len;
-            }
-        }
-        return s;
+        if (k >= n_ordered) return make_seg(0, 0);
+        if ((k >> 6) != swin) load_swin(k >> 6);
+        const uint32_t l = k & 63u;
+        const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_lo, l);
+        const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_lo >> 32), l);
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w_len, l);
+        return make_seg(((uint64_t)lo_h << 32) | lo_l, len);
     };
 
     const uint32_t n_batches = (n_ordered + CW - 1) / CW;
-    u32x4 buf[BAND_D];
     auto issue = [&](const Seg &s, uint32_t r0, int u) {
-        const uint32_t r = r0 + (uint32_t)u * 256u + lane * 4u;
-        u32x4 v = u32x4{0, 0, 0, 0};
-        if (r < s.nal) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s.base + r));
-        return v;
+        if (LOADV == 0) {  // global loads at clamped addresses
+            uint32_t r = r0 + (uint32_t)u * 256u + lane * 4u;
+            r = r < s.nal ? r : 0u;
+            return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s.base + r));
+        }
+        if (LOADV == 2) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane * 16u + (uint32_t)u * 1024u, r0 * 4u, 0));
+        if (LOADV == 3) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, (r0 + lane * 4u + (uint32_t)u * 256u) * 4u, 0, 2));
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane * 16u + (uint32_t)u * 1024u, r0 * 4u, /*nt*/ 2));
     };
+    // the steps of one 16-byte load: presence bits into the band bitmap of the entry.  (Under the execution mask, not as an OR
+    // of zero: the lanes past the end of a segment would all meet on one word, and same-address LDS atomics serialise.)
     auto process = [&](const u32x4 &v, const Seg &s, uint32_t r0, int u, uint32_t *map) {
         const uint32_t q = r0 + (uint32_t)u * 256u + lane * 4u - s.head;  // position in the segment (wraps before it)
         const uint32_t len = s.nal - s.head;
@@ -231,16 +245,15 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
             const uint32_t id = ids[e];
             const bool valid = q + (uint32_t)e < len;
             const bool inb = id - lo_id < width;
-            if (valid && inb) atomicOr(&map[((id >> 11) & (uint32_t)(BT - 1)) * 64u + (id & 63u)], 1u << ((id >> 6) & 31u));
+            if (valid && inb) atomicOr(&map[(((id >> 11) & (uint32_t)(BT - 1)) << 6) | (id & 63u)], 1u << ((id >> 6) & 31u));
             bad |= valid && !inb;
         }
     };
     auto fold = [&](uint32_t batch) {
         const uint32_t k0 = batch * CW;
-        if ((k0 >> 6) != fwin) {
+        if ((k0 >> 6) != fwin) {  // the first batch of a window: w_g still holds this window's groups
             fwin = k0 >> 6;
-            const uint32_t k = fwin * 64u + lane;
-            f_g = k < n_ordered ? ord_group[k] : NONE;
+            f_g = w_g;
         }
         uint32_t x[CW];
 #pragma unroll
@@ -265,22 +278,23 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     if (n_batches) {
         Seg cur = seg_of(0);
         uint32_t c_r0 = 0, c_batch = 0;
-#pragma unroll
-        for (int u = 0; u < BAND_D; ++u) buf[u] = issue(cur, 0, u);
-        while (c_batch < n_batches) {
+        // one group of BAND_D loads per lane: consume `in` slot by slot, the next group's loads going out into `out` as the
+        // slots are taken -- BAND_D loads in flight throughout.  (Two register sets that swap roles: with one set refilled
+        // in place the compiler parks the new loads elsewhere and copies them back at the loop head, i.e. waits for them.)
+        auto group = [&](const u32x4(&in)[BAND_D], u32x4(&out)[BAND_D]) {
             Seg nxt = cur;
             uint32_t n_r0 = c_r0 + 256u * BAND_D, n_batch = c_batch;
             if (n_r0 >= cur.nal) {  // the segment ends with this group of loads
                 n_batch = c_batch + 1;
                 n_r0 = 0;
-                nxt = n_batch < n_batches ? seg_of(n_batch) : Seg{items, 0u, 0u};
+                nxt = n_batch < n_batches ? seg_of(n_batch) : make_seg(0, 0);
             }
             uint32_t *map = &bm[c_batch & 1u][wave][0];
 #pragma unroll
             for (int u = 0; u < BAND_D; ++u) {
-                const u32x4 v = buf[u];
-                buf[u] = issue(nxt, n_r0, u);
-                process(v, cur, c_r0, u, map);
+                out[u] = issue(nxt, n_r0, u);
+                if (c_r0 + (uint32_t)u * 256u < cur.nal) process(in[u], cur, c_r0, u, map);  // (wave-uniform: the slot holds steps)
+                __builtin_amdgcn_sched_barrier(0);  // slot by slot: the other slots' loads stay in flight meanwhile
             }
             if (n_batch != c_batch) {
                 __syncthreads();
@@ -289,6 +303,15 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
             cur = nxt;
             c_r0 = n_r0;
             c_batch = n_batch;
+        };
+        u32x4 bufA[BAND_D], bufB[BAND_D];
+#pragma unroll
+        for (int u = 0; u < BAND_D; ++u) bufA[u] = issue(cur, 0, u);
+        while (true) {
+            group(bufA, bufB);
+            if (c_batch >= n_batches) break;
+            group(bufB, bufA);
+            if (c_batch >= n_batches) break;
         }
         if (cur_g != NONE) flush(cur_g);
     }
@@ -326,7 +349,12 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands) {
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags);
     };
+    static int loadv = getenv("PNX_BAND_LOADV") ? atoi(getenv("PNX_BAND_LOADV")) : 1;
     if (write_m) go(k_band_cover<NPL, 4, true>);
+    else if (loadv == 0) go(k_band_cover<NPL, 4, false, 0>);
+    else if (loadv == 2) go(k_band_cover<NPL, 4, false, 2>);
+    else if (loadv == 3) go(k_band_cover<NPL, 4, false, 3>);
+    else if (loadv == 4) go(k_band_cover<NPL, 4, false, 4>);
     else go(k_band_cover<NPL, 4, false>);
 }
 

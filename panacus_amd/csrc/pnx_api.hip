@@ -73,7 +73,9 @@ int drain_streams(pnx_ctx *ctx) {
 // histogram pass, one when the pass also writes or merges the presence matrix
 static int choose_pass_streams(pnx_ctx *ctx) {
     const bool use_m = ctx->want_M || (!use_rows(ctx) && ctx->last_general_paths > 0);
-    const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m;
+    // (a one-shot pass over the steps is one chain of three kernels: on one stream a dependent kernel follows within ~2 us, across
+    // streams the event hand-over costs ~25 us each -- nothing to overlap it with either)
+    const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m && !ctx->pass_band;
     if (ctx->tk_count && phased != ctx->last_pass_phased) {
         int rc = drain_streams(ctx);  // a pass in flight took the other arrangement: let it finish on the device
         if (rc) return rc;
@@ -825,7 +827,7 @@ int pnx_hist_async(pnx_ctx *ctx) {
     ctx->want_M = ctx->keep_M_user || ctx->growth_needs_M;
     ctx->growth_needs_M = false;
     ctx->cur = &ctx->tk[ctx->tk_next];
-    if ((rc = choose_pass_streams(ctx))) return rc;
+    ctx->pass_band = false;
     if (use_rows(ctx)) {
         // the first sweep of a graph takes the steps themselves when its shape suits the one-shot route (one read, nothing
         // derived); a second sweep is a caller that keeps sweeping: it derives the path rows, and every later pass is 8x cheaper
@@ -833,6 +835,9 @@ int pnx_hist_async(pnx_ctx *ctx) {
                          (ctx->cover_route == 1 || (ctx->cover_route == 0 && ctx->n_band_passes == 0 && band_route_fits(ctx, ctx->n_ordered)));
         if (ctx->pass_band) ctx->n_band_passes += 1;
         else if ((rc = ensure_rows(ctx, false))) return rc;  // once per upload
+    }
+    if ((rc = choose_pass_streams(ctx))) return rc;
+    if (use_rows(ctx)) {
     } else if (!ctx->index_valid || !ctx->cache_index) {
         // a kept index is shared by the passes: nothing may still be reading it while it is rebuilt
         if (ctx->cache_index && ctx->tk_count && (rc = drain_streams(ctx))) return rc;
