@@ -24,14 +24,12 @@
 // are never foreign facts: positions outside the segment are masked.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "pnx_context.hpp"
 #include "tile_counters.hpp"
 
 namespace pnx {
 
-constexpr int BAND_D = 4;              // 16-byte loads in flight per lane
+constexpr int BAND_CW = 4;                  // waves per workgroup = item tiles per band
 constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs through the ids downwards
 
 // first j in [0, len] with key(j) >= X, key = id (ascending path) or ~id (descending); keys are non-decreasing on a
@@ -120,7 +118,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
 
 // The coverage kernel.  flags[5] |= 1 when a step was found outside the band it was dealt to (or an index entry is
 // inconsistent): the result of the pass is void.
-template <int NPL, int CW, bool WRITE_M, int LOADV = 1>
+template <int NPL, int CW, bool WRITE_M, int BAND_D>
 __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restrict__ items, const unsigned long long *__restrict__ bidx,
                                                         const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
@@ -214,8 +212,8 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     };
     auto seg_of = [&](uint32_t batch) {
         const uint32_t k = batch * CW + wave;
+        if ((k >> 6) != swin) load_swin(k >> 6);  // (every wave: the fold needs the window's groups whether or not this wave has an entry)
         if (k >= n_ordered) return make_seg(0, 0);
-        if ((k >> 6) != swin) load_swin(k >> 6);
         const uint32_t l = k & 63u;
         const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_lo, l);
         const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_lo >> 32), l);
@@ -225,13 +223,6 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     const uint32_t n_batches = (n_ordered + CW - 1) / CW;
     auto issue = [&](const Seg &s, uint32_t r0, int u) {
-        if (LOADV == 0) {  // global loads at clamped addresses
-            uint32_t r = r0 + (uint32_t)u * 256u + lane * 4u;
-            r = r < s.nal ? r : 0u;
-            return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(s.base + r));
-        }
-        if (LOADV == 2) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane * 16u + (uint32_t)u * 1024u, r0 * 4u, 0));
-        if (LOADV == 3) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, (r0 + lane * 4u + (uint32_t)u * 256u) * 4u, 0, 2));
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane * 16u + (uint32_t)u * 1024u, r0 * 4u, /*nt*/ 2));
     };
     // the steps of one 16-byte load: presence bits into the band bitmap of the entry.  (Under the execution mask, not as an OR
@@ -327,7 +318,7 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 // The shapes the band route is worth it for: enough bands to fill the chip, segments long enough to stream, an index
 // of reasonable size.  (Anything else -- and any graph whose paths turn out not to be sorted -- takes the path rows.)
 bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries) {
-    constexpr uint32_t BT = 4;
+    constexpr uint32_t BT = BAND_CW;
     if (!n_entries || !ctx->n_steps || !ctx->n_paths) return false;
     const uint64_t n_bands = (ctx->n_blocks + BT - 1) / BT;
     if (n_bands < 2ull * (uint64_t)ctx->prop.multiProcessorCount) return false;
@@ -344,23 +335,21 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands) {
                      ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
     const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(n_bands), dim3(4 * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
+        hipLaunchKernelGGL(kern, dim3(n_bands), dim3(BAND_CW * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
                            (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags);
     };
-    static int loadv = getenv("PNX_BAND_LOADV") ? atoi(getenv("PNX_BAND_LOADV")) : 1;
-    if (write_m) go(k_band_cover<NPL, 4, true>);
-    else if (loadv == 0) go(k_band_cover<NPL, 4, false, 0>);
-    else if (loadv == 2) go(k_band_cover<NPL, 4, false, 2>);
-    else if (loadv == 3) go(k_band_cover<NPL, 4, false, 3>);
-    else if (loadv == 4) go(k_band_cover<NPL, 4, false, 4>);
-    else go(k_band_cover<NPL, 4, false>);
+    // 4 waves per band, 2 loads in flight per lane: measured best on 10 M items x 256 and x 1024 paths (0.64 / 2.45 ms; 4 in flight
+    // 0.67 / 2.56, 8 in flight 0.72; 8 waves per band 0.70, 2 waves 0.71) -- with every workgroup resident at once the chip holds
+    // ~19 waves per CU whatever the register count, and a deeper pipeline only adds loads beyond the ends of the segments
+    if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2>);
+    else go(k_band_cover<NPL, BAND_CW, false, 2>);
 }
 
 // phases 1 + 2 of a one-shot pass over the steps (the histogram phase is shared: launch_cover_pass)
 int launch_band_phases(pnx_ctx *ctx, bool write_m) {
-    constexpr uint32_t BT = 4;
+    constexpr uint32_t BT = BAND_CW;
     Ticket *tk = ctx->cur;
     int rc;
     const uint32_t n_bands = (ctx->n_blocks + BT - 1) / BT;

@@ -1,0 +1,236 @@
+"""The one-shot route (csrc/kernels_band.hip): steps -> coverage vector + histogram in ONE read of the ItemTable, for the
+first sweep of a graph whose paths are sorted by id -- against the CPU oracle (abacus.rs:719-787 restated), through the
+C ABI.  Integer work: bit-exact equality everywhere.  A path that is not sorted makes the pass void; the library then
+runs it again over path rows, and the caller sees the same numbers."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from panacus_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture
+def band(ctx):
+    """every pass over the steps themselves while no rows exist"""
+    from panacus_amd import capi
+    ctx.config(capi.CFG_COVER_ROUTE, 1)
+    yield ctx
+    ctx.config(capi.CFG_COVER_ROUTE, 0)
+
+
+def _oracle_hist(items, pre, pi, gi, n, G, w=None, exclude=None):
+    cov = orc.coverage(items, pre, pi, gi, n, exclude)
+    return cov, orc.hist(cov, G, w)
+
+
+def _concat(segs):
+    pre = np.zeros(len(segs) + 1, dtype=np.uint64)
+    pre[1:] = np.cumsum([len(s) for s in segs])
+    items = np.concatenate(segs).astype(np.uint64) if segs else np.zeros(0, dtype=np.uint64)
+    return items, pre
+
+
+def _sorted_graph(n, seed):
+    """paths that run through the ids in order, of every kind: ascending, descending, every step doubled, runs of one
+    id, empty, one step, strides that leave most item tiles untouched, both ends only"""
+    items, pre, lens = orc.pansyn(seed, n, 6)
+    segs = [items[int(pre[k]):int(pre[k + 1])].copy() for k in range(6)]
+    segs[1] = np.sort(segs[1])[::-1].copy()
+    segs[2] = np.sort(segs[2])
+    segs[3] = np.repeat(np.sort(segs[3]), 2)
+    segs[4] = np.sort(np.concatenate([segs[4], np.full(300, max(1, n // 3), dtype=np.uint64)]))
+    segs[0] = np.sort(segs[0])
+    segs[5] = np.sort(segs[5])[::-1].copy()
+    segs.append(np.zeros(0, dtype=np.uint64))
+    segs.append(np.array([n // 2 + 1], dtype=np.uint64))
+    segs.append(np.arange(1, n + 1, 5003, dtype=np.uint64))
+    segs.append(np.arange(n, 0, -4999, dtype=np.uint64))
+    segs.append(np.array([1, 1, n, n], dtype=np.uint64))
+    segs.append(np.array([n, 1], dtype=np.uint64))
+    items, pre = _concat(segs)
+    return items, pre, lens
+
+
+@pytest.mark.parametrize("n", [1, 2047, 2048, 8191, 8192, 8193, 40_961, 300_000])
+def test_band_route_on_sorted_paths_of_every_kind(band, n):
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    ctx = band
+    items, pre, lens = _sorted_graph(n, 3 + n % 7)
+    P = len(pre) - 1
+    rng = np.random.default_rng(n)
+    excl = (rng.random(n + 1) < 0.05).astype(np.uint8)
+    excl[0] = 0
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens, exclude=excl)
+    assert ctx.info().n_rows == 0                      # nothing derived at upload
+    reruns = ctx.info().n_reruns
+    pi = np.arange(P, dtype=np.uint64)
+    ctx.set_order(pi, pi, P)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, P, lens, excl)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    # groups of three, visited backwards, two paths left out
+    order = np.array([q for q in range(P - 1, -1, -1) if q not in (2, 7)], dtype=np.uint64)
+    gid = (np.arange(len(order)) // 3).astype(np.uint64)
+    G = int(gid.max()) + 1
+    ctx.set_order(order, gid, G)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, order, gid, n, G, lens, excl)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    # the presence matrix written by the same kernel, and growth on top of it
+    r, c = orc.by_group(items, pre, order, gid, n, excl)
+    bits = ctx.presence()
+    got_rows = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, 1: n + 1]
+    assert (got_rows.T == (orc.table_rows(r, c, G) != 0)).all()
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for q in (0.0, 0.5)])
+    out = ctx.ordered_growth([coverage_abs(Threshold(ABSOLUTE, 1), G)] * 2, qt)
+    for t, q in enumerate((0.0, 0.5)):
+        exp = orc.ordered_growth(r, c, G, (orc.ABSOLUTE, 1), (orc.RELATIVE, q), lens)
+        assert out[0, t].tolist() == [int(x) for x in exp]
+    info = ctx.info()
+    assert info.n_rows == 0 and info.n_reruns == reruns  # every pass held, no rows were ever derived
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_band_route_fuzz(band, seed):
+    """random sorted paths (either direction, random duplicates, random lengths incl. 0) on item counts around the tile
+    and band sizes, random grouping, random exclusion; node counts and bp"""
+    ctx = band
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([5, 63, 64, 2047, 2049, 8191, 8192, 8200, 16383, 16385, 50_000, 131_071]))
+    P = int(rng.integers(1, 40))
+    segs = []
+    for _ in range(P):
+        kind = rng.integers(0, 5)
+        ln = 0 if kind == 0 else int(rng.integers(1, max(2, min(3 * n, 60_000))))
+        s = np.sort(rng.integers(1, n + 1, size=ln).astype(np.uint64))
+        if kind == 2:
+            s = s[::-1].copy()
+        segs.append(s)
+    items, pre = _concat(segs)
+    lens = rng.integers(0, 70_000, size=n + 1).astype(np.uint32)
+    lens[0] = 0
+    excl = (rng.random(n + 1) < rng.choice([0.0, 0.1])).astype(np.uint8)
+    excl[0] = 0
+    weighted = bool(seed % 2)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens if weighted else None, exclude=excl if excl.any() else None)
+    reruns = ctx.info().n_reruns
+    order = rng.permutation(P)[: int(rng.integers(1, P + 1))].astype(np.uint64)
+    gid = np.cumsum(rng.random(len(order)) < 0.6).astype(np.uint64)
+    gid -= gid[0]
+    G = int(gid.max()) + 1
+    ctx.set_order(order, gid, G)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, order, gid, n, G, lens if weighted else None, excl if excl.any() else None)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    assert ctx.info().n_reruns == reruns and (ctx.info().n_rows == 0 or len(items) == 0)   # (no steps at all: nothing to read once)
+
+
+def test_a_path_that_is_not_sorted_voids_the_pass_and_the_rows_take_over(band):
+    ctx = band
+    n = 60_000
+    items, pre, _ = orc.pansyn(5, n, 8)
+    segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(8)]
+    s = segs[5].copy()
+    s[len(s) // 2], s[len(s) // 2 + 9000] = s[len(s) // 2 + 9000], s[len(s) // 2]   # two steps swapped across bands
+    segs[5] = s
+    items, pre = _concat(segs)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(8, dtype=np.uint64)
+    ctx.set_order(pi, pi, 8)
+    before = ctx.info().n_reruns
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, 8)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    info = ctx.info()
+    assert info.n_reruns == before + 1 and info.n_rows > 0         # run again, over rows
+    cnt, h = ctx.hist()                                             # and the graph is remembered: no second attempt
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 1
+    # locally jittered and fully shuffled paths: same story, same numbers
+    rng = np.random.default_rng(2)
+    segs[1] = rng.permutation(segs[1])
+    for a in range(0, len(segs[2]) - 50, 211):
+        segs[2][a:a + 37] = segs[2][a:a + 37][::-1].copy()
+    items, pre = _concat(segs)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    ctx.set_order(pi, (pi // 2).astype(np.uint64), 4)
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, pi, pi // 2, n, 4)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 2
+
+
+def test_band_route_rejects_bad_ids_at_upload(band):
+    from panacus_amd import capi
+    ctx = band
+    n = 10_000
+    items, pre, _ = orc.pansyn(9, n, 4)
+    for bad_pos, bad_val in ((0, 0), (len(items) // 2, n + 1), (len(items) - 1, 0xFFFFFFFE)):
+        bad = items.astype(np.uint32).copy()
+        bad[bad_pos] = bad_val
+        with pytest.raises(capi.PnxError) as e:
+            ctx.set_csr(bad, pre, n)
+        assert e.value.code == capi.PNX_EINVAL
+
+
+def test_first_sweep_takes_the_steps_second_sweep_derives_the_rows():
+    """the default policy on a shape the one-shot route fits (enough bands to fill the chip, long segments): nothing is
+    derived for the first sweep; a caller that sweeps again gets the rows, and every later pass runs over them"""
+    from panacus_amd import capi
+    n, p = 5_000_000, 12
+    items, pre, _ = orc.pansyn(11, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(11, n, p)
+        c.set_order(pi, pi, p)
+        cnt, h = c.hist()
+        ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+        assert c.info().n_rows == 0 and c.info().n_reruns == 0
+        gid = (pi // 3).astype(np.uint64)
+        c.set_order(pi[::-1].copy(), gid, 4)
+        cnt2, h2 = c.hist()
+        ocov2, oh2 = _oracle_hist(items, pre, pi[::-1].copy(), gid, n, 4)
+        assert np.array_equal(cnt2, ocov2) and np.array_equal(h2, oh2)
+        assert c.info().n_rows == p * ((n + 1 + 2047) // 2048)
+        # dropped derived data: the next sweep is a first sweep again
+        c.config(capi.CFG_DROP_DERIVED, 0)
+        c.set_order(pi, pi, p)
+        cnt3, h3 = c.hist()
+        assert np.array_equal(cnt3, ocov) and np.array_equal(h3, oh) and c.info().n_rows == 0
+        # the same through an uploaded ItemTable (ids validated at upload, no rows derived there)
+        c.set_csr(items.astype(np.uint32), pre, n)
+        assert c.info().n_rows == 0
+        c.set_order(pi, pi, p)
+        cnt4, h4 = c.hist()
+        assert np.array_equal(cnt4, ocov) and np.array_equal(h4, oh) and c.info().n_rows == 0
+        # path rows only
+        c.config(capi.CFG_COVER_ROUTE, 2)
+        c.config(capi.CFG_DROP_DERIVED, 0)
+        c.set_order(pi, pi, p)
+        cnt5, h5 = c.hist()
+        assert np.array_equal(cnt5, ocov) and np.array_equal(h5, oh) and c.info().n_rows > 0
+
+
+def test_band_passes_in_flight(band):
+    from panacus_amd import capi
+    ctx = band
+    n, p = 200_000, 10
+    items, pre, _ = orc.pansyn(21, n, p)
+    ctx.set_csr_pansyn(21, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+    ctx.hist_async()
+    ctx.hist_async()
+    for _ in range(2):
+        cnt, h = ctx.hist_fetch(want_countable=True)
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    assert ctx.info().n_rows == 0
