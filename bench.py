@@ -1,35 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- histgrowth throughput of the MI355X hot path (BASELINE.json metric).
 
-One "step" = one full histgrowth pass over one synthetic pangenome resident in HBM:
-  rows of the ordered paths laid out in visiting order -> coverage over the path rows (K1) -> histogram (K2)
-  on the GPU, the (G+1)-bin histogram back to the host, then the exact closed-form growth curves (f64, host
-  threads + K7) for the configured (coverage, quorum) pairs -- i.e. `panacus histgrowth -c node -l 1,2,1
-  -q 0,0,0.5` after the GFA has been turned into the CSR.  Resident when the timed region starts: the u32
-  ItemTable and the PATH ROWS that one read of it derives per upload; nothing that depends
-  on the visiting order or on an earlier pass.  What that derivation costs is part of the same JSON line:
-  `cold` = prepare_ms (steps -> rows) and cold_first_pass_ms (resident u32 steps -> first histogram on the host).
+One "step" = ONE COMPLETE `panacus histgrowth -c node -l 1,2,1 -q 0,0,0.5` call on a synthetic pangenome whose u32
+ItemTable is resident in HBM -- and nothing else: before every step everything that an earlier step derived is dropped
+(PNX_CFG_DROP_DERIVED: path rows, boundary index; PNX_CFG_DROP_GROWTH_TABLES: the (n, thresholds) tables of the closed
+forms), so a step is what the reference's one sweep per abacus is (graph_broker.rs:389-432, abacus.rs:539-586):
+
+  band edges of the ordered paths (k_band_index) -> the steps, read ONCE, to coverage vector + histogram (k_band_cover,
+  csrc/kernels_band.hip) -> the (G+1) counters published to the host (k_hist_publish) -> the exact closed-form growth
+  curves (f64, bit-identical to glibc: csrc/kernels_closed_form.hip) from the pass's device counters, their tables derived
+  inside the step on a side stream -> curves on the host.
+
+`value` = N x P / ms_per_step; `roofline` = SURVEY 8(d)'s algorithmic bytes / the HIP-event time of the kernel that reads
+the steps / 8 TB/s (every 4th launch of the timed region is timed; events around every launch would put gaps between the
+kernels); `roofline.traffic` = that kernel's HBM bytes from rocprofv3 counter passes driven by this run.  The pipelined
+pass over RESIDENT path rows that earlier rounds reported as the headline is in `resident_pass` (what a caller that sweeps
+the same graph again gets from the second sweep on), the derivation of those rows in `rows_route`.
 
 `python bench.py --gpus N` launches its N ranks itself (one process per GPU, rendezvous on 127.0.0.1) unless
 RANK / WORLD_SIZE are already in the environment (torch.distributed.run, the driver's way).
 
-Workload at N = 1: BASELINE.json configs[2] ("histgrowth ... on 10M-node / 256-path
-synthetic"), generator pansyn-v1 seed 42.  With --gpus N each rank owns one node-range
-shard of the same shape (weak scaling: the global graph has N x 10M nodes, seeds 42+rank),
-the per-rank histograms are summed with an RCCL all-reduce on the device counters, and
+Workload at N = 1: BASELINE.json configs[2] ("histgrowth ... on 10M-node / 256-path synthetic"), generator pansyn-v1
+seed 42.  With --gpus N each rank owns one node-range shard of the same shape (weak scaling: the global graph has
+N x 10M nodes, seeds 42+rank), the per-rank histograms are summed with an RCCL all-reduce on the device counters, and
 rank 0 evaluates the closed forms.
 
 Besides the headline the same JSON line carries:
-  * "permuted_growth" -- BASELINE.json configs[3]: ordered-histgrowth over R = 128 random group
-    orders on a 10M-node / 512-path graph, STRONG scaling: the R orders are dealt to the ranks
-    (permutation sharding, presence matrix replicated), every rank's out[R/N][T][G] is summed
-    into the full out[R][T][G] with an RCCL all-reduce enqueued behind the growth kernels on the
-    library's own stream, on the device buffer (pnx_ordered_growth_enqueued).  For N > 1 rank 0
-    also times all R orders alone, so that `speedup_vs_1` comes from one run on one box.
-  * "shape_10Mx1k" (N = 1 only) -- north_star's 10M-node / 1k-path histgrowth shape with its
-    kernel breakdown.
-  * "cpu_baseline" (N = 1 only) -- the oracle (serial port of the reference's loops; closed forms
-    one thread per threshold pair like hist.rs:68-81) on the FULL headline workload.
+  * "permuted_growth" -- BASELINE.json configs[3]: ordered-histgrowth over R = 128 random group orders on a
+    10M-node / 512-path graph, STRONG scaling: the R orders are dealt to the ranks (permutation sharding, presence
+    matrix replicated), every rank's out[R/N][T][G] is summed into the full out[R][T][G] with an RCCL all-reduce
+    enqueued behind the growth kernels on the library's own stream.  For N > 1 rank 0 also times all R orders alone, so
+    that `speedup_vs_1` comes from one run on one box.
+  * "shape_10Mx1k" (N = 1 only) -- north_star's 10M-node / 1k-path histgrowth shape, the same step.
+  * "cpu_baseline" (N = 1 only) -- the oracle (serial port of the reference's loops; closed forms one thread per
+    threshold pair like hist.rs:68-81) on the FULL headline workload, its results compared bit for bit.
 
 Prints ONE JSON line (rank 0).
 """
@@ -61,19 +65,18 @@ def algorithmic_bytes_hist(S, P, N, G, weighted=False):
     return 4 * S + 8 * (P + 1) + 4 * N + (4 * N if weighted else 0) + 8 * (G + 1)
 
 
-def moved_bytes_hist(rows_in_order, N, G, weighted=False):
-    """What a coverage pass over path rows HAS to move through HBM: the 256-byte rows of the ordered paths on the
-    tiles they span (read once), the coverage vector (written by K1; K2 reads it back, and the weights if bp), the
-    counters.  The steps themselves are not touched by a pass."""
+def moved_bytes_rows_pass(rows_in_order, N, G):
+    """What a coverage pass over RESIDENT path rows moves through HBM: the 256-byte rows of the ordered paths on the tiles
+    they span, the coverage vector, the counters (the steps themselves are not touched by such a pass)."""
     return 256 * rows_in_order + 4 * (N + 1) + 8 * (G + 1)
 
 
-ROOFLINE_NOTE = ("frac = achieved / peak on the bytes the timed kernel MOVES (256-byte path rows in, coverage vector out), its "
-                 "launch time measured with HIP events in this run; frac_algorithmic prices the same launch on SURVEY 8(d)'s "
-                 "algorithmic bytes (4 B per path step) -- it exceeds 1 because a pass over path rows does not read the steps: "
-                 "they are read ONCE per upload, by the kernel that derives the rows (see `cold`: that read is priced there, "
-                 "on the same algorithmic bytes).  traffic = HBM bytes of the same kernel from rocprofv3 PMC passes driven by "
-                 "this run (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; gfx950 reports half of wide streaming reads)")
+ROOFLINE_NOTE = ("achieved = SURVEY 8(d)'s algorithmic bytes of one histgrowth pass (4 B per path step + 4 B per item + the offsets and "
+                 "counters) / the HIP-event duration of k_band_cover, the kernel that reads the steps, measured on its stream for every "
+                 "4th launch of the timed region; frac = achieved / 8 TB/s.  traffic = HBM bytes of the same kernel from rocprofv3 PMC "
+                 "passes driven by this run (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; gfx950 reports half of wide streaming reads).  "
+                 "whole_step prices the same bytes on ms_per_step: band-edge index, publish, closed forms (tables derived inside the "
+                 "step), launches and the host's share included")
 
 
 def pmc_leg(argv_child, kernels, counters_sets, timeout=240):
@@ -120,6 +123,7 @@ def pmc_leg(argv_child, kernels, counters_sets, timeout=240):
     return out, "measured by this run: rocprofv3 --kernel-trace --pmc passes over child runs of this script on the same workload"
 
 
+
 def launch_ranks(n, force_dist):
     """`bench.py --gpus N` without a launcher: start the N ranks (one process per GPU), hand them RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_*, pass rank 0's stdout through.  Fails loudly when fewer than N devices are visible."""
@@ -155,6 +159,7 @@ def launch_ranks(n, force_dist):
     for pr in procs:
         rc = max(rc, abs(pr.wait()))
     raise SystemExit(rc)
+
 
 
 def cpu_baseline(ctx, n_nodes, n_paths, pairs, seed=42, passes=3, sample_nodes=None):
@@ -217,6 +222,7 @@ def cpu_baseline(ctx, n_nodes, n_paths, pairs, seed=42, passes=3, sample_nodes=N
     }, h, growths
 
 
+
 def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking):
     """BASELINE.json configs[3], strong scaling by permutation sharding (module docstring)."""
     from panacus_amd import capi
@@ -247,27 +253,23 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         torch.cuda.synchronize()
         ctx.sync()
 
-    # what every rank has to derive before it can evaluate an order: the path rows (one read of the steps) ...
-    ctx.prepare()                    # first call: allocations
-    prep = []
+    # what every rank has to derive before it can evaluate an order: the presence matrix of the groups -- ONE read of the steps
+    # (the one-shot route writes the matrix beside the coverage vector, kernels_band.hip), then resident
+    ctx.hist(want_countable=False)   # first call: allocations, code objects
+    ctx.profile_enable(True)
+    packs = []
     for _ in range(3):
         ctx.config(capi.CFG_DROP_DERIVED, 0)
+        ctx.set_order(order, order, P)
+        ctx.profile_reset()
         sync_all()
         t0 = time.perf_counter()
-        ctx.prepare()
-        prep.append(time.perf_counter() - t0)
-    prepare_s = sorted(prep)[len(prep) // 2]
-    ctx.set_order(order, order, P)
-    # ... and the presence matrix of the groups (K1 over the rows with the row stores, K2): built once per rank, then resident
-    ctx.hist(want_countable=False)   # first call: allocations
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
-    ctx.hist(want_countable=False)
-    pack_s = time.perf_counter() - t0
+        ctx.hist(want_countable=False)
+        packs.append(time.perf_counter() - t0)
+    pack_s = sorted(packs)[1]
     pk = ctx.profile_read()
     info = ctx.info()
+    pack_route = "one-shot over the steps (k_band_cover, WRITE_M)" if int(info.n_rows) == 0 else "path rows (k_rows_build + k_rows_cover)"
 
     # ---- all R orders on one GPU: the single-GPU time (every rank could; rank 0's is reported) ----
     ctx.ordered_growth(cov, qt, perms[:1])  # masks, first launch
@@ -367,7 +369,6 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
         n_words = (N + 1 + 63) // 64
         b_growth = R * (8 * P * n_words + 8 * T * P)       # SURVEY 8(d), all R orders
         b_pack = 4 * int(info.n_steps) + 8 * P * n_words
-        b_pack_layout = 256 * int(info.n_rows_in_order) + 8 * P * n_words + 4 * (N + 1)  # path rows in; presence rows + coverage vector out
         cover_ms = pk["cover"][0] / max(pk["cover"][1], 1)
         out = {
             "workload": f"ordered-histgrowth -c node -l 1,2,1 -q 0,0,0.5 over {R} random group orders (pansyn stream 7, seed "
@@ -383,14 +384,15 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
             "allreduce_ms": ar_ms,
             "collective_path": ("none (one rank)" if not use_dist else "rccl through the library's own communicator (pnx_comm_allreduce_u64) on pnx_stream()"
                                 if args.collective == "native" else "rccl via torch.distributed (nccl backend) on pnx_stream()"),
-            "prepare_ms": prepare_s * 1e3,
-            "presence_pack_ms": pack_s * 1e3, "presence_pack_cover_kernel_ms": cover_ms,
-            "presence_pack_algorithmic_bytes": b_pack, "presence_pack_moved_bytes": b_pack_layout,
-            "presence_pack_cover_kernel_GBps_on_moved_bytes": b_pack_layout / (cover_ms * 1e-3) / 1e9 if cover_ms > 0 else None,
-            # a COLD call: every rank derives the rows and packs the presence matrix itself (replicated work: it does not scale)
-            "seconds_per_call_incl_pack": dt + pack_s + prepare_s,
-            "speedup_vs_1_incl_pack": (t1 + pack_s + prepare_s) / (dt + pack_s + prepare_s),
-            "incl_pack_note": "incl_pack = prepare (steps -> path rows) + presence pack + the growth call, all replicated on every rank",
+            "presence_pack_ms": pack_s * 1e3, "presence_pack_route": pack_route,
+            "presence_pack_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in pk.items() if v[1]},
+            "presence_pack_cover_kernel_ms": cover_ms,
+            "presence_pack_algorithmic_bytes": b_pack,
+            "presence_pack_frac_of_hbm_peak": b_pack / pack_s / 1e9 / HBM_PEAK_GBS if pack_s > 0 else None,
+            # a COLD call: every rank packs the presence matrix itself (replicated work: it does not scale)
+            "seconds_per_call_incl_pack": dt + pack_s,
+            "speedup_vs_1_incl_pack": (t1 + pack_s) / (dt + pack_s),
+            "incl_pack_note": "incl_pack = the presence pack from the resident steps (one read, replicated on every rank) + the growth call",
             "algorithmic_bytes": b_growth, "algorithmic_GBps": b_growth / dt / 1e9,
             "steps_in_csr": int(info.n_steps),
             "similarity_intersections": sim,
@@ -403,118 +405,295 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
     return out
 
 
-def cold_numbers(ctx, order, G, reps=3):
-    """What an upload costs before its first histogram: prepare_ms = the steps resident in HBM -> path rows (one read of
-    the steps, synchronous); cold_first_pass_ms = the same + the first pass + its histogram on the host (pnx_hist on a
-    graph whose derived data were dropped).  Medians of `reps` runs on a warm context (buffers exist)."""
+
+
+class OneShot:
+    """One complete histgrowth call from the resident u32 ItemTable, nothing derived kept from call to call."""
+
+    def __init__(self, ctx, P, thr, *, rank=0, world=1, use_dist=False, dist=None, torch=None, local_rank=0, collective="torch",
+                 blocking=False, growth_on_device=False, growth_threads=0):
+        from panacus_amd import capi, hostlib
+        self.capi, self.hostlib = capi, hostlib
+        self.ctx, self.P, self.thr, self.rank = ctx, P, thr, rank
+        self.use_dist, self.dist, self.torch = use_dist, dist, torch
+        self.growth_on_device, self.growth_threads = growth_on_device, growth_threads
+        self.native = use_dist and collective == "native"
+        self.dev = f"cuda:{local_rank}"
+        self.views, self.ext = {}, {}
+        if self.native:
+            # the library reduces flags + histogram behind every pass by itself (pnx_comm_init)
+            uid = [type(ctx).comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], rank, world)
+        elif use_dist:
+            self.tmp = torch.zeros(P + 1, dtype=torch.int64, device=self.dev)
+            self.host = torch.zeros(P + 1, dtype=torch.int64).pin_memory()
+            self.ev = torch.cuda.Event(blocking=blocking)
+
+    def step(self):
+        capi, hostlib, ctx, torch = self.capi, self.hostlib, self.ctx, self.torch
+        ctx.config(capi.CFG_DROP_DERIVED, 0)            # no rows, no index: the pass starts from the steps
+        if self.rank == 0 and not os.environ.get("PANACUS_BENCH_KEEP_TABLES"):  # (the variable: an experiment, never a reported number)
+            ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)  # ... and the closed forms from (n, thresholds)
+        ctx.hist_async()
+        pend = None
+        device_side = self.growth_on_device and self.rank == 0 and (not self.use_dist or self.native)
+        if device_side:
+            # the curves follow the pass on the device, from its own (all-reduced) counters; their tables are derived on a side
+            # stream while the coverage kernel runs
+            pend = hostlib.calc_growths_begin_on_device(self.P, self.thr)
+        if self.use_dist and not self.native:
+            # the collective follows the counters on the stream of the pass
+            d_hist, st = ctx.hist_enqueued_on()
+            ext = self.ext.get(st)
+            if ext is None:
+                ext = self.ext[st] = torch.cuda.ExternalStream(st, device=self.dev)
+            t = self.views.get(d_hist)
+            if t is None:
+                t = self.views[d_hist] = torch.as_tensor(_DevArray(d_hist, self.P + 1), device=self.dev)
+            reruns = int(ctx.info().n_reruns)
+            with torch.cuda.stream(ext):
+                self.tmp.copy_(t)
+                self.dist.all_reduce(self.tmp)  # RCCL, int64 sum == uint64 sum for counts < 2^63
+                self.host.copy_(self.tmp, non_blocking=True)
+                self.ev.record(ext)
+            self.ev.synchronize()
+            ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
+            if int(ctx.info().n_reruns) != reruns:
+                # a pass that fails its verification is run again by the library, and its reduced counters would be stale; it
+                # cannot happen here (pansyn paths are sorted) -- failing is better than an unmatched collective
+                raise RuntimeError("a coverage pass was re-run inside the multi-GPU loop")
+            h = self.host.numpy().view(np.uint64).copy()
+        else:
+            _, h = ctx.hist_fetch(want_countable=False)
+        growths = None
+        if self.rank == 0:
+            if pend is None:
+                pend = hostlib.calc_growths_begin(h, self.thr, self.growth_threads)
+            growths = hostlib.calc_growths_end(pend)
+        return h, growths
+
+    def close(self):
+        if self.native:
+            self.ctx.comm_free()
+        # torch objects that were used on the library's stream must go before the stream does
+        self.views.clear()
+        self.ext.clear()
+        for a in ("tmp", "host", "ev"):
+            if hasattr(self, a):
+                delattr(self, a)
+
+
+def timed_steps(stepper, steps, warmup, barrier, sample_every):
+    """W untimed steps, then exactly K steps between barriers; HIP events around every sample_every-th launch of the
+    three kernels of a pass.  -> (seconds, last histogram, last curves, {slot: (ms, launches)})"""
+    from panacus_amd import capi
+    ctx = stepper.ctx
+    h = growths = None
+    for _ in range(warmup):
+        h, growths = stepper.step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_select([capi.K_INDEX, capi.K_COVER, capi.K_HIST])
+    ctx.profile_sample(sample_every)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h, growths = stepper.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_select(None)
+    ctx.profile_sample(1)
+    ctx.profile_reset()
+    ctx.profile_enable(False)
+    return dt, h, growths, prof
+
+
+def closed_form_costs(ctx, h, thr, growth_threads, reps=3):
+    """what the closed forms of one histogram cost by themselves (host histogram in, curves out): with the (n, thresholds)
+    tables derived inside the call, and with the tables kept"""
+    from panacus_amd import capi, hostlib
+    first, later = [], []
+    for _ in range(reps):
+        ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)
+        for acc in (first, later):
+            g0 = time.perf_counter()
+            hostlib.calc_growths_end(hostlib.calc_growths_begin(h, thr, growth_threads))
+            acc.append((time.perf_counter() - g0) * 1e3)
+    return {"tables_and_curves_ms": min(first), "curves_with_kept_tables_ms": min(later)}
+
+
+def hist_only_block(ctx, N, P, S, steps):
+    """the same one-shot pass without the closed forms behind it: `panacus hist` from the resident steps (derived data dropped
+    before every call) -- the coverage kernel alone on the chip, no table kernels beside it"""
     from panacus_amd import capi
     ctx.sync()
+    ts = []
+    for k in range(steps + 2):
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        t0 = time.perf_counter()
+        ctx.hist(want_countable=False)
+        if k >= 2:
+            ts.append((time.perf_counter() - t0) * 1e3)
+    ctx.profile_enable(True)
+    ctx.profile_select([capi.K_INDEX, capi.K_COVER, capi.K_HIST])
+    ctx.profile_reset()
+    for _ in range(max(4, steps // 4)):
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        ctx.hist(want_countable=False)
+    prof = ctx.profile_read()
+    ctx.profile_select(None)
+    ctx.profile_reset()
+    ctx.profile_enable(False)
+    ts.sort()
+    B = algorithmic_bytes_hist(S, P, N, P)
+    per = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
+    ms = ts[len(ts) // 2]
+    return {"what": "pnx_hist on the resident steps, derived data dropped before every call; wall clock of the call (median), kernels "
+                    "timed in separate calls with HIP events around each",
+            "ms_per_call": ms, "ms_min": ts[0], "calls": len(ts), "value": N * P / (ms * 1e-3) / 1e6,
+            "frac_of_hbm_peak_on_algorithmic_bytes": B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernels_ms": {"band_index": per.get("index"), "band_cover": per.get("cover"), "hist_publish": per.get("hist")},
+            "band_cover_frac_of_hbm_peak": (B / (per["cover"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if per.get("cover") else None}
+
+
+def resident_pass_block(ctx, P, thr, growth_on_device, growth_threads, steps, depth):
+    """What a caller that sweeps the SAME resident graph again gets: the path rows derived once (rows_route.prepare_ms), every
+    further pass over the rows, pipelined `depth` deep, closed forms from kept tables.  NOT the headline: no panacus
+    command sweeps one ItemTable twice with the same grouping."""
+    from panacus_amd import capi, hostlib
+    ctx.sync()
+    ctx.config(capi.CFG_COVER_ROUTE, 2)
+    ctx.config(capi.CFG_MAX_IN_FLIGHT, depth)
     prep, cold = [], []
-    for _ in range(reps):
+    for _ in range(3):
         ctx.config(capi.CFG_DROP_DERIVED, 0)
         t0 = time.perf_counter()
         ctx.prepare()
         prep.append((time.perf_counter() - t0) * 1e3)
-    for _ in range(reps):
+    for _ in range(3):
         ctx.config(capi.CFG_DROP_DERIVED, 0)
-        ctx.set_order(order, order, G)
         t0 = time.perf_counter()
         ctx.hist(want_countable=False)
         cold.append((time.perf_counter() - t0) * 1e3)
-    info = ctx.info()
-    return {"prepare_ms": sorted(prep)[reps // 2], "cold_first_pass_ms": sorted(cold)[reps // 2],
-            "rows": int(info.n_rows), "rows_bytes": 256 * int(info.n_rows), "rows_tile_major": bool(info.rows_tile_major)}
-
-
-def shape_1k_block(args, local_rank):
-    """north_star's shape: histgrowth on a 10M-node / 1k-path pansyn graph, one GPU, same step as the
-    headline (index rebuilt every pass, closed forms included; the O(n^3) quorum sums of n = 1024 run
-    on the GPU, bit-identical), with the kernel breakdown."""
-    from panacus_amd import capi, hostlib
-    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
-    N, P, steps = args.k1_nodes, args.k1_paths, max(2, args.k1_steps)
-    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
-    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
-    ctx = capi.Context(local_rank)
-    ctx.config(capi.CFG_CACHE_INDEX, 0)
-    depth = max(1, min(4, args.depth))
-    ctx.config(capi.CFG_MAX_IN_FLIGHT, depth)
-    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
-    order = np.arange(P, dtype=np.uint32)
-    ctx.set_order(order, order, P)
-    offload = not args.no_quorum_offload and P >= args.quorum_offload_min_n
-    if not args.no_quorum_offload:
-        hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
-
-    on_device = offload and hostlib.device_growth_usable()
 
     def enqueue():
-        """one pass; with the whole closed forms on the device, the curves follow it there (the histogram does not
-        visit the host in between)"""
         ctx.hist_async()
-        return hostlib.calc_growths_begin_on_device(P, thr) if on_device else None
+        return hostlib.calc_growths_begin_on_device(P, thr) if growth_on_device else None
 
     def run(n):
         h = growths = None
-        queue = []
-        enq = 0
-        for _ in range(min(n, depth if P <= 511 else 2)):
-            queue.append(enqueue())
-            enq += 1
+        queue = [enqueue() for _ in range(min(n, depth))]
+        enq = len(queue)
         for _ in range(n):
             _, h = ctx.hist_fetch(want_countable=False)
-            pending = queue.pop(0) or hostlib.calc_growths_begin(h, thr, args.growth_threads)
+            pending = queue.pop(0) or hostlib.calc_growths_begin(h, thr, growth_threads)
             if enq < n:
                 queue.append(enqueue())
                 enq += 1
             growths = hostlib.calc_growths_end(pending)
         return h, growths
 
-    run(3)
+    run(4)
     ctx.sync()
     ctx.profile_enable(True)
     ctx.profile_select([capi.K_COVER])
+    ctx.profile_sample(max(1, min(8, steps // 4)))
     ctx.profile_reset()
     t0 = time.perf_counter()
-    h, growths = run(steps)
+    h, _ = run(steps)
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
-    cover = ctx.profile_read()["cover"]
+    ms, cnt = ctx.profile_read()["cover"]
     ctx.profile_select(None)
+    ctx.profile_sample(1)
     ctx.profile_reset()
-    ctx.config(capi.CFG_OVERLAP_PHASES, 0)  # every kernel on its own
-    run(4)
-    ctx.sync()
-    tail = ctx.profile_read()
     ctx.profile_enable(False)
     info = ctx.info()
-    S = int(info.n_steps)
+    moved = moved_bytes_rows_pass(int(info.n_rows_in_order), int(info.n_items), P)
+    k1 = ms / max(cnt, 1)
+    out = {
+        "what": "pipelined passes over RESIDENT path rows (derived once per upload), closed forms from kept tables: the second and "
+                "later sweeps of one graph -- not a histgrowth call",
+        "ms_per_pass": dt * 1e3, "passes": steps, "passes_in_flight": depth,
+        "k_rows_cover_avg_launch_ms": k1, "moved_bytes_per_pass": moved,
+        "k_rows_cover_frac_of_hbm_peak_on_moved_bytes": moved / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS if k1 > 0 else None,
+        "rows": int(info.n_rows), "rows_bytes": 256 * int(info.n_rows),
+        "rows_route": {"prepare_ms": sorted(prep)[1], "cold_first_pass_ms": sorted(cold)[1],
+                       "what": "the same cold call through the path rows (PNX_CFG_COVER_ROUTE 2): steps -> rows -> pass; what round 3 ran"},
+        "hist_sum": int(h.sum()),
+    }
+    ctx.config(capi.CFG_COVER_ROUTE, 0)
+    ctx.config(capi.CFG_DROP_DERIVED, 0)
+    ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
+    return out
+
+
+def step_report(ctx, N, P, S, dt, steps, prof, world=1):
+    """the numbers of a timed one-shot loop: per-step time, kernel split, roofline of the kernel that reads the steps"""
+    ms_per_step = dt / steps * 1e3
     B = algorithmic_bytes_hist(S, P, N, P)
-    B_layout = moved_bytes_hist(int(info.n_rows_in_order), N, P)
-    cover_beside_ms = cover[0] / max(cover[1], 1)
-    cover_ms = tail["cover"][0] / max(tail["cover"][1], 1)
-    index_ms = tail["scatter"][0] / max(tail["scatter"][1], 1)
-    hist_ms = tail["hist"][0] / max(tail["hist"][1], 1)
-    cold = cold_numbers(ctx, order, P)
+    per = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
+    cover_ms, index_ms, hist_ms = per.get("cover"), per.get("index"), per.get("hist")
+    kernels = sum(x for x in (cover_ms, index_ms, hist_ms) if x)
+    achieved = B / (cover_ms * 1e-3) / 1e9 if cover_ms else 0.0
+    info = ctx.info()
+    one_shot = int(info.n_rows) == 0 and int(info.n_reruns) == 0
+    return ms_per_step, B, cover_ms, {
+        "bound": "hbm",
+        "kernel": "k_band_cover" if one_shot else "k_rows_build + k_rows_cover",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None, "traffic_source": None,
+        "algorithmic_bytes_per_launch": B,
+        "avg_launch_ms": cover_ms, "launches": prof.get("cover", (0, 0))[1],
+        "whole_step": {"ms": ms_per_step, "achieved": B / (ms_per_step * 1e-3) / 1e9, "frac": B / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "note": ROOFLINE_NOTE,
+    }, {"band_index": index_ms, "band_cover": cover_ms, "hist_publish": hist_ms, "kernels_of_the_pass": kernels,
+        "everything_else": ms_per_step - kernels,
+        "everything_else_is": "closed-form evaluation behind the pass (k_cf_eval; the tables are derived beside the pass), kernel launches, "
+                              "the wait for the results, Python"}
+
+
+def shape_1k_block(args, local_rank):
+    """north_star's shape: histgrowth on a 10M-node / 1k-path pansyn graph, one GPU, the same one-shot step as the headline
+    (the O(n^3) quorum tables of n = 1024 are derived inside every step, beside the pass)."""
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    N, P, steps = args.k1_nodes, args.k1_paths, max(2, args.k1_steps)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    ctx = capi.Context(local_rank)
+    if args.cover_route is not None:
+        ctx.config(capi.CFG_COVER_ROUTE, args.cover_route)
+    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
+    hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
+    on_device = P >= args.quorum_offload_min_n and P <= 2048 and hostlib.device_growth_usable()
+    stepper = OneShot(ctx, P, thr, growth_on_device=on_device, growth_threads=args.growth_threads)
+
+    def barrier():
+        ctx.sync()
+
+    dt, h, growths, prof = timed_steps(stepper, steps, 2, barrier, max(1, min(4, steps // 4)))
+    S = int(ctx.info().n_steps)
+    ms_per_step, B, cover_ms, roofline, breakdown = step_report(ctx, N, P, S, dt, steps, prof)
+    cf = closed_form_costs(ctx, h, thr, args.growth_threads) if on_device else None
+    hist_only = hist_only_block(ctx, N, P, S, 8)
+    resident = resident_pass_block(ctx, P, thr, on_device, args.growth_threads, max(8, steps), 4) if not args.no_resident else None
     if int(h.sum()) != N:
         raise SystemExit(f"shape_10Mx1k: histogram sums to {int(h.sum())}, expected {N}")
+    stepper.close()
     hostlib.set_quorum_offload(None)
     ctx.close()
     return {
         "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 seed {args.seed}, {N} nodes x {P} paths (north_star's shape)",
-        "steps": steps, "ms_per_step": dt * 1e3, "value": N * P / dt / 1e6, "unit": "M node*paths/s",
-        "steps_in_csr": S, "algorithmic_bytes_per_pass": B, "moved_bytes_per_pass": B_layout,
-        "cold": cold,
-        "breakdown_ms": {"rows_order": index_ms, "rows_cover": cover_ms, "hist": hist_ms,
-                         "device_total": index_ms + cover_ms + hist_ms,
-                         "rows_cover_beside_the_other_phases": cover_beside_ms,
-                         "quorum_inner_sums_on_gpu": bool(offload and hostlib.quorum_offload_usable()),
-                         "closed_forms_on_gpu": bool(on_device)},
-        "roofline_frac_rows_cover": B_layout / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
-        "roofline_frac_whole_step": B_layout / dt / 1e9 / HBM_PEAK_GBS,
-        "frac_algorithmic_rows_cover": B / (cover_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cover_ms > 0 else None,
-        "frac_algorithmic_whole_step": B / dt / 1e9 / HBM_PEAK_GBS,
-        "frac_algorithmic_cold_first_pass": B / (cold["cold_first_pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "steps": steps, "ms_per_step": ms_per_step, "value": N * P / (ms_per_step * 1e-3) / 1e6, "unit": "M node*paths/s",
+        "steps_in_csr": S, "roofline": roofline, "step_breakdown_ms": breakdown,
+        "closed_forms": cf, "closed_forms_on_gpu": bool(on_device),
+        "hist_only": hist_only, "resident_pass": resident,
         "checks": {"hist_sum": int(h.sum()), "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
     }
 
@@ -522,16 +701,12 @@ def shape_1k_block(args, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--paths", type=int, default=256)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--tile-blocks", type=int, default=1)
-    ap.add_argument("--cover-variant", type=int, default=None)
-    ap.add_argument("--index-coarse", type=int, default=None)
-    ap.add_argument("--cover-waves", type=int, default=None)
-    ap.add_argument("--cover-split", type=int, default=None)
+    ap.add_argument("--cover-route", type=int, default=None, help="PNX_CFG_COVER_ROUTE: 0 chosen per pass [default], 1 one-shot, 2 path rows")
     ap.add_argument("--cpu-sample-nodes", type=int, default=0,
                     help="0 [default]: the CPU baseline runs on the full headline graph; > 0: on a pansyn graph of that many nodes")
     ap.add_argument("--cpu-passes", type=int, default=3)
@@ -543,28 +718,25 @@ def main():
     ap.add_argument("--no-shape-1k", action="store_true")
     ap.add_argument("--k1-nodes", type=int, default=10_000_000)
     ap.add_argument("--k1-paths", type=int, default=1024)
-    ap.add_argument("--k1-steps", type=int, default=40)
+    ap.add_argument("--k1-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-resident", action="store_true", help="skip the resident_pass blocks (pipelined passes over kept path rows)")
+    ap.add_argument("--resident-steps", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=4, help="passes in flight in the resident_pass block (1..4)")
     ap.add_argument("--growth-threads", type=int, default=0)
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="contexts (streams) over the one resident graph whose passes alternate.  1 [default]: one "
-                         "stream, the coverage kernel is timed alone (what `roofline` is defined on); 2: +11 %% passes/s, "
-                         "but two coverage kernels then overlap and a launch takes 1.1 ms (DESIGN.md section 5)")
     ap.add_argument("--collective", choices=["torch", "native"], default="torch",
                     help="who carries the RCCL all-reduce when there is one: torch.distributed's nccl backend [default] or the "
                          "library's own communicator (pnx_comm_init; the id travels through torch's store)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run the three phases of a pass (index | coverage kernel | histogram) on one stream instead of three")
-    ap.add_argument("--no-quorum-offload", action="store_true")
     ap.add_argument("--quorum-offload-min-n", type=int, default=256)
+    ap.add_argument("--allow-host-closed-forms", action="store_true",
+                    help="do not fail when the closed forms of >= 256 groups cannot run on the GPU (a libm whose log2 / exp2 the "
+                         "restatements do not reproduce): the host threads then set the pace of a step")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (child runs of this script) that measure roofline.traffic and roofline_valu")
-    ap.add_argument("--no-cold", action="store_true", help="skip the cold-path block (prepare_ms, cold_first_pass_ms)")
-    ap.add_argument("--rows-layout", type=int, default=None)
-    ap.add_argument("--depth", type=int, default=4,
-                    help="passes a context keeps in flight (PNX_CFG_MAX_IN_FLIGHT, 1..4): the latency of a step -- pass, closed forms on "
-                         "their own streams, the host's share -- is several times the duration of a pass")
+    ap.add_argument("--headline-only", action="store_true", help="the timed steps and nothing else (what the counter passes run)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = True
 
     force_dist = os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or force_dist):
@@ -583,9 +755,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: panacus_amd has no CPU fallback")
     blocking = world > 1 or os.environ.get("PANACUS_BENCH_BLOCKING") == "1"
     if blocking:
-        # Several ranks share the host (and possibly one cgroup CPU quota): waits must sleep, not
-        # spin, or the waiting ranks eat the CPU time rank 0 needs for the closed forms.  The flag
-        # has to be set before the HIP context of the device exists.
+        # Several ranks share the host (and possibly one cgroup CPU quota): waits must sleep, not spin, or the waiting ranks
+        # eat the CPU time rank 0 needs.  The flag has to be set before the HIP context of the device exists.
         try:
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so")
@@ -595,15 +766,14 @@ def main():
             pass
     torch.cuda.set_device(local_rank)
     dist = None
-    # PANACUS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL all-reduce on the device
-    # counters) with a single rank, so it can be exercised on a 1-GPU box
-    use_dist = world > 1 or os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
+    # PANACUS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL all-reduce on the device counters) with a single rank, so
+    # it can be exercised on a 1-GPU box
+    use_dist = world > 1 or force_dist
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from panacus_amd import capi, hostlib
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
@@ -612,314 +782,82 @@ def main():
     pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]  # -l 1,2,1 -q 0,0,0.5
     thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
 
-    def make_context(owner=None):
-        c = capi.Context(local_rank)
-        c.config(capi.CFG_TILE_BLOCKS, args.tile_blocks)
-        c.config(capi.CFG_CACHE_INDEX, 0)
-        c.config(capi.CFG_MAX_IN_FLIGHT, max(1, min(4, args.depth)))
-        if blocking:
-            c.config(capi.CFG_BLOCKING_SYNC, 1)
-        if args.no_overlap:
-            c.config(capi.CFG_OVERLAP_PHASES, 0)
-        if args.index_coarse is not None:
-            c.config(capi.CFG_INDEX_COARSE, args.index_coarse)
-        if args.cover_waves is not None:
-            c.config(capi.CFG_COVER_WAVES, args.cover_waves)
-        if args.cover_split is not None:
-            c.config(capi.CFG_COVER_SPLIT, args.cover_split)
-        if args.cover_variant is not None:
-            c.config(capi.CFG_COVER_VARIANT, args.cover_variant)
-        if args.rows_layout is not None:
-            c.config(capi.CFG_ROWS_LAYOUT, args.rows_layout)
-        if owner is None:
-            c.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
-        else:
-            c.share_csr(owner)  # the same ItemTable in HBM, no copy
-        order = np.arange(P, dtype=np.uint32)
-        c.set_order(order, order, P)
-        return c
-
-    class Lane:
-        """One context = one stream with two passes in flight.  Two lanes over the same resident
-        graph alternate their passes, so that the short latency-bound kernels of one lane's pass
-        (tile index, histogram, the result copy) run beside the coverage kernel of the other's."""
-
-        def __init__(self, ctx, group):
-            self.ctx = ctx
-            self.group = group
-            self.hist_views = {}
-            self.pending = []  # closed forms enqueued behind the passes in flight (None: the host starts them when it has the histogram)
-            self.native = use_dist and args.collective == "native"
-            if self.native:
-                # the library reduces flags + histogram behind every pass by itself (pnx_comm_init): the lane
-                # is then the plain single-GPU pipeline
-                uid = [type(ctx).comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init(uid[0], rank, world)
-            elif use_dist:
-                # the per-shard counters are summed with an RCCL all-reduce that is ENQUEUED behind the
-                # pass on the library's own stream (a collective on another stream would have to wait
-                # for free CUs until the next pass's coverage kernel -- one resident wave per tile -- ends)
-                self.ext = {}  # torch views of the library's streams
-                self.ring = [{"tmp": torch.zeros(P + 1, dtype=torch.int64, device=f"cuda:{local_rank}"),
-                              "host": torch.zeros(P + 1, dtype=torch.int64).pin_memory(),
-                              "ev": torch.cuda.Event(blocking=blocking), "reruns": 0} for _ in range(depth)]
-                self.enq = self.fin = 0
-
-        def enqueue(self):
-            ctx = self.ctx
-            ctx.hist_async()
-            if growth_on_device and self.ctx is all_lanes[0].ctx and (not use_dist or self.native):
-                # the closed forms follow the pass on the device, from its own (all-reduced) counters
-                self.pending.append(hostlib.calc_growths_begin_on_device(P, thr))
-            else:
-                self.pending.append(None)
-            if use_dist and not self.native:
-                # the collective follows the counters on the stream of the pass's histogram phase: the coverage
-                # kernel of the next pass is not held back
-                d_hist, st = ctx.hist_enqueued_on()
-                ext = self.ext.get(st)
-                if ext is None:
-                    ext = self.ext[st] = torch.cuda.ExternalStream(st, device=f"cuda:{local_rank}")
-                t = self.hist_views.get(d_hist)
-                if t is None:
-                    t = self.hist_views[d_hist] = torch.as_tensor(_DevArray(d_hist, P + 1), device=f"cuda:{local_rank}")
-                slot = self.ring[self.enq % depth]
-                self.enq += 1
-                with torch.cuda.stream(ext):
-                    slot["tmp"].copy_(t)
-                    dist.all_reduce(slot["tmp"], group=self.group)  # RCCL, int64 sum == uint64 sum for counts < 2^63
-                    slot["host"].copy_(slot["tmp"], non_blocking=True)
-                    slot["ev"].record(ext)
-                slot["reruns"] = int(ctx.info().n_reruns)
-
-        def settle(self):
-            """wait for the OLDEST enqueued pass of this lane; multi-GPU: its all-reduced counters"""
-            ctx = self.ctx
-            if use_dist and not self.native:
-                slot = self.ring[self.fin % depth]
-                self.fin += 1
-                slot["ev"].synchronize()
-                ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
-                if int(ctx.info().n_reruns) != slot["reruns"]:
-                    # A pass that fails its verification is run again by the library, and its reduced
-                    # counters would be stale.  It cannot happen here (pansyn paths are tile-monotone);
-                    # a host for arbitrary graphs settles the first pass before it pipelines.  Failing
-                    # is better than an unmatched collective.
-                    raise RuntimeError("a coverage pass was re-run inside the pipelined multi-GPU loop")
-                return slot["host"].numpy().view(np.uint64).copy()
-            _, h = ctx.hist_fetch(want_countable=False)
-            return h
-
-        def close(self):
-            if self.native:
-                self.ctx.comm_free()
-            elif use_dist:
-                # torch objects that were used on the library's stream (pinned buffers record it when
-                # they are freed) must go before the stream does
-                self.ring.clear()
-                self.hist_views.clear()
-                self.ext.clear()
-
-    n_lanes = max(1, args.lanes)
-    depth = max(1, min(4, args.depth))
-    ctx = make_context()
-    growth_on_device = False  # set below, once the offload context is known
-    all_lanes = lanes = []
-    lanes.append(Lane(ctx, None))
-    for _ in range(1, n_lanes):
-        # every lane has its own communicator: its collectives are ordered on its own stream
-        lanes.append(Lane(make_context(ctx), dist.new_group() if use_dist else None))
+    ctx = capi.Context(local_rank)
+    if blocking:
+        ctx.config(capi.CFG_BLOCKING_SYNC, 1)
+    if args.cover_route is not None:
+        ctx.config(capi.CFG_COVER_ROUTE, args.cover_route)
+    ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
     S = int(ctx.info().n_steps)
     try:
         n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
         clock_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6
+        arch = getattr(torch.cuda.get_device_properties(local_rank), "gcnArchName", "")
     except Exception:
-        n_cus, clock_ghz = 256, 2.4
-    # ---- the cold path of an upload, measured before anything else is resident: steps -> path rows, and the first histogram
-    cold = None
-    if not args.no_cold:
-        ctx.hist(want_countable=False)  # allocations, code objects
-        cold = cold_numbers(ctx, np.arange(P, dtype=np.uint32), P)
-    else:
-        ctx.prepare()
-    info = ctx.info()
-    rows_in_order = int(info.n_rows_in_order)
+        n_cus, clock_ghz, arch = 256, 2.4, ""
 
-    # large group counts: the O(n^3) inner sums of the quorum closed form run on the GPU
-    # (bit-identical, see csrc/kernels_closed_form.hip); below 512 groups the host is faster
-    if rank == 0 and not args.no_quorum_offload:
+    # from 256 groups on the closed forms run on the GPU, from the histogram to the curve (bit-identical, csrc/kernels_closed_form.hip)
+    growth_on_device = False
+    if rank == 0:
         hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
-        growth_on_device = P >= args.quorum_offload_min_n and P <= 2048 and hostlib.device_growth_usable()
+        growth_on_device = args.quorum_offload_min_n <= P <= 2048 and hostlib.device_growth_usable()
+        if args.quorum_offload_min_n <= P <= 2048 and not growth_on_device and not args.allow_host_closed_forms:
+            raise SystemExit("bench: the device closed forms are not usable on this box (the restated log2 / exp2 do not reproduce its libm "
+                             "bit for bit), so every step would wait for the host threads -- refusing to report that as the MI355X number "
+                             "(--allow-host-closed-forms to measure it anyway)")
 
-    if growth_on_device and cold is not None:
-        # first closed-form call of a context: the (n, thresholds) tables are derived (log2 table, running sums, perc_mult,
-        # the quorum pair's inner sums), then the evaluation; calls that find the tables are the evaluation alone
-        _, h0 = ctx.hist(want_countable=False)
-        first, later = [], []
-        for _ in range(3):
-            ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)
-            for acc in (first, later):
-                g0 = time.perf_counter()
-                hostlib.calc_growths_end(hostlib.calc_growths_begin(h0, thr, args.growth_threads))
-                acc.append((time.perf_counter() - g0) * 1e3)
-        cold["growth_tables_ms"] = min(first)
-        cold["growth_call_ms"] = min(later)
-
-    def growth_begin(h):
-        """rank 0: set the closed forms up and enqueue their device part (if any) behind the pass
-        that is running"""
-        return hostlib.calc_growths_begin(h, thr, args.growth_threads) if rank == 0 else None
-
-    def growth_end(pending):
-        return hostlib.calc_growths_end(pending) if rank == 0 else None
-
-    def run(n_steps, lanes=None):
-        """n_steps complete histgrowth passes, dealt round-robin to the lanes.  Consecutive passes
-        are independent; every lane keeps two of its own in flight: while the host evaluates the
-        closed forms of pass k, later passes run and the next one of that lane is already enqueued
-        behind them.  Every pass is finished inside the call."""
-        h = growths = None
-        lanes = all_lanes if lanes is None else lanes
-        L = len(lanes)
-        enqueued = 0
-        for _ in range(min(n_steps, depth * L)):
-            lanes[enqueued % L].enqueue()
-            enqueued += 1
-        late = None  # the closed forms of the previous pass: collected one pass late, when they are long done
-        for k in range(n_steps):
-            h = lanes[k % L].settle()
-            on_device = lanes[k % L].pending.pop(0)
-            pending = on_device or growth_begin(h)
-            if enqueued < n_steps:
-                lanes[enqueued % L].enqueue()
-                enqueued += 1
-            if on_device is None:  # host threads (+ one quorum offload at a time): finished here
-                growths = growth_end(pending)
-                continue
-            if late is not None:
-                growths = growth_end(late)
-            late = pending
-        if late is not None:
-            growths = growth_end(late)
-        return h, growths
+    stepper = OneShot(ctx, P, thr, rank=rank, world=world, use_dist=use_dist, dist=dist, torch=torch, local_rank=local_rank,
+                      collective=args.collective, blocking=blocking, growth_on_device=growth_on_device, growth_threads=args.growth_threads)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        for ln in lanes:
-            ln.ctx.sync()
+        ctx.sync()
 
-    if args.warmup:
-        run(args.warmup)
-    barrier()
-    # timed region: HIP events (on the context's stream) around the dominant kernel only; the
-    # other kernels are timed in a short untimed tail so that their event records do not sit
-    # between the kernels of the measured passes
-    # (every 8th launch: two event records around EVERY coverage kernel keep the stream from running the kernels back to back --
-    # 0.185 against 0.140 ms per step measured)
-    sample_every = max(1, min(8, args.steps // 4))
-    for ln in lanes:
-        ln.ctx.profile_enable(True)
-        ln.ctx.profile_select([capi.K_COVER])
-        ln.ctx.profile_sample(sample_every)
-        ln.ctx.profile_reset()
-    t0 = time.perf_counter()
-    h, growths = run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = {"cover": (0.0, 0)}
-    for ln in lanes:  # the coverage kernel of every lane, as it ran beside the other lanes' short kernels
-        ms, cnt = ln.ctx.profile_read()["cover"]
-        prof["cover"] = (prof["cover"][0] + ms, prof["cover"][1] + cnt)
-        ln.ctx.profile_select(None)
-        ln.ctx.profile_sample(1)
-        ln.ctx.profile_reset()
-        if ln.ctx is not ctx:
-            ln.ctx.profile_enable(False)
-    ctx.config(capi.CFG_OVERLAP_PHASES, 0)
-    run(5, lanes[:1])  # every kernel on its own: one lane, the three phases of a pass on one stream
-    barrier()
-    prof_tail = ctx.profile_read()
-    ctx.profile_enable(False)
-    ctx.config(capi.CFG_OVERLAP_PHASES, 0 if args.no_overlap else 1)
+    sample_every = max(1, min(4, args.steps // 4))
+    dt, h, growths, prof = timed_steps(stepper, args.steps, args.warmup, barrier, sample_every)
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # latency of one un-pipelined pass (device + fetch + closed form), for the record
-    barrier()
-    l0 = time.perf_counter()
-    for _ in range(3):
-        run(1)
-    barrier()
-    latency_ms = (time.perf_counter() - l0) / 3 * 1e3
-
-    # host-side share of a step (closed-form growth), measured separately on rank 0
-    growth_ms = None
+    out = None
     if rank == 0:
-        g0 = time.perf_counter()
-        for _ in range(3):
-            hostlib.calc_growths(h, thr, args.growth_threads)
-        growth_ms = (time.perf_counter() - g0) / 3 * 1e3
-
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * N * P / (dt / args.steps) / 1e6
-        cover_ms, cover_n = prof["cover"]
-        index_ms, index_n = prof_tail["scatter"]   # k_rows_order: the rows of the ordered paths in visiting order
-        hist_ms, hist_n = prof_tail["hist"]
-        cover_avg_ms = cover_ms / max(cover_n, 1)
-        B = algorithmic_bytes_hist(S, P, N, P)
-        B_moved = moved_bytes_hist(rows_in_order, N, P)
-        achieved_alg = B / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
-        achieved = B_moved / (cover_avg_ms * 1e-3) / 1e9 if cover_avg_ms > 0 else 0.0
-        cover_alone_ms = prof_tail["cover"][0] / max(prof_tail["cover"][1], 1)
-        device_ms = cover_alone_ms + index_ms / max(index_n, 1) + hist_ms / max(hist_n, 1)
-        if cold is not None:
-            # a pass that kept nothing would read the steps every time; the cheapest full read of the steps measured here is the
-            # derivation itself, so: prepare + k * step <= k * prepare  <=>  k >= prepare / (prepare - step)
-            cold["value_cold_first_pass"] = world * N * P / (cold["cold_first_pass_ms"] * 1e-3) / 1e6
-            cold["frac_algorithmic_cold_first_pass"] = B / (cold["cold_first_pass_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            cold["frac_algorithmic_prepare"] = 4 * S / (cold["prepare_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            cold["passes_to_break_even"] = (int(np.ceil(cold["prepare_ms"] / (cold["prepare_ms"] - ms_per_step)))
-                                            if cold["prepare_ms"] > ms_per_step else None)
-            cold["note"] = ("prepare_ms: the u32 steps resident in HBM -> path rows (one read of the steps, ids validated on the way), "
-                            "synchronous; cold_first_pass_ms: pnx_hist on a graph whose derived data were dropped = prepare + one pass + "
-                            "the histogram on the host; frac_algorithmic_*: SURVEY 8(d)'s algorithmic bytes over those times -- the read "
-                            "of the steps is priced HERE, not in `roofline`; passes_to_break_even: against re-reading the steps in "
-                            "every pass, taking the derivation itself as the cheapest full read of the steps")
-        # counters of the dominant kernel (and of the kernel that derives the rows), measured by child runs under rocprofv3
-        traffic = traffic_src = None
+        ms_per_step, B, cover_ms, roofline, breakdown = step_report(ctx, N, P, S, dt, args.steps, prof, world)
+        roofline["launches_timed"] = f"every {sample_every}th of the {args.steps} launches of the timed region"
+        value = world * N * P / (ms_per_step * 1e-3) / 1e6
+        cf = closed_form_costs(ctx, h, thr, args.growth_threads) if growth_on_device else None
+        # counters of the kernel that reads the steps, measured by child runs under rocprofv3
         valu = None
-        cold_traffic = None
         if world == 1 and not args.no_pmc and os.environ.get("PANACUS_BENCH_CHILD") != "1":
             child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--nodes", str(N), "--paths", str(P), "--seed", str(args.seed),
-                     "--no-permuted-growth", "--no-shape-1k", "--no-cpu-baseline", "--no-pmc"]
-            for flag, val in (("--cover-split", args.cover_split), ("--rows-layout", args.rows_layout), ("--cover-variant", args.cover_variant)):
-                if val is not None:
-                    child += [flag, str(val)]
-            pm, traffic_src = pmc_leg(child, ["k_rows_cover", "k_rows_build<false>"], [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"]])
-            kc = pm.get("k_rows_cover", {})
+                     "--headline-only"]
+            if args.cover_route is not None:
+                child += ["--cover-route", str(args.cover_route)]
+            if args.allow_host_closed_forms:
+                child += ["--allow-host-closed-forms"]
+            one_shot = roofline["kernel"] == "k_band_cover"
+            names = ["k_band_cover", "k_band_index"] if one_shot else ["k_rows_build<false>", "k_rows_cover"]
+            pm, src = pmc_leg(child, names, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"]])
+            roofline["traffic_source"] = src
+            kc = pm.get(names[0], {})
             if "FETCH_SIZE" in kc and "WRITE_SIZE" in kc:
-                traffic = (2.0 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024.0
-            if "SQ_INSTS_VALU" in kc:
+                roofline["traffic"] = (2.0 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024.0
+            ki = pm.get(names[1], {})
+            if "FETCH_SIZE" in ki and "WRITE_SIZE" in ki:
+                roofline["traffic_" + ("band_index" if one_shot else "rows_cover")] = (2.0 * ki["FETCH_SIZE"] + ki["WRITE_SIZE"]) * 1024.0
+            if "SQ_INSTS_VALU" in kc and cover_ms:
                 # a wave64 vector instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md): peak = CUs x 4 SIMDs x clock / 2
                 peak_wi = n_cus * 4 * clock_ghz * 1e9 / 2.0
                 wi = kc["SQ_INSTS_VALU"]
-                valu = {"bound": "valu", "kernel": "k_rows_cover", "wave_instructions_per_launch": wi,
-                        "achieved": wi / (cover_avg_ms * 1e-3), "peak": peak_wi, "unit": "wave64 VALU instr/s", "frac": wi / (cover_avg_ms * 1e-3) / peak_wi,
+                valu = {"bound": "valu", "kernel": names[0], "wave_instructions_per_launch": wi,
+                        "achieved": wi / (cover_ms * 1e-3), "peak": peak_wi, "unit": "wave64 VALU instr/s", "frac": wi / (cover_ms * 1e-3) / peak_wi,
                         "scalar_instructions_per_launch": kc.get("SQ_INSTS_SALU"), "lds_instructions_per_launch": kc.get("SQ_INSTS_LDS"),
-                        "per_row": wi * 64 / max(rows_in_order, 1) / 64, "compute_units": n_cus, "clock_ghz": clock_ghz}
-            kb = pm.get("k_rows_build<false>", {})
-            if "FETCH_SIZE" in kb and "WRITE_SIZE" in kb:
-                cold_traffic = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
-                if cold is not None:
-                    cold["build_kernel_traffic_bytes"] = cold_traffic
-                    cold["build_kernel_valu_wave_instructions"] = kb.get("SQ_INSTS_VALU")
-                    cold["build_kernel_lds_instructions"] = kb.get("SQ_INSTS_LDS")
+                        "lds_bank_conflict_cycles_per_launch": kc.get("SQ_LDS_BANK_CONFLICT"),
+                        "vector_instructions_per_step": wi * 64 / S, "compute_units": n_cus, "clock_ghz": clock_ghz}
         out = {
             "metric": "histgrowth_throughput",
             "value": value,
@@ -935,50 +873,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 synthetic, "
-                            f"{N} nodes x {P} paths per GPU (BASELINE.json configs[2])",
+                            f"{N} nodes x {P} paths per GPU (BASELINE.json configs[2]); one step = one complete call from the resident u32 "
+                            f"ItemTable, every derived table dropped between steps",
                 "nodes_per_gpu": N, "paths": P, "groups": P, "steps_in_csr": S, "seed": args.seed,
-                "threshold_pairs": pairs, "tile_items": int(info.tile_items),
+                "threshold_pairs": pairs,
                 "parallelism": "node-range shards, RCCL all-reduce of hist counters" if world > 1 else "single GPU",
                 "collective": args.collective if use_dist else None,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_rows_cover",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "moved_bytes_per_launch": B_moved,
-                "avg_launch_ms": cover_avg_ms,
-                "launches": cover_n,
-                "launches_timed": f"every {sample_every}th of the {args.steps} launches of the timed region",
-                "algorithmic_bytes_per_launch": B,
-                "achieved_algorithmic": achieved_alg,
-                "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
-                "avg_launch_ms_alone": cover_alone_ms,
-                "note": ROOFLINE_NOTE + "; avg_launch_ms is measured over the timed steps, where the order layout of the next pass and "
-                        "the histogram of the previous one run beside the kernel on their own streams; avg_launch_ms_alone is the same "
-                        "kernel with the phases on one stream (5 extra passes)",
-            },
+            "roofline": roofline,
             "roofline_valu": valu,
-            "cold": cold,
-            "breakdown_ms": {
-                "rows_order": index_ms / max(index_n, 1), "rows_cover": cover_alone_ms,
-                "hist": hist_ms / max(hist_n, 1), "device_total": device_ms,
-                "rows_cover_beside_the_other_phases": cover_avg_ms,
-                "lanes": len(lanes), "passes_in_flight": depth,
-                "host_closed_form_growth": growth_ms, "host_threads": hostlib.pool_threads(), "host_usable_cpus": hostlib.usable_cpus(),
-                "quorum_inner_sums_on_gpu": bool(not args.no_quorum_offload and P >= args.quorum_offload_min_n
-                                                 and hostlib.quorum_offload_usable()),
-                "closed_forms_on_gpu": bool(growth_on_device),
-                "single_pass_latency": latency_ms,
-            },
-            "hbm_gbs_whole_step_moved_bytes": B_moved / (ms_per_step * 1e-3) / 1e9,
-            "hbm_gbs_whole_step_algorithmic": B / (ms_per_step * 1e-3) / 1e9,
+            "step_breakdown_ms": breakdown,
+            "closed_forms": cf,
+            "closed_forms_on_gpu": bool(growth_on_device),
+            "host": {"threads": hostlib.pool_threads(), "usable_cpus": hostlib.usable_cpus(), "gpu_arch": arch},
             "checks": {"hist_sum": int(h.sum()), "expected_hist_sum": world * N,
-                       "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
+                       "growth_last_floor": [int(np.floor(g[-1])) for g in growths],
+                       "one_shot_route_held": roofline["kernel"] == "k_band_cover"},
         }
     # a wrong histogram must not produce a valid-looking line: every rank leaves together
     ok = 1 if (rank != 0 or int(h.sum()) == world * N) else 0
@@ -988,10 +898,21 @@ def main():
         ok = int(okt.item())
     if not ok:
         raise SystemExit(f"bench: the histogram does not sum to the number of items ({world * N})")
+    # peak cross-check of the line itself: the algorithmic bytes of a step over its time cannot beat the memory
+    if rank == 0 and world == 1 and out["roofline"]["whole_step"]["frac"] > 1.0:
+        raise SystemExit("bench: algorithmic bytes / ms_per_step exceeds the HBM peak -- the timed step cannot be reading the steps")
+
+    stepper.close()
+    if rank == 0 and world == 1 and not args.headline_only:
+        out["hist_only"] = hist_only_block(ctx, N, P, S, 20)
+    # ---- what a second sweep of the same graph costs (NOT the headline) ----
+    if rank == 0 and world == 1 and not args.no_resident:
+        out["resident_pass"] = resident_pass_block(ctx, P, thr, growth_on_device, args.growth_threads, args.resident_steps,
+                                                   max(1, min(4, args.depth)))
+
     def run_cpu_baseline():
-        """the oracle on the same workload (rank 0, one GPU only), AFTER the other timed blocks: its three busy threads and
-        the 16 GB of host arrays it allocates left the process slower for the closed forms of the 10 M x 1 k block
-        (3.5 against 2.6 ms per step when it ran first)"""
+        """the oracle on the same workload (rank 0, one GPU only), AFTER the other timed blocks: its busy threads and the
+        16 GB of host arrays it allocates slow the process down for whatever is timed beside them"""
         try:
             cb, h_cpu, g_cpu = cpu_baseline(ctx, N, P, pairs, args.seed, passes=args.cpu_passes,
                                             sample_nodes=args.cpu_sample_nodes or None)
@@ -1007,15 +928,12 @@ def main():
         except Exception as e:  # the oracle is optional test infrastructure
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
-    def close_lanes():
-        for ln in lanes:
-            ln.close()
+    def close_ctx():
         hostlib.set_quorum_offload(None)
-        for ln in reversed(lanes):  # borrowers of the resident graph before its owner
-            ln.ctx.close()
+        ctx.close()
 
     if use_dist:
-        close_lanes()
+        close_ctx()
     else:
         hostlib.set_quorum_offload(None)
     # ---- BASELINE.json configs[3]: permuted growth, strong scaling (every rank takes part) ----
@@ -1024,12 +942,12 @@ def main():
         if rank == 0:
             out["permuted_growth"] = pg
     # ---- north_star's 10M x 1k shape (one GPU) ----
-    if world == 1 and not args.no_shape_1k:
+    if world == 1 and not use_dist and not args.no_shape_1k:
         out["shape_10Mx1k"] = shape_1k_block(args, local_rank)
     if not use_dist:
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             run_cpu_baseline()
-        close_lanes()
+        close_ctx()
     if use_dist:
         torch.cuda.synchronize()
         dist.destroy_process_group()

@@ -575,7 +575,13 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n) {
 }
 
 // The growth tables of (n, pairs): built on stream_cf when a call comes with arguments other than the kept ones.
-static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel) {
+// after: an event the table kernels wait for (or nullptr).  Beside a one-shot coverage pass (kernels_band.hip) that is the end of
+// its index kernel: every workgroup of the coverage kernel lives as long as the kernel, so one that finds its CU taken by a
+// table kernel that started first runs AFTER the others -- the pass then takes up to twice as long (10 M x 1 k paths: 2.45 ->
+// 3.67 ms with the tables of n = 1024 started first, measured).  Started behind the index, the table kernels find the coverage
+// kernel already resident and take the wave slots and the LDS it leaves.
+static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel,
+                                hipEvent_t after = nullptr) {
     pnx_ctx::GrowthTables &g = ctx->gtab;
     bool same = g.valid && g.n == n && g.T == n_pairs;
     for (uint32_t t = 0; same && t < n_pairs; ++t)
@@ -608,6 +614,7 @@ static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, cons
         h_cov[t] = g.cov[t] = cov_abs[t];
     }
     PNX_HIP(ctx, hipMemcpyAsync(g.d_par.p, h, par_bytes, hipMemcpyHostToDevice, st));
+    if (after) PNX_HIP(ctx, hipStreamWaitEvent(st, after, 0));
     const double *d_q = (const double *)g.d_par.p;
     const uint32_t *d_br = (const uint32_t *)((const char *)g.d_par.p + T * 8), *d_cov = d_br + T;
     const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
@@ -660,7 +667,7 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
         src = &ctx->tk[ctx->tk_last()];
     }
     int rc;
-    if ((rc = ensure_growth_tables(ctx, n, n_pairs, branch, cov_abs, quorum_rel))) return rc;
+    if ((rc = ensure_growth_tables(ctx, n, n_pairs, branch, cov_abs, quorum_rel, src && src->band ? src->ev_pre : nullptr))) return rc;
     const pnx_ctx::GrowthTables &tab = ctx->gtab;
     const size_t np1 = (size_t)n + 1, T = n_pairs;
     if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;

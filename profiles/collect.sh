@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 db() { find "$1" -name '*.db' | head -1; }
-HEAD_ONLY="--no-cpu-baseline --no-permuted-growth --no-shape-1k"
+HEAD_ONLY="--headline-only"
 
 # 1. the driver-contract line: headline (cfg3) + permuted_growth (cfg4) + shape_10Mx1k + cpu_baseline
 timeout 900 python $REPO/bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err

@@ -1103,8 +1103,8 @@ def test_two_contexts_share_one_resident_graph():
 
 def test_bench_contract_line_small(tmp_path):
     """bench.py end to end on small shapes: one JSON line with the contract's fields plus the
-    permuted_growth / shape_10Mx1k / cpu_baseline blocks; one and two lanes (contexts sharing the
-    resident graph) and the forced single-rank RCCL path agree on the checks"""
+    permuted_growth / shape_10Mx1k / cpu_baseline blocks; the one-shot route (forced: the small shape would take the
+    rows), the default choice, the forced single-rank RCCL path with either carrier -- all agree on the checks"""
     import json
     import os
     import socket
@@ -1114,12 +1114,12 @@ def test_bench_contract_line_small(tmp_path):
     outs, pgs = [], []
     small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--cpu-passes", "1",
              "--pg-nodes", "150000", "--pg-paths", "40", "--pg-orders", "10", "--pg-reps", "2",
-             "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4"]
+             "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4", "--resident-steps", "8"]
     # FORCE_DIST without RANK / WORLD_SIZE in the environment: bench.py launches its rank(s) itself (the --gpus N path)
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    for extra, env in ((["--lanes", "1"], {}), (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {}),
-                       (["--lanes", "2", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {"PANACUS_BENCH_FORCE_DIST": "1"}),
-                       (["--lanes", "1", "--no-cpu-baseline", "--no-shape-1k", "--no-pmc", "--collective", "native"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
+    for extra, env in ((["--cover-route", "1"], {}), (["--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {}),
+                       (["--no-cpu-baseline", "--no-shape-1k", "--no-pmc", "--cover-route", "1"], {"PANACUS_BENCH_FORCE_DIST": "1"}),
+                       (["--no-cpu-baseline", "--no-shape-1k", "--no-pmc", "--collective", "native"], {"PANACUS_BENCH_FORCE_DIST": "1"})):
         sock = socket.socket()
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -1136,14 +1136,24 @@ def test_bench_contract_line_small(tmp_path):
             assert k in d, k
         assert d["steps"] == 12 and d["n_gpus"] == 1 and d["roofline"]["launches"] == 4   # every 3rd of 12 launches is timed
         assert d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 200000
-        rf, cold = d["roofline"], d["cold"]
-        assert rf["kernel"] == "k_rows_cover" and 0 < rf["frac"] < 1 and rf["moved_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
-        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["frac_algorithmic"] > rf["frac"]
-        assert cold["prepare_ms"] > 0 and cold["cold_first_pass_ms"] > cold["prepare_ms"] and cold["rows"] > 0
+        rf = d["roofline"]
+        one_shot = "--cover-route" in extra
+        assert d["checks"]["one_shot_route_held"] is one_shot and rf["kernel"] == ("k_band_cover" if one_shot else "k_rows_build + k_rows_cover")
+        # the line's own peak cross-check: algorithmic bytes over the step, and over the kernel that reads the steps, stay below the memory's peak
+        assert 0 < rf["whole_step"]["frac"] < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+        assert abs(rf["whole_step"]["achieved"] - rf["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6
+        assert abs(d["value"] - 200000 * 64 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+        br = d["step_breakdown_ms"]
+        assert br["band_cover"] > 0 and br["kernels_of_the_pass"] < d["ms_per_step"]
         if "--no-pmc" not in extra:   # the counter passes are driven by the run itself; on a box without rocprofv3 the line says why
             assert (rf["traffic"] is not None and rf["traffic"] > 0 and d["roofline_valu"]["frac"] > 0) or "rocprofv3" in rf["traffic_source"], rf["traffic_source"]
         else:
             assert rf["traffic"] is None and d["roofline_valu"] is None
+        if not env:
+            ho, rp = d["hist_only"], d["resident_pass"]
+            assert ho["ms_per_call"] > 0 and ho["kernels_ms"]["band_cover"] > 0
+            assert rp["ms_per_pass"] > 0 and rp["rows"] > 0 and rp["rows_route"]["cold_first_pass_ms"] > rp["rows_route"]["prepare_ms"] > 0
+            assert rp["hist_sum"] == 200000
         pg = d["permuted_growth"]
         for k in ("seconds_per_call", "orders_per_s", "speedup_vs_1", "growth_kernel_ms_rank_max", "allreduce_ms",
                   "presence_pack_ms", "scaling", "sharding", "n_gpus"):
@@ -1157,9 +1167,12 @@ def test_bench_contract_line_small(tmp_path):
         if "--no-cpu-baseline" not in extra:
             cb, k1 = d["cpu_baseline"], d["shape_10Mx1k"]
             assert cb["agrees_with_gpu"] is True and cb["kind"] == "port" and cb["cores"] == 3 and cb["value"] > 0
-            assert k1["checks"]["hist_sum"] == 150000 and k1["breakdown_ms"]["rows_cover"] > 0 and k1["cold"]["prepare_ms"] > 0
+            assert k1["checks"]["hist_sum"] == 150000 and k1["step_breakdown_ms"]["band_cover"] > 0 and k1["hist_only"]["ms_per_call"] > 0
+            assert 0 < k1["roofline"]["whole_step"]["frac"] < k1["roofline"]["frac"] < 1
         outs.append(d["checks"])
         pgs.append(pg["checks"])
+    for o in outs:
+        o.pop("one_shot_route_held")
     assert outs[0] == outs[1] == outs[2] == outs[3]
     assert pgs[0] == pgs[1] == pgs[2] == pgs[3]
     # more ranks than devices: a clear failure, not a silent single-GPU run
