@@ -1,0 +1,60 @@
+"""What a graph with ONE path that is not sorted costs on its first sweep: the one-shot route is tried (its index meets steps
+out of order, or its coverage kernel a step outside its band), the pass is void, the path rows take over.
+
+  python benchmarks/bench_band_fallback.py [--nodes 6000000] [--paths 16]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as orc  # noqa: E402  (the CPU generator only: the graph has to be edited on the host)
+from panacus_amd import capi  # noqa: E402
+
+
+def first_hist_ms(ctx, items32, pre, n, order, route, reps=3):
+    ts = []
+    for _ in range(reps):
+        ctx.config(capi.CFG_COVER_ROUTE, route)
+        ctx.set_csr(items32, pre, n)
+        ctx.set_order(order, order, len(order))
+        t0 = time.perf_counter()
+        cnt, h = ctx.hist(want_countable=False)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2], h, int(ctx.info().n_reruns)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nodes", type=int, default=6_000_000)
+    ap.add_argument("--paths", type=int, default=16)
+    args = ap.parse_args()
+    n, p = args.nodes, args.paths
+    items, pre, _ = orc.pansyn(3, n, p)
+    order = np.arange(p, dtype=np.uint32)
+    out = {"nodes": n, "paths": p, "steps": int(len(items))}
+    rng = np.random.default_rng(1)
+    variants = {"sorted": items.astype(np.uint32)}
+    a, b = int(pre[3]), int(pre[4])
+    sh = items.astype(np.uint32)
+    sh[a:b] = rng.permutation(sh[a:b])
+    variants["one_path_shuffled"] = sh
+    sw = items.astype(np.uint32)
+    m = (a + b) // 2
+    sw[m], sw[m + 40_000] = sw[m + 40_000], sw[m]
+    variants["two_steps_swapped_across_bands"] = sw
+    with capi.Context(0) as ctx:
+        for name, it in variants.items():
+            auto_ms, h_auto, reruns = first_hist_ms(ctx, it, pre, n, order, 0)
+            rows_ms, h_rows, _ = first_hist_ms(ctx, it, pre, n, order, 2)
+            out[name] = {"first_hist_ms_auto_route": round(auto_ms, 3), "first_hist_ms_rows_route": round(rows_ms, 3),
+                         "same_hist": bool(np.array_equal(h_auto, h_rows)), "reruns_total": reruns}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

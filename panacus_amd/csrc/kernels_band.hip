@@ -30,6 +30,7 @@
 namespace pnx {
 
 constexpr int BAND_CW = 4;                  // waves per workgroup = item tiles per band
+constexpr uint64_t BAND_UNSORTED = 1ull << 62;  // index entry: a probe of the search met steps out of order -- the path is not sorted
 constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs through the ids downwards
 
 // first j in [0, len] with key(j) >= X, key = id (ascending path) or ~id (descending); keys are non-decreasing on a
@@ -42,7 +43,7 @@ constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs throug
 // interpolation + binary search (0.058 -> 0.03 ms on 10 M items x 256 paths).
 template <bool DESC>
 __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ items, uint64_t ps, uint64_t len, uint32_t X, uint32_t ka,
-                                                   uint32_t kz) {
+                                                   uint32_t kz, bool &unsorted) {
     if (ka >= X) return 0;
     if (kz < X) return len;
     uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
@@ -60,13 +61,15 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
         // steps of the sector that belong to the path and lie inside the bracket: [i0, i1]
         const uint64_t first = ps + lo + 1, last = ps + hi - 1;  // absolute; first <= ps + g <= last
         const uint32_t i0 = first > a0 ? (uint32_t)(first - a0) : 0u, i1 = last - a0 < 15 ? (uint32_t)(last - a0) : 15u;
-        uint32_t below = 0, k_first = 0, k_last = 0;
+        uint32_t below = 0, k_first = 0, k_last = 0, prev = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i) {
             const uint32_t key = DESC ? ~w[i] : w[i];
             if (i == i0) k_first = key;
             if (i == i1) k_last = key;
             below += (i >= i0 && i <= i1 && key < X) ? 1u : 0u;
+            unsorted |= i > i0 && i <= i1 && key < prev;  // the sector in hand says the path is not sorted: no need to read it all to find out
+            prev = key;
         }
         const uint32_t n = i1 - i0 + 1;
         if (below != 0 && below != n) return a0 + i0 + below - ps;  // the crossing lies in the sector
@@ -107,13 +110,14 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     const uint32_t a = items[ps], z = items[pe - 1];
     const bool desc = a > z;
     uint64_t j;
+    bool unsorted = false;
     if (e == 0) j = desc ? len : 0;
     else if (e == n_bands) j = desc ? 0 : len;
     else {
         const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ~a, ~z) : band_edge_search<false>(items, ps, len, x, a, z);
+        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ~a, ~z, unsorted) : band_edge_search<false>(items, ps, len, x, a, z, unsorted);
     }
-    bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
+    bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull) | (unsorted ? BAND_UNSORTED : 0ull);
 }
 
 // The coverage kernel.  flags[5] |= 1 when a step was found outside the band it was dealt to (or an index entry is
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     TileCounters<NPL> tc;
     uint32_t acc = 0, cur_g = NONE;
-    bool bad = false;
+    bool bad = false, dead = false;
     auto flush = [&](uint32_t g) {
         const uint32_t x = acc & ~excl;
         acc = 0;
@@ -174,8 +178,11 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         }
         const bool desc = (a & BAND_DESC) != 0;
         if (((a ^ b) & BAND_DESC) != 0) bad = true;
-        a &= ~BAND_DESC;
-        b &= ~BAND_DESC;
+        // the index already knows of a path that is not sorted: the pass is void, and this workgroup stops reading (every wave
+        // of the workgroup loads the same window and leaves after the same fold)
+        if (__ballot(((a | b) & BAND_UNSORTED) != 0)) bad = dead = true;
+        a &= ~(BAND_DESC | BAND_UNSORTED);
+        b &= ~(BAND_DESC | BAND_UNSORTED);
         uint64_t lo = desc ? b : a, hi = desc ? a : b;
         if (hi < lo) {  // the searches of a path that is not sorted
             bad = true;
@@ -298,11 +305,13 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         u32x4 bufA[BAND_D], bufB[BAND_D];
 #pragma unroll
         for (int u = 0; u < BAND_D; ++u) bufA[u] = issue(cur, 0, u);
-        while (true) {
+        // (`dead` changes only where a wave loads a window: before the loop -- every wave at once -- and in the group that ends a
+        // segment, i.e. the one with the barrier and the fold of that batch: the waves of a workgroup leave after the same barrier)
+        while (!dead) {
             group(bufA, bufB);
-            if (c_batch >= n_batches) break;
+            if (c_batch >= n_batches || dead) break;
             group(bufB, bufA);
-            if (c_batch >= n_batches) break;
+            if (c_batch >= n_batches || dead) break;
         }
         if (cur_g != NONE) flush(cur_g);
     }
