@@ -3,11 +3,11 @@
 (docs/chr22.hprc-v1.0-pggb.histgrowth.html:266-276: three 45-bin histograms and 3 x 5 growth curves of 44 values,
 kept in tests/golden/golden.json by make_golden.py).
 
-The graph is a 402 MB download that is not in the build image, so the test SKIPS unless PANACUS_CHR22_GFA names the
-file (plain or .gz):
+The graph is a 402 MB download that is not in the build image (no network), so the test SKIPS unless the file is found
+-- under PANACUS_CHR22_GFA, or dropped in at the fixed place tests/golden/chr22.hprc-v1.0-pggb.gfa[.gz] (git-ignored):
 
-    wget https://s3-us-west-2.amazonaws.com/human-pangenomics/pangenomes/freeze/freeze1/pggb/chroms/chr22.hprc-v1.0-pggb.gfa.gz
-    PANACUS_CHR22_GFA=$PWD/chr22.hprc-v1.0-pggb.gfa.gz python -m pytest tests/test_gpu_chr22.py -m gpu
+    wget -P tests/golden https://s3-us-west-2.amazonaws.com/human-pangenomics/pangenomes/freeze/freeze1/pggb/chroms/chr22.hprc-v1.0-pggb.gfa.gz
+    python -m pytest tests/test_gpu_chr22.py -m gpu
 
 With the file present it pins `hist` itself (coverage on the device, all three count types, -S grouping, the subset
 list of the example) on real data, not only the hist -> growth half that the 660 values pin without the graph."""
@@ -22,14 +22,16 @@ from panacus_amd import hostlib as hl
 
 pytestmark = pytest.mark.gpu
 
-GFA = os.environ.get("PANACUS_CHR22_GFA", "")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GFA = next((f for f in (os.environ.get("PANACUS_CHR22_GFA", ""), os.path.join(_HERE, "golden", "chr22.hprc-v1.0-pggb.gfa"),
+                        os.path.join(_HERE, "golden", "chr22.hprc-v1.0-pggb.gfa.gz")) if f and os.path.exists(f)), "")
 
 
 def _body_rows(text):
     return [l.split("\t") for l in text.split("\n") if l and not l.startswith("#")]
 
 
-@pytest.mark.skipif(not (GFA and os.path.exists(GFA)), reason="PANACUS_CHR22_GFA does not name the chr22 pggb graph (see the module docstring)")
+@pytest.mark.skipif(not (GFA and os.path.exists(GFA)), reason="the chr22 pggb graph is neither under PANACUS_CHR22_GFA nor in tests/golden/ (see the module docstring)")
 @pytest.mark.parametrize("cname", ["node", "bp", "edge"])
 def test_chr22_example_reproduces_the_published_report(golden, tmp_path, cname):
     # step 2 of the example: every path that is not a reference

@@ -1194,6 +1194,7 @@ def test_full_size_cfg3_properties():
         order = np.arange(p, dtype=np.uint32)
         c.set_order(order, order, p)
         cnt, h = c.hist()
+        assert c.info().n_rows == 0 and c.info().n_reruns == 0   # the cold call: the one-shot route over the steps, nothing derived
         assert int(h.sum()) == n and cnt[0] == 0xFFFFFFFF
         assert np.array_equal(np.bincount(cnt[1:], minlength=p + 1).astype(np.uint64), h)
         assert int(cnt[1:].max()) == p and c.info().n_general_paths == 0
@@ -1228,6 +1229,37 @@ def test_full_size_cfg3_properties():
         cnt2, h3 = c.hist()
         assert int(h3.sum()) == n
         assert np.all(cnt2[1:] <= cnt[1:]) and np.all(2 * cnt2[1:].astype(np.int64) >= cnt[1:])
+
+
+def test_full_size_10Mx1k_against_the_oracle():
+    """north_star's shape (10 M nodes x 1024 paths, 3.9 G steps) through the one-shot route, the WHOLE coverage vector and the
+    histogram against the serial restatement of abacus.rs:719-787: with every path its own group the coverage of a graph is
+    the sum of the coverages of disjoint sets of its paths, so the oracle runs over four quarters of the paths (the u64
+    widening of all steps at once would be 31 GB of host memory)."""
+    from panacus_amd import capi
+    n, p = 10_000_000, 1024
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(42, n, p)
+        order = np.arange(p, dtype=np.uint32)
+        c.set_order(order, order, p)
+        cnt, h = c.hist()
+        info = c.info()
+        assert info.n_rows == 0 and info.n_reruns == 0       # the steps were read once, nothing was derived
+        assert int(h.sum()) == n and cnt[0] == 0xFFFFFFFF
+        items32, off, _ = c.get_csr()
+    total = np.zeros(n + 1, dtype=np.uint64)
+    q = p // 4
+    for k in range(4):
+        a, b = int(off[k * q]), int(off[(k + 1) * q])
+        part = items32[a:b].astype(np.uint64)
+        pre = (off[k * q:(k + 1) * q + 1] - off[k * q]).astype(np.uint64)
+        pi = np.arange(q, dtype=np.uint64)
+        cov = orc.coverage(part, pre, pi, pi, n)
+        total[1:] += cov[1:]
+        del part, cov
+    del items32
+    assert np.array_equal(cnt[1:].astype(np.uint64), total[1:])
+    assert np.array_equal(h, np.bincount(total[1:].astype(np.int64), minlength=p + 1).astype(np.uint64))
 
 
 def _pansyn_coverage_of(seed, nodes, n_nodes, n_paths):
