@@ -7,10 +7,11 @@
 // columns are > 90 % of the bytes of a pangenome GFA and every step is independent of every other once it is known where
 // the columns are, so: the raw bytes go to HBM as they are, the host only finds the lines (it needs the S and P headers
 // anyway), and
-//   k_tok_count  one wave per 16 KB of a column counts the steps that START in its piece,
+//   k_tok_count  one wave per 16 KB of a column counts the steps that START in its piece (16 bytes per lane, separators found
+//                by byte-parallel arithmetic),
 //   (scan)       the counts become output offsets -- and, at the first piece of every path, the ItemTable's id_prefsum,
-//   k_tok_emit   the same waves convert the decimal names of their steps (no loop over digits: ballot + a prefix sum over
-//                the lanes) and write the ids (and orientations) in place.
+//   k_tok_emit   the same waves stage 1 KB of text at a time in LDS, list the starts, and convert the decimal names one start
+//                per lane (no loop over digits) -- ids (and orientations) leave in step order, coalesced.
 // Names must be decimal numbers: the id is the number itself (`nice: true`, graph.rs:224-229: the names are 1..N in file
 // order) or comes out of a table indexed by the number that the host fills from the S lines.  Graphs with other names
 // keep the host parser.  A step whose name is not a number, or a number the graph has no segment for, fails the call --
@@ -53,15 +54,51 @@ __device__ static inline TokPiece tok_piece_of(uint64_t c, const uint64_t *__res
 }
 
 // A step belongs to the piece that holds the first character of its name.  P column: the name starts at the column's
-// first byte and after every ','; W column: after every '>' or '<'.  (An empty name -- ",," or a trailing separator --
-// is still a step here, and fails in k_tok_emit like an unknown name.)  Lane = one byte of a 64-byte group.
-__device__ static inline bool tok_is_start(const TokPiece &t, uint64_t i, uint8_t prev) {
-    if (i >= t.e) return false;
-    if (t.walk) return i > t.col_b && (prev == '>' || prev == '<');
-    return i == t.col_b || prev == ',';
+// first byte and after every ','; W column: after every '>' or '<'.  (An empty name -- ",," -- is still a step here, and
+// fails in k_tok_emit like an unknown name.)
+//
+// Both kernels read the text 16 bytes per lane (one aligned 16-byte load: 1 KB per wave and load) and find the separators
+// with byte-parallel arithmetic on the four dwords -- no lane looks at a single byte.
+
+// 0x80 in every byte of x that equals the byte replicated in c4 (exact: no carries between bytes)
+__device__ static inline uint32_t tok_eq(uint32_t x, uint32_t c4) {
+    const uint32_t y = x ^ c4;
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+}
+// separators of a step column: ',' (P) or '>' / '<' (W: 0x3E / 0x3C, one bit apart)
+template <bool WALK>
+__device__ static inline uint32_t tok_sep(uint32_t x) {
+    return WALK ? tok_eq(x & ~0x02020202u, 0x3C3C3C3Cu) : tok_eq(x, 0x2C2C2C2Cu);
+}
+// 0xFF in the bytes [a, b) of a dword (a, b in 0..4, clamped)
+__device__ static inline uint32_t tok_bytes(int a, int b) {
+    a = a < 0 ? 0 : (a > 4 ? 4 : a);
+    b = b < 0 ? 0 : (b > 4 ? 4 : b);
+    const uint32_t hi = b >= 4 ? 0xFFFFFFFFu : ((1u << (8 * b)) - 1u), lo = a >= 4 ? 0xFFFFFFFFu : ((1u << (8 * a)) - 1u);
+    return hi & ~lo;
 }
 
-// how many steps START in every piece
+typedef uint32_t tok_u32x4 __attribute__((ext_vector_type(4)));
+
+// how many steps START in every piece: the separators in [max(b - 1, col_b), e - 1), and the column's first byte (P)
+template <bool WALK>
+__device__ static inline uint32_t tok_count_piece(const uint8_t *__restrict__ text, const TokPiece &t, uint32_t lane) {
+    const uint64_t lo = t.b > t.col_b ? t.b - 1 : t.col_b, hi = t.e - 1;  // (t.e > t.b >= col_b: a piece is never empty)
+    uint32_t n = 0;
+    for (uint64_t pos = (lo & ~15ull) + lane * 16ull; pos < hi; pos += 1024) {
+        const tok_u32x4 v = *reinterpret_cast<const tok_u32x4 *>(text + pos);
+        uint32_t f[4] = {tok_sep<WALK>(v.x), tok_sep<WALK>(v.y), tok_sep<WALK>(v.z), tok_sep<WALK>(v.w)};
+        if (pos < lo || pos + 16 > hi) {  // the first / last lanes of the range: only its bytes
+            const int a = pos < lo ? (int)(lo - pos) : 0, b = pos + 16 > hi ? (int)(hi - pos) : 16;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) f[w] &= tok_bytes(a - 4 * w, b - 4 * w);
+        }
+        n += (uint32_t)(__builtin_popcount(f[0]) + __builtin_popcount(f[1]) + __builtin_popcount(f[2]) + __builtin_popcount(f[3]));
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    return n + ((!WALK && t.b == t.col_b) ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(256) void k_tok_count(const uint8_t *__restrict__ text, const uint64_t *__restrict__ piece_off,
                                                    const uint64_t *__restrict__ col_b, const uint64_t *__restrict__ col_e,
                                                    const uint8_t *__restrict__ is_walk, uint32_t n_paths, uint64_t n_pieces,
@@ -70,92 +107,176 @@ __global__ __launch_bounds__(256) void k_tok_count(const uint8_t *__restrict__ t
     const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_pieces) return;
     const TokPiece t = tok_piece_of(c, piece_off, col_b, col_e, is_walk, n_paths);
-    uint32_t n = 0;
-    uint8_t carry = t.b > t.col_b ? text[t.b - 1] : 0;  // the separator of a step that starts at the piece's first byte
-    for (uint64_t g0 = t.b; g0 < t.e; g0 += 64) {
-        const uint64_t i = g0 + lane;
-        const uint8_t ch = i < t.e ? text[i] : 0;
-        uint8_t prev = (uint8_t)__shfl_up((int)ch, 1);
-        if (lane == 0) prev = carry;
-        carry = (uint8_t)__builtin_amdgcn_readlane((int)ch, 63);
-        n += (uint32_t)__builtin_popcountll(__ballot(tok_is_start(t, i, prev)));
-    }
+    const uint32_t n = t.walk ? tok_count_piece<true>(text, t, lane) : tok_count_piece<false>(text, t, lane);
     if (lane == 0) counts[c] = n;
 }
 
-// The ids.  A wave looks at 64 bytes at a time, one per lane, and OWNS the step starts in the first 48 of them; the other
-// 16 are look-ahead (a name has at most 10 digits, plus its sign), so every owned name lies inside the window and is
-// converted without a loop and without a lane reading on its own: every digit lane knows from the ballot of the
-// non-digits where its number ends, weighs its digit by the power of ten of its place, a prefix sum over the lanes adds
-// the places up, and the lane of the first digit takes the difference of two prefix values.
+// The ids.  Per 1 KB of text (16 bytes per lane, the next KB already on its way): the bytes go to a wave-private LDS buffer,
+// every lane marks the steps that START in its 16 bytes (separator flags moved up by one byte, the last flag of the lane
+// below carried in), a prefix sum over the lanes numbers them, and every lane drops the positions of its starts into a
+// compact list.  Then the wave takes the list 64 starts at a time, one per lane: the 12 bytes behind the start come out of
+// LDS (four aligned dwords + a funnel shift), the run of digits is measured with byte-parallel flags, the same window is
+// read again ENDING at the last digit so that the digits sit right-aligned whatever their number, and three 4-digit
+// groups are converted with one multiplication each.  Ids leave in step order, one coalesced store per 64 steps.
+// Strict like the reference's parser (src/graph_broker/util.rs:1021-1091 panics on all of these): a name must be 1..10
+// decimal digits without a leading zero, a P step ends in '+' / '-' followed by ',' or the end of the column, a P
+// column does not end in ',', a W column starts with '>' / '<'.
+constexpr uint32_t TOK_LDS_PAD = 16;                    // bytes in front of the chunk (a right-aligned window may start before it)
+constexpr uint32_t TOK_LDS_BUF = TOK_LDS_PAD + 1024 + 32;  // + the 16 bytes that follow the chunk + slack for the dword reads
+constexpr uint32_t TOK_LDS_LIST = 512;                   // a W column can start a step every 2 bytes
+
+template <bool WALK>
+__device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, const TokPiece &t, uint32_t lane, uint64_t out,
+                                             const uint32_t *__restrict__ id_of_name, uint64_t n_names, uint32_t n_nodes,
+                                             uint32_t *__restrict__ items, uint8_t *__restrict__ backward, uint32_t &bad, uint8_t *buf,
+                                             uint16_t *list) {
+    const uint64_t base = t.b & ~15ull;
+    auto load = [&](uint64_t pos) {  // 16 bytes at pos; the bytes from the end of the column on read as 0
+        tok_u32x4 v = tok_u32x4{0, 0, 0, 0};
+        if (pos < t.col_e) {
+            v = *reinterpret_cast<const tok_u32x4 *>(text + pos);
+            if (pos + 16 > t.col_e) {
+                const int k = (int)(t.col_e - pos);
+                v.x &= tok_bytes(0, k);
+                v.y &= tok_bytes(0, k - 4);
+                v.z &= tok_bytes(0, k - 8);
+                v.w &= tok_bytes(0, k - 12);
+            }
+        }
+        return v;
+    };
+    // separator flag (0x80) of the byte in front of the first chunk, if that byte belongs to the column
+    uint32_t carry = 0;
+    if (base > t.col_b) carry = tok_sep<WALK>((uint32_t)text[base - 1]) & 0x80u;
+    carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)carry);
+    if (lane < 4) reinterpret_cast<uint32_t *>(buf)[lane] = 0;  // the pad in front: never a digit ...
+    uint32_t last = base > 0 ? (uint32_t)text[base - 1] : 0u;   // ... but its last byte is the character in front of the chunk ('>' / '<' of a W step)
+    last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+    tok_u32x4 cur = load(base + lane * 16ull);
+    for (uint64_t g0 = base; g0 < t.e; g0 += 1024) {
+        const uint64_t pos = g0 + lane * 16ull;
+        const tok_u32x4 nxt = load(pos + 1024);
+        *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + lane * 16u) = cur;
+        if (lane == 0) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1024) = nxt;  // what follows the chunk
+        if (lane == 1) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1040) = tok_u32x4{0, 0, 0, 0};
+        if (lane == 2) buf[TOK_LDS_PAD - 1] = (uint8_t)last;
+        last = ((uint32_t)__builtin_amdgcn_readlane((int)cur.w, 63)) >> 24;
+        // ---- starts in this lane's 16 bytes ----
+        uint32_t sp[4] = {tok_sep<WALK>(cur.x), tok_sep<WALK>(cur.y), tok_sep<WALK>(cur.z), tok_sep<WALK>(cur.w)};
+        if (pos < t.col_b) {  // bytes in front of the column are not part of it
+            const int a = pos + 16 <= t.col_b ? 16 : (int)(t.col_b - pos);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sp[w] &= tok_bytes(a - 4 * w, 4);
+        }
+        uint32_t below = (uint32_t)__shfl_up((int)sp[3], 1);
+        if (lane == 0) below = carry << 24;
+        carry = ((uint32_t)__builtin_amdgcn_readlane((int)sp[3], 63)) >> 24;
+        uint32_t st[4] = {(sp[0] << 8) | (below >> 24), (sp[1] << 8) | (sp[0] >> 24), (sp[2] << 8) | (sp[1] >> 24), (sp[3] << 8) | (sp[2] >> 24)};
+        if (!WALK && pos <= t.col_b && t.col_b < pos + 16) st[(t.col_b - pos) >> 2] |= 0x80u << (8 * ((t.col_b - pos) & 3));  // a P column starts with a step
+        if (pos < t.b || pos + 16 > t.e) {  // only the starts inside the piece are this wave's
+            const int a = pos < t.b ? (pos + 16 <= t.b ? 16 : (int)(t.b - pos)) : 0, b = pos >= t.e ? 0 : (pos + 16 > t.e ? (int)(t.e - pos) : 16);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) st[w] &= tok_bytes(a - 4 * w, b - 4 * w);
+        }
+        const uint32_t mine = (uint32_t)(__builtin_popcount(st[0]) + __builtin_popcount(st[1]) + __builtin_popcount(st[2]) + __builtin_popcount(st[3]));
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= (uint32_t)o) incl += up;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t slot = incl - mine;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t f = st[w];
+            while (f) {
+                const uint32_t k = (uint32_t)__builtin_ctz(f) >> 3;
+                f &= f - 1u;
+                list[slot++] = (uint16_t)(lane * 16u + 4u * (uint32_t)w + k);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- one start per lane ----
+        for (uint32_t j0 = 0; j0 < total; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            if (j < total) {
+                const uint32_t p = TOK_LDS_PAD + list[j];  // byte of the name's first character in buf
+                const uint32_t *d = reinterpret_cast<const uint32_t *>(buf + (p & ~3u));
+                const uint32_t sh = (p & 3u) * 8u;
+                const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+                const uint32_t x[3] = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), __builtin_amdgcn_alignbit(d3, d2, sh)};
+                // digits: bytes '0'..'9'; L = the number of leading ones among the 12 bytes
+                uint32_t nd[3];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const uint32_t y = x[w] ^ 0x30303030u;
+                    nd[w] = (((y & 0x7F7F7F7Fu) + 0x76767676u) | y) & 0x80808080u;  // 0x80 where the byte is NOT a digit
+                }
+                const uint32_t L = nd[0] ? (uint32_t)__builtin_ctz(nd[0]) >> 3
+                                         : (nd[1] ? 4u + ((uint32_t)__builtin_ctz(nd[1]) >> 3) : (nd[2] ? 8u + ((uint32_t)__builtin_ctz(nd[2]) >> 3) : 12u));
+                // the 16 bytes that END four bytes behind the last digit: digits right-aligned in y[0..2], what follows in y[3]
+                const uint32_t q = p + L - 12u;  // (>= 4: the pad; L = 0 reads the bytes in front of the name, masked away below)
+                const uint32_t *e = reinterpret_cast<const uint32_t *>(buf + (q & ~3u));
+                const uint32_t sq = (q & 3u) * 8u;
+                const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+                const uint32_t y0 = __builtin_amdgcn_alignbit(e1, e0, sq), y1 = __builtin_amdgcn_alignbit(e2, e1, sq),
+                               y2 = __builtin_amdgcn_alignbit(e3, e2, sq), y3 = __builtin_amdgcn_alignbit(e4, e3, sq);
+                // keep the top L bytes of the 12: the last four digits in y2, the four before in y1, at most two more in y0
+                auto top = [](uint32_t k) { return k >= 4u ? 0xFFFFFFFFu : (k ? 0xFFFFFFFFu << (32u - 8u * k) : 0u); };
+                const uint32_t m2 = top(L), m1 = top(L > 4u ? L - 4u : 0u), m0 = top(L > 8u ? L - 8u : 0u);
+                const uint32_t t2 = (y2 & m2) - (0x30303030u & m2), t1 = (y1 & m1) - (0x30303030u & m1), t0 = (y0 & m0) - (0x30303030u & m0);
+                auto four = [](uint32_t tt) {  // bytes d0 d1 d2 d3 (d0 lowest) -> d0 * 1000 + d1 * 100 + d2 * 10 + d3
+                    const uint32_t pr = ((tt * 2561u) >> 8) & 0x00FF00FFu;  // (d0 * 10 + d1) | (d2 * 10 + d3) << 16
+                    return (pr & 0xFFFFu) * 100u + (pr >> 16);
+                };
+                const uint64_t v = (uint64_t)four(t0) * 100000000ull + (uint64_t)(four(t1) * 10000u + four(t2));
+                const uint32_t first = x[0] & 0xFFu, term = y3 & 0xFFu, after = (y3 >> 8) & 0xFFu;
+                bool ok = L >= 1u && L <= 10u && !(first == '0' && L > 1u) && v <= 0xFFFFFFFFull;
+                uint32_t back;
+                if (WALK) {
+                    ok = ok && (term == '>' || term == '<' || term == 0);  // 0: the end of the column
+                    back = buf[p - 1] == '<';
+                } else {
+                    ok = ok && (term == '+' || term == '-') && (after == ',' || after == 0);
+                    back = term == '-';
+                }
+                uint32_t id = 0;
+                if (ok) id = id_of_name ? (v < n_names ? id_of_name[v] : 0u) : (uint32_t)v;
+                if (id == 0 || id > n_nodes) bad |= ok ? 2u : 1u;
+                items[out + j] = id;
+                if (backward) backward[out + j] = (uint8_t)back;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        out += total;
+        cur = nxt;
+    }
+    // what no step shows: a P column that ends in a separator, a W column that does not begin with one
+    if (lane == 0) {
+        if (!WALK && t.e == t.col_e && text[t.col_e - 1] == ',') bad |= 1u;
+        if (WALK && t.b == t.col_b && text[t.col_b] != '>' && text[t.col_b] != '<') bad |= 1u;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ text, const uint64_t *__restrict__ piece_off,
                                                   const uint64_t *__restrict__ col_b, const uint64_t *__restrict__ col_e,
                                                   const uint8_t *__restrict__ is_walk, uint32_t n_paths, uint64_t n_pieces,
                                                   const uint64_t *__restrict__ piece_out, const uint32_t *__restrict__ id_of_name,
                                                   uint64_t n_names, uint32_t n_nodes, uint32_t *__restrict__ items,
                                                   uint8_t *__restrict__ backward, uint32_t *__restrict__ flags) {
-    constexpr uint32_t OWN = 48;
+    __shared__ __attribute__((aligned(16))) uint8_t buf_all[4][TOK_LDS_BUF];
+    __shared__ uint16_t list_all[4][TOK_LDS_LIST];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + wave;
     if (c >= n_pieces) return;
     const TokPiece t = tok_piece_of(c, piece_off, col_b, col_e, is_walk, n_paths);
-    uint64_t out = piece_out[c];
     uint32_t bad = 0;
-    uint8_t carry = t.b > t.col_b ? text[t.b - 1] : 0;
-    for (uint64_t w0 = t.b; w0 < t.e; w0 += OWN) {
-        const uint64_t i = w0 + lane;
-        const uint8_t ch = i < t.col_e ? text[i] : 0;  // the look-ahead may leave the piece, never the column
-        uint8_t prev = (uint8_t)__shfl_up((int)ch, 1);
-        if (lane == 0) prev = carry;
-        carry = (uint8_t)__builtin_amdgcn_readlane((int)ch, OWN - 1);
-        const bool start = lane < OWN && tok_is_start(t, i, prev);
-        const unsigned long long m = __ballot(start);
-        if (m == 0) continue;
-        const bool dig = ch >= '0' && ch <= '9';
-        const unsigned long long nondig = __ballot(!dig);
-        // first non-digit lane at or after this one (64: none inside the window)
-        const unsigned long long rest = nondig >> lane;
-        const uint32_t e = rest ? lane + (uint32_t)__builtin_ctzll(rest) : 64u;
-        const uint32_t place = e - 1u - lane;  // 0 = units (meaningful for digit lanes)
-        uint64_t pw = 1;
-        if (place & 1u) pw *= 10ull;
-        if (place & 2u) pw *= 100ull;
-        if (place & 4u) pw *= 10000ull;
-        if (place & 8u) pw *= 100000000ull;
-        uint64_t sum = dig && place < 11u ? (uint64_t)(ch - '0') * pw : 0ull;
-        // inclusive prefix sum over the lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t up = __shfl_up(sum, o);
-            if (lane >= (uint32_t)o) sum += up;
-        }
-        const uint64_t below = __shfl_up(sum, 1);            // prefix up to the lane before this one
-        const uint64_t upto = __shfl(sum, e > 0 ? (e - 1u) & 63u : 0u);  // prefix up to the last digit of a number that starts here
-        const uint8_t term = (uint8_t)__shfl((int)ch, e & 63u);        // the character behind the digits ...
-        const uint8_t after = (uint8_t)__shfl((int)ch, (e + 1u) & 63u);  // ... and the one behind that
-        if (start) {
-            const uint32_t nd = e - lane;
-            const uint64_t v = upto - (lane ? below : 0ull);
-            bool ok = dig && nd > 0 && nd < 11u && e < 64u;
-            uint8_t back = 0;
-            if (t.walk) {
-                ok = ok && (term == '>' || term == '<' || term == 0);  // 0: the end of the column
-                back = prev == '<';
-            } else {
-                ok = ok && (term == '+' || term == '-') && e + 1u <= 64u;
-                back = term == '-';
-                // behind the sign: ',' or the end of the column (0)
-                ok = ok && (e + 1u < 64u ? (after == ',' || after == 0) : false);
-            }
-            uint32_t id = 0;
-            if (ok) id = id_of_name ? (v < n_names ? id_of_name[v] : 0u) : (v <= 0xFFFFFFFFull ? (uint32_t)v : 0u);
-            if (id == 0 || id > n_nodes) bad |= ok ? 2u : 1u;
-            const uint64_t slot = out + (uint64_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            items[slot] = id;
-            if (backward) backward[slot] = back;
-        }
-        out += (uint64_t)__builtin_popcountll(m);
-    }
+    if (t.walk) tok_emit_piece<true>(text, t, lane, piece_out[c], id_of_name, n_names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
+    else tok_emit_piece<false>(text, t, lane, piece_out[c], id_of_name, n_names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
     for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
     if (lane == 0 && bad) atomicOr(flags, bad);
 }

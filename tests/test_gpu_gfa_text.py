@@ -74,21 +74,79 @@ def test_step_columns_tokenised_on_the_device(ctx, nice, upload_first):
     assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 3, lens))
 
 
-@pytest.mark.parametrize("bad", ["name", "unknown", "sign", "empty", "walk", "zero"])
+@pytest.mark.parametrize("bad", ["name", "unknown", "sign", "empty", "walk", "zero", "trailing", "walk_head", "leading_zero", "long", "walk_zero"])
 def test_malformed_steps_fail_the_call(ctx, bad):
     from panacus_amd import capi
     n = 50
-    col = {"name": b"1+,2-,s3+,4+", "unknown": b"1+,51+,2+", "sign": b"1+,2,3+", "empty": b"1+,,3+", "walk": b">1<2>x3", "zero": b"1+,0+"}[bad]
+    col = {"name": b"1+,2-,s3+,4+", "unknown": b"1+,51+,2+", "sign": b"1+,2,3+", "empty": b"1+,,3+", "walk": b">1<2>x3", "zero": b"1+,0+",
+           # what the reference's parser panics on as well (util.rs:1021-1091) and a lenient tokeniser would let through
+           "trailing": b"1+,2+,", "walk_head": b"1>2<3", "leading_zero": b"1+,007+,3+", "long": b"1+,12345678901+", "walk_zero": b">1<02"}[bad]
     text = b"P\tp\t" + col + b"\t*\n"
     cb, ce = np.array([4], np.uint64), np.array([4 + len(col)], np.uint64)
     with pytest.raises(capi.PnxError) as e:
-        ctx.set_csr_gfa(text, cb, ce, np.array([1 if bad == "walk" else 0], np.uint8), n)
+        ctx.set_csr_gfa(text, cb, ce, np.array([1 if bad.startswith("walk") else 0], np.uint8), n)
     assert e.value.code == capi.PNX_EINVAL
     with pytest.raises(capi.PnxError):
         ctx.hist()   # nothing is resident after a rejected upload
     # ... and a column outside the text is refused before anything is touched
     with pytest.raises(capi.PnxError):
         ctx.set_csr_gfa(text, cb, ce + np.uint64(100), np.array([0], np.uint8), n)
+
+
+def _columns(rng, names_of, ids_per_path, walk, pad_char):
+    parts, cb, ce = [b"H\tVN:Z:1.1\n"], [], []
+    pos = len(parts[0])
+    for ids in ids_per_path:
+        back = rng.random(len(ids)) < 0.5
+        pad = pad_char * int(rng.integers(0, 17))     # moves the column to every alignment of the 16-byte lanes
+        if walk:
+            head = b"W\ts\t1\t" + pad + b"\t0\t1\t"
+            col = "".join(("<" if b else ">") + names_of(i) for i, b in zip(ids, back)).encode()
+            tail = b"\n"
+        else:
+            head = b"P\t" + pad + b"p\t"
+            col = ",".join(names_of(i) + ("-" if b else "+") for i, b in zip(ids, back)).encode()
+            tail = b"\t*\n"
+        cb.append(pos + len(head))
+        ce.append(pos + len(head) + len(col))
+        parts += [head, col, tail]
+        pos += len(head) + len(col) + len(tail)
+    return b"".join(parts), np.array(cb, np.uint64), np.array(ce, np.uint64)
+
+
+@pytest.mark.parametrize("walk", [False, True])
+def test_names_of_every_width_and_position(ctx, walk):
+    """names of 1..10 digits (up to the largest id a u32 graph holds), starting at every byte offset of the tokeniser's 16-byte
+    lanes and across its 1 KB chunks and 16 KB pieces; through a name table and as the ids themselves"""
+    from panacus_amd import capi
+    rng = np.random.default_rng(3 + walk)
+    vals = np.unique(np.concatenate([rng.integers(10 ** (k - 1), 10 ** k, size=60) for k in range(1, 10)] +
+                                    [np.array([1, 9, 10, 99, 100, 4294967292, 4294967291, 1000000000, 999999999, 4000000000])]))
+    # names below 3 M through a table (ids = ranks)
+    small = vals[vals < 3_000_000]
+    tab = np.zeros(3_000_001, dtype=np.uint32)
+    tab[small] = np.arange(1, len(small) + 1, dtype=np.uint32)
+    paths = [rng.choice(small, size=int(rng.integers(1, 9000))) for _ in range(24)]
+    text, cb, ce = _columns(rng, lambda i: str(int(i)), paths, walk, b"y")
+    ctx.set_csr_gfa(text, cb, ce, np.full(24, 1 if walk else 0, np.uint8), len(small), id_of_name=tab)
+    items, off, _ = ctx.get_csr()
+    assert np.array_equal(items, np.concatenate([tab[q] for q in paths]))
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum([len(q) for q in paths])]).astype(np.uint64))
+    # the names ARE the ids: every width up to 10 digits on a graph of 2^32 - 4 items (no rows are derived for it: the
+    # one-shot route is asked for, so the upload only validates the ids)
+    ctx.config(capi.CFG_COVER_ROUTE, 1)
+    try:
+        paths = [rng.choice(vals, size=int(rng.integers(1, 5000))) for _ in range(8)]
+        text, cb, ce = _columns(rng, lambda i: str(int(i)), paths, walk, b"z")
+        ctx.set_csr_gfa(text, cb, ce, np.full(8, 1 if walk else 0, np.uint8), 4294967292)
+        items, off, _ = ctx.get_csr()
+        assert np.array_equal(items, np.concatenate(paths).astype(np.uint32))
+        # one item fewer: the largest name is now unknown
+        with pytest.raises(capi.PnxError) as e:
+            ctx.set_csr_gfa(text, cb, ce, np.full(8, 1 if walk else 0, np.uint8), 4294967291)
+        assert e.value.code == capi.PNX_EINVAL
+    finally:
+        ctx.config(capi.CFG_COVER_ROUTE, 0)
 
 
 def _canonical(u, o1, v, o2):
