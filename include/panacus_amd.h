@@ -122,6 +122,13 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *we
  * pnx_set_csr_gfa or the end of the context.  The edge fields of `steps` are ignored here (pnx_set_csr_cut has its own).
  * Like every upload the call ends the residence of the graph that was resident before it (the tokeniser works in its buffers). */
 int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *steps, uint64_t *walk_off);
+/* The walks a preceding pnx_gfa_walks left on the device become the resident graph -- as pnx_set_csr_gfa would have made it
+ * from the text, without tokenising the text again: the node ItemTable (edge_uv == NULL; n_nodes items; weights / exclude as
+ * for pnx_set_csr) or, with edge_uv / edge_oo / n_edges as in pnx_gfa_steps, the EDGE ItemTable of the same paths.  The
+ * walks stay on the device for further calls: `-c all` reads and tokenises its GFA once where the reference builds one
+ * table and clones it (graph_broker/util.rs:201-204) and parses the file again for the edges (graph_broker.rs:404-422). */
+int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, const uint8_t *exclude, const uint64_t *edge_uv,
+                      const uint8_t *edge_oo, uint32_t n_edges);
 
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
  * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)

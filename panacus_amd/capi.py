@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
     "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
-    "pnx_profile_sample", "pnx_gfa_walks",
+    "pnx_profile_sample", "pnx_gfa_walks", "pnx_set_csr_walks",
 ]
 
 
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
     L.pnx_gfa_text_upload.argtypes = [vp, C.c_char_p, C.c_uint64]
     L.pnx_set_csr_gfa.argtypes = [vp, C.POINTER(PnxGfaSteps), u32p, u8p]
     L.pnx_gfa_walks.argtypes = [vp, C.POINTER(PnxGfaSteps), C.POINTER(C.c_uint64)]
+    L.pnx_set_csr_walks.argtypes = [vp, C.c_uint32, u32p, u8p, u64p, u8p, C.c_uint32]
     L.pnx_get_exclude.argtypes = [vp, u8p]
     L.pnx_set_weights.argtypes = [vp, u32p]
     L.pnx_exclude_items.argtypes = [vp, u32p, C.c_uint32]
@@ -346,6 +347,16 @@ class Context:
         off = np.zeros(len(cb) + 1, dtype=np.uint64)
         self._ck(self._L.pnx_gfa_walks(self._h, C.byref(g), _ptr(off, C.c_uint64)))
         return off
+
+    def set_csr_walks(self, n_nodes, weights=None, exclude=None, edge_uv=None, edge_oo=None):
+        """pnx_set_csr_walks: the walks gfa_walks left on the device become the resident graph (node table, or the edge table of
+        the same paths) without the text being tokenised again"""
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+        x = None if exclude is None else np.ascontiguousarray(exclude, dtype=np.uint8)
+        uv = None if edge_uv is None else np.ascontiguousarray(edge_uv, dtype=np.uint64)
+        oo = None if edge_oo is None else np.ascontiguousarray(edge_oo, dtype=np.uint8)
+        self._ck(self._L.pnx_set_csr_walks(self._h, n_nodes, _ptr(w, C.c_uint32), _ptr(x, C.c_uint8), _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8),
+                                           0 if uv is None else len(uv) - 1))
 
     def prepare(self):
         self._ck(self._L.pnx_prepare(self._h))

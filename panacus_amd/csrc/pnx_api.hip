@@ -353,6 +353,15 @@ void pnx_free(pnx_ctx *ctx) {
     delete ctx;
 }
 
+// an upload that does not tokenise: a copy of the GFA text that pnx_gfa_text_upload left in HBM (a host that offers its text
+// before it knows the segment names are not decimal) is of no further use -- on a multi-GB graph it is the memory the item
+// table, the rows and the coverage vectors are about to ask for
+static void drop_gfa_text(pnx_ctx *ctx) {
+    release(ctx->d_gfa_text);
+    ctx->gfa_text_host = nullptr;
+    ctx->gfa_text_bytes = 0;
+}
+
 // what every upload starts with: results, order and derived step data of the old graph are void
 static void begin_upload(pnx_ctx *ctx) {
     invalidate_results(ctx);
@@ -425,6 +434,7 @@ static int set_csr_impl(pnx_ctx *ctx, const uint32_t *items, const uint64_t *pat
     const uint64_t S = path_off[n_paths];
     if (S && !items) return ctx->fail(PNX_EINVAL, "items is NULL");
     begin_upload(ctx);
+    drop_gfa_text(ctx);
     int rc;
     if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t)))) return rc;
@@ -475,6 +485,7 @@ int pnx_set_csr_cut(pnx_ctx *ctx, const pnx_walks *w, const uint32_t *weights, c
         return ctx->fail(PNX_EINVAL, "pnx_set_csr_cut: walk_node is NULL and the context holds no walks with these offsets (pnx_gfa_walks)");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
+    drop_gfa_text(ctx);  // (walks tokenised on the device: pnx_gfa_walks has released it already)
     int rc = pnx::cut_walks(ctx, w, events, cap, n_events);
     if (rc) return rc;
     return finish_upload(ctx, ctx->n_steps, w->n_paths, w->n_items, weights, nullptr, w->exc_off != nullptr,
@@ -511,9 +522,7 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     if (edges && (!g->edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo, and no weights");
     DevBuf d_backward;
     rc = gfa_tokenise(ctx, g, edges ? &d_backward : nullptr);
-    release(ctx->d_gfa_text);
-    ctx->gfa_text_host = nullptr;
-    ctx->gfa_text_bytes = 0;
+    drop_gfa_text(ctx);
     if (rc == PNX_OK && edges) rc = gfa_edge_items(ctx, g->n_paths, d_backward, g->edge_uv, g->edge_oo, g->n_edges);
     release(d_backward);
     if (rc) return rc;
@@ -538,15 +547,35 @@ int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {
         (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
         return rc;
     rc = gfa_tokenise(ctx, g, &ctx->d_walk_back);
-    release(ctx->d_gfa_text);
-    ctx->gfa_text_host = nullptr;
-    ctx->gfa_text_bytes = 0;
+    drop_gfa_text(ctx);
     if (rc) return rc;
     std::swap(ctx->d_items, ctx->d_walk_node);
     ctx->h_walk_off = ctx->h_path_off;
     std::memcpy(walk_off, ctx->h_walk_off.data(), ((size_t)g->n_paths + 1) * sizeof(uint64_t));
     ctx->walks_valid = true;
     return PNX_OK;
+}
+
+int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, const uint8_t *exclude, const uint64_t *edge_uv,
+                      const uint8_t *edge_oo, uint32_t n_edges) {
+    if (!ctx) return PNX_EINVAL;
+    if (!ctx->walks_valid || ctx->h_walk_off.empty()) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: the context holds no walks (pnx_gfa_walks)");
+    const bool edges = edge_uv != nullptr;
+    if (edges && (!edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: edge counts take edge_uv AND edge_oo, and no weights");
+    if (n_nodes >= 0xFFFFFFFEu || (edges && n_edges >= 0xFFFFFFFEu)) return ctx->fail(PNX_ELIMIT, "n_nodes and n_edges must be < 2^32-2");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    begin_upload(ctx);
+    const uint32_t n_paths = (uint32_t)(ctx->h_walk_off.size() - 1);
+    const uint64_t S = ctx->h_walk_off[n_paths];
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_items, S * sizeof(uint32_t) + 64)) || (rc = ensure(ctx, ctx->d_path_off, ((size_t)n_paths + 1) * sizeof(uint64_t))))
+        return rc;
+    if (S) PNX_HIP(ctx, hipMemcpyAsync(ctx->d_items.p, ctx->d_walk_node.p, S * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->h_path_off = ctx->h_walk_off;
+    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, ctx->h_path_off.data(), ((size_t)n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->n_steps = S;
+    if (edges && (rc = gfa_edge_items(ctx, n_paths, ctx->d_walk_back, edge_uv, edge_oo, n_edges))) return rc;
+    return finish_upload(ctx, ctx->n_steps, n_paths, edges ? n_edges : n_nodes, weights, exclude, false, nullptr);
 }
 
 int pnx_set_weights(pnx_ctx *ctx, const uint32_t *weights) {
@@ -665,6 +694,7 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
     if (n_nodes >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes must be < 2^32-2");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
+    drop_gfa_text(ctx);
     int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights);
     if (rc) return rc;
     ctx->have_exclude = false;

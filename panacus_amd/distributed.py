@@ -106,16 +106,34 @@ def default_comm_id_file() -> str:
     return os.path.join(base, f"comm_{tag}.id")
 
 
+def launch_nonce() -> bytes:
+    """16 bytes that every rank of ONE launch computes alike and no other launch does: PANACUS_COMM_NONCE if the launcher
+    exports one (required for launchers whose ranks do not share a parent process -- srun, mpirun -- together with
+    PANACUS_COMM_ID_FILE), else torchrun's run id + rendezvous port, else the START TIME OF THE PARENT process (the launcher
+    that forked every rank) + the rendezvous port.  Not this process's own start time: a rank that starts, or is restarted,
+    seconds after rank 0 published the id must still recognise it."""
+    import hashlib
+    import os
+    src = os.environ.get("PANACUS_COMM_NONCE")
+    if not src:
+        run = os.environ.get("TORCHELASTIC_RUN_ID")
+        port = os.environ.get("MASTER_PORT", "0")
+        src = f"torchrun|{run}|{port}" if run else f"parent|{os.getppid()}|{_process_start_ticks(os.getppid())}|{port}"
+    return hashlib.sha256(src.encode()).digest()[:16]
+
+
 def native_comm_init(ctx, rank: int, world: int, id_file: str | None = None, timeout_s: float = 120.0):
     """Give `ctx` the library's own RCCL communicator (pnx_comm_init): rank 0 asks the library for the
-    128-byte id and publishes it through `id_file` (created exclusively under a temporary name and renamed, so a
-    reader never sees half of it and a planted file is never followed); the other ranks wait for the file.  Once
-    every rank holds the communicator -- one all-reduce through it proves that -- rank 0 removes the file, so a later
-    launch can never pick up this launch's id.  No torch involved: the same steps a Rust host takes."""
+    128-byte id and publishes it through `id_file` -- [launch nonce 16 B | id 128 B], created exclusively under a temporary
+    name and renamed, so a reader never sees half of it and a planted file is never followed; the other ranks wait for a
+    file that carries THIS launch's nonce (a stale file of an earlier launch does not, whenever it was written).  Once
+    every rank holds the communicator -- one all-reduce through it proves that -- rank 0 removes the file.  No torch
+    involved: the same steps a Rust host takes."""
     import os
     import time
     if id_file is None:
         id_file = default_comm_id_file()
+    nonce = launch_nonce()
     if rank == 0:
         uid = type(ctx).comm_unique_id()
         try:
@@ -125,7 +143,7 @@ def native_comm_init(ctx, rank: int, world: int, id_file: str | None = None, tim
         tmp = f"{id_file}.{os.getpid()}.tmp"
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
         with os.fdopen(fd, "wb") as f:
-            f.write(uid)
+            f.write(nonce + uid)
         os.replace(tmp, id_file)
     else:
         t0 = time.time()
@@ -133,16 +151,17 @@ def native_comm_init(ctx, rank: int, world: int, id_file: str | None = None, tim
         while True:
             try:
                 st = os.stat(id_file, follow_symlinks=False)
-                # only a file written after this launch began can be this launch's (a stale one is also unlinked by rank 0)
-                if st.st_size == 128 and st.st_mtime >= _LAUNCH_T0 - 1.0:
+                if st.st_size == 16 + 128:
                     with open(id_file, "rb") as f:
-                        uid = f.read()
-                    if len(uid) == 128:
+                        blob = f.read()
+                    if len(blob) == 16 + 128 and blob[:16] == nonce:
+                        uid = blob[16:]
                         break
             except FileNotFoundError:
                 pass
             if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"no communicator id at {id_file} after {timeout_s} s")
+                raise TimeoutError(f"no communicator id of this launch at {id_file} after {timeout_s} s (ranks that do not share a "
+                                   f"parent process need PANACUS_COMM_ID_FILE and PANACUS_COMM_NONCE from their launcher)")
             time.sleep(0.01)
     ctx.comm_init(uid, rank, world)
     ctx.comm_barrier()  # every rank holds the communicator once this returns
@@ -154,17 +173,10 @@ def native_comm_init(ctx, rank: int, world: int, id_file: str | None = None, tim
     return uid
 
 
-def _process_start_time() -> float:
-    import os
-    import time
+def _process_start_ticks(pid: int) -> int:
+    """start time of a process in clock ticks since boot (0 if unknown): identifies the process together with its pid"""
     try:
-        with open(f"/proc/{os.getpid()}/stat") as f:
-            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
-        with open("/proc/uptime") as f:
-            up = float(f.read().split()[0])
-        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+        with open(f"/proc/{pid}/stat") as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
     except Exception:
-        return time.time()
-
-
-_LAUNCH_T0 = _process_start_time()
+        return 0

@@ -371,6 +371,55 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
         have_node = have_node || c == COUNT_NODE;
         have_bp = have_bp || c == COUNT_BP;
     }
+    bool have_edge = false;
+    for (CountType c : cts) have_edge = have_edge || c == COUNT_EDGE;
+    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    if (on_device && !mk.any() && have_edge && (have_node || have_bp)) {
+        // `-c all` on a graph with numeric names: the text is tokenised ONCE into walks that stay on the device
+        // (pnx_gfa_walks), and every count type's table is made from them there (pnx_set_csr_walks) -- the reference builds
+        // one table for node + bp and parses the file again for the edges (graph_broker/util.rs:201-204, graph_broker.rs:404-422)
+        std::vector<uint64_t> cb, ce, walk_off(g.path_segments().size() + 1, 0), euv;
+        std::vector<uint8_t> wk, eoo;
+        g.step_columns(cb, ce, wk);
+        g.edge_ends(euv, eoo);
+        const bool there = dev.text_uploaded();
+        pnx_gfa_steps st{};
+        st.text = there ? nullptr : g.text_data();
+        st.text_bytes = there ? 0 : g.text_size();
+        st.n_paths = (uint32_t)g.path_segments().size();
+        st.n_nodes = (uint32_t)g.node_count();
+        st.col_begin = cb.data();
+        st.col_end = ce.data();
+        st.is_walk = wk.data();
+        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
+        st.n_names = g.id_of_name().size();
+        dev.check(pnx_gfa_walks(dev.ctx(), &st, walk_off.data()));
+        phase_mark("pnx_gfa_walks (tokenised once for all count types)");
+        auto set_order = [&]() {
+            dev.check(pnx_set_order(dev.ctx(), order.path_idx.data(), order.group_id.data(), (uint32_t)order.path_idx.size(),
+                                    (uint32_t)order.groups.size()));
+        };
+        if (have_node || have_bp) {
+            dev.check(pnx_set_csr_walks(dev.ctx(), (uint32_t)g.node_count(), have_bp ? g.node_lens().data() : nullptr, nullptr, nullptr, nullptr, 0));
+            set_order();
+            for (size_t k = 0; k < cts.size(); ++k) {
+                if (cts[k] == COUNT_EDGE) continue;
+                if (have_bp) dev.check(pnx_config(dev.ctx(), PNX_CFG_USE_WEIGHTS, cts[k] == COUNT_BP ? 1 : 0));
+                out[k].assign(order.groups.size() + 1, 0);
+                dev.check(pnx_hist(dev.ctx(), nullptr, out[k].data()));
+            }
+            phase_mark("node / bp tables from the resident walks + hists");
+        }
+        dev.check(pnx_set_csr_walks(dev.ctx(), (uint32_t)g.node_count(), nullptr, nullptr, euv.data(), eoo.data(), (uint32_t)g.number_of_items(COUNT_EDGE)));
+        set_order();
+        for (size_t k = 0; k < cts.size(); ++k) {
+            if (cts[k] != COUNT_EDGE) continue;
+            out[k].assign(order.groups.size() + 1, 0);
+            dev.check(pnx_hist(dev.ctx(), nullptr, out[k].data()));
+        }
+        phase_mark("edge table from the resident walks + hist");
+        return out;
+    }
     if (have_node && have_bp && !mk.any()) {  // with -s/-e lists the two count types exclude differently
         upload(dev, g, COUNT_BP, order, mk);
         for (size_t k = 0; k < cts.size(); ++k) {

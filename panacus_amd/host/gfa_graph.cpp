@@ -1705,7 +1705,19 @@ inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, ui
 bool GraphStorage::from_cache_file() const { return impl_->cached; }
 
 bool GraphStorage::steps_tokenisable_on_device() const { return !impl_->cached && impl_->numeric_names; }
-bool GraphStorage::names_are_ranks() const { return impl_->cached || impl_->nice; }
+// `nice: true` of the YAML runner (graph.rs:224-229): are the segment names the integers 1..N in the order of the S lines?
+// A parsed graph knows; a graph from the .pcsr cache holds its names, and is asked once.
+bool GraphStorage::names_are_ranks() const {
+    const Impl &im = *impl_;
+    if (!im.cached) return im.nice;
+    for (uint32_t id = 1; id <= node_count_; ++id) {
+        const char *b = im.c_name_blob + im.c_name_off[id - 1], *e = im.c_name_blob + im.c_name_off[id];
+        char buf[12];
+        const int n = std::snprintf(buf, sizeof buf, "%u", id);
+        if ((size_t)(e - b) != (size_t)n || std::memcmp(b, buf, (size_t)n) != 0) return false;
+    }
+    return node_count_ > 0;
+}
 const char *GraphStorage::text_data() const { return impl_->image.data(); }
 size_t GraphStorage::text_size() const { return impl_->image.size(); }
 const std::vector<uint32_t> &GraphStorage::id_of_name() const { return impl_->id_of_name; }

@@ -222,6 +222,19 @@ def test_edge_item_table_from_walks_that_stay_on_the_device(ctx, nice):
     cnt, h = ctx.hist()
     ocov = orc.coverage(np.concatenate(want).astype(np.uint64), off, pi, gi, E)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 2))
+    # `-c all`: the text tokenised once into walks that stay on the device, the node table and the edge table both made from them
+    woff = ctx.gfa_walks(text, np.array(cb, np.uint64), np.array(ce, np.uint64), np.array(wk, np.uint8), n, id_of_name=table)
+    assert np.array_equal(woff, np.concatenate([[0], np.cumsum([len(ids) for ids, _ in walks])]).astype(np.uint64))
+    for _ in range(2):
+        ctx.set_csr_walks(n)
+        it_n, off_n, _ = ctx.get_csr()
+        assert np.array_equal(it_n, np.concatenate([ids for ids, _ in walks]).astype(np.uint32)) and np.array_equal(off_n, woff)
+        ctx.set_csr_walks(n, edge_uv=np.array(uv, np.uint64), edge_oo=np.array(oo, np.uint8))
+        it_e, off_e, _ = ctx.get_csr()
+        assert np.array_equal(it_e, np.concatenate(want)) and np.array_equal(off_e, off) and ctx.info().n_items == E
+    ctx.set_order(pi, gi, P // 2)
+    cnt2, h2 = ctx.hist()
+    assert np.array_equal(cnt2, ocov) and np.array_equal(h2, orc.hist(ocov, P // 2))
     # a step pair the graph has no edge for fails the call (the reference panics, util.rs:1080); so does an edge that is not canonical
     from panacus_amd import capi
     with pytest.raises(capi.PnxError) as e:
