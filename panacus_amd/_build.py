@@ -1,6 +1,8 @@
 """Builds the native parts of panacus_amd in-tree with hipcc / g++ (no JIT cache).
 
   libpanacus_hip.so   HIP kernels + the C ABI of include/panacus_amd.h   (gfx950)
+  libpanacus_hip_steps.so   the step routes of round 2 (kernels_cover.hip, kernels_runs.hip): a CROSS-CHECK module the tests
+                      hold the product against; the product library opens it only when PNX_CFG_COVER_VARIANT asks for one
   libpanacus_host.so  C++ host layer (GFA front end, closed-form growth, TSV writers)
   panacus-amd         CLI (hist | growth | histgrowth | ordered-histgrowth)
 
@@ -19,10 +21,12 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HOSTSRC = os.path.join(HERE, "host")
 LIB_HIP = os.path.join(HERE, "libpanacus_hip.so")
+LIB_STEPS = os.path.join(HERE, "libpanacus_hip_steps.so")
 LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
-HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "kernels_cover.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_band.hip", "kernels_gfa.hip", "kernels_runs.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
+HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "pass_pipeline.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_band.hip", "kernels_gfa.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
+STEP_SOURCES = ["kernels_cover.hip", "kernels_runs.hip"]  # the cross-check module
 HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "mini_yaml.cpp", "report.cpp", "commands.cpp", "host_api.cpp"]
 
 
@@ -52,12 +56,12 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(CSRC, "step_chunks.hpp"), os.path.join(ROOT, "include", "panacus_amd.h"),
             os.path.join(CSRC, "tile_counters.hpp"), os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc"),
             os.path.join(CSRC, "log2_exact.hpp"), os.path.join(CSRC, "log2_table.inc")]
-    objs = []
+    objs, step_objs = [], []
     procs = []
-    for src in HIP_SOURCES:
+    for src in HIP_SOURCES + STEP_SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        objs.append(o)
+        (step_objs if src in STEP_SOURCES else objs).append(o)
         if force or _newer(o, [s] + hdrs):
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o,
                    "-Wno-unused-result"]
@@ -75,6 +79,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
             print(out)
     if force or procs or _newer(LIB_HIP, objs):
         _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs + ["-ldl"])
+    if force or procs or _newer(LIB_STEPS, step_objs + [LIB_HIP]):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_STEPS] + step_objs +
+             ["-L" + HERE, "-lpanacus_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB_HIP
 
 

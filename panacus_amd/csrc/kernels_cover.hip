@@ -1,4 +1,8 @@
-// kernels_cover.hip -- coverage counting + histogram on gfx950 (MI355X).
+// kernels_cover.hip -- the STEP ROUTES: coverage counting straight over (packed) steps with a tile boundary index, round 2's
+// kernels.  Since round 4 a CROSS-CHECK MODULE (libpanacus_hip_steps.so), not part of the product library: the product computes
+// coverage over path rows (kernels_rows.hip) or in one read of the steps (kernels_band.hip); these kernels compute the same
+// results in a completely different way and the tests hold the product against them (PNX_CFG_COVER_VARIANT 0 / 1 / 2 loads
+// the module on demand; a system without it gets a clear error).
 //
 // Replaces, on the device, the reference's serial loops
 //   AbacusByTotal::coverage            src/graph_broker/abacus.rs:719-744
@@ -41,31 +45,6 @@
 #include "step_chunks.hpp"
 
 namespace pnx {
-
-// ------------------------------------------------------------------------------------------
-// upload validation: every step id must be in 1..n_items
-// ------------------------------------------------------------------------------------------
-__global__ void k_validate_items(const uint32_t *__restrict__ items, uint64_t n_steps,
-                                 uint32_t n_items, uint32_t *bad) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint32_t b = 0;
-    for (; i < n_steps; i += stride) {
-        uint32_t id = items[i];
-        b |= (id == 0u) | (id > n_items);
-    }
-    if (b) atomicOr(bad, 1u);
-}
-
-int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad) {
-    if (ctx->n_steps == 0) return PNX_OK;
-    uint64_t want = (ctx->n_steps + 255) / 256;
-    int grid = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(k_validate_items, dim3(grid), dim3(256), 0, ctx->stream,
-                       (const uint32_t *)ctx->d_items.p, ctx->n_steps, ctx->n_items, d_bad);
-    PNX_HIP(ctx, hipGetLastError());
-    return PNX_OK;
-}
 
 // ------------------------------------------------------------------------------------------
 // step preparation: once per upload, one streaming pass over the steps
@@ -1487,57 +1466,12 @@ static int launch_cover_wt(pnx_ctx *ctx, bool write_m, bool use_m) {
     return PNX_OK;
 }
 
-int launch_cover_pass(pnx_ctx *ctx) {
-    int rc;
-    const bool rows = use_rows(ctx);
-    if (!rows && ctx->n_runs && !ctx->runs_sorted && (rc = sort_run_index(ctx))) return rc;
-    const bool use_m = ctx->want_M || (!rows && ctx->last_general_paths > 0);
-    const uint64_t m_words = (uint64_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS;
+// phases 1 + 2 of a pass over the steps themselves (the histogram phase is shared: launch_cover_pass, pass_pipeline.hip)
+static int launch_step_phases(pnx_ctx *ctx, bool use_m, uint64_t m_words) {
     Ticket *tk = ctx->cur;
-    tk->used_m = use_m;
-    tk->wrote_m = ctx->want_M;
-    const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
-    tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
-    tk->hist_fused = rows && ctx->hist_in_cover && (size_t)ctx->n_groups + 1 <= HIST_FUSED_MAX_BINS;
-    const size_t rep_off = (tk->block_bytes + 255) & ~(size_t)255;
-    if (tk->hist_fused) tk->block_bytes = rep_off + (size_t)HIST_REPLICAS * hist_bytes;
-    tk->block_bytes = (tk->block_bytes + 15) & ~(size_t)15;
-    if ((rc = ensure(ctx, tk->d_block, tk->block_bytes))) return rc;
-    tk->d_hist_rep = tk->hist_fused ? (uint64_t *)((char *)tk->d_block.p + rep_off) : nullptr;
-    tk->d_flags = (uint32_t *)tk->d_block.p;
-    tk->d_hist = (uint64_t *)((char *)tk->d_block.p + 8 * sizeof(uint32_t));
-    tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;
-    if ((rc = ensure(ctx, tk->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
-    if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
-    const size_t no = ctx->n_ordered ? ctx->n_ordered : 1;
-    if ((rc = ensure(ctx, tk->d_ord_tfirst, no * sizeof(uint32_t))) || (rc = ensure(ctx, tk->d_ord_tspan, no * sizeof(uint32_t))) ||
-        (rc = ensure(ctx, tk->d_ord_off, no * sizeof(uint64_t))) ||
-        (rc = ensure(ctx, tk->d_win_lo, ((no + 63) / 64) * sizeof(uint32_t))) ||
-        (rc = ensure(ctx, tk->d_win_hi, ((no + 63) / 64) * sizeof(uint32_t))))
-        return rc;
-    if (!rows && ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx)))) return rc;
-    if (!tk->ev_pre) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_pre, hipEventDisableTiming));
-    if (!tk->ev_cov) PNX_HIP(ctx, hipEventCreateWithFlags(&tk->ev_cov, hipEventDisableTiming));
-    const bool phased = ctx->s_pre != ctx->s_main;  // three streams chained by events (see pnx_context.hpp)
-
-    // ---- phase 1 (s_pre, behind this pass's K0 if it has one): counters cleared, the index of the
-    // ordered paths laid out in visiting order
-    // flags, histogram and per-group "general" marks of this pass: one clear
-    if (tk->has_reader) {
-        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_pre, tk->ev_reader, 0));
-        tk->has_reader = false;
-    }
-    // (a pass over rows with paths in the order: the kernel that lays the order out clears the block)
-    if (!(rows && ctx->n_ordered)) PNX_HIP(ctx, hipMemsetAsync(tk->d_block.p, 0, tk->block_bytes, ctx->s_pre));
-
-    tk->band = rows && ctx->pass_band;
-    if (tk->band) {
-        // ---- phases 1 + 2 straight over the steps, one read (kernels_band.hip): the first sweep of a graph with sorted paths
-        if ((rc = launch_band_phases(ctx, ctx->want_M))) return rc;
-    } else if (rows) {
-        // ---- phases 1 + 2 over path rows (kernels_rows.hip): no boundary index, no routes
-        if ((rc = launch_rows_phases(ctx, ctx->want_M))) return rc;
-    } else {
+    int rc;
+    if ((rc = ensure_path_spans(ctx)) || (rc = normalize_order(ctx))) return rc;
+    const bool phased = ctx->s_pre != ctx->s_main;
     if (ctx->n_ordered) {
         prof_begin(ctx, PNX_K_SCATTER, ctx->s_pre);
         hipLaunchKernelGGL(k_count_general, dim3((ctx->n_ordered + 255) / 256), dim3(256), 0, ctx->s_pre,
@@ -1568,16 +1502,19 @@ int launch_cover_pass(pnx_ctx *ctx) {
     prof_end(ctx);
     if (rc) return rc;
     PNX_HIP(ctx, hipGetLastError());
-    }
-    if (phased) {
-        PNX_HIP(ctx, hipEventRecord(tk->ev_cov, ctx->s_main));
-        PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_post, tk->ev_cov, 0));
-    }
+    return PNX_OK;
+}
 
-    // ---- phase 3 (s_post): the histogram of the coverage vector (K2, kernels_hist.hip)
-    if ((rc = launch_hist(ctx, tk))) return rc;
-    ctx->M_valid = false;  // settled by the verification in pnx_api
+static int sort_runs_if_needed(pnx_ctx *ctx) {
+    if (ctx->n_runs && !ctx->runs_sorted) return sort_run_index(ctx);
     return PNX_OK;
 }
 
 }  // namespace pnx
+
+// the table the product library asks for when a step route is configured (pass_pipeline.hip: step_routes)
+extern "C" const pnx::StepRoutes *pnx_step_routes_table() {
+    static const pnx::StepRoutes t{pnx::prepare_steps, pnx::restore_step_order, pnx::launch_tile_index, pnx::build_run_index,
+                                   pnx::sort_runs_if_needed, pnx::launch_step_phases};
+    return &t;
+}

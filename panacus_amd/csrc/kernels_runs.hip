@@ -229,20 +229,6 @@ int sort_run_index(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
-// chunk prefix of the graph (the host knows path_off): once per upload
-int ensure_chunk_off(pnx_ctx *ctx) {
-    if (ctx->chunk_off_valid) return PNX_OK;
-    const uint32_t P = ctx->n_paths;
-    ctx->h_chunk_off.assign((size_t)P + 1, 0);
-    for (uint32_t p = 0; p < P; ++p)
-        ctx->h_chunk_off[p + 1] = ctx->h_chunk_off[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + RUN_CHUNK - 1) / RUN_CHUNK;
-    int rc = ensure(ctx, ctx->d_chunk_off, ((size_t)P + 1) * 8);
-    if (rc) return rc;
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->d_chunk_off.p, ctx->h_chunk_off.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    ctx->chunk_off_valid = true;  // h_chunk_off stays alive with the context
-    return PNX_OK;
-}
-
 // classify every path that is not tile-monotone (path_class 1, 2 or 3 on the device) into
 // run route (2) or scatter route (3) and build the run list of the run-route paths
 int build_run_index(pnx_ctx *ctx) {

@@ -238,7 +238,9 @@ static int settle_oldest(pnx_ctx *ctx) {
         int rc;
         if (need_build) {
             // cut the non-monotone paths into runs (tile route) or leave them to the scatter route
-            if ((rc = build_run_index(ctx))) return rc;
+            const StepRoutes *sr = step_routes(ctx);
+            if (!sr) return PNX_EINVAL;
+            if ((rc = sr->build_run_index(ctx))) return rc;
             ctx->last_general_paths = ctx->n_scatter_paths;
         } else {
             ctx->last_general_paths = t->h_flags[1];  // > 0: the re-run allocates and merges M
@@ -712,7 +714,8 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     if (src->d_items.borrowed) return dst->fail(PNX_EINVAL, "pnx_share_csr: the source itself borrows its graph");
     PNX_HIP(dst, hipSetDevice(dst->device));
     // the packed steps and the path classes are derived data of the graph: made once, by the owner
-    if (int prc = use_rows(src) ? ensure_rows(src, false) : prepare_steps(src)) return dst->fail(prc, "pnx_share_csr: %s", src->err.c_str());
+    if (!use_rows(src) && !step_routes(src)) return dst->fail(PNX_EINVAL, "pnx_share_csr: %s", src->err.c_str());
+    if (int prc = use_rows(src) ? ensure_rows(src, false) : step_routes(src)->prepare_steps(src)) return dst->fail(prc, "pnx_share_csr: %s", src->err.c_str());
     PNX_HIP(dst, hipStreamSynchronize(src->stream));  // its upload is complete
     invalidate_results(dst);
     dst->have_csr = false;
@@ -769,7 +772,8 @@ int pnx_prepare(pnx_ctx *ctx) {
     if (!ctx) return PNX_EINVAL;
     if (!ctx->have_csr) return ctx->fail(PNX_EINVAL, "pnx_prepare before a graph is resident");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = use_rows(ctx) ? ensure_rows(ctx, false) : prepare_steps(ctx);
+    if (!use_rows(ctx) && !step_routes(ctx)) return PNX_EINVAL;
+    int rc = use_rows(ctx) ? ensure_rows(ctx, false) : step_routes(ctx)->prepare_steps(ctx);
     if (rc) return rc;
     PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PNX_OK;
@@ -788,7 +792,7 @@ int pnx_get_csr(pnx_ctx *ctx, uint64_t *n_steps, uint32_t *items, uint64_t *path
         if (ctx->relabeled || ctx->n_sorted_paths) {  // the caller's ids, the caller's order
             if ((rc = ensure(ctx, tmp_items, ctx->n_steps * sizeof(uint32_t) + 64))) return rc;
             e = hipMemcpyAsync(tmp_items.p, ctx->d_items.p, ctx->n_steps * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) rc = restore_step_order(ctx, (uint32_t *)tmp_items.p);
+            if (e == hipSuccess && ctx->n_sorted_paths) rc = step_routes(ctx) ? step_routes(ctx)->restore_step_order(ctx, (uint32_t *)tmp_items.p) : PNX_EINVAL;
             if (e == hipSuccess && !rc && ctx->relabeled) rc = steps_to_caller_ids(ctx, (uint32_t *)tmp_items.p, ctx->n_steps);
             src = tmp_items.p;
         }
@@ -872,7 +876,9 @@ int pnx_hist_async(pnx_ctx *ctx) {
         // a kept index is shared by the passes: nothing may still be reading it while it is rebuilt
         if (ctx->cache_index && ctx->tk_count && (rc = drain_streams(ctx))) return rc;
         drop_run_index(ctx);  // path classes are reset with the index
-        if ((rc = launch_tile_index(ctx))) return rc;
+        const StepRoutes *sr = step_routes(ctx);
+        if (!sr) return PNX_EINVAL;
+        if ((rc = sr->launch_tile_index(ctx))) return rc;
         ctx->index_valid = true;
     }
     ctx->hist_valid = false;
@@ -1240,6 +1246,7 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             return PNX_OK;
         case PNX_CFG_COVER_VARIANT:
             if (value < 0 || value > 3) return ctx->fail(PNX_EINVAL, "cover variant must be 0, 1, 2 or 3");
+            if (value != 3 && !step_routes(ctx)) return PNX_EINVAL;  // the cross-check module is not installed: the error says so
             if ((int)value != ctx->cover_variant && ctx->have_csr) {
                 invalidate_results(ctx);
                 ctx->index_valid = false;

@@ -316,12 +316,20 @@ void prof_end(pnx_ctx *ctx);
 int drain_streams(pnx_ctx *ctx);  // waits for everything enqueued on the context's pass streams
 int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
-// kernels_cover.hip
+// pass_pipeline.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
-int prepare_steps(pnx_ctx *ctx);  // d_steps12 + d_path_mono (no-op when done)
-int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);  // sorted paths back in the caller's order (pnx_get_csr)
-int launch_tile_index(pnx_ctx *ctx);
-int launch_cover_pass(pnx_ctx *ctx);  // scatter + cover + hist for the current order
+int launch_cover_pass(pnx_ctx *ctx);  // phases 1 + 2 (rows / band / step routes) + the histogram phase, for the current order
+int ensure_chunk_off(pnx_ctx *ctx);
+// The step routes (kernels_cover.hip, kernels_runs.hip): a cross-check module, libpanacus_hip_steps.so, opened on demand.
+struct StepRoutes {
+    int (*prepare_steps)(pnx_ctx *ctx);                                    // d_steps12 + d_path_mono (no-op when done)
+    int (*restore_step_order)(pnx_ctx *ctx, uint32_t *d_items_copy);       // sorted paths back in the caller's order (pnx_get_csr)
+    int (*launch_tile_index)(pnx_ctx *ctx);
+    int (*build_run_index)(pnx_ctx *ctx);
+    int (*sort_run_index)(pnx_ctx *ctx);                                    // (no-op when sorted)
+    int (*launch_step_phases)(pnx_ctx *ctx, bool use_m, uint64_t m_words);  // phases 1 + 2 of a pass over the steps
+};
+const StepRoutes *step_routes(pnx_ctx *ctx);  // nullptr (and ctx->err) when the module is not installed
 // kernels_gfa.hip
 int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes);
 int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward);  // -> d_items, d_path_off, h_path_off, n_steps
@@ -334,10 +342,13 @@ int launch_rows_phases(pnx_ctx *ctx, bool write_m);    // phases 1 + 2 of a pass
 // kernels_band.hip
 bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries);  // is the one-shot route worth it for this shape?
 int launch_band_phases(pnx_ctx *ctx, bool write_m);            // phases 1 + 2 of a one-shot pass over the steps
-// kernels_runs.hip
-int ensure_chunk_off(pnx_ctx *ctx);
+// kernels_runs.hip (step-route module)
 int build_run_index(pnx_ctx *ctx);
 int sort_run_index(pnx_ctx *ctx);
+// kernels_cover.hip (step-route module)
+int prepare_steps(pnx_ctx *ctx);
+int restore_step_order(pnx_ctx *ctx, uint32_t *d_items_copy);
+int launch_tile_index(pnx_ctx *ctx);
 // kernels_growth.hip
 int launch_growth(pnx_ctx *ctx, bool identity_perm);
 int ensure_weight_planes(pnx_ctx *ctx, uint32_t *d_scratch = nullptr);  // W_p in presence layout

@@ -105,3 +105,20 @@ def test_plain_c_program_computes_on_the_gpu(tmp_path):
     rc, out = _plain_c_host(tmp_path)
     assert rc == 0 and "hist 0 2 cnt 1 1" in out, out
 
+
+
+def test_step_routes_are_a_module_beside_the_product_library():
+    """round 2's step routes (kernels_cover.hip, kernels_runs.hip) are cross-check code: built into libpanacus_hip_steps.so,
+    which the product library opens only when PNX_CFG_COVER_VARIANT asks for a step route -- its own symbols hold none of them"""
+    import os
+    import subprocess
+    from panacus_amd import _build
+    _build.build_hip()
+    prod = subprocess.run(["nm", "-D", "--defined-only", _build.LIB_HIP], capture_output=True, text=True, check=True).stdout
+    mod = subprocess.run(["nm", "-D", "--defined-only", _build.LIB_STEPS], capture_output=True, text=True, check=True).stdout
+    for sym in ("k_tile_cover", "k_tile_index", "k_runs_count", "k_pack12", "prepare_steps", "build_run_index"):
+        assert sym not in prod, sym
+        assert sym in mod, sym
+    assert "pnx_step_routes_table" in mod and "pnx_step_routes_table" not in prod
+    assert "k_rows_cover" in prod and "k_band_cover" in prod
+    assert os.path.getsize(_build.LIB_HIP) < 12 << 20
