@@ -224,9 +224,12 @@ def cpu_baseline(ctx, n_nodes, n_paths, pairs, seed=42, passes=3, sample_nodes=N
 
 
 def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking):
-    """BASELINE.json configs[3], strong scaling by permutation sharding (module docstring)."""
+    """BASELINE.json configs[3], strong scaling by NODE-RANGE sharding: rank r holds the nodes of its range --
+    1 / N of the steps, of the presence matrix and of every order's work -- evaluates ALL R orders on them, and the
+    out[R][T][G] counters of the ranks are summed with one RCCL all-reduce on the device buffer.  Both halves of a call
+    scale: the presence pack (one read of the rank's steps) and the growth kernels."""
     from panacus_amd import capi
-    from panacus_amd.distributed import split_orders
+    from panacus_amd.distributed import even_node_range
     from panacus_amd.pansyn import random_orders
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
 
@@ -234,119 +237,118 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
     pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
     T = len(pairs)
     dev = f"cuda:{local_rank}"
-    ctx = capi.Context(local_rank)
-    if blocking:
-        ctx.config(capi.CFG_BLOCKING_SYNC, 1)
-    ctx.config(capi.CFG_KEEP_PRESENCE, 1)
-    ctx.set_csr_pansyn(args.seed, N, P, with_weights=False)  # the SAME graph on every rank
     order = np.arange(P, dtype=np.uint32)
-    ctx.set_order(order, order, P)
     cov = [coverage_abs(Threshold(ABSOLUTE, c), P) for c, _ in pairs]
     qt = np.stack([quorum_table(Threshold(RELATIVE, q), P) for _, q in pairs])
     perms = random_orders(args.seed, R, P)
-    mine = list(split_orders(R, world, rank))
-    my_perms = perms[mine] if mine else perms[:0]
 
-    def sync_all():
+    def make(lo, hi):
+        c = capi.Context(local_rank)
+        if blocking:
+            c.config(capi.CFG_BLOCKING_SYNC, 1)
+        c.config(capi.CFG_KEEP_PRESENCE, 1)
+        c.set_csr_pansyn_shard(args.seed, lo, hi - lo, P, with_weights=False)
+        c.set_order(order, order, P)
+        return c
+
+    def sync_all(c):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        c.sync()
 
-    # what every rank has to derive before it can evaluate an order: the presence matrix of the groups -- ONE read of the steps
-    # (the one-shot route writes the matrix beside the coverage vector, kernels_band.hip), then resident
-    ctx.hist(want_countable=False)   # first call: allocations, code objects
-    ctx.profile_enable(True)
-    packs = []
-    for _ in range(3):
-        ctx.config(capi.CFG_DROP_DERIVED, 0)
-        ctx.set_order(order, order, P)
-        ctx.profile_reset()
-        sync_all()
-        t0 = time.perf_counter()
-        ctx.hist(want_countable=False)
-        packs.append(time.perf_counter() - t0)
-    pack_s = sorted(packs)[1]
-    pk = ctx.profile_read()
-    info = ctx.info()
-    pack_route = "one-shot over the steps (k_band_cover, WRITE_M)" if int(info.n_rows) == 0 else "path rows (k_rows_build + k_rows_cover)"
+    def pack_time(c, solo=False):
+        """the presence matrix of the groups from the resident steps: ONE read of them (the one-shot route writes the matrix
+        beside the coverage vector; a shard too small for it derives the path rows first), then resident"""
+        c.hist(want_countable=False)   # first call: allocations, code objects
+        c.profile_enable(True)
+        packs = []
+        for _ in range(3):
+            c.config(capi.CFG_DROP_DERIVED, 0)
+            c.set_order(order, order, P)
+            c.profile_reset()
+            if solo:  # (rank 0 alone on the whole graph: no barrier)
+                torch.cuda.synchronize()
+                c.sync()
+            else:
+                sync_all(c)
+            t0 = time.perf_counter()
+            c.hist(want_countable=False)
+            packs.append(time.perf_counter() - t0)
+        pk = c.profile_read()
+        info = c.info()
+        route = "one-shot over the steps (k_band_cover, WRITE_M)" if int(info.n_rows) == 0 else "path rows (k_rows_build + k_rows_cover)"
+        return sorted(packs)[1], pk, info, route
 
-    # ---- all R orders on one GPU: the single-GPU time (every rank could; rank 0's is reported) ----
+    lo, hi = even_node_range(N, world, rank)
+    ctx = make(lo, hi)
+    pack_s, pk, info, pack_route = pack_time(ctx)
+    steps_mine = int(info.n_steps)
+
+    # ---- the sharded call: all R orders on my nodes -> out[R][T][G] -> RCCL all-reduce on the library's stream and buffer ----
     ctx.ordered_growth(cov, qt, perms[:1])  # masks, first launch
     ctx.profile_reset()
-    single = None
-    t1 = None
-    if rank == 0:
+    ar_ms = 0.0
+    if not use_dist:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            single = ctx.ordered_growth(cov, qt, perms)
-        t1 = (time.perf_counter() - t0) / reps
-    k1 = ctx.profile_read()["growth"]
-    ctx.profile_reset()
-
-    if not use_dist:
-        dt, full_host, ar_ms, gk_ms = t1, single, 0.0, k1[0] / max(k1[1], 1)
+            full_host = ctx.ordered_growth(cov, qt, perms)
+        dt = (time.perf_counter() - t0) / reps
+        gk = ctx.profile_read()["growth"]
+        gk_ms = gk[0] / max(gk[1], 1)
     else:
-        # ---- the sharded call: my orders -> full[R][T][G] (zeros elsewhere) -> RCCL all-reduce, all on
-        # the library's stream and on device buffers; rank 0 then copies the 8*R*T*G bytes to the host
         ext = torch.cuda.ExternalStream(ctx.stream(), device=dev)
-        full = torch.zeros((R, T, P), dtype=torch.int64, device=dev)
         host = torch.zeros((R, T, P), dtype=torch.int64).pin_memory()
         ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         done = torch.cuda.Event(blocking=blocking)
-        idx = torch.tensor(mine, dtype=torch.int64, device=dev)
         views = {}
         native = args.collective == "native"
         if native:
-            ctx.config(capi.CFG_COMM_REDUCE_HIST, 0)  # orders are sharded here, not items: nothing to reduce per pass
+            ctx.config(capi.CFG_COMM_REDUCE_HIST, 0)  # (the pack's histogram is not asked for here)
             uid = [capi.Context.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0], rank, world)
 
         def call(k):
-            if mine:
-                ctx.ordered_growth_async(cov, qt, my_perms)
-                d_out = ctx.ordered_growth_enqueued()
-                t = views.get(d_out)
-                if t is None:
-                    t = views[d_out] = torch.as_tensor(_DevArray(d_out, len(mine) * T * P), device=dev).view(len(mine), T, P)
+            ctx.ordered_growth_async(cov, qt, perms)
+            d_out = ctx.ordered_growth_enqueued()
+            t = views.get(d_out)
+            if t is None:
+                t = views[d_out] = torch.as_tensor(_DevArray(d_out, R * T * P), device=dev).view(R, T, P)
             with torch.cuda.stream(ext):
                 ev_a[k].record(ext)
-                full.zero_()
-                if mine:
-                    full.index_copy_(0, idx, t)
                 if native:
-                    ctx.comm_allreduce_u64(full.data_ptr(), full.numel())  # the library's communicator, same stream
+                    ctx.comm_allreduce_u64(t.data_ptr(), t.numel())  # the library's communicator, same stream
                 else:
-                    dist.all_reduce(full)  # RCCL; int64 sum == u64 sum (counts < 2^63)
+                    dist.all_reduce(t)  # RCCL, in place on the library's buffer; int64 sum == u64 sum (counts < 2^63)
                 ev_b[k].record(ext)
                 if rank == 0:
-                    host.copy_(full, non_blocking=True)
+                    host.copy_(t, non_blocking=True)
                 done.record(ext)
             done.synchronize()
 
         call(reps)  # warm-up (communicator, first launches)
-        sync_all()
+        sync_all(ctx)
         ctx.profile_reset()
         t0 = time.perf_counter()
         for k in range(reps):
             call(k)
-        sync_all()
+        sync_all(ctx)
         dt = (time.perf_counter() - t0) / reps
         gk = ctx.profile_read()["growth"]
         ar_ms = sum(ev_a[k].elapsed_time(ev_b[k]) for k in range(reps)) / reps
-        red = torch.tensor([dt, gk[0] / max(gk[1], 1), ar_ms], dtype=torch.float64, device=dev)
+        red = torch.tensor([dt, gk[0] / max(gk[1], 1), ar_ms, pack_s], dtype=torch.float64, device=dev)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
-        dt, gk_ms, ar_ms = (float(x) for x in red.tolist())
+        dt, gk_ms, ar_ms, pack_s = (float(x) for x in red.tolist())
         full_host = host.numpy().view(np.uint64).copy() if rank == 0 else None
         if native:
             ctx.comm_free()
         views.clear()
-        del ext, full, host, idx
+        del ext, host
     # ---- the same resident presence matrix through `similarity`'s group x group intersections (SURVEY 8f-2; int8 MFMA):
-    # rank 0 only, a "next"-row figure recorded with the driver's run; checked against the histogram-free identities
+    # rank 0's shard only, a "next"-row figure recorded with the driver's run; checked against the histogram-free identities
     sim = None
     if rank == 0:
         inter = ctx.group_intersections()  # warm-up: partial-sum buffers
@@ -355,56 +357,74 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
             inter = ctx.group_intersections()
         sim_ms, sim_n = ctx.profile_read()["pairs"]
         sim_ms /= max(sim_n, 1)
-        row_words = ((N + 1 + 2047) // 2048) * 64
+        row_words = ((hi - lo + 1 + 2047) // 2048) * 64
         side = (P + 127) // 128
         ops = 2 * (side * (side + 1) // 2) * 128 * 128 * row_words * 32
-        sim = {"kernel_ms": sim_ms, "int8_mfma_ops": ops, "mfma_frac_of_5_POPs_peak": ops / (sim_ms * 1e-3) / 5.0e15 if sim_ms > 0 else None,
+        sim = {"kernel_ms": sim_ms, "int8_mfma_ops": ops, "nodes": hi - lo,
+               "mfma_frac_of_5_POPs_peak": ops / (sim_ms * 1e-3) / 5.0e15 if sim_ms > 0 else None,
                "checks": {"symmetric": bool((inter == inter.T).all()), "diagonal_sum": int(np.diag(inter).sum())}}
     ctx.profile_enable(False)
+    if use_dist:
+        torch.cuda.synchronize()
+    ctx.close()
 
+    # ---- one GPU alone on the WHOLE graph (rank 0, same run, same box): what the sharded call is compared with ----
     out = None
     if rank == 0:
+        if world == 1:
+            t1, single, pack1_s, k1_ms = dt, full_host, pack_s, gk_ms
+        else:
+            c1 = make(0, N)
+            pack1_s, _, _, _ = pack_time(c1, solo=True)
+            c1.ordered_growth(cov, qt, perms[:1])
+            c1.profile_enable(True)
+            c1.profile_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                single = c1.ordered_growth(cov, qt, perms)
+            t1 = (time.perf_counter() - t0) / reps
+            k1 = c1.profile_read()["growth"]
+            k1_ms = k1[0] / max(k1[1], 1)
+            c1.profile_enable(False)
+            c1.close()
         if not np.array_equal(full_host, single):
-            raise SystemExit("permuted growth: the sharded result differs from the single-GPU result")
+            raise SystemExit("permuted growth: the sum over the node-range shards differs from the single-GPU result")
         n_words = (N + 1 + 63) // 64
-        b_growth = R * (8 * P * n_words + 8 * T * P)       # SURVEY 8(d), all R orders
-        b_pack = 4 * int(info.n_steps) + 8 * P * n_words
+        b_growth = R * (8 * P * n_words + 8 * T * P)             # SURVEY 8(d), all R orders, whole graph
+        b_pack_mine = 4 * steps_mine + 8 * P * ((hi - lo + 1 + 63) // 64)  # SURVEY 8(d), this rank's shard
         cover_ms = pk["cover"][0] / max(pk["cover"][1], 1)
         out = {
             "workload": f"ordered-histgrowth -c node -l 1,2,1 -q 0,0,0.5 over {R} random group orders (pansyn stream 7, seed "
                         f"{args.seed}), {N} nodes x {P} paths (BASELINE.json configs[3])",
             "n_gpus": world, "scaling": "strong",
-            "sharding": "orders: rank r evaluates orders r, r+N, ...; presence matrix replicated on every rank; "
-                        "RCCL all-reduce (sum) of out[R][T][G] on the device buffer, enqueued on the library's stream",
-            "orders": R, "threshold_pairs": pairs, "orders_per_rank_max": (R + world - 1) // world, "reps": reps,
+            "sharding": "node ranges: rank r holds the nodes of its range (1/N of the steps and of the presence matrix) and evaluates "
+                        "ALL orders on them; RCCL all-reduce (sum) of out[R][T][G] in place on the library's device buffer and stream",
+            "orders": R, "threshold_pairs": pairs, "nodes_per_rank_max": (N + world - 1) // world, "reps": reps,
             "seconds_per_call": dt, "orders_per_s": R / dt,
             "M_node_group_orders_per_s": N * P * R / dt / 1e6,
             "seconds_per_call_1gpu": t1, "speedup_vs_1": t1 / dt,
-            "growth_kernel_ms_rank_max": gk_ms, "growth_kernel_ms_1gpu": k1[0] / max(k1[1], 1),
+            "growth_kernel_ms_rank_max": gk_ms, "growth_kernel_ms_1gpu": k1_ms,
             "allreduce_ms": ar_ms,
             "collective_path": ("none (one rank)" if not use_dist else "rccl through the library's own communicator (pnx_comm_allreduce_u64) on pnx_stream()"
                                 if args.collective == "native" else "rccl via torch.distributed (nccl backend) on pnx_stream()"),
-            "presence_pack_ms": pack_s * 1e3, "presence_pack_route": pack_route,
+            "presence_pack_ms": pack_s * 1e3, "presence_pack_ms_1gpu": pack1_s * 1e3, "presence_pack_route": pack_route,
             "presence_pack_kernels_ms": {k: v[0] / max(v[1], 1) for k, v in pk.items() if v[1]},
             "presence_pack_cover_kernel_ms": cover_ms,
-            "presence_pack_algorithmic_bytes": b_pack,
-            "presence_pack_frac_of_hbm_peak": b_pack / pack_s / 1e9 / HBM_PEAK_GBS if pack_s > 0 else None,
-            # a COLD call: every rank packs the presence matrix itself (replicated work: it does not scale)
+            "presence_pack_algorithmic_bytes_rank0": b_pack_mine,
+            "presence_pack_frac_of_hbm_peak": b_pack_mine / pack_s / 1e9 / HBM_PEAK_GBS if pack_s > 0 else None,
+            # a COLD call: the presence pack from the resident steps + the growth call; both are sharded
             "seconds_per_call_incl_pack": dt + pack_s,
-            "speedup_vs_1_incl_pack": (t1 + pack_s) / (dt + pack_s),
-            "incl_pack_note": "incl_pack = the presence pack from the resident steps (one read, replicated on every rank) + the growth call",
+            "speedup_vs_1_incl_pack": (t1 + pack1_s) / (dt + pack_s),
+            "incl_pack_note": "incl_pack = the presence pack from the rank's resident steps (one read) + the growth call; with node-range "
+                              "shards neither is replicated",
             "algorithmic_bytes": b_growth, "algorithmic_GBps": b_growth / dt / 1e9,
-            "steps_in_csr": int(info.n_steps),
+            "steps_in_csr_rank0": steps_mine,
             "similarity_intersections": sim,
             "checks": {"sharded_equals_single_gpu": True,
                        "growth_last": [int(full_host[0, t, -1]) for t in range(T)]},
         }
-    if use_dist:
-        torch.cuda.synchronize()
-    ctx.close()
     return out
-
-
 
 
 class OneShot:

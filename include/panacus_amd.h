@@ -230,6 +230,12 @@ int pnx_get_exclude(pnx_ctx *ctx, uint8_t *exclude);
  * node lengths (CountType::Bp). */
 int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                        int with_weights);
+/* A NODE-RANGE SHARD of the same graph: the nodes node_lo + 1 .. node_lo + n_nodes of pansyn-v1(seed, *, n_paths) become the
+ * items 1 .. n_nodes of the resident graph (a node of pansyn does not depend on how many nodes the graph has).  Items are
+ * independent for every quantity of the hot path, so D processes that each hold one range and sum their counters -- the
+ * histogram, the ordered-growth curves -- compute what one process computes on the whole graph (node-range
+ * sharding; bench.py's multi-GPU blocks). */
+int pnx_set_csr_pansyn_shard(pnx_ctx *ctx, uint64_t seed, uint64_t node_lo, uint32_t n_nodes, uint32_t n_paths, int with_weights);
 
 /* dst reads the graph that is resident in src -- the same ItemTable in HBM, no copy -- with its own
  * stream, index, counters and results.  Two contexts on one device let the short kernels of one

@@ -21,7 +21,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_exclude",
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_csr_pansyn_shard", "pnx_set_exclude",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued", "pnx_hist_enqueued_on",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.pnx_set_csr.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p]
     L.pnx_set_csr_keyed.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u64p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.pnx_set_csr_pansyn_shard.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
     L.pnx_prepare.argtypes = [vp]
     L.pnx_gfa_text_upload.argtypes = [vp, C.c_char_p, C.c_uint64]
@@ -307,6 +308,11 @@ class Context:
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
         self.n_items = n_nodes
 
+    def set_csr_pansyn_shard(self, seed, node_lo, n_nodes, n_paths, with_weights=False):
+        """pnx_set_csr_pansyn_shard: the nodes node_lo + 1 .. node_lo + n_nodes of the pansyn graph as items 1 .. n_nodes"""
+        self._ck(self._L.pnx_set_csr_pansyn_shard(self._h, seed, node_lo, n_nodes, n_paths, int(with_weights)))
+        self.n_items = n_nodes
+
     def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False,
                     edge_uv=None, edge_oo=None):
         """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device; with edge_uv / edge_oo
@@ -357,6 +363,7 @@ class Context:
         oo = None if edge_oo is None else np.ascontiguousarray(edge_oo, dtype=np.uint8)
         self._ck(self._L.pnx_set_csr_walks(self._h, n_nodes, _ptr(w, C.c_uint32), _ptr(x, C.c_uint8), _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8),
                                            0 if uv is None else len(uv) - 1))
+        self.n_items = n_nodes if uv is None else len(uv) - 1
 
     def prepare(self):
         self._ck(self._L.pnx_prepare(self._h))

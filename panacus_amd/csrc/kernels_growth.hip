@@ -685,7 +685,10 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
     if (n_chunks < 1) n_chunks = 1;
     const uint32_t max_chunks = (NB + GROW_WAVES - 1) / GROW_WAVES;
     if (n_chunks > max_chunks) n_chunks = max_chunks;
-    const uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
+    // blocks per chunk: a multiple of the waves of a workgroup (a wave takes every GROW_WAVES-th block of its chunk: 7 blocks
+    // for 4 waves leave one wave idle for an eighth of the kernel -- 2.29 -> 2.0x ms for 16 orders of cfg4)
+    uint32_t bpc = (NB + n_chunks - 1) / n_chunks;
+    if (!std::getenv("PNX_GROWTH_BPC_ANY")) bpc = (bpc + GROW_WAVES - 1) / GROW_WAVES * GROW_WAVES;
     n_chunks = (NB + bpc - 1) / bpc;
     const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;  // comparison kernel
     const bool w16 = ctx->weighted && ctx->n_wplanes <= 16;  // every weight < 2^16

@@ -23,21 +23,24 @@ constexpr uint32_t GEN_PER_THREAD = 8;
 constexpr uint32_t GEN_CHUNK = 256 * GEN_PER_THREAD;
 
 // per-node containment threshold (on the 53-bit uniform) and length
-__global__ void k_pansyn_nodes(uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
+// (node_lo: the shard holds the nodes node_lo + 1 .. node_lo + n_nodes of the graph as its items 1 .. n_nodes; a node of pansyn
+// does not depend on how many nodes the graph has, so the shards of a graph are generated independently)
+__global__ void k_pansyn_nodes(uint64_t seed, uint32_t n_nodes, uint32_t n_paths, uint64_t node_lo,
                                uint64_t *__restrict__ thr, uint32_t *__restrict__ lens) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_nodes) return;
-    if (i == 0) {
+    const uint64_t il = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (il > n_nodes) return;
+    if (il == 0) {
         thr[0] = 0;
         if (lens) lens[0] = 0;
         return;
     }
+    const uint64_t i = node_lo + il;
     uint64_t t = splitmix64(ps_key(seed, 3) + i) >> 11;
     uint64_t th;
     if (t < ONE53 / 100 * 20) th = ONE53;                 // core: every path
     else if (t < ONE53 / 100 * 65) th = ONE53 / n_paths;  // near-singleton: ~1 path
     else th = splitmix64(ps_key(seed, 4) + i) >> 11;      // shell: uniform frequency
-    thr[i] = th;
+    thr[il] = th;
     if (lens) {
         uint64_t t1 = splitmix64(ps_key(seed, 1) + i) >> 11;
         uint32_t len = 1;
@@ -48,7 +51,7 @@ __global__ void k_pansyn_nodes(uint64_t seed, uint32_t n_nodes, uint32_t n_paths
             uint64_t l = 1 + ((180 * ((k << 16) + (e & 0xFFFF))) >> 16);
             len = (uint32_t)(l > 50000 ? 50000 : l);
         }
-        lens[i] = len;
+        lens[il] = len;
     }
 }
 
@@ -64,6 +67,7 @@ __device__ static inline uint32_t block_sum_256(uint32_t v, uint32_t *sh) {
 
 __device__ static inline void node_entries(uint64_t kp, const uint64_t *__restrict__ thr,
                                            uint32_t n_nodes, uint64_t first, uint32_t cnt[GEN_PER_THREAD]) {
+    // kp: the path's key PLUS the shard's first node (the hash of (path, node) takes the node's number in the whole graph)
 #pragma unroll
     for (uint32_t e = 0; e < GEN_PER_THREAD; ++e) {
         uint64_t i = first + e;
@@ -77,11 +81,11 @@ __device__ static inline void node_entries(uint64_t kp, const uint64_t *__restri
 }
 
 __global__ __launch_bounds__(256) void k_pansyn_count(uint64_t k5, const uint64_t *__restrict__ thr,
-                                                      uint32_t n_nodes, uint32_t n_chunks,
+                                                      uint32_t n_nodes, uint32_t n_chunks, uint64_t node_lo,
                                                       uint32_t *__restrict__ counts) {
     __shared__ uint32_t sh[4];
     const uint32_t p = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
-    const uint64_t kp = splitmix64(k5 + p);
+    const uint64_t kp = splitmix64(k5 + p) + node_lo;
     uint32_t cnt[GEN_PER_THREAD];
     node_entries(kp, thr, n_nodes, (uint64_t)c * GEN_CHUNK + threadIdx.x * GEN_PER_THREAD + 1, cnt);
     uint32_t s = 0;
@@ -117,13 +121,13 @@ __global__ __launch_bounds__(256) void k_pansyn_scan(const uint32_t *__restrict_
 }
 
 __global__ __launch_bounds__(256) void k_pansyn_fill(uint64_t k5, const uint64_t *__restrict__ thr,
-                                                     uint32_t n_nodes, uint32_t n_chunks,
+                                                     uint32_t n_nodes, uint32_t n_chunks, uint64_t node_lo,
                                                      const uint64_t *__restrict__ chunk_base,
                                                      const uint64_t *__restrict__ path_off,
                                                      uint32_t *__restrict__ items) {
     __shared__ uint32_t sh[256];
     const uint32_t p = blockIdx.x / n_chunks, c = blockIdx.x % n_chunks;
-    const uint64_t kp = splitmix64(k5 + p);
+    const uint64_t kp = splitmix64(k5 + p) + node_lo;
     const uint64_t first = (uint64_t)c * GEN_CHUNK + threadIdx.x * GEN_PER_THREAD + 1;
     uint32_t cnt[GEN_PER_THREAD];
     node_entries(kp, thr, n_nodes, first, cnt);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pansyn_fill(uint64_t k5, const uint64_t
     }
 }
 
-int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
+int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights, uint64_t node_lo) {
     int rc;
     const uint32_t n_chunks = (n_nodes + GEN_CHUNK - 1) / GEN_CHUNK;
     const uint64_t nb = (uint64_t)n_paths * n_chunks;
@@ -177,9 +181,9 @@ int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32
     }
     const uint64_t k5 = ps_key(seed, 5);
     hipLaunchKernelGGL(k_pansyn_nodes, dim3((n_nodes + 1 + 255) / 256), dim3(256), 0, ctx->stream, seed, n_nodes,
-                       n_paths, (uint64_t *)d_thr.p, d_lens);
+                       n_paths, node_lo, (uint64_t *)d_thr.p, d_lens);
     hipLaunchKernelGGL(k_pansyn_count, dim3((unsigned)nb), dim3(256), 0, ctx->stream, k5, (const uint64_t *)d_thr.p,
-                       n_nodes, n_chunks, (uint32_t *)d_counts.p);
+                       n_nodes, n_chunks, node_lo, (uint32_t *)d_counts.p);
     hipLaunchKernelGGL(k_pansyn_scan, dim3(n_paths), dim3(256), 0, ctx->stream, (const uint32_t *)d_counts.p,
                        n_chunks, (uint64_t *)d_base.p, (uint64_t *)d_len.p);
     std::vector<uint64_t> len(n_paths);
@@ -203,7 +207,7 @@ int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32
         return ctx->fail(PNX_EHIP, "pansyn: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(k_pansyn_fill, dim3((unsigned)nb), dim3(256), 0, ctx->stream, k5, (const uint64_t *)d_thr.p,
-                       n_nodes, n_chunks, (const uint64_t *)d_base.p, (const uint64_t *)ctx->d_path_off.p,
+                       n_nodes, n_chunks, node_lo, (const uint64_t *)d_base.p, (const uint64_t *)ctx->d_path_off.p,
                        (uint32_t *)ctx->d_items.p);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -691,13 +691,17 @@ int pnx_get_exclude(pnx_ctx *ctx, uint8_t *exclude) {
 }
 
 int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
+    return pnx_set_csr_pansyn_shard(ctx, seed, 0, n_nodes, n_paths, with_weights);
+}
+
+int pnx_set_csr_pansyn_shard(pnx_ctx *ctx, uint64_t seed, uint64_t node_lo, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
     if (!ctx) return PNX_EINVAL;
     if (n_nodes == 0 || n_paths == 0) return ctx->fail(PNX_EINVAL, "n_nodes and n_paths must be > 0");
     if (n_nodes >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes must be < 2^32-2");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
     drop_gfa_text(ctx);
-    int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights);
+    int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights, node_lo);
     if (rc) return rc;
     ctx->have_exclude = false;
     ctx->relabeled = false;

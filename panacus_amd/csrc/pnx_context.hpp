@@ -374,6 +374,6 @@ int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
 int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
-                           int with_weights);
+                           int with_weights, uint64_t node_lo = 0);
 
 }  // namespace pnx

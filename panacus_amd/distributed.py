@@ -87,6 +87,15 @@ def gather_countable(local: np.ndarray, cuts: np.ndarray, rank: int, device=None
     return out
 
 
+def even_node_range(n_items: int, world: int, rank: int):
+    """Node-range shard of a graph whose steps are spread evenly over the ids (pansyn): rank r owns the nodes
+    lo + 1 .. hi, ranges of whole 2048-item tiles.  -> (lo, hi)"""
+    tiles = (n_items + 2047) // 2048
+    lo = min(n_items, (tiles * rank // world) * 2048)
+    hi = min(n_items, (tiles * (rank + 1) // world) * 2048) if rank + 1 < world else n_items
+    return lo, hi
+
+
 def split_orders(n_orders: int, world: int, rank: int) -> range:
     """Permutation sharding for permuted growth: rank r evaluates orders r, r+world, ..."""
     return range(rank, n_orders, world)

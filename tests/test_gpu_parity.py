@@ -1231,6 +1231,48 @@ def test_full_size_cfg3_properties():
         assert np.all(cnt2[1:] <= cnt[1:]) and np.all(2 * cnt2[1:].astype(np.int64) >= cnt[1:])
 
 
+def test_node_range_shards_of_the_generated_graph_sum_to_the_whole():
+    """pnx_set_csr_pansyn_shard: the nodes lo + 1 .. hi of pansyn(seed, N, P) as items 1 .. hi - lo -- the steps of the whole
+    graph restricted to the range, re-based (distributed.shard_csr on the CPU generator's graph).  Items are independent, so
+    histograms and ordered-growth curves of the shards add up to those of the whole graph: what bench.py's multi-GPU blocks do
+    with one shard per rank and an all-reduce, done here with one GPU, one shard after the other."""
+    from panacus_amd import capi
+    from panacus_amd.distributed import even_node_range, shard_csr
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n, p, world = 150_000, 24, 3
+    items, pre, lens = orc.pansyn(9, n, p)
+    order = np.arange(p, dtype=np.uint32)
+    gid = (order // 2).astype(np.uint32)
+    G = p // 2
+    cov = [coverage_abs(Threshold(ABSOLUTE, c), G) for c in (1, 2, 1)]
+    qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for q in (0.0, 0.0, 0.5)])
+    perms = random_orders(5, 6, G)
+    with capi.Context(0) as c:
+        c.set_csr_pansyn(9, n, p, with_weights=True)
+        c.set_order(order, gid, G)
+        cnt_all, h_all = c.hist()
+        out_all = c.ordered_growth(cov, qt, perms)
+        h_sum = np.zeros_like(h_all)
+        out_sum = np.zeros_like(out_all)
+        edges = []
+        for r in range(world):
+            lo, hi = even_node_range(n, world, r)
+            edges.append((lo, hi))
+            c.set_csr_pansyn_shard(9, lo, hi - lo, p, with_weights=True)
+            got, off, w = c.get_csr(want_weights=True)
+            want_items, want_off, n_r = shard_csr(items, pre, lo + 1, hi + 1)
+            assert n_r == hi - lo and np.array_equal(got, want_items) and np.array_equal(off, want_off)
+            assert np.array_equal(w[1:], lens[lo + 1:hi + 1])
+            c.set_order(order, gid, G)
+            cnt, h = c.hist()
+            assert np.array_equal(cnt[1:], cnt_all[lo + 1:hi + 1])
+            h_sum += h
+            out_sum += c.ordered_growth(cov, qt, perms)
+        assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[k][1] == edges[k + 1][0] for k in range(world - 1))
+        assert np.array_equal(h_sum, h_all) and np.array_equal(out_sum, out_all)
+
+
 def test_full_size_10Mx1k_against_the_oracle():
     """north_star's shape (10 M nodes x 1024 paths, 3.9 G steps) through the one-shot route, the WHOLE coverage vector and the
     histogram against the serial restatement of abacus.rs:719-787: with every path its own group the coverage of a graph is
