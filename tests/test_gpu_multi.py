@@ -94,9 +94,10 @@ def test_two_gpus_node_range_shards_equal_one_gpu(tmp_path, backend, variant):
 
 @needs_two
 @pytest.mark.parametrize("collective", ["torch", "native"])
-def test_bench_launches_its_ranks_and_shards_the_orders(collective):
+def test_bench_launches_its_ranks_and_shards_the_nodes(collective):
     """`bench.py --gpus 2` starts two ranks by itself; the JSON line says n_gpus = 2, the weak-scaling histogram covers
-    both shards, and the order-sharded permuted growth equals the single-GPU result bit for bit (the bench fails otherwise)"""
+    both shards, and the permuted growth summed over the node-range shards equals the single-GPU result on the whole graph bit for
+    bit (the bench fails otherwise)"""
     small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--pg-nodes", "150000", "--pg-paths", "40",
              "--pg-orders", "10", "--pg-reps", "2", "--no-pmc", "--collective", collective]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, stdout=subprocess.PIPE,
@@ -108,4 +109,4 @@ def test_bench_launches_its_ranks_and_shards_the_orders(collective):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["checks"]["hist_sum"] == d["checks"]["expected_hist_sum"] == 400000
     pg = d["permuted_growth"]
     assert pg["n_gpus"] == 2 and pg["scaling"] == "strong" and pg["checks"]["sharded_equals_single_gpu"] and pg["allreduce_ms"] > 0
-    assert pg["orders_per_rank_max"] == 5 and "rccl" in pg["collective_path"]
+    assert pg["nodes_per_rank_max"] == 75000 and "rccl" in pg["collective_path"] and pg["speedup_vs_1"] > 0
