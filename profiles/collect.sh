@@ -4,7 +4,7 @@
 # --kernel-trace + counters of one block each; no trace domains mixed in).  Results land in
 # gpurun_out/profiles/ and are copied into profiles/ by hand.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -35,7 +35,10 @@ rm -rf /tmp/p_1k; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/p_1k -o k
     python $REPO/bench.py --paths 1024 --steps 10 --warmup 2 $HEAD_ONLY > $OUT/${R}_hist_10Mx1024_bench_under_rocprof.json 2>/dev/null
 python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_1k)" $OUT/${R}_hist_10Mx1024_kernel_stats.csv > /dev/null
 
-# 4. cfg4: presence pack (K1 with row stores) + permuted growth (K4): kernel stats and counters
+# 3b. the same shape, node-range share of one of 8 ranks in permuted growth (1.25 M nodes x 512 paths x 128 orders)
+timeout 900 python $REPO/benchmarks/bench_ordered_growth.py --reps 5 --warm-full --nodes 1250000 > $OUT/${R}_growth_cfg4_node_shard_of_8_bench.json 2>/dev/null
+
+# 4. cfg4: presence pack (one-shot route with row stores) + permuted growth (K4): kernel stats and counters
 timeout 900 python $REPO/benchmarks/bench_ordered_growth.py --reps 5 --warm-full > $OUT/${R}_growth_cfg4_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_ordered_growth.py --reps 5 --warm-full --orders 16 > $OUT/${R}_growth_cfg4_R16_bench.json 2>/dev/null
 timeout 900 python $REPO/benchmarks/bench_ordered_growth.py --reps 5 --warm-full --bp > $OUT/${R}_growth_cfg4_bp_bench.json 2>/dev/null
@@ -73,7 +76,9 @@ done
 timeout 300 python $REPO/benchmarks/bench_rows.py --steps 30 > $OUT/${R}_rows_cfg3_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_rows.py --paths 1024 --steps 10 --splits 0 > $OUT/${R}_rows_10Mx1024_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_closed_form.py > $OUT/${R}_closed_form_bench.json 2>/dev/null
-timeout 300 python $REPO/benchmarks/bench_step_overheads.py 2>/dev/null | tail -1 > $OUT/${R}_step_overheads.json
+timeout 300 python $REPO/benchmarks/bench_band.py --steps 30 > $OUT/${R}_band_cfg3_bench.json 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_band.py --paths 1024 --steps 10 > $OUT/${R}_band_10Mx1024_bench.json 2>/dev/null
+timeout 300 python $REPO/benchmarks/bench_band_fallback.py > $OUT/${R}_band_fallback_bench.json 2>/dev/null
 for N in 256 1024; do
     rm -rf /tmp/p_cf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cf -o cf -- python $REPO/benchmarks/bench_closed_form.py $N > /dev/null 2>&1
     python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cf)" $OUT/${R}_closed_form_n${N}_kernel_stats.csv > /dev/null
