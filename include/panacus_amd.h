@@ -100,6 +100,17 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        parse_walk_seq_to_item_vec do per step with edge2id, util.rs:1048-1091) and the EDGE ItemTable --
  *                        a path of k steps has k - 1 entries -- becomes the resident graph with n_edges items; a step pair
  *                        without an edge fails the call (the reference panics, util.rs:1080).  weights must be NULL.
+ *   name_off, name_len   (round 4) segment names that are NOT numbers -- `s12`, `utg000012l`, ... : per node (id - 1) the byte
+ *                        offset of its name inside text (the name field of its S line) and its length.  The library builds the
+ *                        node2id map of graph.rs:308-375 in HBM -- a hash table keyed by the name bytes -- and the tokeniser looks
+ *                        every step up there (graph.rs:231, per step, on the host in the reference).  Names of up to 16 bytes;
+ *                        a longer one fails the call with PNX_ELIMIT (such graphs keep the host's parser); a name that occurs
+ *                        twice fails it with PNX_EINVAL (the reference panics, graph.rs:336).  id_of_name must be NULL.
+ *   link_off, n_links    (round 4) edge counts WITHOUT the host's edge map: the byte offset of every L line inside text, in file
+ *                        order.  The library parses the lines (both names and orientations, graph.rs:276-306), puts every edge
+ *                        in canonical form (graph.rs:142-148), numbers the distinct ones by their first line (duplicates are
+ *                        skipped as the reference skips them, graph.rs:296) and looks the step pairs up as above; n_edges is
+ *                        reported by pnx_info (n_items).  edge_uv / edge_oo must be NULL then.
  * pnx_gfa_text_upload copies synchronously; the library frees its copy of the text at the end of pnx_set_csr_gfa. */
 typedef struct pnx_gfa_steps {
     const char *text;
@@ -112,6 +123,10 @@ typedef struct pnx_gfa_steps {
     const uint64_t *edge_uv;
     const uint8_t *edge_oo;
     uint32_t n_edges;
+    const uint64_t *name_off;
+    const uint8_t *name_len;
+    const uint64_t *link_off;
+    uint64_t n_links;
 } pnx_gfa_steps;
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
@@ -129,6 +144,8 @@ int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *steps, uint64_t *walk_off);
  * table and clones it (graph_broker/util.rs:201-204) and parses the file again for the edges (graph_broker.rs:404-422). */
 int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, const uint8_t *exclude, const uint64_t *edge_uv,
                       const uint8_t *edge_oo, uint32_t n_edges);
+/* n_edges of pnx_set_csr_walks (with edge_uv == NULL): the edges are the ones of the L lines that pnx_gfa_walks parsed (link_off) */
+#define PNX_EDGES_FROM_LINKS 0xFFFFFFFFu
 
 /* Replace the exclusion flags of the resident graph (NULL = none): the `exclude_table` argument of
  * AbacusByTotal::item_table_to_abacus (abacus.rs:539-547; ActiveTable::items, src/util.rs:118-124)

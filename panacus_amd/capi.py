@@ -65,7 +65,9 @@ class PnxGfaSteps(C.Structure):  # pnx_gfa_steps
     _fields_ = [("text", C.c_char_p), ("text_bytes", C.c_uint64), ("n_paths", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("col_begin", C.POINTER(C.c_uint64)), ("col_end", C.POINTER(C.c_uint64)), ("is_walk", C.POINTER(C.c_uint8)),
                 ("id_of_name", C.POINTER(C.c_uint32)), ("n_names", C.c_uint64),
-                ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint32)]
+                ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint32),
+                ("name_off", C.POINTER(C.c_uint64)), ("name_len", C.POINTER(C.c_uint8)),
+                ("link_off", C.POINTER(C.c_uint64)), ("n_links", C.c_uint64)]
 
 
 class PnxPieceEvent(C.Structure):  # pnx_piece_event
@@ -314,9 +316,10 @@ class Context:
         self.n_items = n_nodes
 
     def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False,
-                    edge_uv=None, edge_oo=None):
+                    edge_uv=None, edge_oo=None, name_off=None, name_len=None, link_off=None):
         """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device; with edge_uv / edge_oo
-        (n_edges + 1 entries, [0] unused) the EDGE ItemTable of the same walks"""
+        (n_edges + 1 entries, [0] unused) the EDGE ItemTable of the same walks; name_off / name_len: segment names that are not
+        numbers, looked up in a hash table on the device; link_off: the L lines parsed on the device (edge counts)"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
         ce = np.ascontiguousarray(col_end, dtype=np.uint64)
         wk = np.ascontiguousarray(is_walk, dtype=np.uint8)
@@ -335,10 +338,15 @@ class Context:
         uv = None if edge_uv is None else np.ascontiguousarray(edge_uv, dtype=np.uint64)
         oo = None if edge_oo is None else np.ascontiguousarray(edge_oo, dtype=np.uint8)
         g.edge_uv, g.edge_oo, g.n_edges = _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8), (0 if uv is None else len(uv) - 1)
+        no = None if name_off is None else np.ascontiguousarray(name_off, dtype=np.uint64)
+        nl = None if name_len is None else np.ascontiguousarray(name_len, dtype=np.uint8)
+        lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
+        g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
+        g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
         self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
-        self.n_items = n_nodes if uv is None else len(uv) - 1
+        self.n_items = int(self.info().n_items)
 
-    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None) -> np.ndarray:
+    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, name_off=None, name_len=None, link_off=None) -> np.ndarray:
         """pnx_gfa_walks: the walks of GFA text tokenised on the device and kept there for set_csr_cut(walk_node=None, ...);
         -> their n_paths + 1 offsets"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
@@ -350,11 +358,16 @@ class Context:
         g.n_paths, g.n_nodes = len(cb), n_nodes
         g.col_begin, g.col_end, g.is_walk = _ptr(cb, C.c_uint64), _ptr(ce, C.c_uint64), _ptr(wk, C.c_uint8)
         g.id_of_name, g.n_names = _ptr(names, C.c_uint32), (0 if names is None else len(names))
+        no = None if name_off is None else np.ascontiguousarray(name_off, dtype=np.uint64)
+        nl = None if name_len is None else np.ascontiguousarray(name_len, dtype=np.uint8)
+        lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
+        g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
+        g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
         off = np.zeros(len(cb) + 1, dtype=np.uint64)
         self._ck(self._L.pnx_gfa_walks(self._h, C.byref(g), _ptr(off, C.c_uint64)))
         return off
 
-    def set_csr_walks(self, n_nodes, weights=None, exclude=None, edge_uv=None, edge_oo=None):
+    def set_csr_walks(self, n_nodes, weights=None, exclude=None, edge_uv=None, edge_oo=None, edges_from_links=False):
         """pnx_set_csr_walks: the walks gfa_walks left on the device become the resident graph (node table, or the edge table of
         the same paths) without the text being tokenised again"""
         w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
@@ -362,8 +375,8 @@ class Context:
         uv = None if edge_uv is None else np.ascontiguousarray(edge_uv, dtype=np.uint64)
         oo = None if edge_oo is None else np.ascontiguousarray(edge_oo, dtype=np.uint8)
         self._ck(self._L.pnx_set_csr_walks(self._h, n_nodes, _ptr(w, C.c_uint32), _ptr(x, C.c_uint8), _ptr(uv, C.c_uint64), _ptr(oo, C.c_uint8),
-                                           0 if uv is None else len(uv) - 1))
-        self.n_items = n_nodes if uv is None else len(uv) - 1
+                                           0xFFFFFFFF if edges_from_links else (0 if uv is None else len(uv) - 1)))
+        self.n_items = int(self.info().n_items)
 
     def prepare(self):
         self._ck(self._L.pnx_prepare(self._h))

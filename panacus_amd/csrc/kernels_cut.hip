@@ -640,7 +640,8 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
 
 // pnx_set_csr_gfa with edges: the node walks gfa_tokenise left in d_items (+ one orientation byte per step) become the edge
 // ItemTable of the same paths, on the device
-int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges) {
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges,
+                   bool edges_on_device) {
     struct Scratch {
         DevBuf e_uv, e_oo, tab_key, tab_val, eoff, out, counters;
         ~Scratch() {
@@ -663,8 +664,9 @@ int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, con
         (rc = ensure(ctx, s.tab_key, slots * 8)) || (rc = ensure(ctx, s.tab_val, slots * 4)) || (rc = ensure(ctx, s.eoff, p1 * 8)) ||
         (rc = ensure(ctx, s.out, (Se ? Se : 1) * sizeof(uint32_t) + 64)) || (rc = ensure(ctx, s.counters, 64)))
         return rc;
-    PNX_HIP(ctx, hipMemcpyAsync(s.e_uv.p, edge_uv, ((size_t)n_edges + 1) * 8, hipMemcpyHostToDevice, st));
-    PNX_HIP(ctx, hipMemcpyAsync(s.e_oo.p, edge_oo, (size_t)n_edges + 1, hipMemcpyHostToDevice, st));
+    const hipMemcpyKind kind = edges_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    PNX_HIP(ctx, hipMemcpyAsync(s.e_uv.p, edge_uv, ((size_t)n_edges + 1) * 8, kind, st));
+    PNX_HIP(ctx, hipMemcpyAsync(s.e_oo.p, edge_oo, (size_t)n_edges + 1, kind, st));
     PNX_HIP(ctx, hipMemcpyAsync(s.eoff.p, edge_off.data(), p1 * 8, hipMemcpyHostToDevice, st));
     PNX_HIP(ctx, hipMemsetAsync(s.tab_key.p, 0, slots * 8, st));
     PNX_HIP(ctx, hipMemsetAsync(s.counters.p, 0, 64, st));

@@ -23,6 +23,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "name_table.hpp"
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -122,12 +123,13 @@ __global__ __launch_bounds__(256) void k_tok_count(const uint8_t *__restrict__ t
 // decimal digits without a leading zero, a P step ends in '+' / '-' followed by ',' or the end of the column, a P
 // column does not end in ',', a W column starts with '>' / '<'.
 constexpr uint32_t TOK_LDS_PAD = 16;                    // bytes in front of the chunk (a right-aligned window may start before it)
-constexpr uint32_t TOK_LDS_BUF = TOK_LDS_PAD + 1024 + 32;  // + the 16 bytes that follow the chunk + slack for the dword reads
+constexpr uint32_t TOK_LDS_BUF = TOK_LDS_PAD + 1024 + 48;  // + the 32 bytes that follow the chunk + slack for the dword reads
 constexpr uint32_t TOK_LDS_LIST = 512;                   // a W column can start a step every 2 bytes
 
-template <bool WALK>
+// BYNAME: the names are looked up in the name table (name_table.hpp) by their bytes instead of being read as numbers
+template <bool WALK, bool BYNAME>
 __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, const TokPiece &t, uint32_t lane, uint64_t out,
-                                             const uint32_t *__restrict__ id_of_name, uint64_t n_names, uint32_t n_nodes,
+                                             const uint32_t *__restrict__ id_of_name, uint64_t n_names, const NameTab &names, uint32_t n_nodes,
                                              uint32_t *__restrict__ items, uint8_t *__restrict__ backward, uint32_t &bad, uint8_t *buf,
                                              uint16_t *list) {
     const uint64_t base = t.b & ~15ull;
@@ -157,9 +159,9 @@ __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, c
         const uint64_t pos = g0 + lane * 16ull;
         const tok_u32x4 nxt = load(pos + 1024);
         *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + lane * 16u) = cur;
-        if (lane == 0) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1024) = nxt;  // what follows the chunk
-        if (lane == 1) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1040) = tok_u32x4{0, 0, 0, 0};
-        if (lane == 2) buf[TOK_LDS_PAD - 1] = (uint8_t)last;
+        if (lane < 2) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1024 + lane * 16u) = nxt;  // the 32 bytes that follow the chunk
+        if (lane == 2) *reinterpret_cast<tok_u32x4 *>(buf + TOK_LDS_PAD + 1056) = tok_u32x4{0, 0, 0, 0};
+        if (lane == 3) buf[TOK_LDS_PAD - 1] = (uint8_t)last;
         last = ((uint32_t)__builtin_amdgcn_readlane((int)cur.w, 63)) >> 24;
         // ---- starts in this lane's 16 bytes ----
         uint32_t sp[4] = {tok_sep<WALK>(cur.x), tok_sep<WALK>(cur.y), tok_sep<WALK>(cur.z), tok_sep<WALK>(cur.w)};
@@ -205,6 +207,42 @@ __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, c
                 const uint32_t p = TOK_LDS_PAD + list[j];  // byte of the name's first character in buf
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(buf + (p & ~3u));
                 const uint32_t sh = (p & 3u) * 8u;
+                if (BYNAME) {
+                    // 20 bytes from the start: the name ends at the first separator (P: ',' W: '>' / '<') or at the end of the
+                    // column (0); a P name is followed by its sign.  Up to 16 bytes of name are the key of the lookup.
+                    const uint32_t g0 = d[0], g1 = d[1], g2 = d[2], g3 = d[3], g4 = d[4], g5 = d[5];
+                    const uint32_t x[5] = {__builtin_amdgcn_alignbit(g1, g0, sh), __builtin_amdgcn_alignbit(g2, g1, sh), __builtin_amdgcn_alignbit(g3, g2, sh),
+                                           __builtin_amdgcn_alignbit(g4, g3, sh), __builtin_amdgcn_alignbit(g5, g4, sh)};
+                    uint32_t E = 20u;
+#pragma unroll
+                    for (int w = 4; w >= 0; --w) {
+                        const uint32_t f = tok_sep<WALK>(x[w]) | tok_eq(x[w], 0u);
+                        if (f) E = 4u * (uint32_t)w + ((uint32_t)__builtin_ctz(f) >> 3);
+                    }
+                    const uint32_t nlen = WALK ? E : E - 1u;  // (E == 0: an empty P name wraps to a length no name has)
+                    uint32_t back, id = 0;
+                    bool ok = E < 20u && nlen >= 1u && nlen <= 16u;
+                    if (WALK) {
+                        back = buf[p - 1] == '<';
+                    } else {
+                        const uint32_t sign = E ? (uint32_t)buf[p + E - 1u] : 0u;
+                        ok = ok && (sign == '+' || sign == '-');
+                        back = sign == '-';
+                    }
+                    if (ok) {
+                        auto low = [](uint32_t k) { return k >= 4u ? 0xFFFFFFFFu : (k ? (1u << (8u * k)) - 1u : 0u); };
+                        const uint32_t m0 = low(nlen), m1 = low(nlen > 4u ? nlen - 4u : 0u), m2 = low(nlen > 8u ? nlen - 8u : 0u),
+                                       m3 = low(nlen > 12u ? nlen - 12u : 0u);
+                        const unsigned long long k0 = ((unsigned long long)(x[1] & m1) << 32) | (x[0] & m0);
+                        const unsigned long long k1 = ((unsigned long long)(x[3] & m3) << 32) | (x[2] & m2);
+                        id = name_lookup(names, k0, k1);
+                    }
+                    // 1: malformed, 2: unknown segment, 4: a name of more than 16 bytes (no terminator within 20: the device route does not take it)
+                    if (id == 0 || id > n_nodes) bad |= ok ? 2u : ((E >= 20u || nlen > 16u) && E != 0u ? 4u : 1u);
+                    items[out + j] = id;
+                    if (backward) backward[out + j] = (uint8_t)back;
+                    continue;
+                }
                 const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
                 const uint32_t x[3] = {__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), __builtin_amdgcn_alignbit(d3, d2, sh)};
                 // digits: bytes '0'..'9'; L = the number of leading ones among the 12 bytes
@@ -261,11 +299,12 @@ __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, c
     }
 }
 
+template <bool BYNAME>
 __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ text, const uint64_t *__restrict__ piece_off,
                                                   const uint64_t *__restrict__ col_b, const uint64_t *__restrict__ col_e,
                                                   const uint8_t *__restrict__ is_walk, uint32_t n_paths, uint64_t n_pieces,
                                                   const uint64_t *__restrict__ piece_out, const uint32_t *__restrict__ id_of_name,
-                                                  uint64_t n_names, uint32_t n_nodes, uint32_t *__restrict__ items,
+                                                  uint64_t n_names, NameTab names, uint32_t n_nodes, uint32_t *__restrict__ items,
                                                   uint8_t *__restrict__ backward, uint32_t *__restrict__ flags) {
     __shared__ __attribute__((aligned(16))) uint8_t buf_all[4][TOK_LDS_BUF];
     __shared__ uint16_t list_all[4][TOK_LDS_LIST];
@@ -275,10 +314,168 @@ __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ te
     if (c >= n_pieces) return;
     const TokPiece t = tok_piece_of(c, piece_off, col_b, col_e, is_walk, n_paths);
     uint32_t bad = 0;
-    if (t.walk) tok_emit_piece<true>(text, t, lane, piece_out[c], id_of_name, n_names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
-    else tok_emit_piece<false>(text, t, lane, piece_out[c], id_of_name, n_names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
+    if (t.walk) tok_emit_piece<true, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
+    else tok_emit_piece<false, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
     for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
     if (lane == 0 && bad) atomicOr(flags, bad);
+}
+
+// ---- the name table: one thread per S line puts its name in, a second pass makes every name find its own id ----
+__global__ void k_names_insert(const uint8_t *__restrict__ text, const uint64_t *__restrict__ name_off, const uint8_t *__restrict__ name_len,
+                               uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t len = name_len[i];
+    if (len == 0u || len > 16u) {
+        atomicOr(flags, len ? 4u : 1u);
+        return;
+    }
+    unsigned long long k0, k1;
+    name_key(text + name_off[i], len, k0, k1);
+    uint64_t slot = name_hash(k0, k1) & t.mask;
+    for (;;) {
+        if (atomicCAS(&t.e[slot].id, 0u, i + 1u) == 0u) {
+            t.e[slot].k0 = k0;
+            t.e[slot].k1 = k1;
+            return;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+}
+__global__ void k_names_verify(const uint8_t *__restrict__ text, const uint64_t *__restrict__ name_off, const uint8_t *__restrict__ name_len,
+                               uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t len = name_len[i];
+    if (len == 0u || len > 16u) return;
+    unsigned long long k0, k1;
+    name_key(text + name_off[i], len, k0, k1);
+    if (name_lookup(t, k0, k1) != i + 1u) atomicOr(flags, 8u);  // the same name sits in an earlier slot: it occurs twice
+}
+
+// ---- L lines on the device (graph.rs:276-306): both ends of every line -> canonical edge; the distinct edges numbered by
+// their FIRST line (duplicates skipped like the reference, graph.rs:296) ----
+// name of a node: decimal (the id itself, or id_of_name[number]) or, with a name table, its bytes
+struct NodeNames {
+    const uint32_t *id_of_name;
+    uint64_t n_names;
+    NameTab tab;
+    uint32_t by_name;
+};
+// the field [b, e) of the text (e: the tab behind it) as a node id; 0 = no such node; malformed -> bad |= 1
+__device__ static inline uint32_t node_of_field(const uint8_t *__restrict__ text, uint64_t b, uint64_t e, const NodeNames &nn, uint32_t n_nodes, uint32_t &bad) {
+    const uint64_t len = e - b;
+    if (len == 0) {
+        bad |= 1u;
+        return 0;
+    }
+    if (nn.by_name) {
+        if (len > 16) {
+            bad |= 4u;
+            return 0;
+        }
+        unsigned long long k0, k1;
+        name_key(text + b, (uint32_t)len, k0, k1);
+        return name_lookup(nn.tab, k0, k1);
+    }
+    if (len > 10 || (text[b] == '0' && len > 1)) {
+        bad |= 1u;
+        return 0;
+    }
+    uint64_t v = 0;
+    for (uint64_t i = b; i < e; ++i) {
+        const uint32_t c = text[i];
+        if (c < '0' || c > '9') {
+            bad |= 1u;
+            return 0;
+        }
+        v = v * 10 + (c - '0');
+    }
+    if (nn.id_of_name) return v < nn.n_names ? nn.id_of_name[v] : 0u;
+    return v <= n_nodes ? (uint32_t)v : 0u;
+}
+__global__ void k_links_parse(const uint8_t *__restrict__ text, uint64_t text_bytes, const uint64_t *__restrict__ link_off, uint64_t n_links,
+                              NodeNames nn, uint32_t n_nodes, unsigned long long *__restrict__ l_key, uint32_t *__restrict__ flags) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_links) return;
+    uint32_t bad = 0;
+    auto field_end = [&](uint64_t b) {  // first tab (or line end) at or behind b
+        uint64_t e = b;
+        while (e < text_bytes && text[e] != '\t' && text[e] != '\n') ++e;
+        return e;
+    };
+    const uint64_t a0 = link_off[k] + 2, a1 = field_end(a0);
+    unsigned long long key = 0;
+    // L <u> <o1> <v> <o2> ...: every field must end in a tab up to the second orientation
+    if (link_off[k] + 2 > text_bytes || text[link_off[k]] != 'L' || a1 + 2 >= text_bytes || text[a1] != '\t' || text[a1 + 2] != '\t') bad |= 1u;
+    else {
+        const uint64_t b0 = a1 + 3, b1 = field_end(b0);
+        if (b1 + 1 >= text_bytes || text[b1] != '\t') bad |= 1u;
+        else {
+            const uint32_t u = node_of_field(text, a0, a1, nn, n_nodes, bad), v = node_of_field(text, b0, b1, nn, n_nodes, bad);
+            const uint32_t o1 = text[a1 + 1] == '+' ? 0u : 1u, o2 = text[b1 + 1] == '+' ? 0u : 1u;
+            if (!bad && (u == 0 || u > n_nodes || v == 0 || v > n_nodes)) bad |= 2u;
+            if (!bad) {  // Edge::canonical (graph.rs:142-148); the orientations ride in the two top bits (node ids < 2^30)
+                unsigned long long uv;
+                uint32_t oo;
+                if (u > v || (u == v && o1 == 1u)) {
+                    uv = ((unsigned long long)v << 32) | u;
+                    oo = ((o2 ^ 1u) << 1) | (o1 ^ 1u);
+                } else {
+                    uv = ((unsigned long long)u << 32) | v;
+                    oo = (o1 << 1) | o2;
+                }
+                key = uv | ((unsigned long long)oo << 62);
+            }
+        }
+    }
+    l_key[k] = key;
+    if (bad) atomicOr(flags, bad);
+}
+struct LinkTab {
+    unsigned long long *key;  // 0 = empty
+    uint32_t *first;          // smallest line with this edge
+    uint64_t mask;
+};
+__device__ static inline uint64_t link_hash(unsigned long long key) {
+    uint64_t x = key * 0x9FB21C651E98DF25ull;
+    return x ^ (x >> 31);
+}
+__global__ void k_links_insert(const unsigned long long *__restrict__ l_key, uint64_t n_links, LinkTab t) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_links) return;
+    const unsigned long long key = l_key[k];
+    if (!key) return;
+    uint64_t slot = link_hash(key) & t.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(t.key + slot, 0ull, key);
+        if (prev == 0ull || prev == key) {
+            atomicMin(t.first + slot, (uint32_t)k);
+            return;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+}
+__global__ void k_links_first(const unsigned long long *__restrict__ l_key, uint64_t n_links, LinkTab t, uint32_t *__restrict__ is_first) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_links) return;
+    const unsigned long long key = l_key[k];
+    uint32_t f = 0;
+    if (key) {
+        uint64_t slot = link_hash(key) & t.mask;
+        while (t.key[slot] != key) slot = (slot + 1) & t.mask;
+        f = t.first[slot] == (uint32_t)k ? 1u : 0u;
+    }
+    is_first[k] = f;
+}
+// the distinct edges by id (= 1 + the number of first lines before theirs): canonical ends and orientations, as pnx_gfa_steps.edge_uv / edge_oo
+__global__ void k_links_emit(const unsigned long long *__restrict__ l_key, const uint32_t *__restrict__ is_first, const uint32_t *__restrict__ rank,
+                             uint64_t n_links, unsigned long long *__restrict__ e_uv, uint8_t *__restrict__ e_oo) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_links || !is_first[k]) return;
+    const uint32_t id = rank[k] + 1u;
+    e_uv[id] = l_key[k] & 0x3FFFFFFFFFFFFFFFull;
+    e_oo[id] = (uint8_t)(l_key[k] >> 62);
 }
 
 // id_prefsum: the output offset of the first piece of every path (and the total behind the last)
@@ -301,6 +498,123 @@ int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes) {
     if (n_bytes) PNX_HIP(ctx, hipMemcpy(ctx->d_gfa_text.p, text, n_bytes, hipMemcpyHostToDevice));
     ctx->gfa_text_host = text;
     ctx->gfa_text_bytes = n_bytes;
+    return PNX_OK;
+}
+
+// node2id in HBM (name_table.hpp) from the name fields of the S lines; kept in ctx->d_name_tab until the upload ends
+static int gfa_name_table(pnx_ctx *ctx, const pnx_gfa_steps *g, NameTab &names) {
+    if (!g->name_len) return ctx->fail(PNX_EINVAL, "pnx_gfa_steps: name_off without name_len");
+    if (g->id_of_name) return ctx->fail(PNX_EINVAL, "pnx_gfa_steps: name_off and id_of_name are two ways to name the segments: pass one");
+    const uint32_t n = g->n_nodes;
+    hipStream_t st = ctx->stream;
+    uint64_t slots = 1024;
+    while (slots < 2ull * n) slots <<= 1;
+    DevBuf d_off, d_len;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_name_tab, slots * sizeof(NameEntry))) || (rc = ensure(ctx, d_off, ((size_t)n + 1) * 8)) ||
+        (rc = ensure(ctx, d_len, (size_t)n + 1)) || (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) {
+        release(d_off);
+        release(d_len);
+        return rc;
+    }
+    names.e = (NameEntry *)ctx->d_name_tab.p;
+    names.mask = slots - 1;
+    hipError_t e = hipMemsetAsync(ctx->d_name_tab.p, 0, slots * sizeof(NameEntry), st);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), st);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(d_off.p, g->name_off, (size_t)n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(d_len.p, g->name_len, (size_t)n, hipMemcpyHostToDevice, st);
+    uint32_t flags = 0;
+    if (e == hipSuccess && n) {
+        const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
+        hipLaunchKernelGGL(k_names_insert, dim3((n + 255) / 256), dim3(256), 0, st, text, (const uint64_t *)d_off.p, (const uint8_t *)d_len.p, n, names,
+                           (uint32_t *)ctx->d_flags.p);
+        hipLaunchKernelGGL(k_names_verify, dim3((n + 255) / 256), dim3(256), 0, st, text, (const uint64_t *)d_off.p, (const uint8_t *)d_len.p, n, names,
+                           (uint32_t *)ctx->d_flags.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    release(d_off);
+    release(d_len);
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "name table: %s", hipGetErrorString(e));
+    if (flags & 1u) return ctx->fail(PNX_EINVAL, "a segment has an empty name");
+    if (flags & 4u) return ctx->fail(PNX_ELIMIT, "a segment name is longer than 16 bytes: the device tokeniser does not take such names");
+    if (flags & 8u) return ctx->fail(PNX_EINVAL, "a segment name occurs more than once in the GFA");
+    return PNX_OK;
+}
+
+// The L lines of the text -> the distinct edges by id (device arrays in the layout of pnx_gfa_steps.edge_uv / edge_oo).
+// Needs the text in HBM and, for names that are not numbers, the name table of this upload.
+int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, DevBuf &d_e_oo, uint32_t &n_edges) {
+    n_edges = 0;
+    const uint64_t n = g->n_links;
+    if (n >= 0xFFFFFFFEull) return ctx->fail(PNX_ELIMIT, "more than 2^32-2 L lines");
+    if (g->n_nodes >= (1u << 30)) return ctx->fail(PNX_ELIMIT, "L lines on the device: at most 2^30-1 segments");
+    hipStream_t st = ctx->stream;
+    struct Scratch {
+        DevBuf off, key, tkey, tfirst, first, rank, tmp, names;
+        ~Scratch() {
+            for (DevBuf *b : {&off, &key, &tkey, &tfirst, &first, &rank, &tmp, &names}) release(*b);
+        }
+    } sc;
+    uint64_t slots = 1024;
+    while (slots < 2 * n) slots <<= 1;
+    const size_t n1 = n ? n : 1;
+    int rc;
+    if ((rc = ensure(ctx, sc.off, n1 * 8)) || (rc = ensure(ctx, sc.key, n1 * 8)) || (rc = ensure(ctx, sc.tkey, slots * 8)) ||
+        (rc = ensure(ctx, sc.tfirst, slots * 4)) || (rc = ensure(ctx, sc.first, n1 * 4)) || (rc = ensure(ctx, sc.rank, n1 * 4)) ||
+        (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t))))
+        return rc;
+    NodeNames nn{nullptr, 0, NameTab{}, 0};
+    if (g->name_off) {
+        nn.by_name = 1;
+        nn.tab.e = (NameEntry *)ctx->d_name_tab.p;
+        uint64_t ns = 1024;
+        while (ns < 2ull * g->n_nodes) ns <<= 1;
+        nn.tab.mask = ns - 1;
+        if (!nn.tab.e) return ctx->fail(PNX_EINVAL, "L lines by name: the name table of this upload is missing (internal error)");
+    } else if (g->id_of_name) {
+        if ((rc = ensure(ctx, sc.names, (g->n_names ? g->n_names : 1) * 4))) return rc;
+        PNX_HIP(ctx, hipMemcpyAsync(sc.names.p, g->id_of_name, (size_t)g->n_names * 4, hipMemcpyHostToDevice, st));
+        nn.id_of_name = (const uint32_t *)sc.names.p;
+        nn.n_names = g->n_names;
+    }
+    if (n) PNX_HIP(ctx, hipMemcpyAsync(sc.off.p, g->link_off, n * 8, hipMemcpyHostToDevice, st));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), st));
+    PNX_HIP(ctx, hipMemsetAsync(sc.tkey.p, 0, slots * 8, st));
+    PNX_HIP(ctx, hipMemsetAsync(sc.tfirst.p, 0xFF, slots * 4, st));
+    const LinkTab lt{(unsigned long long *)sc.tkey.p, (uint32_t *)sc.tfirst.p, slots - 1};
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    uint32_t tail[2] = {0, 0};
+    if (n) {
+        const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
+        hipLaunchKernelGGL(k_links_parse, dim3(grid), dim3(256), 0, st, text, ctx->gfa_text_bytes, (const uint64_t *)sc.off.p, n, nn, g->n_nodes,
+                           (unsigned long long *)sc.key.p, (uint32_t *)ctx->d_flags.p);
+        hipLaunchKernelGGL(k_links_insert, dim3(grid), dim3(256), 0, st, (const unsigned long long *)sc.key.p, n, lt);
+        hipLaunchKernelGGL(k_links_first, dim3(grid), dim3(256), 0, st, (const unsigned long long *)sc.key.p, n, lt, (uint32_t *)sc.first.p);
+        size_t tmp_bytes = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)sc.first.p, (uint32_t *)sc.rank.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
+        if (e == hipSuccess && (rc = ensure(ctx, sc.tmp, tmp_bytes ? tmp_bytes : 8)) == PNX_OK)
+            e = rocprim::exclusive_scan(sc.tmp.p, tmp_bytes, (uint32_t *)sc.first.p, (uint32_t *)sc.rank.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
+        if (rc) return rc;
+        if (e != hipSuccess) return ctx->fail(PNX_EHIP, "L lines: scan failed: %s", hipGetErrorString(e));
+        PNX_HIP(ctx, hipMemcpyAsync(&tail[0], (uint32_t *)sc.rank.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        PNX_HIP(ctx, hipMemcpyAsync(&tail[1], (uint32_t *)sc.first.p + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    }
+    uint32_t flags = 0;
+    PNX_HIP(ctx, hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st));
+    PNX_HIP(ctx, hipStreamSynchronize(st));
+    if (flags & 1u) return ctx->fail(PNX_EINVAL, "malformed L line");
+    if (flags & 4u) return ctx->fail(PNX_ELIMIT, "an L line names a segment of more than 16 bytes: the device route does not take such names");
+    if (flags & 2u) return ctx->fail(PNX_EINVAL, "an L line names a segment the graph does not have");
+    n_edges = tail[0] + tail[1];
+    if ((rc = ensure(ctx, d_e_uv, ((size_t)n_edges + 1) * 8)) || (rc = ensure(ctx, d_e_oo, (size_t)n_edges + 1))) return rc;
+    PNX_HIP(ctx, hipMemsetAsync(d_e_uv.p, 0, 8, st));
+    PNX_HIP(ctx, hipMemsetAsync(d_e_oo.p, 0, 1, st));
+    if (n) hipLaunchKernelGGL(k_links_emit, dim3(grid), dim3(256), 0, st, (const unsigned long long *)sc.key.p, (const uint32_t *)sc.first.p,
+                              (const uint32_t *)sc.rank.p, n, (unsigned long long *)d_e_uv.p, (uint8_t *)d_e_oo.p);
+    PNX_HIP(ctx, hipGetLastError());
+    PNX_HIP(ctx, hipStreamSynchronize(st));  // (the scratch goes with this scope)
     return PNX_OK;
 }
 
@@ -330,6 +644,10 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
         PNX_HIP(ctx, hipMemcpyAsync(sc.cb.p, g->col_begin, (size_t)P * 8, hipMemcpyHostToDevice, st));
         PNX_HIP(ctx, hipMemcpyAsync(sc.ce.p, g->col_end, (size_t)P * 8, hipMemcpyHostToDevice, st));
         PNX_HIP(ctx, hipMemcpyAsync(sc.walk.p, g->is_walk, (size_t)P, hipMemcpyHostToDevice, st));
+    }
+    NameTab names;
+    if (g->name_off) {
+        if ((rc = gfa_name_table(ctx, g, names))) return rc;
     }
     const uint32_t *d_names = nullptr;
     if (g->id_of_name) {
@@ -364,11 +682,16 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
                        n_pieces, total, (uint64_t *)ctx->d_path_off.p);
     if ((rc = ensure(ctx, ctx->d_items, total * sizeof(uint32_t) + 64))) return rc;
     if (d_backward && (rc = ensure(ctx, *d_backward, total + 64))) return rc;
-    if (n_pieces)
-        hipLaunchKernelGGL(k_tok_emit, dim3(grid), dim3(256), 0, st, text, (const uint64_t *)sc.off.p, (const uint64_t *)sc.cb.p,
-                           (const uint64_t *)sc.ce.p, (const uint8_t *)sc.walk.p, P, n_pieces, (const uint64_t *)sc.outs.p, d_names, g->n_names,
-                           g->n_nodes, (uint32_t *)ctx->d_items.p, d_backward ? (uint8_t *)d_backward->p : (uint8_t *)nullptr,
-                           (uint32_t *)ctx->d_flags.p);
+    if (n_pieces) {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, text, (const uint64_t *)sc.off.p, (const uint64_t *)sc.cb.p,
+                               (const uint64_t *)sc.ce.p, (const uint8_t *)sc.walk.p, P, n_pieces, (const uint64_t *)sc.outs.p, d_names, g->n_names,
+                               names, g->n_nodes, (uint32_t *)ctx->d_items.p, d_backward ? (uint8_t *)d_backward->p : (uint8_t *)nullptr,
+                               (uint32_t *)ctx->d_flags.p);
+        };
+        if (g->name_off) go(k_tok_emit<true>);
+        else go(k_tok_emit<false>);
+    }
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     ctx->h_path_off.assign(p1, 0);
@@ -376,7 +699,8 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
     PNX_HIP(ctx, hipMemcpyAsync(ctx->h_path_off.data(), ctx->d_path_off.p, p1 * 8, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipStreamSynchronize(st));
-    if (flags & 1u) return ctx->fail(PNX_EINVAL, "a path step is not of the form <decimal name><+|-> (P) / <'>'|'<'><decimal name> (W)");
+    if (flags & 1u) return ctx->fail(PNX_EINVAL, "a path step is not of the form <name><+|-> (P) / <'>'|'<'><name> (W)%s", g->name_off ? "" : " with a decimal name");
+    if (flags & 4u) return ctx->fail(PNX_ELIMIT, "a path step names a segment of more than 16 bytes: the device tokeniser does not take such names");
     if (flags & 2u) return ctx->fail(PNX_EINVAL, "a path step names a segment the graph does not have");
     ctx->n_steps = total;
     return PNX_OK;

@@ -323,7 +323,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -501,6 +501,19 @@ int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes) {
     return gfa_text_upload(ctx, text, text_bytes);
 }
 
+// the arguments of pnx_set_csr_gfa / pnx_gfa_walks that say how segments and edges are named
+static int check_gfa_naming(pnx_ctx *ctx, const pnx_gfa_steps *g, const char *who) {
+    if (g->name_off && (!g->name_len || g->id_of_name)) return ctx->fail(PNX_EINVAL, "%s: name_off comes with name_len and without id_of_name", who);
+    if (g->link_off && (g->edge_uv || g->edge_oo)) return ctx->fail(PNX_EINVAL, "%s: link_off (the L lines parsed on the device) and edge_uv / edge_oo are two ways to hand over the edges: pass one", who);
+    if (g->n_links && !g->link_off) return ctx->fail(PNX_EINVAL, "%s: n_links without link_off", who);
+    const uint64_t bytes = g->text ? g->text_bytes : ctx->gfa_text_bytes;
+    for (uint64_t k = 0; g->link_off && k < g->n_links; ++k)
+        if (g->link_off[k] >= bytes) return ctx->fail(PNX_EINVAL, "%s: L line %llu lies outside the text", who, (unsigned long long)k);
+    for (uint32_t i = 0; g->name_off && i < g->n_nodes; ++i)
+        if (g->name_off[i] + g->name_len[i] > bytes) return ctx->fail(PNX_EINVAL, "%s: the name of segment %u lies outside the text", who, i + 1);
+    return PNX_OK;
+}
+
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weights, const uint8_t *exclude) {
     if (!ctx) return PNX_EINVAL;
     if (!g || (g->n_paths && (!g->col_begin || !g->col_end || !g->is_walk)))
@@ -511,24 +524,32 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     for (uint32_t p = 0; p < g->n_paths; ++p)
         if (g->col_begin[p] > g->col_end[p] || g->col_end[p] > bytes)
             return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: the step column of path %u lies outside the text", p);
+    int rc;
+    if ((rc = check_gfa_naming(ctx, g, "pnx_set_csr_gfa"))) return rc;
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
-    int rc;
     if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
         (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
         return rc;
     ctx->walks_valid = false;
     release(ctx->d_walk_node);
     release(ctx->d_walk_back);
-    const bool edges = g->edge_uv != nullptr;
-    if (edges && (!g->edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo, and no weights");
-    DevBuf d_backward;
+    const bool links = g->link_off != nullptr, edges = g->edge_uv != nullptr || links;
+    if (edges && ((!links && !g->edge_oo) || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo (or link_off), and no weights");
+    DevBuf d_backward, d_e_uv, d_e_oo;
+    uint32_t n_edges = g->n_edges;
     rc = gfa_tokenise(ctx, g, edges ? &d_backward : nullptr);
+    if (rc == PNX_OK && links) rc = gfa_links_to_edges(ctx, g, d_e_uv, d_e_oo, n_edges);  // (while the text is still in HBM)
     drop_gfa_text(ctx);
-    if (rc == PNX_OK && edges) rc = gfa_edge_items(ctx, g->n_paths, d_backward, g->edge_uv, g->edge_oo, g->n_edges);
+    release(ctx->d_name_tab);
+    if (rc == PNX_OK && edges)
+        rc = links ? gfa_edge_items(ctx, g->n_paths, d_backward, (const uint64_t *)d_e_uv.p, (const uint8_t *)d_e_oo.p, n_edges, true)
+                   : gfa_edge_items(ctx, g->n_paths, d_backward, g->edge_uv, g->edge_oo, n_edges);
     release(d_backward);
+    release(d_e_uv);
+    release(d_e_oo);
     if (rc) return rc;
-    return finish_upload(ctx, ctx->n_steps, g->n_paths, edges ? g->n_edges : g->n_nodes, weights, exclude, false, nullptr);
+    return finish_upload(ctx, ctx->n_steps, g->n_paths, edges ? n_edges : g->n_nodes, weights, exclude, false, nullptr);
 }
 
 int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {
@@ -541,15 +562,23 @@ int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {
     for (uint32_t p = 0; p < g->n_paths; ++p)
         if (g->col_begin[p] > g->col_end[p] || g->col_end[p] > bytes)
             return ctx->fail(PNX_EINVAL, "pnx_gfa_walks: the step column of path %u lies outside the text", p);
+    int rc;
+    if ((rc = check_gfa_naming(ctx, g, "pnx_gfa_walks"))) return rc;
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);  // (the tokeniser writes through the resident graph's buffers)
     ctx->walks_valid = false;
-    int rc;
+    ctx->n_link_edges = 0;
+    release(ctx->d_link_uv);
+    release(ctx->d_link_oo);
     if (g->text && !(ctx->d_gfa_text.p && ctx->gfa_text_host == g->text && ctx->gfa_text_bytes == g->text_bytes) &&
         (rc = gfa_text_upload(ctx, g->text, g->text_bytes)))
         return rc;
     rc = gfa_tokenise(ctx, g, &ctx->d_walk_back);
+    // the L lines, if handed over: parsed now, while the text is in HBM, and kept beside the walks (pnx_set_csr_walks)
+    if (rc == PNX_OK && g->link_off) rc = gfa_links_to_edges(ctx, g, ctx->d_link_uv, ctx->d_link_oo, ctx->n_link_edges);
+    ctx->links_valid = rc == PNX_OK && g->link_off != nullptr;
     drop_gfa_text(ctx);
+    release(ctx->d_name_tab);
     if (rc) return rc;
     std::swap(ctx->d_items, ctx->d_walk_node);
     ctx->h_walk_off = ctx->h_path_off;
@@ -562,8 +591,11 @@ int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, c
                       const uint8_t *edge_oo, uint32_t n_edges) {
     if (!ctx) return PNX_EINVAL;
     if (!ctx->walks_valid || ctx->h_walk_off.empty()) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: the context holds no walks (pnx_gfa_walks)");
-    const bool edges = edge_uv != nullptr;
-    if (edges && (!edge_oo || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: edge counts take edge_uv AND edge_oo, and no weights");
+    const bool from_links = edge_uv == nullptr && n_edges == PNX_EDGES_FROM_LINKS;  // the L lines pnx_gfa_walks parsed
+    if (from_links && !ctx->links_valid) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: pnx_gfa_walks was not given the L lines (link_off)");
+    if (from_links) n_edges = ctx->n_link_edges;
+    const bool edges = edge_uv != nullptr || from_links;
+    if (edges && ((!from_links && !edge_oo) || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_walks: edge counts take edge_uv AND edge_oo, and no weights");
     if (n_nodes >= 0xFFFFFFFEu || (edges && n_edges >= 0xFFFFFFFEu)) return ctx->fail(PNX_ELIMIT, "n_nodes and n_edges must be < 2^32-2");
     PNX_HIP(ctx, hipSetDevice(ctx->device));
     begin_upload(ctx);
@@ -576,7 +608,9 @@ int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, c
     ctx->h_path_off = ctx->h_walk_off;
     PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, ctx->h_path_off.data(), ((size_t)n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->n_steps = S;
-    if (edges && (rc = gfa_edge_items(ctx, n_paths, ctx->d_walk_back, edge_uv, edge_oo, n_edges))) return rc;
+    if (edges && (rc = from_links ? gfa_edge_items(ctx, n_paths, ctx->d_walk_back, (const uint64_t *)ctx->d_link_uv.p, (const uint8_t *)ctx->d_link_oo.p, n_edges, true)
+                                  : gfa_edge_items(ctx, n_paths, ctx->d_walk_back, edge_uv, edge_oo, n_edges)))
+        return rc;
     return finish_upload(ctx, ctx->n_steps, n_paths, edges ? n_edges : n_nodes, weights, exclude, false, nullptr);
 }
 

@@ -169,6 +169,7 @@ struct pnx_ctx {
 
     // ---- GFA text in HBM (kernels_gfa.hip): the bytes whose step columns pnx_set_csr_gfa tokenises ----
     pnx::DevBuf d_gfa_text;
+    pnx::DevBuf d_name_tab;  // node2id of an upload by name (name_table.hpp): lives from the tokeniser to the L lines of the same upload
     const char *gfa_text_host = nullptr;  // what was uploaded (pnx_gfa_text_upload), to recognise it again
     uint64_t gfa_text_bytes = 0;
 
@@ -242,6 +243,9 @@ struct pnx_ctx {
     pnx::DevBuf d_walk_node, d_walk_back;
     std::vector<uint64_t> h_walk_off;
     bool walks_valid = false;
+    pnx::DevBuf d_link_uv, d_link_oo;  // the distinct edges of the L lines pnx_gfa_walks parsed, by id (pnx_set_csr_walks with PNX_EDGES_FROM_LINKS)
+    uint32_t n_link_edges = 0;
+    bool links_valid = false;
 
     // ---- closed-form quorum sums (kernels_closed_form.hip): scratch kept across calls ----
     pnx::DevBuf d_cf[6];
@@ -333,6 +337,7 @@ const StepRoutes *step_routes(pnx_ctx *ctx);  // nullptr (and ctx->err) when the
 // kernels_gfa.hip
 int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes);
 int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward);  // -> d_items, d_path_off, h_path_off, n_steps
+int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, DevBuf &d_e_oo, uint32_t &n_edges);  // the L lines -> distinct edges by id
 // kernels_hist.hip
 int launch_hist(pnx_ctx *ctx, Ticket *tk);  // K2 of the pass in `tk`, on the stream of its histogram phase
 // kernels_rows.hip
@@ -369,7 +374,8 @@ int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_inte
 // kernels_cut.hip
 int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
 int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n);
-int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges);
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges,
+                   bool edges_on_device = false);  // edges_on_device: edge_uv / edge_oo are device arrays (gfa_links_to_edges)
 int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
 int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip

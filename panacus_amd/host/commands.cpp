@@ -153,7 +153,7 @@ bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &) {
     return !(o.cache || !o.subset_file.empty() || !o.exclude_file.empty() || std::getenv("PANACUS_AMD_HOST_PARSE"));
 }
 
-std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev) {
+std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev, bool links_on_device) {
     struct Decide {  // whatever happens below, the device thread learns that no (further) text is coming
         const Device *d;
         ~Decide() {
@@ -163,7 +163,12 @@ std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, con
     GraphStorage::TextHook hook = nullptr;
     if (dev) hook = [dev](const char *p, size_t n, std::shared_ptr<const void> keep) { dev->offer_text(p, n, std::move(keep)); };
     // subset / exclude lists are applied while walking the path lines: they need the GFA text
-    if (!o.cache || !o.subset_file.empty() || !o.exclude_file.empty()) return GraphStorage::from_gfa(o.file, index_edges, false, hook);
+    if (!o.cache || !o.subset_file.empty() || !o.exclude_file.empty()) {
+        // hist / histgrowth need no edge id on the host: the L lines are found, and parsed on the device (or here, later, if
+        // the graph turns out not to be one the device tokenises)
+        const bool links_only = index_edges && links_on_device && dev && wants_device_tokeniser(o, {});
+        return GraphStorage::from_gfa(o.file, index_edges && !links_only, false, hook, links_only);
+    }
     const std::string cache_file = o.file + ".pcsr";
     if (auto g = GraphStorage::from_cache(cache_file, o.file, index_edges)) return g;
     auto g = GraphStorage::from_gfa(o.file, index_edges);
@@ -182,6 +187,53 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
     if (!parse_count_name(l, t)) throw std::runtime_error("invalid value '" + c + "' for '--count <count>'");
     return {t};
 }
+
+// what pnx_set_csr_gfa / pnx_gfa_walks are told about a graph whose steps the device tokenises: the step columns, how a
+// segment name becomes a node id (a table indexed by the number, or the name fields themselves when the names are not
+// numbers: the device hashes them), and -- edge counts -- the edges: the host's index of the L lines if it was built, else
+// the offsets of the L lines (the device parses and ranks them; no edge map on the host at all)
+struct GfaStepArgs {
+    std::vector<uint64_t> cb, ce, name_off, link_off, euv;
+    std::vector<uint8_t> wk, name_len, eoo;
+    pnx_gfa_steps st{};
+    bool links = false;
+    GfaStepArgs(const GraphStorage &g, bool text_there) {
+        g.step_columns(cb, ce, wk);
+        st.text = text_there ? nullptr : g.text_data();
+        st.text_bytes = text_there ? 0 : g.text_size();
+        st.n_paths = (uint32_t)cb.size();
+        st.n_nodes = (uint32_t)g.node_count();
+        if (g.names_by_bytes_on_device()) {
+            g.name_fields(name_off, name_len);
+            st.name_off = name_off.data();
+            st.name_len = name_len.data();
+        } else {
+            st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
+            st.n_names = g.id_of_name().size();
+        }
+    }
+    void columns() {  // (after the caller emptied the columns it does not want)
+        st.col_begin = cb.data();
+        st.col_end = ce.data();
+        st.is_walk = wk.data();
+    }
+    void edges(const GraphStorage &g, bool into_steps) {
+        static const uint64_t none = 0;
+        links = g.links_for_device();
+        if (links) {
+            g.link_offsets(link_off);
+            st.link_off = link_off.empty() ? &none : link_off.data();
+            st.n_links = link_off.size();
+        } else {
+            g.edge_ends(euv, eoo);
+            if (into_steps) {
+                st.edge_uv = euv.data();
+                st.edge_oo = eoo.data();
+                st.n_edges = (uint32_t)g.number_of_items(COUNT_EDGE);
+            }
+        }
+    }
+};
 
 // upload graph + order for one count type
 
@@ -203,8 +255,8 @@ Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStora
         if (rc != PNX_OK) throw std::runtime_error(pnx_last_error(ctx));
     };
     const uint64_t n_items = g.number_of_items(ct);
-    // numeric segment names: the walks are made from the text on the device (pnx_gfa_walks) and cut where they are; the
-    // paths no interval touches get an empty step column.  Otherwise the host's step parser makes them and they go up.
+    // segment names the device can resolve (numbers, or at most 16 bytes): the walks are made from the text on the device
+    // (pnx_gfa_walks) and cut where they are; the paths no interval touches get an empty step column.  Otherwise the host's step parser makes them and they go up.
     const bool dev_walks = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
     WalkCut cut = g.walk_cut(ct, mk.mode, mk.group_file, mk.subset_file, mk.exclude_file, !dev_walks);
     const uint32_t none32 = 0;
@@ -212,21 +264,11 @@ Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStora
     const uint64_t none64 = 0;
     pnx_walks w{};
     if (dev_walks) {
-        std::vector<uint64_t> cb, ce;
-        std::vector<uint8_t> wk;
-        g.step_columns(cb, ce, wk);
+        GfaStepArgs a(g, false);
         for (size_t k = 0; k < cut.path_mode.size(); ++k)
-            if (cut.path_mode[k] == PNX_WALK_SKIP) ce[k] = cb[k];
-        pnx_gfa_steps st{};
-        st.text = g.text_data();
-        st.text_bytes = g.text_size();
-        st.n_paths = (uint32_t)cut.path_mode.size();
-        st.n_nodes = (uint32_t)g.node_count();
-        st.col_begin = cb.data();
-        st.col_end = ce.data();
-        st.is_walk = wk.data();
-        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
-        st.n_names = g.id_of_name().size();
+            if (cut.path_mode[k] == PNX_WALK_SKIP) a.ce[k] = a.cb[k];
+        a.columns();
+        pnx_gfa_steps &st = a.st;
         cut.walk_off.assign(cut.path_mode.size() + 1, 0);
         ctx = get_ctx();
         check(pnx_gfa_walks(ctx, &st, cut.walk_off.data()));
@@ -291,35 +333,18 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
     if ((mk.any() && !path_level) || (ct == COUNT_EDGE && !g.from_cache_file() && !on_device)) {
         uncovered = upload_cut([&dev]() { return dev.ctx(); }, g, ct, mk, growth_weights);
     } else if (on_device) {
-        // numeric segment names: the ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is parsed
-        // on the host, no ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it.  Edge counts:
-        // the walks stay on the device too, the host hands over the edges of the L lines and the library looks the edge of
-        // every step pair up itself
-        std::vector<uint64_t> cb, ce;
-        std::vector<uint8_t> wk;
-        g.step_columns(cb, ce, wk);
+        // the ItemTable is made from the raw text ON THE DEVICE (pnx_set_csr_gfa) -- no step is parsed on the host, no
+        // ItemTable crosses PCIe; the text is in HBM already if the device thread was offered it.  Edge counts: the walks stay
+        // on the device too; the L lines are parsed and ranked there as well (hist / histgrowth: GfaStepArgs::edges), or the
+        // host hands over its index of them, and the library looks the edge of every step pair up itself
+        const bool there = dev.text_uploaded();
+        GfaStepArgs a(g, there);
         if (path_level)
             for (size_t k = 0; k < take.size(); ++k)
-                if (!take[k]) ce[k] = cb[k];
-        std::vector<uint64_t> euv;
-        std::vector<uint8_t> eoo;
-        if (ct == COUNT_EDGE) g.edge_ends(euv, eoo);
-        const bool there = dev.text_uploaded();
-        pnx_gfa_steps st{};
-        st.text = there ? nullptr : g.text_data();
-        st.text_bytes = there ? 0 : g.text_size();
-        st.n_paths = n_paths;
-        st.n_nodes = (uint32_t)g.node_count();
-        st.col_begin = cb.data();
-        st.col_end = ce.data();
-        st.is_walk = wk.data();
-        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
-        st.n_names = g.id_of_name().size();
-        if (ct == COUNT_EDGE) {
-            st.edge_uv = euv.data();
-            st.edge_oo = eoo.data();
-            st.n_edges = (uint32_t)n_items;
-        }
+                if (!take[k]) a.ce[k] = a.cb[k];
+        a.columns();
+        if (ct == COUNT_EDGE) a.edges(g, true);
+        pnx_gfa_steps &st = a.st;
         phase_mark(there ? "columns ready (text was uploaded beside the parse)" : "columns ready");
         dev.check(pnx_set_csr_gfa(dev.ctx(), &st, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
         phase_mark("pnx_set_csr_gfa (tokenise + rows)");
@@ -375,24 +400,14 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
     for (CountType c : cts) have_edge = have_edge || c == COUNT_EDGE;
     const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
     if (on_device && !mk.any() && have_edge && (have_node || have_bp)) {
-        // `-c all` on a graph with numeric names: the text is tokenised ONCE into walks that stay on the device
+        // `-c all`: the text is tokenised ONCE into walks that stay on the device
         // (pnx_gfa_walks), and every count type's table is made from them there (pnx_set_csr_walks) -- the reference builds
         // one table for node + bp and parses the file again for the edges (graph_broker/util.rs:201-204, graph_broker.rs:404-422)
-        std::vector<uint64_t> cb, ce, walk_off(g.path_segments().size() + 1, 0), euv;
-        std::vector<uint8_t> wk, eoo;
-        g.step_columns(cb, ce, wk);
-        g.edge_ends(euv, eoo);
-        const bool there = dev.text_uploaded();
-        pnx_gfa_steps st{};
-        st.text = there ? nullptr : g.text_data();
-        st.text_bytes = there ? 0 : g.text_size();
-        st.n_paths = (uint32_t)g.path_segments().size();
-        st.n_nodes = (uint32_t)g.node_count();
-        st.col_begin = cb.data();
-        st.col_end = ce.data();
-        st.is_walk = wk.data();
-        st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
-        st.n_names = g.id_of_name().size();
+        std::vector<uint64_t> walk_off(g.path_segments().size() + 1, 0);
+        GfaStepArgs a(g, dev.text_uploaded());
+        a.columns();
+        a.edges(g, false);  // (the L lines go with the walks when the device parses them)
+        pnx_gfa_steps &st = a.st;
         dev.check(pnx_gfa_walks(dev.ctx(), &st, walk_off.data()));
         phase_mark("pnx_gfa_walks (tokenised once for all count types)");
         auto set_order = [&]() {
@@ -410,7 +425,10 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
             }
             phase_mark("node / bp tables from the resident walks + hists");
         }
-        dev.check(pnx_set_csr_walks(dev.ctx(), (uint32_t)g.node_count(), nullptr, nullptr, euv.data(), eoo.data(), (uint32_t)g.number_of_items(COUNT_EDGE)));
+        if (a.links)
+            dev.check(pnx_set_csr_walks(dev.ctx(), (uint32_t)g.node_count(), nullptr, nullptr, nullptr, nullptr, PNX_EDGES_FROM_LINKS));
+        else
+            dev.check(pnx_set_csr_walks(dev.ctx(), (uint32_t)g.node_count(), nullptr, nullptr, a.euv.data(), a.eoo.data(), (uint32_t)g.number_of_items(COUNT_EDGE)));
         set_order();
         for (size_t k = 0; k < cts.size(); ++k) {
             if (cts[k] != COUNT_EDGE) continue;
@@ -473,7 +491,7 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
     const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
-    auto g = load_graph(o, edges, &dev);
+    auto g = load_graph(o, edges, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
@@ -494,7 +512,7 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     bool edges = false;
     for (CountType c : cts) edges = edges || c == COUNT_EDGE;
     const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
-    auto g = load_graph(o, edges, &dev);
+    auto g = load_graph(o, edges, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};

@@ -69,7 +69,7 @@ struct Masking {  // -g/-S/-H grouping + -s/-e lists: what the item table of a c
 
 using Uncovered = std::vector<std::pair<uint32_t, uint64_t>>;  // quantify_uncovered_bps (abacus.rs:1187-1229)
 
-std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev = nullptr);
+std::unique_ptr<GraphStorage> load_graph(const Options &o, bool index_edges, const Device *dev = nullptr, bool links_on_device = false);
 // will this run make its node ItemTable from the raw text on the device, if the graph allows it?  (then the text is worth copying early)
 bool wants_device_tokeniser(const Options &o, const std::vector<CountType> &cts);
 std::vector<CountType> count_types(const std::string &c, bool allow_all);

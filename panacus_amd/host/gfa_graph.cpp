@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <stdexcept>
 
 #include "thread_pool.hpp"
@@ -438,8 +439,12 @@ struct GraphStorage::Impl {
     std::vector<Span> p_lines;        // P and W lines in file order
     std::vector<Span> step_fields;    // per path: the step / walk column
     std::vector<uint8_t> is_walk;     // per path
-    NameMap names;
+    mutable NameMap names;            // name -> id for names that are not the ranks: built on first use (ensure_names)
+    mutable std::once_flag names_once;
     std::vector<Span> node_names;     // per node id - 1: the name field of its S line
+    uint32_t max_name_len = 0;        // longest segment name in bytes
+    std::vector<Span> l_lines;        // the L lines (kept when the edge index is left to the device, or built on demand)
+    bool links_only = false;          // the L lines were found but not parsed: the device parses them (pnx_gfa_steps.link_off)
     bool nice = false;                // segment names are the integers 1..N in file order
     bool numeric_names = false;       // every segment name is a decimal number (nice, or id_of_name maps it)
     std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
@@ -468,7 +473,19 @@ struct GraphStorage::Impl {
             }
             return (uint32_t)v;
         }
+        ensure_names();
         return names.find(p, (uint32_t)len);
+    }
+    // node2id for names that are not numbers in rank order (graph.rs:308-375).  The device routes never ask for it (they hash
+    // the names themselves, or index a table by the number), so it is built when the first host lookup comes.
+    void ensure_names() const {
+        std::call_once(names_once, [this]() {
+            names.init(node_names.size());
+            for (size_t k = 0; k < node_names.size(); ++k)
+                if (!names.insert(image.data() + node_names[k].b, (uint32_t)(node_names[k].e - node_names[k].b), (uint32_t)(k + 1)))
+                    throw std::runtime_error("Segment with ID " + image.substr(node_names[k].b, node_names[k].e - node_names[k].b) +
+                                             " occurs multiple times in GFA");
+        });
     }
 };
 
@@ -477,7 +494,7 @@ GraphStorage::~GraphStorage() = default;
 
 // GraphStorage::from_gfa (graph.rs:195-220): parse_nodes_gfa (308-375) + parse_edge_gfa (276-306)
 std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file, bool index_edges, bool /*nice*/,
-                                                     const TextHook &on_text) {
+                                                     const TextHook &on_text, bool links_only) {
     std::unique_ptr<GraphStorage> g(new GraphStorage());
     Impl &im = *g->impl_;
     phase_mark("start from_gfa");
@@ -513,7 +530,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                 if (e > b) {
                     switch (s[b]) {
                         case 'S': f.s.push_back({b, e}); break;
-                        case 'L': if (index_edges) f.l.push_back({b, e}); break;
+                        case 'L': if (index_edges || links_only) f.l.push_back({b, e}); break;
                         case 'P': case 'W': f.p.push_back({b, e}); break;
                         default: break;
                     }
@@ -543,14 +560,14 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     g->node_lens_.assign(s_lines.size() + 1, 0);
     std::vector<Span> name_of(s_lines.size());
     std::atomic<bool> nice_all{true}, malformed{false}, numeric_all{true};
-    std::atomic<uint64_t> name_max{0};
+    std::atomic<uint64_t> name_max{0}, len_max{0};
     std::vector<uint32_t> name_val(s_lines.size());  // the name as a number (when it is one)
     {
         const size_t BL = 1u << 16;
         const size_t nb = (s_lines.size() + BL - 1) / BL;
         ThreadPool::instance().parallel_for(nb, [&](size_t blk) {
             bool nice = true, numeric = true;
-            uint64_t vmax = 0;
+            uint64_t vmax = 0, lmax = 0;
             const size_t k1 = std::min(s_lines.size(), (blk + 1) * BL);
             for (size_t k = blk * BL; k < k1; ++k) {
                 const Span ln = s_lines[k];
@@ -560,6 +577,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                 }
                 size_t ne = field_end(s, ln.b + 2, ln.e);
                 name_of[k] = {ln.b + 2, ne};
+                lmax = std::max<uint64_t>(lmax, ne - (ln.b + 2));
                 size_t q0 = ne < ln.e ? ne + 1 : ln.e, q1 = q0;
                 const void *tb = q0 < ln.e ? std::memchr(s.data() + q0, '\t', ln.e - q0) : nullptr;
                 q1 = tb ? (size_t)((const char *)tb - s.data()) : ln.e;
@@ -584,28 +602,38 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             uint64_t cur = name_max.load();
             while (vmax > cur && !name_max.compare_exchange_weak(cur, vmax)) {
             }
+            cur = len_max.load();
+            while (lmax > cur && !len_max.compare_exchange_weak(cur, lmax)) {
+            }
         });
     }
     if (malformed.load()) throw std::runtime_error("malformed S line");
     const bool nice = nice_all.load();
     im.nice = nice && !s_lines.empty();
-    if (!im.nice) {
-        im.names.init(s_lines.size());
-        for (size_t k = 0; k < s_lines.size(); ++k)
-            if (!im.names.insert(s.data() + name_of[k].b, (uint32_t)(name_of[k].e - name_of[k].b), (uint32_t)(k + 1)))
-                throw std::runtime_error("Segment with ID " + s.substr(name_of[k].b, name_of[k].e - name_of[k].b) +
-                                         " occurs multiple times in GFA");
-    }
+    im.max_name_len = (uint32_t)std::min<uint64_t>(len_max.load(), 0xFFFFFFFFull);
     g->node_count_ = s_lines.size();
     im.node_names = std::move(name_of);
+    // (the name -> id map of names that are not the ranks is built on first use: Impl::ensure_names.  A name that occurs twice
+    // -- the reference panics, graph.rs:336 -- is found there, by the check of the number table below, or by the device's name
+    // table, whichever route the command takes)
     // numeric names: name -> id as a plain table (the device tokeniser's lookup), when the numbers are small enough
     im.numeric_names = !s_lines.empty() && numeric_all.load() && (im.nice || name_max.load() <= 16 * (uint64_t)s_lines.size() + 4096);
     if (im.numeric_names && !im.nice) {
         im.id_of_name.assign(name_max.load() + 1, 0);
         ThreadPool::instance().parallel_for((s_lines.size() + (1u << 16) - 1) >> 16, [&](size_t blk) {
             const size_t k1 = std::min(s_lines.size(), (blk + 1) << 16);
-            for (size_t k = blk << 16; k < k1; ++k) im.id_of_name[name_val[k]] = (uint32_t)(k + 1);  // (names are unique: checked above)
+            for (size_t k = blk << 16; k < k1; ++k) im.id_of_name[name_val[k]] = (uint32_t)(k + 1);
         });
+        std::atomic<int64_t> dup{-1};
+        ThreadPool::instance().parallel_for((s_lines.size() + (1u << 16) - 1) >> 16, [&](size_t blk) {
+            const size_t k1 = std::min(s_lines.size(), (blk + 1) << 16);
+            for (size_t k = blk << 16; k < k1; ++k)
+                if (im.id_of_name[name_val[k]] != (uint32_t)(k + 1)) dup.store((int64_t)k);  // another S line wrote the same number
+        });
+        if (dup.load() >= 0) {
+            const Span sp = im.node_names[(size_t)dup.load()];
+            throw std::runtime_error("Segment with ID " + s.substr(sp.b, sp.e - sp.b) + " occurs multiple times in GFA");
+        }
     }
 
     phase_mark("S lines (names, lengths)");
@@ -660,8 +688,20 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     });
 
     phase_mark("P/W headers");
-    // --- L lines: edge id = rank of the first occurrence of the canonical form ---
-    if (index_edges) {
+    im.l_lines = std::move(l_lines);
+    im.links_only = links_only && !index_edges;
+    if (index_edges) g->build_edge_index();
+    return g;
+}
+
+// --- L lines: edge id = rank of the first occurrence of the canonical form (graph.rs:276-306) ---
+void GraphStorage::build_edge_index() {
+    GraphStorage *g = this;
+    Impl &im = *impl_;
+    if (im.has_edges) return;
+    const Image &s = im.image;
+    const std::vector<Span> &l_lines = im.l_lines;
+    {
         im.has_edges = true;
         im.edges.init_parallel(l_lines.size());
         // the lines are parsed in parallel (two name lookups each); ids are given in file order afterwards
@@ -772,8 +812,34 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
         g->edge_count_ = next - 1;
         phase_mark("L lines (edges)");
     }
-    return g;
+    im.links_only = false;
 }
+void GraphStorage::ensure_edge_index() const { const_cast<GraphStorage *>(this)->build_edge_index(); }
+void GraphStorage::require_edges(const char *why) const {
+    if (!impl_->has_edges && impl_->links_only) ensure_edge_index();
+    if (!impl_->has_edges) throw std::runtime_error(why);
+}
+bool GraphStorage::has_edge_index() const { return impl_->has_edges; }
+bool GraphStorage::links_for_device() const { return impl_->links_only && !impl_->has_edges && !impl_->cached; }
+void GraphStorage::link_offsets(std::vector<uint64_t> &off) const {
+    const auto &ll = impl_->l_lines;
+    off.resize(ll.size());
+    for (size_t k = 0; k < ll.size(); ++k) off[k] = ll[k].b;
+}
+bool GraphStorage::names_by_bytes_on_device() const {
+    const Impl &im = *impl_;
+    return !im.cached && !im.numeric_names && node_count_ > 0 && im.max_name_len >= 1 && im.max_name_len <= 16;
+}
+void GraphStorage::name_fields(std::vector<uint64_t> &off, std::vector<uint8_t> &len) const {
+    const auto &nn = impl_->node_names;
+    off.resize(nn.size());
+    len.resize(nn.size());
+    for (size_t k = 0; k < nn.size(); ++k) {
+        off[k] = nn[k].b;
+        len[k] = (uint8_t)(nn[k].e - nn[k].b);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // ItemTable
@@ -792,7 +858,7 @@ struct Chunk {
 ItemTableView GraphStorage::item_table_view(CountType count, ItemTable &storage) const {
     const Impl &im = *impl_;
     if (im.cached) {
-        if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+        if (count == COUNT_EDGE) require_edges("graph was loaded without edge index");
         const int k = count == COUNT_EDGE ? 1 : 0;
         return ItemTableView{im.c_items[k], im.c_prefsum[k], im.c_n_items[k]};
     }
@@ -917,7 +983,7 @@ static void parse_all_steps(const GraphStorage::Impl &im, const std::vector<Path
 ItemTable GraphStorage::item_table(CountType count) const {
     const Impl &im = *impl_;
     const size_t P = paths_.size();
-    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    if (count == COUNT_EDGE) require_edges("graph was loaded without edge index");
     if (im.cached) {  // parallel copy out of the mapping (item_table_view() avoids even that)
         const int k = count == COUNT_EDGE ? 1 : 0;
         ItemTable t;
@@ -1434,7 +1500,7 @@ std::string GraphStorage::node_name(uint32_t id) const {
 
 std::vector<std::string> GraphStorage::edge_labels() const {
     const Impl &im = *impl_;
-    if (!im.has_edges) throw std::runtime_error("edge labels need the edge index");
+    require_edges("edge labels need the edge index");
     std::vector<std::string> out(edge_count_ + 1);
     if (im.cached) {
         for (uint64_t id = 1; id <= edge_count_; ++id) {
@@ -1455,7 +1521,7 @@ std::vector<std::string> GraphStorage::edge_labels() const {
 
 std::vector<uint64_t> GraphStorage::edge_keys() const {
     const Impl &im = *impl_;
-    if (!im.has_edges) throw std::runtime_error("edge keys need the edge index");
+    require_edges("edge keys need the edge index");
     std::vector<uint64_t> keys(edge_count_ + 1, 0);
     if (im.cached) {
         for (uint64_t id = 1; id <= edge_count_; ++id) keys[id] = im.c_edge_uv[id];
@@ -1468,7 +1534,7 @@ std::vector<uint64_t> GraphStorage::edge_keys() const {
 
 void GraphStorage::edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo) const {
     const Impl &im = *impl_;
-    if (!im.has_edges) throw std::runtime_error("edge ends need the edge index");
+    require_edges("edge ends need the edge index");
     uv.assign(edge_count_ + 1, 0);
     oo.assign(edge_count_ + 1, 0);
     if (im.cached) {
@@ -1499,7 +1565,7 @@ void GraphStorage::edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo
 
 std::vector<uint32_t> GraphStorage::edge_relabel() const {
     const Impl &im = *impl_;
-    if (!im.has_edges) throw std::runtime_error("edge renumbering needs the edge index");
+    require_edges("edge renumbering needs the edge index");
     struct Key {
         uint64_t uv;
         uint32_t id;
@@ -1704,7 +1770,7 @@ inline void node_pieces(const std::vector<Iv> &list, size_t &cur, uint64_t p, ui
 
 bool GraphStorage::from_cache_file() const { return impl_->cached; }
 
-bool GraphStorage::steps_tokenisable_on_device() const { return !impl_->cached && impl_->numeric_names; }
+bool GraphStorage::steps_tokenisable_on_device() const { return !impl_->cached && (impl_->numeric_names || names_by_bytes_on_device()); }
 // `nice: true` of the YAML runner (graph.rs:224-229): are the segment names the integers 1..N in the order of the S lines?
 // A parsed graph knows; a graph from the .pcsr cache holds its names, and is asked once.
 bool GraphStorage::names_are_ranks() const {
@@ -1784,7 +1850,7 @@ MaskedTable GraphStorage::masked_table(CountType count, GroupMode mode, const st
                                        const std::string &subset_file, const std::string &exclude_file) const {
     const Impl &im = *impl_;
     if (im.cached) throw std::runtime_error("subset / exclude lists need the GFA text: load the graph without the cache");
-    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    if (count == COUNT_EDGE) require_edges("graph was loaded without edge index");
     const size_t P = paths_.size();
     const uint64_t n_items = number_of_items(count);
     MaskSetup ms;
@@ -1938,7 +2004,7 @@ WalkCut GraphStorage::walk_cut(CountType count, GroupMode mode, const std::strin
                                const std::string &exclude_file, bool with_walks) const {
     const Impl &im = *impl_;
     if (im.cached) throw std::runtime_error("subset / exclude lists need the GFA text: load the graph without the cache");
-    if (count == COUNT_EDGE && !im.has_edges) throw std::runtime_error("graph was loaded without edge index");
+    if (count == COUNT_EDGE) require_edges("graph was loaded without edge index");
     const size_t P = paths_.size();
     MaskSetup ms;
     mask_setup(ms, paths_, count, mode, group_file, subset_file, exclude_file);

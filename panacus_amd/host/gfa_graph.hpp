@@ -92,8 +92,16 @@ public:
     // any line has been looked at -- so that a caller can start copying them to the device beside the parse; the bytes
     // stay valid for as long as the caller holds `keep`, whatever happens to the GraphStorage
     using TextHook = std::function<void(const char *, size_t, std::shared_ptr<const void>)>;
+    // links_only: find the L lines but leave them unparsed -- the device parses them (pnx_gfa_steps.link_off); the host's
+    // edge index is then built on demand (ensure_edge_index)
     static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false,
-                                                  const TextHook &on_text = nullptr);
+                                                  const TextHook &on_text = nullptr, bool links_only = false);
+    void ensure_edge_index() const;       // parse the L lines now if that was left out
+    bool has_edge_index() const;
+    bool links_for_device() const;        // L lines found, not parsed: hand their offsets to the device
+    void link_offsets(std::vector<uint64_t> &off) const;
+    bool names_by_bytes_on_device() const;  // names that are not numbers, none longer than 16 bytes: the device hashes them
+    void name_fields(std::vector<uint64_t> &off, std::vector<uint8_t> &len) const;
 
     // ---- for the device tokeniser (pnx_set_csr_gfa): the text and where the step columns are ----
     // true iff every segment name is a decimal number (the names 1..N in file order, or any numbers small enough for a
@@ -167,6 +175,8 @@ public:
     std::vector<uint64_t> edge_keys() const;
     // the edges by id ([0] unused): canonical ends (= edge_keys) and orientations (o1 << 1 | o2, 1 = backward)
     void edge_ends(std::vector<uint64_t> &uv, std::vector<uint8_t> &oo) const;
+    void build_edge_index();
+    void require_edges(const char *why) const;
 
     // labels of AbacusByGroup::to_tsv (abacus.rs:1072-1140): the segment name of a node id, and
     // "{o1}{name1}{o2}{name2}" (> forward, < backward; graph.rs:32-39,154-158) of an edge id

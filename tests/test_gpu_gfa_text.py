@@ -248,3 +248,184 @@ def test_edge_item_table_from_walks_that_stay_on_the_device(ctx, nice):
                         edge_uv=bad, edge_oo=np.array(oo, np.uint8))
     with pytest.raises(capi.PnxError):
         ctx.hist()   # nothing is resident after a rejected upload
+
+
+def _named_gfa(rng, n, P, style, walk_share=0.3, with_links=False, dup_links=0):
+    """A whole GFA text with S (and L) lines in front of the paths.  style: how segments are named.
+    -> text, name_off, name_len, col_begin, col_end, is_walk, walks [(ids, back)], link_off, links [(u, o1, v, o2)] in file order"""
+    if style == "mixed":
+        pool = [lambda i: f"s{i}", lambda i: f"utg{i:06d}l", lambda i: f"n{i}_x", lambda i: "ABCDEFGHIJKLMNOP"[: 1 + i % 16] + str(i)]
+        names = [pool[i % 4](i)[:16] for i in range(1, n + 1)]
+        seen_names = set()
+        for k, nm in enumerate(names):  # (unique)
+            if nm in seen_names:
+                names[k] = nm = f"q{k}"
+            seen_names.add(nm)
+        assert len(set(names)) == n and max(map(len, names)) <= 16
+    elif style == "nice":
+        names = [str(i) for i in range(1, n + 1)]
+    else:  # numeric through a table
+        vals = rng.permutation(4 * n)[:n] + 1
+        names = [str(int(v)) for v in vals]
+    parts, pos = [b"H\tVN:Z:1.1\n"], 11
+    name_off, name_len = [], []
+    for nm in names:
+        head = b"S\t"
+        seq = b"ACGT"[: 1 + len(nm) % 4]
+        name_off.append(pos + len(head))
+        name_len.append(len(nm))
+        line = head + nm.encode() + b"\t" + seq + b"\n"
+        parts.append(line)
+        pos += len(line)
+    walks, cb, ce, wk = [], [], [], []
+    for p in range(P):
+        ln = int(rng.integers(0, 300)) if p % 9 else (1 if p else 0)
+        ids = rng.integers(1, 60, size=ln).cumsum() % n + 1
+        back = (rng.random(ln) < 0.3).astype(np.int64)
+        walks.append((ids, back))
+    links, link_off = [], []
+    if with_links:
+        seen = []
+        for ids, back in walks:
+            for a in range(len(ids) - 1):
+                seen.append((int(ids[a]), int(back[a]), int(ids[a + 1]), int(back[a + 1])))
+        seen += [(n - k, 0, n - k, 0) for k in range(20)] + [(5, 1, 5, 1), (7, 0, 7, 1)]   # edges no path uses, self loops
+        order = rng.permutation(len(seen))
+        for k in order:
+            u, o1, v, o2 = seen[k]
+            if rng.random() < 0.5:   # the same edge written from its other end
+                u, o1, v, o2 = v, o2 ^ 1, u, o1 ^ 1
+            links.append((u, o1, v, o2))
+        for _ in range(dup_links):
+            links.insert(int(rng.integers(0, len(links))), links[int(rng.integers(0, len(links)))])
+        for (u, o1, v, o2) in links:
+            line = f"L\t{names[u - 1]}\t{'-' if o1 else '+'}\t{names[v - 1]}\t{'-' if o2 else '+'}\t0M\n".encode()
+            link_off.append(pos)
+            parts.append(line)
+            pos += len(line)
+    for p, (ids, back) in enumerate(walks):
+        walk = rng.random() < walk_share
+        if walk:
+            head = f"W\ts{p}\t1\tctg\t0\t{len(ids)}\t".encode()
+            col = "".join(("<" if b else ">") + names[i - 1] for i, b in zip(ids, back)).encode()
+            tail = b"\n"
+        else:
+            head = f"P\tp{p}#1#c\t".encode()
+            col = ",".join(names[i - 1] + ("-" if b else "+") for i, b in zip(ids, back)).encode()
+            tail = b"\t*\n"
+        cb.append(pos + len(head))
+        ce.append(pos + len(head) + len(col))
+        wk.append(1 if walk else 0)
+        parts += [head, col, tail]
+        pos += len(head) + len(col) + len(tail)
+    text = b"".join(parts)
+    assert len(text) == pos
+    table = None
+    if style == "table":
+        table = np.zeros(4 * n + 2, dtype=np.uint32)
+        table[np.array([int(x) for x in names])] = np.arange(1, n + 1, dtype=np.uint32)
+    return dict(text=text, names=names, name_off=np.array(name_off, np.uint64), name_len=np.array(name_len, np.uint8),
+                cb=np.array(cb, np.uint64), ce=np.array(ce, np.uint64), wk=np.array(wk, np.uint8), walks=walks,
+                link_off=np.array(link_off, np.uint64), links=links, table=table)
+
+
+def test_segment_names_that_are_not_numbers(ctx):
+    """names like s12 / utg000012l / up to 16 bytes: node2id is a hash table in HBM keyed by the name bytes (graph.rs:308-375),
+    the tokeniser looks every step up there (graph.rs:231) -- same ItemTable as a plain split of the text, histogram against the oracle"""
+    from panacus_amd import capi
+    rng = np.random.default_rng(21)
+    n, P = 7000, 50
+    g = _named_gfa(rng, n, P, "mixed")
+    lens = rng.integers(1, 50, size=n + 1).astype(np.uint32)
+    ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, weights=lens, name_off=g["name_off"], name_len=g["name_len"])
+    items, off, _ = ctx.get_csr()
+    want = np.concatenate([ids for ids, _ in g["walks"]]).astype(np.uint32)
+    assert np.array_equal(items, want)
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum([len(ids) for ids, _ in g["walks"]])]).astype(np.uint64))
+    pi = np.arange(P, dtype=np.uint64)
+    gi = (pi // 5).astype(np.uint64)
+    ctx.set_order(pi, gi, P // 5)
+    cnt, h = ctx.hist()
+    ocov = orc.coverage(want.astype(np.uint64), off, pi, gi, n)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 5, lens))
+    # a name that occurs twice (the reference panics, graph.rs:336), a name of 17 bytes, a step that names no segment, an empty name
+    t = bytearray(g["text"])
+    o0, o1 = int(g["name_off"][0]), int(g["name_off"][4])
+    l0 = int(g["name_len"][0])
+    dup_len = g["name_len"].copy()
+    dup_off = g["name_off"].copy()
+    dup_off[4], dup_len[4] = o0, l0          # segment 5 carries segment 1's name
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, name_off=dup_off, name_len=dup_len)
+    assert e.value.code == capi.PNX_EINVAL and "more than once" in str(e.value)
+    long_len = g["name_len"].copy()
+    long_len[3] = 17
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, name_off=g["name_off"], name_len=long_len)
+    assert e.value.code == capi.PNX_ELIMIT
+    col = b"s1+,nosuchsegment+,s2+"
+    text = g["text"] + b"P\tx\t" + col + b"\t*\n"
+    cb = np.array([len(g["text"]) + 4], np.uint64)
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(text, cb, cb + np.uint64(len(col)), np.array([0], np.uint8), n, name_off=g["name_off"], name_len=g["name_len"])
+    assert e.value.code == capi.PNX_EINVAL
+    col = b"s1+,+,s2+"
+    text = g["text"] + b"P\tx\t" + col + b"\t*\n"
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(text, cb, cb + np.uint64(len(col)), np.array([0], np.uint8), n, name_off=g["name_off"], name_len=g["name_len"])
+    assert e.value.code == capi.PNX_EINVAL
+    with pytest.raises(capi.PnxError):
+        ctx.hist()   # nothing is resident after a rejected upload
+
+
+@pytest.mark.parametrize("style", ["nice", "table", "mixed"])
+def test_l_lines_parsed_on_the_device(ctx, style):
+    """edge counts without the host's edge map: the library parses the L lines (graph.rs:276-306), numbers the distinct
+    canonical edges by their first line -- duplicates and edges written from their other end are skipped like the reference
+    skips them (graph.rs:296) -- and looks the step pairs up; the edge ItemTable must be the one the reference's ids give"""
+    from panacus_amd import capi
+    rng = np.random.default_rng(31 + len(style))
+    n, P = 2500, 40
+    g = _named_gfa(rng, n, P, style, with_links=True, dup_links=30)
+    edge_id = {}
+    for (u, o1, v, o2) in g["links"]:           # ids = ranks of the first occurrences, in file order
+        k = _canonical(u, o1, v, o2)
+        if k not in edge_id:
+            edge_id[k] = len(edge_id) + 1
+    E = len(edge_id)
+    want = [np.array([edge_id[_canonical(int(ids[a]), int(back[a]), int(ids[a + 1]), int(back[a + 1]))] for a in range(len(ids) - 1)],
+                     dtype=np.uint32) for ids, back in g["walks"]]
+    kw = dict(link_off=g["link_off"])
+    if style == "mixed":
+        kw.update(name_off=g["name_off"], name_len=g["name_len"])
+    elif style == "table":
+        kw.update(id_of_name=g["table"])
+    ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, **kw)
+    items, off, _ = ctx.get_csr()
+    assert ctx.info().n_items == E
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum([len(w) for w in want])]).astype(np.uint64))
+    assert np.array_equal(items, np.concatenate(want))
+    pi = np.arange(P, dtype=np.uint64)
+    gi = (pi // 2).astype(np.uint64)
+    ctx.set_order(pi, gi, P // 2)
+    cnt, h = ctx.hist()
+    ocov = orc.coverage(np.concatenate(want).astype(np.uint64), off, pi, gi, E)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 2))
+    # `-c all`: walks + links tokenised once, node table and edge table from them
+    woff = ctx.gfa_walks(g["text"], g["cb"], g["ce"], g["wk"], n, **kw)
+    ctx.set_csr_walks(n)
+    it_n, _, _ = ctx.get_csr()
+    assert np.array_equal(it_n, np.concatenate([ids for ids, _ in g["walks"]]).astype(np.uint32))
+    ctx.set_csr_walks(n, edges_from_links=True)
+    it_e, off_e, _ = ctx.get_csr()
+    assert np.array_equal(it_e, np.concatenate(want)) and np.array_equal(off_e, off) and ctx.info().n_items == E
+    # an L line that names no segment; a malformed one
+    bad = g["text"] + b"L\t" + (b"zz9" if style == "mixed" else b"99999999") + b"\t+\t" + g["names"][0].encode() + b"\t+\t0M\n"
+    lo = np.concatenate([g["link_off"], [len(g["text"])]]).astype(np.uint64)
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(bad, g["cb"], g["ce"], g["wk"], n, **dict(kw, link_off=lo))
+    assert e.value.code == capi.PNX_EINVAL
+    bad = g["text"] + b"L\t" + g["names"][0].encode() + b"\n"
+    with pytest.raises(capi.PnxError) as e:
+        ctx.set_csr_gfa(bad, g["cb"], g["ce"], g["wk"], n, **dict(kw, link_off=lo))
+    assert e.value.code == capi.PNX_EINVAL
