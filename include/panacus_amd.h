@@ -47,6 +47,14 @@ typedef struct pnx_ctx pnx_ctx;
 /* device = HIP device ordinal visible to this process (LOCAL_RANK for torchrun launches). */
 int pnx_init(pnx_ctx **out, int device);
 void pnx_free(pnx_ctx *ctx);
+/* (round 4) Loads the device code of the named routes ahead of their first use.  The HIP runtime loads a code object when the
+ * first kernel of it is launched (tens of ms) -- on the critical path of a one-shot command.  pnx_preload does that work
+ * without launching anything and needs no context: a host thread that has nothing else to do while the context comes up
+ * or the GFA text travels to HBM calls it beside them.  Optional; results never depend on it. */
+#define PNX_PRELOAD_GFA 1u   /* pnx_set_csr_gfa / pnx_gfa_walks: tokeniser, name table */
+#define PNX_PRELOAD_LINKS 2u /* edge counts from GFA text: L lines, edge lookup, renumbering */
+#define PNX_PRELOAD_PASS 4u  /* the coverage / histogram pass and the closed-form growth */
+int pnx_preload(int device, uint32_t what);
 /* message of the last failing call on ctx (ctx == NULL: last pnx_init failure) */
 const char *pnx_last_error(const pnx_ctx *ctx);
 const char *pnx_version(void);
@@ -111,6 +119,9 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        in canonical form (graph.rs:142-148), numbers the distinct ones by their first line (duplicates are
  *                        skipped as the reference skips them, graph.rs:296) and looks the step pairs up as above; n_edges is
  *                        reported by pnx_info (n_items).  edge_uv / edge_oo must be NULL then.
+ *                        link_off == NULL with n_links == PNX_LINKS_FIND: the library FINDS the L lines as well -- every line
+ *                        of text that starts with 'L' -- inside the bytes [link_lo, link_hi) (0, 0 = the whole text; a caller
+ *                        that saw where the first L line starts and the last one ends saves the scan of the step columns).
  * pnx_gfa_text_upload copies synchronously; the library frees its copy of the text at the end of pnx_set_csr_gfa. */
 typedef struct pnx_gfa_steps {
     const char *text;
@@ -127,7 +138,9 @@ typedef struct pnx_gfa_steps {
     const uint8_t *name_len;
     const uint64_t *link_off;
     uint64_t n_links;
+    uint64_t link_lo, link_hi;
 } pnx_gfa_steps;
+#define PNX_LINKS_FIND 0xFFFFFFFFFFFFFFFFull
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
 /* The same tokeniser for a run with -s / -e INTERVALS: the walks (node id + orientation of every step) are made from the text

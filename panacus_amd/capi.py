@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
-    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_prepare",
+    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_preload", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
     "pnx_profile_sample", "pnx_gfa_walks", "pnx_set_csr_walks",
 ]
@@ -67,7 +67,18 @@ class PnxGfaSteps(C.Structure):  # pnx_gfa_steps
                 ("id_of_name", C.POINTER(C.c_uint32)), ("n_names", C.c_uint64),
                 ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint32),
                 ("name_off", C.POINTER(C.c_uint64)), ("name_len", C.POINTER(C.c_uint8)),
-                ("link_off", C.POINTER(C.c_uint64)), ("n_links", C.c_uint64)]
+                ("link_off", C.POINTER(C.c_uint64)), ("n_links", C.c_uint64), ("link_lo", C.c_uint64), ("link_hi", C.c_uint64)]
+
+
+LINKS_FIND = 0xFFFFFFFFFFFFFFFF  # pnx_gfa_steps.n_links: the library finds the L lines itself
+
+
+def _find_links(g, find_links):
+    if find_links is None or find_links is False:
+        return
+    g.n_links = LINKS_FIND
+    if find_links is not True:
+        g.link_lo, g.link_hi = int(find_links[0]), int(find_links[1])
 
 
 class PnxPieceEvent(C.Structure):  # pnx_piece_event
@@ -315,11 +326,19 @@ class Context:
         self._ck(self._L.pnx_set_csr_pansyn_shard(self._h, seed, node_lo, n_nodes, n_paths, int(with_weights)))
         self.n_items = n_nodes
 
+    @staticmethod
+    def preload(device: int = 0, what: int = 7):
+        """pnx_preload: load the device code of the named routes (1 GFA text, 2 edges, 4 pass) before their first use"""
+        rc = load().pnx_preload(C.c_int(device), C.c_uint32(what))
+        if rc != PNX_OK:
+            raise PnxError(rc, "pnx_preload failed")
+
     def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False,
-                    edge_uv=None, edge_oo=None, name_off=None, name_len=None, link_off=None):
+                    edge_uv=None, edge_oo=None, name_off=None, name_len=None, link_off=None, find_links=None):
         """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device; with edge_uv / edge_oo
         (n_edges + 1 entries, [0] unused) the EDGE ItemTable of the same walks; name_off / name_len: segment names that are not
-        numbers, looked up in a hash table on the device; link_off: the L lines parsed on the device (edge counts)"""
+        numbers, looked up in a hash table on the device; link_off: the L lines parsed on the device (edge counts); find_links:
+        True or a byte range (lo, hi) -- the library finds the L lines itself (PNX_LINKS_FIND)"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
         ce = np.ascontiguousarray(col_end, dtype=np.uint64)
         wk = np.ascontiguousarray(is_walk, dtype=np.uint8)
@@ -343,10 +362,11 @@ class Context:
         lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
         g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
         g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
+        _find_links(g, find_links)
         self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = int(self.info().n_items)
 
-    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, name_off=None, name_len=None, link_off=None) -> np.ndarray:
+    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, name_off=None, name_len=None, link_off=None, find_links=None) -> np.ndarray:
         """pnx_gfa_walks: the walks of GFA text tokenised on the device and kept there for set_csr_cut(walk_node=None, ...);
         -> their n_paths + 1 offsets"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
@@ -363,6 +383,7 @@ class Context:
         lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
         g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
         g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
+        _find_links(g, find_links)
         off = np.zeros(len(cb) + 1, dtype=np.uint64)
         self._ck(self._L.pnx_gfa_walks(self._h, C.byref(g), _ptr(off, C.c_uint64)))
         return off

@@ -742,3 +742,19 @@ int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out) {
 }
 
 }  // extern "C"
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_closed_form(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_PASS) {
+        touch((const void *)k_cf_setup);
+        touch((const void *)k_cf_rows);
+        touch((const void *)k_cf_lsq);
+        touch((const void *)k_cf_eval);
+    }
+}
+}  // namespace pnx

@@ -179,36 +179,96 @@ __device__ static inline void piece_of(uint64_t s, uint64_t e, uint64_t p, uint6
 }
 
 // ---- edge ids of the step pairs, looked up on the device ------------------------------------------
-// (uv, oo) -> edge id: open addressing over two arrays; a key may sit in several slots (same ends, other
-// orientations), so neither insert nor lookup stops at an equal key with the wrong orientation
-struct EdgeTab {
-    unsigned long long *key;  // 0 = empty (uv >= 2^32: node ids start at 1)
-    uint32_t *val;            // id << 2 | oo
-    uint64_t mask;
+// (uv, oo) -> edge id.  The edges are filed under their SMALLER end: ent[first[a] .. first[a + 1]) holds the (larger end,
+// id << 2 | oo) entries of node a, sorted by the larger end.  Consecutive steps of a walk name neighbouring nodes, so
+// consecutive lookups read neighbouring lines of both arrays -- a hash table in HBM scattered them over 150 MB: 8.6 ms for the
+// 227 M steps of the chr22 shape (round 3), against ~1 ms for the walk's own bytes.
+struct EdgeAdj {
+    const uint32_t *first;  // n_nodes + 2 entries: first[a] = number of edges whose smaller end is < a
+    const uint2 *ent;       // {larger end, id << 2 | oo}
+    uint32_t n_nodes;
 };
-__device__ static inline uint64_t edge_hash(uint64_t uv, uint32_t oo) {
-    uint64_t x = (uv ^ ((uint64_t)oo << 62)) * 0x9FB21C651E98DF25ull;
-    return x ^ (x >> 31);
+__device__ static inline uint32_t edge_id_of(const EdgeAdj &t, uint64_t uv, uint32_t oo) {
+    const uint32_t a = (uint32_t)(uv >> 32), b = (uint32_t)uv;
+    if (a == 0u || a > t.n_nodes) return 0u;
+    uint32_t lo = t.first[a];
+    const uint32_t hi = t.first[a + 1];
+    if (hi - lo > 8u) {  // a hub: the first entry that is not below b
+        uint32_t h = hi;
+        while (lo < h) {
+            const uint32_t mid = lo + (h - lo) / 2;
+            if (t.ent[mid].x < b) lo = mid + 1; else h = mid;
+        }
+    }
+    for (uint32_t e = lo; e < hi; ++e) {
+        const uint2 x = t.ent[e];
+        if (x.x > b) break;
+        if (x.x == b && (x.y & 3u) == oo) return x.y >> 2;
+    }
+    return 0u;
 }
-__global__ void k_edge_tab_insert(const uint64_t *__restrict__ uv, const uint8_t *__restrict__ oo, uint32_t n_edges, EdgeTab t,
-                                  uint32_t *bad) {
+// sort keys (uv) and values (id << 2 | oo) of the edges, the degree of every smaller end; bad: an entry that is not canonical
+__global__ void k_edge_adj_keys(const uint64_t *__restrict__ uv, const uint8_t *__restrict__ oo, uint32_t n_edges, uint32_t n_nodes,
+                                unsigned long long *__restrict__ key, uint32_t *__restrict__ val, uint32_t *__restrict__ deg, uint32_t *bad) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (id > n_edges) return;
     const unsigned long long k = uv[id];
-    const uint32_t o = oo[id] & 3u;
-    if ((k >> 32) == 0 || (uint32_t)k == 0 || (k >> 32) > (uint32_t)k) {  // canonical: 1 <= smaller <= larger
+    const uint32_t o = oo[id] & 3u, a = (uint32_t)(k >> 32), b = (uint32_t)k;
+    key[id - 1] = k;
+    val[id - 1] = (id << 2) | o;
+    if (a == 0u || a > b || b > n_nodes) {  // canonical: 1 <= smaller <= larger <= n_nodes
         *bad = 1u;
         return;
     }
-    uint64_t slot = edge_hash(k, o) & t.mask;
-    for (;;) {
-        const unsigned long long prev = atomicCAS(t.key + slot, 0ull, k);
-        if (prev == 0ull) {
-            t.val[slot] = (id << 2) | o;
-            return;
-        }
-        slot = (slot + 1) & t.mask;
+    atomicAdd(deg + a, 1u);
+}
+__global__ void k_edge_adj_pack(const unsigned long long *__restrict__ key, const uint32_t *__restrict__ val, uint32_t n_edges,
+                                uint2 *__restrict__ ent) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) ent[e] = make_uint2((uint32_t)key[e], val[e]);
+}
+struct EdgeAdjBufs {
+    DevBuf key, val, key2, val2, deg, first, ent, tmp;
+    ~EdgeAdjBufs() {
+        for (DevBuf *b : {&key, &val, &key2, &val2, &deg, &first, &ent, &tmp}) release(*b);
     }
+};
+// d_uv / d_oo: the edges by id (entry 0 unused), on the device.  *d_bad is set by the kernel when an entry is not canonical
+// (the caller reads it with its other flags).
+static int build_edge_adj(pnx_ctx *ctx, hipStream_t st, const uint64_t *d_uv, const uint8_t *d_oo, uint32_t n_edges, uint32_t n_nodes,
+                          EdgeAdjBufs &s, uint32_t *d_bad, EdgeAdj &adj) {
+    if (n_edges >= (1u << 30)) return ctx->fail(PNX_ELIMIT, "edge lookup: %u edges, room for 2^30 - 1", n_edges);
+    int rc;
+    const size_t E = n_edges ? n_edges : 1, N2 = (size_t)n_nodes + 2;
+    if ((rc = ensure(ctx, s.key, E * 8)) || (rc = ensure(ctx, s.val, E * 4)) || (rc = ensure(ctx, s.key2, E * 8)) ||
+        (rc = ensure(ctx, s.val2, E * 4)) || (rc = ensure(ctx, s.deg, N2 * 4)) || (rc = ensure(ctx, s.first, N2 * 4)) ||
+        (rc = ensure(ctx, s.ent, E * 8)))
+        return rc;
+    PNX_HIP(ctx, hipMemsetAsync(s.deg.p, 0, N2 * 4, st));
+    if (n_edges) {
+        hipLaunchKernelGGL(k_edge_adj_keys, dim3((n_edges + 255) / 256), dim3(256), 0, st, d_uv, d_oo, n_edges, n_nodes,
+                           (unsigned long long *)s.key.p, (uint32_t *)s.val.p, (uint32_t *)s.deg.p, d_bad);
+        PNX_HIP(ctx, hipGetLastError());
+        unsigned bits = 33;  // the larger end's 32 bits + as many as the smaller end can take
+        while (bits < 64 && (n_nodes >> (bits - 32))) ++bits;
+        size_t bytes = 0;
+        PNX_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long *)s.key.p, (unsigned long long *)s.key2.p,
+                                               (const uint32_t *)s.val.p, (uint32_t *)s.val2.p, (size_t)n_edges, 0u, bits, st));
+        if ((rc = ensure(ctx, s.tmp, bytes ? bytes : 8))) return rc;
+        PNX_HIP(ctx, rocprim::radix_sort_pairs(s.tmp.p, bytes, (const unsigned long long *)s.key.p, (unsigned long long *)s.key2.p,
+                                               (const uint32_t *)s.val.p, (uint32_t *)s.val2.p, (size_t)n_edges, 0u, bits, st));
+        hipLaunchKernelGGL(k_edge_adj_pack, dim3((n_edges + 255) / 256), dim3(256), 0, st, (const unsigned long long *)s.key2.p,
+                           (const uint32_t *)s.val2.p, n_edges, (uint2 *)s.ent.p);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    size_t bytes = 0;
+    PNX_HIP(ctx, rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)s.deg.p, (uint32_t *)s.first.p, 0u, N2, rocprim::plus<uint32_t>(), st));
+    if ((rc = ensure(ctx, s.tmp, bytes ? bytes : 8))) return rc;
+    PNX_HIP(ctx, rocprim::exclusive_scan(s.tmp.p, bytes, (const uint32_t *)s.deg.p, (uint32_t *)s.first.p, 0u, N2, rocprim::plus<uint32_t>(), st));
+    adj.first = (const uint32_t *)s.first.p;
+    adj.ent = (const uint2 *)s.ent.p;
+    adj.n_nodes = n_nodes;
+    return PNX_OK;
 }
 // Edge::canonical (graph.rs:142-148) of the step pair (u, o1) -> (v, o2)
 __device__ static inline void canonical_edge(uint32_t u, uint32_t o1, uint32_t v, uint32_t o2, uint64_t &uv, uint32_t &oo) {
@@ -221,7 +281,7 @@ __device__ static inline void canonical_edge(uint32_t u, uint32_t o1, uint32_t v
     }
 }
 // one thread per step: the edge to its successor in the same path -> edge_item[edge_off[path] + local index]
-__global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeTab t, uint32_t *__restrict__ out, unsigned long long *bad_step) {
+__global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeAdj t, uint32_t *__restrict__ out, unsigned long long *bad_step) {
     const CutChunk ch = cut_chunk_of(blockIdx.x, a);
     const uint64_t e0 = a.edge_off[ch.path] - a.off[ch.path];
     for (uint32_t x = threadIdx.x; x < ch.len; x += CUT_THREADS) {
@@ -230,56 +290,34 @@ __global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeTab t
         uint64_t uv;
         uint32_t oo;
         canonical_edge(a.node[j], a.backward ? a.backward[j] & 1u : 0u, a.node[j + 1], a.backward ? a.backward[j + 1] & 1u : 0u, uv, oo);
-        uint64_t slot = edge_hash(uv, oo) & t.mask;
-        uint32_t id = 0;
-        for (;;) {
-            const unsigned long long k = t.key[slot];
-            if (k == 0ull) break;
-            if (k == uv) {
-                const uint32_t v = t.val[slot];
-                if ((v & 3u) == oo) {
-                    id = v >> 2;
-                    break;
-                }
-            }
-            slot = (slot + 1) & t.mask;
-        }
+        const uint32_t id = edge_id_of(t, uv, oo);
         if (!id) atomicMin(bad_step, (unsigned long long)j);
         out[j + e0] = id;
     }
 }
 
-// the same over walks that were tokenised on the device (pnx_set_csr_gfa with edges): one thread per step, its path found
-// by a binary search in the path offsets; out[edge_off[path] + local index] = edge to the successor in the same path
+// the same over walks that were tokenised on the device (pnx_set_csr_gfa with edges): one thread per step; the path of a wave's
+// first step is found by a binary search in the path offsets (once per wave), the other lanes walk on from there;
+// out[edge_off[path] + local index] = edge to the successor in the same path
 __global__ __launch_bounds__(256) void k_edge_items_flat(const uint32_t *__restrict__ node, const uint8_t *__restrict__ backward,
                                                          const uint64_t *__restrict__ path_off, uint32_t n_paths,
-                                                         const uint64_t *__restrict__ edge_off, uint64_t n_steps, EdgeTab t,
+                                                         const uint64_t *__restrict__ edge_off, uint64_t n_steps, EdgeAdj t,
                                                          uint32_t *__restrict__ out, unsigned long long *bad_step) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_steps) return;
-    uint32_t lo = 0, hi = n_paths;  // the path p with path_off[p] <= j < path_off[p + 1]
+    const uint64_t j0 = j - (threadIdx.x & 63u);  // (wave-uniform)
+    if (j0 >= n_steps) return;
+    uint32_t lo = 0, hi = n_paths;  // the path p with path_off[p] <= j0 < path_off[p + 1]
     while (hi - lo > 1) {
         const uint32_t mid = lo + (hi - lo) / 2;
-        if (path_off[mid] <= j) lo = mid; else hi = mid;
+        if (path_off[mid] <= j0) lo = mid; else hi = mid;
     }
+    if (j >= n_steps) return;
+    while (path_off[lo + 1] <= j) ++lo;  // (empty paths are stepped over too)
     if (j + 1 >= path_off[lo + 1]) return;  // last step of its path
     uint64_t uv;
     uint32_t oo;
     canonical_edge(node[j], backward[j] & 1u, node[j + 1], backward[j + 1] & 1u, uv, oo);
-    uint64_t slot = edge_hash(uv, oo) & t.mask;
-    uint32_t id = 0;
-    for (;;) {
-        const unsigned long long k = t.key[slot];
-        if (k == 0ull) break;
-        if (k == uv) {
-            const uint32_t v = t.val[slot];
-            if ((v & 3u) == oo) {
-                id = v >> 2;
-                break;
-            }
-        }
-        slot = (slot + 1) & t.mask;
-    }
+    const uint32_t id = edge_id_of(t, uv, oo);
     if (!id) atomicMin(bad_step, (unsigned long long)j);
     out[edge_off[lo] + (j - path_off[lo])] = id;
 }
@@ -447,10 +485,11 @@ namespace {
 struct Scratch {  // freed on every way out
     std::vector<DevBuf *> all;
     DevBuf node, back, off, chunk_off, start, mode, len, eitem, eoff, inc_off, inc_iv, exc_off, exc_iv, chunk_bp, chunk_base,
-        chunk_cnt, chunk_out, is_partial, last_full, events, counters, tmp, out_off, e_uv, e_oo, tab_key, tab_val;
+        chunk_cnt, chunk_out, is_partial, last_full, events, counters, tmp, out_off, e_uv, e_oo;
+        EdgeAdjBufs adj;
     Scratch() {
         all = {&node, &back, &off, &chunk_off, &start, &mode, &len, &eitem, &eoff, &inc_off, &inc_iv, &exc_off, &exc_iv, &chunk_bp,
-               &chunk_base, &chunk_cnt, &chunk_out, &is_partial, &last_full, &events, &counters, &tmp, &out_off, &e_uv, &e_oo, &tab_key, &tab_val};
+               &chunk_base, &chunk_cnt, &chunk_out, &is_partial, &last_full, &events, &counters, &tmp, &out_off, &e_uv, &e_oo};
     }
     ~Scratch() {
         for (DevBuf *b : all) release(*b);
@@ -562,21 +601,13 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
     uint32_t *d_bad = (uint32_t *)((char *)s.counters.p + 8);
 
     uint64_t total = 0;
-    EdgeTab tab{};
+    EdgeAdj tab{};
     unsigned long long *d_bad_step = (unsigned long long *)((char *)s.counters.p + 16);
-    if (lookup && w->n_items) {  // the edges into a hash table in HBM (load factor <= 1/2)
-        uint64_t slots = 1024;
-        while (slots < 2ull * w->n_items) slots <<= 1;
+    if (lookup && w->n_items) {  // the edges filed under their smaller ends (EdgeAdj)
         if ((rc = up(s.e_uv, w->edge_uv, ((size_t)w->n_items + 1) * 8)) || (rc = up(s.e_oo, w->edge_oo, (size_t)w->n_items + 1)) ||
-            (rc = ensure(ctx, s.tab_key, slots * 8)) || (rc = ensure(ctx, s.tab_val, slots * 4)))
+            (rc = build_edge_adj(ctx, ctx->stream, (const uint64_t *)s.e_uv.p, (const uint8_t *)s.e_oo.p, w->n_items, w->n_nodes, s.adj,
+                                 d_bad + 1, tab)))
             return rc;
-        PNX_HIP(ctx, hipMemsetAsync(s.tab_key.p, 0, slots * 8, ctx->stream));
-        tab.key = (unsigned long long *)s.tab_key.p;
-        tab.val = (uint32_t *)s.tab_val.p;
-        tab.mask = slots - 1;
-        hipLaunchKernelGGL(k_edge_tab_insert, dim3((w->n_items + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t *)s.e_uv.p,
-                           (const uint8_t *)s.e_oo.p, w->n_items, tab, d_bad + 1);
-        PNX_HIP(ctx, hipGetLastError());
     }
     if (C) {
         hipLaunchKernelGGL(k_cut_chunk_bp, dim3((uint32_t)C), dim3(CUT_THREADS), 0, ctx->stream, a, (uint64_t *)s.chunk_bp.p, d_bad);
@@ -585,7 +616,7 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
         PNX_HIP(ctx, hipMemcpyAsync(bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the walk gathers node_len[id]: ids must be valid first
         if (bad[0]) return ctx->fail(PNX_EINVAL, "walk_node contains ids outside 1..n_nodes");
-        if (bad[1]) return ctx->fail(PNX_EINVAL, "edge_uv holds an entry that is not canonical (1 <= smaller end <= larger end)");
+        if (bad[1]) return ctx->fail(PNX_EINVAL, "edge_uv holds an entry that is not canonical (1 <= smaller end <= larger end <= n_nodes)");
         if (lookup && E) {
             if (!w->n_items) return ctx->fail(PNX_EINVAL, "unknown edge in path: the graph has no edges");
             PNX_HIP(ctx, hipMemsetAsync(d_bad_step, 0xFF, 8, ctx->stream));
@@ -640,12 +671,13 @@ int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_
 
 // pnx_set_csr_gfa with edges: the node walks gfa_tokenise left in d_items (+ one orientation byte per step) become the edge
 // ItemTable of the same paths, on the device
-int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges,
-                   bool edges_on_device) {
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, uint32_t n_nodes, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo,
+                   uint32_t n_edges, bool edges_on_device) {
     struct Scratch {
-        DevBuf e_uv, e_oo, tab_key, tab_val, eoff, out, counters;
+        DevBuf e_uv, e_oo, eoff, out, counters;
+        EdgeAdjBufs adj;
         ~Scratch() {
-            for (DevBuf *b : {&e_uv, &e_oo, &tab_key, &tab_val, &eoff, &out, &counters}) release(*b);
+            for (DevBuf *b : {&e_uv, &e_oo, &eoff, &out, &counters}) release(*b);
         }
     } s;
     hipStream_t st = ctx->stream;
@@ -658,25 +690,20 @@ int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, con
         edge_off[p + 1] = edge_off[p] + (len ? len - 1 : 0);
     }
     const uint64_t Se = edge_off[n_paths];
-    uint64_t slots = 1024;
-    while (slots < 2ull * n_edges) slots <<= 1;
     if ((rc = ensure(ctx, s.e_uv, ((size_t)n_edges + 1) * 8)) || (rc = ensure(ctx, s.e_oo, (size_t)n_edges + 1)) ||
-        (rc = ensure(ctx, s.tab_key, slots * 8)) || (rc = ensure(ctx, s.tab_val, slots * 4)) || (rc = ensure(ctx, s.eoff, p1 * 8)) ||
+        (rc = ensure(ctx, s.eoff, p1 * 8)) ||
         (rc = ensure(ctx, s.out, (Se ? Se : 1) * sizeof(uint32_t) + 64)) || (rc = ensure(ctx, s.counters, 64)))
         return rc;
     const hipMemcpyKind kind = edges_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     PNX_HIP(ctx, hipMemcpyAsync(s.e_uv.p, edge_uv, ((size_t)n_edges + 1) * 8, kind, st));
     PNX_HIP(ctx, hipMemcpyAsync(s.e_oo.p, edge_oo, (size_t)n_edges + 1, kind, st));
     PNX_HIP(ctx, hipMemcpyAsync(s.eoff.p, edge_off.data(), p1 * 8, hipMemcpyHostToDevice, st));
-    PNX_HIP(ctx, hipMemsetAsync(s.tab_key.p, 0, slots * 8, st));
     PNX_HIP(ctx, hipMemsetAsync(s.counters.p, 0, 64, st));
     PNX_HIP(ctx, hipMemsetAsync((char *)s.counters.p + 16, 0xFF, 8, st));  // smallest step without an edge
-    EdgeTab tab{(unsigned long long *)s.tab_key.p, (uint32_t *)s.tab_val.p, slots - 1};
+    EdgeAdj tab{};
     uint32_t *d_bad = (uint32_t *)s.counters.p;
     unsigned long long *d_bad_step = (unsigned long long *)((char *)s.counters.p + 16);
-    if (n_edges)
-        hipLaunchKernelGGL(k_edge_tab_insert, dim3((n_edges + 255) / 256), dim3(256), 0, st, (const uint64_t *)s.e_uv.p, (const uint8_t *)s.e_oo.p,
-                           n_edges, tab, d_bad);
+    if ((rc = build_edge_adj(ctx, st, (const uint64_t *)s.e_uv.p, (const uint8_t *)s.e_oo.p, n_edges, n_nodes, s.adj, d_bad, tab))) return rc;
     if (S)
         hipLaunchKernelGGL(k_edge_items_flat, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, (const uint32_t *)ctx->d_items.p,
                            (const uint8_t *)d_backward.p, (const uint64_t *)ctx->d_path_off.p, n_paths, (const uint64_t *)s.eoff.p, S, tab,
@@ -689,7 +716,7 @@ int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, con
     PNX_HIP(ctx, hipMemcpyAsync(&h, s.counters.p, 24, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, s.eoff.p, p1 * 8, hipMemcpyDeviceToDevice, st));
     PNX_HIP(ctx, hipStreamSynchronize(st));
-    if (h.bad) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: an edge is not in canonical form (smaller end << 32 | larger, node ids from 1)");
+    if (h.bad) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: an edge is not in canonical form (smaller end << 32 | larger, node ids 1..n_nodes)");
     if (h.bad_step != ~0ull)
         return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: step %llu and its successor are not joined by an edge of the graph", h.bad_step);
     std::swap(ctx->d_items, s.out);  // (the node walks are released with the scratch)
@@ -726,4 +753,19 @@ int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n) {
     return PNX_OK;
 }
 
+}  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_cut(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_LINKS) {
+        touch((const void *)k_edge_adj_keys);
+        touch((const void *)k_edge_adj_pack);
+        touch((const void *)k_edge_items_flat);
+    }
+}
 }  // namespace pnx

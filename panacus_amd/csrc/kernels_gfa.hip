@@ -432,6 +432,47 @@ __global__ void k_links_parse(const uint8_t *__restrict__ text, uint64_t text_by
     l_key[k] = key;
     if (bad) atomicOr(flags, bad);
 }
+// The L lines found on the device (pnx_gfa_steps.n_links == PNX_LINKS_FIND): a line starts at byte 0 or behind a '\n'; the
+// ones that start with 'L' are links (graph.rs:276).  One workgroup per 4 KB of text, 16 bytes per lane, byte-parallel
+// compares; the offsets come out in file order (counts per tile, a scan, then the same kernel writes).
+constexpr uint32_t FIND_TILE = 4096;
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_links_find(const uint8_t *__restrict__ text, uint64_t lo16, uint64_t lo, uint64_t hi,
+                                                    uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_base,
+                                                    uint64_t *__restrict__ out) {
+    using Scan = rocprim::block_scan<uint32_t, 256>;
+    __shared__ typename Scan::storage_type scan_mem;
+    const uint64_t p = lo16 + (uint64_t)blockIdx.x * FIND_TILE + threadIdx.x * 16u;
+    uint32_t m = 0;  // bit i: byte p + i starts an L line
+    if (p < hi) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(text + p);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        uint32_t carry = (p == 0 || text[p - 1] == '\n') ? 0x80u : 0u;  // "the byte before is a line end", as a flag in bit 7
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t nl = tok_eq(w[k], 0x0A0A0A0Au);
+            const uint32_t f = tok_eq(w[k], 0x4C4C4C4Cu) & ((nl << 8) | carry);
+            carry = nl >> 24;
+            m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * k);
+        }
+        if (p < lo) m &= ~0u << (uint32_t)(lo - p);                 // (lo16 <= lo < lo16 + 16)
+        if (p + 16 > hi) m &= (1u << (uint32_t)(hi - p)) - 1u;
+    }
+    const uint32_t c = __popc(m);
+    uint32_t before = 0, total = 0;
+    Scan().exclusive_scan(c, before, 0u, total, scan_mem);
+    if (!EMIT) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+        return;
+    }
+    uint64_t at = (uint64_t)tile_base[blockIdx.x] + before;
+    while (m) {
+        const uint32_t i = __ffs(m) - 1;
+        m &= m - 1;
+        out[at++] = p + i;
+    }
+}
+
 struct LinkTab {
     unsigned long long *key;  // 0 = empty
     uint32_t *first;          // smallest line with this edge
@@ -547,16 +588,47 @@ static int gfa_name_table(pnx_ctx *ctx, const pnx_gfa_steps *g, NameTab &names) 
 // Needs the text in HBM and, for names that are not numbers, the name table of this upload.
 int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, DevBuf &d_e_oo, uint32_t &n_edges) {
     n_edges = 0;
-    const uint64_t n = g->n_links;
+    const bool find = !g->link_off && g->n_links == PNX_LINKS_FIND;
+    uint64_t n = find ? 0 : g->n_links;
     if (n >= 0xFFFFFFFEull) return ctx->fail(PNX_ELIMIT, "more than 2^32-2 L lines");
     if (g->n_nodes >= (1u << 30)) return ctx->fail(PNX_ELIMIT, "L lines on the device: at most 2^30-1 segments");
     hipStream_t st = ctx->stream;
     struct Scratch {
-        DevBuf off, key, tkey, tfirst, first, rank, tmp, names;
+        DevBuf off, key, tkey, tfirst, first, rank, tmp, names, tile_cnt, tile_base;
         ~Scratch() {
-            for (DevBuf *b : {&off, &key, &tkey, &tfirst, &first, &rank, &tmp, &names}) release(*b);
+            for (DevBuf *b : {&off, &key, &tkey, &tfirst, &first, &rank, &tmp, &names, &tile_cnt, &tile_base}) release(*b);
         }
     } sc;
+    if (find) {  // which lines are L lines: asked of the text itself, inside the byte range the caller names (0, 0: all of it)
+        const uint64_t hi = g->link_hi ? std::min<uint64_t>(g->link_hi, ctx->gfa_text_bytes) : ctx->gfa_text_bytes;
+        const uint64_t lo = std::min<uint64_t>(g->link_lo, hi), lo16 = lo & ~15ull;
+        const uint64_t tiles = (hi - lo16 + FIND_TILE - 1) / FIND_TILE;
+        if (tiles >= 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "L lines on the device: the text range is too long");
+        int rc0;
+        if ((rc0 = ensure(ctx, sc.tile_cnt, (tiles + 1) * 4)) || (rc0 = ensure(ctx, sc.tile_base, (tiles + 1) * 4))) return rc0;
+        const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
+        uint32_t found = 0;
+        if (tiles) {
+            PNX_HIP(ctx, hipMemsetAsync((uint32_t *)sc.tile_cnt.p + tiles, 0, 4, st));
+            hipLaunchKernelGGL(k_links_find<false>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, (uint32_t *)sc.tile_cnt.p,
+                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
+            size_t tmp_bytes = 0;
+            PNX_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)sc.tile_cnt.p, (uint32_t *)sc.tile_base.p, 0u, (size_t)tiles + 1,
+                                                 rocprim::plus<uint32_t>(), st));
+            if ((rc0 = ensure(ctx, sc.tmp, tmp_bytes ? tmp_bytes : 8))) return rc0;
+            PNX_HIP(ctx, rocprim::exclusive_scan(sc.tmp.p, tmp_bytes, (uint32_t *)sc.tile_cnt.p, (uint32_t *)sc.tile_base.p, 0u, (size_t)tiles + 1,
+                                                 rocprim::plus<uint32_t>(), st));
+            PNX_HIP(ctx, hipMemcpyAsync(&found, (uint32_t *)sc.tile_base.p + tiles, 4, hipMemcpyDeviceToHost, st));
+            PNX_HIP(ctx, hipStreamSynchronize(st));
+        }
+        n = found;
+        if (n) {
+            if ((rc0 = ensure(ctx, sc.off, n * 8))) return rc0;
+            hipLaunchKernelGGL(k_links_find<true>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, (uint32_t *)nullptr,
+                               (const uint32_t *)sc.tile_base.p, (uint64_t *)sc.off.p);
+            PNX_HIP(ctx, hipGetLastError());
+        }
+    }
     uint64_t slots = 1024;
     while (slots < 2 * n) slots <<= 1;
     const size_t n1 = n ? n : 1;
@@ -579,7 +651,7 @@ int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, Dev
         nn.id_of_name = (const uint32_t *)sc.names.p;
         nn.n_names = g->n_names;
     }
-    if (n) PNX_HIP(ctx, hipMemcpyAsync(sc.off.p, g->link_off, n * 8, hipMemcpyHostToDevice, st));
+    if (n && !find) PNX_HIP(ctx, hipMemcpyAsync(sc.off.p, g->link_off, n * 8, hipMemcpyHostToDevice, st));
     PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), st));
     PNX_HIP(ctx, hipMemsetAsync(sc.tkey.p, 0, slots * 8, st));
     PNX_HIP(ctx, hipMemsetAsync(sc.tfirst.p, 0xFF, slots * 4, st));
@@ -706,4 +778,31 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
     return PNX_OK;
 }
 
+}  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_gfa(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_GFA) {
+        touch((const void *)k_tok_count);
+        touch((const void *)k_tok_emit<false>);
+        touch((const void *)k_tok_emit<true>);
+        touch((const void *)k_tok_total);
+        touch((const void *)k_tok_path_off);
+        touch((const void *)k_names_insert);
+        touch((const void *)k_names_verify);
+    }
+    if (what & PNX_PRELOAD_LINKS) {
+        touch((const void *)k_links_find<false>);
+        touch((const void *)k_links_find<true>);
+        touch((const void *)k_links_parse);
+        touch((const void *)k_links_insert);
+        touch((const void *)k_links_first);
+        touch((const void *)k_links_emit);
+    }
+}
 }  // namespace pnx

@@ -133,3 +133,14 @@ int launch_hist(pnx_ctx *ctx, Ticket *tk) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_hist(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_PASS) touch((const void *)k_hist_publish);
+}
+}  // namespace pnx

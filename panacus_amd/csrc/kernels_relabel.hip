@@ -199,3 +199,18 @@ int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_relabel(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_LINKS) {
+        touch((const void *)k_keys_sorted);
+        touch((const void *)k_invert_map);
+        touch((const void *)k_map_steps);
+    }
+}
+}  // namespace pnx

@@ -651,3 +651,20 @@ int launch_rows_phases(pnx_ctx *ctx, bool write_m) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_rows(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_PASS) {
+        touch((const void *)k_rows_build<true>);
+        touch((const void *)k_rows_build<false>);
+        touch((const void *)k_rows_spans);
+        touch((const void *)k_rows_order);
+        touch((const void *)k_rows_cover<12, false, 8, 8, false>);
+    }
+}
+}  // namespace pnx

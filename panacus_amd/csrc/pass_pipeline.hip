@@ -155,3 +155,14 @@ int launch_cover_pass(pnx_ctx *ctx) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload: the first launch of a kernel loads the code object of its translation unit (tens of ms) and builds the
+// kernel's function object; asking for a kernel's attributes does the same, without a launch -- and can be done by a host
+// thread that has nothing else to do while the GFA text travels to HBM
+void preload_pass(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_PASS) touch((const void *)k_validate_items);
+}
+}  // namespace pnx

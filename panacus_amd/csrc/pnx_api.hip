@@ -75,12 +75,18 @@ static int choose_pass_streams(pnx_ctx *ctx) {
     const bool use_m = ctx->want_M || (!use_rows(ctx) && ctx->last_general_paths > 0);
     // (a one-shot pass over the steps is one chain of three kernels: on one stream a dependent kernel follows within ~2 us, across
     // streams the event hand-over costs ~25 us each -- nothing to overlap it with either)
-    const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m && !ctx->pass_band;
+    // (the three-stream arrangement pays when passes overlap each other; its two extra queues cost 9 ms each to create, so a
+    // context makes them the first time a pass is enqueued while another is still in flight -- a command that waits for
+    // each histogram before it asks for the next never does, and its passes run on one stream without event hand-overs)
+    const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m && !ctx->pass_band &&
+                        (ctx->stream_pre != nullptr || ctx->tk_count > 0);
     if (ctx->tk_count && phased != ctx->last_pass_phased) {
         int rc = drain_streams(ctx);  // a pass in flight took the other arrangement: let it finish on the device
         if (rc) return rc;
     }
     ctx->last_pass_phased = phased;
+    if (phased && !ctx->stream_pre) PNX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_pre, hipStreamNonBlocking));
+    if (phased && !ctx->stream_post) PNX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking));
     ctx->s_main = ctx->stream;
     ctx->s_pre = phased ? ctx->stream_pre : ctx->stream;
     ctx->s_post = phased ? ctx->stream_post : ctx->stream;
@@ -274,6 +280,19 @@ const char *pnx_version(void) { return "panacus_amd 0.1.0 (gfx950)"; }
 
 const char *pnx_last_error(const pnx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
 
+int pnx_preload(int device, uint32_t what) {
+    if (hipSetDevice(device) != hipSuccess) return PNX_ENODEV;
+    pnx::preload_gfa(what);
+    pnx::preload_cut(what);
+    pnx::preload_relabel(what);
+    pnx::preload_pass(what);
+    pnx::preload_band(what);
+    pnx::preload_rows(what);
+    pnx::preload_hist(what);
+    pnx::preload_closed_form(what);
+    return PNX_OK;
+}
+
 int pnx_init(pnx_ctx **out, int device) {
     if (!out) return PNX_EINVAL;
     *out = nullptr;
@@ -292,9 +311,9 @@ int pnx_init(pnx_ctx **out, int device) {
     if (!ctx) return PNX_ENOMEM;
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream_pre, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking)) != hipSuccess) {
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        // (stream_pre / stream_post: made when the first phased pass asks for them -- a queue costs 9 ms to create, and a
+        // one-shot command never uses these two)
         g_init_err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         delete ctx;
         return PNX_EHIP;
@@ -505,8 +524,11 @@ int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes) {
 static int check_gfa_naming(pnx_ctx *ctx, const pnx_gfa_steps *g, const char *who) {
     if (g->name_off && (!g->name_len || g->id_of_name)) return ctx->fail(PNX_EINVAL, "%s: name_off comes with name_len and without id_of_name", who);
     if (g->link_off && (g->edge_uv || g->edge_oo)) return ctx->fail(PNX_EINVAL, "%s: link_off (the L lines parsed on the device) and edge_uv / edge_oo are two ways to hand over the edges: pass one", who);
-    if (g->n_links && !g->link_off) return ctx->fail(PNX_EINVAL, "%s: n_links without link_off", who);
     const uint64_t bytes = g->text ? g->text_bytes : ctx->gfa_text_bytes;
+    const bool find_links = !g->link_off && g->n_links == PNX_LINKS_FIND;
+    if (find_links && (g->edge_uv || g->edge_oo)) return ctx->fail(PNX_EINVAL, "%s: PNX_LINKS_FIND and edge_uv / edge_oo are two ways to hand over the edges: pass one", who);
+    if (g->n_links && !g->link_off && !find_links) return ctx->fail(PNX_EINVAL, "%s: n_links without link_off", who);
+    if (find_links && g->link_hi && (g->link_lo > g->link_hi || g->link_hi > bytes)) return ctx->fail(PNX_EINVAL, "%s: link_lo .. link_hi is not a range of the text", who);
     for (uint64_t k = 0; g->link_off && k < g->n_links; ++k)
         if (g->link_off[k] >= bytes) return ctx->fail(PNX_EINVAL, "%s: L line %llu lies outside the text", who, (unsigned long long)k);
     for (uint32_t i = 0; g->name_off && i < g->n_nodes; ++i)
@@ -534,7 +556,7 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     ctx->walks_valid = false;
     release(ctx->d_walk_node);
     release(ctx->d_walk_back);
-    const bool links = g->link_off != nullptr, edges = g->edge_uv != nullptr || links;
+    const bool links = g->link_off != nullptr || g->n_links == PNX_LINKS_FIND, edges = g->edge_uv != nullptr || links;
     if (edges && ((!links && !g->edge_oo) || weights)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa: edge counts take edge_uv AND edge_oo (or link_off), and no weights");
     DevBuf d_backward, d_e_uv, d_e_oo;
     uint32_t n_edges = g->n_edges;
@@ -543,8 +565,8 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     drop_gfa_text(ctx);
     release(ctx->d_name_tab);
     if (rc == PNX_OK && edges)
-        rc = links ? gfa_edge_items(ctx, g->n_paths, d_backward, (const uint64_t *)d_e_uv.p, (const uint8_t *)d_e_oo.p, n_edges, true)
-                   : gfa_edge_items(ctx, g->n_paths, d_backward, g->edge_uv, g->edge_oo, n_edges);
+        rc = links ? gfa_edge_items(ctx, g->n_paths, g->n_nodes, d_backward, (const uint64_t *)d_e_uv.p, (const uint8_t *)d_e_oo.p, n_edges, true)
+                   : gfa_edge_items(ctx, g->n_paths, g->n_nodes, d_backward, g->edge_uv, g->edge_oo, n_edges);
     release(d_backward);
     release(d_e_uv);
     release(d_e_oo);
@@ -575,8 +597,9 @@ int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {
         return rc;
     rc = gfa_tokenise(ctx, g, &ctx->d_walk_back);
     // the L lines, if handed over: parsed now, while the text is in HBM, and kept beside the walks (pnx_set_csr_walks)
-    if (rc == PNX_OK && g->link_off) rc = gfa_links_to_edges(ctx, g, ctx->d_link_uv, ctx->d_link_oo, ctx->n_link_edges);
-    ctx->links_valid = rc == PNX_OK && g->link_off != nullptr;
+    const bool with_links = g->link_off != nullptr || g->n_links == PNX_LINKS_FIND;
+    if (rc == PNX_OK && with_links) rc = gfa_links_to_edges(ctx, g, ctx->d_link_uv, ctx->d_link_oo, ctx->n_link_edges);
+    ctx->links_valid = rc == PNX_OK && with_links;
     drop_gfa_text(ctx);
     release(ctx->d_name_tab);
     if (rc) return rc;
@@ -608,8 +631,8 @@ int pnx_set_csr_walks(pnx_ctx *ctx, uint32_t n_nodes, const uint32_t *weights, c
     ctx->h_path_off = ctx->h_walk_off;
     PNX_HIP(ctx, hipMemcpyAsync(ctx->d_path_off.p, ctx->h_path_off.data(), ((size_t)n_paths + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->n_steps = S;
-    if (edges && (rc = from_links ? gfa_edge_items(ctx, n_paths, ctx->d_walk_back, (const uint64_t *)ctx->d_link_uv.p, (const uint8_t *)ctx->d_link_oo.p, n_edges, true)
-                                  : gfa_edge_items(ctx, n_paths, ctx->d_walk_back, edge_uv, edge_oo, n_edges)))
+    if (edges && (rc = from_links ? gfa_edge_items(ctx, n_paths, n_nodes, ctx->d_walk_back, (const uint64_t *)ctx->d_link_uv.p, (const uint8_t *)ctx->d_link_oo.p, n_edges, true)
+                                  : gfa_edge_items(ctx, n_paths, n_nodes, ctx->d_walk_back, edge_uv, edge_oo, n_edges)))
         return rc;
     return finish_upload(ctx, ctx->n_steps, n_paths, edges ? n_edges : n_nodes, weights, exclude, false, nullptr);
 }

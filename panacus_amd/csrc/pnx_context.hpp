@@ -101,7 +101,7 @@ struct pnx_ctx {
     // counters to the host on stream_post -- so K0 of pass k+1 and K2 of pass k-1 run beside K1 of pass k,
     // and the K1s follow each other without the short kernels in between.  s_* = the streams of the
     // pass being enqueued (all three = `stream` when the pass also writes / merges the presence matrix).
-    hipStream_t stream_pre = nullptr, stream_post = nullptr;
+    hipStream_t stream_pre = nullptr, stream_post = nullptr;  // made when a pass is first enqueued behind one still in flight
     hipStream_t s_pre = nullptr, s_main = nullptr, s_post = nullptr;
     bool overlap_phases = true;  // PNX_CFG_OVERLAP_PHASES
     bool last_pass_phased = false;
@@ -371,11 +371,21 @@ int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_call
 int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal);
 int to_caller_ids_u8(pnx_ctx *ctx, const uint8_t *d_internal, uint8_t *d_caller);
 int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_internal);
+// pnx_preload: one function per translation unit
+void preload_gfa(unsigned what);
+void preload_cut(unsigned what);
+void preload_relabel(unsigned what);
+void preload_pass(unsigned what);
+void preload_band(unsigned what);
+void preload_rows(unsigned what);
+void preload_hist(unsigned what);
+void preload_closed_form(unsigned what);
+
 // kernels_cut.hip
 int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events);
 int flag_items(pnx_ctx *ctx, const uint32_t *h_ids, uint32_t n);
-int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo, uint32_t n_edges,
-                   bool edges_on_device = false);  // edges_on_device: edge_uv / edge_oo are device arrays (gfa_links_to_edges)
+int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, uint32_t n_nodes, const DevBuf &d_backward, const uint64_t *edge_uv, const uint8_t *edge_oo,
+                   uint32_t n_edges, bool edges_on_device = false);  // edges_on_device: edge_uv / edge_oo are device arrays (gfa_links_to_edges)
 int steps_to_caller_ids(pnx_ctx *ctx, uint32_t *d_items_copy, uint64_t n_steps);
 int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip

@@ -52,7 +52,7 @@ const char *USAGE =
     "                                   similarity: linkage that orders rows and columns of the table [centroid]\n"
     "       panacus-amd synth --nodes N --paths P [--seed S] [--links] [--sequences] -o FILE.gfa\n"
     "                                        write a pansyn-v1 synthetic pangenome as GFA\n"
-    "       panacus-amd synth --shape pggb --nodes N --samples M [--seed S] [--sequences] -o FILE.gfa\n"
+    "       panacus-amd synth --shape pggb --nodes N --samples M [--seed S] [--sequences] [--name-prefix s] -o FILE.gfa\n"
     "                                        write a pggb-shaped pangenome (contig paths, inversions, duplications)\n";
 
 struct Device::TextSlot {
@@ -64,7 +64,7 @@ struct Device::TextSlot {
     std::shared_ptr<const void> keep;
 };
 
-Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>()) {
+Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>()), ordinal_(ordinal) {
     if (!expect_text) text_->decided = true;
     std::shared_ptr<TextSlot> slot = text_;
     init_ = std::async(std::launch::async, [ordinal, slot]() -> pnx_ctx * {
@@ -94,6 +94,11 @@ Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>
         }
         return c;
     });
+}
+void Device::preload(uint32_t what) const {
+    if (std::getenv("PANACUS_AMD_NO_PRELOAD")) return;
+    (void)pnx_preload(ordinal_, what);
+    phase_mark("device code preloaded");
 }
 void Device::offer_text(const char *data, size_t size, std::shared_ptr<const void> keep) const {
     std::lock_guard<std::mutex> g(text_->mu);
@@ -191,9 +196,9 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 // what pnx_set_csr_gfa / pnx_gfa_walks are told about a graph whose steps the device tokenises: the step columns, how a
 // segment name becomes a node id (a table indexed by the number, or the name fields themselves when the names are not
 // numbers: the device hashes them), and -- edge counts -- the edges: the host's index of the L lines if it was built, else
-// the offsets of the L lines (the device parses and ranks them; no edge map on the host at all)
+// the byte range that holds the L lines (the device finds, parses and ranks them; no edge map on the host at all)
 struct GfaStepArgs {
-    std::vector<uint64_t> cb, ce, name_off, link_off, euv;
+    std::vector<uint64_t> cb, ce, name_off, euv;
     std::vector<uint8_t> wk, name_len, eoo;
     pnx_gfa_steps st{};
     bool links = false;
@@ -218,12 +223,11 @@ struct GfaStepArgs {
         st.is_walk = wk.data();
     }
     void edges(const GraphStorage &g, bool into_steps) {
-        static const uint64_t none = 0;
         links = g.links_for_device();
         if (links) {
-            g.link_offsets(link_off);
-            st.link_off = link_off.empty() ? &none : link_off.data();
-            st.n_links = link_off.size();
+            st.n_links = PNX_LINKS_FIND;
+            g.link_range(st.link_lo, st.link_hi);
+            if (!st.link_hi) st.link_lo = st.link_hi = 1;  // (no L line was seen: an empty range, not "the whole text")
         } else {
             g.edge_ends(euv, eoo);
             if (into_steps) {
@@ -493,6 +497,7 @@ std::string cmd_hist(const Options &o, const std::string &cmdline) {
     const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
     auto g = load_graph(o, edges, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
+    dev.preload(PNX_PRELOAD_PASS | (g->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (edges ? PNX_PRELOAD_LINKS : 0u));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "", ""}};
     std::vector<std::vector<double>> cols;
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
@@ -514,6 +519,7 @@ std::string cmd_histgrowth(const Options &o, const std::string &cmdline, bool gr
     const Device dev(o.device, wants_device_tokeniser(o, cts));  // the GPU comes up (and takes the text) while the graph is read
     auto g = load_graph(o, edges, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, "", o.subset_file, o.exclude_file);
+    dev.preload(PNX_PRELOAD_PASS | (g->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (edges ? PNX_PRELOAD_LINKS : 0u));
     std::vector<std::vector<uint64_t>> hists = device_hists(dev, *g, cts, order, masking(o));
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
     std::vector<std::vector<double>> cols;
@@ -751,6 +757,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             else if (a == "--paths") o.paths = (uint32_t)std::strtoul(value("--paths").c_str(), nullptr, 10);
             else if (a == "--seed") o.seed = std::strtoull(value("--seed").c_str(), nullptr, 10);
             else if (a == "--shape") o.shape = value("--shape");
+            else if (a == "--name-prefix") o.name_prefix = value("--name-prefix");
             else if (a == "--samples") o.samples = (uint32_t)std::strtoul(value("--samples").c_str(), nullptr, 10);
             else if (a == "-o" || a == "--output") o.out_file = value("--output");
             else if (a == "--cache") o.cache = true;
@@ -773,7 +780,7 @@ int run_cli(const std::vector<std::string> &argv, std::string &out, std::string 
             if (o.threads > 0) ThreadPool::instance().set_threads((unsigned)o.threads);
             uint32_t np = 0;
             uint64_t ne = 0;
-            const uint64_t steps = write_pggb_like_gfa(o.out_file, o.seed, o.nodes, o.samples, o.sequences, &np, &ne);
+            const uint64_t steps = write_pggb_like_gfa(o.out_file, o.seed, o.nodes, o.samples, o.sequences, &np, &ne, o.name_prefix);
             out = "wrote " + o.out_file + ": " + std::to_string(o.nodes) + " nodes, " + std::to_string(ne) + " edges, " +
                   std::to_string(np) + " paths, " + std::to_string(steps) + " steps\n";
             return 0;

@@ -25,7 +25,7 @@ struct Options {
     // synth
     uint64_t seed = 42;
     uint32_t nodes = 0, paths = 0, samples = 0;
-    std::string out_file, shape;
+    std::string out_file, shape, name_prefix;
     bool links = false, sequences = false;
 };
 
@@ -45,6 +45,10 @@ struct Device {
     void no_text() const;            // nothing will be offered (idempotent; also after an offer: no effect)
     void leak() const { leaked_ = true; }  // the process is about to exit: leave the context to the driver
     bool text_uploaded() const;      // after ctx(): the offered text is in HBM -- true ONCE (the upload that uses it consumes the copy)
+    // pnx_preload on the calling thread: the device code of the routes the command is about to take is loaded while the
+    // context still comes up / the text still travels on the thread of the constructor (a failure is not reported: the
+    // first launch loads what is missing)
+    void preload(uint32_t what) const;
 
 private:
     struct TextSlot;
@@ -52,6 +56,7 @@ private:
     mutable std::future<pnx_ctx *> init_;
     mutable pnx_ctx *ctx_ = nullptr;
     mutable bool leaked_ = false;
+    int ordinal_ = 0;
 };
 // A stand-alone CLI process ends right after its one command: the command then does not tear down what the exit of the
 // process reclaims anyway -- the 2 GB mapping of the GFA, the GPU context -- and main() leaves through _exit once the table

@@ -443,8 +443,9 @@ struct GraphStorage::Impl {
     mutable std::once_flag names_once;
     std::vector<Span> node_names;     // per node id - 1: the name field of its S line
     uint32_t max_name_len = 0;        // longest segment name in bytes
-    std::vector<Span> l_lines;        // the L lines (kept when the edge index is left to the device, or built on demand)
-    bool links_only = false;          // the L lines were found but not parsed: the device parses them (pnx_gfa_steps.link_off)
+    std::vector<Span> l_lines;        // the L lines (from_gfa with index_edges; else collected when the index is asked for)
+    bool links_only = false;          // the L lines were seen, not kept: the device finds and parses them (PNX_LINKS_FIND)
+    uint64_t link_lo = 0, link_hi = 0;  // links_only: the bytes from the first L line to the end of the last one
     bool nice = false;                // segment names are the integers 1..N in file order
     bool numeric_names = false;       // every segment name is a decimal number (nice, or id_of_name maps it)
     std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
@@ -512,6 +513,7 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
         const size_t n_pieces = (N + PIECE - 1) / PIECE;
         struct Found {
             std::vector<Span> s, l, p;
+            size_t l_lo = ~(size_t)0, l_hi = 0;
         };
         std::vector<Found> found(n_pieces);
         ThreadPool::instance().parallel_for(n_pieces, [&](size_t k) {
@@ -530,7 +532,13 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                 if (e > b) {
                     switch (s[b]) {
                         case 'S': f.s.push_back({b, e}); break;
-                        case 'L': if (index_edges || links_only) f.l.push_back({b, e}); break;
+                        case 'L':
+                            if (index_edges) f.l.push_back({b, e});
+                            else if (links_only) {
+                                f.l_lo = std::min(f.l_lo, b);
+                                f.l_hi = e;
+                            }
+                            break;
                         case 'P': case 'W': f.p.push_back({b, e}); break;
                         default: break;
                     }
@@ -543,6 +551,10 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
             ns += f.s.size();
             nl += f.l.size();
             np += f.p.size();
+            if (f.l_hi) {
+                if (!im.link_hi) im.link_lo = f.l_lo;
+                im.link_hi = f.l_hi;
+            }
         }
         s_lines.reserve(ns);
         l_lines.reserve(nl);
@@ -700,6 +712,15 @@ void GraphStorage::build_edge_index() {
     Impl &im = *impl_;
     if (im.has_edges) return;
     const Image &s = im.image;
+    if (im.links_only && im.link_hi > im.link_lo) {  // the L lines were only seen so far: collect them now
+        size_t b = im.link_lo;                        // (link_lo is the start of a line)
+        while (b < im.link_hi) {
+            const void *nl = std::memchr(s.data() + b, '\n', s.size() - b);
+            const size_t e = nl ? (size_t)((const char *)nl - s.data()) : s.size();
+            if (e > b && s[b] == 'L') im.l_lines.push_back({b, e});
+            b = e + 1;
+        }
+    }
     const std::vector<Span> &l_lines = im.l_lines;
     {
         im.has_edges = true;
@@ -821,10 +842,9 @@ void GraphStorage::require_edges(const char *why) const {
 }
 bool GraphStorage::has_edge_index() const { return impl_->has_edges; }
 bool GraphStorage::links_for_device() const { return impl_->links_only && !impl_->has_edges && !impl_->cached; }
-void GraphStorage::link_offsets(std::vector<uint64_t> &off) const {
-    const auto &ll = impl_->l_lines;
-    off.resize(ll.size());
-    for (size_t k = 0; k < ll.size(); ++k) off[k] = ll[k].b;
+void GraphStorage::link_range(uint64_t &lo, uint64_t &hi) const {
+    lo = impl_->link_lo;
+    hi = impl_->link_hi;
 }
 bool GraphStorage::names_by_bytes_on_device() const {
     const Impl &im = *impl_;

@@ -92,14 +92,14 @@ public:
     // any line has been looked at -- so that a caller can start copying them to the device beside the parse; the bytes
     // stay valid for as long as the caller holds `keep`, whatever happens to the GraphStorage
     using TextHook = std::function<void(const char *, size_t, std::shared_ptr<const void>)>;
-    // links_only: find the L lines but leave them unparsed -- the device parses them (pnx_gfa_steps.link_off); the host's
+    // links_only: note where the L lines are, nothing more -- the device finds and parses them (PNX_LINKS_FIND); the host's
     // edge index is then built on demand (ensure_edge_index)
     static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false,
                                                   const TextHook &on_text = nullptr, bool links_only = false);
     void ensure_edge_index() const;       // parse the L lines now if that was left out
     bool has_edge_index() const;
-    bool links_for_device() const;        // L lines found, not parsed: hand their offsets to the device
-    void link_offsets(std::vector<uint64_t> &off) const;
+    bool links_for_device() const;        // L lines seen, not parsed: the device takes them from the text
+    void link_range(uint64_t &lo, uint64_t &hi) const;  // first byte of the first L line .. end of the last one (0, 0: none)
     bool names_by_bytes_on_device() const;  // names that are not numbers, none longer than 16 bytes: the device hashes them
     void name_fields(std::vector<uint64_t> &off, std::vector<uint8_t> &len) const;
 

@@ -196,7 +196,11 @@ inline uint64_t edge_key(uint32_t a, uint32_t b) {
 }  // namespace
 
 uint64_t write_pggb_like_gfa(const std::string &file, uint64_t seed, uint32_t n_nodes, uint32_t n_samples, bool sequences,
-                             uint32_t *n_paths_out, uint64_t *n_edges_out) {
+                             uint32_t *n_paths_out, uint64_t *n_edges_out, const std::string &name_prefix) {
+    auto append_name = [&name_prefix](std::string &to, uint32_t id) {  // `12`, or `s12` / `utg12` with a prefix
+        to += name_prefix;
+        append_uint(to, id);
+    };
     if (n_nodes < 100) throw std::runtime_error("pggb-shaped graph: at least 100 nodes");
     FILE *f = std::fopen(file.c_str(), "wb");
     if (!f) throw std::runtime_error("cannot write " + file);
@@ -220,7 +224,7 @@ uint64_t write_pggb_like_gfa(const std::string &file, uint64_t seed, uint32_t n_
                 len = (t % 10) < 7 ? 1 : 1 + (uint32_t)(splitmix64(key(seed, 14) + i) % 50);
             }
             buf += "S\t";
-            append_uint(buf, i);
+            append_name(buf, i);
             buf += '\t';
             if (sequences) {
                 uint64_t h = splitmix64(key(seed, 8) + i);
@@ -318,7 +322,7 @@ uint64_t write_pggb_like_gfa(const std::string &file, uint64_t seed, uint32_t n_
                         s += ',';
                         edges.insert(edge_key(walk[q - 1], walk[q]));
                     }
-                    append_uint(s, walk[q] >> 1);
+                    append_name(s, walk[q] >> 1);
                     s += (walk[q] & 1u) ? '-' : '+';
                 }
                 s += "\t*\n";
@@ -343,9 +347,9 @@ uint64_t write_pggb_like_gfa(const std::string &file, uint64_t seed, uint32_t n_
         for (uint64_t k : all) {
             const uint32_t a = (uint32_t)(k >> 32), b = (uint32_t)k;
             buf += "L\t";
-            append_uint(buf, a >> 1);
+            append_name(buf, a >> 1);
             buf += (a & 1u) ? "\t-\t" : "\t+\t";
-            append_uint(buf, b >> 1);
+            append_name(buf, b >> 1);
             buf += (b & 1u) ? "\t-\t0M\n" : "\t+\t0M\n";
             if (buf.size() > (1u << 22)) {
                 std::fwrite(buf.data(), 1, buf.size(), f);

@@ -283,6 +283,11 @@ def _named_gfa(rng, n, P, style, walk_share=0.3, with_links=False, dup_links=0):
         ids = rng.integers(1, 60, size=ln).cumsum() % n + 1
         back = (rng.random(ln) < 0.3).astype(np.int64)
         walks.append((ids, back))
+    if with_links and P > 3:   # a hub: node 3 joined to 40 others, walked back and forth (its edge list is bisected, not scanned)
+        others = rng.permutation(np.arange(4, n + 1))[:40]
+        ids = np.empty(80, dtype=np.int64)
+        ids[0::2], ids[1::2] = 3, others
+        walks[3] = (ids, (rng.random(80) < 0.5).astype(np.int64))
     links, link_off = [], []
     if with_links:
         seen = []
@@ -419,6 +424,16 @@ def test_l_lines_parsed_on_the_device(ctx, style):
     ctx.set_csr_walks(n, edges_from_links=True)
     it_e, off_e, _ = ctx.get_csr()
     assert np.array_equal(it_e, np.concatenate(want)) and np.array_equal(off_e, off) and ctx.info().n_items == E
+    # the library finds the L lines itself (PNX_LINKS_FIND): in the whole text, in the byte range that holds them, and in a
+    # text whose L lines stand between other lines
+    kf = {k: v for k, v in kw.items() if k != "link_off"}
+    l_lo, l_hi = int(g["link_off"][0]), int(g["link_off"][-1]) + 8
+    for find in (True, (l_lo, l_hi), (l_lo, len(g["text"])), (0, l_hi)):
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_links=find, **kf)
+        it_f, off_f, _ = ctx.get_csr()
+        assert np.array_equal(it_f, np.concatenate(want)) and np.array_equal(off_f, off) and ctx.info().n_items == E, find
+    with pytest.raises(capi.PnxError):   # a range that cuts the L lines short: steps without an edge
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_links=(l_lo, (l_lo + l_hi) // 2), **kf)
     # an L line that names no segment; a malformed one
     bad = g["text"] + b"L\t" + (b"zz9" if style == "mixed" else b"99999999") + b"\t+\t" + g["names"][0].encode() + b"\t+\t0M\n"
     lo = np.concatenate([g["link_off"], [len(g["text"])]]).astype(np.uint64)
