@@ -576,8 +576,15 @@ typedef struct {
     uint64_t n_rows;         /* path rows resident (256 bytes each; 0 until they are derived) */
     uint64_t n_rows_in_order;/* rows one pass over the current visiting order reads (sum of the tile spans of its paths) */
     uint64_t n_growth_table_builds; /* times pnx_growth_closed_form_async derived its (n, thresholds) tables */
+    uint32_t n_band_passes;  /* (round 4) one-shot passes over the steps (K-band) enqueued on this upload */
+    uint32_t band_route_failed; /* 1: a one-shot pass met a path that is not sorted by id; this upload takes the path rows */
 } pnx_info_t;
+/* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
+ * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with
+ * the size of ITS struct: the library writes min(out_bytes, its own size) bytes, never more, and returns its own size in
+ * *lib_bytes (may be NULL) so that the caller can tell which fields it got. */
 int pnx_info(pnx_ctx *ctx, pnx_info_t *out);
+int pnx_info_sized(pnx_ctx *ctx, void *out, size_t out_bytes, size_t *lib_bytes);
 
 #ifdef __cplusplus
 }

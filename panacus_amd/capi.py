@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued", "pnx_hist_enqueued_on",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
-    "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_group_intersections",
+    "pnx_profile_reset", "pnx_profile_select", "pnx_config", "pnx_info", "pnx_info_sized", "pnx_group_intersections",
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
@@ -47,7 +47,8 @@ class PnxInfo(C.Structure):
                 ("tile_items", C.c_uint32), ("n_general_paths", C.c_uint32), ("weighted", C.c_uint32),
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
                 ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("rows_tile_major", C.c_uint32),
-                ("n_rows", C.c_uint64), ("n_rows_in_order", C.c_uint64), ("n_growth_table_builds", C.c_uint64)]
+                ("n_rows", C.c_uint64), ("n_rows_in_order", C.c_uint64), ("n_growth_table_builds", C.c_uint64),
+                ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
@@ -164,6 +165,7 @@ def load() -> C.CDLL:
     L.pnx_profile_reset.argtypes = [vp]
     L.pnx_config.argtypes = [vp, C.c_int, C.c_int64]
     L.pnx_info.argtypes = [vp, C.POINTER(PnxInfo)]
+    L.pnx_info_sized.argtypes = [vp, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -627,5 +629,6 @@ class Context:
 
     def info(self) -> PnxInfo:
         out = PnxInfo()
-        self._ck(self._L.pnx_info(self._h, C.byref(out)))
+        lib_bytes = C.c_size_t(0)  # (the sized entry: this binding stays valid when the library's struct grows)
+        self._ck(self._L.pnx_info_sized(self._h, C.byref(out), C.sizeof(out), C.byref(lib_bytes)))
         return out

@@ -296,30 +296,48 @@ __global__ __launch_bounds__(CUT_THREADS) void k_edge_items(CutArgs a, EdgeAdj t
     }
 }
 
-// the same over walks that were tokenised on the device (pnx_set_csr_gfa with edges): one thread per step; the path of a wave's
-// first step is found by a binary search in the path offsets (once per wave), the other lanes walk on from there;
-// out[edge_off[path] + local index] = edge to the successor in the same path
+// the same over walks that were tokenised on the device (pnx_set_csr_gfa with edges): a workgroup takes 2048 consecutive steps,
+// 8 per lane; the path of the first one is found by ONE binary search in the path offsets (a search per wave of 64 steps was
+// a chain of 11 dependent loads in front of 64 steps of work: 2.6 of the kernel's 3.7 ms), every lane walks on from there;
+// the loads of a lane's 8 steps are issued together.  out[edge_off[path] + local index] = edge to the successor in the same path
+constexpr uint32_t EI_PER_LANE = 8;
 __global__ __launch_bounds__(256) void k_edge_items_flat(const uint32_t *__restrict__ node, const uint8_t *__restrict__ backward,
                                                          const uint64_t *__restrict__ path_off, uint32_t n_paths,
                                                          const uint64_t *__restrict__ edge_off, uint64_t n_steps, EdgeAdj t,
                                                          uint32_t *__restrict__ out, unsigned long long *bad_step) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t j0 = j - (threadIdx.x & 63u);  // (wave-uniform)
-    if (j0 >= n_steps) return;
-    uint32_t lo = 0, hi = n_paths;  // the path p with path_off[p] <= j0 < path_off[p + 1]
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + (hi - lo) / 2;
-        if (path_off[mid] <= j0) lo = mid; else hi = mid;
+    __shared__ uint32_t s_path;
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * EI_PER_LANE);
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = n_paths;  // the path p with path_off[p] <= base < path_off[p + 1]
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (path_off[mid] <= base) lo = mid; else hi = mid;
+        }
+        s_path = lo;
     }
-    if (j >= n_steps) return;
-    while (path_off[lo + 1] <= j) ++lo;  // (empty paths are stepped over too)
-    if (j + 1 >= path_off[lo + 1]) return;  // last step of its path
-    uint64_t uv;
-    uint32_t oo;
-    canonical_edge(node[j], backward[j] & 1u, node[j + 1], backward[j + 1] & 1u, uv, oo);
-    const uint32_t id = edge_id_of(t, uv, oo);
-    if (!id) atomicMin(bad_step, (unsigned long long)j);
-    out[edge_off[lo] + (j - path_off[lo])] = id;
+    __syncthreads();
+    uint32_t p = s_path;
+    uint64_t uv[EI_PER_LANE], at[EI_PER_LANE];
+    uint32_t oo[EI_PER_LANE];
+    bool live[EI_PER_LANE];
+#pragma unroll
+    for (uint32_t k = 0; k < EI_PER_LANE; ++k) {
+        const uint64_t j = base + k * 256u + threadIdx.x;
+        live[k] = false;
+        if (j >= n_steps) continue;
+        while (path_off[p + 1] <= j) ++p;  // (empty paths are stepped over too)
+        if (j + 1 >= path_off[p + 1]) continue;  // last step of its path
+        live[k] = true;
+        at[k] = edge_off[p] + (j - path_off[p]);
+        canonical_edge(node[j], backward[j] & 1u, node[j + 1], backward[j + 1] & 1u, uv[k], oo[k]);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EI_PER_LANE; ++k) {
+        if (!live[k]) continue;
+        const uint32_t id = edge_id_of(t, uv[k], oo[k]);
+        if (!id) atomicMin(bad_step, (unsigned long long)(base + k * 256u + threadIdx.x));
+        out[at[k]] = id;
+    }
 }
 
 template <bool EMIT>
@@ -705,7 +723,7 @@ int gfa_edge_items(pnx_ctx *ctx, uint32_t n_paths, uint32_t n_nodes, const DevBu
     unsigned long long *d_bad_step = (unsigned long long *)((char *)s.counters.p + 16);
     if ((rc = build_edge_adj(ctx, st, (const uint64_t *)s.e_uv.p, (const uint8_t *)s.e_oo.p, n_edges, n_nodes, s.adj, d_bad, tab))) return rc;
     if (S)
-        hipLaunchKernelGGL(k_edge_items_flat, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, (const uint32_t *)ctx->d_items.p,
+        hipLaunchKernelGGL(k_edge_items_flat, dim3((unsigned)((S + 256 * EI_PER_LANE - 1) / (256 * EI_PER_LANE))), dim3(256), 0, st, (const uint32_t *)ctx->d_items.p,
                            (const uint8_t *)d_backward.p, (const uint64_t *)ctx->d_path_off.p, n_paths, (const uint64_t *)s.eoff.p, S, tab,
                            (uint32_t *)s.out.p, d_bad_step);
     PNX_HIP(ctx, hipGetLastError());

@@ -1271,6 +1271,19 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_runs = ctx->n_runs;
     out->n_reruns = ctx->n_reruns;
     out->weighted = ctx->weighted ? 1 : 0;
+    out->n_band_passes = ctx->n_band_passes;
+    out->band_route_failed = ctx->band_failed ? 1 : 0;
+    return PNX_OK;
+}
+
+int pnx_info_sized(pnx_ctx *ctx, void *out, size_t out_bytes, size_t *lib_bytes) {
+    if (lib_bytes) *lib_bytes = sizeof(pnx_info_t);
+    if (!ctx || !out) return PNX_EINVAL;
+    pnx_info_t full;
+    std::memset(&full, 0, sizeof full);
+    const int rc = pnx_info(ctx, &full);
+    if (rc) return rc;
+    std::memcpy(out, &full, std::min(out_bytes, sizeof full));
     return PNX_OK;
 }
 

@@ -97,6 +97,15 @@ def test_band_route_on_sorted_paths_of_every_kind(band, n):
         assert out[0, t].tolist() == [int(x) for x in exp]
     info = ctx.info()
     assert info.n_rows == 0 and info.n_reruns == reruns  # every pass held, no rows were ever derived
+    assert info.n_band_passes >= 2 and info.band_route_failed == 0
+    # pnx_info_sized: a caller with an older, shorter pnx_info_t gets its prefix and nothing behind it
+    import ctypes as C
+    from panacus_amd import capi
+    buf = (C.c_uint8 * 64)(*([0xAB] * 64))
+    lib_bytes = C.c_size_t(0)
+    assert capi.load().pnx_info_sized(ctx._h, buf, 24, C.byref(lib_bytes)) == 0
+    assert lib_bytes.value == C.sizeof(capi.PnxInfo) and bytes(buf[24:]) == b"\xAB" * 40
+    assert bytes(buf[:24]) == bytes(info)[:24]
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -152,6 +161,7 @@ def test_a_path_that_is_not_sorted_voids_the_pass_and_the_rows_take_over(band):
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
     assert info.n_reruns == before + 1 and info.n_rows > 0         # run again, over rows
+    assert info.n_band_passes == 1 and info.band_route_failed == 1
     cnt, h = ctx.hist()                                             # and the graph is remembered: no second attempt
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 1
     # locally jittered and fully shuffled paths: same story, same numbers
