@@ -46,6 +46,11 @@ typedef struct pnx_ctx pnx_ctx;
 /* ---- lifetime ------------------------------------------------------------------------ */
 /* device = HIP device ordinal visible to this process (LOCAL_RANK for torchrun launches). */
 int pnx_init(pnx_ctx **out, int device);
+/* (round 4) PNX_INIT_ONE_SHOT: the caller will ask for a histogram or two and leave (a CLI command) -- the two extra streams
+ * of the three-stream pass arrangement (9 ms each to create) are not made up front; they still appear if passes ever overlap
+ * (pnx_hist_async behind a pass in flight), possibly on shared hardware queues.  A host that pipelines passes uses pnx_init. */
+#define PNX_INIT_ONE_SHOT 1u
+int pnx_init_flags(pnx_ctx **out, int device, uint32_t flags);
 void pnx_free(pnx_ctx *ctx);
 /* (round 4) Loads the device code of the named routes ahead of their first use.  The HIP runtime loads a code object when the
  * first kernel of it is launched (tens of ms) -- on the critical path of a one-shot command.  pnx_preload does that work

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "pnx_group_intersections_device", "pnx_presence_row_words", "pnx_presence", "pnx_quorum_sums",
     "pnx_quorum_sums_async", "pnx_quorum_sums_fetch", "pnx_exp2_exact", "pnx_group_visit_counts", "pnx_share_csr",
     "pnx_comm_unique_id", "pnx_comm_init", "pnx_comm_allreduce_u64", "pnx_comm_free", "pnx_comm_barrier",
-    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_preload", "pnx_prepare",
+    "pnx_set_csr_cut", "pnx_set_weights", "pnx_exclude_items", "pnx_get_exclude", "pnx_preload", "pnx_init_flags", "pnx_prepare",
     "pnx_log2_exact", "pnx_growth_closed_form_async", "pnx_growth_closed_form_fetch", "pnx_gfa_text_upload", "pnx_set_csr_gfa",
     "pnx_profile_sample", "pnx_gfa_walks", "pnx_set_csr_walks",
 ]
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, u32p, u64p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
     L.pnx_init.argtypes = [C.POINTER(vp), C.c_int]
+    L.pnx_init_flags.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32]
     L.pnx_free.argtypes = [vp]
     L.pnx_free.restype = None
     L.pnx_last_error.argtypes = [vp]
@@ -177,10 +178,11 @@ def _ptr(a, ty):
 class Context:
     """One engine context = one GPU (one process per GPU)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, one_shot: bool = False):
+        """one_shot: pnx_init_flags(PNX_INIT_ONE_SHOT) -- the two extra pass streams are made when passes first overlap"""
         self._L = load()
         h = C.c_void_p()
-        rc = self._L.pnx_init(C.byref(h), device)
+        rc = self._L.pnx_init_flags(C.byref(h), device, 1 if one_shot else 0)
         if rc != PNX_OK:
             raise PnxError(rc, self._L.pnx_last_error(None).decode())
         self._h = h

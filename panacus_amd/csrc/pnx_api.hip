@@ -75,9 +75,10 @@ static int choose_pass_streams(pnx_ctx *ctx) {
     const bool use_m = ctx->want_M || (!use_rows(ctx) && ctx->last_general_paths > 0);
     // (a one-shot pass over the steps is one chain of three kernels: on one stream a dependent kernel follows within ~2 us, across
     // streams the event hand-over costs ~25 us each -- nothing to overlap it with either)
-    // (the three-stream arrangement pays when passes overlap each other; its two extra queues cost 9 ms each to create, so a
-    // context makes them the first time a pass is enqueued while another is still in flight -- a command that waits for
-    // each histogram before it asks for the next never does, and its passes run on one stream without event hand-overs)
+    // (the three-stream arrangement pays when passes overlap each other.  A context of pnx_init has the streams from the start;
+    // a PNX_INIT_ONE_SHOT context makes them the first time a pass is enqueued while another is still in flight -- a command that
+    // waits for each histogram before it asks for the next never does, and its passes run on one stream without event
+    // hand-overs)
     const bool phased = ctx->overlap_phases && ctx->cover_variant >= 2 && !use_m && !ctx->pass_band &&
                         (ctx->stream_pre != nullptr || ctx->tk_count > 0);
     if (ctx->tk_count && phased != ctx->last_pass_phased) {
@@ -293,7 +294,9 @@ int pnx_preload(int device, uint32_t what) {
     return PNX_OK;
 }
 
-int pnx_init(pnx_ctx **out, int device) {
+int pnx_init(pnx_ctx **out, int device) { return pnx_init_flags(out, device, 0u); }
+
+int pnx_init_flags(pnx_ctx **out, int device, uint32_t flags) {
     if (!out) return PNX_EINVAL;
     *out = nullptr;
     int n = 0;
@@ -311,9 +314,13 @@ int pnx_init(pnx_ctx **out, int device) {
     if (!ctx) return PNX_ENOMEM;
     ctx->device = device;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
-        // (stream_pre / stream_post: made when the first phased pass asks for them -- a queue costs 9 ms to create, and a
-        // one-shot command never uses these two)
+        (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        // stream_pre / stream_post cost 9 ms each to create and a one-shot caller never uses them (PNX_INIT_ONE_SHOT: made when
+        // passes first overlap).  Made HERE they are the process's first streams and get hardware queues of their own; made
+        // late, behind the streams of the closed forms, they share queues and the phases of overlapping passes no longer
+        // run beside each other (0.18 instead of 0.10 ms per pipelined pass on cfg3).
+        (!(flags & PNX_INIT_ONE_SHOT) && ((e = hipStreamCreateWithFlags(&ctx->stream_pre, hipStreamNonBlocking)) != hipSuccess ||
+                                          (e = hipStreamCreateWithFlags(&ctx->stream_post, hipStreamNonBlocking)) != hipSuccess))) {
         g_init_err = std::string("device initialisation failed: ") + hipGetErrorString(e);
         delete ctx;
         return PNX_EHIP;

@@ -69,7 +69,8 @@ Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>
     std::shared_ptr<TextSlot> slot = text_;
     init_ = std::async(std::launch::async, [ordinal, slot]() -> pnx_ctx * {
         pnx_ctx *c = nullptr;
-        const int rc = pnx_init(&c, ordinal);
+        // (every command of this CLI waits for a histogram before it asks for the next: no overlapping passes)
+        const int rc = pnx_init_flags(&c, ordinal, PNX_INIT_ONE_SHOT);
         if (rc != PNX_OK) {
             std::lock_guard<std::mutex> g(slot->mu);
             slot->keep.reset();

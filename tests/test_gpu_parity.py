@@ -755,6 +755,31 @@ def test_two_passes_in_flight(ctx):
         ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
 
 
+def test_one_shot_context_makes_its_pass_streams_when_passes_overlap():
+    """pnx_init_flags(PNX_INIT_ONE_SHOT): no phase streams up front; synchronous calls run on one stream, the first pass enqueued
+    behind one in flight makes the streams and drains the single-stream pass first -- same numbers every way"""
+    from panacus_amd import capi
+    n, p = 50_000, 10
+    items, pre, lens = orc.pansyn(29, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, p)
+    with capi.Context(one_shot=True) as c:
+        c.set_csr(items.astype(np.uint32), pre, n)
+        c.set_order(pi, pi, p)
+        for _ in range(3):                       # the one-shot route, then the rows: one stream each time
+            cnt, h = c.hist()
+            assert np.array_equal(h, oh) and np.array_equal(cnt, ocov)
+        c.config(capi.CFG_MAX_IN_FLIGHT, 4)
+        for rounds in range(3):
+            for _ in range(4):
+                c.hist_async()
+            for _ in range(4):
+                cnt, h = c.hist_fetch(want_countable=True)
+                assert np.array_equal(h, oh) and np.array_equal(cnt, ocov)
+        cnt, h = c.hist()
+        assert np.array_equal(h, oh) and np.array_equal(cnt, ocov)
+
+
 # ---------------------------------------------------------------------------------------------
 # run route: nearly monotone paths (local back-steps across tile borders) stay off the atomics
 # ---------------------------------------------------------------------------------------------
