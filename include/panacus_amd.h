@@ -119,6 +119,10 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        every step up there (graph.rs:231, per step, on the host in the reference).  Names of up to 16 bytes;
  *                        a longer one fails the call with PNX_ELIMIT (such graphs keep the host's parser); a name that occurs
  *                        twice fails it with PNX_EINVAL (the reference panics, graph.rs:336).  id_of_name must be NULL.
+ *                        name_off == NULL, id_of_name == NULL and n_names == PNX_NAMES_FIND: the library finds the S lines itself
+ *                        -- every line of text that starts with 'S', inside the bytes [name_lo, name_hi) (0, 0 = the whole
+ *                        text) -- and takes the field behind "S\t" of the i-th of them as the name of segment i + 1
+ *                        (graph.rs:323-351); their number must be n_nodes.
  *   link_off, n_links    (round 4) edge counts WITHOUT the host's edge map: the byte offset of every L line inside text, in file
  *                        order.  The library parses the lines (both names and orientations, graph.rs:276-306), puts every edge
  *                        in canonical form (graph.rs:142-148), numbers the distinct ones by their first line (duplicates are
@@ -144,8 +148,10 @@ typedef struct pnx_gfa_steps {
     const uint64_t *link_off;
     uint64_t n_links;
     uint64_t link_lo, link_hi;
+    uint64_t name_lo, name_hi;
 } pnx_gfa_steps;
 #define PNX_LINKS_FIND 0xFFFFFFFFFFFFFFFFull
+#define PNX_NAMES_FIND 0xFFFFFFFFFFFFFFFFull
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
 /* The same tokeniser for a run with -s / -e INTERVALS: the walks (node id + orientation of every step) are made from the text

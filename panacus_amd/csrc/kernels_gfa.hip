@@ -321,17 +321,32 @@ __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ te
 }
 
 // ---- the name table: one thread per S line puts its name in, a second pass makes every name find its own id ----
-__global__ void k_names_insert(const uint8_t *__restrict__ text, const uint64_t *__restrict__ name_off, const uint8_t *__restrict__ name_len,
-                               uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
+// name field of segment i: (name_off, name_len) as the caller gave them, or -- name_len == NULL: off holds the offsets of the S
+// lines -- the bytes between "S\t" and the next tab (17: longer than a key can be)
+__device__ static inline uint32_t name_field(const uint8_t *__restrict__ text, uint64_t text_bytes, const uint64_t *__restrict__ off,
+                                             const uint8_t *__restrict__ len, uint32_t i, uint64_t &at) {
+    if (len) {
+        at = off[i];
+        return len[i];
+    }
+    at = off[i] + 2;
+    if (at > text_bytes || text[off[i] + 1] != '\t') return 0u;  // (no name field at all: malformed)
+    uint32_t l = 0;
+    while (l < 17u && at + l < text_bytes && text[at + l] != '\t' && text[at + l] != '\n' && text[at + l] != '\r') ++l;
+    return l;
+}
+__global__ void k_names_insert(const uint8_t *__restrict__ text, uint64_t text_bytes, const uint64_t *__restrict__ name_off,
+                               const uint8_t *__restrict__ name_len, uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const uint32_t len = name_len[i];
+    uint64_t at;
+    const uint32_t len = name_field(text, text_bytes, name_off, name_len, i, at);
     if (len == 0u || len > 16u) {
         atomicOr(flags, len ? 4u : 1u);
         return;
     }
     unsigned long long k0, k1;
-    name_key(text + name_off[i], len, k0, k1);
+    name_key(text + at, len, k0, k1);
     uint64_t slot = name_hash(k0, k1) & t.mask;
     for (;;) {
         if (atomicCAS(&t.e[slot].id, 0u, i + 1u) == 0u) {
@@ -342,14 +357,15 @@ __global__ void k_names_insert(const uint8_t *__restrict__ text, const uint64_t 
         slot = (slot + 1) & t.mask;
     }
 }
-__global__ void k_names_verify(const uint8_t *__restrict__ text, const uint64_t *__restrict__ name_off, const uint8_t *__restrict__ name_len,
-                               uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
+__global__ void k_names_verify(const uint8_t *__restrict__ text, uint64_t text_bytes, const uint64_t *__restrict__ name_off,
+                               const uint8_t *__restrict__ name_len, uint32_t n_nodes, NameTab t, uint32_t *__restrict__ flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const uint32_t len = name_len[i];
+    uint64_t at;
+    const uint32_t len = name_field(text, text_bytes, name_off, name_len, i, at);
     if (len == 0u || len > 16u) return;
     unsigned long long k0, k1;
-    name_key(text + name_off[i], len, k0, k1);
+    name_key(text + at, len, k0, k1);
     if (name_lookup(t, k0, k1) != i + 1u) atomicOr(flags, 8u);  // the same name sits in an earlier slot: it occurs twice
 }
 
@@ -433,11 +449,12 @@ __global__ void k_links_parse(const uint8_t *__restrict__ text, uint64_t text_by
     if (bad) atomicOr(flags, bad);
 }
 // The L lines found on the device (pnx_gfa_steps.n_links == PNX_LINKS_FIND): a line starts at byte 0 or behind a '\n'; the
-// ones that start with 'L' are links (graph.rs:276).  One workgroup per 4 KB of text, 16 bytes per lane, byte-parallel
+// ones that start with 'L' are links (graph.rs:276).  (The S lines of PNX_NAMES_FIND are found by the same kernel: letter4 =
+// the letter in all four bytes.)  One workgroup per 4 KB of text, 16 bytes per lane, byte-parallel
 // compares; the offsets come out in file order (counts per tile, a scan, then the same kernel writes).
 constexpr uint32_t FIND_TILE = 4096;
 template <bool EMIT>
-__global__ __launch_bounds__(256) void k_links_find(const uint8_t *__restrict__ text, uint64_t lo16, uint64_t lo, uint64_t hi,
+__global__ __launch_bounds__(256) void k_links_find(const uint8_t *__restrict__ text, uint64_t lo16, uint64_t lo, uint64_t hi, uint32_t letter4,
                                                     uint32_t *__restrict__ tile_cnt, const uint32_t *__restrict__ tile_base,
                                                     uint64_t *__restrict__ out) {
     using Scan = rocprim::block_scan<uint32_t, 256>;
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(256) void k_links_find(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t nl = tok_eq(w[k], 0x0A0A0A0Au);
-            const uint32_t f = tok_eq(w[k], 0x4C4C4C4Cu) & ((nl << 8) | carry);
+            const uint32_t f = tok_eq(w[k], letter4) & ((nl << 8) | carry);
             carry = nl >> 24;
             m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * k);
         }
@@ -542,42 +559,86 @@ int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes) {
     return PNX_OK;
 }
 
+// the lines of the text that start with `letter`, inside the bytes [lo, hi) (hi == 0: the whole text) -> their offsets in
+// file order (device array `off`, n of them)
+static int find_lines(pnx_ctx *ctx, char letter, uint64_t lo_in, uint64_t hi_in, DevBuf &off, uint64_t &n, DevBuf &tile_cnt, DevBuf &tile_base,
+                      DevBuf &tmp) {
+    hipStream_t st = ctx->stream;
+    n = 0;
+    const uint64_t hi = hi_in ? std::min<uint64_t>(hi_in, ctx->gfa_text_bytes) : ctx->gfa_text_bytes;
+    const uint64_t lo = std::min<uint64_t>(lo_in, hi), lo16 = lo & ~15ull;
+    const uint64_t tiles = (hi - lo16 + FIND_TILE - 1) / FIND_TILE;
+    if (tiles >= 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "%c lines on the device: the text range is too long", letter);
+    int rc;
+    if ((rc = ensure(ctx, tile_cnt, (tiles + 1) * 4)) || (rc = ensure(ctx, tile_base, (tiles + 1) * 4))) return rc;
+    const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
+    const uint32_t letter4 = 0x01010101u * (uint8_t)letter;
+    uint32_t found = 0;
+    if (tiles) {
+        PNX_HIP(ctx, hipMemsetAsync((uint32_t *)tile_cnt.p + tiles, 0, 4, st));
+        hipLaunchKernelGGL(k_links_find<false>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, letter4, (uint32_t *)tile_cnt.p,
+                           (const uint32_t *)nullptr, (uint64_t *)nullptr);
+        size_t tmp_bytes = 0;
+        PNX_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)tile_cnt.p, (uint32_t *)tile_base.p, 0u, (size_t)tiles + 1,
+                                             rocprim::plus<uint32_t>(), st));
+        if ((rc = ensure(ctx, tmp, tmp_bytes ? tmp_bytes : 8))) return rc;
+        PNX_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp_bytes, (uint32_t *)tile_cnt.p, (uint32_t *)tile_base.p, 0u, (size_t)tiles + 1,
+                                             rocprim::plus<uint32_t>(), st));
+        PNX_HIP(ctx, hipMemcpyAsync(&found, (uint32_t *)tile_base.p + tiles, 4, hipMemcpyDeviceToHost, st));
+        PNX_HIP(ctx, hipStreamSynchronize(st));
+    }
+    n = found;
+    if ((rc = ensure(ctx, off, (n ? n : 1) * 8))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_links_find<true>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, letter4, (uint32_t *)nullptr,
+                           (const uint32_t *)tile_base.p, (uint64_t *)off.p);
+        PNX_HIP(ctx, hipGetLastError());
+    }
+    return PNX_OK;
+}
+
 // node2id in HBM (name_table.hpp) from the name fields of the S lines; kept in ctx->d_name_tab until the upload ends
 static int gfa_name_table(pnx_ctx *ctx, const pnx_gfa_steps *g, NameTab &names) {
-    if (!g->name_len) return ctx->fail(PNX_EINVAL, "pnx_gfa_steps: name_off without name_len");
+    const bool find = names_found_on_device(g);
+    if (!find && !g->name_len) return ctx->fail(PNX_EINVAL, "pnx_gfa_steps: name_off without name_len");
     if (g->id_of_name) return ctx->fail(PNX_EINVAL, "pnx_gfa_steps: name_off and id_of_name are two ways to name the segments: pass one");
     const uint32_t n = g->n_nodes;
     hipStream_t st = ctx->stream;
     uint64_t slots = 1024;
     while (slots < 2ull * n) slots <<= 1;
-    DevBuf d_off, d_len;
+    struct Scratch {
+        DevBuf off, len, tile_cnt, tile_base, tmp;
+        ~Scratch() {
+            for (DevBuf *b : {&off, &len, &tile_cnt, &tile_base, &tmp}) release(*b);
+        }
+    } sc;
     int rc;
-    if ((rc = ensure(ctx, ctx->d_name_tab, slots * sizeof(NameEntry))) || (rc = ensure(ctx, d_off, ((size_t)n + 1) * 8)) ||
-        (rc = ensure(ctx, d_len, (size_t)n + 1)) || (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) {
-        release(d_off);
-        release(d_len);
-        return rc;
+    if ((rc = ensure(ctx, ctx->d_name_tab, slots * sizeof(NameEntry))) || (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
+    if (find) {  // the S lines, in file order: segment i + 1 is the i-th of them (graph.rs:323-351)
+        uint64_t found = 0;
+        if ((rc = find_lines(ctx, 'S', g->name_lo, g->name_hi, sc.off, found, sc.tile_cnt, sc.tile_base, sc.tmp))) return rc;
+        if (found != n) return ctx->fail(PNX_EINVAL, "PNX_NAMES_FIND: %llu S lines in the text range, n_nodes = %u", (unsigned long long)found, n);
+    } else {
+        if ((rc = ensure(ctx, sc.off, ((size_t)n + 1) * 8)) || (rc = ensure(ctx, sc.len, (size_t)n + 1))) return rc;
+        if (n) PNX_HIP(ctx, hipMemcpyAsync(sc.off.p, g->name_off, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        if (n) PNX_HIP(ctx, hipMemcpyAsync(sc.len.p, g->name_len, (size_t)n, hipMemcpyHostToDevice, st));
     }
     names.e = (NameEntry *)ctx->d_name_tab.p;
     names.mask = slots - 1;
-    hipError_t e = hipMemsetAsync(ctx->d_name_tab.p, 0, slots * sizeof(NameEntry), st);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), st);
-    if (e == hipSuccess && n) e = hipMemcpyAsync(d_off.p, g->name_off, (size_t)n * 8, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && n) e = hipMemcpyAsync(d_len.p, g->name_len, (size_t)n, hipMemcpyHostToDevice, st);
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_name_tab.p, 0, slots * sizeof(NameEntry), st));
+    PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), st));
     uint32_t flags = 0;
-    if (e == hipSuccess && n) {
+    if (n) {
         const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
-        hipLaunchKernelGGL(k_names_insert, dim3((n + 255) / 256), dim3(256), 0, st, text, (const uint64_t *)d_off.p, (const uint8_t *)d_len.p, n, names,
-                           (uint32_t *)ctx->d_flags.p);
-        hipLaunchKernelGGL(k_names_verify, dim3((n + 255) / 256), dim3(256), 0, st, text, (const uint64_t *)d_off.p, (const uint8_t *)d_len.p, n, names,
-                           (uint32_t *)ctx->d_flags.p);
-        e = hipGetLastError();
+        const uint8_t *d_len = find ? (const uint8_t *)nullptr : (const uint8_t *)sc.len.p;
+        hipLaunchKernelGGL(k_names_insert, dim3((n + 255) / 256), dim3(256), 0, st, text, ctx->gfa_text_bytes, (const uint64_t *)sc.off.p, d_len, n,
+                           names, (uint32_t *)ctx->d_flags.p);
+        hipLaunchKernelGGL(k_names_verify, dim3((n + 255) / 256), dim3(256), 0, st, text, ctx->gfa_text_bytes, (const uint64_t *)sc.off.p, d_len, n,
+                           names, (uint32_t *)ctx->d_flags.p);
+        PNX_HIP(ctx, hipGetLastError());
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    release(d_off);
-    release(d_len);
-    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "name table: %s", hipGetErrorString(e));
+    PNX_HIP(ctx, hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st));
+    PNX_HIP(ctx, hipStreamSynchronize(st));
     if (flags & 1u) return ctx->fail(PNX_EINVAL, "a segment has an empty name");
     if (flags & 4u) return ctx->fail(PNX_ELIMIT, "a segment name is longer than 16 bytes: the device tokeniser does not take such names");
     if (flags & 8u) return ctx->fail(PNX_EINVAL, "a segment name occurs more than once in the GFA");
@@ -600,34 +661,8 @@ int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, Dev
         }
     } sc;
     if (find) {  // which lines are L lines: asked of the text itself, inside the byte range the caller names (0, 0: all of it)
-        const uint64_t hi = g->link_hi ? std::min<uint64_t>(g->link_hi, ctx->gfa_text_bytes) : ctx->gfa_text_bytes;
-        const uint64_t lo = std::min<uint64_t>(g->link_lo, hi), lo16 = lo & ~15ull;
-        const uint64_t tiles = (hi - lo16 + FIND_TILE - 1) / FIND_TILE;
-        if (tiles >= 0x7FFFFFFFull) return ctx->fail(PNX_ELIMIT, "L lines on the device: the text range is too long");
-        int rc0;
-        if ((rc0 = ensure(ctx, sc.tile_cnt, (tiles + 1) * 4)) || (rc0 = ensure(ctx, sc.tile_base, (tiles + 1) * 4))) return rc0;
-        const uint8_t *text = (const uint8_t *)ctx->d_gfa_text.p;
-        uint32_t found = 0;
-        if (tiles) {
-            PNX_HIP(ctx, hipMemsetAsync((uint32_t *)sc.tile_cnt.p + tiles, 0, 4, st));
-            hipLaunchKernelGGL(k_links_find<false>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, (uint32_t *)sc.tile_cnt.p,
-                               (const uint32_t *)nullptr, (uint64_t *)nullptr);
-            size_t tmp_bytes = 0;
-            PNX_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t *)sc.tile_cnt.p, (uint32_t *)sc.tile_base.p, 0u, (size_t)tiles + 1,
-                                                 rocprim::plus<uint32_t>(), st));
-            if ((rc0 = ensure(ctx, sc.tmp, tmp_bytes ? tmp_bytes : 8))) return rc0;
-            PNX_HIP(ctx, rocprim::exclusive_scan(sc.tmp.p, tmp_bytes, (uint32_t *)sc.tile_cnt.p, (uint32_t *)sc.tile_base.p, 0u, (size_t)tiles + 1,
-                                                 rocprim::plus<uint32_t>(), st));
-            PNX_HIP(ctx, hipMemcpyAsync(&found, (uint32_t *)sc.tile_base.p + tiles, 4, hipMemcpyDeviceToHost, st));
-            PNX_HIP(ctx, hipStreamSynchronize(st));
-        }
-        n = found;
-        if (n) {
-            if ((rc0 = ensure(ctx, sc.off, n * 8))) return rc0;
-            hipLaunchKernelGGL(k_links_find<true>, dim3((unsigned)tiles), dim3(256), 0, st, text, lo16, lo, hi, (uint32_t *)nullptr,
-                               (const uint32_t *)sc.tile_base.p, (uint64_t *)sc.off.p);
-            PNX_HIP(ctx, hipGetLastError());
-        }
+        int rc0 = find_lines(ctx, 'L', g->link_lo, g->link_hi, sc.off, n, sc.tile_cnt, sc.tile_base, sc.tmp);
+        if (rc0) return rc0;
     }
     uint64_t slots = 1024;
     while (slots < 2 * n) slots <<= 1;
@@ -638,7 +673,7 @@ int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, Dev
         (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t))))
         return rc;
     NodeNames nn{nullptr, 0, NameTab{}, 0};
-    if (g->name_off) {
+    if (names_by_bytes(g)) {
         nn.by_name = 1;
         nn.tab.e = (NameEntry *)ctx->d_name_tab.p;
         uint64_t ns = 1024;
@@ -718,7 +753,7 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
         PNX_HIP(ctx, hipMemcpyAsync(sc.walk.p, g->is_walk, (size_t)P, hipMemcpyHostToDevice, st));
     }
     NameTab names;
-    if (g->name_off) {
+    if (names_by_bytes(g)) {
         if ((rc = gfa_name_table(ctx, g, names))) return rc;
     }
     const uint32_t *d_names = nullptr;
@@ -761,7 +796,7 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
                                names, g->n_nodes, (uint32_t *)ctx->d_items.p, d_backward ? (uint8_t *)d_backward->p : (uint8_t *)nullptr,
                                (uint32_t *)ctx->d_flags.p);
         };
-        if (g->name_off) go(k_tok_emit<true>);
+        if (names_by_bytes(g)) go(k_tok_emit<true>);
         else go(k_tok_emit<false>);
     }
     prof_end(ctx);
@@ -771,7 +806,7 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
     PNX_HIP(ctx, hipMemcpyAsync(ctx->h_path_off.data(), ctx->d_path_off.p, p1 * 8, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipMemcpyAsync(&flags, ctx->d_flags.p, 4, hipMemcpyDeviceToHost, st));
     PNX_HIP(ctx, hipStreamSynchronize(st));
-    if (flags & 1u) return ctx->fail(PNX_EINVAL, "a path step is not of the form <name><+|-> (P) / <'>'|'<'><name> (W)%s", g->name_off ? "" : " with a decimal name");
+    if (flags & 1u) return ctx->fail(PNX_EINVAL, "a path step is not of the form <name><+|-> (P) / <'>'|'<'><name> (W)%s", names_by_bytes(g) ? "" : " with a decimal name");
     if (flags & 4u) return ctx->fail(PNX_ELIMIT, "a path step names a segment of more than 16 bytes: the device tokeniser does not take such names");
     if (flags & 2u) return ctx->fail(PNX_EINVAL, "a path step names a segment the graph does not have");
     ctx->n_steps = total;

@@ -371,6 +371,10 @@ int to_caller_ids_u32(pnx_ctx *ctx, const uint32_t *d_internal, uint32_t *d_call
 int to_internal_ids_u8(pnx_ctx *ctx, const uint8_t *d_caller, uint8_t *d_internal);
 int to_caller_ids_u8(pnx_ctx *ctx, const uint8_t *d_internal, uint8_t *d_caller);
 int to_internal_ids_u32(pnx_ctx *ctx, const uint32_t *d_caller, uint32_t *d_internal);
+// pnx_gfa_steps: the segments are named by bytes (a name hash on the device), and whether the library finds the S lines itself
+static inline bool names_found_on_device(const pnx_gfa_steps *g) { return !g->name_off && !g->id_of_name && g->n_names == PNX_NAMES_FIND; }
+static inline bool names_by_bytes(const pnx_gfa_steps *g) { return g->name_off != nullptr || names_found_on_device(g); }
+
 // pnx_preload: one function per translation unit
 void preload_gfa(unsigned what);
 void preload_cut(unsigned what);

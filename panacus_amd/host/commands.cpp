@@ -195,12 +195,12 @@ std::vector<CountType> count_types(const std::string &c, bool allow_all) {
 }
 
 // what pnx_set_csr_gfa / pnx_gfa_walks are told about a graph whose steps the device tokenises: the step columns, how a
-// segment name becomes a node id (a table indexed by the number, or the name fields themselves when the names are not
-// numbers: the device hashes them), and -- edge counts -- the edges: the host's index of the L lines if it was built, else
+// segment name becomes a node id (a table indexed by the number, or -- names that are not numbers -- the byte range that
+// holds the S lines: the device finds them and hashes their name fields), and -- edge counts -- the edges: the host's index of the L lines if it was built, else
 // the byte range that holds the L lines (the device finds, parses and ranks them; no edge map on the host at all)
 struct GfaStepArgs {
-    std::vector<uint64_t> cb, ce, name_off, euv;
-    std::vector<uint8_t> wk, name_len, eoo;
+    std::vector<uint64_t> cb, ce, euv;
+    std::vector<uint8_t> wk, eoo;
     pnx_gfa_steps st{};
     bool links = false;
     GfaStepArgs(const GraphStorage &g, bool text_there) {
@@ -209,10 +209,9 @@ struct GfaStepArgs {
         st.text_bytes = text_there ? 0 : g.text_size();
         st.n_paths = (uint32_t)cb.size();
         st.n_nodes = (uint32_t)g.node_count();
-        if (g.names_by_bytes_on_device()) {
-            g.name_fields(name_off, name_len);
-            st.name_off = name_off.data();
-            st.name_len = name_len.data();
+        if (g.names_by_bytes_on_device()) {  // the device finds the S lines and hashes their name fields itself
+            st.n_names = PNX_NAMES_FIND;
+            g.segment_range(st.name_lo, st.name_hi);
         } else {
             st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
             st.n_names = g.id_of_name().size();

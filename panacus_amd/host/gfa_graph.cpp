@@ -446,6 +446,7 @@ struct GraphStorage::Impl {
     std::vector<Span> l_lines;        // the L lines (from_gfa with index_edges; else collected when the index is asked for)
     bool links_only = false;          // the L lines were seen, not kept: the device finds and parses them (PNX_LINKS_FIND)
     uint64_t link_lo = 0, link_hi = 0;  // links_only: the bytes from the first L line to the end of the last one
+    uint64_t seg_lo = 0, seg_hi = 0;    // the bytes from the first S line to the end of the last one
     bool nice = false;                // segment names are the integers 1..N in file order
     bool numeric_names = false;       // every segment name is a decimal number (nice, or id_of_name maps it)
     std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
@@ -567,6 +568,10 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     }
     phase_mark("line scan");
     if (s_lines.size() >= 0xFFFFFFFEull) throw std::runtime_error("more than 2^32-2 segments are not supported");
+    if (!s_lines.empty()) {
+        im.seg_lo = s_lines.front().b;
+        im.seg_hi = s_lines.back().e;
+    }
 
     // --- S lines: ids are 1-based ranks, node_lens[id] = length of the sequence column ---
     g->node_lens_.assign(s_lines.size() + 1, 0);
@@ -849,6 +854,10 @@ void GraphStorage::link_range(uint64_t &lo, uint64_t &hi) const {
 bool GraphStorage::names_by_bytes_on_device() const {
     const Impl &im = *impl_;
     return !im.cached && !im.numeric_names && node_count_ > 0 && im.max_name_len >= 1 && im.max_name_len <= 16;
+}
+void GraphStorage::segment_range(uint64_t &lo, uint64_t &hi) const {
+    lo = impl_->seg_lo;
+    hi = impl_->seg_hi;
 }
 void GraphStorage::name_fields(std::vector<uint64_t> &off, std::vector<uint8_t> &len) const {
     const auto &nn = impl_->node_names;

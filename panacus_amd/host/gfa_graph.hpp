@@ -102,6 +102,7 @@ public:
     void link_range(uint64_t &lo, uint64_t &hi) const;  // first byte of the first L line .. end of the last one (0, 0: none)
     bool names_by_bytes_on_device() const;  // names that are not numbers, none longer than 16 bytes: the device hashes them
     void name_fields(std::vector<uint64_t> &off, std::vector<uint8_t> &len) const;
+    void segment_range(uint64_t &lo, uint64_t &hi) const;  // first byte of the first S line .. end of the last one
 
     // ---- for the device tokeniser (pnx_set_csr_gfa): the text and where the step columns are ----
     // true iff every segment name is a decimal number (the names 1..N in file order, or any numbers small enough for a

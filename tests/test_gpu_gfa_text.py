@@ -353,6 +353,15 @@ def test_segment_names_that_are_not_numbers(ctx):
     cnt, h = ctx.hist()
     ocov = orc.coverage(want.astype(np.uint64), off, pi, gi, n)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, P // 5, lens))
+    # PNX_NAMES_FIND: the library finds the S lines itself -- in the whole text, and in the byte range that holds them
+    s_lo, s_hi = int(g["name_off"][0]) - 2, int(g["name_off"][-1]) + 20
+    for find in (True, (s_lo, s_hi), (0, s_hi)):
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_names=find)
+        it_f, off_f, _ = ctx.get_csr()
+        assert np.array_equal(it_f, want) and np.array_equal(off_f, off), find
+    with pytest.raises(capi.PnxError) as e:   # a range that misses S lines: their number is not n_nodes
+        ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_names=(s_lo, (s_lo + s_hi) // 2))
+    assert e.value.code == capi.PNX_EINVAL and "S lines" in str(e.value)
     # a name that occurs twice (the reference panics, graph.rs:336), a name of 17 bytes, a step that names no segment, an empty name
     t = bytearray(g["text"])
     o0, o1 = int(g["name_off"][0]), int(g["name_off"][4])
@@ -427,6 +436,8 @@ def test_l_lines_parsed_on_the_device(ctx, style):
     # the library finds the L lines itself (PNX_LINKS_FIND): in the whole text, in the byte range that holds them, and in a
     # text whose L lines stand between other lines
     kf = {k: v for k, v in kw.items() if k != "link_off"}
+    if style == "mixed":   # (and the S lines with them)
+        kf = dict(find_names=(int(g["name_off"][0]) - 2, int(g["link_off"][0])))
     l_lo, l_hi = int(g["link_off"][0]), int(g["link_off"][-1]) + 8
     for find in (True, (l_lo, l_hi), (l_lo, len(g["text"])), (0, l_hi)):
         ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_links=find, **kf)
