@@ -123,6 +123,9 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        -- every line of text that starts with 'S', inside the bytes [name_lo, name_hi) (0, 0 = the whole
  *                        text) -- and takes the field behind "S\t" of the i-th of them as the name of segment i + 1
  *                        (graph.rs:323-351); their number must be n_nodes.
+ *   name_prefix, name_prefix_len  (round 4) numeric names with the same 1..8 bytes in front of every number -- `s12` of
+ *                        minigraph-cactus: the tokeniser checks that the bytes stand there and reads the number behind them;
+ *                        id_of_name (or the number itself) as for plain numbers.  Ignored with name_off / PNX_NAMES_FIND.
  *   link_off, n_links    (round 4) edge counts WITHOUT the host's edge map: the byte offset of every L line inside text, in file
  *                        order.  The library parses the lines (both names and orientations, graph.rs:276-306), puts every edge
  *                        in canonical form (graph.rs:142-148), numbers the distinct ones by their first line (duplicates are
@@ -149,6 +152,8 @@ typedef struct pnx_gfa_steps {
     uint64_t n_links;
     uint64_t link_lo, link_hi;
     uint64_t name_lo, name_hi;
+    char name_prefix[8];
+    uint32_t name_prefix_len;
 } pnx_gfa_steps;
 #define PNX_LINKS_FIND 0xFFFFFFFFFFFFFFFFull
 #define PNX_NAMES_FIND 0xFFFFFFFFFFFFFFFFull

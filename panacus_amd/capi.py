@@ -69,13 +69,16 @@ class PnxGfaSteps(C.Structure):  # pnx_gfa_steps
                 ("edge_uv", C.POINTER(C.c_uint64)), ("edge_oo", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint32),
                 ("name_off", C.POINTER(C.c_uint64)), ("name_len", C.POINTER(C.c_uint8)),
                 ("link_off", C.POINTER(C.c_uint64)), ("n_links", C.c_uint64), ("link_lo", C.c_uint64), ("link_hi", C.c_uint64),
-                ("name_lo", C.c_uint64), ("name_hi", C.c_uint64)]
+                ("name_lo", C.c_uint64), ("name_hi", C.c_uint64), ("name_prefix", C.c_char * 8), ("name_prefix_len", C.c_uint32)]
 
 
 LINKS_FIND = 0xFFFFFFFFFFFFFFFF  # pnx_gfa_steps.n_links: the library finds the L lines itself
 
 
-def _find_links(g, find_links, find_names=None):
+def _find_links(g, find_links, find_names=None, name_prefix=None):
+    if name_prefix:
+        g.name_prefix = name_prefix[:8].ljust(8, b"\0") if len(name_prefix) < 8 else name_prefix[:8]
+        g.name_prefix_len = len(name_prefix)
     if find_names is not None and find_names is not False:  # PNX_NAMES_FIND: True, or the byte range of the S lines
         g.n_names = LINKS_FIND
         if find_names is not True:
@@ -343,7 +346,7 @@ class Context:
             raise PnxError(rc, "pnx_preload failed")
 
     def set_csr_gfa(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, weights=None, exclude=None, upload_first=False,
-                    edge_uv=None, edge_oo=None, name_off=None, name_len=None, link_off=None, find_links=None, find_names=None):
+                    edge_uv=None, edge_oo=None, name_off=None, name_len=None, link_off=None, find_links=None, find_names=None, name_prefix=None):
         """pnx_set_csr_gfa: the node ItemTable from the step columns of GFA text, tokenised on the device; with edge_uv / edge_oo
         (n_edges + 1 entries, [0] unused) the EDGE ItemTable of the same walks; name_off / name_len: segment names that are not
         numbers, looked up in a hash table on the device; link_off: the L lines parsed on the device (edge counts); find_links:
@@ -371,11 +374,11 @@ class Context:
         lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
         g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
         g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
-        _find_links(g, find_links, find_names)
+        _find_links(g, find_links, find_names, name_prefix)
         self._ck(self._L.pnx_set_csr_gfa(self._h, C.byref(g), _ptr(w, C.c_uint32), _ptr(ex, C.c_uint8)))
         self.n_items = int(self.info().n_items)
 
-    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, name_off=None, name_len=None, link_off=None, find_links=None, find_names=None) -> np.ndarray:
+    def gfa_walks(self, text: bytes, col_begin, col_end, is_walk, n_nodes, id_of_name=None, name_off=None, name_len=None, link_off=None, find_links=None, find_names=None, name_prefix=None) -> np.ndarray:
         """pnx_gfa_walks: the walks of GFA text tokenised on the device and kept there for set_csr_cut(walk_node=None, ...);
         -> their n_paths + 1 offsets"""
         cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
@@ -392,7 +395,7 @@ class Context:
         lo = None if link_off is None else np.ascontiguousarray(link_off, dtype=np.uint64)
         g.name_off, g.name_len = _ptr(no, C.c_uint64), _ptr(nl, C.c_uint8)
         g.link_off, g.n_links = _ptr(lo, C.c_uint64), (0 if lo is None else len(lo))
-        _find_links(g, find_links, find_names)
+        _find_links(g, find_links, find_names, name_prefix)
         off = np.zeros(len(cb) + 1, dtype=np.uint64)
         self._ck(self._L.pnx_gfa_walks(self._h, C.byref(g), _ptr(off, C.c_uint64)))
         return off

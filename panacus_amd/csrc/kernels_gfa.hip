@@ -126,12 +126,17 @@ constexpr uint32_t TOK_LDS_PAD = 16;                    // bytes in front of the
 constexpr uint32_t TOK_LDS_BUF = TOK_LDS_PAD + 1024 + 48;  // + the 32 bytes that follow the chunk + slack for the dword reads
 constexpr uint32_t TOK_LDS_LIST = 512;                   // a W column can start a step every 2 bytes
 
+// numeric names with something in front of the number (`s12`: pnx_gfa_steps.name_prefix): the same bytes for every segment
+struct NamePrefix {
+    uint32_t lo, hi;  // the bytes, little-endian, zero-padded
+    uint32_t len;     // 0..8
+};
 // BYNAME: the names are looked up in the name table (name_table.hpp) by their bytes instead of being read as numbers
 template <bool WALK, bool BYNAME>
 __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, const TokPiece &t, uint32_t lane, uint64_t out,
-                                             const uint32_t *__restrict__ id_of_name, uint64_t n_names, const NameTab &names, uint32_t n_nodes,
-                                             uint32_t *__restrict__ items, uint8_t *__restrict__ backward, uint32_t &bad, uint8_t *buf,
-                                             uint16_t *list) {
+                                             const uint32_t *__restrict__ id_of_name, uint64_t n_names, const NameTab &names, const NamePrefix &pre,
+                                             uint32_t n_nodes, uint32_t *__restrict__ items, uint8_t *__restrict__ backward, uint32_t &bad,
+                                             uint8_t *buf, uint16_t *list) {
     const uint64_t base = t.b & ~15ull;
     auto load = [&](uint64_t pos) {  // 16 bytes at pos; the bytes from the end of the column on read as 0
         tok_u32x4 v = tok_u32x4{0, 0, 0, 0};
@@ -204,7 +209,19 @@ __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, c
         for (uint32_t j0 = 0; j0 < total; j0 += 64) {
             const uint32_t j = j0 + lane;
             if (j < total) {
-                const uint32_t p = TOK_LDS_PAD + list[j];  // byte of the name's first character in buf
+                const uint32_t p_name = TOK_LDS_PAD + list[j];  // byte of the name's first character in buf
+                uint32_t p = p_name;
+                bool pre_ok = true;
+                if (!BYNAME && pre.len) {  // the prefix must stand there; the number starts behind it
+                    const uint32_t *c = reinterpret_cast<const uint32_t *>(buf + (p & ~3u));
+                    const uint32_t sc = (p & 3u) * 8u;
+                    const uint32_t c0 = c[0], c1 = c[1], c2 = c[2];
+                    const uint32_t w0 = __builtin_amdgcn_alignbit(c1, c0, sc), w1 = __builtin_amdgcn_alignbit(c2, c1, sc);
+                    const uint32_t m0 = pre.len >= 4u ? 0xFFFFFFFFu : (1u << (8u * pre.len)) - 1u;
+                    const uint32_t m1 = pre.len >= 8u ? 0xFFFFFFFFu : (pre.len > 4u ? (1u << (8u * (pre.len - 4u))) - 1u : 0u);
+                    pre_ok = (((w0 ^ pre.lo) & m0) | ((w1 ^ pre.hi) & m1)) == 0u;
+                    p += pre.len;
+                }
                 const uint32_t *d = reinterpret_cast<const uint32_t *>(buf + (p & ~3u));
                 const uint32_t sh = (p & 3u) * 8u;
                 if (BYNAME) {
@@ -271,11 +288,11 @@ __device__ static inline void tok_emit_piece(const uint8_t *__restrict__ text, c
                 };
                 const uint64_t v = (uint64_t)four(t0) * 100000000ull + (uint64_t)(four(t1) * 10000u + four(t2));
                 const uint32_t first = x[0] & 0xFFu, term = y3 & 0xFFu, after = (y3 >> 8) & 0xFFu;
-                bool ok = L >= 1u && L <= 10u && !(first == '0' && L > 1u) && v <= 0xFFFFFFFFull;
+                bool ok = pre_ok && L >= 1u && L <= 10u && !(first == '0' && L > 1u) && v <= 0xFFFFFFFFull;
                 uint32_t back;
                 if (WALK) {
                     ok = ok && (term == '>' || term == '<' || term == 0);  // 0: the end of the column
-                    back = buf[p - 1] == '<';
+                    back = buf[p_name - 1] == '<';
                 } else {
                     ok = ok && (term == '+' || term == '-') && (after == ',' || after == 0);
                     back = term == '-';
@@ -304,7 +321,7 @@ __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ te
                                                   const uint64_t *__restrict__ col_b, const uint64_t *__restrict__ col_e,
                                                   const uint8_t *__restrict__ is_walk, uint32_t n_paths, uint64_t n_pieces,
                                                   const uint64_t *__restrict__ piece_out, const uint32_t *__restrict__ id_of_name,
-                                                  uint64_t n_names, NameTab names, uint32_t n_nodes, uint32_t *__restrict__ items,
+                                                  uint64_t n_names, NameTab names, NamePrefix pre, uint32_t n_nodes, uint32_t *__restrict__ items,
                                                   uint8_t *__restrict__ backward, uint32_t *__restrict__ flags) {
     __shared__ __attribute__((aligned(16))) uint8_t buf_all[4][TOK_LDS_BUF];
     __shared__ uint16_t list_all[4][TOK_LDS_LIST];
@@ -314,8 +331,8 @@ __global__ __launch_bounds__(256) void k_tok_emit(const uint8_t *__restrict__ te
     if (c >= n_pieces) return;
     const TokPiece t = tok_piece_of(c, piece_off, col_b, col_e, is_walk, n_paths);
     uint32_t bad = 0;
-    if (t.walk) tok_emit_piece<true, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
-    else tok_emit_piece<false, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
+    if (t.walk) tok_emit_piece<true, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, pre, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
+    else tok_emit_piece<false, BYNAME>(text, t, lane, piece_out[c], id_of_name, n_names, names, pre, n_nodes, items, backward, bad, buf_all[wave], list_all[wave]);
     for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
     if (lane == 0 && bad) atomicOr(flags, bad);
 }
@@ -377,6 +394,7 @@ struct NodeNames {
     uint64_t n_names;
     NameTab tab;
     uint32_t by_name;
+    NamePrefix pre;  // numeric names: what stands in front of the number
 };
 // the field [b, e) of the text (e: the tab behind it) as a node id; 0 = no such node; malformed -> bad |= 1
 __device__ static inline uint32_t node_of_field(const uint8_t *__restrict__ text, uint64_t b, uint64_t e, const NodeNames &nn, uint32_t n_nodes, uint32_t &bad) {
@@ -394,7 +412,21 @@ __device__ static inline uint32_t node_of_field(const uint8_t *__restrict__ text
         name_key(text + b, (uint32_t)len, k0, k1);
         return name_lookup(nn.tab, k0, k1);
     }
-    if (len > 10 || (text[b] == '0' && len > 1)) {
+    if (nn.pre.len) {  // the prefix must stand in front of the number
+        if (len <= nn.pre.len) {
+            bad |= 1u;
+            return 0;
+        }
+        for (uint32_t k = 0; k < nn.pre.len; ++k) {
+            const uint32_t want = ((k < 4 ? nn.pre.lo : nn.pre.hi) >> (8 * (k & 3))) & 0xFFu;
+            if (text[b + k] != want) {
+                bad |= 1u;
+                return 0;
+            }
+        }
+        b += nn.pre.len;
+    }
+    if (e - b > 10 || (text[b] == '0' && e - b > 1)) {
         bad |= 1u;
         return 0;
     }
@@ -559,6 +591,15 @@ int gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t n_bytes) {
     return PNX_OK;
 }
 
+static NamePrefix name_prefix_of(const pnx_gfa_steps *g) {
+    NamePrefix pre{0, 0, names_by_bytes(g) ? 0u : std::min<uint32_t>(g->name_prefix_len, 8u)};
+    unsigned char b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = 0; k < pre.len; ++k) b[k] = (unsigned char)g->name_prefix[k];
+    pre.lo = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+    pre.hi = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+    return pre;
+}
+
 // the lines of the text that start with `letter`, inside the bytes [lo, hi) (hi == 0: the whole text) -> their offsets in
 // file order (device array `off`, n of them)
 static int find_lines(pnx_ctx *ctx, char letter, uint64_t lo_in, uint64_t hi_in, DevBuf &off, uint64_t &n, DevBuf &tile_cnt, DevBuf &tile_base,
@@ -672,7 +713,7 @@ int gfa_links_to_edges(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf &d_e_uv, Dev
         (rc = ensure(ctx, sc.tfirst, slots * 4)) || (rc = ensure(ctx, sc.first, n1 * 4)) || (rc = ensure(ctx, sc.rank, n1 * 4)) ||
         (rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t))))
         return rc;
-    NodeNames nn{nullptr, 0, NameTab{}, 0};
+    NodeNames nn{nullptr, 0, NameTab{}, 0, name_prefix_of(g)};
     if (names_by_bytes(g)) {
         nn.by_name = 1;
         nn.tab.e = (NameEntry *)ctx->d_name_tab.p;
@@ -793,7 +834,7 @@ int gfa_tokenise(pnx_ctx *ctx, const pnx_gfa_steps *g, DevBuf *d_backward) {
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, text, (const uint64_t *)sc.off.p, (const uint64_t *)sc.cb.p,
                                (const uint64_t *)sc.ce.p, (const uint8_t *)sc.walk.p, P, n_pieces, (const uint64_t *)sc.outs.p, d_names, g->n_names,
-                               names, g->n_nodes, (uint32_t *)ctx->d_items.p, d_backward ? (uint8_t *)d_backward->p : (uint8_t *)nullptr,
+                               names, name_prefix_of(g), g->n_nodes, (uint32_t *)ctx->d_items.p, d_backward ? (uint8_t *)d_backward->p : (uint8_t *)nullptr,
                                (uint32_t *)ctx->d_flags.p);
         };
         if (names_by_bytes(g)) go(k_tok_emit<true>);

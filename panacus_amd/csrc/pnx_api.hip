@@ -530,6 +530,7 @@ int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes) {
 // the arguments of pnx_set_csr_gfa / pnx_gfa_walks that say how segments and edges are named
 static int check_gfa_naming(pnx_ctx *ctx, const pnx_gfa_steps *g, const char *who) {
     if (g->name_off && (!g->name_len || g->id_of_name)) return ctx->fail(PNX_EINVAL, "%s: name_off comes with name_len and without id_of_name", who);
+    if (g->name_prefix_len > 8) return ctx->fail(PNX_EINVAL, "%s: name_prefix_len is at most 8", who);
     if (names_found_on_device(g) && g->name_hi && (g->name_lo > g->name_hi || g->name_hi > (g->text ? g->text_bytes : ctx->gfa_text_bytes)))
         return ctx->fail(PNX_EINVAL, "%s: name_lo .. name_hi is not a range of the text", who);
     if (g->link_off && (g->edge_uv || g->edge_oo)) return ctx->fail(PNX_EINVAL, "%s: link_off (the L lines parsed on the device) and edge_uv / edge_oo are two ways to hand over the edges: pass one", who);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -215,6 +216,8 @@ struct GfaStepArgs {
         } else {
             st.id_of_name = g.id_of_name().empty() ? nullptr : g.id_of_name().data();
             st.n_names = g.id_of_name().size();
+            st.name_prefix_len = (uint32_t)g.name_prefix().size();  // (`s12`: at most 8 bytes in front of the number)
+            std::memcpy(st.name_prefix, g.name_prefix().data(), g.name_prefix().size());
         }
     }
     void columns() {  // (after the caller emptied the columns it does not want)

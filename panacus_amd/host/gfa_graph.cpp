@@ -448,8 +448,12 @@ struct GraphStorage::Impl {
     uint64_t link_lo = 0, link_hi = 0;  // links_only: the bytes from the first L line to the end of the last one
     uint64_t seg_lo = 0, seg_hi = 0;    // the bytes from the first S line to the end of the last one
     bool nice = false;                // segment names are the integers 1..N in file order
-    bool numeric_names = false;       // every segment name is a decimal number (nice, or id_of_name maps it)
-    std::vector<uint32_t> id_of_name; // numeric, not nice: name value -> node id (0 = no such segment)
+    // every segment name is name_prefix (at most 8 bytes, the same for all; empty for pggb's plain numbers, "s" for
+    // minigraph-cactus' s1, s2, ...) followed by a decimal number: the number IS the id (number_is_rank) or id_of_name maps it
+    bool numeric_names = false;
+    bool number_is_rank = false;      // the numbers are 1..N in file order (nice: and the prefix is empty)
+    std::string name_prefix;
+    std::vector<uint32_t> id_of_name; // numeric, not number_is_rank: name value -> node id (0 = no such segment)
     bool has_edges = false;
     EdgeMap edges;
     std::vector<uint64_t> edge_uv_by_id;  // the edges in id order ([0] unused), kept beside the map: what edge_ends hands out
@@ -466,9 +470,11 @@ struct GraphStorage::Impl {
     const uint8_t *c_edge_oo = nullptr;  // per edge id: (o1 << 1) | o2
 
     uint32_t node_id(const char *p, size_t len) const {
-        if (nice) {
+        if (number_is_rank) {
+            const size_t pl = name_prefix.size();
+            if (len <= pl || std::memcmp(p, name_prefix.data(), pl) != 0) return 0;
             uint64_t v = 0;
-            for (size_t i = 0; i < len; ++i) {
+            for (size_t i = pl; i < len; ++i) {
                 if (p[i] < '0' || p[i] > '9') return 0;
                 v = v * 10 + (uint64_t)(p[i] - '0');
                 if (v > 0xFFFFFFFFull) return 0;
@@ -578,10 +584,11 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     std::vector<Span> name_of(s_lines.size());
     std::atomic<bool> nice_all{true}, malformed{false}, numeric_all{true};
     std::atomic<uint64_t> name_max{0}, len_max{0};
-    std::vector<uint32_t> name_val(s_lines.size());  // the name as a number (when it is one)
+    std::vector<uint32_t> name_val(s_lines.size());  // the number at the end of the name (when there is one)
+    const size_t BL = 1u << 16;
+    const size_t nb = (s_lines.size() + BL - 1) / BL;
+    std::vector<Span> block_head(nb, Span{0, 0});    // what stands in front of the number, per block (the same for all its names)
     {
-        const size_t BL = 1u << 16;
-        const size_t nb = (s_lines.size() + BL - 1) / BL;
         ThreadPool::instance().parallel_for(nb, [&](size_t blk) {
             bool nice = true, numeric = true;
             uint64_t vmax = 0, lmax = 0;
@@ -600,18 +607,29 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
                 q1 = tb ? (size_t)((const char *)tb - s.data()) : ln.e;
                 if (q1 > q0 && s[q1 - 1] == '\r' && q1 == ln.e) --q1;
                 g->node_lens_[k + 1] = (uint32_t)(q1 - q0);
-                {   // the name as a decimal number (no sign, no leading zero, < 2^32); nice: exactly k + 1
+                if (numeric) {
+                    // the name as [head] + a decimal number (no sign, no leading zero, < 2^32); the head -- at most 8 bytes --
+                    // must be the same for every segment; nice: the number is exactly k + 1 (and, below, the head is empty)
+                    size_t ts = ne;
+                    while (ts > ln.b + 2 && s[ts - 1] >= '0' && s[ts - 1] <= '9') --ts;
                     uint64_t v = 0;
-                    bool ok = ne > ln.b + 2 && ne - (ln.b + 2) <= 10 && (s[ln.b + 2] != '0' || ne == ln.b + 3);
-                    for (size_t i = ln.b + 2; ok && i < ne; ++i) {
-                        ok = s[i] >= '0' && s[i] <= '9';
-                        v = v * 10 + (uint64_t)(s[i] - '0');
-                    }
+                    bool ok = ne > ts && ne - ts <= 10 && (s[ts] != '0' || ne == ts + 1) && ts - (ln.b + 2) <= 8;
+                    for (size_t i = ts; ok && i < ne; ++i) v = v * 10 + (uint64_t)(s[i] - '0');
                     ok = ok && v <= 0xFFFFFFFEull;
+                    if (ok) {
+                        const Span head{ln.b + 2, ts};
+                        if (k == blk * BL) block_head[blk] = head;
+                        else {
+                            const Span h0 = block_head[blk];
+                            ok = h0.e - h0.b == head.e - head.b && std::memcmp(s.data() + h0.b, s.data() + head.b, head.e - head.b) == 0;
+                        }
+                    }
                     nice = nice && ok && v == k + 1;
-                    numeric = numeric && ok;
+                    numeric = ok;
                     name_val[k] = ok ? (uint32_t)v : 0u;
                     if (ok && v > vmax) vmax = v;
+                } else {
+                    nice = false;
                 }
             }
             if (!nice) nice_all.store(false);
@@ -625,8 +643,14 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
         });
     }
     if (malformed.load()) throw std::runtime_error("malformed S line");
-    const bool nice = nice_all.load();
-    im.nice = nice && !s_lines.empty();
+    bool same_head = numeric_all.load();
+    for (size_t b = 1; same_head && b < nb; ++b)
+        same_head = block_head[b].e - block_head[b].b == block_head[0].e - block_head[0].b &&
+                    std::memcmp(s.data() + block_head[b].b, s.data() + block_head[0].b, block_head[0].e - block_head[0].b) == 0;
+    if (!same_head) numeric_all.store(false);
+    if (same_head && nb) im.name_prefix = s.substr(block_head[0].b, block_head[0].e - block_head[0].b);
+    im.number_is_rank = same_head && nice_all.load() && !s_lines.empty();
+    im.nice = im.number_is_rank && im.name_prefix.empty();
     im.max_name_len = (uint32_t)std::min<uint64_t>(len_max.load(), 0xFFFFFFFFull);
     g->node_count_ = s_lines.size();
     im.node_names = std::move(name_of);
@@ -634,8 +658,12 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     // -- the reference panics, graph.rs:336 -- is found there, by the check of the number table below, or by the device's name
     // table, whichever route the command takes)
     // numeric names: name -> id as a plain table (the device tokeniser's lookup), when the numbers are small enough
-    im.numeric_names = !s_lines.empty() && numeric_all.load() && (im.nice || name_max.load() <= 16 * (uint64_t)s_lines.size() + 4096);
-    if (im.numeric_names && !im.nice) {
+    im.numeric_names = !s_lines.empty() && numeric_all.load() && (im.number_is_rank || name_max.load() <= 16 * (uint64_t)s_lines.size() + 4096);
+    if (!im.numeric_names) {
+        im.name_prefix.clear();
+        im.number_is_rank = false;
+    }
+    if (im.numeric_names && !im.number_is_rank) {
         im.id_of_name.assign(name_max.load() + 1, 0);
         ThreadPool::instance().parallel_for((s_lines.size() + (1u << 16) - 1) >> 16, [&](size_t blk) {
             const size_t k1 = std::min(s_lines.size(), (blk + 1) << 16);
@@ -1816,6 +1844,7 @@ bool GraphStorage::names_are_ranks() const {
 const char *GraphStorage::text_data() const { return impl_->image.data(); }
 size_t GraphStorage::text_size() const { return impl_->image.size(); }
 const std::vector<uint32_t> &GraphStorage::id_of_name() const { return impl_->id_of_name; }
+const std::string &GraphStorage::name_prefix() const { return impl_->name_prefix; }
 void GraphStorage::step_columns(std::vector<uint64_t> &col_begin, std::vector<uint64_t> &col_end, std::vector<uint8_t> &is_walk) const {
     const size_t P = impl_->step_fields.size();
     col_begin.resize(P);

@@ -112,6 +112,7 @@ public:
     size_t text_size() const;
     void step_columns(std::vector<uint64_t> &col_begin, std::vector<uint64_t> &col_end, std::vector<uint8_t> &is_walk) const;
     const std::vector<uint32_t> &id_of_name() const;  // empty: the name is the id
+    const std::string &name_prefix() const;  // numeric names: what stands in front of the number ("" for plain numbers, "s" for s12)
     // every segment name is the decimal rank of its S line (1..N in file order): what the reference's `nice: true`
     // (graph.rs:224-229: the name parsed as an integer IS the id) needs to mean the same graph.  Unknown (true) for a cache.
     bool names_are_ranks() const;

@@ -52,6 +52,19 @@ void *pnh_graph_from_cache(const char *cache_file, const char *gfa_file, int nee
 }
 void pnh_graph_free(void *g) { delete static_cast<pnh::GraphStorage *>(g); }
 uint64_t pnh_graph_n_nodes(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_count(); }
+// how the segments are named, as the device routes see it: 0 names the device does not take (longer than 16 bytes), 1 a
+// number that is the rank of the S line, 2 a number that a table maps, 3 up to 16 bytes that are hashed; prefix8 receives
+// what stands in front of the number (kinds 1 and 2; NUL-terminated, at most 8 bytes)
+int pnh_graph_name_kind(const void *g, char *prefix8) {
+    const auto *gs = static_cast<const pnh::GraphStorage *>(g);
+    if (prefix8) {
+        std::memset(prefix8, 0, 9);
+        std::memcpy(prefix8, gs->name_prefix().data(), std::min<size_t>(8, gs->name_prefix().size()));
+    }
+    if (gs->names_by_bytes_on_device()) return 3;
+    if (!gs->steps_tokenisable_on_device()) return 0;
+    return gs->id_of_name().empty() ? 1 : 2;
+}
 uint64_t pnh_graph_n_edges(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->edge_count(); }
 uint64_t pnh_graph_n_paths(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->path_segments().size(); }
 const uint32_t *pnh_graph_node_lens(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_lens().data(); }

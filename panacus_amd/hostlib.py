@@ -158,6 +158,7 @@ def _bind_graph(L):
     for n in ("pnh_graph_n_nodes", "pnh_graph_n_edges", "pnh_graph_n_paths"):
         getattr(L, n).restype = C.c_uint64
         getattr(L, n).argtypes = [C.c_void_p]
+    L.pnh_graph_name_kind.argtypes = [C.c_void_p, C.c_char_p]
     L.pnh_graph_node_lens.restype = u32p
     L.pnh_graph_node_lens.argtypes = [C.c_void_p]
     L.pnh_graph_path_name.restype = C.c_uint64
@@ -220,6 +221,12 @@ class GfaGraph:
     @property
     def n_nodes(self):
         return int(self._L.pnh_graph_n_nodes(self._h))
+
+    def name_kind(self):
+        """-> (kind, prefix): 0 names the device does not take, 1 number = rank, 2 number through a table, 3 hashed bytes"""
+        buf = C.create_string_buffer(9)
+        k = int(self._L.pnh_graph_name_kind(self._h, buf))
+        return k, buf.value.decode()
 
     @property
     def n_edges(self):

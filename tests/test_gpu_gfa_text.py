@@ -264,6 +264,11 @@ def _named_gfa(rng, n, P, style, walk_share=0.3, with_links=False, dup_links=0):
         assert len(set(names)) == n and max(map(len, names)) <= 16
     elif style == "nice":
         names = [str(i) for i in range(1, n + 1)]
+    elif style == "prefix":        # minigraph-cactus: s1, s2, ...
+        names = [f"s{i}" for i in range(1, n + 1)]
+    elif style == "prefix_table":  # a longer prefix, numbers that are not the ranks
+        vals = rng.permutation(4 * n)[:n] + 1
+        names = [f"chr22_{int(v)}" for v in vals]
     else:  # numeric through a table
         vals = rng.permutation(4 * n)[:n] + 1
         names = [str(int(v)) for v in vals]
@@ -326,9 +331,9 @@ def _named_gfa(rng, n, P, style, walk_share=0.3, with_links=False, dup_links=0):
     text = b"".join(parts)
     assert len(text) == pos
     table = None
-    if style == "table":
+    if style in ("table", "prefix_table"):
         table = np.zeros(4 * n + 2, dtype=np.uint32)
-        table[np.array([int(x) for x in names])] = np.arange(1, n + 1, dtype=np.uint32)
+        table[np.array([int(x.split("_")[-1]) for x in names])] = np.arange(1, n + 1, dtype=np.uint32)
     return dict(text=text, names=names, name_off=np.array(name_off, np.uint64), name_len=np.array(name_len, np.uint8),
                 cb=np.array(cb, np.uint64), ce=np.array(ce, np.uint64), wk=np.array(wk, np.uint8), walks=walks,
                 link_off=np.array(link_off, np.uint64), links=links, table=table)
@@ -392,7 +397,7 @@ def test_segment_names_that_are_not_numbers(ctx):
         ctx.hist()   # nothing is resident after a rejected upload
 
 
-@pytest.mark.parametrize("style", ["nice", "table", "mixed"])
+@pytest.mark.parametrize("style", ["nice", "table", "mixed", "prefix", "prefix_table"])
 def test_l_lines_parsed_on_the_device(ctx, style):
     """edge counts without the host's edge map: the library parses the L lines (graph.rs:276-306), numbers the distinct
     canonical edges by their first line -- duplicates and edges written from their other end are skipped like the reference
@@ -414,6 +419,10 @@ def test_l_lines_parsed_on_the_device(ctx, style):
         kw.update(name_off=g["name_off"], name_len=g["name_len"])
     elif style == "table":
         kw.update(id_of_name=g["table"])
+    elif style == "prefix":          # the number behind the prefix IS the id
+        kw.update(name_prefix=b"s")
+    elif style == "prefix_table":
+        kw.update(id_of_name=g["table"], name_prefix=b"chr22_")
     ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, **kw)
     items, off, _ = ctx.get_csr()
     assert ctx.info().n_items == E
@@ -446,7 +455,17 @@ def test_l_lines_parsed_on_the_device(ctx, style):
     with pytest.raises(capi.PnxError):   # a range that cuts the L lines short: steps without an edge
         ctx.set_csr_gfa(g["text"], g["cb"], g["ce"], g["wk"], n, find_links=(l_lo, (l_lo + l_hi) // 2), **kf)
     # an L line that names no segment; a malformed one
-    bad = g["text"] + b"L\t" + (b"zz9" if style == "mixed" else b"99999999") + b"\t+\t" + g["names"][0].encode() + b"\t+\t0M\n"
+    pre = {"prefix": b"s", "prefix_table": b"chr22_"}.get(style, b"")
+    if pre:   # a step whose name lacks the prefix, or carries another one: malformed, not segment 7
+        col = b"7+," + g["names"][1].encode() + b"+"
+        text = g["text"] + b"P\tx\t" + col + b"\t*\n"
+        cb1 = np.array([len(g["text"]) + 4], np.uint64)
+        for c in (col, col.replace(b"7+", b"t7+")):
+            t2 = g["text"] + b"P\tx\t" + c + b"\t*\n"
+            with pytest.raises(capi.PnxError) as e:
+                ctx.set_csr_gfa(t2, cb1, cb1 + np.uint64(len(c)), np.array([0], np.uint8), n, **{k: v for k, v in kw.items() if k != "link_off"})
+            assert e.value.code == capi.PNX_EINVAL
+    bad = g["text"] + b"L\t" + (b"zz9" if style == "mixed" else pre + b"99999999") + b"\t+\t" + g["names"][0].encode() + b"\t+\t0M\n"
     lo = np.concatenate([g["link_off"], [len(g["text"])]]).astype(np.uint64)
     with pytest.raises(capi.PnxError) as e:
         ctx.set_csr_gfa(bad, g["cb"], g["ce"], g["wk"], n, **dict(kw, link_off=lo))

@@ -395,3 +395,29 @@ def test_duplicated_links_resolve_to_their_first_line(tmp_path):
     ia, pa = a.item_table(hl.EDGE)
     ib, pb = b.item_table(hl.EDGE)
     assert np.array_equal(pa, pb) and np.array_equal(ia.astype(np.uint64), ib)
+
+
+def test_how_segments_are_named(tmp_path):
+    """what the S-line pass concludes about the names: plain numbers and `s12`-style names (the same <= 8 bytes in front of a
+    number) go through the numeric tokeniser, anything else of <= 16 bytes is hashed, longer names stay on the host"""
+    def kind(names, steps=None):
+        p = str(tmp_path / "k.gfa")
+        steps = steps or names
+        with open(p, "w") as f:
+            f.write("H\tVN:Z:1.0\n" + "".join(f"S\t{nm}\tACGT\n" for nm in names) + "P\tp#1#c\t" + ",".join(x + "+" for x in steps) + "\t*\n")
+        g = hl.GfaGraph(p)
+        items, _ = g.item_table(hl.NODE)
+        assert items.tolist() == [names.index(x) + 1 for x in steps]   # (the host's own parser resolves them either way)
+        return g.name_kind()
+    assert kind(["1", "2", "3"]) == (1, "")
+    assert kind(["s1", "s2", "s3"], ["s3", "s1", "s2", "s3"]) == (1, "s")
+    assert kind(["chr22_1", "chr22_2"]) == (1, "chr22_")
+    assert kind(["s2", "s1", "s7"]) == (2, "s")
+    assert kind(["5", "9", "2"]) == (2, "")
+    assert kind(["s1", "t2", "s3"])[0] == 3             # two prefixes
+    assert kind(["s01", "s02"])[0] == 3                  # leading zeros: not numbers
+    assert kind(["utg000001l", "utg000002l"])[0] == 3    # the number is not at the end
+    assert kind(["s1", "2", "s3"])[0] == 3               # with and without
+    assert kind(["abcdefghi1", "abcdefghi2"])[0] == 3    # nine bytes in front of the number
+    assert kind(["a", "b"])[0] == 3
+    assert kind(["NODE_1_length_1000_cov_12.5", "NODE_2_length_900_cov_3.25"])[0] == 0
