@@ -109,10 +109,16 @@ int pnx_set_csr_keyed(pnx_ctx *ctx, const uint32_t *items, const uint64_t *path_
  *                        entries indexed by edge id ([0] unused), canonical ends (smaller node id << 32 | larger) and
  *                        orientations (o1 << 1 | o2) as Edge::canonical writes them (graph.rs:142-148), every edge once.
  *                        The walks (node id + orientation of every step) then never leave the device: the edge of every
- *                        consecutive step pair is looked up in a hash table in HBM (what parse_path_seq_to_item_vec /
- *                        parse_walk_seq_to_item_vec do per step with edge2id, util.rs:1048-1091) and the EDGE ItemTable --
- *                        a path of k steps has k - 1 entries -- becomes the resident graph with n_edges items; a step pair
- *                        without an edge fails the call (the reference panics, util.rs:1080).  weights must be NULL.
+ *                        consecutive step pair is looked up among the edges filed under their smaller end (what
+ *                        parse_path_seq_to_item_vec / parse_walk_seq_to_item_vec do per step with edge2id,
+ *                        util.rs:1048-1091) and the EDGE ItemTable -- a path of k steps has k - 1 entries -- becomes the
+ *                        resident graph with n_edges items; a step pair without an edge fails the call (the reference
+ *                        panics, util.rs:1080).  weights must be NULL.
+ *                        One case is the CALLER's: update_tables_edgecount (util.rs:723-795) includes an edge only where
+ *                        `include_coords[0].0 < p + l`, i.e. it leaves out the edges among the LEADING ZERO-LENGTH nodes of a
+ *                        path that starts at coordinate 0.  A graph with a node of length 0 (an empty sequence field) goes
+ *                        through pnx_set_csr_cut with the whole-path interval instead, which walks the coordinates
+ *                        (this repository's CLI does: GraphStorage::has_zero_length_nodes).
  *   name_off, name_len   (round 4) segment names that are NOT numbers -- `s12`, `utg000012l`, ... : per node (id - 1) the byte
  *                        offset of its name inside text (the name field of its S line) and its length.  The library builds the
  *                        node2id map of graph.rs:308-375 in HBM -- a hash table keyed by the name bytes -- and the tokeniser looks

@@ -326,13 +326,15 @@ Uncovered upload_cut(const std::function<pnx_ctx *()> &get_ctx, const GraphStora
 
 Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const PathOrder &order, const Masking &mk,
                  bool growth_weights, bool /*per_item_output*/) {
-    const uint64_t n_items = g.number_of_items(ct);
     const uint32_t n_paths = (uint32_t)g.path_segments().size();
     Uncovered uncovered;
     // -s / -e lists: the walks are cut on the device.  Edge counts take the same entry even without lists (every path
     // "cut" by the whole-path interval): the node walks go up and the library finds the edge of every step pair in a hash
     // table in HBM, instead of one edge2id lookup per step on the host (a graph from the .pcsr cache has its edge table)
-    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    // (edge counts on a graph with zero-length nodes: the reference drops the edges among the leading zero-length nodes of a
+    // path, GraphStorage::has_zero_length_nodes -- the cut route below reproduces that, the device's plain edge route does not)
+    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE") &&
+                           !(ct == COUNT_EDGE && g.has_zero_length_nodes());
     // a -s list that only picks whole paths (names of paths, samples, haplotypes; intervals that contain a path) needs no walk:
     // the paths it leaves out get an empty step column
     std::vector<uint8_t> take;
@@ -356,6 +358,7 @@ Uncovered upload(const Device &dev, const GraphStorage &g, CountType ct, const P
         dev.check(pnx_set_csr_gfa(dev.ctx(), &st, ct == COUNT_BP ? g.node_lens().data() : nullptr, nullptr));
         phase_mark("pnx_set_csr_gfa (tokenise + rows)");
     } else {
+        const uint64_t n_items = g.number_of_items(ct);  // (asked here: the device routes above never need the host's edge index)
         ItemTable tab;
         const ItemTableView view = g.item_table_view(ct, tab);
         std::vector<uint64_t> keys;  // a cached edge table: ranked by the canonical ends of its edges (pnx_set_csr_keyed)
@@ -405,7 +408,8 @@ std::vector<std::vector<uint64_t>> device_hists(const Device &dev, const GraphSt
     }
     bool have_edge = false;
     for (CountType c : cts) have_edge = have_edge || c == COUNT_EDGE;
-    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE");
+    const bool on_device = g.steps_tokenisable_on_device() && !g.from_cache_file() && !std::getenv("PANACUS_AMD_HOST_PARSE") &&
+                           !(have_edge && g.has_zero_length_nodes());
     if (on_device && !mk.any() && have_edge && (have_node || have_bp)) {
         // `-c all`: the text is tokenised ONCE into walks that stay on the device
         // (pnx_gfa_walks), and every count type's table is made from them there (pnx_set_csr_walks) -- the reference builds

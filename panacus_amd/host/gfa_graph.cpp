@@ -869,6 +869,11 @@ void GraphStorage::build_edge_index() {
     im.links_only = false;
 }
 void GraphStorage::ensure_edge_index() const { const_cast<GraphStorage *>(this)->build_edge_index(); }
+bool GraphStorage::has_zero_length_nodes() const {
+    for (size_t i = 1; i < node_lens_.size(); ++i)
+        if (node_lens_[i] == 0) return true;
+    return false;
+}
 void GraphStorage::require_edges(const char *why) const {
     if (!impl_->has_edges && impl_->links_only) ensure_edge_index();
     if (!impl_->has_edges) throw std::runtime_error(why);

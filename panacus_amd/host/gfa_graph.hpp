@@ -96,6 +96,11 @@ public:
     // edge index is then built on demand (ensure_edge_index)
     static std::unique_ptr<GraphStorage> from_gfa(const std::string &gfa_file, bool index_edges, bool nice = false,
                                                   const TextHook &on_text = nullptr, bool links_only = false);
+    // A node of length 0 (an empty sequence field, LN:i:0).  The reference's edge tables leave out the edges among the LEADING
+    // zero-length nodes of a path that starts at 0 (update_tables_edgecount includes an edge only where
+    // `include_coords[0].0 < p + l`, util.rs:723-795): the device's edge route (k - 1 edges for k steps) is only the
+    // reference's table when no such node exists -- true of every real graph; otherwise the cut route is taken.
+    bool has_zero_length_nodes() const;
     void ensure_edge_index() const;       // parse the L lines now if that was left out
     bool has_edge_index() const;
     bool links_for_device() const;        // L lines seen, not parsed: the device takes them from the text
@@ -118,8 +123,11 @@ public:
     bool names_are_ranks() const;
 
     uint64_t node_count() const { return node_count_; }
-    uint64_t edge_count() const { return edge_count_; }
-    uint64_t number_of_items(CountType c) const { return c == COUNT_EDGE ? edge_count_ : node_count_; }
+    uint64_t edge_count() const {  // (a graph whose L lines were left to the device parses them when somebody asks)
+        if (links_for_device()) ensure_edge_index();
+        return edge_count_;
+    }
+    uint64_t number_of_items(CountType c) const { return c == COUNT_EDGE ? edge_count() : node_count_; }
     const std::vector<uint32_t> &node_lens() const { return node_lens_; }  // [0] = 0
     const std::vector<PathSegment> &path_segments() const { return paths_; }
 

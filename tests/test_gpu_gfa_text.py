@@ -474,3 +474,30 @@ def test_l_lines_parsed_on_the_device(ctx, style):
     with pytest.raises(capi.PnxError) as e:
         ctx.set_csr_gfa(bad, g["cb"], g["ce"], g["wk"], n, **dict(kw, link_off=lo))
     assert e.value.code == capi.PNX_EINVAL
+
+
+def test_edges_among_leading_zero_length_nodes(tmp_path):
+    """update_tables_edgecount (util.rs:723-795) includes an edge only where `include_coords[0].0 < p + l`: the edges among the
+    leading zero-length nodes of a path that starts at 0 are not in the reference's table.  The CLI takes the cut route for
+    edge counts on such a graph (the device's plain edge route has k - 1 edges for k steps); found by the CLI fuzz, seed 171"""
+    from panacus_amd import hostlib as hl
+    gfa = str(tmp_path / "z.gfa")
+    with open(gfa, "w") as f:
+        f.write("H\tVN:Z:1.0\n" "S\t1\t\n" "S\t2\t\n" "S\t3\tACGT\n" "S\t4\t\n" "S\t5\tAC\n"
+                "L\t1\t+\t2\t+\t0M\n" "L\t2\t+\t3\t+\t0M\n" "L\t3\t+\t4\t+\t0M\n" "L\t4\t+\t5\t+\t0M\n" "L\t1\t+\t1\t+\t0M\n" "L\t2\t+\t4\t-\t0M\n"
+                "P\ta#1#c\t1+,1+,2+,3+,4+,5+\t*\n"          # 1-1 and 1-2 are left out (p + l == 0), 2-3 on are in
+                "P\tb#1#c:7-90\t1+,2+,3+\t*\n"               # starts at 7: nothing is left out
+                "P\tc#1#c\t3+,4+,5+\t*\n"
+                "W\td\t1\tc\t0\t9\t>2<4\n"                  # 2+ -> 4-: both of length 0, left out
+                "P\te#1#c\t4+,2-\t*\n")                       # the same edge from its other end: left out too
+    g = orc.Graph(gfa, index_edges=True)
+    items, pre = g.item_table(orc.EDGE)
+    assert np.diff(pre).tolist() == [3, 2, 2, 0, 0]
+    pi, gi, names = g.path_order(orc.GROUP_PATHID)
+    want = orc.hist(orc.coverage(items, pre, pi, gi, g.n_items(orc.EDGE)), len(names)).tolist()
+    for args in (["hist", "-c", "edge", gfa], ["hist", "-c", "all", gfa]):
+        rc, out, err = hl.run_cli(args)
+        assert rc == 0, err
+        rows = [l.split("\t") for l in out.split("\n") if l and not l.startswith("#")]
+        j = [k for k in range(1, len(rows[0])) if rows[1][k] == "edge"][0]
+        assert [int(r[j]) for r in rows[4:]] == want, args
