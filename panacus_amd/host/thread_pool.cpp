@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -128,9 +129,16 @@ void ThreadPool::worker_loop(unsigned id) {
         }
         seen = e;
         if (quit_.load()) return;
-        const std::function<void(size_t)> *fn = fn_;
-        const size_t n_tasks = n_tasks_;
-        if (fn && id + 1 < active_limit_) drain(*fn, n_tasks, e);
+        // the job of this epoch, read inside the sequence lock: if anything else than job e stands there -- before or after
+        // the fields were read -- the job is over (its caller has moved on) and there is nothing for this worker to do
+        const uint64_t g1 = gen_.load(std::memory_order_acquire);
+        const std::function<void(size_t)> *fn = fn_.load(std::memory_order_relaxed);
+        const size_t n_tasks = n_tasks_.load(std::memory_order_relaxed);
+        const unsigned limit = active_limit_.load(std::memory_order_relaxed);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        const uint64_t g2 = gen_.load(std::memory_order_relaxed);
+        if (g1 != 2 * e || g2 != 2 * e) continue;
+        if (fn && id + 1 < limit) drain(*fn, n_tasks, e);
     }
 }
 
@@ -142,12 +150,23 @@ void ThreadPool::parallel_for(size_t n_tasks, const std::function<void(size_t)> 
         for (size_t t = 0; t < n_tasks; ++t) fn(t);
         return;
     }
-    // publish the job (fn_/n_tasks_ first, then the ticket, then the epoch the workers watch)
-    fn_ = &fn;
-    n_tasks_ = n_tasks;
-    active_limit_ = limit;
-    done_.store(0, std::memory_order_relaxed);
+    if (n_tasks >= 0xFFFFFFFFull) throw std::runtime_error("parallel_for: too many tasks");
+    // Publish the job.  A worker may still be on its way into the PREVIOUS job (it saw that job's epoch, all of whose tasks
+    // other threads have taken since): it must find nothing to do.  It used to be able to read the NEW function and task
+    // count while the ticket still named the old job -- an index below the new count, a task of the new job run as part of
+    // the old one: run twice, and counted into done_ so that this call returned one task early (seen once in ~50,000 CLI runs
+    // of the fuzz soak: a table row missing, a crash).  Hence: (1) the ticket is closed under the NEW job's id first, so no
+    // index can be taken from now on; (2) the fields change inside a sequence lock that the workers check on both sides of
+    // their reads; (3) only then the ticket opens and the epoch moves.
     const uint64_t job = epoch_.load(std::memory_order_relaxed) + 1;
+    ticket_.store(((job & 0xFFFFFFFFull) << 32) | 0xFFFFFFFFull, std::memory_order_seq_cst);
+    gen_.store(2 * job + 1, std::memory_order_seq_cst);
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    fn_.store(&fn, std::memory_order_relaxed);
+    n_tasks_.store(n_tasks, std::memory_order_relaxed);
+    active_limit_.store(limit, std::memory_order_relaxed);
+    done_.store(0, std::memory_order_relaxed);
+    gen_.store(2 * job, std::memory_order_release);
     ticket_.store((job & 0xFFFFFFFFull) << 32, std::memory_order_release);
     {
         std::lock_guard<std::mutex> lk(mu_);

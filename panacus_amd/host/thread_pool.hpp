@@ -42,9 +42,13 @@ private:
     std::atomic<uint64_t> ticket_{0};  // (job id << 32) | next task index
     std::atomic<size_t> done_{0};
     std::atomic<int> sleepers_{0};
-    const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_tasks_ = 0;
-    unsigned active_limit_ = 0;
+    // the current job, written by parallel_for inside a sequence lock: gen_ is odd while the three fields change and
+    // 2 * (job id) while they describe that job -- a worker that woke up late for job k must not pair job k's ticket with
+    // the fields of job k + 1 (see parallel_for)
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<const std::function<void(size_t)> *> fn_{nullptr};
+    std::atomic<size_t> n_tasks_{0};
+    std::atomic<unsigned> active_limit_{0};
     std::atomic<bool> quit_{false};
     std::mutex err_mu_;
     std::exception_ptr first_error_;  // the first exception a task of the current job threw; rethrown by parallel_for
