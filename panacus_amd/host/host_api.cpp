@@ -3,7 +3,12 @@
 // (panacus_amd/hostlib.py) and linked into the panacus-amd CLI.
 #include <cstdint>
 #include <algorithm>
+#include <csignal>
+#include <cstdio>
 #include <cstring>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -21,6 +26,40 @@ static thread_local std::string g_host_err;
 extern "C" {
 
 const char *pnh_last_error(void) { return g_host_err.c_str(); }
+
+// Debugging aid (soak runs): on SIGSEGV / SIGBUS / SIGABRT / SIGFPE the C stack of the faulting thread goes to `path`
+// (appended) before the default action takes place.
+static char g_crash_path[512];
+static void crash_handler(int sig) {
+    int fd = ::open(g_crash_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd >= 0) {
+        char head[64];
+        const int n = std::snprintf(head, sizeof head, "--- signal %d, pid %d\n", sig, (int)getpid());
+        if (n > 0 && ::write(fd, head, (size_t)n) < 0) {
+        }
+        void *frames[64];
+        const int k = backtrace(frames, 64);
+        backtrace_symbols_fd(frames, k, fd);
+        ::close(fd);
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+void pnh_install_crash_handler(const char *path) {
+    std::snprintf(g_crash_path, sizeof g_crash_path, "%s", path ? path : "/tmp/panacus_amd_crash.txt");
+    void *warm[4];
+    (void)backtrace(warm, 4);  // (loads libgcc now, not inside the handler)
+    static char alt_stack[1 << 16];
+    stack_t ss{};
+    ss.ss_sp = alt_stack;
+    ss.ss_size = sizeof alt_stack;
+    sigaltstack(&ss, nullptr);
+    struct sigaction sa{};
+    sa.sa_handler = crash_handler;
+    sa.sa_flags = SA_ONSTACK | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    for (int sig : {SIGSEGV, SIGBUS, SIGABRT, SIGFPE}) sigaction(sig, &sa, nullptr);
+}
 
 // ---- GFA front end (gfa_graph.hpp) ----
 void *pnh_graph_load(const char *gfa_file, int index_edges) {
