@@ -54,7 +54,7 @@ def _run(cmd):
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, "pnx_context.hpp"), os.path.join(CSRC, "step_chunks.hpp"), os.path.join(ROOT, "include", "panacus_amd.h"),
-            os.path.join(CSRC, "tile_counters.hpp"), os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc"),
+            os.path.join(CSRC, "tile_counters.hpp"), os.path.join(CSRC, "name_table.hpp"), os.path.join(CSRC, "exp2_exact.hpp"), os.path.join(CSRC, "exp2_table.inc"),
             os.path.join(CSRC, "log2_exact.hpp"), os.path.join(CSRC, "log2_table.inc")]
     objs, step_objs = [], []
     procs = []
