@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_cf_lsq(uint32_t n, const double *__rest
 // (32 KB of buffers: the workgroup must find room on a CU beside the workgroups of a coverage pass, which leave about
 // 110 KB of its LDS free -- with 128-row buffers, 128 KB, it could only start when a pass had ended.)
 constexpr int CF_CHUNK = 32;  // rows per LDS buffer (2 buffers x 32 x 64 x 8 B = 32 KB)
-constexpr int CF_WAVES = 8;
+constexpr int CF_WAVES = 16;  // (8: 35 us per call at n = 256 behind a pass, 16: 30 us -- each wave turns 2 rows of a chunk into terms instead of 4)
 
 // term of row i from the table value v:  QUORUM_PART ? exp2(lh[i] + v), skipped where v is NaN  :  exp2((lh[i] + v) - nf)
 template <bool QUORUM_PART>
