@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -671,12 +672,42 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
     std::vector<std::string> labels;
     if (ct == COUNT_EDGE) labels = g->edge_labels();
     auto label = [&](uint64_t i) { return ct == COUNT_EDGE ? labels[i] : g->node_name((uint32_t)i); };
+    // rows are formatted in chunks of 16 K items on the worker pool (3.76 M rows of `table --total` on the chr22 shape were
+    // 0.33 s of string concatenation on one thread) and appended in order
+    auto put_uint = [](std::string &to, uint64_t v) {
+        char buf[24];
+        int k = 24;
+        do {
+            buf[--k] = (char)('0' + v % 10);
+            v /= 10;
+        } while (v);
+        to.append(buf + k, (size_t)(24 - k));
+    };
+    auto append_rows = [&](uint64_t lo, uint64_t hi, const std::function<void(std::string &, uint64_t)> &row) {
+        const uint64_t CH = 1u << 14, nch = (hi - lo + CH - 1) / CH;
+        std::vector<std::string> parts(nch);
+        ThreadPool::instance().parallel_for(nch, [&](size_t c) {
+            std::string &out = parts[c];
+            const uint64_t a = lo + c * CH, b = std::min(hi, a + CH);
+            out.reserve((size_t)(b - a) * 16);
+            for (uint64_t i = a; i < b; ++i) row(out, i);
+        });
+        size_t total = res.size();
+        for (const auto &x : parts) total += x.size();
+        res.reserve(total);
+        for (const auto &x : parts) res += x;
+    };
     if (o.total) {
         res += "\ttotal\n";
         std::vector<uint32_t> countable(n + 1, 0);
         std::vector<uint64_t> hist(G + 1, 0);
         dev.check(pnx_hist(dev.ctx(), countable.data(), hist.data()));
-        for (uint64_t i = 1; i <= n; ++i) res += label(i) + "\t" + std::to_string(countable[i]) + "\n";
+        append_rows(1, n + 1, [&](std::string &out, uint64_t i) {
+            out += label(i);
+            out += '\t';
+            put_uint(out, countable[i]);
+            out += '\n';
+        });
         return res;
     }
     for (const auto &name : order.groups) res += "\t" + name;
@@ -708,22 +739,23 @@ std::string cmd_table(const Options &o, const std::string &cmdline) {
         const uint64_t hi = std::min(n + 1, lo + slice);
         counts.assign(G * (hi - lo), 0);
         if (G) dev.check(pnx_group_visit_counts(dev.ctx(), (uint32_t)lo, (uint32_t)hi, counts.data()));
-        for (uint64_t i = lo; i < hi; ++i) {
-            res += label(i);
+        append_rows(lo, hi, [&](std::string &out, uint64_t i) {
+            out += label(i);
             for (size_t j = 0; j < G; ++j) {
                 const uint32_t v = counts[j * (hi - lo) + (i - lo)];
+                out += '\t';
                 if (!v) {
-                    res += "\t0";
+                    out += '0';
                 } else if (ct == COUNT_EDGE) {
                     if (j >= first_slots.size())
                         throw std::runtime_error("table -c edge: the reference indexes v by group id here and runs past its end (panic)");
-                    res += "\t" + std::to_string(first_slots[j]);
+                    put_uint(out, first_slots[j]);
                 } else {
-                    res += "\t" + std::to_string((uint64_t)v * (ct == COUNT_BP ? bp[i] : 1));
+                    put_uint(out, (uint64_t)v * (ct == COUNT_BP ? bp[i] : 1));
                 }
             }
-            res += "\n";
-        }
+            out += '\n';
+        });
     }
     return res;
 }
