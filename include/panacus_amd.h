@@ -59,6 +59,9 @@ void pnx_free(pnx_ctx *ctx);
 #define PNX_PRELOAD_GFA 1u   /* pnx_set_csr_gfa / pnx_gfa_walks: tokeniser, name table */
 #define PNX_PRELOAD_LINKS 2u /* edge counts from GFA text: L lines, edge lookup, renumbering */
 #define PNX_PRELOAD_PASS 4u  /* the coverage / histogram pass and the closed-form growth */
+#define PNX_PRELOAD_GROWTH 8u   /* pnx_ordered_growth */
+#define PNX_PRELOAD_PAIRS 16u   /* pnx_group_intersections (similarity) */
+#define PNX_PRELOAD_TABLES 32u  /* pnx_presence, pnx_group_visit_counts (table) */
 int pnx_preload(int device, uint32_t what);
 /* message of the last failing call on ctx (ctx == NULL: last pnx_init failure) */
 const char *pnx_last_error(const pnx_ctx *ctx);

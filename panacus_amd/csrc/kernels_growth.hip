@@ -794,3 +794,16 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload (see kernels_gfa.hip): touching one kernel loads the code object of this translation unit
+void preload_growth(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_GROWTH) {
+        touch((const void *)k_cov_masks);
+        touch((const void *)k_growth_prefix);
+        touch((const void *)k_max_u32);
+    }
+}
+}  // namespace pnx

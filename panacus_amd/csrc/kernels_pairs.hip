@@ -335,3 +335,15 @@ int launch_presence_plain(pnx_ctx *ctx, DevBuf &out) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload (see kernels_gfa.hip): touching one kernel loads the code object of this translation unit
+void preload_pairs(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_TABLES) {
+        touch((const void *)k_presence_plain);
+        touch((const void *)k_visit_counts);
+    }
+}
+}  // namespace pnx

@@ -317,3 +317,15 @@ int launch_pair_intersections_mfma(pnx_ctx *ctx) {
 }
 
 }  // namespace pnx
+
+namespace pnx {
+// pnx_preload (see kernels_gfa.hip): touching one kernel loads the code object of this translation unit
+void preload_pairs_mfma(unsigned what) {
+    hipFuncAttributes a;
+    auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
+    if (what & PNX_PRELOAD_PAIRS) {
+        touch((const void *)k_pair_mfma_reduce);
+        touch((const void *)k_weight_digits);
+    }
+}
+}  // namespace pnx

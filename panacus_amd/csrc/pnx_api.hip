@@ -291,6 +291,9 @@ int pnx_preload(int device, uint32_t what) {
     pnx::preload_rows(what);
     pnx::preload_hist(what);
     pnx::preload_closed_form(what);
+    pnx::preload_growth(what);
+    pnx::preload_pairs(what);
+    pnx::preload_pairs_mfma(what);
     return PNX_OK;
 }
 

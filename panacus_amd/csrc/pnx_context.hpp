@@ -384,6 +384,9 @@ void preload_band(unsigned what);
 void preload_rows(unsigned what);
 void preload_hist(unsigned what);
 void preload_closed_form(unsigned what);
+void preload_growth(unsigned what);
+void preload_pairs(unsigned what);
+void preload_pairs_mfma(unsigned what);
 
 // kernels_cut.hip
 int cut_walks(pnx_ctx *ctx, const pnx_walks *w, pnx_piece_event *events, uint64_t cap, uint64_t *n_events);

@@ -588,9 +588,10 @@ std::vector<std::vector<double>> device_ordered_growth(const Device &dev, const 
 std::string cmd_ordered(const Options &o, const std::string &cmdline) {
     ThresholdContainer tc = ThresholdContainer::parse_params(o.quorum, o.coverage);
     CountType ct = count_types(o.count, false)[0];
-    const Device dev(o.device);  // the GPU comes up while the graph is read
-    auto g = load_graph(o, ct == COUNT_EDGE);
+    const Device dev(o.device, wants_device_tokeniser(o, {ct}));  // the GPU comes up (and takes the text) while the graph is read
+    auto g = load_graph(o, ct == COUNT_EDGE, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    dev.preload(PNX_PRELOAD_PASS | PNX_PRELOAD_GROWTH | (g->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (ct == COUNT_EDGE ? PNX_PRELOAD_LINKS : 0u));
     const uint32_t G = (uint32_t)order.groups.size();
     upload(dev, *g, ct, order, masking(o), true);
     std::vector<std::vector<std::string>> headers = {{"panacus", "count", "coverage", "quorum"}};
@@ -648,9 +649,10 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
     ClusterMethod method;
     if (!parse_cluster_method(o.method, method))
         throw std::runtime_error("invalid value '" + o.method + "' for --method (single, complete, average, weighted, ward, centroid, median)");
-    const Device dev(o.device);  // the GPU comes up while the graph is read
-    auto g = load_graph(o, ct == COUNT_EDGE);
+    const Device dev(o.device, wants_device_tokeniser(o, {ct}));  // the GPU comes up (and takes the text) while the graph is read
+    auto g = load_graph(o, ct == COUNT_EDGE, &dev, true);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    dev.preload(PNX_PRELOAD_PASS | PNX_PRELOAD_PAIRS | (g->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (ct == COUNT_EDGE ? PNX_PRELOAD_LINKS : 0u));
     upload(dev, *g, ct, order, masking(o));
     return metadata_comments(cmdline) + similarity_table_string(device_similarity(dev, order.groups, o.method), order.groups);
 }
@@ -661,9 +663,10 @@ std::string cmd_similarity(const Options &o, const std::string &cmdline) {
 // item's bp (node_len - uncovered for bp counts, else 1).
 std::string cmd_table(const Options &o, const std::string &cmdline) {
     CountType ct = count_types(o.count, false)[0];
-    const Device dev(o.device);  // the GPU comes up while the graph is read
-    auto g = load_graph(o, ct == COUNT_EDGE);
+    const Device dev(o.device, wants_device_tokeniser(o, {ct}));  // the GPU comes up (and takes the text) while the graph is read
+    auto g = load_graph(o, ct == COUNT_EDGE, &dev, false);
     PathOrder order = g->path_order(group_mode(o), o.group_file, o.order_file, o.subset_file, o.exclude_file);
+    dev.preload(PNX_PRELOAD_PASS | PNX_PRELOAD_TABLES | (g->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (ct == COUNT_EDGE ? PNX_PRELOAD_LINKS : 0u));
     const uint64_t n = g->number_of_items(ct);
     const size_t G = order.groups.size();
     const Uncovered uncovered = upload(dev, *g, ct, order, masking(o), false, true);
