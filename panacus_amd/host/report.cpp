@@ -467,8 +467,10 @@ struct RunState {
         lo.file = run.graph;
         lo.subset_file = run.subset;
         lo.exclude_file = run.exclude;
-        dev.reset(new Device(opts.device));  // the GPU comes up while the graph is read
-        graph = load_graph(lo, need_edges);
+        // the GPU comes up -- and takes the text of the GFA for the first upload of the run -- while the graph is read
+        dev.reset(new Device(opts.device, wants_device_tokeniser(lo, built)));
+        graph = load_graph(lo, need_edges, dev.get());
+        dev->preload(PNX_PRELOAD_PASS | (graph->steps_tokenisable_on_device() ? PNX_PRELOAD_GFA : 0u) | (need_edges ? PNX_PRELOAD_LINKS : 0u));
         mk.mode = run.grouping == 1 ? GROUP_SAMPLE : run.grouping == 2 ? GROUP_HAPLOTYPE : run.grouping == 3 ? GROUP_FILE : GROUP_PATHID;
         mk.group_file = run.group_file;
         mk.subset_file = run.subset;
