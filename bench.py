@@ -731,6 +731,7 @@ def main():
                     help="0 [default]: the CPU baseline runs on the full headline graph; > 0: on a pansyn graph of that many nodes")
     ap.add_argument("--cpu-passes", type=int, default=3)
     ap.add_argument("--no-permuted-growth", action="store_true")
+    ap.add_argument("--permuted-timeout", type=float, default=300.0, help="N > 1: seconds the permuted-growth block may take before the line is printed without it")
     ap.add_argument("--pg-nodes", type=int, default=10_000_000)
     ap.add_argument("--pg-paths", type=int, default=512)
     ap.add_argument("--pg-orders", type=int, default=128)
@@ -958,7 +959,34 @@ def main():
         hostlib.set_quorum_offload(None)
     # ---- BASELINE.json configs[3]: permuted growth, strong scaling (every rank takes part) ----
     if not args.no_permuted_growth:
-        pg = permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking)
+        # With N > 1 ranks this block is the one place where the ranks exchange data (RCCL all-reduce of the curves).  The
+        # headline above is measured and complete at this point: a failure or a hang in here must not cost the line.  An
+        # exception becomes an "error" entry; a watchdog prints the line without the block and ends the rank if the block has
+        # not come back after --permuted-timeout seconds (a rank that died leaves the others inside a collective).
+        watchdog = None
+        if use_dist:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out["permuted_growth"] = {"error": f"no result after {args.permuted_timeout} s: the block was abandoned"}
+                    sys.stdout.flush()
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(args.permuted_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            pg = permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, blocking)
+        except SystemExit:
+            raise
+        except Exception as e:
+            if not use_dist:
+                raise
+            pg = {"error": f"{type(e).__name__}: {e}"}
+        if watchdog is not None:
+            watchdog.cancel()
         if rank == 0:
             out["permuted_growth"] = pg
     # ---- north_star's 10M x 1k shape (one GPU) ----
