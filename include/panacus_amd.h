@@ -576,6 +576,10 @@ enum {
                                   one read, nothing derived (kernels_band.hip; paths sorted by id, ascending or descending; a path
                                   that is not makes the pass void and it is run again over path rows) --, a second sweep derives the
                                   rows; 1: the one-shot route for every pass while no rows exist; 2: path rows only */
+    PNX_CFG_ROWS_KERNEL = 23,  /* (round 4) coverage kernel of a pass over path rows: 0 [default] and 1: one row per load
+                                  (k_rows_cover); 2: four rows per load (k_rows_cover_q, an experiment that is not faster yet)
+                                  wherever it is legal: plain histogram passes, tile-major rows, at most 2048 order entries, at
+                                  least 4 groups */
     PNX_CFG_DROP_DERIVED = 18, /* (value ignored) forget what was derived from the resident steps (path rows / packed steps /
                                   tile index); the next pass or pnx_prepare derives it again.  Measurement only */
 };
@@ -603,6 +607,7 @@ typedef struct {
     uint64_t n_growth_table_builds; /* times pnx_growth_closed_form_async derived its (n, thresholds) tables */
     uint32_t n_band_passes;  /* (round 4) one-shot passes over the steps (K-band) enqueued on this upload */
     uint32_t band_route_failed; /* 1: a one-shot pass met a path that is not sorted by id; this upload takes the path rows */
+    uint64_t n_rows_q_passes; /* (round 4) passes over path rows that took the four-rows-per-load kernel, since pnx_init */
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpanacus_hip.so")
 PNX_OK, PNX_EINVAL, PNX_ENODEV, PNX_EHIP, PNX_ENOMEM, PNX_ELIMIT = 0, -1, -2, -3, -4, -5
 K_INDEX, K_SCATTER, K_COVER, K_HIST, K_MASK, K_GROWTH, K_PAIRS, K_COUNT = range(8)
 KERNEL_SLOT_NAMES = ["index", "scatter", "cover", "hist", "mask", "growth", "pairs"]
-CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT, CFG_ROWS_LAYOUT, CFG_DROP_DERIVED, CFG_MAX_IN_FLIGHT, CFG_DROP_GROWTH_TABLES, CFG_HIST_IN_COVER, CFG_COVER_ROUTE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
+CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDEX_COARSE, CFG_COVER_WAVES, CFG_USE_WEIGHTS, CFG_BLOCKING_SYNC, CFG_COVER_SPLIT, CFG_INDEX_BY_ENTRY, CFG_COVER_SKIP, CFG_INDEX_PROBE, CFG_COMM_REDUCE_HIST, CFG_OVERLAP_PHASES, CFG_SORT_SHUFFLED, CFG_PAIRS_VARIANT, CFG_ROWS_LAYOUT, CFG_DROP_DERIVED, CFG_MAX_IN_FLIGHT, CFG_DROP_GROWTH_TABLES, CFG_HIST_IN_COVER, CFG_COVER_ROUTE, CFG_ROWS_KERNEL = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -48,7 +48,7 @@ class PnxInfo(C.Structure):
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
                 ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("rows_tile_major", C.c_uint32),
                 ("n_rows", C.c_uint64), ("n_rows_in_order", C.c_uint64), ("n_growth_table_builds", C.c_uint64),
-                ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32)]
+                ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32), ("n_rows_q_passes", C.c_uint64)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)

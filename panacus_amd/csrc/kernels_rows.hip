@@ -540,6 +540,149 @@ __global__ __launch_bounds__(CW * 64) void k_rows_cover(const uint32_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1 over rows, four rows per load (verdict r3 #7): for plain histogram passes over DENSE tile-major rows.
+// One wave owns one item tile.  Its four 16-lane quarters walk the four group-aligned parts of the visiting order side by
+// side: one 16-byte load per lane fetches FOUR rows (one per quarter, four presence words of it per lane), so a wave needs a
+// quarter of the load instructions, address computations and scalar bookkeeping per row of k_rows_cover.  What a part's
+// entry is on this tile -- its row, and whether it ends its group -- is worked out once per wave into LDS (4 bytes per
+// entry); a slot of the main loop is then: one LDS read, one load, four ORs.  The quarters' groups end at different slots,
+// but the counters are only touched when ALL quarters have finished a group (a quarter that is done idles: its loads go to
+// row 0 and are masked), so that the carry-save tree of the bit-sliced counters sees wave-uniform steps.  At the end the four
+// quarters' counters are added up by a reduce-scatter over lane ^ 32 and lane ^ 16, which leaves every lane with ONE word of
+// the tile, and the tail of k_rows_cover takes over.
+// ------------------------------------------------------------------------------------------
+constexpr int ROWQ_D = 4;                        // slots (of four rows) in flight per register buffer, two buffers
+constexpr uint32_t ROWQ_NONE = 0x7FFFFFFFu;      // meta: no row on this tile
+constexpr uint32_t ROWQ_LAST = 0x80000000u;      // meta: the entry ends its group
+constexpr uint32_t ROWQ_MAX_ORDER = 2048;        // entries of the order a wave keeps in LDS (8 KB)
+
+typedef uint32_t rowq_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_rows_cover_q(const uint32_t *__restrict__ rows, uint32_t tstride, RowOrd oi,
+                                                      const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
+                                                      const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
+                                                      uint32_t *__restrict__ countable, RowSplit sp, RowHist hs) {
+    extern __shared__ unsigned long long sh_hist[];  // [n_groups + 1 bins when the kernel adds the histogram | meta of 4 waves]
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q = lane >> 4, j = lane & 15u;
+    const uint32_t tile_raw = blockIdx.x * 4 + wave;
+    const bool active = tile_raw < n_tiles;  // idle waves still meet the barriers
+    const uint32_t tile = active ? tile_raw : n_tiles - 1;
+    const size_t hist_words = hs.rep ? ((size_t)hs.n_groups + 1) : 0;
+    uint32_t *meta = reinterpret_cast<uint32_t *>(sh_hist + hist_words) + (size_t)wave * n_ordered;
+    if (hs.rep) {
+        for (uint32_t b = threadIdx.x; b <= hs.n_groups; b += 256) sh_hist[b] = 0;
+    }
+    // ---- what every entry of the order is on this tile ----
+    for (uint32_t k = lane; k < n_ordered; k += 64) {
+        const uint32_t jt = tile - oi.tfirst[k];  // wraps for tiles before the path's first one
+        uint32_t m = jt < oi.tspan[k] ? oi.base[k] + tile * tstride : ROWQ_NONE;
+        const bool last = k + 1 == n_ordered || k + 1 == sp.k[1] || k + 1 == sp.k[2] || k + 1 == sp.k[3] || ord_group[k + 1] != ord_group[k];
+        meta[k] = m | (last ? ROWQ_LAST : 0u);
+    }
+    __syncthreads();  // (also: the zeroed histogram bins)
+    uint32_t kq = active ? sp.k[q] : 0u;
+    const uint32_t khi = active ? sp.k[q + 1] : 0u;
+    uint32_t excl[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) excl[c] = tile_exclusion_word(exclude, tile, 4 * j + c, n_items);
+    TileCounters<NPL> tc[4];
+    uint32_t acc[4] = {0, 0, 0, 0};
+    bool done = false;  // this quarter has finished the group of the current round
+    // issue stage of one slot: -> the loaded words, whether they count, whether the round ends behind this slot
+    bool any_live = false;  // (wave-uniform) the last fill held at least one entry
+    auto issue = [&](rowq_u32x4 &v, bool &keep, bool &round_end) {
+        const bool live = !done && kq < khi;
+        any_live = any_live || __builtin_amdgcn_ballot_w64(live) != 0ull;
+        const uint32_t m = live ? meta[kq] : ROWQ_NONE;
+        const uint32_t row = m & 0x7FFFFFFFu;
+        keep = live && row != ROWQ_NONE;
+        v = __builtin_nontemporal_load(reinterpret_cast<const rowq_u32x4 *>(rows + (uint64_t)(keep ? row : 0u) * 64u) + j);
+        if (live) {
+            ++kq;
+            done = (m & ROWQ_LAST) != 0u;
+        }
+        round_end = __builtin_amdgcn_ballot_w64(done || kq >= khi) == ~0ull;
+        if (round_end) done = false;
+    };
+    auto consume = [&](const rowq_u32x4 &v, bool keep, bool round_end) {
+        const uint32_t km = keep ? 0xFFFFFFFFu : 0u;
+        acc[0] |= v.x & km;
+        acc[1] |= v.y & km;
+        acc[2] |= v.z & km;
+        acc[3] |= v.w & km;
+        if (round_end) {  // (wave-uniform)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                tc[c].add_group(acc[c] & ~excl[c]);
+                acc[c] = 0;
+            }
+        }
+    };
+    {
+        // Two register buffers of ROWQ_D slots that swap roles (one set refilled in place makes the compiler park the new loads
+        // elsewhere and copy them back at the loop head, i.e. wait for them); a group consumes `in` slot by slot while the loads
+        // of `out` go out, ROWQ_D loads in flight throughout.  Every group issues ALL its loads, whatever is left of the order
+        // (a slot behind the end loads row 0 and counts nothing, its "round" adds an empty group): with the number of loads
+        // in flight known at every point the compiler waits for exactly the slot it consumes.
+        rowq_u32x4 va[ROWQ_D], vb[ROWQ_D];
+        bool ka[ROWQ_D], kb[ROWQ_D], ea[ROWQ_D], eb[ROWQ_D];
+        auto group = [&](const rowq_u32x4 (&vi)[ROWQ_D], const bool (&ki)[ROWQ_D], const bool (&ei)[ROWQ_D], rowq_u32x4 (&vo)[ROWQ_D],
+                         bool (&ko)[ROWQ_D], bool (&eo)[ROWQ_D]) {
+            any_live = false;
+#pragma unroll
+            for (int t = 0; t < ROWQ_D; ++t) {
+                issue(vo[t], ko[t], eo[t]);
+                consume(vi[t], ki[t], ei[t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < ROWQ_D; ++t) issue(va[t], ka[t], ea[t]);
+        while (any_live) {  // `in` holds entries
+            group(va, ka, ea, vb, kb, eb);
+            if (!any_live) break;  // nothing went into vb
+            group(vb, kb, eb, va, ka, ea);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tc[c].settle();
+    }
+    // ---- the four quarters' counters -> one word per lane: reduce-scatter over lane ^ 32, then lane ^ 16 ----
+    uint32_t two[2][NPL], one[NPL];
+    {
+        const bool up = (lane & 32u) != 0u;  // keeps words 2, 3 of its four; the lower half keeps 0, 1
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const uint32_t mine = up ? tc[2 + h].cnt[k] : tc[h].cnt[k], give = up ? tc[h].cnt[k] : tc[2 + h].cnt[k];
+                const uint32_t got = (uint32_t)__shfl_xor((int)give, 32);
+                two[h][k] = mine ^ got ^ carry;
+                carry = (mine & got) | (carry & (mine ^ got));
+            }
+        }
+        const bool up2 = (lane & 16u) != 0u;  // keeps the second of its two
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const uint32_t mine = up2 ? two[1][k] : two[0][k], give = up2 ? two[0][k] : two[1][k];
+            const uint32_t got = (uint32_t)__shfl_xor((int)give, 16);
+            one[k] = mine ^ got ^ carry;
+            carry = (mine & got) | (carry & (mine ^ got));
+        }
+    }
+    const uint32_t word = 4 * j + ((lane >> 5) & 1u) * 2u + ((lane >> 4) & 1u);
+    if (active) tile_tail<NPL>(one, tile, lane, n_items, countable, hs, sh_hist, 0u, 32u, 0xFFFFFFFFu, word);
+    if (hs.rep) {
+        __syncthreads();
+        hist_bins_flush(hs, sh_hist, 256);
+    }
+}
+
 // Within a group the order of the paths does not matter for any result, so the paths of every group are put
 // in the order of their first tile once per (graph, order): 64 consecutive entries then reach a narrow band of
 // tiles, and a coverage wave skips the windows whose band misses its tile.
@@ -594,6 +737,37 @@ static void launch_rows_cover_t(pnx_ctx *ctx, bool write_m) {
                            (uint32_t *)ctx->d_M.p, row_words, (uint32_t *)tk->d_countable.p, sp, hs);
     };
     const bool skip = !write_m && (ctx->cover_skip == 1 || (ctx->cover_skip == 0 && ctx->n_ordered >= 4096));
+    // four rows per load (k_rows_cover_q): plain histogram passes over dense tile-major rows, orders that a wave can keep in
+    // LDS and that split into four group-aligned parts; PNX_CFG_ROWS_KERNEL 1 keeps k_rows_cover, 2 asks for the new one
+    // wherever it is legal
+    {
+        const bool legal = !write_m && ctx->rows_tile_major && ctx->n_ordered <= ROWQ_MAX_ORDER && ctx->n_groups >= 4 && ctx->n_ordered >= 4 &&
+                           !(ctx->cover_skip == 1);
+        uint64_t rows_in_order = 0;
+        if (legal && ctx->h_rt_span.size() == ctx->n_paths)
+            for (uint32_t k = 0; k < ctx->n_ordered; ++k) rows_in_order += ctx->h_rt_span[ctx->h_ord_path[k]];
+        const bool dense = rows_in_order * 10 >= (uint64_t)n_tiles * ctx->n_ordered * 7;  // idle slots are loads of row 0
+        // (not the default yet: 0.105 ms per launch on cfg3 against k_rows_cover's 0.092 -- 104 registers, 4 waves per SIMD, but
+        // the compiler reuses the destination registers of loads in flight as temporaries at the loop head and waits for them;
+        // DESIGN section 8)
+        (void)dense;
+        if (legal && ctx->rows_kernel == 2) {
+            for (int jq = 0; jq <= 4; ++jq) {  // group-aligned cut points of the visiting order
+                uint64_t t = (uint64_t)ctx->n_ordered * jq / 4;
+                while (t > 0 && t < ctx->n_ordered && ctx->h_ord_group[t] == ctx->h_ord_group[t - 1]) ++t;
+                sp.k[jq] = (uint32_t)t;
+            }
+            const RowHist hs{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
+                             ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
+            const size_t lds = (tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0) + (size_t)4 * ctx->n_ordered * 4;
+            hipLaunchKernelGGL(k_rows_cover_q<NPL>, dim3((n_tiles + 3) / 4), dim3(256), lds, ctx->s_main, (const uint32_t *)ctx->d_rows.p,
+                               ctx->row_tstride, oi, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
+                               ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, n_tiles,
+                               (uint32_t *)tk->d_countable.p, sp, hs);
+            ctx->n_rows_q_passes += 1;
+            return;
+        }
+    }
     int split = ctx->cover_split;
     if (split == 0) {  // enough waves to fill the chip a few times over, and no part shorter than 32 entries
         const uint64_t want = (uint64_t)ctx->prop.multiProcessorCount * 4 * 8 * 2;

@@ -331,6 +331,9 @@ int pnx_init_flags(pnx_ctx **out, int device, uint32_t flags) {
     if (const char *v = getenv("PNX_COVER_VARIANT")) {  // default of PNX_CFG_COVER_VARIANT (cross-check runs of a whole host)
         if (v[0] >= '0' && v[0] <= '3' && v[1] == 0) ctx->cover_variant = v[0] - '0';
     }
+    if (const char *v = getenv("PNX_ROWS_KERNEL")) {  // default of PNX_CFG_ROWS_KERNEL
+        if (v[0] >= '0' && v[0] <= '2' && v[1] == 0) ctx->rows_kernel = v[0] - '0';
+    }
     if (const char *v = getenv("PNX_HIST_IN_COVER")) {  // default of PNX_CFG_HIST_IN_COVER
         if ((v[0] == '0' || v[0] == '1') && v[1] == 0) ctx->hist_in_cover = v[0] == '1';
     }
@@ -1286,6 +1289,7 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->weighted = ctx->weighted ? 1 : 0;
     out->n_band_passes = ctx->n_band_passes;
     out->band_route_failed = ctx->band_failed ? 1 : 0;
+    out->n_rows_q_passes = ctx->n_rows_q_passes;
     return PNX_OK;
 }
 
@@ -1380,6 +1384,10 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
         case PNX_CFG_COVER_SPLIT:
             if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return ctx->fail(PNX_EINVAL, "cover split must be 0 (auto), 1, 2, 4 or 8");
             ctx->cover_split = (int)value;
+            return PNX_OK;
+        case PNX_CFG_ROWS_KERNEL:
+            if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "rows_kernel must be 0 (auto), 1 or 2");
+            ctx->rows_kernel = (int)value;
             return PNX_OK;
         case PNX_CFG_COVER_SKIP:
             if (value < 0 || value > 2) return ctx->fail(PNX_EINVAL, "cover_skip must be 0 (auto), 1 or 2");

@@ -142,6 +142,8 @@ struct pnx_ctx {
     int index_by_entry = 0;    // K0 thread numbering: 0 = automatic, 1 = one thread per index entry, 2 = path-major
     int cover_skip = 0;        // window skipping of the coverage kernel: 0 = automatic, 1 = whenever legal, 2 = never
     int cover_split = 0;       // waves per tile of the coverage kernel: 0 = automatic, 1, 2, 4, 8
+    uint64_t n_rows_q_passes = 0;  // passes that took k_rows_cover_q
+    int rows_kernel = 0;       // PNX_CFG_ROWS_KERNEL: 0 = automatic, 1 = k_rows_cover, 2 = k_rows_cover_q wherever legal
     bool hist_in_cover = true;  // PNX_CFG_HIST_IN_COVER: the coverage kernel over rows adds the histogram itself (0: K2 reads the coverage vector)
     int cover_variant = 3;     // 0 = plain, 1 = software-pipelined, 2 = pipelined + non-temporal loads (all three over the
                                // steps), 3 = over path rows (kernels_rows.hip)

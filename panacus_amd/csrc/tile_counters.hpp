@@ -87,10 +87,13 @@ struct TileCounters {
 // positions [b_lo, b_lo + n_bits) of every word: the waves that share a tile split them) and, with hs.rep, added to the
 // workgroup's histogram bins in LDS (sh_hist: n_groups + 1 u64 bins, read as 4-byte bins for node counts; zeroed and
 // flushed by the caller).  `own` = mask of this wave's bit positions.
+// `word`: the presence word this lane holds (its items are word + 64 b); it is the lane itself except in k_rows_cover_q, whose
+// lanes end up with the words in another order.
 template <int NPL>
 __device__ __forceinline__ void tile_tail(const uint32_t (&cnt)[NPL], uint32_t tile, uint32_t lane, uint32_t n_items,
                                           uint32_t *__restrict__ countable, const RowHist &hs, unsigned long long *sh_hist,
-                                          uint32_t b_lo, uint32_t n_bits, uint32_t own) {
+                                          uint32_t b_lo, uint32_t n_bits, uint32_t own, uint32_t word = 0xFFFFFFFFu) {
+    if (word == 0xFFFFFFFFu) word = lane;
     uint32_t *sh32 = reinterpret_cast<uint32_t *>(sh_hist);  // node counts: 4-byte bins (a workgroup holds few tiles of 2048 items)
     const bool hist = hs.rep != nullptr, weighted = hs.weights != nullptr;
     // The bins 0, 1 and n_groups (uncovered, private and core items) hold most items of a pangenome; through LDS atomics
@@ -110,7 +113,7 @@ __device__ __forceinline__ void tile_tail(const uint32_t (&cnt)[NPL], uint32_t t
         if (hs.n_groups <= 1 || (NPL < 32 && (hs.n_groups >> NPL) != 0)) mg = 0;  // (bin 1 / bin 0 take those items)
         uint32_t vm = 0;  // items 1 .. n_items of this word
         {
-            const uint64_t first = (uint64_t)tile * BLOCK_ITEMS + lane;  // item of bit 0; bit b: first + 64 b
+            const uint64_t first = (uint64_t)tile * BLOCK_ITEMS + word;  // item of bit 0; bit b: first + 64 b
             if (first <= n_items) {
                 const uint64_t nb = (n_items - first) / 64 + 1;  // bits with an item <= n_items
                 vm = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
@@ -130,7 +133,7 @@ __device__ __forceinline__ void tile_tail(const uint32_t (&cnt)[NPL], uint32_t t
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) v |= ((cnt[k] >> b) & 1u) << k;
-        const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
+        const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + word;
         // countable[0] is the reference's reserved element (abacus.rs:549-551)
         if (node <= n_items) __builtin_nontemporal_store(node ? v : 0xFFFFFFFFu, countable + node);
         if (hist && !weighted) {

@@ -307,3 +307,57 @@ def test_profile_sampling_times_every_nth_launch(ctx):
         ctx.profile_select(None)
         ctx.profile_reset()
         ctx.profile_enable(False)
+
+
+@pytest.mark.parametrize("n", [2047, 2048, 70_001, 300_000])
+def test_four_rows_per_load(ctx, n):
+    """PNX_CFG_ROWS_KERNEL 2: k_rows_cover_q -- the four quarters of a wave walk the four parts of the visiting order, one 16-byte
+    load per lane fetches four rows, the counters of the quarters are added up at the end -- against the oracle and against
+    k_rows_cover (1): groups of every size (so that the quarters' groups end at different slots), parts of unequal length, a
+    subset of the paths, paths that miss tiles (rows that are not there), excluded items, bp weights, a last tile that is
+    not full"""
+    from panacus_amd import capi
+    p = 53
+    items, pre, lens = orc.pansyn(31, n, p)
+    rng = np.random.default_rng(n)
+    # some paths only visit a range of the ids: tiles without a row of theirs
+    segs = []
+    for k in range(p):
+        s = items[int(pre[k]):int(pre[k + 1])]
+        if k % 5 == 1:
+            s = s[(s > n // 3) & (s < 2 * n // 3)]
+        elif k % 7 == 2:
+            s = s[:0]
+        segs.append(np.sort(s))
+    items = np.concatenate(segs).astype(np.uint64)
+    pre = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint64)
+    excl = (rng.random(n + 1) < 0.03).astype(np.uint8)
+    excl[0] = 0
+    try:
+        ctx.config(capi.CFG_COVER_ROUTE, 2)   # path rows
+        ctx.config(capi.CFG_ROWS_LAYOUT, 1)   # ... tile-major: what the kernel reads
+        for w, ex in ((None, None), (lens, excl)):
+            ctx.set_csr(items.astype(np.uint32), pre, n, weights=w, exclude=ex)
+            orders = [(np.arange(p), np.arange(p)),
+                      (np.arange(p), np.sort(rng.integers(0, 9, size=p))),            # groups of random sizes
+                      (np.arange(p), np.repeat(np.arange(4), [1, 2, 10, 40])),          # four groups, very unequal
+                      (np.arange(3, p - 2), np.arange(p - 5) // 3),
+                      (rng.permutation(p)[:30], np.sort(rng.integers(0, 12, size=30)))]
+            for pi, gid in orders:
+                pi = pi.astype(np.uint64)
+                gid = gid.astype(np.uint64)
+                gid = np.unique(gid, return_inverse=True)[1].astype(np.uint64)           # 0 .. G - 1 without gaps
+                G = int(gid.max()) + 1
+                ctx.set_order(pi, gid, G)
+                ocov = orc.coverage(items, pre, pi, gid, n, ex)
+                oh = orc.hist(ocov, G, w)
+                for kern in (2, 1):
+                    ctx.config(capi.CFG_ROWS_KERNEL, kern)
+                    before = ctx.info().n_rows_q_passes
+                    cnt, h = ctx.hist()
+                    assert ctx.info().n_rows_q_passes == before + (1 if kern == 2 and G >= 4 else 0), (kern, G)
+                    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh), (kern, G, w is not None)
+    finally:
+        ctx.config(capi.CFG_ROWS_KERNEL, 0)
+        ctx.config(capi.CFG_ROWS_LAYOUT, 0)
+        ctx.config(capi.CFG_COVER_ROUTE, 0)
