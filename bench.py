@@ -462,6 +462,13 @@ class OneShot:
             # the curves follow the pass on the device, from its own (all-reduced) counters; their tables are derived on a side
             # stream while the coverage kernel runs
             pend = hostlib.calc_growths_begin_on_device(self.P, self.thr)
+        warm = None
+        if self.use_dist and not self.native and self.growth_on_device and self.rank == 0 and not os.environ.get("PANACUS_BENCH_TABLES_BEHIND"):
+            # N > 1 with torch's collective: the curves can only be asked for once the reduced histogram is on the host, which
+            # would put the derivation of the (n, thresholds) tables BEHIND the pass and the all-reduce instead of beside the
+            # pass as with one GPU.  A call with a stand-in histogram derives them now, on the side stream; its curves are
+            # thrown away, the call behind the all-reduce finds the tables kept.
+            warm = hostlib.calc_growths_begin(np.ones(self.P + 1, dtype=np.uint64), self.thr, self.growth_threads)
         if self.use_dist and not self.native:
             # the collective follows the counters on the stream of the pass
             d_hist, st = ctx.hist_enqueued_on()
@@ -487,6 +494,8 @@ class OneShot:
         else:
             _, h = ctx.hist_fetch(want_countable=False)
         growths = None
+        if warm is not None:
+            hostlib.calc_growths_end(warm)
         if self.rank == 0:
             if pend is None:
                 pend = hostlib.calc_growths_begin(h, self.thr, self.growth_threads)
