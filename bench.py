@@ -446,7 +446,6 @@ class OneShot:
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0], rank, world)
         elif use_dist:
-            self.tmp = torch.zeros(P + 1, dtype=torch.int64, device=self.dev)
             self.host = torch.zeros(P + 1, dtype=torch.int64).pin_memory()
             self.ev = torch.cuda.Event(blocking=blocking)
 
@@ -480,9 +479,10 @@ class OneShot:
                 t = self.views[d_hist] = torch.as_tensor(_DevArray(d_hist, self.P + 1), device=self.dev)
             reruns = int(ctx.info().n_reruns)
             with torch.cuda.stream(ext):
-                self.tmp.copy_(t)
-                self.dist.all_reduce(self.tmp)  # RCCL, int64 sum == uint64 sum for counts < 2^63
-                self.host.copy_(self.tmp, non_blocking=True)
+                # in place on the pass's device counters (the library's own host copy was written by the kernel that published
+                # them, before this point of the stream): one launch less than through a staging tensor
+                self.dist.all_reduce(t)  # RCCL, int64 sum == uint64 sum for counts < 2^63
+                self.host.copy_(t, non_blocking=True)
                 self.ev.record(ext)
             self.ev.synchronize()
             ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
@@ -508,7 +508,7 @@ class OneShot:
         # torch objects that were used on the library's stream must go before the stream does
         self.views.clear()
         self.ext.clear()
-        for a in ("tmp", "host", "ev"):
+        for a in ("host", "ev"):
             if hasattr(self, a):
                 delattr(self, a)
 
