@@ -456,20 +456,14 @@ class OneShot:
             ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)  # ... and the closed forms from (n, thresholds)
         ctx.hist_async()
         pend = None
-        device_side = self.growth_on_device and self.rank == 0 and (not self.use_dist or self.native)
-        if device_side:
+        device_side = self.growth_on_device and self.rank == 0
+        if device_side and (not self.use_dist or self.native):
             # the curves follow the pass on the device, from its own (all-reduced) counters; their tables are derived on a side
             # stream while the coverage kernel runs
             pend = hostlib.calc_growths_begin_on_device(self.P, self.thr)
-        warm = None
-        if self.use_dist and not self.native and self.growth_on_device and self.rank == 0 and not os.environ.get("PANACUS_BENCH_TABLES_BEHIND"):
-            # N > 1 with torch's collective: the curves can only be asked for once the reduced histogram is on the host, which
-            # would put the derivation of the (n, thresholds) tables BEHIND the pass and the all-reduce instead of beside the
-            # pass as with one GPU.  A call with a stand-in histogram derives them now, on the side stream; its curves are
-            # thrown away, the call behind the all-reduce finds the tables kept.
-            warm = hostlib.calc_growths_begin(np.ones(self.P + 1, dtype=np.uint64), self.thr, self.growth_threads)
         if self.use_dist and not self.native:
-            # the collective follows the counters on the stream of the pass
+            # the collective follows the counters on the stream of the pass, IN PLACE on the pass's device counters (the
+            # library's own host copy was written by the kernel that published them, before this point of the stream) ...
             d_hist, st = ctx.hist_enqueued_on()
             ext = self.ext.get(st)
             if ext is None:
@@ -479,10 +473,13 @@ class OneShot:
                 t = self.views[d_hist] = torch.as_tensor(_DevArray(d_hist, self.P + 1), device=self.dev)
             reruns = int(ctx.info().n_reruns)
             with torch.cuda.stream(ext):
-                # in place on the pass's device counters (the library's own host copy was written by the kernel that published
-                # them, before this point of the stream): one launch less than through a staging tensor
                 self.dist.all_reduce(t)  # RCCL, int64 sum == uint64 sum for counts < 2^63
                 self.host.copy_(t, non_blocking=True)
+            if device_side:
+                # ... and the curves follow the reduced counters on the same stream, as with one GPU: no host round trip between
+                # the all-reduce and the closed forms, the tables derived beside the pass
+                pend = hostlib.calc_growths_begin_on_device(self.P, self.thr)
+            with torch.cuda.stream(ext):
                 self.ev.record(ext)
             self.ev.synchronize()
             ctx.hist_fetch(want_countable=False)  # verifies and retires the pass
@@ -494,8 +491,6 @@ class OneShot:
         else:
             _, h = ctx.hist_fetch(want_countable=False)
         growths = None
-        if warm is not None:
-            hostlib.calc_growths_end(warm)
         if self.rank == 0:
             if pend is None:
                 pend = hostlib.calc_growths_begin(h, self.thr, self.growth_threads)
