@@ -164,6 +164,124 @@ __global__ __launch_bounds__(64) void k_quorum_sums(uint32_t n, uint32_t c, uint
     if (m <= n) sum_q[(size_t)i * (n + 1) + m] = jlo < jhi ? s : pnx_exp2::as_f64(0x7ff8000000000000ull);
 }
 
+// K7 fused (round 4): the terms never leave the compute unit.  One workgroup = one i.  It takes the j of its row in chunks of
+// 256 (one thread per j, ASCENDING chunks) and walks m in tiles of QF_MB steps: phase A is K7a's walk -- every thread keeps
+// its q[i][j] in a register from its first m to its last and parks the term of every admissible m in an LDS tile
+// [QF_MB][256] --, phase B is K7b's sum -- lane r of the first wave adds row r of the tile to sum_q[i][m0 + r], kept in
+// LDS for every m, in ascending j.  The chunks follow each other in ascending j and a row's sum lives through all of
+// them, so every (i, m) still sees the reference's order of additions (hist.rs:164-176), and nothing but the finished
+// sums goes to HBM (the two-kernel route writes and reads n^3/6 terms: 2.8 GB for n = 1024, beside a coverage pass that
+// needs the same HBM).
+constexpr int QF_MB = 32;
+constexpr uint32_t QF_MAX_N = 640;
+constexpr int QF_LD = 257;  // doubles per tile row: lane r of phase B reads row r -- 2 r mod 64 banks apart
+__host__ __device__ static inline size_t quorum_fused_lds(uint32_t n) {
+    return ((size_t)2 * (n + 1) + (size_t)(n + 1) + (size_t)QF_MB * QF_LD) * sizeof(double);
+}
+__global__ __launch_bounds__(256) void k_quorum_fused(uint32_t n, uint32_t c, const uint32_t *__restrict__ m_quorum,
+                                                       const double *__restrict__ g_L, const double *__restrict__ m_fact,
+                                                       const double *__restrict__ n_fall, double *__restrict__ sum_q) {
+    extern __shared__ double sh_qf[];
+    __shared__ uint64_t s_exp2[256];
+    double *sL = sh_qf;                       // log2 table, 2 (n + 1) entries
+    double *s_sum = sL + 2 * (size_t)(n + 1);  // sum_q[i][0 .. n]
+    double *tile = s_sum + (n + 1);            // [QF_MB][QF_LD]
+    const uint32_t tid = threadIdx.x;
+    const uint32_t i = gridDim.x - 1u - blockIdx.x;  // i = 0 .. n - 1
+    s_exp2[tid] = c_exp2_tab[tid];
+    for (uint32_t k = tid; k < 2 * (n + 1); k += 256) sL[k] = g_L[k];
+    for (uint32_t k = tid; k <= n; k += 256) s_sum[k] = 0.0;
+    __syncthreads();
+    const uint32_t j_end = i < n - 1 ? i : n - 1;  // j <= i and j < n
+    for (uint32_t j0 = 0; j0 <= j_end; j0 += 256) {
+        const uint32_t j = j0 + tid;
+        const uint32_t wave_j0 = j0 + ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u);
+        bool alive = j <= j_end;
+        double q = 0.0, seed = 0.0;
+        if (alive) {  // choose(i, j), hist.rs:21-36
+            const uint32_t k = j > i - j ? i - j : j;
+            for (uint32_t a = 0; a < k; ++a) {
+                seed = pnx_exp2::add(seed, sL[i - a]);
+                seed = pnx_exp2::sub(seed, sL[a + 1]);
+            }
+        }
+        for (uint32_t m0 = j0 + 1; m0 <= n; m0 += QF_MB) {
+            // ---- phase A: the terms of m0 .. m0 + QF_MB - 1 (a wave none of whose lanes has started or is left skips the tile)
+            if (m0 + QF_MB - 1 > wave_j0 && __builtin_amdgcn_ballot_w64(alive)) {
+                for (uint32_t r = 0; r < (uint32_t)QF_MB; ++r) {
+                    const uint32_t m = m0 + r;
+                    if (m > n) break;
+                    uint32_t jlo, jhi;
+                    j_range(n, c, m_quorum[m], i, m, jlo, jhi);
+                    const double mf = m_fact[m], nf = n_fall[m];
+                    if (alive && m > j) {
+                        if (j < jlo || j >= jhi) {
+                            alive = false;
+                        } else {
+                            if (q == 0.0) q = seed;
+                            q = pnx_exp2::add(q, sL[n - i - m + 1 + j]);  // hist.rs:171
+                            q = pnx_exp2::sub(q, sL[m - j]);              // hist.rs:172
+                            const double x = pnx_exp2::sub(pnx_exp2::add(q, mf), nf);
+                            tile[r * QF_LD + tid] = pnx_exp2::exp2_exact(x, s_exp2);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phase B: row r is added to the sum of m0 + r in ascending j (the part of its j range that lies in this chunk)
+            if (tid < 64) {  // (the first wave; lanes beyond the tile's rows carry an empty range)
+                const uint32_t m = m0 + tid;
+                uint32_t a = 0, b = 0;
+                if (tid < (uint32_t)QF_MB && m <= n) {
+                    uint32_t jlo, jhi;
+                    j_range(n, c, m_quorum[m], i, m, jlo, jhi);
+                    a = jlo > j0 ? jlo : j0;
+                    b = jhi < j0 + 256 ? jhi : j0 + 256;
+                    if (a >= b) a = b = 0;
+                }
+                uint32_t lo_all = a < b ? a : 0xFFFFFFFFu, hi_all = b;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t x = __shfl_xor(lo_all, o), y = __shfl_xor(hi_all, o);
+                    lo_all = x < lo_all ? x : lo_all;
+                    hi_all = y > hi_all ? y : hi_all;
+                }
+                if (lo_all < hi_all) {
+                    const uint32_t rr = tid < (uint32_t)QF_MB ? tid : 0u;
+                    const double *row = tile + rr * QF_LD;
+                    double sacc = a < b ? s_sum[m] : 0.0;
+                    // eight entries of the row per step, the next eight already on their way while these are added
+                    uint32_t k0 = (lo_all - j0) & ~7u;
+                    const uint32_t k1 = hi_all - j0;  // <= 256
+                    double v[8], w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = row[k0 + u];
+                    for (; k0 < k1; k0 += 8) {
+                        const uint32_t kn = k0 + 8 < 256 ? k0 + 8 : 248;  // (clamped: the last prefetch is never used)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) w[u] = row[kn + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const uint32_t jj = j0 + k0 + (uint32_t)u;
+                            if (jj >= a && jj < b) sacc = pnx_exp2::add(sacc, v[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = w[u];
+                    }
+                    if (a < b) s_sum[m] = sacc;
+                }
+            }
+            if (!__syncthreads_or(alive ? 1 : 0)) break;
+        }
+        __syncthreads();
+    }
+    // sum_q[i][m], NaN where no j is admissible (add == false, hist.rs:163-179)
+    for (uint32_t m = 1 + tid; m <= n; m += 256) {
+        uint32_t jlo, jhi;
+        j_range(n, c, m_quorum[m], i, m, jlo, jhi);
+        sum_q[(size_t)i * (n + 1) + m] = jlo < jhi ? s_sum[m] : pnx_exp2::as_f64(0x7ff8000000000000ull);
+    }
+}
+
 __global__ void k_exp2_exact(const double *__restrict__ x, double *__restrict__ y, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = pnx_exp2::exp2_exact(x[i], c_exp2_tab);
@@ -174,12 +292,27 @@ __global__ void k_exp2_exact(const double *__restrict__ x, double *__restrict__ 
 static int launch_quorum_sums(pnx_ctx *ctx, hipStream_t st, DevBuf &d_terms, uint32_t n, uint32_t c, const uint32_t *d_mq, const double *d_L,
                               const double *d_mf, const double *d_nf, double *d_sum) {
     const size_t np1 = (size_t)n + 1;
+    PNX_HIP(ctx, hipMemsetAsync(d_sum, 0xFF, np1 * np1 * sizeof(double), st));  // NaN everywhere
+    {
+        // PNX_QUORUM_ROUTE = 0: the terms through HBM (K7a + K7b), 1: fused; default: fused up to QF_MAX_N groups (measured: n = 256
+        // alone 0.235 against 0.209 ms for all tables, but the coverage pass beside it runs undisturbed -- 0.656 against 0.703 ms;
+        // n = 1024: one workgroup per CU, 2.5 against 1.04 ms alone, and the tables outlast the pass)
+        const char *e = getenv("PNX_QUORUM_ROUTE");
+        const size_t lds = quorum_fused_lds(n);
+        const bool want = e && (e[0] == '0' || e[0] == '1') ? e[0] == '1' : n <= QF_MAX_N;
+        if (want && lds + 4096 <= 144 * 1024 && n >= 2) {
+            if (lds > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quorum_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_quorum_fused, dim3(n), dim3(256), lds, st, n, c, d_mq, d_L, d_mf, d_nf, d_sum);
+            PNX_HIP(ctx, hipGetLastError());
+            return PNX_OK;
+        }
+    }
     // rows per slab: up to 12 GiB of terms at a time (n = 1024: all rows in one launch, 16 K waves)
     uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)12 << 30) / (np1 * term_ld(n) * sizeof(double)));
     if (slab > n) slab = n;
     int rc;
     if ((rc = ensure(ctx, d_terms, (size_t)slab * np1 * term_ld(n) * sizeof(double)))) return rc;
-    PNX_HIP(ctx, hipMemsetAsync(d_sum, 0xFF, np1 * np1 * sizeof(double), st));  // NaN everywhere
     for (uint32_t i0 = 0; i0 < n; i0 += slab) {
         const uint32_t i1 = std::min(n, i0 + slab);
         const size_t tab_bytes = (2 * np1) * sizeof(double);  // the log2 table
