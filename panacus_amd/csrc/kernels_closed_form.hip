@@ -172,45 +172,86 @@ __global__ __launch_bounds__(64) void k_quorum_sums(uint32_t n, uint32_t c, uint
 // them, so every (i, m) still sees the reference's order of additions (hist.rs:164-176), and nothing but the finished
 // sums goes to HBM (the two-kernel route writes and reads n^3/6 terms: 2.8 GB for n = 1024, beside a coverage pass that
 // needs the same HBM).
-constexpr int QF_MB = 32;
-constexpr uint32_t QF_MAX_N = 640;
+constexpr uint32_t QF_MAX_N = 384;
 constexpr int QF_LD = 257;  // doubles per tile row: lane r of phase B reads row r -- 2 r mod 64 banks apart
-__host__ __device__ static inline size_t quorum_fused_lds(uint32_t n) {
-    return ((size_t)2 * (n + 1) + (size_t)(n + 1) + (size_t)QF_MB * QF_LD) * sizeof(double);
+// dynamic LDS: [log2 table, 2 (n + 1), if LDS_L] sum_q[i][0 .. n], the seeds choose(i, k) for k = 0 .. n / 2, the tile
+__host__ __device__ static inline size_t quorum_fused_lds(uint32_t n, int mb, bool lds_l) {
+    return ((lds_l ? (size_t)2 * (n + 1) : 0) + (size_t)(n + 1) + (size_t)(n / 2 + 1) + (size_t)mb * QF_LD) * sizeof(double);
 }
+template <int MB, bool LDS_L>
 __global__ __launch_bounds__(256) void k_quorum_fused(uint32_t n, uint32_t c, const uint32_t *__restrict__ m_quorum,
                                                        const double *__restrict__ g_L, const double *__restrict__ m_fact,
                                                        const double *__restrict__ n_fall, double *__restrict__ sum_q) {
     extern __shared__ double sh_qf[];
     __shared__ uint64_t s_exp2[256];
-    double *sL = sh_qf;                       // log2 table, 2 (n + 1) entries
-    double *s_sum = sL + 2 * (size_t)(n + 1);  // sum_q[i][0 .. n]
-    double *tile = s_sum + (n + 1);            // [QF_MB][QF_LD]
+    double *s_sum = sh_qf + (LDS_L ? 2 * (size_t)(n + 1) : 0);  // sum_q[i][0 .. n]
+    double *s_seed = s_sum + (n + 1);                             // choose(i, k), k = 0 .. i / 2
+    double *tile = s_seed + (n / 2 + 1);                          // [MB][QF_LD]
+    const double *L = g_L;
     const uint32_t tid = threadIdx.x;
     const uint32_t i = gridDim.x - 1u - blockIdx.x;  // i = 0 .. n - 1
     s_exp2[tid] = c_exp2_tab[tid];
-    for (uint32_t k = tid; k < 2 * (n + 1); k += 256) sL[k] = g_L[k];
+    if (LDS_L) {
+        for (uint32_t k = tid; k < 2 * (n + 1); k += 256) sh_qf[k] = g_L[k];
+        L = sh_qf;
+    }
     for (uint32_t k = tid; k <= n; k += 256) s_sum[k] = 0.0;
+    // choose(i, k), hist.rs:21-36: res += log2(i - a); res -= log2(a + 1) for a < k -- the terms do not depend on k, so the
+    // seeds of one i are the prefixes of ONE chain of i / 2 steps (and k = min(j, i - j) picks one): its inputs are laid out by
+    // all threads (in the tile, which is free yet), the chain is walked once, by one lane
+    const uint32_t K = i / 2;
+    for (uint32_t a = tid; a < K; a += 256) {
+        tile[2 * a] = g_L[i - a];
+        tile[2 * a + 1] = g_L[a + 1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sd = 0.0;
+        s_seed[0] = sd;
+        uint32_t a = 0;
+        for (; a + 4 <= K; a += 4) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = tile[2 * a + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sd = pnx_exp2::add(sd, x[2 * u]);
+                sd = pnx_exp2::sub(sd, x[2 * u + 1]);
+                s_seed[a + u + 1] = sd;
+            }
+        }
+        for (; a < K; ++a) {
+            sd = pnx_exp2::add(sd, tile[2 * a]);
+            sd = pnx_exp2::sub(sd, tile[2 * a + 1]);
+            s_seed[a + 1] = sd;
+        }
+    }
     __syncthreads();
     const uint32_t j_end = i < n - 1 ? i : n - 1;  // j <= i and j < n
+    const uint32_t C = n - i + 1;                  // hist.rs:171: log2(n - i - m + 1 + j) = L[C - (m - j)]
     for (uint32_t j0 = 0; j0 <= j_end; j0 += 256) {
         const uint32_t j = j0 + tid;
         const uint32_t wave_j0 = j0 + ((uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u);
         bool alive = j <= j_end;
-        double q = 0.0, seed = 0.0;
-        if (alive) {  // choose(i, j), hist.rs:21-36
-            const uint32_t k = j > i - j ? i - j : j;
-            for (uint32_t a = 0; a < k; ++a) {
-                seed = pnx_exp2::add(seed, sL[i - a]);
-                seed = pnx_exp2::sub(seed, sL[a + 1]);
-            }
-        }
-        for (uint32_t m0 = j0 + 1; m0 <= n; m0 += QF_MB) {
-            // ---- phase A: the terms of m0 .. m0 + QF_MB - 1 (a wave none of whose lanes has started or is left skips the tile)
-            if (m0 + QF_MB - 1 > wave_j0 && __builtin_amdgcn_ballot_w64(alive)) {
-                for (uint32_t r = 0; r < (uint32_t)QF_MB; ++r) {
+        double q = 0.0;
+        const double seed = alive ? s_seed[j > i - j ? i - j : j] : 0.0;
+        for (uint32_t m0 = j0 + 1; m0 <= n; m0 += MB) {
+            // ---- phase A: the terms of m0 .. m0 + MB - 1 (a wave none of whose lanes has started or is left skips the tile)
+            if (m0 + MB - 1 > wave_j0 && __builtin_amdgcn_ballot_w64(alive)) {
+                // the two table values of a step do not depend on q: they are fetched one step ahead (at clamped indices)
+                auto fetch = [&](uint32_t m, double &la, double &lb) {
+                    const uint32_t d = m > j ? m - j : 0u;
+                    la = L[C > d ? C - d : 0u];
+                    lb = L[d <= n ? d : n];
+                };
+                double la, lb;
+                fetch(m0, la, lb);
+#pragma unroll 2
+                for (uint32_t r = 0; r < (uint32_t)MB; ++r) {
                     const uint32_t m = m0 + r;
                     if (m > n) break;
+                    double la1, lb1;
+                    fetch(m + 1, la1, lb1);
                     uint32_t jlo, jhi;
                     j_range(n, c, m_quorum[m], i, m, jlo, jhi);
                     const double mf = m_fact[m], nf = n_fall[m];
@@ -219,12 +260,14 @@ __global__ __launch_bounds__(256) void k_quorum_fused(uint32_t n, uint32_t c, co
                             alive = false;
                         } else {
                             if (q == 0.0) q = seed;
-                            q = pnx_exp2::add(q, sL[n - i - m + 1 + j]);  // hist.rs:171
-                            q = pnx_exp2::sub(q, sL[m - j]);              // hist.rs:172
+                            q = pnx_exp2::add(q, la);  // hist.rs:171
+                            q = pnx_exp2::sub(q, lb);  // hist.rs:172
                             const double x = pnx_exp2::sub(pnx_exp2::add(q, mf), nf);
                             tile[r * QF_LD + tid] = pnx_exp2::exp2_exact(x, s_exp2);
                         }
                     }
+                    la = la1;
+                    lb = lb1;
                 }
             }
             __syncthreads();
@@ -232,7 +275,7 @@ __global__ __launch_bounds__(256) void k_quorum_fused(uint32_t n, uint32_t c, co
             if (tid < 64) {  // (the first wave; lanes beyond the tile's rows carry an empty range)
                 const uint32_t m = m0 + tid;
                 uint32_t a = 0, b = 0;
-                if (tid < (uint32_t)QF_MB && m <= n) {
+                if (tid < (uint32_t)MB && m <= n) {
                     uint32_t jlo, jhi;
                     j_range(n, c, m_quorum[m], i, m, jlo, jhi);
                     a = jlo > j0 ? jlo : j0;
@@ -246,7 +289,7 @@ __global__ __launch_bounds__(256) void k_quorum_fused(uint32_t n, uint32_t c, co
                     hi_all = y > hi_all ? y : hi_all;
                 }
                 if (lo_all < hi_all) {
-                    const uint32_t rr = tid < (uint32_t)QF_MB ? tid : 0u;
+                    const uint32_t rr = tid < (uint32_t)MB ? tid : 0u;
                     const double *row = tile + rr * QF_LD;
                     double sacc = a < b ? s_sum[m] : 0.0;
                     // eight entries of the row per step, the next eight already on their way while these are added
@@ -294,16 +337,26 @@ static int launch_quorum_sums(pnx_ctx *ctx, hipStream_t st, DevBuf &d_terms, uin
     const size_t np1 = (size_t)n + 1;
     PNX_HIP(ctx, hipMemsetAsync(d_sum, 0xFF, np1 * np1 * sizeof(double), st));  // NaN everywhere
     {
-        // PNX_QUORUM_ROUTE = 0: the terms through HBM (K7a + K7b), 1: fused; default: fused up to QF_MAX_N groups (measured: n = 256
-        // alone 0.235 against 0.209 ms for all tables, but the coverage pass beside it runs undisturbed -- 0.656 against 0.703 ms;
-        // n = 1024: one workgroup per CU, 2.5 against 1.04 ms alone, and the tables outlast the pass)
+        // PNX_QUORUM_ROUTE = 0: the terms through HBM (K7a + K7b), 1: fused wherever it fits; default: fused up to QF_MAX_N groups.
+        // Measured (all tables of the bench's three pairs, alone / the histgrowth step of 10 M nodes beside whose pass they are
+        // derived): n = 256 fused 0.236 / 0.746-0.763 ms, two kernels 0.209 / 0.79-0.81 -- the pass runs undisturbed beside the
+        // fused kernel (0.634-0.656 against 0.69-0.70 ms); n = 512: 0.57 / 1.460 against 0.36 / 1.466; n = 1024: 1.47 / 3.99
+        // against 1.04 / 3.6-3.9 -- there the pass leaves the fused kernel's workgroups (47 KB, 256 threads) too few slots and
+        // they outlast it
         const char *e = getenv("PNX_QUORUM_ROUTE");
-        const size_t lds = quorum_fused_lds(n);
+        // small n: 32 steps per tile and the log2 table in LDS; large n: 16 steps and the table from the cache, fetched a step
+        // ahead -- 47 KB for n = 1024, so that two workgroups find room on a CU beside a coverage pass
+        const bool small = n <= 384;
+        const size_t lds = quorum_fused_lds(n, small ? 32 : 16, small);
         const bool want = e && (e[0] == '0' || e[0] == '1') ? e[0] == '1' : n <= QF_MAX_N;
-        if (want && lds + 4096 <= 144 * 1024 && n >= 2) {
-            if (lds > 48 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_quorum_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k_quorum_fused, dim3(n), dim3(256), lds, st, n, c, d_mq, d_L, d_mf, d_nf, d_sum);
+        if (want && lds + 4096 <= 144 * 1024 && n >= 2 && n <= (uint32_t)(small ? 32 : 16) * QF_LD /* the seed chain's inputs fit the tile */) {
+            auto go = [&](auto kern) {
+                if (lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, dim3(n), dim3(256), lds, st, n, c, d_mq, d_L, d_mf, d_nf, d_sum);
+            };
+            if (small) go(k_quorum_fused<32, true>);
+            else go(k_quorum_fused<16, false>);
             PNX_HIP(ctx, hipGetLastError());
             return PNX_OK;
         }

@@ -55,6 +55,35 @@ def test_quorum_growth_offload_bitwise(ctx, n):
         assert b.tobytes() == exp.tobytes(), (n, c, q)
 
 
+@pytest.mark.parametrize("route", ["0", "1"])
+@pytest.mark.parametrize("n", [3, 130, 301, 385, 700])
+def test_quorum_inner_sums_both_routes_bitwise(ctx, monkeypatch, n, route):
+    """the inner sums of the quorum pair through HBM (K7a + K7b, PNX_QUORUM_ROUTE=0) and kept in LDS (k_quorum_fused, =1; both of
+    its shapes: <= 384 groups and above) == the host path == the oracle, bit for bit"""
+    from panacus_amd import hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    monkeypatch.setenv("PNX_QUORUM_ROUTE", route)
+    rng = np.random.default_rng(7 * n)
+    h = rng.integers(0, 10**7, size=n + 1).astype(np.uint64)
+    h[rng.integers(0, n + 1, size=2)] = 0
+    pairs = [(1, 0.5), (0, 0.1), (2, 0.9), (max(1, n // 3), 0.3), (1, 2.0 / n), (1, 0.999), (n, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    host_only = hostlib.calc_growths(h, thr)
+    hostlib.set_quorum_offload(ctx, min_n=1)
+    try:
+        ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)
+        got = hostlib.calc_growths(h, thr)
+    finally:
+        hostlib.set_quorum_offload(None)
+        ctx.sync()
+        ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)
+        ctx.config(capi.CFG_MAX_IN_FLIGHT, 2)
+    for (c, q), a, b in zip(pairs, got, host_only):
+        assert a.tobytes() == b.tobytes(), (n, c, q, route)
+        if n <= 301:
+            assert a.tobytes() == orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q)).tobytes(), (n, c, q, route)
+
+
 def test_quorum_growth_offload_large_n(ctx):
     """n = 1024 (the north_star shape): offload == host path bit for bit"""
     from panacus_amd import hostlib
