@@ -371,8 +371,11 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
                        BT * BLOCK_ITEMS, (unsigned long long *)tk->d_tile_idx_own.p, (uint4 *)tk->d_block.p, (uint32_t)(tk->block_bytes / 16));
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
-    // (recorded on one stream as well: the derivation of the closed forms' tables starts behind it -- kernels_closed_form.hip)
-    PNX_HIP(ctx, hipEventRecord(tk->ev_pre, ctx->s_pre));
+    // (recorded on one stream as well where the closed forms' tables are derived by the two-kernel route: that derivation starts
+    // behind it -- kernels_closed_form.hip.  Otherwise nothing waits for it, and an event between the two kernels of one stream
+    // costs the second one 6-15 us: index end -> coverage start 8-17 us with it, as seen in the kernel trace)
+    tk->pre_recorded = phased || !quorum_route_fused(ctx->n_groups);
+    if (tk->pre_recorded) PNX_HIP(ctx, hipEventRecord(tk->ev_pre, ctx->s_pre));
     if (phased) PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_main, tk->ev_pre, 0));
     uint32_t bits = 1;  // planes needed to count up to n_groups inclusive
     while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;

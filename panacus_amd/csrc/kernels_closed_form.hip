@@ -172,7 +172,6 @@ __global__ __launch_bounds__(64) void k_quorum_sums(uint32_t n, uint32_t c, uint
 // them, so every (i, m) still sees the reference's order of additions (hist.rs:164-176), and nothing but the finished
 // sums goes to HBM (the two-kernel route writes and reads n^3/6 terms: 2.8 GB for n = 1024, beside a coverage pass that
 // needs the same HBM).
-constexpr uint32_t QF_MAX_N = 384;
 constexpr int QF_LD = 257;  // doubles per tile row: lane r of phase B reads row r -- 2 r mod 64 banks apart
 // dynamic LDS: [log2 table, 2 (n + 1), if LDS_L] sum_q[i][0 .. n], the seeds choose(i, k) for k = 0 .. n / 2, the tile
 __host__ __device__ static inline size_t quorum_fused_lds(uint32_t n, int mb, bool lds_l) {
@@ -337,18 +336,17 @@ static int launch_quorum_sums(pnx_ctx *ctx, hipStream_t st, DevBuf &d_terms, uin
     const size_t np1 = (size_t)n + 1;
     PNX_HIP(ctx, hipMemsetAsync(d_sum, 0xFF, np1 * np1 * sizeof(double), st));  // NaN everywhere
     {
-        // PNX_QUORUM_ROUTE = 0: the terms through HBM (K7a + K7b), 1: fused wherever it fits; default: fused up to QF_MAX_N groups.
+        // PNX_QUORUM_ROUTE = 0: the terms through HBM (K7a + K7b), 1: fused wherever it fits; default: fused up to 384 groups (quorum_route_fused).
         // Measured (all tables of the bench's three pairs, alone / the histgrowth step of 10 M nodes beside whose pass they are
         // derived): n = 256 fused 0.236 / 0.746-0.763 ms, two kernels 0.209 / 0.79-0.81 -- the pass runs undisturbed beside the
         // fused kernel (0.634-0.656 against 0.69-0.70 ms); n = 512: 0.57 / 1.460 against 0.36 / 1.466; n = 1024: 1.47 / 3.99
         // against 1.04 / 3.6-3.9 -- there the pass leaves the fused kernel's workgroups (47 KB, 256 threads) too few slots and
         // they outlast it
-        const char *e = getenv("PNX_QUORUM_ROUTE");
         // small n: 32 steps per tile and the log2 table in LDS; large n: 16 steps and the table from the cache, fetched a step
         // ahead -- 47 KB for n = 1024, so that two workgroups find room on a CU beside a coverage pass
         const bool small = n <= 384;
         const size_t lds = quorum_fused_lds(n, small ? 32 : 16, small);
-        const bool want = e && (e[0] == '0' || e[0] == '1') ? e[0] == '1' : n <= QF_MAX_N;
+        const bool want = quorum_route_fused(n);
         if (want && lds + 4096 <= 144 * 1024 && n >= 2 && n <= (uint32_t)(small ? 32 : 16) * QF_LD /* the seed chain's inputs fit the tile */) {
             auto go = [&](auto kern) {
                 if (lds > 48 * 1024)
@@ -642,6 +640,103 @@ __global__ __launch_bounds__(64 * CF_WAVES) void k_cf_eval(uint32_t n, const uin
     if (in && threadIdx.x < 64) out[(size_t)t * n + m - 1] = y;
 }
 
+// k_cf_eval for up to CFS_MAX_N groups: the whole column strip at once.  k_cf_eval walks its columns in chunks of 32 rows -- fetch,
+// exp2, barrier, 32 additions, eight to sixteen times in a row (30 us at n = 256, most of it the chunks' round trips).  Here a
+// workgroup serves 32 values of m and holds ALL rows of its strip: every table value is requested before the prologue's first
+// barrier, all terms are evaluated at once (nine per thread) and parked in LDS [i][32], then one wave walks the first sum and
+// another, beside it, the quorum pair's second sum -- each lane its column in ascending i, the reference's order; entries
+// outside a column's range are +0.0 (y + 0.0 is y, as in cf_column_sum).
+constexpr int CFS_COLS = 32;
+constexpr uint32_t CFS_MAX_N = 256;
+constexpr int CFS_ROWS_PER_THREAD = (CFS_MAX_N + 1 + 31) / 32;  // 1024 threads = 32 columns x 32 row lanes
+__host__ __device__ static inline size_t cf_eval_small_lds(uint32_t n) { return ((size_t)2 * (n + 1) * CFS_COLS + (n + 1) + CFS_COLS) * sizeof(double); }
+__global__ __launch_bounds__(1024) void k_cf_eval_small(uint32_t n, const uint64_t *__restrict__ hist, const uint32_t *__restrict__ branch,
+                                                         const uint32_t *__restrict__ cov, const uint32_t *__restrict__ m_quorum,
+                                                         const double *__restrict__ n_fall, const double *__restrict__ pm,
+                                                         const double *__restrict__ lsq, double *__restrict__ out) {
+    extern __shared__ double s_dyn[];
+    __shared__ uint64_t s_exp2[256];
+    __shared__ uint64_t s_log2[274];
+    __shared__ unsigned long long s_tot;
+    const uint32_t np1 = n + 1;
+    double *tA = s_dyn, *tB = tA + (size_t)np1 * CFS_COLS, *s_lh = tB + (size_t)np1 * CFS_COLS, *s_yr = s_lh + np1;
+    const uint32_t tid = threadIdx.x, col = tid & 31u, row0 = tid >> 5, t = blockIdx.y;
+    const uint32_t m_raw = blockIdx.x * CFS_COLS + col + 1;
+    const bool in = m_raw <= n;
+    const uint32_t m = in ? m_raw : n;
+    const uint32_t c = cov[t], br = branch[t];
+    const size_t tab = (size_t)t * np1 * np1 + m;
+    double v[CFS_ROWS_PER_THREAD], w[CFS_ROWS_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = row0 + 32u * (uint32_t)k;
+        v[k] = pm[tab + (size_t)(i <= n ? i : n) * np1];
+        w[k] = 0.0;
+    }
+    if (br == CF_QUORUM) {
+#pragma unroll
+        for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
+            const uint32_t i = row0 + 32u * (uint32_t)k;
+            w[k] = lsq[tab + (size_t)(i <= n ? i : n) * np1];
+        }
+    }
+    const double nf = n_fall[(size_t)t * np1 + m];
+    const uint32_t qlo = br == CF_QUORUM ? m_quorum[(size_t)t * np1 + m] : 0u;
+    for (uint32_t k = tid; k < 256; k += blockDim.x) s_exp2[k] = c_exp2_tab[k];
+    for (uint32_t k = tid; k < 274; k += blockDim.x) s_log2[k] = c_log2_tab[k];
+    if (tid == 0) s_tot = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i <= n; i += blockDim.x) s_lh[i] = pnx_exp2::log2_exact((double)hist[i], s_log2);  // hist.rs:106
+    if (br == CF_UNION) {  // hist.rs:95-97
+        unsigned long long part = 0;
+        for (uint32_t i = c + tid; i <= n; i += blockDim.x) part += hist[i];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((tid & 63u) == 0 && part) atomicAdd(&s_tot, part);
+    }
+    __syncthreads();
+    // union: i in c .. n - m; core / quorum: i in max(m, c) .. n;  quorum's second sum: i in m_quorum .. n - 1 where a j was admissible
+    const uint32_t lo = br == CF_UNION ? c : (m > c ? m : c);
+    const uint32_t hi = br == CF_UNION ? (n >= m ? n - m + 1 : 0u) : n + 1;
+#pragma unroll
+    for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
+        const uint32_t i = row0 + 32u * (uint32_t)k;
+        if (i > n) continue;
+        double ta = 0.0, tb = 0.0;
+        if (in && i >= lo && i < hi) ta = pnx_exp2::exp2_exact(pnx_exp2::sub(pnx_exp2::add(s_lh[i], v[k]), nf), s_exp2);
+        if (br == CF_QUORUM && in && i >= qlo && i < n && w[k] == w[k]) tb = pnx_exp2::exp2_exact(pnx_exp2::add(s_lh[i], w[k]), s_exp2);
+        tA[(size_t)i * CFS_COLS + col] = ta;
+        tB[(size_t)i * CFS_COLS + col] = tb;
+    }
+    __syncthreads();
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    double y = 0.0;
+    if (lane < (uint32_t)CFS_COLS && (wave == 0 || (wave == 1 && br == CF_QUORUM))) {
+        const double *src = (wave == 0 ? tA : tB) + lane;
+        uint32_t i = 0;
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(i + u <= n ? i + u : n) * CFS_COLS];
+        for (; i + 8 <= np1; i += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b[u] = src[(size_t)(i + 8 + u <= n ? i + 8 + u : n) * CFS_COLS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) y = pnx_exp2::add(y, a[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = b[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i + (uint32_t)u < np1) y = pnx_exp2::add(y, a[u]);
+        if (wave == 1) s_yr[lane] = y;
+    }
+    __syncthreads();
+    if (wave == 0 && lane < (uint32_t)CFS_COLS) {
+        if (br == CF_UNION) y = pnx_exp2::sub((double)s_tot, y);
+        else if (br == CF_QUORUM) y = pnx_exp2::add(y, s_yr[lane]);
+        if (in) out[(size_t)t * n + m - 1] = y;
+    }
+}
+
 __global__ void k_log2_exact(const double *__restrict__ x, double *__restrict__ y, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = pnx_exp2::log2_exact(x[i], c_log2_tab);
@@ -853,7 +948,7 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
         src = &ctx->tk[ctx->tk_last()];
     }
     int rc;
-    if ((rc = ensure_growth_tables(ctx, n, n_pairs, branch, cov_abs, quorum_rel, src && src->band ? src->ev_pre : nullptr))) return rc;
+    if ((rc = ensure_growth_tables(ctx, n, n_pairs, branch, cov_abs, quorum_rel, src && src->band && src->pre_recorded ? src->ev_pre : nullptr))) return rc;
     const pnx_ctx::GrowthTables &tab = ctx->gtab;
     const size_t np1 = (size_t)n + 1, T = n_pairs;
     if (ctx->gslot_count == 0) ctx->gslot_next = ctx->gslot_oldest = 0;
@@ -895,6 +990,14 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
         std::memcpy(h, hist, np1 * 8);
     }
     const uint32_t *d_br = (const uint32_t *)((const char *)tab.d_par.p + T * 8), *d_cov = d_br + T;
+    static const bool eval_chunked = getenv("PNX_CF_EVAL_CHUNKED") != nullptr;  // (experiments: the chunked kernel for every n)
+    if (n <= CFS_MAX_N && !eval_chunked) {
+        const size_t lds_small = cf_eval_small_lds(n);
+        if (lds_small > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+        hipLaunchKernelGGL(k_cf_eval_small, dim3((n + CFS_COLS - 1) / CFS_COLS, n_pairs), dim3(1024), lds_small, st, n, d_hist, d_br, d_cov,
+                           (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p, d_out);
+    } else
     hipLaunchKernelGGL(k_cf_eval, dim3((n + 63) / 64, n_pairs), dim3(64 * CF_WAVES), (2 * CF_CHUNK * 64 + np1) * sizeof(double), st, n, d_hist, d_br,
                        d_cov, (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p,
                        d_out);
@@ -941,6 +1044,7 @@ void preload_closed_form(unsigned what) {
         touch((const void *)k_cf_rows);
         touch((const void *)k_cf_lsq);
         touch((const void *)k_cf_eval);
+        touch((const void *)k_cf_eval_small);
     }
 }
 }  // namespace pnx

@@ -5,6 +5,7 @@
 // and DESIGN.md for the data layout.
 #pragma once
 
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -16,6 +17,15 @@
 #include "../../include/panacus_amd.h"
 
 namespace pnx {
+
+// Route of the quorum pair's inner sums (kernels_closed_form.hip, K7): fused (terms in LDS) up to 384 groups, two kernels
+// through HBM above; PNX_QUORUM_ROUTE = 0 / 1 forces one.  The one-shot pass reads it too: the two-kernel route's many
+// workgroups must start BEHIND the pass's index kernel (an event between index and coverage kernel), the fused route's need not.
+inline bool quorum_route_fused(uint32_t n) {
+    const char *e = getenv("PNX_QUORUM_ROUTE");
+    return e && (e[0] == '0' || e[0] == '1') ? e[0] == '1' : n <= 384u;
+}
+
 
 // ---- geometry of the presence bit matrix ------------------------------------------------
 // A "block" is 2048 consecutive item ids held as 64 u32 words, one per lane of a wave:
@@ -58,6 +68,7 @@ struct Ticket {
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
+    bool pre_recorded = false;                       // ev_pre was recorded by this pass (a one-shot pass leaves it out where nothing waits for it)
     // rows route, up to HIST_FUSED_MAX_BINS bins: the coverage kernel adds the histogram itself, into HIST_REPLICAS copies at the
     // end of d_block (cleared with it); k_hist_publish adds them up and writes flags + hist into h_block directly
     uint64_t *d_hist_rep = nullptr;
