@@ -646,10 +646,14 @@ __global__ __launch_bounds__(64 * CF_WAVES) void k_cf_eval(uint32_t n, const uin
 // barrier, all terms are evaluated at once (nine per thread) and parked in LDS [i][32], then one wave walks the first sum and
 // another, beside it, the quorum pair's second sum -- each lane its column in ascending i, the reference's order; entries
 // outside a column's range are +0.0 (y + 0.0 is y, as in cf_column_sum).
-constexpr int CFS_COLS = 32;
-constexpr uint32_t CFS_MAX_N = 256;
-constexpr int CFS_ROWS_PER_THREAD = (CFS_MAX_N + 1 + 31) / 32;  // 1024 threads = 32 columns x 32 row lanes
-__host__ __device__ static inline size_t cf_eval_small_lds(uint32_t n) { return ((size_t)2 * (n + 1) * CFS_COLS + (n + 1) + CFS_COLS) * sizeof(double); }
+// Two shapes: 32 columns for up to 256 groups, 8 columns for up to 1024 (the strip's rows x columns x 8 B, twice, must fit the LDS);
+// 1024 threads = COLS columns x (1024 / COLS) row lanes, nine rows per thread either way.
+constexpr uint32_t CFS_MAX_N = 1024;
+__host__ __device__ static inline int cf_eval_small_cols(uint32_t n) { return n <= 256 ? 32 : 8; }
+__host__ __device__ static inline size_t cf_eval_small_lds(uint32_t n) {
+    return ((size_t)2 * (n + 1) * cf_eval_small_cols(n) + (n + 1) + 32) * sizeof(double);
+}
+template <int CFS_COLS, uint32_t MAXN>
 __global__ __launch_bounds__(1024) void k_cf_eval_small(uint32_t n, const uint64_t *__restrict__ hist, const uint32_t *__restrict__ branch,
                                                          const uint32_t *__restrict__ cov, const uint32_t *__restrict__ m_quorum,
                                                          const double *__restrict__ n_fall, const double *__restrict__ pm,
@@ -660,7 +664,9 @@ __global__ __launch_bounds__(1024) void k_cf_eval_small(uint32_t n, const uint64
     __shared__ unsigned long long s_tot;
     const uint32_t np1 = n + 1;
     double *tA = s_dyn, *tB = tA + (size_t)np1 * CFS_COLS, *s_lh = tB + (size_t)np1 * CFS_COLS, *s_yr = s_lh + np1;
-    const uint32_t tid = threadIdx.x, col = tid & 31u, row0 = tid >> 5, t = blockIdx.y;
+    constexpr uint32_t RL = 1024 / CFS_COLS;                         // row lanes
+    constexpr int CFS_ROWS_PER_THREAD = (int)((MAXN + 1 + RL - 1) / RL);
+    const uint32_t tid = threadIdx.x, col = tid % CFS_COLS, row0 = tid / CFS_COLS, t = blockIdx.y;
     const uint32_t m_raw = blockIdx.x * CFS_COLS + col + 1;
     const bool in = m_raw <= n;
     const uint32_t m = in ? m_raw : n;
@@ -669,14 +675,14 @@ __global__ __launch_bounds__(1024) void k_cf_eval_small(uint32_t n, const uint64
     double v[CFS_ROWS_PER_THREAD], w[CFS_ROWS_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
-        const uint32_t i = row0 + 32u * (uint32_t)k;
+        const uint32_t i = row0 + RL * (uint32_t)k;
         v[k] = pm[tab + (size_t)(i <= n ? i : n) * np1];
         w[k] = 0.0;
     }
     if (br == CF_QUORUM) {
 #pragma unroll
         for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
-            const uint32_t i = row0 + 32u * (uint32_t)k;
+            const uint32_t i = row0 + RL * (uint32_t)k;
             w[k] = lsq[tab + (size_t)(i <= n ? i : n) * np1];
         }
     }
@@ -699,7 +705,7 @@ __global__ __launch_bounds__(1024) void k_cf_eval_small(uint32_t n, const uint64
     const uint32_t hi = br == CF_UNION ? (n >= m ? n - m + 1 : 0u) : n + 1;
 #pragma unroll
     for (int k = 0; k < CFS_ROWS_PER_THREAD; ++k) {
-        const uint32_t i = row0 + 32u * (uint32_t)k;
+        const uint32_t i = row0 + RL * (uint32_t)k;
         if (i > n) continue;
         double ta = 0.0, tb = 0.0;
         if (in && i >= lo && i < hi) ta = pnx_exp2::exp2_exact(pnx_exp2::sub(pnx_exp2::add(s_lh[i], v[k]), nf), s_exp2);
@@ -993,10 +999,14 @@ int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n,
     static const bool eval_chunked = getenv("PNX_CF_EVAL_CHUNKED") != nullptr;  // (experiments: the chunked kernel for every n)
     if (n <= CFS_MAX_N && !eval_chunked) {
         const size_t lds_small = cf_eval_small_lds(n);
-        if (lds_small > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
-        hipLaunchKernelGGL(k_cf_eval_small, dim3((n + CFS_COLS - 1) / CFS_COLS, n_pairs), dim3(1024), lds_small, st, n, d_hist, d_br, d_cov,
-                           (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p, d_out);
+        auto go = [&](auto kern, int cols) {
+            if (lds_small > 48 * 1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+            hipLaunchKernelGGL(kern, dim3((n + cols - 1) / cols, n_pairs), dim3(1024), lds_small, st, n, d_hist, d_br, d_cov,
+                               (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p, d_out);
+        };
+        if (n <= 256) go(k_cf_eval_small<32, 256>, 32);
+        else go(k_cf_eval_small<8, 1024>, 8);
     } else
     hipLaunchKernelGGL(k_cf_eval, dim3((n + 63) / 64, n_pairs), dim3(64 * CF_WAVES), (2 * CF_CHUNK * 64 + np1) * sizeof(double), st, n, d_hist, d_br,
                        d_cov, (const uint32_t *)tab.d_mq.p, (const double *)tab.d_nf.p, (const double *)tab.d_pm.p, (const double *)tab.d_lsq.p,
@@ -1044,7 +1054,8 @@ void preload_closed_form(unsigned what) {
         touch((const void *)k_cf_rows);
         touch((const void *)k_cf_lsq);
         touch((const void *)k_cf_eval);
-        touch((const void *)k_cf_eval_small);
+        touch((const void *)k_cf_eval_small<32, 256>);
+        touch((const void *)k_cf_eval_small<8, 1024>);
     }
 }
 }  // namespace pnx

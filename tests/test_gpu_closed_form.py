@@ -161,7 +161,7 @@ def test_device_log2_equals_libm_bitwise(ctx):
         assert bad.size == 0, (x[bad[:5]], got[bad[:5]], exp[bad[:5]])
 
 
-@pytest.mark.parametrize("n", [2, 5, 44, 130, 256, 301])
+@pytest.mark.parametrize("n", [2, 5, 44, 130, 256, 257, 301, 700, 1024, 1025])
 def test_whole_closed_forms_on_the_device_bitwise(ctx, n):
     """pnx_growth_closed_form: union, core and quorum curves from the histogram to the value on the device == the serial
     restatement of hist.rs:89-187 == the host path, bit for bit; also straight from the counters of a coverage pass"""
