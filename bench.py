@@ -722,6 +722,64 @@ def shape_1k_block(args, local_rank):
     }
 
 
+def strayed_block(args, local_rank):
+    """The headline step on paths that are NOT sorted by id: pansyn-v1r (pnx_set_csr_pansyn_rearranged -- of the 64-step blocks of
+    every path 1 % reversed in place, 0.1 % replaced by a copy of an earlier block, 0.05 % moved elsewhere in the id space),
+    same nodes x paths, same thresholds.  The one-shot route has to hold (no rerun, no rows): the steps that are not in the
+    band their position says are spilled by k_band_cover and added by k_band_tail.  The histogram is checked against the
+    oracle on the same graph (read back from HBM)."""
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    N, P, steps = args.nodes, args.paths, max(4, args.strayed_steps)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    ctx = capi.Context(local_rank)
+    ctx.set_csr_pansyn_rearranged(args.seed, N, P, with_weights=False)
+    order = np.arange(P, dtype=np.uint32)
+    ctx.set_order(order, order, P)
+    hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
+    on_device = args.quorum_offload_min_n <= P <= 2048 and hostlib.device_growth_usable()
+    stepper = OneShot(ctx, P, thr, growth_on_device=on_device, growth_threads=args.growth_threads)
+
+    def barrier():
+        ctx.sync()
+
+    dt, h, growths, prof = timed_steps(stepper, steps, 3, barrier, max(1, min(4, steps // 4)))
+    info = ctx.info()
+    S = int(info.n_steps)
+    ms_per_step, B, cover_ms, roofline, breakdown = step_report(ctx, N, P, S, dt, steps, prof)
+    hist_only = hist_only_block(ctx, N, P, S, 12)
+    held = int(info.n_rows) == 0 and int(info.n_reruns) == 0
+    agrees = None
+    if not args.no_cpu_baseline:
+        try:
+            import oracle as orc
+            items32, pre, _ = ctx.get_csr()
+            pi = np.arange(P, dtype=np.uint64)
+            ocov = orc.coverage(items32.astype(np.uint64), pre, pi, pi, N)
+            del items32
+            agrees = bool(np.array_equal(orc.hist(ocov, P), h))
+            del ocov
+        except Exception as e:  # the oracle is optional test infrastructure
+            agrees = f"{type(e).__name__}: {e}"
+        if agrees is False:
+            raise SystemExit("bench: the histogram of the rearranged graph differs from the CPU oracle")
+    if int(h.sum()) != N:
+        raise SystemExit(f"strayed_paths: histogram sums to {int(h.sum())}, expected {N}")
+    stepper.close()
+    hostlib.set_quorum_offload(None)
+    ctx.close()
+    return {
+        "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1r seed {args.seed} (paths not sorted by id: 1 % of the 64-step "
+                    f"blocks reversed, 0.1 % copied from earlier in the path, 0.05 % moved elsewhere), {N} nodes x {P} paths",
+        "steps": steps, "ms_per_step": ms_per_step, "value": N * P / (ms_per_step * 1e-3) / 1e6, "unit": "M node*paths/s",
+        "steps_in_csr": S, "spilled_steps_per_pass": int(info.n_spilled_last), "n_reruns": int(info.n_reruns), "n_rows": int(info.n_rows),
+        "one_shot_route_held": held, "roofline": roofline, "step_breakdown_ms": breakdown, "hist_only": hist_only,
+        "checks": {"hist_sum": int(h.sum()), "hist_agrees_with_oracle": agrees,
+                   "growth_last_floor": [int(np.floor(g[-1])) for g in growths]},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -744,6 +802,8 @@ def main():
     ap.add_argument("--k1-nodes", type=int, default=10_000_000)
     ap.add_argument("--k1-paths", type=int, default=1024)
     ap.add_argument("--k1-steps", type=int, default=20)
+    ap.add_argument("--no-strayed", action="store_true", help="skip the strayed_paths block (the headline step on pansyn-v1r: paths not sorted by id)")
+    ap.add_argument("--strayed-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-resident", action="store_true", help="skip the resident_pass blocks (pipelined passes over kept path rows)")
     ap.add_argument("--resident-steps", type=int, default=100)
@@ -761,7 +821,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="the timed steps and nothing else (what the counter passes run)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = True
+        args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = args.no_strayed = True
 
     force_dist = os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or force_dist):
@@ -996,6 +1056,9 @@ def main():
     # ---- north_star's 10M x 1k shape (one GPU) ----
     if world == 1 and not use_dist and not args.no_shape_1k:
         out["shape_10Mx1k"] = shape_1k_block(args, local_rank)
+    # ---- the headline step on paths that are not sorted by id (one GPU) ----
+    if world == 1 and not use_dist and not args.no_strayed:
+        out["strayed_paths"] = strayed_block(args, local_rank)
     if not use_dist:
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             run_cpu_baseline()

@@ -291,6 +291,12 @@ int pnx_set_csr_pansyn(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n
  * histogram, the ordered-growth curves -- compute what one process computes on the whole graph (node-range
  * sharding; bench.py's multi-GPU blocks). */
 int pnx_set_csr_pansyn_shard(pnx_ctx *ctx, uint64_t seed, uint64_t node_lo, uint32_t n_nodes, uint32_t n_paths, int with_weights);
+/* (round 5) pansyn-v1r: the paths of pansyn-v1(seed, n_nodes, n_paths) rearranged the way real pangenome paths stray from the
+ * order of the ids -- of the 64-step blocks of every path 1 % are reversed in place (local inversions), 0.1 % replaced by a copy
+ * of an earlier block of the same path (jumps back, duplications), 0.05 % moved elsewhere in the id space (translocations); the
+ * first and the last block of a path stay.  The bench/test input for coverage passes over paths that are NOT sorted by id
+ * (the reference's sweep is insensitive to the order of a group's steps, abacus.rs:727-742).  Path lengths are pansyn-v1's. */
+int pnx_set_csr_pansyn_rearranged(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights);
 
 /* dst reads the graph that is resident in src -- the same ItemTable in HBM, no copy -- with its own
  * stream, index, counters and results.  Two contexts on one device let the short kernels of one
@@ -608,6 +614,11 @@ typedef struct {
     uint32_t n_band_passes;  /* (round 4) one-shot passes over the steps (K-band) enqueued on this upload */
     uint32_t band_route_failed; /* 1: a one-shot pass met a path that is not sorted by id; this upload takes the path rows */
     uint64_t n_rows_q_passes; /* (round 4) passes over path rows that took the four-rows-per-load kernel, since pnx_init */
+    uint32_t n_spilled_last; /* (round 5) steps the one-shot pass settled last found outside the band they were dealt to (paths that
+                                are not sorted by id) and added through its spill list; clipped at 2^20 per rank under a communicator */
+    uint32_t band_splits;    /* (round 5) workgroups per band of the one-shot pass enqueued last (> 1: a small graph, the visiting
+                                order is shared out) */
+    uint64_t n_spilled_total;/* (round 5) ... summed over the settled one-shot passes of this upload */
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

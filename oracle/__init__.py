@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
         L.pansyn_node_thr.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.pansyn_generate.restype = C.c_int64
         L.pansyn_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(u64p), u64p]
+        L.pansyn_rearrange.restype = None
+        L.pansyn_rearrange.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p]
         _lib = L
     return _lib
 
@@ -424,4 +426,13 @@ def pansyn(seed: int, n_nodes: int, n_paths: int):
     lib().orc_free(ptr)
     lens = np.zeros(n_nodes + 1, dtype=np.uint32)
     lib().pansyn_node_lens(seed, n_nodes, _p(lens, C.c_uint32))
+    return items, pre, lens
+
+
+def pansyn_rearranged(seed: int, n_nodes: int, n_paths: int):
+    """pansyn-v1r: pansyn-v1 with 1 % of the 64-step blocks of every path reversed, 0.1 % replaced by a copy of an earlier
+    block and 0.05 % moved elsewhere in the id space (paths that are not sorted by id)."""
+    items, pre, lens = pansyn(seed, n_nodes, n_paths)
+    items = np.ascontiguousarray(items)
+    lib().pansyn_rearrange(seed, n_nodes, n_paths, _p(items, C.c_uint64), _p(pre, C.c_uint64))
     return items, pre, lens

@@ -2416,3 +2416,38 @@ int64_t pansyn_generate(uint64_t seed, uint64_t n_nodes, uint64_t n_paths, uint6
     *items_out = items.v ? items.v : xmalloc(8);
     return (int64_t)items.n;
 }
+
+/* pansyn-v1r: the paths of pansyn-v1 REARRANGED, position by position, the way real pangenome paths stray from the order of
+ * the ids -- a model of inversions, duplications and translocations, not of any reference function (the reference's sweep,
+ * abacus.rs:727-742, does not care in which order a group's steps come).  A path is taken in blocks of 64 steps; block B of
+ * path p draws r = h mod 10000, h = splitmix64(splitmix64(key(seed, 8) + p) + B), and (the first and the last block of a
+ * path stay as they are)
+ *   r < 100         the block is reversed in place                                  (1 %: a local inversion)
+ *   100 <= r < 110  the block becomes a copy of block (h >> 20) mod B of the same path  (0.1 %: a jump back, a duplication)
+ *   110 <= r < 115  every id of the block is moved by 1 + (h >> 24) mod (n_nodes - 1), wrapping round  (0.05 %: a translocation)
+ * Copies are taken from the path as pansyn-v1 made it.  Path lengths do not change. */
+void pansyn_rearrange(uint64_t seed, uint64_t n_nodes, uint64_t n_paths, uint64_t *items, const uint64_t *prefsum) {
+    const uint64_t k8 = pansyn_key(seed, 8);
+    for (uint64_t p = 0; p < n_paths; p++) {
+        const uint64_t s0 = prefsum[p], len = prefsum[p + 1] - s0;
+        if (len == 0) continue;
+        const uint64_t n_blocks = (len + 63) / 64;
+        const uint64_t kp = pansyn_splitmix64(k8 + p);
+        uint64_t *orig = xmalloc(len * sizeof *orig);
+        memcpy(orig, items + s0, len * sizeof *orig);
+        for (uint64_t B = 1; B + 1 < n_blocks; B++) {
+            const uint64_t h = pansyn_splitmix64(kp + B), r = h % 10000;
+            const uint64_t b0 = B * 64, bl = len - b0 < 64 ? len - b0 : 64;
+            if (r < 100) {
+                for (uint64_t j = 0; j < bl; j++) items[s0 + b0 + j] = orig[b0 + bl - 1 - j];
+            } else if (r < 110) {
+                const uint64_t src = ((h >> 20) % B) * 64;
+                for (uint64_t j = 0; j < bl; j++) items[s0 + b0 + j] = orig[src + j];
+            } else if (r < 115 && n_nodes > 1) {
+                const uint64_t off = 1 + (h >> 24) % (n_nodes - 1);
+                for (uint64_t j = 0; j < bl; j++) items[s0 + b0 + j] = (orig[b0 + j] - 1 + off) % n_nodes + 1;
+            }
+        }
+        free(orig);
+    }
+}

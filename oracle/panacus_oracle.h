@@ -165,6 +165,9 @@ uint64_t pansyn_node_thr(uint64_t seed, uint64_t i, uint64_t n_paths);
 /* Generates the CSR (u64 items like the reference ItemTable).  *items malloc'ed. */
 int64_t pansyn_generate(uint64_t seed, uint64_t n_nodes, uint64_t n_paths, uint64_t **items,
                         uint64_t *prefsum /* n_paths+1 */);
+/* pansyn-v1r: the same paths rearranged in place -- 1 % of the 64-step blocks reversed, 0.1 % replaced by a copy of an earlier
+ * block of the path, 0.05 % moved elsewhere in the id space (see the definition in panacus_oracle.c) */
+void pansyn_rearrange(uint64_t seed, uint64_t n_nodes, uint64_t n_paths, uint64_t *items, const uint64_t *prefsum);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_csr_pansyn_shard", "pnx_set_exclude",
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_csr_pansyn_shard", "pnx_set_csr_pansyn_rearranged", "pnx_set_exclude",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued", "pnx_hist_enqueued_on",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",
@@ -48,7 +48,8 @@ class PnxInfo(C.Structure):
                 ("n_run_paths", C.c_uint32), ("n_scatter_paths", C.c_uint32), ("n_runs", C.c_uint64),
                 ("n_reruns", C.c_uint64), ("n_sorted_paths", C.c_uint32), ("rows_tile_major", C.c_uint32),
                 ("n_rows", C.c_uint64), ("n_rows_in_order", C.c_uint64), ("n_growth_table_builds", C.c_uint64),
-                ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32), ("n_rows_q_passes", C.c_uint64)]
+                ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32), ("n_rows_q_passes", C.c_uint64),
+                ("n_spilled_last", C.c_uint32), ("band_splits", C.c_uint32), ("n_spilled_total", C.c_uint64)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)
@@ -123,6 +124,7 @@ def load() -> C.CDLL:
     L.pnx_set_csr_keyed.argtypes = [vp, u32p, u64p, C.c_uint32, C.c_uint32, u32p, u8p, u64p]
     L.pnx_set_csr_pansyn.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_csr_pansyn_shard.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
+    L.pnx_set_csr_pansyn_rearranged.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]
     L.pnx_set_exclude.argtypes = [vp, u8p]
     L.pnx_prepare.argtypes = [vp]
     L.pnx_gfa_text_upload.argtypes = [vp, C.c_char_p, C.c_uint64]
@@ -331,6 +333,11 @@ class Context:
 
     def set_csr_pansyn(self, seed, n_nodes, n_paths, with_weights=False):
         self._ck(self._L.pnx_set_csr_pansyn(self._h, seed, n_nodes, n_paths, int(with_weights)))
+        self.n_items = n_nodes
+
+    def set_csr_pansyn_rearranged(self, seed, n_nodes, n_paths, with_weights=False):
+        """pnx_set_csr_pansyn_rearranged: pansyn-v1r, paths that are not sorted by id (inversions, jumps back, translocations)"""
+        self._ck(self._L.pnx_set_csr_pansyn_rearranged(self._h, seed, n_nodes, n_paths, int(with_weights)))
         self.n_items = n_nodes
 
     def set_csr_pansyn_shard(self, seed, node_lo, n_nodes, n_paths, with_weights=False):

@@ -17,12 +17,33 @@
 //                  CW bitmaps in visiting order and folds finished groups into its counters (tile_counters.hpp).  The
 //                  tail of a tile -- coverage vector, histogram bins -- is the one the rows kernel has.
 //
-// Exactness does not rest on the search: the segments of a path partition its steps (edge positions are checked to be
-// monotone), every step is checked against the band it was dealt to, and a single step outside -- a path that is not
-// sorted by id -- raises flags[5]: the pass is void and the host runs it again over path rows, which serve any path
-// (pnx_api.hip: settle_oldest).  Steps ORed from positions of the SAME path beyond a segment's ends (16-byte alignment)
-// are never foreign facts: positions outside the segment are masked.
+//   k_band_tail    what the pass ends with: the steps that were NOT in the band they were dealt to (below), then the sum of
+//                  the histogram replicas, handed to the host.
+//
+// Exactness does not rest on the search, nor on the paths being sorted.  AbacusByTotal::coverage is insensitive to the order
+// of the steps inside a group (abacus.rs:727-742: last[sid] != group): all that has to hold is that every step of every
+// path is seen.  The segments of a path are the intervals between consecutive edge positions, whatever the searches
+// returned: a chain of positions from 0 to the path's length covers every step at least once (twice does no harm: a
+// presence bit is idempotent).  Every step is checked against the band it was dealt to; a step outside -- a local inversion
+// across a band edge, a back-jump, a duplication elsewhere in the graph -- is SPILLED: (group, id) goes to a list in HBM
+// (one wave-aggregated atomic per 256 steps that hold any), and the counters of the pass are those of the in-band steps.
+// k_band_tail takes the list 64 records at a time: the records of one (group, band) cell -- consecutive steps of a path
+// that left its band usually land in ONE cell -- go into a bitmap of that band; the wave streams the segments the group's
+// paths have in that band and clears what it meets (those visits were counted in-band); what is left is deduplicated
+// across the whole list by a hash set in HBM and added: coverage vector +1, histogram bin moved, presence bit set.  Spills
+// cost what they read: a cell is a few thousand steps.  The list is bounded and so is the volume of the scans; beyond
+// either bound (a graph whose paths do not follow the ids at all) flags[5] is raised: the pass is void and the host runs
+// it again over path rows, which serve any path (pnx_api.hip: settle_oldest).  Steps ORed from positions of the SAME
+// path beyond a segment's ends (16-byte alignment) are never foreign facts: positions outside the segment are masked.
+//
+// Small graphs (a node-range shard of a multi-GPU run): a band per workgroup would leave most of the chip idle, so the
+// visiting order is cut at group boundaries into `splits`, one workgroup per (band, split); the counters of a band's
+// splits meet in the coverage vector (atomic adds onto zeros) and the histogram is taken from it (kernels_hist.hip).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 #include "pnx_context.hpp"
 #include "tile_counters.hpp"
@@ -30,11 +51,26 @@
 namespace pnx {
 
 constexpr int BAND_CW = 4;                  // waves per workgroup = item tiles per band
-constexpr uint64_t BAND_UNSORTED = 1ull << 62;  // index entry: a probe of the search met steps out of order -- the path is not sorted
+constexpr uint32_t BAND_SHIFT = 13;         // log2 of the ids of a band (BAND_CW tiles of 2048)
+static_assert((uint32_t)BAND_CW * BLOCK_ITEMS == 1u << BAND_SHIFT, "a band is 2^BAND_SHIFT ids");
 constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs through the ids downwards
+constexpr int BAND_MAX_SPLITS = 16;
+constexpr uint32_t BAND_TAIL_GRID = 256;    // workgroups of k_band_tail (4 waves each; a wave takes 64 spill records at a time)         // workgroups that share a band (each takes a range of the visiting order)
+
+// the visiting order cut at group boundaries: split s takes the entries [k[s], k[s + 1])
+struct BandSplits {
+    uint32_t n;
+    uint32_t k[BAND_MAX_SPLITS + 1];
+};
+
+// where the steps go that were not in the band they were dealt to: rec[i] = (group << 32) | id, i < min(flags[6], cap)
+struct BandSpill {
+    unsigned long long *rec;
+    uint32_t cap;
+};
 
 // first j in [0, len] with key(j) >= X, key = id (ascending path) or ~id (descending); keys are non-decreasing on a
-// sorted path -- on any other the result is some position in [0, len] and the coverage kernel finds out.
+// sorted path -- on any other the result is some position in [0, len]: the steps it deals to the wrong band are spilled.
 // A probe is one aligned 64-byte sector = 16 steps (four 16-byte loads, one latency): either the sector holds the
 // crossing, or its nearest step becomes one of the two points of the next secant guess (the path's ends at first: ids
 // along a pangenome path are close to evenly spread, so the first guess is off by a few thousand steps of millions, the
@@ -43,7 +79,7 @@ constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs throug
 // interpolation + binary search (0.058 -> 0.03 ms on 10 M items x 256 paths).
 template <bool DESC>
 __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ items, uint64_t ps, uint64_t len, uint32_t X, uint32_t ka,
-                                                   uint32_t kz, bool &unsorted) {
+                                                   uint32_t kz) {
     if (ka >= X) return 0;
     if (kz < X) return len;
     uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
@@ -61,15 +97,13 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
         // steps of the sector that belong to the path and lie inside the bracket: [i0, i1]
         const uint64_t first = ps + lo + 1, last = ps + hi - 1;  // absolute; first <= ps + g <= last
         const uint32_t i0 = first > a0 ? (uint32_t)(first - a0) : 0u, i1 = last - a0 < 15 ? (uint32_t)(last - a0) : 15u;
-        uint32_t below = 0, k_first = 0, k_last = 0, prev = 0;
+        uint32_t below = 0, k_first = 0, k_last = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i) {
             const uint32_t key = DESC ? ~w[i] : w[i];
             if (i == i0) k_first = key;
             if (i == i1) k_last = key;
             below += (i >= i0 && i <= i1 && key < X) ? 1u : 0u;
-            unsorted |= i > i0 && i <= i1 && key < prev;  // the sector in hand says the path is not sorted: no need to read it all to find out
-            prev = key;
         }
         const uint32_t n = i1 - i0 + 1;
         if (below != 0 && below != n) return a0 + i0 + below - ps;  // the crossing lies in the sector
@@ -91,13 +125,27 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
 // bidx[k * (n_bands + 1) + e] = absolute step position where entry k's path crosses band edge e (id e * band_items), e = 0 ..
 // n_bands, | BAND_DESC for a descending path: band b of an ascending path is [bidx[k][b], bidx[k][b+1]), of a descending one
 // [bidx[k][b+1], bidx[k][b]).  The lanes of a wave take consecutive edges of ONE path: their probes stay within a few
-// hundred KB of each other (one or two translation entries per round of probes instead of 64).  (Also clears the pass's counter block: a memset in front is one more kernel in the chain.)
+// hundred KB of each other (one or two translation entries per round of probes instead of 64).  (Also clears the pass's
+// counter block -- a memset in front is one more kernel in the chain --, lays out where the entries of every group begin
+// (group_first, n_groups + 1: the tail kernel walks the paths of a group), and, for a pass whose bands are shared by several
+// workgroups, zeroes the coverage vector they add to.)
+// Which way a path runs: by the majority of five evenly spaced steps, its two ends deciding a tie -- a first or last step
+// out of place does not turn the whole path around.
 __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
-                                                    const uint32_t *__restrict__ ord_path, uint32_t n_ordered, uint32_t n_bands,
-                                                    uint32_t band_items, unsigned long long *__restrict__ bidx,
-                                                    uint4 *__restrict__ block16, uint32_t n_block16) {
+                                                    const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
+                                                    uint32_t n_ordered, uint32_t n_groups, uint32_t n_bands, uint32_t band_items,
+                                                    unsigned long long *__restrict__ bidx, uint32_t *__restrict__ group_first,
+                                                    uint4 *__restrict__ block16, uint32_t n_block16, uint4 *__restrict__ zero16,
+                                                    uint64_t n_zero16) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t q = tid; q < n_block16; q += (uint64_t)gridDim.x * blockDim.x) block16[q] = make_uint4(0, 0, 0, 0);
+    const uint64_t n_threads = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = tid; q < n_block16; q += n_threads) block16[q] = make_uint4(0, 0, 0, 0);
+    for (uint64_t q = tid; q < n_zero16; q += n_threads) zero16[q] = make_uint4(0, 0, 0, 0);
+    if (tid < n_ordered) {
+        const uint32_t g = ord_group[tid];
+        if (tid == 0 || ord_group[tid - 1] != g) group_first[g] = (uint32_t)tid;
+        if (tid == 0) group_first[n_groups] = n_ordered;
+    }
     const uint64_t total = (uint64_t)(n_bands + 1) * n_ordered;
     if (tid >= total) return;
     const uint32_t e = (uint32_t)(tid % (n_bands + 1)), k = (uint32_t)(tid / (n_bands + 1));
@@ -108,26 +156,44 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         return;
     }
     const uint32_t a = items[ps], z = items[pe - 1];
-    const bool desc = a > z;
+    bool desc = a > z;
+    uint32_t ka_fix = 0xFFFFFFFFu, kz_fix = 0u;  // (keys of the inner samples: smallest, largest)
+    if (len >= 16) {
+        const uint32_t q1 = items[ps + len / 4], q2 = items[ps + len / 2], q3 = items[ps + len / 2 + len / 4];
+        const int down = (int)(a > q1) + (int)(q1 > q2) + (int)(q2 > q3) + (int)(q3 > z);
+        const int up = (int)(a < q1) + (int)(q1 < q2) + (int)(q2 < q3) + (int)(q3 < z);
+        if (down != up) desc = down > up;
+        const uint32_t k1 = desc ? ~q1 : q1, k2 = desc ? ~q2 : q2, k3 = desc ? ~q3 : q3;
+        ka_fix = k1 < k2 ? (k1 < k3 ? k1 : k3) : (k2 < k3 ? k2 : k3);
+        kz_fix = k1 > k2 ? (k1 > k3 ? k1 : k3) : (k2 > k3 ? k2 : k3);
+    }
+    // the ends bracket the search; an end that is not where the rest of the path says (a first step from elsewhere, the path's
+    // start visited again at its end) would send every edge to that end, and with it every step out of its band: such an end is
+    // taken for "below / above everything" instead, and the search finds the edges inside
+    uint32_t ka = desc ? ~a : a, kz = desc ? ~z : z;
+    if (ka > ka_fix) ka = 0u;
+    if (kz < kz_fix) kz = 0xFFFFFFFFu;
     uint64_t j;
-    bool unsorted = false;
     if (e == 0) j = desc ? len : 0;
     else if (e == n_bands) j = desc ? 0 : len;
     else {
         const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ~a, ~z, unsorted) : band_edge_search<false>(items, ps, len, x, a, z, unsorted);
+        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz) : band_edge_search<false>(items, ps, len, x, ka, kz);
     }
-    bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull) | (unsorted ? BAND_UNSORTED : 0ull);
+    bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
 }
 
-// The coverage kernel.  flags[5] |= 1 when a step was found outside the band it was dealt to (or an index entry is
-// inconsistent): the result of the pass is void.
-template <int NPL, int CW, bool WRITE_M, int BAND_D>
+// The coverage kernel.  flags[6] += the steps found outside the band they were dealt to (spilled to sl.rec: k_band_tail);
+// flags[5] |= 1 when an index entry is inconsistent: the result of the pass is void.
+// SPLIT: the workgroups (band, split) of a band share its tiles: each adds its counters to the (zeroed) coverage vector and
+// leaves the histogram to K2.
+template <int NPL, int CW, bool WRITE_M, int BAND_D, bool SPLIT>
 __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restrict__ items, const unsigned long long *__restrict__ bidx,
                                                         const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
                                                         uint32_t *__restrict__ M, uint64_t row_words, uint32_t *__restrict__ countable,
-                                                        RowHist hs, uint32_t *__restrict__ flags) {
+                                                        RowHist hs, uint32_t *__restrict__ flags, uint32_t n_bands, BandSplits sp,
+                                                        BandSpill sl) {
     constexpr int BT = CW;  // tiles per band = waves per workgroup
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -136,11 +202,13 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t band = blockIdx.x;
+    const uint32_t band = SPLIT ? blockIdx.x % n_bands : blockIdx.x;
+    const uint32_t split = SPLIT ? blockIdx.x / n_bands : 0u;
+    const uint32_t k_lo = SPLIT ? sp.k[split] : 0u, k_hi = SPLIT ? sp.k[split + 1] : n_ordered;  // this workgroup's entries
     const uint32_t tile = band * BT + wave;
     const bool active = tile < n_tiles;  // the last band may hold fewer tiles; its spare waves still stream segments
     for (uint32_t i = threadIdx.x; i < 2 * CW * BT * 64; i += CW * 64) (&bm[0][0][0])[i] = 0;
-    if (hs.rep)
+    if (!SPLIT && hs.rep)
         for (uint32_t b = threadIdx.x; b <= hs.n_groups; b += CW * 64) sh_hist[b] = 0;
     __syncthreads();
     const uint32_t excl = active ? tile_exclusion_word(exclude, tile, lane, n_items) : 0u;
@@ -152,7 +220,7 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     TileCounters<NPL> tc;
     uint32_t acc = 0, cur_g = NONE;
-    bool bad = false, dead = false;
+    bool bad = false;
     auto flush = [&](uint32_t g) {
         const uint32_t x = acc & ~excl;
         acc = 0;
@@ -164,30 +232,24 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     uint64_t w_lo = 0;
     uint32_t w_len = 0, swin = NONE;  // swin: which window of 64 entries
     uint32_t w_g = NONE;              // ... and their groups: handed to the fold side when it reaches the window
-    const uint32_t n_edges = gridDim.x + 1;  // per entry: n_bands + 1 edge positions
+    const uint32_t n_edges = n_bands + 1;  // per entry: n_bands + 1 edge positions
     auto load_swin = [&](uint32_t win) {
         swin = win;
         const uint32_t k = win * 64u + lane;
         uint64_t a = 0, b = 0;
         w_g = NONE;
-        if (k < n_ordered) {
+        if (k >= k_lo && k < k_hi) {
             const unsigned long long *ek = bidx + (uint64_t)k * n_edges + band;
             a = ek[0];
             b = ek[1];
             w_g = ord_group[k];
         }
-        const bool desc = (a & BAND_DESC) != 0;
         if (((a ^ b) & BAND_DESC) != 0) bad = true;
-        // the index already knows of a path that is not sorted: the pass is void, and this workgroup stops reading (every wave
-        // of the workgroup loads the same window and leaves after the same fold)
-        if (__ballot(((a | b) & BAND_UNSORTED) != 0)) bad = dead = true;
-        a &= ~(BAND_DESC | BAND_UNSORTED);
-        b &= ~(BAND_DESC | BAND_UNSORTED);
-        uint64_t lo = desc ? b : a, hi = desc ? a : b;
-        if (hi < lo) {  // the searches of a path that is not sorted
-            bad = true;
-            hi = lo;
-        }
+        a &= ~BAND_DESC;
+        b &= ~BAND_DESC;
+        // the interval between the two edge positions, whichever comes first: the intervals of a path cover all its steps
+        // even where the searches of a path that is not sorted returned positions out of order
+        const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
         uint64_t len = hi - lo;
         if (len >= (1ull << 29)) {  // (a buffer descriptor holds 2^32 bytes)
             bad = true;
@@ -208,27 +270,30 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         __amdgpu_buffer_rsrc_t rs;
         const uint32_t *base;
         uint32_t head, nal;  // steps of the first load before the segment; head + length
+        uint32_t g;          // the group of the segment's entry (wave-uniform): what a spilled step is recorded under
     };
-    auto make_seg = [&](uint64_t lo, uint32_t len) {
+    auto make_seg = [&](uint64_t lo, uint32_t len, uint32_t g) {
         const uint32_t *base = items + (lo & ~3ull);
         const uint32_t head = len ? (uint32_t)(lo & 3ull) : 0u, nal = head + len;
         const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
         const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
         void *bp = (void *)(((uintptr_t)b_hi << 32) | b_lo);
-        return Seg{__builtin_amdgcn_make_buffer_rsrc(bp, 0, (int)__builtin_amdgcn_readfirstlane(nal * 4u), 0x00020000), (const uint32_t *)bp, head, nal};
+        return Seg{__builtin_amdgcn_make_buffer_rsrc(bp, 0, (int)__builtin_amdgcn_readfirstlane(nal * 4u), 0x00020000), (const uint32_t *)bp, head, nal, g};
     };
     auto seg_of = [&](uint32_t batch) {
         const uint32_t k = batch * CW + wave;
         if ((k >> 6) != swin) load_swin(k >> 6);  // (every wave: the fold needs the window's groups whether or not this wave has an entry)
-        if (k >= n_ordered) return make_seg(0, 0);
+        if (k < k_lo || k >= k_hi) return make_seg(0, 0, NONE);
         const uint32_t l = k & 63u;
         const uint32_t lo_l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_lo, l);
         const uint32_t lo_h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_lo >> 32), l);
         const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)w_len, l);
-        return make_seg(((uint64_t)lo_h << 32) | lo_l, len);
+        return make_seg(((uint64_t)lo_h << 32) | lo_l, len, (uint32_t)__builtin_amdgcn_readlane((int)w_g, l));
     };
 
-    const uint32_t n_batches = (n_ordered + CW - 1) / CW;
+    // batches of CW entries, numbered over the whole visiting order (64 is a multiple of CW: a batch never straddles two
+    // windows); a split's first and last batch may hold entries of its neighbours: they are empty here
+    const uint32_t batch_lo = k_lo / CW, batch_hi = (k_hi + CW - 1) / CW;
     auto issue = [&](const Seg &s, uint32_t r0, int u) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s.rs, lane * 16u + (uint32_t)u * 1024u, r0 * 4u, /*nt*/ 2));
     };
@@ -238,13 +303,36 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         const uint32_t q = r0 + (uint32_t)u * 256u + lane * 4u - s.head;  // position in the segment (wraps before it)
         const uint32_t len = s.nal - s.head;
         const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
+        uint32_t out = 0;  // which of the four steps lie outside the band
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t id = ids[e];
             const bool valid = q + (uint32_t)e < len;
             const bool inb = id - lo_id < width;
             if (valid && inb) atomicOr(&map[(((id >> 11) & (uint32_t)(BT - 1)) << 6) | (id & 63u)], 1u << ((id >> 6) & 31u));
-            bad |= valid && !inb;
+            out |= (valid && !inb) ? 1u << e : 0u;
+        }
+        if (__builtin_expect(__ballot(out != 0) != 0ull, 0)) {
+            // spilled: one slot range of the list per wave and load (a path that leaves its band does so for a stretch of steps)
+            const uint32_t n_mine = (uint32_t)__builtin_popcount(out);
+            uint32_t incl = n_mine;  // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += t;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(flags + 6, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+            uint32_t at = base + incl - n_mine;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((out >> e) & 1u) {
+                    if (at < sl.cap) sl.rec[at] = ((unsigned long long)s.g << 32) | ids[e];
+                    ++at;
+                }
+            }
         }
     };
     auto fold = [&](uint32_t batch) {
@@ -262,8 +350,9 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         }
 #pragma unroll
         for (int i = 0; i < CW; ++i) {
-            if (k0 + (uint32_t)i < n_ordered) {
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)f_g, (k0 + (uint32_t)i) & 63u);
+            const uint32_t k = k0 + (uint32_t)i;
+            if (k >= k_lo && k < k_hi) {
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)f_g, k & 63u);
                 if (g != cur_g) {
                     if (cur_g != NONE) flush(cur_g);
                     cur_g = g;
@@ -273,9 +362,9 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         }
     };
 
-    if (n_batches) {
-        Seg cur = seg_of(0);
-        uint32_t c_r0 = 0, c_batch = 0;
+    if (batch_lo < batch_hi) {
+        Seg cur = seg_of(batch_lo);
+        uint32_t c_r0 = 0, c_batch = batch_lo;
         // one group of BAND_D loads per lane: consume `in` slot by slot, the next group's loads going out into `out` as the
         // slots are taken -- BAND_D loads in flight throughout.  (Two register sets that swap roles: with one set refilled
         // in place the compiler parks the new loads elsewhere and copies them back at the loop head, i.e. waits for them.)
@@ -285,7 +374,7 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
             if (n_r0 >= cur.nal) {  // the segment ends with this group of loads
                 n_batch = c_batch + 1;
                 n_r0 = 0;
-                nxt = n_batch < n_batches ? seg_of(n_batch) : make_seg(0, 0);
+                nxt = n_batch < batch_hi ? seg_of(n_batch) : make_seg(0, 0, NONE);
             }
             uint32_t *map = &bm[c_batch & 1u][wave][0];
 #pragma unroll
@@ -305,18 +394,33 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         u32x4 bufA[BAND_D], bufB[BAND_D];
 #pragma unroll
         for (int u = 0; u < BAND_D; ++u) bufA[u] = issue(cur, 0, u);
-        // (`dead` changes only where a wave loads a window: before the loop -- every wave at once -- and in the group that ends a
-        // segment, i.e. the one with the barrier and the fold of that batch: the waves of a workgroup leave after the same barrier)
-        while (!dead) {
+        while (true) {
             group(bufA, bufB);
-            if (c_batch >= n_batches || dead) break;
+            if (c_batch >= batch_hi) break;
             group(bufB, bufA);
-            if (c_batch >= n_batches || dead) break;
+            if (c_batch >= batch_hi) break;
         }
         if (cur_g != NONE) flush(cur_g);
     }
     tc.settle();
     if (__ballot(bad) && lane == 0) atomicOr(flags + 5, 1u);
+    if (SPLIT) {
+        // the band's other workgroups hold the counts of the other groups: they meet in the coverage vector
+        if (active) {
+            for (uint32_t b = 0; b < 32; ++b) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) v |= ((tc.cnt[k] >> b) & 1u) << k;
+                const uint64_t node = (uint64_t)tile * BLOCK_ITEMS + b * 64u + lane;
+                if (node == 0) {
+                    if (split == 0) countable[0] = 0xFFFFFFFFu;  // the reference's reserved element (abacus.rs:549-551)
+                } else if (node <= n_items && v) {
+                    atomicAdd(countable + node, v);
+                }
+            }
+        }
+        return;
+    }
     if (active) tile_tail<NPL>(tc.cnt, tile, lane, n_items, countable, hs, sh_hist, 0u, 32u, 0xFFFFFFFFu);
     if (hs.rep) {
         __syncthreads();
@@ -324,51 +428,289 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     }
 }
 
-// The shapes the band route is worth it for: enough bands to fill the chip, segments long enough to stream, an index
-// of reasonable size.  (Anything else -- and any graph whose paths turn out not to be sorted -- takes the path rows.)
+// ------------------------------------------------------------------------------------------
+// the tail of a one-shot pass: spilled steps, then the histogram handed over
+// ------------------------------------------------------------------------------------------
+struct BandTail {
+    const uint32_t *items;
+    const unsigned long long *bidx;
+    const uint32_t *group_first;  // n_groups + 1: the entries of group g are [group_first[g], group_first[g + 1])
+    const uint8_t *exclude;
+    uint32_t n_edges, n_items;
+    BandSpill sl;
+    unsigned long long *hset;  // (generation << 56) | (group << 32) | id: the pairs this pass has added
+    uint32_t hmask, gen;
+    uint32_t *countable;
+    uint32_t *M;  // nullptr: the pass writes no presence matrix
+    uint64_t row_words;
+    RowHist hs;                // rep == nullptr: K2 takes the histogram from the coverage vector afterwards
+    unsigned long long *hist;  // the pass's histogram in HBM
+    uint32_t *flags;
+    uint32_t *host_block;      // [flags u32[8] | hist] in the ticket's pinned memory, or nullptr
+    uint32_t scan_budget;      // steps the spill scans may read in all, in units of 1024
+};
+
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+typedef __attribute__((address_space(1))) unsigned long long g_u64;
+__device__ static inline uint32_t agent_load(const uint32_t *p) {
+    return __hip_atomic_load((g_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static inline unsigned long long agent_load(const unsigned long long *p) {
+    return __hip_atomic_load((g_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// true: (g, id) was not in the set of this pass.  Slots of older passes (another generation) count as empty; the table is
+// at most half full (2 x the capacity of the spill list), so a probe sequence ends.  The compare-and-swap decides: a load
+// that returned an outdated slot costs one more round, never a wrong answer (a slot changes once per pass).
+__device__ static inline bool spill_set_insert(unsigned long long *slots, uint32_t mask, uint32_t gen, uint32_t g, uint32_t id) {
+    const unsigned long long key = ((unsigned long long)gen << 56) | ((unsigned long long)g << 32) | id;
+    unsigned long long z = key * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
+    uint32_t h = (uint32_t)(z >> 32) & mask;
+    for (;;) {
+        const unsigned long long cur = agent_load(slots + h);
+        if (cur == key) return false;
+        if ((uint32_t)(cur >> 56) != gen) {
+            const unsigned long long old = atomicCAS(slots + h, cur, key);
+            if (old == cur) return true;
+            if (old == key) return false;
+            if ((uint32_t)(old >> 56) != gen) continue;
+        }
+        h = (h + 1u) & mask;
+    }
+}
+
+// One wave per 64 records of the spill list.  Every word that several workgroups touch -- flags, the set, the coverage
+// vector, the histogram replicas, M -- is touched by device-scope atomics and agent-scope loads only (the L2s of the
+// XCDs are not coherent with each other); the workgroup that arrives last adds the replicas up (the others have
+// released what they wrote before they took their ticket).
+__global__ __launch_bounds__(256) void k_band_tail(BandTail a) {
+    __shared__ uint32_t bmp_all[4][256];  // per wave: the 8192 ids of one band
+    __shared__ uint32_t s_last;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *bmp = bmp_all[wave];
+    uint32_t n = agent_load(a.flags + 6);
+    if (n > a.sl.cap) {  // the list did not hold them all: the pass is void
+        if (threadIdx.x == 0) atomicOr(a.flags + 5, 2u);
+        n = 0;
+    }
+    const uint32_t n_chunks = (n + 63u) / 64u;
+    bool over = false;
+    for (uint32_t c = blockIdx.x * 4u + wave; c < n_chunks && !over; c += gridDim.x * 4u) {
+        const uint32_t i = c * 64u + lane;
+        const bool valid = i < n;
+        const unsigned long long rec = valid ? a.sl.rec[i] : 0ull;
+        const uint32_t g = (uint32_t)(rec >> 32), id = (uint32_t)rec;
+        const uint32_t b = id >> BAND_SHIFT;
+        const uint32_t wi = (id & ((1u << BAND_SHIFT) - 1u)) >> 5, bit = 1u << (id & 31u);
+        unsigned long long todo = __ballot(valid && id >= 1u && id <= a.n_items);
+        while (todo && !over) {
+            const int l0 = __ffsll((long long)todo) - 1;
+            const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)g, l0), lb = (uint32_t)__builtin_amdgcn_readlane((int)b, l0);
+            const bool mine = ((todo >> lane) & 1ull) != 0 && g == lg && b == lb;
+            todo &= ~__ballot(mine);
+            // the records of the cell (lg, lb) as a bitmap of the band
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bmp[w * 64 + lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (mine) atomicOr(&bmp[wi], bit);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // what the group's paths visit IN the band was counted by the coverage kernel: clear it
+            const uint32_t k0 = a.group_first[lg], k1 = a.group_first[lg + 1];
+            uint32_t vol = 0;
+            for (uint32_t k = k0; k < k1; ++k) {
+                const unsigned long long *ek = a.bidx + (uint64_t)k * a.n_edges + lb;
+                const uint64_t e0 = ek[0] & ~BAND_DESC, e1 = ek[1] & ~BAND_DESC;
+                const uint64_t lo = e0 < e1 ? e0 : e1, hi = e0 < e1 ? e1 : e0;
+                vol += (uint32_t)((hi - lo + 1023u) >> 10);
+                for (uint64_t pos = (lo & ~3ull) + lane * 4u; pos < hi; pos += 256u) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(a.items + pos);
+                    const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint64_t q = pos + (uint64_t)e;
+                        const uint32_t x = ids[e];
+                        if (q >= lo && q < hi && (x >> BAND_SHIFT) == lb) {
+                            const uint32_t xw = (x & ((1u << BAND_SHIFT) - 1u)) >> 5, xb = 1u << (x & 31u);
+                            if (bmp[xw] & xb) atomicAnd(&bmp[xw], ~xb);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // what is left was visited only out of band: one lane per id takes it
+            bool won = false;
+            if (mine) won = (atomicAnd(&bmp[wi], ~bit) & bit) != 0;
+            if (won && !(a.exclude && a.exclude[id]) && spill_set_insert(a.hset, a.hmask, a.gen, lg, id)) {
+                const uint32_t old = atomicAdd(a.countable + id, 1u);  // AbacusByTotal::coverage: one more group visits the item
+                if (a.hs.rep) {
+                    const unsigned long long w = a.hs.weights ? (unsigned long long)a.hs.weights[id] : 1ull;
+                    unsigned long long *rep = a.hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * (a.hs.n_groups + 1);
+                    atomicAdd(&rep[old], 0ull - w);
+                    atomicAdd(&rep[old + 1u], w);
+                }
+                if (a.M) atomicOr(a.M + (uint64_t)lg * a.row_words + (uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u), 1u << ((id >> 6) & 31u));
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the scans are bounded: a graph whose paths do not follow the ids is served by path rows
+            uint32_t seen = 0;
+            if (lane == 0) seen = atomicAdd(a.flags + 3, vol) + vol;
+            seen = (uint32_t)__builtin_amdgcn_readfirstlane(seen);
+            if (seen > a.scan_budget) {
+                if (lane == 0) atomicOr(a.flags + 5, 4u);
+                over = true;
+            }
+        }
+    }
+    // ---- the histogram is handed over: by workgroup 0 when the list was empty (every workgroup knows: the count was final
+    // when the kernel began), else by the last workgroup to arrive ----
+    if (n_chunks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = __hip_atomic_fetch_add((g_u32 *)(a.flags + 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (!s_last) return;
+    } else {
+        if (blockIdx.x != 0) return;
+        __syncthreads();  // (the flag of a list that overflowed, set above)
+    }
+    if (a.hs.rep) {
+        const uint32_t bins = a.hs.n_groups + 1u;
+        for (uint32_t bn = threadIdx.x; bn < bins; bn += blockDim.x) {
+            unsigned long long v[HIST_REPLICAS], sum = 0;  // all loads in flight before the first addition
+#pragma unroll
+            for (uint32_t r = 0; r < HIST_REPLICAS; ++r) v[r] = agent_load(a.hs.rep + (size_t)r * bins + bn);
+#pragma unroll
+            for (uint32_t r = 0; r < HIST_REPLICAS; ++r) sum += v[r];
+            a.hist[bn] = sum;
+            if (a.host_block) {
+                a.host_block[8 + 2 * bn] = (uint32_t)sum;
+                a.host_block[8 + 2 * bn + 1] = (uint32_t)(sum >> 32);
+            }
+        }
+    }
+    if (a.host_block && threadIdx.x < 8) a.host_block[threadIdx.x] = agent_load(a.flags + threadIdx.x);
+}
+
+// The shapes the band route is worth it for: enough bands (times the splits of the visiting order) to fill the chip,
+// segments long enough to stream, an index of reasonable size.  (Anything else -- and any graph whose paths stray from
+// the order of the ids by more than the spill list holds -- takes the path rows.)
+uint32_t band_route_splits(const pnx_ctx *ctx, uint32_t n_groups) {
+    constexpr uint32_t BT = BAND_CW;
+    const uint64_t n_bands = (ctx->n_blocks + BT - 1) / BT;
+    if (const char *e = getenv("PNX_BAND_SPLITS")) {  // measurement: a fixed number of splits
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= BAND_MAX_SPLITS) return (uint32_t)std::min<uint64_t>((uint64_t)v, n_groups ? n_groups : 1);
+    }
+    // ~4.75 workgroups of 4 waves per CU is what the chip holds of this kernel
+    const uint64_t want = (19ull * (uint64_t)ctx->prop.multiProcessorCount + 3) / 4;
+    uint64_t s = n_bands ? (want + n_bands - 1) / n_bands : 1;
+    if (n_bands >= 2ull * (uint64_t)ctx->prop.multiProcessorCount) s = 1;  // enough bands by themselves: one workgroup keeps a band's counters and adds the histogram itself
+    s = std::min<uint64_t>(s, BAND_MAX_SPLITS);
+    s = std::min<uint64_t>(s, n_groups ? n_groups : 1);
+    return (uint32_t)(s ? s : 1);
+}
+
 bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries) {
     constexpr uint32_t BT = BAND_CW;
     if (!n_entries || !ctx->n_steps || !ctx->n_paths) return false;
     const uint64_t n_bands = (ctx->n_blocks + BT - 1) / BT;
-    if (n_bands < 2ull * (uint64_t)ctx->prop.multiProcessorCount) return false;
+    if (n_bands * BAND_MAX_SPLITS < 2ull * (uint64_t)ctx->prop.multiProcessorCount) return false;
+    if (n_bands < 2ull * (uint64_t)ctx->prop.multiProcessorCount && n_entries < 2 * BAND_MAX_SPLITS) return false;  // (nothing to split)
     const uint64_t cells = n_bands * ctx->n_paths;
     if (ctx->n_steps / cells < 512) return false;
     if ((n_bands + 1) * n_entries * 8 > (256ull << 20)) return false;
     return true;
 }
 
+// the spill list and the set of added pairs: per context, made when the first one-shot pass is enqueued
+static int ensure_spill(pnx_ctx *ctx) {
+    uint64_t cap = ctx->n_steps / 128;
+    cap = std::max<uint64_t>(cap, 1ull << 14);
+    cap = std::min<uint64_t>(cap, 1ull << 25);
+    uint64_t slots = 1;
+    while (slots < 2 * cap) slots <<= 1;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_spill, cap * 8))) return rc;
+    ctx->spill_cap = (uint32_t)cap;
+    const bool fresh = ctx->d_spill_set.cap < slots * 8 || ctx->spill_slots != slots;
+    if ((rc = ensure(ctx, ctx->d_spill_set, slots * 8))) return rc;
+    ctx->spill_gen += 1;
+    if (fresh || ctx->spill_gen > 255u) {  // a new table, or the generations have come round: every slot is empty again
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_spill_set.p, 0, slots * 8, ctx->s_pre));
+        ctx->spill_gen = 1;
+    }
+    ctx->spill_slots = slots;
+    return PNX_OK;
+}
+
 template <int NPL>
-static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands) {
+static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, const BandSplits &sp) {
     Ticket *tk = ctx->cur;
     const RowHist hs{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
                      ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
     const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
+    const BandSpill sl{(unsigned long long *)ctx->d_spill.p, ctx->spill_cap};
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(n_bands), dim3(BAND_CW * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
+        hipLaunchKernelGGL(kern, dim3(n_bands * sp.n), dim3(BAND_CW * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
                            (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
-                           (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags);
+                           (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags,
+                           n_bands, sp, sl);
     };
     // 4 waves per band, 2 loads in flight per lane: measured best on 10 M items x 256 and x 1024 paths (0.64 / 2.45 ms; 4 in flight
     // 0.67 / 2.56, 8 in flight 0.72; 8 waves per band 0.70, 2 waves 0.71) -- with every workgroup resident at once the chip holds
     // ~19 waves per CU whatever the register count, and a deeper pipeline only adds loads beyond the ends of the segments
-    if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2>);
-    else go(k_band_cover<NPL, BAND_CW, false, 2>);
+    if (sp.n > 1) {
+        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, true>);
+        else go(k_band_cover<NPL, BAND_CW, false, 2, true>);
+    } else {
+        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, false>);
+        else go(k_band_cover<NPL, BAND_CW, false, 2, false>);
+    }
 }
 
-// phases 1 + 2 of a one-shot pass over the steps (the histogram phase is shared: launch_cover_pass)
+// phases 1 + 2 of a one-shot pass over the steps (its tail: launch_band_tail)
 int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     constexpr uint32_t BT = BAND_CW;
     Ticket *tk = ctx->cur;
     int rc;
     const uint32_t n_bands = (ctx->n_blocks + BT - 1) / BT;
     const uint64_t cells = (uint64_t)(n_bands + 1) * ctx->n_ordered;
-    if ((rc = ensure(ctx, tk->d_tile_idx_own, cells * 8))) return rc;
+    if ((rc = ensure(ctx, tk->d_tile_idx_own, cells * 8)) || (rc = ensure(ctx, tk->d_group_first, ((size_t)ctx->n_groups + 1) * 4)) ||
+        (rc = ensure_spill(ctx)))
+        return rc;
+    // the visiting order cut into splits of about as many entries each, at group boundaries
+    BandSplits sp{};
+    sp.n = ctx->band_splits ? ctx->band_splits : 1u;
+    {
+        const std::vector<uint32_t> &g = ctx->h_ord_group;
+        const uint32_t no = ctx->n_ordered;
+        sp.k[0] = 0;
+        for (uint32_t s = 1; s < sp.n; ++s) {
+            uint32_t k = (uint32_t)((uint64_t)no * s / sp.n);
+            while (k < no && k > 0 && g[k] == g[k - 1]) ++k;  // the first entry of the next group
+            sp.k[s] = k < sp.k[s - 1] ? sp.k[s - 1] : k;
+        }
+        sp.k[sp.n] = no;
+    }
     const bool phased = ctx->s_pre != ctx->s_main;
+    const uint64_t n_zero16 = sp.n > 1 ? ((uint64_t)ctx->n_items + 1 + 3) / 4 : 0;  // (the buffer is a multiple of 256 bytes)
     prof_begin(ctx, PNX_K_INDEX, ctx->s_pre);
-    hipLaunchKernelGGL(k_band_index, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->s_pre, (const uint32_t *)ctx->d_items.p,
-                       (const uint64_t *)ctx->d_path_off.p, (const uint32_t *)ctx->d_ord_path.p, ctx->n_ordered, n_bands,
-                       BT * BLOCK_ITEMS, (unsigned long long *)tk->d_tile_idx_own.p, (uint4 *)tk->d_block.p, (uint32_t)(tk->block_bytes / 16));
+    hipLaunchKernelGGL(k_band_index, dim3((unsigned)((std::max<uint64_t>(cells, ctx->n_ordered) + 255) / 256)), dim3(256), 0, ctx->s_pre,
+                       (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, (const uint32_t *)ctx->d_ord_path.p,
+                       (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
+                       (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
+                       (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     // (recorded on one stream as well where the closed forms' tables are derived by the two-kernel route: that derivation starts
@@ -380,12 +722,48 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     uint32_t bits = 1;  // planes needed to count up to n_groups inclusive
     while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;
     prof_begin(ctx, PNX_K_COVER, ctx->s_main);
-    if (bits <= 12) launch_band_cover_t<12>(ctx, write_m, n_bands);
-    else if (bits <= 24) launch_band_cover_t<24>(ctx, write_m, n_bands);
+    if (bits <= 12) launch_band_cover_t<12>(ctx, write_m, n_bands, sp);
+    else if (bits <= 24) launch_band_cover_t<24>(ctx, write_m, n_bands, sp);
     else {
         prof_end(ctx);
         return ctx->fail(PNX_ELIMIT, "more than 2^24-1 groups are not supported (got %u)", ctx->n_groups);
     }
+    prof_end(ctx);
+    PNX_HIP(ctx, hipGetLastError());
+    return PNX_OK;
+}
+
+// phase 3 of a one-shot pass: the spilled steps are added, then (a pass that added its histogram itself) the replicas are
+// summed and [flags | hist] handed to the host -- one kernel where the rows route has k_hist_publish
+int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
+    constexpr uint32_t BT = BAND_CW;
+    const uint32_t n_bands = (ctx->n_blocks + BT - 1) / BT;
+    // (multi-GPU: the all-reduce of the block follows this kernel, the copy to the host follows that)
+    const bool to_host = tk->hist_fused && tk->h_block_mapped && !(ctx->comm && ctx->comm_reduce_hist);
+    tk->host_written = to_host;
+    BandTail a{};
+    a.items = (const uint32_t *)ctx->d_items.p;
+    a.bidx = (const unsigned long long *)tk->d_tile_idx_own.p;
+    a.group_first = (const uint32_t *)tk->d_group_first.p;
+    a.exclude = ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : nullptr;
+    a.n_edges = n_bands + 1;
+    a.n_items = ctx->n_items;
+    a.sl = BandSpill{(unsigned long long *)ctx->d_spill.p, ctx->spill_cap};
+    a.hset = (unsigned long long *)ctx->d_spill_set.p;
+    a.hmask = (uint32_t)(ctx->spill_slots - 1);
+    a.gen = ctx->spill_gen;
+    a.countable = (uint32_t *)tk->d_countable.p;
+    a.M = write_m ? (uint32_t *)ctx->d_M.p : nullptr;
+    a.row_words = (uint64_t)ctx->n_blocks * BLOCK_WORDS;
+    a.hs = RowHist{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
+                   ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
+    a.hist = (unsigned long long *)tk->d_hist;
+    a.flags = tk->d_flags;
+    a.host_block = to_host ? (uint32_t *)tk->h_block_mapped : nullptr;
+    // the scans may read a quarter of what the pass itself reads (and 4 M steps -- microseconds -- whatever the size of the graph)
+    a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 4096 + 4096, 0xFFFFFFF0ull);
+    prof_begin(ctx, PNX_K_HIST, ctx->s_post);
+    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(256), 0, ctx->s_post, a);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;
@@ -402,8 +780,9 @@ void preload_band(unsigned what) {
     auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
     if (what & PNX_PRELOAD_PASS) {
         touch((const void *)k_band_index);
-        touch((const void *)k_band_cover<12, BAND_CW, false, 2>);
-        touch((const void *)k_band_cover<24, BAND_CW, false, 2>);
+        touch((const void *)k_band_cover<12, BAND_CW, false, 2, false>);
+        touch((const void *)k_band_cover<24, BAND_CW, false, 2, false>);
+        touch((const void *)k_band_tail);
     }
 }
 }  // namespace pnx

@@ -5,6 +5,8 @@
 // the definition is integer-only so host and device agree bit for bit (DESIGN.md,
 // "pansyn-v1").  This is the input of BASELINE.json configs 2-4 (10M nodes x 256..512
 // paths = 1..2 G steps), which is too large to ship through PCIe for every benchmark run.
+#include <vector>
+
 #include "pnx_context.hpp"
 
 namespace pnx {
@@ -152,6 +154,70 @@ __global__ __launch_bounds__(256) void k_pansyn_fill(uint64_t k5, const uint64_t
             ++pos;
         }
     }
+}
+
+// pansyn-v1r (the definition: DESIGN.md, "pansyn-v1r"): the paths of pansyn-v1 rearranged in blocks of 64
+// steps -- reversed in place (1 %), replaced by a copy of an earlier block of the same path (0.1 %), moved elsewhere in the id
+// space (0.05 %); the first and the last block of a path stay.  One wave per block, from the generated steps `src` into
+// `dst`.  What paths that are not sorted by id look like to the coverage pass: steps outside the band their position says.
+__global__ __launch_bounds__(256) void k_pansyn_rearrange(uint64_t k8, uint32_t n_nodes, uint32_t n_paths, const uint64_t *__restrict__ path_off,
+                                                          const uint64_t *__restrict__ blk_off, uint64_t n_blk_total,
+                                                          const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // global block number
+    const uint32_t lane = threadIdx.x & 63u;
+    if (w >= n_blk_total) return;
+    // which path: the last p with blk_off[p] <= w
+    uint32_t lo = 0, hi = n_paths;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (blk_off[mid] <= w) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t p = lo;
+    const uint64_t B = w - blk_off[p];
+    const uint64_t s0 = path_off[p], len = path_off[p + 1] - s0, n_blocks = (len + 63) / 64;
+    const uint64_t b0 = B * 64, bl = len - b0 < 64 ? len - b0 : 64;
+    if (lane >= bl) return;
+    uint64_t from = b0 + lane;
+    uint64_t off = 0;
+    if (B >= 1 && B + 1 < n_blocks) {
+        const uint64_t h = splitmix64(splitmix64(k8 + p) + B), r = h % 10000;
+        if (r < 100) from = b0 + bl - 1 - lane;
+        else if (r < 110) from = ((h >> 20) % B) * 64 + lane;
+        else if (r < 115 && n_nodes > 1) off = 1 + (h >> 24) % ((uint64_t)n_nodes - 1);
+    }
+    uint32_t id = src[s0 + from];
+    if (off) id = (uint32_t)(((uint64_t)id - 1 + off) % n_nodes) + 1u;
+    dst[s0 + b0 + lane] = id;
+}
+
+int pansyn_rearrange_device(pnx_ctx *ctx, uint64_t seed) {
+    const uint32_t P = ctx->n_paths;
+    const uint64_t S = ctx->n_steps;
+    if (!P || !S) return PNX_OK;
+    std::vector<uint64_t> blk((size_t)P + 1, 0);
+    for (uint32_t p = 0; p < P; ++p) blk[p + 1] = blk[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + 63) / 64;
+    const uint64_t n_blk = blk[P];
+    DevBuf d_blk, d_src;
+    int rc;
+    if ((rc = ensure(ctx, d_blk, ((size_t)P + 1) * 8)) || (rc = ensure(ctx, d_src, S * 4 + 64))) {
+        release(d_blk);
+        release(d_src);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_blk.p, blk.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_src.p, ctx->d_items.p, S * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && n_blk) {
+        const uint64_t grid = (n_blk * 64 + 255) / 256;
+        hipLaunchKernelGGL(k_pansyn_rearrange, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ps_key(seed, 8), ctx->n_items, P,
+                           (const uint64_t *)ctx->d_path_off.p, (const uint64_t *)d_blk.p, n_blk, (const uint32_t *)d_src.p, (uint32_t *)ctx->d_items.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(d_blk);
+    release(d_src);
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "pansyn (rearranged): %s", hipGetErrorString(e));
+    return PNX_OK;
 }
 
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights, uint64_t node_lo) {

@@ -99,6 +99,12 @@ int launch_cover_pass(pnx_ctx *ctx) {
     const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
     tk->hist_fused = rows && ctx->hist_in_cover && (size_t)ctx->n_groups + 1 <= HIST_FUSED_MAX_BINS;
+    ctx->band_splits = 1;
+    if (rows && ctx->pass_band) {
+        // a small graph: several workgroups share a band, their counters meet in the coverage vector and K2 takes the histogram
+        ctx->band_splits = band_route_splits(ctx, ctx->n_groups);
+        if (ctx->band_splits > 1) tk->hist_fused = false;
+    }
     const size_t rep_off = (tk->block_bytes + 255) & ~(size_t)255;
     if (tk->hist_fused) tk->block_bytes = rep_off + (size_t)HIST_REPLICAS * hist_bytes;
     tk->block_bytes = (tk->block_bytes + 15) & ~(size_t)15;
@@ -148,8 +154,10 @@ int launch_cover_pass(pnx_ctx *ctx) {
         PNX_HIP(ctx, hipStreamWaitEvent(ctx->s_post, tk->ev_cov, 0));
     }
 
-    // ---- phase 3 (s_post): the histogram of the coverage vector (K2, kernels_hist.hip)
-    if ((rc = launch_hist(ctx, tk))) return rc;
+    // ---- phase 3 (s_post): the histogram of the coverage vector (K2, kernels_hist.hip); a one-shot pass first adds the steps
+    // it spilled, and hands the histogram over in the same kernel if it added one itself
+    if (tk->band && (rc = launch_band_tail(ctx, tk, ctx->want_M))) return rc;
+    if (!(tk->band && tk->hist_fused) && (rc = launch_hist(ctx, tk))) return rc;
     ctx->M_valid = false;  // settled by the verification in pnx_api
     return PNX_OK;
 }

@@ -146,6 +146,8 @@ static void set_geometry(pnx_ctx *ctx) {
     ctx->rows_valid = false;
     ctx->band_failed = false;
     ctx->n_band_passes = 0;
+    ctx->n_spilled_total = 0;
+    ctx->n_spilled_last = 0;
 }
 
 // the ticket's pinned result block [flags u32[8] | hist (G+1) u64], before the pass is launched: its publishing kernel may
@@ -203,10 +205,11 @@ static int settle_oldest(pnx_ctx *ctx) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         PNX_HIP(ctx, hipEventSynchronize(t->done));
         prof_resolve(ctx, false);
-        if (t->band && t->h_flags[5] != 0) {
-            // the one-shot route met a path that is not sorted by id: the pass is void.  Path rows serve any path (and
-            // validate the ids on the way: an id outside 1..n_items also ends up here).  With a communicator the flags
-            // were reduced over all ranks, so every rank is here and the collectives stay matched.
+        // flags[5]: a one-shot pass (of this rank, or -- the flags are reduced with the histogram -- of any rank of the communicator)
+        // met paths that stray from the order of the ids by more than its spill list or its scan budget hold: the pass is void.
+        // Path rows serve any path (and validate the ids on the way: an id outside 1..n_items also ends up here).  Every rank
+        // sees the same reduced flag and runs again, whichever route its own pass took: the collectives stay matched.
+        if ((t->band || (ctx->comm && ctx->comm_reduce_hist)) && t->h_flags[5] != 0) {
             int rc = drain_streams(ctx);
             if (rc) return rc;
             ctx->band_failed = true;
@@ -227,6 +230,10 @@ static int settle_oldest(pnx_ctx *ctx) {
         const bool bad = need_build || (t->h_flags[1] != 0 && !used_m);
         if (t->h_flags[4] != 0) return ctx->fail(PNX_EHIP, "run index inconsistency (internal error)");
         if (!bad) {
+            if (t->band) {
+                ctx->n_spilled_last = t->h_flags[6];
+                ctx->n_spilled_total += t->h_flags[6];
+            }
             ctx->last_general_paths = t->h_flags[1];
             t->in_flight = false;
             ctx->tk_oldest = (ctx->tk_oldest + 1) % pnx_ctx::N_TICKETS;
@@ -355,7 +362,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_set})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -377,7 +384,7 @@ void pnx_free(pnx_ctx *ctx) {
         if (t.ev_pre) (void)hipEventDestroy(t.ev_pre);
         if (t.ev_cov) (void)hipEventDestroy(t.ev_cov);
         if (t.ev_reader) (void)hipEventDestroy(t.ev_reader);
-        for (DevBuf *b : {&t.d_block, &t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own})
+        for (DevBuf *b : {&t.d_block, &t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own, &t.d_group_first})
             release(*b);
     }
     if (ctx->stream_pre) (void)hipStreamDestroy(ctx->stream_pre);
@@ -775,6 +782,23 @@ int pnx_set_csr_pansyn_shard(pnx_ctx *ctx, uint64_t seed, uint64_t node_lo, uint
     begin_upload(ctx);
     drop_gfa_text(ctx);
     int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights, node_lo);
+    if (rc) return rc;
+    ctx->have_exclude = false;
+    ctx->relabeled = false;
+    set_geometry(ctx);
+    ctx->have_csr = true;
+    return PNX_OK;
+}
+
+int pnx_set_csr_pansyn_rearranged(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths, int with_weights) {
+    if (!ctx) return PNX_EINVAL;
+    if (n_nodes == 0 || n_paths == 0) return ctx->fail(PNX_EINVAL, "n_nodes and n_paths must be > 0");
+    if (n_nodes >= 0xFFFFFFFEu) return ctx->fail(PNX_ELIMIT, "n_nodes must be < 2^32-2");
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    begin_upload(ctx);
+    drop_gfa_text(ctx);
+    int rc = pansyn_generate_device(ctx, seed, n_nodes, n_paths, with_weights, 0);
+    if (rc == PNX_OK) rc = pansyn_rearrange_device(ctx, seed);
     if (rc) return rc;
     ctx->have_exclude = false;
     ctx->relabeled = false;
@@ -1290,6 +1314,9 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_band_passes = ctx->n_band_passes;
     out->band_route_failed = ctx->band_failed ? 1 : 0;
     out->n_rows_q_passes = ctx->n_rows_q_passes;
+    out->n_spilled_last = ctx->n_spilled_last;
+    out->band_splits = ctx->band_splits;
+    out->n_spilled_total = ctx->n_spilled_total;
     return PNX_OK;
 }
 

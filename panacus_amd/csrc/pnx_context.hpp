@@ -67,6 +67,7 @@ struct Ticket {
     // taken, while the coverage kernel of pass k runs): the order-aligned index arrays, the coverage
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
+    DevBuf d_group_first;  // one-shot route: n_groups + 1 u32, where the entries of every group begin in the visiting order
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
     bool pre_recorded = false;                       // ev_pre was recorded by this pass (a one-shot pass leaves it out where nothing waits for it)
     // rows route, up to HIST_FUSED_MAX_BINS bins: the coverage kernel adds the histogram itself, into HIST_REPLICAS copies at the
@@ -203,6 +204,14 @@ struct pnx_ctx {
     bool band_failed = false;    // a band pass found a path that is not sorted by id: this upload takes the rows from now on
     uint32_t n_band_passes = 0;  // band passes enqueued on this upload (the second sweep of a graph derives the rows)
     bool pass_band = false;      // the pass being enqueued takes the band route
+    uint32_t band_splits = 1;    // ... with this many workgroups per band (each takes a range of the visiting order)
+    // steps found outside the band they were dealt to (paths that are not sorted by id): the list of a pass, and the set of
+    // (group, id) pairs its tail has added -- slots carry the generation of the pass that wrote them, so no pass clears the set
+    pnx::DevBuf d_spill, d_spill_set;
+    uint32_t spill_cap = 0, spill_gen = 0;
+    uint64_t spill_slots = 0;
+    uint64_t n_spilled_total = 0;  // spilled steps of all settled passes of this upload
+    uint32_t n_spilled_last = 0;   // ... of the pass settled last
 
     // ---- run index: tile route for non-monotone paths (kernels_runs.hip) ----
     // path_class: 0 tile-monotone (K0 index), 1 not monotone & unclassified, 2 run route, 3 scatter route
@@ -360,6 +369,8 @@ int launch_rows_phases(pnx_ctx *ctx, bool write_m);    // phases 1 + 2 of a pass
 // kernels_band.hip
 bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries);  // is the one-shot route worth it for this shape?
 int launch_band_phases(pnx_ctx *ctx, bool write_m);            // phases 1 + 2 of a one-shot pass over the steps
+int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m);  // phase 3: spilled steps added, histogram handed over
+uint32_t band_route_splits(const pnx_ctx *ctx, uint32_t n_groups);  // workgroups per band for this shape
 // kernels_runs.hip (step-route module)
 int build_run_index(pnx_ctx *ctx);
 int sort_run_index(pnx_ctx *ctx);
@@ -411,5 +422,6 @@ int presence_to_caller_ids(pnx_ctx *ctx, const DevBuf &in, DevBuf &out);
 // pansyn.hip
 int pansyn_generate_device(pnx_ctx *ctx, uint64_t seed, uint32_t n_nodes, uint32_t n_paths,
                            int with_weights, uint64_t node_lo = 0);
+int pansyn_rearrange_device(pnx_ctx *ctx, uint64_t seed);  // pansyn-v1r: the resident pansyn-v1 paths rearranged in place
 
 }  // namespace pnx

@@ -1,7 +1,11 @@
 """The one-shot route (csrc/kernels_band.hip): steps -> coverage vector + histogram in ONE read of the ItemTable, for the
-first sweep of a graph whose paths are sorted by id -- against the CPU oracle (abacus.rs:719-787 restated), through the
-C ABI.  Integer work: bit-exact equality everywhere.  A path that is not sorted makes the pass void; the library then
-runs it again over path rows, and the caller sees the same numbers."""
+first sweep of a graph whose paths follow the order of the ids -- against the CPU oracle (abacus.rs:719-787 restated),
+through the C ABI.  Integer work: bit-exact equality everywhere.  Steps that are not where the order of the ids says
+(inversions, jumps back, duplications, translocations) are spilled and added by the pass's tail; only a graph whose paths
+do not follow the ids at all makes the pass void -- the library then runs it again over path rows, and the caller sees
+the same numbers."""
+import os
+
 import numpy as np
 import pytest
 
@@ -143,38 +147,179 @@ def test_band_route_fuzz(band, seed):
     assert ctx.info().n_reruns == reruns and (ctx.info().n_rows == 0 or len(items) == 0)   # (no steps at all: nothing to read once)
 
 
-def test_a_path_that_is_not_sorted_voids_the_pass_and_the_rows_take_over(band):
+def _check(ctx, items, pre, n, order, gid, G, lens=None, excl=None, presence=False):
+    cnt, h = ctx.hist()
+    ocov, oh = _oracle_hist(items, pre, order, gid, n, G, lens, excl)
+    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+    if presence:
+        r, c = orc.by_group(items, pre, order, gid, n, excl)
+        bits = ctx.presence()
+        got_rows = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, 1: n + 1]
+        assert (got_rows.T == (orc.table_rows(r, c, G) != 0)).all()
+        cnt2, h2 = ctx.hist()           # the pass that wrote M counted the same
+        assert np.array_equal(cnt2, ocov) and np.array_equal(h2, oh)
+
+
+def test_steps_out_of_place_are_spilled_and_added_by_the_tail(band):
+    """two steps swapped across bands; a path jittered locally; a stretch visited a second time far away; a stretch that
+    belongs elsewhere -- no pass is run again, no rows are derived, and the numbers are the oracle's (coverage vector,
+    histogram of node counts and of bp, presence matrix)"""
     ctx = band
     n = 60_000
-    items, pre, _ = orc.pansyn(5, n, 8)
+    items, pre, lens = orc.pansyn(5, n, 8)
     segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(8)]
     s = segs[5].copy()
     s[len(s) // 2], s[len(s) // 2 + 9000] = s[len(s) // 2 + 9000], s[len(s) // 2]   # two steps swapped across bands
     segs[5] = s
+    for a in range(0, len(segs[2]) - 50, 211):                                        # local inversions, some across a band edge
+        segs[2][a:a + 37] = segs[2][a:a + 37][::-1].copy()
+    s = segs[3]
+    segs[3] = np.concatenate([s[:9000], s[200:500], s[9000:], s[100:164]])           # two stretches visited again, out of place
+    s = segs[6][::-1].copy()                                                          # a descending path ...
+    s[4000:4100] = np.arange(n - 99, n + 1, dtype=np.uint64)                          # ... with a stretch from the other end of the graph
+    segs[6] = s
+    segs[7] = np.concatenate([segs[7], segs[7][:3000]])                               # the path's start once more at its end
+    items, pre = _concat(segs)
+    rng = np.random.default_rng(4)
+    excl = (rng.random(n + 1) < 0.03).astype(np.uint8)
+    excl[0] = 0
+    pi = np.arange(8, dtype=np.uint64)
+    before = ctx.info().n_reruns
+    for weights, exclude in ((None, None), (lens, excl)):
+        ctx.set_csr(items.astype(np.uint32), pre, n, weights=weights, exclude=exclude)
+        ctx.set_order(pi, pi, 8)
+        _check(ctx, items, pre, n, pi, pi, 8, weights, exclude, presence=True)
+        info = ctx.info()
+        assert info.n_reruns == before and info.n_rows == 0 and info.band_route_failed == 0
+        assert info.n_spilled_last > 0 and info.n_spilled_total >= info.n_spilled_last
+        # groups of several paths: a step spilled by one path of a group may be in band on another
+        order = np.array([6, 2, 3, 5, 0, 7, 1], dtype=np.uint64)
+        gid = np.array([0, 0, 0, 1, 1, 2, 2], dtype=np.uint64)
+        ctx.set_order(order, gid, 3)
+        _check(ctx, items, pre, n, order, gid, 3, weights, exclude, presence=True)
+        assert ctx.info().n_reruns == before and ctx.info().n_rows == 0
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_band_route_fuzz_with_paths_that_stray(band, seed):
+    """random paths sorted by id (either direction), then rearranged at random: blocks reversed, blocks copied from
+    elsewhere in the path, blocks moved to other ids, single steps replaced; random grouping, exclusion, node counts and bp"""
+    ctx = band
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([700, 8191, 8192, 8200, 16385, 50_000, 131_071, 400_000]))
+    P = int(rng.integers(2, 24))
+    segs = []
+    for _ in range(P):
+        ln = int(rng.integers(1, max(2, min(2 * n, 80_000))))
+        s = np.sort(rng.integers(1, n + 1, size=ln).astype(np.uint64))
+        if rng.random() < 0.3:
+            s = s[::-1].copy()
+        for _ in range(int(rng.integers(0, 12))):
+            if ln < 4:
+                break
+            a = int(rng.integers(0, ln - 1))
+            w = int(rng.integers(1, min(ln - a, 300) + 1))
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                s[a:a + w] = s[a:a + w][::-1].copy()
+            elif kind == 1:
+                src = int(rng.integers(0, ln - w + 1))
+                s[a:a + w] = s[src:src + w].copy()
+            elif kind == 2:
+                s[a:a + w] = (s[a:a + w] - 1 + int(rng.integers(1, n))) % n + 1
+            else:
+                s[a] = int(rng.integers(1, n + 1))
+        segs.append(s)
+    items, pre = _concat(segs)
+    lens = rng.integers(0, 70_000, size=n + 1).astype(np.uint32)
+    lens[0] = 0
+    excl = (rng.random(n + 1) < rng.choice([0.0, 0.1])).astype(np.uint8)
+    excl[0] = 0
+    weighted = bool(seed % 2)
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=lens if weighted else None, exclude=excl if excl.any() else None)
+    reruns = ctx.info().n_reruns
+    order = rng.permutation(P)[: int(rng.integers(1, P + 1))].astype(np.uint64)
+    gid = np.cumsum(rng.random(len(order)) < 0.5).astype(np.uint64)
+    gid -= gid[0]
+    G = int(gid.max()) + 1
+    ctx.set_order(order, gid, G)
+    os.environ["PNX_BAND_SPLITS"] = str(1 + seed % 4)     # bands shared by 1..4 workgroups (capped by the number of groups)
+    try:
+        _check(ctx, items, pre, n, order, gid, G, lens if weighted else None, excl if excl.any() else None, presence=seed % 3 == 0)
+    finally:
+        del os.environ["PNX_BAND_SPLITS"]
+    info = ctx.info()
+    # the scans of the tail are bounded by the size of the graph: a tiny graph with much disorder may be run again over rows
+    assert info.n_reruns <= reruns + 2
+    if info.n_reruns == reruns:
+        assert info.n_rows == 0
+
+
+def test_paths_that_do_not_follow_the_ids_void_the_pass_and_the_rows_take_over(band):
+    ctx = band
+    n = 300_000
+    items, pre, _ = orc.pansyn(5, n, 8)
+    rng = np.random.default_rng(2)
+    segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(8)]
+    for k in (1, 4, 6):
+        segs[k] = rng.permutation(segs[k])                 # no order at all: every step is out of place
     items, pre = _concat(segs)
     ctx.set_csr(items.astype(np.uint32), pre, n)
     pi = np.arange(8, dtype=np.uint64)
-    ctx.set_order(pi, pi, 8)
+    ctx.set_order(pi, (pi // 2).astype(np.uint64), 4)
     before = ctx.info().n_reruns
     cnt, h = ctx.hist()
-    ocov, oh = _oracle_hist(items, pre, pi, pi, n, 8)
+    ocov, oh = _oracle_hist(items, pre, pi, pi // 2, n, 4)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
     assert info.n_reruns == before + 1 and info.n_rows > 0         # run again, over rows
     assert info.n_band_passes == 1 and info.band_route_failed == 1
     cnt, h = ctx.hist()                                             # and the graph is remembered: no second attempt
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 1
-    # locally jittered and fully shuffled paths: same story, same numbers
-    rng = np.random.default_rng(2)
-    segs[1] = rng.permutation(segs[1])
-    for a in range(0, len(segs[2]) - 50, 211):
-        segs[2][a:a + 37] = segs[2][a:a + 37][::-1].copy()
-    items, pre = _concat(segs)
-    ctx.set_csr(items.astype(np.uint32), pre, n)
-    ctx.set_order(pi, (pi // 2).astype(np.uint64), 4)
-    cnt, h = ctx.hist()
-    ocov, oh = _oracle_hist(items, pre, pi, pi // 2, n, 4)
-    assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 2
+
+
+@pytest.mark.parametrize("n,p", [(70_000, 5), (300_000, 12), (2_000_000, 24)])
+def test_rearranged_pansyn_device_generator_and_pass(band, n, p):
+    """pansyn-v1r (1 % of the 64-step blocks reversed, 0.1 % copied from earlier in the path, 0.05 % moved elsewhere): the
+    device generator makes the oracle's graph, and the one-shot pass over it holds -- spills, no rerun, no rows"""
+    ctx = band
+    items, pre, lens = orc.pansyn_rearranged(13, n, p)
+    ctx.set_csr_pansyn_rearranged(13, n, p, with_weights=True)
+    got, off, w = ctx.get_csr(want_weights=True)
+    assert np.array_equal(got, items.astype(np.uint32)) and np.array_equal(off, pre) and np.array_equal(w, lens)
+    before = ctx.info().n_reruns
+    pi = np.arange(p, dtype=np.uint64)
+    ctx.set_order(pi, pi, p)
+    _check(ctx, items, pre, n, pi, pi, p, lens)
+    gid = (pi // 2).astype(np.uint64)
+    ctx.set_order(pi, gid, int(gid.max()) + 1)
+    _check(ctx, items, pre, n, pi, gid, int(gid.max()) + 1, lens, presence=n <= 300_000)
+    info = ctx.info()
+    assert info.n_reruns == before and info.n_rows == 0 and info.n_spilled_last > 0
+
+
+@pytest.mark.parametrize("splits", [2, 3, 16])
+def test_bands_shared_by_several_workgroups(band, splits):
+    """a small graph: the visiting order is cut at group boundaries, the counters of a band's workgroups meet in the
+    coverage vector and K2 takes the histogram from it"""
+    ctx = band
+    n, p = 150_000, 40
+    items, pre, lens = orc.pansyn_rearranged(17, n, p)
+    ctx.set_csr_pansyn_rearranged(17, n, p, with_weights=True)
+    rng = np.random.default_rng(splits)
+    order = rng.permutation(p).astype(np.uint64)
+    gid = np.cumsum(rng.random(p) < 0.7).astype(np.uint64)
+    gid -= gid[0]
+    G = int(gid.max()) + 1
+    ctx.set_order(order, gid, G)
+    before = ctx.info().n_reruns
+    os.environ["PNX_BAND_SPLITS"] = str(splits)
+    try:
+        _check(ctx, items, pre, n, order, gid, G, lens, presence=True)
+        assert ctx.info().band_splits == min(splits, G)
+    finally:
+        del os.environ["PNX_BAND_SPLITS"]
+    assert ctx.info().n_reruns == before and ctx.info().n_rows == 0
 
 
 def test_band_route_rejects_bad_ids_at_upload(band):
