@@ -619,6 +619,9 @@ typedef struct {
     uint32_t band_splits;    /* (round 5) workgroups per band of the one-shot pass enqueued last (> 1: a small graph, the visiting
                                 order is shared out) */
     uint64_t n_spilled_total;/* (round 5) ... summed over the settled one-shot passes of this upload */
+    uint32_t n_spill_bursts_last; /* (round 5) ... of the pass settled last, in this many bursts (one burst = what one wave found in one
+                                16-byte-per-lane load: up to 256 consecutive steps of one path) */
+    uint32_t reserved0;
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

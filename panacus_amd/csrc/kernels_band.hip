@@ -54,8 +54,10 @@ constexpr int BAND_CW = 4;                  // waves per workgroup = item tiles 
 constexpr uint32_t BAND_SHIFT = 13;         // log2 of the ids of a band (BAND_CW tiles of 2048)
 static_assert((uint32_t)BAND_CW * BLOCK_ITEMS == 1u << BAND_SHIFT, "a band is 2^BAND_SHIFT ids");
 constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs through the ids downwards
-constexpr int BAND_MAX_SPLITS = 16;
-constexpr uint32_t BAND_TAIL_GRID = 256;    // workgroups of k_band_tail (4 waves each; a wave takes 64 spill records at a time)         // workgroups that share a band (each takes a range of the visiting order)
+constexpr int BAND_MAX_SPLITS = 16;         // workgroups that share a band (each takes a range of the visiting order)
+constexpr int SCAN_U = 4;                   // 16-byte loads a lane of k_band_tail keeps in flight while it scans a segment
+constexpr uint32_t BAND_TAIL_WAVES = 8;     // waves per workgroup of k_band_tail (a wave takes one burst of the spill list at a time)
+constexpr uint32_t BAND_TAIL_GRID = 1024;   // ... and its workgroups
 
 // the visiting order cut at group boundaries: split s takes the entries [k[s], k[s + 1])
 struct BandSplits {
@@ -63,10 +65,14 @@ struct BandSplits {
     uint32_t k[BAND_MAX_SPLITS + 1];
 };
 
-// where the steps go that were not in the band they were dealt to: rec[i] = (group << 32) | id, i < min(flags[6], cap)
+// where the steps go that were not in the band they were dealt to.  A BURST is what one wave found in one load (up to 256
+// consecutive steps of one path, i.e. of one group): its ids go to rec[start ..], and dir[b] = (start << 32) | group says where
+// they begin -- bursts are numbered in the order of their starts, so burst b ends where burst b + 1 begins.  flags[6] counts
+// the records, flags[7] the bursts (one 64-bit atomic takes a range of both).
 struct BandSpill {
-    unsigned long long *rec;
-    uint32_t cap;
+    uint32_t *rec;
+    unsigned long long *dir;
+    uint32_t cap, dir_cap;
 };
 
 // first j in [0, len] with key(j) >= X, key = id (ascending path) or ~id (descending); keys are non-decreasing on a
@@ -147,40 +153,84 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         if (tid == 0) group_first[n_groups] = n_ordered;
     }
     const uint64_t total = (uint64_t)(n_bands + 1) * n_ordered;
-    if (tid >= total) return;
-    const uint32_t e = (uint32_t)(tid % (n_bands + 1)), k = (uint32_t)(tid / (n_bands + 1));
-    const uint32_t p = ord_path[k];
-    const uint64_t ps = path_off[p], pe = path_off[p + 1], len = pe - ps;
-    if (len == 0) {
-        bidx[tid] = ps;
-        return;
+    // (no early exit: the lanes of a wave compare notes at the end)
+    const bool live = tid < total;
+    const uint32_t e = live ? (uint32_t)(tid % (n_bands + 1)) : 0u, k = live ? (uint32_t)(tid / (n_bands + 1)) : 0xFFFFFFFFu;
+    uint64_t ps = 0, len = 0;
+    bool desc = false;
+    uint64_t j = 0;
+    if (live) {
+        const uint32_t p = ord_path[k];
+        ps = path_off[p];
+        len = path_off[p + 1] - ps;
     }
-    const uint32_t a = items[ps], z = items[pe - 1];
-    bool desc = a > z;
-    uint32_t ka_fix = 0xFFFFFFFFu, kz_fix = 0u;  // (keys of the inner samples: smallest, largest)
-    if (len >= 16) {
-        const uint32_t q1 = items[ps + len / 4], q2 = items[ps + len / 2], q3 = items[ps + len / 2 + len / 4];
-        const int down = (int)(a > q1) + (int)(q1 > q2) + (int)(q2 > q3) + (int)(q3 > z);
-        const int up = (int)(a < q1) + (int)(q1 < q2) + (int)(q2 < q3) + (int)(q3 < z);
-        if (down != up) desc = down > up;
-        const uint32_t k1 = desc ? ~q1 : q1, k2 = desc ? ~q2 : q2, k3 = desc ? ~q3 : q3;
-        ka_fix = k1 < k2 ? (k1 < k3 ? k1 : k3) : (k2 < k3 ? k2 : k3);
-        kz_fix = k1 > k2 ? (k1 > k3 ? k1 : k3) : (k2 > k3 ? k2 : k3);
+    if (len) {
+        const uint32_t a = items[ps], z = items[ps + len - 1];
+        desc = a > z;
+        uint32_t ka_fix = 0xFFFFFFFFu, kz_fix = 0u;  // (keys of the inner samples: smallest, largest)
+        if (len >= 16) {
+            const uint32_t q1 = items[ps + len / 4], q2 = items[ps + len / 2], q3 = items[ps + len / 2 + len / 4];
+            const int down = (int)(a > q1) + (int)(q1 > q2) + (int)(q2 > q3) + (int)(q3 > z);
+            const int up = (int)(a < q1) + (int)(q1 < q2) + (int)(q2 < q3) + (int)(q3 < z);
+            if (down != up) desc = down > up;
+            const uint32_t k1 = desc ? ~q1 : q1, k2 = desc ? ~q2 : q2, k3 = desc ? ~q3 : q3;
+            ka_fix = k1 < k2 ? (k1 < k3 ? k1 : k3) : (k2 < k3 ? k2 : k3);
+            kz_fix = k1 > k2 ? (k1 > k3 ? k1 : k3) : (k2 > k3 ? k2 : k3);
+        }
+        // the ends bracket the search; an end that is not where the rest of the path says (a first step from elsewhere, the path's
+        // start visited again at its end) would send every edge to that end, and with it every step out of its band: such an end is
+        // taken for "below / above everything" instead, and the search finds the edges inside
+        uint32_t ka = desc ? ~a : a, kz = desc ? ~z : z;
+        if (ka > ka_fix) ka = 0u;
+        if (kz < kz_fix) kz = 0xFFFFFFFFu;
+        if (e == 0) j = desc ? len : 0;
+        else if (e == n_bands) j = desc ? 0 : len;
+        else {
+            const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
+            j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz) : band_edge_search<false>(items, ps, len, x, ka, kz);
+        }
     }
-    // the ends bracket the search; an end that is not where the rest of the path says (a first step from elsewhere, the path's
-    // start visited again at its end) would send every edge to that end, and with it every step out of its band: such an end is
-    // taken for "below / above everything" instead, and the search finds the edges inside
-    uint32_t ka = desc ? ~a : a, kz = desc ? ~z : z;
-    if (ka > ka_fix) ka = 0u;
-    if (kz < kz_fix) kz = 0xFFFFFFFFu;
-    uint64_t j;
-    if (e == 0) j = desc ? len : 0;
-    else if (e == n_bands) j = desc ? 0 : len;
-    else {
-        const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-        j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz) : band_edge_search<false>(items, ps, len, x, ka, kz);
+    // A search that probed a stretch of the path that is out of place (a translocated block, a copy of another region) may end
+    // far from the crossing; the segment between it and its neighbour would then hold thousands of steps of other bands -- all
+    // spilled, and one wave of the coverage kernel streaming them while its workgroup waits.  Edge positions of a path run
+    // one way, so a position that its neighbours (the lanes next to this one: consecutive edges of the same path) do not
+    // bracket is replaced by their median: of five where two neighbours exist on either side, of three, or held against the
+    // one neighbour there is.  Any positions make a valid cover of the path; these make one without outliers.
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        auto nb = [&](int d, uint64_t &v) {  // the position of edge e + d of the same path, if a lane of this wave holds it
+            const int src = (int)lane + d;
+            const uint64_t pv = __shfl(j, src & 63);
+            const uint32_t kv = __shfl(k, src & 63);
+            v = pv;
+            return src >= 0 && src < 64 && kv == k && live;
+        };
+        uint64_t m2, m1, p1, p2;
+        const bool hm2 = nb(-2, m2), hm1 = nb(-1, m1), hp1 = nb(1, p1), hp2 = nb(2, p2);
+        auto lo2 = [](uint64_t &x, uint64_t &y) {
+            if (y < x) {
+                const uint64_t t = x;
+                x = y;
+                y = t;
+            }
+        };
+        if (live && len && e != 0 && e != n_bands) {
+            if (hm2 && hm1 && hp1 && hp2) {
+                uint64_t v0 = m2, v1 = m1, v2 = j, v3 = p1, v4 = p2;  // median of five
+                lo2(v0, v1), lo2(v3, v4), lo2(v0, v3), lo2(v1, v4), lo2(v1, v2), lo2(v2, v3), lo2(v1, v2);
+                j = v2;
+            } else if (hm1 && hp1) {
+                uint64_t v0 = m1, v1 = j, v2 = p1;
+                lo2(v0, v1), lo2(v1, v2), lo2(v0, v1);
+                j = v1;
+            } else if (hp1) {
+                if (desc ? j < p1 : j > p1) j = p1;
+            } else if (hm1) {
+                if (desc ? j > m1 : j < m1) j = m1;
+            }
+        }
     }
-    bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
+    if (live) bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
 }
 
 // The coverage kernel.  flags[6] += the steps found outside the band they were dealt to (spilled to sl.rec: k_band_tail);
@@ -322,14 +372,16 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
                 if (lane >= (uint32_t)o) incl += t;
             }
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(flags + 6, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane(base);
+            unsigned long long took = 0;
+            if (lane == 0) took = atomicAdd(reinterpret_cast<unsigned long long *>(flags + 6), (unsigned long long)total | (1ull << 32));
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)took);
+            const uint32_t burst = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(took >> 32));
+            if (lane == 0 && burst < sl.dir_cap) sl.dir[burst] = ((unsigned long long)base << 32) | s.g;
             uint32_t at = base + incl - n_mine;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if ((out >> e) & 1u) {
-                    if (at < sl.cap) sl.rec[at] = ((unsigned long long)s.g << 32) | ids[e];
+                    if (at < sl.cap) sl.rec[at] = ids[e];
                     ++at;
                 }
             }
@@ -446,6 +498,7 @@ struct BandTail {
     RowHist hs;                // rep == nullptr: K2 takes the histogram from the coverage vector afterwards
     unsigned long long *hist;  // the pass's histogram in HBM
     uint32_t *flags;
+    uint32_t *scratch;         // (cleared with the pass's counters) [0] arrivals of the workgroups, [1] steps the scans have read, in units of 1024
     uint32_t *host_block;      // [flags u32[8] | hist] in the ticket's pinned memory, or nullptr
     uint32_t scan_budget;      // steps the spill scans may read in all, in units of 1024
 };
@@ -480,101 +533,183 @@ __device__ static inline bool spill_set_insert(unsigned long long *slots, uint32
     }
 }
 
-// One wave per 64 records of the spill list.  Every word that several workgroups touch -- flags, the set, the coverage
-// vector, the histogram replicas, M -- is touched by device-scope atomics and agent-scope loads only (the L2s of the
-// XCDs are not coherent with each other); the workgroup that arrives last adds the replicas up (the others have
-// released what they wrote before they took their ticket).
-__global__ __launch_bounds__(256) void k_band_tail(BandTail a) {
-    __shared__ uint32_t bmp_all[4][256];  // per wave: the 8192 ids of one band
+// The spill list, one wave per burst.  Every word that several workgroups touch -- flags, the set, the coverage vector, the
+// histogram replicas, M -- is touched by device-scope atomics and agent-scope loads only (the L2s of the XCDs are not
+// coherent with each other); the workgroup that arrives last adds the replicas up.
+// What it costs is the chain of dependent reads a burst starts at places nobody has touched before (its records -> the band
+// edges of its group's entries -> the segment; then set slot -> coverage word): ~7 us per burst and wave on 10 M x 256
+// whatever the volume of the scans (DESIGN.md, K-band), so bursts are what the time scales with, 8192 of them at a time.
+struct TailAdd {
+    const BandTail &a;
+    __device__ __forceinline__ void operator()(uint32_t g, uint32_t id, uint32_t salt) const {
+        if (a.exclude && a.exclude[id]) return;
+        if (!spill_set_insert(a.hset, a.hmask, a.gen, g, id)) return;
+        const uint32_t old = atomicAdd(a.countable + id, 1u);  // AbacusByTotal::coverage: one more group visits the item
+        if (a.hs.rep) {
+            const unsigned long long w = a.hs.weights ? (unsigned long long)a.hs.weights[id] : 1ull;
+            unsigned long long *rep = a.hs.rep + (size_t)(salt % HIST_REPLICAS) * (a.hs.n_groups + 1);
+            atomicAdd(&rep[old], 0ull - w);
+            atomicAdd(&rep[old + 1u], w);
+        }
+        if (a.M) atomicOr(a.M + (uint64_t)g * a.row_words + (uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u), 1u << ((id >> 6) & 31u));
+    }
+};
+
+__global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t bmp_all[BAND_TAIL_WAVES][256];  // per wave: the 8192 ids of one band
     __shared__ uint32_t s_last;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *bmp = bmp_all[wave];
-    uint32_t n = agent_load(a.flags + 6);
-    if (n > a.sl.cap) {  // the list did not hold them all: the pass is void
+    const TailAdd add{a};
+    uint32_t n = agent_load(a.flags + 6), n_bursts = agent_load(a.flags + 7);
+    if (n > a.sl.cap || n_bursts > a.sl.dir_cap) {  // the list did not hold them all: the pass is void
         if (threadIdx.x == 0) atomicOr(a.flags + 5, 2u);
-        n = 0;
+        n = n_bursts = 0;
     }
-    const uint32_t n_chunks = (n + 63u) / 64u;
     bool over = false;
-    for (uint32_t c = blockIdx.x * 4u + wave; c < n_chunks && !over; c += gridDim.x * 4u) {
-        const uint32_t i = c * 64u + lane;
-        const bool valid = i < n;
-        const unsigned long long rec = valid ? a.sl.rec[i] : 0ull;
-        const uint32_t g = (uint32_t)(rec >> 32), id = (uint32_t)rec;
-        const uint32_t b = id >> BAND_SHIFT;
-        const uint32_t wi = (id & ((1u << BAND_SHIFT) - 1u)) >> 5, bit = 1u << (id & 31u);
-        unsigned long long todo = __ballot(valid && id >= 1u && id <= a.n_items);
-        while (todo && !over) {
-            const int l0 = __ffsll((long long)todo) - 1;
-            const uint32_t lg = (uint32_t)__builtin_amdgcn_readlane((int)g, l0), lb = (uint32_t)__builtin_amdgcn_readlane((int)b, l0);
-            const bool mine = ((todo >> lane) & 1ull) != 0 && g == lg && b == lb;
-            todo &= ~__ballot(mine);
-            // the records of the cell (lg, lb) as a bitmap of the band
+    uint32_t vol_acc = 0;
+    const uint32_t bu_step = gridDim.x * BAND_TAIL_WAVES;
+    uint32_t bu = blockIdx.x * BAND_TAIL_WAVES + wave;
+    // (the directory entries of the next burst are asked for while this one is scanned: one link less in the chain)
+    unsigned long long d0 = bu < n_bursts ? a.sl.dir[bu] : 0ull, d1 = bu + 1u < n_bursts ? a.sl.dir[bu + 1u] : 0ull;
+    for (; bu < n_bursts && !over; bu += bu_step) {
+        const uint32_t start = (uint32_t)(d0 >> 32), lg = (uint32_t)d0;
+        uint32_t end = bu + 1u < n_bursts ? (uint32_t)(d1 >> 32) : n;
+        if (end > n || end < start || end - start > 256u) end = start;  // (cannot be: a burst is one load of one wave)
+        {
+            const uint32_t nb = bu + bu_step;
+            d0 = nb < n_bursts ? a.sl.dir[nb] : 0ull;
+            d1 = nb + 1u < n_bursts ? a.sl.dir[nb + 1u] : 0ull;
+        }
+        uint32_t idv[4], pend = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t i = start + (uint32_t)r * 64u + lane;
+            idv[r] = i < end ? a.sl.rec[i] : 0u;
+            pend |= (i < end && idv[r] >= 1u && idv[r] <= a.n_items) ? 1u << r : 0u;
+        }
+        const uint32_t k0 = a.group_first[lg], k1 = a.group_first[lg + 1];
+        while (!over) {
+            // the band of the first record still pending: the burst's records on that band are one cell (lg, lb)
+            uint32_t lb = NONE;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long m = __ballot(((pend >> r) & 1u) != 0);
+                if (lb == NONE && m) lb = (uint32_t)__builtin_amdgcn_readlane((int)(idv[r] >> BAND_SHIFT), __ffsll((long long)m) - 1);
+            }
+            if (lb == NONE) break;
+            uint32_t mine = 0, mn = 0xFFFFFFFFu, mx = 0u;  // ... and the range of their ids: what a scanned step is first held against
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (((pend >> r) & 1u) && (idv[r] >> BAND_SHIFT) == lb) {
+                    mine |= 1u << r;
+                    mn = idv[r] < mn ? idv[r] : mn;
+                    mx = idv[r] > mx ? idv[r] : mx;
+                }
+            }
+            pend &= ~mine;
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t t0 = __shfl_xor(mn, o), t1 = __shfl_xor(mx, o);
+                mn = t0 < mn ? t0 : mn;
+                mx = t1 > mx ? t1 : mx;
+            }
+            mn = (uint32_t)__builtin_amdgcn_readfirstlane(mn);
+            const uint32_t span = (uint32_t)__builtin_amdgcn_readfirstlane(mx) - mn;
+            // the records of the cell as a bitmap of the band
 #pragma unroll
             for (int w = 0; w < 4; ++w) bmp[w * 64 + lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (mine) atomicOr(&bmp[wi], bit);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((mine >> r) & 1u) atomicOr(&bmp[(idv[r] & ((1u << BAND_SHIFT) - 1u)) >> 5], 1u << (idv[r] & 31u));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // what the group's paths visit IN the band was counted by the coverage kernel: clear it
-            const uint32_t k0 = a.group_first[lg], k1 = a.group_first[lg + 1];
             uint32_t vol = 0;
             for (uint32_t k = k0; k < k1; ++k) {
                 const unsigned long long *ek = a.bidx + (uint64_t)k * a.n_edges + lb;
                 const uint64_t e0 = ek[0] & ~BAND_DESC, e1 = ek[1] & ~BAND_DESC;
-                const uint64_t lo = e0 < e1 ? e0 : e1, hi = e0 < e1 ? e1 : e0;
-                vol += (uint32_t)((hi - lo + 1023u) >> 10);
-                for (uint64_t pos = (lo & ~3ull) + lane * 4u; pos < hi; pos += 256u) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(a.items + pos);
-                    const uint32_t ids[4] = {v.x, v.y, v.z, v.w};
+                const uint64_t lo = e0 < e1 ? e0 : e1;
+                const uint32_t seg_len = (uint32_t)((e0 < e1 ? e1 : e0) - lo);
+                vol += (seg_len + 1023u) >> 10;
+                // (SCAN_U 16-byte loads per lane in flight; positions relative to the aligned start of the segment: a segment holds
+                // fewer than 2^29 steps)
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(a.items + (lo & ~3ull));
+                const uint32_t head = (uint32_t)(lo & 3ull), nal = head + seg_len;  // steps before the segment in its first load; + its length
+                for (uint32_t r0 = 0; r0 < nal; r0 += 256u * SCAN_U) {
+                    u32x4 v[SCAN_U];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint64_t q = pos + (uint64_t)e;
-                        const uint32_t x = ids[e];
-                        if (q >= lo && q < hi && (x >> BAND_SHIFT) == lb) {
-                            const uint32_t xw = (x & ((1u << BAND_SHIFT) - 1u)) >> 5, xb = 1u << (x & 31u);
-                            if (bmp[xw] & xb) atomicAnd(&bmp[xw], ~xb);
+                    for (int u = 0; u < SCAN_U; ++u) {
+                        const uint32_t q = r0 + (uint32_t)u * 256u + lane * 4u;
+                        v[u] = q < nal ? __builtin_nontemporal_load(src + (q >> 2)) : u32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < SCAN_U; ++u) {
+                        const uint32_t q = r0 + (uint32_t)u * 256u + lane * 4u;
+                        const uint32_t ids[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        uint32_t hit = 0;  // steps of the segment with an id in the range of the records
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hit |= (ids[e] - mn <= span && q + (uint32_t)e - head < seg_len) ? 1u << e : 0u;
+                        if (__ballot(hit != 0)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if ((hit >> e) & 1u) {
+                                    const uint32_t x = ids[e];
+                                    const uint32_t xw = (x & ((1u << BAND_SHIFT) - 1u)) >> 5, xb = 1u << (x & 31u);
+                                    if (bmp[xw] & xb) atomicAnd(&bmp[xw], ~xb);
+                                }
+                            }
                         }
                     }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // what is left was visited only out of band: one lane per id takes it
-            bool won = false;
-            if (mine) won = (atomicAnd(&bmp[wi], ~bit) & bit) != 0;
-            if (won && !(a.exclude && a.exclude[id]) && spill_set_insert(a.hset, a.hmask, a.gen, lg, id)) {
-                const uint32_t old = atomicAdd(a.countable + id, 1u);  // AbacusByTotal::coverage: one more group visits the item
-                if (a.hs.rep) {
-                    const unsigned long long w = a.hs.weights ? (unsigned long long)a.hs.weights[id] : 1ull;
-                    unsigned long long *rep = a.hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * (a.hs.n_groups + 1);
-                    atomicAdd(&rep[old], 0ull - w);
-                    atomicAdd(&rep[old + 1u], w);
-                }
-                if (a.M) atomicOr(a.M + (uint64_t)lg * a.row_words + (uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u), 1u << ((id >> 6) & 31u));
+            // what is left was visited only out of band: one lane per id adds it
+            uint32_t wonm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t id = idv[r];
+                const uint32_t wi = (id & ((1u << BAND_SHIFT) - 1u)) >> 5, bit = 1u << (id & 31u);
+                if (((mine >> r) & 1u) && (atomicAnd(&bmp[wi], ~bit) & bit) != 0) wonm |= 1u << r;
+            }
+            while (wonm) {  // (one copy of the code that adds a pair, not four)
+                const int r = __builtin_ctz(wonm);
+                wonm &= wonm - 1u;
+                add(lg, r == 0 ? idv[0] : r == 1 ? idv[1] : r == 2 ? idv[2] : idv[3], blockIdx.x * BAND_TAIL_WAVES + wave);
             }
             __builtin_amdgcn_wave_barrier();
-            // the scans are bounded: a graph whose paths do not follow the ids is served by path rows
-            uint32_t seen = 0;
-            if (lane == 0) seen = atomicAdd(a.flags + 3, vol) + vol;
-            seen = (uint32_t)__builtin_amdgcn_readfirstlane(seen);
-            if (seen > a.scan_budget) {
-                if (lane == 0) atomicOr(a.flags + 5, 4u);
-                over = true;
+            // the scans are bounded: a graph whose paths do not follow the ids is served by path rows.  (The volume is taken to the
+            // shared counter every 256 K steps a wave has read, not per cell: tens of thousands of atomics on one word would take
+            // longer than the scans.)
+            vol_acc += vol;
+            if (vol_acc >= 256u) {
+                uint32_t seen = 0;
+                if (lane == 0) seen = atomicAdd(a.scratch + 1, vol_acc) + vol_acc;
+                vol_acc = 0;
+                seen = (uint32_t)__builtin_amdgcn_readfirstlane(seen);
+                if (seen > a.scan_budget) {
+                    if (lane == 0) atomicOr(a.flags + 5, 4u);
+                    over = true;
+                }
             }
         }
     }
+    if (vol_acc && lane == 0 && atomicAdd(a.scratch + 1, vol_acc) + vol_acc > a.scan_budget) atomicOr(a.flags + 5, 4u);
     // ---- the histogram is handed over: by workgroup 0 when the list was empty (every workgroup knows: the count was final
     // when the kernel began), else by the last workgroup to arrive ----
-    if (n_chunks) {
+    if (n_bursts) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // (what this workgroup wrote for others it wrote with device-scope atomics, which are performed where every XCD sees
+        // them: once they are acknowledged -- the wait above -- the ticket may follow.  A release fence here would write back the
+        // XCD's L2 once per workgroup, and those write-backs queue up: 0.1 ms for 2048 workgroups, measured)
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_last = __hip_atomic_fetch_add((g_u32 *)(a.flags + 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+            s_last = __hip_atomic_fetch_add((g_u32 *)a.scratch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
             if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -586,11 +721,16 @@ __global__ __launch_bounds__(256) void k_band_tail(BandTail a) {
     if (a.hs.rep) {
         const uint32_t bins = a.hs.n_groups + 1u;
         for (uint32_t bn = threadIdx.x; bn < bins; bn += blockDim.x) {
-            unsigned long long v[HIST_REPLICAS], sum = 0;  // all loads in flight before the first addition
+            unsigned long long sum = 0;
+            // (8 loads in flight at a time: all 64 at once are 128 registers, and the registers of this corner of the kernel
+            // would set the occupancy of the spill scans)
+            for (uint32_t r0 = 0; r0 < HIST_REPLICAS; r0 += 8) {
+                unsigned long long v[8];
 #pragma unroll
-            for (uint32_t r = 0; r < HIST_REPLICAS; ++r) v[r] = agent_load(a.hs.rep + (size_t)r * bins + bn);
+                for (uint32_t r = 0; r < 8; ++r) v[r] = agent_load(a.hs.rep + (size_t)(r0 + r) * bins + bn);
 #pragma unroll
-            for (uint32_t r = 0; r < HIST_REPLICAS; ++r) sum += v[r];
+                for (uint32_t r = 0; r < 8; ++r) sum += v[r];
+            }
             a.hist[bn] = sum;
             if (a.host_block) {
                 a.host_block[8 + 2 * bn] = (uint32_t)sum;
@@ -640,7 +780,8 @@ static int ensure_spill(pnx_ctx *ctx) {
     uint64_t slots = 1;
     while (slots < 2 * cap) slots <<= 1;
     int rc;
-    if ((rc = ensure(ctx, ctx->d_spill, cap * 8))) return rc;
+    // (a burst holds 1 .. 256 records; a list of single-step bursts is cut short by the directory: 1 entry per 4 records)
+    if ((rc = ensure(ctx, ctx->d_spill, cap * 4)) || (rc = ensure(ctx, ctx->d_spill_dir, (cap / 4) * 8))) return rc;
     ctx->spill_cap = (uint32_t)cap;
     const bool fresh = ctx->d_spill_set.cap < slots * 8 || ctx->spill_slots != slots;
     if ((rc = ensure(ctx, ctx->d_spill_set, slots * 8))) return rc;
@@ -659,7 +800,7 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, co
     const RowHist hs{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
                      ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
     const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
-    const BandSpill sl{(unsigned long long *)ctx->d_spill.p, ctx->spill_cap};
+    const BandSpill sl{(uint32_t *)ctx->d_spill.p, (unsigned long long *)ctx->d_spill_dir.p, ctx->spill_cap, ctx->spill_cap / 4};
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_bands * sp.n), dim3(BAND_CW * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
                            (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
@@ -748,7 +889,8 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     a.exclude = ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : nullptr;
     a.n_edges = n_bands + 1;
     a.n_items = ctx->n_items;
-    a.sl = BandSpill{(unsigned long long *)ctx->d_spill.p, ctx->spill_cap};
+    a.sl = BandSpill{(uint32_t *)ctx->d_spill.p, (unsigned long long *)ctx->d_spill_dir.p, ctx->spill_cap, ctx->spill_cap / 4};
+    a.scratch = tk->d_band_scratch;
     a.hset = (unsigned long long *)ctx->d_spill_set.p;
     a.hmask = (uint32_t)(ctx->spill_slots - 1);
     a.gen = ctx->spill_gen;
@@ -763,7 +905,7 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     // the scans may read a quarter of what the pass itself reads (and 4 M steps -- microseconds -- whatever the size of the graph)
     a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 4096 + 4096, 0xFFFFFFF0ull);
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
-    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(256), 0, ctx->s_post, a);
+    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(BAND_TAIL_WAVES * 64), 0, ctx->s_post, a);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;

@@ -98,6 +98,9 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->wrote_m = ctx->want_M;
     const size_t hist_bytes = ((size_t)ctx->n_groups + 1) * sizeof(uint64_t);
     tk->block_bytes = 8 * sizeof(uint32_t) + hist_bytes + (((size_t)ctx->n_groups + 15) & ~(size_t)15) + 16;
+    tk->block_bytes = (tk->block_bytes + 15) & ~(size_t)15;
+    const size_t scratch_off = tk->block_bytes;  // 16 words the workgroups of k_band_tail share
+    tk->block_bytes += 64;
     tk->hist_fused = rows && ctx->hist_in_cover && (size_t)ctx->n_groups + 1 <= HIST_FUSED_MAX_BINS;
     ctx->band_splits = 1;
     if (rows && ctx->pass_band) {
@@ -113,6 +116,7 @@ int launch_cover_pass(pnx_ctx *ctx) {
     tk->d_flags = (uint32_t *)tk->d_block.p;
     tk->d_hist = (uint64_t *)((char *)tk->d_block.p + 8 * sizeof(uint32_t));
     tk->d_grp_general = (uint8_t *)tk->d_block.p + 8 * sizeof(uint32_t) + hist_bytes;
+    tk->d_band_scratch = (uint32_t *)((char *)tk->d_block.p + scratch_off);
     if ((rc = ensure(ctx, tk->d_countable, ((size_t)ctx->n_items + 1) * sizeof(uint32_t)))) return rc;
     if (use_m && (rc = ensure(ctx, ctx->d_M, (m_words ? m_words : 1) * sizeof(uint32_t)))) return rc;
     const size_t no = ctx->n_ordered ? ctx->n_ordered : 1;

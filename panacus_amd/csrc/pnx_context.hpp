@@ -55,6 +55,7 @@ struct Ticket {
     uint32_t *d_flags = nullptr;
     uint64_t *d_hist = nullptr;
     uint8_t *d_grp_general = nullptr;
+    uint32_t *d_band_scratch = nullptr;  // 16 words behind them, cleared with them: what the workgroups of k_band_tail share
     size_t block_bytes = 0;
     void *h_block = nullptr;  // pinned copy of flags + hist
     size_t h_cap = 0;         // bytes of h_block
@@ -207,11 +208,12 @@ struct pnx_ctx {
     uint32_t band_splits = 1;    // ... with this many workgroups per band (each takes a range of the visiting order)
     // steps found outside the band they were dealt to (paths that are not sorted by id): the list of a pass, and the set of
     // (group, id) pairs its tail has added -- slots carry the generation of the pass that wrote them, so no pass clears the set
-    pnx::DevBuf d_spill, d_spill_set;
+    pnx::DevBuf d_spill, d_spill_dir, d_spill_set;
     uint32_t spill_cap = 0, spill_gen = 0;
     uint64_t spill_slots = 0;
     uint64_t n_spilled_total = 0;  // spilled steps of all settled passes of this upload
     uint32_t n_spilled_last = 0;   // ... of the pass settled last
+    uint32_t n_spill_bursts_last = 0;  // ... in this many bursts (a burst: what one wave found in one load)
 
     // ---- run index: tile route for non-monotone paths (kernels_runs.hip) ----
     // path_class: 0 tile-monotone (K0 index), 1 not monotone & unclassified, 2 run route, 3 scatter route
