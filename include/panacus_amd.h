@@ -66,6 +66,10 @@ int pnx_preload(int device, uint32_t what);
 /* message of the last failing call on ctx (ctx == NULL: last pnx_init failure) */
 const char *pnx_last_error(const pnx_ctx *ctx);
 const char *pnx_version(void);
+/* (round 5) counts the changes of this header that a binding has to know about (structs that grew, entry points added): a host
+ * built against header version v runs against a library with pnx_abi_version() >= v through the _sized entry points */
+#define PNX_ABI_VERSION 5
+int pnx_abi_version(void);
 
 /* ---- graph upload: the ItemTable (src/util.rs:81-93) ------------------------------------
  * Replaces the hand-off of `item_table` into AbacusByTotal::item_table_to_abacus
@@ -168,6 +172,12 @@ typedef struct pnx_gfa_steps {
 #define PNX_NAMES_FIND 0xFFFFFFFFFFFFFFFFull
 int pnx_gfa_text_upload(pnx_ctx *ctx, const char *text, uint64_t text_bytes);
 int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *weights, const uint8_t *exclude);
+/* (round 5) pnx_gfa_steps has grown at its end from round to round (name_off .. name_prefix_len are round 4's).  pnx_set_csr_gfa
+ * and pnx_gfa_walks assume the caller's struct is THIS header's; a binding built against an older header -- or one that wants
+ * to stay valid across rebuilds of the library -- calls the _sized forms with the size of ITS struct: the library reads
+ * min(steps_bytes, its own size) bytes and takes every field behind them for zero / NULL (the meaning the fields had before they
+ * existed).  PNX_ABI_VERSION / pnx_abi_version() count the changes of this header that a binding has to know about. */
+int pnx_set_csr_gfa_sized(pnx_ctx *ctx, const void *steps, size_t steps_bytes, const uint32_t *weights, const uint8_t *exclude);
 /* The same tokeniser for a run with -s / -e INTERVALS: the walks (node id + orientation of every step) are made from the text
  * and KEPT in the context instead of becoming the resident graph; walk_off receives their n_paths + 1 offsets.  A following
  * pnx_set_csr_cut with walk_node == NULL (and that walk_off) cuts them where they are -- nothing of the walks crosses PCIe in
@@ -175,6 +185,7 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *steps, const uint32_t *we
  * pnx_set_csr_gfa or the end of the context.  The edge fields of `steps` are ignored here (pnx_set_csr_cut has its own).
  * Like every upload the call ends the residence of the graph that was resident before it (the tokeniser works in its buffers). */
 int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *steps, uint64_t *walk_off);
+int pnx_gfa_walks_sized(pnx_ctx *ctx, const void *steps, size_t steps_bytes, uint64_t *walk_off);
 /* The walks a preceding pnx_gfa_walks left on the device become the resident graph -- as pnx_set_csr_gfa would have made it
  * from the text, without tokenising the text again: the node ItemTable (edge_uv == NULL; n_nodes items; weights / exclude as
  * for pnx_set_csr) or, with edge_uv / edge_oo / n_edges as in pnx_gfa_steps, the EDGE ItemTable of the same paths.  The

@@ -9,4 +9,4 @@ from . import capi  # noqa: F401
 from .capi import Context, PnxError  # noqa: F401
 from .thresholds import Threshold, ThresholdContainer, coverage_abs, quorum_table  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.5.0"

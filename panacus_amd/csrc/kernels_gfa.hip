@@ -461,7 +461,11 @@ __global__ void k_links_parse(const uint8_t *__restrict__ text, uint64_t text_by
         if (b1 + 1 >= text_bytes || text[b1] != '\t') bad |= 1u;
         else {
             const uint32_t u = node_of_field(text, a0, a1, nn, n_nodes, bad), v = node_of_field(text, b0, b1, nn, n_nodes, bad);
-            const uint32_t o1 = text[a1 + 1] == '+' ? 0u : 1u, o2 = text[b1 + 1] == '+' ? 0u : 1u;
+            const uint8_t c1 = text[a1 + 1], c2 = text[b1 + 1];
+            // an orientation is '+' or '-' and nothing else (the reference panics on anything else: Orientation::from_pm,
+            // graph.rs:42-48): a malformed link must not become a backward edge and change the edge ids
+            if ((c1 != '+' && c1 != '-') || (c2 != '+' && c2 != '-')) bad |= 1u;
+            const uint32_t o1 = c1 == '+' ? 0u : 1u, o2 = c2 == '+' ? 0u : 1u;
             if (!bad && (u == 0 || u > n_nodes || v == 0 || v > n_nodes)) bad |= 2u;
             if (!bad) {  // Edge::canonical (graph.rs:142-148); the orientations ride in the two top bits (node ids < 2^30)
                 unsigned long long uv;

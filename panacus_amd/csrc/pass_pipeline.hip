@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include <hip/hip_runtime.h>
@@ -58,29 +59,36 @@ int ensure_chunk_off(pnx_ctx *ctx) {
 
 // The step routes are a cross-check module beside the product library: opened on first use, from the library's own directory.
 const StepRoutes *step_routes(pnx_ctx *ctx) {
+    // (contexts of several host threads may ask at once: one lock around the lookup and its cached outcome.  A module that was
+    // not there is looked for again the next time -- it may have been installed since.)
+    static std::mutex mu;
     static const StepRoutes *table = nullptr;
-    static std::string why;
-    if (!table && why.empty()) {
-        Dl_info info{};
-        std::string dir = ".";
-        if (dladdr(reinterpret_cast<const void *>(&step_routes), &info) && info.dli_fname) {
-            dir = info.dli_fname;
-            const size_t slash = dir.rfind('/');
-            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+    std::string why;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!table) {
+            Dl_info info{};
+            std::string dir = ".";
+            if (dladdr(reinterpret_cast<const void *>(&step_routes), &info) && info.dli_fname) {
+                dir = info.dli_fname;
+                const size_t slash = dir.rfind('/');
+                dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+            }
+            const std::string path = dir + "/libpanacus_hip_steps.so";
+            void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (!h) {
+                why = std::string("the step routes (PNX_CFG_COVER_VARIANT 0 / 1 / 2) are a cross-check module that this installation does not have: ") + dlerror();
+            } else {
+                using fn_t = const StepRoutes *(*)();
+                fn_t fn = reinterpret_cast<fn_t>(dlsym(h, "pnx_step_routes_table"));
+                if (fn) table = fn();
+                else why = "libpanacus_hip_steps.so does not export pnx_step_routes_table";
+            }
         }
-        const std::string path = dir + "/libpanacus_hip_steps.so";
-        void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) {
-            why = std::string("the step routes (PNX_CFG_COVER_VARIANT 0 / 1 / 2) are a cross-check module that this installation does not have: ") + dlerror();
-        } else {
-            using fn_t = const StepRoutes *(*)();
-            fn_t fn = reinterpret_cast<fn_t>(dlsym(h, "pnx_step_routes_table"));
-            if (fn) table = fn();
-            else why = "libpanacus_hip_steps.so does not export pnx_step_routes_table";
-        }
+        if (table) return table;
     }
-    if (!table) ctx->fail(PNX_EINVAL, "%s", why.c_str());
-    return table;
+    ctx->fail(PNX_EINVAL, "%s", why.c_str());
+    return nullptr;
 }
 
 int launch_cover_pass(pnx_ctx *ctx) {

@@ -1,5 +1,6 @@
 // pnx_api.hip -- extern "C" entry points of libpanacus_hip.so (see include/panacus_amd.h).
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -285,7 +286,9 @@ using namespace pnx;
 
 extern "C" {
 
-const char *pnx_version(void) { return "panacus_amd 0.1.0 (gfx950)"; }
+const char *pnx_version(void) { return "panacus_amd 0.5.0 (gfx950)"; }
+
+int pnx_abi_version(void) { return PNX_ABI_VERSION; }
 
 const char *pnx_last_error(const pnx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
 
@@ -596,6 +599,28 @@ int pnx_set_csr_gfa(pnx_ctx *ctx, const pnx_gfa_steps *g, const uint32_t *weight
     release(d_e_oo);
     if (rc) return rc;
     return finish_upload(ctx, ctx->n_steps, g->n_paths, edges ? n_edges : g->n_nodes, weights, exclude, false, nullptr);
+}
+
+// a caller's (possibly older, shorter) pnx_gfa_steps as this library's: the fields it does not have are zero / NULL
+static bool widen_gfa_steps(pnx_gfa_steps *full, const void *steps, size_t steps_bytes) {
+    std::memset(full, 0, sizeof *full);
+    if (!steps || steps_bytes < offsetof(pnx_gfa_steps, id_of_name)) return false;  // (text .. is_walk: what every version has had)
+    std::memcpy(full, steps, std::min(steps_bytes, sizeof *full));
+    return true;
+}
+
+int pnx_set_csr_gfa_sized(pnx_ctx *ctx, const void *steps, size_t steps_bytes, const uint32_t *weights, const uint8_t *exclude) {
+    if (!ctx) return PNX_EINVAL;
+    pnx_gfa_steps full;
+    if (!widen_gfa_steps(&full, steps, steps_bytes)) return ctx->fail(PNX_EINVAL, "pnx_set_csr_gfa_sized: steps is NULL or shorter than any pnx_gfa_steps has been");
+    return pnx_set_csr_gfa(ctx, &full, weights, exclude);
+}
+
+int pnx_gfa_walks_sized(pnx_ctx *ctx, const void *steps, size_t steps_bytes, uint64_t *walk_off) {
+    if (!ctx) return PNX_EINVAL;
+    pnx_gfa_steps full;
+    if (!widen_gfa_steps(&full, steps, steps_bytes)) return ctx->fail(PNX_EINVAL, "pnx_gfa_walks_sized: steps is NULL or shorter than any pnx_gfa_steps has been");
+    return pnx_gfa_walks(ctx, &full, walk_off);
 }
 
 int pnx_gfa_walks(pnx_ctx *ctx, const pnx_gfa_steps *g, uint64_t *walk_off) {

@@ -733,6 +733,9 @@ std::unique_ptr<GraphStorage> GraphStorage::from_gfa(const std::string &gfa_file
     });
 
     phase_mark("P/W headers");
+    // (names that are not numbers are checked for duplicates -- the reference panics, graph.rs:336 -- where they are first looked
+    // up: the host's map, or the device's name table.  A graph without a single P, W or L line never looks one up: check it here)
+    if (!im.numeric_names && g->paths_.empty() && l_lines.empty() && !s_lines.empty()) im.ensure_names();
     im.l_lines = std::move(l_lines);
     im.links_only = links_only && !index_edges;
     if (index_edges) g->build_edge_index();
@@ -776,6 +779,12 @@ void GraphStorage::build_edge_index() {
                     return;
                 }
                 const uint32_t u = im.node_id(s.data() + a0, a1 - a0);
+                // (an orientation is '+' or '-': the reference panics on anything else, Orientation::from_pm, graph.rs:42-48)
+                if (s[a1 + 1] != '+' && s[a1 + 1] != '-') {
+                    bad_kind.store(1);
+                    bad_line.store((int64_t)k);
+                    return;
+                }
                 const uint8_t o1 = s[a1 + 1] == '+' ? 0 : 1;
                 size_t b0 = a1 + 3, b1 = field_end(s, b0, ln.e);
                 if (b1 + 1 >= ln.e) {
@@ -784,6 +793,11 @@ void GraphStorage::build_edge_index() {
                     return;
                 }
                 const uint32_t v = im.node_id(s.data() + b0, b1 - b0);
+                if (s[b1 + 1] != '+' && s[b1 + 1] != '-') {
+                    bad_kind.store(1);
+                    bad_line.store((int64_t)k);
+                    return;
+                }
                 const uint8_t o2 = s[b1 + 1] == '+' ? 0 : 1;
                 if (!u || u > g->node_count_ || !v || v > g->node_count_) {
                     bad_kind.store(!u || u > g->node_count_ ? 2 : 3);
@@ -868,7 +882,12 @@ void GraphStorage::build_edge_index() {
     }
     im.links_only = false;
 }
-void GraphStorage::ensure_edge_index() const { const_cast<GraphStorage *>(this)->build_edge_index(); }
+void GraphStorage::ensure_edge_index() const {
+    // (const accessors come here from any thread: one of them builds, the others wait)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    const_cast<GraphStorage *>(this)->build_edge_index();
+}
 bool GraphStorage::has_zero_length_nodes() const {
     for (size_t i = 1; i < node_lens_.size(); ++i)
         if (node_lens_[i] == 0) return true;

@@ -180,7 +180,7 @@ std::string write_ordered_table(const std::vector<std::vector<std::string>> &hea
 }
 
 std::string metadata_comments(const std::string &cmdline) {
-    return "# " + cmdline + "\n# version panacus-amd 0.1.0\n";
+    return "# " + cmdline + "\n# version panacus-amd 0.5.0\n";
 }
 
 // parse_tsv + parse_hists (io.rs:153-290)
