@@ -21,16 +21,20 @@ the same graph again gets from the second sweep on), the derivation of those row
 RANK / WORLD_SIZE are already in the environment (torch.distributed.run, the driver's way).
 
 Workload at N = 1: BASELINE.json configs[2] ("histgrowth ... on 10M-node / 256-path synthetic"), generator pansyn-v1
-seed 42.  With --gpus N each rank owns one node-range shard of the same shape (weak scaling: the global graph has
-N x 10M nodes, seeds 42+rank), the per-rank histograms are summed with an RCCL all-reduce on the device counters, and
-rank 0 evaluates the closed forms.
+seed 42.  With --gpus N the headline `value` is WEAK scaling (the contract's per-GPU work fixed: every rank owns a graph
+of the same shape, seeds 42+rank, i.e. one node-range shard of an N x 10M-node graph); the per-rank histograms are summed
+with an RCCL all-reduce on the device counters, and rank 0 evaluates the closed forms.
 
 Besides the headline the same JSON line carries:
+  * "strong_scaling" (N > 1) -- the SAME 10M-node / 256-path graph split into N node ranges (SURVEY 8e's primary
+    partitioning): rank r holds the steps whose id falls into its range, the same one-shot step, the (G+1) counters
+    all-reduced; rank 0 then runs alone on the whole graph, so `speedup_vs_1` comes from one run on one box.
   * "permuted_growth" -- BASELINE.json configs[3]: ordered-histgrowth over R = 128 random group orders on a
-    10M-node / 512-path graph, STRONG scaling: the R orders are dealt to the ranks (permutation sharding, presence
-    matrix replicated), every rank's out[R/N][T][G] is summed into the full out[R][T][G] with an RCCL all-reduce
-    enqueued behind the growth kernels on the library's own stream.  For N > 1 rank 0 also times all R orders alone, so
-    that `speedup_vs_1` comes from one run on one box.
+    10M-node / 512-path graph, STRONG scaling by node ranges as well: rank r holds the nodes of its range -- 1 / N of
+    the steps, of the presence matrix and of every order's work --, evaluates ALL R orders on them, and the
+    out[R][T][G] counters of the ranks are summed with one RCCL all-reduce in place on the library's device buffer
+    and stream.  For N > 1 rank 0 also times the whole graph alone, so that `speedup_vs_1` comes from one run on one box.
+  * "strayed_paths" (N = 1 only) -- the headline step on pansyn-v1r: paths that are NOT sorted by id.
   * "shape_10Mx1k" (N = 1 only) -- north_star's 10M-node / 1k-path histgrowth shape, the same step.
   * "cpu_baseline" (N = 1 only) -- the oracle (serial port of the reference's loops; closed forms one thread per
     threshold pair like hist.rs:68-81) on the FULL headline workload, its results compared bit for bit.
@@ -427,6 +431,85 @@ def permuted_growth_block(args, torch, dist, use_dist, world, rank, local_rank, 
     return out
 
 
+def strong_hist_block(args, torch, dist, use_dist, world, rank, local_rank, blocking, growth_on_device):
+    """The headline workload STRONGLY scaled (node-range sharding): ONE pansyn graph of --nodes x --paths, rank r
+    holds the nodes of its range -- the steps whose id falls into it, 1 / N of the ItemTable -- and runs the same one-shot step
+    on them; the (G+1) counters of the ranks are summed by an RCCL all-reduce in place on the device counters and rank 0
+    evaluates the closed forms.  For N > 1 rank 0 afterwards runs the same steps alone on the whole graph, so that
+    `speedup_vs_1` comes from one run on one box."""
+    from panacus_amd import capi, hostlib
+    from panacus_amd.distributed import even_node_range
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    N, P, steps = args.nodes, args.paths, max(4, args.strong_steps)
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    order = np.arange(P, dtype=np.uint32)
+
+    def run(lo, hi, dist_on, label):
+        ctx = capi.Context(local_rank)
+        if blocking:
+            ctx.config(capi.CFG_BLOCKING_SYNC, 1)
+        if args.cover_route is not None:
+            ctx.config(capi.CFG_COVER_ROUTE, args.cover_route)
+        ctx.set_csr_pansyn_shard(args.seed, lo, hi - lo, P, with_weights=False)
+        ctx.set_order(order, order, P)
+        if rank == 0:
+            hostlib.set_quorum_offload(ctx, args.quorum_offload_min_n)
+        stepper = OneShot(ctx, P, thr, rank=rank, world=world if dist_on else 1, use_dist=dist_on, dist=dist, torch=torch,
+                          local_rank=local_rank, collective=args.collective, blocking=blocking,
+                          growth_on_device=growth_on_device and rank == 0, growth_threads=args.growth_threads)
+
+        def barrier():
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ctx.sync()
+
+        dt, h, growths, prof = timed_steps(stepper, steps, 3, barrier, max(1, min(4, steps // 4)))
+        if dist_on:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        info = ctx.info()
+        per = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
+        res = {"label": label, "nodes": hi - lo, "steps_in_csr": int(info.n_steps), "ms_per_step": dt / steps * 1e3,
+               "kernels_ms": {"band_index": per.get("index"), "band_cover": per.get("cover"), "tail_or_hist": per.get("hist")},
+               "route": ("one-shot over the steps, %d workgroup(s) per band" % int(info.band_splits)) if int(info.n_rows) == 0 else "path rows",
+               "n_reruns": int(info.n_reruns), "hist_sum": int(h.sum()),
+               "growth_last_floor": [int(np.floor(g[-1])) for g in growths] if growths is not None else None}
+        stepper.close()
+        if rank == 0:
+            hostlib.set_quorum_offload(None)
+        if dist_on:
+            torch.cuda.synchronize()
+        ctx.close()
+        return res
+
+    lo, hi = even_node_range(N, world, rank)
+    sharded = run(lo, hi, use_dist, f"rank {rank} of {world}")
+    out = None
+    if rank == 0:
+        alone = sharded if world == 1 else run(0, N, False, "rank 0 alone on the whole graph")
+        if sharded["hist_sum"] != N or alone["hist_sum"] != N or sharded["growth_last_floor"] != alone["growth_last_floor"]:
+            raise SystemExit("strong scaling block: the sharded histogram / curves differ from the single-GPU ones")
+        S = alone["steps_in_csr"]
+        B = algorithmic_bytes_hist(S, P, N, P)
+        out = {
+            "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on ONE pansyn-v1 graph (seed {args.seed}), {N} nodes x {P} paths, split into "
+                        f"{world} node range(s)",
+            "n_gpus": world, "scaling": "strong", "steps": steps,
+            "sharding": "node ranges (SURVEY 8e): rank r holds the steps whose id falls into its range; RCCL all-reduce (sum) of the "
+                        "(G+1) counters in place on the device; closed forms on rank 0",
+            "ms_per_step": sharded["ms_per_step"], "ms_per_step_1gpu": alone["ms_per_step"],
+            "speedup_vs_1": alone["ms_per_step"] / sharded["ms_per_step"],
+            "value": N * P / (sharded["ms_per_step"] * 1e-3) / 1e6, "unit": "M node*paths/s",
+            "frac_of_aggregate_hbm_peak_on_algorithmic_bytes": B / (sharded["ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+            "rank0": sharded, "alone": None if world == 1 else alone,
+            "checks": {"hist_sum": sharded["hist_sum"], "sharded_equals_single_gpu": True},
+        }
+    return out
+
+
 class OneShot:
     """One complete histgrowth call from the resident u32 ItemTable, nothing derived kept from call to call."""
 
@@ -734,6 +817,8 @@ def strayed_block(args, local_rank):
     pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
     thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
     ctx = capi.Context(local_rank)
+    if args.cover_route is not None:
+        ctx.config(capi.CFG_COVER_ROUTE, args.cover_route)
     ctx.set_csr_pansyn_rearranged(args.seed, N, P, with_weights=False)
     order = np.arange(P, dtype=np.uint32)
     ctx.set_order(order, order, P)
@@ -802,6 +887,8 @@ def main():
     ap.add_argument("--k1-nodes", type=int, default=10_000_000)
     ap.add_argument("--k1-paths", type=int, default=1024)
     ap.add_argument("--k1-steps", type=int, default=20)
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong_scaling block (one headline graph split by node range)")
+    ap.add_argument("--strong-steps", type=int, default=40)
     ap.add_argument("--no-strayed", action="store_true", help="skip the strayed_paths block (the headline step on pansyn-v1r: paths not sorted by id)")
     ap.add_argument("--strayed-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -821,7 +908,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="the timed steps and nothing else (what the counter passes run)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = args.no_strayed = True
+        args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = args.no_strayed = args.no_strong = True
 
     force_dist = os.environ.get("PANACUS_BENCH_FORCE_DIST") == "1"
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and (args.gpus > 1 or force_dist):
@@ -995,6 +1082,33 @@ def main():
         out["resident_pass"] = resident_pass_block(ctx, P, thr, growth_on_device, args.growth_threads, args.resident_steps,
                                                    max(1, min(4, args.depth)))
 
+    def reference_binary_leg():
+        """if a `panacus` >= 0.4 binary happens to be on this box's PATH it is timed too (`-t 0`: all cores) on a GFA of
+        the CPU-runnable size and labelled "reference binary"; the image has none (no Rust toolchain, no network), and then the
+        line says so.  Never the thing measured, never on the product path."""
+        import shutil
+        import subprocess
+        import tempfile
+        exe = shutil.which("panacus")
+        if not exe:
+            return {"found": False, "note": "no `panacus` binary on PATH: the CPU baseline is the oracle (kind \"port\")"}
+        try:
+            from panacus_amd import hostlib
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                gfa = os.path.join(td, "syn.gfa")
+                n_ref, p_ref = 1_000_000, 64
+                rc, _, err = hostlib.run_cli(["synth", "--nodes", str(n_ref), "--paths", str(p_ref), "--seed", str(args.seed), "-o", gfa])
+                if rc != 0:
+                    return {"found": True, "path": exe, "error": "synth failed: " + err[-200:]}
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "hist", "-c", "node", "-t", "0", gfa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                dt = time.perf_counter() - t0
+                return {"found": True, "path": exe, "kind": "reference binary", "rc": r.returncode, "command": "panacus hist -c node -t 0 <pansyn 1M x 64 GFA>",
+                        "seconds": dt, "value": n_ref * p_ref / dt / 1e6, "unit": "M node*paths/s (end to end, GFA parse included)",
+                        "cores": os.cpu_count()}
+        except Exception as e:
+            return {"found": True, "path": exe, "error": f"{type(e).__name__}: {e}"}
+
     def run_cpu_baseline():
         """the oracle on the same workload (rank 0, one GPU only), AFTER the other timed blocks: its busy threads and the
         16 GB of host arrays it allocates slow the process down for whatever is timed beside them"""
@@ -1007,6 +1121,7 @@ def main():
                                              all(a.tobytes() == b.tobytes() for a, b in zip(g_cpu, growths)))
                 if not cb["agrees_with_gpu"]:
                     raise SystemExit("bench: histogram / growth of the GPU path differ from the CPU oracle")
+            cb["reference_binary"] = reference_binary_leg()
             out["cpu_baseline"] = cb
         except SystemExit:
             raise
@@ -1021,6 +1136,16 @@ def main():
         close_ctx()
     else:
         hostlib.set_quorum_offload(None)
+    # ---- the headline workload strongly scaled: one graph split by node range (N > 1; every rank takes part) ----
+    if use_dist and not args.no_strong:
+        try:
+            sb = strong_hist_block(args, torch, dist, use_dist, world, rank, local_rank, blocking, growth_on_device)
+        except SystemExit:
+            raise
+        except Exception as e:
+            sb = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["strong_scaling"] = sb
     # ---- BASELINE.json configs[3]: permuted growth, strong scaling (every rank takes part) ----
     if not args.no_permuted_growth:
         # With N > 1 ranks this block is the one place where the ranks exchange data (RCCL all-reduce of the curves).  The

@@ -82,7 +82,10 @@ def main():
         "steps_in_csr": int(info.n_steps), "kernel_ms": k_ms, "wall_ms_per_call": wall * 1e3,
         "pair_words_per_s": pair_words / (k_ms * 1e-3),
         "item_pairs_per_s": pair_words * 32 / (k_ms * 1e-3),
-        "valu_lane_ops": valu_ops, "valu_frac_of_peak": valu_ops / (k_ms * 1e-3) / peak_ops,
+        # the AND + popcount cost model prices the vector-ALU variant only; the matrix-core variant does none of those operations
+        # (a fraction above 1 -- r04 printed 1.26 and 18.1 -- is that model applied to the wrong kernel, not evidence)
+        "valu_lane_ops": valu_ops if args.variant == 0 else None,
+        "valu_frac_of_peak": (valu_ops / (k_ms * 1e-3) / peak_ops) if args.variant == 0 else None,
         "presence_bytes": P * row_words * 4,
         "presence_read_amplification_by_tiling": 2 * tile_pairs / side,
         "checks": {"diag_sum": int(np.diag(inter).sum()), "symmetric": bool((inter == inter.T).all())},

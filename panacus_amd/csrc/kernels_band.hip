@@ -85,10 +85,11 @@ struct BandSpill {
 // interpolation + binary search (0.058 -> 0.03 ms on 10 M items x 256 paths).
 template <bool DESC>
 __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ items, uint64_t ps, uint64_t len, uint32_t X, uint32_t ka,
-                                                   uint32_t kz) {
+                                                   uint32_t kz, uint32_t &n_probes, uint32_t &n_astray) {
     if (ka >= X) return 0;
     if (kz < X) return len;
     uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
+    uint32_t klo = ka, khi = kz;    // ... those two keys: what a step between the two positions of a sorted path lies between
     double pa = 0.0, va = (double)ka, pb = (double)(len - 1), vb = (double)kz;  // the two points of the secant
     for (int iter = 0; hi - lo > 1; ++iter) {
         uint64_t g = lo + ((hi - lo) >> 1);
@@ -104,13 +105,17 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
         const uint64_t first = ps + lo + 1, last = ps + hi - 1;  // absolute; first <= ps + g <= last
         const uint32_t i0 = first > a0 ? (uint32_t)(first - a0) : 0u, i1 = last - a0 < 15 ? (uint32_t)(last - a0) : 15u;
         uint32_t below = 0, k_first = 0, k_last = 0;
+        bool astray = false;  // a step of the sector that cannot stand between the bracket's ends on a sorted path
 #pragma unroll
         for (uint32_t i = 0; i < 16; ++i) {
             const uint32_t key = DESC ? ~w[i] : w[i];
             if (i == i0) k_first = key;
             if (i == i1) k_last = key;
             below += (i >= i0 && i <= i1 && key < X) ? 1u : 0u;
+            astray |= i >= i0 && i <= i1 && (key < klo || key > khi);
         }
+        n_probes += 1;
+        n_astray += astray ? 1u : 0u;
         const uint32_t n = i1 - i0 + 1;
         if (below != 0 && below != n) return a0 + i0 + below - ps;  // the crossing lies in the sector
         pa = pb;
@@ -119,10 +124,12 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
             hi = a0 + i0 - ps;
             pb = (double)hi;
             vb = (double)k_first;
+            khi = k_first;
         } else {
             lo = a0 + i1 - ps;
             pb = (double)lo;
             vb = (double)k_last;
+            klo = k_last;
         }
     }
     return hi;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
                                                     uint32_t n_ordered, uint32_t n_groups, uint32_t n_bands, uint32_t band_items,
                                                     unsigned long long *__restrict__ bidx, uint32_t *__restrict__ group_first,
                                                     uint4 *__restrict__ block16, uint32_t n_block16, uint4 *__restrict__ zero16,
-                                                    uint64_t n_zero16) {
+                                                    uint64_t n_zero16, uint32_t *__restrict__ probe_stats) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_threads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < n_block16; q += n_threads) block16[q] = make_uint4(0, 0, 0, 0);
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     uint64_t ps = 0, len = 0;
     bool desc = false;
     uint64_t j = 0;
+    uint32_t n_probes = 0, n_astray = 0;
     if (live) {
         const uint32_t p = ord_path[k];
         ps = path_off[p];
@@ -187,7 +195,22 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         else if (e == n_bands) j = desc ? 0 : len;
         else {
             const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-            j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz) : band_edge_search<false>(items, ps, len, x, ka, kz);
+            j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz, n_probes, n_astray)
+                     : band_edge_search<false>(items, ps, len, x, ka, kz, n_probes, n_astray);
+        }
+    }
+    // How the probes fared, summed over the kernel: a sector with a step that cannot stand between the ends of the bracket it
+    // was probed in is a sign of LONG-RANGE disorder (local jitter stays between the ends).  Where a quarter of the probes met
+    // one, the paths do not follow the ids and the coverage kernel does not start: k_band_cover reads the two sums.
+    {
+        uint32_t np = n_probes, na = n_astray;
+        for (int o = 32; o > 0; o >>= 1) {
+            np += __shfl_down(np, o);
+            na += __shfl_down(na, o);
+        }
+        if ((threadIdx.x & 63u) == 0 && np) {
+            atomicAdd(probe_stats, np);
+            if (na) atomicAdd(probe_stats + 1, na);
         }
     }
     // A search that probed a stretch of the path that is out of place (a translocated block, a copy of another region) may end
@@ -243,13 +266,19 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
                                                         uint32_t *__restrict__ M, uint64_t row_words, uint32_t *__restrict__ countable,
                                                         RowHist hs, uint32_t *__restrict__ flags, uint32_t n_bands, BandSplits sp,
-                                                        BandSpill sl) {
+                                                        BandSpill sl, const uint32_t *__restrict__ probe_stats) {
     constexpr int BT = CW;  // tiles per band = waves per workgroup
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t bm[2][CW][BT * 64];  // two generations of CW band bitmaps (one per entry of a batch)
     extern __shared__ unsigned long long sh_hist[];
 
+    // the index kernel's probes say the paths do not follow the ids (a quarter of the sectors it looked at held steps from
+    // elsewhere): nearly every step would be spilled and the pass void at the end -- it is void now, and nothing is read
+    if (probe_stats[1] > 64u && (unsigned long long)probe_stats[1] * 4ull > probe_stats[0]) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags + 5, 8u);
+        return;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t band = SPLIT ? blockIdx.x % n_bands : blockIdx.x;
@@ -499,6 +528,7 @@ struct BandTail {
     unsigned long long *hist;  // the pass's histogram in HBM
     uint32_t *flags;
     uint32_t *scratch;         // (cleared with the pass's counters) [0] arrivals of the workgroups, [1] steps the scans have read, in units of 1024
+    uint32_t *probe_stats;     // the index kernel's two sums (probes, probes that met steps astray): set back to zero for the next pass
     uint32_t *host_block;      // [flags u32[8] | hist] in the ticket's pinned memory, or nullptr
     uint32_t scan_budget;      // steps the spill scans may read in all, in units of 1024
 };
@@ -739,6 +769,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
         }
     }
     if (a.host_block && threadIdx.x < 8) a.host_block[threadIdx.x] = agent_load(a.flags + threadIdx.x);
+    if (threadIdx.x < 2) a.probe_stats[threadIdx.x] = 0;
 }
 
 // The shapes the band route is worth it for: enough bands (times the splits of the visiting order) to fill the chip,
@@ -780,6 +811,10 @@ static int ensure_spill(pnx_ctx *ctx) {
     uint64_t slots = 1;
     while (slots < 2 * cap) slots <<= 1;
     int rc;
+    if (!ctx->d_band_probe.p) {  // the index kernel's probe statistics: zero once, every pass's tail sets them back
+        if ((rc = ensure(ctx, ctx->d_band_probe, 16))) return rc;
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_band_probe.p, 0, 16, ctx->s_pre));
+    }
     // (a burst holds 1 .. 256 records; a list of single-step bursts is cut short by the directory: 1 entry per 4 records)
     if ((rc = ensure(ctx, ctx->d_spill, cap * 4)) || (rc = ensure(ctx, ctx->d_spill_dir, (cap / 4) * 8))) return rc;
     ctx->spill_cap = (uint32_t)cap;
@@ -806,7 +841,7 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, co
                            (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags,
-                           n_bands, sp, sl);
+                           n_bands, sp, sl, (const uint32_t *)ctx->d_band_probe.p);
     };
     // 4 waves per band, 2 loads in flight per lane: measured best on 10 M items x 256 and x 1024 paths (0.64 / 2.45 ms; 4 in flight
     // 0.67 / 2.56, 8 in flight 0.72; 8 waves per band 0.70, 2 waves 0.71) -- with every workgroup resident at once the chip holds
@@ -851,7 +886,7 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
                        (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, (const uint32_t *)ctx->d_ord_path.p,
                        (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
                        (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
-                       (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16);
+                       (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     // (recorded on one stream as well where the closed forms' tables are derived by the two-kernel route: that derivation starts
@@ -891,6 +926,7 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     a.n_items = ctx->n_items;
     a.sl = BandSpill{(uint32_t *)ctx->d_spill.p, (unsigned long long *)ctx->d_spill_dir.p, ctx->spill_cap, ctx->spill_cap / 4};
     a.scratch = tk->d_band_scratch;
+    a.probe_stats = (uint32_t *)ctx->d_band_probe.p;
     a.hset = (unsigned long long *)ctx->d_spill_set.p;
     a.hmask = (uint32_t)(ctx->spill_slots - 1);
     a.gen = ctx->spill_gen;
@@ -902,8 +938,9 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     a.hist = (unsigned long long *)tk->d_hist;
     a.flags = tk->d_flags;
     a.host_block = to_host ? (uint32_t *)tk->h_block_mapped : nullptr;
-    // the scans may read a quarter of what the pass itself reads (and 4 M steps -- microseconds -- whatever the size of the graph)
-    a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 4096 + 4096, 0xFFFFFFF0ull);
+    // the scans may read half of what the pass itself reads (a burst scans the segments of EVERY path of its group: groups of two
+    // haplotypes double the volume) -- and 4 M steps, microseconds, whatever the size of the graph
+    a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 2048 + 4096, 0xFFFFFFF0ull);
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
     hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(BAND_TAIL_WAVES * 64), 0, ctx->s_post, a);
     prof_end(ctx);

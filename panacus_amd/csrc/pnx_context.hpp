@@ -208,7 +208,7 @@ struct pnx_ctx {
     uint32_t band_splits = 1;    // ... with this many workgroups per band (each takes a range of the visiting order)
     // steps found outside the band they were dealt to (paths that are not sorted by id): the list of a pass, and the set of
     // (group, id) pairs its tail has added -- slots carry the generation of the pass that wrote them, so no pass clears the set
-    pnx::DevBuf d_spill, d_spill_dir, d_spill_set;
+    pnx::DevBuf d_spill, d_spill_dir, d_spill_set, d_band_probe;
     uint32_t spill_cap = 0, spill_gen = 0;
     uint64_t spill_slots = 0;
     uint64_t n_spilled_total = 0;  // spilled steps of all settled passes of this upload

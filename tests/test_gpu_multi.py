@@ -99,7 +99,7 @@ def test_bench_launches_its_ranks_and_shards_the_nodes(collective):
     both shards, and the permuted growth summed over the node-range shards equals the single-GPU result on the whole graph bit for
     bit (the bench fails otherwise)"""
     small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--pg-nodes", "150000", "--pg-paths", "40",
-             "--pg-orders", "10", "--pg-reps", "2", "--no-pmc", "--collective", collective]
+             "--pg-orders", "10", "--pg-reps", "2", "--no-pmc", "--strong-steps", "8", "--collective", collective]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=_clean_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
@@ -110,3 +110,68 @@ def test_bench_launches_its_ranks_and_shards_the_nodes(collective):
     pg = d["permuted_growth"]
     assert pg["n_gpus"] == 2 and pg["scaling"] == "strong" and pg["checks"]["sharded_equals_single_gpu"] and pg["allreduce_ms"] > 0
     assert pg["nodes_per_rank_max"] == 75000 and "rccl" in pg["collective_path"] and pg["speedup_vs_1"] > 0
+    # the headline graph itself split into two node ranges: same histogram and curves as rank 0 alone on the whole
+    # graph (the bench fails otherwise), both times from this run
+    sb = d["strong_scaling"]
+    for k in ("workload", "n_gpus", "scaling", "sharding", "ms_per_step", "ms_per_step_1gpu", "speedup_vs_1", "value", "rank0", "alone", "checks"):
+        assert k in sb, (k, sb)
+    assert sb["n_gpus"] == 2 and sb["scaling"] == "strong" and sb["checks"]["hist_sum"] == 200000 and sb["checks"]["sharded_equals_single_gpu"]
+    assert sb["rank0"]["nodes"] < 200000 and sb["alone"]["nodes"] == 200000 and sb["speedup_vs_1"] > 0
+
+
+@needs_two
+def test_two_gpus_unequal_shards_one_with_paths_that_do_not_follow_the_ids():
+    """the ranks of a communicator may take different routes: rank 0 takes the one-shot route and its shard's paths are shuffled (its
+    pass is void), rank 1's shard is sorted and takes the path rows.  The flags are reduced with the histogram, so BOTH ranks see the void flag and run the
+    pass again -- whatever their own route was -- and the collectives stay matched (a hang or a corrupted
+    histogram otherwise).  Checked against one context on the whole graph."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch, torch.distributed as dist
+rank = int(os.environ["RANK"]); torch.cuda.set_device(rank)
+dist.init_process_group("gloo")
+from panacus_amd import capi
+import oracle as orc
+n, p = 120_000, 8
+items, pre, _ = orc.pansyn(3, n, p)
+half = 61_440
+def shard(lo, hi):
+    segs = []
+    for k in range(p):
+        s = items[int(pre[k]):int(pre[k + 1])]
+        s = s[(s > lo) & (s <= hi)] - lo
+        segs.append(s)
+    return segs
+segs = shard(0, half) if rank == 0 else shard(half, n)
+if rank == 0:
+    rng = np.random.default_rng(1)
+    segs = [rng.permutation(s) for s in segs]          # no order at all: rank 0's one-shot pass will be void
+pre_r = np.zeros(p + 1, dtype=np.uint64); pre_r[1:] = np.cumsum([len(s) for s in segs])
+it_r = np.concatenate(segs).astype(np.uint32)
+c = capi.Context(rank)
+c.config(capi.CFG_COVER_ROUTE, 1 if rank == 0 else 0)   # rank 0: one-shot; rank 1: whatever the shape says (rows)
+uid = [capi.Context.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+c.comm_init(uid[0], rank, 2)
+c.set_csr(it_r, pre_r, half if rank == 0 else n - half)
+o = np.arange(p, dtype=np.uint32)
+c.set_order(o, o, p)
+_, h = c.hist(want_countable=False)
+_, h2 = c.hist(want_countable=False)
+pi = np.arange(p, dtype=np.uint64)
+want = orc.hist(orc.coverage(items, pre, pi, pi, n), p)
+assert np.array_equal(h, want) and np.array_equal(h2, want), (rank, h.tolist(), want.tolist())
+c.comm_free(); c.close()
+dist.barrier()
+print("ok", rank)
+""" % ROOT
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              env=_clean_env(RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                                             HSA_ENABLE_IPC_MODE_LEGACY="0")) for r in range(2)]
+    for pr in procs:
+        out, err = pr.communicate(timeout=600)
+        assert pr.returncode == 0 and b"ok" in out, err.decode()[-3000:]

@@ -1139,7 +1139,7 @@ def test_bench_contract_line_small(tmp_path):
     outs, pgs = [], []
     small = ["--nodes", "200000", "--paths", "64", "--steps", "12", "--warmup", "2", "--cpu-passes", "1",
              "--pg-nodes", "150000", "--pg-paths", "40", "--pg-orders", "10", "--pg-reps", "2",
-             "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4", "--resident-steps", "8"]
+             "--k1-nodes", "150000", "--k1-paths", "96", "--k1-steps", "4", "--resident-steps", "8", "--strong-steps", "6", "--strayed-steps", "6"]
     # FORCE_DIST without RANK / WORLD_SIZE in the environment: bench.py launches its rank(s) itself (the --gpus N path)
     clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for extra, env in ((["--cover-route", "1"], {}), (["--no-cpu-baseline", "--no-shape-1k", "--no-pmc"], {}),
@@ -1189,6 +1189,20 @@ def test_bench_contract_line_small(tmp_path):
         assert sim["kernel_ms"] > 0 and sim["checks"]["symmetric"] and sim["checks"]["diagonal_sum"] > 0
         if env:
             assert pg["allreduce_ms"] > 0 and "rccl" in pg["collective_path"]
+            # the headline graph split by node range (one rank here: its range is the whole graph), through the same collective
+            sb = d["strong_scaling"]
+            for k in ("workload", "n_gpus", "scaling", "sharding", "ms_per_step", "ms_per_step_1gpu", "speedup_vs_1", "value", "rank0", "checks"):
+                assert k in sb, (k, sb)
+            assert sb["scaling"] == "strong" and sb["n_gpus"] == 1 and sb["speedup_vs_1"] == 1.0
+            assert sb["checks"]["hist_sum"] == 200000 and sb["checks"]["sharded_equals_single_gpu"] and sb["rank0"]["n_reruns"] == 0
+        else:
+            # the headline step on paths that are not sorted by id: forced onto the one-shot route it holds (spills, no rerun, no rows)
+            sp = d["strayed_paths"]
+            assert sp["checks"]["hist_sum"] == 200000 and sp["ms_per_step"] > 0 and sp["n_reruns"] == 0
+            if one_shot:
+                assert sp["one_shot_route_held"] and sp["spilled_steps_per_pass"] > 0 and sp["n_rows"] == 0
+            if "--no-cpu-baseline" not in extra:
+                assert sp["checks"]["hist_agrees_with_oracle"] is True
         if "--no-cpu-baseline" not in extra:
             cb, k1 = d["cpu_baseline"], d["shape_10Mx1k"]
             assert cb["agrees_with_gpu"] is True and cb["kind"] == "port" and cb["cores"] == 3 and cb["value"] > 0
@@ -1254,6 +1268,41 @@ def test_full_size_cfg3_properties():
         cnt2, h3 = c.hist()
         assert int(h3.sum()) == n
         assert np.all(cnt2[1:] <= cnt[1:]) and np.all(2 * cnt2[1:].astype(np.int64) >= cnt[1:])
+
+
+def test_full_size_cfg3_with_paths_that_stray_against_the_oracle():
+    """configs[2]'s shape on pansyn-v1r -- 10 M nodes x 256 paths whose steps are NOT sorted by id (1 % of the 64-step blocks
+    reversed, 0.1 % copies of earlier blocks, 0.05 % moved elsewhere in the id space): the cold call takes the one-shot
+    route and holds it (steps out of their band are spilled and added by the pass's tail: no rerun, no rows), and the WHOLE
+    coverage vector and the histogram are the ones the serial restatement of abacus.rs:719-787 computes on the same steps
+    (read back from HBM); grouped in pairs as well, where a step spilled by one path of a group may be in band on the other."""
+    from panacus_amd import capi
+    n, p = 10_000_000, 256
+    with capi.Context(0) as c:
+        c.set_csr_pansyn_rearranged(42, n, p)
+        order = np.arange(p, dtype=np.uint32)
+        c.set_order(order, order, p)
+        cnt, h = c.hist()
+        info = c.info()
+        assert info.n_rows == 0 and info.n_reruns == 0 and info.band_route_failed == 0
+        assert info.n_spilled_last > 1_000_000 and info.n_spill_bursts_last > 10_000       # ~0.17 % of 0.98 G steps
+        assert int(h.sum()) == n and cnt[0] == 0xFFFFFFFF
+        items32, off, _ = c.get_csr()
+        items = items32.astype(np.uint64)
+        del items32
+        pi = np.arange(p, dtype=np.uint64)
+        ocov = orc.coverage(items, off, pi, pi, n)
+        assert np.array_equal(cnt, ocov) and np.array_equal(h, orc.hist(ocov, p))
+        # the device generator made the oracle's graph: the first million nodes' worth of every path cannot be compared (the
+        # rearrangement is by position), so compare the whole of a smaller graph elsewhere (test_gpu_band) and here the step count
+        assert len(items) == int(off[-1]) == int(info.n_steps)
+        gid = (pi // 2).astype(np.uint64)
+        c.config(capi.CFG_DROP_DERIVED, 0)
+        c.set_order(order, gid.astype(np.uint32), p // 2)
+        cnt2, h2 = c.hist()
+        assert c.info().n_rows == 0 and c.info().n_reruns == 0
+        ocov2 = orc.coverage(items, off, pi, gid, n)
+        assert np.array_equal(cnt2, ocov2) and np.array_equal(h2, orc.hist(ocov2, p // 2))
 
 
 def test_node_range_shards_of_the_generated_graph_sum_to_the_whole():
@@ -1525,7 +1574,10 @@ def test_shuffled_paths_at_scale_are_sorted_once_and_read_back_in_order(variant)
         c.set_order(order, order // 2, p // 2)
         cnt, h = c.hist()
         info = c.info()
-        assert info.n_sorted_paths == (p if variant == 2 else 0) and info.n_scatter_paths == 0 and info.n_run_paths == 0 and info.n_reruns == 0
+        assert info.n_sorted_paths == (p if variant == 2 else 0) and info.n_scatter_paths == 0 and info.n_run_paths == 0
+        # (the default route tries the one-shot pass on this shape; its index kernel's probes find the paths shuffled, the coverage
+        # kernel does not start, and the pass runs over path rows: one cheap rerun, remembered for the upload)
+        assert info.n_reruns == (1 if variant == 3 else 0) and info.band_route_failed == (1 if variant == 3 else 0)
         assert np.array_equal(cnt, cnt0) and np.array_equal(h, h0)
         c.set_order(order[::-1].copy(), (order // 2)[::-1].max() - (order // 2)[::-1], p // 2)
         cnt2, h2 = c.hist()
