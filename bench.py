@@ -605,11 +605,16 @@ def timed_steps(stepper, steps, warmup, barrier, sample_every):
     ctx.profile_sample(sample_every)
     ctx.profile_reset()
     barrier()
+    each = []
     t0 = time.perf_counter()
     for _ in range(steps):
         h, growths = stepper.step()
+        each.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    # (the spread of the steps of the timed region, for the record: a step ends when its curves are on the host)
+    per = sorted(b - a for a, b in zip([t0] + each[:-1], each))
+    stepper.step_spread_ms = {"min": per[0] * 1e3, "median": per[len(per) // 2] * 1e3, "max": per[-1] * 1e3}
     prof = ctx.profile_read()
     ctx.profile_select(None)
     ctx.profile_sample(1)
@@ -858,6 +863,7 @@ def strayed_block(args, local_rank):
         "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1r seed {args.seed} (paths not sorted by id: 1 % of the 64-step "
                     f"blocks reversed, 0.1 % copied from earlier in the path, 0.05 % moved elsewhere), {N} nodes x {P} paths",
         "steps": steps, "ms_per_step": ms_per_step, "value": N * P / (ms_per_step * 1e-3) / 1e6, "unit": "M node*paths/s",
+        "step_spread_ms": getattr(stepper, "step_spread_ms", None),
         "steps_in_csr": S, "spilled_steps_per_pass": int(info.n_spilled_last), "n_reruns": int(info.n_reruns), "n_rows": int(info.n_rows),
         "one_shot_route_held": held, "roofline": roofline, "step_breakdown_ms": breakdown, "hist_only": hist_only,
         "checks": {"hist_sum": int(h.sum()), "hist_agrees_with_oracle": agrees,
@@ -906,6 +912,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (child runs of this script) that measure roofline.traffic and roofline_valu")
     ap.add_argument("--headline-only", action="store_true", help="the timed steps and nothing else (what the counter passes run)")
+    ap.add_argument("--rearranged", action="store_true", help="measurement: the headline loop on pansyn-v1r (paths not sorted by id) instead of "
+                                                               "pansyn-v1 -- what the strayed_paths block runs, for profiling it alone; never the reported line")
     args = ap.parse_args()
     if args.headline_only:
         args.no_permuted_growth = args.no_shape_1k = args.no_cpu_baseline = args.no_resident = args.no_pmc = args.no_strayed = args.no_strong = True
@@ -959,7 +967,10 @@ def main():
         ctx.config(capi.CFG_BLOCKING_SYNC, 1)
     if args.cover_route is not None:
         ctx.config(capi.CFG_COVER_ROUTE, args.cover_route)
-    ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
+    if args.rearranged:
+        ctx.set_csr_pansyn_rearranged(args.seed + rank, N, P, with_weights=False)
+    else:
+        ctx.set_csr_pansyn(args.seed + rank, N, P, with_weights=False)
     order = np.arange(P, dtype=np.uint32)
     ctx.set_order(order, order, P)
     S = int(ctx.info().n_steps)
@@ -1002,34 +1013,40 @@ def main():
         roofline["launches_timed"] = f"every {sample_every}th of the {args.steps} launches of the timed region"
         value = world * N * P / (ms_per_step * 1e-3) / 1e6
         cf = closed_form_costs(ctx, h, thr, args.growth_threads) if growth_on_device else None
-        # counters of the kernel that reads the steps, measured by child runs under rocprofv3
-        valu = None
-        if world == 1 and not args.no_pmc and os.environ.get("PANACUS_BENCH_CHILD") != "1":
-            child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--nodes", str(N), "--paths", str(P), "--seed", str(args.seed),
-                     "--headline-only"]
-            if args.cover_route is not None:
-                child += ["--cover-route", str(args.cover_route)]
-            if args.allow_host_closed_forms:
-                child += ["--allow-host-closed-forms"]
-            one_shot = roofline["kernel"] == "k_band_cover"
-            names = ["k_band_cover", "k_band_index"] if one_shot else ["k_rows_build<false>", "k_rows_cover"]
-            pm, src = pmc_leg(child, names, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"]])
-            roofline["traffic_source"] = src
-            kc = pm.get(names[0], {})
-            if "FETCH_SIZE" in kc and "WRITE_SIZE" in kc:
-                roofline["traffic"] = (2.0 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024.0
-            ki = pm.get(names[1], {})
-            if "FETCH_SIZE" in ki and "WRITE_SIZE" in ki:
-                roofline["traffic_" + ("band_index" if one_shot else "rows_cover")] = (2.0 * ki["FETCH_SIZE"] + ki["WRITE_SIZE"]) * 1024.0
-            if "SQ_INSTS_VALU" in kc and cover_ms:
-                # a wave64 vector instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md): peak = CUs x 4 SIMDs x clock / 2
-                peak_wi = n_cus * 4 * clock_ghz * 1e9 / 2.0
-                wi = kc["SQ_INSTS_VALU"]
-                valu = {"bound": "valu", "kernel": names[0], "wave_instructions_per_launch": wi,
-                        "achieved": wi / (cover_ms * 1e-3), "peak": peak_wi, "unit": "wave64 VALU instr/s", "frac": wi / (cover_ms * 1e-3) / peak_wi,
-                        "scalar_instructions_per_launch": kc.get("SQ_INSTS_SALU"), "lds_instructions_per_launch": kc.get("SQ_INSTS_LDS"),
-                        "lds_bank_conflict_cycles_per_launch": kc.get("SQ_LDS_BANK_CONFLICT"),
-                        "vector_instructions_per_step": wi * 64 / S, "compute_units": n_cus, "clock_ghz": clock_ghz}
+        # counters of the kernel that reads the steps, measured by child runs under rocprofv3 -- AFTER every timed block of this
+        # run (run_pmc is called just before the line is printed): the counter passes of the children leave the driver busy for
+        # a while after they exit, and a 37 ms stall of one HIP call inside a later timed block was traced to them
+        valu_holder = {"valu": None}
+
+        def run_pmc():
+            valu = None
+            if world == 1 and not args.no_pmc and os.environ.get("PANACUS_BENCH_CHILD") != "1":
+                child = ["--gpus", "1", "--steps", "4", "--warmup", "1", "--nodes", str(N), "--paths", str(P), "--seed", str(args.seed),
+                         "--headline-only"]
+                if args.cover_route is not None:
+                    child += ["--cover-route", str(args.cover_route)]
+                if args.allow_host_closed_forms:
+                    child += ["--allow-host-closed-forms"]
+                one_shot = roofline["kernel"] == "k_band_cover"
+                names = ["k_band_cover", "k_band_index"] if one_shot else ["k_rows_build<false>", "k_rows_cover"]
+                pm, src = pmc_leg(child, names, [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"]])
+                roofline["traffic_source"] = src
+                kc = pm.get(names[0], {})
+                if "FETCH_SIZE" in kc and "WRITE_SIZE" in kc:
+                    roofline["traffic"] = (2.0 * kc["FETCH_SIZE"] + kc["WRITE_SIZE"]) * 1024.0
+                ki = pm.get(names[1], {})
+                if "FETCH_SIZE" in ki and "WRITE_SIZE" in ki:
+                    roofline["traffic_" + ("band_index" if one_shot else "rows_cover")] = (2.0 * ki["FETCH_SIZE"] + ki["WRITE_SIZE"]) * 1024.0
+                if "SQ_INSTS_VALU" in kc and cover_ms:
+                    # a wave64 vector instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md): peak = CUs x 4 SIMDs x clock / 2
+                    peak_wi = n_cus * 4 * clock_ghz * 1e9 / 2.0
+                    wi = kc["SQ_INSTS_VALU"]
+                    valu = {"bound": "valu", "kernel": names[0], "wave_instructions_per_launch": wi,
+                            "achieved": wi / (cover_ms * 1e-3), "peak": peak_wi, "unit": "wave64 VALU instr/s", "frac": wi / (cover_ms * 1e-3) / peak_wi,
+                            "scalar_instructions_per_launch": kc.get("SQ_INSTS_SALU"), "lds_instructions_per_launch": kc.get("SQ_INSTS_LDS"),
+                            "lds_bank_conflict_cycles_per_launch": kc.get("SQ_LDS_BANK_CONFLICT"),
+                            "vector_instructions_per_step": wi * 64 / S, "compute_units": n_cus, "clock_ghz": clock_ghz}
+            out["roofline_valu"] = valu
         out = {
             "metric": "histgrowth_throughput",
             "value": value,
@@ -1044,7 +1061,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on pansyn-v1 synthetic, "
+                "workload": f"histgrowth -c node -l 1,2,1 -q 0,0,0.5 on {'pansyn-v1r (NOT the reported workload)' if args.rearranged else 'pansyn-v1'} synthetic, "
                             f"{N} nodes x {P} paths per GPU (BASELINE.json configs[2]); one step = one complete call from the resident u32 "
                             f"ItemTable, every derived table dropped between steps",
                 "nodes_per_gpu": N, "paths": P, "groups": P, "steps_in_csr": S, "seed": args.seed,
@@ -1053,8 +1070,9 @@ def main():
                 "collective": args.collective if use_dist else None,
             },
             "roofline": roofline,
-            "roofline_valu": valu,
+            "roofline_valu": None,
             "step_breakdown_ms": breakdown,
+            "step_spread_ms": getattr(stepper, "step_spread_ms", None),
             "closed_forms": cf,
             "closed_forms_on_gpu": bool(growth_on_device),
             "host": {"threads": hostlib.pool_threads(), "usable_cpus": hostlib.usable_cpus(), "gpu_arch": arch},
@@ -1191,6 +1209,8 @@ def main():
     if use_dist:
         torch.cuda.synchronize()
         dist.destroy_process_group()
+    if rank == 0 and world == 1:
+        run_pmc()
     if rank == 0:
         # RCCL writes a version banner through C stdio; push it out before the one JSON line
         try:

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
             np += __shfl_down(np, o);
             na += __shfl_down(na, o);
         }
-        if ((threadIdx.x & 63u) == 0 && np) {
+        // (a sample: every 16th workgroup reports -- thousands of atomics on two words would outlast the searches)
+        if ((threadIdx.x & 63u) == 0 && np && (blockIdx.x & 15u) == 0u) {
             atomicAdd(probe_stats, np);
             if (na) atomicAdd(probe_stats + 1, na);
         }
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     // the index kernel's probes say the paths do not follow the ids (a quarter of the sectors it looked at held steps from
     // elsewhere): nearly every step would be spilled and the pass void at the end -- it is void now, and nothing is read
-    if (probe_stats[1] > 64u && (unsigned long long)probe_stats[1] * 4ull > probe_stats[0]) {
+    if (probe_stats[1] > 16u && (unsigned long long)probe_stats[1] * 4ull > probe_stats[0]) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags + 5, 8u);
         return;
     }
