@@ -2,7 +2,7 @@
 """Group x group intersections (the `similarity` accumulation, similarity.rs:119-150) on the
 presence matrix of a pansyn-v1 graph: K5 timed with HIP events on the context's stream.
 
-Work model: the kernel is VALU-bound -- one AND + one popcount-accumulate per
+Work model (DESIGN_DEADENDS.md section 4, K5): the kernel is VALU-bound -- one AND + one popcount-accumulate per
 (pair, 32-item word), pairs counted on and above the diagonal at tile granularity.
 Prints one JSON line.
 """

@@ -313,7 +313,7 @@ __device__ static inline uint64_t bsearch_before(const uint32_t *__restrict__ a,
 // inside the window we are done; otherwise the smallest / largest id seen tells how many ids are
 // still missing, and the bracket's own density (steps per id) turns that into the next guess -- the
 // error shrinks from ~sqrt(bracket) to ~sqrt(error) per probe.
-// Measured, not guessed: the index is bound by the RATE of L1->L2 requests --
+// Measured, not guessed (DESIGN_DEADENDS.md section 8): the index is bound by the RATE of L1->L2 requests --
 // 44 G requests/s against the ~50 G/s that benchmarks/micro/random_sector_rate.hip reaches with wave-
 // local 64-byte probes -- not by round trips: 32-id windows for the later probes (fewer rounds per
 // wave, more lines per probe) and windows centred on the guess (fewer probes, two lines each) both
