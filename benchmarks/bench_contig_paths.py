@@ -60,12 +60,35 @@ def main():
     prof = ctx.profile_read()
     info = ctx.info()
     S = int(info.n_steps)
+    # the COLD call: everything derived dropped before it (what a command line run pays once per count type)
+    cold = {}
+    for route, name in ((0, "default_route"), (2, "rows_route"), (1, "one_shot_route")):
+        ctx.config(capi.CFG_COVER_ROUTE, route)
+        ts = []
+        for k in range(5):
+            ctx.config(capi.CFG_DROP_DERIVED, 0)
+            ctx.set_order(order, grp, n_groups)
+            ctx.sync()
+            t1 = time.perf_counter()
+            _, hc = ctx.hist(want_countable=False)
+            if k >= 2:
+                ts.append((time.perf_counter() - t1) * 1e3)
+            assert np.array_equal(hc, h), (name, k, int(ctx.info().n_rows), int(ctx.info().n_reruns), int((hc != h).sum()), hc[:6].tolist(), h[:6].tolist())
+        ctx.profile_reset()
+        ctx.config(capi.CFG_DROP_DERIVED, 0)
+        ctx.set_order(order, grp, n_groups)
+        ctx.hist(want_countable=False)
+        ci = ctx.info()
+        cold[name] = {"ms_per_call": sorted(ts)[len(ts) // 2], "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in ctx.profile_read().items() if v[1]},
+                      "route": "one-shot" if int(ci.n_rows) == 0 else "rows", "n_reruns": int(ci.n_reruns), "band_splits": int(ci.band_splits),
+                      "frac_of_hbm_peak_on_4S_bytes": 4.0 * S / (sorted(ts)[len(ts) // 2] * 1e-3) / 8e12}
+    ctx.config(capi.CFG_COVER_ROUTE, 0)
     out = {"benchmark": "contig_paths", "nodes": N, "paths": P, "groups": n_groups, "steps": S,
            "tiles": int(info.n_tiles), "general_paths": int(info.n_general_paths),
            "nonempty_path_tile_fraction": float(args.span + 1.0 / max(int(info.n_tiles), 1)),
            "ms_per_hist": wall * 1e3,
            "kernels_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items() if v[1]},
-           "ideal_stream_ms_at_5.6TBs": 4.0 * S / 5.6e12 * 1e3, "hist_sum_ok": int(h.sum()) == N}
+           "ideal_stream_ms_at_5.6TBs": 4.0 * S / 5.6e12 * 1e3, "hist_sum_ok": int(h.sum()) == N, "cold": cold}
     print(json.dumps(out))
     ctx.close()
 

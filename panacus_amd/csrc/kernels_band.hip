@@ -446,6 +446,10 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
 
     if (batch_lo < batch_hi) {
         Seg cur = seg_of(batch_lo);
+        // (the groups of the first window, taken now: where a split begins with the LAST batch of a window the issue side has
+        // loaded the next window by the time that batch is folded)
+        fwin = (batch_lo * CW) >> 6;
+        f_g = w_g;
         uint32_t c_r0 = 0, c_batch = batch_lo;
         // one group of BAND_D loads per lane: consume `in` slot by slot, the next group's loads going out into `out` as the
         // slots are taken -- BAND_D loads in flight throughout.  (Two register sets that swap roles: with one set refilled

@@ -298,6 +298,37 @@ def test_rearranged_pansyn_device_generator_and_pass(band, n, p):
     assert info.n_reruns == before and info.n_rows == 0 and info.n_spilled_last > 0
 
 
+@pytest.mark.parametrize("n_paths,splits", [(180, 3), (252, 4), (400, 3), (1000, 7), (129, 2)])
+def test_split_boundaries_anywhere_in_a_window_of_the_visiting_order(band, n_paths, splits):
+    """many short paths (contigs), every path its own group or groups of a few: the visiting order is longer than one 64-entry
+    window and the splits begin at any entry -- also at the last batch of a window (180 paths / 3 splits: entry 60), where
+    the groups of the window being folded must not be those of the window the loads have moved on to"""
+    ctx = band
+    rng = np.random.default_rng(n_paths)
+    n = 300_000
+    span = n // 12
+    segs = []
+    for p in range(n_paths):
+        a = int(rng.integers(1, n - span + 2))
+        ids = (a + np.flatnonzero(rng.random(span) < 0.3)).astype(np.uint64)
+        segs.append(ids[::-1].copy() if p % 7 == 3 else ids)
+    items, pre = _concat(segs)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    before = ctx.info().n_reruns
+    for group_size in (1, 3):
+        order = rng.permutation(n_paths).astype(np.uint64)
+        gid = (np.arange(n_paths) // group_size).astype(np.uint64)
+        G = int(gid.max()) + 1
+        ctx.set_order(order, gid, G)
+        os.environ["PNX_BAND_SPLITS"] = str(splits)
+        try:
+            _check(ctx, items, pre, n, order, gid, G, presence=group_size == 3)
+            assert ctx.info().band_splits == splits
+        finally:
+            del os.environ["PNX_BAND_SPLITS"]
+    assert ctx.info().n_reruns == before and ctx.info().n_rows == 0
+
+
 @pytest.mark.parametrize("splits", [2, 3, 16])
 def test_bands_shared_by_several_workgroups(band, splits):
     """a small graph: the visiting order is cut at group boundaries, the counters of a band's workgroups meet in the
