@@ -257,17 +257,48 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     if (live) bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
 }
 
+// Graphs of many short paths (the contigs of an assembly-based pangenome: thousands of paths that each touch a few bands): most
+// (entry, band) cells are empty, and a workgroup that takes the visiting order four entries at a time pays a barrier and a
+// fold for every four empty cells (4 M items x 4000 paths: 0.67 ms for 1.2 GB of steps).  For such shapes the entries that DO
+// have steps on a band are listed first -- one wave per (band, split of the visiting order): the two edge positions of 64
+// entries at a time, a ballot, the survivors written in order -- and k_band_cover<SPARSE> walks the list instead of the order.
+// clist[band * n_ordered + k_lo(split) ...]: the entries, ccnt[split * n_bands + band]: how many.
+__global__ __launch_bounds__(256) void k_band_compact(const unsigned long long *__restrict__ bidx, uint32_t n_bands, uint32_t n_ordered, BandSplits sp,
+                                                      uint32_t *__restrict__ clist, uint32_t *__restrict__ ccnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t cell = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (cell >= n_bands * sp.n) return;
+    const uint32_t band = cell % n_bands, split = cell / n_bands;
+    const uint32_t k_lo = sp.k[split], k_hi = sp.k[split + 1];
+    uint32_t *out = clist + (uint64_t)band * n_ordered + k_lo;
+    uint32_t n = 0;
+    for (uint32_t k0 = k_lo; k0 < k_hi; k0 += 64u) {
+        const uint32_t k = k0 + lane;
+        bool some = false;
+        if (k < k_hi) {
+            const unsigned long long *ek = bidx + (uint64_t)k * (n_bands + 1u) + band;
+            some = (ek[0] & ~BAND_DESC) != (ek[1] & ~BAND_DESC);
+        }
+        const unsigned long long m = __ballot(some);
+        if (some) out[n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = k;
+        n += (uint32_t)__builtin_popcountll(m);
+    }
+    if (lane == 0) ccnt[cell] = n;
+}
+
 // The coverage kernel.  flags[6] += the steps found outside the band they were dealt to (spilled to sl.rec: k_band_tail);
 // flags[5] |= 1 when an index entry is inconsistent: the result of the pass is void.
 // SPLIT: the workgroups (band, split) of a band share its tiles: each adds its counters to the (zeroed) coverage vector and
 // leaves the histogram to K2.
-template <int NPL, int CW, bool WRITE_M, int BAND_D, bool SPLIT>
+// SPARSE: the entries are those of the band's list (k_band_compact) instead of the visiting order itself.
+template <int NPL, int CW, bool WRITE_M, int BAND_D, bool SPLIT, bool SPARSE>
 __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restrict__ items, const unsigned long long *__restrict__ bidx,
                                                         const uint32_t *__restrict__ ord_group, uint32_t n_ordered,
                                                         const uint8_t *__restrict__ exclude, uint32_t n_items, uint32_t n_tiles,
                                                         uint32_t *__restrict__ M, uint64_t row_words, uint32_t *__restrict__ countable,
                                                         RowHist hs, uint32_t *__restrict__ flags, uint32_t n_bands, BandSplits sp,
-                                                        BandSpill sl, const uint32_t *__restrict__ probe_stats) {
+                                                        BandSpill sl, const uint32_t *__restrict__ probe_stats,
+                                                        const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt) {
     constexpr int BT = CW;  // tiles per band = waves per workgroup
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -284,7 +315,10 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t band = SPLIT ? blockIdx.x % n_bands : blockIdx.x;
     const uint32_t split = SPLIT ? blockIdx.x / n_bands : 0u;
-    const uint32_t k_lo = SPLIT ? sp.k[split] : 0u, k_hi = SPLIT ? sp.k[split + 1] : n_ordered;  // this workgroup's entries
+    // this workgroup's entries: a range of the visiting order -- or (SPARSE) of the band's list of entries that have steps here
+    const uint32_t k_lo = SPARSE ? 0u : (SPLIT ? sp.k[split] : 0u);
+    const uint32_t k_hi = SPARSE ? ccnt[blockIdx.x] : (SPLIT ? sp.k[split + 1] : n_ordered);
+    const uint32_t *mine_list = SPARSE ? clist + (uint64_t)band * n_ordered + (SPLIT ? sp.k[split] : 0u) : nullptr;
     const uint32_t tile = band * BT + wave;
     const bool active = tile < n_tiles;  // the last band may hold fewer tiles; its spare waves still stream segments
     for (uint32_t i = threadIdx.x; i < 2 * CW * BT * 64; i += CW * 64) (&bm[0][0][0])[i] = 0;
@@ -315,10 +349,11 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     const uint32_t n_edges = n_bands + 1;  // per entry: n_bands + 1 edge positions
     auto load_swin = [&](uint32_t win) {
         swin = win;
-        const uint32_t k = win * 64u + lane;
+        const uint32_t kc = win * 64u + lane;
         uint64_t a = 0, b = 0;
         w_g = NONE;
-        if (k >= k_lo && k < k_hi) {
+        if (kc >= k_lo && kc < k_hi) {
+            const uint32_t k = SPARSE ? mine_list[kc] : kc;
             const unsigned long long *ek = bidx + (uint64_t)k * n_edges + band;
             a = ek[0];
             b = ek[1];
@@ -802,9 +837,10 @@ bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries) {
     const uint64_t n_bands = (ctx->n_blocks + BT - 1) / BT;
     if (n_bands * BAND_MAX_SPLITS < 2ull * (uint64_t)ctx->prop.multiProcessorCount) return false;
     if (n_bands < 2ull * (uint64_t)ctx->prop.multiProcessorCount && n_entries < 2 * BAND_MAX_SPLITS) return false;  // (nothing to split)
-    const uint64_t cells = n_bands * ctx->n_paths;
-    if (ctx->n_steps / cells < 512) return false;
-    if ((n_bands + 1) * n_entries * 8 > (256ull << 20)) return false;
+    // segments long enough to stream: the paths must be long (a graph of many SHORT paths -- fewer than 4096 steps each on average --
+    // has nothing but segment ends; one of many paths that each touch a few bands is fine: its empty cells are skipped, band_sparse)
+    if (ctx->n_steps / ctx->n_paths < 4096) return false;
+    if ((n_bands + 1) * n_entries * 12 > (384ull << 20)) return false;  // the index (8 bytes per cell) + the per-band entry lists (4)
     return true;
 }
 
@@ -834,8 +870,17 @@ static int ensure_spill(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+// Most (entry, band) cells empty -- fewer than 512 steps per cell on average: thousands of paths that each touch a few bands --:
+// the workgroups walk per-band lists of the entries that have steps there (k_band_compact, k_band_cover<SPARSE>)
+static bool band_sparse(const pnx_ctx *ctx, uint32_t n_bands) {
+    if (const char *e = getenv("PNX_BAND_SPARSE")) {  // measurement: 0 / 1 forces one
+        if ((e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
+    }
+    return ctx->n_ordered >= 64 && ctx->n_steps / ((uint64_t)n_bands * ctx->n_paths) < 512;
+}
+
 template <int NPL>
-static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, const BandSplits &sp) {
+static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, const BandSplits &sp, bool sparse) {
     Ticket *tk = ctx->cur;
     const RowHist hs{tk->hist_fused ? (unsigned long long *)tk->d_hist_rep : nullptr,
                      ctx->weighted ? (const uint32_t *)ctx->d_weights.p : (const uint32_t *)nullptr, ctx->n_groups};
@@ -846,17 +891,26 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, co
                            (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags,
-                           n_bands, sp, sl, (const uint32_t *)ctx->d_band_probe.p);
+                           n_bands, sp, sl, (const uint32_t *)ctx->d_band_probe.p, (const uint32_t *)tk->d_band_clist.p,
+                           (const uint32_t *)tk->d_band_ccnt.p);
     };
     // 4 waves per band, 2 loads in flight per lane: measured best on 10 M items x 256 and x 1024 paths (0.64 / 2.45 ms; 4 in flight
     // 0.67 / 2.56, 8 in flight 0.72; 8 waves per band 0.70, 2 waves 0.71) -- with every workgroup resident at once the chip holds
     // ~19 waves per CU whatever the register count, and a deeper pipeline only adds loads beyond the ends of the segments
-    if (sp.n > 1) {
-        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, true>);
-        else go(k_band_cover<NPL, BAND_CW, false, 2, true>);
+    if (sparse) {
+        if (sp.n > 1) {
+            if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, true, true>);
+            else go(k_band_cover<NPL, BAND_CW, false, 2, true, true>);
+        } else {
+            if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, false, true>);
+            else go(k_band_cover<NPL, BAND_CW, false, 2, false, true>);
+        }
+    } else if (sp.n > 1) {
+        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, true, false>);
+        else go(k_band_cover<NPL, BAND_CW, false, 2, true, false>);
     } else {
-        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, false>);
-        else go(k_band_cover<NPL, BAND_CW, false, 2, false>);
+        if (write_m) go(k_band_cover<NPL, BAND_CW, true, 2, false, false>);
+        else go(k_band_cover<NPL, BAND_CW, false, 2, false, false>);
     }
 }
 
@@ -884,6 +938,13 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
         }
         sp.k[sp.n] = no;
     }
+    const bool sparse = band_sparse(ctx, n_bands);
+    if (sparse) {
+        if ((rc = ensure(ctx, tk->d_band_clist, (size_t)n_bands * ctx->n_ordered * 4)) || (rc = ensure(ctx, tk->d_band_ccnt, (size_t)n_bands * sp.n * 4)))
+            return rc;
+        // groups without a step on a band are never met there: their part of the presence matrix is zero beforehand
+        if (write_m) PNX_HIP(ctx, hipMemsetAsync(ctx->d_M.p, 0, (size_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS * 4, ctx->s_pre));
+    }
     const bool phased = ctx->s_pre != ctx->s_main;
     const uint64_t n_zero16 = sp.n > 1 ? ((uint64_t)ctx->n_items + 1 + 3) / 4 : 0;  // (the buffer is a multiple of 256 bytes)
     prof_begin(ctx, PNX_K_INDEX, ctx->s_pre);
@@ -892,6 +953,9 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
                        (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
                        (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
                        (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p);
+    if (sparse)
+        hipLaunchKernelGGL(k_band_compact, dim3((n_bands * sp.n + 3) / 4), dim3(256), 0, ctx->s_pre, (const unsigned long long *)tk->d_tile_idx_own.p,
+                           n_bands, ctx->n_ordered, sp, (uint32_t *)tk->d_band_clist.p, (uint32_t *)tk->d_band_ccnt.p);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     // (recorded on one stream as well where the closed forms' tables are derived by the two-kernel route: that derivation starts
@@ -903,8 +967,8 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     uint32_t bits = 1;  // planes needed to count up to n_groups inclusive
     while (bits < 32 && (ctx->n_groups >> bits) != 0) ++bits;
     prof_begin(ctx, PNX_K_COVER, ctx->s_main);
-    if (bits <= 12) launch_band_cover_t<12>(ctx, write_m, n_bands, sp);
-    else if (bits <= 24) launch_band_cover_t<24>(ctx, write_m, n_bands, sp);
+    if (bits <= 12) launch_band_cover_t<12>(ctx, write_m, n_bands, sp, sparse);
+    else if (bits <= 24) launch_band_cover_t<24>(ctx, write_m, n_bands, sp, sparse);
     else {
         prof_end(ctx);
         return ctx->fail(PNX_ELIMIT, "more than 2^24-1 groups are not supported (got %u)", ctx->n_groups);
@@ -964,8 +1028,8 @@ void preload_band(unsigned what) {
     auto touch = [&a](const void *k) { (void)hipFuncGetAttributes(&a, k); };
     if (what & PNX_PRELOAD_PASS) {
         touch((const void *)k_band_index);
-        touch((const void *)k_band_cover<12, BAND_CW, false, 2, false>);
-        touch((const void *)k_band_cover<24, BAND_CW, false, 2, false>);
+        touch((const void *)k_band_cover<12, BAND_CW, false, 2, false, false>);
+        touch((const void *)k_band_cover<24, BAND_CW, false, 2, false, false>);
         touch((const void *)k_band_tail);
     }
 }

@@ -388,7 +388,7 @@ void pnx_free(pnx_ctx *ctx) {
         if (t.ev_pre) (void)hipEventDestroy(t.ev_pre);
         if (t.ev_cov) (void)hipEventDestroy(t.ev_cov);
         if (t.ev_reader) (void)hipEventDestroy(t.ev_reader);
-        for (DevBuf *b : {&t.d_block, &t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own, &t.d_group_first})
+        for (DevBuf *b : {&t.d_block, &t.d_ord_tfirst, &t.d_ord_tspan, &t.d_ord_off, &t.d_win_lo, &t.d_win_hi, &t.d_countable, &t.d_tile_idx_own, &t.d_group_first, &t.d_band_clist, &t.d_band_ccnt})
             release(*b);
     }
     if (ctx->stream_pre) (void)hipStreamDestroy(ctx->stream_pre);

@@ -69,6 +69,7 @@ struct Ticket {
     // vector, and -- when the tile index is rebuilt in every pass -- the boundary table itself
     DevBuf d_ord_tfirst, d_ord_tspan, d_ord_off, d_win_lo, d_win_hi, d_countable, d_tile_idx_own;
     DevBuf d_group_first;  // one-shot route: n_groups + 1 u32, where the entries of every group begin in the visiting order
+    DevBuf d_band_clist, d_band_ccnt;  // ... of a graph of many short paths: per band the entries that have steps there, and how many
     hipEvent_t ev_pre = nullptr, ev_cov = nullptr;  // index ready / coverage vector ready
     bool pre_recorded = false;                       // ev_pre was recorded by this pass (a one-shot pass leaves it out where nothing waits for it)
     // rows route, up to HIST_FUSED_MAX_BINS bins: the coverage kernel adds the histogram itself, into HIST_REPLICAS copies at the

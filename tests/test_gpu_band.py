@@ -298,11 +298,14 @@ def test_rearranged_pansyn_device_generator_and_pass(band, n, p):
     assert info.n_reruns == before and info.n_rows == 0 and info.n_spilled_last > 0
 
 
-@pytest.mark.parametrize("n_paths,splits", [(180, 3), (252, 4), (400, 3), (1000, 7), (129, 2)])
-def test_split_boundaries_anywhere_in_a_window_of_the_visiting_order(band, n_paths, splits):
+@pytest.mark.parametrize("sparse", ["0", "1"])
+@pytest.mark.parametrize("n_paths,splits", [(180, 3), (252, 4), (400, 3), (1000, 7), (129, 2), (700, 1)])
+def test_split_boundaries_anywhere_in_a_window_of_the_visiting_order(band, n_paths, splits, sparse):
     """many short paths (contigs), every path its own group or groups of a few: the visiting order is longer than one 64-entry
     window and the splits begin at any entry -- also at the last batch of a window (180 paths / 3 splits: entry 60), where
-    the groups of the window being folded must not be those of the window the loads have moved on to"""
+    the groups of the window being folded must not be those of the window the loads have moved on to.  sparse = "1": the
+    workgroups walk per-band lists of the entries that have steps there (k_band_compact; what such a shape takes by itself),
+    "0": the visiting order itself"""
     ctx = band
     rng = np.random.default_rng(n_paths)
     n = 300_000
@@ -321,11 +324,13 @@ def test_split_boundaries_anywhere_in_a_window_of_the_visiting_order(band, n_pat
         G = int(gid.max()) + 1
         ctx.set_order(order, gid, G)
         os.environ["PNX_BAND_SPLITS"] = str(splits)
+        os.environ["PNX_BAND_SPARSE"] = sparse
         try:
             _check(ctx, items, pre, n, order, gid, G, presence=group_size == 3)
             assert ctx.info().band_splits == splits
         finally:
             del os.environ["PNX_BAND_SPLITS"]
+            del os.environ["PNX_BAND_SPARSE"]
     assert ctx.info().n_reruns == before and ctx.info().n_rows == 0
 
 
