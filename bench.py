@@ -537,9 +537,13 @@ class OneShot:
         ctx.config(capi.CFG_DROP_DERIVED, 0)            # no rows, no index: the pass starts from the steps
         if self.rank == 0 and not os.environ.get("PANACUS_BENCH_KEEP_TABLES"):  # (the variable: an experiment, never a reported number)
             ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)  # ... and the closed forms from (n, thresholds)
+        device_side = self.growth_on_device and self.rank == 0
+        if device_side:
+            # the thresholds are known: the two small table kernels go first, while the pass's kernels are being launched (beside the
+            # pass the perc_mult rows -- LDS round trips per lane -- take 0.5 ms instead of 23 us and hold the curves up behind it)
+            hostlib.growth_tables_begin(self.P, self.thr)
         ctx.hist_async()
         pend = None
-        device_side = self.growth_on_device and self.rank == 0
         if device_side and (not self.use_dist or self.native):
             # the curves follow the pass on the device, from its own (all-reduced) counters; their tables are derived on a side
             # stream while the coverage kernel runs

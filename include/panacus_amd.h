@@ -503,6 +503,13 @@ enum { PNX_GROWTH_UNION = 0, PNX_GROWTH_CORE = 1, PNX_GROWTH_QUORUM = 2 };
 int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,
                                  const uint32_t *cov_abs, const double *quorum_rel);
 int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out);
+/* (round 5) A host that knows its thresholds BEFORE it enqueues the coverage pass tells the library here: the first part of the
+ * tables of (n, pairs) -- the log2 table, the per-pair running sums, perc_mult: two small kernels -- is enqueued at once and runs
+ * while the pass's kernels are still being launched; pnx_growth_closed_form_async with the same arguments then only adds the
+ * quorum pair's inner sums (beside the pass) and the evaluation (behind it).  Beside a coverage pass the perc_mult kernel --
+ * a chain of LDS round trips per lane -- takes 0.5 ms instead of 23 us and holds the curves up behind the pass.  No-op when the
+ * tables of these arguments are kept; optional: without it pnx_growth_closed_form_async builds everything as before. */
+int pnx_growth_tables_begin(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel);
 
 /* ---- measurement ---------------------------------------------------------------------------
  * HIP-event timing of the kernels, recorded on the context's own stream.  Slots: */

@@ -21,7 +21,7 @@ CFG_CACHE_INDEX, CFG_TILE_BLOCKS, CFG_KEEP_PRESENCE, CFG_COVER_VARIANT, CFG_INDE
 
 # every symbol include/panacus_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_abi_version", "pnx_set_csr_gfa_sized", "pnx_gfa_walks_sized", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_csr_pansyn_shard", "pnx_set_csr_pansyn_rearranged", "pnx_set_exclude",
+    "pnx_init", "pnx_free", "pnx_last_error", "pnx_version", "pnx_abi_version", "pnx_set_csr_gfa_sized", "pnx_gfa_walks_sized", "pnx_growth_tables_begin", "pnx_set_csr", "pnx_set_csr_keyed", "pnx_set_csr_pansyn", "pnx_set_csr_pansyn_shard", "pnx_set_csr_pansyn_rearranged", "pnx_set_exclude",
     "pnx_get_csr", "pnx_set_order", "pnx_hist", "pnx_hist_async", "pnx_hist_device", "pnx_hist_fetch", "pnx_hist_enqueued", "pnx_hist_enqueued_on",
     "pnx_sync", "pnx_stream", "pnx_ordered_growth", "pnx_ordered_growth_async",
     "pnx_ordered_growth_device", "pnx_ordered_growth_fetch", "pnx_ordered_growth_enqueued", "pnx_profile_enable", "pnx_profile_read",

@@ -861,23 +861,28 @@ int pnx_log2_exact(pnx_ctx *ctx, const double *x, double *y, uint64_t n) {
     return PNX_OK;
 }
 
-// The growth tables of (n, pairs): built on stream_cf when a call comes with arguments other than the kept ones.
-// after: an event the table kernels wait for (or nullptr).  Beside a one-shot coverage pass (kernels_band.hip) that is the end of
-// its index kernel: every workgroup of the coverage kernel lives as long as the kernel, so one that finds its CU taken by a
-// table kernel that started first runs AFTER the others -- the pass then takes up to twice as long (10 M x 1 k paths: 2.45 ->
-// 3.67 ms with the tables of n = 1024 started first, measured).  Started behind the index, the table kernels find the coverage
-// kernel already resident and take the wave slots and the LDS it leaves.
-static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel,
-                                hipEvent_t after = nullptr) {
-    pnx_ctx::GrowthTables &g = ctx->gtab;
-    bool same = g.valid && g.n == n && g.T == n_pairs;
+static bool growth_params_are(const pnx_ctx::GrowthTables &g, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs,
+                              const double *quorum_rel) {
+    bool same = g.n == n && g.T == n_pairs;
     for (uint32_t t = 0; same && t < n_pairs; ++t)
         same = g.branch[t] == branch[t] && g.cov[t] == cov_abs[t] && std::memcmp(&g.quorum[t], &quorum_rel[t], sizeof(double)) == 0;
-    if (same) return PNX_OK;
+    return same;
+}
+
+// First part of a build: buffers, parameters, k_cf_setup, k_cf_rows -- one and fifteen waves (n = 256) that do not take a coverage
+// kernel's place on the chip, and that must not run BESIDE one either: a lane of k_cf_rows walks m through an LDS tile, and on a CU
+// whose LDS pipe is full of a pass's ds_or traffic that walk takes 0.5 ms instead of 23 us; the quorum kernel behind it then
+// outlasts the pass and the curves wait for it (0.77 instead of 0.71 ms a histgrowth step, as seen in the kernel trace).  A host
+// that knows its thresholds before it enqueues the pass calls pnx_growth_tables_begin first: this part then runs while the
+// pass's kernels are still being launched.
+static int growth_tables_first_part(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs,
+                                    const double *quorum_rel, hipEvent_t wait_first = nullptr) {
+    pnx_ctx::GrowthTables &g = ctx->gtab;
     // calls in flight read the kept tables: they finish first (a change of thresholds between pipelined calls is the rare case)
     for (auto &sl : ctx->gslot)
         if (sl.pending && sl.done) PNX_HIP(ctx, hipEventSynchronize(sl.done));
     g.valid = false;
+    g.first_part_done = false;
     const size_t np1 = (size_t)n + 1, T = n_pairs;
     bool any_quorum = false;
     for (uint32_t t = 0; t < n_pairs; ++t) any_quorum |= branch[t] == PNX_GROWTH_QUORUM;
@@ -900,8 +905,10 @@ static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, cons
         h_br[t] = g.branch[t] = branch[t];
         h_cov[t] = g.cov[t] = cov_abs[t];
     }
+    g.n = n;
+    g.T = n_pairs;
     PNX_HIP(ctx, hipMemcpyAsync(g.d_par.p, h, par_bytes, hipMemcpyHostToDevice, st));
-    if (after) PNX_HIP(ctx, hipStreamWaitEvent(st, after, 0));
+    if (wait_first) PNX_HIP(ctx, hipStreamWaitEvent(st, wait_first, 0));
     const double *d_q = (const double *)g.d_par.p;
     const uint32_t *d_br = (const uint32_t *)((const char *)g.d_par.p + T * 8), *d_cov = d_br + T;
     const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
@@ -916,6 +923,29 @@ static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, cons
     hipLaunchKernelGGL(k_cf_rows, dim3((unsigned)((np1 + 63) / 64), n_pairs), dim3(64), lds_rows, st, n, (const double *)g.d_L.p, d_br, d_cov,
                        (double *)g.d_pm.p);
     PNX_HIP(ctx, hipGetLastError());
+    g.first_part_done = true;
+    return PNX_OK;
+}
+
+// The growth tables of (n, pairs): built on stream_cf when a call comes with arguments other than the kept ones.
+// after: an event the quorum kernels wait for (or nullptr).  Beside a one-shot coverage pass (kernels_band.hip) that is the end of
+// its index kernel: every workgroup of the coverage kernel lives as long as the kernel, so one that finds its CU taken by a
+// table kernel that started first runs AFTER the others -- the pass then takes up to twice as long (10 M x 1 k paths: 2.45 ->
+// 3.67 ms with the tables of n = 1024 started first, measured).  Started behind the index, the table kernels find the coverage
+// kernel already resident and take the wave slots and the LDS it leaves.
+static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel,
+                                hipEvent_t after = nullptr) {
+    pnx_ctx::GrowthTables &g = ctx->gtab;
+    const bool same = growth_params_are(g, n, n_pairs, branch, cov_abs, quorum_rel);
+    if (g.valid && same) return PNX_OK;
+    int rc;
+    // (built here, beside a pass: everything behind the pass's index kernel, as before -- above 384 groups the rows kernel, starved
+    // beside the pass, is what holds the quorum kernels back until the pass is four fifths through: pnx_growth_tables_begin)
+    if (!(g.first_part_done && same) && (rc = growth_tables_first_part(ctx, n, n_pairs, branch, cov_abs, quorum_rel, after))) return rc;
+    g.first_part_done = false;
+    const size_t np1 = (size_t)n + 1;
+    hipStream_t st = ctx->stream_cf;
+    if (after) PNX_HIP(ctx, hipStreamWaitEvent(st, after, 0));
     for (uint32_t t = 0; t < n_pairs; ++t) {
         if (branch[t] != PNX_GROWTH_QUORUM) continue;
         if ((rc = launch_quorum_sums(ctx, st, g.d_terms, n, cov_abs[t], (const uint32_t *)g.d_mq.p + t * np1, (const double *)g.d_L.p,
@@ -926,12 +956,30 @@ static int ensure_growth_tables(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, cons
     }
     PNX_HIP(ctx, hipGetLastError());
     PNX_HIP(ctx, hipEventRecord(g.ready, st));
-    g.n = n;
-    g.T = n_pairs;
     g.gen += 1;
     g.n_builds += 1;
     g.valid = true;
     return PNX_OK;
+}
+
+int pnx_growth_tables_begin(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs, const double *quorum_rel) {
+    if (!ctx) return PNX_EINVAL;
+    if (!branch || !cov_abs || !quorum_rel || n == 0 || n > PNX_GROWTH_MAX_N || n_pairs == 0 || n_pairs > PNX_GROWTH_MAX_PAIRS)
+        return ctx->fail(PNX_EINVAL, "pnx_growth_tables_begin: bad arguments (1 <= n <= %d, 1 <= pairs <= %d)", PNX_GROWTH_MAX_N, PNX_GROWTH_MAX_PAIRS);
+    for (uint32_t t = 0; t < n_pairs; ++t)
+        if (branch[t] > PNX_GROWTH_QUORUM || cov_abs[t] == 0) return ctx->fail(PNX_EINVAL, "pnx_growth_tables_begin: bad threshold pair %u", t);
+    PNX_HIP(ctx, hipSetDevice(ctx->device));
+    pnx_ctx::GrowthTables &g = ctx->gtab;
+    const bool same = growth_params_are(g, n, n_pairs, branch, cov_abs, quorum_rel);
+    if ((g.valid || g.first_part_done) && same) return PNX_OK;  // kept, or begun already
+    // Above 384 groups the quorum pair's inner sums go through HBM (two kernels, 1.8 GB at n = 1024), and the sooner they start
+    // beside a coverage pass the more they cost it: 10 M x 1 k paths, the pass 2.67 ms with them over its last fifth (where the
+    // rows kernel, starved beside the pass, happens to hold them back), 3.5 ms with them over all of it -- 3.27 against 3.94 ms a
+    // step (DESIGN_DEADENDS 10).  There the build stays where it was: inside pnx_growth_closed_form_async, behind the pass's index.
+    bool any_quorum = false;
+    for (uint32_t t = 0; t < n_pairs; ++t) any_quorum |= branch[t] == PNX_GROWTH_QUORUM;
+    if (any_quorum && !quorum_route_fused(n)) return PNX_OK;
+    return growth_tables_first_part(ctx, n, n_pairs, branch, cov_abs, quorum_rel);
 }
 
 int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,

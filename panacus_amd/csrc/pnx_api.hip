@@ -1421,6 +1421,7 @@ int pnx_config(pnx_ctx *ctx, int key, int64_t value) {
             for (auto &sl : ctx->gslot)
                 if (sl.pending && sl.done) PNX_HIP(ctx, hipEventSynchronize(sl.done));
             ctx->gtab.valid = false;
+            ctx->gtab.first_part_done = false;
             return PNX_OK;
         case PNX_CFG_DROP_DERIVED:
             if (ctx->d_rows.borrowed || ctx->d_steps12.borrowed) return ctx->fail(PNX_EINVAL, "this context borrows its graph (pnx_share_csr)");

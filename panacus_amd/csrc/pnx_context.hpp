@@ -282,6 +282,7 @@ struct pnx_ctx {
     // as tables shared by all calls; a call has a slot with its own stream, so that calls in flight run beside each other
     struct GrowthTables {
         bool valid = false;
+        bool first_part_done = false;  // setup + perc_mult rows of (n, pairs) are enqueued (pnx_growth_tables_begin); the quorum part is not
         uint32_t n = 0, T = 0;
         uint32_t branch[PNX_GROWTH_MAX_PAIRS] = {}, cov[PNX_GROWTH_MAX_PAIRS] = {};
         double quorum[PNX_GROWTH_MAX_PAIRS] = {};

@@ -29,6 +29,8 @@ struct pnx_ctx;
 extern "C" int pnx_quorum_sums_async(pnx_ctx *ctx, uint32_t n, uint32_t c, const uint32_t *m_quorum,
                                      const double *log2_tab, const double *m_fact, const double *n_fall);
 extern "C" int pnx_quorum_sums_fetch(pnx_ctx *ctx, const double **sum_q);
+extern "C" int pnx_growth_tables_begin(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, const uint32_t *branch, const uint32_t *cov_abs,
+                                       const double *quorum_rel);
 extern "C" int pnx_growth_closed_form_async(pnx_ctx *ctx, const uint64_t *hist, uint32_t n, uint32_t n_pairs, const uint32_t *branch,
                                             const uint32_t *cov_abs, const double *quorum_rel);
 extern "C" int pnx_growth_closed_form_fetch(pnx_ctx *ctx, double *out);
@@ -563,6 +565,30 @@ bool start_device_growth(GrowthRun &run, const uint64_t *hist) {
     return true;
 }
 }  // namespace
+
+// The thresholds are known before the coverage pass is enqueued: the first part of the device tables of (n, pairs) -- two small
+// kernels -- is started now and runs while the pass's kernels are being launched (pnx_growth_tables_begin); false: the device path
+// would not take these arguments anyway.
+bool growth_tables_begin(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum) {
+    pnx_ctx *ctx = nullptr;
+    uint64_t min_n = 0;
+    {
+        std::lock_guard<std::mutex> g(g_offload_mu);
+        ctx = g_offload_ctx;
+        min_n = g_offload_min_n;
+    }
+    const size_t n_pairs = coverage.size();
+    if (!ctx || n < min_n || n < 2 || n > 2048 || n_pairs == 0 || n_pairs > 16 || quorum.size() != n_pairs || !device_growth_usable()) return false;
+    std::vector<uint32_t> br(n_pairs), cv(n_pairs);
+    std::vector<double> qr(n_pairs, 0.0);
+    for (size_t t = 0; t < n_pairs; ++t) {
+        const Branch b = dispatch(n, quorum[t]);  // Hist::calc_growth, hist.rs:51-66
+        br[t] = b == UNION ? 0u : (b == CORE ? 1u : 2u);
+        cv[t] = (uint32_t)std::max<uint64_t>(1, coverage[t].to_absolute(b == CORE ? n + 1 : n));  // hist.rs:91, :118, :142
+        if (b == QUORUM) qr[t] = quorum[t].to_relative(n);
+    }
+    return pnx_growth_tables_begin(ctx, (uint32_t)n, (uint32_t)n_pairs, br.data(), cv.data(), qr.data()) == 0;
+}
 
 GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::vector<Threshold> &coverage,
                                   const std::vector<Threshold> &quorum, unsigned n_threads) {

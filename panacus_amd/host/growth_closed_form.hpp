@@ -47,6 +47,8 @@ std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *run);
 // the curves of the histogram of the coverage pass enqueued last on the offload context, computed without the histogram
 // visiting the host (nullptr: not available -- fetch the histogram and use calc_all_growths_begin)
 GrowthRun *calc_all_growths_begin_on_device(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum);
+// before the coverage pass is enqueued: start the first part of the device tables of (n_groups, pairs) (false: not on the device)
+bool growth_tables_begin(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum);
 // true iff the restated log2 AND exp2 reproduce this platform's libm bit for bit: whole closed forms may run on the device
 bool device_growth_usable();
 void log2_restated(const double *x, double *y, uint64_t n);

@@ -327,6 +327,14 @@ void *pnh_calc_all_growths_begin(const uint64_t *hist, uint64_t hist_len, const 
     if (!hist && hist_len >= 2) return pnh::calc_all_growths_begin_on_device(hist_len - 1, cov, quo);  // the device's own counters
     return pnh::calc_all_growths_begin(h, cov, quo, n_threads);
 }
+int pnh_growth_tables_begin(uint64_t n_groups, const int *cov_kind, const double *cov_val, const int *quo_kind, const double *quo_val, uint32_t n_pairs) {
+    std::vector<pnh::Threshold> cov, quo;
+    for (uint32_t t = 0; t < n_pairs; ++t) {
+        cov.push_back(pnh::Threshold{cov_kind[t], cov_val[t]});
+        quo.push_back(pnh::Threshold{quo_kind[t], quo_val[t]});
+    }
+    return pnh::growth_tables_begin(n_groups, cov, quo) ? 1 : 0;
+}
 int64_t pnh_calc_all_growths_end(void *handle, uint64_t n, uint32_t n_pairs, double *out) {
     std::vector<std::vector<double>> g = pnh::calc_all_growths_end(static_cast<pnh::GrowthRun *>(handle));
     for (uint32_t t = 0; t < n_pairs && t < g.size(); ++t)

@@ -105,6 +105,18 @@ def _pair_arrays(pairs):
     return a
 
 
+def growth_tables_begin(n_groups: int, pairs) -> bool:
+    """Before the coverage pass is enqueued: the first part of the device tables of (n_groups, pairs) -- two small kernels that must
+    not run beside the pass -- is started now (pnx_growth_tables_begin).  False: the device path does not take these arguments."""
+    L = load()
+    if not getattr(L, "_tables_begin_bound", False):
+        L.pnh_growth_tables_begin.restype = C.c_int
+        L.pnh_growth_tables_begin.argtypes = [C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_uint32]
+        L._tables_begin_bound = True
+    ck, cv, qk, qv = _pair_arrays(pairs)
+    return bool(L.pnh_growth_tables_begin(n_groups, ck, cv, qk, qv, len(pairs)))
+
+
 def calc_growths_begin_on_device(n_groups: int, pairs):
     """The curves of the histogram of the coverage pass enqueued LAST on the offload context (set_quorum_offload),
     computed on the device without the histogram visiting the host.  None when the device path cannot take it (no
