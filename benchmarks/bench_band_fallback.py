@@ -1,5 +1,7 @@
-"""What a graph with ONE path that is not sorted costs on its first sweep: the one-shot route is tried (its index meets steps
-out of order, or its coverage kernel a step outside its band), the pass is void, the path rows take over.
+"""What a graph with ONE path that is not sorted costs on its first sweep, beside the same graph with every path sorted and
+through the path rows: a path with no order at all (shuffled) is recognised by the index kernel, its group left to a bitmap that
+the pass's tail folds in (kernels_band.hip: BandLoose); two steps swapped across bands are spilled and added by the tail.
+Neither runs a pass again (reruns_total stays 0).
 
   python benchmarks/bench_band_fallback.py [--nodes 6000000] [--paths 16]
 """

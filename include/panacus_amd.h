@@ -639,7 +639,9 @@ typedef struct {
     uint64_t n_spilled_total;/* (round 5) ... summed over the settled one-shot passes of this upload */
     uint32_t n_spill_bursts_last; /* (round 5) ... of the pass settled last, in this many bursts (one burst = what one wave found in one
                                 16-byte-per-lane load: up to 256 consecutive steps of one path) */
-    uint32_t reserved0;
+    uint32_t n_loose_groups_last; /* (round 5) groups with a path that does not follow the ids at all (a shuffled path) which the
+                                     one-shot pass settled last left to per-group bitmaps instead of the bands; at most 16 per pass,
+                                     beyond that the pass is void and the path rows take over (n_reruns) */
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

@@ -59,6 +59,27 @@ constexpr int SCAN_U = 4;                   // 16-byte loads a lane of k_band_ta
 constexpr uint32_t BAND_TAIL_WAVES = 8;     // waves per workgroup of k_band_tail (a wave takes one burst of the spill list at a time)
 constexpr uint32_t BAND_TAIL_GRID = 1024;   // ... and its workgroups
 
+constexpr uint32_t LOOSE_MAX = 16;          // groups with paths that do not follow the ids at all which one pass takes in
+constexpr uint32_t LOOSE_WORKGROUPS = 256;  // the first workgroups of k_band_tail's grid: they mark the steps of such groups and fold the bitmaps
+
+// Groups with a path that does not follow the ids AT ALL (a shuffled path; edge ids in the order of the L lines): no position
+// deals its steps to bands.  The index kernel recognises such a path by the sectors it samples along it (most of them hold
+// steps that go up AND down), skips the searches and flags the path's GROUP and every entry of it; the coverage kernel leaves
+// the flagged entries out; the first LOOSE_WORKGROUPS workgroups of the tail kernel stream those groups' steps, setting presence
+// bits in a bitmap per group (the block layout of a row of the presence matrix; 1.25 MB for 10 M ids: the atomics stay in the
+// L2s), wait for each other, and fold the bitmaps into the coverage vector and the histogram, tile by tile, clearing them.
+// AbacusByTotal::coverage (abacus.rs:727-742) counts a group once per item however its steps are ordered: the result is exact.
+// More than LOOSE_MAX such groups, or more steps in them than an eighth of the graph (one atomic per step is no way to read a
+// graph): the pass is void and the path rows take over.
+// state (= the probe statistics' block): [0] probes, [1] probes astray, [2] flagged groups, [3] their steps / 1024, [4 .. 4 + LOOSE_MAX) which ones;
+// the tail kernel of every pass sets it, and the flags of the groups, back to zero.
+struct BandLoose {
+    uint32_t *state;
+    uint32_t *group_flag;  // n_groups words: nonzero = every entry of the group is left to the bitmaps
+    uint32_t *entry_flag;  // n_ordered words: the same per entry of the visiting order (what the coverage kernel reads)
+    uint32_t *bits;        // LOOSE_MAX bitmaps of n_tiles x 64 words, zero between passes
+};
+
 // the visiting order cut at group boundaries: split s takes the entries [k[s], k[s + 1])
 struct BandSplits {
     uint32_t n;
@@ -91,7 +112,8 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
     uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
     uint32_t klo = ka, khi = kz;    // ... those two keys: what a step between the two positions of a sorted path lies between
     double pa = 0.0, va = (double)ka, pb = (double)(len - 1), vb = (double)kz;  // the two points of the secant
-    for (int iter = 0; hi - lo > 1; ++iter) {
+    uint32_t astray_here = 0;  // (a search that keeps meeting steps from elsewhere is not converging on anything: any position will do)
+    for (int iter = 0; hi - lo > 1 && astray_here < 8u; ++iter) {
         uint64_t g = lo + ((hi - lo) >> 1);
         if (iter < 8 && vb != va) {
             const double t = pb + ((double)X - vb) * (pb - pa) / (vb - va);
@@ -116,6 +138,7 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
         }
         n_probes += 1;
         n_astray += astray ? 1u : 0u;
+        astray_here += astray ? 1u : 0u;
         const uint32_t n = i1 - i0 + 1;
         if (below != 0 && below != n) return a0 + i0 + below - ps;  // the crossing lies in the sector
         pa = pb;
@@ -149,7 +172,8 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
                                                     uint32_t n_ordered, uint32_t n_groups, uint32_t n_bands, uint32_t band_items,
                                                     unsigned long long *__restrict__ bidx, uint32_t *__restrict__ group_first,
                                                     uint4 *__restrict__ block16, uint32_t n_block16, uint4 *__restrict__ zero16,
-                                                    uint64_t n_zero16, uint32_t *__restrict__ probe_stats) {
+                                                    uint64_t n_zero16, uint32_t *__restrict__ probe_stats, uint32_t *__restrict__ group_loose,
+                                                    uint32_t *__restrict__ entry_loose) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_threads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < n_block16; q += n_threads) block16[q] = make_uint4(0, 0, 0, 0);
@@ -172,7 +196,63 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         ps = path_off[p];
         len = path_off[p + 1] - ps;
     }
-    if (len) {
+    // ---- does the path follow the ids at all?  Every lane looks at one 64-byte sector of its path (the lanes of a wave hold
+    // consecutive edges of one path: their sectors are spread evenly along it): on a path that runs through the ids -- upwards
+    // or downwards, with blocks reversed, repeated or from elsewhere -- the 15 steps from one id to the next inside a sector go
+    // ONE way; where more than a quarter of them go the other way the sector is jumbled, and a path most of whose sectors are
+    // is LOOSE: no search (each would take its full 30 probes, and mean nothing), its group flagged (BandLoose).  The verdict
+    // is per wave; a path whose waves disagree is loose, since ANY wave's flag takes the whole group out of the bands.
+    bool sampled = false, jumbled = false;
+    if (len >= 1024) {
+        const uint64_t pos = (uint64_t)e * (len - 16) / n_bands;
+        uint64_t a0 = (ps + pos) & ~15ull;
+        if (a0 < ps) a0 += 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(items + a0);
+        const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        const uint32_t w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        uint32_t up = 0, down = 0;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            up += w[i + 1] > w[i] ? 1u : 0u;
+            down += w[i + 1] < w[i] ? 1u : 0u;
+        }
+        sampled = true;
+        jumbled = up + down >= 8u && (up < down ? up : down) * 4u > up + down;
+    }
+    bool loose = false;
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        unsigned long long rem = __ballot(sampled);
+        while (rem) {  // (wave-uniform: once per path that has lanes in this wave)
+            const uint32_t l0 = (uint32_t)__ffsll((long long)rem) - 1u;
+            const uint32_t kk = (uint32_t)__shfl((int)k, (int)l0);
+            const unsigned long long same = __ballot(sampled && k == kk), jum = __ballot(sampled && k == kk && jumbled);
+            const bool lw = (uint32_t)__builtin_popcountll(jum) * 2u > (uint32_t)__builtin_popcountll(same);
+            if (lw && k == kk) loose = true;
+            if (lw && lane == l0) {
+                const uint32_t g = ord_group[kk];
+                if (atomicOr(group_loose + g, 1u) == 0u) {  // the first to flag the group enters it into the list, and flags its entries
+                    const uint32_t li = atomicAdd(probe_stats + 2, 1u);
+                    if (li < LOOSE_MAX) probe_stats[4u + li] = g;
+                    uint32_t k0 = kk, k1 = kk + 1u;
+                    while (k0 > 0u && ord_group[k0 - 1u] == g) --k0;
+                    while (k1 < n_ordered && ord_group[k1] == g) ++k1;
+                    uint64_t vol = 0;  // the steps of the group: what the tail kernel will have to mark, one atomic each
+                    for (uint32_t q = k0; q < k1; ++q) {
+                        entry_loose[q] = 1u;
+                        vol += path_off[ord_path[q] + 1] - path_off[ord_path[q]];
+                    }
+                    atomicAdd(probe_stats + 3, (uint32_t)((vol + 1023u) >> 10));
+                }
+            }
+            rem &= ~same;
+        }
+    }
+    if (len && loose) {
+        const uint64_t pr = (uint64_t)e * len / n_bands;  // (never read: the coverage kernel leaves the group out)
+        desc = items[ps] > items[ps + len - 1];
+        j = desc ? len - pr : pr;
+    } else if (len) {
         const uint32_t a = items[ps], z = items[ps + len - 1];
         desc = a > z;
         uint32_t ka_fix = 0xFFFFFFFFu, kz_fix = 0u;  // (keys of the inner samples: smallest, largest)
@@ -298,7 +378,8 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
                                                         uint32_t *__restrict__ M, uint64_t row_words, uint32_t *__restrict__ countable,
                                                         RowHist hs, uint32_t *__restrict__ flags, uint32_t n_bands, BandSplits sp,
                                                         BandSpill sl, const uint32_t *__restrict__ probe_stats,
-                                                        const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt) {
+                                                        const uint32_t *__restrict__ clist, const uint32_t *__restrict__ ccnt,
+                                                        const uint32_t *__restrict__ entry_loose) {
     constexpr int BT = CW;  // tiles per band = waves per workgroup
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -313,11 +394,12 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t band = SPLIT ? blockIdx.x % n_bands : blockIdx.x;
-    const uint32_t split = SPLIT ? blockIdx.x / n_bands : 0u;
+    const uint32_t bid = blockIdx.x;
+    const uint32_t band = SPLIT ? bid % n_bands : bid;
+    const uint32_t split = SPLIT ? bid / n_bands : 0u;
     // this workgroup's entries: a range of the visiting order -- or (SPARSE) of the band's list of entries that have steps here
     const uint32_t k_lo = SPARSE ? 0u : (SPLIT ? sp.k[split] : 0u);
-    const uint32_t k_hi = SPARSE ? ccnt[blockIdx.x] : (SPLIT ? sp.k[split + 1] : n_ordered);
+    const uint32_t k_hi = SPARSE ? ccnt[bid] : (SPLIT ? sp.k[split + 1] : n_ordered);
     const uint32_t *mine_list = SPARSE ? clist + (uint64_t)band * n_ordered + (SPLIT ? sp.k[split] : 0u) : nullptr;
     const uint32_t tile = band * BT + wave;
     const bool active = tile < n_tiles;  // the last band may hold fewer tiles; its spare waves still stream segments
@@ -355,9 +437,11 @@ __global__ __launch_bounds__(CW * 64) void k_band_cover(const uint32_t *__restri
         if (kc >= k_lo && kc < k_hi) {
             const uint32_t k = SPARSE ? mine_list[kc] : kc;
             const unsigned long long *ek = bidx + (uint64_t)k * n_edges + band;
+            const uint32_t lz = entry_loose[k];
             a = ek[0];
             b = ek[1];
             w_g = ord_group[k];
+            if (lz != 0u) a = b = 0;  // an entry of a group left to the bitmaps (BandLoose): no steps of it here
         }
         if (((a ^ b) & BAND_DESC) != 0) bad = true;
         a &= ~BAND_DESC;
@@ -571,6 +655,11 @@ struct BandTail {
     uint32_t *probe_stats;     // the index kernel's two sums (probes, probes that met steps astray): set back to zero for the next pass
     uint32_t *host_block;      // [flags u32[8] | hist] in the ticket's pinned memory, or nullptr
     uint32_t scan_budget;      // steps the spill scans may read in all, in units of 1024
+    BandLoose lo;              // the groups that were left to bitmaps, and the bitmaps
+    const uint64_t *path_off;  // ... their paths
+    const uint32_t *ord_path;
+    uint32_t n_tiles, n_groups, n_ordered;
+    uint32_t loose_budget;     // steps the loose groups may hold in all, in units of 1024
 };
 
 typedef __attribute__((address_space(1))) uint32_t g_u32;
@@ -630,10 +719,111 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t bmp_all[BAND_TAIL_WAVES][256];  // per wave: the 8192 ids of one band
     __shared__ uint32_t s_last;
+    extern __shared__ unsigned long long t_hist[];  // n_groups + 1 bins (a pass that adds its histogram itself): what the bitmaps move
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *bmp = bmp_all[wave];
     const TailAdd add{a};
+    // ---- the groups that were left to bitmaps (BandLoose), by the first LOOSE_WORKGROUPS workgroups of the grid (they are
+    // dispatched first, so all of them get to run whatever else is on the chip: they may wait for each other).  First the
+    // groups' steps, wherever they lie, become presence bits of the group's bitmap; then -- all marks made -- a wave takes a
+    // tile at a time and adds every such group's presence word to the tile's items: coverage word + 1 (atomically: the spilled
+    // steps below add to the same vector), the item's weight moved from bin `old` to bin `old + 1` in the workgroup's LDS
+    // bins; it writes the group's row of the presence matrix and clears the bitmap behind it.  (state[2]: how many groups;
+    // beyond LOOSE_MAX nothing is marked and the pass is void: the path rows serve any path.)
+    const uint32_t nl_raw = a.lo.state[2];
+    const bool loose_ok = nl_raw <= LOOSE_MAX && a.lo.state[3] <= a.loose_budget;  // (state[3]: their steps, in units of 1024)
+    const uint32_t nl = loose_ok ? nl_raw : 0u;
+    if (!loose_ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.flags + 5, 16u);
+    if (nl && blockIdx.x < LOOSE_WORKGROUPS) {
+        const uint32_t bins = a.n_groups + 1u;
+        if (a.hs.rep)
+            for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) t_hist[b] = 0;
+        const uint64_t wid = (uint64_t)blockIdx.x * BAND_TAIL_WAVES + wave, n_waves = (uint64_t)LOOSE_WORKGROUPS * BAND_TAIL_WAVES;
+        bool bad_id = false;
+        for (uint32_t li = 0; li < nl; ++li) {
+            const uint32_t g = a.lo.state[4u + li];
+            uint32_t *bits = a.lo.bits + (uint64_t)li * a.n_tiles * BLOCK_WORDS;
+            for (uint32_t k = a.group_first[g]; k < a.group_first[g + 1]; ++k) {
+                const uint32_t p = a.ord_path[k];
+                const uint64_t ps = a.path_off[p], pe = a.path_off[p + 1];
+                for (uint64_t c = (ps & ~3ull) + wid * 1024u; c < pe; c += n_waves * 1024u) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t q = c + (uint64_t)u * 256u + lane * 4u;
+                        v[u] = q < pe ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.items + q)) : u32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint64_t q = c + (uint64_t)u * 256u + lane * 4u;
+                        const uint32_t ids[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t id = ids[e];
+                            if (q + (uint32_t)e >= ps && q + (uint32_t)e < pe) {
+                                if (id - 1u < a.n_items)
+                                    __hip_atomic_fetch_or(bits + (uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u), 1u << ((id >> 6) & 31u), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+                                else bad_id = true;  // (an id that is no item: the rows route reports it)
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(bad_id) && lane == 0) atomicOr(a.flags + 5, 32u);
+        // all marks of all the marking workgroups made (device-scope atomics, acknowledged) before any bitmap is read
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add((g_u32 *)(a.scratch + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (agent_load(a.scratch + 2) < LOOSE_WORKGROUPS) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+        for (uint32_t tile = blockIdx.x * BAND_TAIL_WAVES + wave; tile < a.n_tiles; tile += LOOSE_WORKGROUPS * BAND_TAIL_WAVES) {
+            uint32_t excl = 0xFFFFFFFFu;  // (computed for the first bitmap that holds anything on the tile)
+            for (uint32_t li = 0; li < nl; ++li) {
+                uint32_t *word = a.lo.bits + ((uint64_t)li * a.n_tiles + tile) * BLOCK_WORDS + lane;
+                uint32_t x = agent_load(word);
+                if (__ballot(x != 0u) == 0ull) continue;
+                if (x) *word = 0;
+                if (excl == 0xFFFFFFFFu) excl = tile_exclusion_word(a.exclude, tile, lane, a.n_items);
+                x &= ~excl;
+                const uint32_t g = a.lo.state[4u + li];
+                if (a.M) a.M[(uint64_t)g * a.row_words + (uint64_t)tile * BLOCK_WORDS + lane] = x;
+                // (eight coverage words at a time: their atomics are on their way together, the bins follow when the old values are back)
+                for (uint32_t b0 = 0; b0 < 32; b0 += 8) {
+                    if (__ballot(((x >> b0) & 0xFFu) != 0u) == 0ull) continue;
+                    uint32_t old[8];
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) {
+                        const uint32_t id = tile * BLOCK_ITEMS + (b0 + j) * 64u + lane;
+                        old[j] = ((x >> (b0 + j)) & 1u) ? atomicAdd(a.countable + id, 1u) : 0xFFFFFFFFu;
+                    }
+                    if (a.hs.rep) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j) {
+                            if (old[j] < a.n_groups) {
+                                const uint32_t id = tile * BLOCK_ITEMS + (b0 + j) * 64u + lane;
+                                const unsigned long long w = a.hs.weights ? (unsigned long long)a.hs.weights[id] : 1ull;
+                                atomicAdd(&t_hist[old[j]], 0ull - w);
+                                atomicAdd(&t_hist[old[j] + 1u], w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (a.hs.rep) {
+            __syncthreads();
+            unsigned long long *rep = a.hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * bins;
+            for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) {
+                const unsigned long long x = t_hist[b];
+                if (x) atomicAdd(&rep[b], x);
+            }
+        }
+    }
     uint32_t n = agent_load(a.flags + 6), n_bursts = agent_load(a.flags + 7);
     if (n > a.sl.cap || n_bursts > a.sl.dir_cap) {  // the list did not hold them all: the pass is void
         if (threadIdx.x == 0) atomicOr(a.flags + 5, 2u);
@@ -772,7 +962,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
     if (vol_acc && lane == 0 && atomicAdd(a.scratch + 1, vol_acc) + vol_acc > a.scan_budget) atomicOr(a.flags + 5, 4u);
     // ---- the histogram is handed over: by workgroup 0 when the list was empty (every workgroup knows: the count was final
     // when the kernel began), else by the last workgroup to arrive ----
-    if (n_bursts) {
+    if (n_bursts || nl_raw) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // (what this workgroup wrote for others it wrote with device-scope atomics, which are performed where every XCD sees
@@ -808,8 +998,21 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
             }
         }
     }
-    if (a.host_block && threadIdx.x < 8) a.host_block[threadIdx.x] = agent_load(a.flags + threadIdx.x);
-    if (threadIdx.x < 2) a.probe_stats[threadIdx.x] = 0;
+    if (a.host_block && threadIdx.x < 8) a.host_block[threadIdx.x] = threadIdx.x == 3 ? nl_raw : agent_load(a.flags + threadIdx.x);
+    if (!a.host_block && threadIdx.x == 0) a.flags[3] = nl_raw;  // (the pass's own copy of the block to the host follows this kernel)
+    // the index kernel's block goes back to zero for the next pass: its statistics, the flags of the groups it found loose
+    if (nl_raw > LOOSE_MAX) {
+        for (uint32_t g = threadIdx.x; g < a.n_groups; g += blockDim.x) a.lo.group_flag[g] = 0;
+        for (uint32_t k = threadIdx.x; k < a.n_ordered; k += blockDim.x) a.lo.entry_flag[k] = 0;
+    } else {
+        for (uint32_t li = 0; li < nl_raw; ++li) {
+            const uint32_t g = a.lo.state[4u + li];
+            for (uint32_t k = a.group_first[g] + threadIdx.x; k < a.group_first[g + 1]; k += blockDim.x) a.lo.entry_flag[k] = 0;
+            if (threadIdx.x == 0) a.lo.group_flag[g] = 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) a.probe_stats[threadIdx.x] = 0;
 }
 
 // The shapes the band route is worth it for: enough bands (times the splits of the visiting order) to fill the chip,
@@ -852,9 +1055,19 @@ static int ensure_spill(pnx_ctx *ctx) {
     uint64_t slots = 1;
     while (slots < 2 * cap) slots <<= 1;
     int rc;
-    if (!ctx->d_band_probe.p) {  // the index kernel's probe statistics: zero once, every pass's tail sets them back
-        if ((rc = ensure(ctx, ctx->d_band_probe, 16))) return rc;
-        PNX_HIP(ctx, hipMemsetAsync(ctx->d_band_probe.p, 0, 16, ctx->s_pre));
+    if (!ctx->d_band_probe.p) {  // the index kernel's probe statistics and its list of loose groups: zero once, every pass's tail sets them back
+        if ((rc = ensure(ctx, ctx->d_band_probe, (4 + LOOSE_MAX) * 4))) return rc;
+        PNX_HIP(ctx, hipMemsetAsync(ctx->d_band_probe.p, 0, (4 + LOOSE_MAX) * 4, ctx->s_pre));
+    }
+    {  // the flags of the groups and the bitmaps of the loose ones (BandLoose): zero when made, kept zero by the tail of every pass
+        const size_t flag_bytes = ((size_t)ctx->n_groups + 1) * 4, bits_bytes = (size_t)LOOSE_MAX * ctx->n_blocks * BLOCK_WORDS * 4;
+        const void *f0 = ctx->d_group_loose.p, *b0 = ctx->d_loose_bits.p, *e0 = ctx->d_entry_loose.p;
+        if ((rc = ensure(ctx, ctx->d_group_loose, flag_bytes)) || (rc = ensure(ctx, ctx->d_loose_bits, bits_bytes)) ||
+            (rc = ensure(ctx, ctx->d_entry_loose, ((size_t)ctx->n_ordered + 1) * 4)))
+            return rc;
+        if (ctx->d_entry_loose.p != e0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_entry_loose.p, 0, ctx->d_entry_loose.cap, ctx->s_pre));
+        if (ctx->d_group_loose.p != f0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_group_loose.p, 0, ctx->d_group_loose.cap, ctx->s_pre));
+        if (ctx->d_loose_bits.p != b0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_loose_bits.p, 0, ctx->d_loose_bits.cap, ctx->s_pre));
     }
     // (a burst holds 1 .. 256 records; a list of single-step bursts is cut short by the directory: 1 entry per 4 records)
     if ((rc = ensure(ctx, ctx->d_spill, cap * 4)) || (rc = ensure(ctx, ctx->d_spill_dir, (cap / 4) * 8))) return rc;
@@ -879,6 +1092,10 @@ static bool band_sparse(const pnx_ctx *ctx, uint32_t n_bands) {
     return ctx->n_ordered >= 64 && ctx->n_steps / ((uint64_t)n_bands * ctx->n_paths) < 512;
 }
 
+static BandLoose band_loose(const pnx_ctx *ctx) {
+    return BandLoose{(uint32_t *)ctx->d_band_probe.p, (uint32_t *)ctx->d_group_loose.p, (uint32_t *)ctx->d_entry_loose.p, (uint32_t *)ctx->d_loose_bits.p};
+}
+
 template <int NPL>
 static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, const BandSplits &sp, bool sparse) {
     Ticket *tk = ctx->cur;
@@ -892,7 +1109,7 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, co
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags,
                            n_bands, sp, sl, (const uint32_t *)ctx->d_band_probe.p, (const uint32_t *)tk->d_band_clist.p,
-                           (const uint32_t *)tk->d_band_ccnt.p);
+                           (const uint32_t *)tk->d_band_ccnt.p, (const uint32_t *)ctx->d_entry_loose.p);
     };
     // 4 waves per band, 2 loads in flight per lane: measured best on 10 M items x 256 and x 1024 paths (0.64 / 2.45 ms; 4 in flight
     // 0.67 / 2.56, 8 in flight 0.72; 8 waves per band 0.70, 2 waves 0.71) -- with every workgroup resident at once the chip holds
@@ -952,7 +1169,8 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
                        (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, (const uint32_t *)ctx->d_ord_path.p,
                        (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
                        (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
-                       (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p);
+                       (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p,
+                       (uint32_t *)ctx->d_group_loose.p, (uint32_t *)ctx->d_entry_loose.p);
     if (sparse)
         hipLaunchKernelGGL(k_band_compact, dim3((n_bands * sp.n + 3) / 4), dim3(256), 0, ctx->s_pre, (const unsigned long long *)tk->d_tile_idx_own.p,
                            n_bands, ctx->n_ordered, sp, (uint32_t *)tk->d_band_clist.p, (uint32_t *)tk->d_band_ccnt.p);
@@ -1010,8 +1228,16 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     // the scans may read half of what the pass itself reads (a burst scans the segments of EVERY path of its group: groups of two
     // haplotypes double the volume) -- and 4 M steps, microseconds, whatever the size of the graph
     a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 2048 + 4096, 0xFFFFFFF0ull);
+    a.lo = band_loose(ctx);
+    a.path_off = (const uint64_t *)ctx->d_path_off.p;
+    a.ord_path = (const uint32_t *)ctx->d_ord_path.p;
+    a.n_tiles = ctx->n_blocks;
+    a.n_groups = ctx->n_groups;
+    a.n_ordered = ctx->n_ordered;
+    a.loose_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ctx->n_steps / 8, 4ull << 20) >> 10, 0xFFFFFFF0ull);
+    const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
-    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(BAND_TAIL_WAVES * 64), 0, ctx->s_post, a);
+    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(BAND_TAIL_WAVES * 64), lds_hist, ctx->s_post, a);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;

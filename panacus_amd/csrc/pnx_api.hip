@@ -216,6 +216,11 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->band_failed = true;
             ctx->pass_band = false;
             ctx->n_reruns += 1;
+            // (why: 1 inconsistent index entry, 2 spill list full, 4 scan volume, 8 the index's probes met steps from elsewhere,
+            // 16 more loose groups than a pass takes in, 32 an id that is no item)
+            if (getenv("PNX_BAND_DEBUG"))
+                fprintf(stderr, "[panacus_amd] one-shot pass void: flags[5] = %u, spilled %u in %u bursts, loose groups %u\n", t->h_flags[5],
+                        t->h_flags[6], t->h_flags[7], t->h_flags[3]);
             if ((rc = ensure_rows(ctx, true))) return rc;
             ctx->cur = t;
             ctx->want_M = t->wrote_m;
@@ -234,6 +239,7 @@ static int settle_oldest(pnx_ctx *ctx) {
             if (t->band) {
                 ctx->n_spilled_last = t->h_flags[6];
                 ctx->n_spill_bursts_last = t->h_flags[7];
+                ctx->n_loose_last = t->h_flags[3];
                 ctx->n_spilled_total += t->h_flags[6];
             }
             ctx->last_general_paths = t->h_flags[1];
@@ -366,7 +372,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe, &ctx->d_group_loose, &ctx->d_entry_loose, &ctx->d_loose_bits})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -1344,7 +1350,7 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->band_splits = ctx->band_splits;
     out->n_spilled_total = ctx->n_spilled_total;
     out->n_spill_bursts_last = ctx->n_spill_bursts_last;
-    out->reserved0 = 0;
+    out->n_loose_groups_last = ctx->n_loose_last;
     return PNX_OK;
 }
 

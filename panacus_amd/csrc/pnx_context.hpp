@@ -210,6 +210,8 @@ struct pnx_ctx {
     // steps found outside the band they were dealt to (paths that are not sorted by id): the list of a pass, and the set of
     // (group, id) pairs its tail has added -- slots carry the generation of the pass that wrote them, so no pass clears the set
     pnx::DevBuf d_spill, d_spill_dir, d_spill_set, d_band_probe;
+    pnx::DevBuf d_group_loose, d_entry_loose, d_loose_bits;  // groups with a path that does not follow the ids at all: their flags, their presence bitmaps (kernels_band.hip: BandLoose)
+    uint32_t n_loose_last = 0;                // ... how many the pass settled last took in
     uint32_t spill_cap = 0, spill_gen = 0;
     uint64_t spill_slots = 0;
     uint64_t n_spilled_total = 0;  // spilled steps of all settled passes of this upload

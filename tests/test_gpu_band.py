@@ -255,27 +255,84 @@ def test_band_route_fuzz_with_paths_that_stray(band, seed):
         assert info.n_rows == 0
 
 
-def test_paths_that_do_not_follow_the_ids_void_the_pass_and_the_rows_take_over(band):
+def _graph_with_shuffled_paths(n, P, which, seed, half=()):
+    items, pre, lens = orc.pansyn(5, n, P)
+    rng = np.random.default_rng(seed)
+    segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(P)]
+    for k in which:
+        segs[k] = rng.permutation(segs[k])                 # no order at all: every step is out of place
+    for k in half:                                         # in order up to the middle, shuffled from there on
+        m = len(segs[k]) // 2
+        segs[k] = np.concatenate([segs[k][:m], rng.permutation(segs[k][m:])])
+    items, pre = _concat(segs)
+    return items, pre, lens
+
+
+@pytest.mark.parametrize("splits", [1, 3])
+def test_paths_that_do_not_follow_the_ids_at_all_are_left_to_bitmaps(band, splits):
+    """three shuffled paths and one that is shuffled from its middle on, among sorted ones and one with strays: their groups are
+    taken out of the bands, their steps marked in per-group bitmaps and folded in by the pass's tail -- no rerun, no rows, the
+    oracle's numbers (coverage vector, histogram of node counts and of bp with exclusion, presence matrix)"""
     ctx = band
     n = 300_000
-    items, pre, _ = orc.pansyn(5, n, 8)
-    rng = np.random.default_rng(2)
-    segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(8)]
-    for k in (1, 4, 6):
-        segs[k] = rng.permutation(segs[k])                 # no order at all: every step is out of place
-    items, pre = _concat(segs)
+    items, pre, lens = _graph_with_shuffled_paths(n, 10, (1, 4, 6), 2, half=(8,))
+    a = int(pre[3]) + 1000
+    items[a:a + 300] = items[a + 5000:a + 5300].copy()      # (path 3 strays: spilled steps in the same pass)
+    rng = np.random.default_rng(9)
+    excl = (rng.random(n + 1) < 0.04).astype(np.uint8)
+    excl[0] = 0
+    pi = np.arange(10, dtype=np.uint64)
+    os.environ["PNX_BAND_SPLITS"] = str(splits)
+    try:
+        for weights, exclude in ((None, None), (lens, excl)):
+            ctx.set_csr(items.astype(np.uint32), pre, n, weights=weights, exclude=exclude)
+            before = ctx.info().n_reruns
+            ctx.set_order(pi, pi, 10)                       # every path its own group
+            _check(ctx, items, pre, n, pi, pi, 10, weights, exclude, presence=True)
+            info = ctx.info()
+            assert info.n_reruns == before and info.n_rows == 0 and info.band_route_failed == 0
+            assert info.n_loose_groups_last == 4 and info.n_spilled_last > 0
+            gid = (pi // 2).astype(np.uint64)               # groups of two: a loose path takes its sorted partner along
+            ctx.set_order(pi, gid, 5)
+            _check(ctx, items, pre, n, pi, gid, 5, weights, exclude, presence=True)
+            info = ctx.info()
+            assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 4
+            order = np.array([9, 6, 0, 2, 1], dtype=np.uint64)      # a subset, the loose paths in one group
+            gid = np.array([0, 1, 1, 2, 2], dtype=np.uint64)
+            ctx.set_order(order, gid, 3)
+            _check(ctx, items, pre, n, order, gid, 3, weights, exclude, presence=True)
+            assert ctx.info().n_reruns == before and ctx.info().n_loose_groups_last == 2
+            ctx.set_order(np.array([0, 2, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3)   # none of them
+            _check(ctx, items, pre, n, np.array([0, 2, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3, weights, exclude)
+            assert ctx.info().n_loose_groups_last == 0
+    finally:
+        del os.environ["PNX_BAND_SPLITS"]
+
+
+def test_more_loose_groups_than_a_pass_takes_in_void_the_pass_and_the_rows_take_over(band):
+    ctx = band
+    n = 200_000
+    P = 40
+    items, pre, _ = _graph_with_shuffled_paths(n, P, tuple(range(0, P, 2)), 3)     # 20 groups of shuffled paths: more than 16
     ctx.set_csr(items.astype(np.uint32), pre, n)
-    pi = np.arange(8, dtype=np.uint64)
-    ctx.set_order(pi, (pi // 2).astype(np.uint64), 4)
+    pi = np.arange(P, dtype=np.uint64)
+    ctx.set_order(pi, pi, P)
     before = ctx.info().n_reruns
     cnt, h = ctx.hist()
-    ocov, oh = _oracle_hist(items, pre, pi, pi // 2, n, 4)
+    ocov, oh = _oracle_hist(items, pre, pi, pi, n, P)
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
     info = ctx.info()
     assert info.n_reruns == before + 1 and info.n_rows > 0         # run again, over rows
     assert info.n_band_passes == 1 and info.band_route_failed == 1
     cnt, h = ctx.hist()                                             # and the graph is remembered: no second attempt
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 1
+    # the next upload starts from a clean slate (the flags of the groups were set back by the void pass's tail)
+    items, pre, _ = _graph_with_shuffled_paths(n, 6, (2,), 4)
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    pi = np.arange(6, dtype=np.uint64)
+    ctx.set_order(pi, pi, 6)
+    _check(ctx, items, pre, n, pi, pi, 6)
+    assert ctx.info().n_reruns == before + 1 and ctx.info().n_loose_groups_last == 1 and ctx.info().n_rows == 0
 
 
 @pytest.mark.parametrize("n,p", [(70_000, 5), (300_000, 12), (2_000_000, 24)])

@@ -134,7 +134,7 @@ rank = int(os.environ["RANK"]); torch.cuda.set_device(rank)
 dist.init_process_group("gloo")
 from panacus_amd import capi
 import oracle as orc
-n, p = 120_000, 8
+n, p = 120_000, 20                                    # (20 shuffled paths: more groups than a pass leaves to bitmaps)
 items, pre, _ = orc.pansyn(3, n, p)
 half = 61_440
 def shard(lo, hi):
