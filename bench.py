@@ -465,7 +465,7 @@ def strong_hist_block(args, torch, dist, use_dist, world, rank, local_rank, bloc
             torch.cuda.synchronize()
             ctx.sync()
 
-        dt, h, growths, prof = timed_steps(stepper, steps, 3, barrier, max(1, min(4, steps // 4)))
+        dt, h, growths, prof = timed_steps(stepper, steps, 10, barrier, max(1, min(4, steps // 4)))
         if dist_on:
             tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -617,8 +617,9 @@ def timed_steps(stepper, steps, warmup, barrier, sample_every):
     barrier()
     dt = time.perf_counter() - t0
     # (the spread of the steps of the timed region, for the record: a step ends when its curves are on the host)
-    per = sorted(b - a for a, b in zip([t0] + each[:-1], each))
-    stepper.step_spread_ms = {"min": per[0] * 1e3, "median": per[len(per) // 2] * 1e3, "max": per[-1] * 1e3}
+    raw = [b - a for a, b in zip([t0] + each[:-1], each)]
+    per = sorted(raw)
+    stepper.step_spread_ms = {"min": per[0] * 1e3, "median": per[len(per) // 2] * 1e3, "max": per[-1] * 1e3, "max_at_step": raw.index(per[-1])}
     prof = ctx.profile_read()
     ctx.profile_select(None)
     ctx.profile_sample(1)
@@ -838,7 +839,7 @@ def strayed_block(args, local_rank):
     def barrier():
         ctx.sync()
 
-    dt, h, growths, prof = timed_steps(stepper, steps, 3, barrier, max(1, min(4, steps // 4)))
+    dt, h, growths, prof = timed_steps(stepper, steps, 10, barrier, max(1, min(4, steps // 4)))
     info = ctx.info()
     S = int(info.n_steps)
     ms_per_step, B, cover_ms, roofline, breakdown = step_report(ctx, N, P, S, dt, steps, prof)

@@ -27,7 +27,17 @@ def first_hist_ms(ctx, items32, pre, n, order, route, reps=3):
         t0 = time.perf_counter()
         cnt, h = ctx.hist(want_countable=False)
         ts.append((time.perf_counter() - t0) * 1e3)
-    return sorted(ts)[len(ts) // 2], h, int(ctx.info().n_reruns)
+    # the kernels of one more such call, timed with HIP events (the events hold the chain up: not part of the wall clock above)
+    ctx.config(capi.CFG_COVER_ROUTE, route)
+    ctx.set_csr(items32, pre, n)
+    ctx.set_order(order, order, len(order))
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    ctx.hist(want_countable=False)
+    pr = ctx.profile_read()
+    ctx.profile_enable(False)
+    kern = {k: round(v[0] / v[1], 4) for k, v in pr.items() if v[1]}
+    return sorted(ts)[len(ts) // 2], h, int(ctx.info().n_reruns), kern
 
 
 def main():
@@ -51,9 +61,9 @@ def main():
     variants["two_steps_swapped_across_bands"] = sw
     with capi.Context(0) as ctx:
         for name, it in variants.items():
-            auto_ms, h_auto, reruns = first_hist_ms(ctx, it, pre, n, order, 0)
-            rows_ms, h_rows, _ = first_hist_ms(ctx, it, pre, n, order, 2)
-            out[name] = {"first_hist_ms_auto_route": round(auto_ms, 3), "first_hist_ms_rows_route": round(rows_ms, 3),
+            auto_ms, h_auto, reruns, kern = first_hist_ms(ctx, it, pre, n, order, 0)
+            rows_ms, h_rows, _, _ = first_hist_ms(ctx, it, pre, n, order, 2)
+            out[name] = {"first_hist_ms_auto_route": round(auto_ms, 3), "first_hist_ms_rows_route": round(rows_ms, 3), "kernels_ms_auto_route": kern,
                          "same_hist": bool(np.array_equal(h_auto, h_rows)), "reruns_total": reruns}
     print(json.dumps(out))
 

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add((g_u32 *)(a.scratch + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (agent_load(a.scratch + 2) < LOOSE_WORKGROUPS) __builtin_amdgcn_s_sleep(8);
+            while (agent_load(a.scratch + 2) < LOOSE_WORKGROUPS) __builtin_amdgcn_s_sleep(127);  // (a poll every ~3 us: the arrivals queue on the same word)
         }
         __syncthreads();
         for (uint32_t tile = blockIdx.x * BAND_TAIL_WAVES + wave; tile < a.n_tiles; tile += LOOSE_WORKGROUPS * BAND_TAIL_WAVES) {
