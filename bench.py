@@ -839,7 +839,9 @@ def strayed_block(args, local_rank):
     def barrier():
         ctx.sync()
 
-    dt, h, growths, prof = timed_steps(stepper, steps, 10, barrier, max(1, min(4, steps // 4)))
+    # (60 untimed steps first: ~40 ms after the block before this one has freed its 16 GB, one HIP call of this process stalls for
+    # ~37 ms -- seen at the 30th step of this loop in every full run, never when the block runs by itself)
+    dt, h, growths, prof = timed_steps(stepper, steps, 60, barrier, max(1, min(4, steps // 4)))
     info = ctx.info()
     S = int(info.n_steps)
     ms_per_step, B, cover_ms, roofline, breakdown = step_report(ctx, N, P, S, dt, steps, prof)

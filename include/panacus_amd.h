@@ -642,6 +642,10 @@ typedef struct {
     uint32_t n_loose_groups_last; /* (round 5) groups with a path that does not follow the ids at all (a shuffled path) which the
                                      one-shot pass settled last left to per-group bitmaps instead of the bands; at most 16 per pass,
                                      beyond that the pass is void and the path rows take over (n_reruns) */
+    uint32_t n_path_cuts;    /* (round 5) places where the upload found a path turning round or jumping back by more than two bands
+                                for at least 8 K steps (inversions, duplications, translocations): the one-shot pass takes the
+                                pieces between them as entries of their own, under the path's group */
+    uint32_t n_band_entries; /* (round 5) entries of the one-shot pass enqueued last: the visiting order with the paths cut there */
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

@@ -167,8 +167,8 @@ __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ 
 // workgroups, zeroes the coverage vector they add to.)
 // Which way a path runs: by the majority of five evenly spaced steps, its two ends deciding a tie -- a first or last step
 // out of place does not turn the whole path around.
-__global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__ items, const uint64_t *__restrict__ path_off,
-                                                    const uint32_t *__restrict__ ord_path, const uint32_t *__restrict__ ord_group,
+__global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__ items, const uint64_t *__restrict__ ent_start,
+                                                    const uint64_t *__restrict__ ent_len, const uint32_t *__restrict__ ord_group,
                                                     uint32_t n_ordered, uint32_t n_groups, uint32_t n_bands, uint32_t band_items,
                                                     unsigned long long *__restrict__ bidx, uint32_t *__restrict__ group_first,
                                                     uint4 *__restrict__ block16, uint32_t n_block16, uint4 *__restrict__ zero16,
@@ -192,9 +192,8 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     uint64_t j = 0;
     uint32_t n_probes = 0, n_astray = 0;
     if (live) {
-        const uint32_t p = ord_path[k];
-        ps = path_off[p];
-        len = path_off[p + 1] - ps;
+        ps = ent_start[k];
+        len = ent_len[k];
     }
     // ---- does the path follow the ids at all?  Every lane looks at one 64-byte sector of its path (the lanes of a wave hold
     // consecutive edges of one path: their sectors are spread evenly along it): on a path that runs through the ids -- upwards
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
                     uint64_t vol = 0;  // the steps of the group: what the tail kernel will have to mark, one atomic each
                     for (uint32_t q = k0; q < k1; ++q) {
                         entry_loose[q] = 1u;
-                        vol += path_off[ord_path[q] + 1] - path_off[ord_path[q]];
+                        vol += ent_len[q];
                     }
                     atomicAdd(probe_stats + 3, (uint32_t)((vol + 1023u) >> 10));
                 }
@@ -288,8 +287,10 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
             np += __shfl_down(np, o);
             na += __shfl_down(na, o);
         }
-        // (a sample: every 16th workgroup reports -- thousands of atomics on two words would outlast the searches)
-        if ((threadIdx.x & 63u) == 0 && np && (blockIdx.x & 15u) == 0u) {
+        // (a sample: every 16th workgroup reports -- thousands of atomics on two words would outlast the searches; a grid of a few
+        // hundred workgroups reports in full: sixteen of them would speak for two or three entries, and ONE piece of a path that the
+        // searches have trouble with would be taken for the whole graph)
+        if ((threadIdx.x & 63u) == 0 && np && ((blockIdx.x & 15u) == 0u || gridDim.x <= 256u)) {
             atomicAdd(probe_stats, np);
             if (na) atomicAdd(probe_stats + 1, na);
         }
@@ -656,8 +657,8 @@ struct BandTail {
     uint32_t *host_block;      // [flags u32[8] | hist] in the ticket's pinned memory, or nullptr
     uint32_t scan_budget;      // steps the spill scans may read in all, in units of 1024
     BandLoose lo;              // the groups that were left to bitmaps, and the bitmaps
-    const uint64_t *path_off;  // ... their paths
-    const uint32_t *ord_path;
+    const uint64_t *ent_start;  // ... their entries' steps
+    const uint64_t *ent_len;
     uint32_t n_tiles, n_groups, n_ordered;
     uint32_t loose_budget;     // steps the loose groups may hold in all, in units of 1024
 };
@@ -745,8 +746,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
             const uint32_t g = a.lo.state[4u + li];
             uint32_t *bits = a.lo.bits + (uint64_t)li * a.n_tiles * BLOCK_WORDS;
             for (uint32_t k = a.group_first[g]; k < a.group_first[g + 1]; ++k) {
-                const uint32_t p = a.ord_path[k];
-                const uint64_t ps = a.path_off[p], pe = a.path_off[p + 1];
+                const uint64_t ps = a.ent_start[k], pe = ps + a.ent_len[k];
                 for (uint64_t c = (ps & ~3ull) + wid * 1024u; c < pe; c += n_waves * 1024u) {
                     u32x4 v[4];
 #pragma unroll
@@ -1049,7 +1049,7 @@ bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries) {
 
 // the spill list and the set of added pairs: per context, made when the first one-shot pass is enqueued
 static int ensure_spill(pnx_ctx *ctx) {
-    uint64_t cap = ctx->n_steps / 128;
+    uint64_t cap = ctx->n_steps / 64;
     cap = std::max<uint64_t>(cap, 1ull << 14);
     cap = std::min<uint64_t>(cap, 1ull << 25);
     uint64_t slots = 1;
@@ -1061,13 +1061,14 @@ static int ensure_spill(pnx_ctx *ctx) {
     }
     {  // the flags of the groups and the bitmaps of the loose ones (BandLoose): zero when made, kept zero by the tail of every pass
         const size_t flag_bytes = ((size_t)ctx->n_groups + 1) * 4, bits_bytes = (size_t)LOOSE_MAX * ctx->n_blocks * BLOCK_WORDS * 4;
-        const void *f0 = ctx->d_group_loose.p, *b0 = ctx->d_loose_bits.p, *e0 = ctx->d_entry_loose.p;
+        // (by capacity, not by address: the allocator may hand a larger block out at the address of the one just freed)
+        const size_t f0 = ctx->d_group_loose.cap, b0 = ctx->d_loose_bits.cap, e0 = ctx->d_entry_loose.cap;
         if ((rc = ensure(ctx, ctx->d_group_loose, flag_bytes)) || (rc = ensure(ctx, ctx->d_loose_bits, bits_bytes)) ||
-            (rc = ensure(ctx, ctx->d_entry_loose, ((size_t)ctx->n_ordered + 1) * 4)))
+            (rc = ensure(ctx, ctx->d_entry_loose, ((size_t)ctx->n_entries + 1) * 4)))
             return rc;
-        if (ctx->d_entry_loose.p != e0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_entry_loose.p, 0, ctx->d_entry_loose.cap, ctx->s_pre));
-        if (ctx->d_group_loose.p != f0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_group_loose.p, 0, ctx->d_group_loose.cap, ctx->s_pre));
-        if (ctx->d_loose_bits.p != b0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_loose_bits.p, 0, ctx->d_loose_bits.cap, ctx->s_pre));
+        if (ctx->d_entry_loose.cap != e0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_entry_loose.p, 0, ctx->d_entry_loose.cap, ctx->s_pre));
+        if (ctx->d_group_loose.cap != f0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_group_loose.p, 0, ctx->d_group_loose.cap, ctx->s_pre));
+        if (ctx->d_loose_bits.cap != b0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_loose_bits.p, 0, ctx->d_loose_bits.cap, ctx->s_pre));
     }
     // (a burst holds 1 .. 256 records; a list of single-step bursts is cut short by the directory: 1 entry per 4 records)
     if ((rc = ensure(ctx, ctx->d_spill, cap * 4)) || (rc = ensure(ctx, ctx->d_spill_dir, (cap / 4) * 8))) return rc;
@@ -1083,13 +1084,58 @@ static int ensure_spill(pnx_ctx *ctx) {
     return PNX_OK;
 }
 
+// The entries of a one-shot pass: the visiting order, every path cut where the upload's summaries of its chunks say it turns
+// round or jumps back (pass_pipeline.hip: path_cuts_from_chunks) -- the pieces of a path are entries of their own under the
+// path's group.  Made once per (graph, order); without cuts it is the order itself with the paths' offsets written out, which
+// saves the index kernel a dependent load.
+static int ensure_band_entries(pnx_ctx *ctx) {
+    if (ctx->entries_valid) return PNX_OK;
+    const uint32_t no = ctx->n_ordered;
+    const bool cuts = ctx->h_cut_off.size() == (size_t)ctx->n_paths + 1 && !ctx->h_cuts.empty();
+    std::vector<uint64_t> st, ln;
+    std::vector<uint32_t> &gr = ctx->h_ent_group;
+    gr.clear();
+    st.reserve(no);
+    ln.reserve(no);
+    gr.reserve(no);
+    for (uint32_t k = 0; k < no; ++k) {
+        const uint32_t p = ctx->h_ord_path[k], g = ctx->h_ord_group[k];
+        uint64_t a = ctx->h_path_off[p];
+        const uint64_t z = ctx->h_path_off[p + 1];
+        if (cuts) {
+            for (uint32_t c = ctx->h_cut_off[p]; c < ctx->h_cut_off[p + 1]; ++c) {
+                const uint64_t cut = ctx->h_cuts[c];
+                if (cut > a && cut < z) {
+                    st.push_back(a), ln.push_back(cut - a), gr.push_back(g);
+                    a = cut;
+                }
+            }
+        }
+        st.push_back(a), ln.push_back(z - a), gr.push_back(g);
+    }
+    if (st.size() >= 0xFFFFFFFEull) return ctx->fail(PNX_ELIMIT, "too many pieces of paths in the visiting order");
+    const size_t n = st.size();
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_ent_start, (n + 1) * 8)) || (rc = ensure(ctx, ctx->d_ent_len, (n + 1) * 8)) || (rc = ensure(ctx, ctx->d_ent_group, (n + 1) * 4)))
+        return rc;
+    if (n) {
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_start.p, st.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_len.p, ln.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_group.p, gr.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+        PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go; other streams read the arrays)
+    }
+    ctx->n_entries = (uint32_t)n;
+    ctx->entries_valid = true;
+    return PNX_OK;
+}
+
 // Most (entry, band) cells empty -- fewer than 512 steps per cell on average: thousands of paths that each touch a few bands --:
 // the workgroups walk per-band lists of the entries that have steps there (k_band_compact, k_band_cover<SPARSE>)
 static bool band_sparse(const pnx_ctx *ctx, uint32_t n_bands) {
     if (const char *e = getenv("PNX_BAND_SPARSE")) {  // measurement: 0 / 1 forces one
         if ((e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
     }
-    return ctx->n_ordered >= 64 && ctx->n_steps / ((uint64_t)n_bands * ctx->n_paths) < 512;
+    return ctx->n_entries >= 64 && ctx->n_steps / ((uint64_t)n_bands * ctx->n_paths) < 512;
 }
 
 static BandLoose band_loose(const pnx_ctx *ctx) {
@@ -1105,7 +1151,7 @@ static void launch_band_cover_t(pnx_ctx *ctx, bool write_m, uint32_t n_bands, co
     const BandSpill sl{(uint32_t *)ctx->d_spill.p, (unsigned long long *)ctx->d_spill_dir.p, ctx->spill_cap, ctx->spill_cap / 4};
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(n_bands * sp.n), dim3(BAND_CW * 64), lds_hist, ctx->s_main, (const uint32_t *)ctx->d_items.p,
-                           (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered,
+                           (const unsigned long long *)tk->d_tile_idx_own.p, (const uint32_t *)ctx->d_ent_group.p, ctx->n_entries,
                            ctx->have_exclude ? (const uint8_t *)ctx->d_exclude.p : (const uint8_t *)nullptr, ctx->n_items, ctx->n_blocks,
                            (uint32_t *)ctx->d_M.p, (uint64_t)ctx->n_blocks * BLOCK_WORDS, (uint32_t *)tk->d_countable.p, hs, tk->d_flags,
                            n_bands, sp, sl, (const uint32_t *)ctx->d_band_probe.p, (const uint32_t *)tk->d_band_clist.p,
@@ -1137,7 +1183,8 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     Ticket *tk = ctx->cur;
     int rc;
     const uint32_t n_bands = (ctx->n_blocks + BT - 1) / BT;
-    const uint64_t cells = (uint64_t)(n_bands + 1) * ctx->n_ordered;
+    if ((rc = ensure_band_entries(ctx))) return rc;
+    const uint64_t cells = (uint64_t)(n_bands + 1) * ctx->n_entries;
     if ((rc = ensure(ctx, tk->d_tile_idx_own, cells * 8)) || (rc = ensure(ctx, tk->d_group_first, ((size_t)ctx->n_groups + 1) * 4)) ||
         (rc = ensure_spill(ctx)))
         return rc;
@@ -1145,8 +1192,8 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     BandSplits sp{};
     sp.n = ctx->band_splits ? ctx->band_splits : 1u;
     {
-        const std::vector<uint32_t> &g = ctx->h_ord_group;
-        const uint32_t no = ctx->n_ordered;
+        const std::vector<uint32_t> &g = ctx->h_ent_group;
+        const uint32_t no = ctx->n_entries;
         sp.k[0] = 0;
         for (uint32_t s = 1; s < sp.n; ++s) {
             uint32_t k = (uint32_t)((uint64_t)no * s / sp.n);
@@ -1157,7 +1204,7 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     }
     const bool sparse = band_sparse(ctx, n_bands);
     if (sparse) {
-        if ((rc = ensure(ctx, tk->d_band_clist, (size_t)n_bands * ctx->n_ordered * 4)) || (rc = ensure(ctx, tk->d_band_ccnt, (size_t)n_bands * sp.n * 4)))
+        if ((rc = ensure(ctx, tk->d_band_clist, (size_t)n_bands * ctx->n_entries * 4)) || (rc = ensure(ctx, tk->d_band_ccnt, (size_t)n_bands * sp.n * 4)))
             return rc;
         // groups without a step on a band are never met there: their part of the presence matrix is zero beforehand
         if (write_m) PNX_HIP(ctx, hipMemsetAsync(ctx->d_M.p, 0, (size_t)ctx->n_groups * ctx->n_blocks * BLOCK_WORDS * 4, ctx->s_pre));
@@ -1165,15 +1212,15 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     const bool phased = ctx->s_pre != ctx->s_main;
     const uint64_t n_zero16 = sp.n > 1 ? ((uint64_t)ctx->n_items + 1 + 3) / 4 : 0;  // (the buffer is a multiple of 256 bytes)
     prof_begin(ctx, PNX_K_INDEX, ctx->s_pre);
-    hipLaunchKernelGGL(k_band_index, dim3((unsigned)((std::max<uint64_t>(cells, ctx->n_ordered) + 255) / 256)), dim3(256), 0, ctx->s_pre,
-                       (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_path_off.p, (const uint32_t *)ctx->d_ord_path.p,
-                       (const uint32_t *)ctx->d_ord_group.p, ctx->n_ordered, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
+    hipLaunchKernelGGL(k_band_index, dim3((unsigned)((std::max<uint64_t>(cells, ctx->n_entries) + 255) / 256)), dim3(256), 0, ctx->s_pre,
+                       (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_ent_start.p, (const uint64_t *)ctx->d_ent_len.p,
+                       (const uint32_t *)ctx->d_ent_group.p, ctx->n_entries, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
                        (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
                        (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p,
                        (uint32_t *)ctx->d_group_loose.p, (uint32_t *)ctx->d_entry_loose.p);
     if (sparse)
         hipLaunchKernelGGL(k_band_compact, dim3((n_bands * sp.n + 3) / 4), dim3(256), 0, ctx->s_pre, (const unsigned long long *)tk->d_tile_idx_own.p,
-                           n_bands, ctx->n_ordered, sp, (uint32_t *)tk->d_band_clist.p, (uint32_t *)tk->d_band_ccnt.p);
+                           n_bands, ctx->n_entries, sp, (uint32_t *)tk->d_band_clist.p, (uint32_t *)tk->d_band_ccnt.p);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     // (recorded on one stream as well where the closed forms' tables are derived by the two-kernel route: that derivation starts
@@ -1229,11 +1276,11 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     // haplotypes double the volume) -- and 4 M steps, microseconds, whatever the size of the graph
     a.scan_budget = (uint32_t)std::min<uint64_t>(ctx->n_steps / 2048 + 4096, 0xFFFFFFF0ull);
     a.lo = band_loose(ctx);
-    a.path_off = (const uint64_t *)ctx->d_path_off.p;
-    a.ord_path = (const uint32_t *)ctx->d_ord_path.p;
+    a.ent_start = (const uint64_t *)ctx->d_ent_start.p;
+    a.ent_len = (const uint64_t *)ctx->d_ent_len.p;
     a.n_tiles = ctx->n_blocks;
     a.n_groups = ctx->n_groups;
-    a.n_ordered = ctx->n_ordered;
+    a.n_ordered = ctx->n_entries;
     a.loose_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ctx->n_steps / 8, 4ull << 20) >> 10, 0xFFFFFFF0ull);
     const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);

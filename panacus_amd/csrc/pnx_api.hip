@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "pnx_context.hpp"
 
@@ -236,6 +237,19 @@ static int settle_oldest(pnx_ctx *ctx) {
         const bool bad = need_build || (t->h_flags[1] != 0 && !used_m);
         if (t->h_flags[4] != 0) return ctx->fail(PNX_EHIP, "run index inconsistency (internal error)");
         if (!bad) {
+            if (t->band && getenv("PNX_BAND_DEBUG") && ctx->d_entry_loose.p && ctx->d_group_loose.p) {  // (what the pass's tail must have set back)
+                std::vector<uint32_t> ef(ctx->n_entries), gf(ctx->n_groups), st(20);
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(ef.data(), ctx->d_entry_loose.p, ef.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(gf.data(), ctx->d_group_loose.p, gf.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(st.data(), ctx->d_band_probe.p, 80, hipMemcpyDeviceToHost);
+                size_t ne = 0, ng = 0;
+                for (uint32_t x : ef) ne += x != 0;
+                for (uint32_t x : gf) ng += x != 0;
+                if (ne || ng || st[0] || st[1] || st[2] || st[3])
+                    fprintf(stderr, "[panacus_amd] LEFT BEHIND by a one-shot pass: %zu entry flags, %zu group flags, state %u %u %u %u (loose groups of the pass: %u)\n", ne, ng,
+                            st[0], st[1], st[2], st[3], t->h_flags[3]);
+            }
             if (t->band) {
                 ctx->n_spilled_last = t->h_flags[6];
                 ctx->n_spill_bursts_last = t->h_flags[7];
@@ -372,7 +386,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe, &ctx->d_group_loose, &ctx->d_entry_loose, &ctx->d_loose_bits})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe, &ctx->d_group_loose, &ctx->d_entry_loose, &ctx->d_loose_bits, &ctx->d_chunk_sum, &ctx->d_ent_start, &ctx->d_ent_len, &ctx->d_ent_group})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -416,6 +430,10 @@ static void drop_gfa_text(pnx_ctx *ctx) {
 // what every upload starts with: results, order and derived step data of the old graph are void
 static void begin_upload(pnx_ctx *ctx) {
     invalidate_results(ctx);
+    ctx->h_chunk_sum.clear();
+    ctx->h_cuts.clear();
+    ctx->h_cut_off.clear();
+    ctx->entries_valid = false;
     ctx->have_csr = false;
     ctx->have_order = false;
     ctx->steps_prepared = false;
@@ -457,13 +475,29 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
     if ((rc = ensure(ctx, ctx->d_flags, 8 * sizeof(uint32_t)))) return rc;
     // a shape the one-shot route may take (kernels_band.hip) derives no rows at upload: its first sweep reads the steps once
     const bool defer_rows = use_rows(ctx) && !item_key && ctx->cover_route != 2 && (ctx->cover_route == 1 || band_route_fits(ctx, n_paths));
+    ctx->h_chunk_sum.clear();
+    ctx->h_cuts.clear();
+    ctx->h_cut_off.clear();
+    ctx->entries_valid = false;
     if (item_key || !use_rows(ctx) || defer_rows) {
         PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
-        if ((rc = launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
+        // (a graph the one-shot route may take: the same read says where its paths turn round or jump back)
+        const bool summarise = defer_rows && !item_key;
+        if ((rc = summarise ? launch_chunk_summaries(ctx, (uint32_t *)ctx->d_flags.p) : launch_validate_items(ctx, (uint32_t *)ctx->d_flags.p))) return rc;
         uint32_t bad = 0;
         PNX_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_flags.p, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (bad) return ctx->fail(PNX_EINVAL, "items contains ids outside 1..n_items");
+        if (summarise) {
+            path_cuts_from_chunks(ctx);
+            if ((rc = refine_path_cuts(ctx))) return rc;
+            if (getenv("PNX_BAND_DEBUG"))
+                for (uint32_t p = 0; p < n_paths; ++p) {
+                    fprintf(stderr, "[panacus_amd] path %u (%llu steps): cuts at", p, (unsigned long long)(ctx->h_path_off[p + 1] - ctx->h_path_off[p]));
+                    for (uint32_t c = ctx->h_cut_off[p]; c < ctx->h_cut_off[p + 1]; ++c) fprintf(stderr, " %llu", (unsigned long long)(ctx->h_cuts[c] - ctx->h_path_off[p]));
+                    fprintf(stderr, "\n");
+                }
+        }
     }
     ctx->relabeled = false;
     if (item_key && (rc = relabel_by_keys(ctx, item_key))) return rc;
@@ -875,6 +909,9 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_old_of_new, src->d_old_of_new);
     dst->relabeled = src->relabeled;
     dst->h_path_off = src->h_path_off;
+    dst->h_cuts = src->h_cuts;  // (where the paths turn round or jump back: found at the owner's upload)
+    dst->h_cut_off = src->h_cut_off;
+    dst->entries_valid = false;
     dst->weighted = src->weighted;
     dst->have_weights = src->have_weights;
     dst->have_exclude = src->have_exclude;
@@ -977,6 +1014,7 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
     ctx->h_ord_path.assign(path_idx, path_idx + n_ordered);
     ctx->h_ord_group.assign(group_id, group_id + n_ordered);
     ctx->runs_sorted = false;  // run keys carry the group of the path
+    ctx->entries_valid = false;
     ctx->n_ordered = n_ordered;
     ctx->n_groups = n_groups;
     ctx->have_order = true;
@@ -1351,6 +1389,8 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_spilled_total = ctx->n_spilled_total;
     out->n_spill_bursts_last = ctx->n_spill_bursts_last;
     out->n_loose_groups_last = ctx->n_loose_last;
+    out->n_path_cuts = (uint32_t)ctx->h_cuts.size();
+    out->n_band_entries = ctx->entries_valid ? ctx->n_entries : 0u;
     return PNX_OK;
 }
 

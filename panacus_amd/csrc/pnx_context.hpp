@@ -86,6 +86,12 @@ struct Ticket {
     bool band = false;  // the pass took the one-shot route over the steps (kernels_band.hip); flags[5] says whether it held
 };
 
+// what the upload's read of the steps leaves of every chunk of 4096 steps (pass_pipeline.hip: k_chunk_summaries)
+struct ChunkSummary {
+    uint32_t s[5];      // the ids at 0, 1/4, 1/2, 3/4 and the end of the chunk
+    uint32_t up, down;  // steps (three of every four) that go to a larger / a smaller id
+};
+
 struct Profile {
     bool on = false;
     bool open = false;          // a prof_begin of a selected slot awaits its prof_end
@@ -210,6 +216,15 @@ struct pnx_ctx {
     // steps found outside the band they were dealt to (paths that are not sorted by id): the list of a pass, and the set of
     // (group, id) pairs its tail has added -- slots carry the generation of the pass that wrote them, so no pass clears the set
     pnx::DevBuf d_spill, d_spill_dir, d_spill_set, d_band_probe;
+    // the entries of a one-shot pass: the visiting order with every path cut where it turns round or jumps back (pieces of a path
+    // are entries of their own under the path's group; an order over paths without such breaks is its own entry list)
+    pnx::DevBuf d_chunk_sum, d_ent_start, d_ent_len, d_ent_group;
+    std::vector<pnx::ChunkSummary> h_chunk_sum;
+    std::vector<uint64_t> h_cuts;      // absolute step positions, path by path
+    std::vector<uint32_t> h_cut_off;   // n_paths + 1: the cuts of path p are h_cuts[h_cut_off[p] .. h_cut_off[p + 1])
+    std::vector<uint32_t> h_ent_group;
+    uint32_t n_entries = 0;
+    bool entries_valid = false;        // (of the order and the graph as they stand)
     pnx::DevBuf d_group_loose, d_entry_loose, d_loose_bits;  // groups with a path that does not follow the ids at all: their flags, their presence bitmaps (kernels_band.hip: BandLoose)
     uint32_t n_loose_last = 0;                // ... how many the pass settled last took in
     uint32_t spill_cap = 0, spill_gen = 0;
@@ -350,6 +365,9 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 
 // pass_pipeline.hip
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
+int launch_chunk_summaries(pnx_ctx *ctx, uint32_t *d_bad);  // ... of a graph the one-shot route may take: the ids validated, the chunks summarised
+int refine_path_cuts(pnx_ctx *ctx);                        // ... every cut moved from its chunk boundary to the step where the ids jump
+void path_cuts_from_chunks(pnx_ctx *ctx);                   // ... and the paths cut where the summaries turn round or jump back
 int launch_cover_pass(pnx_ctx *ctx);  // phases 1 + 2 (rows / band / step routes) + the histogram phase, for the current order
 int ensure_chunk_off(pnx_ctx *ctx);
 // The step routes (kernels_cover.hip, kernels_runs.hip): a cross-check module, libpanacus_hip_steps.so, opened on demand.

@@ -335,6 +335,90 @@ def test_more_loose_groups_than_a_pass_takes_in_void_the_pass_and_the_rows_take_
     assert ctx.info().n_reruns == before + 1 and ctx.info().n_loose_groups_last == 1 and ctx.info().n_rows == 0
 
 
+def _paths_with_large_rearrangements(n, P, seed):
+    """pansyn paths, sorted; then per path one LARGE rearrangement: an inversion, a tandem duplication, a stretch moved elsewhere,
+    two inversions, an inversion inside a descending path -- each tens of thousands of steps long"""
+    items, pre, lens = orc.pansyn(seed, n, P)
+    rng = np.random.default_rng(seed)
+    segs = []
+    for k in range(P):
+        s = np.sort(items[int(pre[k]):int(pre[k + 1])])
+        ln = len(s)
+        w = ln // 12
+        a = int(rng.integers(ln // 8, ln - 2 * w - ln // 8))
+        kind = k % 6
+        if kind == 0:
+            s[a:a + w] = s[a:a + w][::-1].copy()
+        elif kind == 1:
+            s = np.concatenate([s[:a + w], s[a:a + w], s[a + w:]])
+        elif kind == 2:
+            cut = s[a:a + w].copy()
+            rest = np.concatenate([s[:a], s[a + w:]])
+            b = int(rng.integers(0, len(rest)))
+            s = np.concatenate([rest[:b], cut, rest[b:]])
+        elif kind == 3:
+            s[a:a + w] = s[a:a + w][::-1].copy()
+            s[a + w + 5000:a + 2 * w] = s[a + w + 5000:a + 2 * w][::-1].copy()
+        elif kind == 4:
+            s = s[::-1].copy()
+            s[a:a + w] = s[a:a + w][::-1].copy()
+        segs.append(s)                                  # kind 5: left sorted
+    items, pre = _concat(segs)
+    return items, pre, lens
+
+
+@pytest.mark.parametrize("splits", [1, 2])
+def test_paths_with_large_rearrangements_are_cut_into_pieces_that_follow_the_ids(band, splits):
+    """inversions, duplications and translocations of a twelfth of a path: the upload's summaries of the chunks find the breaks,
+    the one-shot pass takes the pieces as entries of their own under the path's group -- no rerun, no rows, few spilled steps
+    (the chunk a break lies in), and the oracle's numbers (coverage vector, node and bp histograms with exclusion, presence)"""
+    ctx = band
+    n, P = 1_500_000, 12
+    items, pre, lens = _paths_with_large_rearrangements(n, P, 21)
+    rng = np.random.default_rng(8)
+    excl = (rng.random(n + 1) < 0.02).astype(np.uint8)
+    excl[0] = 0
+    pi = np.arange(P, dtype=np.uint64)
+    os.environ["PNX_BAND_SPLITS"] = str(splits)
+    try:
+        for weights, exclude in ((None, None), (lens, excl)):
+            ctx.set_csr(items.astype(np.uint32), pre, n, weights=weights, exclude=exclude)
+            before = ctx.info().n_reruns
+            assert ctx.info().n_path_cuts >= 10                 # 2 per inversion / duplication, 2-3 per translocation, 4 for two inversions
+            ctx.set_order(pi, pi, P)
+            _check(ctx, items, pre, n, pi, pi, P, weights, exclude, presence=weights is None)
+            info = ctx.info()
+            assert info.n_reruns == before and info.n_rows == 0 and info.band_route_failed == 0 and info.n_loose_groups_last == 0
+            assert info.n_band_entries == P + info.n_path_cuts
+            assert info.n_spilled_last < len(items) // 100      # (uncut, a twelfth of every path would have been spilled: the pass void)
+            order = np.array([7, 0, 3, 5, 1, 2, 10], dtype=np.uint64)       # a subset, groups of several paths
+            gid = np.array([0, 0, 1, 1, 1, 2, 3], dtype=np.uint64)
+            ctx.set_order(order, gid, 4)
+            _check(ctx, items, pre, n, order, gid, 4, weights, exclude, presence=True)
+            assert ctx.info().n_reruns == before and ctx.info().n_rows == 0
+    finally:
+        del os.environ["PNX_BAND_SPLITS"]
+
+
+def test_small_disorder_makes_no_cuts(band):
+    """pansyn-v1r (blocks of 64 steps reversed, copied, moved) and a path with no order at all: nothing to cut at -- the first is
+    spilled, the second left to a bitmap"""
+    ctx = band
+    n, P = 600_000, 6
+    items, pre, _ = orc.pansyn_rearranged(9, n, P)
+    rng = np.random.default_rng(1)
+    a, b = int(pre[2]), int(pre[3])
+    items[a:b] = rng.permutation(items[a:b])
+    ctx.set_csr(items.astype(np.uint32), pre, n)
+    assert ctx.info().n_path_cuts == 0
+    pi = np.arange(P, dtype=np.uint64)
+    before = ctx.info().n_reruns
+    ctx.set_order(pi, pi, P)
+    _check(ctx, items, pre, n, pi, pi, P)
+    info = ctx.info()
+    assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 1 and info.n_band_entries == P
+
+
 @pytest.mark.parametrize("n,p", [(70_000, 5), (300_000, 12), (2_000_000, 24)])
 def test_rearranged_pansyn_device_generator_and_pass(band, n, p):
     """pansyn-v1r (1 % of the 64-step blocks reversed, 0.1 % copied from earlier in the path, 0.05 % moved elsewhere): the
