@@ -4,7 +4,7 @@
 # --kernel-trace + counters of one block each; no trace domains mixed in).  Results land in
 # gpurun_out/profiles/ and are copied into profiles/ by hand.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -79,6 +79,8 @@ timeout 300 python $REPO/benchmarks/bench_closed_form.py > $OUT/${R}_closed_form
 timeout 300 python $REPO/benchmarks/bench_band.py --steps 30 > $OUT/${R}_band_cfg3_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_band.py --paths 1024 --steps 10 > $OUT/${R}_band_10Mx1024_bench.json 2>/dev/null
 timeout 300 python $REPO/benchmarks/bench_band_fallback.py > $OUT/${R}_band_fallback_bench.json 2>/dev/null
+timeout 600 python $REPO/benchmarks/bench_structural_variants.py --check > $OUT/${R}_structural_variants_bench.json 2>/dev/null
+timeout 600 python $REPO/benchmarks/bench_shard_of_8.py > $OUT/${R}_shard_of_8_budget.json 2>/dev/null
 for N in 256 1024; do
     rm -rf /tmp/p_cf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_cf -o cf -- python $REPO/benchmarks/bench_closed_form.py $N > /dev/null 2>&1
     python $REPO/profiles/summarize_rocprof.py "$(db /tmp/p_cf)" $OUT/${R}_closed_form_n${N}_kernel_stats.csv > /dev/null
