@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     // was probed in is a sign of LONG-RANGE disorder (local jitter stays between the ends).  Where a quarter of the probes met
     // one, the paths do not follow the ids and the coverage kernel does not start: k_band_cover reads the two sums.
     {
+        __shared__ uint32_t s_np, s_na;
+        if (threadIdx.x == 0) s_np = s_na = 0;
+        __syncthreads();
         uint32_t np = n_probes, na = n_astray;
         for (int o = 32; o > 0; o >>= 1) {
             np += __shfl_down(np, o);
@@ -290,9 +293,15 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         // (a sample: every 16th workgroup reports -- thousands of atomics on two words would outlast the searches; a grid of a few
         // hundred workgroups reports in full: sixteen of them would speak for two or three entries, and ONE piece of a path that the
         // searches have trouble with would be taken for the whole graph)
-        if ((threadIdx.x & 63u) == 0 && np && ((blockIdx.x & 15u) == 0u || gridDim.x <= 256u)) {
-            atomicAdd(probe_stats, np);
-            if (na) atomicAdd(probe_stats + 1, na);
+        const bool reports = (blockIdx.x & 15u) == 0u || gridDim.x <= 256u;
+        if (reports && (threadIdx.x & 63u) == 0 && np) {
+            atomicAdd(&s_np, np);
+            if (na) atomicAdd(&s_na, na);
+        }
+        __syncthreads();
+        if (reports && threadIdx.x == 0 && s_np) {
+            atomicAdd(probe_stats, s_np);
+            if (s_na) atomicAdd(probe_stats + 1, s_na);
         }
     }
     // A search that probed a stretch of the path that is out of place (a translocated block, a copy of another region) may end
@@ -1088,7 +1097,7 @@ static int ensure_spill(pnx_ctx *ctx) {
 // round or jumps back (pass_pipeline.hip: path_cuts_from_chunks) -- the pieces of a path are entries of their own under the
 // path's group.  Made once per (graph, order); without cuts it is the order itself with the paths' offsets written out, which
 // saves the index kernel a dependent load.
-static int ensure_band_entries(pnx_ctx *ctx) {
+int ensure_band_entries(pnx_ctx *ctx) {
     if (ctx->entries_valid) return PNX_OK;
     const uint32_t no = ctx->n_ordered;
     const bool cuts = ctx->h_cut_off.size() == (size_t)ctx->n_paths + 1 && !ctx->h_cuts.empty();

@@ -1018,6 +1018,8 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
     ctx->n_ordered = n_ordered;
     ctx->n_groups = n_groups;
     ctx->have_order = true;
+    // (the entries of a one-shot pass follow from the order and the graph alone: made here, not inside the first pass)
+    if (use_rows(ctx) && ctx->have_csr && ctx->h_path_off.size() == (size_t)ctx->n_paths + 1 && (rc = ensure_band_entries(ctx))) return rc;
     return PNX_OK;
 }
 

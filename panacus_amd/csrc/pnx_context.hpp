@@ -392,6 +392,7 @@ int ensure_rows(pnx_ctx *ctx, bool validate);          // d_rows & co. (no-op wh
 int launch_rows_phases(pnx_ctx *ctx, bool write_m);    // phases 1 + 2 of a pass over rows
 // kernels_band.hip
 bool band_route_fits(const pnx_ctx *ctx, uint32_t n_entries);  // is the one-shot route worth it for this shape?
+int ensure_band_entries(pnx_ctx *ctx);                         // the visiting order with the paths cut where they turn round or jump back: once per (graph, order)
 int launch_band_phases(pnx_ctx *ctx, bool write_m);            // phases 1 + 2 of a one-shot pass over the steps
 int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m);  // phase 3: spilled steps added, histogram handed over
 uint32_t band_route_splits(const pnx_ctx *ctx, uint32_t n_groups);  // workgroups per band for this shape
