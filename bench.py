@@ -534,10 +534,15 @@ class OneShot:
 
     def step(self):
         capi, hostlib, ctx, torch = self.capi, self.hostlib, self.ctx, self.torch
+        device_side = self.growth_on_device and self.rank == 0
+        if device_side and not self.use_dist and not os.environ.get("PANACUS_BENCH_KEEP_TABLES") and not os.environ.get("PANACUS_BENCH_PYTHON_STEP"):
+            # one GPU: the whole call is ONE native call of the host library (pnh_histgrowth_resident: the library calls of the lines
+            # below, in their order -- everything derived dropped, the tables' first kernels, the pass, the curves behind it, the
+            # fetches -- without Python between them: ~15 us of a 0.74 ms step)
+            return hostlib.histgrowth_resident(ctx, self.P, self.thr, drop_derived=True, drop_tables=True)
         ctx.config(capi.CFG_DROP_DERIVED, 0)            # no rows, no index: the pass starts from the steps
         if self.rank == 0 and not os.environ.get("PANACUS_BENCH_KEEP_TABLES"):  # (the variable: an experiment, never a reported number)
             ctx.config(capi.CFG_DROP_GROWTH_TABLES, 0)  # ... and the closed forms from (n, thresholds)
-        device_side = self.growth_on_device and self.rank == 0
         if device_side:
             # the thresholds are known: the two small table kernels go first, while the pass's kernels are being launched (beside the
             # pass the perc_mult rows -- LDS round trips per lane -- take 0.5 ms instead of 23 us and hold the curves up behind it)

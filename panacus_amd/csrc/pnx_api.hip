@@ -237,7 +237,8 @@ static int settle_oldest(pnx_ctx *ctx) {
         const bool bad = need_build || (t->h_flags[1] != 0 && !used_m);
         if (t->h_flags[4] != 0) return ctx->fail(PNX_EHIP, "run index inconsistency (internal error)");
         if (!bad) {
-            if (t->band && getenv("PNX_BAND_DEBUG") && ctx->d_entry_loose.p && ctx->d_group_loose.p) {  // (what the pass's tail must have set back)
+            static const bool band_debug = getenv("PNX_BAND_DEBUG") != nullptr;
+            if (t->band && band_debug && ctx->d_entry_loose.p && ctx->d_group_loose.p) {  // (what the pass's tail must have set back)
                 std::vector<uint32_t> ef(ctx->n_entries), gf(ctx->n_groups), st(20);
                 (void)hipDeviceSynchronize();
                 (void)hipMemcpy(ef.data(), ctx->d_entry_loose.p, ef.size() * 4, hipMemcpyDeviceToHost);
@@ -491,6 +492,7 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
         if (summarise) {
             path_cuts_from_chunks(ctx);
             if ((rc = refine_path_cuts(ctx))) return rc;
+            std::vector<pnx::ChunkSummary>().swap(ctx->h_chunk_sum);  // (28 bytes per 4096 steps: not kept beyond the cuts)
             if (getenv("PNX_BAND_DEBUG"))
                 for (uint32_t p = 0; p < n_paths; ++p) {
                     fprintf(stderr, "[panacus_amd] path %u (%llu steps): cuts at", p, (unsigned long long)(ctx->h_path_off[p + 1] - ctx->h_path_off[p]));

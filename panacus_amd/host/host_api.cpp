@@ -342,6 +342,45 @@ int64_t pnh_calc_all_growths_end(void *handle, uint64_t n, uint32_t n_pairs, dou
     return (int64_t)n;
 }
 
+// One complete `histgrowth` from the RESIDENT steps of a context whose order is set, in one native call: the coverage pass, its
+// histogram, the closed-form curves of every (coverage, quorum) pair -- what `panacus histgrowth` computes after the parse
+// (hist.rs:68-87 behind graph_broker.rs:353-362), with nothing but library calls in between (a host language between them costs
+// tens of microseconds of a sub-millisecond call).  flags: 1 = everything derived from the steps is dropped first, 2 = the
+// closed forms' tables too (a cold call).  The curves come from the device when the context is the offload context
+// (pnh_set_quorum_offload) and takes n_groups, else from the host threads.  hist_out: n_groups + 1, growth_out: n_pairs x n_groups.
+// Returns 0, or the library's error code (pnx_last_error has the text).
+int pnh_histgrowth_resident(void *pnx_context, uint64_t n_groups, const int *cov_kind, const double *cov_val, const int *quo_kind,
+                            const double *quo_val, uint32_t n_pairs, uint32_t flags, uint64_t *hist_out, double *growth_out) {
+    pnx_ctx *ctx = static_cast<pnx_ctx *>(pnx_context);
+    if (!ctx || !hist_out || !growth_out || n_groups == 0) return PNX_EINVAL;
+    try {
+        std::vector<pnh::Threshold> cov, quo;
+        for (uint32_t t = 0; t < n_pairs; ++t) {
+            cov.push_back(pnh::Threshold{cov_kind[t], cov_val[t]});
+            quo.push_back(pnh::Threshold{quo_kind[t], quo_val[t]});
+        }
+        int rc;
+        if ((flags & 1u) && (rc = pnx_config(ctx, PNX_CFG_DROP_DERIVED, 0))) return rc;
+        if ((flags & 2u) && (rc = pnx_config(ctx, PNX_CFG_DROP_GROWTH_TABLES, 0))) return rc;
+        // the first part of the tables before the pass is enqueued (two small kernels that must not run beside it), the curves behind it
+        const bool tables = pnh::growth_tables_begin(n_groups, cov, quo);
+        if ((rc = pnx_hist_async(ctx))) return rc;
+        pnh::GrowthRun *run = tables ? pnh::calc_all_growths_begin_on_device(n_groups, cov, quo) : nullptr;
+        if ((rc = pnx_hist_fetch(ctx, nullptr, hist_out))) {
+            if (run) (void)pnh::calc_all_growths_end(run);
+            return rc;
+        }
+        if (!run) run = pnh::calc_all_growths_begin(std::vector<uint64_t>(hist_out, hist_out + n_groups + 1), cov, quo, 0);
+        const std::vector<std::vector<double>> g = pnh::calc_all_growths_end(run);
+        for (uint32_t t = 0; t < n_pairs && t < g.size(); ++t)
+            std::memcpy(growth_out + (size_t)t * n_groups, g[t].data(), std::min<size_t>(g[t].size(), n_groups) * sizeof(double));
+        return 0;
+    } catch (const std::exception &e) {
+        g_host_err = e.what();
+        return PNX_EHIP;
+    }
+}
+
 void pnh_set_threads(unsigned n) { pnh::ThreadPool::instance().set_threads(n); }
 unsigned pnh_get_threads(void) { return pnh::ThreadPool::instance().size(); }
 

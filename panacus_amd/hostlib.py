@@ -132,6 +132,27 @@ def calc_growths_begin_on_device(n_groups: int, pairs):
     return (handle, len(pairs), n_groups) if handle else None
 
 
+def histgrowth_resident(ctx, n_groups: int, pairs, *, drop_derived=False, drop_tables=False, hist_out=None, growth_out=None):
+    """One complete histgrowth from the resident steps of `ctx` (a capi.Context whose order is set) in ONE native call
+    (pnh_histgrowth_resident): pass, histogram, the curves of every pair -- from the device when ctx is the offload context
+    (set_quorum_offload).  -> (hist u64[n_groups + 1], [curve f64[n_groups] per pair]); the arrays are hist_out / growth_out if given."""
+    L = load()
+    if not getattr(L, "_hg_bound", False):
+        L.pnh_histgrowth_resident.restype = C.c_int
+        L.pnh_histgrowth_resident.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_double), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L._hg_bound = True
+    ck, cv, qk, qv = _pair_arrays(pairs)
+    T = len(pairs)
+    h = hist_out if hist_out is not None else np.zeros(n_groups + 1, dtype=np.uint64)
+    g = growth_out if growth_out is not None else np.zeros((T, n_groups), dtype=np.float64)
+    rc = L.pnh_histgrowth_resident(ctx._h, n_groups, ck, cv, qk, qv, T, (1 if drop_derived else 0) | (2 if drop_tables else 0),
+                                   h.ctypes.data, g.ctypes.data)
+    if rc:
+        raise RuntimeError(f"pnh_histgrowth_resident failed ({rc}): {ctx._L.pnx_last_error(ctx._h).decode()} {L.pnh_last_error().decode()}")
+    return h, [g[t] for t in range(T)]
+
+
 def calc_growths_end(pending):
     """Second half: waits for the device part, finishes on the host threads. -> list of curves"""
     handle, T, n = pending

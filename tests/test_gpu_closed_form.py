@@ -289,3 +289,35 @@ def test_reference_vectors_through_the_device_closed_forms(ctx, golden):
         assert n_vals == 660
     finally:
         hostlib.set_quorum_offload(None)
+
+
+def test_histgrowth_in_one_native_call_equals_the_calls_one_by_one_and_the_oracle():
+    """pnh_histgrowth_resident: pass + histogram + the curves of every pair from the resident steps in one call of the host library
+    -- the same numbers as pnx_hist followed by the closed forms, and as the oracle's (hist.rs:68-187 restated), cold and warm,
+    with the curves from the device (offload context) and from the host threads"""
+    import oracle as orc
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    n, p = 400_000, 300
+    pairs = [(Threshold(ABSOLUTE, 1), Threshold(RELATIVE, 0.0)), (Threshold(ABSOLUTE, 2), Threshold(RELATIVE, 0.0)),
+             (Threshold(ABSOLUTE, 1), Threshold(RELATIVE, 0.5))]
+    items, pre, _ = orc.pansyn(9, n, p)
+    pi = np.arange(p, dtype=np.uint64)
+    oh = orc.hist(orc.coverage(items, pre, pi, pi, n), p)
+    want = [orc.growth(oh, (orc.ABSOLUTE, int(c.value)), (orc.RELATIVE, q.value)) for c, q in pairs]
+    with capi.Context(0) as ctx:
+        ctx.set_csr_pansyn(9, n, p, with_weights=False)
+        order = np.arange(p, dtype=np.uint32)
+        ctx.set_order(order, order, p)
+        for offload in (True, False):
+            hostlib.set_quorum_offload(ctx if offload else None, 256)
+            try:
+                for cold in (True, False, True):
+                    h, g = hostlib.histgrowth_resident(ctx, p, pairs, drop_derived=cold, drop_tables=cold)
+                    assert np.array_equal(h, oh)
+                    for a, b in zip(g, want):
+                        assert a.tobytes() == np.asarray(b, dtype=np.float64).tobytes()
+            finally:
+                hostlib.set_quorum_offload(None)
+        _, h2 = ctx.hist(want_countable=False)
+        assert np.array_equal(h2, oh)
