@@ -349,6 +349,45 @@ def test_cli_cfg2_full_size_hist_bp(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_hist_on_a_gfa_whose_paths_have_large_rearrangements(tmp_path):
+    """a GFA file whose P lines hold an inversion, a tandem duplication, a translocation, two inversions, an inversion inside a
+    descending path (each a twelfth of the path) and one shuffled path: `hist -c node|bp` and `histgrowth` through the whole
+    CLI path (the step columns tokenised on the device, the upload's chunk summaries cutting the paths, the one-shot pass over the
+    pieces, the shuffled path's group left to a bitmap) against the oracle on the same file"""
+    from test_gpu_band import _paths_with_large_rearrangements
+    n, P = 300_000, 34          # (a small graph takes the one-shot route from 32 entries of the visiting order on)
+    items, pre, _ = _paths_with_large_rearrangements(n, P - 1, 33)
+    rng = np.random.default_rng(3)
+    segs = [items[int(pre[k]):int(pre[k + 1])] for k in range(P - 1)]
+    segs.append(rng.permutation(segs[2]))                   # one path with no order at all
+    lens = rng.integers(1, 9, size=n)
+    path = str(tmp_path / "sv.gfa")
+    with open(path, "w") as f:
+        f.write("H\tVN:Z:1.1\n")
+        f.write("".join(f"S\t{i + 1}\t{'A' * int(lens[i])}\n" for i in range(n)))
+        for k, sgm in enumerate(segs):
+            f.write(f"P\ts{k}#1#c{k}\t" + ",".join(f"{int(x)}+" for x in sgm) + "\t*\n")
+    g = orc.Graph(path, index_edges=False)
+    pi, gi, names = g.path_order(orc.GROUP_PATHID)
+    it, off = g.item_table(orc.NODE)
+    cov = orc.coverage(it, off, pi, gi, g.n_nodes)
+    for cname, w in (("node", None), ("bp", g.node_lens)):
+        exp = orc.hist(cov, P, w)
+        rc, out, err = hl.run_cli(["hist", "-c", cname, path])
+        assert rc == 0, err
+        rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+        assert [int(r[1]) for r in rows] == exp.tolist()
+    h = orc.hist(cov, P)
+    rc, out, err = hl.run_cli(["histgrowth", "-a", "-c", "node", "-l", "1,2", "-q", "0,0.5", path])
+    assert rc == 0, err
+    rows = [r.split("\t") for r in _body(out).split("\n")[4:] if r]
+    assert [int(r[1]) for r in rows] == h.tolist()
+    for k, (c, q) in enumerate(((1, 0.0), (2, 0.5))):
+        exp = orc.growth(h, (orc.ABSOLUTE, c), (orc.RELATIVE, q))
+        assert [r[2 + k] for r in rows[1:]] == [hl.format_f64(math.floor(x)) for x in exp]
+
+
+@pytest.mark.gpu
 def test_cli_similarity_chrM(golden_dir):
     """`similarity` = the Jaccard table of the groups, rows and columns in the dendrogram order of
     -m/--method (default centroid) like Similarity::set_table (similarity.rs:119-190): every method,
