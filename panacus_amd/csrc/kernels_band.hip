@@ -787,7 +787,15 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add((g_u32 *)(a.scratch + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (agent_load(a.scratch + 2) < LOOSE_WORKGROUPS) __builtin_amdgcn_s_sleep(127);  // (a poll every ~3 us: the arrivals queue on the same word)
+            // (a poll every ~3 us: the arrivals queue on the same word.  Bounded: the 256 workgroups are the first of the grid and the
+            // chip holds three times as many, but should several contexts' tail kernels ever share it so that none has all its
+            // markers resident, the wait ends after ~70 ms: the pass is void -- flags[5] |= 64 --, the host clears the bitmaps)
+            uint32_t polls = 0;
+            while (agent_load(a.scratch + 2) < LOOSE_WORKGROUPS && polls < 20000u) {
+                __builtin_amdgcn_s_sleep(127);
+                ++polls;
+            }
+            if (polls >= 20000u) atomicOr(a.flags + 5, 64u);
         }
         __syncthreads();
         for (uint32_t tile = blockIdx.x * BAND_TAIL_WAVES + wave; tile < a.n_tiles; tile += LOOSE_WORKGROUPS * BAND_TAIL_WAVES) {
@@ -1077,7 +1085,8 @@ static int ensure_spill(pnx_ctx *ctx) {
             return rc;
         if (ctx->d_entry_loose.cap != e0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_entry_loose.p, 0, ctx->d_entry_loose.cap, ctx->s_pre));
         if (ctx->d_group_loose.cap != f0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_group_loose.p, 0, ctx->d_group_loose.cap, ctx->s_pre));
-        if (ctx->d_loose_bits.cap != b0) PNX_HIP(ctx, hipMemsetAsync(ctx->d_loose_bits.p, 0, ctx->d_loose_bits.cap, ctx->s_pre));
+        if (ctx->d_loose_bits.cap != b0 || ctx->loose_dirty) PNX_HIP(ctx, hipMemsetAsync(ctx->d_loose_bits.p, 0, ctx->d_loose_bits.cap, ctx->s_pre));
+        ctx->loose_dirty = false;
     }
     // (a burst holds 1 .. 256 records; a list of single-step bursts is cut short by the directory: 1 entry per 4 records)
     if ((rc = ensure(ctx, ctx->d_spill, cap * 4)) || (rc = ensure(ctx, ctx->d_spill_dir, (cap / 4) * 8))) return rc;

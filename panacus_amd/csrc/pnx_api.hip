@@ -217,8 +217,9 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->band_failed = true;
             ctx->pass_band = false;
             ctx->n_reruns += 1;
+            if (t->h_flags[5] & 64u) ctx->loose_dirty = true;
             // (why: 1 inconsistent index entry, 2 spill list full, 4 scan volume, 8 the index's probes met steps from elsewhere,
-            // 16 more loose groups than a pass takes in, 32 an id that is no item)
+            // 16 more loose groups (or steps in them) than a pass takes in, 32 an id that is no item, 64 the marking workgroups did not meet)
             if (getenv("PNX_BAND_DEBUG"))
                 fprintf(stderr, "[panacus_amd] one-shot pass void: flags[5] = %u, spilled %u in %u bursts, loose groups %u\n", t->h_flags[5],
                         t->h_flags[6], t->h_flags[7], t->h_flags[3]);

@@ -227,6 +227,7 @@ struct pnx_ctx {
     bool entries_valid = false;        // (of the order and the graph as they stand)
     pnx::DevBuf d_group_loose, d_entry_loose, d_loose_bits;  // groups with a path that does not follow the ids at all: their flags, their presence bitmaps (kernels_band.hip: BandLoose)
     uint32_t n_loose_last = 0;                // ... how many the pass settled last took in
+    bool loose_dirty = false;                 // a pass gave up waiting for its marking workgroups: the bitmaps are cleared before the next one
     uint32_t spill_cap = 0, spill_gen = 0;
     uint64_t spill_slots = 0;
     uint64_t n_spilled_total = 0;  // spilled steps of all settled passes of this upload
