@@ -646,6 +646,10 @@ typedef struct {
                                 for at least 8 K steps (inversions, duplications, translocations): the one-shot pass takes the
                                 pieces between them as entries of their own, under the path's group */
     uint32_t n_band_entries; /* (round 5) entries of the one-shot pass enqueued last: the visiting order with the paths cut there */
+    uint32_t n_sorted_copies;/* (round 5) paths that follow the ids nowhere (shuffled) and are stored a second time, sorted, behind the
+                                steps of the graph: the one-shot pass reads the copy (coverage does not depend on the order of a
+                                path's steps); pnx_get_csr and the path rows see the ItemTable as it was uploaded */
+    uint32_t reserved1;
 } pnx_info_t;
 /* pnx_info assumes the caller's pnx_info_t is THIS header's (the struct has grown every round, at its end).  A binding built
  * against an older header -- or one that wants to stay valid across rebuilds of the library -- calls pnx_info_sized with

@@ -25,7 +25,7 @@ LIB_STEPS = os.path.join(HERE, "libpanacus_hip_steps.so")
 LIB_HOST = os.path.join(HERE, "libpanacus_host.so")
 CLI = os.path.join(HERE, "panacus-amd")
 
-HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "pass_pipeline.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_band.hip", "kernels_gfa.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
+HIP_SOURCES = ["pnx_api.hip", "pnx_comm.hip", "pass_pipeline.hip", "upload_scan.hip", "kernels_hist.hip", "kernels_rows.hip", "kernels_band.hip", "kernels_gfa.hip", "kernels_relabel.hip", "kernels_cut.hip", "kernels_growth.hip", "kernels_pairs.hip", "kernels_pairs_mfma.hip", "kernels_closed_form.hip", "pansyn.hip"]
 STEP_SOURCES = ["kernels_cover.hip", "kernels_runs.hip"]  # the cross-check module
 HOST_SOURCES = ["thread_pool.cpp", "growth_closed_form.cpp", "gfa_graph.cpp", "tables.cpp", "synth_gfa.cpp", "linkage.cpp", "mini_yaml.cpp", "report.cpp", "commands.cpp", "host_api.cpp"]
 

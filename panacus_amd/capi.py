@@ -51,7 +51,7 @@ class PnxInfo(C.Structure):
                 ("n_band_passes", C.c_uint32), ("band_route_failed", C.c_uint32), ("n_rows_q_passes", C.c_uint64),
                 ("n_spilled_last", C.c_uint32), ("band_splits", C.c_uint32), ("n_spilled_total", C.c_uint64),
                 ("n_spill_bursts_last", C.c_uint32), ("n_loose_groups_last", C.c_uint32), ("n_path_cuts", C.c_uint32),
-                ("n_band_entries", C.c_uint32)]
+                ("n_band_entries", C.c_uint32), ("n_sorted_copies", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class PnxWalks(C.Structure):  # pnx_walks (include/panacus_amd.h)

@@ -1119,8 +1119,11 @@ int ensure_band_entries(pnx_ctx *ctx) {
     for (uint32_t k = 0; k < no; ++k) {
         const uint32_t p = ctx->h_ord_path[k], g = ctx->h_ord_group[k];
         uint64_t a = ctx->h_path_off[p];
-        const uint64_t z = ctx->h_path_off[p + 1];
-        if (cuts) {
+        uint64_t z = ctx->h_path_off[p + 1];
+        if (ctx->h_sorted_at.size() == ctx->n_paths && ctx->h_sorted_at[p]) {  // a path that follows the ids nowhere: its sorted copy (upload_scan.hip)
+            z = ctx->h_sorted_at[p] + (z - a);
+            a = ctx->h_sorted_at[p];
+        } else if (cuts) {
             for (uint32_t c = ctx->h_cut_off[p]; c < ctx->h_cut_off[p + 1]; ++c) {
                 const uint64_t cut = ctx->h_cuts[c];
                 if (cut > a && cut < z) {

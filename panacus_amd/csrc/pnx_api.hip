@@ -435,6 +435,9 @@ static void begin_upload(pnx_ctx *ctx) {
     ctx->h_chunk_sum.clear();
     ctx->h_cuts.clear();
     ctx->h_cut_off.clear();
+    ctx->h_jumbled.clear();
+    ctx->h_sorted_at.clear();
+    ctx->n_sorted_copies = 0;
     ctx->entries_valid = false;
     ctx->have_csr = false;
     ctx->have_order = false;
@@ -480,6 +483,9 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
     ctx->h_chunk_sum.clear();
     ctx->h_cuts.clear();
     ctx->h_cut_off.clear();
+    ctx->h_jumbled.clear();
+    ctx->h_sorted_at.clear();
+    ctx->n_sorted_copies = 0;
     ctx->entries_valid = false;
     if (item_key || !use_rows(ctx) || defer_rows) {
         PNX_HIP(ctx, hipMemsetAsync(ctx->d_flags.p, 0, 8 * sizeof(uint32_t), ctx->stream));
@@ -493,6 +499,7 @@ static int finish_upload(pnx_ctx *ctx, uint64_t S, uint32_t n_paths, uint32_t n_
         if (summarise) {
             path_cuts_from_chunks(ctx);
             if ((rc = refine_path_cuts(ctx))) return rc;
+            if ((rc = sort_jumbled_paths(ctx))) return rc;
             std::vector<pnx::ChunkSummary>().swap(ctx->h_chunk_sum);  // (28 bytes per 4096 steps: not kept beyond the cuts)
             if (getenv("PNX_BAND_DEBUG"))
                 for (uint32_t p = 0; p < n_paths; ++p) {
@@ -914,6 +921,8 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     dst->h_path_off = src->h_path_off;
     dst->h_cuts = src->h_cuts;  // (where the paths turn round or jump back: found at the owner's upload)
     dst->h_cut_off = src->h_cut_off;
+    dst->h_sorted_at = src->h_sorted_at;  // (the copies lie in the owner's d_items, behind the steps)
+    dst->n_sorted_copies = src->n_sorted_copies;
     dst->entries_valid = false;
     dst->weighted = src->weighted;
     dst->have_weights = src->have_weights;
@@ -1396,6 +1405,8 @@ int pnx_info(pnx_ctx *ctx, pnx_info_t *out) {
     out->n_loose_groups_last = ctx->n_loose_last;
     out->n_path_cuts = (uint32_t)ctx->h_cuts.size();
     out->n_band_entries = ctx->entries_valid ? ctx->n_entries : 0u;
+    out->n_sorted_copies = ctx->n_sorted_copies;
+    out->reserved1 = 0;
     return PNX_OK;
 }
 

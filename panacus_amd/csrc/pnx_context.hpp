@@ -222,6 +222,9 @@ struct pnx_ctx {
     std::vector<pnx::ChunkSummary> h_chunk_sum;
     std::vector<uint64_t> h_cuts;      // absolute step positions, path by path
     std::vector<uint32_t> h_cut_off;   // n_paths + 1: the cuts of path p are h_cuts[h_cut_off[p] .. h_cut_off[p + 1])
+    std::vector<uint8_t> h_jumbled;    // n_paths: most chunks of the path go both ways
+    std::vector<uint64_t> h_sorted_at; // n_paths: where in d_items (behind the graph's steps) the path is stored once more in the order of the ids, or 0
+    uint32_t n_sorted_copies = 0;
     std::vector<uint32_t> h_ent_group;
     uint32_t n_entries = 0;
     bool entries_valid = false;        // (of the order and the graph as they stand)
@@ -368,7 +371,8 @@ int prof_resolve(pnx_ctx *ctx, bool wait = true);
 int launch_validate_items(pnx_ctx *ctx, uint32_t *d_bad);
 int launch_chunk_summaries(pnx_ctx *ctx, uint32_t *d_bad);  // ... of a graph the one-shot route may take: the ids validated, the chunks summarised
 int refine_path_cuts(pnx_ctx *ctx);                        // ... every cut moved from its chunk boundary to the step where the ids jump
-void path_cuts_from_chunks(pnx_ctx *ctx);                   // ... and the paths cut where the summaries turn round or jump back
+void path_cuts_from_chunks(pnx_ctx *ctx);
+int sort_jumbled_paths(pnx_ctx *ctx);                      // ... and the paths that follow the ids nowhere stored once more, sorted (upload_scan.hip)                   // ... and the paths cut where the summaries turn round or jump back
 int launch_cover_pass(pnx_ctx *ctx);  // phases 1 + 2 (rows / band / step routes) + the histogram phase, for the current order
 int ensure_chunk_off(pnx_ctx *ctx);
 // The step routes (kernels_cover.hip, kernels_runs.hip): a cross-check module, libpanacus_hip_steps.so, opened on demand.

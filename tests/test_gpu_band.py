@@ -261,23 +261,25 @@ def _graph_with_shuffled_paths(n, P, which, seed, half=()):
     segs = [np.sort(items[int(pre[k]):int(pre[k + 1])]) for k in range(P)]
     for k in which:
         segs[k] = rng.permutation(segs[k])                 # no order at all: every step is out of place
-    for k in half:                                         # in order up to the middle, shuffled from there on
-        m = len(segs[k]) // 2
+    for k in half:                                         # in order for the first 55 %, shuffled from there on
+        m = len(segs[k]) * 55 // 100
         segs[k] = np.concatenate([segs[k][:m], rng.permutation(segs[k][m:])])
     items, pre = _concat(segs)
     return items, pre, lens
 
 
 @pytest.mark.parametrize("splits", [1, 3])
-def test_paths_that_do_not_follow_the_ids_at_all_are_left_to_bitmaps(band, splits):
-    """three shuffled paths and one that is shuffled from its middle on, among sorted ones and one with strays: their groups are
-    taken out of the bands, their steps marked in per-group bitmaps and folded in by the pass's tail -- no rerun, no rows, the
-    oracle's numbers (coverage vector, histogram of node counts and of bp with exclusion, presence matrix)"""
+def test_paths_that_do_not_follow_the_ids_are_sorted_at_upload_or_left_to_bitmaps(band, splits):
+    """three shuffled paths, two that are shuffled over their last 45 %, among sorted ones and one with strays.  The shuffled ones
+    are stored a second time at upload, sorted (the pass reads the copies like any path; pnx_get_csr returns what was uploaded);
+    the partly shuffled ones are recognised by the index kernel: their groups are taken out of the bands, their steps marked in
+    per-group bitmaps and folded in by the pass's tail.  No rerun, no rows, the oracle's numbers (coverage vector, histogram of
+    node counts and of bp with exclusion, presence matrix)"""
     ctx = band
     n = 300_000
-    items, pre, lens = _graph_with_shuffled_paths(n, 10, (1, 4, 6), 2, half=(8,))
-    a = int(pre[3]) + 1000
-    items[a:a + 300] = items[a + 5000:a + 5300].copy()      # (path 3 strays: spilled steps in the same pass)
+    items, pre, lens = _graph_with_shuffled_paths(n, 10, (1, 4, 6), 2, half=(8, 3))
+    a = int(pre[5]) + 1000
+    items[a:a + 300] = items[a + 5000:a + 5300].copy()      # (path 5 strays: spilled steps in the same pass)
     rng = np.random.default_rng(9)
     excl = (rng.random(n + 1) < 0.04).astype(np.uint8)
     excl[0] = 0
@@ -287,23 +289,26 @@ def test_paths_that_do_not_follow_the_ids_at_all_are_left_to_bitmaps(band, split
         for weights, exclude in ((None, None), (lens, excl)):
             ctx.set_csr(items.astype(np.uint32), pre, n, weights=weights, exclude=exclude)
             before = ctx.info().n_reruns
+            assert ctx.info().n_sorted_copies == 3
+            got, off, _ = ctx.get_csr()
+            assert np.array_equal(got, items.astype(np.uint32)) and np.array_equal(off, pre)   # the ItemTable as uploaded
             ctx.set_order(pi, pi, 10)                       # every path its own group
             _check(ctx, items, pre, n, pi, pi, 10, weights, exclude, presence=True)
             info = ctx.info()
             assert info.n_reruns == before and info.n_rows == 0 and info.band_route_failed == 0
-            assert info.n_loose_groups_last == 4 and info.n_spilled_last > 0
-            gid = (pi // 2).astype(np.uint64)               # groups of two: a loose path takes its sorted partner along
+            assert info.n_loose_groups_last == 2 and info.n_spilled_last > 0
+            gid = (pi // 2).astype(np.uint64)               # groups of two: a loose path takes its partner along
             ctx.set_order(pi, gid, 5)
             _check(ctx, items, pre, n, pi, gid, 5, weights, exclude, presence=True)
             info = ctx.info()
-            assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 4
-            order = np.array([9, 6, 0, 2, 1], dtype=np.uint64)      # a subset, the loose paths in one group
+            assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 2
+            order = np.array([9, 6, 0, 8, 3], dtype=np.uint64)      # a subset, the two loose paths in one group
             gid = np.array([0, 1, 1, 2, 2], dtype=np.uint64)
             ctx.set_order(order, gid, 3)
             _check(ctx, items, pre, n, order, gid, 3, weights, exclude, presence=True)
-            assert ctx.info().n_reruns == before and ctx.info().n_loose_groups_last == 2
-            ctx.set_order(np.array([0, 2, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3)   # none of them
-            _check(ctx, items, pre, n, np.array([0, 2, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3, weights, exclude)
+            assert ctx.info().n_reruns == before and ctx.info().n_loose_groups_last == 1
+            ctx.set_order(np.array([0, 1, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3)   # none of the loose ones
+            _check(ctx, items, pre, n, np.array([0, 1, 5], dtype=np.uint64), np.array([0, 1, 2], dtype=np.uint64), 3, weights, exclude)
             assert ctx.info().n_loose_groups_last == 0
     finally:
         del os.environ["PNX_BAND_SPLITS"]
@@ -313,8 +318,9 @@ def test_more_loose_groups_than_a_pass_takes_in_void_the_pass_and_the_rows_take_
     ctx = band
     n = 200_000
     P = 40
-    items, pre, _ = _graph_with_shuffled_paths(n, P, tuple(range(0, P, 2)), 3)     # 20 groups of shuffled paths: more than 16
+    items, pre, _ = _graph_with_shuffled_paths(n, P, (), 3, half=tuple(range(0, P, 2)))     # 20 groups with a partly shuffled path: more than 16
     ctx.set_csr(items.astype(np.uint32), pre, n)
+    assert ctx.info().n_sorted_copies == 0
     pi = np.arange(P, dtype=np.uint64)
     ctx.set_order(pi, pi, P)
     before = ctx.info().n_reruns
@@ -327,7 +333,7 @@ def test_more_loose_groups_than_a_pass_takes_in_void_the_pass_and_the_rows_take_
     cnt, h = ctx.hist()                                             # and the graph is remembered: no second attempt
     assert np.array_equal(cnt, ocov) and np.array_equal(h, oh) and ctx.info().n_reruns == before + 1
     # the next upload starts from a clean slate (the flags of the groups were set back by the void pass's tail)
-    items, pre, _ = _graph_with_shuffled_paths(n, 6, (2,), 4)
+    items, pre, _ = _graph_with_shuffled_paths(n, 6, (), 4, half=(2,))
     ctx.set_csr(items.astype(np.uint32), pre, n)
     pi = np.arange(6, dtype=np.uint64)
     ctx.set_order(pi, pi, 6)
@@ -402,7 +408,7 @@ def test_paths_with_large_rearrangements_are_cut_into_pieces_that_follow_the_ids
 
 def test_small_disorder_makes_no_cuts(band):
     """pansyn-v1r (blocks of 64 steps reversed, copied, moved) and a path with no order at all: nothing to cut at -- the first is
-    spilled, the second left to a bitmap"""
+    spilled, the second stored once more, sorted"""
     ctx = band
     n, P = 600_000, 6
     items, pre, _ = orc.pansyn_rearranged(9, n, P)
@@ -416,7 +422,7 @@ def test_small_disorder_makes_no_cuts(band):
     ctx.set_order(pi, pi, P)
     _check(ctx, items, pre, n, pi, pi, P)
     info = ctx.info()
-    assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 1 and info.n_band_entries == P
+    assert info.n_reruns == before and info.n_rows == 0 and info.n_loose_groups_last == 0 and info.n_sorted_copies == 1 and info.n_band_entries == P
 
 
 @pytest.mark.parametrize("n,p", [(70_000, 5), (300_000, 12), (2_000_000, 24)])
