@@ -57,7 +57,7 @@ constexpr uint64_t BAND_DESC = 1ull << 63;  // index entry: the path runs throug
 constexpr int BAND_MAX_SPLITS = 16;         // workgroups that share a band (each takes a range of the visiting order)
 constexpr int SCAN_U = 4;                   // 16-byte loads a lane of k_band_tail keeps in flight while it scans a segment
 constexpr uint32_t BAND_TAIL_WAVES = 8;     // waves per workgroup of k_band_tail (a wave takes one burst of the spill list at a time)
-constexpr uint32_t BAND_TAIL_GRID = 1024;   // ... and its workgroups
+constexpr uint32_t BAND_TAIL_GRID = 1024;   // ... and at most this many workgroups (as many as the chip holds at once: launch_band_tail)
 
 constexpr uint32_t LOOSE_MAX = 16;          // groups with paths that do not follow the ids at all which one pass takes in
 constexpr uint32_t LOOSE_WORKGROUPS = 256;  // the first workgroups of k_band_tail's grid: they mark the steps of such groups and fold the bitmaps
@@ -708,17 +708,20 @@ __device__ static inline bool spill_set_insert(unsigned long long *slots, uint32
 // What it costs is the chain of dependent reads a burst starts at places nobody has touched before (its records -> the band
 // edges of its group's entries -> the segment; then set slot -> coverage word): ~7 us per burst and wave on 10 M x 256
 // whatever the volume of the scans (DESIGN.md, K-band), so bursts are what the time scales with, 8192 of them at a time.
+// (The histogram bins an added pair moves are the workgroup's LDS bins, flushed once at the end: most pairs move an item from
+// bin 0 to bin 1 or from 1 to 2, and two atomics per pair on the same few words of a replica in HBM are performed one after the
+// other, ~12 ns each -- 1 M pairs on 64 replicas: 0.19 of the tail kernel's 0.21 ms on pansyn-v1r 10 M x 256.)
 struct TailAdd {
     const BandTail &a;
-    __device__ __forceinline__ void operator()(uint32_t g, uint32_t id, uint32_t salt) const {
+    unsigned long long *bins;  // the workgroup's histogram bins in LDS (hs.rep != nullptr)
+    __device__ __forceinline__ void operator()(uint32_t g, uint32_t id) const {
         if (a.exclude && a.exclude[id]) return;
         if (!spill_set_insert(a.hset, a.hmask, a.gen, g, id)) return;
         const uint32_t old = atomicAdd(a.countable + id, 1u);  // AbacusByTotal::coverage: one more group visits the item
-        if (a.hs.rep) {
+        if (a.hs.rep && old < a.hs.n_groups) {
             const unsigned long long w = a.hs.weights ? (unsigned long long)a.hs.weights[id] : 1ull;
-            unsigned long long *rep = a.hs.rep + (size_t)(salt % HIST_REPLICAS) * (a.hs.n_groups + 1);
-            atomicAdd(&rep[old], 0ull - w);
-            atomicAdd(&rep[old + 1u], w);
+            atomicAdd(&bins[old], 0ull - w);
+            atomicAdd(&bins[old + 1u], w);
         }
         if (a.M) atomicOr(a.M + (uint64_t)g * a.row_words + (uint64_t)(id >> 11) * BLOCK_WORDS + (id & 63u), 1u << ((id >> 6) & 31u));
     }
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *bmp = bmp_all[wave];
-    const TailAdd add{a};
+    const TailAdd add{a, t_hist};
     // ---- the groups that were left to bitmaps (BandLoose), by the first LOOSE_WORKGROUPS workgroups of the grid (they are
     // dispatched first, so all of them get to run whatever else is on the chip: they may wait for each other).  First the
     // groups' steps, wherever they lie, become presence bits of the group's bitmap; then -- all marks made -- a wave takes a
@@ -745,10 +748,13 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
     const bool loose_ok = nl_raw <= LOOSE_MAX && a.lo.state[3] <= a.loose_budget;  // (state[3]: their steps, in units of 1024)
     const uint32_t nl = loose_ok ? nl_raw : 0u;
     if (!loose_ok && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.flags + 5, 16u);
+    // the workgroup's histogram bins: what the bitmaps and the spilled steps move, flushed once before the workgroup arrives
+    const bool lds_bins = a.hs.rep && (nl != 0u || agent_load(a.flags + 7) != 0u);
+    if (lds_bins) {
+        for (uint32_t b = threadIdx.x; b <= a.n_groups; b += blockDim.x) t_hist[b] = 0;
+        __syncthreads();
+    }
     if (nl && blockIdx.x < LOOSE_WORKGROUPS) {
-        const uint32_t bins = a.n_groups + 1u;
-        if (a.hs.rep)
-            for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) t_hist[b] = 0;
         const uint64_t wid = (uint64_t)blockIdx.x * BAND_TAIL_WAVES + wave, n_waves = (uint64_t)LOOSE_WORKGROUPS * BAND_TAIL_WAVES;
         bool bad_id = false;
         for (uint32_t li = 0; li < nl; ++li) {
@@ -830,14 +836,6 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
                         }
                     }
                 }
-            }
-        }
-        if (a.hs.rep) {
-            __syncthreads();
-            unsigned long long *rep = a.hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * bins;
-            for (uint32_t b = threadIdx.x; b < bins; b += blockDim.x) {
-                const unsigned long long x = t_hist[b];
-                if (x) atomicAdd(&rep[b], x);
             }
         }
     }
@@ -957,7 +955,7 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
             while (wonm) {  // (one copy of the code that adds a pair, not four)
                 const int r = __builtin_ctz(wonm);
                 wonm &= wonm - 1u;
-                add(lg, r == 0 ? idv[0] : r == 1 ? idv[1] : r == 2 ? idv[2] : idv[3], blockIdx.x * BAND_TAIL_WAVES + wave);
+                add(lg, r == 0 ? idv[0] : r == 1 ? idv[1] : r == 2 ? idv[2] : idv[3]);
             }
             __builtin_amdgcn_wave_barrier();
             // the scans are bounded: a graph whose paths do not follow the ids is served by path rows.  (The volume is taken to the
@@ -977,6 +975,14 @@ __global__ __launch_bounds__(BAND_TAIL_WAVES * 64) void k_band_tail(BandTail a) 
         }
     }
     if (vol_acc && lane == 0 && atomicAdd(a.scratch + 1, vol_acc) + vol_acc > a.scan_budget) atomicOr(a.flags + 5, 4u);
+    if (lds_bins) {
+        __syncthreads();
+        unsigned long long *rep = a.hs.rep + (size_t)(blockIdx.x % HIST_REPLICAS) * (a.n_groups + 1u);
+        for (uint32_t b = threadIdx.x; b <= a.n_groups; b += blockDim.x) {
+            const unsigned long long x = t_hist[b];
+            if (x) atomicAdd(&rep[b], x);
+        }
+    }
     // ---- the histogram is handed over: by workgroup 0 when the list was empty (every workgroup knows: the count was final
     // when the kernel began), else by the last workgroup to arrive ----
     if (n_bursts || nl_raw) {
@@ -1304,8 +1310,22 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
     a.n_ordered = ctx->n_entries;
     a.loose_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ctx->n_steps / 8, 4ull << 20) >> 10, 0xFFFFFFF0ull);
     const size_t lds_hist = tk->hist_fused ? ((size_t)ctx->n_groups + 1) * sizeof(unsigned long long) : 0;
+    // as many workgroups as the chip holds at once (the bursts are dealt round robin: workgroups that have to wait for a free
+    // slot would start their share when the others have finished theirs -- 1024 workgroups on a chip that holds 768 of them, 3
+    // per CU at 106 SGPRs, took two rounds where 768 take one), never fewer than the marking needs
+    static thread_local int per_cu = 0;
+    static thread_local size_t per_cu_lds = ~(size_t)0;
+    if (per_cu_lds != lds_hist) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(k_band_tail), (int)(BAND_TAIL_WAVES * 64), lds_hist) != hipSuccess || n < 1) n = 2;
+        per_cu = n;
+        per_cu_lds = lds_hist;
+    }
+    uint32_t grid = (uint32_t)per_cu * (uint32_t)ctx->prop.multiProcessorCount;
+    if (const char *e = getenv("PNX_BAND_TAIL_GRID")) grid = (uint32_t)atoi(e);  // (measurement)
+    grid = std::min<uint32_t>(std::max<uint32_t>(grid, LOOSE_WORKGROUPS), BAND_TAIL_GRID);
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
-    hipLaunchKernelGGL(k_band_tail, dim3(BAND_TAIL_GRID), dim3(BAND_TAIL_WAVES * 64), lds_hist, ctx->s_post, a);
+    hipLaunchKernelGGL(k_band_tail, dim3(grid), dim3(BAND_TAIL_WAVES * 64), lds_hist, ctx->s_post, a);
     prof_end(ctx);
     PNX_HIP(ctx, hipGetLastError());
     return PNX_OK;
