@@ -1322,7 +1322,8 @@ int launch_band_tail(pnx_ctx *ctx, Ticket *tk, bool write_m) {
         per_cu_lds = lds_hist;
     }
     uint32_t grid = (uint32_t)per_cu * (uint32_t)ctx->prop.multiProcessorCount;
-    if (const char *e = getenv("PNX_BAND_TAIL_GRID")) grid = (uint32_t)atoi(e);  // (measurement)
+    static const char *grid_env = getenv("PNX_BAND_TAIL_GRID");  // (measurement)
+    if (grid_env) grid = (uint32_t)atoi(grid_env);
     grid = std::min<uint32_t>(std::max<uint32_t>(grid, LOOSE_WORKGROUPS), BAND_TAIL_GRID);
     prof_begin(ctx, PNX_K_HIST, ctx->s_post);
     hipLaunchKernelGGL(k_band_tail, dim3(grid), dim3(BAND_TAIL_WAVES * 64), lds_hist, ctx->s_post, a);

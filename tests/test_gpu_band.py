@@ -406,6 +406,37 @@ def test_paths_with_large_rearrangements_are_cut_into_pieces_that_follow_the_ids
         del os.environ["PNX_BAND_SPLITS"]
 
 
+def test_a_borrowing_context_takes_the_cuts_and_the_sorted_copies_along():
+    """pnx_share_csr: the second context reads the first one's steps in place -- with the cuts of its paths and the sorted copy
+    of its shuffled path (they lie behind the steps, in the owner's buffer) --, under an order of its own"""
+    from panacus_amd import capi
+    n, P = 1_500_000, 12
+    items, pre, _ = _paths_with_large_rearrangements(n, P, 21)
+    rng = np.random.default_rng(2)
+    a0, b0 = int(pre[11]), int(pre[12])
+    items[a0:b0] = rng.permutation(items[a0:b0])
+    a, b = capi.Context(0), capi.Context(0)
+    try:
+        for c in (a, b):
+            c.config(capi.CFG_COVER_ROUTE, 1)
+        a.set_csr(items.astype(np.uint32), pre, n)
+        assert a.info().n_path_cuts >= 10 and a.info().n_sorted_copies == 1
+        b.share_csr(a)
+        pa = np.arange(P, dtype=np.uint64)
+        pb = pa[::-1].copy()
+        gb = (np.arange(P, dtype=np.uint64) // 3)
+        a.set_order(pa, pa, P)
+        b.set_order(pb, gb, 4)
+        for c, (pi, gi, G) in ((a, (pa, pa, P)), (b, (pb, gb, 4)), (a, (pa, pa, P))):
+            cnt, h = c.hist()
+            ocov, oh = _oracle_hist(items, pre, pi, gi, n, G)
+            assert np.array_equal(cnt, ocov) and np.array_equal(h, oh)
+            assert c.info().n_reruns == 0      # (a shared graph has its path rows made by the owner: both contexts sweep those)
+    finally:
+        b.close()
+        a.close()
+
+
 def test_small_disorder_makes_no_cuts(band):
     """pansyn-v1r (blocks of 64 steps reversed, copied, moved) and a path with no order at all: nothing to cut at -- the first is
     spilled, the second stored once more, sorted"""
