@@ -249,7 +249,8 @@ struct GrowthTabs {
 
 // WMODE: 0 = items count 1, 1 = weights below 2^16 (staged as u16: 4 KB of LDS per wave),
 //        2 = any u32 weights (8 KB per wave)
-template <int NPL1, int N0, int NQ, int WMODE>
+// ALT: every pair of ranks of every quorum table of the launch is d = (1, 0)  (q = 0.5): the short pair step
+template <int NPL1, int N0, int NQ, int WMODE, bool ALT>
 __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1) void k_growth_fused(
     const uint32_t *__restrict__ M, uint32_t n_blocks, uint32_t G,
     const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
     constexpr int EVW = 1 + NA + NQ;  // event: (rank << 8 | lane), up mask per accumulator, down mask per quorum pair
     uint32_t *evq = wp_all + (size_t)GROW_WAVES * (WMODE == 1 ? 1024 : 2048) + (size_t)wave * GROW_EVQ * EVW;
     uint32_t qn = 0;  // events in the queue (wave-uniform)
-    const char *Mb = reinterpret_cast<const char *>(M);
+    // the presence matrix as a buffer (below 4 GiB on this route): a row load is base + the row's byte offset (a scalar) +
+    // the lane's offset within the row, no vector instruction for the address
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(M), 0, -1, 0x00020000);
 
     for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) acc[i] = 0;
     __syncthreads();
@@ -382,33 +385,35 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
         };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
         uint32_t seen = 0;
-        // The slack s = cnt - Tq(j) of every item, bit-sliced, in TWO parts: s = 16 H + L with L in [0, 31] (five planes) and
-        // H (NPLH planes, two's complement).  A rank moves s by at most one, so only the five planes of L are rippled per rank;
-        // every eight ranks L is brought back into [8, 23] by moving 16 into or out of H -- one ripple over H per eight ranks
-        // instead of one per rank -- and between two such steps H does not change: s >= 0 <=> H >= 0, or H == -1 and L >= 16,
-        // with "H >= 0" and "H == -1" kept as masks.
-        constexpr int NPLH = NPL1 - 3;
-        uint32_t lo[NQ > 0 ? NQ : 1][5], hi[NQ > 0 ? NQ : 1][NPLH], hpos[NQ > 0 ? NQ : 1], hm1[NQ > 0 ? NQ : 1];
+        // The slack s = cnt - Tq(j) of every item, bit-sliced, in TWO parts: s = 32 H + L with L in [0, 63] (six planes) and
+        // H (NPLH planes, two's complement).  A rank moves s by at most one, so only the planes of L are rippled per rank;
+        // once per batch of 16 ranks L is brought back into [16, 47] by moving 32 into or out of H -- one ripple over H per
+        // batch -- and between two such steps H does not change: s >= 0 <=> H >= 0, or H == -1 and L >= 32, with "H >= 0"
+        // and "H == -1" kept as masks.  The pair's coverage mask is folded into those two, so that `ok` never leaves it.
+        // (Round 3 / 4: five planes, H every eight ranks; with two ranks per ripple a plane of L costs one instruction
+        // per rank and a step over H three and a half.)
+        constexpr int NLO = 6, NPLH = NPL1 - 4;
+        uint32_t lo[NQ > 0 ? NQ : 1][NLO], hi[NQ > 0 ? NQ : 1][NPLH], hpos[NQ > 0 ? NQ : 1], hm1[NQ > 0 ? NQ : 1];
         uint32_t ok[NQ > 0 ? NQ : 1];
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {  // s = 0: H = -1, L = 16
+        for (int qi = 0; qi < NQ; ++qi) {  // s = 0: H = -1, L = 32
             ok[qi] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lo[qi][k] = 0;
-            lo[qi][4] = 0xFFFFFFFFu;
+            for (int k = 0; k < NLO - 1; ++k) lo[qi][k] = 0;
+            lo[qi][NLO - 1] = 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 0; k < NPLH; ++k) hi[qi][k] = 0xFFFFFFFFu;
             hpos[qi] = 0;
-            hm1[qi] = 0xFFFFFFFFu;
+            hm1[qi] = mask[N0 + qi];
         }
         auto renorm = [&]() {
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
-                const uint32_t l3 = lo[qi][3], l4 = lo[qi][4];
-                const uint32_t dn = ~(l4 | l3);  // L < 8: L += 16, H -= 1
-                uint32_t m = (l4 & l3) | dn;     // L >= 24: L -= 16, H += 1
-                lo[qi][4] = ~l3;
-                uint32_t all = 0xFFFFFFFFu;
+                const uint32_t l4 = lo[qi][NLO - 2], l5 = lo[qi][NLO - 1];
+                const uint32_t dn = ~(l5 | l4);  // L < 16: L += 32, H -= 1
+                uint32_t m = (l5 & l4) | dn;     // L >= 48: L -= 32, H += 1
+                lo[qi][NLO - 1] = ~l4;
+                uint32_t all = mask[N0 + qi];
 #pragma unroll
                 for (int k = 0; k < NPLH; ++k) {
                     const uint32_t t = (hi[qi][k] ^ dn) & m;  // carry where the bit was 1 (up), borrow where it was 0 (down)
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                     m = t;
                     all &= hi[qi][k];
                 }
-                hpos[qi] = ~hi[qi][NPLH - 1];
+                hpos[qi] = ~hi[qi][NPLH - 1] & mask[N0 + qi];
                 hm1[qi] = all;
             }
         };
@@ -434,14 +439,54 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                 const uint32_t dm = dmask[(uint64_t)tabs.qq_slot[qi] * G + j];  // wave-uniform
                 uint32_t m = xv ^ dm;  // dT = 0: increment where x ; dT = 1: decrement where !x
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < NLO; ++k) {
                     const uint32_t t = (lo[qi][k] ^ dm) & m;
                     lo[qi][k] ^= m;
                     m = t;
                 }
-                const uint32_t ge = hpos[qi] | (hm1[qi] & lo[qi][4]);  // s >= 0  <=>  cnt >= Tq
+                const uint32_t ge = hpos[qi] | (hm1[qi] & lo[qi][NLO - 1]);  // s >= 0  <=>  cnt >= Tq  (within the pair's mask)
                 ok[qi] = (ok[qi] & ~xv) | (ge & xv);
-                val[N0 + qi] = ok[qi] & mask[N0 + qi];
+                val[N0 + qi] = ok[qi];
+            }
+        };
+
+        // TWO ranks a = j, b = j + 1 in one step where every pair of ranks of the quorum tables is d = (1, 0) -- q = 0.5
+        // (round 5): the kernel's time is its vector instructions (30 per rank at cfg4, 20 of them the quorum pair's), and
+        // two ranks share ONE pass over the planes of L.  The slack moves by (x_a - 1) + x_b: +1 where both bits are set,
+        // -1 where neither is, nothing where one is -- the masked ripple of the single step with a per-item direction.
+        // `ok` after rank a needs "s_a >= 0" only where x_a is set, and there s_a = s_prev + 1 - d_a = s_prev: the mask
+        // "s >= 0" as it stands before the step.  (The same for any table -- the ripple starting at plane 0 or 1 by
+        // |x_a + x_b - d_a - d_b|, "s == -1" beside "s >= 0" where d_a = 0 -- was written and counted: 494 instructions per
+        // batch against 481 for single steps; such tables keep the single step.)
+        auto pair_step = [&](uint32_t xa, uint32_t xb, uint32_t (&va)[NA > 0 ? NA : 1], uint32_t (&vb)[NA > 0 ? NA : 1]) {
+            if (N0 > 0) {
+                const uint32_t nwa = xa & ~seen;
+                seen |= xa;
+                const uint32_t nwb = xb & ~seen;
+                seen |= xb;
+#pragma unroll
+                for (int a = 0; a < N0; ++a) {
+                    va[a] = nwa & mask[a];
+                    vb[a] = nwb & mask[a];
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                uint32_t *L = lo[qi];
+                const uint32_t gp = hpos[qi] | (hm1[qi] & L[NLO - 1]);  // s_prev >= 0
+                const uint32_t oka = (ok[qi] & ~xa) | (gp & xa);
+                va[N0 + qi] = oka;
+                const uint32_t h = xa & xb;
+                uint32_t m = ~(xa ^ xb);
+#pragma unroll
+                for (int k = 0; k < NLO; ++k) {
+                    const uint32_t t = ~(L[k] ^ h) & m;  // carry where both (the bit was 1), borrow where neither (it was 0)
+                    L[k] ^= m;
+                    m = t;
+                }
+                const uint32_t ge = hpos[qi] | (hm1[qi] & L[NLO - 1]);  // s_b >= 0
+                ok[qi] = (oka & ~xb) | (ge & xb);
+                vb[N0 + qi] = ok[qi];
             }
         };
 
@@ -449,20 +494,30 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
         for (; jb + B <= G; jb += B) {  // full batches: no guards on the per-rank path
             uint32_t x[B];
 #pragma unroll
-            for (int u = 0; u < B; ++u) x[u] = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb + u] + voff));
+            for (int u = 0; u < B; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b32(mrs, voff, ro[jb + u], 0);
             if (!WEIGHTED) {
                 uint32_t pk[NA > 0 ? NA : 1][B / 2];
+                if (ALT) {
 #pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    uint32_t val[NA > 0 ? NA : 1];
-                    rank_step(x[u], jb + u, val);
-                    if (NQ > 0 && (u & 7) == 7) renorm();
+                    for (int u = 0; u < B; u += 2) {
+                        uint32_t va[NA > 0 ? NA : 1], vb[NA > 0 ? NA : 1];
+                        pair_step(x[u], x[u + 1], va, vb);
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        const uint32_t c = (uint32_t)__popc(val[a]);
-                        if (u & 1) pk[a][u >> 1] |= c << 16; else pk[a][u >> 1] = c;
+                        for (int a = 0; a < NA; ++a) pk[a][u >> 1] = (uint32_t)__popc(va[a]) | ((uint32_t)__popc(vb[a]) << 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        uint32_t val[NA > 0 ? NA : 1];
+                        rank_step(x[u], jb + u, val);
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            const uint32_t c = (uint32_t)__popc(val[a]);
+                            if (u & 1) pk[a][u >> 1] |= c << 16; else pk[a][u >> 1] = c;
+                        }
                     }
                 }
+                if (NQ > 0) renorm();
                 // The NA x B/2 packed registers are summed over the 64 lanes by a reduce-SCATTER: v_permlane32_swap puts the upper
                 // half of register i beside the lower half of register i + H, so ONE addition folds both over lane ^ 32 and leaves
                 // each in one half of the wave; v_permlane16_swap does the same for the 16-lane rows.  Row rho then holds 2 NA
@@ -512,20 +567,29 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                     }
                 }
             } else {
+                if (ALT) {
 #pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    uint32_t val[NA > 0 ? NA : 1];
-                    rank_step(x[u], jb + u, val);
-                    if (NQ > 0 && (u & 7) == 7) renorm();
-                    weighted_rank(val, jb + u);
+                    for (int u = 0; u < B; u += 2) {
+                        uint32_t va[NA > 0 ? NA : 1], vb[NA > 0 ? NA : 1];
+                        pair_step(x[u], x[u + 1], va, vb);
+                        weighted_rank(va, jb + u);
+                        weighted_rank(vb, jb + u + 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        uint32_t val[NA > 0 ? NA : 1];
+                        rank_step(x[u], jb + u, val);
+                        weighted_rank(val, jb + u);
+                    }
                 }
+                if (NQ > 0) renorm();
             }
         }
-        for (; jb < G; ++jb) {  // tail ranks (G not a multiple of the batch)
-            const uint32_t xv = *reinterpret_cast<const uint32_t *>(Mb + (ro[jb] + voff));
+        for (; jb < G; ++jb) {  // tail ranks (G not a multiple of the batch: fewer than 16, L stays within its planes)
+            const uint32_t xv = __builtin_amdgcn_raw_buffer_load_b32(mrs, voff, ro[jb], 0);
             uint32_t val[NA > 0 ? NA : 1];
             rank_step(xv, jb, val);
-            if (NQ > 0 && (jb & 7u) == 7u) renorm();
             if (WEIGHTED) {
                 weighted_rank(val, jb);
             } else {
@@ -698,6 +762,16 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
 
     uint32_t bits = 1;
     while (bits < 32 && (G >> bits) != 0) ++bits;
+    // PNX_GROWTH_STEP=1: two ranks per step by the general rule even where every pair of a table is d = (1, 0)  (tests)
+    const char *e_step = std::getenv("PNX_GROWTH_STEP");
+    const bool general_step = e_step && e_step[0] == '1';
+    // does the table of pair t rise at every even rank and only there, over the full batches (q = 0.5)?
+    auto alternates = [&](uint32_t t) {
+        const uint32_t full = G / GROW_PREFETCH * GROW_PREFETCH;
+        for (uint32_t j = 0; j < full; ++j)
+            if ((dtab[(size_t)t * G + j] != 0) != ((j & 1u) == 0)) return false;
+        return true;
+    };
     prof_begin(ctx, PNX_K_GROWTH);
     {   // fused launches: up to GROW_Q0_MAX q == 0 pairs + up to 2 slack pairs each
         size_t i0 = 0, iq = 0;
@@ -713,6 +787,9 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
                 tabs.qq_midx[k] = k < nq ? mask_of[qslack[iq + k]] : -1;
                 tabs.qq_slot[k] = k < nq ? qslack[iq + k] : 0;
             }
+            bool alt = nq > 0 && !general_step;
+            for (int k = 0; k < nq; ++k)
+                if (!alternates(qslack[iq + k])) alt = false;
             const size_t evq_bytes = ctx->weighted ? (size_t)GROW_WAVES * GROW_EVQ * (1 + n0 + 2 * nq) * 4 : 0;
             const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wl_bytes + evq_bytes;
             if (shmem > 150 * 1024)
@@ -728,9 +805,11 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
             };
 #define PNX_GROW_NQ(NPL1, N0V, W)                                                                 \
     do {                                                                                          \
-        if (nq == 0) go(k_growth_fused<NPL1, N0V, 0, W>);                                         \
-        else if (nq == 1) go(k_growth_fused<NPL1, N0V, 1, W>);                                    \
-        else go(k_growth_fused<NPL1, N0V, 2, W>);                                                 \
+        if (nq == 0) go(k_growth_fused<NPL1, N0V, 0, W, false>);                                  \
+        else if (nq == 1 && alt) go(k_growth_fused<NPL1, N0V, 1, W, true>);                       \
+        else if (nq == 1) go(k_growth_fused<NPL1, N0V, 1, W, false>);                             \
+        else if (alt) go(k_growth_fused<NPL1, N0V, 2, W, true>);                                  \
+        else go(k_growth_fused<NPL1, N0V, 2, W, false>);                                          \
     } while (0)
 #define PNX_GROW_N0(NPL1, W)                                                                      \
     do {                                                                                          \

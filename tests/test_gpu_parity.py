@@ -389,6 +389,41 @@ def test_ordered_growth_many_groups(ctx):
             assert out[r, t].tolist() == [int(x) for x in exp]
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("p,groups_of", [(40, 1), (130, 1), (264, 1), (96, 2), (530, 1)])
+def test_ordered_growth_two_ranks_per_step(ctx, p, groups_of, weighted, monkeypatch):
+    """k_growth_fused<..., ALT>: tables whose every pair of ranks is d = (1, 0) (q = 0.5) take two ranks per ripple over the slack's
+    planes, any other table one; full batches of 16 ranks + tail ranks, one and two quorum pairs per launch, quorum pairs with a
+    coverage mask (folded into the sign masks of the slack), q = 0 pairs beside them; the same call with the short step switched
+    off (PNX_GROWTH_STEP=1) gives the same numbers.  Rule: abacus.rs:1001-1010."""
+    from panacus_amd.pansyn import random_orders
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold, coverage_abs, quorum_table
+    n = 9000
+    items, pre, lens = orc.pansyn(100 + p, n, p)
+    w = lens if weighted else None
+    ctx.set_csr(items.astype(np.uint32), pre, n, weights=w)
+    G = p // groups_of
+    pg = (np.arange(p) // groups_of).astype(np.uint64)
+    ctx.set_order(np.arange(p, dtype=np.uint64), pg, G)
+    perms = random_orders(5, 3, G)
+    for pairs in ([(1, 0.0), (2, 0.0), (1, 0.5)],            # cfg4's: one table that alternates
+                  [(2, 0.5), (1, 0.5), (1, 0.0)],            # two of them, one under a coverage mask
+                  [(1, 0.5), (3, 0.3)],                      # one that alternates beside one that does not: single steps
+                  [(2, 0.25), (1, 0.9), (1, 1.0), (3, 0.0)],  # none alternates; three quorum pairs = two launches
+                  [(1, 0.5)]):
+        cov = [coverage_abs(Threshold(ABSOLUTE, c), G) for c, _ in pairs]
+        qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for _, q in pairs])
+        out = ctx.ordered_growth(cov, qt, perms)
+        for r in range(len(perms)):
+            for t, (c, q) in enumerate(pairs):
+                exp = _oracle_growth(items, pre, n, G, pg, perms[r], c, q, w)
+                assert out[r, t].tolist() == [int(x) for x in exp], (pairs, r, c, q)
+        monkeypatch.setenv("PNX_GROWTH_STEP", "1")
+        out1 = ctx.ordered_growth(cov, qt, perms)
+        monkeypatch.delenv("PNX_GROWTH_STEP")
+        assert np.array_equal(out, out1), pairs
+
+
 @pytest.mark.parametrize("route,sort_shuffled", [(3, 1), (30, 1), (2, 1), (2, 0)], indirect=True)
 def test_growth_after_scatter_route(ctx, route, sort_shuffled):
     """edge-like (unsorted) paths: sorted at preparation, or the presence matrix comes from the scatter route"""
