@@ -282,6 +282,35 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
     for (uint32_t i = threadIdx.x; i < (uint32_t)NA * G; i += blockDim.x) acc[i] = 0;
     __syncthreads();
 
+    // where the lane's total of the in-row reduce-scatter below goes: the register that ends in this lane (walking the four
+    // levels back: a lane's bit chooses the first or the second of a folded pair), the accumulator and the ranks that
+    // register carries; where a register folded without a partner the lanes with the bit set hold a copy and stay out
+    const bool rs_sel8 = (lane & 8u) != 0, rs_sel4 = (lane & 4u) != 0, rs_sel2 = (lane & 2u) != 0, rs_sel1 = (lane & 1u) != 0;
+    bool rs_writer = !WEIGHTED;
+    uint32_t rs_acc = 0;
+    if (!WEIGHTED) {
+        constexpr int H1 = (NA > 0 ? NA : 1) * (B / 4), H2 = H1 / 2;  // (NA = 0 is compiled, never launched)
+        constexpr int nin[4] = {H2, (H2 + 1) / 2, ((H2 + 1) / 2 + 1) / 2, (((H2 + 1) / 2 + 1) / 2 + 1) / 2};
+        static_assert((nin[3] + 1) / 2 == 1, "four levels bring the registers of a row down to one");
+        uint32_t pos = 0;
+#pragma unroll
+        for (int L = 3; L >= 0; --L) {
+            const uint32_t bit = (lane >> (3 - L)) & 1u;
+            if (2 * pos + 1 < (uint32_t)nin[L]) {
+                pos = 2 * pos + bit;
+            } else {
+                pos = 2 * pos;
+                if (bit) rs_writer = false;
+            }
+        }
+        // row rho: even rows hold the registers i < H2 of the packed counts, odd rows i + H2; register a * 4 + i carries, of
+        // accumulator a, the pairs of ranks i (low half) and i + 4 (high half): the even rank in the rows 0, 1 (the lanes below
+        // 32), the odd one in the rows 2, 3
+        const uint32_t rho = lane >> 4;
+        const uint32_t r = (uint32_t)H2 * (rho & 1u) + pos;
+        rs_acc = (r >> 2) * G + 2u * (r & 3u) + (rho >> 1);
+    }
+
     const uint32_t b_end = min(n_blocks, (chunk + 1) * blocks_per_chunk);
     for (uint32_t blk = chunk * blocks_per_chunk + wave; blk < b_end; blk += GROW_WAVES) {
         uint32_t mask[NA > 0 ? NA : 1];
@@ -496,6 +525,12 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
 #pragma unroll
             for (int u = 0; u < B; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b32(mrs, voff, ro[jb + u], 0);
             if (!WEIGHTED) {
+                // The per-rank counts are summed over the 64 lanes by a reduce-SCATTER that starts on the BITS: v_permlane32_swap
+                // puts the upper half of rank u's mask beside the lower half of rank u + 1's, so the two population counts of
+                // a lane (the second one adds the first: v_bcnt's free operand) are already folded over lane ^ 32 -- rank u in
+                // lanes 0..31, rank u + 1 in lanes 32..63 -- for the three instructions that two counts and their packing
+                // cost before.  Pairs p and p + 4 then share a register (16 bits each: a half-wave's count is at most 2048),
+                // v_permlane16_swap folds register i beside register i + H2 over the 16-lane rows.
                 uint32_t pk[NA > 0 ? NA : 1][B / 2];
                 if (ALT) {
 #pragma unroll
@@ -503,67 +538,64 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                         uint32_t va[NA > 0 ? NA : 1], vb[NA > 0 ? NA : 1];
                         pair_step(x[u], x[u + 1], va, vb);
 #pragma unroll
-                        for (int a = 0; a < NA; ++a) pk[a][u >> 1] = (uint32_t)__popc(va[a]) | ((uint32_t)__popc(vb[a]) << 16);
+                        for (int a = 0; a < NA; ++a) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(va[a], vb[a], false, false);
+                            pk[a][u >> 1] = (uint32_t)__popc(sw[0]) + (uint32_t)__popc(sw[1]);
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < B; ++u) {
-                        uint32_t val[NA > 0 ? NA : 1];
-                        rank_step(x[u], jb + u, val);
+                    for (int u = 0; u < B; u += 2) {
+                        uint32_t va[NA > 0 ? NA : 1], vb[NA > 0 ? NA : 1];
+                        rank_step(x[u], jb + u, va);
+                        rank_step(x[u + 1], jb + u + 1, vb);
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
-                            const uint32_t c = (uint32_t)__popc(val[a]);
-                            if (u & 1) pk[a][u >> 1] |= c << 16; else pk[a][u >> 1] = c;
+                            const auto sw = __builtin_amdgcn_permlane32_swap(va[a], vb[a], false, false);
+                            pk[a][u >> 1] = (uint32_t)__popc(sw[0]) + (uint32_t)__popc(sw[1]);
                         }
                     }
                 }
                 if (NQ > 0) renorm();
-                // The NA x B/2 packed registers are summed over the 64 lanes by a reduce-SCATTER: v_permlane32_swap puts the upper
-                // half of register i beside the lower half of register i + H, so ONE addition folds both over lane ^ 32 and leaves
-                // each in one half of the wave; v_permlane16_swap does the same for the 16-lane rows.  Row rho then holds 2 NA
-                // registers (i + NA (rho & 1) + 2 NA (rho >> 1)... see below) that four DPP steps sum within the row: 60 vector
-                // instructions per batch instead of six DPP steps on every register (144) and a round trip through LDS.
                 {
-                    constexpr int NREG = NA * (B / 2), H1 = NREG / 2, H2 = NREG / 4;
-                    static_assert(B == 16, "the reduce-scatter below halves NA x 8 registers twice");
-                    uint32_t w[NREG > 0 ? NREG : 1];
+                    constexpr int NA1 = NA > 0 ? NA : 1, H1 = NA1 * (B / 4), H2 = H1 / 2;  // (NA = 0 is compiled, never launched)
+                    static_assert(B == 16, "the reduce-scatter below takes 8 pairs of ranks per accumulator");
+                    uint32_t w1[H1], w2[H2];
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
 #pragma unroll
-                        for (int k = 0; k < B / 2; ++k) w[a * (B / 2) + k] = pk[a][k];
-                    uint32_t w1[H1 > 0 ? H1 : 1], w2[H2 > 0 ? H2 : 1];
-#pragma unroll
-                    for (int i = 0; i < H1; ++i) {  // lanes 0..31: register i, lanes 32..63: register i + H1, each folded over lane ^ 32
-                        const auto sw = __builtin_amdgcn_permlane32_swap(w[i], w[i + H1], false, false);
-                        w1[i] = sw[0] + sw[1];
-                    }
+                        for (int i = 0; i < B / 4; ++i) w1[a * (B / 4) + i] = pk[a][i] | (pk[a][i + B / 4] << 16);
 #pragma unroll
                     for (int i = 0; i < H2; ++i) {  // even rows: register i of w1, odd rows: register i + H2, folded over lane ^ 16
                         const auto sw = __builtin_amdgcn_permlane16_swap(w1[i], w1[i + H2], false, false);
                         w2[i] = sw[0] + sw[1];
                     }
-#pragma unroll
-                    for (int i = 0; i < H2; ++i) {  // within the row: the total lands in its last lane
-                        uint32_t v = w2[i];
-                        v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);  // row_shr:1
-                        v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);  // row_shr:2
-                        v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xe, true);  // row_shr:4
-                        v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xc, true);  // row_shr:8
-                        w2[i] = v;
+                    // Within the rows the reduce-scatter goes on (round 5): two registers fold into one over lane ^ 8 -- the lanes
+                    // with bit 3 clear keep the first, the others the second: two selects and one addition with a DPP operand
+                    // (row_ror:8) --, then over the mirrored half rows, the reversed quads, the neighbours; a register without a
+                    // partner folds on its own.  2 NA registers take 17 instructions at NA = 3 instead of 24, and every total
+                    // ends in a lane of its own (rs_acc: where it goes, worked out once per kernel), so that ONE pair of LDS
+                    // additions serves the row instead of one per register.
+                    constexpr int n0 = H2, n1 = (n0 + 1) / 2, n2 = (n1 + 1) / 2, n3 = (n2 + 1) / 2;
+                    uint32_t a1[n1], a2[n2], a3[n3], a4;
+#define PNX_RS_LEVEL(IN, NIN, OUT, CTRL, SEL)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < (NIN) / 2; ++i) {                                                          \
+        const uint32_t x = (SEL) ? IN[2 * i + 1] : IN[2 * i], y = (SEL) ? IN[2 * i] : IN[2 * i + 1];                 \
+        OUT[i] = x + (uint32_t)__builtin_amdgcn_update_dpp(0u, y, CTRL, 0xf, 0xf, true);                             \
+    }                                                                                                                \
+    if ((NIN) & 1) OUT[(NIN) / 2] = IN[(NIN) - 1] + (uint32_t)__builtin_amdgcn_update_dpp(0u, IN[(NIN) - 1], CTRL, 0xf, 0xf, true);
+                    PNX_RS_LEVEL(w2, n0, a1, 0x128, rs_sel8)  // row_ror:8
+                    PNX_RS_LEVEL(a1, n1, a2, 0x141, rs_sel4)  // row_half_mirror
+                    PNX_RS_LEVEL(a2, n2, a3, 0x01B, rs_sel2)  // quad_perm:[3,2,1,0]
+                    {
+                        uint32_t *a4p = &a4;
+                        PNX_RS_LEVEL(a3, n3, a4p, 0x0B1, rs_sel1)  // quad_perm:[1,0,3,2]
                     }
-                    if ((lane & 15u) == 15u) {
-                        // row rho holds the original registers i + H2 (rho & 1) + H1 (rho >> 1), i < H2; register r = a * 8 + k
-                        // carries ranks jb + 2 k (low half) and jb + 2 k + 1 of accumulator a
-                        const uint32_t rho = lane >> 4;
-                        const uint32_t r0 = (uint32_t)H2 * (rho & 1u) + (uint32_t)H1 * (rho >> 1);
-#pragma unroll
-                        for (int i = 0; i < H2; ++i) {
-                            const uint32_t r = r0 + (uint32_t)i, a = r >> 3, k = r & 7u;
-                            const uint32_t c0 = w2[i] & 0xFFFFu, c1 = w2[i] >> 16;
-                            unsigned long long *dst = &acc[(size_t)a * G + jb + 2 * k];
-                            if (c0) atomicAdd(dst, (unsigned long long)c0);
-                            if (c1) atomicAdd(dst + 1, (unsigned long long)c1);
-                        }
+#undef PNX_RS_LEVEL
+                    if (rs_writer) {  // the lane's register carries one rank of pair p (low half) and one of pair p + 4
+                        unsigned long long *dst = &acc[rs_acc + jb];
+                        atomicAdd(dst, (unsigned long long)(a4 & 0xFFFFu));  // a test for zero would cost more than the add
+                        atomicAdd(dst + B / 2, (unsigned long long)(a4 >> 16));
                     }
                 }
             } else {

@@ -122,6 +122,6 @@ def test_step_routes_are_a_module_beside_the_product_library():
     assert "pnx_step_routes_table" in mod and "pnx_step_routes_table" not in prod
     assert "k_rows_cover" in prod and "k_band_cover" in prod
     # (15.5 MB while the step routes were inside; 12.0 MB without them, 12.6 MB with k_quorum_fused and k_cf_eval_small, 15.0 MB
-    # with rocPRIM's radix sort of u32 keys: the sorted copies of shuffled paths at upload, upload_scan.hip -- the symbols above are
-    # what keeps the step routes out)
-    assert os.path.getsize(_build.LIB_HIP) < 16 << 20
+    # with rocPRIM's radix sort of u32 keys: the sorted copies of shuffled paths at upload, upload_scan.hip; 17.2 MB with the
+    # two-ranks-per-step instances of k_growth_fused -- the symbols above are what keeps the step routes out)
+    assert os.path.getsize(_build.LIB_HIP) < 18 << 20
