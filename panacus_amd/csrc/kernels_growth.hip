@@ -13,11 +13,12 @@
 // Device formulation (integer set work, bit-parallel; no MFMA):
 //   * one lane owns one u32 word = 32 items of a 2048-item block; a wave walks the ranks
 //     of one order sequentially, reading one coalesced 256 B row slice per rank;
-//   * q == 0 pairs:  ok_j = "seen so far", so only NEW bits (x & ~seen) change res; they
-//     are sparse (32 per lane per order in total) and are pushed as deltas with LDS atomics;
-//   * q > 0 pairs:   cnt is kept bit-sliced (NPL planes, ripple-carry increment by the
-//     bitmask x), compared against the wave-uniform Tq[j] plane by plane, and the dense
-//     popcount is reduced over the wave with a 6-instruction DPP row/bcast reduction;
+//   * q == 0 pairs:  ok_j = "seen so far", so only NEW bits (x & ~seen) change res: their
+//     counts are deltas, prefix-summed by a finishing kernel;
+//   * q > 0 pairs:   the slack cnt - Tq[j] is kept bit-sliced (a masked ripple per rank, or per
+//     TWO ranks where the table rises at every other rank: q = 0.5) and only its sign is looked
+//     at; the dense popcounts of a batch of 16 ranks are summed over the wave by a
+//     reduce-scatter (v_permlane32_swap on the bits, v_permlane16_swap, DPP folds in the rows);
 //   * per-workgroup LDS accumulators (u64 per rank) are flushed once with global atomics;
 //     deltas of the q == 0 path are prefix-summed by a finishing kernel;
 //   * bp counts use bit planes of the weights: sum_i w_i b_i = sum_p 2^p popc(b & W_p).
@@ -222,20 +223,19 @@ __global__ __launch_bounds__(GROW_WAVES * 64) void k_growth_quorum(
 // presence rows of an order.
 //   * q > 0 pairs use the slack form s_j = cnt_j - Tq[j], bit-sliced.  Tq rises by dT in {0,1} per rank (q <= 1), so per
 //     rank s += x (dT = 0) or s += x - 1 (dT = 1): ONE ripple pass under mask m = x ^ dmask with the plane complemented by
-//     dmask (dmask = 0 / ~0 is wave-uniform and comes from a host table).  Since round 3 the pass runs over FIVE planes
-//     only: s = 16 H + L, L in [0, 31] is rippled per rank, H (two's complement) every eight ranks when L is brought back
-//     into [8, 23]; "cnt >= Tq" is (H >= 0) | (H == -1 & L >= 16) with the two H masks kept between those steps -- 20
-//     instead of 34 vector instructions per rank and pair.
+//     dmask (dmask = 0 / ~0 is wave-uniform and comes from a host table).  The pass runs over the SIX low planes only:
+//     s = 32 H + L, L in [0, 63] is rippled per rank (or per two ranks: ALT), H (two's complement) once per batch of 16
+//     ranks when L is brought back into [16, 47]; "cnt >= Tq" is (H >= 0) | (H == -1 & L >= 32) with the two H masks kept
+//     between those steps (round 3: five planes, H every eight ranks).
 //   * everything on the per-rank path is branch-free VALU: the first version of this kernel
 //     was bound by the CU's single scalar unit (27 SALU instructions per rank for uniform
 //     branches, exec-mask juggling and 64-bit address arithmetic); row offsets now come
 //     pre-multiplied from the host as 32-bit byte offsets (saddr + voffset addressing).
-//   * per-rank popcounts (<= 32 per lane) are packed two per register for the 16 ranks of a batch and summed over the
-//     wave once per batch by a reduce-scatter: v_permlane32_swap / v_permlane16_swap (gfx950) fold two registers with one
-//     addition each, four DPP steps finish inside the 16-lane rows, and the last lane of every row adds its share of the
-//     totals to the workgroup's LDS accumulators (round 2: six DPP steps on each of the 24 registers, then a round trip
-//     through LDS so that 16 lanes could issue the atomics -- measured as more than half of the kernel's time: 18.4 ms with
-//     it, 8.5 ms with the sums thrown away; now 15.8 ms per 128 orders, 2.33 ms per 16).
+//   * per-rank popcounts are summed over the wave once per batch of 16 ranks by a reduce-scatter (see the batch loop):
+//     round 2 took six DPP steps on each of 24 registers and a round trip through LDS (18.4 ms per 128 orders of cfg4, 8.5
+//     with the sums thrown away), round 3 v_permlane32_swap / v_permlane16_swap + four DPP steps per row register (15.8 ms),
+//     round 5 starts on the bits and scatters inside the rows as well (11.8 ms with the two-rank step; DESIGN.md K4: the
+//     kernel's time is its vector instructions, 481 -> 332 per batch).
 // Workgroups of one block chunk carry consecutive blockIdx for all R orders.  (Giving all R orders of a
 // chunk to ONE XCD -- chunk % 8, so that its L2 serves a row to R orders for one fetch -- was measured:
 // 18.8 against 18.2 ms on cfg4; the kernel is bound by VALU issue, not by the rows.)
