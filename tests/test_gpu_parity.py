@@ -410,7 +410,13 @@ def test_ordered_growth_two_ranks_per_step(ctx, p, groups_of, weighted, monkeypa
                   [(2, 0.5), (1, 0.5), (1, 0.0)],            # two of them, one under a coverage mask
                   [(1, 0.5), (3, 0.3)],                      # one that alternates beside one that does not: single steps
                   [(2, 0.25), (1, 0.9), (1, 1.0), (3, 0.0)],  # none alternates; three quorum pairs = two launches
-                  [(1, 0.5)]):
+                  [(1, 0.5)],
+                  # 2, 4, 5, 6 accumulators in one launch: 4, 8, 10, 12 registers per row in the reduce-scatter (pairs and lone ones)
+                  [(1, 0.0), (2, 0.0)],
+                  [(1, 0.0), (2, 0.0), (3, 0.0), (1, 0.5)],
+                  [(1, 0.0), (2, 0.0), (3, 0.0), (1, 0.5), (2, 0.5)],
+                  [(1, 0.0), (2, 0.0), (3, 0.0), (4, 0.0), (1, 0.5), (2, 0.5)],
+                  [(1, 0.0), (2, 0.0), (3, 0.0), (5, 0.0), (1, 0.3), (2, 0.7)]):
         cov = [coverage_abs(Threshold(ABSOLUTE, c), G) for c, _ in pairs]
         qt = np.stack([quorum_table(Threshold(RELATIVE, q), G) for _, q in pairs])
         out = ctx.ordered_growth(cov, qt, perms)
