@@ -406,14 +406,27 @@ enum { CF_UNION = PNX_GROWTH_UNION, CF_CORE = PNX_GROWTH_CORE, CF_QUORUM = PNX_G
 // one workgroup: the log2 tables, then the two running sums -- the only sequential part: lane 0 walks n_fall, lane 1
 // m_fact, nothing but one LDS read, one addition and one LDS write per step (they depend on n alone, so every pair gets
 // a copy) -- then everything per (pair, m) in parallel again
-__global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, double *__restrict__ L, const uint32_t *__restrict__ branch,
-                                                  const double *__restrict__ quorum, double *__restrict__ n_fall,
-                                                  double *__restrict__ m_fact, uint32_t *__restrict__ m_quorum) {
+// The pairs' parameters come BY VALUE (192 bytes of kernel arguments) and leave as the device block the later kernels read
+// ([quorum f64 T | branch u32 T | cov u32 T]): a copy from pinned memory in front of this kernel was one more enqueue and
+// 3-7 us on the stream in front of every cold call's tables.
+struct CfPairs {
+    double quorum[PNX_GROWTH_MAX_PAIRS];
+    uint32_t branch[PNX_GROWTH_MAX_PAIRS], cov[PNX_GROWTH_MAX_PAIRS];
+};
+__global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, double *__restrict__ L, CfPairs par, void *__restrict__ par_out,
+                                                  double *__restrict__ n_fall, double *__restrict__ m_fact, uint32_t *__restrict__ m_quorum) {
     extern __shared__ double s_dyn[];  // L: 2 (n + 1) values | n_fall: n + 1 | m_fact: n + 1
     __shared__ uint64_t s_log2[274];
     const uint32_t np1 = n + 1, nl = 2 * np1;
     double *s_L = s_dyn, *s_nf = s_dyn + nl, *s_mf = s_nf + np1;
     for (uint32_t k = threadIdx.x; k < 274; k += 256) s_log2[k] = c_log2_tab[k];
+    if (threadIdx.x < n_pairs) {
+        double *o_q = (double *)par_out;
+        uint32_t *o_br = (uint32_t *)(o_q + n_pairs), *o_cov = o_br + n_pairs;
+        o_q[threadIdx.x] = par.quorum[threadIdx.x];
+        o_br[threadIdx.x] = par.branch[threadIdx.x];
+        o_cov[threadIdx.x] = par.cov[threadIdx.x];
+    }
     __syncthreads();
     for (uint32_t v = threadIdx.x; v < nl; v += 256) {
         const double x = pnx_exp2::log2_exact((double)v, s_log2);
@@ -448,10 +461,10 @@ __global__ __launch_bounds__(256) void k_cf_setup(uint32_t n, uint32_t n_pairs, 
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < n_pairs * np1; k += 256) {
         const uint32_t t = k / np1, m = k % np1;
-        const bool quo = branch[t] == CF_QUORUM;
+        const bool quo = par.branch[t] == CF_QUORUM;
         n_fall[k] = s_nf[m];
         m_fact[k] = quo ? s_mf[m] : 0.0;
-        m_quorum[k] = quo && m ? (uint32_t)ceil(pnx_exp2::mul((double)m, quorum[t])) : 0u;  // hist.rs:150
+        m_quorum[k] = quo && m ? (uint32_t)ceil(pnx_exp2::mul((double)m, par.quorum[t])) : 0u;  // hist.rs:150
     }
 }
 
@@ -892,33 +905,31 @@ static int growth_tables_first_part(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, 
         (rc = ensure(ctx, g.d_mf, T * np1 * 8)) || (rc = ensure(ctx, g.d_mq, T * np1 * 4)) || (rc = ensure(ctx, g.d_pm, T * np1 * np1 * 8)) ||
         (any_quorum && ((rc = ensure(ctx, g.d_lsq, T * np1 * np1 * 8)) || (rc = ensure(ctx, g.d_sum, np1 * np1 * 8)))))
         return rc;
-    if (!g.h_par) PNX_HIP(ctx, hipHostMalloc(&g.h_par, PNX_GROWTH_MAX_PAIRS * 16, hipHostMallocDefault));
     if (!g.ready) PNX_HIP(ctx, hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
     if (!ctx->stream_cf) PNX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_cf, hipStreamNonBlocking));
     hipStream_t st = ctx->stream_cf;
-    PNX_HIP(ctx, hipStreamSynchronize(st));  // (the pinned parameter block of the previous build is free)
-    char *h = (char *)g.h_par;
-    double *h_q = (double *)h;
-    uint32_t *h_br = (uint32_t *)(h + T * 8), *h_cov = h_br + T;
+    CfPairs par = {};
     for (uint32_t t = 0; t < n_pairs; ++t) {
-        h_q[t] = g.quorum[t] = quorum_rel[t];
-        h_br[t] = g.branch[t] = branch[t];
-        h_cov[t] = g.cov[t] = cov_abs[t];
+        par.quorum[t] = g.quorum[t] = quorum_rel[t];
+        par.branch[t] = g.branch[t] = branch[t];
+        par.cov[t] = g.cov[t] = cov_abs[t];
     }
     g.n = n;
     g.T = n_pairs;
-    PNX_HIP(ctx, hipMemcpyAsync(g.d_par.p, h, par_bytes, hipMemcpyHostToDevice, st));
     if (wait_first) PNX_HIP(ctx, hipStreamWaitEvent(st, wait_first, 0));
     const double *d_q = (const double *)g.d_par.p;
     const uint32_t *d_br = (const uint32_t *)((const char *)g.d_par.p + T * 8), *d_cov = d_br + T;
     const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
     const size_t lds_eval = (2 * CF_CHUNK * 64 + np1) * sizeof(double);
-    if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    if (g.lds_attr_n != n) {  // (once per n: the attribute calls are host time in front of every cold call otherwise)
+        if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval);
+        g.lds_attr_n = n;
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval);
-    hipLaunchKernelGGL(k_cf_setup, dim3(1), dim3(256), lds_setup, st, n, n_pairs, (double *)g.d_L.p, d_br, d_q, (double *)g.d_nf.p,
+    hipLaunchKernelGGL(k_cf_setup, dim3(1), dim3(256), lds_setup, st, n, n_pairs, (double *)g.d_L.p, par, g.d_par.p, (double *)g.d_nf.p,
                        (double *)g.d_mf.p, (uint32_t *)g.d_mq.p);
     hipLaunchKernelGGL(k_cf_rows, dim3((unsigned)((np1 + 63) / 64), n_pairs), dim3(64), lds_rows, st, n, (const double *)g.d_L.p, d_br, d_cov,
                        (double *)g.d_pm.p);
