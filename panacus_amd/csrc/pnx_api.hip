@@ -401,7 +401,6 @@ void pnx_free(pnx_ctx *ctx) {
     {
         auto &t = ctx->gtab;
         for (DevBuf *b : {&t.d_par, &t.d_L, &t.d_nf, &t.d_mf, &t.d_mq, &t.d_pm, &t.d_lsq, &t.d_terms, &t.d_sum}) release(*b);
-        if (t.h_par) (void)hipHostFree(t.h_par);
         if (t.ready) (void)hipEventDestroy(t.ready);
     }
     for (auto &t : ctx->tk) {

@@ -311,7 +311,6 @@ struct pnx_ctx {
         pnx::DevBuf d_L, d_nf, d_mf, d_mq;  // log2 table, per-pair running sums, m_quorum
         pnx::DevBuf d_pm, d_lsq;         // perc_mult[t][i][m]; log2 of the quorum branch's inner sums [t][i][m]
         pnx::DevBuf d_terms, d_sum;      // scratch of a build: terms of the inner sums, the sums
-        void *h_par = nullptr;           // (unused since the pairs travel as kernel arguments)
         uint32_t lds_attr_n = 0;         // the n the kernels' LDS attributes were set for
         hipEvent_t ready = nullptr;
         uint64_t gen = 0, n_builds = 0;
