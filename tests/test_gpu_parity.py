@@ -1511,6 +1511,23 @@ def test_full_size_cfg4_all_orders_and_masked_prefix_parity():
                 for t, (cv, q) in enumerate(pairs):
                     exp = _oracle_growth(items, pre, m, p, pg, perms[r], cv, q, w)
                     assert out[r, t].tolist() == [int(x) for x in exp], (weighted, r, cv, q)
+            if not weighted:
+                # EVERY one of the 128 orders against the oracle, on a shorter prefix (12 500 nodes: the serial loop takes
+                # milliseconds per order there); the device's work is the same 10 M x 512 matrix whatever the mask
+                m2 = 12_500
+                items2, pre2, _ = orc.pansyn(42, m2, p)
+                excl2 = np.zeros(n + 1, dtype=np.uint8)
+                excl2[m2 + 1:] = 1
+                c.set_exclude(excl2)
+                c.hist()
+                out2 = c.ordered_growth(cov, qt, perms)
+                pi2 = np.arange(p, dtype=np.uint64)
+                for r in range(R):
+                    # one path per group: the paths in the order of their group's rank
+                    rows, cols = orc.by_group(items2, pre2, perms[r].astype(np.uint64), pi2, m2)
+                    for t, (cv, q) in enumerate(pairs):
+                        exp = orc.ordered_growth(rows, cols, p, (orc.ABSOLUTE, cv), (orc.RELATIVE, q), None)
+                        assert out2[r, t].tolist() == [int(x) for x in exp], (r, cv, q)
             c.set_exclude(None)
 
 
