@@ -20,6 +20,17 @@ except ImportError:
     pass
 
 
+# A process that dies inside the native libraries leaves the C stack of the faulting thread behind (hostlib installs the
+# handler when it loads the host library): pytest's fd capture swallows whatever the runtime printed on its way down.
+if "PANACUS_AMD_CRASH_LOG" not in os.environ:
+    _crash_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(_crash_dir, exist_ok=True)
+    except OSError:
+        _crash_dir = "/tmp"
+    os.environ["PANACUS_AMD_CRASH_LOG"] = os.path.join(_crash_dir, "pytest_crash.txt")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -35,3 +46,22 @@ def golden():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# PNX_TEST_RESOURCES=<file>: after every test one line with the process's open descriptors, threads and mappings (a leak that
+# only a whole session accumulates shows as a trend; the file is flushed per line, so it survives a process that dies)
+_RES = os.environ.get("PNX_TEST_RESOURCES")
+
+
+def pytest_runtest_teardown(item, nextitem):
+    if not _RES:
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            n_maps = sum(1 for _ in f)
+        line = "%s\tfds=%d\tthreads=%d\tmaps=%d\n" % (item.nodeid, len(os.listdir("/proc/self/fd")),
+                                                      len(os.listdir("/proc/self/task")), n_maps)
+        with open(_RES, "a") as f:
+            f.write(line)
+    except OSError:
+        pass
