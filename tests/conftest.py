@@ -75,7 +75,9 @@ def _run_cli_in_a_process(args):
     import subprocess
 
     exe = os.path.join(ROOT, "panacus_amd", "panacus-amd")
-    p = subprocess.run([exe] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    # (argv[0] as the in-process runner passes it: the tables' header line echoes the command)
+    p = subprocess.run(["panacus-amd"] + [str(a) for a in args], executable=exe, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
     if p.returncode < 0:
         raise RuntimeError("panacus-amd %s died with signal %d\n%s" % (" ".join(map(str, args)), -p.returncode,
                                                                        p.stderr.decode(errors="replace")[-4000:]))
