@@ -3,7 +3,9 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "pnx_context.hpp"
@@ -12,17 +14,88 @@ static std::string g_init_err;
 
 namespace pnx {
 
+// PNX_GUARD_ALLOC=1 (a debugging aid, never the default): every device buffer is a mapping of its own (HIP's virtual memory
+// management calls) that ENDS where the buffer and its 256 bytes of over-read allowance end, with an unmapped page behind it, and
+// the address range of a released buffer is never handed out again -- a kernel that reads or writes past a buffer, or through a
+// stale pointer, raises a GPU memory fault at once instead of touching whatever the allocator placed there (the intermittent
+// abort of whole sessions at the end of round 5, DESIGN.md section 2, was hunted with this).
+namespace {
+struct GuardRec {
+    void *base;
+    size_t mapped;
+    hipMemGenericAllocationHandle_t h;
+};
+std::mutex g_guard_mu;
+std::unordered_map<void *, GuardRec> g_guard;
+bool guard_mode() {
+    static const bool on = [] {
+        const char *e = getenv("PNX_GUARD_ALLOC");
+        return e && e[0] && e[0] != '0';
+    }();
+    return on;
+}
+hipError_t guard_malloc(void **out, size_t bytes, int device) {
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran < 4096) gran = 4096;
+    const size_t mapped = (bytes + gran - 1) / gran * gran;
+    void *base = nullptr;
+    if ((e = hipMemAddressReserve(&base, mapped + gran, gran, nullptr, 0)) != hipSuccess) return e;
+    hipMemGenericAllocationHandle_t h;
+    if ((e = hipMemCreate(&h, mapped, &prop, 0)) != hipSuccess) return e;
+    if ((e = hipMemMap(base, mapped, 0, h, 0)) != hipSuccess) return e;
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(base, mapped, &acc, 1)) != hipSuccess) return e;
+    void *p = (char *)base + (mapped - bytes);
+    {
+        std::lock_guard<std::mutex> g(g_guard_mu);
+        g_guard[p] = GuardRec{base, mapped, h};
+    }
+    *out = p;
+    return hipSuccess;
+}
+void guard_free(void *p) {
+    GuardRec r;
+    {
+        std::lock_guard<std::mutex> g(g_guard_mu);
+        auto it = g_guard.find(p);
+        if (it == g_guard.end()) {
+            (void)hipFree(p);
+            return;
+        }
+        r = it->second;
+        g_guard.erase(it);
+    }
+    (void)hipDeviceSynchronize();  // (hipFree waits for the device as well)
+    (void)hipMemUnmap(r.base, r.mapped);
+    (void)hipMemRelease(r.h);
+    // the reservation stays: the range is never mapped again, so a stale pointer faults for the rest of the process
+}
+hipError_t dev_malloc(void **out, size_t bytes, int device) { return guard_mode() ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes); }
+void dev_free(void *p) {
+    if (guard_mode()) guard_free(p);
+    else (void)hipFree(p);
+}
+}  // namespace
+
 int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
     if (!b.borrowed && b.cap >= bytes) return PNX_OK;
     if (b.p) {
-        if (!b.borrowed) (void)hipFree(b.p);
+        if (!b.borrowed) dev_free(b.p);
         b.p = nullptr;
         b.cap = 0;
         b.borrowed = false;
     }
-    hipError_t e = hipMalloc(&b.p, bytes + 256);  // +256: vector loads may over-read a tail
+    hipError_t e = dev_malloc(&b.p, bytes + 256, ctx->device);  // +256: vector loads may over-read a tail
     if (e != hipSuccess) {
         b.p = nullptr;
         return ctx->fail(PNX_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
@@ -32,7 +105,7 @@ int ensure(pnx_ctx *ctx, DevBuf &b, size_t bytes) {
 }
 
 void release(DevBuf &b) {
-    if (b.p && !b.borrowed) (void)hipFree(b.p);
+    if (b.p && !b.borrowed) dev_free(b.p);
     b.p = nullptr;
     b.cap = 0;
     b.borrowed = false;

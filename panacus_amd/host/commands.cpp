@@ -78,9 +78,6 @@ Device::Device(int ordinal, bool expect_text) : text_(std::make_shared<TextSlot>
             slot->keep.reset();
             throw std::runtime_error(std::string("GPU initialisation failed: ") + pnx_last_error(nullptr));
         }
-        // quorum closed form with >= 256 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps
-        // the whole closed form on the host threads; the results are the same bits either way)
-        if (!std::getenv("PANACUS_AMD_HOST_GROWTH")) set_quorum_offload(c);
         phase_mark("GPU context up");
         // the bytes of the GFA, as soon as the parser has them: copied to HBM beside the parse
         std::unique_lock<std::mutex> lk(slot->mu);
@@ -126,7 +123,13 @@ bool Device::text_uploaded() const {
     return there;
 }
 pnx_ctx *Device::ctx() const {
-    if (init_.valid()) ctx_ = init_.get();  // throws what the initialisation threw
+    if (init_.valid()) {
+        ctx_ = init_.get();  // throws what the initialisation threw
+        // quorum closed form with >= 256 groups: inner sums on this GPU (PANACUS_AMD_HOST_GROWTH=1 keeps the whole closed form on
+        // the host threads; the results are the same bits either way).  Bound for the command's THREAD, not for the process: a
+        // host that runs commands on several threads gives each its own context.
+        if (ctx_ && !std::getenv("PANACUS_AMD_HOST_GROWTH")) bind_thread_offload(ctx_);
+    }
     return ctx_;
 }
 namespace {
@@ -148,7 +151,7 @@ Device::~Device() {
     } catch (...) {
     }
     if (!ctx_ || leaked_) return;
-    release_quorum_offload(ctx_);  // the next run's context may be registered already (report runner)
+    unbind_thread_offload(ctx_);  // (only if it is still this one: the next run's context may be bound already -- report runner)
     pnx_free(ctx_);
 }
 void Device::check(int rc) const {

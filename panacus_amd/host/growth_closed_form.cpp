@@ -163,6 +163,19 @@ bool log2_restatement_matches_libm() {
 std::mutex g_offload_mu;
 pnx_ctx *g_offload_ctx = nullptr;
 uint64_t g_offload_min_n = 256;
+// a context bound by THIS thread (bind_thread_offload: the in-process CLI, one context per command) goes before the process-wide
+// one: two commands on two threads must not evaluate their closed forms on each other's context (a pnx_ctx serves one thread at a time)
+thread_local pnx_ctx *t_offload_ctx = nullptr;
+// -> the context the calling thread offloads to (nullptr: none) and its threshold
+pnx_ctx *offload_context(uint64_t &min_n) {
+    if (t_offload_ctx) {
+        min_n = 256;
+        return t_offload_ctx;
+    }
+    std::lock_guard<std::mutex> g(g_offload_mu);
+    min_n = g_offload_min_n;
+    return g_offload_ctx;
+}
 
 // The (n+1)^2 term arrays are recycled across calls: fresh 8 MB allocations are mmap'ed by
 // malloc and first touched by all workers at once, and those page faults (plus the munmap
@@ -389,11 +402,7 @@ bool offload_eligible(const Job &j, uint64_t min_n) {
 Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
     Offload o;
     uint64_t min_n = 0;
-    {
-        std::lock_guard<std::mutex> g(g_offload_mu);
-        o.ctx = g_offload_ctx;
-        min_n = g_offload_min_n;
-    }
+    o.ctx = offload_context(min_n);
     if (!o.ctx) return o;
     for (auto &j : jobs) {
         if (!offload_eligible(*j, min_n)) continue;
@@ -413,10 +422,7 @@ Offload start_offload(std::vector<std::unique_ptr<Job>> &jobs) {
 void finish_offload(const Offload &o, std::vector<std::unique_ptr<Job>> &jobs) {
     if (!o.job) return;
     uint64_t min_n = 0;
-    {
-        std::lock_guard<std::mutex> g(g_offload_mu);
-        min_n = g_offload_min_n;
-    }
+    (void)offload_context(min_n);
     std::vector<Job *> more;
     for (auto &j : jobs)
         if (j.get() != o.job && offload_eligible(*j, min_n)) more.push_back(j.get());
@@ -516,6 +522,11 @@ void release_quorum_offload(void *pnx_context) {
     if (g_offload_ctx == static_cast<pnx_ctx *>(pnx_context)) g_offload_ctx = nullptr;
 }
 
+void bind_thread_offload(void *pnx_context) { t_offload_ctx = static_cast<pnx_ctx *>(pnx_context); }
+void unbind_thread_offload(void *pnx_context) {
+    if (t_offload_ctx == static_cast<pnx_ctx *>(pnx_context)) t_offload_ctx = nullptr;
+}
+
 bool quorum_offload_usable() { return exp2_restatement_matches_libm(); }
 bool device_growth_usable() { return exp2_restatement_matches_libm() && log2_restatement_matches_libm(); }
 void log2_restated(const double *x, double *y, uint64_t n) {
@@ -542,14 +553,10 @@ void host_jobs(GrowthRun &run) {
 
 // Whole closed forms on the device: with a context set (set_quorum_offload), both libm restatements confirmed, and n
 // in the range the device path takes.  hist == nullptr: the counters of the context's last coverage pass.
-bool start_device_growth(GrowthRun &run, const uint64_t *hist) {
-    pnx_ctx *ctx = nullptr;
+bool start_device_growth(GrowthRun &run, const uint64_t *hist, const void *only_ctx = nullptr) {
     uint64_t min_n = 0;
-    {
-        std::lock_guard<std::mutex> g(g_offload_mu);
-        ctx = g_offload_ctx;
-        min_n = g_offload_min_n;
-    }
+    pnx_ctx *ctx = offload_context(min_n);
+    if (only_ctx && ctx != only_ctx) return false;  // "the counters of the last pass" are those of the offload context and of no other
     const uint64_t n = run.n;
     if (!ctx || n < min_n || n < 2 || n > 2048 || run.n_pairs == 0 || run.n_pairs > 16 || !device_growth_usable()) return false;
     std::vector<uint32_t> br(run.n_pairs), cv(run.n_pairs);
@@ -569,14 +576,10 @@ bool start_device_growth(GrowthRun &run, const uint64_t *hist) {
 // The thresholds are known before the coverage pass is enqueued: the first part of the device tables of (n, pairs) -- two small
 // kernels -- is started now and runs while the pass's kernels are being launched (pnx_growth_tables_begin); false: the device path
 // would not take these arguments anyway.
-bool growth_tables_begin(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum) {
-    pnx_ctx *ctx = nullptr;
+bool growth_tables_begin(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum, const void *only_ctx) {
     uint64_t min_n = 0;
-    {
-        std::lock_guard<std::mutex> g(g_offload_mu);
-        ctx = g_offload_ctx;
-        min_n = g_offload_min_n;
-    }
+    pnx_ctx *ctx = offload_context(min_n);
+    if (only_ctx && ctx != only_ctx) return false;
     const size_t n_pairs = coverage.size();
     if (!ctx || n < min_n || n < 2 || n > 2048 || n_pairs == 0 || n_pairs > 16 || quorum.size() != n_pairs || !device_growth_usable()) return false;
     std::vector<uint32_t> br(n_pairs), cv(n_pairs);
@@ -610,13 +613,14 @@ GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::
 
 // the curves of the histogram of the coverage pass enqueued LAST on the offload context (n groups), without the histogram
 // visiting the host; nullptr when the device path cannot take it (the caller then fetches the histogram and uses _begin)
-GrowthRun *calc_all_growths_begin_on_device(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum) {
+GrowthRun *calc_all_growths_begin_on_device(uint64_t n, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum,
+                                            const void *only_ctx) {
     std::unique_ptr<GrowthRun> run(new GrowthRun);
     run->coverage = coverage;
     run->quorum = quorum;
     run->n_pairs = coverage.size();
     run->n = n;
-    if (!start_device_growth(*run, nullptr)) return nullptr;
+    if (!start_device_growth(*run, nullptr, only_ctx)) return nullptr;
     return run.release();
 }
 

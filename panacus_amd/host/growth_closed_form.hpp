@@ -29,6 +29,10 @@ double choose_log2(uint64_t n, uint64_t k);  // hist.rs:21-36
 void set_quorum_offload(void *pnx_context, uint64_t min_n = 256);
 // forget the context if it is the registered one (a context that goes away while a newer one is already registered)
 void release_quorum_offload(void *pnx_context);
+// the same for the CALLING THREAD only, ahead of the process-wide context: what the in-process CLI binds (one context per command,
+// commands on several threads at once must not evaluate on each other's context); unbind clears it if it is still this context
+void bind_thread_offload(void *pnx_context);
+void unbind_thread_offload(void *pnx_context);
 bool quorum_offload_usable();
 
 // Hist::calc_all_growths (hist.rs:68-87) without the NaN row: one curve per (coverage, quorum)
@@ -46,9 +50,11 @@ GrowthRun *calc_all_growths_begin(const std::vector<uint64_t> &hist, const std::
 std::vector<std::vector<double>> calc_all_growths_end(GrowthRun *run);
 // the curves of the histogram of the coverage pass enqueued last on the offload context, computed without the histogram
 // visiting the host (nullptr: not available -- fetch the histogram and use calc_all_growths_begin)
-GrowthRun *calc_all_growths_begin_on_device(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum);
+// only_ctx: take the device path only when THIS context is the offload context (a caller that just enqueued its pass on it)
+GrowthRun *calc_all_growths_begin_on_device(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum,
+                                            const void *only_ctx = nullptr);
 // before the coverage pass is enqueued: start the first part of the device tables of (n_groups, pairs) (false: not on the device)
-bool growth_tables_begin(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum);
+bool growth_tables_begin(uint64_t n_groups, const std::vector<Threshold> &coverage, const std::vector<Threshold> &quorum, const void *only_ctx = nullptr);
 // true iff the restated log2 AND exp2 reproduce this platform's libm bit for bit: whole closed forms may run on the device
 bool device_growth_usable();
 void log2_restated(const double *x, double *y, uint64_t n);

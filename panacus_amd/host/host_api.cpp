@@ -3,6 +3,7 @@
 // (panacus_amd/hostlib.py) and linked into the panacus-amd CLI.
 #include <cstdint>
 #include <algorithm>
+#include <atomic>
 #include <csignal>
 #include <cstdio>
 #include <cstring>
@@ -89,7 +90,12 @@ void *pnh_graph_from_cache(const char *cache_file, const char *gfa_file, int nee
         return nullptr;
     }
 }
-void pnh_graph_free(void *g) { delete static_cast<pnh::GraphStorage *>(g); }
+// (every free advances the epoch: a per-thread cache keyed by a graph's ADDRESS must not serve the next graph the allocator puts there)
+static std::atomic<uint64_t> g_graph_epoch{0};
+void pnh_graph_free(void *g) {
+    g_graph_epoch.fetch_add(1);
+    delete static_cast<pnh::GraphStorage *>(g);
+}
 uint64_t pnh_graph_n_nodes(const void *g) { return static_cast<const pnh::GraphStorage *>(g)->node_count(); }
 // how the segments are named, as the device routes see it: 0 names the device does not take (longer than 16 bytes), 1 a
 // number that is the rank of the S line, 2 a number that a table maps, 3 up to 16 bytes that are hashed; prefix8 receives
@@ -123,8 +129,10 @@ int64_t pnh_graph_item_table(const void *g, int count_type, uint32_t *items, uin
     static thread_local pnh::ItemTable cache;
     static thread_local const void *cache_g = nullptr;
     static thread_local int cache_c = -1;
+    static thread_local uint64_t cache_epoch = 0;
     try {
-        if (cache_g != g || cache_c != count_type) {
+        if (cache_g != g || cache_c != count_type || cache_epoch != g_graph_epoch.load()) {
+            cache_epoch = g_graph_epoch.load();
             cache = static_cast<const pnh::GraphStorage *>(g)->item_table((pnh::CountType)count_type);
             cache_g = g;
             cache_c = count_type;
@@ -363,17 +371,30 @@ int pnh_histgrowth_resident(void *pnx_context, uint64_t n_groups, const int *cov
         if ((flags & 1u) && (rc = pnx_config(ctx, PNX_CFG_DROP_DERIVED, 0))) return rc;
         if ((flags & 2u) && (rc = pnx_config(ctx, PNX_CFG_DROP_GROWTH_TABLES, 0))) return rc;
         // the first part of the tables before the pass is enqueued (two small kernels that must not run beside it), the curves behind it
-        const bool tables = pnh::growth_tables_begin(n_groups, cov, quo);
+        // (the device curves are those of the OFFLOAD context's last pass: taken only when `ctx` is that context)
+        const bool tables = pnh::growth_tables_begin(n_groups, cov, quo, ctx);
         if ((rc = pnx_hist_async(ctx))) return rc;
-        pnh::GrowthRun *run = tables ? pnh::calc_all_growths_begin_on_device(n_groups, cov, quo) : nullptr;
+        pnh::GrowthRun *run = tables ? pnh::calc_all_growths_begin_on_device(n_groups, cov, quo, ctx) : nullptr;
         if ((rc = pnx_hist_fetch(ctx, nullptr, hist_out))) {
             if (run) (void)pnh::calc_all_growths_end(run);
             return rc;
         }
-        if (!run) run = pnh::calc_all_growths_begin(std::vector<uint64_t>(hist_out, hist_out + n_groups + 1), cov, quo, 0);
-        const std::vector<std::vector<double>> g = pnh::calc_all_growths_end(run);
-        for (uint32_t t = 0; t < n_pairs && t < g.size(); ++t)
-            std::memcpy(growth_out + (size_t)t * n_groups, g[t].data(), std::min<size_t>(g[t].size(), n_groups) * sizeof(double));
+        const std::vector<uint64_t> hist(hist_out, hist_out + n_groups + 1);
+        if (!run) run = pnh::calc_all_growths_begin(hist, cov, quo, 0);
+        std::vector<std::vector<double>> g = pnh::calc_all_growths_end(run);
+        auto complete = [&] {
+            if (g.size() != n_pairs) return false;
+            for (const auto &c : g)
+                if (c.size() != n_groups) return false;
+            return true;
+        };
+        // the device curves failed at the fetch (there is no histogram in that run to fall back on): from the histogram that IS here
+        if (!complete()) g = pnh::calc_all_growths_end(pnh::calc_all_growths_begin(hist, cov, quo, 0));
+        if (!complete()) {
+            g_host_err = "histgrowth: the closed-form curves could not be computed";
+            return PNX_EHIP;
+        }
+        for (uint32_t t = 0; t < n_pairs; ++t) std::memcpy(growth_out + (size_t)t * n_groups, g[t].data(), n_groups * sizeof(double));
         return 0;
     } catch (const std::exception &e) {
         g_host_err = e.what();
@@ -399,6 +420,15 @@ int pnh_run_cli(const char *argv_joined, char *out_buf, uint64_t out_cap, uint64
         }
     }
     argv.push_back(cur);
+    // PNX_TRACE_CLI=<file>: every in-process command is appended to the file BEFORE it runs (one line, flushed), so that a
+    // session that dies inside the native libraries names the command it died in
+    if (const char *tr = std::getenv("PNX_TRACE_CLI")) {
+        if (FILE *f = std::fopen(tr, "a")) {
+            for (size_t i = 0; i < argv.size(); ++i) std::fprintf(f, "%s%s", i ? " " : "", argv[i].c_str());
+            std::fputc('\n', f);
+            std::fclose(f);
+        }
+    }
     std::string out, err;
     int rc = pnh::run_cli(argv, out, err);
     auto put = [](const std::string &s, char *buf, uint64_t cap, uint64_t *len) {
