@@ -145,7 +145,11 @@ def launch_ranks(n, force_dist):
     if have < 0:
         import torch
         have = torch.cuda.device_count()
-    if have < n:
+    # PANACUS_BENCH_ONE_DEVICE=1 (tests): the N ranks share device 0 and reduce their counters over gloo -- every line of the
+    # multi-rank path (node-range shards, the reduced flags, the collectives' call pattern) runs on a box with ONE GPU; the
+    # numbers of such a run say nothing about scaling and the line says so ("one_device": true)
+    one_device = os.environ.get("PANACUS_BENCH_ONE_DEVICE") == "1"
+    if have < n and not (one_device and have >= 1):
         raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible to this process -- nothing was measured")
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
@@ -153,7 +157,7 @@ def launch_ranks(n, force_dist):
     sock.close()
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if one_device else str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    PANACUS_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if force_dist:
             env["PANACUS_BENCH_FORCE_DIST"] = "1"
@@ -508,6 +512,108 @@ def strong_hist_block(args, torch, dist, use_dist, world, rank, local_rank, bloc
             "frac_of_aggregate_hbm_peak_on_algorithmic_bytes": B / (sharded["ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
             "rank0": sharded, "alone": None if world == 1 else alone,
             "checks": {"hist_sum": sharded["hist_sum"], "sharded_equals_single_gpu": True},
+        }
+    return out
+
+
+def strong_pggb_block(args, torch, dist, use_dist, world, rank, local_rank, blocking):
+    """A second strong-scaling case (N > 1) on a graph whose steps are NOT spread evenly over the ids: a pggb-shaped pangenome
+    (`panacus-amd synth --shape pggb`: contig paths per haplotype, inversions, tandem duplications; grouped by sample as
+    `histgrowth -S`), parsed from its GFA file, split into N node ranges BALANCED BY STEP COUNT (distributed.plan_node_shards:
+    a step costs the rank that owns its id) -- a step of the job is the MAX over the ranks, so ranges of equal node count would
+    let the densest range set the pace.  The line reports both plans' imbalance (largest shard's steps / mean) beside the
+    measured step; rank 0 afterwards runs alone on the whole graph (`speedup_vs_1` from one run on one box)."""
+    import shutil
+    import tempfile
+    from panacus_amd import capi, hostlib
+    from panacus_amd.distributed import even_node_range, plan_node_shards, shard_csr
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
+    thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
+    steps = max(4, args.strong_steps)
+    box = [None]
+    if rank == 0:
+        box[0] = tempfile.mkdtemp(prefix="pnx_bench_pggb_")
+        gfa = os.path.join(box[0], "pggb.gfa")
+        rc, msg, err = hostlib.run_cli(["synth", "--shape", "pggb", "--nodes", str(args.ss2_nodes), "--samples", str(args.ss2_samples),
+                                        "--seed", str(args.seed), "-o", gfa])
+        if rc != 0:
+            raise RuntimeError(err)
+    if use_dist:
+        dist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    gfa = os.path.join(tmp, "pggb.gfa")
+    try:
+        g = hostlib.GfaGraph(gfa)
+        items, pre = g.item_table(hostlib.NODE)
+        pi, gi, names = g.path_order(hostlib.GROUP_SAMPLE)
+        n, G = g.n_nodes, len(names)
+        g.close()
+        if use_dist:
+            dist.barrier()  # every rank has read the file
+    finally:
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+    cuts = plan_node_shards(items, n, world)
+    per_item = np.bincount(items.astype(np.int64), minlength=n + 1)
+    cum = np.concatenate([[0], np.cumsum(per_item)])  # cum[k] = steps with id < k
+    by_steps = [int(cum[int(cuts[r + 1])] - cum[int(cuts[r])]) for r in range(world)]
+    even = []
+    for r in range(world):
+        lo, hi = even_node_range(n, world, r)
+        even.append(int(cum[hi + 1] - cum[lo + 1]))
+    mean = len(items) / world
+
+    def run(lo, hi, dist_on, label):  # ids lo .. hi - 1
+        it, off, n_r = shard_csr(items, pre, lo, hi)
+        ctx = capi.Context(local_rank)
+        if blocking:
+            ctx.config(capi.CFG_BLOCKING_SYNC, 1)
+        ctx.set_csr(it, off, n_r)
+        ctx.set_order(pi, gi, G)
+        stepper = OneShot(ctx, G, thr, rank=rank, world=world if dist_on else 1, use_dist=dist_on, dist=dist, torch=torch,
+                          local_rank=local_rank, collective=args.collective, blocking=blocking, growth_on_device=False,
+                          growth_threads=args.growth_threads)
+
+        def barrier():
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ctx.sync()
+
+        dt, h, growths, prof = timed_steps(stepper, steps, 4, barrier, max(1, min(4, steps // 4)))
+        if dist_on:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        info = ctx.info()
+        res = {"label": label, "nodes": hi - lo, "steps_in_csr": int(info.n_steps), "ms_per_step": dt / steps * 1e3,
+               "route": "one-shot over the steps" if int(info.n_rows) == 0 else "path rows", "n_reruns": int(info.n_reruns),
+               "hist": [int(x) for x in h], "growth_last_floor": [int(np.floor(gr[-1])) for gr in growths] if growths is not None else None}
+        stepper.close()
+        if dist_on:
+            torch.cuda.synchronize()
+        ctx.close()
+        return res
+
+    sharded = run(int(cuts[rank]), int(cuts[rank + 1]), use_dist, f"rank {rank} of {world}")
+    out = None
+    if rank == 0:
+        alone = sharded if world == 1 else run(1, n + 1, False, "rank 0 alone on the whole graph")
+        if sharded["hist"] != alone["hist"] or sum(alone["hist"]) != n or sharded["growth_last_floor"] != alone["growth_last_floor"]:
+            raise SystemExit("strong scaling (pggb shape): the sharded histogram / curves differ from the single-GPU ones")
+        out = {
+            "workload": f"histgrowth -S -c node -l 1,2,1 -q 0,0,0.5 on a pggb-shaped graph (synth --shape pggb, seed {args.seed}): {n} nodes, "
+                        f"{len(pre) - 1} paths in {G} groups, {len(items)} steps, split into {world} node range(s) of about equal STEP count",
+            "n_gpus": world, "scaling": "strong", "steps": steps,
+            "sharding": "node ranges balanced by step count (distributed.plan_node_shards); all-reduce (sum) of the (G+1) counters; closed forms on rank 0",
+            "steps_per_rank": by_steps, "imbalance_by_steps": max(by_steps) / mean,
+            "steps_per_rank_if_even_node_ranges": even, "imbalance_even_node_ranges": max(even) / mean,
+            "ms_per_step": sharded["ms_per_step"], "ms_per_step_1gpu": alone["ms_per_step"],
+            "speedup_vs_1": alone["ms_per_step"] / sharded["ms_per_step"],
+            "rank0": {k: v for k, v in sharded.items() if k != "hist"},
+            "alone": None if world == 1 else {k: v for k, v in alone.items() if k != "hist"},
+            "checks": {"hist_sum": sum(sharded["hist"]), "sharded_equals_single_gpu": True},
         }
     return out
 
@@ -909,6 +1015,8 @@ def main():
     ap.add_argument("--k1-steps", type=int, default=20)
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong_scaling block (one headline graph split by node range)")
     ap.add_argument("--strong-steps", type=int, default=40)
+    ap.add_argument("--ss2-nodes", type=int, default=1_000_000, help="N > 1: nodes of the pggb-shaped graph of the second strong-scaling block")
+    ap.add_argument("--ss2-samples", type=int, default=44)
     ap.add_argument("--no-strayed", action="store_true", help="skip the strayed_paths block (the headline step on pansyn-v1r: paths not sorted by id)")
     ap.add_argument("--strayed-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -967,7 +1075,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PANACUS_BENCH_ONE_DEVICE") == "1":  # several ranks on one device: RCCL cannot, gloo can (through the host)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from panacus_amd import capi, hostlib
     from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
@@ -1066,6 +1177,7 @@ def main():
             "value": value,
             "unit": "M node*paths/s",
             "n_gpus": world,
+            "one_device": os.environ.get("PANACUS_BENCH_ONE_DEVICE") == "1" and world > 1,  # (true: a test of the multi-rank path on ONE GPU over gloo, not a scaling measurement)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -1178,6 +1290,14 @@ def main():
             sb = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             out["strong_scaling"] = sb
+        try:
+            sb2 = strong_pggb_block(args, torch, dist, use_dist, world, rank, local_rank, blocking)
+        except SystemExit:
+            raise
+        except Exception as e:
+            sb2 = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["strong_scaling_pggb_shape"] = sb2
     # ---- BASELINE.json configs[3]: permuted growth, strong scaling (every rank takes part) ----
     if not args.no_permuted_growth:
         # With N > 1 ranks this block is the one place where the ranks exchange data (RCCL all-reduce of the curves).  The

@@ -68,6 +68,11 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--calls", type=int, default=9)
     ap.add_argument("--no-whole", action="store_true", help="skip the whole-graph legs (the shard's numbers only)")
+    ap.add_argument("--all-shards", action="store_true",
+                    help="measure EVERY shard (a step of the job is the MAX over the ranks) and price the estimate on the slowest one")
+    ap.add_argument("--allreduce-us", type=float, default=50.0,
+                    help="what the estimate charges for the all-reduce of the result among the D ranks (microseconds; one rank's launch "
+                         "floor is measured, the wire of D ranks is not: a stated latency, not a measurement)")
     args = ap.parse_args()
     from panacus_amd import capi
     from panacus_amd.distributed import even_node_range
@@ -136,6 +141,21 @@ def main():
 
     out["cfg3_shard"] = legs(256, lo, hi, False)
     out["cfg4_shard"] = legs(512, lo, hi, True)
+    if args.all_shards:
+        # every shard, one after the other on this GPU: what the slowest rank of D would take
+        per = []
+        for r in range(D):
+            lo_r, hi_r = even_node_range(N, D, r)
+            if r == args.shard:
+                s3, s4 = out["cfg3_shard"], out["cfg4_shard"]
+            else:
+                s3, s4 = legs(256, lo_r, hi_r, False), legs(512, lo_r, hi_r, True)
+            per.append({"shard": r, "nodes": hi_r - lo_r, "cfg3_steps": s3["steps"], "cfg3_cold_hist_ms": s3["cold_hist"]["ms_per_call"],
+                        "cfg3_route": s3["cold_hist"]["route"], "cfg4_steps": s4["steps"], "cfg4_cold_pack_ms": s4["cold_pack"]["ms_per_call"],
+                        "cfg4_pack_frac_of_hbm_peak": s4["cold_pack"]["frac_of_hbm_peak_on_algorithmic_bytes"],
+                        "cfg4_growth_ms": s4["growth"]["ms_per_call"], "cfg4_growth_kernel_ms": s4["growth"]["kernel_ms"],
+                        "allreduce_one_rank_ms": s4.get("allreduce", {}).get("ms_per_call_one_rank")})
+        out["all_shards"] = per
     if not args.no_whole:
         out["cfg3_whole"] = legs(256, 0, N, False)
         out["cfg4_whole"] = legs(512, 0, N, True)
@@ -143,6 +163,20 @@ def main():
         ar = s.get("allreduce", {}).get("ms_per_call_one_rank", 0.0) or 0.0
         one = w["cold_pack"]["ms_per_call"] + w["growth"]["ms_per_call"]
         eight = s["cold_pack"]["ms_per_call"] + s["growth"]["ms_per_call"] + ar
+        if args.all_shards:
+            # the job's call is the slowest rank's (pack + growth) + the collective among D ranks at a STATED latency
+            worst = max(x["cfg4_cold_pack_ms"] + x["cfg4_growth_ms"] for x in out["all_shards"])
+            w3 = out["cfg3_whole"]
+            worst3 = max(x["cfg3_cold_hist_ms"] for x in out["all_shards"])
+            out["estimate_all_shards"] = {
+                "permuted_growth_one_gpu_ms": one, "slowest_shard_ms": worst, "allreduce_charged_ms": args.allreduce_us * 1e-3,
+                "permuted_growth_speedup": one / (worst + args.allreduce_us * 1e-3),
+                "hist_one_gpu_ms": w3["cold_hist"]["ms_per_call"], "hist_slowest_shard_ms": worst3,
+                "hist_speedup": w3["cold_hist"]["ms_per_call"] / (worst3 + args.allreduce_us * 1e-3),
+                "from": f"every one of the {D} shards measured in this run, one after the other on ONE GPU; the job's time is the SLOWEST shard's "
+                        f"(cold pack + growth call) + {args.allreduce_us:.0f} us charged for the all-reduce among {D} ranks (a stated latency: RCCL "
+                        f"has not run on two devices here); speedup = the whole graph on one GPU / that",
+            }
         out["estimate_8_gpus_permuted_growth"] = {
             "one_gpu_ms": one, "eight_gpus_ms": eight, "speedup": one / eight,
             "from": "cold pack + growth call of the whole graph on one GPU / (cold pack + growth call of ONE shard of 8 + the all-reduce's "

@@ -1162,7 +1162,7 @@ static bool band_sparse(const pnx_ctx *ctx, uint32_t n_bands) {
     if (const char *e = getenv("PNX_BAND_SPARSE")) {  // measurement: 0 / 1 forces one
         if ((e[0] == '0' || e[0] == '1') && e[1] == 0) return e[0] == '1';
     }
-    return ctx->n_entries >= 64 && ctx->n_steps / ((uint64_t)n_bands * ctx->n_paths) < 512;
+    return ctx->n_entries >= 64 && ctx->n_steps / ((uint64_t)n_bands * std::max<uint32_t>(ctx->n_entries, 1u)) < 512;
 }
 
 static BandLoose band_loose(const pnx_ctx *ctx) {

@@ -13,6 +13,7 @@
 //        lane, sequentially -- the reference's order of additions
 // The host then finishes each (i, m) with libm: exp2(log2(h[i]) + log2(sum_q)) (:178-180).
 #include <algorithm>
+#include <mutex>
 #include <cstring>
 
 #include "exp2_exact.hpp"
@@ -921,12 +922,22 @@ static int growth_tables_first_part(pnx_ctx *ctx, uint32_t n, uint32_t n_pairs, 
     const uint32_t *d_br = (const uint32_t *)((const char *)g.d_par.p + T * 8), *d_cov = d_br + T;
     const size_t lds_setup = 4 * np1 * sizeof(double), lds_rows = 2 * np1 * sizeof(double);  // tables staged in LDS
     const size_t lds_eval = (2 * CF_CHUNK * 64 + np1) * sizeof(double);
-    if (g.lds_attr_n != n) {  // (once per n: the attribute calls are host time in front of every cold call otherwise)
-        if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+    // The attribute belongs to the device FUNCTION, not to a context: kept per device as the largest n asked for so far (a second
+    // context with a smaller n must not lower what the first one launches with), raised when a larger n comes -- once per n
+    // at most: the attribute calls are host time in front of every cold call otherwise.
+    {
+        static std::mutex mu;
+        static uint32_t max_n[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        uint32_t &have = max_n[(unsigned)ctx->device & 63u];
+        if (n > have) {
+            if (n > 1000) {  // beyond the default 64 KB per workgroup (k_cf_rows also holds a 33 KB tile)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_setup), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_setup);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows);
+            }
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval);
+            have = n;
         }
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_cf_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_eval);
         g.lds_attr_n = n;
     }
     hipLaunchKernelGGL(k_cf_setup, dim3(1), dim3(256), lds_setup, st, n, n_pairs, (double *)g.d_L.p, par, g.d_par.p, (double *)g.d_nf.p,

@@ -78,7 +78,19 @@ void guard_free(void *p) {
     (void)hipMemRelease(r.h);
     // the reservation stays: the range is never mapped again, so a stale pointer faults for the rest of the process
 }
-hipError_t dev_malloc(void **out, size_t bytes, int device) { return guard_mode() ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes); }
+// (buffers beyond PNX_GUARD_MAX_MB [256] keep hipMalloc: multi-GB mappings made of minimum-granularity pages raised faults INSIDE
+// their own range on this stack -- k_pansyn_fill writing a 15.6 GB mapping, found with AMD_LOG_LEVEL=3 -- and the over-reads this
+// mode hunts are at the ends of small and medium buffers)
+size_t guard_max_bytes() {
+    static const size_t v = [] {
+        const char *e = getenv("PNX_GUARD_MAX_MB");
+        return (size_t)(e ? strtoull(e, nullptr, 10) : 256ull) << 20;
+    }();
+    return v;
+}
+hipError_t dev_malloc(void **out, size_t bytes, int device) {
+    return guard_mode() && bytes <= guard_max_bytes() ? guard_malloc(out, bytes, device) : hipMalloc(out, bytes);
+}
 void dev_free(void *p) {
     if (guard_mode()) guard_free(p);
     else (void)hipFree(p);
@@ -290,7 +302,9 @@ static int settle_oldest(pnx_ctx *ctx) {
             ctx->band_failed = true;
             ctx->pass_band = false;
             ctx->n_reruns += 1;
-            if (t->h_flags[5] & 64u) ctx->loose_dirty = true;
+            // (under a communicator flags[5] is the SUM over the ranks of a set of bits: which bits cannot be told -- two ranks
+            // with bit 64 give 128 -- so any void pass there leaves the bitmaps to be cleared)
+            if ((t->h_flags[5] & 64u) || (ctx->comm && ctx->comm_reduce_hist)) ctx->loose_dirty = true;
             // (why: 1 inconsistent index entry, 2 spill list full, 4 scan volume, 8 the index's probes met steps from elsewhere,
             // 16 more loose groups (or steps in them) than a pass takes in, 32 an id that is no item, 64 the marking workgroups did not meet)
             if (getenv("PNX_BAND_DEBUG"))
@@ -1103,7 +1117,10 @@ int pnx_set_order(pnx_ctx *ctx, const uint32_t *path_idx, const uint32_t *group_
     ctx->n_groups = n_groups;
     ctx->have_order = true;
     // (the entries of a one-shot pass follow from the order and the graph alone: made here, not inside the first pass)
-    if (use_rows(ctx) && ctx->have_csr && ctx->h_path_off.size() == (size_t)ctx->n_paths + 1 && (rc = ensure_band_entries(ctx))) return rc;
+    // (the entries serve the one-shot route alone: not built where no such pass can follow)
+    if (use_rows(ctx) && ctx->have_csr && ctx->h_path_off.size() == (size_t)ctx->n_paths + 1 && !ctx->rows_valid && !ctx->band_failed && ctx->cover_route != 2 &&
+        (rc = ensure_band_entries(ctx)))
+        return rc;
     return PNX_OK;
 }
 
@@ -1123,7 +1140,7 @@ int pnx_hist_async(pnx_ctx *ctx) {
         // the first sweep of a graph takes the steps themselves when its shape suits the one-shot route (one read, nothing
         // derived); a second sweep is a caller that keeps sweeping: it derives the path rows, and every later pass is 8x cheaper
         ctx->pass_band = !ctx->rows_valid && !ctx->band_failed && ctx->n_ordered && ctx->n_steps &&
-                         (ctx->cover_route == 1 || (ctx->cover_route == 0 && ctx->n_band_passes == 0 && band_route_fits(ctx, ctx->n_ordered)));
+                         (ctx->cover_route == 1 || (ctx->cover_route == 0 && ctx->n_band_passes == 0 && band_route_fits(ctx, ctx->entries_valid ? ctx->n_entries : ctx->n_ordered)));  // (the pieces of cut paths are entries too)
         if (ctx->pass_band) ctx->n_band_passes += 1;
         else if ((rc = ensure_rows(ctx, false))) return rc;  // once per upload
     }

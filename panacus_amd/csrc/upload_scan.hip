@@ -237,8 +237,13 @@ int sort_jumbled_paths(pnx_ctx *ctx) {
     DevBuf bigger;
     int rc;
     if ((rc = ensure(ctx, bigger, (base + extra) * 4 + 64))) return rc;
-    PNX_HIP(ctx, hipMemcpyAsync(bigger.p, ctx->d_items.p, S * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    if (base > S) PNX_HIP(ctx, hipMemsetAsync((uint32_t *)bigger.p + S, 0, (base - S) * 4, ctx->stream));
+    // (no early-return macro from here on: `bigger` -- a copy of all the steps -- and `tmp` are released on every way out)
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == PNX_OK) rc = ctx->fail(e == hipErrorOutOfMemory ? PNX_ENOMEM : PNX_EHIP, "%s failed: %s", what, hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    hip_ok(hipMemcpyAsync(bigger.p, ctx->d_items.p, S * 4, hipMemcpyDeviceToDevice, ctx->stream), "copying the steps at upload");
+    if (rc == PNX_OK && base > S) hip_ok(hipMemsetAsync((uint32_t *)bigger.p + S, 0, (base - S) * 4, ctx->stream), "padding the steps at upload");
     unsigned bits = 1;
     while (bits < 32 && (ctx->n_items >> bits)) ++bits;
     DevBuf tmp;
@@ -253,7 +258,7 @@ int sort_jumbled_paths(pnx_ctx *ctx) {
         if (e == hipSuccess && (rc = ensure(ctx, tmp, bytes ? bytes : 8)) == PNX_OK) e = rocprim::radix_sort_keys(tmp.p, bytes, in, out, (size_t)len, 0u, bits, ctx->stream);
         if (e != hipSuccess) rc = ctx->fail(PNX_EHIP, "sorting a path at upload failed: %s", hipGetErrorString(e));
         const uint64_t pad = ((len + 63) & ~63ull) - len;
-        if (rc == PNX_OK && pad) PNX_HIP(ctx, hipMemsetAsync(out + len, 0, pad * 4, ctx->stream));
+        if (rc == PNX_OK && pad) hip_ok(hipMemsetAsync(out + len, 0, pad * 4, ctx->stream), "padding a sorted path");
         ctx->h_sorted_at[p] = at;
         at += len + pad;
     }
