@@ -79,8 +79,10 @@ struct Log2Table {
 __attribute__((target_clones("avx2", "default"), optimize("O3")))
 #endif
 void quorum_step(double *__restrict q, const double *__restrict ch, const double *__restrict la,
-                 const double *__restrict lb, double mf, double nf, double *__restrict x, uint64_t jlo, uint64_t jhi) {
-    for (uint64_t j = jlo; j < jhi; ++j) {
+                 const double *__restrict lb, double mf, double nf, double *__restrict x, uint64_t len) {
+    // (every array begins at the first admissible j: a base "la - something" in front of the table it points into is undefined
+    // behaviour even if only in-range elements are read -- UBSan, round 6)
+    for (uint64_t j = 0; j < len; ++j) {
         double qj = q[j];
         qj = qj == 0.0 ? ch[j] : qj;
         qj = qj + la[j];
@@ -340,7 +342,8 @@ struct Job {
             }
             ch_hi = std::max(ch_hi, jhi);
             // q[j] += log2(n - i - m + 1 + j); q[j] -= log2(m - j); x = q[j] + m_fact - n_fall
-            quorum_step(qq, ch, L.v.data() + (n - i - m + 1), L.rev.data() + (K - m), m_fact[m], n_fall[m], xs, jlo, jhi);
+            quorum_step(qq + jlo, ch + jlo, L.v.data() + ((n + 1 + jlo) - (i + m)), L.rev.data() + (K - m) + jlo, m_fact[m], n_fall[m], xs + jlo,
+                        jhi - jlo);
             double sum_q = 0.0;
             for (uint64_t j = jlo; j < jhi; ++j) {
                 // sum_q += exp2(x).  The libm call is skipped where its result provably cannot change

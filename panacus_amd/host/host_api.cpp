@@ -9,6 +9,7 @@
 #include <cstring>
 #include <execinfo.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <stdexcept>
 #include <string>
@@ -41,6 +42,25 @@ static void crash_handler(int sig) {
         void *frames[64];
         const int k = backtrace(frames, 64);
         backtrace_symbols_fd(frames, k, fd);
+        // What the process last wrote to stderr / stdout, when those are regular files: under pytest's descriptor capture they
+        // are unlinked temporary files that die with the process -- and the ROCm runtime says WHY it aborts ("Memory access
+        // fault by GPU node ...", "HSA_STATUS_ERROR_...") on stderr just before it does.  The tail of each goes to the crash log.
+        for (int cap = 2; cap >= 1; --cap) {
+            struct stat st;
+            if (::fstat(cap, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) continue;
+            static char tail[8192];
+            const off_t from = st.st_size > (off_t)sizeof tail ? st.st_size - (off_t)sizeof tail : 0;
+            const ssize_t got = ::pread(cap, tail, sizeof tail, from);
+            if (got > 0) {
+                const int m = std::snprintf(head, sizeof head, "--- last %d bytes of descriptor %d\n", (int)got, cap);
+                if (m > 0 && ::write(fd, head, (size_t)m) < 0) {
+                }
+                if (::write(fd, tail, (size_t)got) < 0) {
+                }
+                if (::write(fd, "\n", 1) < 0) {
+                }
+            }
+        }
         ::close(fd);
     }
     signal(sig, SIG_DFL);

@@ -29,6 +29,9 @@ def load() -> C.CDLL:
                                          C.c_uint, f64p]
     L.pnh_choose_log2.restype = C.c_double
     L.pnh_choose_log2.argtypes = [C.c_uint64, C.c_uint64]
+    if os.environ.get("PANACUS_AMD_CRASH_LOG"):  # the C stack (and the tail of a captured stderr) of a process that dies in native code goes to this file
+        L.pnh_install_crash_handler.argtypes = [C.c_char_p]
+        L.pnh_install_crash_handler(os.environ["PANACUS_AMD_CRASH_LOG"].encode())
     _lib = L
     return L
 
@@ -191,9 +194,6 @@ def _bind_graph(L):
     for n in ("pnh_graph_n_nodes", "pnh_graph_n_edges", "pnh_graph_n_paths"):
         getattr(L, n).restype = C.c_uint64
         getattr(L, n).argtypes = [C.c_void_p]
-    if os.environ.get("PANACUS_AMD_CRASH_LOG"):  # soak runs: the C stack of a crash goes to this file
-        L.pnh_install_crash_handler.argtypes = [C.c_char_p]
-        L.pnh_install_crash_handler(os.environ["PANACUS_AMD_CRASH_LOG"].encode())
     L.pnh_graph_name_kind.argtypes = [C.c_void_p, C.c_char_p]
     L.pnh_graph_node_lens.restype = u32p
     L.pnh_graph_node_lens.argtypes = [C.c_void_p]
