@@ -256,7 +256,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
     const uint32_t *__restrict__ rowoff /* R x G byte offsets of the rows */, uint32_t R,
     uint32_t blocks_per_chunk, const uint32_t *__restrict__ cmask, GrowthTabs tabs,
     const uint32_t *__restrict__ dmask /* T x G: 0 or ~0 */, uint32_t T,
-    const uint32_t *__restrict__ weights, uint32_t n_items, unsigned long long *out) {
+    const uint32_t *__restrict__ weights, uint32_t n_items, unsigned long long *out, uint32_t evq_n /* bp: events a wave queues */) {
     constexpr int NA = N0 + NQ;
     constexpr bool WEIGHTED = WMODE != 0;
     constexpr int B = GROW_PREFETCH;  // ranks per batch
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
     uint32_t *wp = wp_all + (size_t)wave * (WMODE == 1 ? 1024 : 2048);
     uint16_t *wp16 = reinterpret_cast<uint16_t *>(wp);
     constexpr int EVW = 1 + NA + NQ;  // event: (rank << 8 | lane), up mask per accumulator, down mask per quorum pair
-    uint32_t *evq = wp_all + (size_t)GROW_WAVES * (WMODE == 1 ? 1024 : 2048) + (size_t)wave * GROW_EVQ * EVW;
+    uint32_t *evq = wp_all + (size_t)GROW_WAVES * (WMODE == 1 ? 1024 : 2048) + (size_t)wave * evq_n * EVW;
     uint32_t qn = 0;  // events in the queue (wave-uniform)
     // the presence matrix as a buffer (below 4 GiB on this route): a row load is base + the row's byte offset (a scalar) +
     // the lane's offset within the row, no vector instruction for the address
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                     for (int qi = 0; qi < NQ; ++qi) ev[1 + NA + qi] = dn[qi];
                 }
                 qn += (uint32_t)__builtin_popcountll(bal);
-                if (qn > (uint32_t)(GROW_EVQ - 64)) apply_events();
+                if (qn > evq_n - 64u) apply_events();
             }
         };
         const uint32_t voff = (blk * BLOCK_WORDS + lane) * 4u;  // byte offset of this lane's word in a row
@@ -822,7 +822,11 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
             bool alt = nq > 0 && !general_step;
             for (int k = 0; k < nq; ++k)
                 if (!alternates(qslack[iq + k])) alt = false;
-            const size_t evq_bytes = ctx->weighted ? (size_t)GROW_WAVES * GROW_EVQ * (1 + n0 + 2 * nq) * 4 : 0;
+            // bp: the flip events a wave queues before its 64 lanes apply them, one event per lane: a longer queue is applied in
+            // full rounds (128: a flush of 65 .. 128 events is one full round and a partial one)
+            uint32_t evq_n = GROW_EVQ;
+            if (const char *e = std::getenv("PNX_GROWTH_EVQ")) evq_n = std::max(128, std::atoi(e)) / 64 * 64;  // experiments
+            const size_t evq_bytes = ctx->weighted ? (size_t)GROW_WAVES * evq_n * (1 + n0 + 2 * nq) * 4 : 0;
             const size_t shmem = (size_t)(n0 + nq) * G * 8 + (size_t)GROW_WAVES * (n0 + nq) * (GROW_PREFETCH / 2) * 4 + wl_bytes + evq_bytes;
             if (shmem > 150 * 1024)
                 return ctx->fail(PNX_ELIMIT, "ordered growth: %u groups x %d threshold pairs exceed the LDS accumulators",
@@ -833,7 +837,7 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
                 hipLaunchKernelGGL(kern, dim3(R * n_chunks), dim3(GROW_WAVES * 64), shmem, ctx->stream,
                                    (const uint32_t *)ctx->d_M.p, NB, G, d_rowoff, R, bpc, (const uint32_t *)ctx->d_cmask.p,
                                    tabs, d_dmask, T, (const uint32_t *)ctx->d_weights.p, ctx->n_items,
-                                   (unsigned long long *)ctx->d_growth_out.p);
+                                   (unsigned long long *)ctx->d_growth_out.p, evq_n);
             };
 #define PNX_GROW_NQ(NPL1, N0V, W)                                                                 \
     do {                                                                                          \

@@ -413,6 +413,9 @@ def run_cli(args):
         return rc, out.value.decode(), err.value.decode()
 
 
+run_cli_inprocess = run_cli  # (tests/conftest.py may point run_cli at the panacus-amd binary; this name always runs in this process)
+
+
 def format_f64(x: float) -> str:
     L = load()
     L.pnh_format_f64.restype = C.c_uint64

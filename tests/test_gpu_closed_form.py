@@ -321,3 +321,43 @@ def test_histgrowth_in_one_native_call_equals_the_calls_one_by_one_and_the_oracl
                 hostlib.set_quorum_offload(None)
         _, h2 = ctx.hist(want_countable=False)
         assert np.array_equal(h2, oh)
+
+
+def test_histgrowth_in_one_native_call_on_a_context_that_is_not_the_offload_context():
+    """pnh_histgrowth_resident(ctx) while ANOTHER context is the offload context (round-5 advisor): "the counters of the last pass"
+    are those of the offload context -- with a different graph and a different number of groups there -- so the call must take
+    its curves from ITS OWN histogram (host threads, or the device fed with that histogram), never from the other context's
+    pass.  Both contexts' results equal the oracle's."""
+    import oracle as orc
+    from panacus_amd import capi, hostlib
+    from panacus_amd.thresholds import ABSOLUTE, RELATIVE, Threshold
+    pairs = [(Threshold(ABSOLUTE, 1), Threshold(RELATIVE, 0.0)), (Threshold(ABSOLUTE, 1), Threshold(RELATIVE, 0.5))]
+
+    def want(seed, n, p):
+        items, pre, _ = orc.pansyn(seed, n, p)
+        pi = np.arange(p, dtype=np.uint64)
+        oh = orc.hist(orc.coverage(items, pre, pi, pi, n), p)
+        return oh, [orc.growth(oh, (orc.ABSOLUTE, int(c.value)), (orc.RELATIVE, q.value)) for c, q in pairs]
+
+    (na, pa), (nb, pb) = (150_000, 320), (90_000, 260)
+    oh_a, g_a = want(3, na, pa)
+    oh_b, g_b = want(4, nb, pb)
+    with capi.Context(0) as a, capi.Context(0) as b:
+        for c, seed, n, p in ((a, 3, na, pa), (b, 4, nb, pb)):
+            c.set_csr_pansyn(seed, n, p, with_weights=False)
+            o = np.arange(p, dtype=np.uint32)
+            c.set_order(o, o, p)
+        hostlib.set_quorum_offload(b, 256)
+        try:
+            b.hist(want_countable=False)   # b's last pass: 260 groups
+            for _ in range(2):
+                h, g = hostlib.histgrowth_resident(a, pa, pairs, drop_derived=True, drop_tables=True)   # a is NOT the offload context
+                assert np.array_equal(h, oh_a)
+                for x, y in zip(g, g_a):
+                    assert x.tobytes() == np.asarray(y, dtype=np.float64).tobytes()
+                h, g = hostlib.histgrowth_resident(b, pb, pairs, drop_derived=True, drop_tables=True)   # b is
+                assert np.array_equal(h, oh_b)
+                for x, y in zip(g, g_b):
+                    assert x.tobytes() == np.asarray(y, dtype=np.float64).tobytes()
+        finally:
+            hostlib.set_quorum_offload(None)

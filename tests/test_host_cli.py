@@ -717,3 +717,47 @@ def test_cli_pggb_shaped_graph_example_commands(tmp_path):
     for k, (c, q) in enumerate(((1, 0.0), (2, 0.5))):
         exp = orc.ordered_growth(r_, c_, G, (orc.ABSOLUTE, c), (orc.RELATIVE, q), g.node_lens)
         assert [x[1 + k] for x in rows] == [hl.format_f64(float(v)) for v in exp], (c, q)
+
+
+@pytest.mark.gpu
+def test_cli_commands_on_several_threads_of_one_process(tmp_path):
+    """A host that binds the library in-process may run commands on several threads at once (the reference calls the replaced
+    functions from rayon workers, src/analyses/ordered_histgrowth.rs:174-188): every command has a GPU context of its own, and
+    the closed forms of >= 256 groups are evaluated on THAT context (bound per thread, round 6) -- not on whichever context
+    another thread's command registered last.  Four threads, each its own graph and commands, tables equal to the ones the
+    same commands print one after the other."""
+    import threading
+    graphs = []
+    for k, (n, p) in enumerate(((30000, 300), (20000, 270), (25000, 40), (12000, 330))):
+        path = str(tmp_path / f"g{k}.gfa")
+        rc, out, err = hl.run_cli_inprocess(["synth", "--nodes", str(n), "--paths", str(p), "--seed", str(5 + k), "-o", path])
+        assert rc == 0, err
+        graphs.append(path)
+    cmds = [["histgrowth", "-a", "-c", "node", "-l", "1,2,1", "-q", "0,0,0.5"], ["histgrowth", "-c", "bp", "-l", "1,1", "-q", "0.3,0.9"],
+            ["ordered-histgrowth", "-c", "node", "-l", "1,2", "-q", "0,0.5"], ["hist", "-c", "all"]]
+    serial = {}
+    for g in graphs:
+        for c in cmds:
+            rc, out, err = hl.run_cli_inprocess(c + [g])
+            assert rc == 0, err
+            serial[(g, tuple(c))] = _body(out)
+    errors = []
+
+    def worker(g):
+        try:
+            for rep in range(3):
+                for c in cmds:
+                    rc, out, err = hl.run_cli_inprocess(c + [g])
+                    if rc != 0:
+                        errors.append((g, c, err))
+                    elif _body(out) != serial[(g, tuple(c))]:
+                        errors.append((g, c, "table differs from the command run alone"))
+        except Exception as e:   # noqa: BLE001
+            errors.append((g, None, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(g,)) for g in graphs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
