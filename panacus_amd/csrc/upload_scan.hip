@@ -113,16 +113,21 @@ int refine_path_cuts(pnx_ctx *ctx) {
             hi[c] = pe - cut > RUN_CHUNK ? cut + RUN_CHUNK : pe;
         }
     int rc;
-    if ((rc = ensure(ctx, ctx->d_chunk_sum, 3 * n * 8))) return rc;  // (the summaries are on the host: their buffer serves)
-    uint64_t *d = (uint64_t *)ctx->d_chunk_sum.p;
-    PNX_HIP(ctx, hipMemcpyAsync(d, lo.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipMemcpyAsync(d + n, hi.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-    PNX_HIP(ctx, hipMemcpyAsync(d + 2 * n, ctx->h_cuts.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_refine_cuts, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t *)ctx->d_items.p, (const uint64_t *)d,
-                       (const uint64_t *)(d + n), d + 2 * n);
-    PNX_HIP(ctx, hipGetLastError());
-    PNX_HIP(ctx, hipMemcpyAsync(ctx->h_cuts.data(), d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DevBuf scratch;  // (the summaries stay where they are: the index kernel of every one-shot pass reads them)
+    if ((rc = ensure(ctx, scratch, 3 * n * 8))) return rc;
+    uint64_t *d = (uint64_t *)scratch.p;
+    hipError_t e = hipMemcpyAsync(d, lo.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, hi.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 2 * n, ctx->h_cuts.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_refine_cuts, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t *)ctx->d_items.p, (const uint64_t *)d,
+                           (const uint64_t *)(d + n), d + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_cuts.data(), d + 2 * n, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release(scratch);
+    if (e != hipSuccess) return ctx->fail(PNX_EHIP, "moving the cuts of the paths to their steps failed: %s", hipGetErrorString(e));
     return PNX_OK;
 }
 
@@ -139,6 +144,7 @@ int launch_chunk_summaries(pnx_ctx *ctx, uint32_t *d_bad) {
     PNX_HIP(ctx, hipGetLastError());
     ctx->h_chunk_sum.resize(n_chunks);
     PNX_HIP(ctx, hipMemcpyAsync(ctx->h_chunk_sum.data(), ctx->d_chunk_sum.p, n_chunks * sizeof(ChunkSummary), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->chunk_sum_valid = true;
     return PNX_OK;
 }
 

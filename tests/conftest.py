@@ -67,10 +67,14 @@ def pytest_runtest_teardown(item, nextitem):
         pass
 
 
-# On a GPU box the CLI tests run every command the way a user does: `panacus_amd/panacus-amd` in a process of its own.  The in-process
-# runner (hostlib.run_cli: hundreds of commands, each with a GPU context of its own, inside the one pytest process) aborted the whole
-# session now and then at the end of round 5 (profiles/README.md, last section); a command that dies in its own process fails ONE
-# test, with its stderr in the report.  PNX_TEST_CLI_INPROCESS=1 brings the in-process runner back (that is where the bug is hunted).
+# The CLI tests run their commands IN this process (hostlib.run_cli -> pnh_run_cli): the way a host binds the library, hundreds of
+# commands with a GPU context each in one pytest process.  At the end of round 5 three of eight whole sessions died of SIGABRT
+# inside such tests and the suite ran every command as the `panacus-amd` binary instead; round 6 hunted the abort (guard-page
+# device allocator, AddressSanitizer / UBSan / ThreadSanitizer builds of both libraries under soak harnesses, 13 whole in-process
+# sessions -- 5 of them on round 5's own tree -- without one abort: DESIGN.md section 2) and made in-process the default again.
+# PNX_TEST_CLI_OWN_PROCESS=1 runs every command as the binary in a process of its own (a command that dies then fails ONE test,
+# with its stderr in the report); a process that dies in native code leaves its C stack and the tail of the captured stderr in
+# PANACUS_AMD_CRASH_LOG (above).
 def _run_cli_in_a_process(args):
     import subprocess
 
@@ -86,17 +90,11 @@ def _run_cli_in_a_process(args):
 
 @pytest.fixture(scope="session", autouse=True)
 def _cli_commands_in_their_own_process():
-    if os.environ.get("PNX_TEST_CLI_INPROCESS"):
+    if not os.environ.get("PNX_TEST_CLI_OWN_PROCESS"):
         yield
         return
-    try:
-        import torch
-
-        on_gpu = torch.cuda.is_available()
-    except ImportError:
-        on_gpu = False
     exe = os.path.join(ROOT, "panacus_amd", "panacus-amd")
-    if not on_gpu or not os.path.exists(exe):
+    if not os.path.exists(exe):
         yield
         return
     from panacus_amd import hostlib
