@@ -105,61 +105,14 @@ struct BandSpill {
 // second by tens, the third lands in the sector) and tightens the bracket; after 8 probes the guess is the midpoint.
 // The chain of dependent reads is what this kernel costs: ~4 probes here against ~14 single-step probes of a plain
 // interpolation + binary search (0.058 -> 0.03 ms on 10 M items x 256 paths).
-// The bracket of a search, narrowed on the upload's chunk summaries before a single step is probed: chunk i of the entry's path
-// (i counted over all paths) begins at c0_start + (i - c0) * 4096 and holds min(4096, pend - begin) steps; its summary holds the
-// ids at begin + (steps - 1) * q / 4, q = 0 .. 4 (k_chunk_summaries).  A round reads ONE summary -- that of the chunk a secant
-// through the bracket's ends points at -- and takes every one of its five ids that lies inside the bracket: an id below X moves
-// the lower end up, one at or above X the upper end down.  The ends stay steps of the entry with key(lo) < X <= key(hi), whatever
-// the order of the path, so whatever the search makes of the bracket is as valid as before.  The summaries are 7 bytes per 1024
-// steps -- the caches hold them --, a round costs a fraction of a probe into the steps, and two rounds leave <= 1024 steps.
-struct EdgeBracket {
-    uint64_t lo, hi;    // positions relative to the entry's first step
-    uint32_t klo, khi;  // their keys
-};
-template <bool DESC>
-__device__ static inline void seed_bracket(const ChunkSummary *__restrict__ csum, uint64_t c0, uint64_t c0_start, uint64_t pend, uint64_t ps,
-                                           uint64_t len, uint32_t X, EdgeBracket &b) {
-    const uint64_t last_abs = ps + len - 1;
-    for (int round = 0; round < 3 && b.hi - b.lo > 1024; ++round) {
-        const double t = (double)b.lo + ((double)X - (double)b.klo) * (double)(b.hi - b.lo) / ((double)b.khi - (double)b.klo + 1.0);
-        const uint64_t g = t <= (double)(b.lo + 1) ? b.lo + 1 : (t >= (double)(b.hi - 1) ? b.hi - 1 : (uint64_t)t);
-        const uint64_t i = c0 + (ps + g - c0_start) / RUN_CHUNK;
-        const uint64_t begin = c0_start + (i - c0) * RUN_CHUNK;
-        const uint64_t steps = pend - begin < RUN_CHUNK ? pend - begin : RUN_CHUNK;
-        const uint32_t *sp = csum[i].s;
-        const uint32_t sv[5] = {sp[0], sp[1], sp[2], sp[3], sp[4]};
-        bool moved = false;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const uint64_t pos = begin + (steps - 1) * (uint64_t)q / 4;
-            const uint32_t key = DESC ? ~sv[q] : sv[q];
-            if (pos <= ps || pos >= last_abs) continue;
-            const uint64_t rel = pos - ps;
-            if (rel <= b.lo || rel >= b.hi) continue;
-            if (key < X) {
-                b.lo = rel;
-                b.klo = key;
-            } else {
-                b.hi = rel;
-                b.khi = key;
-            }
-            moved = true;
-        }
-        if (!moved) break;
-    }
-}
-
 template <bool DESC>
 __device__ static inline uint64_t band_edge_search(const uint32_t *__restrict__ items, uint64_t ps, uint64_t len, uint32_t X, uint32_t ka,
-                                                   uint32_t kz, uint32_t &n_probes, uint32_t &n_astray, const ChunkSummary *__restrict__ csum = nullptr,
-                                                   uint64_t c0 = ~0ull, uint64_t c0_start = 0, uint64_t pend = 0) {
+                                                   uint32_t kz, uint32_t &n_probes, uint32_t &n_astray) {
     if (ka >= X) return 0;
     if (kz < X) return len;
-    EdgeBracket br{0, len - 1, ka, kz};
-    if (csum && c0 != ~0ull && len > 3 * (uint64_t)RUN_CHUNK) seed_bracket<DESC>(csum, c0, c0_start, pend, ps, len, X, br);
-    uint64_t lo = br.lo, hi = br.hi;  // key(lo) < X <= key(hi)
-    uint32_t klo = br.klo, khi = br.khi;  // ... those two keys: what a step between the two positions of a sorted path lies between
-    double pa = (double)lo, va = (double)klo, pb = (double)hi, vb = (double)khi;  // the two points of the secant
+    uint64_t lo = 0, hi = len - 1;  // key(lo) < X <= key(hi)
+    uint32_t klo = ka, khi = kz;    // ... those two keys: what a step between the two positions of a sorted path lies between
+    double pa = 0.0, va = (double)ka, pb = (double)(len - 1), vb = (double)kz;  // the two points of the secant
     uint32_t astray_here = 0;  // (a search that keeps meeting steps from elsewhere is not converging on anything: any position will do)
     for (int iter = 0; hi - lo > 1 && astray_here < 8u; ++iter) {
         uint64_t g = lo + ((hi - lo) >> 1);
@@ -221,8 +174,13 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
                                                     unsigned long long *__restrict__ bidx, uint32_t *__restrict__ group_first,
                                                     uint4 *__restrict__ block16, uint32_t n_block16, uint4 *__restrict__ zero16,
                                                     uint64_t n_zero16, uint32_t *__restrict__ probe_stats, uint32_t *__restrict__ group_loose,
-                                                    uint32_t *__restrict__ entry_loose, const ChunkSummary *__restrict__ csum,
-                                                    const uint64_t *__restrict__ ent_seed) {
+                                                    uint32_t *__restrict__ entry_loose, unsigned long long *__restrict__ dbg_time) {
+    // PNX_BAND_INDEX_TIMING (measurement): one wave in the middle of the grid stamps the 100 MHz clock behind every phase
+    const bool dbg_wave = dbg_time && blockIdx.x == gridDim.x / 2 && threadIdx.x < 64;
+    auto stamp = [&](int i) {
+        if (dbg_wave && threadIdx.x == 0) dbg_time[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n_threads = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t q = tid; q < n_block16; q += n_threads) block16[q] = make_uint4(0, 0, 0, 0);
@@ -240,16 +198,12 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
     bool desc = false;
     uint64_t j = 0;
     uint32_t n_probes = 0, n_astray = 0;
-    uint64_t sd_c0 = ~0ull, sd_start = 0, sd_pend = 0;
     if (live) {
         ps = ent_start[k];
         len = ent_len[k];
-        if (ent_seed) {
-            sd_c0 = ent_seed[3ull * k];
-            sd_start = ent_seed[3ull * k + 1];
-            sd_pend = ent_seed[3ull * k + 2];
-        }
     }
+    if (dbg_wave && (ps + len) == 0x7FFFFFFFFFFFFFFFull) dbg_time[15] = 1;  // (a use of the loads: the stamp waits for them)
+    stamp(1);
     // ---- does the path follow the ids at all?  Every lane looks at one 64-byte sector of its path (the lanes of a wave hold
     // consecutive edges of one path: their sectors are spread evenly along it): on a path that runs through the ids -- upwards
     // or downwards, with blocks reversed, repeated or from elsewhere -- the 15 steps from one id to the next inside a sector go
@@ -286,6 +240,8 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         sampled = true;
         jumbled = up + down >= 8u && (up < down ? up : down) * 4u > up + down;
     }
+    if (dbg_wave && (end_a ^ end_z ^ in_q1 ^ in_q2 ^ in_q3) == 0xFFFFFFFEu && jumbled) dbg_time[15] = 2;
+    stamp(2);
     bool loose = false;
     {
         const uint32_t lane = threadIdx.x & 63u;
@@ -315,6 +271,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
             rem &= ~same;
         }
     }
+    stamp(3);
     if (len && loose) {
         const uint64_t pr = (uint64_t)e * len / n_bands;  // (never read: the coverage kernel leaves the group out)
         desc = end_a > end_z;
@@ -342,9 +299,16 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         else if (e == n_bands) j = desc ? 0 : len;
         else {
             const uint32_t x = e * band_items;  // 1 <= x <= n_items: inner edges only
-            j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz, n_probes, n_astray, csum, sd_c0, sd_start, sd_pend)
-                     : band_edge_search<false>(items, ps, len, x, ka, kz, n_probes, n_astray, csum, sd_c0, sd_start, sd_pend);
+            j = desc ? band_edge_search<true>(items, ps, len, ~(x - 1u), ka, kz, n_probes, n_astray)
+                     : band_edge_search<false>(items, ps, len, x, ka, kz, n_probes, n_astray);
         }
+    }
+    if (dbg_wave && j == 0x7FFFFFFFFFFFFFFFull) dbg_time[15] = 3;
+    stamp(4);
+    if (dbg_wave) {
+        uint32_t np = n_probes;
+        for (int o = 32; o > 0; o >>= 1) np += __shfl_down(np, o);
+        if (threadIdx.x == 0) dbg_time[8] = np;
     }
     // How the probes fared, summed over the kernel: a sector with a step that cannot stand between the ends of the bracket it
     // was probed in is a sign of LONG-RANGE disorder (local jitter stays between the ends).  Where a quarter of the probes met
@@ -372,6 +336,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
             if (s_na) atomicAdd(probe_stats + 1, s_na);
         }
     }
+    stamp(5);
     // A search that probed a stretch of the path that is out of place (a translocated block, a copy of another region) may end
     // far from the crossing; the segment between it and its neighbour would then hold thousands of steps of other bands -- all
     // spilled, and one wave of the coverage kernel streaming them while its workgroup waits.  Edge positions of a path run
@@ -413,6 +378,7 @@ __global__ __launch_bounds__(256) void k_band_index(const uint32_t *__restrict__
         }
     }
     if (live) bidx[tid] = (ps + j) | (desc ? BAND_DESC : 0ull);
+    stamp(6);
 }
 
 // Graphs of many short paths (the contigs of an assembly-based pangenome: thousands of paths that each touch a few bands): most
@@ -1190,50 +1156,24 @@ int ensure_band_entries(pnx_ctx *ctx) {
     st.reserve(no);
     ln.reserve(no);
     gr.reserve(no);
-    // Seeds of the index kernel's searches (round 6): the upload's read of the steps left five ids of every chunk of 4096 steps
-    // (upload_scan.hip) -- one id per 1024 steps of every path, 7 bytes per 1024 steps, resident beside the steps.  An entry
-    // says which chunk holds its first step, where that chunk begins and where its path ends; the kernel then brackets every
-    // band edge between two of those ids (two or three reads of a table the caches hold) before it probes the steps themselves.
-    static const bool seed_env = [] {
-        const char *e = getenv("PNX_BAND_SEED");
-        return !(e && e[0] == '0');
-    }();
-    const bool seeds = seed_env && ctx->chunk_sum_valid && ctx->d_chunk_sum.p && ctx->h_path_off.size() == (size_t)ctx->n_paths + 1;
-    std::vector<uint64_t> coff, sd;
-    if (seeds) {
-        coff.assign((size_t)ctx->n_paths + 1, 0);
-        for (uint32_t p = 0; p < ctx->n_paths; ++p) coff[p + 1] = coff[p] + (ctx->h_path_off[p + 1] - ctx->h_path_off[p] + RUN_CHUNK - 1) / RUN_CHUNK;
-        sd.reserve(3 * (size_t)no);
-    }
-    auto push = [&](uint64_t a, uint64_t len, uint32_t g, uint32_t p, bool on_path) {
-        st.push_back(a), ln.push_back(len), gr.push_back(g);
-        if (!seeds) return;
-        if (on_path && len) {
-            const uint64_t rel = (a - ctx->h_path_off[p]) / RUN_CHUNK;
-            sd.push_back(coff[p] + rel), sd.push_back(ctx->h_path_off[p] + rel * RUN_CHUNK), sd.push_back(ctx->h_path_off[p + 1]);
-        } else {
-            sd.push_back(~0ull), sd.push_back(0), sd.push_back(0);  // (a sorted copy lies behind the graph's steps: no summaries of it)
-        }
-    };
+    auto push = [&](uint64_t a, uint64_t len, uint32_t g) { st.push_back(a), ln.push_back(len), gr.push_back(g); };
     for (uint32_t k = 0; k < no; ++k) {
         const uint32_t p = ctx->h_ord_path[k], g = ctx->h_ord_group[k];
         uint64_t a = ctx->h_path_off[p];
         uint64_t z = ctx->h_path_off[p + 1];
-        bool on_path = true;
         if (ctx->h_sorted_at.size() == ctx->n_paths && ctx->h_sorted_at[p]) {  // a path that follows the ids nowhere: its sorted copy (upload_scan.hip)
             z = ctx->h_sorted_at[p] + (z - a);
             a = ctx->h_sorted_at[p];
-            on_path = false;
         } else if (cuts) {
             for (uint32_t c = ctx->h_cut_off[p]; c < ctx->h_cut_off[p + 1]; ++c) {
                 const uint64_t cut = ctx->h_cuts[c];
                 if (cut > a && cut < z) {
-                    push(a, cut - a, g, p, true);
+                    push(a, cut - a, g);
                     a = cut;
                 }
             }
         }
-        push(a, z - a, g, p, on_path);
+        push(a, z - a, g);
     }
     if (st.size() >= 0xFFFFFFFEull) return ctx->fail(PNX_ELIMIT, "too many pieces of paths in the visiting order");
     const size_t n = st.size();
@@ -1244,13 +1184,8 @@ int ensure_band_entries(pnx_ctx *ctx) {
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_start.p, st.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_len.p, ln.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
         PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_group.p, gr.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
-        if (seeds) {
-            if ((rc = ensure(ctx, ctx->d_ent_seed, 3 * n * 8))) return rc;
-            PNX_HIP(ctx, hipMemcpyAsync(ctx->d_ent_seed.p, sd.data(), 3 * n * 8, hipMemcpyHostToDevice, ctx->stream));
-        }
         PNX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (the host vectors go; other streams read the arrays)
     }
-    ctx->ent_seed_valid = seeds && n;
     ctx->n_entries = (uint32_t)n;
     ctx->entries_valid = true;
     return PNX_OK;
@@ -1338,15 +1273,27 @@ int launch_band_phases(pnx_ctx *ctx, bool write_m) {
     }
     const bool phased = ctx->s_pre != ctx->s_main;
     const uint64_t n_zero16 = sp.n > 1 ? ((uint64_t)ctx->n_items + 1 + 3) / 4 : 0;  // (the buffer is a multiple of 256 bytes)
+    unsigned long long *dbg_time = nullptr;
+    static const bool index_timing = getenv("PNX_BAND_INDEX_TIMING") != nullptr;
+    static DevBuf d_dbg_time;  // (measurement only: one buffer per process, never freed)
+    if (index_timing && ensure(ctx, d_dbg_time, 16 * 8) == PNX_OK) {
+        dbg_time = (unsigned long long *)d_dbg_time.p;
+        (void)hipMemsetAsync(dbg_time, 0, 16 * 8, ctx->s_pre);
+    }
     prof_begin(ctx, PNX_K_INDEX, ctx->s_pre);
     hipLaunchKernelGGL(k_band_index, dim3((unsigned)((std::max<uint64_t>(cells, ctx->n_entries) + 255) / 256)), dim3(256), 0, ctx->s_pre,
                        (const uint32_t *)ctx->d_items.p, (const uint64_t *)ctx->d_ent_start.p, (const uint64_t *)ctx->d_ent_len.p,
                        (const uint32_t *)ctx->d_ent_group.p, ctx->n_entries, ctx->n_groups, n_bands, BT * BLOCK_ITEMS,
                        (unsigned long long *)tk->d_tile_idx_own.p, (uint32_t *)tk->d_group_first.p, (uint4 *)tk->d_block.p,
                        (uint32_t)(tk->block_bytes / 16), (uint4 *)tk->d_countable.p, n_zero16, (uint32_t *)ctx->d_band_probe.p,
-                       (uint32_t *)ctx->d_group_loose.p, (uint32_t *)ctx->d_entry_loose.p,
-                       ctx->ent_seed_valid && ctx->chunk_sum_valid ? (const ChunkSummary *)ctx->d_chunk_sum.p : (const ChunkSummary *)nullptr,
-                       ctx->ent_seed_valid && ctx->chunk_sum_valid ? (const uint64_t *)ctx->d_ent_seed.p : (const uint64_t *)nullptr);
+                       (uint32_t *)ctx->d_group_loose.p, (uint32_t *)ctx->d_entry_loose.p, dbg_time);
+    if (dbg_time) {  // (measurement only: waits for the kernel)
+        unsigned long long t[16] = {};
+        (void)hipStreamSynchronize(ctx->s_pre);
+        (void)hipMemcpy(t, dbg_time, sizeof t, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[panacus_amd] k_band_index, one wave, us behind its start: entries %.2f, ends + sector %.2f, verdict %.2f, (branch) %.2f, search %.2f (%llu probes of the wave), statistics %.2f, filter + store %.2f\n",
+                (t[1] - t[0]) / 100.0, (t[2] - t[0]) / 100.0, (t[3] - t[0]) / 100.0, (t[3] - t[0]) / 100.0, (t[4] - t[0]) / 100.0, t[8], (t[5] - t[0]) / 100.0, (t[6] - t[0]) / 100.0);
+    }
     if (sparse)
         hipLaunchKernelGGL(k_band_compact, dim3((n_bands * sp.n + 3) / 4), dim3(256), 0, ctx->s_pre, (const unsigned long long *)tk->d_tile_idx_own.p,
                            n_bands, ctx->n_entries, sp, (uint32_t *)tk->d_band_clist.p, (uint32_t *)tk->d_band_ccnt.p);

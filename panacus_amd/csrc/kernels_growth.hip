@@ -36,6 +36,11 @@ constexpr int GROW_PREFETCH = 16;  // row slices in flight per wave
 constexpr int GROW_Q0_MAX = 4;     // q == 0 threshold pairs handled by one launch
 constexpr int WPLANES_MAX = 32;
 constexpr int GROW_EVQ = 128;  // bp: flip events queued per wave before they are applied
+// bp: the weights of a block staged in LDS per wave (round 2) or read where an event needs one (round 6).  The kernel's bp
+// variant is bound by how many workgroups a CU holds: 39 KB of LDS per workgroup with the staging (16 KB of it), 4 per CU; longer
+// event queues made it slower (128 events: 18.7 ms, 256: 20.9, 512: 27.7 on cfg4) -- so the staging went: an event reads its
+// weight from the block's 8 KB of the weight vector (L1 / L2 hits: the R orders of a block run side by side).
+constexpr bool GROW_W_LDS = false;
 
 // full-wave sum, result valid in lane 63 (gfx9 DPP: row_shr within rows of 16, then row_bcast)
 __device__ static inline uint32_t wave_sum_to_lane63(uint32_t v) {
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
     const uint32_t r = blockIdx.x % R, chunk = blockIdx.x / R;
     const uint32_t *ro = rowoff + (uint64_t)r * G;
     uint32_t *stage = stage_all + wave * NA * (B / 2);
-    uint32_t *wp = wp_all + (size_t)wave * (WMODE == 1 ? 1024 : 2048);
+    constexpr uint32_t WSTAGE = GROW_W_LDS ? (WMODE == 1 ? 1024u : 2048u) : 0u;  // words of staged weights per wave
+    uint32_t *wp = wp_all + (size_t)wave * WSTAGE;
     uint16_t *wp16 = reinterpret_cast<uint16_t *>(wp);
     constexpr int EVW = 1 + NA + NQ;  // event: (rank << 8 | lane), up mask per accumulator, down mask per quorum pair
-    uint32_t *evq = wp_all + (size_t)GROW_WAVES * (WMODE == 1 ? 1024 : 2048) + (size_t)wave * evq_n * EVW;
+    uint32_t *evq = wp_all + (size_t)GROW_WAVES * WSTAGE + (size_t)wave * evq_n * EVW;
     uint32_t qn = 0;  // events in the queue (wave-uniform)
     // the presence matrix as a buffer (below 4 GiB on this route): a row load is base + the row's byte offset (a scalar) +
     // the lane's offset within the row, no vector instruction for the address
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
             mask[a] = 0xFFFFFFFFu;
             if (mi >= 0) mask[a] = cmask[((uint64_t)mi * n_blocks + blk) * BLOCK_WORDS + lane];
         }
-        if (WEIGHTED) {
+        if (WEIGHTED && GROW_W_LDS) {
             // weights of this block in presence layout: item (bit b, lane) at wp[b * 64 + lane]
             for (uint32_t b = 0; b < 32; ++b) {
                 const uint64_t node = (uint64_t)blk * BLOCK_ITEMS + b * 64u + lane;
@@ -366,7 +372,9 @@ __global__ __launch_bounds__(GROW_WAVES * 64, (WMODE == 0 && NPL1 <= 11) ? 6 : 1
                 while (any) {
                     const uint32_t b = (uint32_t)__builtin_ctz(any);
                     any &= any - 1;
-                    const unsigned long long w = WMODE == 1 ? (uint32_t)wp16[b * 64 + el] : wp[b * 64 + el];
+                    // (a set bit is an item of the graph: its id is within 1 .. n_items)
+                    const unsigned long long w = !GROW_W_LDS ? weights[(uint64_t)blk * BLOCK_ITEMS + b * 64u + el]
+                                                 : (WMODE == 1 ? (uint32_t)wp16[b * 64 + el] : wp[b * 64 + el]);
 #pragma unroll
                     for (int a = 0; a < NA; ++a) d[a] += ((up[a] >> b) & 1u) ? w : 0ull;
 #pragma unroll
@@ -788,7 +796,7 @@ int launch_growth(pnx_ctx *ctx, bool /*identity_perm: h_perms holds the identity
     n_chunks = (NB + bpc - 1) / bpc;
     const size_t wp_bytes = ctx->weighted ? (size_t)GROW_WAVES * WPLANES_MAX * 64 * sizeof(uint32_t) : 0;  // comparison kernel
     const bool w16 = ctx->weighted && ctx->n_wplanes <= 16;  // every weight < 2^16
-    const size_t wl_bytes = ctx->weighted ? (size_t)GROW_WAVES * 2048 * (w16 ? 2 : 4) : 0;                  // fused kernel
+    const size_t wl_bytes = ctx->weighted && GROW_W_LDS ? (size_t)GROW_WAVES * 2048 * (w16 ? 2 : 4) : 0;   // fused kernel: staged weights
     const uint32_t *d_wpl = ctx->weighted ? (const uint32_t *)ctx->d_wplanes.p : nullptr;
     const uint32_t n_planes = ctx->weighted ? ctx->n_wplanes : 0;
 

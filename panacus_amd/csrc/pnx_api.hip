@@ -475,7 +475,7 @@ void pnx_free(pnx_ctx *ctx) {
                       &ctx->d_cmask, &ctx->d_wplanes, &ctx->d_growth_out, &ctx->d_thr_meta, &ctx->d_run_start,
                       &ctx->d_run_len, &ctx->d_run_tile, &ctx->d_run_path, &ctx->d_srun_start, &ctx->d_srun_len,
                       &ctx->d_srun_group, &ctx->d_run_tile_off, &ctx->d_inter, &ctx->d_pair_partial, &ctx->d_plain, &ctx->d_new_of_old, &ctx->d_old_of_new, &ctx->d_countable_ext, &ctx->d_steps12, &ctx->d_path_mono, &ctx->d_rows, &ctx->d_row_base, &ctx->d_id_minmax, &ctx->d_rt_first, &ctx->d_rt_span, &ctx->d_chunk_off, &ctx->d_rb[0], &ctx->d_rb[1], &ctx->d_rb[2], &ctx->d_rb[3], &ctx->d_rb[4], &ctx->d_rb[5], &ctx->d_rs[0], &ctx->d_rs[1], &ctx->d_rs[2], &ctx->d_rs[3], &ctx->d_rs[4], &ctx->d_rs[5], &ctx->d_cf[0], &ctx->d_cf[1], &ctx->d_cf[2],
-                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe, &ctx->d_group_loose, &ctx->d_entry_loose, &ctx->d_loose_bits, &ctx->d_chunk_sum, &ctx->d_ent_seed, &ctx->d_ent_start, &ctx->d_ent_len, &ctx->d_ent_group})
+                      &ctx->d_cf[3], &ctx->d_cf[4], &ctx->d_cf[5], &ctx->d_comm_word, &ctx->d_gfa_text, &ctx->d_walk_node, &ctx->d_walk_back, &ctx->d_name_tab, &ctx->d_link_uv, &ctx->d_link_oo, &ctx->d_spill, &ctx->d_spill_dir, &ctx->d_spill_set, &ctx->d_band_probe, &ctx->d_group_loose, &ctx->d_entry_loose, &ctx->d_loose_bits, &ctx->d_chunk_sum, &ctx->d_ent_start, &ctx->d_ent_len, &ctx->d_ent_group})
         release(*b);
     if (ctx->h_cf) (void)hipHostFree(ctx->h_cf);
     if (ctx->ev_cf) (void)hipEventDestroy(ctx->ev_cf);
@@ -519,8 +519,6 @@ static void drop_gfa_text(pnx_ctx *ctx) {
 static void begin_upload(pnx_ctx *ctx) {
     invalidate_results(ctx);
     ctx->h_chunk_sum.clear();
-    ctx->chunk_sum_valid = false;
-    ctx->ent_seed_valid = false;
     ctx->h_cuts.clear();
     ctx->h_cut_off.clear();
     ctx->h_jumbled.clear();
@@ -1007,9 +1005,6 @@ int pnx_share_csr(pnx_ctx *dst, pnx_ctx *src) {
     borrow(dst->d_old_of_new, src->d_old_of_new);
     dst->relabeled = src->relabeled;
     dst->h_path_off = src->h_path_off;
-    borrow(dst->d_chunk_sum, src->d_chunk_sum);  // (the upload's summaries of the steps: what the index kernel narrows its searches on)
-    dst->chunk_sum_valid = src->chunk_sum_valid;
-    dst->ent_seed_valid = false;
     dst->h_cuts = src->h_cuts;  // (where the paths turn round or jump back: found at the owner's upload)
     dst->h_cut_off = src->h_cut_off;
     dst->h_sorted_at = src->h_sorted_at;  // (the copies lie in the owner's d_items, behind the steps)

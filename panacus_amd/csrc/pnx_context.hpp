@@ -219,11 +219,6 @@ struct pnx_ctx {
     // the entries of a one-shot pass: the visiting order with every path cut where it turns round or jumps back (pieces of a path
     // are entries of their own under the path's group; an order over paths without such breaks is its own entry list)
     pnx::DevBuf d_chunk_sum, d_ent_start, d_ent_len, d_ent_group;
-    // the upload's chunk summaries stay in d_chunk_sum (28 bytes per 4096 steps: five ids of every chunk = one id per 1024 steps of
-    // every path): the index kernel of a one-shot pass narrows the bracket of every edge search on them before it probes the steps
-    bool chunk_sum_valid = false;       // d_chunk_sum holds the summaries of the resident steps
-    pnx::DevBuf d_ent_seed;             // per entry [chunk that holds its first step | where that chunk begins | where its path ends] (u64 each), or not made
-    bool ent_seed_valid = false;
     std::vector<pnx::ChunkSummary> h_chunk_sum;
     std::vector<uint64_t> h_cuts;      // absolute step positions, path by path
     std::vector<uint32_t> h_cut_off;   // n_paths + 1: the cuts of path p are h_cuts[h_cut_off[p] .. h_cut_off[p + 1])

@@ -113,7 +113,7 @@ int refine_path_cuts(pnx_ctx *ctx) {
             hi[c] = pe - cut > RUN_CHUNK ? cut + RUN_CHUNK : pe;
         }
     int rc;
-    DevBuf scratch;  // (the summaries stay where they are: the index kernel of every one-shot pass reads them)
+    DevBuf scratch;
     if ((rc = ensure(ctx, scratch, 3 * n * 8))) return rc;
     uint64_t *d = (uint64_t *)scratch.p;
     hipError_t e = hipMemcpyAsync(d, lo.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -144,7 +144,6 @@ int launch_chunk_summaries(pnx_ctx *ctx, uint32_t *d_bad) {
     PNX_HIP(ctx, hipGetLastError());
     ctx->h_chunk_sum.resize(n_chunks);
     PNX_HIP(ctx, hipMemcpyAsync(ctx->h_chunk_sum.data(), ctx->d_chunk_sum.p, n_chunks * sizeof(ChunkSummary), hipMemcpyDeviceToHost, ctx->stream));
-    ctx->chunk_sum_valid = true;
     return PNX_OK;
 }
 

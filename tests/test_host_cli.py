@@ -730,7 +730,7 @@ def test_cli_commands_on_several_threads_of_one_process(tmp_path):
     graphs = []
     for k, (n, p) in enumerate(((30000, 300), (20000, 270), (25000, 40), (12000, 330))):
         path = str(tmp_path / f"g{k}.gfa")
-        rc, out, err = hl.run_cli_inprocess(["synth", "--nodes", str(n), "--paths", str(p), "--seed", str(5 + k), "-o", path])
+        rc, out, err = hl.run_cli_inprocess(["synth", "--nodes", str(n), "--paths", str(p), "--seed", str(5 + k), "--links", "-o", path])
         assert rc == 0, err
         graphs.append(path)
     cmds = [["histgrowth", "-a", "-c", "node", "-l", "1,2,1", "-q", "0,0,0.5"], ["histgrowth", "-c", "bp", "-l", "1,1", "-q", "0.3,0.9"],
