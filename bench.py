@@ -531,26 +531,47 @@ def strong_pggb_block(args, torch, dist, use_dist, world, rank, local_rank, bloc
     pairs = [(1, 0.0), (2, 0.0), (1, 0.5)]
     thr = [(Threshold(ABSOLUTE, c), Threshold(RELATIVE, q)) for c, q in pairs]
     steps = max(4, args.strong_steps)
-    box = [None]
+    # (every step that can fail on ONE rank is followed by an agreement of all ranks: a rank that raised alone would leave the
+    # others inside the next collective for ever)
+    def all_agree(ok, what):
+        if use_dist:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        if not ok:
+            raise RuntimeError(f"strong scaling (pggb shape): {what} failed on a rank")
+
+    box = [None, None]
     if rank == 0:
-        box[0] = tempfile.mkdtemp(prefix="pnx_bench_pggb_")
-        gfa = os.path.join(box[0], "pggb.gfa")
-        rc, msg, err = hostlib.run_cli(["synth", "--shape", "pggb", "--nodes", str(args.ss2_nodes), "--samples", str(args.ss2_samples),
-                                        "--seed", str(args.seed), "-o", gfa])
-        if rc != 0:
-            raise RuntimeError(err)
+        try:
+            box[0] = tempfile.mkdtemp(prefix="pnx_bench_pggb_")
+            rc, msg, err = hostlib.run_cli(["synth", "--shape", "pggb", "--nodes", str(args.ss2_nodes), "--samples", str(args.ss2_samples),
+                                            "--seed", str(args.seed), "-o", os.path.join(box[0], "pggb.gfa")])
+            if rc != 0:
+                box[1] = err
+        except Exception as e:  # noqa: BLE001
+            box[1] = repr(e)
     if use_dist:
         dist.broadcast_object_list(box, src=0)
     tmp = box[0]
+    if box[1] is not None or tmp is None:
+        if rank == 0 and tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+        raise RuntimeError(f"strong scaling (pggb shape): the graph could not be written: {box[1]}")
     gfa = os.path.join(tmp, "pggb.gfa")
+    items = pre = pi = gi = names = None
+    n = G = 0
+    ok = True
     try:
         g = hostlib.GfaGraph(gfa)
         items, pre = g.item_table(hostlib.NODE)
         pi, gi, names = g.path_order(hostlib.GROUP_SAMPLE)
         n, G = g.n_nodes, len(names)
         g.close()
-        if use_dist:
-            dist.barrier()  # every rank has read the file
+    except Exception:  # noqa: BLE001
+        ok = False
+    try:
+        all_agree(ok, "reading the graph")  # (also: every rank has read the file)
     finally:
         if rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -565,12 +586,21 @@ def strong_pggb_block(args, torch, dist, use_dist, world, rank, local_rank, bloc
     mean = len(items) / world
 
     def run(lo, hi, dist_on, label):  # ids lo .. hi - 1
-        it, off, n_r = shard_csr(items, pre, lo, hi)
-        ctx = capi.Context(local_rank)
-        if blocking:
-            ctx.config(capi.CFG_BLOCKING_SYNC, 1)
-        ctx.set_csr(it, off, n_r)
-        ctx.set_order(pi, gi, G)
+        ctx = None
+        up_ok = True
+        try:
+            it, off, n_r = shard_csr(items, pre, lo, hi)
+            ctx = capi.Context(local_rank)
+            if blocking:
+                ctx.config(capi.CFG_BLOCKING_SYNC, 1)
+            ctx.set_csr(it, off, n_r)
+            ctx.set_order(pi, gi, G)
+        except Exception:  # noqa: BLE001
+            up_ok = False
+        if dist_on:
+            all_agree(up_ok, "the upload of a shard")
+        elif not up_ok:
+            raise RuntimeError("strong scaling (pggb shape): the upload of the whole graph failed")
         stepper = OneShot(ctx, G, thr, rank=rank, world=world if dist_on else 1, use_dist=dist_on, dist=dist, torch=torch,
                           local_rank=local_rank, collective=args.collective, blocking=blocking, growth_on_device=False,
                           growth_threads=args.growth_threads)
