@@ -70,7 +70,7 @@ def pytest_runtest_teardown(item, nextitem):
 # The CLI tests run their commands IN this process (hostlib.run_cli -> pnh_run_cli): the way a host binds the library, hundreds of
 # commands with a GPU context each in one pytest process.  At the end of round 5 three of eight whole sessions died of SIGABRT
 # inside such tests and the suite ran every command as the `panacus-amd` binary instead; round 6 hunted the abort (guard-page
-# device allocator, AddressSanitizer / UBSan / ThreadSanitizer builds of both libraries under soak harnesses, 13 whole in-process
+# device allocator, AddressSanitizer / UBSan / ThreadSanitizer builds of both libraries under soak harnesses, 15 whole in-process
 # sessions -- 5 of them on round 5's own tree -- without one abort: DESIGN.md section 2) and made in-process the default again.
 # PNX_TEST_CLI_OWN_PROCESS=1 runs every command as the binary in a process of its own (a command that dies then fails ONE test,
 # with its stderr in the report); a process that dies in native code leaves its C stack and the tail of the captured stderr in
