@@ -108,9 +108,27 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
     return LIB_HOST
 
 
+def build_soak(force: bool = False, verbose: bool = False):
+    """The two soak harnesses (tools/soak_pnx.cpp: the device ABI alone; tools/soak_cli.cpp: the in-process CLI), no Python in
+    them: contexts and commands in loops on several threads -- how a host binds the libraries in-process.  tests/test_gpu_soak.py
+    runs both briefly in every GPU session; tools/soak_gpu.sh runs them long, plain and under sanitizers."""
+    tools = os.path.join(ROOT, "tools")
+    for name, libs in (("soak_pnx", ["-lpanacus_hip"]), ("soak_cli", ["-lpanacus_host", "-lpanacus_hip"])):
+        src, exe = os.path.join(tools, name + ".cpp"), os.path.join(HERE, name)
+        if not os.path.exists(src):
+            continue
+        if force or _newer(exe, [src, LIB_HIP, LIB_HOST, os.path.join(ROOT, "include", "panacus_amd.h")]):
+            cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-L" + HERE] + libs + \
+                  ["-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + HERE, "-Wl,-rpath-link,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd))
+            _run(cmd)
+
+
 def build_all(force: bool = False, verbose: bool = False):
     build_hip(force, verbose)
     build_host(force, verbose)
+    build_soak(force, verbose)
 
 
 if __name__ == "__main__":
